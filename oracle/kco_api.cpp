@@ -1,0 +1,358 @@
+// oracle/kco_api.cpp — TEST INFRASTRUCTURE ONLY (CPU oracle; see kco_common.h).
+// C entry points (ctypes-friendly) over the restated reference encoders.
+// zstd: restates (*Encoder).encodeAll, zstd/encoder.go:731-839, MaxEncodedSize :843-873,
+// frameHeader.appendTo zstd/frameenc.go:25-92.
+#include "kco_common.h"
+#include "kco_xxhash.h"
+#include "kco_huff0.h"
+#include "kco_zstd_fse.h"
+#include "kco_zstd_block.h"
+#include "kco_zstd_fast.h"
+#include "kco_zstd_dfast.h"
+#include "kco_zstd_better.h"
+#include "kco_s2.h"
+#include <thread>
+#include <atomic>
+#include <memory>
+
+using namespace kco;
+
+extern "C" {
+
+// Resolved encoder options (after applying the reference's EOption functions in order;
+// the option-resolution logic itself lives in the product's host layer and is tested
+// against zstd/encoder_options.go).
+typedef struct {
+    int32_t level;            // 1 SpeedFastest, 2 SpeedDefault, 3 SpeedBetterCompression
+    int32_t window_size;      // o.windowSize
+    int32_t block_size;       // o.blockSize
+    int32_t crc;              // o.crc
+    int32_t single;           // -1: o.single == nil; else 0/1
+    int32_t full_zero;        // o.fullZero
+    int32_t no_entropy;       // o.noEntropy
+    int32_t all_lit_entropy;  // o.allLitEntropy
+    int32_t low_mem;          // o.lowMem
+    uint32_t dict_id;         // 0 = no dict (raw-content dictionary, WithEncoderDictRaw)
+    const uint8_t* dict;      // dict content
+    uint64_t dict_len;
+} kco_zstd_opts;
+
+}  // extern "C"
+
+namespace {
+
+// zstd/frameenc.go:25 appendTo
+void frameHeaderAppend(Bytes* dst, uint64_t ContentSize, uint32_t WindowSize, bool SingleSegment, bool Checksum, uint32_t DictID) {
+    dst->push_back(0x28); dst->push_back(0xb5); dst->push_back(0x2f); dst->push_back(0xfd);
+    uint8_t fhd = 0;
+    if (Checksum) fhd |= 1 << 2;
+    if (SingleSegment) fhd |= 1 << 5;
+    uint8_t dictIDContent[4];
+    int dictIDLen = 0;
+    if (DictID > 0) {
+        if (DictID < 256) { fhd |= 1; dictIDContent[0] = (uint8_t)DictID; dictIDLen = 1; }
+        else if (DictID < (1u << 16)) { fhd |= 2; dictIDContent[0] = (uint8_t)DictID; dictIDContent[1] = (uint8_t)(DictID >> 8); dictIDLen = 2; }
+        else { fhd |= 3; for (int i = 0; i < 4; i++) dictIDContent[i] = (uint8_t)(DictID >> (8 * i)); dictIDLen = 4; }
+    }
+    uint8_t fcs = 0;
+    if (ContentSize >= 256) fcs++;
+    if (ContentSize >= 65536 + 256) fcs++;
+    if (ContentSize >= 0xffffffffULL) fcs++;
+    fhd |= (uint8_t)(fcs << 6);
+    dst->push_back(fhd);
+    if (!SingleSegment) {
+        const int winLogMin = 10;
+        int windowLog = (bitsLen32(WindowSize - 1) - winLogMin) << 3;
+        dst->push_back((uint8_t)windowLog);
+    }
+    for (int i = 0; i < dictIDLen; i++) dst->push_back(dictIDContent[i]);
+    switch (fcs) {
+    case 0:
+        if (SingleSegment) dst->push_back((uint8_t)ContentSize);
+        break;
+    case 1:
+        ContentSize -= 256;
+        dst->push_back((uint8_t)ContentSize); dst->push_back((uint8_t)(ContentSize >> 8));
+        break;
+    case 2:
+        for (int i = 0; i < 4; i++) dst->push_back((uint8_t)(ContentSize >> (8 * i)));
+        break;
+    case 3:
+        for (int i = 0; i < 8; i++) dst->push_back((uint8_t)(ContentSize >> (8 * i)));
+        break;
+    }
+}
+
+struct OracleEncoder {
+    kco_zstd_opts o;
+    DictO dict;
+    bool hasDict = false;
+    std::unique_ptr<FastBase> enc;
+
+    explicit OracleEncoder(const kco_zstd_opts& opts) : o(opts) {
+        if (o.dict_id != 0 || (o.dict != nullptr && o.dict_len > 0)) {
+            hasDict = true;
+            dict.id = o.dict_id;
+            dict.content.assign(o.dict, o.dict + o.dict_len);
+            dict.offsets[0] = 1; dict.offsets[1] = 4; dict.offsets[2] = 8;  // WithEncoderDictRaw, encoder_options.go:398
+            dict.litEnc = nullptr;
+        }
+        // encoderOptions.encoder(), encoder_options.go:51
+        switch (o.level) {
+        case 1: if (hasDict) enc.reset(new FastEncoderDict()); else enc.reset(new FastEncoder()); break;
+        case 2: if (hasDict) enc.reset(new DoubleFastEncoderDict()); else enc.reset(new DoubleFastEncoder()); break;
+        case 3: if (hasDict) enc.reset(new BetterFastEncoderDict()); else enc.reset(new BetterFastEncoder()); break;
+        default: enc.reset(new FastEncoder());
+        }
+        enc->setup(o.window_size, o.low_mem != 0);
+    }
+
+    // zstd/encoder.go:731 encodeAll — appends to dst.
+    int encodeAll(const uint8_t* src, size_t n, Bytes* dst) {
+        const DictO* d = hasDict ? &dict : nullptr;
+        if (n == 0) {
+            if (o.full_zero) {
+                frameHeaderAppend(dst, 0, MinWindowSize, true, false, 0);
+                BlockHeader blk;
+                blk.setSize(0);
+                blk.setType(blockTypeRaw);
+                blk.setLast(true);
+                blk.appendTo(dst);
+            }
+            return 0;
+        }
+        bool single = (int64_t)n <= (int64_t)o.window_size && (int64_t)n > MinWindowSize;
+        if (o.single >= 0) single = o.single != 0;
+        frameHeaderAppend(dst, (uint64_t)n, (uint32_t)enc->WindowSize((int64_t)n), single, o.crc != 0, d ? d->id : 0);
+        if ((int64_t)n <= (int64_t)o.block_size) {
+            enc->Reset(d, true);
+            if (o.crc) enc->crc.Write(src, n);
+            BlockEnc* blk = &enc->blk;
+            blk->last = true;
+            if (d == nullptr) enc->EncodeNoHist(blk, src, n);
+            else enc->Encode(blk, src, n);
+            Bytes oldout;
+            oldout.swap(blk->output);
+            blk->output.swap(*dst);
+            int err = blk->encode(src, n, o.no_entropy != 0, !o.all_lit_entropy);
+            blk->output.swap(*dst);
+            blk->output.swap(oldout);
+            if (err != 0) return -1;
+        } else {
+            enc->Reset(d, false);
+            BlockEnc* blk = &enc->blk;
+            while (n > 0) {
+                size_t todo = n;
+                if (todo > (size_t)o.block_size) todo = (size_t)o.block_size;
+                const uint8_t* tp = src;
+                src += todo;
+                n -= todo;
+                if (o.crc) enc->crc.Write(tp, todo);
+                blk->pushOffsets();
+                enc->Encode(blk, tp, todo);
+                if (n == 0) blk->last = true;
+                int err = blk->encode(tp, todo, o.no_entropy != 0, !o.all_lit_entropy);
+                if (err != 0) return -1;
+                dst->insert(dst->end(), blk->output.begin(), blk->output.end());
+                blk->reset(nullptr);
+            }
+        }
+        if (o.crc) enc->AppendCRC(dst);
+        return 0;
+    }
+};
+
+// zstd/encoder.go:843 MaxEncodedSize (pad==0)
+int64_t maxEncodedSize(const kco_zstd_opts* o, int64_t size) {
+    int64_t frameHeader = 4 + 2;
+    if (o->dict_id != 0 || o->dict_len != 0) frameHeader += 4;
+    if (size < 256) frameHeader++;
+    else if (size < 65536 + 256) frameHeader += 2;
+    else if (size < 0x7fffffff) frameHeader += 4;
+    else frameHeader += 8;
+    if (o->crc) frameHeader += 4;
+    int64_t blocks = (size + o->block_size) / o->block_size;
+    return frameHeader + 3 * blocks + size;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* kco_zstd_encoder_new(const kco_zstd_opts* opts) { return new OracleEncoder(*opts); }
+void kco_zstd_encoder_free(void* e) { delete (OracleEncoder*)e; }
+
+// EncodeAll(src, nil) on a persistent encoder state (like one pooled Go encoder).
+// Returns bytes written or -1 (error) / -2 (dst too small).
+int64_t kco_zstd_encode_all(void* e, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
+    Bytes out;
+    out.reserve((size_t)n / 2 + 64);
+    if (((OracleEncoder*)e)->encodeAll(src, (size_t)n, &out) != 0) return -1;
+    if (out.size() > cap) return -2;
+    memcpy(dst, out.data(), out.size());
+    return (int64_t)out.size();
+}
+
+int64_t kco_zstd_max_encoded_size(const kco_zstd_opts* o, int64_t size) { return maxEncodedSize(o, size); }
+
+// Encode many independent units (each == EncodeAll(unit, nil)) with `threads` host threads,
+// one encoder state per thread (the reference's pool of `concurrent` encoders,
+// zstd/encoder.go:90-99).  out_off has n_units+1 entries; units are written at
+// dst + unit_index*stride and compacted afterwards when `compact` != 0.
+int64_t kco_zstd_encode_units(const kco_zstd_opts* opts, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units,
+                              uint8_t* dst, uint64_t dst_cap, uint64_t* out_off, int threads) {
+    if (threads < 1) threads = 1;
+    std::vector<Bytes> outs(n_units);
+    std::atomic<uint32_t> next(0);
+    std::atomic<int> fail(0);
+    auto worker = [&]() {
+        OracleEncoder enc(*opts);
+        for (;;) {
+            uint32_t i = next.fetch_add(1);
+            if (i >= n_units) break;
+            if (enc.encodeAll(src + unit_off[i], (size_t)(unit_off[i + 1] - unit_off[i]), &outs[i]) != 0) fail = 1;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    if (fail) return -1;
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < n_units; i++) {
+        out_off[i] = pos;
+        if (pos + outs[i].size() > dst_cap) return -2;
+        memcpy(dst + pos, outs[i].data(), outs[i].size());
+        pos += outs[i].size();
+    }
+    out_off[n_units] = pos;
+    return (int64_t)pos;
+}
+
+// Debug/inspection: run only the match finder for one unit and return the sequence list
+// and literal bytes of each block (used to diff GPU intermediates against the oracle).
+// seqs out: triples (litLen, matchLen, offset) per sequence; blk_nseq[b], blk_nlit[b] per block.
+int64_t kco_zstd_parse_unit(const kco_zstd_opts* opts, const uint8_t* src, uint64_t n, uint32_t* seqs, uint64_t seq_cap,
+                            uint8_t* lits, uint64_t lit_cap, uint32_t* blk_nseq, uint32_t* blk_nlit, uint32_t max_blocks) {
+    OracleEncoder E(*opts);
+    const DictO* d = E.hasDict ? &E.dict : nullptr;
+    uint64_t ns = 0, nl = 0;
+    uint32_t nb = 0;
+    auto dump = [&](BlockEnc* blk) -> bool {
+        if (nb >= max_blocks) return false;
+        if (ns + blk->sequences.size() > seq_cap || nl + blk->literals.size() > lit_cap) return false;
+        for (auto& s : blk->sequences) { seqs[3 * ns] = s.litLen; seqs[3 * ns + 1] = s.matchLen; seqs[3 * ns + 2] = s.offset; ns++; }
+        memcpy(lits + nl, blk->literals.data(), blk->literals.size());
+        nl += blk->literals.size();
+        blk_nseq[nb] = (uint32_t)blk->sequences.size();
+        blk_nlit[nb] = (uint32_t)blk->literals.size();
+        nb++;
+        return true;
+    };
+    if ((int64_t)n <= (int64_t)E.o.block_size) {
+        E.enc->Reset(d, true);
+        BlockEnc* blk = &E.enc->blk;
+        blk->last = true;
+        if (d == nullptr) E.enc->EncodeNoHist(blk, src, (size_t)n);
+        else E.enc->Encode(blk, src, (size_t)n);
+        if (!dump(blk)) return -2;
+    } else {
+        E.enc->Reset(d, false);
+        BlockEnc* blk = &E.enc->blk;
+        while (n > 0) {
+            size_t todo = (size_t)n;
+            if (todo > (size_t)E.o.block_size) todo = (size_t)E.o.block_size;
+            blk->pushOffsets();
+            E.enc->Encode(blk, src, todo);
+            if (!dump(blk)) return -2;
+            if (n == todo) blk->last = true;
+            if (blk->encode(src, todo, E.o.no_entropy != 0, !E.o.all_lit_entropy) != 0) return -1;
+            blk->reset(nullptr);
+            src += todo;
+            n -= todo;
+        }
+    }
+    return (int64_t)nb;
+}
+
+uint64_t kco_xxh64(const uint8_t* p, uint64_t n) {
+    XXH64 h;
+    h.Write(p, (size_t)n);
+    return h.Sum64();
+}
+// chunked variant to exercise Digest.Write buffering (xxhash_test.go testDigest)
+uint64_t kco_xxh64_chunked(const uint8_t* p, uint64_t n, uint64_t chunk) {
+    XXH64 h;
+    for (uint64_t i = 0; i < n; i += chunk) h.Write(p + i, (size_t)std::min(chunk, n - i));
+    return h.Sum64();
+}
+
+int32_t kco_zstd_matchlen(const uint8_t* a, uint64_t alen, const uint8_t* b) { return matchLen(a, (size_t)alen, b); }
+uint32_t kco_zstd_hashlen(uint64_t u, uint32_t length, uint32_t mls) { return hashLen(u, (uint8_t)length, (uint8_t)mls); }
+
+// huff0.Compress1X / Compress4X on a fresh Scratch (WantLogLess as given).
+// Returns: >=0 output size; -1 ErrIncompressible; -2 ErrUseRLE; -3 ErrTooBig; -4 internal.
+int64_t kco_huff0_compress(const uint8_t* in, uint64_t n, int four, int want_log_less, uint8_t* out, uint64_t cap) {
+    huff0::Scratch s;
+    s.WantLogLess = (uint8_t)want_log_less;
+    bool reUsed = false;
+    huff0::Err e = huff0::compress(in, (size_t)n, &s, four != 0, &reUsed);
+    if (e != huff0::OK) return -(int64_t)e;
+    if (s.Out.size() > cap) return -5;
+    memcpy(out, s.Out.data(), s.Out.size());
+    return (int64_t)s.Out.size();
+}
+
+// fse.Compress (byte FSE) on a fresh Scratch. Returns >=0 size, -1 incompressible, -2 RLE, -3 internal.
+int64_t kco_fse_compress(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap) {
+    std::unique_ptr<fseb::Scratch> s(new fseb::Scratch());
+    fseb::Err e = fseb::Compress(in, (size_t)n, s.get());
+    if (e != fseb::OK) return -(int64_t)e;
+    if (s->Out.size() > cap) return -5;
+    memcpy(out, s->Out.data(), s->Out.size());
+    return (int64_t)s->Out.size();
+}
+
+// ---- S2 ----
+int64_t kco_s2_max_encoded_len(int64_t n) { return s2::MaxEncodedLen(n); }
+int64_t kco_s2_encode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::Encode(dst, cap, src, (size_t)n); }
+// encodeBlock only (no varint header); 0 == incompressible.  The WriterCustomEncoder contract.
+int64_t kco_s2_encode_block(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
+    if (cap < (uint64_t)s2::MaxEncodedLen((int64_t)n)) return -2;
+    return s2::encodeBlock(dst, src, (size_t)n);
+}
+int64_t kco_s2_emit_literal(uint8_t* dst, const uint8_t* lit, uint64_t n) { return s2::emitLiteral(dst, lit, (size_t)n); }
+int64_t kco_s2_emit_copy(uint8_t* dst, int64_t offset, int64_t length) { return s2::emitCopy(dst, (int)offset, (int)length); }
+int64_t kco_s2_emit_repeat(uint8_t* dst, int64_t offset, int64_t length) { return s2::emitRepeat(dst, (int)offset, (int)length); }
+int64_t kco_s2_decode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::Decode(dst, cap, src, (size_t)n); }
+uint32_t kco_s2_crc(const uint8_t* p, uint64_t n) { return s2::crc(p, (size_t)n); }
+
+int64_t kco_s2_encode_blocks(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
+                             uint64_t* out_off, int threads) {
+    if (threads < 1) threads = 1;
+    std::vector<Bytes> outs(n_blocks);
+    std::atomic<uint32_t> next(0);
+    auto worker = [&]() {
+        for (;;) {
+            uint32_t i = next.fetch_add(1);
+            if (i >= n_blocks) break;
+            size_t n = (size_t)(blk_off[i + 1] - blk_off[i]);
+            outs[i].resize((size_t)s2::MaxEncodedLen((int64_t)n));
+            int64_t r = s2::Encode(outs[i].data(), outs[i].size(), src + blk_off[i], n);
+            outs[i].resize((size_t)r);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < n_blocks; i++) {
+        out_off[i] = pos;
+        if (pos + outs[i].size() > dst_cap) return -2;
+        memcpy(dst + pos, outs[i].data(), outs[i].size());
+        pos += outs[i].size();
+    }
+    out_off[n_blocks] = pos;
+    return (int64_t)pos;
+}
+
+}  // extern "C"

@@ -1,0 +1,346 @@
+// oracle/kco_s2.h — TEST INFRASTRUCTURE ONLY (CPU oracle; see kco_common.h).
+// Restates the portable-Go ("noasm") S2 block encoder: s2/encode.go:29-56,389-418,
+// s2/encode_all.go:17-30,72-500 (encodeBlockGo / encodeBlockGo64K), s2/encode_go.go:19-27,
+// 80-234 (emitLiteral/emitRepeat/emitCopy), s2/s2.go:120-147 (crc, literalExtraSize),
+// plus a bounds-checked block decoder following s2/decode_other.go:22-260 used only to
+// verify that oracle/GPU output round-trips.
+// PARITY TARGET: encodeBlockGo64K / encodeBlockGo (build tag noasm) — NOT the amd64 asm
+// variant.
+#pragma once
+#include "kco_common.h"
+
+namespace kco {
+namespace s2 {
+
+constexpr int tagLiteral = 0x00, tagCopy1 = 0x01, tagCopy2 = 0x02, tagCopy4 = 0x03;
+constexpr int inputMargin = 8, minNonLiteralBlockSize = 32;
+
+// s2/s2.go:129 literalExtraSize
+static inline int64_t literalExtraSize(int64_t n) {
+    if (n == 0) return 0;
+    if (n < 60) return 1;
+    if (n < (1 << 8)) return 2;
+    if (n < (1 << 16)) return 3;
+    if (n < (1 << 24)) return 4;
+    return 5;
+}
+// s2/encode.go:389 MaxEncodedLen (64-bit int)
+static inline int64_t MaxEncodedLen(int64_t srcLen) {
+    uint64_t n = (uint64_t)srcLen;
+    if (n > 0xffffffffULL) return -1;
+    n = n + (uint64_t)((bitsLen64(n) + 7) / 7);
+    n += (uint64_t)literalExtraSize(srcLen);
+    if (n > 0xffffffffULL) return -1;
+    return (int64_t)n;
+}
+static inline int putUvarint(uint8_t* buf, uint64_t x) {
+    int i = 0;
+    while (x >= 0x80) { buf[i++] = (uint8_t)x | 0x80; x >>= 7; }
+    buf[i] = (uint8_t)x;
+    return i + 1;
+}
+
+// s2/encode_go.go:80 emitLiteral
+static inline int emitLiteral(uint8_t* dst, const uint8_t* lit, size_t len) {
+    if (len == 0) return 0;
+    int i = 0;
+    uint64_t n = (uint64_t)(len - 1);
+    if (n < 60) { dst[0] = (uint8_t)((uint8_t)n << 2 | tagLiteral); i = 1; }
+    else if (n < (1 << 8)) { dst[1] = (uint8_t)n; dst[0] = 60 << 2 | tagLiteral; i = 2; }
+    else if (n < (1 << 16)) { dst[2] = (uint8_t)(n >> 8); dst[1] = (uint8_t)n; dst[0] = 61 << 2 | tagLiteral; i = 3; }
+    else if (n < (1 << 24)) { dst[3] = (uint8_t)(n >> 16); dst[2] = (uint8_t)(n >> 8); dst[1] = (uint8_t)n; dst[0] = 62 << 2 | tagLiteral; i = 4; }
+    else { dst[4] = (uint8_t)(n >> 24); dst[3] = (uint8_t)(n >> 16); dst[2] = (uint8_t)(n >> 8); dst[1] = (uint8_t)n; dst[0] = 63 << 2 | tagLiteral; i = 5; }
+    memcpy(dst + i, lit, len);
+    return i + (int)len;
+}
+
+// s2/encode_go.go:118 emitRepeat
+static inline int emitRepeat(uint8_t* dst, int offset, int length) {
+    length -= 4;
+    if (length <= 4) { dst[0] = (uint8_t)((uint8_t)length << 2 | tagCopy1); dst[1] = 0; return 2; }
+    if (length < 8 && offset < 2048) {
+        dst[1] = (uint8_t)offset;
+        dst[0] = (uint8_t)((uint8_t)(offset >> 8) << 5 | (uint8_t)length << 2 | tagCopy1);
+        return 2;
+    }
+    if (length < (1 << 8) + 4) {
+        length -= 4;
+        dst[2] = (uint8_t)length; dst[1] = 0; dst[0] = 5 << 2 | tagCopy1;
+        return 3;
+    }
+    if (length < (1 << 16) + (1 << 8)) {
+        length -= 1 << 8;
+        dst[3] = (uint8_t)(length >> 8); dst[2] = (uint8_t)length; dst[1] = 0; dst[0] = 6 << 2 | tagCopy1;
+        return 4;
+    }
+    const int maxRepeat = (1 << 24) - 1;
+    length -= 1 << 16;
+    int left = 0;
+    if (length > maxRepeat) { left = length - maxRepeat + 4; length = maxRepeat - 4; }
+    dst[4] = (uint8_t)(length >> 16); dst[3] = (uint8_t)(length >> 8); dst[2] = (uint8_t)length; dst[1] = 0; dst[0] = 7 << 2 | tagCopy1;
+    if (left > 0) return 5 + emitRepeat(dst + 5, offset, left);
+    return 5;
+}
+
+// s2/encode_go.go:172 emitCopy
+static inline int emitCopy(uint8_t* dst, int offset, int length) {
+    if (offset >= 65536) {
+        int i = 0;
+        if (length > 64) {
+            dst[4] = (uint8_t)(offset >> 24); dst[3] = (uint8_t)(offset >> 16); dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset;
+            dst[0] = 63 << 2 | tagCopy4;
+            length -= 64;
+            if (length >= 4) return 5 + emitRepeat(dst + 5, offset, length);
+            i = 5;
+        }
+        if (length == 0) return i;
+        dst[i + 0] = (uint8_t)((uint8_t)(length - 1) << 2 | tagCopy4);
+        dst[i + 1] = (uint8_t)offset; dst[i + 2] = (uint8_t)(offset >> 8); dst[i + 3] = (uint8_t)(offset >> 16); dst[i + 4] = (uint8_t)(offset >> 24);
+        return i + 5;
+    }
+    if (length > 64) {
+        int off = 3;
+        if (offset < 2048) {
+            dst[1] = (uint8_t)offset;
+            dst[0] = (uint8_t)((uint8_t)(offset >> 8) << 5 | (uint8_t)(8 - 4) << 2 | tagCopy1);
+            length -= 8;
+            off = 2;
+        } else {
+            dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset; dst[0] = 59 << 2 | tagCopy2;
+            length -= 60;
+        }
+        return off + emitRepeat(dst + off, offset, length);
+    }
+    if (length >= 12 || offset >= 2048) {
+        dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset; dst[0] = (uint8_t)((uint8_t)(length - 1) << 2 | tagCopy2);
+        return 3;
+    }
+    dst[1] = (uint8_t)offset;
+    dst[0] = (uint8_t)((uint8_t)(offset >> 8) << 5 | (uint8_t)(length - 4) << 2 | tagCopy1);
+    return 2;
+}
+
+// s2/encode_all.go:27 hash6
+static inline uint32_t hash6(uint64_t u, uint8_t h) {
+    const uint64_t prime6bytes = 227718039650203ULL;
+    return (uint32_t)(((u << (64 - 48)) * prime6bytes) >> ((64 - h) & 63));
+}
+
+// s2/encode_all.go:72 encodeBlockGo (T=uint32_t, SKIP=6) / :287 encodeBlockGo64K (T=uint16_t, SKIP=5)
+template <typename T, int SKIP>
+static int encodeBlockGoT(uint8_t* dst, const uint8_t* src, size_t srcLen) {
+    const uint8_t tableBits = 14;
+    const int maxTableSize = 1 << tableBits;
+    std::vector<T> table((size_t)maxTableSize, (T)0);
+    const int len = (int)srcLen;
+    int sLimit = len - inputMargin;
+    int dstLimit = len - (len >> 5) - 5;
+    int nextEmit = 0;
+    int s = 1;
+    uint64_t cv = load64(src, s);
+    int repeat = 1;
+    int d = 0;
+    for (;;) {
+        int candidate = 0;
+        for (;;) {
+            int nextS = s + ((s - nextEmit) >> SKIP) + 4;
+            if (nextS > sLimit) goto emitRemainder;
+            {
+                uint32_t hash0 = hash6(cv, tableBits);
+                uint32_t hash1 = hash6(cv >> 8, tableBits);
+                candidate = (int)table[hash0];
+                int candidate2 = (int)table[hash1];
+                table[hash0] = (T)s;
+                table[hash1] = (T)(s + 1);
+                uint32_t hash2 = hash6(cv >> 16, tableBits);
+                const int checkRep = 1;
+                if ((uint32_t)(cv >> (checkRep * 8)) == load32(src, s - repeat + checkRep)) {
+                    int base = s + checkRep;
+                    for (int i = base - repeat; base > nextEmit && i > 0 && src[i - 1] == src[base - 1];) { i--; base--; }
+                    if (d + (base - nextEmit) > dstLimit) return 0;
+                    d += emitLiteral(dst + d, src + nextEmit, (size_t)(base - nextEmit));
+                    int cand = s - repeat + 4 + checkRep;
+                    s += 4 + checkRep;
+                    while (s <= sLimit) {
+                        uint64_t diff = load64(src, s) ^ load64(src, cand);
+                        if (diff != 0) { s += tz64(diff) >> 3; break; }
+                        s += 8;
+                        cand += 8;
+                    }
+                    if (nextEmit > 0) d += emitRepeat(dst + d, repeat, s - base);
+                    else d += emitCopy(dst + d, repeat, s - base);
+                    nextEmit = s;
+                    if (s >= sLimit) goto emitRemainder;
+                    cv = load64(src, s);
+                    continue;
+                }
+                if ((uint32_t)cv == load32(src, candidate)) break;
+                candidate = (int)table[hash2];
+                if ((uint32_t)(cv >> 8) == load32(src, candidate2)) {
+                    table[hash2] = (T)(s + 2);
+                    candidate = candidate2;
+                    s++;
+                    break;
+                }
+                table[hash2] = (T)(s + 2);
+                if ((uint32_t)(cv >> 16) == load32(src, candidate)) { s += 2; break; }
+                cv = load64(src, nextS);
+                s = nextS;
+            }
+        }
+        while (candidate > 0 && s > nextEmit && src[candidate - 1] == src[s - 1]) { candidate--; s--; }
+        if (d + (s - nextEmit) > dstLimit) return 0;
+        d += emitLiteral(dst + d, src + nextEmit, (size_t)(s - nextEmit));
+        for (;;) {
+            int base = s;
+            repeat = base - candidate;
+            s += 4;
+            candidate += 4;
+            while (s <= len - 8) {
+                uint64_t diff = load64(src, s) ^ load64(src, candidate);
+                if (diff != 0) { s += tz64(diff) >> 3; break; }
+                s += 8;
+                candidate += 8;
+            }
+            d += emitCopy(dst + d, repeat, s - base);
+            nextEmit = s;
+            if (s >= sLimit) goto emitRemainder;
+            if (d > dstLimit) return 0;
+            uint64_t x = load64(src, s - 2);
+            uint32_t m2Hash = hash6(x, tableBits);
+            uint32_t currHash = hash6(x >> 16, tableBits);
+            candidate = (int)table[currHash];
+            table[m2Hash] = (T)(s - 2);
+            table[currHash] = (T)s;
+            if ((uint32_t)(x >> 16) != load32(src, candidate)) {
+                cv = load64(src, s + 1);
+                s++;
+                break;
+            }
+        }
+    }
+emitRemainder:
+    if (nextEmit < len) {
+        if (d + len - nextEmit > dstLimit) return 0;
+        d += emitLiteral(dst + d, src + nextEmit, (size_t)(len - nextEmit));
+    }
+    return d;
+}
+
+// s2/encode_go.go:19 encodeBlock
+static inline int encodeBlock(uint8_t* dst, const uint8_t* src, size_t n) {
+    if (n < (size_t)minNonLiteralBlockSize) return 0;
+    if (n <= (64 << 10)) return encodeBlockGoT<uint16_t, 5>(dst, src, n);
+    return encodeBlockGoT<uint32_t, 6>(dst, src, n);
+}
+
+// s2/encode.go:29 Encode; returns bytes written or -1 (too large) / -2 (dst too small)
+static inline int64_t Encode(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n) {
+    int64_t m = MaxEncodedLen((int64_t)n);
+    if (m < 0) return -1;
+    if (cap < (uint64_t)m) return -2;
+    int d = putUvarint(dst, (uint64_t)n);
+    if (n == 0) return d;
+    if (n < (size_t)minNonLiteralBlockSize) { d += emitLiteral(dst + d, src, n); return d; }
+    int k = encodeBlock(dst + d, src, n);
+    if (k > 0) return d + k;
+    d += emitLiteral(dst + d, src, n);
+    return d;
+}
+
+// CRC32C (Castagnoli) + s2/s2.go:120 crc masking: ((c>>15)|(c<<17)) + 0xa282ead8
+static inline uint32_t crc32c(const uint8_t* p, size_t n) {
+    static uint32_t tab[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            tab[i] = c;
+        }
+        init = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) c = tab[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+static inline uint32_t crc(const uint8_t* p, size_t n) {
+    uint32_t c = crc32c(p, n);
+    return ((c >> 15) | (c << 17)) + 0xa282ead8u;
+}
+
+// Block decoder (format per s2/decode_other.go:22-260); verifier only.
+// Returns decoded length or -1 on corruption / -2 if dst too small.
+static inline int64_t Decode(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n) {
+    size_t s = 0;
+    uint64_t dLen = 0;
+    int shift = 0;
+    for (;;) {
+        if (s >= n || shift > 63) return -1;
+        uint8_t b = src[s++];
+        dLen |= (uint64_t)(b & 0x7f) << shift;
+        if (!(b & 0x80)) break;
+        shift += 7;
+    }
+    if (dLen > cap) return -2;
+    uint64_t d = 0;
+    uint64_t offset = 0;
+    while (s < n) {
+        uint64_t length;
+        uint8_t tag = src[s];
+        switch (tag & 3) {
+        case tagLiteral: {
+            uint32_t x = tag >> 2;
+            if (x < 60) { s += 1; }
+            else if (x == 60) { if (s + 2 > n) return -1; x = src[s + 1]; s += 2; }
+            else if (x == 61) { if (s + 3 > n) return -1; x = load16(src, (int64_t)s + 1); s += 3; }
+            else if (x == 62) { if (s + 4 > n) return -1; x = (uint32_t)src[s + 1] | (uint32_t)src[s + 2] << 8 | (uint32_t)src[s + 3] << 16; s += 4; }
+            else { if (s + 5 > n) return -1; x = load32(src, (int64_t)s + 1); s += 5; }
+            length = (uint64_t)x + 1;
+            if (length > dLen - d || length > n - s) return -1;
+            memcpy(dst + d, src + s, length);
+            d += length;
+            s += length;
+            continue;
+        }
+        case tagCopy1: {
+            if (s + 2 > n) return -1;
+            uint64_t toffset = ((uint64_t)(tag & 0xe0) << 3) | src[s + 1];
+            length = (tag >> 2) & 7;
+            s += 2;
+            if (toffset == 0) {
+                switch (length) {
+                case 5: if (s + 1 > n) return -1; length = (uint64_t)src[s] + 4; s += 1; break;
+                case 6: if (s + 2 > n) return -1; length = (uint64_t)load16(src, (int64_t)s) + (1 << 8); s += 2; break;
+                case 7: if (s + 3 > n) return -1; length = ((uint64_t)src[s] | (uint64_t)src[s + 1] << 8 | (uint64_t)src[s + 2] << 16) + (1 << 16); s += 3; break;
+                default: break;
+                }
+            } else {
+                offset = toffset;
+            }
+            length += 4;
+            break;
+        }
+        case tagCopy2:
+            if (s + 3 > n) return -1;
+            offset = load16(src, (int64_t)s + 1);
+            length = 1 + (uint64_t)(tag >> 2);
+            s += 3;
+            break;
+        default:
+            if (s + 5 > n) return -1;
+            offset = load32(src, (int64_t)s + 1);
+            length = 1 + (uint64_t)(tag >> 2);
+            s += 5;
+            break;
+        }
+        if (offset == 0 || d < offset || length > dLen - d) return -1;
+        for (uint64_t i = 0; i < length; i++) dst[d + i] = dst[d + i - offset];
+        d += length;
+    }
+    if (d != dLen) return -1;
+    return (int64_t)d;
+}
+
+}  // namespace s2
+}  // namespace kco

@@ -1,0 +1,451 @@
+// oracle/kco_zstd_block.h — TEST INFRASTRUCTURE ONLY (CPU oracle; see kco_common.h).
+// Restates zstd/blockenc.go (blockEnc: headers, encodeLits, encodeRLE, encode, genCodes),
+// zstd/seqenc.go:21-42 (seqCoders.setPrev) and zstd/seqdec.go:13-21 (seq).
+#pragma once
+#include "kco_common.h"
+#include "kco_huff0.h"
+#include "kco_zstd_fse.h"
+
+namespace kco {
+
+constexpr int zstdMinMatch = 3;                    // zstd/zstd.go:37
+constexpr int maxCompressedBlockSize = 128 << 10;  // zstd/blockdec.go:40
+constexpr int MinWindowSize = 1 << 10;             // zstd/decoder_options.go
+
+struct Seq {  // zstd/seqdec.go:13
+    uint32_t litLen, matchLen, offset;
+    uint8_t llCode, mlCode, ofCode;
+};
+
+enum BlockType { blockTypeRaw = 0, blockTypeRLE = 1, blockTypeCompressed = 2 };
+enum LiteralsBlockType { literalsBlockRaw = 0, literalsBlockRLE = 1, literalsBlockCompressed = 2, literalsBlockTreeless = 3 };
+enum SeqCompMode { compModePredefined = 0, compModeRLE = 1, compModeFSE = 2, compModeRepeat = 3 };
+
+// zstd/blockenc.go:109-136 blockHeader
+struct BlockHeader {
+    uint32_t h = 0;
+    void setLast(bool b) { if (b) h |= 1; else h &= ((1u << 24) - 2); }
+    void setSize(uint32_t v) { h = (h & 7) | (v << 3); }
+    void setType(uint32_t t) { const uint32_t mask = 1 | (((1u << 24) - 1) ^ 7); h = (h & mask) | (t << 1); }
+    void appendTo(Bytes* b) const { b->push_back((uint8_t)h); b->push_back((uint8_t)(h >> 8)); b->push_back((uint8_t)(h >> 16)); }
+    void writeAt(uint8_t* p) const { p[0] = (uint8_t)h; p[1] = (uint8_t)(h >> 8); p[2] = (uint8_t)(h >> 16); }
+};
+
+// zstd/blockenc.go:139-242 literalsHeader
+struct LiteralsHeader {
+    uint64_t h = 0;
+    void setType(uint64_t t) { h = (h & ~(uint64_t)3) | t; }
+    void setSize(int regenLen) {  // :150
+        int inBits = bitsLen32((uint32_t)regenLen);
+        uint64_t lh = h & 3;
+        if (inBits < 5) lh |= ((uint64_t)regenLen << 3) | ((uint64_t)1 << 60);
+        else if (inBits < 12) lh |= (1 << 2) | ((uint64_t)regenLen << 4) | ((uint64_t)2 << 60);
+        else lh |= (3 << 2) | ((uint64_t)regenLen << 4) | ((uint64_t)3 << 60);  // inBits < 20 (else panic)
+        h = lh;
+    }
+    void setSizes(int compLen, int inLen, bool single) {  // :178
+        int compBits = bitsLen32((uint32_t)compLen), inBits = bitsLen32((uint32_t)inLen);
+        uint64_t lh = h & 3;
+        if (compBits <= 10 && inBits <= 10) {
+            if (!single) lh |= 1 << 2;
+            lh |= ((uint64_t)inLen << 4) | ((uint64_t)compLen << (10 + 4)) | ((uint64_t)3 << 60);
+        } else if (compBits <= 14 && inBits <= 14) {
+            lh |= (2 << 2) | ((uint64_t)inLen << 4) | ((uint64_t)compLen << (14 + 4)) | ((uint64_t)4 << 60);
+        } else {
+            lh |= (3 << 2) | ((uint64_t)inLen << 4) | ((uint64_t)compLen << (18 + 4)) | ((uint64_t)5 << 60);
+        }
+        h = lh;
+    }
+    int size() const { return (int)(h >> 60); }
+    void appendTo(Bytes* b) const {
+        int sz = size();
+        for (int i = 0; i < sz; i++) b->push_back((uint8_t)(h >> (8 * i)));
+    }
+};
+
+struct SeqCoders {  // zstd/seqenc.go:9
+    zfse::FseEncoder *llEnc, *ofEnc, *mlEnc, *llPrev, *ofPrev, *mlPrev;
+    static void compareSwap(zfse::FseEncoder* used, zfse::FseEncoder** current, zfse::FseEncoder** prev) {
+        if (*current == used) {
+            std::swap(*prev, *current);
+            (*current)->reUsed = false;
+            (*prev)->reUsed = true;
+            return;
+        }
+        if (used == *prev) return;
+        (*prev)->symbolLen = 0;
+    }
+    // seqenc.go:21 setPrev
+    void setPrev(zfse::FseEncoder* ll, zfse::FseEncoder* ml, zfse::FseEncoder* of) {
+        compareSwap(ll, &llEnc, &llPrev);
+        compareSwap(ml, &mlEnc, &mlPrev);
+        compareSwap(of, &ofEnc, &ofPrev);
+    }
+};
+
+struct BlockEnc {  // zstd/blockenc.go:17
+    int size = 0;
+    Bytes literals;
+    std::vector<Seq> sequences;
+    zfse::FseEncoder fseStore[6];
+    SeqCoders coders;
+    huff0::Scratch litEncStore;
+    huff0::Scratch* litEnc;
+    const huff0::Scratch* dictLitEnc = nullptr;
+    BitWriter wr;
+    int extraLits = 0;
+    Bytes output;
+    uint32_t recentOffsets[3] = {0, 0, 0};
+    uint32_t prevRecentOffsets[3] = {0, 0, 0};
+    bool last = false;
+
+    BlockEnc() { init(); }
+    // blockenc.go:37 init
+    void init() {
+        coders.mlEnc = &fseStore[0]; coders.mlPrev = &fseStore[1];
+        coders.ofEnc = &fseStore[2]; coders.ofPrev = &fseStore[3];
+        coders.llEnc = &fseStore[4]; coders.llPrev = &fseStore[5];
+        litEnc = &litEncStore;
+        litEnc->WantLogLess = 4;
+        reset(nullptr);
+    }
+    // blockenc.go:77 initNewEncode
+    void initNewEncode() {
+        recentOffsets[0] = 1; recentOffsets[1] = 4; recentOffsets[2] = 8;
+        litEnc->Reuse = huff0::ReusePolicyNone;
+        coders.setPrev(nullptr, nullptr, nullptr);
+        dictLitEnc = nullptr;
+    }
+    // blockenc.go:87 reset
+    void reset(BlockEnc* prev) {
+        extraLits = 0;
+        literals.clear();
+        size = 0;
+        sequences.clear();
+        output.clear();
+        last = false;
+        if (prev) memcpy(recentOffsets, prev->prevRecentOffsets, sizeof(recentOffsets));
+        dictLitEnc = nullptr;
+    }
+    void pushOffsets() { memcpy(prevRecentOffsets, recentOffsets, sizeof(recentOffsets)); }  // :245
+    void popOffsets() { memcpy(recentOffsets, prevRecentOffsets, sizeof(recentOffsets)); }   // :250
+
+    // blockenc.go:324 encodeRawTo (dst == output truncated to bhOffset)
+    void encodeRawTo(size_t bhOffset, const uint8_t* src, size_t n) {
+        output.resize(bhOffset);
+        BlockHeader bh;
+        bh.setLast(last);
+        bh.setSize((uint32_t)n);
+        bh.setType(blockTypeRaw);
+        bh.appendTo(&output);
+        output.insert(output.end(), src, src + n);
+    }
+
+    // blockenc.go:337 encodeLits; returns false on internal error
+    bool encodeLits(const uint8_t* lits, size_t n, bool raw) {
+        BlockHeader bh;
+        bh.setLast(last);
+        bh.setSize((uint32_t)n);
+        if (n < 8 || (n < 32 && dictLitEnc == nullptr) || raw) {
+            bh.setType(blockTypeRaw);
+            bh.appendTo(&output);
+            output.insert(output.end(), lits, lits + n);
+            return true;
+        }
+        bool reUsed = false, single = false;
+        huff0::Err err;
+        if (dictLitEnc != nullptr) {
+            litEnc->TransferCTable(dictLitEnc);
+            litEnc->Reuse = huff0::ReusePolicyAllow;
+            dictLitEnc = nullptr;
+        }
+        if (n >= 1024) {
+            err = huff0::compress(lits, n, litEnc, true, &reUsed);
+        } else if (n > 16) {
+            single = true;
+            err = huff0::compress(lits, n, litEnc, false, &reUsed);
+        } else {
+            err = huff0::ErrIncompressible;
+        }
+        const Bytes& out = litEnc->Out;
+        if (err == huff0::OK && out.size() + 5 > n) {
+            LiteralsHeader lh;
+            lh.setSizes((int)out.size(), (int)n, single);
+            if (out.size() + (size_t)lh.size() >= n) err = huff0::ErrIncompressible;
+        }
+        switch (err) {
+        case huff0::ErrIncompressible:
+            bh.setType(blockTypeRaw);
+            bh.appendTo(&output);
+            output.insert(output.end(), lits, lits + n);
+            return true;
+        case huff0::ErrUseRLE:
+            bh.setType(blockTypeRLE);
+            bh.appendTo(&output);
+            output.push_back(lits[0]);
+            return true;
+        case huff0::OK: break;
+        default: return false;
+        }
+        litEnc->Reuse = huff0::ReusePolicyAllow;
+        bh.setType(blockTypeCompressed);
+        LiteralsHeader lh;
+        if (reUsed) lh.setType(literalsBlockTreeless);
+        else lh.setType(literalsBlockCompressed);
+        lh.setSizes((int)out.size(), (int)n, single);
+        bh.setSize((uint32_t)(out.size() + (size_t)lh.size() + 1));
+        bh.appendTo(&output);
+        lh.appendTo(&output);
+        output.insert(output.end(), out.begin(), out.end());
+        output.push_back(0);
+        return true;
+    }
+
+    // blockenc.go:433 encodeRLE
+    void encodeRLE(uint8_t val, uint32_t length) {
+        BlockHeader bh;
+        bh.setLast(last);
+        bh.setSize(length);
+        bh.setType(blockTypeRLE);
+        bh.appendTo(&output);
+        output.push_back(val);
+    }
+
+    // blockenc.go:831 genCodes
+    void genCodes() {
+        if (sequences.empty()) return;
+        uint32_t* llH = coders.llEnc->count;
+        uint32_t* ofH = coders.ofEnc->count;
+        uint32_t* mlH = coders.mlEnc->count;
+        memset(llH, 0, 256 * 4);
+        memset(ofH, 0, 256 * 4);
+        memset(mlH, 0, 256 * 4);
+        uint8_t llMax = 0, ofMax = 0, mlMax = 0;
+        for (size_t i = 0; i < sequences.size(); i++) {
+            Seq* s = &sequences[i];
+            uint8_t v = zfse::llCode(s->litLen);
+            s->llCode = v; llH[v]++; if (v > llMax) llMax = v;
+            v = zfse::ofCode(s->offset);
+            s->ofCode = v; ofH[v]++; if (v > ofMax) ofMax = v;
+            v = zfse::mlCode(s->matchLen);
+            s->mlCode = v; mlH[v]++; if (v > mlMax) mlMax = v;
+        }
+        auto maxOf = [](const uint32_t* h, int n) { uint32_t m = 0; for (int i = 0; i < n; i++) if (h[i] > m) m = h[i]; return (int)m; };
+        coders.mlEnc->HistogramFinished(mlMax, maxOf(mlH, mlMax + 1));
+        coders.ofEnc->HistogramFinished(ofMax, maxOf(ofH, ofMax + 1));
+        coders.llEnc->HistogramFinished(llMax, maxOf(llH, llMax + 1));
+    }
+
+    // blockenc.go:481 encode.  org may be null only when orgLen==0 and caller passes nil.
+    // Returns 0 ok, 1 errIncompressible (org == nil path), -1 internal error.
+    int encode(const uint8_t* org, size_t orgLen, bool raw, bool rawAllLits) {
+        using namespace zfse;
+        if (sequences.empty()) return encodeLits(literals.data(), literals.size(), rawAllLits) ? 0 : -1;
+        if (sequences.size() == 1 && orgLen > 0 && literals.size() <= 1) {
+            Seq seq = sequences[0];
+            if (seq.litLen == (uint32_t)literals.size() && seq.offset - 3 == 1) {
+                encodeRLE(org[0], sequences[0].matchLen + zstdMinMatch + seq.litLen);
+                return 0;
+            }
+        }
+        int saved = size - (int)literals.size() - (size >> 6);
+        if (saved < 16) {
+            if (org == nullptr) return 1;
+            popOffsets();
+            return encodeLits(org, orgLen, rawAllLits) ? 0 : -1;
+        }
+        BlockHeader bh;
+        LiteralsHeader lh;
+        bh.setLast(last);
+        bh.setType(blockTypeCompressed);
+        size_t bhOffset = output.size();
+        bh.appendTo(&output);
+
+        bool reUsed = false, single = false;
+        huff0::Err err;
+        if (dictLitEnc != nullptr) {
+            litEnc->TransferCTable(dictLitEnc);
+            litEnc->Reuse = huff0::ReusePolicyAllow;
+            dictLitEnc = nullptr;
+        }
+        if (literals.size() >= 1024 && !raw) {
+            err = huff0::compress(literals.data(), literals.size(), litEnc, true, &reUsed);
+        } else if (literals.size() > 16 && !raw) {
+            single = true;
+            err = huff0::compress(literals.data(), literals.size(), litEnc, false, &reUsed);
+        } else {
+            err = huff0::ErrIncompressible;
+        }
+        const Bytes& out = litEnc->Out;
+        if (err == huff0::OK && out.size() + 5 > literals.size()) {
+            LiteralsHeader lh2;
+            lh2.setSize((int)literals.size());
+            int szRaw = lh2.size();
+            lh2.setSizes((int)out.size(), (int)literals.size(), single);
+            int szComp = lh2.size();
+            if (out.size() + (size_t)szComp >= literals.size() + (size_t)szRaw) err = huff0::ErrIncompressible;
+        }
+        switch (err) {
+        case huff0::ErrIncompressible:
+            lh.setType(literalsBlockRaw);
+            lh.setSize((int)literals.size());
+            lh.appendTo(&output);
+            output.insert(output.end(), literals.begin(), literals.end());
+            break;
+        case huff0::ErrUseRLE:
+            lh.setType(literalsBlockRLE);
+            lh.setSize((int)literals.size());
+            lh.appendTo(&output);
+            output.push_back(literals[0]);
+            break;
+        case huff0::OK:
+            if (reUsed) lh.setType(literalsBlockTreeless);
+            else lh.setType(literalsBlockCompressed);
+            lh.setSizes((int)out.size(), (int)literals.size(), single);
+            lh.appendTo(&output);
+            output.insert(output.end(), out.begin(), out.end());
+            litEnc->Reuse = huff0::ReusePolicyAllow;
+            break;
+        default: return -1;
+        }
+        // Sequence compression (:599)
+        size_t nSeq = sequences.size();
+        if (nSeq < 128) {
+            output.push_back((uint8_t)nSeq);
+        } else if (nSeq < 0x7f00) {
+            output.push_back((uint8_t)(128 + (uint8_t)(nSeq >> 8)));
+            output.push_back((uint8_t)nSeq);
+        } else {
+            size_t n = nSeq - 0x7f00;
+            output.push_back(255);
+            output.push_back((uint8_t)n);
+            output.push_back((uint8_t)(n >> 8));
+        }
+        genCodes();
+        FseEncoder* llEnc = coders.llEnc;
+        FseEncoder* ofEnc = coders.ofEnc;
+        FseEncoder* mlEnc = coders.mlEnc;
+        if (!llEnc->normalizeCount((int)nSeq)) return -1;
+        if (!ofEnc->normalizeCount((int)nSeq)) return -1;
+        if (!mlEnc->normalizeCount((int)nSeq)) return -1;
+
+        // :633 chooseComp
+        auto chooseComp = [](FseEncoder* cur, FseEncoder* prev, FseEncoder* preDef, SeqCompMode* m) -> FseEncoder* {
+            const uint32_t* hist = cur->count;
+            int histLen = cur->symbolLen;
+            uint32_t nSize = cur->approxSize(hist, histLen) + cur->maxHeaderSize();
+            uint32_t predefSize = preDef->approxSize(hist, histLen);
+            uint32_t prevSize = prev->approxSize(hist, histLen);
+            nSize = nSize + ((nSize + 2 * 8 * 16) >> 4);
+            if (predefSize <= prevSize && predefSize <= nSize) { *m = compModePredefined; return preDef; }
+            if (prevSize <= nSize) { *m = compModeRepeat; return prev; }
+            *m = compModeFSE;
+            return cur;
+        };
+        uint8_t mode = 0;
+        if (llEnc->useRLE) {
+            mode |= (uint8_t)(compModeRLE << 6);
+            llEnc->setRLE(sequences[0].llCode);
+        } else {
+            SeqCompMode m;
+            llEnc = chooseComp(llEnc, coders.llPrev, &predef().enc[0], &m);
+            mode |= (uint8_t)(m << 6);
+        }
+        if (ofEnc->useRLE) {
+            mode |= (uint8_t)(compModeRLE << 4);
+            ofEnc->setRLE(sequences[0].ofCode);
+        } else {
+            SeqCompMode m;
+            ofEnc = chooseComp(ofEnc, coders.ofPrev, &predef().enc[1], &m);
+            mode |= (uint8_t)(m << 4);
+        }
+        if (mlEnc->useRLE) {
+            mode |= (uint8_t)(compModeRLE << 2);
+            mlEnc->setRLE(sequences[0].mlCode);
+        } else {
+            SeqCompMode m;
+            mlEnc = chooseComp(mlEnc, coders.mlPrev, &predef().enc[2], &m);
+            mode |= (uint8_t)(m << 2);
+        }
+        output.push_back(mode);
+        if (!llEnc->writeCount(&output)) return -1;
+        if (!ofEnc->writeCount(&output)) return -1;
+        if (!mlEnc->writeCount(&output)) return -1;
+
+        // :725 bitstream
+        wr.reset(&output);
+        CState ll, of, ml;
+        int64_t seqi = (int64_t)nSeq - 1;
+        Seq s = sequences[seqi];
+        llEnc->setBits(llBitsTable);
+        mlEnc->setBits(mlBitsTable);
+        ofEnc->setBits(nullptr);
+        const SymbolTransform* llTT = llEnc->symbolTT;
+        const SymbolTransform* ofTT = ofEnc->symbolTT;
+        const SymbolTransform* mlTT = mlEnc->symbolTT;
+        SymbolTransform llB = llTT[s.llCode], ofB = ofTT[s.ofCode], mlB = mlTT[s.mlCode];
+        ll.init(&wr, llEnc, llB);
+        of.init(&wr, ofEnc, ofB);
+        wr.flush32();
+        ml.init(&wr, mlEnc, mlB);
+        wr.addBits32NC(s.litLen, llB.outBits);
+        wr.addBits32NC(s.matchLen, mlB.outBits);
+        wr.flush32();
+        wr.addBits32NC(s.offset, ofB.outBits);
+        seqi--;
+        while (seqi >= 0) {
+            s = sequences[seqi];
+            SymbolTransform ofB2 = ofTT[s.ofCode];
+            wr.flush32();
+            uint32_t nbBitsOut = ((uint32_t)of.state + ofB2.deltaNbBits) >> 16;
+            int32_t dstState = (int32_t)(of.state >> (nbBitsOut & 15)) + (int32_t)ofB2.deltaFindState;
+            wr.addBits16NC(of.state, (uint8_t)nbBitsOut);
+            of.state = of.stateTable[dstState];
+
+            uint8_t outBits = ofB2.outBits & 31;
+            uint64_t extraBits = (uint64_t)(s.offset & (outBits == 0 ? 0u : (0xFFFFFFFFu >> (32 - outBits))));
+            uint8_t extraBitsN = outBits;
+
+            SymbolTransform mlB2 = mlTT[s.mlCode];
+            nbBitsOut = ((uint32_t)ml.state + mlB2.deltaNbBits) >> 16;
+            dstState = (int32_t)(ml.state >> (nbBitsOut & 15)) + (int32_t)mlB2.deltaFindState;
+            wr.addBits16NC(ml.state, (uint8_t)nbBitsOut);
+            ml.state = ml.stateTable[dstState];
+
+            outBits = mlB2.outBits & 31;
+            extraBits = extraBits << outBits | (uint64_t)(s.matchLen & (outBits == 0 ? 0u : (0xFFFFFFFFu >> (32 - outBits))));
+            extraBitsN = (uint8_t)(extraBitsN + outBits);
+
+            SymbolTransform llB2 = llTT[s.llCode];
+            nbBitsOut = ((uint32_t)ll.state + llB2.deltaNbBits) >> 16;
+            dstState = (int32_t)(ll.state >> (nbBitsOut & 15)) + (int32_t)llB2.deltaFindState;
+            wr.addBits16NC(ll.state, (uint8_t)nbBitsOut);
+            ll.state = ll.stateTable[dstState];
+
+            outBits = llB2.outBits & 31;
+            extraBits = extraBits << outBits | (uint64_t)(s.litLen & (outBits == 0 ? 0u : (0xFFFFFFFFu >> (32 - outBits))));
+            extraBitsN = (uint8_t)(extraBitsN + outBits);
+
+            wr.flush32();
+            wr.addBits64NC(extraBits, extraBitsN);
+            seqi--;
+        }
+        ml.flush(mlEnc->actualTableLog);
+        of.flush(ofEnc->actualTableLog);
+        ll.flush(llEnc->actualTableLog);
+        wr.close();
+
+        if ((int64_t)output.size() - 3 - (int64_t)bhOffset >= (int64_t)size) {
+            encodeRawTo(bhOffset, org, orgLen);
+            popOffsets();
+            litEnc->Reuse = huff0::ReusePolicyNone;
+            return 0;
+        }
+        bh.setSize((uint32_t)(output.size() - bhOffset) - 3);
+        bh.writeAt(&output[bhOffset]);
+        coders.setPrev(llEnc, mlEnc, ofEnc);
+        return 0;
+    }
+};
+
+}  // namespace kco

@@ -1,0 +1,225 @@
+"""ctypes binding of the CPU oracle (oracle/libkcoracle.so) — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ODIR = os.path.join(_ROOT, "oracle")
+_SO = os.path.join(_ODIR, "libkcoracle.so")
+
+
+class ZstdOpts(C.Structure):
+    _fields_ = [
+        ("level", C.c_int32), ("window_size", C.c_int32), ("block_size", C.c_int32), ("crc", C.c_int32),
+        ("single", C.c_int32), ("full_zero", C.c_int32), ("no_entropy", C.c_int32), ("all_lit_entropy", C.c_int32),
+        ("low_mem", C.c_int32), ("dict_id", C.c_uint32), ("dict", C.c_char_p), ("dict_len", C.c_uint64),
+    ]
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or any(
+            os.path.getmtime(os.path.join(_ODIR, f)) > os.path.getmtime(_SO)
+            for f in os.listdir(_ODIR) if f.endswith((".h", ".cpp"))):
+        subprocess.check_call(["make", "-C", _ODIR, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u8p, u64p, u32p = C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        L.kco_zstd_encoder_new.restype = C.c_void_p
+        L.kco_zstd_encoder_new.argtypes = [C.POINTER(ZstdOpts)]
+        L.kco_zstd_encoder_free.argtypes = [C.c_void_p]
+        L.kco_zstd_encode_all.restype = C.c_int64
+        L.kco_zstd_encode_all.argtypes = [C.c_void_p, u8p, C.c_uint64, u8p, C.c_uint64]
+        L.kco_zstd_max_encoded_size.restype = C.c_int64
+        L.kco_zstd_max_encoded_size.argtypes = [C.POINTER(ZstdOpts), C.c_int64]
+        L.kco_zstd_encode_units.restype = C.c_int64
+        L.kco_zstd_encode_units.argtypes = [C.POINTER(ZstdOpts), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.kco_zstd_parse_unit.restype = C.c_int64
+        L.kco_zstd_parse_unit.argtypes = [C.POINTER(ZstdOpts), u8p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.kco_xxh64.restype = C.c_uint64
+        L.kco_xxh64.argtypes = [u8p, C.c_uint64]
+        L.kco_xxh64_chunked.restype = C.c_uint64
+        L.kco_xxh64_chunked.argtypes = [u8p, C.c_uint64, C.c_uint64]
+        L.kco_zstd_matchlen.restype = C.c_int32
+        L.kco_zstd_matchlen.argtypes = [u8p, C.c_uint64, u8p]
+        L.kco_zstd_hashlen.restype = C.c_uint32
+        L.kco_zstd_hashlen.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.kco_huff0_compress.restype = C.c_int64
+        L.kco_huff0_compress.argtypes = [u8p, C.c_uint64, C.c_int, C.c_int, u8p, C.c_uint64]
+        L.kco_fse_compress.restype = C.c_int64
+        L.kco_fse_compress.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64]
+        L.kco_s2_max_encoded_len.restype = C.c_int64
+        L.kco_s2_max_encoded_len.argtypes = [C.c_int64]
+        for name in ("kco_s2_encode", "kco_s2_encode_block", "kco_s2_decode"):
+            f = getattr(L, name)
+            f.restype = C.c_int64
+            f.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64]
+        L.kco_s2_emit_literal.restype = C.c_int64
+        L.kco_s2_emit_literal.argtypes = [u8p, u8p, C.c_uint64]
+        L.kco_s2_emit_copy.restype = C.c_int64
+        L.kco_s2_emit_copy.argtypes = [u8p, C.c_int64, C.c_int64]
+        L.kco_s2_emit_repeat.restype = C.c_int64
+        L.kco_s2_emit_repeat.argtypes = [u8p, C.c_int64, C.c_int64]
+        L.kco_s2_crc.restype = C.c_uint32
+        L.kco_s2_crc.argtypes = [u8p, C.c_uint64]
+        L.kco_s2_encode_blocks.restype = C.c_int64
+        L.kco_s2_encode_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def make_opts(level=2, window_size=None, block_size=None, crc=True, single=None, full_zero=True,
+              no_entropy=False, all_lit_entropy=None, low_mem=False, dict_id=0, dict_content=None):
+    """Resolved options.  Defaults follow encoderOptions.setDefault + WithEncoderLevel
+    (zstd/encoder_options.go:36-48,236-266)."""
+    if window_size is None:
+        window_size = (4 << 20) if level == 1 else (8 << 20)
+    if block_size is None:
+        block_size = (1 << 16) if level == 1 else (128 << 10)
+        block_size = min(block_size, window_size)
+    if all_lit_entropy is None:
+        all_lit_entropy = level > 2
+    o = ZstdOpts()
+    o.level, o.window_size, o.block_size, o.crc = level, window_size, block_size, int(crc)
+    o.single = -1 if single is None else int(single)
+    o.full_zero, o.no_entropy, o.all_lit_entropy, o.low_mem = int(full_zero), int(no_entropy), int(all_lit_entropy), int(low_mem)
+    o.dict_id = dict_id
+    o._keep = dict_content
+    o.dict = dict_content
+    o.dict_len = len(dict_content) if dict_content else 0
+    return o
+
+
+class ZstdOracle:
+    """One persistent reference-encoder state (like one pooled Go encoder)."""
+
+    def __init__(self, **kw):
+        self.opts = make_opts(**kw)
+        self.h = lib().kco_zstd_encoder_new(C.byref(self.opts))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().kco_zstd_encoder_free(self.h)
+            self.h = None
+
+    def max_encoded_size(self, n):
+        return lib().kco_zstd_max_encoded_size(C.byref(self.opts), n)
+
+    def encode_all(self, src: bytes) -> bytes:
+        cap = self.max_encoded_size(len(src)) + 64
+        buf = C.create_string_buffer(cap)
+        r = lib().kco_zstd_encode_all(self.h, src, len(src), buf, cap)
+        if r < 0:
+            raise RuntimeError("oracle encode_all failed: %d" % r)
+        return buf.raw[:r]
+
+
+def zstd_encode_units(src, unit_off, threads=1, **kw):
+    """src: bytes/numpy u8; unit_off: numpy u64 [n+1]. Returns (bytes, out_off numpy)."""
+    import numpy as np
+    opts = make_opts(**kw)
+    src = np.ascontiguousarray(np.frombuffer(src, dtype=np.uint8) if isinstance(src, (bytes, bytearray)) else src)
+    unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
+    n = len(unit_off) - 1
+    cap = int(sum(lib().kco_zstd_max_encoded_size(C.byref(opts), int(unit_off[i + 1] - unit_off[i])) for i in range(n))) + 64
+    dst = np.empty(cap, dtype=np.uint8)
+    out_off = np.empty(n + 1, dtype=np.uint64)
+    r = lib().kco_zstd_encode_units(C.byref(opts), src.ctypes.data, unit_off.ctypes.data, n, dst.ctypes.data, cap, out_off.ctypes.data, threads)
+    if r < 0:
+        raise RuntimeError("oracle encode_units failed: %d" % r)
+    return dst[:r], out_off
+
+
+def zstd_parse_unit(src: bytes, **kw):
+    """Match-finder intermediates: list of (seqs[n,3] u32, literals bytes) per block."""
+    import numpy as np
+    opts = make_opts(**kw)
+    n = len(src)
+    seqs = np.empty((n // 3 + 16, 3), dtype=np.uint32)
+    lits = np.empty(n + 16, dtype=np.uint8)
+    mb = n // max(1, opts.block_size) + 2
+    nseq = np.empty(mb, dtype=np.uint32)
+    nlit = np.empty(mb, dtype=np.uint32)
+    nb = lib().kco_zstd_parse_unit(C.byref(opts), src, n, seqs.ctypes.data, len(seqs), lits.ctypes.data, len(lits),
+                                   nseq.ctypes.data, nlit.ctypes.data, mb)
+    if nb < 0:
+        raise RuntimeError("oracle parse_unit failed: %d" % nb)
+    out, so, lo = [], 0, 0
+    for b in range(nb):
+        out.append((seqs[so:so + nseq[b]].copy(), lits[lo:lo + nlit[b]].tobytes()))
+        so += int(nseq[b])
+        lo += int(nlit[b])
+    return out
+
+
+def s2_encode(src: bytes) -> bytes:
+    cap = lib().kco_s2_max_encoded_len(len(src))
+    buf = C.create_string_buffer(max(cap, 1))
+    r = lib().kco_s2_encode(src, len(src), buf, cap)
+    if r < 0:
+        raise RuntimeError("s2 encode failed %d" % r)
+    return buf.raw[:r]
+
+
+def s2_encode_block(src: bytes) -> bytes:
+    cap = lib().kco_s2_max_encoded_len(len(src))
+    buf = C.create_string_buffer(max(cap, 1))
+    r = lib().kco_s2_encode_block(src, len(src), buf, cap)
+    if r < 0:
+        raise RuntimeError("s2 encode_block failed %d" % r)
+    return buf.raw[:r]
+
+
+def s2_decode(enc: bytes, cap: int) -> bytes:
+    buf = C.create_string_buffer(max(cap, 1))
+    r = lib().kco_s2_decode(enc, len(enc), buf, cap)
+    if r < 0:
+        raise RuntimeError("s2 decode failed %d" % r)
+    return buf.raw[:r]
+
+
+# ---- independent zstd decoder: system libzstd 1.4.8 (runtime only) ----
+_zstd = None
+
+
+def libzstd():
+    global _zstd
+    if _zstd is None:
+        Z = C.CDLL("libzstd.so.1")
+        Z.ZSTD_decompress.restype = C.c_size_t
+        Z.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        Z.ZSTD_isError.restype = C.c_uint
+        Z.ZSTD_isError.argtypes = [C.c_size_t]
+        Z.ZSTD_getErrorName.restype = C.c_char_p
+        Z.ZSTD_getErrorName.argtypes = [C.c_size_t]
+        Z.ZSTD_createDCtx.restype = C.c_void_p
+        Z.ZSTD_freeDCtx.argtypes = [C.c_void_p]
+        Z.ZSTD_decompress_usingDict.restype = C.c_size_t
+        Z.ZSTD_decompress_usingDict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        _zstd = Z
+    return _zstd
+
+
+def zstd_decompress(enc: bytes, cap: int, dict_content: bytes = None) -> bytes:
+    Z = libzstd()
+    buf = C.create_string_buffer(max(cap, 1))
+    if dict_content:
+        ctx = Z.ZSTD_createDCtx()
+        r = Z.ZSTD_decompress_usingDict(ctx, buf, cap, enc, len(enc), dict_content, len(dict_content))
+        Z.ZSTD_freeDCtx(ctx)
+    else:
+        r = Z.ZSTD_decompress(buf, cap, enc, len(enc))
+    if Z.ZSTD_isError(r):
+        raise RuntimeError("libzstd: " + Z.ZSTD_getErrorName(r).decode())
+    return buf.raw[:r]
