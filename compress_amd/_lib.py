@@ -1,0 +1,160 @@
+"""ctypes binding of include/kcgpu.h (libkcgpu.so).  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libkcgpu.so")
+
+KC_OK = 0
+KC_ERR_BAD_ARG, KC_ERR_DST_TOO_SMALL, KC_ERR_HIP, KC_ERR_UNSUPPORTED, KC_ERR_NO_DEVICE, KC_ERR_INTERNAL = -1, -2, -3, -4, -5, -6
+_NAMES = {0: "KC_OK", -1: "KC_ERR_BAD_ARG", -2: "KC_ERR_DST_TOO_SMALL", -3: "KC_ERR_HIP", -4: "KC_ERR_UNSUPPORTED",
+          -5: "KC_ERR_NO_DEVICE", -6: "KC_ERR_INTERNAL"}
+
+
+class KcError(RuntimeError):
+    def __init__(self, status, msg=""):
+        self.status = status
+        super().__init__("%s%s" % (_NAMES.get(status, str(status)), (": " + msg) if msg else ""))
+
+
+class ZstdOpts(C.Structure):
+    _fields_ = [
+        ("level", C.c_int32), ("window_size", C.c_int32), ("block_size", C.c_int32), ("crc", C.c_int32),
+        ("single", C.c_int32), ("full_zero", C.c_int32), ("no_entropy", C.c_int32), ("all_lit_entropy", C.c_int32),
+        ("low_mem", C.c_int32), ("custom_window", C.c_int32), ("custom_block", C.c_int32), ("custom_alent", C.c_int32),
+        ("dict_id", C.c_uint32), ("dict", C.c_void_p), ("dict_len", C.c_uint64),
+    ]
+
+
+class Timings(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("match_ms", C.c_float), ("entropy_ms", C.c_float), ("other_ms", C.c_float),
+                ("redo_units", C.c_uint32)]
+
+
+# every symbol include/kcgpu.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "kc_zstd_opts_default", "kc_zstd_opts_level", "kc_zstd_opts_window", "kc_zstd_opts_crc", "kc_zstd_opts_zero_frames",
+    "kc_zstd_opts_no_entropy", "kc_zstd_opts_all_lit_entropy", "kc_zstd_opts_single_segment", "kc_zstd_opts_dict_raw",
+    "kc_zstd_max_encoded_size", "kc_ctx_create", "kc_ctx_destroy", "kc_last_error", "kc_device_info",
+    "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
+    "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_block",
+    "kc_last_timings", "kc_corpus_fill",
+]
+
+_lib = None
+
+
+def lib_path():
+    return _SO
+
+
+def load():
+    """Load libkcgpu.so; raises if it has not been built (python -m compress_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise KcError(KC_ERR_NO_DEVICE, "libkcgpu.so not built: run `python -m compress_amd.build` (no CPU fallback exists)")
+    # One HIP runtime per process: when PyTorch is present it must be imported first so that
+    # libkcgpu.so binds to the libamdhip64.so.7 PyTorch already mapped (device pointers and
+    # streams are then shareable); without PyTorch the system ROCm runtime is used.
+    if os.environ.get("KC_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(_SO)
+    vp, u64 = C.c_void_p, C.c_uint64
+    po = C.POINTER(ZstdOpts)
+    L.kc_zstd_opts_default.argtypes = [po]
+    L.kc_zstd_opts_default.restype = None
+    for n in ("level", "window", "crc", "zero_frames", "no_entropy", "all_lit_entropy", "single_segment"):
+        f = getattr(L, "kc_zstd_opts_" + n)
+        f.argtypes = [po, C.c_int]
+        f.restype = C.c_int
+    L.kc_zstd_opts_dict_raw.argtypes = [po, C.c_uint32, vp, u64]
+    L.kc_zstd_opts_dict_raw.restype = C.c_int
+    L.kc_zstd_max_encoded_size.argtypes = [po, C.c_int64]
+    L.kc_zstd_max_encoded_size.restype = C.c_int64
+    L.kc_ctx_create.argtypes = [C.POINTER(vp), C.c_int, vp]
+    L.kc_ctx_create.restype = C.c_int
+    L.kc_ctx_destroy.argtypes = [vp]
+    L.kc_ctx_destroy.restype = None
+    L.kc_last_error.argtypes = [vp]
+    L.kc_last_error.restype = C.c_char_p
+    L.kc_device_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]
+    L.kc_device_info.restype = C.c_int
+    for n in ("kc_zstd_encode_units", "kc_zstd_encode_units_dev"):
+        f = getattr(L, n)
+        f.argtypes = [vp, po, vp, vp, C.c_uint32, vp, u64, vp]
+        f.restype = C.c_int
+    L.kc_xxh64_units_dev.argtypes = [vp, vp, vp, C.c_uint32, vp]
+    L.kc_xxh64_units_dev.restype = C.c_int
+    L.kc_zstd_debug_parse_dev.argtypes = [vp, po, vp, vp, C.c_uint32, vp, u64, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.kc_zstd_debug_parse_dev.restype = C.c_int
+    L.kc_s2_max_encoded_len.argtypes = [C.c_int64]
+    L.kc_s2_max_encoded_len.restype = C.c_int64
+    for n in ("kc_s2_encode_blocks", "kc_s2_encode_blocks_dev"):
+        f = getattr(L, n)
+        f.argtypes = [vp, vp, vp, C.c_uint32, vp, u64, vp]
+        f.restype = C.c_int
+    L.kc_s2_encode_block.argtypes = [vp, vp, u64, vp, u64]
+    L.kc_s2_encode_block.restype = C.c_int64
+    L.kc_last_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.kc_last_timings.restype = C.c_int
+    L.kc_corpus_fill.argtypes = [C.c_int, u64, u64, C.c_uint32, C.c_uint32, vp, C.c_int]
+    L.kc_corpus_fill.restype = C.c_int
+    _lib = L
+    return L
+
+
+class Context:
+    """kc_ctx: device scratch + stream.  stream: an int hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load()
+        h = C.c_void_p()
+        st = self.L.kc_ctx_create(C.byref(h), device, C.c_void_p(stream) if stream else None)
+        if st != KC_OK:
+            raise KcError(st, "kc_ctx_create (is a gfx950 GPU visible? there is no CPU fallback)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.kc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, st):
+        if st != KC_OK:
+            raise KcError(st, self.L.kc_last_error(self.h).decode(errors="replace"))
+
+    def device_info(self):
+        ncu, lds, clk = C.c_int32(), C.c_int32(), C.c_int32()
+        name = C.create_string_buffer(128)
+        self.check(self.L.kc_device_info(self.h, C.byref(ncu), C.byref(lds), C.byref(clk), name, 128))
+        return {"n_cu": ncu.value, "lds_per_cu": lds.value, "clock_khz": clk.value, "arch": name.value.decode()}
+
+    def timings(self):
+        t = Timings()
+        self.check(self.L.kc_last_timings(self.h, C.byref(t)))
+        return {"total_ms": t.total_ms, "match_ms": t.match_ms, "entropy_ms": t.entropy_ms, "other_ms": t.other_ms,
+                "redo_units": t.redo_units}
+
+
+def corpus_fill(kind, seed, first_unit, n_units, unit_size, threads=None):
+    """Deterministic synthetic corpus (kc_corpus_fill): returns a numpy uint8 array of n_units*unit_size bytes."""
+    import numpy as np
+    L = load()
+    buf = np.empty(int(n_units) * int(unit_size), dtype=np.uint8)
+    if threads is None:
+        threads = os.cpu_count() or 1
+    st = L.kc_corpus_fill(ord(kind), seed, first_unit, n_units, unit_size, buf.ctypes.data, threads)
+    if st != KC_OK:
+        raise KcError(st, "kc_corpus_fill")
+    return buf

@@ -1,0 +1,59 @@
+"""In-tree build of libkcgpu.so (HIP kernels + C ABI) for gfx950.
+
+    python -m compress_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects are cached under compress_amd/_build/.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libkcgpu.so")
+BDIR = os.path.join(HERE, "_build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable", "-munsafe-fp-atomics"]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(BDIR, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "kcgpu.h"))
+    objs = []
+    procs = []
+    for s in srcs:
+        sp = os.path.join(CSRC, s)
+        op = os.path.join(BDIR, s + ".o")
+        objs.append(op)
+        if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
+            cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("== %s failed ==\n%s\n" % (s, out.decode(errors="replace")))
+        elif verbose and out:
+            sys.stderr.write(out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or not os.path.exists(OUT):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,105 @@
+// kc_dev.h — device-side helpers shared by the gfx950 kernels (wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KC_WAVE 64
+
+// ---- unaligned little-endian loads (reference: internal/le/unsafe_enabled.go) ----
+struct __attribute__((packed)) kc_u64u { uint64_t v; };
+struct __attribute__((packed)) kc_u32u { uint32_t v; };
+struct __attribute__((packed)) kc_u16u { uint16_t v; };
+__device__ __forceinline__ uint64_t ld64(const uint8_t* p) { return ((const kc_u64u*)p)->v; }
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return ((const kc_u32u*)p)->v; }
+__device__ __forceinline__ uint16_t ld16(const uint8_t* p) { return ((const kc_u16u*)p)->v; }
+
+// ---- wave primitives ----
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ int ctz64(uint64_t v) { return __builtin_ctzll(v); }
+__device__ __forceinline__ uint32_t bcast32(uint32_t v, int srcLane) { return (uint32_t)__shfl((int)v, srcLane, 64); }
+__device__ __forceinline__ uint64_t bcast64(uint64_t v, int srcLane) {
+    uint32_t lo = bcast32((uint32_t)v, srcLane), hi = bcast32((uint32_t)(v >> 32), srcLane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// bits.Len32(v)
+__device__ __forceinline__ int bits_len32(uint32_t v) { return v == 0 ? 0 : 32 - __builtin_clz(v); }
+// highBit: uint32(bits.Len32(v) - 1); highBit(0) == 0xFFFFFFFF (zstd/seqenc.go:44)
+__device__ __forceinline__ uint32_t high_bit(uint32_t v) { return (uint32_t)(bits_len32(v) - 1); }
+
+// ---- zstd hashLen (zstd/hash.go:20-35) ----
+#define KC_PRIME4 2654435761u
+#define KC_PRIME5 889523592379ULL
+#define KC_PRIME6 227718039650203ULL
+#define KC_PRIME8 0xcf1bbcdcb7a56463ULL
+__device__ __forceinline__ uint32_t hash4(uint32_t u, int bits) { return (u * KC_PRIME4) >> (32 - bits); }
+__device__ __forceinline__ uint32_t hash5(uint64_t u, int bits) { return (uint32_t)(((u << 24) * KC_PRIME5) >> (64 - bits)); }
+__device__ __forceinline__ uint32_t hash6(uint64_t u, int bits) { return (uint32_t)(((u << 16) * KC_PRIME6) >> (64 - bits)); }
+__device__ __forceinline__ uint32_t hash8(uint64_t u, int bits) { return (uint32_t)((u * KC_PRIME8) >> (64 - bits)); }
+
+// ---- sequence packing in HBM scratch: of:24 | ml:20 | ll:20 ----
+// of = offset code value (real offset + 3, or 1 for repeat), ml = matchLen - 3, ll = litLen
+__device__ __forceinline__ uint64_t seq_pack(uint32_t ll, uint32_t ml, uint32_t of) {
+    return (uint64_t)of | ((uint64_t)ml << 24) | ((uint64_t)ll << 44);
+}
+__device__ __forceinline__ uint32_t seq_of(uint64_t s) { return (uint32_t)(s & 0xFFFFFF); }
+__device__ __forceinline__ uint32_t seq_ml(uint64_t s) { return (uint32_t)((s >> 24) & 0xFFFFF); }
+__device__ __forceinline__ uint32_t seq_ll(uint64_t s) { return (uint32_t)(s >> 44); }
+
+// ---- wave-cooperative common-prefix length (zstd/matchlen_generic.go:17-37) ----
+// a has `left` readable bytes, b (earlier in the buffer) is at least as long.
+// All 64 lanes must call; returns the same value in every lane.
+__device__ __forceinline__ int wave_matchlen(const uint8_t* a, const uint8_t* b, int left, int lane) {
+    int n = 0;
+    int width = 8;  // first probe 8 lanes (64 B): most matches are short; then full wave
+    for (;;) {
+        int words = (left - n) >> 3;
+        int active = words < width ? words : width;
+        uint64_t diff = 0;
+        if (lane < active) diff = ld64(a + n + 8 * lane) ^ ld64(b + n + 8 * lane);
+        uint64_t m = ballot64(diff != 0);
+        if (m) {
+            int fl = ctz64(m);
+            uint64_t d = bcast64(diff, fl);
+            return n + 8 * fl + (ctz64(d) >> 3);
+        }
+        n += 8 * active;
+        if (active < width) break;
+        width = 64;
+    }
+    int tail = left - n;  // < 8 bytes
+    bool ne = lane < tail && a[n + lane] != b[n + lane];
+    uint64_t m = ballot64(ne);
+    return n + (m ? ctz64(m) : tail);
+}
+
+// Number of consecutive k = 1..kmax with base[t-k] == base[s-k] (backward extension loops,
+// e.g. zstd/enc_fast.go:230-234).  Wave-uniform result.
+__device__ __forceinline__ int wave_backlen(const uint8_t* base, int s, int t, int kmax, int lane) {
+    int cnt = 0;
+    while (cnt < kmax) {
+        int k = cnt + lane + 1;
+        bool ne = true;
+        if (k <= kmax) ne = base[t - k] != base[s - k];
+        uint64_t m = ballot64(ne);
+        int c = m ? ctz64(m) : 64;
+        cnt += c;
+        if (c < 64) break;
+    }
+    return cnt < kmax ? cnt : kmax;
+}
+
+// Per-block record written by the match finders and consumed by the entropy kernel.
+struct KcBlkMeta {
+    uint32_t nseq;       // sequences in this block
+    uint32_t nlit;       // len(blk.literals) == sum(litLen) + extraLits
+    uint32_t extra_lits; // trailing literals after the last sequence
+    uint32_t flags;      // KC_BF_*
+    uint32_t o1_in, o2_in;   // recentOffsets[0..1] before the block (what popOffsets restores)
+    uint32_t o1_out, o2_out; // recentOffsets[0..1] the match finder carried into the next block
+};
+#define KC_BF_POP_A 1u   // block took the saved<16 literals-only path (blockenc.go:496-503): offsets popped
+#define KC_BF_FORCED 2u  // pop forced by the host for a re-run (block re-emitted raw, blockenc.go:811-817)

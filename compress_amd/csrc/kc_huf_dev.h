@@ -1,0 +1,303 @@
+// kc_huf_dev.h — device-side Huffman (huff0) table construction.
+//
+// Follows huff0/compress.go: optimalTableLog :428, huffSort :570, buildCTable :457,
+// setMaxHeight :609, and huff0/huff0.go cTable.write :180 with fse.Compress of the weights
+// (fse/compress.go:18-204).  The symbol sort is computed as a parallel rank (stable by
+// count descending, symbol ascending == the reference's bucketed insertion sort); the
+// tree build, height limiting and weight-table serialisation are O(256) serial work done
+// by one lane on LDS-resident arrays.
+#pragma once
+#include "kc_dev.h"
+#include "kc_fse_dev.h"
+
+#define HUF_TABLELOG_MAX 11
+#define HUF_NODES 512
+
+struct KcHufNodes {          // huffNode[-1 .. 511] stored at index+1 (huffNode0 view of the reference)
+    uint32_t count[HUF_NODES + 1];
+    uint16_t parent[HUF_NODES + 1];
+    uint8_t nbits[HUF_NODES + 1];
+    uint8_t symbol[HUF_NODES + 1];
+};
+
+struct KcHufTable {  // cTable: val/nBits per symbol
+    uint16_t val[256];
+    uint8_t nb[256];
+};
+
+// huff0.Scratch.optimalTableLog (compress.go:428) with TableLog = 11
+__device__ inline uint8_t huf_optimal_table_log(int srcLen, int symbolLen) {
+    uint8_t tableLog = 11;
+    uint32_t minBitsSrc = high_bit((uint32_t)srcLen) + 1;
+    uint32_t minBitsSymbols = high_bit((uint32_t)(uint16_t)(symbolLen - 1)) + 2;
+    uint8_t minBits = (uint8_t)(minBitsSrc < minBitsSymbols ? minBitsSrc : minBitsSymbols);
+    uint8_t maxBitsSrc = (uint8_t)((uint8_t)high_bit((uint32_t)(srcLen - 1)) - 1);
+    if (maxBitsSrc < tableLog) tableLog = maxBitsSrc;
+    if (minBits > tableLog) tableLog = minBits;
+    if (tableLog < 5) tableLog = 5;
+    if (tableLog > 11) tableLog = 11;
+    return tableLog;
+}
+
+// setMaxHeight (compress.go:609).  N: nodes (index+1 addressing handled by the macros below).
+#define HN_CNT(i) N->count[(i) + 1]
+#define HN_PAR(i) N->parent[(i) + 1]
+#define HN_NB(i) N->nbits[(i) + 1]
+#define HN_SYM(i) N->symbol[(i) + 1]
+
+__device__ inline uint8_t huf_set_max_height(KcHufNodes* N, int lastNonNull, uint8_t maxNbBits) {
+    const uint8_t largestBits = HN_NB(lastNonNull);
+    if (largestBits <= maxNbBits) return largestBits;
+    int totalCost = 0;
+    const int baseCost = 1 << (largestBits - maxNbBits);
+    uint32_t n = (uint32_t)lastNonNull;
+    while (HN_NB(n) > maxNbBits) {
+        totalCost += baseCost - (1 << (largestBits - HN_NB(n)));
+        HN_NB(n) = maxNbBits;
+        n--;
+    }
+    while (HN_NB(n) == maxNbBits) n--;
+    totalCost >>= (largestBits - maxNbBits);
+    const uint32_t noSymbol = 0xF0F0F0F0u;
+    uint32_t rankLast[HUF_TABLELOG_MAX + 2];
+    for (int i = 0; i < HUF_TABLELOG_MAX + 2; i++) rankLast[i] = noSymbol;
+    {
+        uint8_t currentNbBits = maxNbBits;
+        for (int pos = (int)n; pos >= 0; pos--) {
+            if (HN_NB(pos) >= currentNbBits) continue;
+            currentNbBits = HN_NB(pos);
+            rankLast[maxNbBits - currentNbBits] = (uint32_t)pos;
+        }
+    }
+    while (totalCost > 0) {
+        uint8_t nBitsToDecrease = (uint8_t)((uint8_t)high_bit((uint32_t)totalCost) + 1);
+        for (; nBitsToDecrease > 1; nBitsToDecrease--) {
+            const uint32_t highPos = rankLast[nBitsToDecrease];
+            const uint32_t lowPos = rankLast[nBitsToDecrease - 1];
+            if (highPos == noSymbol) continue;
+            if (lowPos == noSymbol) break;
+            const uint32_t highTotal = HN_CNT(highPos);
+            const uint32_t lowTotal = 2 * HN_CNT(lowPos);
+            if (highTotal <= lowTotal) break;
+        }
+        while (nBitsToDecrease <= HUF_TABLELOG_MAX && rankLast[nBitsToDecrease] == noSymbol) nBitsToDecrease++;
+        totalCost -= 1 << (nBitsToDecrease - 1);
+        if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+        HN_NB(rankLast[nBitsToDecrease]) = (uint8_t)(1 + HN_NB(rankLast[nBitsToDecrease]));
+        if (rankLast[nBitsToDecrease] == 0) {
+            rankLast[nBitsToDecrease] = noSymbol;
+        } else {
+            rankLast[nBitsToDecrease]--;
+            if (HN_NB(rankLast[nBitsToDecrease]) != (uint8_t)(maxNbBits - nBitsToDecrease)) rankLast[nBitsToDecrease] = noSymbol;
+        }
+    }
+    while (totalCost < 0) {
+        if (rankLast[1] == noSymbol) {
+            while (HN_NB(n) == maxNbBits) n--;
+            HN_NB(n + 1) = (uint8_t)(HN_NB(n + 1) - 1);
+            rankLast[1] = n + 1;
+            totalCost++;
+            continue;
+        }
+        HN_NB(rankLast[1] + 1) = (uint8_t)(HN_NB(rankLast[1] + 1) - 1);
+        rankLast[1]++;
+        totalCost++;
+    }
+    return maxNbBits;
+}
+
+// Serial part of buildCTable (compress.go:457-567).  Precondition: nodes 0..symbolLen-1 hold
+// the symbols sorted by (count desc, symbol asc) (huffSort).  Produces T (val/nb for
+// symbols < symbolLen) and returns actualTableLog, or 0xFF on internal error.
+__device__ inline uint8_t huf_build_serial(KcHufNodes* N, KcHufTable* T, int symbolLen, int srcLen) {
+    const uint8_t tableLog0 = huf_optimal_table_log(srcLen, symbolLen);
+    for (int i = 0; i < symbolLen; i++) { T->val[i] = 0; T->nb[i] = 0; }
+    const int startNode = symbolLen;
+    int nonNullRank = symbolLen - 1;
+    while (HN_CNT(nonNullRank) == 0) nonNullRank--;
+    int lowS = nonNullRank;
+    int nodeNb = startNode;
+    const int nodeRoot = nodeNb + lowS - 1;
+    int lowN = nodeNb;
+    HN_CNT(nodeNb) = HN_CNT(lowS) + HN_CNT(lowS - 1);
+    HN_PAR(lowS) = (uint16_t)nodeNb;
+    HN_PAR(lowS - 1) = (uint16_t)nodeNb;
+    nodeNb++;
+    lowS -= 2;
+    for (int n = nodeNb; n <= nodeRoot; n++) HN_CNT(n) = 1u << 30;
+    HN_CNT(-1) = 1u << 31;  // fake entry, strong barrier
+    while (nodeNb <= nodeRoot) {
+        int n1, n2;
+        if (HN_CNT(lowS) < HN_CNT(lowN)) { n1 = lowS; lowS--; } else { n1 = lowN; lowN++; }
+        if (HN_CNT(lowS) < HN_CNT(lowN)) { n2 = lowS; lowS--; } else { n2 = lowN; lowN++; }
+        HN_CNT(nodeNb) = HN_CNT(n1) + HN_CNT(n2);
+        HN_PAR(n1) = (uint16_t)nodeNb;
+        HN_PAR(n2) = (uint16_t)nodeNb;
+        nodeNb++;
+    }
+    HN_NB(nodeRoot) = 0;
+    for (int n = nodeRoot - 1; n >= startNode; n--) HN_NB(n) = (uint8_t)(HN_NB(HN_PAR(n)) + 1);
+    for (int n = 0; n <= nonNullRank; n++) HN_NB(n) = (uint8_t)(HN_NB(HN_PAR(n)) + 1);
+    const uint8_t maxNbBits = huf_set_max_height(N, nonNullRank, tableLog0);
+    if (maxNbBits > HUF_TABLELOG_MAX) return 0xFF;
+    uint16_t nbPerRank[HUF_TABLELOG_MAX + 1];
+    uint16_t valPerRank[16];
+    for (int i = 0; i <= HUF_TABLELOG_MAX; i++) nbPerRank[i] = 0;
+    for (int i = 0; i < 16; i++) valPerRank[i] = 0;
+    for (int i = 0; i <= nonNullRank; i++) nbPerRank[HN_NB(i)]++;
+    {
+        uint16_t min = 0;
+        for (int n = maxNbBits; n > 0; n--) {
+            valPerRank[n] = min;
+            min = (uint16_t)(min + nbPerRank[n]);
+            min >>= 1;
+        }
+    }
+    for (int i = 0; i <= nonNullRank; i++) T->nb[HN_SYM(i)] = HN_NB(i);
+    for (int n = 0; n < symbolLen; n++) {
+        const uint8_t nbits = T->nb[n] & 15;
+        const uint16_t v = valPerRank[nbits];
+        T->val[n] = v;
+        valPerRank[nbits] = (uint16_t)(v + 1);
+    }
+    return maxNbBits;
+}
+
+// ---- byte FSE of the Huffman weights (fse.Compress with TableLog 6; fse/compress.go:18-204) ----
+struct KcWeightFse {  // scratch, LDS
+    uint32_t count[16];
+    int16_t norm[16];
+    uint16_t st[64];
+    uint32_t dnb[16];
+    int32_t dfs[16];
+    uint8_t tsym[64];
+    int16_t cumul[18];
+};
+
+struct KcBitW {  // serial LSB-first bit writer into a byte buffer (fse/bitwriter.go)
+    uint64_t acc;
+    int nb;
+    uint8_t* out;
+    int pos;
+    __device__ void add(uint32_t value, int bits) {
+        if (bits == 0) return;
+        acc |= (uint64_t)(value & ((1u << bits) - 1u)) << nb;
+        nb += bits;
+        while (nb >= 8) { out[pos++] = (uint8_t)acc; acc >>= 8; nb -= 8; }
+    }
+    __device__ void close() {  // end mark + align
+        add(1, 1);
+        if (nb > 0) { out[pos++] = (uint8_t)acc; acc = 0; nb = 0; }
+    }
+};
+
+// Returns compressed size (header + stream) written to out, or -1 when fse.Compress would
+// return an error (incompressible / RLE / internal), in which case huff0 falls back to raw
+// 4-bit weights.  W: scratch with count[] already holding the weight histogram.
+__device__ inline int huf_fse_compress_weights(const uint8_t* w, int n, int huffMax, int huffMaxCnt, KcWeightFse* W, uint8_t* out, int outCap) {
+    if (n <= 1) return -1;
+    const int symbolLen = huffMax + 1;
+    const int maxCount = huffMaxCnt;
+    if (maxCount == n) return -1;                       // ErrUseRLE
+    if (maxCount == 1 || maxCount < (n >> 7)) return -1;  // ErrIncompressible
+    // optimalTableLog (fse/compress.go:484) with TableLog = 6
+    uint8_t tableLog = 6;
+    {
+        uint32_t minBitsSrc = high_bit((uint32_t)(n - 1)) + 1;
+        uint32_t minBitsSymbols = high_bit((uint32_t)(uint16_t)(symbolLen - 1)) + 2;
+        uint8_t minBits = (uint8_t)(minBitsSrc < minBitsSymbols ? minBitsSrc : minBitsSymbols);
+        uint8_t maxBitsSrc = (uint8_t)((uint8_t)high_bit((uint32_t)(n - 1)) - 2);
+        if (maxBitsSrc < tableLog) tableLog = maxBitsSrc;
+        if (minBits > tableLog) tableLog = minBits;
+        if (tableLog < 5) tableLog = 5;
+        if (tableLog > 12) tableLog = 12;
+    }
+    if (tableLog > 6) return -2;  // cannot happen for <=256 weights; guarded for the scratch sizes
+    if (!fse_normalize_core(W->count, W->norm, symbolLen, n, tableLog)) return -1;
+    int hdr = fse_write_ncount(W->norm, symbolLen, tableLog, out);
+    if (hdr < 0) return -1;
+    if (!fse_build_core<int32_t>(W->norm, symbolLen, tableLog, W->tsym, W->cumul, W->st, W->dnb, W->dfs)) return -1;
+    if (n <= 2) return -1;  // compress: "src too small"
+    KcBitW bw;
+    bw.acc = 0; bw.nb = 0; bw.out = out; bw.pos = hdr;
+    uint16_t c1 = 0, c2 = 0;
+    auto init = [&](uint8_t sym) -> uint16_t {
+        const uint32_t d = W->dnb[sym];
+        const uint32_t nbBitsOut = (d + (1u << 15)) >> 16;
+        const int32_t im = (int32_t)((nbBitsOut << 16) - d);
+        const int32_t lu = (im >> nbBitsOut) + W->dfs[sym];
+        return W->st[lu];
+    };
+    auto enc = [&](uint16_t& state, uint8_t sym) {
+        const uint32_t nbBitsOut = ((uint32_t)state + W->dnb[sym]) >> 16;
+        const int32_t dstState = (int32_t)(state >> (nbBitsOut & 15)) + W->dfs[sym];
+        bw.add(state, (int)nbBitsOut);
+        state = W->st[dstState];
+    };
+    int ip = n;
+    if (ip & 1) {
+        c1 = init(w[ip - 1]);
+        c2 = init(w[ip - 2]);
+        enc(c1, w[ip - 3]);
+        ip -= 3;
+    } else {
+        c2 = init(w[ip - 1]);
+        c1 = init(w[ip - 2]);
+        ip -= 2;
+    }
+    if (ip & 2) {
+        enc(c2, w[ip - 1]);
+        enc(c1, w[ip - 2]);
+        ip -= 2;
+    }
+    for (; ip >= 4; ip -= 4) {
+        enc(c2, w[ip - 1]);
+        enc(c1, w[ip - 2]);
+        enc(c2, w[ip - 3]);
+        enc(c1, w[ip - 4]);
+    }
+    bw.add(c2, tableLog);
+    bw.add(c1, tableLog);
+    bw.close();
+    if (bw.pos > outCap) return -2;
+    if (bw.pos >= n) return -1;  // "len(s.Out) >= len(in)" → ErrIncompressible
+    return bw.pos;
+}
+
+// cTable.write (huff0/huff0.go:180): serialise the weights of table T into out.
+// Returns the description length, or -1 for ErrIncompressible (maxSymbolValue > 128 with
+// no FSE gain).  weights: 256-byte scratch.
+__device__ inline int huf_write_table(const KcHufTable* T, int symbolLen, uint8_t huffLog, uint8_t* weights, KcWeightFse* W, uint8_t* out, int outCap) {
+    uint8_t bitsToWeight[HUF_TABLELOG_MAX + 1];
+    bitsToWeight[0] = 0;
+    for (int n = 1; n <= HUF_TABLELOG_MAX; n++) bitsToWeight[n] = (n < (int)huffLog + 1) ? (uint8_t)(huffLog + 1 - n) : 0;
+    const int maxSym = (int)(uint8_t)(symbolLen - 1);
+    for (int i = 0; i < 16; i++) W->count[i] = 0;
+    for (int n = 0; n < maxSym; n++) {
+        const uint8_t nbv = T->nb[n];
+        const uint8_t v = (nbv <= HUF_TABLELOG_MAX ? bitsToWeight[nbv] : 0) & 15;
+        weights[n] = v;
+        W->count[v]++;
+    }
+    if (maxSym >= 2) {
+        uint32_t huffMaxCnt = 0;
+        int huffMax = 0;
+        for (int i = 0; i < 16; i++) {
+            const uint32_t v = W->count[i];
+            if (v == 0) continue;
+            huffMax = i;
+            if (v > huffMaxCnt) huffMaxCnt = v;
+        }
+        const int r = huf_fse_compress_weights(weights, maxSym, huffMax, (int)huffMaxCnt, W, out + 1, outCap - 1);
+        if (r >= 0 && r < (symbolLen >> 1)) {
+            out[0] = (uint8_t)r;
+            return 1 + r;
+        }
+    }
+    if (maxSym > (256 - 128)) return -1;
+    out[0] = (uint8_t)(128 | (maxSym - 1));
+    weights[maxSym] = 0;
+    int p = 1;
+    for (int n = 0; n < maxSym; n += 2) out[p++] = (uint8_t)((weights[n] << 4) | weights[n + 1]);
+    return p;
+}

@@ -1,0 +1,57 @@
+// kc_kernels.h — host-visible parameter blocks and launchers of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kc_dev.h"
+
+// ---- match finders (kc_zstd_match.hip) ----
+struct KcMatchParams {
+    const uint8_t* src;         // device: concatenated units
+    const uint64_t* unit_off;   // device: n_units+1
+    const uint32_t* unit_blk0;  // device: n_units+1, first global block index of each unit
+    uint64_t* seqs;             // device scratch: seq_stride packed sequences per block
+    KcBlkMeta* meta;            // device: one record per block
+    const uint32_t* popmask;    // device or null: per-unit bitmask of blocks whose offsets must be popped (re-run)
+    const uint32_t* unit_list;  // device or null: indirection for re-runs
+    uint32_t seq_stride;
+    int32_t block_size;
+    int32_t max_match_off;
+};
+void kc_launch_zfast_match(const KcMatchParams& P, uint32_t grid, hipStream_t st);
+
+// ---- entropy + emit (kc_zstd_entropy.hip) ----
+struct KcFsePredef;  // opaque device blob built by kc_launch_fse_predef_init
+struct KcEntropyParams {
+    const uint8_t* src;
+    const uint64_t* unit_off;
+    const uint32_t* unit_blk0;
+    const uint64_t* seqs;
+    const KcBlkMeta* meta;
+    uint8_t* lits;          // device scratch: lit_stride bytes per block (gathered literals, later seq bitstream staging)
+    uint64_t* aux;          // device scratch: seq_stride u64 per block (huffman stream staging, then FSE state bits)
+    uint8_t* stage;         // device: per-unit staging area for the encoded frame
+    const uint64_t* stage_off;  // device: n_units+1 offsets into stage (16-byte aligned)
+    uint32_t* out_size;     // device: encoded size per unit
+    const uint64_t* xxh;    // device: XXH64 per unit (only read when crc != 0)
+    uint32_t* redo_mask;    // device: per unit, blocks whose late raw fallback invalidated carried offsets
+    const uint32_t* unit_list;
+    const void* predef;     // device: KcFsePredef
+    uint32_t seq_stride;
+    uint32_t lit_stride;
+    int32_t block_size;
+    int32_t window_size;
+    int32_t crc, single, no_entropy, all_lit_entropy, full_zero;
+    uint32_t dict_id;
+    uint32_t* err_flag;     // device: set non-zero on a device-side invariant violation
+};
+size_t kc_fse_predef_bytes();
+void kc_launch_fse_predef_init(void* d_predef, hipStream_t st);
+void kc_launch_zstd_entropy(const KcEntropyParams& P, uint32_t grid, hipStream_t st);
+
+// ---- misc (kc_misc.hip) ----
+void kc_launch_xxh64(const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out, hipStream_t st);
+// exclusive scan of sizes (u32) into offsets (u64, n+1 entries)
+void kc_launch_scan_sizes(const uint32_t* sizes, uint32_t n, uint64_t* out_off, hipStream_t st);
+// dst[out_off[i] .. ) = stage[stage_off[i] .. +sizes[i])
+void kc_launch_compact(const uint8_t* stage, const uint64_t* stage_off, const uint32_t* sizes, const uint64_t* out_off,
+                       uint8_t* dst, uint32_t n, hipStream_t st);

@@ -1,0 +1,126 @@
+// kc_misc.hip — frame checksum (XXH64), size scan and output compaction kernels.
+#include "kc_dev.h"
+#include "kc_kernels.h"
+
+// ---------------------------------------------------------------------------------------
+// XXH64 (seed 0) per unit — replaces xxhash.Digest.Write/Sum64
+// (zstd/internal/xxhash/xxhash.go:61-156).  The four accumulators of XXH64 are independent
+// 8-byte lanes of a 32-byte stripe, each a serial multiply-rotate chain, so one unit maps to
+// 4 lanes (one per accumulator) and a wave hashes 16 units at a time; the 32-byte stripes of a
+// unit are read as 4 adjacent 8-byte loads.
+// ---------------------------------------------------------------------------------------
+#define XP1 11400714785074694791ULL
+#define XP2 14029467366897019727ULL
+#define XP3 1609587929392839161ULL
+#define XP4 9650029242287828579ULL
+#define XP5 2870177450012600261ULL
+__device__ __forceinline__ uint64_t xrol(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t xround(uint64_t acc, uint64_t input) { return xrol(acc + input * XP2, 31) * XP1; }
+__device__ __forceinline__ uint64_t xmerge(uint64_t acc, uint64_t val) { return (acc ^ xround(0, val)) * XP1 + XP4; }
+
+__global__ __launch_bounds__(256) void kc_xxh64_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ unit_off,
+                                                       uint32_t n_units, uint64_t* __restrict__ out) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t u = gt >> 2;
+    const int a = (int)(gt & 3);
+    const bool active = u < n_units;
+    const uint8_t* p = src;
+    uint64_t len = 0;
+    if (active) { p = src + unit_off[u]; len = unit_off[u + 1] - unit_off[u]; }
+    uint64_t v = a == 0 ? XP1 + XP2 : (a == 1 ? XP2 : (a == 2 ? 0ULL : 0ULL - XP1));
+    const uint64_t stripes = len >> 5;
+    const uint8_t* q = p + 8 * a;
+    for (uint64_t i = 0; i < stripes; i++) v = xround(v, ld64(q + (i << 5)));
+    // combine the 4 accumulators of this unit (4 adjacent lanes)
+    const int lane = (int)(threadIdx.x & 63);
+    const int l0 = lane & ~3;
+    const uint64_t v1 = bcast64(v, l0), v2 = bcast64(v, l0 + 1), v3 = bcast64(v, l0 + 2), v4 = bcast64(v, l0 + 3);
+    if (!active || a != 0) return;
+    uint64_t h;
+    if (len >= 32) {
+        h = xrol(v1, 1) + xrol(v2, 7) + xrol(v3, 12) + xrol(v4, 18);
+        h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+    } else {
+        h = XP5;  // v3 + prime5 with v3 == 0
+    }
+    h += len;
+    const uint8_t* t = p + (stripes << 5);
+    int rem = (int)(len & 31);
+    for (; rem >= 8; t += 8, rem -= 8) { h ^= xround(0, ld64(t)); h = xrol(h, 27) * XP1 + XP4; }
+    if (rem >= 4) { h ^= (uint64_t)ld32(t) * XP1; h = xrol(h, 23) * XP2 + XP3; t += 4; rem -= 4; }
+    for (; rem > 0; t++, rem--) { h ^= (uint64_t)t[0] * XP5; h = xrol(h, 11) * XP1; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    out[u] = h;
+}
+void kc_launch_xxh64(const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out, hipStream_t st) {
+    if (n_units == 0) return;
+    const uint32_t threads = n_units * 4;
+    hipLaunchKernelGGL(kc_xxh64_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, src, unit_off, n_units, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// exclusive scan of per-unit sizes -> output offsets (single workgroup; n is at most a few 1e5)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void kc_scan_sizes_kernel(const uint32_t* __restrict__ sizes, uint32_t n, uint64_t* __restrict__ out_off) {
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        uint64_t v = i < n ? sizes[i] : 0;
+        uint64_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d, 64);
+            uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d, 64);
+            if (lane >= d) inc += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint64_t pre = carry;
+        for (int k = 0; k < w; k++) pre += wsum[k];
+        if (i < n) out_off[i] = pre + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry = pre + inc;
+        __syncthreads();
+    }
+    if (tid == 0) out_off[n] = carry;
+}
+void kc_launch_scan_sizes(const uint32_t* sizes, uint32_t n, uint64_t* out_off, hipStream_t st) {
+    hipLaunchKernelGGL(kc_scan_sizes_kernel, dim3(1), dim3(1024), 0, st, sizes, n, out_off);
+}
+
+// ---------------------------------------------------------------------------------------
+// compaction: variable-size frames from the per-unit staging slots to the contiguous output
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kc_compact_kernel(const uint8_t* __restrict__ stage, const uint64_t* __restrict__ stage_off,
+                                                         const uint32_t* __restrict__ sizes, const uint64_t* __restrict__ out_off,
+                                                         uint8_t* __restrict__ dst, uint32_t n) {
+    const uint32_t u = blockIdx.x;
+    if (u >= n) return;
+    const uint8_t* s = stage + stage_off[u];  // 16-byte aligned
+    uint8_t* d = dst + out_off[u];
+    const uint32_t len = sizes[u];
+    const int tid = threadIdx.x;
+    // align destination to 16 bytes, then 16-byte stores with unaligned source loads
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)d & 15)) & 15);
+    if (head > len) head = len;
+    for (uint32_t i = tid; i < head; i += 256) d[i] = s[i];
+    const uint32_t body = (len - head) >> 4;
+    const uint8_t* sb = s + head;
+    uint4* db = (uint4*)(d + head);
+    for (uint32_t i = tid; i < body; i += 256) {
+        uint4 v;
+        const uint8_t* q = sb + ((size_t)i << 4);
+        v.x = ld32(q); v.y = ld32(q + 4); v.z = ld32(q + 8); v.w = ld32(q + 12);
+        db[i] = v;
+    }
+    for (uint32_t i = head + (body << 4) + tid; i < len; i += 256) d[i] = s[i];
+}
+void kc_launch_compact(const uint8_t* stage, const uint64_t* stage_off, const uint32_t* sizes, const uint64_t* out_off,
+                       uint8_t* dst, uint32_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(kc_compact_kernel, dim3(n), dim3(256), 0, st, stage, stage_off, sizes, out_off, dst, n);
+}

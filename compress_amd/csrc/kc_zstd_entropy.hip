@@ -1,0 +1,872 @@
+// kc_zstd_entropy.hip — per-unit block serialisation for gfx950: literal gather + 256-bin
+// histogram, huff0 table build and 1/4-stream Huffman emit, sequence code histograms,
+// FSE table build / mode choice / NCount headers, the interleaved FSE bitstream, block and
+// frame headers, raw / RLE fallbacks and the frame checksum.
+//
+// Replaces blockEnc.encode / encodeLits / encodeRLE / encodeRawTo (zstd/blockenc.go:310-827),
+// huff0.Compress1X/4X (huff0/compress.go:14-302), frameHeader.appendTo
+// (zstd/frameenc.go:25-92) and the per-frame glue of (*Encoder).encodeAll
+// (zstd/encoder.go:731-839).
+//
+// One 256-thread workgroup per unit; blocks of a unit are processed in order because
+// they share entropy state (huff0 prevTable + Reuse policy, FSE "prev" tables).  Within a
+// block the O(n) passes are data parallel:
+//   * literals are gathered from the source through a tile-wise exclusive scan of the
+//     sequence list (the match finder stores no literal bytes);
+//   * Huffman streams: one wave per stream, per-lane bit counts -> wave scan -> lanes OR
+//     their codes into a zeroed, word-aligned staging area;
+//   * FSE: the three state chains are inherently serial (tANS) and run on three lanes of
+//     three different waves over LDS-resident code chunks; bit packing of state bits and
+//     extra bits is parallel over sequences with a block-wide scan of bit lengths.
+// The O(alphabet) table constructions run on one lane per table out of LDS.
+#include "kc_dev.h"
+#include "kc_kernels.h"
+#include "kc_fse_dev.h"
+#include "kc_huf_dev.h"
+
+#define ET 256            // threads per workgroup
+#define SEQ_CHUNK 2048    // sequences staged in LDS per FSE chain chunk
+#define LONG_RUN 48       // literal runs longer than this are copied cooperatively
+#define LONG_CAP 64
+
+static_assert(sizeof(KcFsePredefBlob) == 3 * sizeof(KcFseT), "blob layout");
+size_t kc_fse_predef_bytes() { return sizeof(KcFsePredefBlob); }
+
+// ---------------------------------------------------------------------------------------
+// predefined encoders (zstd/fse_predefined.go:112-155, encoder half)
+// ---------------------------------------------------------------------------------------
+__global__ void kc_fse_predef_init_kernel(KcFsePredefBlob* B) {
+    __shared__ uint8_t tsym[3][256];
+    __shared__ int16_t cumul[3][66];
+    const int i = threadIdx.x;
+    if (i >= 3) return;
+    const int16_t llNorm[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+    const int16_t ofNorm[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+    const int16_t mlNorm[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+    KcFseT* f = &B->t[i];
+    for (int k = 0; k < 64; k++) { f->norm[k] = 0; f->dnb[k] = 0; f->dfs[k] = 0; f->outBits[k] = 0; }
+    for (int k = 0; k < 256; k++) f->st[k] = 0;
+    if (i == 0) { for (int k = 0; k < 36; k++) f->norm[k] = llNorm[k]; f->symbolLen = 36; f->tableLog = 6; }
+    if (i == 1) { for (int k = 0; k < 29; k++) f->norm[k] = ofNorm[k]; f->symbolLen = 29; f->tableLog = 5; }
+    if (i == 2) { for (int k = 0; k < 53; k++) f->norm[k] = mlNorm[k]; f->symbolLen = 53; f->tableLog = 6; }
+    f->useRLE = 0; f->rleVal = 0; f->reUsed = 0; f->stLen1 = 0;
+    fse_build_core<int16_t>(f->norm, f->symbolLen, f->tableLog, tsym[i], cumul[i], f->st, f->dnb, f->dfs);
+    for (int k = 0; k < (int)f->symbolLen; k++)
+        f->outBits[k] = (uint8_t)(i == 0 ? kc_ll_bits(k) : (i == 1 ? (uint32_t)k : kc_ml_bits(k)));
+    f->preDefined = 1;
+}
+void kc_launch_fse_predef_init(void* d_predef, hipStream_t st) {
+    hipLaunchKernelGGL(kc_fse_predef_init_kernel, dim3(1), dim3(64), 0, st, (KcFsePredefBlob*)d_predef);
+}
+
+// ---------------------------------------------------------------------------------------
+// workgroup primitives
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
+        uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+        if (lane >= d) v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+// Exclusive scan over the 256 threads; *total receives the block sum.  wsum: 4 x u64 LDS scratch.
+__device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t* wsum, uint64_t* total) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t inc = wave_incl_scan64(v, lane);
+    __syncthreads();  // protect wsum reuse
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint64_t base = 0;
+    for (int k = 0; k < w; k++) base += wsum[k];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return base + inc - v;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// shared state
+// ---------------------------------------------------------------------------------------
+struct HufState {  // huff0.Scratch fields that persist across the blocks of a unit
+    KcHufTable prev;   // prevTable
+    int prevLen;       // len(prevTable)
+    uint8_t prevLog;   // prevTableLog
+    int reuse;         // Reuse policy: 0 Allow, 2 None (only these two occur on this path)
+};
+
+struct Shared {
+    // --- literal histogram / huffman build ---
+    uint32_t whist[4][256];
+    uint32_t cnt[256];
+    KcHufNodes nodes;
+    KcHufTable cur;     // freshly built cTable
+    HufState huf;
+    uint8_t weights[256];
+    KcWeightFse wfse;
+    uint8_t tdesc[192];  // serialised Huffman table description
+    // --- sequences ---
+    KcFseT fse[9];       // 0..5: ll/of/ml cur+prev pool, 6..8: predefined LL/OF/ML
+    uint8_t curIdx[3], prevIdx[3];  // pool index per table kind (0 LL, 1 OF, 2 ML)
+    uint8_t useIdx[3];   // encoder chosen for this block
+    uint32_t shist[3][64];
+    uint32_t smax[3];
+    uint8_t tsym[3][256];
+    int16_t cumul[3][66];
+    uint8_t seqhdr[224];
+    int seqhdrLen;
+    uint8_t codes[3][SEQ_CHUNK];     // ll / of / ml code per staged sequence
+    uint16_t sbits[3][SEQ_CHUNK];    // state bits emitted for that sequence: nb<<12 | value
+    uint16_t state[3];               // running FSE states (ll, of, ml)
+    // --- scan / misc ---
+    uint64_t wsum[4];
+    uint32_t wtot[4];
+    uint32_t longList[LONG_CAP][3];
+    uint32_t longCnt;
+    int ivar[24];  // broadcast slots
+};
+
+enum { IV_SYMLEN = 0, IV_MAXCNT, IV_CANREUSE, IV_LITMODE, IV_USEPREV, IV_TABLOG, IV_DESCLEN, IV_DATALEN, IV_LITSEC,
+       IV_OK, IV_SEQBYTES, IV_RAW, IV_TMP0, IV_TMP1 };
+
+// ---------------------------------------------------------------------------------------
+// byte helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_block_header(uint8_t* p, bool last, uint32_t type, uint32_t size) {
+    // blockHeader (zstd/blockenc.go:109-136): last(1) | type(2) | size(21)
+    const uint32_t h = (last ? 1u : 0u) | (type << 1) | (size << 3);
+    p[0] = (uint8_t)h; p[1] = (uint8_t)(h >> 8); p[2] = (uint8_t)(h >> 16);
+}
+// literalsHeader.setSize (blockenc.go:150): raw / RLE literal sections. Returns header size.
+__device__ __forceinline__ int lit_header_size1(int regenLen) {
+    const int inBits = bits_len32((uint32_t)regenLen);
+    return inBits < 5 ? 1 : (inBits < 12 ? 2 : 3);
+}
+__device__ __forceinline__ int put_lit_header1(uint8_t* p, uint32_t type, int regenLen) {
+    const int inBits = bits_len32((uint32_t)regenLen);
+    uint64_t lh = type;
+    int sz;
+    if (inBits < 5) { lh |= ((uint64_t)regenLen << 3); sz = 1; }
+    else if (inBits < 12) { lh |= (1 << 2) | ((uint64_t)regenLen << 4); sz = 2; }
+    else { lh |= (3 << 2) | ((uint64_t)regenLen << 4); sz = 3; }
+    for (int i = 0; i < sz; i++) p[i] = (uint8_t)(lh >> (8 * i));
+    return sz;
+}
+// literalsHeader.setSizes (blockenc.go:178): compressed literal sections.
+__device__ __forceinline__ int lit_header_size2(int compLen, int inLen) {
+    const int compBits = bits_len32((uint32_t)compLen), inBits = bits_len32((uint32_t)inLen);
+    if (compBits <= 10 && inBits <= 10) return 3;
+    if (compBits <= 14 && inBits <= 14) return 4;
+    return 5;
+}
+__device__ __forceinline__ int put_lit_header2(uint8_t* p, uint32_t type, int compLen, int inLen, bool single) {
+    const int compBits = bits_len32((uint32_t)compLen), inBits = bits_len32((uint32_t)inLen);
+    uint64_t lh = type;
+    int sz;
+    if (compBits <= 10 && inBits <= 10) {
+        if (!single) lh |= 1 << 2;
+        lh |= ((uint64_t)inLen << 4) | ((uint64_t)compLen << (10 + 4));
+        sz = 3;
+    } else if (compBits <= 14 && inBits <= 14) {
+        lh |= (2 << 2) | ((uint64_t)inLen << 4) | ((uint64_t)compLen << (14 + 4));
+        sz = 4;
+    } else {
+        lh |= (3 << 2) | ((uint64_t)inLen << 4) | ((uint64_t)compLen << (18 + 4));
+        sz = 5;
+    }
+    for (int i = 0; i < sz; i++) p[i] = (uint8_t)(lh >> (8 * i));
+    return sz;
+}
+
+// cooperative byte copy (global -> global), 256 threads
+__device__ __forceinline__ void wg_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, int n) {
+    const int tid = threadIdx.x;
+    // head to 4-byte dst alignment is not attempted: source alignment is arbitrary; go bytewise in
+    // 4-byte units with unaligned loads and byte-exact tail.
+    const int n4 = n >> 2;
+    if ((((uintptr_t)dst) & 3) == 0) {
+        for (int i = tid; i < n4; i += ET) ((uint32_t*)dst)[i] = ld32(src + 4 * i);
+        for (int i = (n4 << 2) + tid; i < n; i += ET) dst[i] = src[i];
+    } else {
+        for (int i = tid; i < n; i += ET) dst[i] = src[i];
+    }
+}
+
+// OR `nbits` (<= 57) bits of `value` at absolute bit position `bitpos` of a zeroed,
+// 4-byte aligned global buffer.
+__device__ __forceinline__ void or_bits(uint32_t* words, uint64_t bitpos, uint64_t value, int nbits) {
+    if (nbits == 0) return;
+    const uint32_t w = (uint32_t)(bitpos >> 5);
+    const int sh = (int)(bitpos & 31);
+    const uint64_t lo = value << sh;                    // bits for words w, w+1
+    atomicOr(&words[w], (uint32_t)lo);
+    if (sh + nbits > 32) atomicOr(&words[w + 1], (uint32_t)(lo >> 32));
+    if (sh + nbits > 64) atomicOr(&words[w + 2], (uint32_t)(value >> (64 - sh)));
+}
+
+// ---------------------------------------------------------------------------------------
+// Huffman stream emit: one wave per stream.
+// Stream symbols are encoded last-to-first (huff0/compress.go:233-266) followed by the end
+// mark bit; lane l encodes reversed positions [l*chunk, (l+1)*chunk).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t huf_lane_bits(const uint8_t* __restrict__ seg, int segLen, const KcHufTable* T, int lane, int chunk) {
+    uint32_t bits = 0;
+    const int r0 = lane * chunk;
+    int r1 = r0 + chunk;
+    if (r1 > segLen) r1 = segLen;
+    for (int r = r0; r < r1; r++) bits += T->nb[seg[segLen - 1 - r]];
+    return bits;
+}
+__device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, int segLen, const KcHufTable* T, int lane, int chunk,
+                                              uint32_t* words, uint64_t bitpos) {
+    const int r0 = lane * chunk;
+    int r1 = r0 + chunk;
+    if (r1 > segLen) r1 = segLen;
+    uint64_t acc = 0;
+    int nb = 0;
+    for (int r = r0; r < r1; r++) {
+        const uint8_t sym = seg[segLen - 1 - r];
+        acc |= (uint64_t)T->val[sym] << nb;
+        nb += T->nb[sym];
+        if (nb >= 32) {
+            or_bits(words, bitpos, acc & 0xFFFFFFFFull, 32);
+            bitpos += 32;
+            acc >>= 32;
+            nb -= 32;
+        }
+    }
+    if (nb > 0) or_bits(words, bitpos, acc, nb);
+}
+
+// ---------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) {
+    __shared__ Shared S;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : blockIdx.x;
+    const uint8_t* __restrict__ base = P.src + P.unit_off[u];
+    const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]);
+    const uint32_t blk0 = P.unit_blk0[u];
+    const int bs = P.block_size;
+    const int nblk = (ulen + bs - 1) / bs;
+    uint8_t* __restrict__ outp = P.stage + P.stage_off[u];
+    const bool rawAllLits = !P.all_lit_entropy;
+    const bool noEntropy = P.no_entropy != 0;
+
+    // ---- per-unit state init: Reset -> initNewEncode (blockenc.go:77-82) ----
+    {
+        const uint32_t* pb = (const uint32_t*)P.predef;
+        uint32_t* dstp = (uint32_t*)&S.fse[6];
+        for (int i = tid; i < (int)(sizeof(KcFsePredefBlob) / 4); i += ET) dstp[i] = pb[i];
+        if (tid < 6) {
+            KcFseT* f = &S.fse[tid];
+            f->symbolLen = 0; f->tableLog = 0; f->useRLE = 0; f->rleVal = 0; f->reUsed = 0; f->preDefined = 0; f->stLen1 = 0;
+        }
+        if (tid == 0) {
+            for (int k = 0; k < 3; k++) { S.curIdx[k] = (uint8_t)(2 * k); S.prevIdx[k] = (uint8_t)(2 * k + 1); }
+            S.huf.prevLen = 0;
+            S.huf.prevLog = 0;
+            S.huf.reuse = 2;  // ReusePolicyNone
+        }
+    }
+    int opos = 0;  // bytes written to the staging area (wave-uniform, tracked by every thread)
+    // ---- frame header (frameenc.go:25-92; encoder.go:756-772) ----
+    if (ulen > 0) {
+        bool single = ulen <= P.window_size && ulen > 1024;
+        if (P.single >= 0) single = P.single != 0;
+        // fastBase.WindowSize (enc_base.go:42)
+        uint32_t windowSize = (uint32_t)P.window_size;
+        if (ulen < P.window_size) {
+            uint32_t bsz = 1u << bits_len32((uint32_t)ulen);
+            windowSize = bsz < 1024u ? 1024u : bsz;
+        }
+        uint8_t hdr[16];
+        int h = 0;
+        hdr[h++] = 0x28; hdr[h++] = 0xb5; hdr[h++] = 0x2f; hdr[h++] = 0xfd;
+        uint8_t fhd = 0;
+        if (P.crc) fhd |= 1 << 2;
+        if (single) fhd |= 1 << 5;
+        const uint32_t did = P.dict_id;
+        int didLen = 0;
+        if (did > 0) { if (did < 256) { fhd |= 1; didLen = 1; } else if (did < (1u << 16)) { fhd |= 2; didLen = 2; } else { fhd |= 3; didLen = 4; } }
+        uint8_t fcs = 0;
+        if (ulen >= 256) fcs++;
+        if (ulen >= 65536 + 256) fcs++;
+        fhd |= (uint8_t)(fcs << 6);
+        hdr[h++] = fhd;
+        if (!single) hdr[h++] = (uint8_t)((bits_len32(windowSize - 1) - 10) << 3);
+        for (int i = 0; i < didLen; i++) hdr[h++] = (uint8_t)(did >> (8 * i));
+        if (fcs == 0) { if (single) hdr[h++] = (uint8_t)ulen; }
+        else if (fcs == 1) { const uint32_t c = (uint32_t)ulen - 256; hdr[h++] = (uint8_t)c; hdr[h++] = (uint8_t)(c >> 8); }
+        else { for (int i = 0; i < 4; i++) hdr[h++] = (uint8_t)((uint32_t)ulen >> (8 * i)); }
+        if (tid == 0) for (int i = 0; i < h; i++) outp[i] = hdr[i];
+        opos = h;
+    }
+    __syncthreads();
+    if (ulen == 0) {
+        // zero-length input: optional 9-byte frame (encoder.go:732-752, App. A-18)
+        if (tid == 0) {
+            if (P.full_zero) {
+                const uint8_t z[9] = {0x28, 0xb5, 0x2f, 0xfd, 0x20, 0x00, 0x01, 0x00, 0x00};
+                for (int i = 0; i < 9; i++) outp[i] = z[i];
+                P.out_size[u] = 9;
+            } else {
+                P.out_size[u] = 0;
+            }
+        }
+        return;
+    }
+
+    for (int b = 0; b < nblk; b++) {
+        const KcBlkMeta m = P.meta[blk0 + (uint32_t)b];
+        const int blkStart = b * bs;
+        const int blkEnd = (blkStart + bs < ulen) ? blkStart + bs : ulen;
+        const int size = blkEnd - blkStart;
+        const bool last = b == nblk - 1;
+        const uint8_t* __restrict__ org = base + blkStart;
+        const uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
+        uint8_t* __restrict__ lits = P.lits + (size_t)(blk0 + (uint32_t)b) * P.lit_stride;
+        uint32_t* __restrict__ auxw = (uint32_t*)(P.aux + (size_t)(blk0 + (uint32_t)b) * P.seq_stride);
+        const int nseq = (int)m.nseq;
+        const int nlit = (int)m.nlit;
+        uint8_t* bout = outp + opos;  // block header goes here
+
+        // ---------- literals-only / RLE / incompressible verdicts (blockenc.go:482-503) ----------
+        bool rawBlock = false;
+        if (nseq == 0) {
+            // encodeLits(b.literals, rawAllLits): with no sequences the literals are the whole block.
+            // TODO(all_lit_entropy): huff0 path of encodeLits for SpeedBetterCompression.
+            rawBlock = true;
+        } else {
+            const uint64_t s0 = sq[0];
+            if (nseq == 1 && nlit <= 1 && (int)seq_ll(s0) == nlit && seq_of(s0) - 3u == 1u) {
+                // encodeRLE(org[0], matchLen + zstdMinMatch + litLen) (blockenc.go:485-493)
+                if (tid == 0) {
+                    put_block_header(bout, last, 1u, seq_ml(s0) + 3u + seq_ll(s0));
+                    bout[3] = org[0];
+                }
+                opos += 4;
+                __syncthreads();
+                continue;
+            }
+            if (m.flags & KC_BF_POP_A) rawBlock = true;  // saved < 16: popOffsets + encodeLits(org, rawAllLits)
+        }
+        if (rawBlock) {
+            if (!rawAllLits && tid == 0) atomicExch(P.err_flag, 100u);  // unsupported combination reached the device
+            if (tid == 0) put_block_header(bout, last, 0u, (uint32_t)size);
+            wg_copy(bout + 3, org, size);
+            opos += 3 + size;
+            __syncthreads();
+            continue;
+        }
+
+        // ==================== compressed block attempt ====================
+        // ---------- 1. gather literals + histogram ----------
+        for (int i = tid; i < 4 * 256; i += ET) ((uint32_t*)S.whist)[i] = 0;
+        if (tid == 0) S.longCnt = 0;
+        __syncthreads();
+        {
+            uint64_t run = 0;  // lo32: literal bytes so far, hi32: source bytes so far
+            for (int t0 = 0; t0 < nseq; t0 += ET) {
+                const int i = t0 + tid;
+                uint32_t ll = 0, adv = 0;
+                if (i < nseq) { const uint64_t s = sq[i]; ll = seq_ll(s); adv = ll + seq_ml(s) + 3u; }
+                uint64_t tot;
+                const uint64_t ex = block_excl_scan64((uint64_t)ll | ((uint64_t)adv << 32), S.wsum, &tot) + run;
+                const uint32_t lo = (uint32_t)ex, sp = (uint32_t)(ex >> 32);
+                if (ll > LONG_RUN) {
+                    const uint32_t slot = atomicAdd(&S.longCnt, 1u);
+                    if (slot < LONG_CAP) { S.longList[slot][0] = (uint32_t)blkStart + sp; S.longList[slot][1] = lo; S.longList[slot][2] = ll; ll = 0; }
+                }
+                const uint8_t* sp8 = base + blkStart + sp;
+                for (uint32_t k = 0; k < ll; k++) {
+                    const uint8_t c = sp8[k];
+                    lits[lo + k] = c;
+                    atomicAdd(&S.whist[wv][c], 1u);
+                }
+                run += tot;
+            }
+            __syncthreads();
+            // deferred long runs + trailing literals, cooperatively
+            const int nl = (int)(S.longCnt < LONG_CAP ? S.longCnt : LONG_CAP);
+            for (int e = 0; e <= nl; e++) {
+                uint32_t spos, lo, len;
+                if (e < nl) { spos = S.longList[e][0]; lo = S.longList[e][1]; len = S.longList[e][2]; }
+                else { len = m.extra_lits; spos = (uint32_t)blkEnd - len; lo = (uint32_t)nlit - len; }
+                for (uint32_t k = tid; k < len; k += ET) {
+                    const uint8_t c = base[spos + k];
+                    lits[lo + k] = c;
+                    atomicAdd(&S.whist[wv][c], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            // reduce histogram (huff0 countSimple, compress.go:351): maxCount, symbolLen
+            const uint32_t c = S.whist[0][tid] + S.whist[1][tid] + S.whist[2][tid] + S.whist[3][tid];
+            S.cnt[tid] = c;
+            const uint32_t wm = wave_reduce_max(c);
+            const uint32_t wl = wave_reduce_max(c ? (uint32_t)tid + 1u : 0u);
+            if (lane == 0) { S.wtot[wv] = wm; S.wsum[wv] = wl; }
+        }
+        __syncthreads();  // also makes the gathered literals visible workgroup-wide
+
+        // ---------- 2. huff0.compress decisions (compress.go:43-163) ----------
+        const bool wantHuf = !noEntropy && nlit > 16;
+        const bool four = nlit >= 1024;
+        // litMode: 0 raw literals, 1 RLE literals, 2 compressed (new table), 3 compressed (reused table)
+        if (tid == 0) {
+            int litMode = 0;
+            uint32_t maxCount = 0, symbolLen = 0;
+            for (int k = 0; k < 4; k++) { if (S.wtot[k] > maxCount) maxCount = S.wtot[k]; if ((uint32_t)S.wsum[k] > symbolLen) symbolLen = (uint32_t)S.wsum[k]; }
+            S.ivar[IV_SYMLEN] = (int)symbolLen;
+            S.ivar[IV_MAXCNT] = (int)maxCount;
+            S.ivar[IV_OK] = 0;
+            if (wantHuf) {
+                if (S.huf.reuse == 2) S.huf.prevLen = 0;  // ReusePolicyNone nukes prevTable (compress.go:45)
+                if ((int)maxCount >= nlit) litMode = (nlit == 1) ? 0 : 1;              // single symbol -> RLE
+                else if (maxCount == 1 || (int)maxCount < (nlit >> 7)) litMode = 0;    // ErrIncompressible
+                else S.ivar[IV_OK] = 1;                                              // go on and build a table
+            }
+            S.ivar[IV_LITMODE] = litMode;
+        }
+        __syncthreads();
+        int litSecLen = 0;  // bytes of the literals section (header included), wave-uniform
+        bool single = false;
+        if (S.ivar[IV_OK]) {
+            const int symbolLen = S.ivar[IV_SYMLEN];
+            // canReuse (countSimple): every present symbol has a code in prevTable
+            {
+                bool bad = false;
+                if (S.huf.prevLen > 0) { if (S.cnt[tid] != 0 && (tid >= S.huf.prevLen || S.huf.prev.nb[tid] == 0)) bad = true; }
+                else bad = true;
+                const int anyBad = __syncthreads_or(bad ? 1 : 0);
+                if (tid == 0) S.ivar[IV_CANREUSE] = anyBad ? 0 : 1;
+            }
+            // huffSort as a parallel rank: stable by (count desc, symbol asc)
+            if (tid < symbolLen) {
+                const uint32_t c = S.cnt[tid];
+                int rank = 0;
+                for (int j = 0; j < symbolLen; j++) {
+                    const uint32_t cj = S.cnt[j];
+                    rank += (cj > c || (cj == c && j < tid)) ? 1 : 0;
+                }
+                S.nodes.count[rank + 1] = c;
+                S.nodes.symbol[rank + 1] = (uint8_t)tid;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const uint8_t tl = huf_build_serial(&S.nodes, &S.cur, symbolLen, nlit);
+                if (tl == 0xFF) atomicExch(P.err_flag, 1u);
+                S.ivar[IV_TABLOG] = tl;
+            }
+            __syncthreads();
+            // estimateSize for old/new tables (huff0.go:308) — block reduction of nBits*count
+            {
+                const uint32_t c = tid < symbolLen ? S.cnt[tid] : 0u;
+                const uint32_t nn = wave_reduce_sum(c * (uint32_t)(tid < symbolLen ? S.cur.nb[tid] : 0));
+                const uint32_t no = wave_reduce_sum(c * (uint32_t)((tid < symbolLen && tid < S.huf.prevLen) ? S.huf.prev.nb[tid] : 0));
+                if (lane == 0) { S.wtot[wv] = nn; S.wsum[wv] = no; }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t newBits = 7 + S.wtot[0] + S.wtot[1] + S.wtot[2] + S.wtot[3];
+                const uint32_t oldBits = 7 + (uint32_t)(S.wsum[0] + S.wsum[1] + S.wsum[2] + S.wsum[3]);
+                const int newSize = (int)(newBits >> 3), oldSize = (int)(oldBits >> 3);
+                int wantSize = nlit - (nlit >> 4);  // WantLogLess = 4 (blockenc.go:72)
+                int usePrev = 0;
+                // ReusePolicyAllow && canReuse: hSize == len(s.Out) == 0 at this point (App. A-12)
+                if (S.huf.reuse == 0 && S.ivar[IV_CANREUSE]) {
+                    if (oldSize <= 0 + newSize || 0 + 12 >= wantSize) usePrev = 1;
+                }
+                S.ivar[IV_USEPREV] = usePrev;
+                int descLen = 0;
+                if (!usePrev) {
+                    descLen = huf_write_table(&S.cur, symbolLen, (uint8_t)S.ivar[IV_TABLOG], S.weights, &S.wfse, S.tdesc, (int)sizeof(S.tdesc));
+                }
+                S.ivar[IV_DESCLEN] = descLen;  // -1: cTable.write failed (ErrIncompressible)
+            }
+            __syncthreads();
+            const bool usePrev = S.ivar[IV_USEPREV] != 0;
+            const KcHufTable* T = usePrev ? &S.huf.prev : &S.cur;
+            const int descLen = S.ivar[IV_DESCLEN];
+            // ---- size pass: exact stream sizes with table T ----
+            const int nstreams = four ? 4 : 1;
+            const int segSize = four ? (nlit + 3) / 4 : nlit;
+            int segStart = 0, segLen = 0, chunk = 1;
+            uint32_t laneBits = 0, laneOff = 0, streamBits = 0;
+            if (wv < nstreams && descLen >= 0) {
+                segStart = wv * segSize;
+                segLen = nlit - segStart;
+                if (segLen > segSize) segLen = segSize;
+                if (segLen < 0) segLen = 0;
+                chunk = (segLen + 63) / 64;
+                if (chunk < 1) chunk = 1;
+                laneBits = huf_lane_bits(lits + segStart, segLen, T, lane, chunk);
+                const uint32_t inc = wave_incl_scan(laneBits, lane);
+                laneOff = inc - laneBits;
+                streamBits = (uint32_t)__shfl((int)inc, 63, 64);
+            }
+            if (lane == 0) S.wtot[wv] = (wv < nstreams) ? ((streamBits + 1 + 7) >> 3) : 0u;  // + end mark, byte aligned
+            __syncthreads();
+            if (tid == 0) {
+                int litMode = 0;
+                int wantSize = nlit - (nlit >> 4);
+                int dataLen = (int)(S.wtot[0] + S.wtot[1] + S.wtot[2] + S.wtot[3]) + (four ? 6 : 0);
+                bool ok = descLen >= 0;
+                if (ok && four) for (int k = 0; k < 4; k++) if (S.wtot[k] > 65535u) ok = false;  // jump table limit (compress.go:288)
+                int outLen = dataLen + (usePrev ? 0 : descLen);
+                if (ok && outLen >= wantSize) ok = false;
+                if (ok && !usePrev) {
+                    // Move current table into previous (compress.go:160): happens before blockenc's own checks.
+                    for (int k = 0; k < symbolLen; k++) { S.huf.prev.val[k] = S.cur.val[k]; S.huf.prev.nb[k] = S.cur.nb[k]; }
+                    S.huf.prevLen = symbolLen;
+                    S.huf.prevLog = (uint8_t)S.ivar[IV_TABLOG];
+                }
+                if (ok && outLen + 5 > nlit) {
+                    // close call: compare with raw including header sizes (blockenc.go:534-544)
+                    const int szRaw = lit_header_size1(nlit);
+                    const int szComp = lit_header_size2(outLen, nlit);
+                    if (outLen + szComp >= nlit + szRaw) ok = false;
+                }
+                if (ok) {
+                    litMode = usePrev ? 3 : 2;
+                    S.huf.reuse = 0;  // b.litEnc.Reuse = ReusePolicyAllow (blockenc.go:588)
+                }
+                S.ivar[IV_LITMODE] = litMode;
+                S.ivar[IV_DATALEN] = outLen;
+            }
+            __syncthreads();
+            const int litMode = S.ivar[IV_LITMODE];
+            if (litMode >= 2) {
+                single = !four;
+                const int outLen = S.ivar[IV_DATALEN];
+                const int hsz = lit_header_size2(outLen, nlit);
+                // stream byte offsets inside the section payload
+                const int tabLen = usePrev ? 0 : descLen;
+                const uint32_t sb0 = S.wtot[0], sb1 = S.wtot[1], sb2 = S.wtot[2];
+                uint32_t myByteOff = (uint32_t)(tabLen + (four ? 6 : 0));
+                if (wv >= 1) myByteOff += sb0;
+                if (wv >= 2) myByteOff += sb1;
+                if (wv >= 3) myByteOff += sb2;
+                // Emit streams into the zeroed, word-aligned staging area (aux scratch), each stream
+                // at its final byte offset relative to the payload start.
+                const int payloadWords = (outLen + 3 + 4) >> 2;
+                for (int i = tid; i < payloadWords; i += ET) auxw[i] = 0;
+                __syncthreads();
+                if (wv < nstreams) {
+                    const uint64_t bitBase = (uint64_t)myByteOff * 8 + laneOff;
+                    huf_lane_emit(lits + segStart, segLen, T, lane, chunk, auxw, bitBase);
+                    if (lane == 63) or_bits(auxw, (uint64_t)myByteOff * 8 + streamBits, 1, 1);  // end mark
+                }
+                __syncthreads();
+                // copy payload to its final place and write the byte-granular headers
+                uint8_t* lsec = bout + 3;
+                wg_copy(lsec + hsz + tabLen + (four ? 6 : 0), (const uint8_t*)auxw + tabLen + (four ? 6 : 0), outLen - tabLen - (four ? 6 : 0));
+                if (tid == 0) {
+                    put_lit_header2(lsec, litMode == 3 ? 3u : 2u, outLen, nlit, single);
+                    for (int k = 0; k < tabLen; k++) lsec[hsz + k] = S.tdesc[k];
+                    if (four) {
+                        uint8_t* jt = lsec + hsz + tabLen;
+                        jt[0] = (uint8_t)sb0; jt[1] = (uint8_t)(sb0 >> 8);
+                        jt[2] = (uint8_t)sb1; jt[3] = (uint8_t)(sb1 >> 8);
+                        jt[4] = (uint8_t)sb2; jt[5] = (uint8_t)(sb2 >> 8);
+                    }
+                }
+                litSecLen = hsz + outLen;
+            }
+        }
+        {
+            const int litMode = S.ivar[IV_LITMODE];
+            if (litMode == 0) {  // raw literals (blockenc.go:546-552)
+                const int hsz = lit_header_size1(nlit);
+                if (tid == 0) put_lit_header1(bout + 3, 0u, nlit);
+                wg_copy(bout + 3 + hsz, lits, nlit);
+                litSecLen = hsz + nlit;
+            } else if (litMode == 1) {  // RLE literals (blockenc.go:553-560)
+                const int hsz = lit_header_size1(nlit);
+                if (tid == 0) { put_lit_header1(bout + 3, 1u, nlit); bout[3 + hsz] = lits[0]; }
+                litSecLen = hsz + 1;
+            }
+        }
+        __syncthreads();
+
+        // ---------- 3. sequence codes + histograms (genCodes, blockenc.go:831-893) ----------
+        for (int i = tid; i < 3 * 64; i += ET) ((uint32_t*)S.shist)[i] = 0;
+        if (tid < 3) S.smax[tid] = 0;
+        __syncthreads();
+        {
+            uint32_t mll = 0, mof = 0, mml = 0;
+            for (int i = tid; i < nseq; i += ET) {
+                const uint64_t s = sq[i];
+                const uint32_t cl = kc_ll_code(seq_ll(s)), co = kc_of_code(seq_of(s)), cm = kc_ml_code(seq_ml(s));
+                atomicAdd(&S.shist[0][cl], 1u);
+                atomicAdd(&S.shist[1][co], 1u);
+                atomicAdd(&S.shist[2][cm], 1u);
+                mll = cl > mll ? cl : mll;
+                mof = co > mof ? co : mof;
+                mml = cm > mml ? cm : mml;
+            }
+            mll = wave_reduce_max(mll); mof = wave_reduce_max(mof); mml = wave_reduce_max(mml);
+            if (lane == 0) { atomicMax(&S.smax[0], mll); atomicMax(&S.smax[1], mof); atomicMax(&S.smax[2], mml); }
+        }
+        __syncthreads();
+        // ---------- 4. normalizeCount + buildCTable for the three "cur" encoders (one lane each) ----------
+        if (lane == 0 && wv < 3) {
+            const int k = wv;
+            KcFseT* f = &S.fse[S.curIdx[k]];
+            const int maxSym = (int)S.smax[k];
+            uint32_t maxCount = 0;
+            for (int i = 0; i <= maxSym; i++) if (S.shist[k][i] > maxCount) maxCount = S.shist[k][i];
+            f->symbolLen = (uint16_t)(maxSym + 1);  // HistogramFinished
+            if (!f->reUsed) {  // normalizeCount returns early for reused encoders (fse_encoder.go:260)
+                f->tableLog = fse_optimal_table_log(nseq, f->symbolLen);
+                f->stLen1 = 0;
+                if ((int)maxCount == nseq) {
+                    f->useRLE = 1;
+                } else {
+                    f->useRLE = 0;
+                    bool ok = fse_normalize_core(S.shist[k], f->norm, f->symbolLen, nseq, f->tableLog);
+                    ok = ok && fse_build_core<int16_t>(f->norm, f->symbolLen, f->tableLog, S.tsym[k], S.cumul[k], f->st, f->dnb, f->dfs);
+                    if (!ok) atomicExch(P.err_flag, 2u);
+                }
+            }
+        }
+        __syncthreads();
+        // ---------- 5. mode choice, mode byte, NCount headers (blockenc.go:633-722) ----------
+        if (tid == 0) {
+            uint8_t* h = S.seqhdr;
+            int hp = 0;
+            if (nseq < 128) h[hp++] = (uint8_t)nseq;
+            else if (nseq < 0x7f00) { h[hp++] = (uint8_t)(128 + (uint8_t)(nseq >> 8)); h[hp++] = (uint8_t)nseq; }
+            else { const int n = nseq - 0x7f00; h[hp++] = 255; h[hp++] = (uint8_t)n; h[hp++] = (uint8_t)(n >> 8); }
+            uint8_t mode = 0;
+            const uint32_t firstCodes[3] = {kc_ll_code(seq_ll(sq[0])), kc_of_code(seq_of(sq[0])), kc_ml_code(seq_ml(sq[0]))};
+            const int shifts[3] = {6, 4, 2};
+            for (int k = 0; k < 3; k++) {
+                KcFseT* cur = &S.fse[S.curIdx[k]];
+                int use = S.curIdx[k];
+                uint32_t mk;
+                if (cur->useRLE) {
+                    mk = 1;  // compModeRLE; setRLE (fse_encoder.go:208)
+                    const uint32_t v = firstCodes[k];
+                    cur->tableLog = 0;
+                    cur->stLen1 = 1;
+                    cur->dfs[v] = 0; cur->dnb[v] = 0; cur->outBits[v] = 0;
+                    cur->st[0] = 0;  // cState.init pins state 0 for a 1-entry table (fse_encoder.go:685-690)
+                    cur->rleVal = (uint8_t)v;
+                } else {
+                    const KcFseT* prev = &S.fse[S.prevIdx[k]];
+                    const KcFseT* pre = &S.fse[6 + k];
+                    const uint32_t* hist = S.shist[k];
+                    const int histLen = cur->symbolLen;
+                    uint32_t nSize = fse_approx_size(cur, hist, histLen) + fse_max_header_size(cur);
+                    const uint32_t predefSize = fse_approx_size(pre, hist, histLen);
+                    const uint32_t prevSize = fse_approx_size(prev, hist, histLen);
+                    nSize = nSize + ((nSize + 2 * 8 * 16) >> 4);
+                    if (predefSize <= prevSize && predefSize <= nSize) { mk = 0; use = 6 + k; }
+                    else if (prevSize <= nSize) { mk = 3; use = S.prevIdx[k]; }
+                    else mk = 2;
+                }
+                S.useIdx[k] = (uint8_t)use;
+                mode |= (uint8_t)(mk << shifts[k]);
+            }
+            h[hp++] = mode;
+            for (int k = 0; k < 3; k++) {  // writeCount order: LL, OF, ML
+                const KcFseT* f = &S.fse[S.useIdx[k]];
+                if (f->useRLE) { h[hp++] = f->rleVal; continue; }
+                if (f->preDefined || f->reUsed) continue;
+                const int n = fse_write_ncount(f->norm, f->symbolLen, f->tableLog, h + hp);
+                if (n < 0) atomicExch(P.err_flag, 3u); else hp += n;
+            }
+            S.seqhdrLen = hp;
+            // setBits (fse_encoder.go:225): extra-bit counts per code for encoders built this block
+            for (int k = 0; k < 3; k++) {
+                KcFseT* f = &S.fse[S.useIdx[k]];
+                if (f->reUsed || f->preDefined) continue;
+                if (f->useRLE) {
+                    const uint32_t v = f->rleVal;
+                    f->outBits[v] = (uint8_t)(k == 0 ? kc_ll_bits(v) : (k == 1 ? v : kc_ml_bits(v)));
+                } else {
+                    for (int i = 0; i < (int)f->symbolLen; i++)
+                        f->outBits[i] = (uint8_t)(k == 0 ? kc_ll_bits(i) : (k == 1 ? (uint32_t)i : kc_ml_bits(i)));
+                }
+            }
+        }
+        __syncthreads();
+        const KcFseT* E[3] = {&S.fse[S.useIdx[0]], &S.fse[S.useIdx[1]], &S.fse[S.useIdx[2]]};
+        const int seqhdrLen = S.seqhdrLen;
+        // ---------- 6. FSE state chains + bit packing, chunk by chunk from the last sequence ----------
+        // Stream element order (blockenc.go:725-807): element 0 = last sequence (extra bits only, states
+        // initialised), elements 1..n-1 = sequences n-2..0 (OF, ML, LL state bits then extra bits with LL
+        // lowest), element n = final states ML, OF, LL + end mark.
+        const int seqBudgetBytes = size - litSecLen - seqhdrLen;  // stream must be smaller than this to beat raw
+        uint32_t* __restrict__ sw = (uint32_t*)lits;               // literals are consumed: reuse as bit staging
+        uint64_t bitRun = 0;
+        bool overflow = seqBudgetBytes <= 0;
+        // zero the staging words the stream may touch, up front (bounded by the raw-size budget)
+        if (!overflow) {
+            const int zw = (seqBudgetBytes + 3 + 16) >> 2;
+            __syncthreads();
+            for (int i = tid; i < zw; i += ET) sw[i] = 0;
+        }
+        __syncthreads();
+        for (int hiSeq = nseq; hiSeq > 0 && !overflow; hiSeq -= SEQ_CHUNK) {
+            const int loSeq = hiSeq - SEQ_CHUNK > 0 ? hiSeq - SEQ_CHUNK : 0;
+            const int cn = hiSeq - loSeq;
+            // stage codes of sequences [loSeq, hiSeq), stored in stream order: slot j <-> seq hiSeq-1-j
+            for (int j = tid; j < cn; j += ET) {
+                const uint64_t s = sq[hiSeq - 1 - j];
+                S.codes[0][j] = (uint8_t)kc_ll_code(seq_ll(s));
+                S.codes[1][j] = (uint8_t)kc_of_code(seq_of(s));
+                S.codes[2][j] = (uint8_t)kc_ml_code(seq_ml(s));
+            }
+            __syncthreads();
+            if (lane == 0 && wv < 3) {
+                const int k = wv;
+                const KcFseT* f = E[k];
+                uint16_t st = S.state[k];
+                int j = 0;
+                if (hiSeq == nseq) {  // very first stream element: cState.init
+                    st = fse_init_state(f, S.codes[k][0]);
+                    S.sbits[k][0] = 0;
+                    j = 1;
+                }
+                for (; j < cn; j++) {
+                    const uint32_t c = S.codes[k][j];
+                    const uint32_t nbBitsOut = ((uint32_t)st + f->dnb[c]) >> 16;
+                    const int32_t dstState = (int32_t)(st >> (nbBitsOut & 15)) + (int32_t)f->dfs[c];
+                    S.sbits[k][j] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
+                    st = f->st[dstState];
+                }
+                S.state[k] = st;
+            }
+            __syncthreads();
+            // pack this chunk
+            for (int t0 = 0; t0 < cn; t0 += ET) {
+                const int j = t0 + tid;
+                uint64_t fv0 = 0, fv1 = 0;  // up to 27 state bits, then up to 63 extra bits
+                int fb0 = 0, fb1 = 0;
+                if (j < cn) {
+                    const uint64_t s = sq[hiSeq - 1 - j];
+                    const uint32_t cl = S.codes[0][j], co = S.codes[1][j], cm = S.codes[2][j];
+                    const int lb = E[0]->outBits[cl] & 31, ob = E[1]->outBits[co] & 31, mb = E[2]->outBits[cm] & 31;
+                    const uint32_t ll = seq_ll(s), ml = seq_ml(s), of = seq_of(s);
+                    const uint64_t lv = ll & (lb ? (0xFFFFFFFFu >> (32 - lb)) : 0u);
+                    const uint64_t mv = ml & (mb ? (0xFFFFFFFFu >> (32 - mb)) : 0u);
+                    const uint64_t ov = of & (ob ? (0xFFFFFFFFu >> (32 - ob)) : 0u);
+                    // state bits: OF, ML, LL (blockenc.go:757-787)
+                    const uint32_t so = S.sbits[1][j], sm = S.sbits[2][j], sl = S.sbits[0][j];
+                    fv0 = (uint64_t)(so & 0xFFF); fb0 = (int)(so >> 12);
+                    fv0 |= (uint64_t)(sm & 0xFFF) << fb0; fb0 += (int)(sm >> 12);
+                    fv0 |= (uint64_t)(sl & 0xFFF) << fb0; fb0 += (int)(sl >> 12);
+                    // extra bits: LL lowest, then ML, then OF (first element: LL, ML, OF — same order)
+                    fv1 = lv | (mv << lb) | (ov << (lb + mb));
+                    fb1 = lb + mb + ob;
+                }
+                uint64_t tot;
+                const uint64_t ex = block_excl_scan64((uint64_t)(fb0 + fb1), S.wsum, &tot) + bitRun;
+                if ((int64_t)((bitRun + tot + 7) >> 3) >= (int64_t)seqBudgetBytes) { overflow = true; break; }
+                if (j < cn) {
+                    or_bits(sw, ex, fv0, fb0);
+                    if (fb1 <= 32) or_bits(sw, ex + fb0, fv1, fb1);
+                    else { or_bits(sw, ex + fb0, fv1 & 0xFFFFFFFFull, 32); or_bits(sw, ex + fb0 + 32, fv1 >> 32, fb1 - 32); }
+                }
+                bitRun += tot;
+            }
+            __syncthreads();
+        }
+        int seqStreamBytes = 0;
+        if (!overflow) {
+            // final states: ml.flush, of.flush, ll.flush, end mark (blockenc.go:804-807)
+            const int tb = (int)E[2]->tableLog + (int)E[1]->tableLog + (int)E[0]->tableLog + 1;
+            if ((int64_t)((bitRun + tb + 7) >> 3) >= (int64_t)seqBudgetBytes) overflow = true;
+            else {
+                if (tid == 0) {
+                    uint64_t bp = bitRun;
+                    const int mlL = E[2]->tableLog, ofL = E[1]->tableLog, llL = E[0]->tableLog;
+                    or_bits(sw, bp, (uint64_t)(S.state[2] & ((1u << mlL) - 1u)), mlL); bp += mlL;
+                    or_bits(sw, bp, (uint64_t)(S.state[1] & ((1u << ofL) - 1u)), ofL); bp += ofL;
+                    or_bits(sw, bp, (uint64_t)(S.state[0] & ((1u << llL) - 1u)), llL); bp += llL;
+                    or_bits(sw, bp, 1, 1);
+                }
+                seqStreamBytes = (int)((bitRun + tb + 7) >> 3);
+            }
+        }
+        __syncthreads();
+        const int bodyLen = litSecLen + seqhdrLen + seqStreamBytes;
+        if (overflow || bodyLen >= size) {
+            // ---------- raw fallback (blockenc.go:811-817) ----------
+            __syncthreads();
+            if (tid == 0) {
+                put_block_header(bout, last, 0u, (uint32_t)size);
+                S.huf.reuse = 2;  // litEnc.Reuse = ReusePolicyNone
+                if (!last) {
+                    if (!(m.flags & KC_BF_FORCED) && (m.o1_out != m.o1_in || m.o2_out != m.o2_in)) atomicOr(&P.redo_mask[u], 1u << b);
+                }
+            }
+            wg_copy(bout + 3, org, size);
+            opos += 3 + size;
+            __syncthreads();
+            continue;
+        }
+        if ((m.flags & KC_BF_FORCED) && tid == 0) atomicExch(P.err_flag, 4u);  // host forced a pop that did not recur
+        // ---------- assemble: sequence header bytes + stream, patch block header, setPrev ----------
+        wg_copy(bout + 3 + litSecLen + seqhdrLen, (const uint8_t*)sw, seqStreamBytes);
+        if (tid == 0) {
+            uint8_t* p = bout + 3 + litSecLen;
+            for (int k = 0; k < seqhdrLen; k++) p[k] = S.seqhdr[k];
+            put_block_header(bout, last, 2u, (uint32_t)bodyLen);
+            // seqCoders.setPrev(ll, ml, of) (seqenc.go:21-42)
+            for (int k = 0; k < 3; k++) {
+                const int used = S.useIdx[k];
+                if (used == S.curIdx[k]) {
+                    const uint8_t t = S.prevIdx[k]; S.prevIdx[k] = S.curIdx[k]; S.curIdx[k] = t;
+                    S.fse[S.curIdx[k]].reUsed = 0;
+                    S.fse[S.prevIdx[k]].reUsed = 1;
+                } else if (used != S.prevIdx[k]) {
+                    S.fse[S.prevIdx[k]].symbolLen = 0;  // ensure we cannot reuse by accident
+                }
+            }
+        }
+        opos += 3 + bodyLen;
+        __syncthreads();
+    }
+
+    // ---- zero-length input (encoder.go:732-753) is handled on the host; checksum (enc_base.go:34-38) ----
+    if (ulen > 0 && P.crc) {
+        if (tid == 0) {
+            const uint64_t h = P.xxh[u];
+            outp[opos] = (uint8_t)h; outp[opos + 1] = (uint8_t)(h >> 8); outp[opos + 2] = (uint8_t)(h >> 16); outp[opos + 3] = (uint8_t)(h >> 24);
+        }
+        opos += 4;
+    }
+    if (tid == 0) P.out_size[u] = (uint32_t)opos;
+}
+
+void kc_launch_zstd_entropy(const KcEntropyParams& P, uint32_t grid, hipStream_t st) {
+    hipLaunchKernelGGL(kc_zstd_entropy_kernel, dim3(grid), dim3(ET), 0, st, P);
+}

@@ -1,0 +1,179 @@
+"""Host mirror of the reference's zstd encoder API for the EncodeAll hot path.
+
+Names, argument meaning and error behaviour follow zstd/encoder.go and
+zstd/encoder_options.go; the bytes come from the HIP engine behind include/kcgpu.h.
+
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(zstd.SpeedFastest))
+    frame = enc.EncodeAll(src, b"")                     # == reference EncodeAll(src, nil)
+    frames, off = enc.EncodeUnits(buf, unit_off)        # N independent EncodeAll calls, one launch
+"""
+import ctypes as C
+
+from . import _lib
+from ._lib import KcError
+
+# zstd.EncoderLevel (encoder_options.go:163-179)
+SpeedFastest, SpeedDefault, SpeedBetterCompression, SpeedBestCompression = 1, 2, 3, 4
+MinWindowSize, MaxWindowSize = 1 << 10, 1 << 29
+
+
+def EncoderLevelFromString(s):
+    """encoder_options.go:181-198: case-insensitive name -> (ok, level)."""
+    m = {"fastest": SpeedFastest, "default": SpeedDefault, "better": SpeedBetterCompression, "best": SpeedBestCompression}
+    lvl = m.get(s.lower())
+    return (lvl is not None), (lvl if lvl is not None else SpeedDefault)
+
+
+def EncoderLevelFromZstd(level):
+    """encoder_options.go:200-218."""
+    if level < 3:
+        return SpeedFastest
+    if level < 6:
+        return SpeedDefault
+    if level < 10:
+        return SpeedBetterCompression
+    return SpeedBestCompression
+
+
+# ---- EOption constructors: each returns a callable applied in order to the options struct ----
+def _opt(name, *args):
+    def apply(o):
+        L = _lib.load()
+        st = getattr(L, "kc_zstd_opts_" + name)(C.byref(o), *args)
+        if st != 0:
+            raise ValueError("zstd option %s%r rejected" % (name, args))
+    return apply
+
+
+def WithEncoderLevel(l):
+    return _opt("level", int(l))
+
+
+def WithWindowSize(n):
+    return _opt("window", int(n))
+
+
+def WithEncoderCRC(b):
+    return _opt("crc", int(bool(b)))
+
+
+def WithZeroFrames(b):
+    return _opt("zero_frames", int(bool(b)))
+
+
+def WithNoEntropyCompression(b):
+    return _opt("no_entropy", int(bool(b)))
+
+
+def WithAllLitEntropyCompression(b):
+    return _opt("all_lit_entropy", int(bool(b)))
+
+
+def WithSingleSegment(b):
+    return _opt("single_segment", int(bool(b)))
+
+
+def WithEncoderDictRaw(id, content):
+    content = bytes(content)
+
+    def apply(o):
+        L = _lib.load()
+        buf = C.create_string_buffer(content, len(content))
+        o._dict_keep = buf
+        if L.kc_zstd_opts_dict_raw(C.byref(o), id, C.cast(buf, C.c_void_p), len(content)) != 0:
+            raise ValueError("dictionary rejected")
+    return apply
+
+
+def WithEncoderConcurrency(n):
+    """Accepted for API compatibility; the device path is batch-parallel (no bytes depend on it)."""
+    if n <= 0:
+        raise ValueError("concurrency must be at least 1")
+    return lambda o: None
+
+
+def WithLowerEncoderMem(b):
+    return lambda o: setattr(o, "low_mem", int(bool(b)))
+
+
+class Encoder:
+    """zstd.Encoder for the block (EncodeAll) path.  Streaming Write/Close is a 'next' row."""
+
+    def __init__(self, *opts, device=0, stream=None):
+        L = _lib.load()
+        self.o = _lib.ZstdOpts()
+        L.kc_zstd_opts_default(C.byref(self.o))
+        for op in opts:
+            op(self.o)
+        self._device, self._stream = device, stream
+        self._ctx = None
+
+    # -- reference API --
+    def MaxEncodedSize(self, size):
+        return int(_lib.load().kc_zstd_max_encoded_size(C.byref(self.o), int(size)))
+
+    def EncodeAll(self, src, dst=b""):
+        """Encode all of src as one frame and append to dst (zstd/encoder.go:722)."""
+        import numpy as np
+        src = bytes(src)
+        off = np.array([0, len(src)], dtype=np.uint64)
+        out, _ = self.EncodeUnits(np.frombuffer(src, dtype=np.uint8), off)
+        return bytes(dst) + out.tobytes()
+
+    # -- batched form: what the cgo shim calls --
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.Context(self._device, self._stream)
+        return self._ctx
+
+    def EncodeUnits(self, src, unit_off):
+        """src: numpy uint8 (host); unit_off: uint64[n+1].  Returns (numpy uint8 frames, uint64[n+1] offsets)."""
+        import numpy as np
+        ctx = self.ctx()
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
+        n = len(unit_off) - 1
+        cap = sum(((self.MaxEncodedSize(int(unit_off[i + 1] - unit_off[i])) + 15) & ~15) for i in range(n)) + 64
+        dst = np.empty(cap, dtype=np.uint8)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        ctx.check(ctx.L.kc_zstd_encode_units(ctx.h, C.byref(self.o), src.ctypes.data, unit_off.ctypes.data, n,
+                                             dst.ctypes.data, cap, out_off.ctypes.data))
+        return dst[:int(out_off[n])], out_off
+
+    def EncodeUnitsDevice(self, d_src_ptr, unit_off, d_dst_ptr, dst_cap):
+        """Device-resident form (pointers are ints).  Returns uint64[n+1] offsets (host numpy)."""
+        import numpy as np
+        ctx = self.ctx()
+        unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
+        n = len(unit_off) - 1
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        ctx.check(ctx.L.kc_zstd_encode_units_dev(ctx.h, C.byref(self.o), d_src_ptr, unit_off.ctypes.data, n, d_dst_ptr,
+                                                 int(dst_cap), out_off.ctypes.data))
+        return out_off
+
+    def DebugParseDevice(self, d_src_ptr, unit_off):
+        """Match-finder intermediates for parity tests: list over blocks of (seqs[n,3] u32, extra_lits)."""
+        import numpy as np
+        ctx = self.ctx()
+        unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
+        n = len(unit_off) - 1
+        total = int(unit_off[n] - unit_off[0])
+        bs = self.o.block_size
+        blk_cap = total // bs + n + 2
+        seqs = np.empty((total // 4 + 16, 3), dtype=np.uint32)
+        first = np.zeros(blk_cap + 1, dtype=np.uint64)
+        extra = np.zeros(blk_cap, dtype=np.uint32)
+        nb = C.c_uint32()
+        ctx.check(ctx.L.kc_zstd_debug_parse_dev(ctx.h, C.byref(self.o), d_src_ptr, unit_off.ctypes.data, n, seqs.ctypes.data,
+                                                len(seqs), first.ctypes.data, extra.ctypes.data, blk_cap, C.byref(nb)))
+        return [(seqs[int(first[b]):int(first[b + 1])].copy(), int(extra[b])) for b in range(nb.value)]
+
+    def Close(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+
+def NewWriter(w, *opts, **kw):
+    """zstd.NewWriter(w, opts...) (encoder.go:71).  w is accepted for signature parity; the block API ignores it."""
+    return Encoder(*opts, **kw)

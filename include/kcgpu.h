@@ -1,0 +1,140 @@
+/* kcgpu.h — C ABI of the MI355X-native block-parallel zstd / S2 encode engine.
+ *
+ * This is the drop-in boundary for the encode hot path of klauspost/compress: every entry
+ * point below is what a cgo binding in the reference would call instead of its pure-Go
+ * encoder.  Plain pointers and sizes only; no exceptions cross this boundary; every call
+ * returns a kc_status (0 == KC_OK, negative == error) and never aborts the host process
+ * (the reference turns encoder panics into errors at its goroutine boundaries,
+ * zstd/encoder.go:397-403,421-427).
+ *
+ * Reference seams replaced (file:line under the reference tree):
+ *   kc_zstd_encode_units[_dev]  == N x (*Encoder).EncodeAll(unit, nil)   zstd/encoder.go:722-839
+ *   kc_zstd_max_encoded_size    == (*Encoder).MaxEncodedSize             zstd/encoder.go:843-873
+ *   kc_s2_encode_blocks[_dev]   == N x s2.Encode(nil, block)             s2/encode.go:29-56
+ *   kc_s2_encode_block          == the s2.WriterCustomEncoder callback   s2/writer.go:1053-1064
+ *   kc_s2_max_encoded_len       == s2.MaxEncodedLen                      s2/encode.go:389-418
+ *   kc_xxh64_units_dev          == xxhash.Digest over each unit          zstd/internal/xxhash/xxhash.go:27-230
+ */
+#ifndef KCGPU_H
+#define KCGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kc_ctx kc_ctx; /* opaque: device buffers, stream, scratch */
+
+typedef enum {
+    KC_OK = 0,
+    KC_ERR_BAD_ARG = -1,       /* null pointer, unsorted offsets, zero units ... */
+    KC_ERR_DST_TOO_SMALL = -2, /* dst_cap < sum of MaxEncodedSize(unit) */
+    KC_ERR_HIP = -3,           /* a HIP runtime call failed; kc_last_error() has the text */
+    KC_ERR_UNSUPPORTED = -4,   /* options outside what the device path implements; caller falls back to the CPU encoder */
+    KC_ERR_NO_DEVICE = -5,     /* no gfx950 device visible */
+    KC_ERR_INTERNAL = -6       /* device-side invariant violated (reported, never silently ignored) */
+} kc_status;
+
+/* zstd.EncoderLevel (zstd/encoder_options.go:163-179) */
+typedef enum { KC_SPEED_FASTEST = 1, KC_SPEED_DEFAULT = 2, KC_SPEED_BETTER = 3 } kc_level;
+
+/* Resolved zstd encoder options == the fields of encoderOptions (zstd/encoder_options.go:18-34)
+ * that change output bytes.  Use kc_zstd_opts_default() + kc_zstd_opts_* helpers, which apply the
+ * reference's EOption functions with the same order-dependent side effects. */
+typedef struct {
+    int32_t level;           /* o.level */
+    int32_t window_size;     /* o.windowSize */
+    int32_t block_size;      /* o.blockSize */
+    int32_t crc;             /* o.crc            (WithEncoderCRC) */
+    int32_t single;          /* o.single: -1 nil, 0 false, 1 true (WithSingleSegment) */
+    int32_t full_zero;       /* o.fullZero       (WithZeroFrames) */
+    int32_t no_entropy;      /* o.noEntropy      (WithNoEntropyCompression) */
+    int32_t all_lit_entropy; /* o.allLitEntropy  (WithAllLitEntropyCompression) */
+    int32_t low_mem;         /* o.lowMem         (WithLowerEncoderMem; no effect on bytes) */
+    int32_t custom_window, custom_block, custom_alent; /* o.customWindow / customBlockSize / customALEntropy */
+    uint32_t dict_id;        /* WithEncoderDictRaw id (0 = no dictionary) */
+    const uint8_t* dict;     /* raw dictionary content (host pointer), used as initial history */
+    uint64_t dict_len;
+} kc_zstd_opts;
+
+/* encoderOptions.setDefault, zstd/encoder_options.go:36-48 */
+void kc_zstd_opts_default(kc_zstd_opts* o);
+/* WithEncoderLevel, zstd/encoder_options.go:236-266 */
+int kc_zstd_opts_level(kc_zstd_opts* o, int level);
+/* WithWindowSize, zstd/encoder_options.go:110-133 */
+int kc_zstd_opts_window(kc_zstd_opts* o, int n);
+/* WithEncoderCRC / WithZeroFrames / WithNoEntropyCompression / WithAllLitEntropyCompression / WithSingleSegment */
+int kc_zstd_opts_crc(kc_zstd_opts* o, int b);
+int kc_zstd_opts_zero_frames(kc_zstd_opts* o, int b);
+int kc_zstd_opts_no_entropy(kc_zstd_opts* o, int b);
+int kc_zstd_opts_all_lit_entropy(kc_zstd_opts* o, int b);
+int kc_zstd_opts_single_segment(kc_zstd_opts* o, int b);
+/* WithEncoderDictRaw, zstd/encoder_options.go:398-406 */
+int kc_zstd_opts_dict_raw(kc_zstd_opts* o, uint32_t id, const uint8_t* content, uint64_t len);
+
+/* (*Encoder).MaxEncodedSize, zstd/encoder.go:843-873 (padding off) */
+int64_t kc_zstd_max_encoded_size(const kc_zstd_opts* o, int64_t size);
+
+/* ---- context ---- */
+/* device: HIP device ordinal.  stream: a hipStream_t to launch on (NULL = the context's own stream).
+ * The context owns all device scratch; it is safe to use one context per host thread. */
+kc_status kc_ctx_create(kc_ctx** out, int device, void* stream);
+void kc_ctx_destroy(kc_ctx* ctx);
+const char* kc_last_error(const kc_ctx* ctx);
+/* Device properties as probed (CU count, LDS bytes per CU, clock, name) */
+kc_status kc_device_info(const kc_ctx* ctx, int32_t* n_cu, int32_t* lds_per_cu, int32_t* clock_khz, char* name, size_t name_cap);
+
+/* ---- zstd: N independent units, each == EncodeAll(unit, nil) ----
+ * src:       all units, concatenated (host memory for the plain call, device memory for _dev)
+ * unit_off:  n_units+1 ascending byte offsets into src (HOST memory in both variants)
+ * dst:       output buffer; unit i's frame is written at dst + out_off[i]
+ * dst_cap:   must be >= sum_i kc_zstd_max_encoded_size(unit_i)
+ * out_off:   n_units+1 offsets of the compacted frames (HOST memory in both variants)
+ * The _dev variant leaves the frames in device memory (dst is a device pointer) and only
+ * copies the n_units+1 offsets back; it synchronises the stream before returning. */
+kc_status kc_zstd_encode_units(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off,
+                               uint32_t n_units, uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
+kc_status kc_zstd_encode_units_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
+                                   uint32_t n_units, uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
+
+/* XXH64(seed 0) of every unit (the frame checksum primitive), device-resident input, host output. */
+kc_status kc_xxh64_units_dev(kc_ctx* ctx, const uint8_t* d_src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out_hash);
+
+/* Debug/inspection (parity of intermediates): run only the match finder on device-resident units and
+ * return, for every block, the sequence list as (litLen, matchLen, offset) u32 triples.
+ * blk_first_seq has n_blocks+1 entries.  Buffers are HOST memory. */
+kc_status kc_zstd_debug_parse_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
+                                  uint32_t n_units, uint32_t* seqs, uint64_t seq_cap, uint64_t* blk_first_seq,
+                                  uint32_t* blk_extra_lits, uint32_t blk_cap, uint32_t* n_blocks_out);
+
+/* ---- S2: N independent blocks, each == s2.Encode(nil, block) (varint length + body) ---- */
+int64_t kc_s2_max_encoded_len(int64_t src_len);
+kc_status kc_s2_encode_blocks(kc_ctx* ctx, const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks,
+                              uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
+kc_status kc_s2_encode_blocks_dev(kc_ctx* ctx, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
+                                  uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
+/* Single-block form with the WriterCustomEncoder contract (s2/writer.go:1053-1064): no varint header;
+ * returns bytes used, 0 = incompressible (store raw), <0 = fall back to the built-in encoder. */
+int64_t kc_s2_encode_block(kc_ctx* ctx, uint8_t* dst, uint64_t dst_cap, const uint8_t* src, uint64_t src_len);
+
+/* ---- timing of the last call (HIP events recorded on the launch stream) ---- */
+typedef struct {
+    float total_ms;   /* all kernels of the last encode call */
+    float match_ms;   /* match-finder kernel(s) */
+    float entropy_ms; /* histogram + table build + bitstream emit kernel(s) */
+    float other_ms;   /* checksum, scan, compaction */
+    uint32_t redo_units; /* units re-run because a speculated block verdict was wrong */
+} kc_timings;
+kc_status kc_last_timings(const kc_ctx* ctx, kc_timings* t);
+
+/* ---- synthetic corpora: deterministic, per-unit seeded, host-side generator ----
+ * kind: 'T' enwik-style text, 'H' high-entropy, 'J' JSON records, 'M' mixed.  Fills
+ * n_units * unit_size bytes at dst (host memory) using `threads` host threads. */
+kc_status kc_corpus_fill(int kind, uint64_t seed, uint64_t first_unit, uint32_t n_units, uint32_t unit_size, uint8_t* dst, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KCGPU_H */

@@ -1,0 +1,39 @@
+"""Seeded test inputs shared by the CPU and GPU tests (no dependency on /root/reference)."""
+import numpy as np
+
+from compress_amd import _lib
+
+SEED_T, SEED_H, SEED_J, SEED_M = 0x5EED0001, 0x5EED0002, 0x5EED0003, 0x5EED0004
+
+
+def corpus(kind, n_units, unit_size, first_unit=0, seed=None):
+    seed = {"T": SEED_T, "H": SEED_H, "J": SEED_J, "M": SEED_M}[kind] if seed is None else seed
+    return _lib.corpus_fill(kind, seed, first_unit, n_units, unit_size)
+
+
+def edge_units():
+    """Small and pathological units: empty, tiny, RLE, periodic, noise+repeat, boundary sizes."""
+    rng = np.random.default_rng(1234)
+    units = [b"", b"a", b"ab" * 4, b"abcdefghi", b"0123456789", b"\x00" * 100, b"\x00" * 70000, b"ab" * 40000,
+             bytes(rng.integers(0, 256, 1000, dtype=np.uint8)),
+             bytes(rng.integers(0, 4, 5000, dtype=np.uint8)),
+             b"the quick brown fox jumps over the lazy dog. " * 300,
+             bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) * 9,
+             bytes(rng.integers(97, 123, 65536, dtype=np.uint8)),
+             bytes(rng.integers(97, 101, 65537, dtype=np.uint8)),
+             bytes(rng.integers(0, 256, 65535, dtype=np.uint8)),
+             (b"x" * 1023), (b"xy" * 512), (b"xyz" * 342)[:1025], b"q" * 131072,
+             bytes(rng.integers(0, 2, 131072, dtype=np.uint8)),
+             ]
+    text = corpus("T", 1, 200000).tobytes()
+    for n in (9, 10, 11, 15, 16, 17, 31, 32, 33, 255, 256, 257, 1023, 1024, 1025, 4095, 65535, 65536, 65537, 131071, 131072, 131073, 200000):
+        units.append(text[:n])
+    return units
+
+
+def pack_units(units):
+    off = np.zeros(len(units) + 1, dtype=np.uint64)
+    for i, u in enumerate(units):
+        off[i + 1] = off[i] + len(u)
+    buf = np.frombuffer(b"".join(units), dtype=np.uint8).copy() if off[-1] else np.zeros(0, dtype=np.uint8)
+    return buf, off

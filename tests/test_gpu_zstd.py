@@ -1,0 +1,123 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import corpora
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def _enc(level=1, **kw):
+    from compress_amd import zstd
+    return zstd.NewWriter(None, zstd.WithEncoderLevel(level), **kw)
+
+
+def _check_units(oracle, units, level=1):
+    buf, off = corpora.pack_units(units)
+    enc = _enc(level)
+    out, out_off = enc.EncodeUnits(buf, off)
+    ref, ref_off = oracle.zstd_encode_units(buf, off, threads=8, level=level)
+    bad = []
+    for i in range(len(units)):
+        a = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        b = ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()
+        if a != b:
+            bad.append((i, len(units[i]), len(a), len(b)))
+    assert not bad, "units differing from the oracle (index, in_len, gpu_len, oracle_len): %r" % bad[:10]
+    assert np.array_equal(out_off, ref_off)
+    enc.Close()
+
+
+def test_parse_matches_oracle(oracle, kclib):
+    """Intermediate artefact parity: the sequence list of every block equals the oracle's."""
+    torch = _torch()
+    units = [corpora.corpus("T", 1, 131072, first_unit=k).tobytes() for k in range(4)]
+    units += [corpora.corpus("M", 1, 131072, first_unit=k).tobytes() for k in range(4)]
+    units += [corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("H", 1, 131072).tobytes()]
+    units += [u for u in corpora.edge_units() if len(u) > 0]
+    buf, off = corpora.pack_units(units)
+    d = torch.from_numpy(buf).cuda()
+    enc = _enc(1)
+    blocks = enc.DebugParseDevice(d.data_ptr(), off)
+    bi = 0
+    for ui, u in enumerate(units):
+        ref = oracle.zstd_parse_unit(u, level=1)
+        for rb, (rseqs, rlits) in enumerate(ref):
+            gseqs, gextra = blocks[bi]
+            bi += 1
+            assert len(gseqs) == len(rseqs), "unit %d block %d: nseq %d vs oracle %d" % (ui, rb, len(gseqs), len(rseqs))
+            if len(rseqs):
+                neq = np.nonzero((gseqs != rseqs).any(axis=1))[0]
+                assert len(neq) == 0, "unit %d block %d first differing seq %d: gpu %r oracle %r" % (
+                    ui, rb, neq[0], gseqs[neq[0]], rseqs[neq[0]])
+    assert bi == len(blocks)
+    enc.Close()
+
+
+def test_edge_units_bit_exact(oracle, kclib):
+    _torch()
+    _check_units(oracle, corpora.edge_units())
+
+
+@pytest.mark.parametrize("kind", ["T", "H", "J", "M"])
+def test_corpus_units_bit_exact(oracle, kclib, kind):
+    _torch()
+    buf = corpora.corpus(kind, 96, 131072)
+    units = [buf[i * 131072:(i + 1) * 131072].tobytes() for i in range(96)]
+    _check_units(oracle, units)
+
+
+def test_ragged_units_bit_exact(oracle, kclib):
+    _torch()
+    rng = np.random.default_rng(7)
+    text = corpora.corpus("T", 8, 131072).tobytes()
+    mixed = corpora.corpus("M", 8, 131072).tobytes()
+    units = []
+    for k in range(200):
+        src = text if k % 2 == 0 else mixed
+        n = int(rng.integers(0, 300000)) if k % 5 else int(rng.integers(0, 64))
+        s = int(rng.integers(0, len(src) - n))
+        units.append(src[s:s + n])
+    _check_units(oracle, units)
+
+
+def test_xxh64_units(oracle, kclib):
+    torch = _torch()
+    import ctypes as C
+    units = corpora.edge_units()
+    buf, off = corpora.pack_units(units)
+    d = torch.from_numpy(buf).cuda()
+    enc = _enc(1)
+    ctx = enc.ctx()
+    out = np.zeros(len(units), dtype=np.uint64)
+    ctx.check(ctx.L.kc_xxh64_units_dev(ctx.h, d.data_ptr(), off.ctypes.data, len(units), out.ctypes.data))
+    for i, u in enumerate(units):
+        assert int(out[i]) == oracle.lib().kco_xxh64(u, len(u)), i
+    enc.Close()
+
+
+def test_device_resident_roundtrip_full_size(oracle, kclib):
+    """BASELINE-size property check (no oracle at this size): every frame decodes back with libzstd."""
+    torch = _torch()
+    n, usz = 2048, 131072
+    buf = corpora.corpus("T", n, usz)
+    off = (np.arange(n + 1, dtype=np.uint64) * usz)
+    d_src = torch.from_numpy(buf).cuda()
+    enc = _enc(1)
+    cap = n * ((enc.MaxEncodedSize(usz) + 15) & ~15) + 64
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    out_off = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    out = d_dst[:int(out_off[n])].cpu().numpy()
+    rng = np.random.default_rng(3)
+    for i in rng.choice(n, 64, replace=False):
+        frame = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        assert oracle.zstd_decompress(frame, usz + 16) == buf[i * usz:(i + 1) * usz].tobytes()
+    ratio = float(out_off[n]) / float(n * usz)
+    assert 0.2 < ratio < 0.7, ratio
+    enc.Close()
