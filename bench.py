@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X zstd encode hot path (BASELINE.json configs[1]).
+
+Workload (C2): zstd SpeedFastest, synthetic enwik-style text 'T' in independent 128 KiB units
+(each unit == one reference EncodeAll call: 1 frame, 2 x 64 KiB blocks sharing history), 4 GiB
+per GPU, inputs resident in HBM before the timed region.  A "step" is one pass of the whole
+hot path (checksum + match finder + entropy/emit + compaction) over the batch; for N > 1 each
+rank encodes its own 4 GiB shard (weak scaling) and the compressed frames are gathered to
+rank 0 over RCCL (the only exchange step of this path).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--gib G] [--kind T|H|J|M]
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+UNIT = 128 << 10
+SEEDS = {"T": 0x5EED0001, "H": 0x5EED0002, "J": 0x5EED0003, "M": 0x5EED0004}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gib", type=float, default=4.0, help="input GiB per GPU")
+    ap.add_argument("--kind", default="T")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-units", type=int, default=16384)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from compress_amd import _lib, zstd
+    from compress_amd.shard import shard_range, gather_frames
+
+    n_units = int(args.gib * (1 << 30)) // UNIT
+    first_unit = rank * n_units  # contiguous shard per rank keeps output order == concatenation order
+    t0 = time.time()
+    host = _lib.corpus_fill(args.kind, SEEDS[args.kind], first_unit, n_units, UNIT)
+    gen_s = time.time() - t0
+    d_src = torch.from_numpy(host).cuda(local_rank)
+    unit_off = np.arange(n_units + 1, dtype=np.uint64) * UNIT
+
+    stream = torch.cuda.current_stream().cuda_stream
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(zstd.SpeedFastest), device=local_rank, stream=stream)
+    cap = n_units * ((enc.MaxEncodedSize(UNIT) + 15) & ~15) + 64
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    info = enc.ctx().device_info()
+
+    def step():
+        off = enc.EncodeUnitsDevice(d_src.data_ptr(), unit_off, d_dst.data_ptr(), cap)
+        gathered = None
+        if world > 1:
+            gathered = gather_frames(d_dst, int(off[n_units]), rank, world)
+        return off, gathered
+
+    for _ in range(args.warmup):
+        out_off, _g = step()
+    match_ms = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_off, _g = step()
+        match_ms.append(enc.ctx().timings())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt * 1000.0 / args.steps
+    in_bytes = n_units * UNIT
+    out_bytes = int(out_off[n_units])
+    value = world * in_bytes / (ms_per_step / 1000.0) / 1e6  # MB/s (1e6) of input, whole job
+
+    # ---- roofline of the dominant kernel (match finder), from HIP events on the launch stream ----
+    tm = match_ms[-1]
+    k_match = sum(t["match_ms"] for t in match_ms) / len(match_ms)
+    k_entropy = sum(t["entropy_ms"] for t in match_ms) / len(match_ms)
+    k_total = sum(t["total_ms"] for t in match_ms) / len(match_ms)
+    algo_bytes = in_bytes + out_bytes  # 1 B read + ratio B written per input byte
+    achieved = algo_bytes / (k_match / 1000.0) / 1e9
+    roofline = {"bound": "hbm", "kernel": "kc_zfast_match_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel_ms": round(k_match, 3), "entropy_kernel_ms": round(k_entropy, 3), "pipeline_kernel_ms": round(k_total, 3),
+                "read_only_frac": round(in_bytes / (k_match / 1000.0) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement of the reference, all host threads ----
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib
+        cores = os.cpu_count() or 1
+        sample = min(n_units, args.cpu_sample_units)
+        t0 = time.perf_counter()
+        ref, ref_off = oracle_lib.zstd_encode_units(host[:sample * UNIT], unit_off[:sample + 1], threads=cores, level=1)
+        cdt = time.perf_counter() - t0
+        cpu = {"value": round(sample * UNIT / cdt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
+               "sample": "first %d units (%.2f GiB) of the same corpus, one std::thread per hardware thread" % (sample, sample * UNIT / 2**30)}
+        got = d_dst[:int(out_off[sample])].cpu().numpy()
+        parity = bool(np.array_equal(got, ref) and np.array_equal(out_off[:sample + 1], ref_off))
+
+    if rank == 0:
+        line = {
+            "metric": "encode MB/s (input) + ratio, zstd SpeedFastest 128KiB blocks, 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "zstd SpeedFastest EncodeAll, %.2f GiB/GPU synthetic '%s' corpus in 128 KiB units (2 x 64 KiB blocks with history), device-resident"
+                       % (args.gib, args.kind), "units_per_gpu": n_units, "unit_bytes": UNIT, "corpus": args.kind,
+                       "parallelism": "units sharded contiguously over %d GPU(s); RCCL gather of frames to rank 0" % world if world > 1 else "1 GPU",
+                       "device": info},
+            "ratio": round(out_bytes / in_bytes, 5),
+            "value_GiBps": round(value * 1e6 / 2**30, 3),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "bit_exact_vs_oracle_on_sample": parity,
+            "redo_units": tm["redo_units"],
+            "host": {"gen_s": round(gen_s, 2), "nproc": os.cpu_count()},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

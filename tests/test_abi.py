@@ -1,0 +1,103 @@
+"""Host-side checks of the product library that need no GPU: it loads, exports every symbol
+include/kcgpu.h declares, resolves options like zstd/encoder_options.go, and refuses to
+compute without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported(kclib):
+    from compress_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "kcgpu.h")).read()
+    declared = set(re.findall(r"\b(kc_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"kc_ctx", "kc_status", "kc_level", "kc_zstd_opts", "kc_timings"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for s in declared:
+        assert hasattr(kclib, s), s
+
+
+def _opts(*ops):
+    from compress_amd import zstd
+    e = zstd.NewWriter(None, *ops)
+    return e.o
+
+
+def test_option_resolution_matches_reference():
+    """encoder_options.go:36-48 (defaults), :236-266 (WithEncoderLevel), :110-133 (WithWindowSize) incl.
+    the order dependence of the two."""
+    from compress_amd import zstd
+    o = _opts()
+    assert (o.level, o.window_size, o.block_size, o.crc, o.single, o.full_zero, o.all_lit_entropy) == (2, 8 << 20, 128 << 10, 1, -1, 1, 0)
+    o = _opts(zstd.WithEncoderLevel(zstd.SpeedFastest))
+    assert (o.window_size, o.block_size, o.all_lit_entropy) == (4 << 20, 1 << 16, 0)  # App. A-1
+    o = _opts(zstd.WithEncoderLevel(zstd.SpeedBetterCompression))
+    assert (o.window_size, o.block_size, o.all_lit_entropy) == (8 << 20, 128 << 10, 1)
+    # custom window first: level keeps it and keeps the block size derived from it
+    o = _opts(zstd.WithWindowSize(1 << 15), zstd.WithEncoderLevel(zstd.SpeedFastest))
+    assert (o.window_size, o.block_size) == (1 << 15, 1 << 15)
+    # level first, then a large custom window: block size stays at the level's 64 KiB
+    o = _opts(zstd.WithEncoderLevel(zstd.SpeedFastest), zstd.WithWindowSize(1 << 20))
+    assert (o.window_size, o.block_size) == (1 << 20, 1 << 16)
+    o = _opts(zstd.WithAllLitEntropyCompression(True), zstd.WithEncoderLevel(zstd.SpeedFastest))
+    assert o.all_lit_entropy == 1  # customALEntropy sticks
+    with pytest.raises(ValueError):
+        _opts(zstd.WithWindowSize(1000))
+    with pytest.raises(ValueError):
+        _opts(zstd.WithWindowSize(1 << 30))
+    with pytest.raises(ValueError):
+        _opts(zstd.WithEncoderLevel(0))
+    # zstd/encoder_options_test.go:9-124 level mappings
+    assert zstd.EncoderLevelFromString("Fastest") == (True, zstd.SpeedFastest)
+    assert zstd.EncoderLevelFromString("nope")[0] is False
+    assert [zstd.EncoderLevelFromZstd(i) for i in (1, 2, 3, 5, 6, 9, 10, 22)] == [1, 1, 2, 2, 3, 3, 4, 4]
+
+
+def test_max_encoded_size_matches_oracle(oracle):
+    from compress_amd import zstd
+    for lvl in (1, 2, 3):
+        e = zstd.NewWriter(None, zstd.WithEncoderLevel(lvl))
+        oe = oracle.ZstdOracle(level=lvl)
+        for n in (0, 1, 255, 256, 65535 + 256, 65536 + 256, 65536, 131072, 1 << 20, (1 << 31) - 1, 1 << 31):
+            assert e.MaxEncodedSize(n) == oe.max_encoded_size(n), (lvl, n)
+    e = zstd.NewWriter(None, zstd.WithEncoderLevel(1), zstd.WithEncoderCRC(False))
+    assert e.MaxEncodedSize(131072) == 131072 + 6 + 4 + 9
+
+
+def test_no_cpu_fallback_without_device():
+    """On a machine without a GPU the product path must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from compress_amd import zstd, KcError
+    e = zstd.NewWriter(None, zstd.WithEncoderLevel(zstd.SpeedFastest))
+    with pytest.raises(KcError):
+        e.EncodeAll(b"hello world")
+
+
+def test_product_does_not_reference_oracle():
+    """The oracle is test infrastructure: nothing under compress_amd/ may import, link or mention it."""
+    for dp, _, fns in os.walk(os.path.join(ROOT, "compress_amd")):
+        if "_build" in dp or "__pycache__" in dp:
+            continue
+        for fn in fns:
+            if fn.endswith((".py", ".cpp", ".h", ".hip")):
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                assert "kcoracle" not in txt and "oracle_lib" not in txt and "kco_" not in txt, os.path.join(dp, fn)
+
+
+def test_corpus_generator_deterministic_and_shardable(kclib):
+    import numpy as np
+    import corpora
+    a = corpora.corpus("T", 8, 4096)
+    b = np.concatenate([corpora.corpus("T", 3, 4096), corpora.corpus("T", 5, 4096, first_unit=3)])
+    assert np.array_equal(a, b)
+    for k in "THJM":
+        x = corpora.corpus(k, 2, 70000)
+        assert np.array_equal(x, corpora.corpus(k, 2, 70000))
+        assert not np.array_equal(x[:70000], x[70000:])
+    h = corpora.corpus("H", 1, 1 << 16)
+    assert len(np.unique(h)) == 256

@@ -1,0 +1,157 @@
+"""Pin the CPU oracle against the reference's own known-answer tests and fixtures (no GPU)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import pytest
+
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kats.json")))
+REF = "/root/reference"
+
+
+def test_xxh64_kats(oracle):
+    L = oracle.lib()
+    for s, h in KATS["xxh64"]:
+        b = s.encode()
+        assert L.kco_xxh64(b, len(b)) == int(h, 16)
+        for chunk in range(1, max(2, len(b) + 1)):  # xxhash_test.go testDigest: every chunking of Write
+            assert L.kco_xxh64_chunked(b, len(b), chunk) == int(h, 16)
+
+
+def test_matchlen_kat(oracle):
+    """zstd/zstd_test.go:45-64 TestMatchLen."""
+    L = oracle.lib()
+    b = bytes(range(130))
+    for l in range(130):
+        a = bytearray(b)
+        a[l] ^= 0xFF
+        assert L.kco_zstd_matchlen(bytes(a), len(a), b) == l
+        assert L.kco_zstd_matchlen(bytes(a[:l]), l, b) == l
+
+
+def test_hashlen_matches_formula(oracle):
+    """zstd/hash.go:20-35 restated independently in Python."""
+    L = oracle.lib()
+    M = (1 << 64) - 1
+    primes = {3: 506832829, 4: 2654435761, 5: 889523592379, 6: 227718039650203, 7: 58295818150454627, 8: 0xcf1bbcdcb7a56463}
+    for u in (0, 1, 0x0123456789abcdef, M, 0x8000000000000000, 0x00ff00ff00ff00ff):
+        for bits in (13, 15, 17, 19):
+            for mls in (3, 4, 5, 6, 7, 8):
+                if mls == 3:
+                    want = ((((u << 8) & 0xFFFFFFFF) * primes[3]) & 0xFFFFFFFF) >> (32 - bits)
+                elif mls == 4:
+                    want = (((u & 0xFFFFFFFF) * primes[4]) & 0xFFFFFFFF) >> (32 - bits)
+                elif mls == 8:
+                    want = ((u * primes[8]) & M) >> (64 - bits)
+                else:
+                    want = ((((u << (64 - 8 * mls)) & M) * primes[mls]) & M) >> (64 - bits)
+                assert L.kco_zstd_hashlen(u, bits, mls) == (want & 0xFFFFFFFF)
+
+
+def test_s2_emit_literal_kat(oracle):
+    L = oracle.lib()
+    dst = C.create_string_buffer(70000)
+    nines = b"\x99" * 65536
+    for length, want in KATS["s2_emit_literal"]:
+        n = L.kco_s2_emit_literal(dst, nines[:length], length)
+        assert dst.raw[n - length:n] == nines[:length]
+        assert dst.raw[:n - length].hex() == want
+
+
+def test_s2_emit_copy_kat(oracle):
+    L = oracle.lib()
+    dst = C.create_string_buffer(1024)
+    for offset, length, want in KATS["s2_emit_copy"]:
+        n = L.kco_s2_emit_copy(dst, offset, length)
+        assert dst.raw[:n].hex() == want, (offset, length)
+
+
+def test_s2_max_encoded_len_kat(oracle, kclib):
+    L = oracle.lib()
+    for n, want in KATS["s2_max_encoded_len"]:
+        assert L.kco_s2_max_encoded_len(n) == want, n
+        assert kclib.kc_s2_max_encoded_len(n) == want, n
+    for i in list(range(0, 70000, 7)) + [(1 << 22) - 1, 1 << 22]:
+        varint = 1
+        z = i << 1
+        while z >= 0x80:
+            z >>= 7
+            varint += 1
+        extra = 0 if i == 0 else 1 if i < 60 else 2 if i < 256 else 3 if i < 65536 else 4 if i < (1 << 24) else 5
+        assert L.kco_s2_max_encoded_len(i) == i + varint + extra == kclib.kc_s2_max_encoded_len(i)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference fixtures not present on this machine")
+def test_frame_boundaries_on_reference_fixtures(oracle):
+    """C1: EncodeAll(e.txt) at SpeedFastest starts 28 B5 2F FD A4 A3 86 01 00 and ends 5F 0C 04 7D."""
+    enc = oracle.ZstdOracle(level=1)
+    for name, g in KATS["files"].items():
+        if "frame_prefix" not in g:
+            continue
+        data = open(os.path.join(REF, "testdata", name), "rb").read()
+        assert hashlib.sha256(data).hexdigest() == g["sha256"]
+        out = enc.encode_all(data)
+        assert out.hex().startswith(g["frame_prefix"]), name
+        assert out[-4:].hex() == g["frame_suffix"], name
+        assert oracle.lib().kco_xxh64(data, len(data)) == int(g["xxh64"], 16)
+        assert oracle.zstd_decompress(out, len(data) + 16) == data
+    e = open(os.path.join(REF, "testdata", "e.txt"), "rb").read()
+    out = enc.encode_all(e)
+    assert out[:9].hex() == "28b52ffda4a3860100" and out[-4:].hex() == "5f0c047d"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference fixtures not present on this machine")
+@pytest.mark.parametrize("level", [1, 2])
+def test_reference_corpora_roundtrip(oracle, level):
+    """The reference's encoder tests are round-trip tests (zstd/encoder_test.go:68-160, fuzz_test.go:154):
+    every oracle output must decode to the input with an independent decoder (libzstd 1.4.8) and stay
+    within MaxEncodedSize; a persistent encoder state must give the same bytes as a fresh one."""
+    import zipfile
+    enc = oracle.ZstdOracle(level=level)
+    n = 0
+    for zf in ("zstd/testdata/fuzz/encode-corpus-raw.zip", "zstd/testdata/comp-crashers.zip"):
+        z = zipfile.ZipFile(os.path.join(REF, zf))
+        for k, name in enumerate(z.namelist()):
+            d = z.read(name)
+            out = enc.encode_all(d)
+            if len(d) == 0:
+                assert out.hex() == "28b52ffd2000010000"
+                continue
+            assert len(out) <= enc.max_encoded_size(len(d))
+            assert oracle.zstd_decompress(out, len(d) + 16) == d, (zf, name)
+            if k % 16 == 0:
+                assert oracle.ZstdOracle(level=level).encode_all(d) == out, "encoder state leaked between frames"
+            n += 1
+    assert n > 3000
+
+
+def test_empty_and_tiny_frames(oracle):
+    enc = oracle.ZstdOracle(level=1)
+    assert enc.encode_all(b"").hex() == "28b52ffd2000010000"  # App. A-18
+    assert oracle.ZstdOracle(level=1, full_zero=False).encode_all(b"") == b""
+    for n in range(1, 40):
+        d = bytes((i * 7) & 0xFF for i in range(n))
+        out = enc.encode_all(d)
+        assert oracle.zstd_decompress(out, n + 16) == d
+
+
+def test_s2_roundtrip_and_bounds(oracle):
+    import corpora
+    for kind in "TJHM":
+        buf = corpora.corpus(kind, 4, 65536).tobytes()
+        for n in (0, 1, 31, 32, 33, 1000, 65535, 65536, 65537, 200000):
+            d = buf[:n]
+            e = oracle.s2_encode(d)
+            assert len(e) <= oracle.lib().kco_s2_max_encoded_len(n)
+            assert oracle.s2_decode(e, n + 8) == d
+    # TestEncodeNoiseThenRepeats (s2/s2_test.go:736-753): noise then repeats must compress the repeats
+    import numpy as np
+    rng = np.random.default_rng(1)
+    for orig in (256 * 1024, 2048 * 1024):
+        src = bytearray(rng.integers(0, 256, orig, dtype=np.uint8).tobytes())
+        half = orig // 2
+        src[half:] = bytes([(i >> 8) & 0xFF for i in range(half)])
+        e = oracle.s2_encode(bytes(src))
+        assert len(e) <= orig * 3 // 4
+        assert oracle.s2_decode(e, orig + 8) == bytes(src)
