@@ -90,7 +90,7 @@ def load():
         f.restype = C.c_int
     L.kc_xxh64_units_dev.argtypes = [vp, vp, vp, C.c_uint32, vp]
     L.kc_xxh64_units_dev.restype = C.c_int
-    L.kc_zstd_debug_parse_dev.argtypes = [vp, po, vp, vp, C.c_uint32, vp, u64, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.kc_zstd_debug_parse_dev.argtypes = [vp, po, vp, vp, C.c_uint32, vp, u64, vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.kc_zstd_debug_parse_dev.restype = C.c_int
     L.kc_s2_max_encoded_len.argtypes = [C.c_int64]
     L.kc_s2_max_encoded_len.restype = C.c_int64

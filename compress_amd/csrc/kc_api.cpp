@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -37,7 +38,7 @@ struct kc_ctx {
     std::string err;
     hipDeviceProp_t prop;
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
-        predef, errflag, tmp_src, tmp_dst;
+        predef, errflag, tmp_src, tmp_dst, tables;
     bool predef_ready = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     kc_timings last = {0, 0, 0, 0, 0};
@@ -171,7 +172,7 @@ void kc_ctx_destroy(kc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
-                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst};
+                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
@@ -217,6 +218,28 @@ kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
     if (o->dict != nullptr || o->dict_id != 0) { c->err = "dictionary encoding not implemented on the device path"; return KC_ERR_UNSUPPORTED; }
     if (o->all_lit_entropy) { c->err = "WithAllLitEntropyCompression(true) not implemented on the device path"; return KC_ERR_UNSUPPORTED; }
     if (o->block_size < 1024 || o->block_size > kMaxCompressedBlockSize || o->window_size < kMinWindowSize) { c->err = "bad block/window size"; return KC_ERR_BAD_ARG; }
+    return KC_OK;
+}
+
+
+// Match-finder variant selection.  Default: sub-wave groups (8 lanes per unit, HBM tables);
+// KC_ZFAST_VARIANT=lds|v1|g8|g16 overrides (lds: packed LDS table + LDS-resident block, one wave per unit;
+// v1: u32 LDS table, source from global memory).
+kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_off, uint32_t n_units, uint32_t n_launch, int bs, hipStream_t st) {
+    const char* v = getenv("KC_ZFAST_VARIANT");
+    std::string var = v ? v : "g8";
+    if (var == "lds") {
+        bool ok = bs <= 65536;
+        for (uint32_t i = 0; i < n_units && ok; i++) if (unit_off[i + 1] - unit_off[i] > 131072) ok = false;
+        kc_launch_zfast_match(mp, n_launch, st, ok);
+        return KC_OK;
+    }
+    if (var == "v1") { kc_launch_zfast_match(mp, n_launch, st, false); return KC_OK; }
+    const int G = var == "g16" ? 16 : 8;
+    kc_status s = ensure(c, c->tables, (size_t)n_launch * kc_zfast_table_bytes());
+    if (s != KC_OK) return s;
+    HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * kc_zfast_table_bytes(), st));
+    kc_launch_zfast_match_grp(mp, (uint32_t*)c->tables.p, n_launch, G, st);
     return KC_OK;
 }
 
@@ -312,7 +335,7 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (o->crc) kc_launch_xxh64(d_src, mp.unit_off, n_units, (uint64_t*)c->xxh.p, st);
     HIPCHK(c, hipEventRecord(c->ev[1], st));
-    kc_launch_zfast_match(mp, n_units, st);
+    if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, st)) != KC_OK) return s;
     HIPCHK(c, hipEventRecord(c->ev[2], st));
     kc_launch_zstd_entropy(ep, n_units, st);
     HIPCHK(c, hipEventRecord(c->ev[3], st));
@@ -350,7 +373,7 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
             mp.popmask = (const uint32_t*)c->popmask.p;
             mp.unit_list = (const uint32_t*)c->unit_list.p;
             ep.unit_list = mp.unit_list;
-            kc_launch_zfast_match(mp, (uint32_t)list.size(), st);
+            if ((s = launch_match(c, mp, unit_off, n_units, (uint32_t)list.size(), bs, st)) != KC_OK) return s;
             kc_launch_zstd_entropy(ep, (uint32_t)list.size(), st);
             HIPCHK(c, hipGetLastError());
         }
@@ -456,8 +479,8 @@ kc_status kc_xxh64_units_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* un
 }
 
 kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off, uint32_t n_units,
-                                  uint32_t* seqs, uint64_t seq_cap, uint64_t* blk_first_seq, uint32_t* blk_extra_lits, uint32_t blk_cap,
-                                  uint32_t* n_blocks_out) {
+                                  uint32_t* seqs, uint64_t seq_cap, uint64_t* blk_first_seq, uint32_t* blk_extra_lits, uint32_t* blk_flags,
+                                  uint32_t blk_cap, uint32_t* n_blocks_out) {
     if (!c || !o || !unit_off || !seqs || !blk_first_seq || !blk_extra_lits || !n_blocks_out) return KC_ERR_BAD_ARG;
     c->err.clear();
     kc_status s = check_supported(c, o);
@@ -485,7 +508,7 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
     mp.seq_stride = seq_stride;
     mp.block_size = bs;
     mp.max_match_off = o->window_size;
-    kc_launch_zfast_match(mp, n_units, c->stream);
+    if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, c->stream)) != KC_OK) return s;
     std::vector<KcBlkMeta> meta(nb);
     HIPCHK(c, hipMemcpyAsync(meta.data(), c->meta.p, (size_t)nb * sizeof(KcBlkMeta), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -495,6 +518,7 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
     for (uint32_t b = 0; b < nb; b++) {
         blk_first_seq[b] = total;
         blk_extra_lits[b] = meta[b].extra_lits;
+        if (blk_flags) blk_flags[b] = meta[b].flags;
         const uint32_t n = meta[b].nseq;
         if (total + n > seq_cap) return KC_ERR_DST_TOO_SMALL;
         packed.resize(n);

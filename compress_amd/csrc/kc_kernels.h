@@ -17,7 +17,11 @@ struct KcMatchParams {
     int32_t block_size;
     int32_t max_match_off;
 };
-void kc_launch_zfast_match(const KcMatchParams& P, uint32_t grid, hipStream_t st);
+// lds_variant: every unit <= 131064 bytes and block_size <= 65536 (packed 17-bit table + LDS-resident block)
+void kc_launch_zfast_match(const KcMatchParams& P, uint32_t grid, hipStream_t st, bool lds_variant);
+// sub-wave-group variant: G (8|16) lanes per unit, tables = n_launch x 2^15 x u32 in HBM, zeroed by the caller
+void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, int G, hipStream_t st);
+static inline size_t kc_zfast_table_bytes() { return (size_t)4 << 15; }
 
 // ---- entropy + emit (kc_zstd_entropy.hip) ----
 struct KcFsePredef;  // opaque device blob built by kc_launch_fse_predef_init

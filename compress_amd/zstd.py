@@ -163,9 +163,12 @@ class Encoder:
         seqs = np.empty((total // 4 + 16, 3), dtype=np.uint32)
         first = np.zeros(blk_cap + 1, dtype=np.uint64)
         extra = np.zeros(blk_cap, dtype=np.uint32)
+        flags = np.zeros(blk_cap, dtype=np.uint32)
         nb = C.c_uint32()
         ctx.check(ctx.L.kc_zstd_debug_parse_dev(ctx.h, C.byref(self.o), d_src_ptr, unit_off.ctypes.data, n, seqs.ctypes.data,
-                                                len(seqs), first.ctypes.data, extra.ctypes.data, blk_cap, C.byref(nb)))
+                                                len(seqs), first.ctypes.data, extra.ctypes.data, flags.ctypes.data, blk_cap,
+                                                C.byref(nb)))
+        self.last_block_flags = flags[:nb.value].copy()
         return [(seqs[int(first[b]):int(first[b + 1])].copy(), int(extra[b])) for b in range(nb.value)]
 
     def Close(self):

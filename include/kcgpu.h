@@ -104,10 +104,11 @@ kc_status kc_xxh64_units_dev(kc_ctx* ctx, const uint8_t* d_src, const uint64_t* 
 
 /* Debug/inspection (parity of intermediates): run only the match finder on device-resident units and
  * return, for every block, the sequence list as (litLen, matchLen, offset) u32 triples.
- * blk_first_seq has n_blocks+1 entries.  Buffers are HOST memory. */
+ * blk_first_seq has n_blocks+1 entries; blk_flags (may be NULL) receives KC_BF_* verdict bits in bits 0..7 and
+ * the number of speculative probe rounds in bits 8..31.  Buffers are HOST memory. */
 kc_status kc_zstd_debug_parse_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
                                   uint32_t n_units, uint32_t* seqs, uint64_t seq_cap, uint64_t* blk_first_seq,
-                                  uint32_t* blk_extra_lits, uint32_t blk_cap, uint32_t* n_blocks_out);
+                                  uint32_t* blk_extra_lits, uint32_t* blk_flags, uint32_t blk_cap, uint32_t* n_blocks_out);
 
 /* ---- S2: N independent blocks, each == s2.Encode(nil, block) (varint length + body) ---- */
 int64_t kc_s2_max_encoded_len(int64_t src_len);
