@@ -38,7 +38,7 @@ struct kc_ctx {
     std::string err;
     hipDeviceProp_t prop;
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
-        predef, errflag, tmp_src, tmp_dst, tables;
+        predef, errflag, tmp_src, tmp_dst, tables, prof;
     bool predef_ready = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     kc_timings last = {0, 0, 0, 0, 0};
@@ -172,7 +172,7 @@ void kc_ctx_destroy(kc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
-                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables};
+                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
@@ -331,6 +331,13 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     ep.full_zero = o->full_zero;
     ep.dict_id = o->dict_id;
     ep.err_flag = (uint32_t*)c->errflag.p;
+    ep.prof = nullptr;
+    const bool k2prof = getenv("KC_K2_PROF") != nullptr;
+    if (k2prof) {
+        if ((s = ensure(c, c->prof, 32 * 8)) != KC_OK) return s;
+        HIPCHK(c, hipMemsetAsync(c->prof.p, 0, 32 * 8, st));
+        ep.prof = (unsigned long long*)c->prof.p;
+    }
 
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (o->crc) kc_launch_xxh64(d_src, mp.unit_off, n_units, (uint64_t*)c->xxh.p, st);
@@ -397,6 +404,15 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     c->last.other_ms += t01 + t34 + t45;
     c->last.total_ms += t01 + t12 + t23 + t34 + t45;
     c->last.redo_units += redo_units;
+    if (k2prof) {
+        unsigned long long pv[32];
+        HIPCHK(c, hipMemcpy(pv, c->prof.p, sizeof(pv), hipMemcpyDeviceToHost));
+        unsigned long long tot = 0;
+        for (int i = 0; i < 16; i++) tot += pv[i];
+        fprintf(stderr, "[K2 prof] shader-clock share per phase:");
+        for (int i = 0; i < 14; i++) fprintf(stderr, " p%d=%.1f%%", i, tot ? 100.0 * (double)pv[i] / (double)tot : 0.0);
+        fprintf(stderr, "  (total %.3g cycles over %u units)\n", (double)tot, n_units);
+    }
     *produced = out_off_host[n_units];
     return KC_OK;
 }

@@ -47,6 +47,7 @@ struct KcEntropyParams {
     int32_t crc, single, no_entropy, all_lit_entropy, full_zero;
     uint32_t dict_id;
     uint32_t* err_flag;     // device: set non-zero on a device-side invariant violation
+    unsigned long long* prof;  // device or null: per-phase shader-clock totals (diagnostics, KC_K2_PROF=1)
 };
 size_t kc_fse_predef_bytes();
 void kc_launch_fse_predef_init(void* d_predef, hipStream_t st);

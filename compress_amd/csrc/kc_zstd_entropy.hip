@@ -25,7 +25,7 @@
 #include "kc_huf_dev.h"
 
 #define ET 256            // threads per workgroup
-#define SEQ_CHUNK 2048    // sequences staged in LDS per FSE chain chunk
+#define SEQ_CHUNK 1024    // sequences staged in LDS per FSE chain chunk
 #define LONG_RUN 48       // literal runs longer than this are copied cooperatively
 #define LONG_CAP 64
 
@@ -263,7 +263,7 @@ __device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, i
 // ---------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) {
+__global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams P) {
     __shared__ Shared S;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : blockIdx.x;
@@ -293,6 +293,9 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
         }
     }
     int opos = 0;  // bytes written to the staging area (wave-uniform, tracked by every thread)
+    long long pt0 = 0;
+#define PROF_MARK(i) do { if (P.prof && tid == 0) { const long long t1__ = clock64(); atomicAdd(&P.prof[i], (unsigned long long)(t1__ - pt0)); pt0 = t1__; } } while (0)
+    if (P.prof && tid == 0) pt0 = clock64();
     // ---- frame header (frameenc.go:25-92; encoder.go:756-772) ----
     if (ulen > 0) {
         bool single = ulen <= P.window_size && ulen > 1024;
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
             continue;
         }
 
+        PROF_MARK(0);
         // ==================== compressed block attempt ====================
         // ---------- 1. gather literals + histogram ----------
         for (int i = tid; i < 4 * 256; i += ET) ((uint32_t*)S.whist)[i] = 0;
@@ -434,6 +438,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
         }
         __syncthreads();  // also makes the gathered literals visible workgroup-wide
 
+        PROF_MARK(1);
         // ---------- 2. huff0.compress decisions (compress.go:43-163) ----------
         const bool wantHuf = !noEntropy && nlit > 16;
         const bool four = nlit >= 1024;
@@ -466,6 +471,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
                 const int anyBad = __syncthreads_or(bad ? 1 : 0);
                 if (tid == 0) S.ivar[IV_CANREUSE] = anyBad ? 0 : 1;
             }
+            PROF_MARK(2);
             // huffSort as a parallel rank: stable by (count desc, symbol asc)
             if (tid < symbolLen) {
                 const uint32_t c = S.cnt[tid];
@@ -484,6 +490,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
                 S.ivar[IV_TABLOG] = tl;
             }
             __syncthreads();
+            PROF_MARK(3);
             // estimateSize for old/new tables (huff0.go:308) — block reduction of nBits*count
             {
                 const uint32_t c = tid < symbolLen ? S.cnt[tid] : 0u;
@@ -513,6 +520,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
             const bool usePrev = S.ivar[IV_USEPREV] != 0;
             const KcHufTable* T = usePrev ? &S.huf.prev : &S.cur;
             const int descLen = S.ivar[IV_DESCLEN];
+            PROF_MARK(4);
             // ---- size pass: exact stream sizes with table T ----
             const int nstreams = four ? 4 : 1;
             const int segSize = four ? (nlit + 3) / 4 : nlit;
@@ -560,6 +568,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
                 S.ivar[IV_DATALEN] = outLen;
             }
             __syncthreads();
+            PROF_MARK(5);
             const int litMode = S.ivar[IV_LITMODE];
             if (litMode >= 2) {
                 single = !four;
@@ -614,6 +623,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
         }
         __syncthreads();
 
+        PROF_MARK(6);
         // ---------- 3. sequence codes + histograms (genCodes, blockenc.go:831-893) ----------
         for (int i = tid; i < 3 * 64; i += ET) ((uint32_t*)S.shist)[i] = 0;
         if (tid < 3) S.smax[tid] = 0;
@@ -634,6 +644,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
             if (lane == 0) { atomicMax(&S.smax[0], mll); atomicMax(&S.smax[1], mof); atomicMax(&S.smax[2], mml); }
         }
         __syncthreads();
+        PROF_MARK(7);
         // ---------- 4. normalizeCount + buildCTable for the three "cur" encoders (one lane each) ----------
         if (lane == 0 && wv < 3) {
             const int k = wv;
@@ -656,6 +667,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
             }
         }
         __syncthreads();
+        PROF_MARK(8);
         // ---------- 5. mode choice, mode byte, NCount headers (blockenc.go:633-722) ----------
         if (tid == 0) {
             uint8_t* h = S.seqhdr;
@@ -719,6 +731,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
         __syncthreads();
         const KcFseT* E[3] = {&S.fse[S.useIdx[0]], &S.fse[S.useIdx[1]], &S.fse[S.useIdx[2]]};
         const int seqhdrLen = S.seqhdrLen;
+        PROF_MARK(9);
         // ---------- 6. FSE state chains + bit packing, chunk by chunk from the last sequence ----------
         // Stream element order (blockenc.go:725-807): element 0 = last sequence (extra bits only, states
         // initialised), elements 1..n-1 = sequences n-2..0 (OF, ML, LL state bits then extra bits with LL
@@ -745,6 +758,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
                 S.codes[2][j] = (uint8_t)kc_ml_code(seq_ml(s));
             }
             __syncthreads();
+            PROF_MARK(10);
             if (lane == 0 && wv < 3) {
                 const int k = wv;
                 const KcFseT* f = E[k];
@@ -755,16 +769,30 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
                     S.sbits[k][0] = 0;
                     j = 1;
                 }
-                for (; j < cn; j++) {
-                    const uint32_t c = S.codes[k][j];
-                    const uint32_t nbBitsOut = ((uint32_t)st + f->dnb[c]) >> 16;
-                    const int32_t dstState = (int32_t)(st >> (nbBitsOut & 15)) + (int32_t)f->dfs[c];
-                    S.sbits[k][j] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
-                    st = f->st[dstState];
+                // Software-pipelined tANS chain: the symbol-transform fields of the NEXT code are loaded
+                // before the current step's dependent state-table lookup, so each step costs one LDS
+                // round trip (stateTable[dst]) instead of three.
+                if (j < cn) {
+                    const uint8_t* __restrict__ cod = S.codes[k];
+                    uint16_t* __restrict__ sb = S.sbits[k];
+                    uint32_t c = cod[j];
+                    uint32_t d = f->dnb[c];
+                    int32_t fs = (int32_t)f->dfs[c];
+                    for (; j < cn; j++) {
+                        const uint32_t cn1 = (j + 1 < cn) ? cod[j + 1] : c;
+                        const uint32_t dn = f->dnb[cn1];
+                        const int32_t fsn = (int32_t)f->dfs[cn1];
+                        const uint32_t nbBitsOut = ((uint32_t)st + d) >> 16;
+                        const int32_t dstState = (int32_t)(st >> (nbBitsOut & 15)) + fs;
+                        sb[j] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
+                        st = f->st[dstState];
+                        c = cn1; d = dn; fs = fsn;
+                    }
                 }
                 S.state[k] = st;
             }
             __syncthreads();
+            PROF_MARK(11);
             // pack this chunk
             for (int t0 = 0; t0 < cn; t0 += ET) {
                 const int j = t0 + tid;
@@ -799,6 +827,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
             }
             __syncthreads();
         }
+        PROF_MARK(12);
         int seqStreamBytes = 0;
         if (!overflow) {
             // final states: ml.flush, of.flush, ll.flush, end mark (blockenc.go:804-807)
@@ -854,6 +883,7 @@ __global__ __launch_bounds__(ET) void kc_zstd_entropy_kernel(KcEntropyParams P) 
         }
         opos += 3 + bodyLen;
         __syncthreads();
+        PROF_MARK(13);
     }
 
     // ---- zero-length input (encoder.go:732-753) is handled on the host; checksum (enc_base.go:34-38) ----

@@ -584,6 +584,9 @@ __device__ __forceinline__ int grp_backlen(const uint8_t* __restrict__ base, int
     return cnt < kmax ? cnt : kmax;
 }
 
+#ifndef ZG_W0
+#define ZG_W0 4  // initial speculation width after a match
+#endif
 template <int G>
 __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P, uint32_t* __restrict__ tables, uint32_t n_launch) {
     constexpr int UPW = 64 / G;
@@ -601,6 +604,14 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const bool HIST = ulen > bs;
     const uint32_t pm = (gact && P.popmask) ? P.popmask[u] : 0u;
     uint32_t* __restrict__ tab = tables + (size_t)ui * (1u << ZF_TABLE_BITS);  // zeroed by the host before the launch
+    // Table entry = (position+1) in the low PB bits | a TB-bit tag of the 4 source bytes at that position.
+    // The reference accepts a candidate iff its 4 bytes equal the probe's (tableEntry.val == uint32(cv),
+    // enc_fast.go:176,188); a tag mismatch proves they differ, so the (random, HBM-bound) candidate fetch is
+    // skipped exactly when the reference would reject anyway; equal tags are still verified on the bytes.
+    const int PB = ulen > 16 ? bits_len32((uint32_t)(ulen - 6)) : 5;
+    const int TB = (32 - PB) > 16 ? 16 : (32 - PB);
+    const uint32_t posMask = (PB >= 32) ? 0xFFFFFFFFu : ((1u << PB) - 1u);
+    auto tagOf = [&](uint32_t v) -> uint32_t { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; };
 
     int o1 = 1, o2 = 4;
     for (int b = 0; b < nblk; b++) {  // group-uniform trip count; groups diverge freely
@@ -622,13 +633,14 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
         if (srcLen >= 10) {
             const int sLimit = blkEnd - 8;
             bool canRep = false, fin = false, pendO2 = false;
+            int W = G;  // speculation width: narrow right after a match (hits come early in text), doubling on a miss
             while (!fin) {
                 rounds++;
                 const int d0 = s - nextEmit;
                 const int k0 = d0 >> 5;
                 const int step = 2 + k0;
                 const int p = s + lig * step;
-                const bool valid = (lig == 0 || ((d0 + (lig - 1) * step) >> 5) == k0) && p < sLimit;
+                const bool valid = lig < W && (lig == 0 || ((d0 + (lig - 1) * step) >> 5) == k0) && p < sLimit;
                 const uint64_t cv = valid ? ld64(base + p) : 0ull;
                 if (pendO2) {  // offset-2 check (enc_fast.go:250) sharing this round's source load
                     pendO2 = false;
@@ -637,8 +649,9 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     const uint64_t cv0 = gbcast64<G>(cv, grp, 0);
                     if (w2 == (uint32_t)cv0) {
                         const int l2 = 4 + grp_matchlen<G>(base, s + 4, o2pos + 4, blkEnd - (s + 4), lig, grp);
-                        if (lig == 0) tab[hash6(cv0, ZF_TABLE_BITS)] = (uint32_t)s + 1u;
+                        if (lig == 0) tab[hash6(cv0, ZF_TABLE_BITS)] = ((uint32_t)s + 1u) | (PB < 32 ? tagOf((uint32_t)cv0) << PB : 0u);
                         emit(0, l2 - 3, 1u);
+                        W = ZG_W0;
                         s += l2;
                         nextEmit = s;
                         const int tmp = o1; o1 = o2; o2 = tmp;
@@ -665,9 +678,10 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 if (valid) {
                     const int repIndex = p - o1 + 2;
                     const bool repOk = canRep && repIndex >= 0;
-                    const int t0 = (int)c0 - 1, t1 = (int)c1 - 1;
-                    const bool ok0 = c0 != 0 && (p - t0) < mmo;
-                    const bool ok1 = c1 != 0 && (p - t1 + 1) < mmo;
+                    const uint32_t e0 = c0 & posMask, e1 = c1 & posMask;
+                    const int t0 = (int)e0 - 1, t1 = (int)e1 - 1;
+                    const bool ok0 = e0 != 0 && (p - t0) < mmo && (PB >= 32 || (c0 >> PB) == tagOf((uint32_t)cv));
+                    const bool ok1 = e1 != 0 && (p - t1 + 1) < mmo && (PB >= 32 || (c1 >> PB) == tagOf((uint32_t)(cv >> 8)));
                     const uint32_t wr = ld32(base + (repOk ? repIndex : p));
                     const uint32_t w0 = ld32(base + (ok0 ? t0 : p));
                     const uint32_t w1 = ld32(base + (ok1 ? t1 : p));
@@ -685,10 +699,11 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 const int f = found ? __builtin_ctz(hmc) : 0;
                 const int commitUpTo = found ? f : ((c < nvalid ? c : nvalid) - 1);
                 if (valid && lig <= commitUpTo) {
-                    tab[h0] = (uint32_t)p + 1u;
-                    tab[h1] = (uint32_t)p + 2u;  // program order: wins when h0 == h1
+                    tab[h0] = ((uint32_t)p + 1u) | (PB < 32 ? tagOf((uint32_t)cv) << PB : 0u);
+                    tab[h1] = ((uint32_t)p + 2u) | (PB < 32 ? tagOf((uint32_t)(cv >> 8)) << PB : 0u);  // program order: wins when h0 == h1
                 }
                 if (!found) {
+                    W = (2 * W < G) ? 2 * W : G;
                     if (c < nvalid) {
                         s = s + c * step;
                     } else {
@@ -717,6 +732,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     const int back = grp_backlen<G>(base, start, repIndex, kmax, lig, grp);
                     start -= back;
                     emit(start - nextEmit, length - 3 + back, 1u);
+                    W = ZG_W0;
                     s = ps + length + 2;
                     nextEmit = s;
                     if (s >= sLimit) fin = true;
@@ -738,6 +754,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     l += back;
                 }
                 emit(s - nextEmit, l - 3, (uint32_t)(s - mt) + 3u);
+                W = ZG_W0;
                 s += l;
                 nextEmit = s;
                 const bool canRepO2 = HIST ? canRep : (nseq > 2);

@@ -1,0 +1,50 @@
+// Package s2gpu adapts the MI355X engine to s2.WriterCustomEncoder (s2/writer.go:1053-1064)
+// and offers the batched block form.  Source only (no Go toolchain in the build image).
+package s2gpu
+
+/*
+#cgo LDFLAGS: -lkcgpu
+#include "kcgpu.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"unsafe"
+)
+
+type Ctx struct{ c *C.kc_ctx }
+
+func NewCtx(device int) (*Ctx, error) {
+	var c *C.kc_ctx
+	if st := C.kc_ctx_create(&c, C.int(device), nil); st != C.KC_OK {
+		return nil, errors.New("no MI355X device")
+	}
+	return &Ctx{c}, nil
+}
+
+func (x *Ctx) Close() { C.kc_ctx_destroy(x.c) }
+
+// CustomEncoder returns the function to pass to s2.WriterCustomEncoder: bytes used, 0 = incompressible,
+// <0 = use the built-in encoder.
+func CustomEncoder(x *Ctx) func(dst, src []byte) int {
+	return func(dst, src []byte) int {
+		if len(src) == 0 || len(dst) == 0 {
+			return -1
+		}
+		return int(C.kc_s2_encode_block(x.c, (*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)),
+			(*C.uint8_t)(unsafe.Pointer(&src[0])), C.uint64_t(len(src))))
+	}
+}
+
+// EncodeBlocks == N x s2.Encode(nil, src[off[i]:off[i+1]]).
+func EncodeBlocks(x *Ctx, src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
+	n := len(off) - 1
+	outOff := make([]uint64, n+1)
+	st := C.kc_s2_encode_blocks(x.c, (*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
+		(*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
+	if st != C.KC_OK {
+		return nil, nil, errors.New(C.GoString(C.kc_last_error(x.c)))
+	}
+	return dst[:outOff[n]], outOff, nil
+}

@@ -1,0 +1,156 @@
+// Package zstdgpu is the cgo shim that lets klauspost/compress users route batched
+// EncodeAll work to the MI355X engine (libkcgpu.so, include/kcgpu.h).  Source only: the
+// build image has no Go toolchain.  The GPU path and the reference path produce the same
+// bytes; anything the device path does not implement falls back to the reference encoder.
+package zstdgpu
+
+/*
+#cgo LDFLAGS: -lkcgpu
+#include <stdlib.h>
+#include "kcgpu.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"unsafe"
+
+	"github.com/klauspost/compress/zstd"
+)
+
+// Option mirrors zstd.EOption for the options that change output bytes.
+type Option func(e *Encoder) error
+
+type Encoder struct {
+	ctx     *C.kc_ctx
+	opts    C.kc_zstd_opts
+	cpuOpts []zstd.EOption
+	cpu     *zstd.Encoder
+}
+
+func WithEncoderLevel(l zstd.EncoderLevel) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithEncoderLevel(l))
+		if C.kc_zstd_opts_level(&e.opts, C.int(l)) != 0 {
+			return errors.New("unknown encoder level")
+		}
+		return nil
+	}
+}
+
+func WithWindowSize(n int) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithWindowSize(n))
+		if C.kc_zstd_opts_window(&e.opts, C.int(n)) != 0 {
+			return errors.New("invalid window size")
+		}
+		return nil
+	}
+}
+
+func WithEncoderCRC(b bool) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithEncoderCRC(b))
+		C.kc_zstd_opts_crc(&e.opts, boolInt(b))
+		return nil
+	}
+}
+
+func WithZeroFrames(b bool) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithZeroFrames(b))
+		C.kc_zstd_opts_zero_frames(&e.opts, boolInt(b))
+		return nil
+	}
+}
+
+func WithSingleSegment(b bool) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithSingleSegment(b))
+		C.kc_zstd_opts_single_segment(&e.opts, boolInt(b))
+		return nil
+	}
+}
+
+func boolInt(b bool) C.int {
+	if b {
+		return 1
+	}
+	return 0
+}
+
+// New creates an encoder bound to GPU `device`. If no device is present the encoder still works
+// through the reference implementation.
+func New(device int, opts ...Option) (*Encoder, error) {
+	e := &Encoder{}
+	C.kc_zstd_opts_default(&e.opts)
+	for _, o := range opts {
+		if err := o(e); err != nil {
+			return nil, err
+		}
+	}
+	cpu, err := zstd.NewWriter(nil, e.cpuOpts...)
+	if err != nil {
+		return nil, err
+	}
+	e.cpu = cpu
+	if st := C.kc_ctx_create(&e.ctx, C.int(device), nil); st != C.KC_OK {
+		e.ctx = nil // CPU only
+	}
+	return e, nil
+}
+
+func (e *Encoder) Close() {
+	if e.ctx != nil {
+		C.kc_ctx_destroy(e.ctx)
+		e.ctx = nil
+	}
+	e.cpu.Close()
+}
+
+// MaxEncodedSize == (*zstd.Encoder).MaxEncodedSize.
+func (e *Encoder) MaxEncodedSize(size int) int {
+	return int(C.kc_zstd_max_encoded_size(&e.opts, C.int64_t(size)))
+}
+
+// EncodeAll == (*zstd.Encoder).EncodeAll for one unit (prefer EncodeUnits).
+func (e *Encoder) EncodeAll(src, dst []byte) []byte {
+	out, _, err := e.EncodeUnits(src, []uint64{0, uint64(len(src))}, nil)
+	if err != nil {
+		return e.cpu.EncodeAll(src, dst)
+	}
+	return append(dst, out...)
+}
+
+// EncodeUnits encodes src[off[i]:off[i+1]] as independent frames, each identical to EncodeAll(unit, nil).
+func (e *Encoder) EncodeUnits(src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
+	n := len(off) - 1
+	need := 0
+	for i := 0; i < n; i++ {
+		need += (e.MaxEncodedSize(int(off[i+1]-off[i])) + 15) &^ 15
+	}
+	if cap(dst) < need+64 {
+		dst = make([]byte, need+64)
+	}
+	dst = dst[:cap(dst)]
+	outOff := make([]uint64, n+1)
+	if e.ctx != nil && n > 0 && len(src) > 0 {
+		st := C.kc_zstd_encode_units(e.ctx, &e.opts,
+			(*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
+			(*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
+		if st == C.KC_OK {
+			return dst[:outOff[n]], outOff, nil
+		}
+		if st != C.KC_ERR_UNSUPPORTED && st != C.KC_ERR_NO_DEVICE {
+			return nil, nil, errors.New(C.GoString(C.kc_last_error(e.ctx)))
+		}
+	}
+	// reference path
+	out := dst[:0]
+	for i := 0; i < n; i++ {
+		outOff[i] = uint64(len(out))
+		out = e.cpu.EncodeAll(src[off[i]:off[i+1]], out)
+	}
+	outOff[n] = uint64(len(out))
+	return out, outOff, nil
+}
