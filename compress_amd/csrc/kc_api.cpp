@@ -15,8 +15,6 @@
 #include "../../include/kcgpu.h"
 #include "kc_kernels.h"
 
-extern "C" kc_status kc_s2_encode_blocks_dev_impl(kc_ctx* ctx, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
-                                                  uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
 
 namespace {
 
@@ -566,10 +564,60 @@ int64_t kc_s2_max_encoded_len(int64_t srcLen) {  // s2/encode.go:389-418 (64-bit
     return (int64_t)n;
 }
 
-kc_status kc_s2_encode_blocks_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* d_dst,
+kc_status kc_s2_encode_blocks_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
                                   uint64_t dst_cap, uint64_t* out_off) {
-    if (!c) return KC_ERR_BAD_ARG;
-    return kc_s2_encode_blocks_dev_impl(c, d_src, blk_off, n_blocks, d_dst, dst_cap, out_off);
+    if (!c || !blk_off || !out_off || (n && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
+    c->err.clear();
+    c->last = kc_timings{0, 0, 0, 0, 0};
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0) { out_off[0] = 0; return KC_OK; }
+    hipStream_t st = c->stream;
+    std::vector<uint64_t> rel(n + 1), so(n + 1);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (blk_off[i + 1] < blk_off[i]) { c->err = "blk_off not ascending"; return KC_ERR_BAD_ARG; }
+        const uint64_t len = blk_off[i + 1] - blk_off[i];
+        if (len > (uint64_t)(4 << 20)) { c->err = "S2 block larger than 4 MiB (s2.maxBlockSize) not served by the device path"; return KC_ERR_UNSUPPORTED; }
+        rel[i] = blk_off[i] - blk_off[0];
+        so[i] = acc;
+        acc += ((uint64_t)kc_s2_max_encoded_len((int64_t)len) + 15) & ~(uint64_t)15;
+    }
+    rel[n] = blk_off[n] - blk_off[0];
+    so[n] = acc;
+    if (acc > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
+    kc_status s;
+    if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) || (s = ensure(c, c->out_off, (n + 1) * 8)) ||
+        (s = ensure(c, c->stage, acc + 64)) || (s = ensure(c, c->out_size, (size_t)n * 4)) ||
+        (s = ensure(c, c->tables, (size_t)n * kc_s2_table_bytes())))
+        return s;
+    HIPCHK(c, hipMemcpyAsync(c->unit_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->stage_off.p, so.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(), st));
+    KcS2Params P;
+    P.src = d_src + blk_off[0];
+    P.blk_off = (const uint64_t*)c->unit_off.p;
+    P.stage_off = (const uint64_t*)c->stage_off.p;
+    P.stage = (uint8_t*)c->stage.p;
+    P.out_size = (uint32_t*)c->out_size.p;
+    P.tables = (uint32_t*)c->tables.p;
+    P.n_blocks = n;
+    kc_launch_s2_encode(P, st);
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n, (uint64_t*)c->out_off.p, st);
+    kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p, (const uint32_t*)c->out_size.p,
+                      (const uint64_t*)c->out_off.p, d_dst, n, st);
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    HIPCHK(c, hipMemcpyAsync(out_off, c->out_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    float t01 = 0, t12 = 0;
+    (void)hipEventElapsedTime(&t01, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
+    c->last.match_ms = t01;
+    c->last.other_ms = t12;
+    c->last.total_ms = t01 + t12;
+    return KC_OK;
 }
 
 kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* dst, uint64_t dst_cap,
@@ -608,7 +656,8 @@ int64_t kc_s2_encode_block(kc_ctx* c, uint8_t* dst, uint64_t dst_cap, const uint
     while (tmp[h] & 0x80) h++;
     h++;
     const uint64_t body = oo[1] - h;
-    const uint64_t storedLen = src_len + (src_len < 60 ? 1 : (src_len < (1 << 8) ? 2 : (src_len < (1 << 16) ? 3 : (src_len < (1 << 24) ? 4 : 5))));
+    const uint64_t nm1 = src_len - 1;  // emitLiteral header size depends on len-1 (encode_go.go:86-113)
+    const uint64_t storedLen = src_len + (nm1 < 60 ? 1 : (nm1 < (1 << 8) ? 2 : (nm1 < (1 << 16) ? 3 : (nm1 < (1 << 24) ? 4 : 5))));
     if (body == storedLen && src_len >= 32) return 0;  // encodeBlock returned 0 -> stored
     if (src_len < 32) return 0;                        // encodeBlock: len < minNonLiteralBlockSize -> 0
     if (body > dst_cap) return -1;

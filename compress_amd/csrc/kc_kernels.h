@@ -53,6 +53,19 @@ size_t kc_fse_predef_bytes();
 void kc_launch_fse_predef_init(void* d_predef, hipStream_t st);
 void kc_launch_zstd_entropy(const KcEntropyParams& P, uint32_t grid, hipStream_t st);
 
+// ---- S2 block encoder (kc_s2.hip) ----
+struct KcS2Params {
+    const uint8_t* src;
+    const uint64_t* blk_off;    // device, n+1
+    const uint64_t* stage_off;  // device, n+1 (16-byte aligned slots of MaxEncodedLen)
+    uint8_t* stage;
+    uint32_t* out_size;
+    uint32_t* tables;           // n x 2^14 u32, zeroed by the caller
+    uint32_t n_blocks;
+};
+void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st);
+static inline size_t kc_s2_table_bytes() { return (size_t)4 << 14; }
+
 // ---- misc (kc_misc.hip) ----
 void kc_launch_xxh64(const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out, hipStream_t st);
 // exclusive scan of sizes (u32) into offsets (u64, n+1 entries)

@@ -1,7 +1,339 @@
-// kc_s2.hip — S2 block encoder kernels (placeholder until the S2 milestone lands).
+// kc_s2.hip — S2 block encoder for gfx950: N independent blocks, each == s2.Encode(nil, block).
+//
+// Replaces s2.Encode (s2/encode.go:29-56), encodeBlockGo / encodeBlockGo64K
+// (s2/encode_all.go:72-284 / 287-500) and emitLiteral / emitRepeat / emitCopy
+// (s2/encode_go.go:80-234).  Parity target is the portable Go encoder (build tag noasm), NOT the
+// amd64 assembly variant.
+//
+// Same execution scheme as the zstd match finder (kc_zstd_match.hip, v3): 8 lanes per block,
+// 8 blocks per wave, speculative probing of the next probe steps of the current skip segment with
+// ordered commit, hash table (2^14 x u32) per block in an HBM scratch arena.  S2 has no entropy
+// stage: the group emits the tag bytes and literal runs directly into the block's staging slot.
+// Differences from the zstd parse that are reproduced literally:
+//   * three positions are hashed per probe step (s, s+1, s+2); the s+2 bucket is read AFTER the
+//     s and s+1 buckets were written (encode_all.go:327-401), and is written only on some paths;
+//   * table entries carry no validity: an empty (zero) slot means "candidate = position 0" and is
+//     verified on the bytes only (App. A-20b);
+//   * the repeat check at s+1 is always armed (repeat starts at 1), its forward extension stops at
+//     sLimit, the regular one at len-8, both in whole 8-byte steps with no byte tail;
+//   * incompressible bail-outs against dstLimit = len - len>>5 - 5 (App. A-20).
+// Table entry layout: position in the low PB bits, a tag of the 4 source bytes at that position
+// above; a zero entry is the empty slot and is never filtered by its tag.
 #include "kc_dev.h"
 #include "kc_kernels.h"
-#include "../../include/kcgpu.h"
-extern "C" kc_status kc_s2_encode_blocks_dev_impl(kc_ctx*, const uint8_t*, const uint64_t*, uint32_t, uint8_t*, uint64_t, uint64_t*) {
-    return KC_ERR_UNSUPPORTED;
+
+#define S2_TABLE_BITS 14
+#define S2G 8
+
+__device__ __forceinline__ uint32_t s2g_ballot(bool p, int grp) { return (uint32_t)((ballot64(p) >> (grp * S2G)) & 0xFFull); }
+__device__ __forceinline__ uint32_t s2g_bcast32(uint32_t v, int grp, int srcLig) { return (uint32_t)__shfl((int)v, grp * S2G + srcLig, 64); }
+__device__ __forceinline__ uint64_t s2g_bcast64(uint64_t v, int grp, int srcLig) {
+    const int src = grp * S2G + srcLig;
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Forward extension in whole 8-byte steps: positions a (ahead) and b (behind) advance together while
+// a <= limit (encode_all.go:353-360 with limit = sLimit, :435-442 with limit = len-8).  Returns the new a.
+__device__ __forceinline__ int s2_extend(const uint8_t* __restrict__ base, int a, int b, int limit, int lig, int grp) {
+    for (;;) {
+        const int pa = a + 8 * lig, pb = b + 8 * lig;
+        const bool inb = pa <= limit;
+        uint64_t diff = 0;
+        if (inb) diff = ld64(base + pa) ^ ld64(base + pb);
+        const uint32_t oob = s2g_ballot(!inb, grp);       // lanes past the limit (a suffix)
+        const uint32_t dm = s2g_ballot(inb && diff != 0, grp);
+        const int firstOob = oob ? __builtin_ctz(oob) : S2G;
+        if (dm) {
+            const int fl = __builtin_ctz(dm);  // necessarily < firstOob
+            const uint64_t d = s2g_bcast64(diff, grp, fl);
+            return a + 8 * fl + (ctz64(d) >> 3);
+        }
+        if (firstOob < S2G) return a + 8 * firstOob;
+        a += 8 * S2G;
+        b += 8 * S2G;
+    }
+}
+
+// ---- emit helpers (group-uniform arguments; lane 0 writes tag bytes, all lanes copy literals) ----
+__device__ __forceinline__ int s2_emit_literal(uint8_t* __restrict__ dst, const uint8_t* __restrict__ lit, int len, int lig) {
+    if (len == 0) return 0;
+    const uint32_t n = (uint32_t)(len - 1);
+    int i;
+    if (n < 60) { i = 1; if (lig == 0) dst[0] = (uint8_t)(n << 2); }
+    else if (n < (1u << 8)) { i = 2; if (lig == 0) { dst[0] = 60 << 2; dst[1] = (uint8_t)n; } }
+    else if (n < (1u << 16)) { i = 3; if (lig == 0) { dst[0] = 61 << 2; dst[1] = (uint8_t)n; dst[2] = (uint8_t)(n >> 8); } }
+    else if (n < (1u << 24)) { i = 4; if (lig == 0) { dst[0] = 62 << 2; dst[1] = (uint8_t)n; dst[2] = (uint8_t)(n >> 8); dst[3] = (uint8_t)(n >> 16); } }
+    else { i = 5; if (lig == 0) { dst[0] = 63 << 2; dst[1] = (uint8_t)n; dst[2] = (uint8_t)(n >> 8); dst[3] = (uint8_t)(n >> 16); dst[4] = (uint8_t)(n >> 24); } }
+    for (int k = lig; k < len; k += S2G) dst[i + k] = lit[k];
+    return i + len;
+}
+// emitRepeat (encode_go.go:118); single lane writes. Returns bytes.
+__device__ inline int s2_emit_repeat1(uint8_t* dst, int offset, int length) {
+    int total = 0;
+    for (;;) {
+        length -= 4;
+        if (length <= 4) { dst[0] = (uint8_t)((uint32_t)length << 2 | 1); dst[1] = 0; return total + 2; }
+        if (length < 8 && offset < 2048) { dst[1] = (uint8_t)offset; dst[0] = (uint8_t)((uint32_t)(offset >> 8) << 5 | (uint32_t)length << 2 | 1); return total + 2; }
+        if (length < (1 << 8) + 4) { length -= 4; dst[2] = (uint8_t)length; dst[1] = 0; dst[0] = 5 << 2 | 1; return total + 3; }
+        if (length < (1 << 16) + (1 << 8)) { length -= 1 << 8; dst[3] = (uint8_t)(length >> 8); dst[2] = (uint8_t)length; dst[1] = 0; dst[0] = 6 << 2 | 1; return total + 4; }
+        const int maxRepeat = (1 << 24) - 1;
+        length -= 1 << 16;
+        int left = 0;
+        if (length > maxRepeat) { left = length - maxRepeat + 4; length = maxRepeat - 4; }
+        dst[4] = (uint8_t)(length >> 16); dst[3] = (uint8_t)(length >> 8); dst[2] = (uint8_t)length; dst[1] = 0; dst[0] = 7 << 2 | 1;
+        total += 5;
+        if (left <= 0) return total;
+        dst += 5;
+        length = left;  // tail call emitRepeat(dst[5:], offset, left)
+    }
+}
+// emitCopy (encode_go.go:172); single lane writes.
+__device__ inline int s2_emit_copy1(uint8_t* dst, int offset, int length) {
+    if (offset >= 65536) {
+        int i = 0;
+        if (length > 64) {
+            dst[4] = (uint8_t)(offset >> 24); dst[3] = (uint8_t)(offset >> 16); dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset; dst[0] = 63 << 2 | 3;
+            length -= 64;
+            if (length >= 4) return 5 + s2_emit_repeat1(dst + 5, offset, length);
+            i = 5;
+        }
+        if (length == 0) return i;
+        dst[i + 0] = (uint8_t)((uint32_t)(length - 1) << 2 | 3);
+        dst[i + 1] = (uint8_t)offset; dst[i + 2] = (uint8_t)(offset >> 8); dst[i + 3] = (uint8_t)(offset >> 16); dst[i + 4] = (uint8_t)(offset >> 24);
+        return i + 5;
+    }
+    if (length > 64) {
+        int off = 3;
+        if (offset < 2048) {
+            dst[1] = (uint8_t)offset; dst[0] = (uint8_t)((uint32_t)(offset >> 8) << 5 | (uint32_t)(8 - 4) << 2 | 1);
+            length -= 8;
+            off = 2;
+        } else {
+            dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset; dst[0] = 59 << 2 | 2;
+            length -= 60;
+        }
+        return off + s2_emit_repeat1(dst + off, offset, length);
+    }
+    if (length >= 12 || offset >= 2048) {
+        dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset; dst[0] = (uint8_t)((uint32_t)(length - 1) << 2 | 2);
+        return 3;
+    }
+    dst[1] = (uint8_t)offset; dst[0] = (uint8_t)((uint32_t)(offset >> 8) << 5 | (uint32_t)(length - 4) << 2 | 1);
+    return 2;
+}
+// sizes without writing (every lane of the group needs the byte count; only lane 0 writes)
+__device__ inline int s2_repeat_size(int offset, int length) {
+    int total = 0;
+    for (;;) {
+        length -= 4;
+        if (length <= 4) return total + 2;
+        if (length < 8 && offset < 2048) return total + 2;
+        if (length < (1 << 8) + 4) return total + 3;
+        if (length < (1 << 16) + (1 << 8)) return total + 4;
+        const int maxRepeat = (1 << 24) - 1;
+        length -= 1 << 16;
+        int left = 0;
+        if (length > maxRepeat) { left = length - maxRepeat + 4; length = maxRepeat - 4; }
+        total += 5;
+        if (left <= 0) return total;
+        length = left;
+    }
+}
+__device__ inline int s2_copy_size(int offset, int length) {
+    if (offset >= 65536) {
+        int i = 0;
+        if (length > 64) { length -= 64; if (length >= 4) return 5 + s2_repeat_size(offset, length); i = 5; }
+        if (length == 0) return i;
+        return i + 5;
+    }
+    if (length > 64) {
+        if (offset < 2048) return 2 + s2_repeat_size(offset, length - 8);
+        return 3 + s2_repeat_size(offset, length - 60);
+    }
+    if (length >= 12 || offset >= 2048) return 3;
+    return 2;
+}
+
+__device__ __forceinline__ uint32_t s2_hash6(uint64_t u) { return (uint32_t)(((u << 16) * KC_PRIME6) >> (64 - S2_TABLE_BITS)); }
+
+__global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
+    constexpr int G = S2G;
+    const int lane = (int)threadIdx.x;
+    const int lig = lane % G, grp = lane / G;
+    const uint32_t bi = blockIdx.x * (64 / G) + (uint32_t)grp;
+    const bool gact = bi < P.n_blocks;
+    const uint32_t bq = gact ? bi : 0u;
+    const uint8_t* __restrict__ src = P.src + P.blk_off[bq];
+    const int len = gact ? (int)(P.blk_off[bq + 1] - P.blk_off[bq]) : 0;
+    uint8_t* __restrict__ out = P.stage + P.stage_off[bq];
+    uint32_t* __restrict__ tab = P.tables + (size_t)bi * (1u << S2_TABLE_BITS);
+    if (!gact) return;  // whole group leaves together
+
+    // uvarint(len) header (encode.go:39)
+    int hdr = 0;
+    {
+        uint64_t x = (uint64_t)len;
+        while (x >= 0x80) { if (lig == 0) out[hdr] = (uint8_t)x | 0x80; hdr++; x >>= 7; }
+        if (lig == 0) out[hdr] = (uint8_t)x;
+        hdr++;
+    }
+    uint8_t* __restrict__ dst = out + hdr;
+    int d = 0;
+    bool stored = false;  // encodeBlock returned 0 -> emit everything as one literal
+    if (len == 0) { if (lig == 0) P.out_size[bi] = (uint32_t)hdr; return; }
+    if (len < 32) stored = true;  // minNonLiteralBlockSize
+
+    if (!stored) {
+        const int SKIP = len <= (64 << 10) ? 5 : 6;  // encodeBlockGo64K vs encodeBlockGo (encode_go.go:23-26)
+        const int PB = bits_len32((uint32_t)len);
+        const int TB = (32 - PB) > 16 ? 16 : (32 - PB);
+        const uint32_t posMask = (1u << PB) - 1u;
+        auto tagOf = [&](uint32_t v) -> uint32_t { return (v * 2654435761u) >> (32 - TB); };
+        auto mk = [&](int pos, uint32_t val) -> uint32_t { return (uint32_t)pos | (tagOf(val) << PB); };
+        const int sLimit = len - 8;
+        const int dstLimit = len - (len >> 5) - 5;
+        int nextEmit = 0, s = 1, repeat = 1;
+        bool fin = false;   // goto emitRemainder
+        while (!fin && !stored) {
+            // ---------------- speculative probe round ----------------
+            const int d0 = s - nextEmit;
+            const int k0 = d0 >> SKIP;
+            const int step = 4 + k0;
+            const int p = s + lig * step;
+            // lane i is a real probe step iff all earlier steps stayed in the skip segment and nextS(p) <= sLimit
+            const bool inseg = lig == 0 || ((d0 + (lig - 1) * step) >> SKIP) == k0;
+            const int nextS = p + ((p - nextEmit) >> SKIP) + 4;
+            const bool valid = inseg && nextS <= sLimit;
+            const bool term = inseg && nextS > sLimit;  // this step would `goto emitRemainder`
+            uint64_t cv = 0;
+            uint32_t h0 = 0xFFFFFFF0u, h1 = 0xFFFFFFF1u, h2 = 0xFFFFFFF2u, e0 = 0, e1 = 0, e2 = 0;
+            if (valid) {
+                cv = ld64(src + p);
+                h0 = s2_hash6(cv); h1 = s2_hash6(cv >> 8); h2 = s2_hash6(cv >> 16);
+                e0 = tab[h0]; e1 = tab[h1]; e2 = tab[h2];
+            }
+            bool dep = false;
+#pragma unroll
+            for (int dd = 1; dd < G; dd++) {
+                const uint32_t a0 = (uint32_t)__shfl_up((int)h0, dd, G), a1 = (uint32_t)__shfl_up((int)h1, dd, G), a2 = (uint32_t)__shfl_up((int)h2, dd, G);
+                if (lig >= dd && (a0 == h0 || a0 == h1 || a0 == h2 || a1 == h0 || a1 == h1 || a1 == h2 || a2 == h0 || a2 == h1 || a2 == h2)) dep = true;
+            }
+            int kind = 0, cand = 0;  // 1 repeat at s+1, 2 match at s, 3 match at s+1, 4 match at s+2
+            if (valid) {
+                // the s+2 bucket is read after the s / s+1 buckets were written (encode_all.go:401)
+                uint32_t e2v = e2;
+                if (h2 == h1) e2v = mk(p + 1, (uint32_t)(cv >> 8));
+                else if (h2 == h0) e2v = mk(p, (uint32_t)cv);
+                const int c0 = (int)(e0 & posMask), c1 = (int)(e1 & posMask), c2 = (int)(e2v & posMask);
+                const bool ok0 = e0 == 0 || (e0 >> PB) == tagOf((uint32_t)cv);
+                const bool ok1 = e1 == 0 || (e1 >> PB) == tagOf((uint32_t)(cv >> 8));
+                const bool ok2 = e2v == 0 || (e2v >> PB) == tagOf((uint32_t)(cv >> 16));
+                const uint32_t wr = ld32(src + (p - repeat + 1));
+                const uint32_t w0 = ok0 ? ld32(src + c0) : ~(uint32_t)cv;
+                const uint32_t w1 = ok1 ? ld32(src + c1) : ~(uint32_t)(cv >> 8);
+                const uint32_t w2 = ok2 ? ld32(src + c2) : ~(uint32_t)(cv >> 16);
+                if ((uint32_t)(cv >> 8) == wr) kind = 1;
+                else if ((uint32_t)cv == w0) { kind = 2; cand = c0; }
+                else if ((uint32_t)(cv >> 8) == w1) { kind = 3; cand = c1; }
+                else if ((uint32_t)(cv >> 16) == w2) { kind = 4; cand = c2; }
+            }
+            const uint32_t vm = s2g_ballot(valid, grp);
+            const uint32_t tm = s2g_ballot(term, grp);
+            const uint32_t depm = s2g_ballot(valid && dep, grp);
+            const uint32_t hm = s2g_ballot(kind != 0, grp);
+            const int nvalid = __popc(vm);  // valid lanes form a prefix; the terminating step (if any) is lane nvalid
+            const int c = depm ? __builtin_ctz(depm) : G;
+            const uint32_t hmc = hm & ((1u << c) - 1u);
+            const bool found = hmc != 0;
+            const int f = found ? __builtin_ctz(hmc) : 0;
+            const int commitUpTo = found ? f : ((c < nvalid ? c : nvalid) - 1);
+            if (valid && lig <= commitUpTo) {
+                const bool winner = found && lig == f;
+                tab[h0] = mk(p, (uint32_t)cv);
+                tab[h1] = mk(p + 1, (uint32_t)(cv >> 8));
+                // table[hash2] = s+2 is skipped when the step ends on the repeat or on the match at s
+                if (!(winner && (kind == 1 || kind == 2))) tab[h2] = mk(p + 2, (uint32_t)(cv >> 16));
+            }
+            if (!found) {
+                if (c < nvalid) {
+                    s = s + c * step;  // first dependent lane restarts as lane 0
+                } else if (tm & (1u << nvalid)) {
+                    fin = true;        // the step after the last committed one hits `nextS > sLimit`
+                } else {
+                    const int pl = s + (nvalid - 1) * step;  // nvalid >= 1 here
+                    s = pl + ((pl - nextEmit) >> SKIP) + 4;
+                }
+                continue;
+            }
+            const int mkind = (int)s2g_bcast32((uint32_t)kind, grp, f);
+            int candidate = (int)s2g_bcast32((uint32_t)cand, grp, f);
+            const int ps = s + f * step;
+            if (mkind == 1) {
+                // ---------------- repeat at s+1 (encode_all.go:336-384) ----------------
+                int base = ps + 1;
+                {
+                    // extend back: i = base - repeat; while base > nextEmit && i > 0 && src[i-1] == src[base-1]
+                    int i0 = base - repeat;
+                    int kmax = base - nextEmit;
+                    if (i0 < kmax) kmax = i0;
+                    const int back = grp_backlen<S2G>(src, base, i0, kmax, lig, grp);
+                    base -= back;
+                }
+                if (d + (base - nextEmit) > dstLimit) { stored = true; continue; }
+                d += s2_emit_literal(dst + d, src + nextEmit, base - nextEmit, lig);
+                const int cand2 = ps - repeat + 4 + 1;
+                s = s2_extend(src, ps + 4 + 1, cand2, sLimit, lig, grp);
+                if (nextEmit > 0) { if (lig == 0) s2_emit_repeat1(dst + d, repeat, s - base); d += s2_repeat_size(repeat, s - base); }
+                else { if (lig == 0) s2_emit_copy1(dst + d, repeat, s - base); d += s2_copy_size(repeat, s - base); }
+                nextEmit = s;
+                if (s >= sLimit) fin = true;
+                continue;
+            }
+            // ---------------- regular match (encode_all.go:387-489) ----------------
+            s = ps + (mkind - 2);
+            {
+                int kmax = candidate;  // candidate > 0
+                if (s - nextEmit < kmax) kmax = s - nextEmit;
+                const int back = grp_backlen<S2G>(src, s, candidate, kmax, lig, grp);
+                candidate -= back;
+                s -= back;
+            }
+            if (d + (s - nextEmit) > dstLimit) { stored = true; continue; }
+            d += s2_emit_literal(dst + d, src + nextEmit, s - nextEmit, lig);
+            for (;;) {
+                const int base = s;
+                repeat = base - candidate;
+                s = s2_extend(src, s + 4, candidate + 4, len - 8, lig, grp);
+                if (lig == 0) s2_emit_copy1(dst + d, repeat, s - base);
+                d += s2_copy_size(repeat, s - base);
+                nextEmit = s;
+                if (s >= sLimit) { fin = true; break; }
+                if (d > dstLimit) { stored = true; break; }
+                // check for an immediate match, otherwise start the search at s+1 (:474-488)
+                const uint64_t x = ld64(src + s - 2);
+                const uint32_t m2Hash = s2_hash6(x), currHash = s2_hash6(x >> 16);
+                const uint32_t ec = tab[currHash];
+                if (lig == 0) { tab[m2Hash] = mk(s - 2, (uint32_t)x); tab[currHash] = mk(s, (uint32_t)(x >> 16)); }
+                // make the writes visible to the group's next reads of these buckets (same wave: program order)
+                candidate = (int)(ec & posMask);
+                const bool okc = ec == 0 || (ec >> PB) == tagOf((uint32_t)(x >> 16));
+                if (!okc || (uint32_t)(x >> 16) != ld32(src + candidate)) { s++; break; }
+            }
+        }
+        if (!stored) {
+            // emitRemainder (:491-499)
+            if (nextEmit < len) {
+                if (d + len - nextEmit > dstLimit) stored = true;
+                else d += s2_emit_literal(dst + d, src + nextEmit, len - nextEmit, lig);
+            }
+        }
+    }
+    if (stored) d = s2_emit_literal(dst, src, len, lig);  // encode.go:44-55: not compressible -> one literal
+    if (lig == 0) P.out_size[bi] = (uint32_t)(hdr + d);
+}
+
+void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st) {
+    if (P.n_blocks == 0) return;
+    hipLaunchKernelGGL(kc_s2_encode_kernel, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
 }

@@ -533,57 +533,6 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P)
 // units of a 4 GiB batch are in flight at once.  Tables (2^15 x u32 position+1 per unit) live
 // in a scratch arena in HBM; conflicts inside a probe round are detected exactly by comparing
 // bucket indices across the group's lanes (no LDS at all).
-template <int G>
-__device__ __forceinline__ uint32_t gballot(bool p, int grp) {
-    return (uint32_t)((ballot64(p) >> (grp * G)) & ((1ull << G) - 1ull));
-}
-template <int G>
-__device__ __forceinline__ uint64_t gbcast64(uint64_t v, int grp, int srcLig) {
-    const int src = grp * G + srcLig;
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-template <int G>
-__device__ __forceinline__ uint32_t gbcast32(uint32_t v, int grp, int srcLig) {
-    return (uint32_t)__shfl((int)v, grp * G + srcLig, 64);
-}
-template <int G>
-__device__ __forceinline__ int grp_matchlen(const uint8_t* __restrict__ base, int a, int b, int left, int lig, int grp) {
-    int n = 0;
-    for (;;) {
-        const int words = (left - n) >> 3;
-        const int active = words < G ? words : G;
-        uint64_t diff = 0;
-        if (lig < active) diff = ld64(base + a + n + 8 * lig) ^ ld64(base + b + n + 8 * lig);
-        const uint32_t m = gballot<G>(diff != 0, grp);
-        if (m) {
-            const int fl = __builtin_ctz(m);
-            const uint64_t d = gbcast64<G>(diff, grp, fl);
-            return n + 8 * fl + (ctz64(d) >> 3);
-        }
-        n += 8 * active;
-        if (active < G) break;
-    }
-    const int tail = left - n;  // < 8 <= G
-    const bool ne = lig < tail && base[a + n + lig] != base[b + n + lig];
-    const uint32_t m = gballot<G>(ne, grp);
-    return n + (m ? __builtin_ctz(m) : tail);
-}
-template <int G>
-__device__ __forceinline__ int grp_backlen(const uint8_t* __restrict__ base, int s, int t, int kmax, int lig, int grp) {
-    int cnt = 0;
-    while (cnt < kmax) {
-        const int k = cnt + lig + 1;
-        bool ne = true;
-        if (k <= kmax) ne = base[t - k] != base[s - k];
-        const uint32_t m = gballot<G>(ne, grp);
-        const int c = m ? __builtin_ctz(m) : G;
-        cnt += c;
-        if (c < G) break;
-    }
-    return cnt < kmax ? cnt : kmax;
-}
-
 #ifndef ZG_W0
 #define ZG_W0 4  // initial speculation width after a match
 #endif

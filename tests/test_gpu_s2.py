@@ -1,0 +1,96 @@
+"""GPU parity tests for the S2 block encoder: HIP path (C ABI) vs the CPU oracle, bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import corpora
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_blocks(oracle, buf, off):
+    L = oracle.lib()
+    n = len(off) - 1
+    cap = int(sum(L.kco_s2_max_encoded_len(int(off[i + 1] - off[i])) for i in range(n))) + 64
+    dst = np.empty(cap, dtype=np.uint8)
+    oo = np.empty(n + 1, dtype=np.uint64)
+    buf = np.ascontiguousarray(buf)
+    r = L.kco_s2_encode_blocks(buf.ctypes.data, off.ctypes.data, n, dst.ctypes.data, cap, oo.ctypes.data, 8)
+    assert r >= 0
+    return dst[:r], oo
+
+
+def _check(oracle, blocks):
+    from compress_amd import s2
+    buf, off = corpora.pack_units(blocks)
+    enc = s2.BlockEncoder()
+    out, out_off = enc.EncodeBlocks(buf, off)
+    ref, ref_off = _oracle_blocks(oracle, buf, off)
+    bad = []
+    for i in range(len(blocks)):
+        a = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        b = ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()
+        if a != b:
+            bad.append((i, len(blocks[i]), len(a), len(b)))
+    assert not bad, "blocks differing from the oracle (index, in_len, gpu_len, oracle_len): %r" % bad[:10]
+    # and every block decodes back
+    for i in (0, len(blocks) // 2, len(blocks) - 1):
+        a = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        assert oracle.s2_decode(a, len(blocks[i]) + 8) == blocks[i]
+    enc.Close()
+
+
+@pytest.mark.parametrize("kind", ["J", "T", "M", "H"])
+def test_s2_64k_blocks_bit_exact(oracle, kclib, kind):
+    buf = corpora.corpus(kind, 128, 65536)
+    _check(oracle, [buf[i * 65536:(i + 1) * 65536].tobytes() for i in range(128)])
+
+
+def test_s2_edge_blocks_bit_exact(oracle, kclib):
+    _check(oracle, corpora.edge_units())
+
+
+def test_s2_large_blocks_bit_exact(oracle, kclib):
+    """Blocks > 64 KiB take encodeBlockGo (u32 table, skip >>6) in the reference."""
+    j = corpora.corpus("J", 8, 1 << 20).tobytes()
+    t = corpora.corpus("T", 8, 1 << 20).tobytes()
+    m = corpora.corpus("M", 4, 1 << 20).tobytes()
+    blocks = [j[:65537], j[:200000], t[:1 << 20], j[1 << 20:3 << 20], m[:4 << 20], t[100:700000], (b"abcd" * 300000), bytes(1 << 20)]
+    _check(oracle, blocks)
+
+
+def test_s2_custom_encoder_contract(oracle, kclib):
+    """WriterCustomEncoder contract (s2/writer.go:1053-1064): no varint header; 0 == incompressible."""
+    from compress_amd import s2
+    enc = s2.BlockEncoder()
+    fn = enc.CustomEncoder()
+    text = corpora.corpus("J", 1, 65536).tobytes()
+    dst = bytearray(s2.MaxEncodedLen(len(text)))
+    n = fn(dst, text)
+    want = oracle.s2_encode_block(text)
+    assert n == len(want) and bytes(dst[:n]) == want
+    noise = corpora.corpus("H", 1, 65536).tobytes()
+    assert fn(dst, noise) == 0
+    enc.Close()
+
+
+def test_s2_full_size_roundtrip(oracle, kclib):
+    """C4-size property check: 16384 x 64 KiB JSON blocks, device resident, sample decodes back."""
+    import torch
+    from compress_amd import s2
+    n, bsz = 16384, 65536
+    buf = corpora.corpus("J", n, bsz)
+    off = np.arange(n + 1, dtype=np.uint64) * bsz
+    d_src = torch.from_numpy(buf).cuda()
+    enc = s2.BlockEncoder()
+    cap = n * ((s2.MaxEncodedLen(bsz) + 15) & ~15) + 64
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    out_off = enc.EncodeBlocksDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    out = d_dst[:int(out_off[n])].cpu().numpy()
+    rng = np.random.default_rng(5)
+    for i in rng.choice(n, 64, replace=False):
+        blk = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        assert oracle.s2_decode(blk, bsz + 8) == buf[i * bsz:(i + 1) * bsz].tobytes()
+    assert float(out_off[n]) / (n * bsz) < 0.5
+    enc.Close()

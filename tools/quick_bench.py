@@ -20,3 +20,12 @@ for it in range(3):
     tm = enc.ctx().timings()
     print("%s %.2f GiB unit %d: %.3fs %.2f GB/s ratio %.4f match %.1f ms entropy %.1f ms other %.1f ms redo %d" % (
         kind, gib, usz, dt, len(buf) / dt / 1e9, int(oo[n]) / len(buf), tm["match_ms"], tm["entropy_ms"], tm["other_ms"], tm["redo_units"]))
+if len(sys.argv) > 4 and sys.argv[4] == "s2":
+    from compress_amd import s2
+    e2 = s2.BlockEncoder()
+    cap2 = n * ((s2.MaxEncodedLen(usz) + 15) & ~15) + 64
+    d2 = torch.empty(cap2, dtype=torch.uint8, device="cuda")
+    for it in range(3):
+        t = time.time(); oo = e2.EncodeBlocksDevice(d.data_ptr(), off, d2.data_ptr(), cap2); torch.cuda.synchronize(); dt = time.time() - t
+        tm = e2._ctx.timings()
+        print("S2 %s %.2f GiB block %d: %.3fs %.2f GB/s ratio %.4f kernel %.1f ms other %.1f ms" % (kind, gib, usz, dt, len(buf) / dt / 1e9, int(oo[n]) / len(buf), tm["match_ms"], tm["other_ms"]))
