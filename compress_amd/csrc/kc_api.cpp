@@ -212,7 +212,7 @@ struct Plan {
 };
 
 kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
-    if (o->level != KC_SPEED_FASTEST) { c->err = "device path implements SpeedFastest only in this build"; return KC_ERR_UNSUPPORTED; }
+    if (o->level != KC_SPEED_FASTEST && o->level != KC_SPEED_DEFAULT) { c->err = "device path implements SpeedFastest and SpeedDefault in this build"; return KC_ERR_UNSUPPORTED; }
     if (o->dict != nullptr || o->dict_id != 0) { c->err = "dictionary encoding not implemented on the device path"; return KC_ERR_UNSUPPORTED; }
     if (o->all_lit_entropy) { c->err = "WithAllLitEntropyCompression(true) not implemented on the device path"; return KC_ERR_UNSUPPORTED; }
     if (o->block_size < 1024 || o->block_size > kMaxCompressedBlockSize || o->window_size < kMinWindowSize) { c->err = "bad block/window size"; return KC_ERR_BAD_ARG; }
@@ -223,7 +223,14 @@ kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
 // Match-finder variant selection.  Default: sub-wave groups (8 lanes per unit, HBM tables);
 // KC_ZFAST_VARIANT=lds|v1|g8|g16 overrides (lds: packed LDS table + LDS-resident block, one wave per unit;
 // v1: u32 LDS table, source from global memory).
-kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_off, uint32_t n_units, uint32_t n_launch, int bs, hipStream_t st) {
+kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_off, uint32_t n_units, uint32_t n_launch, int bs, hipStream_t st, int level) {
+    if (level == KC_SPEED_DEFAULT) {
+        kc_status s2 = ensure(c, c->tables, (size_t)n_launch * kc_zdfast_table_bytes());
+        if (s2 != KC_OK) return s2;
+        HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * kc_zdfast_table_bytes(), st));
+        kc_launch_zdfast_match_grp(mp, (uint32_t*)c->tables.p, n_launch, st);
+        return KC_OK;
+    }
     const char* v = getenv("KC_ZFAST_VARIANT");
     std::string var = v ? v : "g8";
     if (var == "lds") {
@@ -340,7 +347,7 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (o->crc) kc_launch_xxh64(d_src, mp.unit_off, n_units, (uint64_t*)c->xxh.p, st);
     HIPCHK(c, hipEventRecord(c->ev[1], st));
-    if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, st)) != KC_OK) return s;
+    if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, st, o->level)) != KC_OK) return s;
     HIPCHK(c, hipEventRecord(c->ev[2], st));
     kc_launch_zstd_entropy(ep, n_units, st);
     HIPCHK(c, hipEventRecord(c->ev[3], st));
@@ -378,7 +385,7 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
             mp.popmask = (const uint32_t*)c->popmask.p;
             mp.unit_list = (const uint32_t*)c->unit_list.p;
             ep.unit_list = mp.unit_list;
-            if ((s = launch_match(c, mp, unit_off, n_units, (uint32_t)list.size(), bs, st)) != KC_OK) return s;
+            if ((s = launch_match(c, mp, unit_off, n_units, (uint32_t)list.size(), bs, st, o->level)) != KC_OK) return s;
             kc_launch_zstd_entropy(ep, (uint32_t)list.size(), st);
             HIPCHK(c, hipGetLastError());
         }
@@ -522,7 +529,7 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
     mp.seq_stride = seq_stride;
     mp.block_size = bs;
     mp.max_match_off = o->window_size;
-    if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, c->stream)) != KC_OK) return s;
+    if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, c->stream, o->level)) != KC_OK) return s;
     std::vector<KcBlkMeta> meta(nb);
     HIPCHK(c, hipMemcpyAsync(meta.data(), c->meta.p, (size_t)nb * sizeof(KcBlkMeta), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

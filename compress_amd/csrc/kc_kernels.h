@@ -22,6 +22,9 @@ void kc_launch_zfast_match(const KcMatchParams& P, uint32_t grid, hipStream_t st
 // sub-wave-group variant: G (8|16) lanes per unit, tables = n_launch x 2^15 x u32 in HBM, zeroed by the caller
 void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, int G, hipStream_t st);
 static inline size_t kc_zfast_table_bytes() { return (size_t)4 << 15; }
+// SpeedDefault: long (2^17) + short (2^15) u32 tables per unit in HBM, zeroed by the caller
+void kc_launch_zdfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st);
+static inline size_t kc_zdfast_table_bytes() { return ((size_t)4 << 17) + ((size_t)4 << 15); }
 
 // ---- entropy + emit (kc_zstd_entropy.hip) ----
 struct KcFsePredef;  // opaque device blob built by kc_launch_fse_predef_init

@@ -34,7 +34,8 @@ def _check_units(oracle, units, level=1):
     enc.Close()
 
 
-def test_parse_matches_oracle(oracle, kclib):
+@pytest.mark.parametrize("level", [1, 2])
+def test_parse_matches_oracle(oracle, kclib, level):
     """Intermediate artefact parity: the sequence list of every block equals the oracle's."""
     torch = _torch()
     units = [corpora.corpus("T", 1, 131072, first_unit=k).tobytes() for k in range(4)]
@@ -43,11 +44,11 @@ def test_parse_matches_oracle(oracle, kclib):
     units += [u for u in corpora.edge_units() if len(u) > 0]
     buf, off = corpora.pack_units(units)
     d = torch.from_numpy(buf).cuda()
-    enc = _enc(1)
+    enc = _enc(level)
     blocks = enc.DebugParseDevice(d.data_ptr(), off)
     bi = 0
     for ui, u in enumerate(units):
-        ref = oracle.zstd_parse_unit(u, level=1)
+        ref = oracle.zstd_parse_unit(u, level=level)
         for rb, (rseqs, rlits) in enumerate(ref):
             gseqs, gextra = blocks[bi]
             bi += 1
@@ -60,20 +61,23 @@ def test_parse_matches_oracle(oracle, kclib):
     enc.Close()
 
 
-def test_edge_units_bit_exact(oracle, kclib):
+@pytest.mark.parametrize("level", [1, 2])
+def test_edge_units_bit_exact(oracle, kclib, level):
     _torch()
-    _check_units(oracle, corpora.edge_units())
+    _check_units(oracle, corpora.edge_units(), level)
 
 
+@pytest.mark.parametrize("level", [1, 2])
 @pytest.mark.parametrize("kind", ["T", "H", "J", "M"])
-def test_corpus_units_bit_exact(oracle, kclib, kind):
+def test_corpus_units_bit_exact(oracle, kclib, kind, level):
     _torch()
     buf = corpora.corpus(kind, 96, 131072)
     units = [buf[i * 131072:(i + 1) * 131072].tobytes() for i in range(96)]
-    _check_units(oracle, units)
+    _check_units(oracle, units, level)
 
 
-def test_ragged_units_bit_exact(oracle, kclib):
+@pytest.mark.parametrize("level", [1, 2])
+def test_ragged_units_bit_exact(oracle, kclib, level):
     _torch()
     rng = np.random.default_rng(7)
     text = corpora.corpus("T", 8, 131072).tobytes()
@@ -84,7 +88,7 @@ def test_ragged_units_bit_exact(oracle, kclib):
         n = int(rng.integers(0, 300000)) if k % 5 else int(rng.integers(0, 64))
         s = int(rng.integers(0, len(src) - n))
         units.append(src[s:s + n])
-    _check_units(oracle, units)
+    _check_units(oracle, units, level)
 
 
 def test_xxh64_units(oracle, kclib):
@@ -102,14 +106,15 @@ def test_xxh64_units(oracle, kclib):
     enc.Close()
 
 
-def test_device_resident_roundtrip_full_size(oracle, kclib):
+@pytest.mark.parametrize("level", [1, 2])
+def test_device_resident_roundtrip_full_size(oracle, kclib, level):
     """BASELINE-size property check (no oracle at this size): every frame decodes back with libzstd."""
     torch = _torch()
     n, usz = 2048, 131072
     buf = corpora.corpus("T", n, usz)
     off = (np.arange(n + 1, dtype=np.uint64) * usz)
     d_src = torch.from_numpy(buf).cuda()
-    enc = _enc(1)
+    enc = _enc(level)
     cap = n * ((enc.MaxEncodedSize(usz) + 15) & ~15) + 64
     d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
     out_off = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)

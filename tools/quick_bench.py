@@ -11,7 +11,7 @@ n = int(gib * 2**30) // usz
 seed = {"T": 0x5EED0001, "H": 0x5EED0002, "J": 0x5EED0003, "M": 0x5EED0004}[kind]
 buf = _lib.corpus_fill(kind, seed, 0, n, usz)
 d = torch.from_numpy(buf).cuda()
-enc = zstd.NewWriter(None, zstd.WithEncoderLevel(zstd.SpeedFastest))
+enc = zstd.NewWriter(None, zstd.WithEncoderLevel(int(os.environ.get('KC_LEVEL', '1'))))
 off = np.arange(n + 1, dtype=np.uint64) * usz
 cap = n * ((enc.MaxEncodedSize(usz) + 15) & ~15) + 64
 dd = torch.empty(cap, dtype=torch.uint8, device="cuda")
