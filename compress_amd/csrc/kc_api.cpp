@@ -308,6 +308,9 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     mp.seq_stride = pl.seq_stride;
     mp.block_size = bs;
     mp.max_match_off = o->window_size;
+    mp.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : 1;
+    if (mp.spec_w0 < 1) mp.spec_w0 = 1;
+    if (mp.spec_w0 > 8) mp.spec_w0 = 8;
 
     KcEntropyParams ep;
     memset(&ep, 0, sizeof(ep));
@@ -529,6 +532,9 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
     mp.seq_stride = seq_stride;
     mp.block_size = bs;
     mp.max_match_off = o->window_size;
+    mp.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : 1;
+    if (mp.spec_w0 < 1) mp.spec_w0 = 1;
+    if (mp.spec_w0 > 8) mp.spec_w0 = 8;
     if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, c->stream, o->level)) != KC_OK) return s;
     std::vector<KcBlkMeta> meta(nb);
     HIPCHK(c, hipMemcpyAsync(meta.data(), c->meta.p, (size_t)nb * sizeof(KcBlkMeta), hipMemcpyDeviceToHost, c->stream));

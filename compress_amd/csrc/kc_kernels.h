@@ -16,6 +16,7 @@ struct KcMatchParams {
     uint32_t seq_stride;
     int32_t block_size;
     int32_t max_match_off;
+    int32_t spec_w0;            // initial speculation width after a match (group kernels)
 };
 // lds_variant: every unit <= 131064 bytes and block_size <= 65536 (packed 17-bit table + LDS-resident block)
 void kc_launch_zfast_match(const KcMatchParams& P, uint32_t grid, hipStream_t st, bool lds_variant);

@@ -137,7 +137,7 @@ struct Shared {
     int16_t cumul[3][66];
     uint8_t seqhdr[224];
     int seqhdrLen;
-    uint8_t codes[3][SEQ_CHUNK];     // ll / of / ml code per staged sequence
+    alignas(4) uint8_t codes[3][SEQ_CHUNK];     // ll / of / ml code per staged sequence
     uint16_t sbits[3][SEQ_CHUNK];    // state bits emitted for that sequence: nb<<12 | value
     uint16_t state[3];               // running FSE states (ll, of, ml)
     // --- scan / misc ---
@@ -769,25 +769,38 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
                     S.sbits[k][0] = 0;
                     j = 1;
                 }
-                // Software-pipelined tANS chain: the symbol-transform fields of the NEXT code are loaded
-                // before the current step's dependent state-table lookup, so each step costs one LDS
-                // round trip (stateTable[dst]) instead of three.
-                if (j < cn) {
+                // Software-pipelined tANS chain.  The only true dependence is state -> stateTable[dst] -> state;
+                // the symbol-transform fields of the next four codes are fetched (one 32-bit code word, then
+                // eight table reads issued back to back) while the current four steps run, so every step costs
+                // a single LDS round trip.
+                {
                     const uint8_t* __restrict__ cod = S.codes[k];
                     uint16_t* __restrict__ sb = S.sbits[k];
-                    uint32_t c = cod[j];
-                    uint32_t d = f->dnb[c];
-                    int32_t fs = (int32_t)f->dfs[c];
-                    for (; j < cn; j++) {
-                        const uint32_t cn1 = (j + 1 < cn) ? cod[j + 1] : c;
-                        const uint32_t dn = f->dnb[cn1];
-                        const int32_t fsn = (int32_t)f->dfs[cn1];
+                    auto stepf = [&](uint32_t d, int32_t fs, int jj) {
                         const uint32_t nbBitsOut = ((uint32_t)st + d) >> 16;
                         const int32_t dstState = (int32_t)(st >> (nbBitsOut & 15)) + fs;
-                        sb[j] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
+                        sb[jj] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
                         st = f->st[dstState];
-                        c = cn1; d = dn; fs = fsn;
+                    };
+                    for (; j < cn && (j & 3); j++) { const uint32_t c = cod[j]; stepf(f->dnb[c], (int32_t)f->dfs[c], j); }
+                    if (j + 4 <= cn) {
+                        uint32_t w = *(const uint32_t*)(cod + j);
+                        uint32_t d0 = f->dnb[w & 0xFF], d1 = f->dnb[(w >> 8) & 0xFF], d2 = f->dnb[(w >> 16) & 0xFF], d3 = f->dnb[w >> 24];
+                        int32_t f0 = f->dfs[w & 0xFF], f1 = f->dfs[(w >> 8) & 0xFF], f2 = f->dfs[(w >> 16) & 0xFF], f3 = f->dfs[w >> 24];
+                        for (; j + 4 <= cn; j += 4) {
+                            const bool more = j + 8 <= cn;
+                            const uint32_t wn = more ? *(const uint32_t*)(cod + j + 4) : 0u;
+                            const uint32_t e0 = f->dnb[wn & 0xFF], e1 = f->dnb[(wn >> 8) & 0xFF], e2 = f->dnb[(wn >> 16) & 0xFF], e3 = f->dnb[wn >> 24];
+                            const int32_t g0 = f->dfs[wn & 0xFF], g1 = f->dfs[(wn >> 8) & 0xFF], g2 = f->dfs[(wn >> 16) & 0xFF], g3 = f->dfs[wn >> 24];
+                            stepf(d0, f0, j);
+                            stepf(d1, f1, j + 1);
+                            stepf(d2, f2, j + 2);
+                            stepf(d3, f3, j + 3);
+                            d0 = e0; d1 = e1; d2 = e2; d3 = e3;
+                            f0 = g0; f1 = g1; f2 = g2; f3 = g3;
+                        }
                     }
+                    for (; j < cn; j++) { const uint32_t c = cod[j]; stepf(f->dnb[c], (int32_t)f->dfs[c], j); }
                 }
                 S.state[k] = st;
             }

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                         const int l2 = 4 + grp_matchlen<G>(base, s + 4, o2pos + 4, blkEnd - (s + 4), lig, grp);
                         if (lig == 0) tab[hash6(cv0, ZF_TABLE_BITS)] = ((uint32_t)s + 1u) | (PB < 32 ? tagOf((uint32_t)cv0) << PB : 0u);
                         emit(0, l2 - 3, 1u);
-                        W = ZG_W0;
+                        W = P.spec_w0;
                         s += l2;
                         nextEmit = s;
                         const int tmp = o1; o1 = o2; o2 = tmp;
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     const int back = grp_backlen<G>(base, start, repIndex, kmax, lig, grp);
                     start -= back;
                     emit(start - nextEmit, length - 3 + back, 1u);
-                    W = ZG_W0;
+                    W = P.spec_w0;
                     s = ps + length + 2;
                     nextEmit = s;
                     if (s >= sLimit) fin = true;
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     l += back;
                 }
                 emit(s - nextEmit, l - 3, (uint32_t)(s - mt) + 3u);
-                W = ZG_W0;
+                W = P.spec_w0;
                 s += l;
                 nextEmit = s;
                 const bool canRepO2 = HIST ? canRep : (nseq > 2);

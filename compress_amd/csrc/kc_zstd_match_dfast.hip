@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
                     const int back = grp_backlen<G>(base, start, repIndex, kmax, lig, grp);
                     start -= back;
                     emit(start - nextEmit, length - 3 + back, 1u);
-                    W = ZD_W0;
+                    W = P.spec_w0;
                     s = ps + length + 1;
                     nextEmit = s;
                     if (s >= sLimit) fin = true;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
                     l += back;
                 }
                 emit(s - nextEmit, l - 3, (uint32_t)(s - mt) + 3u);
-                W = ZD_W0;
+                W = P.spec_w0;
                 s += l;
                 nextEmit = s;
                 const bool canRepO2 = HIST ? canRep : (nseq > 2);
