@@ -36,7 +36,7 @@ struct kc_ctx {
     std::string err;
     hipDeviceProp_t prop;
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
-        predef, errflag, tmp_src, tmp_dst, tables, prof;
+        predef, errflag, tmp_src, tmp_dst, tables, prof, work, work_off, dictbuf, proto;
     bool predef_ready = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     kc_timings last = {0, 0, 0, 0, 0};
@@ -170,7 +170,7 @@ void kc_ctx_destroy(kc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
-                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof};
+                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
@@ -211,10 +211,41 @@ struct Plan {
     uint32_t seq_stride = 0, lit_stride = 0;
 };
 
+
+// Host-side construction of the dictionary-primed tables of betterFastEncoderDict.Reset
+// (zstd/enc_better.go:1114-1183) in the device entry format (position+1 | tag << pos_bits).
+void build_better_dict_tables(const uint8_t* dict, size_t len, int pos_bits, uint8_t* out) {
+    const int TB = (32 - pos_bits) > 16 ? 16 : (32 - pos_bits);
+    auto tagOf = [&](uint32_t v) -> uint32_t { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; };
+    auto mk = [&](uint64_t pos, uint32_t val) -> uint32_t { return ((uint32_t)pos + 1u) | (tagOf(val) << pos_bits); };
+    auto ld64h = [&](size_t i) -> uint64_t { uint64_t v; memcpy(&v, dict + i, 8); return v; };
+    uint32_t* ltab = (uint32_t*)out;  // pairs {offset, prev}
+    uint32_t* stab = (uint32_t*)(out + ((size_t)8 << 19));
+    if (len < 8) return;
+    // short table: every position i, i+1, i+2, i+3 for i stepping by 4 while i < len-8 (:1126-1152)
+    for (size_t i = 0; i + 8 < len; i += 4) {
+        const uint64_t cv = ld64h(i);
+        for (int k = 0; k < 4; k++) {
+            const uint64_t v = cv >> (8 * k);
+            const uint32_t h = (uint32_t)(((v << 24) * 889523592379ULL) >> (64 - 13));
+            stab[h] = mk(i + k, (uint32_t)v);
+        }
+    }
+    // long table: every position 0 .. len-9, chained (:1161-1183)
+    for (size_t i = 0; i + 8 < len || i == 0; i++) {
+        const uint64_t cv = ld64h(i);
+        const uint32_t h = (uint32_t)((cv * 0xcf1bbcdcb7a56463ULL) >> (64 - 19));
+        const uint32_t old = ltab[2 * h];
+        ltab[2 * h] = mk(i, (uint32_t)cv);
+        ltab[2 * h + 1] = old;
+        if (i + 8 >= len) break;
+    }
+}
+
 kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
-    if (o->level != KC_SPEED_FASTEST && o->level != KC_SPEED_DEFAULT) { c->err = "device path implements SpeedFastest and SpeedDefault in this build"; return KC_ERR_UNSUPPORTED; }
-    if (o->dict != nullptr || o->dict_id != 0) { c->err = "dictionary encoding not implemented on the device path"; return KC_ERR_UNSUPPORTED; }
-    if (o->all_lit_entropy) { c->err = "WithAllLitEntropyCompression(true) not implemented on the device path"; return KC_ERR_UNSUPPORTED; }
+    if (o->level < KC_SPEED_FASTEST || o->level > KC_SPEED_BETTER) { c->err = "device path implements SpeedFastest, SpeedDefault and SpeedBetterCompression"; return KC_ERR_UNSUPPORTED; }
+    if ((o->dict != nullptr && o->dict_len > 0) && o->level != KC_SPEED_BETTER) { c->err = "dictionary encoding is implemented for SpeedBetterCompression only on the device path"; return KC_ERR_UNSUPPORTED; }
+    if (o->dict_len > ((uint64_t)1 << 20)) { c->err = "dictionary larger than 1 MiB not served by the device path"; return KC_ERR_UNSUPPORTED; }
     if (o->block_size < 1024 || o->block_size > kMaxCompressedBlockSize || o->window_size < kMinWindowSize) { c->err = "bad block/window size"; return KC_ERR_BAD_ARG; }
     return KC_OK;
 }
@@ -224,6 +255,15 @@ kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
 // KC_ZFAST_VARIANT=lds|v1|g8|g16 overrides (lds: packed LDS table + LDS-resident block, one wave per unit;
 // v1: u32 LDS table, source from global memory).
 kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_off, uint32_t n_units, uint32_t n_launch, int bs, hipStream_t st, int level) {
+    if (level == KC_SPEED_BETTER) {
+        const size_t tb = kc_zbetter_table_bytes();
+        kc_status s3 = ensure(c, c->tables, (size_t)n_launch * tb);
+        if (s3 != KC_OK) return s3;
+        if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, tb, n_launch, st);  // dictionary-primed tables
+        else HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * tb, st));
+        kc_launch_zbetter_match_grp(mp, (uint8_t*)c->tables.p, n_launch, mp.hist0 > 0, st);
+        return KC_OK;
+    }
     if (level == KC_SPEED_DEFAULT) {
         kc_status s2 = ensure(c, c->tables, (size_t)n_launch * kc_zdfast_table_bytes());
         if (s2 != KC_OK) return s2;
@@ -296,10 +336,40 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 64, st));
 
     const uint8_t* d_src = d_src_base + unit_off[0];
+    // ---- dictionary (raw content, WithEncoderDictRaw): history = dict || unit (enc_base.go:189-198) ----
+    const bool useDict = o->dict != nullptr && o->dict_len > 0;
+    const int hist0 = useDict ? (int)o->dict_len : 0;
+    uint64_t maxLen = 16;
+    for (uint32_t i = 0; i < n_units; i++) maxLen = std::max<uint64_t>(maxLen, unit_off[i + 1] - unit_off[i]);
+    int pos_bits = 1;
+    while (((uint64_t)1 << pos_bits) <= (uint64_t)hist0 + maxLen + 2) pos_bits++;
+    const uint8_t* k_src = d_src;               // what the match finder / entropy kernels read
+    const uint64_t* k_off = (const uint64_t*)c->unit_off.p;
+    if (useDict) {
+        std::vector<uint64_t> woff(n_units + 1);
+        for (uint32_t i = 0; i <= n_units; i++) woff[i] = pl.rel_off[i] + (uint64_t)i * (uint64_t)hist0;
+        if ((s = ensure(c, c->work, woff[n_units] + 64)) || (s = ensure(c, c->work_off, (n_units + 1) * 8)) ||
+            (s = ensure(c, c->dictbuf, (size_t)hist0 + 64)) || (s = ensure(c, c->proto, kc_zbetter_table_bytes())))
+            return s;
+        HIPCHK(c, hipMemcpyAsync(c->work_off.p, woff.data(), (n_units + 1) * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->dictbuf.p, o->dict, (size_t)hist0, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));  // woff is a local
+        kc_launch_prefix_units(d_src, (const uint64_t*)c->unit_off.p, (const uint64_t*)c->work_off.p, (const uint8_t*)c->dictbuf.p,
+                               (uint32_t)hist0, (uint8_t*)c->work.p, n_units, st);
+        // pristine dictionary tables (betterFastEncoderDict.Reset, enc_better.go:1114-1183) in the device entry format
+        std::vector<uint8_t> proto(kc_zbetter_table_bytes(), 0);
+        build_better_dict_tables(o->dict, (size_t)hist0, pos_bits, proto.data());
+        HIPCHK(c, hipMemcpyAsync(c->proto.p, proto.data(), proto.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        k_src = (const uint8_t*)c->work.p;
+        k_off = (const uint64_t*)c->work_off.p;
+    }
     KcMatchParams mp;
     memset(&mp, 0, sizeof(mp));
-    mp.src = d_src;
-    mp.unit_off = (const uint64_t*)c->unit_off.p;
+    mp.src = k_src;
+    mp.unit_off = k_off;
+    mp.hist0 = hist0;
+    mp.pos_bits = pos_bits;
     mp.unit_blk0 = (const uint32_t*)c->unit_blk0.p;
     mp.seqs = (uint64_t*)c->seqs.p;
     mp.meta = (KcBlkMeta*)c->meta.p;
@@ -314,8 +384,9 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
 
     KcEntropyParams ep;
     memset(&ep, 0, sizeof(ep));
-    ep.src = d_src;
-    ep.unit_off = mp.unit_off;
+    ep.src = k_src;
+    ep.unit_off = k_off;
+    ep.hist0 = hist0;
     ep.unit_blk0 = mp.unit_blk0;
     ep.seqs = mp.seqs;
     ep.meta = mp.meta;
@@ -348,7 +419,7 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     }
 
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    if (o->crc) kc_launch_xxh64(d_src, mp.unit_off, n_units, (uint64_t*)c->xxh.p, st);
+    if (o->crc) kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p, n_units, (uint64_t*)c->xxh.p, st);
     HIPCHK(c, hipEventRecord(c->ev[1], st));
     if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, st, o->level)) != KC_OK) return s;
     HIPCHK(c, hipEventRecord(c->ev[2], st));
@@ -450,7 +521,9 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
     std::vector<uint64_t> tmp;
     while (i0 < n_units) {
         uint32_t i1 = i0;
-        while (i1 < n_units && (i1 == i0 || unit_off[i1 + 1] - unit_off[i0] <= c->max_batch_bytes)) i1++;
+        const uint64_t cap_bytes = o->level == KC_SPEED_BETTER ? ((uint64_t)1 << 30) : c->max_batch_bytes;  // better: 4 MiB of tables per unit
+        const uint32_t cap_units = o->level == KC_SPEED_BETTER ? 16384u : 0xFFFFFFFFu;
+        while (i1 < n_units && (i1 == i0 || (unit_off[i1 + 1] - unit_off[i0] <= cap_bytes && i1 - i0 < cap_units))) i1++;
         const uint32_t nb = i1 - i0;
         tmp.resize(nb + 1);
         uint64_t produced = 0;
@@ -535,6 +608,15 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
     mp.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : 1;
     if (mp.spec_w0 < 1) mp.spec_w0 = 1;
     if (mp.spec_w0 > 8) mp.spec_w0 = 8;
+    mp.hist0 = 0;
+    {
+        uint64_t maxLen = 16;
+        for (uint32_t i = 0; i < n_units; i++) maxLen = std::max<uint64_t>(maxLen, unit_off[i + 1] - unit_off[i]);
+        int pb = 1;
+        while (((uint64_t)1 << pb) <= maxLen + 2) pb++;
+        mp.pos_bits = pb;
+    }
+    if (o->dict != nullptr && o->dict_len > 0) { c->err = "debug parse does not take dictionaries"; return KC_ERR_UNSUPPORTED; }
     if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, c->stream, o->level)) != KC_OK) return s;
     std::vector<KcBlkMeta> meta(nb);
     HIPCHK(c, hipMemcpyAsync(meta.data(), c->meta.p, (size_t)nb * sizeof(KcBlkMeta), hipMemcpyDeviceToHost, c->stream));

@@ -17,6 +17,8 @@ struct KcMatchParams {
     int32_t block_size;
     int32_t max_match_off;
     int32_t spec_w0;            // initial speculation width after a match (group kernels)
+    int32_t hist0;              // bytes of dictionary content prepended to every unit in `src` (0: no dictionary)
+    int32_t pos_bits;           // bits reserved for position+1 in tagged table entries (better level)
 };
 // lds_variant: every unit <= 131064 bytes and block_size <= 65536 (packed 17-bit table + LDS-resident block)
 void kc_launch_zfast_match(const KcMatchParams& P, uint32_t grid, hipStream_t st, bool lds_variant);
@@ -26,6 +28,9 @@ static inline size_t kc_zfast_table_bytes() { return (size_t)4 << 15; }
 // SpeedDefault: long (2^17) + short (2^15) u32 tables per unit in HBM, zeroed by the caller
 void kc_launch_zdfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st);
 static inline size_t kc_zdfast_table_bytes() { return ((size_t)4 << 17) + ((size_t)4 << 15); }
+// SpeedBetterCompression: long 2^19 x {offset,prev} + short 2^13 x u32 per unit
+void kc_launch_zbetter_match_grp(const KcMatchParams& P, uint8_t* tables, uint32_t n_launch, bool dict, hipStream_t st);
+static inline size_t kc_zbetter_table_bytes() { return ((size_t)8 << 19) + ((size_t)4 << 13); }
 
 // ---- entropy + emit (kc_zstd_entropy.hip) ----
 struct KcFsePredef;  // opaque device blob built by kc_launch_fse_predef_init
@@ -50,6 +55,7 @@ struct KcEntropyParams {
     int32_t window_size;
     int32_t crc, single, no_entropy, all_lit_entropy, full_zero;
     uint32_t dict_id;
+    int32_t hist0;          // bytes of dictionary content prepended to every unit in `src`
     uint32_t* err_flag;     // device: set non-zero on a device-side invariant violation
     unsigned long long* prof;  // device or null: per-phase shader-clock totals (diagnostics, KC_K2_PROF=1)
 };
@@ -71,6 +77,11 @@ void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st);
 static inline size_t kc_s2_table_bytes() { return (size_t)4 << 14; }
 
 // ---- misc (kc_misc.hip) ----
+// work[work_off[i] ..] = dict (dict_len bytes) || src[unit_off[i] .. unit_off[i+1])
+void kc_launch_prefix_units(const uint8_t* src, const uint64_t* unit_off, const uint64_t* work_off, const uint8_t* dict, uint32_t dict_len,
+                            uint8_t* work, uint32_t n, hipStream_t st);
+// dst[i*bytes ..] = proto[0 .. bytes) for i < n  (bytes multiple of 16)
+void kc_launch_bcast(const uint8_t* proto, uint8_t* dst, size_t bytes, uint32_t n, hipStream_t st);
 void kc_launch_xxh64(const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out, hipStream_t st);
 // exclusive scan of sizes (u32) into offsets (u64, n+1 entries)
 void kc_launch_scan_sizes(const uint32_t* sizes, uint32_t n, uint64_t* out_off, hipStream_t st);

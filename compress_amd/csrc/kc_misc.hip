@@ -124,3 +124,35 @@ void kc_launch_compact(const uint8_t* stage, const uint64_t* stage_off, const ui
     if (n == 0) return;
     hipLaunchKernelGGL(kc_compact_kernel, dim3(n), dim3(256), 0, st, stage, stage_off, sizes, out_off, dst, n);
 }
+
+// ---------------------------------------------------------------------------------------
+// dictionary support: prefix every unit with the dictionary content (history), broadcast primed tables
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kc_prefix_units_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ unit_off,
+                                                              const uint64_t* __restrict__ work_off, const uint8_t* __restrict__ dict,
+                                                              uint32_t dict_len, uint8_t* __restrict__ work, uint32_t n) {
+    const uint32_t u = blockIdx.x;
+    if (u >= n) return;
+    uint8_t* w = work + work_off[u];
+    const uint8_t* s = src + unit_off[u];
+    const uint32_t len = (uint32_t)(unit_off[u + 1] - unit_off[u]);
+    for (uint32_t i = threadIdx.x; i < dict_len; i += 256) w[i] = dict[i];
+    for (uint32_t i = threadIdx.x; i < len; i += 256) w[dict_len + i] = s[i];
+}
+void kc_launch_prefix_units(const uint8_t* src, const uint64_t* unit_off, const uint64_t* work_off, const uint8_t* dict, uint32_t dict_len,
+                            uint8_t* work, uint32_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(kc_prefix_units_kernel, dim3(n), dim3(256), 0, st, src, unit_off, work_off, dict, dict_len, work, n);
+}
+__global__ __launch_bounds__(256) void kc_bcast_kernel(const uint4* __restrict__ proto, uint4* __restrict__ dst, size_t n16, uint32_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const uint4 v = proto[i];
+    for (uint32_t k = blockIdx.y; k < n; k += gridDim.y) dst[(size_t)k * n16 + i] = v;
+}
+void kc_launch_bcast(const uint8_t* proto, uint8_t* dst, size_t bytes, uint32_t n, hipStream_t st) {
+    if (n == 0 || bytes == 0) return;
+    const size_t n16 = bytes / 16;
+    const uint32_t gy = n < 64 ? n : 64;
+    hipLaunchKernelGGL(kc_bcast_kernel, dim3((unsigned)((n16 + 255) / 256), gy), dim3(256), 0, st, (const uint4*)proto, (uint4*)dst, n16, n);
+}

@@ -268,12 +268,13 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : blockIdx.x;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
-    const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]);
+    const int hist0 = P.hist0;  // dictionary content in front of the unit (history only; not part of the frame)
+    const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0;
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
     const int nblk = (ulen + bs - 1) / bs;
     uint8_t* __restrict__ outp = P.stage + P.stage_off[u];
-    const bool rawAllLits = !P.all_lit_entropy;
+    const bool rawAllLits = !P.all_lit_entropy;  // blk.encode(src, noEntropy, !allLitEntropy) (encoder.go:795)
     const bool noEntropy = P.no_entropy != 0;
 
     // ---- per-unit state init: Reset -> initNewEncode (blockenc.go:77-82) ----
@@ -345,8 +346,8 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
 
     for (int b = 0; b < nblk; b++) {
         const KcBlkMeta m = P.meta[blk0 + (uint32_t)b];
-        const int blkStart = b * bs;
-        const int blkEnd = (blkStart + bs < ulen) ? blkStart + bs : ulen;
+        const int blkStart = hist0 + b * bs;
+        const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;
         const int size = blkEnd - blkStart;
         const bool last = b == nblk - 1;
         const uint8_t* __restrict__ org = base + blkStart;
@@ -358,11 +359,9 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
         uint8_t* bout = outp + opos;  // block header goes here
 
         // ---------- literals-only / RLE / incompressible verdicts (blockenc.go:482-503) ----------
-        bool rawBlock = false;
+        bool litsOnly = false;  // encodeLits path: no sequences, or saved < 16 (offsets popped by the match finder)
         if (nseq == 0) {
-            // encodeLits(b.literals, rawAllLits): with no sequences the literals are the whole block.
-            // TODO(all_lit_entropy): huff0 path of encodeLits for SpeedBetterCompression.
-            rawBlock = true;
+            litsOnly = true;  // encodeLits(b.literals, rawAllLits): with no sequences the literals are the whole block
         } else {
             const uint64_t s0 = sq[0];
             if (nseq == 1 && nlit <= 1 && (int)seq_ll(s0) == nlit && seq_of(s0) - 3u == 1u) {
@@ -375,16 +374,19 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
                 __syncthreads();
                 continue;
             }
-            if (m.flags & KC_BF_POP_A) rawBlock = true;  // saved < 16: popOffsets + encodeLits(org, rawAllLits)
+            if (m.flags & KC_BF_POP_A) litsOnly = true;  // saved < 16: popOffsets + encodeLits(org, rawAllLits)
         }
-        if (rawBlock) {
-            if (!rawAllLits && tid == 0) atomicExch(P.err_flag, 100u);  // unsupported combination reached the device
+        // encodeLits (blockenc.go:337-352): extremely small blocks and rawAllLits go out as raw blocks
+        if (litsOnly && (rawAllLits || size < 32)) {
             if (tid == 0) put_block_header(bout, last, 0u, (uint32_t)size);
             wg_copy(bout + 3, org, size);
             opos += 3 + size;
             __syncthreads();
             continue;
         }
+        // literal source for the entropy stage: gathered literals, or the block itself on the encodeLits path
+        const uint8_t* __restrict__ L = litsOnly ? org : lits;
+        const int nlitE = litsOnly ? size : nlit;
 
         PROF_MARK(0);
         // ==================== compressed block attempt ====================
@@ -392,6 +394,9 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
         for (int i = tid; i < 4 * 256; i += ET) ((uint32_t*)S.whist)[i] = 0;
         if (tid == 0) S.longCnt = 0;
         __syncthreads();
+        if (litsOnly) {
+            for (int k = tid; k < size; k += ET) atomicAdd(&S.whist[wv][org[k]], 1u);
+        } else
         {
             uint64_t run = 0;  // lo32: literal bytes so far, hi32: source bytes so far
             for (int t0 = 0; t0 < nseq; t0 += ET) {
@@ -440,8 +445,8 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
 
         PROF_MARK(1);
         // ---------- 2. huff0.compress decisions (compress.go:43-163) ----------
-        const bool wantHuf = !noEntropy && nlit > 16;
-        const bool four = nlit >= 1024;
+        const bool wantHuf = litsOnly ? (nlitE > 16) : (!noEntropy && nlitE > 16);  // encodeLits ignores noEntropy (encoder.go:795)
+        const bool four = nlitE >= 1024;
         // litMode: 0 raw literals, 1 RLE literals, 2 compressed (new table), 3 compressed (reused table)
         if (tid == 0) {
             int litMode = 0;
@@ -452,8 +457,8 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
             S.ivar[IV_OK] = 0;
             if (wantHuf) {
                 if (S.huf.reuse == 2) S.huf.prevLen = 0;  // ReusePolicyNone nukes prevTable (compress.go:45)
-                if ((int)maxCount >= nlit) litMode = (nlit == 1) ? 0 : 1;              // single symbol -> RLE
-                else if (maxCount == 1 || (int)maxCount < (nlit >> 7)) litMode = 0;    // ErrIncompressible
+                if ((int)maxCount >= nlitE) litMode = (nlitE == 1) ? 0 : 1;              // single symbol -> RLE
+                else if (maxCount == 1 || (int)maxCount < (nlitE >> 7)) litMode = 0;    // ErrIncompressible
                 else S.ivar[IV_OK] = 1;                                              // go on and build a table
             }
             S.ivar[IV_LITMODE] = litMode;
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
             }
             __syncthreads();
             if (tid == 0) {
-                const uint8_t tl = huf_build_serial(&S.nodes, &S.cur, symbolLen, nlit);
+                const uint8_t tl = huf_build_serial(&S.nodes, &S.cur, symbolLen, nlitE);
                 if (tl == 0xFF) atomicExch(P.err_flag, 1u);
                 S.ivar[IV_TABLOG] = tl;
             }
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
                 const uint32_t newBits = 7 + S.wtot[0] + S.wtot[1] + S.wtot[2] + S.wtot[3];
                 const uint32_t oldBits = 7 + (uint32_t)(S.wsum[0] + S.wsum[1] + S.wsum[2] + S.wsum[3]);
                 const int newSize = (int)(newBits >> 3), oldSize = (int)(oldBits >> 3);
-                int wantSize = nlit - (nlit >> 4);  // WantLogLess = 4 (blockenc.go:72)
+                int wantSize = nlitE - (nlitE >> 4);  // WantLogLess = 4 (blockenc.go:72)
                 int usePrev = 0;
                 // ReusePolicyAllow && canReuse: hSize == len(s.Out) == 0 at this point (App. A-12)
                 if (S.huf.reuse == 0 && S.ivar[IV_CANREUSE]) {
@@ -523,17 +528,17 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
             PROF_MARK(4);
             // ---- size pass: exact stream sizes with table T ----
             const int nstreams = four ? 4 : 1;
-            const int segSize = four ? (nlit + 3) / 4 : nlit;
+            const int segSize = four ? (nlitE + 3) / 4 : nlitE;
             int segStart = 0, segLen = 0, chunk = 1;
             uint32_t laneBits = 0, laneOff = 0, streamBits = 0;
             if (wv < nstreams && descLen >= 0) {
                 segStart = wv * segSize;
-                segLen = nlit - segStart;
+                segLen = nlitE - segStart;
                 if (segLen > segSize) segLen = segSize;
                 if (segLen < 0) segLen = 0;
                 chunk = (segLen + 63) / 64;
                 if (chunk < 1) chunk = 1;
-                laneBits = huf_lane_bits(lits + segStart, segLen, T, lane, chunk);
+                laneBits = huf_lane_bits(L + segStart, segLen, T, lane, chunk);
                 const uint32_t inc = wave_incl_scan(laneBits, lane);
                 laneOff = inc - laneBits;
                 streamBits = (uint32_t)__shfl((int)inc, 63, 64);
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
             __syncthreads();
             if (tid == 0) {
                 int litMode = 0;
-                int wantSize = nlit - (nlit >> 4);
+                int wantSize = nlitE - (nlitE >> 4);
                 int dataLen = (int)(S.wtot[0] + S.wtot[1] + S.wtot[2] + S.wtot[3]) + (four ? 6 : 0);
                 bool ok = descLen >= 0;
                 if (ok && four) for (int k = 0; k < 4; k++) if (S.wtot[k] > 65535u) ok = false;  // jump table limit (compress.go:288)
@@ -554,11 +559,11 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
                     S.huf.prevLen = symbolLen;
                     S.huf.prevLog = (uint8_t)S.ivar[IV_TABLOG];
                 }
-                if (ok && outLen + 5 > nlit) {
-                    // close call: compare with raw including header sizes (blockenc.go:534-544)
-                    const int szRaw = lit_header_size1(nlit);
-                    const int szComp = lit_header_size2(outLen, nlit);
-                    if (outLen + szComp >= nlit + szRaw) ok = false;
+                if (ok && outLen + 5 > nlitE) {
+                    // close call: compare with raw including header sizes (blockenc.go:534-544; encodeLits :374-381)
+                    const int szRaw = litsOnly ? 0 : lit_header_size1(nlitE);
+                    const int szComp = lit_header_size2(outLen, nlitE);
+                    if (outLen + szComp >= nlitE + szRaw) ok = false;
                 }
                 if (ok) {
                     litMode = usePrev ? 3 : 2;
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
             if (litMode >= 2) {
                 single = !four;
                 const int outLen = S.ivar[IV_DATALEN];
-                const int hsz = lit_header_size2(outLen, nlit);
+                const int hsz = lit_header_size2(outLen, nlitE);
                 // stream byte offsets inside the section payload
                 const int tabLen = usePrev ? 0 : descLen;
                 const uint32_t sb0 = S.wtot[0], sb1 = S.wtot[1], sb2 = S.wtot[2];
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
                 __syncthreads();
                 if (wv < nstreams) {
                     const uint64_t bitBase = (uint64_t)myByteOff * 8 + laneOff;
-                    huf_lane_emit(lits + segStart, segLen, T, lane, chunk, auxw, bitBase);
+                    huf_lane_emit(L + segStart, segLen, T, lane, chunk, auxw, bitBase);
                     if (lane == 63) or_bits(auxw, (uint64_t)myByteOff * 8 + streamBits, 1, 1);  // end mark
                 }
                 __syncthreads();
@@ -596,7 +601,7 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
                 uint8_t* lsec = bout + 3;
                 wg_copy(lsec + hsz + tabLen + (four ? 6 : 0), (const uint8_t*)auxw + tabLen + (four ? 6 : 0), outLen - tabLen - (four ? 6 : 0));
                 if (tid == 0) {
-                    put_lit_header2(lsec, litMode == 3 ? 3u : 2u, outLen, nlit, single);
+                    put_lit_header2(lsec, litMode == 3 ? 3u : 2u, outLen, nlitE, single);
                     for (int k = 0; k < tabLen; k++) lsec[hsz + k] = S.tdesc[k];
                     if (four) {
                         uint8_t* jt = lsec + hsz + tabLen;
@@ -607,6 +612,24 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
                 }
                 litSecLen = hsz + outLen;
             }
+        }
+        if (litsOnly) {
+            // ---------- encodeLits block assembly (blockenc.go:382-427) ----------
+            const int litMode = S.ivar[IV_LITMODE];
+            if (litMode == 0) {  // ErrIncompressible -> raw block
+                if (tid == 0) put_block_header(bout, last, 0u, (uint32_t)size);
+                wg_copy(bout + 3, org, size);
+                opos += 3 + size;
+            } else if (litMode == 1) {  // ErrUseRLE -> RLE block
+                if (tid == 0) { put_block_header(bout, last, 1u, (uint32_t)size); bout[3] = org[0]; }
+                opos += 4;
+            } else {  // compressed block: literals section + "no sequences" byte
+                if (tid == 0) { put_block_header(bout, last, 2u, (uint32_t)(litSecLen + 1)); bout[3 + litSecLen] = 0; }
+                opos += 3 + litSecLen + 1;
+            }
+            __syncthreads();
+            PROF_MARK(6);
+            continue;
         }
         {
             const int litMode = S.ivar[IV_LITMODE];

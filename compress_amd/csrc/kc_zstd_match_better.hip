@@ -1,0 +1,311 @@
+// kc_zstd_match_better.hip — SpeedBetterCompression match finder for gfx950.
+//
+// Replaces betterFastEncoder.Encode (zstd/enc_better.go:56-568; EncodeNoHist == ensureHist + Encode,
+// :573-576) and betterFastEncoderDict.Encode (:579-1091).  8 lanes per unit, 8 units per wave; tables in
+// an HBM arena per unit: long table 2^19 x {offset, prev} (8-byte hash, chain of length 2) followed by the
+// short table 2^13 x u32 (5-byte hash).  Every stored position is (pos+1) | tag(4 source bytes) << PB, so
+// candidates that the reference would reject on its 8-byte / 4-byte compare are mostly rejected on the tag
+// without touching their (random) source line.
+// The probe loop advances one position per round (the reference steps by 1 and re-indexes densely, so
+// speculative multi-probe rounds would mostly be rolled back); the group's lanes cooperate on match
+// extension (8 B per lane) and on the dense re-indexing of every second byte of a match, where lanes that
+// hit the same long-table bucket are chained in order exactly as the sequential loop would chain them.
+// Reproduced literally: RLE pre-check (non-dict), repeat at s+1, long / prev-long / short priority, the lazy
+// long lookup at s+1 after a short match (with its table write), the end-of-match re-search with
+// skipBeginning = 3 (non-dict) or 0 (dict), maxMatchLength caps, offset-2 loop, canRepeat snapshot.
+#include "kc_dev.h"
+#include "kc_kernels.h"
+
+#define ZB_LONG_BITS 19
+#define ZB_SHORT_BITS 13
+#define ZB_MAX_MATCH_LENGTH 131074
+#define ZBG 8
+
+struct ZbCtx {
+    const uint8_t* base;   // hist: (dict ||) unit
+    uint2* ltab;           // {offset, prev}
+    uint32_t* stab;
+    int PB, TB;
+    uint32_t posMask;
+    int mmo;
+    __device__ __forceinline__ uint32_t tagOf(uint32_t v) const { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; }
+    __device__ __forceinline__ uint32_t mk(int pos, uint32_t val) const { return ((uint32_t)pos + 1u) | (tagOf(val) << PB); }
+    __device__ __forceinline__ int posOf(uint32_t e) const { return (int)(e & posMask) - 1; }  // -1 == empty
+    // candidate acceptable for an 8-byte compare against cv at position s?
+    __device__ __forceinline__ bool long_ok(uint32_t e, int s, uint64_t cv) const {
+        const int t = posOf(e);
+        if (t < 0 || (s - t) >= mmo) return false;
+        if ((e >> PB) != tagOf((uint32_t)cv)) return false;
+        return ld64(base + t) == cv;
+    }
+};
+
+template <bool DICT>
+__global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams P, uint8_t* __restrict__ tables, uint32_t n_launch) {
+    constexpr int G = ZBG;
+    constexpr int UPW = 64 / G;
+    const int lane = (int)threadIdx.x;
+    const int lig = lane % G, grp = lane / G;
+    const uint32_t ui = blockIdx.x * UPW + (uint32_t)grp;
+    const bool gact = ui < n_launch;
+    const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : ui) : 0u;
+    const uint8_t* __restrict__ base = P.src + P.unit_off[u];
+    const int hist0 = P.hist0;  // bytes of dictionary content in front of the unit (0 without a dictionary)
+    const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0 : 0;
+    const uint32_t blk0 = P.unit_blk0[u];
+    const int bs = P.block_size;
+    const int nblk = (ulen + bs - 1) / bs;
+    const uint32_t pm = (gact && P.popmask) ? P.popmask[u] : 0u;
+    const size_t tabBytes = ((size_t)8 << ZB_LONG_BITS) + ((size_t)4 << ZB_SHORT_BITS);
+    ZbCtx C;
+    C.base = base;
+    C.ltab = (uint2*)(tables + (size_t)ui * tabBytes);
+    C.stab = (uint32_t*)(tables + (size_t)ui * tabBytes + ((size_t)8 << ZB_LONG_BITS));
+    C.PB = P.pos_bits;  // per-launch constant so that dictionary-primed tables can be shared by all units
+    C.TB = (32 - C.PB) > 16 ? 16 : (32 - C.PB);
+    C.posMask = (1u << C.PB) - 1u;
+    C.mmo = P.max_match_off;
+    const int mmo = C.mmo;
+    auto hL = [&](uint64_t v) -> uint32_t { return hash8(v, ZB_LONG_BITS); };
+    auto hS = [&](uint64_t v) -> uint32_t { return hash5(v, ZB_SHORT_BITS); };
+
+    int o1 = 1, o2 = 4;  // raw-content dictionaries keep {1,4,8} too (encoder_options.go:398-406)
+    for (int b = 0; b < nblk; b++) {
+        const int blkStart = hist0 + b * bs;
+        const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;  // == len(e.hist)
+        const int srcLen = blkEnd - blkStart;
+        const int o1_in = o1, o2_in = o2;
+        uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
+        int nseq = 0, sumLL = 0;
+        uint32_t rounds = 0;
+        int nextEmit = blkStart, s = blkStart;
+        uint32_t firstLL = 0, firstOf = 0;
+        bool rleBlock = false;
+        auto emit = [&](int ll, int ml3, uint32_t of) {
+            if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
+            if (lig == 0) sq[nseq] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
+            nseq++;
+            sumLL += ll;
+        };
+        // dense re-indexing of [from, s-1) every 2nd byte (:438-447 / :157-165), group-parallel with in-order chaining
+        auto reindex = [&](int from, int upto /* exclusive: s-1 */) {
+            for (int i0 = from; i0 < upto; i0 += 2 * G) {
+                const int idx = i0 + 2 * lig;
+                const bool act = idx < upto;
+                uint64_t cv0 = 0;
+                uint32_t h0 = 0xFFFFFFFFu - (uint32_t)lig, h1 = 0xFFFFFF00u - (uint32_t)lig;
+                if (act) { cv0 = ld64(base + idx); h0 = hL(cv0); h1 = hS(cv0 >> 8); }
+                uint32_t oldOff = 0;
+                if (act) oldOff = C.ltab[h0].x;
+                // nearest lower lane with the same long bucket supplies `prev`; a higher lane with the same bucket owns the store
+                uint32_t prevE = oldOff;
+                bool laterL = false, laterS = false;
+                const uint32_t myE = act ? C.mk(idx, (uint32_t)cv0) : 0u;
+#pragma unroll
+                for (int d = G - 1; d >= 1; d--) {  // far to near, so the nearest lower match wins
+                    const uint32_t a0 = (uint32_t)__shfl_up((int)h0, d, G);
+                    const uint32_t ae = (uint32_t)__shfl_up((int)myE, d, G);
+                    if (lig >= d && a0 == h0) prevE = ae;
+                }
+#pragma unroll
+                for (int d = 1; d < G; d++) {
+                    const uint32_t b0 = (uint32_t)__shfl_down((int)h0, d, G);
+                    const uint32_t b1 = (uint32_t)__shfl_down((int)h1, d, G);
+                    if (lig + d < G && b0 == h0) laterL = true;
+                    if (lig + d < G && b1 == h1) laterS = true;
+                }
+                if (act && !laterL) C.ltab[h0] = make_uint2(myE, prevE);
+                if (act && !laterS) C.stab[h1] = C.mk(idx + 1, (uint32_t)(cv0 >> 8));
+            }
+        };
+
+        if (!DICT && srcLen > 3) {
+            // Check RLE first (:109-117): the whole block is one byte repeated
+            const int ml = grp_matchlen<G>(base, blkStart + 1, blkStart, srcLen - 1, lig, grp);
+            if (ml == srcLen - 1) {
+                emit(1, (srcLen - 1) - 3, 1u + 3u);
+                rleBlock = true;
+            }
+        }
+        if (!rleBlock && srcLen >= 16) {
+            const int sLimit = blkEnd - 10;
+            bool fin = false;
+            while (!fin) {  // encodeLoop
+                int t = 0, matched = 0, index0 = 0;
+                const bool canRep = nseq > 2;
+                bool brk = false;
+                for (;;) {  // search loop
+                    rounds++;
+                    const uint64_t cv = ld64(base + s);
+                    const uint32_t nhL = hL(cv), nhS = hS(cv);
+                    const uint2 cL = C.ltab[nhL];
+                    const uint32_t cS = C.stab[nhS];
+                    const int repIndex = s - o1 + 1;
+                    if (lig == 0) {
+                        C.ltab[nhL] = make_uint2(C.mk(s, (uint32_t)cv), cL.x);
+                        C.stab[nhS] = C.mk(s, (uint32_t)cv);
+                    }
+                    index0 = s + 1;
+                    if (canRep && repIndex >= 0 && ld32(base + repIndex) == (uint32_t)(cv >> 8)) {
+                        int ri = repIndex;
+                        const int length = 4 + grp_matchlen<G>(base, s + 5, ri + 4, blkEnd - (s + 5), lig, grp);
+                        int start = s + 1;
+                        const int startLimit = nextEmit + 1;
+                        const int tMin = (s - mmo) > 0 ? (s - mmo) : 0;
+                        int kmax = ri - tMin;
+                        if (start - startLimit < kmax) kmax = start - startLimit;
+                        const int cap = (ZB_MAX_MATCH_LENGTH - 3 - 1) - (length - 3);
+                        if (cap < kmax) kmax = cap;
+                        if (kmax < 0) kmax = 0;
+                        const int back = grp_backlen<G>(base, start, ri, kmax, lig, grp);
+                        start -= back;
+                        emit(start - nextEmit, length - 3 + back, 1u);
+                        const int idx = s + 1;
+                        s += length + 1;
+                        nextEmit = s;
+                        if (s >= sLimit) { fin = true; brk = true; break; }
+                        reindex(idx, s - 1);
+                        continue;
+                    }
+                    // long match on offset, possibly improved by prev (:264-296)
+                    const bool okL = C.long_ok(cL.x, s, cv);
+                    const bool okP = C.long_ok(cL.y, s, cv);
+                    if (okL) {
+                        const int tl = C.posOf(cL.x);
+                        matched = grp_matchlen<G>(base, s + 8, tl + 8, blkEnd - (s + 8), lig, grp) + 8;
+                        t = tl;
+                        if (okP) {
+                            const int tp = C.posOf(cL.y);
+                            const int pm2 = grp_matchlen<G>(base, s + 8, tp + 8, blkEnd - (s + 8), lig, grp) + 8;
+                            if (pm2 > matched) { matched = pm2; t = tp; }
+                        }
+                        break;
+                    }
+                    if (okP) {
+                        const int tp = C.posOf(cL.y);
+                        matched = grp_matchlen<G>(base, s + 8, tp + 8, blkEnd - (s + 8), lig, grp) + 8;
+                        t = tp;
+                        break;
+                    }
+                    {
+                        const int ts = C.posOf(cS);
+                        if (ts >= 0 && (s - ts) < mmo && (cS >> C.PB) == C.tagOf((uint32_t)cv) && ld32(base + ts) == (uint32_t)cv) {
+                            matched = grp_matchlen<G>(base, s + 4, ts + 4, blkEnd - (s + 4), lig, grp) + 4;
+                            // long match at s+1? (:309-343)
+                            const uint64_t cv2 = ld64(base + s + 1);
+                            const uint32_t nh2 = hL(cv2);
+                            const uint2 c2 = C.ltab[nh2];
+                            if (lig == 0) C.ltab[nh2] = make_uint2(C.mk(s + 1, (uint32_t)cv2), c2.x);
+                            // s-coffsetL < maxMatchOff is evaluated with s (not s+1) in the reference
+                            bool taken = false;
+                            {
+                                const int tl = C.posOf(c2.x);
+                                if (tl >= 0 && (s - tl) < mmo && (c2.x >> C.PB) == C.tagOf((uint32_t)cv2) && ld64(base + tl) == cv2) {
+                                    const int mn = grp_matchlen<G>(base, s + 9, tl + 8, blkEnd - (s + 9), lig, grp) + 8;
+                                    if (mn > matched) { t = tl; s += 1; matched = mn; taken = true; }
+                                }
+                            }
+                            if (!taken) {
+                                const int tp = C.posOf(c2.y);
+                                if (tp >= 0 && (s - tp) < mmo && (c2.y >> C.PB) == C.tagOf((uint32_t)cv2) && ld64(base + tp) == cv2) {
+                                    const int mn = grp_matchlen<G>(base, s + 9, tp + 8, blkEnd - (s + 9), lig, grp) + 8;
+                                    if (mn > matched) { t = tp; s += 1; matched = mn; taken = true; }
+                                }
+                            }
+                            if (!taken) t = ts;
+                            break;
+                        }
+                    }
+                    s += 1 + ((s - nextEmit) >> 8);  // kSearchStrength-1 == 8
+                    if (s >= sLimit) { fin = true; brk = true; break; }
+                }
+                if (brk) continue;  // leaves encodeLoop when fin, or restarts the search after nothing (not reached)
+                // ---- end-of-match re-search (:419-460) ----
+                if (s + matched < sLimit) {
+                    const int skipBeginning = DICT ? 0 : 3;
+                    const uint32_t nh = hL(ld64(base + s + matched));
+                    const int s2 = s + skipBeginning;
+                    const uint32_t cv4 = ld32(base + s2);
+                    const uint2 cE = C.ltab[nh];
+                    {
+                        const int co = C.posOf(cE.x) - matched + skipBeginning;
+                        if (C.posOf(cE.x) >= 0 && co >= 0 && co < s2 && (s2 - co) < mmo && cv4 == ld32(base + co)) {
+                            const int mn = grp_matchlen<G>(base, s2 + 4, co + 4, blkEnd - (s2 + 4), lig, grp) + 4;
+                            if (mn > matched) { t = co; s = s2; matched = mn; }
+                        }
+                    }
+                    {
+                        const int co = C.posOf(cE.y) - matched + skipBeginning;
+                        if (C.posOf(cE.y) >= 0 && co >= 0 && co < s2 && (s2 - co) < mmo && cv4 == ld32(base + co)) {
+                            const int mn = grp_matchlen<G>(base, s2 + 4, co + 4, blkEnd - (s2 + 4), lig, grp) + 4;
+                            if (mn > matched) { t = co; s = s2; matched = mn; }
+                        }
+                    }
+                }
+                o2 = o1;
+                o1 = s - t;
+                int l = matched;
+                {
+                    const int tMin = (s - mmo) > 0 ? (s - mmo) : 0;
+                    int kmax = t - tMin;
+                    if (s - nextEmit < kmax) kmax = s - nextEmit;
+                    if ((ZB_MAX_MATCH_LENGTH - l) < kmax) kmax = ZB_MAX_MATCH_LENGTH - l;
+                    if (kmax < 0) kmax = 0;
+                    const int back = grp_backlen<G>(base, s, t, kmax, lig, grp);
+                    s -= back;
+                    t -= back;
+                    l += back;
+                }
+                emit(s - nextEmit, l - 3, (uint32_t)(s - t) + 3u);
+                s += l;
+                nextEmit = s;
+                if (s >= sLimit) { fin = true; continue; }
+                reindex(index0, s - 1);
+                if (!canRep) continue;
+                for (;;) {  // offset-2 loop (:482-522)
+                    const uint64_t cvs = ld64(base + s);
+                    const int o2pos = s - o2;
+                    if (ld32(base + o2pos) != (uint32_t)cvs) break;
+                    const uint32_t nhL2 = hL(cvs), nhS2 = hS(cvs);
+                    const int l2 = 4 + grp_matchlen<G>(base, s + 4, o2pos + 4, blkEnd - (s + 4), lig, grp);
+                    const uint32_t oldx = C.ltab[nhL2].x;
+                    if (lig == 0) {
+                        C.ltab[nhL2] = make_uint2(C.mk(s, (uint32_t)cvs), oldx);
+                        C.stab[nhS2] = C.mk(s, (uint32_t)cvs);
+                    }
+                    emit(0, l2 - 3, 1u);
+                    s += l2;
+                    nextEmit = s;
+                    const int tmp = o1; o1 = o2; o2 = tmp;
+                    if (s >= sLimit) { fin = true; break; }
+                }
+            }
+        }
+        int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
+        int nlit = sumLL + extra;
+        if (rleBlock) { extra = 0; nlit = 1; }  // literals = src[0]; recentOffsets untouched (early return, :114)
+        const bool rle = nseq == 1 && nlit <= 1 && (int)firstLL == nlit && firstOf - 3u == 1u;
+        const int saved = srcLen - nlit - (srcLen >> 6);
+        uint32_t flags = 0;
+        if (nseq > 0 && !rle && saved < 16) flags |= KC_BF_POP_A;
+        if ((pm >> b) & 1u) flags |= KC_BF_FORCED;
+        const int o1c = o1, o2c = o2;
+        if (flags) { o1 = o1_in; o2 = o2_in; }
+        flags |= rounds << 8;
+        if (lig == 0) {
+            KcBlkMeta m;
+            m.nseq = (uint32_t)nseq;
+            m.nlit = (uint32_t)nlit;
+            m.extra_lits = (uint32_t)extra;
+            m.flags = flags;
+            m.o1_in = (uint32_t)o1_in; m.o2_in = (uint32_t)o2_in;
+            m.o1_out = (uint32_t)o1c; m.o2_out = (uint32_t)o2c;
+            P.meta[blk0 + (uint32_t)b] = m;
+        }
+    }
+}
+
+void kc_launch_zbetter_match_grp(const KcMatchParams& P, uint8_t* tables, uint32_t n_launch, bool dict, hipStream_t st) {
+    if (dict) hipLaunchKernelGGL(kc_zbetter_match_grp_kernel<true>, dim3((n_launch + 7) / 8), dim3(64), 0, st, P, tables, n_launch);
+    else hipLaunchKernelGGL(kc_zbetter_match_grp_kernel<false>, dim3((n_launch + 7) / 8), dim3(64), 0, st, P, tables, n_launch);
+}

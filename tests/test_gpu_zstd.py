@@ -34,7 +34,7 @@ def _check_units(oracle, units, level=1):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_parse_matches_oracle(oracle, kclib, level):
     """Intermediate artefact parity: the sequence list of every block equals the oracle's."""
     torch = _torch()
@@ -61,13 +61,13 @@ def test_parse_matches_oracle(oracle, kclib, level):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_edge_units_bit_exact(oracle, kclib, level):
     _torch()
     _check_units(oracle, corpora.edge_units(), level)
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 @pytest.mark.parametrize("kind", ["T", "H", "J", "M"])
 def test_corpus_units_bit_exact(oracle, kclib, kind, level):
     _torch()
@@ -76,7 +76,7 @@ def test_corpus_units_bit_exact(oracle, kclib, kind, level):
     _check_units(oracle, units, level)
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_ragged_units_bit_exact(oracle, kclib, level):
     _torch()
     rng = np.random.default_rng(7)
@@ -106,7 +106,7 @@ def test_xxh64_units(oracle, kclib):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_device_resident_roundtrip_full_size(oracle, kclib, level):
     """BASELINE-size property check (no oracle at this size): every frame decodes back with libzstd."""
     torch = _torch()
@@ -125,4 +125,28 @@ def test_device_resident_roundtrip_full_size(oracle, kclib, level):
         assert oracle.zstd_decompress(frame, usz + 16) == buf[i * usz:(i + 1) * usz].tobytes()
     ratio = float(out_off[n]) / float(n * usz)
     assert 0.2 < ratio < 0.7, ratio
+    enc.Close()
+
+
+@pytest.mark.parametrize("dict_id", [0, 1, 70000])
+def test_better_with_raw_dictionary_bit_exact(oracle, kclib, dict_id):
+    """C5: SpeedBetterCompression + 64 KiB raw-content dictionary (WithEncoderDictRaw), mixed corpus."""
+    _torch()
+    from compress_amd import zstd
+    dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
+    buf = corpora.corpus("M", 48, 131072)
+    units = [buf[i * 131072:(i + 1) * 131072].tobytes() for i in range(48)]
+    t = corpora.corpus("T", 8, 131072, first_unit=77).tobytes()
+    units += [t[:200000], t[5:40000], t[:9], t[:100], b"", t[100000:400000], dct[:50000], dct]
+    ubuf, off = corpora.pack_units(units)
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(zstd.SpeedBetterCompression), zstd.WithEncoderDictRaw(dict_id, dct))
+    out, out_off = enc.EncodeUnits(ubuf, off)
+    ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=3, dict_id=dict_id, dict_content=dct)
+    bad = [i for i in range(len(units))
+           if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
+    assert not bad, bad[:10]
+    if dict_id == 0:  # libzstd treats raw-content dictionaries as ID 0
+        for i in (0, 5, 48, 53):
+            frame = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+            assert oracle.zstd_decompress(frame, len(units[i]) + 16, dict_content=dct) == units[i]
     enc.Close()

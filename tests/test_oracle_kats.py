@@ -102,7 +102,7 @@ def test_frame_boundaries_on_reference_fixtures(oracle):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference fixtures not present on this machine")
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_reference_corpora_roundtrip(oracle, level):
     """The reference's encoder tests are round-trip tests (zstd/encoder_test.go:68-160, fuzz_test.go:154):
     every oracle output must decode to the input with an independent decoder (libzstd 1.4.8) and stay
@@ -155,3 +155,26 @@ def test_s2_roundtrip_and_bounds(oracle):
         e = oracle.s2_encode(bytes(src))
         assert len(e) <= orig * 3 // 4
         assert oracle.s2_decode(e, orig + 8) == bytes(src)
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_raw_dictionary_roundtrip(oracle, level):
+    """WithEncoderDictRaw (encoder_options.go:398-406): dictionary content is history only; libzstd decodes
+    raw-content dictionaries as ID 0; a non-zero ID only adds the dictID field to the frame header."""
+    import corpora
+    dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
+    e0 = oracle.ZstdOracle(level=level, dict_id=0, dict_content=dct)
+    e1 = oracle.ZstdOracle(level=level, dict_id=1, dict_content=dct)
+    plain = oracle.ZstdOracle(level=level)
+    m = corpora.corpus("M", 6, 131072)
+    t = corpora.corpus("T", 3, 131072, first_unit=100).tobytes()
+    units = [m[i * 131072:(i + 1) * 131072].tobytes() for i in range(6)] + [t[:n] for n in (5, 100, 20000, 40000, 131072, 300000)] + [dct]
+    won = 0
+    for u in units:
+        out = e0.encode_all(u)
+        assert oracle.zstd_decompress(out, len(u) + 16, dict_content=dct) == u
+        o1 = e1.encode_all(u)
+        assert o1[:4] == out[:4] and o1[4] == out[4] | 1 and o1[5] == 1 and o1[6:] == out[5:]
+        won += len(out) < len(plain.encode_all(u))
+    assert won >= 6  # the dictionary helps on text-like units
+    assert e0.encode_all(b"").hex() == "28b52ffd2000010000"
