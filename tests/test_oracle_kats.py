@@ -174,7 +174,8 @@ def test_raw_dictionary_roundtrip(oracle, level):
         out = e0.encode_all(u)
         assert oracle.zstd_decompress(out, len(u) + 16, dict_content=dct) == u
         o1 = e1.encode_all(u)
-        assert o1[:4] == out[:4] and o1[4] == out[4] | 1 and o1[5] == 1 and o1[6:] == out[5:]
+        k = 5 if len(u) > 1024 else 6  # the dictID follows the window descriptor of non-single-segment frames (frameenc.go:66-73)
+        assert o1[:4] == out[:4] and o1[4] == out[4] | 1 and o1[5:k] == out[5:k] and o1[k] == 1 and o1[k + 1:] == out[k:]
         won += len(out) < len(plain.encode_all(u))
     assert won >= 6  # the dictionary helps on text-like units
     assert e0.encode_all(b"").hex() == "28b52ffd2000010000"
