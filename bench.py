@@ -109,8 +109,18 @@ def main():
     k_total = sum(t["total_ms"] for t in match_ms) / len(match_ms)
     algo_bytes = in_bytes + out_bytes  # 1 B read + ratio B written per input byte
     achieved = algo_bytes / (k_match / 1000.0) / 1e9
-    roofline = {"bound": "hbm", "kernel": "kc_zfast_match_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+    # HBM traffic of the dominant kernel from PMC counters (separate rocprofv3 --pmc passes, see profiles/): read from the
+    # committed summary when it was taken on this workload; FETCH_SIZE is reported raw (the x2 correction of
+    # MI355X_MICROARCH.md applies to wide coalesced reads; this kernel issues scattered 4-8 byte accesses: uncalibrated).
+    traffic = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pj.get("units") == n_units and pj.get("corpus") == args.kind:
+            traffic = pj["match_kernel_hbm_bytes"]
+    except Exception:
+        pass
+    roofline = {"bound": "hbm", "kernel": "kc_zfast_match_grp_kernel<8>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel_ms": round(k_match, 3), "entropy_kernel_ms": round(k_entropy, 3), "pipeline_kernel_ms": round(k_total, 3),
                 "read_only_frac": round(in_bytes / (k_match / 1000.0) / 1e9 / HBM_PEAK_GBS, 5)}
 

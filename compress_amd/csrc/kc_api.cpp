@@ -280,7 +280,7 @@ kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_
         return KC_OK;
     }
     if (var == "v1") { kc_launch_zfast_match(mp, n_launch, st, false); return KC_OK; }
-    const int G = var == "g16" ? 16 : 8;
+    const int G = var == "g16" ? 16 : (var == "g4" ? 4 : (var == "g2" ? 2 : 8));
     kc_status s = ensure(c, c->tables, (size_t)n_launch * kc_zfast_table_bytes());
     if (s != KC_OK) return s;
     HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * kc_zfast_table_bytes(), st));
@@ -378,7 +378,7 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     mp.seq_stride = pl.seq_stride;
     mp.block_size = bs;
     mp.max_match_off = o->window_size;
-    mp.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : 1;
+    mp.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : (o->level == KC_SPEED_DEFAULT ? 2 : 1);
     if (mp.spec_w0 < 1) mp.spec_w0 = 1;
     if (mp.spec_w0 > 8) mp.spec_w0 = 8;
 

@@ -124,10 +124,14 @@ __device__ __forceinline__ int grp_matchlen(const uint8_t* __restrict__ base, in
         n += 8 * active;
         if (active < G) break;
     }
-    const int tail = left - n;  // < 8 <= G
-    const bool ne = lig < tail && base[a + n + lig] != base[b + n + lig];
-    const uint32_t m = gballot<G>(ne, grp);
-    return n + (m ? __builtin_ctz(m) : tail);
+    const int tail = left - n;  // < 8
+    for (int k0 = 0; k0 < tail; k0 += G) {
+        const int k = k0 + lig;
+        const bool ne = k < tail && base[a + n + k] != base[b + n + k];
+        const uint32_t m = gballot<G>(ne, grp);
+        if (m) return n + k0 + __builtin_ctz(m);
+    }
+    return n + tail;
 }
 template <int G>
 __device__ __forceinline__ int grp_backlen(const uint8_t* __restrict__ base, int s, int t, int kmax, int lig, int grp) {

@@ -737,6 +737,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
 
 void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, int G, hipStream_t st) {
     if (G == 16) hipLaunchKernelGGL(kc_zfast_match_grp_kernel<16>, dim3((n_launch + 3) / 4), dim3(64), 0, st, P, tables, n_launch);
+    else if (G == 4) hipLaunchKernelGGL(kc_zfast_match_grp_kernel<4>, dim3((n_launch + 15) / 16), dim3(64), 0, st, P, tables, n_launch);
+    else if (G == 2) hipLaunchKernelGGL(kc_zfast_match_grp_kernel<2>, dim3((n_launch + 31) / 32), dim3(64), 0, st, P, tables, n_launch);
     else hipLaunchKernelGGL(kc_zfast_match_grp_kernel<8>, dim3((n_launch + 7) / 8), dim3(64), 0, st, P, tables, n_launch);
 }
 
