@@ -536,6 +536,13 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P)
 #ifndef ZG_W0
 #define ZG_W0 4  // initial speculation width after a match
 #endif
+#ifdef KC_TAB_NT
+#define KC_TAB_LD(p) __builtin_nontemporal_load(p)
+#define KC_TAB_ST(v, p) __builtin_nontemporal_store((uint32_t)(v), p)
+#else
+#define KC_TAB_LD(p) (*(p))
+#define KC_TAB_ST(v, p) (*(p) = (v))
+#endif
 template <int G>
 __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P, uint32_t* __restrict__ tables, uint32_t n_launch) {
     constexpr int UPW = 64 / G;
@@ -613,8 +620,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 if (valid) {
                     h0 = hash6(cv, ZF_TABLE_BITS);
                     h1 = hash6(cv >> 8, ZF_TABLE_BITS);
-                    c0 = tab[h0];
-                    c1 = tab[h1];
+                    c0 = KC_TAB_LD(&tab[h0]);
+                    c1 = KC_TAB_LD(&tab[h1]);
                 }
                 // exact in-round conflict detection: a lower lane of the group touches one of my buckets
                 bool dep = false;
@@ -648,8 +655,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 const int f = found ? __builtin_ctz(hmc) : 0;
                 const int commitUpTo = found ? f : ((c < nvalid ? c : nvalid) - 1);
                 if (valid && lig <= commitUpTo) {
-                    tab[h0] = ((uint32_t)p + 1u) | (PB < 32 ? tagOf((uint32_t)cv) << PB : 0u);
-                    tab[h1] = ((uint32_t)p + 2u) | (PB < 32 ? tagOf((uint32_t)(cv >> 8)) << PB : 0u);  // program order: wins when h0 == h1
+                    KC_TAB_ST(((uint32_t)p + 1u) | (PB < 32 ? tagOf((uint32_t)cv) << PB : 0u), &tab[h0]);
+                    KC_TAB_ST(((uint32_t)p + 2u) | (PB < 32 ? tagOf((uint32_t)(cv >> 8)) << PB : 0u), &tab[h1]);  // program order: wins when h0 == h1
                 }
                 if (!found) {
                     W = (2 * W < G) ? 2 * W : G;
