@@ -13,6 +13,7 @@ struct KcMatchParams {
     KcBlkMeta* meta;            // device: one record per block
     const uint32_t* popmask;    // device or null: per-unit bitmask of blocks whose offsets must be popped (re-run)
     const uint32_t* unit_list;  // device or null: indirection for re-runs
+    uint32_t unit_base;         // first unit of this launch when unit_list is null (chunked launches)
     uint32_t seq_stride;
     int32_t block_size;
     int32_t max_match_off;
@@ -48,6 +49,7 @@ struct KcEntropyParams {
     const uint64_t* xxh;    // device: XXH64 per unit (only read when crc != 0)
     uint32_t* redo_mask;    // device: per unit, blocks whose late raw fallback invalidated carried offsets
     const uint32_t* unit_list;
+    uint32_t unit_base;     // first unit of this launch when unit_list is null
     const void* predef;     // device: KcFsePredef
     uint32_t seq_stride;
     uint32_t lit_stride;

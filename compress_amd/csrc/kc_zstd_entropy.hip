@@ -266,7 +266,7 @@ __device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, i
 __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams P) {
     __shared__ Shared S;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : blockIdx.x;
+    const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : P.unit_base + blockIdx.x;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
     const int hist0 = P.hist0;  // dictionary content in front of the unit (history only; not part of the frame)
     const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0;

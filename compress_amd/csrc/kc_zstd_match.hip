@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_kernel(KcMatchParams P) {
     __shared__ uint32_t tab[1 << ZF_TABLE_BITS];
     __shared__ uint32_t mark[ZF_MARK_SLOTS];
     const int lane = (int)threadIdx.x;
-    const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : blockIdx.x;
+    const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : P.unit_base + blockIdx.x;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
     const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]);
     const uint32_t blk0 = P.unit_blk0[u];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P)
     __shared__ uint32_t srcw[ZL_SRC_WORDS];
     __shared__ uint32_t mark[ZF_MARK_SLOTS];
     const int lane = (int)threadIdx.x;
-    const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : blockIdx.x;
+    const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : P.unit_base + blockIdx.x;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
     const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]);
     const uint32_t blk0 = P.unit_blk0[u];
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const int lig = lane % G, grp = lane / G;
     const uint32_t ui = blockIdx.x * UPW + (uint32_t)grp;
     const bool gact = ui < n_launch;
-    const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : ui) : 0u;
+    const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
     const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) : 0;
     const uint32_t blk0 = P.unit_blk0[u];

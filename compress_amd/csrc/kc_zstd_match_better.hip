@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
     const int lig = lane % G, grp = lane / G;
     const uint32_t ui = blockIdx.x * UPW + (uint32_t)grp;
     const bool gact = ui < n_launch;
-    const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : ui) : 0u;
+    const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
     const int hist0 = P.hist0;  // bytes of dictionary content in front of the unit (0 without a dictionary)
     const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0 : 0;

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
     const int lig = lane % G, grp = lane / G;
     const uint32_t ui = blockIdx.x * UPW + (uint32_t)grp;
     const bool gact = ui < n_launch;
-    const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : ui) : 0u;
+    const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
     const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) : 0;
     const uint32_t blk0 = P.unit_blk0[u];
