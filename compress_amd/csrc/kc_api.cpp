@@ -705,13 +705,20 @@ int64_t kc_s2_max_encoded_len(int64_t srcLen) {  // s2/encode.go:389-418 (64-bit
     return (int64_t)n;
 }
 
-kc_status kc_s2_encode_blocks_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
-                                  uint64_t dst_cap, uint64_t* out_off) {
+static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
+                               uint64_t dst_cap, uint64_t* out_off, int framed, int with_stream_id) {
     if (!c || !blk_off || !out_off || (n && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
     c->err.clear();
     c->last = kc_timings{0, 0, 0, 0, 0};
     HIPCHK(c, hipSetDevice(c->device));
-    if (n == 0) { out_off[0] = 0; return KC_OK; }
+    const uint64_t lead = (framed && with_stream_id) ? 10 : 0;
+    if (lead) {
+        static const uint8_t magic[10] = {0xff, 0x06, 0x00, 0x00, 'S', '2', 's', 'T', 'w', 'O'};  // magicChunk, s2/s2.go:79
+        if (dst_cap < 10) return KC_ERR_DST_TOO_SMALL;
+        HIPCHK(c, hipMemcpyAsync(d_dst, magic, 10, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (n == 0) { out_off[0] = lead; return KC_OK; }
     hipStream_t st = c->stream;
     std::vector<uint64_t> rel(n + 1), so(n + 1);
     uint64_t acc = 0;
@@ -721,11 +728,11 @@ kc_status kc_s2_encode_blocks_dev(kc_ctx* c, const uint8_t* d_src, const uint64_
         if (len > (uint64_t)(4 << 20)) { c->err = "S2 block larger than 4 MiB (s2.maxBlockSize) not served by the device path"; return KC_ERR_UNSUPPORTED; }
         rel[i] = blk_off[i] - blk_off[0];
         so[i] = acc;
-        acc += ((uint64_t)kc_s2_max_encoded_len((int64_t)len) + 15) & ~(uint64_t)15;
+        acc += ((uint64_t)kc_s2_max_encoded_len((int64_t)len) + (framed ? 8 : 0) + 15) & ~(uint64_t)15;
     }
     rel[n] = blk_off[n] - blk_off[0];
     so[n] = acc;
-    if (acc > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
+    if (acc + lead > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
     kc_status s;
     if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) || (s = ensure(c, c->out_off, (n + 1) * 8)) ||
         (s = ensure(c, c->stage, acc + 64)) || (s = ensure(c, c->out_size, (size_t)n * 4)) ||
@@ -743,15 +750,17 @@ kc_status kc_s2_encode_blocks_dev(kc_ctx* c, const uint8_t* d_src, const uint64_
     P.out_size = (uint32_t*)c->out_size.p;
     P.tables = (uint32_t*)c->tables.p;
     P.n_blocks = n;
+    P.framed = framed;
     kc_launch_s2_encode(P, st);
     HIPCHK(c, hipEventRecord(c->ev[1], st));
     kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n, (uint64_t*)c->out_off.p, st);
     kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p, (const uint32_t*)c->out_size.p,
-                      (const uint64_t*)c->out_off.p, d_dst, n, st);
+                      (const uint64_t*)c->out_off.p, d_dst + lead, n, st);
     HIPCHK(c, hipEventRecord(c->ev[2], st));
     HIPCHK(c, hipMemcpyAsync(out_off, c->out_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
+    for (uint32_t i = 0; i <= n; i++) out_off[i] += lead;
     float t01 = 0, t12 = 0;
     (void)hipEventElapsedTime(&t01, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
@@ -759,6 +768,16 @@ kc_status kc_s2_encode_blocks_dev(kc_ctx* c, const uint8_t* d_src, const uint64_
     c->last.other_ms = t12;
     c->last.total_ms = t01 + t12;
     return KC_OK;
+}
+
+kc_status kc_s2_encode_blocks_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
+                                  uint64_t dst_cap, uint64_t* out_off) {
+    return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 0, 0);
+}
+
+kc_status kc_s2_encode_stream_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
+                                  uint64_t dst_cap, uint64_t* out_off, int with_stream_id) {
+    return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 1, with_stream_id);
 }
 
 kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* dst, uint64_t dst_cap,

@@ -74,6 +74,7 @@ struct KcS2Params {
     uint32_t* out_size;
     uint32_t* tables;           // n x 2^14 u32, zeroed by the caller
     uint32_t n_blocks;
+    int32_t framed;             // 1: emit s2.Writer chunks (type | len24 | masked CRC32C | body), s2/writer.go:414-451
 };
 void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st);
 static inline size_t kc_s2_table_bytes() { return (size_t)4 << 14; }

@@ -157,8 +157,34 @@ __device__ inline int s2_copy_size(int offset, int length) {
 
 __device__ __forceinline__ uint32_t s2_hash6(uint64_t u) { return (uint32_t)(((u << 16) * KC_PRIME6) >> (64 - S2_TABLE_BITS)); }
 
+// CRC32C (Castagnoli, reflected 0x82F63B78), slicing-by-4 tables in LDS; masked as s2.crc (s2/s2.go:120-125).
+__device__ __forceinline__ uint32_t s2_crc32c(const uint8_t* __restrict__ p, int n, const uint32_t (*T)[256]) {
+    uint32_t c = 0xFFFFFFFFu;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        c ^= ld32(p + i);
+        c = T[3][c & 0xFF] ^ T[2][(c >> 8) & 0xFF] ^ T[1][(c >> 16) & 0xFF] ^ T[0][c >> 24];
+    }
+    for (; i < n; i++) c = T[0][(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
 __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     constexpr int G = S2G;
+    __shared__ uint32_t crcT[4][256];
+    if (P.framed) {
+        for (int i = (int)threadIdx.x; i < 256; i += 64) {
+            uint32_t c = (uint32_t)i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            crcT[0][i] = c;
+        }
+        __syncthreads();
+        for (int i = (int)threadIdx.x; i < 256; i += 64) {
+            uint32_t c = crcT[0][i];
+            for (int t = 1; t < 4; t++) { c = crcT[0][c & 0xFF] ^ (c >> 8); crcT[t][i] = c; }
+        }
+        __syncthreads();
+    }
     const int lane = (int)threadIdx.x;
     const int lig = lane % G, grp = lane / G;
     const uint32_t bi = blockIdx.x * (64 / G) + (uint32_t)grp;
@@ -166,7 +192,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     const uint32_t bq = gact ? bi : 0u;
     const uint8_t* __restrict__ src = P.src + P.blk_off[bq];
     const int len = gact ? (int)(P.blk_off[bq + 1] - P.blk_off[bq]) : 0;
-    uint8_t* __restrict__ out = P.stage + P.stage_off[bq];
+    uint8_t* __restrict__ slot = P.stage + P.stage_off[bq];
+    uint8_t* __restrict__ out = slot + (P.framed ? 8 : 0);  // chunk header (type, len24, crc) goes in front
     uint32_t* __restrict__ tab = P.tables + (size_t)bi * (1u << S2_TABLE_BITS);
     if (!gact) return;  // whole group leaves together
 
@@ -181,7 +208,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     uint8_t* __restrict__ dst = out + hdr;
     int d = 0;
     bool stored = false;  // encodeBlock returned 0 -> emit everything as one literal
-    if (len == 0) { if (lig == 0) P.out_size[bi] = (uint32_t)hdr; return; }
+    if (len == 0 && !P.framed) { if (lig == 0) P.out_size[bi] = (uint32_t)hdr; return; }
+    if (len == 0) stored = true;
     if (len < 32) stored = true;  // minNonLiteralBlockSize
 
     if (!stored) {
@@ -329,8 +357,30 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
             }
         }
     }
-    if (stored) d = s2_emit_literal(dst, src, len, lig);  // encode.go:44-55: not compressible -> one literal
-    if (lig == 0) P.out_size[bi] = (uint32_t)(hdr + d);
+    if (!P.framed) {
+        if (stored) d = s2_emit_literal(dst, src, len, lig);  // encode.go:44-55: not compressible -> one literal
+        if (lig == 0) P.out_size[bi] = (uint32_t)(hdr + d);
+        return;
+    }
+    // ---- s2.Writer chunk (s2/writer.go:414-451) ----
+    uint32_t chunkLen;
+    uint8_t chunkType;
+    if (stored) {  // encodeBlock returned 0: uncompressed chunk, raw copy
+        for (int k = lig; k < len; k += G) out[k] = src[k];
+        chunkType = 0x01;
+        chunkLen = 4u + (uint32_t)len;
+    } else {
+        chunkType = 0x00;
+        chunkLen = 4u + (uint32_t)hdr + (uint32_t)d;
+    }
+    if (lig == 0) {
+        const uint32_t c = s2_crc32c(src, len, crcT);
+        const uint32_t checksum = ((c >> 15) | (c << 17)) + 0xa282ead8u;
+        slot[0] = chunkType;
+        slot[1] = (uint8_t)chunkLen; slot[2] = (uint8_t)(chunkLen >> 8); slot[3] = (uint8_t)(chunkLen >> 16);
+        slot[4] = (uint8_t)checksum; slot[5] = (uint8_t)(checksum >> 8); slot[6] = (uint8_t)(checksum >> 16); slot[7] = (uint8_t)(checksum >> 24);
+        P.out_size[bi] = 4u + chunkLen;
+    }
 }
 
 void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st) {

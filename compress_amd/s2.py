@@ -35,6 +35,17 @@ class BlockEncoder:
         ctx.check(ctx.L.kc_s2_encode_blocks_dev(ctx.h, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data))
         return out_off
 
+    def EncodeStreamDevice(self, d_src_ptr, blk_off, d_dst_ptr, dst_cap, with_stream_id=True):
+        """s2.Writer framing of the blocks (stream identifier + chunks).  Returns uint64[n+1] chunk offsets."""
+        import numpy as np
+        ctx = self._ctx
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.uint64)
+        n = len(blk_off) - 1
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        ctx.check(ctx.L.kc_s2_encode_stream_dev(ctx.h, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data,
+                                                int(with_stream_id)))
+        return out_off
+
     def Encode(self, dst, src):
         """s2.Encode(dst, src) (s2/encode.go:29): uvarint length + block body."""
         import numpy as np

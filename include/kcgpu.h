@@ -13,6 +13,7 @@
  *   kc_s2_encode_blocks[_dev]   == N x s2.Encode(nil, block)             s2/encode.go:29-56
  *   kc_s2_encode_block          == the s2.WriterCustomEncoder callback   s2/writer.go:1053-1064
  *   kc_s2_max_encoded_len       == s2.MaxEncodedLen                      s2/encode.go:389-418
+ *   kc_s2_encode_stream_dev     == s2.Writer.EncodeBuffer framing        s2/writer.go:357-451
  *   kc_xxh64_units_dev          == xxhash.Digest over each unit          zstd/internal/xxhash/xxhash.go:27-230
  */
 #ifndef KCGPU_H
@@ -116,6 +117,12 @@ kc_status kc_s2_encode_blocks(kc_ctx* ctx, const uint8_t* src, const uint64_t* b
                               uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
 kc_status kc_s2_encode_blocks_dev(kc_ctx* ctx, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
                                   uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
+/* s2.Writer framing on the device (s2/writer.go:394-451): every block becomes one chunk
+ * `type(1) | len24 | masked CRC32C(4) | body` (compressed 0x00: uvarint(len) + block; incompressible 0x01: raw bytes),
+ * optionally preceded by the stream identifier `ff 06 00 00 "S2sTwO"`.  The result is a complete, concatenable .s2
+ * stream; out_off[i] is the start of chunk i (out_off[0] == 10 with the identifier).  dst_cap >= sum(MaxEncodedLen+8)+10. */
+kc_status kc_s2_encode_stream_dev(kc_ctx* ctx, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
+                                  uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off, int with_stream_id);
 /* Single-block form with the WriterCustomEncoder contract (s2/writer.go:1053-1064): no varint header;
  * returns bytes used, 0 = incompressible (store raw), <0 = fall back to the built-in encoder. */
 int64_t kc_s2_encode_block(kc_ctx* ctx, uint8_t* dst, uint64_t dst_cap, const uint8_t* src, uint64_t src_len);

@@ -326,6 +326,27 @@ int64_t kco_s2_emit_repeat(uint8_t* dst, int64_t offset, int64_t length) { retur
 int64_t kco_s2_decode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::Decode(dst, cap, src, (size_t)n); }
 uint32_t kco_s2_crc(const uint8_t* p, uint64_t n) { return s2::crc(p, (size_t)n); }
 
+// s2.Writer output for the blocks (stream identifier optional): chunks back to back; out_off[i] = start of chunk i.
+int64_t kco_s2_encode_stream(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
+                             uint64_t* out_off, int with_stream_id) {
+    static const uint8_t magic[10] = {0xff, 0x06, 0x00, 0x00, 'S', '2', 's', 'T', 'w', 'O'};
+    uint64_t pos = 0;
+    if (with_stream_id) { if (dst_cap < 10) return -2; memcpy(dst, magic, 10); pos = 10; }
+    std::vector<uint8_t> tmp;
+    for (uint32_t i = 0; i < n_blocks; i++) {
+        const size_t n = (size_t)(blk_off[i + 1] - blk_off[i]);
+        tmp.resize(n + 32);
+        const int64_t r = s2::EncodeChunk(tmp.data(), src + blk_off[i], n);
+        out_off[i] = pos;
+        if (pos + (uint64_t)r > dst_cap) return -2;
+        memcpy(dst + pos, tmp.data(), (size_t)r);
+        pos += (uint64_t)r;
+    }
+    out_off[n_blocks] = pos;
+    return (int64_t)pos;
+}
+int64_t kco_s2_decode_stream(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::DecodeStream(dst, cap, src, (size_t)n); }
+
 int64_t kco_s2_encode_blocks(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
                              uint64_t* out_off, int threads) {
     if (threads < 1) threads = 1;

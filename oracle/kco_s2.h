@@ -342,5 +342,51 @@ static inline int64_t Decode(uint8_t* dst, uint64_t cap, const uint8_t* src, siz
     return (int64_t)d;
 }
 
+// s2.Writer chunk for one block (s2/writer.go:414-451): type(1) | len24 | masked CRC32C(4) | body.
+// Compressed body = uvarint(len) + encodeBlock output; encodeBlock == 0 -> uncompressed chunk (type 0x01, raw bytes).
+// Returns bytes written to dst (needs len + 8 + 5).
+static inline int64_t EncodeChunk(uint8_t* dst, const uint8_t* src, size_t n) {
+    const uint32_t checksum = crc(src, n);
+    uint8_t chunkType = 0x01;
+    size_t chunkLen = 4 + n;
+    const int v = putUvarint(dst + 8, (uint64_t)n);
+    const int n2 = encodeBlock(dst + 8 + v, src, n);
+    if (n2 > 0) { chunkType = 0x00; chunkLen = 4 + (size_t)v + (size_t)n2; }
+    else memcpy(dst + 8, src, n);
+    dst[0] = chunkType;
+    dst[1] = (uint8_t)chunkLen; dst[2] = (uint8_t)(chunkLen >> 8); dst[3] = (uint8_t)(chunkLen >> 16);
+    dst[4] = (uint8_t)checksum; dst[5] = (uint8_t)(checksum >> 8); dst[6] = (uint8_t)(checksum >> 16); dst[7] = (uint8_t)(checksum >> 24);
+    return (int64_t)(4 + chunkLen);
+}
+// Stream decoder (verifier): stream identifier + compressed / uncompressed chunks, CRC checked. Returns decoded size or -1.
+static inline int64_t DecodeStream(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n) {
+    static const uint8_t magic[10] = {0xff, 0x06, 0x00, 0x00, 'S', '2', 's', 'T', 'w', 'O'};
+    size_t s = 0;
+    uint64_t d = 0;
+    while (s + 4 <= n) {
+        const uint8_t t = src[s];
+        const size_t cl = (size_t)src[s + 1] | (size_t)src[s + 2] << 8 | (size_t)src[s + 3] << 16;
+        s += 4;
+        if (s + cl > n) return -1;
+        if (t == 0xff) { if (cl != 6 || memcmp(src + s - 4, magic, 10) != 0) return -1; s += cl; continue; }
+        if (t != 0x00 && t != 0x01) return -1;
+        if (cl < 4) return -1;
+        const uint32_t want = load32(src, (int64_t)s);
+        int64_t got;
+        if (t == 0x01) {
+            got = (int64_t)cl - 4;
+            if (d + (uint64_t)got > cap) return -2;
+            memcpy(dst + d, src + s + 4, (size_t)got);
+        } else {
+            got = Decode(dst + d, cap - d, src + s + 4, cl - 4);
+            if (got < 0) return -1;
+        }
+        if (crc(dst + d, (size_t)got) != want) return -3;
+        d += (uint64_t)got;
+        s += cl;
+    }
+    return s == n ? (int64_t)d : -1;
+}
+
 }  // namespace s2
 }  // namespace kco

@@ -73,6 +73,10 @@ def lib():
         L.kco_s2_emit_repeat.argtypes = [u8p, C.c_int64, C.c_int64]
         L.kco_s2_crc.restype = C.c_uint32
         L.kco_s2_crc.argtypes = [u8p, C.c_uint64]
+        L.kco_s2_encode_stream.restype = C.c_int64
+        L.kco_s2_encode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.kco_s2_decode_stream.restype = C.c_int64
+        L.kco_s2_decode_stream.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64]
         L.kco_s2_encode_blocks.restype = C.c_int64
         L.kco_s2_encode_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         _lib = L
@@ -222,4 +226,27 @@ def zstd_decompress(enc: bytes, cap: int, dict_content: bytes = None) -> bytes:
         r = Z.ZSTD_decompress(buf, cap, enc, len(enc))
     if Z.ZSTD_isError(r):
         raise RuntimeError("libzstd: " + Z.ZSTD_getErrorName(r).decode())
+    return buf.raw[:r]
+
+
+def s2_encode_stream(src, blk_off, with_stream_id=True):
+    """Reference s2.Writer framing of the given blocks: (numpy u8 stream, out_off[n+1])."""
+    import numpy as np
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    blk_off = np.ascontiguousarray(blk_off, dtype=np.uint64)
+    n = len(blk_off) - 1
+    cap = int(blk_off[n] - blk_off[0]) + 16 * n + 64
+    dst = np.empty(cap, dtype=np.uint8)
+    oo = np.empty(n + 1, dtype=np.uint64)
+    r = lib().kco_s2_encode_stream(src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, oo.ctypes.data, int(with_stream_id))
+    if r < 0:
+        raise RuntimeError("s2 encode_stream failed %d" % r)
+    return dst[:r], oo
+
+
+def s2_decode_stream(enc: bytes, cap: int) -> bytes:
+    buf = C.create_string_buffer(max(cap, 1))
+    r = lib().kco_s2_decode_stream(enc, len(enc), buf, cap)
+    if r < 0:
+        raise RuntimeError("s2 decode_stream failed %d" % r)
     return buf.raw[:r]

@@ -94,3 +94,25 @@ def test_s2_full_size_roundtrip(oracle, kclib):
         assert oracle.s2_decode(blk, bsz + 8) == buf[i * bsz:(i + 1) * bsz].tobytes()
     assert float(out_off[n]) / (n * bsz) < 0.5
     enc.Close()
+
+
+@pytest.mark.parametrize("with_id", [True, False])
+def test_s2_stream_framing_bit_exact(oracle, kclib, with_id):
+    """s2.Writer framing (stream id, chunk header, masked CRC32C, stored chunks) equals the oracle's and decodes."""
+    import torch
+    from compress_amd import s2
+    blocks = [corpora.corpus("J", 1, 65536, first_unit=k).tobytes() for k in range(24)]
+    blocks += [corpora.corpus("H", 1, 65536, first_unit=k).tobytes() for k in range(4)]
+    blocks += [b"", b"abc", b"x" * 31, b"y" * 32, corpora.corpus("T", 1, 1 << 20).tobytes(), corpora.corpus("M", 1, 200000).tobytes()]
+    buf, off = corpora.pack_units(blocks)
+    d_src = torch.from_numpy(buf).cuda()
+    enc = s2.BlockEncoder()
+    cap = sum(((s2.MaxEncodedLen(len(b)) + 8 + 15) & ~15) for b in blocks) + 80
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    out_off = enc.EncodeStreamDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap, with_stream_id=with_id)
+    out = d_dst[:int(out_off[len(blocks)])].cpu().numpy()
+    ref, ref_off = oracle.s2_encode_stream(buf, off, with_stream_id=with_id)
+    assert np.array_equal(out_off, ref_off)
+    assert np.array_equal(out, ref)
+    assert oracle.s2_decode_stream(out.tobytes(), len(buf) + 8) == buf.tobytes()
+    enc.Close()
