@@ -250,9 +250,39 @@ void build_better_dict_tables(const uint8_t* dict, size_t len, int pos_bits, uin
     }
 }
 
+// fastEncoderDict.Reset (zstd/enc_fast.go:813-845): 2^15 table, 6-byte hash, positions i and i+1 for i stepping by 2.
+// Also the SHORT table of doubleFastEncoderDict, which embeds fastEncoderDict and keeps this priming although its
+// lookups use the 5-byte hash (enc_dfast.go:1053-1056).
+void build_fast_dict_table(const uint8_t* dict, size_t len, int pos_bits, uint32_t* tab) {
+    const int TB = (32 - pos_bits) > 16 ? 16 : (32 - pos_bits);
+    auto tagOf = [&](uint32_t v) -> uint32_t { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; };
+    auto mk = [&](uint64_t pos, uint32_t val) -> uint32_t { return ((uint32_t)pos + 1u) | (tagOf(val) << pos_bits); };
+    if (len < 8) return;
+    for (size_t i = 0; i + 8 < len; i += 2) {
+        uint64_t cv;
+        memcpy(&cv, dict + i, 8);
+        const uint32_t h0 = (uint32_t)(((cv << 16) * 227718039650203ULL) >> (64 - 15));
+        const uint32_t h1 = (uint32_t)((((cv >> 8) << 16) * 227718039650203ULL) >> (64 - 15));
+        tab[h0] = mk(i, (uint32_t)cv);
+        tab[h1] = mk(i + 1, (uint32_t)(cv >> 8));
+    }
+}
+// doubleFastEncoderDict.Reset long table (zstd/enc_dfast.go:1060-1083): every position 0 .. len-9, 8-byte hash, 2^17.
+void build_dfast_dict_long(const uint8_t* dict, size_t len, int pos_bits, uint32_t* ltab) {
+    const int TB = (32 - pos_bits) > 16 ? 16 : (32 - pos_bits);
+    auto tagOf = [&](uint32_t v) -> uint32_t { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; };
+    if (len < 8) return;
+    for (size_t i = 0; i == 0 || i + 8 < len; i++) {
+        uint64_t cv;
+        memcpy(&cv, dict + i, 8);
+        const uint32_t h = (uint32_t)((cv * 0xcf1bbcdcb7a56463ULL) >> (64 - 17));
+        ltab[h] = ((uint32_t)i + 1u) | (tagOf((uint32_t)cv) << pos_bits);
+        if (i + 8 >= len) break;
+    }
+}
+
 kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
     if (o->level < KC_SPEED_FASTEST || o->level > KC_SPEED_BETTER) { c->err = "device path implements SpeedFastest, SpeedDefault and SpeedBetterCompression"; return KC_ERR_UNSUPPORTED; }
-    if ((o->dict != nullptr && o->dict_len > 0) && o->level != KC_SPEED_BETTER) { c->err = "dictionary encoding is implemented for SpeedBetterCompression only on the device path"; return KC_ERR_UNSUPPORTED; }
     if (o->dict_len > ((uint64_t)1 << 20)) { c->err = "dictionary larger than 1 MiB not served by the device path"; return KC_ERR_UNSUPPORTED; }
     if (o->block_size < 1024 || o->block_size > kMaxCompressedBlockSize || o->window_size < kMinWindowSize) { c->err = "bad block/window size"; return KC_ERR_BAD_ARG; }
     return KC_OK;
@@ -275,12 +305,14 @@ kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_
     if (level == KC_SPEED_DEFAULT) {
         kc_status s2 = ensure(c, c->tables, (size_t)n_launch * kc_zdfast_table_bytes());
         if (s2 != KC_OK) return s2;
-        HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * kc_zdfast_table_bytes(), st));
+        if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, kc_zdfast_table_bytes(), n_launch, st);
+        else HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * kc_zdfast_table_bytes(), st));
         kc_launch_zdfast_match_grp(mp, (uint32_t*)c->tables.p, n_launch, st);
         return KC_OK;
     }
     const char* v = getenv("KC_ZFAST_VARIANT");
     std::string var = v ? v : "g8";
+    if (mp.hist0 > 0) var = "g8";  // dictionary-primed tables exist for the group kernels only
     if (var == "lds") {
         bool ok = bs <= 65536;
         for (uint32_t i = 0; i < n_units && ok; i++) if (unit_off[i + 1] - unit_off[i] > 131072) ok = false;
@@ -291,7 +323,8 @@ kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_
     const int G = var == "g16" ? 16 : (var == "g4" ? 4 : (var == "g2" ? 2 : 8));
     kc_status s = ensure(c, c->tables, (size_t)n_launch * kc_zfast_table_bytes());
     if (s != KC_OK) return s;
-    HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * kc_zfast_table_bytes(), st));
+    if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, kc_zfast_table_bytes(), n_launch, st);
+    else HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * kc_zfast_table_bytes(), st));
     kc_launch_zfast_match_grp(mp, (uint32_t*)c->tables.p, n_launch, G, st);
     return KC_OK;
 }
@@ -366,7 +399,11 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
                                (uint32_t)hist0, (uint8_t*)c->work.p, n_units, st);
         // pristine dictionary tables (betterFastEncoderDict.Reset, enc_better.go:1114-1183) in the device entry format
         std::vector<uint8_t> proto(kc_zbetter_table_bytes(), 0);
-        build_better_dict_tables(o->dict, (size_t)hist0, pos_bits, proto.data());
+        if (o->level == KC_SPEED_BETTER) build_better_dict_tables(o->dict, (size_t)hist0, pos_bits, proto.data());
+        else if (o->level == KC_SPEED_DEFAULT) {
+            build_dfast_dict_long(o->dict, (size_t)hist0, pos_bits, (uint32_t*)proto.data());
+            build_fast_dict_table(o->dict, (size_t)hist0, pos_bits, (uint32_t*)(proto.data() + ((size_t)4 << 17)));
+        } else build_fast_dict_table(o->dict, (size_t)hist0, pos_bits, (uint32_t*)proto.data());
         HIPCHK(c, hipMemcpyAsync(c->proto.p, proto.data(), proto.size(), hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));
         k_src = (const uint8_t*)c->work.p;

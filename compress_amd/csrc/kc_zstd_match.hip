@@ -552,27 +552,29 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const bool gact = ui < n_launch;
     const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
-    const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) : 0;
+    const int hist0 = P.hist0;  // dictionary content in front of the unit (history): fastEncoderDict (enc_fast.go:534-790)
+    const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0 : 0;
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
     const int mmo = P.max_match_off;
     const int nblk = (ulen + bs - 1) / bs;
-    const bool HIST = ulen > bs;
+    const bool HIST = ulen > bs || hist0 > 0;  // with a dictionary encodeAll always calls Encode (encoder.go:783-787)
     const uint32_t pm = (gact && P.popmask) ? P.popmask[u] : 0u;
     uint32_t* __restrict__ tab = tables + (size_t)ui * (1u << ZF_TABLE_BITS);  // zeroed by the host before the launch
     // Table entry = (position+1) in the low PB bits | a TB-bit tag of the 4 source bytes at that position.
     // The reference accepts a candidate iff its 4 bytes equal the probe's (tableEntry.val == uint32(cv),
     // enc_fast.go:176,188); a tag mismatch proves they differ, so the (random, HBM-bound) candidate fetch is
     // skipped exactly when the reference would reject anyway; equal tags are still verified on the bytes.
-    const int PB = ulen > 16 ? bits_len32((uint32_t)(ulen - 6)) : 5;
+    const int PB = P.pos_bits;  // per-launch constant (dictionary-primed tables are shared by all units)
     const int TB = (32 - PB) > 16 ? 16 : (32 - PB);
     const uint32_t posMask = (PB >= 32) ? 0xFFFFFFFFu : ((1u << PB) - 1u);
     auto tagOf = [&](uint32_t v) -> uint32_t { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; };
 
     int o1 = 1, o2 = 4;
+    bool allDirty = false;  // fastEncoderDict.allDirty: small-input variant (kSearchStrength 7) only until a block > 32 KiB was seen
     for (int b = 0; b < nblk; b++) {  // group-uniform trip count; groups diverge freely
-        const int blkStart = b * bs;
-        const int blkEnd = (blkStart + bs < ulen) ? blkStart + bs : ulen;
+        const int blkStart = hist0 + b * bs;
+        const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;
         const int srcLen = blkEnd - blkStart;
         const int o1_in = o1, o2_in = o2;
         uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
@@ -586,6 +588,10 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
             nseq++;
             sumLL += ll;
         };
+        int SK = 5;  // kSearchStrength - 1
+        if (hist0 > 0) {  // enc_fast.go:539-543,585
+            if (allDirty || srcLen > (32 << 10)) allDirty = true; else SK = 6;
+        }
         if (srcLen >= 10) {
             const int sLimit = blkEnd - 8;
             bool canRep = false, fin = false, pendO2 = false;
@@ -593,10 +599,10 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
             while (!fin) {
                 rounds++;
                 const int d0 = s - nextEmit;
-                const int k0 = d0 >> 5;
+                const int k0 = d0 >> SK;
                 const int step = 2 + k0;
                 const int p = s + lig * step;
-                const bool valid = lig < W && (lig == 0 || ((d0 + (lig - 1) * step) >> 5) == k0) && p < sLimit;
+                const bool valid = lig < W && (lig == 0 || ((d0 + (lig - 1) * step) >> SK) == k0) && p < sLimit;
                 const uint64_t cv = valid ? ld64(base + p) : 0ull;
                 if (pendO2) {  // offset-2 check (enc_fast.go:250) sharing this round's source load
                     pendO2 = false;
@@ -664,7 +670,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                         s = s + c * step;
                     } else {
                         const int pl = s + (nvalid - 1) * step;
-                        s = pl + 2 + ((pl - nextEmit) >> 5);
+                        s = pl + 2 + ((pl - nextEmit) >> SK);
                     }
                     if (s >= sLimit) fin = true;
                     continue;

@@ -31,16 +31,17 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
     const bool gact = ui < n_launch;
     const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
-    const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) : 0;
+    const int hist0 = P.hist0;  // dictionary content in front of the unit: doubleFastEncoderDict (enc_dfast.go:678-1031)
+    const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0 : 0;
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
     const int mmo = P.max_match_off;
     const int nblk = (ulen + bs - 1) / bs;
-    const bool HIST = ulen > bs;
+    const bool HIST = ulen > bs || hist0 > 0;
     const uint32_t pm = (gact && P.popmask) ? P.popmask[u] : 0u;
     uint32_t* __restrict__ ltab = tables + (size_t)ui * ((1u << ZD_LONG_BITS) + (1u << ZD_SHORT_BITS));
     uint32_t* __restrict__ stab = ltab + (1u << ZD_LONG_BITS);
-    const int PB = ulen > 16 ? bits_len32((uint32_t)ulen) : 5;
+    const int PB = P.pos_bits;
     const int TB = (32 - PB) > 16 ? 16 : (32 - PB);
     const uint32_t posMask = (1u << PB) - 1u;
     auto tagOf = [&](uint32_t v) -> uint32_t { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; };
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
 
     int o1 = 1, o2 = 4;
     for (int b = 0; b < nblk; b++) {
-        const int blkStart = b * bs;
-        const int blkEnd = (blkStart + bs < ulen) ? blkStart + bs : ulen;
+        const int blkStart = hist0 + b * bs;
+        const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;
         const int srcLen = blkEnd - blkStart;
         const int o1_in = o1, o2_in = o2;
         uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;

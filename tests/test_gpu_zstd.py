@@ -128,9 +128,11 @@ def test_device_resident_roundtrip_full_size(oracle, kclib, level):
     enc.Close()
 
 
+@pytest.mark.parametrize("level", [1, 2, 3])
 @pytest.mark.parametrize("dict_id", [0, 1, 70000])
-def test_better_with_raw_dictionary_bit_exact(oracle, kclib, dict_id):
-    """C5: SpeedBetterCompression + 64 KiB raw-content dictionary (WithEncoderDictRaw), mixed corpus."""
+def test_with_raw_dictionary_bit_exact(oracle, kclib, dict_id, level):
+    """C5: 64 KiB raw-content dictionary (WithEncoderDictRaw) at every level, mixed corpus.  Units <= 32 KiB take the
+    fastEncoderDict small-input variant (kSearchStrength 7) at SpeedFastest."""
     _torch()
     from compress_amd import zstd
     dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
@@ -138,10 +140,11 @@ def test_better_with_raw_dictionary_bit_exact(oracle, kclib, dict_id):
     units = [buf[i * 131072:(i + 1) * 131072].tobytes() for i in range(48)]
     t = corpora.corpus("T", 8, 131072, first_unit=77).tobytes()
     units += [t[:200000], t[5:40000], t[:9], t[:100], b"", t[100000:400000], dct[:50000], dct]
+    units += [t[7:7 + n] for n in (32768, 32769, 20000, 4096, 1000, 17, 65536, 65537, 98304)] + [dct[1000:30000], buf[3000:30000].tobytes()]
     ubuf, off = corpora.pack_units(units)
-    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(zstd.SpeedBetterCompression), zstd.WithEncoderDictRaw(dict_id, dct))
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderDictRaw(dict_id, dct))
     out, out_off = enc.EncodeUnits(ubuf, off)
-    ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=3, dict_id=dict_id, dict_content=dct)
+    ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=level, dict_id=dict_id, dict_content=dct)
     bad = [i for i in range(len(units))
            if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
     assert not bad, bad[:10]
