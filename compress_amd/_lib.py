@@ -23,6 +23,8 @@ class ZstdOpts(C.Structure):
         ("single", C.c_int32), ("full_zero", C.c_int32), ("no_entropy", C.c_int32), ("all_lit_entropy", C.c_int32),
         ("low_mem", C.c_int32), ("custom_window", C.c_int32), ("custom_block", C.c_int32), ("custom_alent", C.c_int32),
         ("dict_id", C.c_uint32), ("dict", C.c_void_p), ("dict_len", C.c_uint64),
+        ("dict_offsets", C.c_uint32 * 3), ("dict_huf_len", C.c_int32), ("dict_huf_log", C.c_int32),
+        ("dict_huf_val", C.c_uint16 * 256), ("dict_huf_nbits", C.c_uint8 * 256),
     ]
 
 
@@ -34,7 +36,7 @@ class Timings(C.Structure):
 # every symbol include/kcgpu.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "kc_zstd_opts_default", "kc_zstd_opts_level", "kc_zstd_opts_window", "kc_zstd_opts_crc", "kc_zstd_opts_zero_frames",
-    "kc_zstd_opts_no_entropy", "kc_zstd_opts_all_lit_entropy", "kc_zstd_opts_single_segment", "kc_zstd_opts_dict_raw",
+    "kc_zstd_opts_no_entropy", "kc_zstd_opts_all_lit_entropy", "kc_zstd_opts_single_segment", "kc_zstd_opts_dict_raw", "kc_zstd_opts_dict",
     "kc_zstd_max_encoded_size", "kc_ctx_create", "kc_ctx_destroy", "kc_last_error", "kc_device_info",
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
     "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_encode_block",
@@ -74,6 +76,8 @@ def load():
         f.restype = C.c_int
     L.kc_zstd_opts_dict_raw.argtypes = [po, C.c_uint32, vp, u64]
     L.kc_zstd_opts_dict_raw.restype = C.c_int
+    L.kc_zstd_opts_dict.argtypes = [po, vp, u64]
+    L.kc_zstd_opts_dict.restype = C.c_int
     L.kc_zstd_max_encoded_size.argtypes = [po, C.c_int64]
     L.kc_zstd_max_encoded_size.restype = C.c_int64
     L.kc_ctx_create.argtypes = [C.POINTER(vp), C.c_int, vp]

@@ -36,7 +36,7 @@ struct kc_ctx {
     std::string err;
     hipDeviceProp_t prop;
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
-        predef, errflag, tmp_src, tmp_dst, tables, prof, work, work_off, dictbuf, proto;
+        predef, errflag, tmp_src, tmp_dst, tables, prof, work, work_off, dictbuf, proto, dicthuf;
     bool predef_ready = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream2 = nullptr;  // entropy kernels of chunk i overlap the match finder of chunk i+1
@@ -87,6 +87,7 @@ void kc_zstd_opts_default(kc_zstd_opts* o) {  // setDefault :36-48
     o->no_entropy = 0;
     o->all_lit_entropy = 0;
     o->low_mem = 0;
+    o->dict_offsets[0] = 1; o->dict_offsets[1] = 4; o->dict_offsets[2] = 8;
 }
 
 int kc_zstd_opts_level(kc_zstd_opts* o, int l) {  // WithEncoderLevel :236-266
@@ -127,6 +128,9 @@ int kc_zstd_opts_dict_raw(kc_zstd_opts* o, uint32_t id, const uint8_t* content, 
     o->dict_id = id;
     o->dict = content;
     o->dict_len = len;
+    o->dict_offsets[0] = 1; o->dict_offsets[1] = 4; o->dict_offsets[2] = 8;  // offsets: [3]int{1, 4, 8}, no litEnc
+    o->dict_huf_len = 0;
+    o->dict_huf_log = 0;
     return KC_OK;
 }
 
@@ -175,7 +179,7 @@ void kc_ctx_destroy(kc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
-                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto};
+                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
@@ -415,6 +419,9 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     mp.unit_off = k_off;
     mp.hist0 = hist0;
     mp.pos_bits = pos_bits;
+    mp.rep1 = (int32_t)o->dict_offsets[0];
+    mp.rep2 = (int32_t)o->dict_offsets[1];
+    if (mp.rep1 <= 0 || mp.rep2 <= 0) { mp.rep1 = 1; mp.rep2 = 4; }  // opts not initialised through kc_zstd_opts_default
     mp.unit_blk0 = (const uint32_t*)c->unit_blk0.p;
     mp.seqs = (uint64_t*)c->seqs.p;
     mp.meta = (KcBlkMeta*)c->meta.p;
@@ -432,6 +439,20 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     ep.src = k_src;
     ep.unit_off = k_off;
     ep.hist0 = hist0;
+    ep.dict_huf = nullptr;
+    ep.dict_huf_len = 0;
+    ep.dict_huf_log = 0;
+    if (o->dict_huf_len > 0) {  // dictionary literal table -> prevTable of every unit's first block
+        uint8_t blobh[768];
+        memcpy(blobh, o->dict_huf_val, 512);
+        memcpy(blobh + 512, o->dict_huf_nbits, 256);
+        if ((s = ensure(c, c->dicthuf, 768))) return s;
+        HIPCHK(c, hipMemcpyAsync(c->dicthuf.p, blobh, 768, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));  // blobh is a stack buffer
+        ep.dict_huf = (const uint8_t*)c->dicthuf.p;
+        ep.dict_huf_len = o->dict_huf_len;
+        ep.dict_huf_log = o->dict_huf_log;
+    }
     ep.unit_blk0 = mp.unit_blk0;
     ep.seqs = mp.seqs;
     ep.meta = mp.meta;
@@ -692,6 +713,8 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
     if (mp.spec_w0 < 1) mp.spec_w0 = 1;
     if (mp.spec_w0 > 8) mp.spec_w0 = 8;
     mp.hist0 = 0;
+    mp.rep1 = 1;
+    mp.rep2 = 4;
     {
         uint64_t maxLen = 16;
         for (uint32_t i = 0; i < n_units; i++) maxLen = std::max<uint64_t>(maxLen, unit_off[i + 1] - unit_off[i]);

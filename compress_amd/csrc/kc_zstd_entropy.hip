@@ -377,7 +377,8 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
             if (m.flags & KC_BF_POP_A) litsOnly = true;  // saved < 16: popOffsets + encodeLits(org, rawAllLits)
         }
         // encodeLits (blockenc.go:337-352): extremely small blocks and rawAllLits go out as raw blocks
-        if (litsOnly && (rawAllLits || size < 32)) {
+        const bool dictLit = b == 0 && P.dict_huf != nullptr;  // blk.dictLitEnc: first block only (reset clears it, blockenc.go:97)
+        if (litsOnly && (rawAllLits || size < (dictLit ? 8 : 32))) {
             if (tid == 0) put_block_header(bout, last, 0u, (uint32_t)size);
             wg_copy(bout + 3, org, size);
             opos += 3 + size;
@@ -455,6 +456,14 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
             S.ivar[IV_SYMLEN] = (int)symbolLen;
             S.ivar[IV_MAXCNT] = (int)maxCount;
             S.ivar[IV_OK] = 0;
+            if (dictLit) {  // TransferCTable(dictLitEnc) + Reuse = Allow, before the size checks (blockenc.go:358-362, 518-522)
+                const uint16_t* dv = (const uint16_t*)P.dict_huf;
+                const uint8_t* dn = P.dict_huf + 512;
+                for (int k = 0; k < P.dict_huf_len; k++) { S.huf.prev.val[k] = dv[k]; S.huf.prev.nb[k] = dn[k]; }
+                S.huf.prevLen = P.dict_huf_len;
+                S.huf.prevLog = (uint8_t)P.dict_huf_log;
+                S.huf.reuse = 0;
+            }
             if (wantHuf) {
                 if (S.huf.reuse == 2) S.huf.prevLen = 0;  // ReusePolicyNone nukes prevTable (compress.go:45)
                 if ((int)maxCount >= nlitE) litMode = (nlitE == 1) ? 0 : 1;              // single symbol -> RLE

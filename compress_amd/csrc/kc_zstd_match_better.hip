@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
     auto hL = [&](uint64_t v) -> uint32_t { return hash8(v, ZB_LONG_BITS); };
     auto hS = [&](uint64_t v) -> uint32_t { return hash5(v, ZB_SHORT_BITS); };
 
-    int o1 = 1, o2 = 4;  // raw-content dictionaries keep {1,4,8} too (encoder_options.go:398-406)
+    int o1 = P.rep1, o2 = P.rep2;  // {1,4} (blockenc.go:78) or the dictionary's offsets (enc_base.go:189-195)
     for (int b = 0; b < nblk; b++) {
         const int blkStart = hist0 + b * bs;
         const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;  // == len(e.hist)

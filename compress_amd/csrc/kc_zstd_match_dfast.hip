@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
     auto hL = [&](uint64_t v) -> uint32_t { return hash8(v, ZD_LONG_BITS); };
     auto hS = [&](uint64_t v) -> uint32_t { return hash5(v, ZD_SHORT_BITS); };
 
-    int o1 = 1, o2 = 4;
+    int o1 = P.rep1, o2 = P.rep2;  // {1,4} (blockenc.go:78) or the dictionary's offsets (enc_base.go:189-195)
     for (int b = 0; b < nblk; b++) {
         const int blkStart = hist0 + b * bs;
         const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;

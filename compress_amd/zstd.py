@@ -85,6 +85,19 @@ def WithEncoderDictRaw(id, content):
     return apply
 
 
+def WithEncoderDict(dict):
+    """zstd.WithEncoderDict (zstd/encoder_options.go:382-391): a dictionary in the `zstd --train` format."""
+    blob = bytes(dict)
+
+    def apply(o):
+        L = _lib.load()
+        buf = C.create_string_buffer(blob, len(blob))
+        o._dict_keep = buf  # o.dict points into the blob
+        if L.kc_zstd_opts_dict(C.byref(o), C.cast(buf, C.c_void_p), len(blob)) != 0:
+            raise ValueError("dictionary rejected (loadDict error)")
+    return apply
+
+
 def WithEncoderConcurrency(n):
     """Accepted for API compatibility; the device path is batch-parallel (no bytes depend on it)."""
     if n <= 0:

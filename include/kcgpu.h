@@ -56,8 +56,14 @@ typedef struct {
     int32_t low_mem;         /* o.lowMem         (WithLowerEncoderMem; no effect on bytes) */
     int32_t custom_window, custom_block, custom_alent; /* o.customWindow / customBlockSize / customALEntropy */
     uint32_t dict_id;        /* WithEncoderDictRaw id (0 = no dictionary) */
-    const uint8_t* dict;     /* raw dictionary content (host pointer), used as initial history */
+    const uint8_t* dict;     /* dictionary content (host pointer), used as initial history */
     uint64_t dict_len;
+    /* full-format dictionaries only (kc_zstd_opts_dict); raw dictionaries keep {1,4,8} and no literal table */
+    uint32_t dict_offsets[3];     /* dict.offsets -> blk.recentOffsets (zstd/enc_base.go:189-195) */
+    int32_t dict_huf_len;         /* len(dict.litEnc.prevTable); 0 = no literal table */
+    int32_t dict_huf_log;         /* dict.litEnc.prevTableLog */
+    uint16_t dict_huf_val[256];   /* cTableEntry.val  (huff0/decompress.go:142-165) */
+    uint8_t dict_huf_nbits[256];  /* cTableEntry.nBits */
 } kc_zstd_opts;
 
 /* encoderOptions.setDefault, zstd/encoder_options.go:36-48 */
@@ -74,6 +80,11 @@ int kc_zstd_opts_all_lit_entropy(kc_zstd_opts* o, int b);
 int kc_zstd_opts_single_segment(kc_zstd_opts* o, int b);
 /* WithEncoderDictRaw, zstd/encoder_options.go:398-406 */
 int kc_zstd_opts_dict_raw(kc_zstd_opts* o, uint32_t id, const uint8_t* content, uint64_t len);
+/* WithEncoderDict, zstd/encoder_options.go:382-391: a dictionary in the "zstd --train" format.  Parses it like loadDict
+ * (zstd/dict.go:71-150): ID, literal Huffman table (becomes huff0 prevTable of each unit's first block,
+ * zstd/blockenc.go:518-522), repeat offsets, content.  `blob` must outlive every encode call using `o`
+ * (o->dict points into it).  Returns 0, or -1 when the reference's loadDict would return an error. */
+int kc_zstd_opts_dict(kc_zstd_opts* o, const uint8_t* blob, uint64_t len);
 
 /* (*Encoder).MaxEncodedSize, zstd/encoder.go:843-873 (padding off) */
 int64_t kc_zstd_max_encoded_size(const kc_zstd_opts* o, int64_t size);

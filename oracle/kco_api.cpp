@@ -11,6 +11,7 @@
 #include "kco_zstd_dfast.h"
 #include "kco_zstd_better.h"
 #include "kco_s2.h"
+#include "kco_dict.h"
 #include <thread>
 #include <atomic>
 #include <memory>
@@ -35,6 +36,7 @@ typedef struct {
     uint32_t dict_id;         // 0 = no dict (raw-content dictionary, WithEncoderDictRaw)
     const uint8_t* dict;      // dict content
     uint64_t dict_len;
+    int32_t dict_full;        // 1: dict/dict_len is a full-format dictionary blob (WithEncoderDict -> loadDict)
 } kco_zstd_opts;
 
 }  // extern "C"
@@ -87,10 +89,15 @@ struct OracleEncoder {
     kco_zstd_opts o;
     DictO dict;
     bool hasDict = false;
+    bool bad = false;  // loadDict returned an error (the EOption would have failed)
+    huff0::Scratch dictLit;
     std::unique_ptr<FastBase> enc;
 
     explicit OracleEncoder(const kco_zstd_opts& opts) : o(opts) {
-        if (o.dict_id != 0 || (o.dict != nullptr && o.dict_len > 0)) {
+        if (o.dict_full) {
+            hasDict = true;
+            if (!dictload::loadDict(o.dict, (size_t)o.dict_len, &dict, &dictLit)) bad = true;
+        } else if (o.dict_id != 0 || (o.dict != nullptr && o.dict_len > 0)) {
             hasDict = true;
             dict.id = o.dict_id;
             dict.content.assign(o.dict, o.dict + o.dict_len);
@@ -179,7 +186,26 @@ int64_t maxEncodedSize(const kco_zstd_opts* o, int64_t size) {
 
 extern "C" {
 
-void* kco_zstd_encoder_new(const kco_zstd_opts* opts) { return new OracleEncoder(*opts); }
+// loadDict result as the encoder sees it (zstd/dict.go:71-150): returns 0, or -1 when loadDict errors.
+int kco_zstd_load_dict(const uint8_t* blob, uint64_t len, uint32_t* id, int32_t* offsets, uint16_t* val, uint8_t* nbits,
+                       int32_t* huf_len, int32_t* huf_log, uint64_t* content_off) {
+    DictO d;
+    huff0::Scratch lit;
+    if (!dictload::loadDict(blob, (size_t)len, &d, &lit)) return -1;
+    *id = d.id;
+    for (int k = 0; k < 3; k++) offsets[k] = d.offsets[k];
+    for (int k = 0; k < 256; k++) { val[k] = k < lit.prevTable.len ? lit.prevTable.e[k].val : 0; nbits[k] = k < lit.prevTable.len ? lit.prevTable.e[k].nBits : 0; }
+    *huf_len = lit.prevTable.len;
+    *huf_log = lit.prevTableLog;
+    *content_off = len - d.content.size();
+    return 0;
+}
+
+void* kco_zstd_encoder_new(const kco_zstd_opts* opts) {
+    OracleEncoder* e = new OracleEncoder(*opts);
+    if (e->bad) { delete e; return nullptr; }
+    return e;
+}
 void kco_zstd_encoder_free(void* e) { delete (OracleEncoder*)e; }
 
 // EncodeAll(src, nil) on a persistent encoder state (like one pooled Go encoder).
@@ -207,6 +233,7 @@ int64_t kco_zstd_encode_units(const kco_zstd_opts* opts, const uint8_t* src, con
     std::atomic<int> fail(0);
     auto worker = [&]() {
         OracleEncoder enc(*opts);
+        if (enc.bad) { fail = 1; return; }
         for (;;) {
             uint32_t i = next.fetch_add(1);
             if (i >= n_units) break;

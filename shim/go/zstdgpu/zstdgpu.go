@@ -26,6 +26,7 @@ type Encoder struct {
 	opts    C.kc_zstd_opts
 	cpuOpts []zstd.EOption
 	cpu     *zstd.Encoder
+	dictMem unsafe.Pointer // C copy of the dictionary (kc_zstd_opts.dict points into it)
 }
 
 func WithEncoderLevel(l zstd.EncoderLevel) Option {
@@ -72,6 +73,37 @@ func WithSingleSegment(b bool) Option {
 	}
 }
 
+// WithEncoderDict registers a dictionary in the "zstd --train" format (zstd.WithEncoderDict).
+func WithEncoderDict(dict []byte) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithEncoderDict(dict))
+		e.setDictMem(dict)
+		if C.kc_zstd_opts_dict(&e.opts, (*C.uint8_t)(e.dictMem), C.uint64_t(len(dict))) != 0 {
+			return errors.New("invalid dictionary")
+		}
+		return nil
+	}
+}
+
+// WithEncoderDictRaw registers raw content as initial history (zstd.WithEncoderDictRaw).
+func WithEncoderDictRaw(id uint32, content []byte) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithEncoderDictRaw(id, content))
+		e.setDictMem(content)
+		if C.kc_zstd_opts_dict_raw(&e.opts, C.uint32_t(id), (*C.uint8_t)(e.dictMem), C.uint64_t(len(content))) != 0 {
+			return errors.New("invalid dictionary")
+		}
+		return nil
+	}
+}
+
+func (e *Encoder) setDictMem(b []byte) {
+	if e.dictMem != nil {
+		C.free(e.dictMem)
+	}
+	e.dictMem = C.CBytes(b) // the options struct keeps a pointer: it must not live in Go memory
+}
+
 func boolInt(b bool) C.int {
 	if b {
 		return 1
@@ -104,6 +136,10 @@ func (e *Encoder) Close() {
 	if e.ctx != nil {
 		C.kc_ctx_destroy(e.ctx)
 		e.ctx = nil
+	}
+	if e.dictMem != nil {
+		C.free(e.dictMem)
+		e.dictMem = nil
 	}
 	e.cpu.Close()
 }

@@ -123,6 +123,20 @@ def main():
     z = open(os.path.join(REF, "zstd/testdata/z000028.zst"), "rb").read()
     zin = open(os.path.join(REF, "zstd/testdata/z000028"), "rb").read()
     out["files"]["z000028"] = {"len": len(zin), "xxh64": "%016x" % xxh64(zin), "zst_trailer": z[-4:].hex()}
+    # Full-format dictionary fixtures of the reference's dictionary tests (zstd/dict_test.go:150 TestEncoder_SmallDict reads
+    # testdata/dict-tests-small.zip): d0.dict + the d0/*.zst frames (compressed WITH that dictionary by the C zstd; the
+    # tests decode them with libzstd to get inputs typical for the dictionary).  Frames <= 32 KiB only, to stay small.
+    import zipfile
+    zf = zipfile.ZipFile(os.path.join(REF, "zstd/testdata/dict-tests-small.zip"))
+    ddir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dict")
+    os.makedirs(ddir, exist_ok=True)
+    blob = zf.read("d0.dict")
+    open(os.path.join(ddir, "d0.dict"), "wb").write(blob)
+    names = sorted(n for n in zf.namelist() if n.startswith("d0/") and n.endswith(".zst") and zf.getinfo(n).file_size <= 32768)
+    for n in names:
+        open(os.path.join(ddir, os.path.basename(n)), "wb").write(zf.read(n))
+    out["dict"] = {"d0.dict": {"len": len(blob), "sha256": hashlib.sha256(blob).hexdigest(), "id": struct.unpack_from("<I", blob, 4)[0]},
+                   "frames": [os.path.basename(n) for n in names]}
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "kats.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote kats.json:", {k: (len(v) if hasattr(v, "__len__") else v) for k, v in out.items()})

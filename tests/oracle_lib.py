@@ -16,6 +16,7 @@ class ZstdOpts(C.Structure):
         ("level", C.c_int32), ("window_size", C.c_int32), ("block_size", C.c_int32), ("crc", C.c_int32),
         ("single", C.c_int32), ("full_zero", C.c_int32), ("no_entropy", C.c_int32), ("all_lit_entropy", C.c_int32),
         ("low_mem", C.c_int32), ("dict_id", C.c_uint32), ("dict", C.c_char_p), ("dict_len", C.c_uint64),
+        ("dict_full", C.c_int32),
     ]
 
 
@@ -84,7 +85,7 @@ def lib():
 
 
 def make_opts(level=2, window_size=None, block_size=None, crc=True, single=None, full_zero=True,
-              no_entropy=False, all_lit_entropy=None, low_mem=False, dict_id=0, dict_content=None):
+              no_entropy=False, all_lit_entropy=None, low_mem=False, dict_id=0, dict_content=None, dict_blob=None):
     """Resolved options.  Defaults follow encoderOptions.setDefault + WithEncoderLevel
     (zstd/encoder_options.go:36-48,236-266)."""
     if window_size is None:
@@ -102,6 +103,11 @@ def make_opts(level=2, window_size=None, block_size=None, crc=True, single=None,
     o._keep = dict_content
     o.dict = dict_content
     o.dict_len = len(dict_content) if dict_content else 0
+    if dict_blob is not None:  # WithEncoderDict: full-format dictionary, parsed by the oracle's loadDict
+        o._keep = dict_blob
+        o.dict = dict_blob
+        o.dict_len = len(dict_blob)
+        o.dict_full = 1
     return o
 
 
@@ -143,6 +149,20 @@ def zstd_encode_units(src, unit_off, threads=1, **kw):
     if r < 0:
         raise RuntimeError("oracle encode_units failed: %d" % r)
     return dst[:r], out_off
+
+
+def zstd_load_dict(blob: bytes):
+    """loadDict as the encoder sees it: dict(id, offsets, val[256], nbits[256], huf_len, huf_log, content_off) or None."""
+    L = lib()
+    L.kco_zstd_load_dict.restype = C.c_int
+    L.kco_zstd_load_dict.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_int32 * 3), C.POINTER(C.c_uint16 * 256),
+                                     C.POINTER(C.c_uint8 * 256), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    id_, offs, val, nb = C.c_uint32(), (C.c_int32 * 3)(), (C.c_uint16 * 256)(), (C.c_uint8 * 256)()
+    hl, hg, co = C.c_int32(), C.c_int32(), C.c_uint64()
+    if L.kco_zstd_load_dict(blob, len(blob), C.byref(id_), C.byref(offs), C.byref(val), C.byref(nb), C.byref(hl), C.byref(hg), C.byref(co)) != 0:
+        return None
+    return {"id": id_.value, "offsets": list(offs), "val": list(val), "nbits": list(nb), "huf_len": hl.value, "huf_log": hg.value,
+            "content_off": co.value}
 
 
 def zstd_parse_unit(src: bytes, **kw):

@@ -101,3 +101,32 @@ def test_corpus_generator_deterministic_and_shardable(kclib):
         assert not np.array_equal(x[:70000], x[70000:])
     h = corpora.corpus("H", 1, 1 << 16)
     assert len(np.unique(h)) == 256
+
+
+def test_full_format_dictionary_loader_matches_oracle(oracle):
+    """kc_zstd_opts_dict (WithEncoderDict) against the oracle's loadDict restatement (zstd/dict.go:71-150) on the
+    reference's own dictionary fixture (tests/golden/dict/d0.dict): ID, offsets, literal cTable, content start;
+    and loadDict's error cases."""
+    import ctypes as C
+    from compress_amd import zstd, _lib
+    blob = open(os.path.join(ROOT, "tests", "golden", "dict", "d0.dict"), "rb").read()
+    ref = oracle.zstd_load_dict(blob)
+    assert ref is not None and ref["huf_len"] > 0
+    e = zstd.NewWriter(None, zstd.WithEncoderDict(blob))
+    o = e.o
+    assert o.dict_id == ref["id"] == int.from_bytes(blob[4:8], "little")
+    assert list(o.dict_offsets) == ref["offsets"]
+    assert (o.dict_huf_len, o.dict_huf_log) == (ref["huf_len"], ref["huf_log"])
+    assert list(o.dict_huf_val) == ref["val"]
+    assert list(o.dict_huf_nbits) == ref["nbits"]
+    assert o.dict_len == len(blob) - ref["content_off"]
+    base = C.addressof(o._dict_keep)
+    assert o.dict - base == ref["content_off"]
+    # error behaviour: bad magic, ID 0, truncated tables, offsets beyond the content
+    for bad in (b"\x00" + blob[1:], blob[:4] + b"\0\0\0\0" + blob[8:], blob[:20], blob[:60], blob[:ref["content_off"] + 2]):
+        assert oracle.zstd_load_dict(bad) is None
+        with pytest.raises(ValueError):
+            zstd.NewWriter(None, zstd.WithEncoderDict(bad))
+    # a raw dictionary afterwards resets offsets and drops the literal table (last option wins, like o.dict = ...)
+    e = zstd.NewWriter(None, zstd.WithEncoderDict(blob), zstd.WithEncoderDictRaw(7, b"x" * 100))
+    assert (list(e.o.dict_offsets), e.o.dict_huf_len, e.o.dict_id) == ([1, 4, 8], 0, 7)

@@ -153,3 +153,31 @@ def test_with_raw_dictionary_bit_exact(oracle, kclib, dict_id, level):
             frame = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
             assert oracle.zstd_decompress(frame, len(units[i]) + 16, dict_content=dct) == units[i]
     enc.Close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("which", ["d0", "skewed"])
+def test_with_full_format_dictionary_bit_exact(oracle, kclib, level, which):
+    """a16: WithEncoderDict (zstd --train format): dictionary offsets, content as history and the literal Huffman table
+    as prevTable of each unit's first block.  'd0' is the reference's own fixture with inputs of its kind; 'skewed' makes
+    huff0 actually keep the dictionary table (treeless literals) and exercises encodeLits' 8..31-byte rule."""
+    _torch()
+    from compress_amd import zstd
+    import test_oracle_kats as tk
+    blob, ins = tk._dict_fixture(oracle)
+    units = list(ins) + [ins[1][:40], ins[1][:20], ins[1][:9], b"", ins[2] + ins[4] + ins[2][:50000]]
+    if which == "skewed":
+        blob, probs = tk.skewed_dict(blob)
+        units += tk.skewed_units(probs, seeds=4)
+    units += [corpora.corpus("T", 3, 131072, first_unit=5).tobytes()[:n] for n in (300000, 131072, 65537, 31, 17)]
+    ubuf, off = corpora.pack_units(units)
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderDict(blob))
+    out, out_off = enc.EncodeUnits(ubuf, off)
+    ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=level, dict_blob=blob)
+    bad = [i for i in range(len(units))
+           if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
+    assert not bad, bad[:10]
+    for i in (1, 3, len(units) - 5):
+        frame = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        assert oracle.zstd_decompress(frame, len(units[i]) + 16, dict_content=blob) == units[i]
+    enc.Close()

@@ -179,3 +179,67 @@ def test_raw_dictionary_roundtrip(oracle, level):
         won += len(out) < len(plain.encode_all(u))
     assert won >= 6  # the dictionary helps on text-like units
     assert e0.encode_all(b"").hex() == "28b52ffd2000010000"
+
+
+def _dict_fixture(oracle):
+    """The reference's dictionary fixture (zstd/dict_test.go:150 TestEncoder_SmallDict; tests/golden/make_golden.py):
+    d0.dict + inputs recovered by decoding the C-zstd frames with libzstd and the dictionary."""
+    import glob
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dict")
+    blob = open(os.path.join(gdir, "d0.dict"), "rb").read()
+    ins = [oracle.zstd_decompress(open(f, "rb").read(), 1 << 22, dict_content=blob) for f in sorted(glob.glob(os.path.join(gdir, "*.zst")))]
+    return blob, ins
+
+
+def skewed_dict(blob):
+    """d0.dict with its (nearly flat, hence never reused) literal Huffman description replaced by a skewed 7-symbol code
+    (direct weights 6,5,4,3,2,1,(1) -> code lengths 1..6,6 for bytes 0..6) and another ID.  Returns (blob, probabilities)."""
+    hb = blob[8]
+    end = 9 + hb if hb < 128 else 9 + ((hb - 127) + 1) // 2
+    wts = [6, 5, 4, 3, 2, 1]
+    desc = bytes([127 + len(wts)]) + bytes([(wts[i] << 4) | wts[i + 1] for i in range(0, len(wts), 2)])
+    return blob[:4] + (0x1234567).to_bytes(4, "little") + desc + blob[end:], [2.0 ** -k for k in (1, 2, 3, 4, 5, 6, 6)]
+
+
+def skewed_units(probs, sizes=(20, 31, 40, 100, 300, 1000, 1024, 4000, 70000), seeds=3):
+    import numpy as np
+    out = []
+    for n in sizes:
+        for seed in range(seeds):
+            out.append(np.random.default_rng(seed * 1000 + n).choice(7, size=n, p=probs).astype(np.uint8).tobytes())
+    return out
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_full_dictionary_roundtrip_like_TestEncoder_SmallDict(oracle, level):
+    """WithEncoderDict (encoder_options.go:382-391): the same loop as the reference's TestEncoder_SmallDict
+    (decode fixture -> EncodeAll with the dictionary -> decode with the dictionary), with libzstd as the decoder."""
+    blob, ins = _dict_fixture(oracle)
+    enc = oracle.ZstdOracle(level=level, dict_blob=blob)
+    plain = oracle.ZstdOracle(level=level)
+    tot = tot_plain = 0
+    for d in ins + [ins[1][:40], ins[1][:20], ins[1][:9], b""]:
+        fr = enc.encode_all(d)
+        assert oracle.zstd_decompress(fr, len(d) + 16, dict_content=blob) == d
+        tot += len(fr)
+        tot_plain += len(plain.encode_all(d))
+    assert tot < tot_plain * 0.95  # the dictionary pays on its own kind of data
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_full_dictionary_literal_table_is_used_and_decodes(oracle, level):
+    """Pins loadDict's Huffman table (huff0.ReadTable -> prevTable) with an independent decoder: on literals drawn from
+    the dictionary code's own distribution huff0 keeps the dictionary table (ReusePolicyAllow, compress.go:121-135),
+    the frame carries "treeless" literals, and libzstd must decode them with the same dictionary."""
+    blob, _ = _dict_fixture(oracle)
+    syn, probs = skewed_dict(blob)
+    ld = oracle.zstd_load_dict(syn)
+    assert (ld["id"], ld["huf_len"], ld["huf_log"], ld["nbits"][:7]) == (0x1234567, 7, 6, [1, 2, 3, 4, 5, 6, 6])
+    enc = oracle.ZstdOracle(level=level, dict_blob=syn)
+    raw = oracle.ZstdOracle(level=level, dict_id=ld["id"], dict_content=syn[ld["content_off"]:])
+    differs = 0
+    for d in skewed_units(probs):
+        fr = enc.encode_all(d)
+        assert oracle.zstd_decompress(fr, len(d) + 16, dict_content=syn) == d
+        differs += fr != raw.encode_all(d)
+    assert differs >= 4
