@@ -793,7 +793,7 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
             PROF_MARK(10);
             if (lane == 0 && wv < 3) {
                 const int k = wv;
-                const KcFseT* f = E[k];
+                const KcFseT* f = &S.fse[S.useIdx[k]];  // derived from S directly: keeps the LDS address space (ds_read, not flat_load)
                 uint16_t st = S.state[k];
                 int j = 0;
                 if (hiSeq == nseq) {  // very first stream element: cState.init
