@@ -25,7 +25,12 @@
 #include "kc_huf_dev.h"
 
 #define ET 256            // threads per workgroup
+#ifndef SEQ_CHUNK
 #define SEQ_CHUNK 1024    // sequences staged in LDS per FSE chain chunk
+#endif
+#ifndef KC_K2_WGS
+#define KC_K2_WGS 4
+#endif
 #define LONG_RUN 48       // literal runs longer than this are copied cooperatively
 #define LONG_CAP 64
 
@@ -263,8 +268,12 @@ __device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, i
 // ---------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams P) {
+__global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntropyParams P) {
     __shared__ Shared S;
+#ifdef KC_K2_PAD
+    __shared__ uint32_t padLds[KC_K2_PAD / 4];  // occupancy experiment only
+    if (P.block_size == -12345) padLds[threadIdx.x] = 1;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : P.unit_base + blockIdx.x;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
@@ -791,8 +800,8 @@ __global__ __launch_bounds__(ET, 4) void kc_zstd_entropy_kernel(KcEntropyParams 
             }
             __syncthreads();
             PROF_MARK(10);
-            if (lane == 0 && wv < 3) {
-                const int k = wv;
+            if (wv == 0 && lane < 3) {  // the three chains run in lockstep on three lanes of one wave (same trip count)
+                const int k = lane;
                 const KcFseT* f = &S.fse[S.useIdx[k]];  // derived from S directly: keeps the LDS address space (ds_read, not flat_load)
                 uint16_t st = S.state[k];
                 int j = 0;
