@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--kind", default="T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-units", type=int, default=16384)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="override the CPU baseline thread count")
     args = ap.parse_args()
 
     import numpy as np
@@ -130,12 +131,25 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib
         cores = os.cpu_count() or 1
+        quota = None
+        try:  # cgroup v2 CPU quota of this container: more runnable threads than this only get throttled
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota = max(1, int(round(int(q) / int(per))))
+        except Exception:
+            pass
+        host_threads = cores
+        if quota is not None and quota < cores:
+            cores = quota
+        if args.cpu_threads > 0:
+            cores = args.cpu_threads
         sample = min(n_units, args.cpu_sample_units)
         t0 = time.perf_counter()
         ref, ref_off = oracle_lib.zstd_encode_units(host[:sample * UNIT], unit_off[:sample + 1], threads=cores, level=1)
         cdt = time.perf_counter() - t0
         cpu = {"value": round(sample * UNIT / cdt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
-               "sample": "first %d units (%.2f GiB) of the same corpus, one std::thread per hardware thread" % (sample, sample * UNIT / 2**30)}
+               "sample": "first %d units (%.2f GiB) of the same corpus, %d std::threads (host has %d hardware threads%s)"
+                         % (sample, sample * UNIT / 2**30, cores, host_threads, ", cgroup cpu.max allows %d CPUs" % quota if quota else "")}
         got = d_dst[:int(out_off[sample])].cpu().numpy()
         parity = bool(np.array_equal(got, ref) and np.array_equal(out_off[:sample + 1], ref_off))
 

@@ -247,11 +247,26 @@ int64_t kco_zstd_encode_units(const kco_zstd_opts* opts, const uint8_t* src, con
     uint64_t pos = 0;
     for (uint32_t i = 0; i < n_units; i++) {
         out_off[i] = pos;
-        if (pos + outs[i].size() > dst_cap) return -2;
-        memcpy(dst + pos, outs[i].data(), outs[i].size());
         pos += outs[i].size();
     }
     out_off[n_units] = pos;
+    if (pos > dst_cap) return -2;
+    // gather the frames with the same threads (first touch of dst in parallel, like the encode itself)
+    std::atomic<uint32_t> nextc(0);
+    auto copier = [&]() {
+        for (;;) {
+            uint32_t i = nextc.fetch_add(64);
+            if (i >= n_units) break;
+            const uint32_t e = i + 64 < n_units ? i + 64 : n_units;
+            for (uint32_t k = i; k < e; k++) {
+                memcpy(dst + out_off[k], outs[k].data(), outs[k].size());
+                Bytes().swap(outs[k]);
+            }
+        }
+    };
+    th.clear();
+    for (int t = 0; t < threads; t++) th.emplace_back(copier);
+    for (auto& t : th) t.join();
     return (int64_t)pos;
 }
 

@@ -142,7 +142,9 @@ def zstd_encode_units(src, unit_off, threads=1, **kw):
     src = np.ascontiguousarray(np.frombuffer(src, dtype=np.uint8) if isinstance(src, (bytes, bytearray)) else src)
     unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
     n = len(unit_off) - 1
-    cap = int(sum(lib().kco_zstd_max_encoded_size(C.byref(opts), int(unit_off[i + 1] - unit_off[i])) for i in range(n))) + 64
+    sizes = np.diff(unit_off.astype(np.int64)) if n else np.zeros(0, dtype=np.int64)
+    mes = {int(z): lib().kco_zstd_max_encoded_size(C.byref(opts), int(z)) for z in np.unique(sizes)}
+    cap = int(sum(mes[int(z)] * int(c) for z, c in zip(*np.unique(sizes, return_counts=True)))) + 64
     dst = np.empty(cap, dtype=np.uint8)
     out_off = np.empty(n + 1, dtype=np.uint64)
     r = lib().kco_zstd_encode_units(C.byref(opts), src.ctypes.data, unit_off.ctypes.data, n, dst.ctypes.data, cap, out_off.ctypes.data, threads)
