@@ -595,6 +595,7 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
         fprintf(stderr, "[K2 prof] shader-clock share per phase:");
         for (int i = 0; i < 14; i++) fprintf(stderr, " p%d=%.1f%%", i, tot ? 100.0 * (double)pv[i] / (double)tot : 0.0);
         fprintf(stderr, "  (total %.3g cycles over %u units)\n", (double)tot, n_units);
+        fprintf(stderr, "[K2 prof] tANS chain segments: %llu chunk-streams, %llu lanes re-encoded after a wrong entry-state guess\n", pv[16], pv[17]);
     }
     *produced = out_off_host[n_units];
     return KC_OK;

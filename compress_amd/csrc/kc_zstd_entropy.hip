@@ -31,6 +31,9 @@
 #ifndef KC_K2_WGS
 #define KC_K2_WGS 4
 #endif
+#ifndef KC_CHAIN_WARM
+#define KC_CHAIN_WARM 48  // warm-up symbols per tANS chain segment (speculation, verified; any value is exact)
+#endif
 #define LONG_RUN 48       // literal runs longer than this are copied cooperatively
 #define LONG_CAP 64
 
@@ -241,7 +244,16 @@ __device__ __forceinline__ uint32_t huf_lane_bits(const uint8_t* __restrict__ se
     const int r0 = lane * chunk;
     int r1 = r0 + chunk;
     if (r1 > segLen) r1 = segLen;
-    for (int r = r0; r < r1; r++) bits += T->nb[seg[segLen - 1 - r]];
+    // forward positions hi..lo, walked downwards; 8 symbols per global load (a byte load per symbol costs one
+    // 64-address memory instruction each — the texture/L1 path, not the ALU, was the limiter)
+    int p = segLen - 1 - r0;
+    const int lo = segLen - r1;
+    for (; p - 7 >= lo; p -= 8) {
+        const uint64_t v = ld64(seg + p - 7);
+#pragma unroll
+        for (int b = 7; b >= 0; b--) bits += T->nb[(uint32_t)(v >> (8 * b)) & 0xFFu];
+    }
+    for (; p >= lo; p--) bits += T->nb[seg[p]];
     return bits;
 }
 __device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, int segLen, const KcHufTable* T, int lane, int chunk,
@@ -251,8 +263,7 @@ __device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, i
     if (r1 > segLen) r1 = segLen;
     uint64_t acc = 0;
     int nb = 0;
-    for (int r = r0; r < r1; r++) {
-        const uint8_t sym = seg[segLen - 1 - r];
+    auto put = [&](uint32_t sym) {
         acc |= (uint64_t)T->val[sym] << nb;
         nb += T->nb[sym];
         if (nb >= 32) {
@@ -261,7 +272,15 @@ __device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, i
             acc >>= 32;
             nb -= 32;
         }
+    };
+    int p = segLen - 1 - r0;
+    const int lo = segLen - r1;
+    for (; p - 7 >= lo; p -= 8) {
+        const uint64_t v = ld64(seg + p - 7);
+#pragma unroll
+        for (int b = 7; b >= 0; b--) put((uint32_t)(v >> (8 * b)) & 0xFFu);
     }
+    for (; p >= lo; p--) put(seg[p]);
     if (nb > 0) or_bits(words, bitpos, acc, nb);
 }
 
@@ -800,50 +819,63 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             }
             __syncthreads();
             PROF_MARK(10);
-            if (wv == 0 && lane < 3) {  // the three chains run in lockstep on three lanes of one wave (same trip count)
-                const int k = lane;
+            if (wv < 3) {
+                // tANS state chains, one wave per stream (LL, OF, ML).  The chain st -> stateTable[...] -> st is serial, but
+                // chains started from different states coalesce after a few symbols, so the chunk is cut into 64 segments:
+                // lane i warms up over the KC_CHAIN_WARM symbols before its segment from an arbitrary valid state, encodes
+                // its segment, and the wave then VERIFIES that every lane's assumed entry state equals its predecessor's
+                // exit state.  A lane that guessed wrong re-encodes its segment from the proven state (rare), so the result
+                // is exactly the sequential chain of blockenc.go:757-787.
+                const int k = wv;
                 const KcFseT* f = &S.fse[S.useIdx[k]];  // derived from S directly: keeps the LDS address space (ds_read, not flat_load)
-                uint16_t st = S.state[k];
-                int j = 0;
-                if (hiSeq == nseq) {  // very first stream element: cState.init
-                    st = fse_init_state(f, S.codes[k][0]);
-                    S.sbits[k][0] = 0;
-                    j = 1;
+                const uint8_t* __restrict__ cod = S.codes[k];
+                uint16_t* __restrict__ sb = S.sbits[k];
+                const bool firstChunk = hiSeq == nseq;
+                const int jb = firstChunk ? 1 : 0;  // very first stream element: cState.init, no state bits
+                uint16_t trueIn = firstChunk ? fse_init_state(f, cod[0]) : S.state[k];
+                if (firstChunk && lane == 0) sb[0] = 0;
+                const int nrem = cn - jb;
+                const int L = (nrem + 63) >> 6;
+                const int nL = L > 0 ? (nrem + L - 1) / L : 0;  // lanes with a non-empty segment
+                const int a = jb + lane * L;
+                int bnd = a + L;
+                if (bnd > cn) bnd = cn;
+                const bool act = lane < nL;
+                uint16_t st = trueIn, assumed = trueIn, endSt = trueIn;
+                auto step = [&](int jj, bool emit) {
+                    const uint32_t c = cod[jj];
+                    const uint32_t d = f->dnb[c];
+                    const int32_t fs = (int32_t)f->dfs[c];
+                    const uint32_t nbBitsOut = ((uint32_t)st + d) >> 16;
+                    const int32_t dstState = (int32_t)(st >> (nbBitsOut & 15)) + fs;
+                    if (emit) sb[jj] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
+                    st = f->st[dstState];
+                };
+                if (act) {
+                    int w = a - KC_CHAIN_WARM;
+                    if (w <= jb) w = jb; else st = f->st[0];  // any table entry is a valid state
+                    for (int jj = w; jj < a; jj++) step(jj, false);
+                    assumed = st;
+                    for (int jj = a; jj < bnd; jj++) step(jj, true);
+                    endSt = st;
                 }
-                // Software-pipelined tANS chain.  The only true dependence is state -> stateTable[dst] -> state;
-                // the symbol-transform fields of the next four codes are fetched (one 32-bit code word, then
-                // eight table reads issued back to back) while the current four steps run, so every step costs
-                // a single LDS round trip.
-                {
-                    const uint8_t* __restrict__ cod = S.codes[k];
-                    uint16_t* __restrict__ sb = S.sbits[k];
-                    auto stepf = [&](uint32_t d, int32_t fs, int jj) {
-                        const uint32_t nbBitsOut = ((uint32_t)st + d) >> 16;
-                        const int32_t dstState = (int32_t)(st >> (nbBitsOut & 15)) + fs;
-                        sb[jj] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
-                        st = f->st[dstState];
-                    };
-                    for (; j < cn && (j & 3); j++) { const uint32_t c = cod[j]; stepf(f->dnb[c], (int32_t)f->dfs[c], j); }
-                    if (j + 4 <= cn) {
-                        uint32_t w = *(const uint32_t*)(cod + j);
-                        uint32_t d0 = f->dnb[w & 0xFF], d1 = f->dnb[(w >> 8) & 0xFF], d2 = f->dnb[(w >> 16) & 0xFF], d3 = f->dnb[w >> 24];
-                        int32_t f0 = f->dfs[w & 0xFF], f1 = f->dfs[(w >> 8) & 0xFF], f2 = f->dfs[(w >> 16) & 0xFF], f3 = f->dfs[w >> 24];
-                        for (; j + 4 <= cn; j += 4) {
-                            const bool more = j + 8 <= cn;
-                            const uint32_t wn = more ? *(const uint32_t*)(cod + j + 4) : 0u;
-                            const uint32_t e0 = f->dnb[wn & 0xFF], e1 = f->dnb[(wn >> 8) & 0xFF], e2 = f->dnb[(wn >> 16) & 0xFF], e3 = f->dnb[wn >> 24];
-                            const int32_t g0 = f->dfs[wn & 0xFF], g1 = f->dfs[(wn >> 8) & 0xFF], g2 = f->dfs[(wn >> 16) & 0xFF], g3 = f->dfs[wn >> 24];
-                            stepf(d0, f0, j);
-                            stepf(d1, f1, j + 1);
-                            stepf(d2, f2, j + 2);
-                            stepf(d3, f3, j + 3);
-                            d0 = e0; d1 = e1; d2 = e2; d3 = e3;
-                            f0 = g0; f1 = g1; f2 = g2; f3 = g3;
-                        }
+                for (;;) {
+                    uint16_t prevEnd = (uint16_t)__shfl_up((int)endSt, 1, 64);
+                    if (lane == 0) prevEnd = trueIn;
+                    const unsigned long long bad = __ballot(act && assumed != prevEnd);
+                    if (bad == 0ull) break;
+                    if (P.prof && lane == 0) atomicAdd(&P.prof[17], 1ull);
+                    const int m = __builtin_ctzll(bad);  // lanes below m are proven, so lane m's predecessor state is exact
+                    if (lane == m) {
+                        st = prevEnd;
+                        assumed = prevEnd;
+                        for (int jj = a; jj < bnd; jj++) step(jj, true);
+                        endSt = st;
                     }
-                    for (; j < cn; j++) { const uint32_t c = cod[j]; stepf(f->dnb[c], (int32_t)f->dfs[c], j); }
                 }
-                S.state[k] = st;
+                if (P.prof && lane == 0) atomicAdd(&P.prof[16], 1ull);
+                const uint16_t fin = (uint16_t)__shfl((int)endSt, nL > 0 ? nL - 1 : 0, 64);
+                if (lane == 0) S.state[k] = nL > 0 ? fin : trueIn;
             }
             __syncthreads();
             PROF_MARK(11);
