@@ -234,6 +234,17 @@ __device__ __forceinline__ void or_bits(uint32_t* words, uint64_t bitpos, uint64
     if (sh + nbits > 64) atomicOr(&words[w + 2], (uint32_t)(value >> (64 - sh)));
 }
 
+// same into an LDS word buffer (ds_or_b32)
+__device__ __forceinline__ void lds_or_bits(uint32_t* words, uint64_t bitpos, uint64_t value, int nbits) {
+    if (nbits == 0) return;
+    const uint32_t w = (uint32_t)(bitpos >> 5);
+    const int sh = (int)(bitpos & 31);
+    const uint64_t lo = value << sh;
+    atomicOr(&words[w], (uint32_t)lo);
+    if (sh + nbits > 32) atomicOr(&words[w + 1], (uint32_t)(lo >> 32));
+    if (sh + nbits > 64) atomicOr(&words[w + 2], (uint32_t)(value >> (64 - sh)));
+}
+
 // ---------------------------------------------------------------------------------------
 // Huffman stream emit: one wave per stream.
 // Stream symbols are encoded last-to-first (huff0/compress.go:233-266) followed by the end
@@ -261,14 +272,19 @@ __device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, i
     const int r0 = lane * chunk;
     int r1 = r0 + chunk;
     if (r1 > segLen) r1 = segLen;
+    // The lane owns the bit range [bitpos, bitpos + laneBits): only its first and last word can be shared with the
+    // neighbouring lanes (atomicOr); every word in between is written whole with a plain store.
+    uint32_t* wp = words + (bitpos >> 5);
     uint64_t acc = 0;
-    int nb = 0;
+    int nb = (int)(bitpos & 31);
+    bool firstWord = true;
     auto put = [&](uint32_t sym) {
         acc |= (uint64_t)T->val[sym] << nb;
         nb += T->nb[sym];
         if (nb >= 32) {
-            or_bits(words, bitpos, acc & 0xFFFFFFFFull, 32);
-            bitpos += 32;
+            if (firstWord) { atomicOr(wp, (uint32_t)acc); firstWord = false; }
+            else *wp = (uint32_t)acc;
+            wp++;
             acc >>= 32;
             nb -= 32;
         }
@@ -281,7 +297,7 @@ __device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, i
         for (int b = 7; b >= 0; b--) put((uint32_t)(v >> (8 * b)) & 0xFFu);
     }
     for (; p >= lo; p--) put(seg[p]);
-    if (nb > 0) or_bits(words, bitpos, acc, nb);
+    if (nb > 0 && (uint32_t)acc != 0u) atomicOr(wp, (uint32_t)acc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -904,10 +920,24 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 uint64_t tot;
                 const uint64_t ex = block_excl_scan64((uint64_t)(fb0 + fb1), S.wsum, &tot) + bitRun;
                 if ((int64_t)((bitRun + tot + 7) >> 3) >= (int64_t)seqBudgetBytes) { overflow = true; break; }
+                // Pack this step's fields in LDS (ds_or), then flush whole words to the staging stream with coalesced stores;
+                // only the first and last word of the step can be shared with the neighbouring steps (global atomicOr).
+                uint32_t* __restrict__ pk = (uint32_t*)S.whist;  // 1024 words, free during the sequence phase
+                const uint32_t wbase = (uint32_t)(bitRun >> 5);
+                const int nwords = (int)((((uint32_t)bitRun & 31u) + (uint32_t)tot + 31u) >> 5);
+                for (int i = tid; i < nwords + 2; i += ET) pk[i] = 0;
+                __syncthreads();
                 if (j < cn) {
-                    or_bits(sw, ex, fv0, fb0);
-                    if (fb1 <= 32) or_bits(sw, ex + fb0, fv1, fb1);
-                    else { or_bits(sw, ex + fb0, fv1 & 0xFFFFFFFFull, 32); or_bits(sw, ex + fb0 + 32, fv1 >> 32, fb1 - 32); }
+                    const uint64_t rel = ex - ((uint64_t)wbase << 5);
+                    lds_or_bits(pk, rel, fv0, fb0);
+                    if (fb1 <= 32) lds_or_bits(pk, rel + fb0, fv1, fb1);
+                    else { lds_or_bits(pk, rel + fb0, fv1 & 0xFFFFFFFFull, 32); lds_or_bits(pk, rel + fb0 + 32, fv1 >> 32, fb1 - 32); }
+                }
+                __syncthreads();
+                for (int i = tid; i < nwords; i += ET) {
+                    const uint32_t v = pk[i];
+                    if (i == 0 || i == nwords - 1) { if (v) atomicOr(&sw[wbase + i], v); }
+                    else sw[wbase + i] = v;
                 }
                 bitRun += tot;
             }
