@@ -34,7 +34,7 @@
 #ifndef KC_CHAIN_WARM
 #define KC_CHAIN_WARM 48  // warm-up symbols per tANS chain segment (speculation, verified; any value is exact)
 #endif
-#define LONG_RUN 48       // literal runs longer than this are copied cooperatively
+#define LONG_RUN 32       // literal runs longer than this are copied cooperatively (256 x LONG_RUN fits one LDS window)
 #define LONG_CAP 64
 
 static_assert(sizeof(KcFsePredefBlob) == 3 * sizeof(KcFseT), "blob layout");
@@ -145,7 +145,7 @@ struct Shared {
     int16_t cumul[3][66];
     uint8_t seqhdr[224];
     int seqhdrLen;
-    alignas(4) uint8_t codes[3][SEQ_CHUNK];     // ll / of / ml code per staged sequence
+    alignas(16) uint8_t codes[3][SEQ_CHUNK];     // ll / of / ml code per staged sequence
     uint16_t sbits[3][SEQ_CHUNK];    // state bits emitted for that sequence: nb<<12 | value
     uint16_t state[3];               // running FSE states (ll, of, ml)
     // --- scan / misc ---
@@ -443,35 +443,80 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             for (int k = tid; k < size; k += ET) atomicAdd(&S.whist[wv][org[k]], 1u);
         } else
         {
+            // Literal gather = compaction of the literal runs of all sequences into `lits`.  One sequence per thread per
+            // batch of ET; the runs are written into an LDS window over the literal stream (ds_write_b8 is cheap, a global
+            // byte store per lane is a 64-address memory instruction) and the window is flushed with 16-byte stores.
+            // Runs longer than LONG_RUN are copied by the whole workgroup; bytes past the last full 16-byte word stay in
+            // LDS as the head of the next batch's window.
+            uint8_t* __restrict__ tile = &S.codes[0][0];  // codes + sbits: 9216 bytes, unused until the sequence phase
+            constexpr int TILE = 8192;
             uint64_t run = 0;  // lo32: literal bytes so far, hi32: source bytes so far
+            const uint8_t* __restrict__ bsrc = base + blkStart;
             for (int t0 = 0; t0 < nseq; t0 += ET) {
                 const int i = t0 + tid;
                 uint32_t ll = 0, adv = 0;
                 if (i < nseq) { const uint64_t s = sq[i]; ll = seq_ll(s); adv = ll + seq_ml(s) + 3u; }
+                if (tid == 0) S.longCnt = 0;
                 uint64_t tot;
                 const uint64_t ex = block_excl_scan64((uint64_t)ll | ((uint64_t)adv << 32), S.wsum, &tot) + run;
                 const uint32_t lo = (uint32_t)ex, sp = (uint32_t)(ex >> 32);
+                bool mine = ll > 0;
                 if (ll > LONG_RUN) {
                     const uint32_t slot = atomicAdd(&S.longCnt, 1u);
-                    if (slot < LONG_CAP) { S.longList[slot][0] = (uint32_t)blkStart + sp; S.longList[slot][1] = lo; S.longList[slot][2] = ll; ll = 0; }
+                    if (slot < LONG_CAP) { S.longList[slot][0] = sp; S.longList[slot][1] = lo; S.longList[slot][2] = ll; mine = false; }
                 }
-                const uint8_t* sp8 = base + blkStart + sp;
-                for (uint32_t k = 0; k < ll; k++) {
-                    const uint8_t c = sp8[k];
-                    lits[lo + k] = c;
-                    atomicAdd(&S.whist[wv][c], 1u);
+                __syncthreads();
+                const int nl = (int)(S.longCnt < LONG_CAP ? S.longCnt : LONG_CAP);
+                const uint32_t begLo = (uint32_t)run;
+                const uint32_t endLo = begLo + (uint32_t)tot;  // literal bytes after this batch
+                for (uint32_t winBase = begLo & ~15u; winBase < endLo; winBase += TILE) {
+                    if (mine && lo < winBase + TILE && lo + ll > winBase) {
+                        for (uint32_t k = 0; k < ll; k += 8) {
+                            uint64_t v;
+                            const uint32_t n8 = ll - k < 8u ? ll - k : 8u;
+                            if ((int)(sp + k) + 8 <= size) v = ld64(bsrc + sp + k);
+                            else { v = 0; for (uint32_t q = 0; q < n8; q++) v |= (uint64_t)bsrc[sp + k + q] << (8 * q); }
+                            for (uint32_t q = 0; q < n8; q++) {
+                                const uint32_t o = lo + k + q - winBase;
+                                if (o < (uint32_t)TILE) {
+                                    const uint32_t c = (uint32_t)(v >> (8 * q)) & 0xFFu;
+                                    tile[o] = (uint8_t)c;
+                                    atomicAdd(&S.whist[wv][c], 1u);
+                                }
+                            }
+                        }
+                    }
+                    for (int e = 0; e < nl; e++) {
+                        const uint32_t lsp = S.longList[e][0], llo = S.longList[e][1], lln = S.longList[e][2];
+                        const uint32_t o0 = llo > winBase ? llo : winBase;
+                        const uint32_t o1 = llo + lln < winBase + TILE ? llo + lln : winBase + TILE;
+                        for (uint32_t o = o0 + tid; o < o1; o += ET) {
+                            const uint8_t c = bsrc[lsp + (o - llo)];
+                            tile[o - winBase] = c;
+                            atomicAdd(&S.whist[wv][c], 1u);
+                        }
+                    }
+                    __syncthreads();
+                    const uint32_t wEnd = endLo < winBase + TILE ? endLo : winBase + TILE;
+                    const uint32_t nfull = (wEnd - winBase) >> 4;
+                    for (uint32_t w = tid; w < nfull; w += ET) ((uint4*)(lits + winBase))[w] = ((const uint4*)tile)[w];
+                    const uint32_t tail = (wEnd - winBase) & 15u;  // only the last window of a batch has a tail
+                    uint8_t carry = 0;
+                    if (nfull > 0 && tid < (int)tail) carry = tile[(nfull << 4) + tid];
+                    __syncthreads();
+                    if (nfull > 0 && tid < (int)tail) tile[tid] = carry;
                 }
                 run += tot;
+                __syncthreads();
             }
-            __syncthreads();
-            // deferred long runs + trailing literals, cooperatively
-            const int nl = (int)(S.longCnt < LONG_CAP ? S.longCnt : LONG_CAP);
-            for (int e = 0; e <= nl; e++) {
-                uint32_t spos, lo, len;
-                if (e < nl) { spos = S.longList[e][0]; lo = S.longList[e][1]; len = S.longList[e][2]; }
-                else { len = m.extra_lits; spos = (uint32_t)blkEnd - len; lo = (uint32_t)nlit - len; }
+            // bytes still in LDS (less than one 16-byte word) + trailing literals after the last sequence
+            {
+                const uint32_t total = (uint32_t)run;
+                const uint32_t rem = total & 15u;
+                if (tid < (int)rem) lits[(total & ~15u) + tid] = tile[tid];
+                const uint32_t len = m.extra_lits, spos = (uint32_t)size - len, lo = (uint32_t)nlit - len;
                 for (uint32_t k = tid; k < len; k += ET) {
-                    const uint8_t c = base[spos + k];
+                    const uint8_t c = bsrc[spos + k];
                     lits[lo + k] = c;
                     atomicAdd(&S.whist[wv][c], 1u);
                 }
