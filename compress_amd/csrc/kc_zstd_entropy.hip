@@ -925,16 +925,23 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     if (lane == 0) prevEnd = trueIn;
                     const unsigned long long bad = __ballot(act && assumed != prevEnd);
                     if (bad == 0ull) break;
+#ifdef KC_CHAIN_STATS
                     if (P.prof && lane == 0) atomicAdd(&P.prof[17], 1ull);
-                    const int m = __builtin_ctzll(bad);  // lanes below m are proven, so lane m's predecessor state is exact
-                    if (lane == m) {
+#endif
+                    // Every lane that guessed wrong re-encodes its segment from its predecessor's current exit state, all at
+                    // once.  The lowest such lane has a proven predecessor, so each pass fixes at least that lane for good; a
+                    // lane whose predecessor changes again simply fails the next check.  On exit every entry state equals
+                    // the predecessor's exit state, i.e. the sequential chain.
+                    if (act && assumed != prevEnd) {
                         st = prevEnd;
                         assumed = prevEnd;
                         for (int jj = a; jj < bnd; jj++) step(jj, true);
                         endSt = st;
                     }
                 }
+#ifdef KC_CHAIN_STATS
                 if (P.prof && lane == 0) atomicAdd(&P.prof[16], 1ull);
+#endif
                 const uint16_t fin = (uint16_t)__shfl((int)endSt, nL > 0 ? nL - 1 : 0, 64);
                 if (lane == 0) S.state[k] = nL > 0 ? fin : trueIn;
             }
