@@ -37,3 +37,34 @@ def pack_units(units):
         off[i + 1] = off[i] + len(u)
     buf = np.frombuffer(b"".join(units), dtype=np.uint8).copy() if off[-1] else np.zeros(0, dtype=np.uint8)
     return buf, off
+
+
+def stress_units(seed=7, n=96):
+    """Adversarial mixes for the entropy stage: text pieces alternating with noise runs of every length class
+    (below / around / far above the cooperative-copy threshold and the 8 KiB literal window), low-entropy noise
+    (Huffman-compressible literals without matches), long zero runs, and sizes straddling block boundaries."""
+    rng = np.random.default_rng(seed)
+    text = corpus("T", 8, 131072, first_unit=900).tobytes()
+    js = corpus("J", 2, 131072, first_unit=5).tobytes()
+    units = []
+    for u in range(n):
+        target = int(rng.choice([300, 5000, 40000, 65536, 70000, 131072, 150000, 262144, 300001]))
+        parts, tot = [], 0
+        while tot < target:
+            kind = rng.integers(0, 6)
+            if kind == 0:
+                ln = int(rng.choice([1, 3, 7, 20, 31, 32, 33, 34, 48, 49, 100, 600, 5000, 9000, 20000]))
+                p = bytes(rng.integers(0, 256, ln, dtype=np.uint8))
+            elif kind == 1:
+                ln = int(rng.integers(4, 3000)); o = int(rng.integers(0, len(text) - ln)); p = text[o:o + ln]
+            elif kind == 2:
+                ln = int(rng.choice([10, 40, 500, 9000, 30000])); p = bytes(rng.integers(0, int(rng.choice([2, 5, 17, 64])), ln, dtype=np.uint8))
+            elif kind == 3:
+                ln = int(rng.choice([5, 64, 1000, 70000])); p = bytes([int(rng.integers(0, 256))]) * ln
+            elif kind == 4:
+                ln = int(rng.integers(4, 2000)); o = int(rng.integers(0, len(js) - ln)); p = js[o:o + ln]
+            else:
+                p = parts[int(rng.integers(0, len(parts)))] if parts else b"seed"
+            parts.append(p); tot += len(p)
+        units.append(b"".join(parts)[:target])
+    return units

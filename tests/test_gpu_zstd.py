@@ -181,3 +181,31 @@ def test_with_full_format_dictionary_bit_exact(oracle, kclib, level, which):
         frame = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
         assert oracle.zstd_decompress(frame, len(units[i]) + 16, dict_content=blob) == units[i]
     enc.Close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_stress_mixes_bit_exact(oracle, kclib, level):
+    """Adversarial literal/sequence mixes (corpora.stress_units): long literal runs across the LDS gather window,
+    more cooperative runs than the per-batch list holds, Huffman-only blocks, RLE blocks, multi-block units."""
+    _torch()
+    _check_units(oracle, corpora.stress_units(), level=level)
+
+
+def test_stress_mixes_entropy_options(oracle, kclib):
+    """The same mixes under the options that change the entropy stage's decisions."""
+    _torch()
+    from compress_amd import zstd
+    units = corpora.stress_units(seed=11, n=40)
+    ubuf, off = corpora.pack_units(units)
+    for kw, ops in (({"no_entropy": True}, [zstd.WithNoEntropyCompression(True)]),
+                    ({"all_lit_entropy": True}, [zstd.WithAllLitEntropyCompression(True)]),
+                    ({"crc": False, "window_size": 1 << 15}, [zstd.WithEncoderCRC(False), zstd.WithWindowSize(1 << 15)])):
+        enc = zstd.NewWriter(None, *ops, zstd.WithEncoderLevel(zstd.SpeedFastest))
+        out, out_off = enc.EncodeUnits(ubuf, off)
+        if "window_size" in kw:
+            kw = dict(kw, block_size=1 << 15)
+        ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=1, **kw)
+        bad = [i for i in range(len(units))
+               if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
+        assert not bad, (kw, bad[:10])
+        enc.Close()
