@@ -38,7 +38,7 @@ SYMBOLS = [
     "kc_zstd_opts_default", "kc_zstd_opts_level", "kc_zstd_opts_window", "kc_zstd_opts_crc", "kc_zstd_opts_zero_frames",
     "kc_zstd_opts_no_entropy", "kc_zstd_opts_all_lit_entropy", "kc_zstd_opts_single_segment", "kc_zstd_opts_dict_raw", "kc_zstd_opts_dict",
     "kc_zstd_max_encoded_size", "kc_ctx_create", "kc_ctx_destroy", "kc_last_error", "kc_device_info",
-    "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
+    "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
     "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_encode_block",
     "kc_last_timings", "kc_corpus_fill",
 ]
@@ -92,6 +92,12 @@ def load():
         f = getattr(L, n)
         f.argtypes = [vp, po, vp, vp, C.c_uint32, vp, u64, vp]
         f.restype = C.c_int
+    L.kc_zstd_encode_units_dev_begin.argtypes = [vp, po, vp, vp, C.c_uint32, vp, u64]
+    L.kc_zstd_encode_units_dev_begin.restype = C.c_int
+    L.kc_zstd_encode_units_dev_end.argtypes = [vp, vp]
+    L.kc_zstd_encode_units_dev_end.restype = C.c_int
+    L.kc_ctx_chain_after.argtypes = [vp, vp]
+    L.kc_ctx_chain_after.restype = None
     L.kc_xxh64_units_dev.argtypes = [vp, vp, vp, C.c_uint32, vp]
     L.kc_xxh64_units_dev.restype = C.c_int
     L.kc_zstd_debug_parse_dev.argtypes = [vp, po, vp, vp, C.c_uint32, vp, u64, vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <memory>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -27,6 +28,22 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// A batch in flight between its two halves: everything up to and including the match finder is enqueued by batch_begin
+// (no host synchronisation unless a dictionary has to be staged), the entropy stage, the speculation check, compaction and
+// the copy of the offsets by batch_end.  Two contexts on two streams can therefore pipeline consecutive batches: the match
+// finder of batch i+1 (random-access HBM bound, waves mostly parked) runs under the entropy stage of batch i.
+struct Pending {
+    kc_zstd_opts o;
+    KcMatchParams mp;
+    KcEntropyParams ep;
+    std::vector<uint64_t> unit_off;
+    uint32_t n_units = 0;
+    uint8_t* d_dst = nullptr;
+    int bs = 0;
+    bool k2prof = false;
+};
+
+
 }  // namespace
 
 struct kc_ctx {
@@ -43,6 +60,8 @@ struct kc_ctx {
     hipEvent_t evc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     kc_timings last = {0, 0, 0, 0, 0};
     size_t max_batch_bytes = (size_t)8 << 30;  // input bytes per device batch (scratch is ~6x this)
+    void* pend = nullptr;            // batch between kc_zstd_encode_units_dev_begin and _end (Pending)
+    kc_ctx* chain_after = nullptr;   // pipelining: this context's match finder waits for that context's last one
 };
 
 namespace {
@@ -186,6 +205,7 @@ void kc_ctx_destroy(kc_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->evc)
         if (e) (void)hipEventDestroy(e);
+    if (c->pend) { delete (Pending*)c->pend; c->pend = nullptr; }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -333,9 +353,10 @@ kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_
     return KC_OK;
 }
 
-kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base, const uint64_t* unit_off, uint32_t n_units,
-                    uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off_host, uint64_t* produced) {
+kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base, const uint64_t* unit_off, uint32_t n_units,
+                      uint8_t* d_dst, uint64_t dst_cap) {
     hipStream_t st = c->stream;
+    if (c->pend) { c->err = "a batch is already in flight on this context"; return KC_ERR_BAD_ARG; }
     const int bs = o->block_size;
     Plan pl;
     pl.n_units = n_units;
@@ -484,49 +505,44 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
         ep.prof = (unsigned long long*)c->prof.p;
     }
 
+    if (c->chain_after) HIPCHK(c, hipStreamWaitEvent(st, c->chain_after->ev[2], 0));  // pipelined contexts: one match finder at a time
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (o->crc) kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p, n_units, (uint64_t*)c->xxh.p, st);
     HIPCHK(c, hipEventRecord(c->ev[1], st));
-    // Optional chunked launch (KC_OVERLAP=1): the entropy kernel of chunk i runs on a second stream under the match
-    // finder of chunk i+1.  Measured slower than back-to-back launches on MI355X (the match finder is bound by
-    // random-access HBM bandwidth and loses more to the contention than the overlap hides), so it is off by default.
-    std::vector<std::pair<uint32_t, uint32_t>> chunks;  // (first unit, count)
-    {
-        const char* ov = getenv("KC_OVERLAP");
-        const bool overlap = (ov ? atoi(ov) != 0 : false) && n_units >= 4096;  // measured: off wins (213 vs 223-250 ms / 4 GiB): both kernels contend for HBM
-        if (overlap) {
-            const double frac = getenv("KC_SPLIT") ? atof(getenv("KC_SPLIT")) : 0.7;
-            uint32_t nA = (uint32_t)((double)n_units * frac) & ~7u;
-            if (nA < 8 || nA >= n_units) nA = n_units / 2;
-            chunks.push_back({0u, nA});
-            chunks.push_back({nA, n_units - nA});
-        } else {
-            chunks.push_back({0u, n_units});
-        }
-    }
-    for (size_t ci = 0; ci < chunks.size(); ci++) {
-        mp.unit_base = chunks[ci].first;
-        ep.unit_base = chunks[ci].first;
-        if ((s = launch_match(c, mp, unit_off, n_units, chunks[ci].second, bs, st, o->level)) != KC_OK) return s;
-        if (chunks.size() == 1) {
-            HIPCHK(c, hipEventRecord(c->ev[2], st));
-            kc_launch_zstd_entropy(ep, chunks[ci].second, st);
-            HIPCHK(c, hipEventRecord(c->ev[3], st));
-        } else {
-            HIPCHK(c, hipEventRecord(c->evc[ci], st));
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evc[ci], 0));
-            if (ci == 0) HIPCHK(c, hipEventRecord(c->evc[6], c->stream2));
-            kc_launch_zstd_entropy(ep, chunks[ci].second, c->stream2);
-        }
-    }
-    if (chunks.size() > 1) {
-        HIPCHK(c, hipEventRecord(c->ev[2], st));            // end of the match finders
-        HIPCHK(c, hipEventRecord(c->evc[7], c->stream2));   // end of the entropy kernels
-        HIPCHK(c, hipStreamWaitEvent(st, c->evc[7], 0));
-        HIPCHK(c, hipEventRecord(c->ev[3], st));
-    }
     mp.unit_base = 0;
     ep.unit_base = 0;
+    if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, st, o->level)) != KC_OK) return s;
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    HIPCHK(c, hipGetLastError());
+    Pending* P = new Pending();
+    P->o = *o;
+    P->mp = mp;
+    P->ep = ep;
+    P->unit_off.assign(unit_off, unit_off + n_units + 1);
+    P->n_units = n_units;
+    P->d_dst = d_dst;
+    P->bs = bs;
+    P->k2prof = k2prof;
+    c->pend = P;
+    return KC_OK;
+}
+
+kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
+    if (!c->pend) { c->err = "no batch in flight on this context"; return KC_ERR_BAD_ARG; }
+    std::unique_ptr<Pending> P((Pending*)c->pend);
+    c->pend = nullptr;
+    hipStream_t st = c->stream;
+    const kc_zstd_opts* o = &P->o;
+    KcMatchParams& mp = P->mp;
+    KcEntropyParams& ep = P->ep;
+    const uint64_t* unit_off = P->unit_off.data();
+    const uint32_t n_units = P->n_units;
+    uint8_t* d_dst = P->d_dst;
+    const int bs = P->bs;
+    const bool k2prof = P->k2prof;
+    kc_status s;
+    kc_launch_zstd_entropy(ep, n_units, st);
+    HIPCHK(c, hipEventRecord(c->ev[3], st));
     HIPCHK(c, hipGetLastError());
 
     // Speculation check: a block that fell back to raw only after entropy coding (blockenc.go:811-817)
@@ -581,7 +597,7 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     (void)hipEventElapsedTime(&t34, c->ev[3], c->ev[4]);
     (void)hipEventElapsedTime(&t45, c->ev[4], c->ev[5]);
     (void)hipEventElapsedTime(&t05, c->ev[0], c->ev[5]);
-    if (chunks.size() > 1) (void)hipEventElapsedTime(&tk2, c->evc[6], c->evc[7]); else tk2 = t23;
+    tk2 = t23;
     c->last.match_ms += t12;       // all match-finder launches (with overlap: includes time shared with entropy kernels)
     c->last.entropy_ms += tk2;     // first to last entropy launch on its stream
     c->last.other_ms += t01 + t34 + t45;
@@ -599,6 +615,13 @@ kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base,
     }
     *produced = out_off_host[n_units];
     return KC_OK;
+}
+
+kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base, const uint64_t* unit_off, uint32_t n_units,
+                    uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off_host, uint64_t* produced) {
+    kc_status s = batch_begin(c, o, d_src_base, unit_off, n_units, d_dst, dst_cap);
+    if (s != KC_OK) return s;
+    return batch_end(c, out_off_host, produced);
 }
 
 }  // namespace
@@ -640,6 +663,45 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
     }
     if (n_units == 0) out_off[0] = 0;
     return KC_OK;
+}
+
+static kc_status validate_units(kc_ctx* c, const kc_zstd_opts* o, const uint64_t* unit_off, uint32_t n_units) {
+    for (uint32_t i = 0; i < n_units; i++) {
+        if (unit_off[i + 1] < unit_off[i]) { c->err = "unit_off not ascending"; return KC_ERR_BAD_ARG; }
+        if (unit_off[i + 1] - unit_off[i] > (uint64_t)32 * (uint64_t)o->block_size) {
+            c->err = "unit larger than 32 blocks: not served by the device path";
+            return KC_ERR_UNSUPPORTED;
+        }
+    }
+    return KC_OK;
+}
+
+kc_status kc_zstd_encode_units_dev_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off, uint32_t n_units,
+                                         uint8_t* d_dst, uint64_t dst_cap) {
+    if (!c || !o || !unit_off || n_units == 0 || !d_src || !d_dst) return KC_ERR_BAD_ARG;
+    c->err.clear();
+    c->last = kc_timings{0, 0, 0, 0, 0};
+    kc_status s = check_supported(c, o);
+    if (s != KC_OK) return s;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((s = validate_units(c, o, unit_off, n_units)) != KC_OK) return s;
+    const uint64_t cap_bytes = o->level == KC_SPEED_BETTER ? ((uint64_t)1 << 30) : c->max_batch_bytes;
+    if (unit_off[n_units] - unit_off[0] > cap_bytes || (o->level == KC_SPEED_BETTER && n_units > 16384u)) {
+        c->err = "begin/end serves one device batch; use kc_zstd_encode_units_dev for larger inputs";
+        return KC_ERR_UNSUPPORTED;
+    }
+    return batch_begin(c, o, d_src, unit_off, n_units, d_dst, dst_cap);
+}
+
+kc_status kc_zstd_encode_units_dev_end(kc_ctx* c, uint64_t* out_off) {
+    if (!c || !out_off) return KC_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t produced = 0;
+    return batch_end(c, out_off, &produced);
+}
+
+void kc_ctx_chain_after(kc_ctx* c, kc_ctx* prev) {
+    if (c) c->chain_after = prev;
 }
 
 kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units,

@@ -164,6 +164,27 @@ class Encoder:
                                                  int(dst_cap), out_off.ctypes.data))
         return out_off
 
+    def EncodeUnitsDeviceBegin(self, d_src_ptr, unit_off, d_dst_ptr, dst_cap):
+        """First half of EncodeUnitsDevice (one device batch): enqueue up to and including the match finder, no wait."""
+        import numpy as np
+        ctx = self.ctx()
+        unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
+        self._pending_n = len(unit_off) - 1
+        ctx.check(ctx.L.kc_zstd_encode_units_dev_begin(ctx.h, C.byref(self.o), d_src_ptr, unit_off.ctypes.data, self._pending_n,
+                                                       d_dst_ptr, int(dst_cap)))
+
+    def EncodeUnitsDeviceEnd(self):
+        """Second half: entropy stage, wait, offsets (uint64[n+1], host numpy)."""
+        import numpy as np
+        ctx = self.ctx()
+        out_off = np.zeros(self._pending_n + 1, dtype=np.uint64)
+        ctx.check(ctx.L.kc_zstd_encode_units_dev_end(ctx.h, out_off.ctypes.data))
+        return out_off
+
+    def ChainAfter(self, other):
+        """Pipelining two encoders: this one's match finder waits for `other`'s last one (see include/kcgpu.h)."""
+        self.ctx().L.kc_ctx_chain_after(self.ctx().h, other.ctx().h if other is not None else None)
+
     def DebugParseDevice(self, d_src_ptr, unit_off):
         """Match-finder intermediates for parity tests: list over blocks of (seqs[n,3] u32, extra_lits)."""
         import numpy as np

@@ -110,6 +110,17 @@ kc_status kc_zstd_encode_units(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t
                                uint32_t n_units, uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
 kc_status kc_zstd_encode_units_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
                                    uint32_t n_units, uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
+/* Split form of kc_zstd_encode_units_dev for ONE device batch (<= 8 GiB): _begin enqueues everything up to and including
+ * the match finder and returns without waiting; _end enqueues the entropy stage, waits, and returns the offsets.  With two
+ * contexts (two streams, two sets of scratch) a caller pipelines consecutive batches:
+ *     begin(A, batch0); begin(B, batch1); end(A); begin(A, batch2); end(B); ...
+ * so that the match finder of batch i+1 runs under the entropy stage of batch i.  kc_ctx_chain_after(B, A) makes B's match
+ * finder wait for A's (and vice versa), which keeps one match finder on the device at a time.  d_src, d_dst and the options'
+ * dictionary must stay valid until _end returns; unit_off is copied. */
+kc_status kc_zstd_encode_units_dev_begin(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
+                                         uint32_t n_units, uint8_t* d_dst, uint64_t dst_cap);
+kc_status kc_zstd_encode_units_dev_end(kc_ctx* ctx, uint64_t* out_off);
+void kc_ctx_chain_after(kc_ctx* ctx, kc_ctx* prev);
 
 /* XXH64(seed 0) of every unit (the frame checksum primitive), device-resident input, host output. */
 kc_status kc_xxh64_units_dev(kc_ctx* ctx, const uint8_t* d_src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out_hash);

@@ -209,3 +209,42 @@ def test_stress_mixes_entropy_options(oracle, kclib):
                if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
         assert not bad, (kw, bad[:10])
         enc.Close()
+
+
+def test_begin_end_pipeline_two_contexts(oracle, kclib):
+    """kc_zstd_encode_units_dev_begin/_end on two chained contexts (the bench's software pipeline) produce the same
+    frames as the blocking call, batch after batch."""
+    torch = _torch()
+    from compress_amd import zstd
+    n, usz = 512, 131072
+    bufs = [corpora.corpus(k, n, usz, first_unit=17 * j) for j, k in enumerate("TJMT")]
+    off = np.arange(n + 1, dtype=np.uint64) * usz
+    d_srcs = [torch.from_numpy(b).cuda() for b in bufs]
+    ref_enc = _enc(1)
+    cap = n * ((ref_enc.MaxEncodedSize(usz) + 15) & ~15) + 64
+    refs = []
+    d_ref = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    for d in d_srcs:
+        o = ref_enc.EncodeUnitsDevice(d.data_ptr(), off, d_ref.data_ptr(), cap)
+        refs.append((o.copy(), d_ref[:int(o[n])].cpu().numpy().copy()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    encs = [zstd.NewWriter(None, zstd.WithEncoderLevel(1), stream=s.cuda_stream) for s in streams]
+    encs[0].ChainAfter(encs[1]); encs[1].ChainAfter(encs[0])
+    d_dst = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    encs[0].EncodeUnitsDeviceBegin(d_srcs[0].data_ptr(), off, d_dst[0].data_ptr(), cap)
+    for i in range(len(d_srcs)):
+        if i + 1 < len(d_srcs):
+            encs[(i + 1) % 2].EncodeUnitsDeviceBegin(d_srcs[i + 1].data_ptr(), off, d_dst[(i + 1) % 2].data_ptr(), cap)
+        o = encs[i % 2].EncodeUnitsDeviceEnd()
+        assert np.array_equal(o, refs[i][0]), i
+        assert np.array_equal(d_dst[i % 2][:int(o[n])].cpu().numpy(), refs[i][1]), i
+    # misuse is reported, not undefined: a second begin on a busy context, an end without a begin
+    encs[0].EncodeUnitsDeviceBegin(d_srcs[0].data_ptr(), off, d_dst[0].data_ptr(), cap)
+    with pytest.raises(Exception):
+        encs[0].EncodeUnitsDeviceBegin(d_srcs[0].data_ptr(), off, d_dst[0].data_ptr(), cap)
+    encs[0].EncodeUnitsDeviceEnd()
+    with pytest.raises(Exception):
+        encs[0].EncodeUnitsDeviceEnd()
+    for e in encs + [ref_enc]:
+        e.Close()
