@@ -65,3 +65,207 @@ class BlockEncoder:
 
     def Close(self):
         self._ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# s2.Writer (s2/writer.go) over the device path: the reference's chunking rules decide WHERE the stream is cut (they
+# depend on the Write/Flush/EncodeBuffer call pattern), the GPU encodes and frames the chunks in batches.
+# ---------------------------------------------------------------------------------------------------------------------
+_MIN_BLOCK, _MAX_BLOCK, _DEFAULT_BLOCK = 4 << 10, 4 << 20, 1 << 20  # s2/encode.go minBlockSize/maxBlockSize, writer.go defaultBlockSize
+_MAGIC = b"\xff\x06\x00\x00S2sTwO"                                   # magicChunk (s2/s2.go)
+
+
+def WriterBlockSize(n):
+    def apply(w):
+        if n > _MAX_BLOCK or n < _MIN_BLOCK:
+            raise ValueError("s2: block size too large. Must be <= 4MB and >=4KB")  # writer.go:985
+        w.blockSize = int(n)
+    return apply
+
+
+def WriterConcurrency(n):
+    def apply(w):
+        if n <= 0:
+            raise ValueError("concurrency must be at least 1")  # writer.go:911
+        w.concurrency = int(n)  # no effect on bytes: the device batches chunks regardless
+    return apply
+
+
+def WriterFlushOnWrite():
+    return lambda w: setattr(w, "flushOnWrite", True)
+
+
+def _unsupported(name):
+    def opt(*a, **k):
+        def apply(w):
+            raise NotImplementedError("s2.%s is not served by the device path; use the reference writer" % name)
+        return apply
+    return opt
+
+
+WriterBetterCompression = _unsupported("WriterBetterCompression")
+WriterBestCompression = _unsupported("WriterBestCompression")
+WriterSnappyCompat = _unsupported("WriterSnappyCompat")
+WriterAddIndex = _unsupported("WriterAddIndex")
+WriterPadding = _unsupported("WriterPadding")
+WriterUncompressed = _unsupported("WriterUncompressed")
+
+
+class Writer:
+    """s2.Writer: Write / ReadFrom / EncodeBuffer / AddSkippableBlock / Flush / Close / Reset with the reference's chunk
+    boundaries (writer.go:182-218, 357-453, 483-571, 741-857); default level, no index, no padding.  Chunks are queued and
+    encoded on the GPU in batches of `batch_bytes`; the bytes written equal the reference's for the same call sequence."""
+
+    def __init__(self, w, *opts, device=0, stream=None, batch_bytes=256 << 20):
+        self.blockSize = _DEFAULT_BLOCK
+        self.concurrency = 1
+        self.flushOnWrite = False
+        for o in opts:
+            o(self)
+        self._enc = BlockEncoder(device, stream)
+        self._device = device
+        self._batch = int(batch_bytes)
+        self.Reset(w)
+
+    def Reset(self, w):
+        self.writer = w
+        self._ibuf = bytearray()
+        self._queue = []       # ("c", bytes) data chunk | ("r", bytes) raw bytes to pass through (skippable blocks)
+        self._queued = 0
+        self._wroteHeader = False
+        self._closed = False
+        self.written = 0
+        self.uncompWritten = 0
+
+    # -- chunk cutting, exactly as writer.go --
+    def _write(self, p):  # writer.go:483 write(): everything in p becomes chunks now, the last one may be short
+        mv = memoryview(p)
+        for i in range(0, len(mv), self.blockSize):
+            self._queue.append(("c", bytes(mv[i:i + self.blockSize])))
+        self._queued += len(mv)
+        self.uncompWritten += len(mv)
+        if self._queued >= self._batch:
+            self._drain()
+
+    def Write(self, p):
+        if self._closed:
+            raise IOError("s2: Writer is closed")
+        p = bytes(p)
+        if self.flushOnWrite:
+            self._write(p)
+            return len(p)
+        n_ret = 0
+        while len(p) > self.blockSize - len(self._ibuf):  # writer.go:190
+            if len(self._ibuf) == 0:
+                self._write(p)  # large write, empty buffer: all of p, including its tail
+                n = len(p)
+            else:
+                n = self.blockSize - len(self._ibuf)
+                self._ibuf += p[:n]
+                self._write(self._ibuf)
+                self._ibuf = bytearray()
+            n_ret += n
+            p = p[n:]
+        self._ibuf += p
+        return n_ret + len(p)
+
+    def EncodeBuffer(self, buf):  # writer.go:357
+        if self._closed:
+            raise IOError("s2: Writer is closed")
+        if self.flushOnWrite:
+            self._write(bytes(buf))
+            return
+        if self._ibuf:
+            self._async_flush()
+        self._write(bytes(buf))
+
+    def ReadFrom(self, r):  # writer.go:220: blockSize reads until EOF
+        if self._closed:
+            raise IOError("s2: Writer is closed")
+        if self._ibuf:
+            self._async_flush()
+        n = 0
+        while True:
+            b = r.read(self.blockSize)
+            while b and len(b) < self.blockSize:  # io.ReadFull
+                more = r.read(self.blockSize - len(b))
+                if not more:
+                    break
+                b += more
+            if not b:
+                break
+            n += len(b)
+            self._write(b)
+            if len(b) < self.blockSize:
+                break
+        return n
+
+    def AddSkippableBlock(self, id, data):  # writer.go:272
+        data = bytes(data)
+        if len(data) == 0:
+            return
+        if id < 0x80 or id > 0xfe:
+            raise ValueError("invalid skippable block id %x" % id)
+        if len(data) > 0xFFFFFF:
+            raise ValueError("skippable block excessed maximum size")
+        self._queue.append(("r", bytes([id, len(data) & 0xFF, (len(data) >> 8) & 0xFF, (len(data) >> 16) & 0xFF]) + data))
+
+    def _async_flush(self):  # writer.go:741
+        if self._ibuf:
+            b = bytes(self._ibuf)
+            self._ibuf = bytearray()
+            self._write(b)
+
+    def Flush(self):
+        if self._closed:
+            return
+        self._async_flush()
+        self._drain()
+
+    def Close(self):
+        if self._closed:
+            return
+        self.Flush()
+        self._closed = True
+
+    # -- device batch --
+    def _drain(self):
+        import numpy as np
+        import torch
+        out = []
+        i = 0
+        q = self._queue
+        while i < len(q):
+            if q[i][0] == "r":
+                if not self._wroteHeader:  # the stream identifier precedes the first output of any kind
+                    out.append(_MAGIC)
+                    self._wroteHeader = True
+                out.append(q[i][1])
+                i += 1
+                continue
+            j = i
+            while j < len(q) and q[j][0] == "c":
+                j += 1
+            chunks = [c[1] for c in q[i:j]]
+            off = np.zeros(len(chunks) + 1, dtype=np.uint64)
+            off[1:] = np.cumsum([len(c) for c in chunks])
+            src = np.frombuffer(b"".join(chunks), dtype=np.uint8)
+            d_src = torch.from_numpy(src.copy()).cuda(self._device)
+            cap = sum(((MaxEncodedLen(len(c)) + 8 + 15) & ~15) for c in chunks) + 64
+            d_dst = torch.empty(cap, dtype=torch.uint8, device=d_src.device)
+            oo = self._enc.EncodeStreamDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap, with_stream_id=not self._wroteHeader)
+            self._wroteHeader = True
+            out.append(d_dst[:int(oo[-1])].cpu().numpy().tobytes())
+            i = j
+        self._queue = []
+        self._queued = 0
+        for b in out:
+            self.writer.write(b)
+            self.written += len(b)
+
+    def CloseDevice(self):
+        self._enc.Close()
+
+
+def NewWriter(w, *opts, **kw):
+    return Writer(w, *opts, **kw)

@@ -369,6 +369,7 @@ static inline int64_t DecodeStream(uint8_t* dst, uint64_t cap, const uint8_t* sr
         s += 4;
         if (s + cl > n) return -1;
         if (t == 0xff) { if (cl != 6 || memcmp(src + s - 4, magic, 10) != 0) return -1; s += cl; continue; }
+        if (t >= 0x80 && t <= 0xfe) { s += cl; continue; }  // skippable chunks / padding (s2/reader.go: chunkTypePadding 0xfe, 0x80-0xfd skippable)
         if (t != 0x00 && t != 0x01) return -1;
         if (cl < 4) return -1;
         const uint32_t want = load32(src, (int64_t)s);

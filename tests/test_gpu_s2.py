@@ -116,3 +116,60 @@ def test_s2_stream_framing_bit_exact(oracle, kclib, with_id):
     assert np.array_equal(out, ref)
     assert oracle.s2_decode_stream(out.tobytes(), len(buf) + 8) == buf.tobytes()
     enc.Close()
+
+
+def test_s2_writer_chunking_and_bytes(oracle, kclib):
+    """s2.Writer façade: the chunk boundaries follow writer.go's buffering rules for this exact call sequence (worked out
+    by hand from writer.go:182-218 / 357-453 / 741-763), and the bytes equal the oracle's framing of those chunks."""
+    import io
+    from compress_amd import s2
+    data = corpora.corpus("J", 1, 60000).tobytes() + corpora.corpus("H", 1, 9000).tobytes()
+    sink = io.BytesIO()
+    w = s2.NewWriter(sink, s2.WriterBlockSize(4096), s2.WriterConcurrency(4))
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        b = data[pos:pos + n]
+        pos += n
+        return b
+    assert w.Write(take(1000)) == 1000      # buffered
+    assert w.Write(take(5000)) == 5000      # fills the buffer -> chunk 4096, 1904 stay buffered
+    w.Flush()                               # chunk 1904
+    assert w.Write(take(10000)) == 10000    # empty buffer, large write: chunks 4096, 4096, 1808 (tail included)
+    assert w.Write(take(4096)) == 4096      # exactly fits: buffered, not yet a chunk
+    assert w.Write(take(1)) == 1            # buffer is full: chunk 4096, the byte is buffered
+    w.EncodeBuffer(take(9000))              # flushes the buffered byte (chunk 1), then 4096, 4096, 808
+    w.AddSkippableBlock(0x80, b"hello")
+    n = w.ReadFrom(io.BytesIO(take(5000)))  # 4096, 904
+    assert n == 5000
+    w.Close()
+    w.Close()
+    with pytest.raises(IOError):
+        w.Write(b"x")
+    sizes = [4096, 1904, 4096, 4096, 1808, 4096, 1, 4096, 4096, 808]
+    off = np.zeros(len(sizes) + 1, dtype=np.uint64); off[1:] = np.cumsum(sizes)
+    ref1, _ = oracle.s2_encode_stream(np.frombuffer(data[:int(off[-1])], dtype=np.uint8), off, True)
+    s2sizes = [4096, 904]
+    off2 = np.zeros(3, dtype=np.uint64); off2[1:] = np.cumsum(s2sizes)
+    ref2, _ = oracle.s2_encode_stream(np.frombuffer(data[int(off[-1]):int(off[-1]) + 5000], dtype=np.uint8), off2, False)
+    want = ref1.tobytes() + b"\x80\x05\x00\x00hello" + ref2.tobytes()
+    got = sink.getvalue()
+    assert got == want
+    assert oracle.s2_decode_stream(got, len(data) + 16) == data[:pos]
+    # an empty writer writes nothing at all (the stream identifier goes out with the first chunk)
+    sink2 = io.BytesIO(); w2 = s2.NewWriter(sink2); w2.Close(); assert sink2.getvalue() == b""
+    # default block size 1 MiB, flush-on-write, and a batch limit small enough to force several device batches
+    big = corpora.corpus("T", 24, 131072).tobytes()
+    sink3 = io.BytesIO(); w3 = s2.NewWriter(sink3, s2.WriterFlushOnWrite(), batch_bytes=1 << 20)
+    for i in range(0, len(big), 700000):
+        w3.Write(big[i:i + 700000])
+    w3.Close()
+    sz = [min(700000, len(big) - i) for i in range(0, len(big), 700000)]
+    off3 = np.zeros(len(sz) + 1, dtype=np.uint64); off3[1:] = np.cumsum(sz)
+    ref3, _ = oracle.s2_encode_stream(np.frombuffer(big, dtype=np.uint8), off3, True)
+    assert sink3.getvalue() == ref3.tobytes()
+    with pytest.raises(ValueError):
+        s2.NewWriter(io.BytesIO(), s2.WriterBlockSize(1000))
+    with pytest.raises(NotImplementedError):
+        s2.NewWriter(io.BytesIO(), s2.WriterAddIndex())
