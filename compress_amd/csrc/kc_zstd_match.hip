@@ -644,9 +644,11 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     const int t0 = (int)e0 - 1, t1 = (int)e1 - 1;
                     const bool ok0 = e0 != 0 && (p - t0) < mmo && (PB >= 32 || (c0 >> PB) == tagOf((uint32_t)cv));
                     const bool ok1 = e1 != 0 && (p - t1 + 1) < mmo && (PB >= 32 || (c1 >> PB) == tagOf((uint32_t)(cv >> 8)));
-                    const uint32_t wr = ld32(base + (repOk ? repIndex : p));
-                    const uint32_t w0 = ld32(base + (ok0 ? t0 : p));
-                    const uint32_t w1 = ld32(base + (ok1 ? t1 : p));
+                    // predicated candidate fetches: a masked-off lane costs no address slot in the texture path
+                    uint32_t wr = 0, w0 = 0, w1 = 0;
+                    if (repOk) wr = ld32(base + repIndex);
+                    if (ok0) w0 = ld32(base + t0);
+                    if (ok1) w1 = ld32(base + t1);
                     if (repOk && wr == (uint32_t)(cv >> 16)) kind = 1;
                     else if (ok0 && w0 == (uint32_t)cv) { kind = 2; t = t0; }
                     else if (ok1 && w1 == (uint32_t)(cv >> 8)) { kind = 3; t = t1; }
