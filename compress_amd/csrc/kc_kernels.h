@@ -18,6 +18,7 @@ struct KcMatchParams {
     int32_t block_size;
     int32_t max_match_off;
     int32_t spec_w0;            // initial speculation width after a match (group kernels)
+    int32_t spec_grow;          // speculation width after a round without a match: 0 keep, 1 +1, 2 double (default)
     int32_t hist0;              // bytes of dictionary content prepended to every unit in `src` (0: no dictionary)
     int32_t pos_bits;           // bits reserved for position+1 in tagged table entries (better level)
     int32_t rep1, rep2;         // initial recentOffsets[0..1]: {1,4} unless a full-format dictionary supplies its own

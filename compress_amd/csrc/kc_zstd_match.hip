@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     KC_TAB_ST(((uint32_t)p + 2u) | (PB < 32 ? tagOf((uint32_t)(cv >> 8)) << PB : 0u), &tab[h1]);  // program order: wins when h0 == h1
                 }
                 if (!found) {
-                    W = (2 * W < G) ? 2 * W : G;
+                    W = P.spec_grow == 0 ? W : (P.spec_grow == 1 ? (W + 1 < G ? W + 1 : G) : ((2 * W < G) ? 2 * W : G));
                     if (c < nvalid) {
                         s = s + c * step;
                     } else {
