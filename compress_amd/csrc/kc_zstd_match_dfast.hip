@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
                     stab[hs] = e;
                 }
                 if (!found) {
-                    W = (2 * W < G) ? 2 * W : G;
+                    W = P.spec_grow == 0 ? W : (P.spec_grow == 1 ? (W + 1 < G ? W + 1 : G) : ((2 * W < G) ? 2 * W : G));
                     if (c < nvalid) {
                         s = s + c * step;
                     } else {
