@@ -12,6 +12,7 @@
 #include "kco_zstd_better.h"
 #include "kco_s2.h"
 #include "kco_dict.h"
+#include "kco_zstd_dec.h"
 #include <thread>
 #include <atomic>
 #include <memory>
@@ -199,6 +200,45 @@ int kco_zstd_load_dict(const uint8_t* blob, uint64_t len, uint32_t* id, int32_t*
     *huf_log = lit.prevTableLog;
     *content_off = len - d.content.size();
     return 0;
+}
+
+// In-repo zstd decoder (kco_zstd_dec.h): decodes the concatenated frames in [enc, enc+n) into dst.
+// dict/dict_len: raw dictionary content (dict_full = 0, any id accepted) or a full-format dictionary blob (dict_full = 1).
+// Returns the decoded size, -1 on a format error, -2 if dst is too small.
+int64_t kco_zstd_decode(const uint8_t* enc, uint64_t n, uint8_t* dst, uint64_t cap, const uint8_t* dict, uint64_t dict_len, int dict_full) {
+    zdec::DictState ds;
+    const zdec::DictState* dp = nullptr;
+    if (dict != nullptr && dict_len > 0) {
+        if (dict_full) { if (!zdec::loadDictState(dict, (size_t)dict_len, &ds)) return -1; }
+        else zdec::rawDictState(0, dict, (size_t)dict_len, &ds);
+        dp = &ds;
+    }
+    uint64_t pos = 0, outp = 0;
+    zdec::FrameDec fd;
+    while (pos < n) {
+        Bytes content;
+        if (n - pos >= 8 && (load32(enc, (int64_t)pos) & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame (framedec.go:79-110)
+            const uint64_t sz = load32(enc, (int64_t)pos + 4);
+            if (pos + 8 + sz > n) return -1;
+            pos += 8 + sz;
+            continue;
+        }
+        if (dict != nullptr && !dict_full) {  // raw content dictionaries match whatever id the frame carries
+            const uint8_t fhd = n - pos > 5 ? enc[pos + 4] : 0;
+            const int dsz = (fhd & 3) == 3 ? 4 : (fhd & 3);
+            const size_t at = pos + 5 + (((fhd >> 5) & 1) ? 0 : 1);
+            uint32_t id = 0;
+            for (int k = 0; k < dsz && at + (size_t)k < n; k++) id |= (uint32_t)enc[at + (size_t)k] << (8 * k);
+            ds.id = id;
+        }
+        const size_t used = fd.decodeFrame(enc + pos, (size_t)(n - pos), dp, &content);
+        if (used == 0) return -1;
+        if (outp + content.size() > cap) return -2;
+        memcpy(dst + outp, content.data(), content.size());
+        outp += content.size();
+        pos += used;
+    }
+    return (int64_t)outp;
 }
 
 void* kco_zstd_encoder_new(const kco_zstd_opts* opts) {

@@ -153,6 +153,19 @@ def zstd_encode_units(src, unit_off, threads=1, **kw):
     return dst[:r], out_off
 
 
+def zstd_decode(enc: bytes, cap: int, dict_content: bytes = None, dict_blob: bytes = None) -> bytes:
+    """The oracle's own zstd decoder (oracle/kco_zstd_dec.h): concatenated frames -> content.  Raises on malformed input."""
+    L = lib()
+    L.kco_zstd_decode.restype = C.c_int64
+    L.kco_zstd_decode.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int]
+    buf = C.create_string_buffer(max(cap, 1))
+    d = dict_blob if dict_blob is not None else dict_content
+    r = L.kco_zstd_decode(enc, len(enc), buf, cap, d, len(d) if d else 0, 1 if dict_blob is not None else 0)
+    if r < 0:
+        raise RuntimeError("oracle zstd decode failed: %d" % r)
+    return buf.raw[:r]
+
+
 def zstd_load_dict(blob: bytes):
     """loadDict as the encoder sees it: dict(id, offsets, val[256], nbits[256], huf_len, huf_log, content_off) or None."""
     L = lib()
@@ -238,7 +251,14 @@ def libzstd():
 
 
 def zstd_decompress(enc: bytes, cap: int, dict_content: bytes = None) -> bytes:
-    Z = libzstd()
+    """Independent decoder for round trips: the system libzstd when it is installed, cross-checked against the in-repo decoder
+    (oracle/kco_zstd_dec.h); the in-repo decoder alone when it is not."""
+    is_full = bool(dict_content) and dict_content[:4] == b"\x37\xa4\x30\xec"
+    own = zstd_decode(enc, cap, dict_content=None if is_full else dict_content, dict_blob=dict_content if is_full else None)
+    try:
+        Z = libzstd()
+    except OSError:
+        return own
     buf = C.create_string_buffer(max(cap, 1))
     if dict_content:
         ctx = Z.ZSTD_createDCtx()
@@ -246,6 +266,8 @@ def zstd_decompress(enc: bytes, cap: int, dict_content: bytes = None) -> bytes:
         Z.ZSTD_freeDCtx(ctx)
     else:
         r = Z.ZSTD_decompress(buf, cap, enc, len(enc))
+    if not Z.ZSTD_isError(r) and buf.raw[:r] != own:
+        raise RuntimeError("in-repo zstd decoder and libzstd disagree")
     if Z.ZSTD_isError(r):
         raise RuntimeError("libzstd: " + Z.ZSTD_getErrorName(r).decode())
     return buf.raw[:r]

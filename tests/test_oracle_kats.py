@@ -243,3 +243,58 @@ def test_full_dictionary_literal_table_is_used_and_decodes(oracle, level):
         assert oracle.zstd_decompress(fr, len(d) + 16, dict_content=syn) == d
         differs += fr != raw.encode_all(d)
     assert differs >= 4
+
+
+def test_in_repo_decoder_on_c_zstd_frames(oracle):
+    """oracle/kco_zstd_dec.h on frames it did not produce: the reference's dictionary fixtures were compressed
+    by the C zstd with d0.dict (Huffman + FSE tables, repeat modes, treeless literals from the dictionary), and must decode
+    to what libzstd gives."""
+    import glob
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dict")
+    blob = open(os.path.join(gdir, "d0.dict"), "rb").read()
+    try:
+        Z = oracle.libzstd()
+    except OSError:
+        pytest.skip("no system libzstd to compare with")
+    n = 0
+    for f in sorted(glob.glob(os.path.join(gdir, "*.zst"))):
+        z = open(f, "rb").read()
+        buf = C.create_string_buffer(1 << 22)
+        ctx = Z.ZSTD_createDCtx()
+        r = Z.ZSTD_decompress_usingDict(ctx, buf, 1 << 22, z, len(z), blob, len(blob))
+        Z.ZSTD_freeDCtx(ctx)
+        assert not Z.ZSTD_isError(r)
+        assert oracle.zstd_decode(z, 1 << 22, dict_blob=blob) == buf.raw[:r]
+        n += 1
+    assert n >= 8
+    # malformed input is rejected, not mis-decoded
+    z = open(sorted(glob.glob(os.path.join(gdir, "z0076*.zst")))[0], "rb").read()
+    for bad in (z[:-1], z[:20], b"\x00" + z[1:], z[:9] + bytes([z[9] ^ 0x40]) + z[10:]):
+        with pytest.raises(RuntimeError):
+            oracle.zstd_decode(bad, 1 << 22, dict_blob=blob)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference fixtures not present on this machine")
+def test_in_repo_decoder_on_reference_regression_frames(oracle):
+    """The reference's decoder test inputs (zstd/testdata/good.zip, benchdecoder.zip: C-zstd frames at many levels, skippable
+    frames, multi-frame files): wherever libzstd decodes a file, the in-repo decoder must produce the same bytes."""
+    import zipfile
+    try:
+        Z = oracle.libzstd()
+    except OSError:
+        pytest.skip("no system libzstd to compare with")
+    checked = 0
+    for name in ("good.zip", "benchdecoder.zip"):
+        zf = zipfile.ZipFile(os.path.join(REF, "zstd", "testdata", name))
+        for n in zf.namelist()[:400]:
+            z = zf.read(n)
+            if len(z) < 6 or len(z) > 300000:
+                continue
+            cap = 16 << 20
+            buf = C.create_string_buffer(cap)
+            r = Z.ZSTD_decompress(buf, cap, z, len(z))
+            if Z.ZSTD_isError(r):
+                continue
+            assert oracle.zstd_decode(z, cap) == buf.raw[:r], (name, n)
+            checked += 1
+    assert checked >= 20
