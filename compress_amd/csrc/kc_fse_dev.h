@@ -238,6 +238,99 @@ __device__ inline bool fse_build_core(const int16_t* norm, int symbolLen, uint8_
     return true;
 }
 
+// Wave-parallel form of fse_build_core for the sequence coders (alphabet <= 64 symbols, tableLog 5..8): all 64 lanes of
+// one wave call it together and obtain exactly the tables of zstd/fse_encoder.go:102-204.
+//  * cumul / symbolTT: one lane per symbol, exclusive wave scan of the normalised counts;
+//  * spread: the placement walk visits the cells (t*step) & mask, t = 0,1,2,.. and skips the low-probability area, so the
+//    k-th placed cell is the k-th valid cell of that orbit: one lane per orbit index, ballot-prefix for k, binary search of k
+//    in the per-symbol prefix sums for the symbol;
+//  * stateTable: cells in ascending order take consecutive slots of their symbol: 64 cells per pass, rank among equal
+//    symbols by ballot, running per-symbol slot counters in `cumul` exactly like the reference's cumul[v]++.
+// posx: scratch of 66 int16.  Returns false (wave-uniform) on the reference's internal error.
+__device__ inline bool fse_build_wave(const int16_t* norm, int symbolLen, uint8_t tableLog, uint8_t* tsym, int16_t* cumul, int16_t* posx,
+                                      uint16_t* stateTable, uint32_t* dnb, int16_t* dfs, int lane) {
+    const uint32_t tableSize = 1u << tableLog;
+    const unsigned long long ltMask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const bool isSym = lane < symbolLen;
+    const int v = isSym ? (int)norm[lane] : 0;
+    const int cnt = v == -1 ? 1 : v;   // states owned by the symbol
+    const int pcnt = v > 0 ? v : 0;    // cells placed by the spread walk
+    int incC = cnt, incP = pcnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int a = __shfl_up(incC, d, 64), b = __shfl_up(incP, d, 64);
+        if (lane >= d) { incC += a; incP += b; }
+    }
+    const int exC = incC - cnt, exP = incP - pcnt;
+    const int total = __shfl(incC, 63, 64);
+    if ((uint32_t)total != tableSize) return false;
+    const unsigned long long lowMask = __ballot(isSym && v == -1);
+    const uint32_t nLow = (uint32_t)__popcll(lowMask);
+    const uint32_t highThreshold = tableSize - 1 - nLow;
+    if (isSym) {
+        cumul[lane] = (int16_t)exC;
+        posx[lane] = (int16_t)exP;
+        if (v == -1) tsym[tableSize - 1 - (uint32_t)__popcll(lowMask & ltMask)] = (uint8_t)lane;
+        // symbolTT (fse_encoder.go:176-203): `total` before symbol i is the exclusive prefix of the state counts
+        if (v != 0) {
+            if (v == -1 || v == 1) {
+                dnb[lane] = ((uint32_t)tableLog << 16) - (1u << tableLog);
+                dfs[lane] = (int16_t)(exC - 1);
+            } else {
+                const uint32_t maxBitsOut = (uint32_t)tableLog - high_bit((uint32_t)(v - 1));
+                const uint32_t minStatePlus = (uint32_t)v << maxBitsOut;
+                dnb[lane] = (maxBitsOut << 16) - minStatePlus;
+                dfs[lane] = (int16_t)(exC - v);
+            }
+        }
+    }
+    if (lane == 0) { cumul[symbolLen] = (int16_t)((int16_t)tableSize + 1); posx[symbolLen] = (int16_t)(tableSize - nLow); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // spread
+    {
+        const uint32_t step = fse_table_step(tableSize), mask = tableSize - 1;
+        uint32_t placed = 0;
+        for (uint32_t t0 = 0; t0 < tableSize; t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            const uint32_t pos = (t * step) & mask;
+            const bool valid = t < tableSize && pos <= highThreshold;
+            const unsigned long long vm = __ballot(valid);
+            if (valid) {
+                const int k = (int)(placed + (uint32_t)__popcll(vm & ltMask));
+                int lo = 0, hi = symbolLen;  // largest s with posx[s] <= k (symbols without cells share a prefix value: take the last)
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)posx[mid] <= k) lo = mid; else hi = mid;
+                }
+                tsym[pos] = (uint8_t)lo;
+            }
+            placed += (uint32_t)__popcll(vm);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // state table
+    for (uint32_t u0 = 0; u0 < tableSize; u0 += 64) {
+        const uint32_t u = u0 + (uint32_t)lane;
+        const bool act = u < tableSize;
+        const int sy = act ? (int)tsym[u] : -1;
+        unsigned long long rem = __ballot(act);
+        int slot = 0;
+        while (rem) {
+            const int leader = __builtin_ctzll(rem);
+            const int ls = __shfl(sy, leader, 64);
+            const unsigned long long m = __ballot(act && sy == ls);
+            const int base = (int)cumul[ls];
+            if (act && sy == ls) slot = base + __popcll(m & ltMask);
+            if (lane == leader) cumul[ls] = (int16_t)(base + __popcll(m));
+            rem &= ~m;
+        }
+        if (act) stateTable[slot] = (uint16_t)(tableSize + u);
+    }
+    return true;
+}
+
 // NCount header writer shared by zstd/fse_encoder.go:488-600 and fse/compress.go:208-306.
 // tableLogBase = minTablelog (5 in both).  Returns bytes written, or -1 on internal error.
 __device__ inline int fse_write_ncount(const int16_t* norm, int symbolLen, uint8_t tableLog, uint8_t* out) {

@@ -115,6 +115,35 @@ __device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
     return v;
 }
 
+// fseEncoder.approxSize (zstd/fse_encoder.go:603-660) with one lane per symbol: the sum is a wrapping uint32 sum, so
+// the lane order does not matter; any "impossible" symbol makes the whole estimate MaxUint32 like the serial code.
+__device__ __forceinline__ uint32_t wave_approx_size(const KcFseT* f, const uint32_t* hist, int histLen, int lane) {
+    if ((int)f->symbolLen < histLen) return 0xFFFFFFFFu;
+    if (f->useRLE) return 0xFFFFFFFFu;
+    const uint32_t kAccuracyLog = 8;
+    const uint32_t badCost = ((uint32_t)f->tableLog + 1) << kAccuracyLog;
+    uint32_t term = 0;
+    bool bad = false;
+    if (lane < histLen) {
+        const uint32_t v = hist[lane];
+        if (v != 0) {
+            if (f->norm[lane] == 0) bad = true;
+            else {
+                const uint32_t minNbBits = f->dnb[lane] >> 16;
+                const uint32_t threshold = (minNbBits + 1) << 16;
+                const uint32_t tableSize = 1u << f->tableLog;
+                const uint32_t deltaFromThreshold = threshold - (f->dnb[lane] + tableSize);
+                const uint32_t normalizedDelta = (deltaFromThreshold << kAccuracyLog) >> f->tableLog;
+                const uint32_t bc = (minNbBits + 1) * (1u << kAccuracyLog) - normalizedDelta;
+                if (bc > badCost) bad = true;
+                term = v * bc;
+            }
+        }
+    }
+    if (__ballot(bad) != 0ull) return 0xFFFFFFFFu;
+    return wave_reduce_sum(term) >> kAccuracyLog;
+}
+
 // ---------------------------------------------------------------------------------------
 // shared state
 // ---------------------------------------------------------------------------------------
@@ -143,7 +172,12 @@ struct Shared {
     uint32_t smax[3];
     uint8_t tsym[3][256];
     int16_t cumul[3][66];
+    int16_t posx[3][66];
     uint8_t seqhdr[224];
+    uint32_t asz[3][3];   // approxSize of {new, predefined, previous} encoder per stream
+    uint8_t nc[3][72];    // NCount bytes per stream (maxHeaderSize <= ((53 * 9) >> 3) + 3)
+    int ncLen[3];
+    uint8_t seqMode;
     int seqhdrLen;
     alignas(16) uint8_t codes[3][SEQ_CHUNK];     // ll / of / ml code per staged sequence
     uint16_t sbits[3][SEQ_CHUNK];    // state bits emitted for that sequence: nb<<12 | value
@@ -766,36 +800,53 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         }
         __syncthreads();
         PROF_MARK(7);
-        // ---------- 4. normalizeCount + buildCTable for the three "cur" encoders (one lane each) ----------
-        if (lane == 0 && wv < 3) {
+        // ---------- 4. normalizeCount (one lane) + buildCTable (whole wave) for the three "cur" encoders, one wave each ----------
+        if (wv < 3) {
             const int k = wv;
             KcFseT* f = &S.fse[S.curIdx[k]];
-            const int maxSym = (int)S.smax[k];
-            uint32_t maxCount = 0;
-            for (int i = 0; i <= maxSym; i++) if (S.shist[k][i] > maxCount) maxCount = S.shist[k][i];
-            f->symbolLen = (uint16_t)(maxSym + 1);  // HistogramFinished
-            if (!f->reUsed) {  // normalizeCount returns early for reused encoders (fse_encoder.go:260)
-                f->tableLog = fse_optimal_table_log(nseq, f->symbolLen);
-                f->stLen1 = 0;
-                if ((int)maxCount == nseq) {
-                    f->useRLE = 1;
-                } else {
-                    f->useRLE = 0;
-                    bool ok = fse_normalize_core(S.shist[k], f->norm, f->symbolLen, nseq, f->tableLog);
-                    ok = ok && fse_build_core<int16_t>(f->norm, f->symbolLen, f->tableLog, S.tsym[k], S.cumul[k], f->st, f->dnb, f->dfs);
-                    if (!ok) atomicExch(P.err_flag, 2u);
+            int doBuild = 0;
+            if (lane == 0) {
+                const int maxSym = (int)S.smax[k];
+                uint32_t maxCount = 0;
+                for (int i = 0; i <= maxSym; i++) if (S.shist[k][i] > maxCount) maxCount = S.shist[k][i];
+                f->symbolLen = (uint16_t)(maxSym + 1);  // HistogramFinished
+                if (!f->reUsed) {  // normalizeCount returns early for reused encoders (fse_encoder.go:260)
+                    f->tableLog = fse_optimal_table_log(nseq, f->symbolLen);
+                    f->stLen1 = 0;
+                    if ((int)maxCount == nseq) {
+                        f->useRLE = 1;
+                    } else {
+                        f->useRLE = 0;
+                        if (fse_normalize_core(S.shist[k], f->norm, f->symbolLen, nseq, f->tableLog)) doBuild = 1;
+                        else atomicExch(P.err_flag, 2u);
+                    }
+                }
+            }
+            doBuild = __shfl(doBuild, 0, 64);
+            if (doBuild) {
+                if (!fse_build_wave(f->norm, f->symbolLen, f->tableLog, S.tsym[k], S.cumul[k], S.posx[k], f->st, f->dnb, f->dfs, lane)) {
+                    if (lane == 0) atomicExch(P.err_flag, 2u);
                 }
             }
         }
         __syncthreads();
         PROF_MARK(8);
         // ---------- 5. mode choice, mode byte, NCount headers (blockenc.go:633-722) ----------
+        // 5a. approxSize of the new / predefined / previous encoder for each stream: one wave per stream, one lane per symbol
+        if (wv < 3) {
+            const int k = wv;
+            const KcFseT* cur = &S.fse[S.curIdx[k]];
+            if (!cur->useRLE) {
+                const uint32_t* hist = S.shist[k];
+                const int histLen = cur->symbolLen;
+                const uint32_t v0 = wave_approx_size(cur, hist, histLen, lane);
+                const uint32_t v1 = wave_approx_size(&S.fse[6 + k], hist, histLen, lane);
+                const uint32_t v2 = wave_approx_size(&S.fse[S.prevIdx[k]], hist, histLen, lane);
+                if (lane == 0) { S.asz[k][0] = v0; S.asz[k][1] = v1; S.asz[k][2] = v2; }
+            }
+        }
+        __syncthreads();
         if (tid == 0) {
-            uint8_t* h = S.seqhdr;
-            int hp = 0;
-            if (nseq < 128) h[hp++] = (uint8_t)nseq;
-            else if (nseq < 0x7f00) { h[hp++] = (uint8_t)(128 + (uint8_t)(nseq >> 8)); h[hp++] = (uint8_t)nseq; }
-            else { const int n = nseq - 0x7f00; h[hp++] = 255; h[hp++] = (uint8_t)n; h[hp++] = (uint8_t)(n >> 8); }
             uint8_t mode = 0;
             const uint32_t firstCodes[3] = {kc_ll_code(seq_ll(sq[0])), kc_of_code(seq_of(sq[0])), kc_ml_code(seq_ml(sq[0]))};
             const int shifts[3] = {6, 4, 2};
@@ -812,13 +863,9 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     cur->st[0] = 0;  // cState.init pins state 0 for a 1-entry table (fse_encoder.go:685-690)
                     cur->rleVal = (uint8_t)v;
                 } else {
-                    const KcFseT* prev = &S.fse[S.prevIdx[k]];
-                    const KcFseT* pre = &S.fse[6 + k];
-                    const uint32_t* hist = S.shist[k];
-                    const int histLen = cur->symbolLen;
-                    uint32_t nSize = fse_approx_size(cur, hist, histLen) + fse_max_header_size(cur);
-                    const uint32_t predefSize = fse_approx_size(pre, hist, histLen);
-                    const uint32_t prevSize = fse_approx_size(prev, hist, histLen);
+                    uint32_t nSize = S.asz[k][0] + fse_max_header_size(cur);
+                    const uint32_t predefSize = S.asz[k][1];
+                    const uint32_t prevSize = S.asz[k][2];
                     nSize = nSize + ((nSize + 2 * 8 * 16) >> 4);
                     if (predefSize <= prevSize && predefSize <= nSize) { mk = 0; use = 6 + k; }
                     else if (prevSize <= nSize) { mk = 3; use = S.prevIdx[k]; }
@@ -827,27 +874,42 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 S.useIdx[k] = (uint8_t)use;
                 mode |= (uint8_t)(mk << shifts[k]);
             }
-            h[hp++] = mode;
-            for (int k = 0; k < 3; k++) {  // writeCount order: LL, OF, ML
-                const KcFseT* f = &S.fse[S.useIdx[k]];
-                if (f->useRLE) { h[hp++] = f->rleVal; continue; }
-                if (f->preDefined || f->reUsed) continue;
-                const int n = fse_write_ncount(f->norm, f->symbolLen, f->tableLog, h + hp);
-                if (n < 0) atomicExch(P.err_flag, 3u); else hp += n;
+            S.seqMode = mode;
+        }
+        __syncthreads();
+        // 5b. NCount of the encoders built this block (one lane per stream) and setBits (one lane per code)
+        if (wv < 3) {
+            const int k = wv;
+            KcFseT* f = &S.fse[S.useIdx[k]];
+            if (lane == 0) {
+                int n = 0;
+                if (f->useRLE) { S.nc[k][0] = f->rleVal; n = 1; }
+                else if (!(f->preDefined || f->reUsed)) {
+                    n = fse_write_ncount(f->norm, f->symbolLen, f->tableLog, S.nc[k]);
+                    if (n < 0) { atomicExch(P.err_flag, 3u); n = 0; }
+                }
+                S.ncLen[k] = n;
             }
-            S.seqhdrLen = hp;
             // setBits (fse_encoder.go:225): extra-bit counts per code for encoders built this block
-            for (int k = 0; k < 3; k++) {
-                KcFseT* f = &S.fse[S.useIdx[k]];
-                if (f->reUsed || f->preDefined) continue;
+            if (!(f->reUsed || f->preDefined)) {
                 if (f->useRLE) {
-                    const uint32_t v = f->rleVal;
-                    f->outBits[v] = (uint8_t)(k == 0 ? kc_ll_bits(v) : (k == 1 ? v : kc_ml_bits(v)));
-                } else {
-                    for (int i = 0; i < (int)f->symbolLen; i++)
-                        f->outBits[i] = (uint8_t)(k == 0 ? kc_ll_bits(i) : (k == 1 ? (uint32_t)i : kc_ml_bits(i)));
+                    if (lane == 0) { const uint32_t v = f->rleVal; f->outBits[v] = (uint8_t)(k == 0 ? kc_ll_bits(v) : (k == 1 ? v : kc_ml_bits(v))); }
+                } else if (lane < (int)f->symbolLen) {
+                    f->outBits[lane] = (uint8_t)(k == 0 ? kc_ll_bits((uint32_t)lane) : (k == 1 ? (uint32_t)lane : kc_ml_bits((uint32_t)lane)));
                 }
             }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint8_t* h = S.seqhdr;
+            int hp = 0;
+            if (nseq < 128) h[hp++] = (uint8_t)nseq;
+            else if (nseq < 0x7f00) { h[hp++] = (uint8_t)(128 + (uint8_t)(nseq >> 8)); h[hp++] = (uint8_t)nseq; }
+            else { const int n = nseq - 0x7f00; h[hp++] = 255; h[hp++] = (uint8_t)n; h[hp++] = (uint8_t)(n >> 8); }
+            h[hp++] = S.seqMode;
+            for (int k = 0; k < 3; k++)  // writeCount order: LL, OF, ML
+                for (int i = 0; i < S.ncLen[k]; i++) h[hp++] = S.nc[k][i];
+            S.seqhdrLen = hp;
         }
         __syncthreads();
         const KcFseT* E[3] = {&S.fse[S.useIdx[0]], &S.fse[S.useIdx[1]], &S.fse[S.useIdx[2]]};
