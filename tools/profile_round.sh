@@ -8,9 +8,9 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/kt -- python bench.py --no-cpu-baseline > $OUT/kt.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pf.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pw.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python bench.py --no-cpu-baseline > $OUT/kt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pf.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pw.log 2>&1
 python - <<PY
 import sqlite3, glob, json, csv, os
 out = "$OUT"
