@@ -61,7 +61,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from compress_amd import _lib, zstd
-    from compress_amd.shard import shard_range, gather_frames
+    from compress_amd.shard import shard_range, gather_frames, FrameGather
 
     n_units = int(args.gib * (1 << 30)) // UNIT
     first_unit = rank * n_units  # contiguous shard per rank keeps output order == concatenation order
@@ -79,7 +79,9 @@ def main():
     encs = [zstd.NewWriter(None, zstd.WithEncoderLevel(zstd.SpeedFastest), device=local_rank, stream=st.cuda_stream) for st in streams]
     enc = encs[0]
     cap = n_units * ((enc.MaxEncodedSize(UNIT) + 15) & ~15) + 64
-    d_dsts = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(npipe)]
+    ndst = 2 if (npipe == 2 or world > 1) else 1  # N > 1: the gather of step i reads one buffer while step i+1 fills the other
+    d_dsts = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(ndst)]
+    gather = FrameGather(rank, world) if world > 1 else None
     if npipe == 2:
         encs[0].ChainAfter(encs[1])
         encs[1].ChainAfter(encs[0])
@@ -87,22 +89,30 @@ def main():
     torch.cuda.synchronize()
 
     def run_steps(k):
-        """k passes over the batch; returns (offsets of the last pass, its buffer index, per-pass kernel timings)."""
+        """k passes over the batch; returns (offsets of the last pass, its buffer index, per-pass kernel timings).
+        N > 1: the RCCL gather of step i's frames to rank 0 is posted after step i and completed after step i+1's encode,
+        so the transfer over xGMI overlaps the next step's kernels; the last gather completes inside the timed region."""
         tms, off, last = [], None, 0
         if k <= 0:
             return off, last, tms
+        pending = None
         encs[0].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[0].data_ptr(), cap)
         for i in range(k):
             cur, nxt = i % npipe, (i + 1) % npipe
+            db = i % ndst
             if npipe == 2 and i + 1 < k:
-                encs[nxt].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[nxt].data_ptr(), cap)
+                encs[nxt].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[(i + 1) % ndst].data_ptr(), cap)
             off = encs[cur].EncodeUnitsDeviceEnd()
             tms.append(encs[cur].ctx().timings())
             if world > 1:
-                gather_frames(d_dsts[cur], int(off[n_units]), rank, world)
+                if pending is not None:
+                    pending.wait()
+                pending = gather.start(d_dsts[db], int(off[n_units]))
             if npipe == 1 and i + 1 < k:
-                encs[0].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[0].data_ptr(), cap)
-            last = cur
+                encs[0].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[(i + 1) % ndst].data_ptr(), cap)
+            last = db
+        if pending is not None:
+            pending.wait()
         return off, last, tms
 
     run_steps(args.warmup)

@@ -48,3 +48,50 @@ def gather_frames(buf, nbytes, rank, world, root=0):
     if nbytes > 0:
         dist.isend(buf[:nbytes], dst=root).wait()
     return None
+
+
+class FrameGather:
+    """The same gather, split so that it overlaps the next batch's encode: start() exchanges the byte counts and posts the
+    point-to-point transfers, wait() completes them (and, on CUDA, blocks the host until the bytes have landed, so that the
+    source buffer may be overwritten and the result read).  One gather in flight per object; the root keeps one receive
+    buffer and grows it on demand."""
+
+    def __init__(self, rank, world, root=0):
+        self.rank, self.world, self.root = rank, world, root
+        self._out = None
+        self._reqs = None
+        self._offs = None
+
+    def start(self, buf, nbytes):
+        assert self._reqs is None, "previous gather not waited for"
+        sizes = gather_sizes(nbytes, buf.device)
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + s)
+        self._offs = offs
+        self._reqs = []
+        self._dev = buf.device
+        if self.rank == self.root:
+            if self._out is None or self._out.numel() < offs[-1]:
+                self._out = torch.empty(max(offs[-1], 1), dtype=torch.uint8, device=buf.device)
+            self._out[offs[self.root]:offs[self.root + 1]].copy_(buf[:nbytes])
+            for r in range(self.world):
+                if r == self.root or sizes[r] == 0:
+                    continue
+                self._reqs.append(dist.irecv(self._out[offs[r]:offs[r + 1]], src=r))
+        elif nbytes > 0:
+            self._reqs.append(dist.isend(buf[:nbytes], dst=self.root))
+        return self
+
+    def wait(self):
+        """Returns (gathered uint8 tensor, per-rank byte offsets) on the root, None elsewhere."""
+        if self._reqs is None:
+            return None
+        for q in self._reqs:
+            q.wait()
+        if self._dev.type == "cuda":
+            torch.cuda.current_stream(self._dev).synchronize()
+        self._reqs = None
+        if self.rank == self.root:
+            return self._out[:self._offs[-1]], self._offs
+        return None

@@ -34,6 +34,19 @@ def _worker(rank, world, port, n_units, ret):
         ret["offs"] = offs
     else:
         assert got is None
+    # overlappable form: three gathers back to back through one object (sizes differ per round), results identical
+    from compress_amd.shard import FrameGather
+    fg = FrameGather(rank, world)
+    for rnd in range(3):
+        cut = max(0, len(mine) - rnd)
+        h = fg.start(buf, cut)
+        got2 = h.wait()
+        if rank == 0:
+            out2, offs2 = got2
+            ret["out2_%d" % rnd] = out2.numpy().copy()
+            ret["offs2_%d" % rnd] = list(offs2)
+        else:
+            assert got2 is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -48,6 +61,10 @@ def test_shard_and_gather_world2(n_units):
     want = np.concatenate([np.full((i % 7) + 1, i & 0xFF, dtype=np.uint8) for i in range(n_units)]) if n_units else np.zeros(0, dtype=np.uint8)
     assert np.array_equal(ret["out"], want)
     assert ret["offs"][0] == 0 and ret["offs"][-1] == len(want) and len(ret["offs"]) == world + 1
+    assert np.array_equal(ret["out2_0"], want) and ret["offs2_0"] == list(ret["offs"])
+    for rnd in (1, 2):  # every rank dropped its last `rnd` bytes
+        o = ret["offs2_%d" % rnd]
+        assert len(ret["out2_%d" % rnd]) == o[-1] and o[-1] <= len(want)
 
 
 def test_shard_range_partitions():
