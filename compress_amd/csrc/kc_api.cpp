@@ -60,6 +60,7 @@ struct kc_ctx {
     hipEvent_t evc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     kc_timings last = {0, 0, 0, 0, 0};
     size_t max_batch_bytes = (size_t)8 << 30;  // input bytes per device batch (scratch is ~6x this)
+    int stream_mode = 0;             // set for the duration of kc_zstd_encode_streams_dev
     void* pend = nullptr;            // batch between kc_zstd_encode_units_dev_begin and _end (Pending)
     kc_ctx* chain_after = nullptr;   // pipelining: this context's match finder waits for that context's last one
 };
@@ -336,7 +337,7 @@ kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_
     }
     const char* v = getenv("KC_ZFAST_VARIANT");
     std::string var = v ? v : "g8";
-    if (mp.hist0 > 0) var = "g8";  // dictionary-primed tables exist for the group kernels only
+    if (mp.hist0 > 0 || mp.stream_mode) var = "g8";  // dictionary-primed tables / stream parsing exist for the group kernels only
     if (var == "lds") {
         bool ok = bs <= 65536;
         for (uint32_t i = 0; i < n_units && ok; i++) if (unit_off[i + 1] - unit_off[i] > 131072) ok = false;
@@ -440,6 +441,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     mp.unit_off = k_off;
     mp.hist0 = hist0;
     mp.pos_bits = pos_bits;
+    mp.stream_mode = c->stream_mode;
     mp.rep1 = (int32_t)o->dict_offsets[0];
     mp.rep2 = (int32_t)o->dict_offsets[1];
     if (mp.rep1 <= 0 || mp.rep2 <= 0) { mp.rep1 = 1; mp.rep2 = 4; }  // opts not initialised through kc_zstd_opts_default
@@ -462,6 +464,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     ep.src = k_src;
     ep.unit_off = k_off;
     ep.hist0 = hist0;
+    ep.stream_mode = c->stream_mode;
     ep.dict_huf = nullptr;
     ep.dict_huf_len = 0;
     ep.dict_huf_log = 0;
@@ -704,6 +707,19 @@ kc_status kc_zstd_encode_units_dev_end(kc_ctx* c, uint64_t* out_off) {
 
 void kc_ctx_chain_after(kc_ctx* c, kc_ctx* prev) {
     if (c) c->chain_after = prev;
+}
+
+kc_status kc_zstd_encode_streams_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off, uint32_t n_units,
+                                     uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off) {
+    if (!c || !o) return KC_ERR_BAD_ARG;
+    if (o->dict != nullptr || o->dict_id != 0) {
+        c->err = "streaming with a dictionary is not served by the device path (the reference's sync and async block paths disagree on the dictionary literal table)";
+        return KC_ERR_UNSUPPORTED;
+    }
+    c->stream_mode = 1;
+    const kc_status s = kc_zstd_encode_units_dev(c, o, d_src, unit_off, n_units, d_dst, dst_cap, out_off);
+    c->stream_mode = 0;
+    return s;
 }
 
 kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units,

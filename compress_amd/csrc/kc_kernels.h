@@ -22,6 +22,7 @@ struct KcMatchParams {
     int32_t hist0;              // bytes of dictionary content prepended to every unit in `src` (0: no dictionary)
     int32_t pos_bits;           // bits reserved for position+1 in tagged table entries (better level)
     int32_t rep1, rep2;         // initial recentOffsets[0..1]: {1,4} unless a full-format dictionary supplies its own
+    int32_t stream_mode;        // units are Write+Close streams: a unit of >= one block is parsed with Encode (history) from its first block
 };
 // lds_variant: every unit <= 131064 bytes and block_size <= 65536 (packed 17-bit table + LDS-resident block)
 void kc_launch_zfast_match(const KcMatchParams& P, uint32_t grid, hipStream_t st, bool lds_variant);
@@ -62,6 +63,8 @@ struct KcEntropyParams {
     int32_t hist0;          // bytes of dictionary content prepended to every unit in `src`
     const uint8_t* dict_huf;   // device or null: dictionary literal table, 256 x u16 val then 256 x u8 nBits (KcHufTable layout)
     int32_t dict_huf_len, dict_huf_log;
+    int32_t stream_mode;       // streaming frame layout for units >= one block (zstd/encoder.go:257-428): no content size, no single
+                               // segment, last flag only on a short final block, else an empty raw last block
     uint32_t* err_flag;     // device: set non-zero on a device-side invariant violation
     unsigned long long* prof;  // device or null: per-phase shader-clock totals (diagnostics, KC_K2_PROF=1)
 };

@@ -376,12 +376,16 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
 #define PROF_MARK(i) do { if (P.prof && tid == 0) { const long long t1__ = clock64(); atomicAdd(&P.prof[i], (unsigned long long)(t1__ - pt0)); pt0 = t1__; } } while (0)
     if (P.prof && tid == 0) pt0 = clock64();
     // ---- frame header (frameenc.go:25-92; encoder.go:756-772) ----
+    // Streaming layout (Write ... Close, zstd/encoder.go:257-428) for units of at least one block: frame header without content
+    // size or single segment, window = the encoder's, `last` only on a short final block, otherwise an empty raw last block.
+    const bool streamU = P.stream_mode && ulen >= bs;
     if (ulen > 0) {
         bool single = ulen <= P.window_size && ulen > 1024;
         if (P.single >= 0) single = P.single != 0;
+        if (streamU) single = false;
         // fastBase.WindowSize (enc_base.go:42)
         uint32_t windowSize = (uint32_t)P.window_size;
-        if (ulen < P.window_size) {
+        if (ulen < P.window_size && !streamU) {
             uint32_t bsz = 1u << bits_len32((uint32_t)ulen);
             windowSize = bsz < 1024u ? 1024u : bsz;
         }
@@ -395,13 +399,16 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         int didLen = 0;
         if (did > 0) { if (did < 256) { fhd |= 1; didLen = 1; } else if (did < (1u << 16)) { fhd |= 2; didLen = 2; } else { fhd |= 3; didLen = 4; } }
         uint8_t fcs = 0;
-        if (ulen >= 256) fcs++;
-        if (ulen >= 65536 + 256) fcs++;
+        if (!streamU) {  // streaming: ContentSize 0 -> no FCS field (frameenc.go:40-58)
+            if (ulen >= 256) fcs++;
+            if (ulen >= 65536 + 256) fcs++;
+        }
         fhd |= (uint8_t)(fcs << 6);
         hdr[h++] = fhd;
         if (!single) hdr[h++] = (uint8_t)((bits_len32(windowSize - 1) - 10) << 3);
         for (int i = 0; i < didLen; i++) hdr[h++] = (uint8_t)(did >> (8 * i));
-        if (fcs == 0) { if (single) hdr[h++] = (uint8_t)ulen; }
+        if (streamU) { /* no content size */ }
+        else if (fcs == 0) { if (single) hdr[h++] = (uint8_t)ulen; }
         else if (fcs == 1) { const uint32_t c = (uint32_t)ulen - 256; hdr[h++] = (uint8_t)c; hdr[h++] = (uint8_t)(c >> 8); }
         else { for (int i = 0; i < 4; i++) hdr[h++] = (uint8_t)((uint32_t)ulen >> (8 * i)); }
         if (tid == 0) for (int i = 0; i < h; i++) outp[i] = hdr[i];
@@ -411,7 +418,21 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
     if (ulen == 0) {
         // zero-length input: optional 9-byte frame (encoder.go:732-752, App. A-18)
         if (tid == 0) {
-            if (P.full_zero) {
+            if (P.full_zero && P.stream_mode) {
+                // Close on an empty stream (encoder.go:266-329): streaming header, empty raw last block, checksum of nothing
+                int h = 0;
+                outp[h++] = 0x28; outp[h++] = 0xb5; outp[h++] = 0x2f; outp[h++] = 0xfd;
+                uint8_t fhd = P.crc ? (1 << 2) : 0;
+                const uint32_t did = P.dict_id;
+                int didLen = 0;
+                if (did > 0) { if (did < 256) { fhd |= 1; didLen = 1; } else if (did < (1u << 16)) { fhd |= 2; didLen = 2; } else { fhd |= 3; didLen = 4; } }
+                outp[h++] = fhd;
+                outp[h++] = (uint8_t)((bits_len32((uint32_t)P.window_size - 1) - 10) << 3);
+                for (int i = 0; i < didLen; i++) outp[h++] = (uint8_t)(did >> (8 * i));
+                outp[h++] = 0x01; outp[h++] = 0x00; outp[h++] = 0x00;
+                if (P.crc) { outp[h++] = 0x99; outp[h++] = 0xe9; outp[h++] = 0xd8; outp[h++] = 0x51; }  // XXH64("") & 0xffffffff
+                P.out_size[u] = (uint32_t)h;
+            } else if (P.full_zero) {
                 const uint8_t z[9] = {0x28, 0xb5, 0x2f, 0xfd, 0x20, 0x00, 0x01, 0x00, 0x00};
                 for (int i = 0; i < 9; i++) outp[i] = z[i];
                 P.out_size[u] = 9;
@@ -427,7 +448,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         const int blkStart = hist0 + b * bs;
         const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;
         const int size = blkEnd - blkStart;
-        const bool last = b == nblk - 1;
+        const bool last = b == nblk - 1 && !(streamU && (ulen % bs) == 0);
         const uint8_t* __restrict__ org = base + blkStart;
         const uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
         uint8_t* __restrict__ lits = P.lits + (size_t)(blk0 + (uint32_t)b) * P.lit_stride;
@@ -1116,7 +1137,11 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         PROF_MARK(13);
     }
 
-    // ---- zero-length input (encoder.go:732-753) is handled on the host; checksum (enc_base.go:34-38) ----
+    if (streamU && (ulen % bs) == 0) {  // Close found nothing buffered: final block without data (encoder.go:315-329)
+        if (tid == 0) { outp[opos] = 0x01; outp[opos + 1] = 0x00; outp[opos + 2] = 0x00; }
+        opos += 3;
+    }
+    // ---- checksum (enc_base.go:34-38) ----
     if (ulen > 0 && P.crc) {
         if (tid == 0) {
             const uint64_t h = P.xxh[u];

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const int bs = P.block_size;
     const int mmo = P.max_match_off;
     const int nblk = (ulen + bs - 1) / bs;
-    const bool HIST = ulen > bs || hist0 > 0;  // with a dictionary encodeAll always calls Encode (encoder.go:783-787)
+    const bool HIST = ulen > bs || hist0 > 0 || (P.stream_mode && ulen >= bs);  // with a dictionary encodeAll always calls Encode (encoder.go:783-787)
     const uint32_t pm = (gact && P.popmask) ? P.popmask[u] : 0u;
     uint32_t* __restrict__ tab = tables + (size_t)ui * (1u << ZF_TABLE_BITS);  // zeroed by the host before the launch
     // Table entry = (position+1) in the low PB bits | a TB-bit tag of the 4 source bytes at that position.

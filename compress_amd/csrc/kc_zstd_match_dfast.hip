@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
     const int bs = P.block_size;
     const int mmo = P.max_match_off;
     const int nblk = (ulen + bs - 1) / bs;
-    const bool HIST = ulen > bs || hist0 > 0;
+    const bool HIST = ulen > bs || hist0 > 0 || (P.stream_mode && ulen >= bs);
     const uint32_t pm = (gact && P.popmask) ? P.popmask[u] : 0u;
     uint32_t* __restrict__ ltab = tables + (size_t)ui * ((1u << ZD_LONG_BITS) + (1u << ZD_SHORT_BITS));
     uint32_t* __restrict__ stab = ltab + (1u << ZD_LONG_BITS);

@@ -110,9 +110,15 @@ def WithLowerEncoderMem(b):
 
 
 class Encoder:
-    """zstd.Encoder for the block (EncodeAll) path.  Streaming Write/Close is a 'next' row."""
+    """zstd.Encoder: EncodeAll and its batched forms, plus the streaming surface Write / ReadFrom / Flush / Close / Reset
+    (zstd/encoder.go:140-649).  A stream is buffered on the host and encoded on Close as ONE device unit whose bytes equal the
+    reference's for the same Write sequence; streams of more than 32 blocks, mid-stream Flush and dictionaries are not served
+    (the caller falls back to the reference).  EncodeStreams / EncodeStreamsDevice batch many streams per launch."""
 
-    def __init__(self, *opts, device=0, stream=None):
+    def __init__(self, *opts, device=0, stream=None, w=None):
+        self._w = w
+        self._buf = bytearray()
+        self._closed = False
         L = _lib.load()
         self.o = _lib.ZstdOpts()
         L.kc_zstd_opts_default(C.byref(self.o))
@@ -164,6 +170,65 @@ class Encoder:
                                                  int(dst_cap), out_off.ctypes.data))
         return out_off
 
+    # -- streaming surface (encoder.go:140-253, 531-649) --
+    def Reset(self, w):
+        self._w = w
+        self._buf = bytearray()
+        self._closed = False
+
+    def Write(self, p):
+        if self._closed:
+            raise IOError("zstd: encoder closed")  # ErrEncoderClosed
+        self._buf += bytes(p)
+        return len(p)
+
+    def ReadFrom(self, r):
+        n = 0
+        while True:
+            b = r.read(1 << 20)
+            if not b:
+                return n
+            n += self.Write(b)
+
+    def Flush(self):
+        if self._buf:
+            raise NotImplementedError("mid-stream Flush cuts a block early; not served by the device path")
+
+    def _finish_stream(self):
+        """The frame the reference writes for Write(everything) + Close() goes to w."""
+        if self._closed or self._w is None:
+            self._closed = True
+            return
+        import numpy as np
+        data = bytes(self._buf)
+        self._buf = bytearray()
+        self._closed = True
+        out, _ = self.EncodeStreams(np.frombuffer(data, dtype=np.uint8), np.array([0, len(data)], dtype=np.uint64))
+        self._w.write(out.tobytes())
+
+    def EncodeStreams(self, src, unit_off):
+        """Like EncodeUnits, but every unit is a stream: NewWriter(w).Write(unit) ... Close()."""
+        import numpy as np
+        import torch
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
+        n = len(unit_off) - 1
+        cap = sum(((self.MaxEncodedSize(int(unit_off[i + 1] - unit_off[i])) + 15) & ~15) for i in range(n)) + 64
+        d_src = torch.from_numpy(src.copy() if len(src) else np.zeros(1, dtype=np.uint8)).cuda(self._device)
+        d_dst = torch.empty(cap, dtype=torch.uint8, device=d_src.device)
+        out_off = self.EncodeStreamsDevice(d_src.data_ptr(), unit_off, d_dst.data_ptr(), cap)
+        return d_dst[:int(out_off[n])].cpu().numpy(), out_off
+
+    def EncodeStreamsDevice(self, d_src_ptr, unit_off, d_dst_ptr, dst_cap):
+        import numpy as np
+        ctx = self.ctx()
+        unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
+        n = len(unit_off) - 1
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        ctx.check(ctx.L.kc_zstd_encode_streams_dev(ctx.h, C.byref(self.o), d_src_ptr, unit_off.ctypes.data, n, d_dst_ptr,
+                                                   int(dst_cap), out_off.ctypes.data))
+        return out_off
+
     def EncodeUnitsDeviceBegin(self, d_src_ptr, unit_off, d_dst_ptr, dst_cap):
         """First half of EncodeUnitsDevice (one device batch): enqueue up to and including the match finder, no wait."""
         import numpy as np
@@ -206,11 +271,14 @@ class Encoder:
         return [(seqs[int(first[b]):int(first[b + 1])].copy(), int(extra[b])) for b in range(nb.value)]
 
     def Close(self):
+        """Encoder.Close (encoder.go:567): finish the stream, if one was written to a writer; the device context is released
+        and re-created on the next use (the encoder stays usable after Reset, like the reference's)."""
+        self._finish_stream()
         if self._ctx is not None:
             self._ctx.close()
             self._ctx = None
 
 
 def NewWriter(w, *opts, **kw):
-    """zstd.NewWriter(w, opts...) (encoder.go:71).  w is accepted for signature parity; the block API ignores it."""
-    return Encoder(*opts, **kw)
+    """zstd.NewWriter(w, opts...) (encoder.go:71).  w (may be None for block-API use) receives the stream on Close."""
+    return Encoder(*opts, w=w, **kw)

@@ -168,6 +168,66 @@ struct OracleEncoder {
         if (o.crc) enc->AppendCRC(dst);
         return 0;
     }
+
+    // Streaming use of the encoder (zstd/encoder.go: Write :154-253 -> nextBlock :257-428 -> Close :567-649), synchronous
+    // form.  `cuts` lists the input positions at which Flush was called (ascending, may be empty); full blocks are cut every
+    // blockSize bytes after the last cut, as writeBlocks does.  The asynchronous form (concurrent > 1) differs only in which
+    // stale repeat offsets a block starts with, and no matcher reads them before it has found three sequences of its own
+    // (`canRepeat := len(blk.sequences) > 2`), so both forms give these bytes.  Dictionaries are not served here: the two
+    // forms disagree on whether the dictionary's literal table reaches the first block (blk.reset(nil) at :371 clears it).
+    int encodeStream(const uint8_t* src, size_t n, const uint64_t* cuts, size_t n_cuts, Bytes* dst) {
+        if (hasDict) return -1;
+        // block boundaries
+        std::vector<size_t> ends;
+        {
+            size_t pos = 0, ci = 0;
+            while (pos < n) {
+                size_t e = pos + (size_t)o.block_size;
+                while (ci < n_cuts && cuts[ci] <= pos) ci++;
+                if (ci < n_cuts && cuts[ci] < e) e = (size_t)cuts[ci];
+                if (e > n) e = n;
+                ends.push_back(e);
+                pos = e;
+            }
+        }
+        // Did Close find bytes in `filling`?  Not if a Flush drained it at the very end or the tail filled a whole block.
+        bool tailBuffered = false;
+        if (!ends.empty()) {
+            const size_t lastStart = ends.size() > 1 ? ends[ends.size() - 2] : 0;
+            const bool flushedAtEnd = n_cuts > 0 && cuts[n_cuts - 1] >= n;
+            tailBuffered = !flushedAtEnd && (n - lastStart) < (size_t)o.block_size;
+        }
+        if (n == 0 || (ends.size() == 1 && tailBuffered)) {
+            if (n == 0) {
+                if (!o.full_zero) return 0;  // :266-271
+            } else {
+                return encodeAll(src, n, dst);  // :272-288 single block: a complete EncodeAll frame
+            }
+        }
+        enc->Reset(nullptr, false);
+        frameHeaderAppend(dst, 0, (uint32_t)enc->WindowSize(0), false, o.crc != 0, 0);  // :290-297
+        BlockEnc* blk = &enc->blk;
+        size_t pos = 0;
+        for (size_t bi = 0; bi < ends.size(); bi++) {
+            const size_t todo = ends[bi] - pos;
+            if (o.crc) enc->crc.Write(src + pos, todo);
+            blk->reset(nullptr);
+            enc->Encode(blk, src + pos, todo);
+            blk->last = (bi + 1 == ends.size()) && tailBuffered;
+            if (blk->encode(src + pos, todo, o.no_entropy != 0, !o.all_lit_entropy) != 0) return -1;
+            dst->insert(dst->end(), blk->output.begin(), blk->output.end());
+            pos = ends[bi];
+        }
+        if (!tailBuffered) {  // :315-329 final block without data
+            BlockHeader bh;
+            bh.setSize(0);
+            bh.setType(blockTypeRaw);
+            bh.setLast(true);
+            bh.appendTo(dst);
+        }
+        if (o.crc) enc->AppendCRC(dst);
+        return 0;
+    }
 };
 
 // zstd/encoder.go:843 MaxEncodedSize (pad==0)
@@ -186,6 +246,15 @@ int64_t maxEncodedSize(const kco_zstd_opts* o, int64_t size) {
 }  // namespace
 
 extern "C" {
+
+// NewWriter(w).Write(src[...]); Flush at each cuts[i]; Close() on a persistent encoder state.  Returns bytes or -1 / -2.
+int64_t kco_zstd_encode_stream(void* e, const uint8_t* src, uint64_t n, const uint64_t* cuts, uint64_t n_cuts, uint8_t* dst, uint64_t cap) {
+    Bytes out;
+    if (((OracleEncoder*)e)->encodeStream(src, (size_t)n, cuts, (size_t)n_cuts, &out) != 0) return -1;
+    if (out.size() > cap) return -2;
+    memcpy(dst, out.data(), out.size());
+    return (int64_t)out.size();
+}
 
 // loadDict result as the encoder sees it (zstd/dict.go:71-150): returns 0, or -1 when loadDict errors.
 int kco_zstd_load_dict(const uint8_t* blob, uint64_t len, uint32_t* id, int32_t* offsets, uint16_t* val, uint8_t* nbits,

@@ -126,6 +126,20 @@ class ZstdOracle:
     def max_encoded_size(self, n):
         return lib().kco_zstd_max_encoded_size(C.byref(self.opts), n)
 
+    def encode_stream(self, src: bytes, flush_at=()) -> bytes:
+        """NewWriter(w); Write(src) with Flush() at the given input positions; Close()."""
+        import numpy as np
+        L = lib()
+        L.kco_zstd_encode_stream.restype = C.c_int64
+        L.kco_zstd_encode_stream.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
+        cuts = np.ascontiguousarray(sorted(flush_at), dtype=np.uint64)
+        cap = self.max_encoded_size(len(src)) + 64 + 3 * (len(cuts) + 2)
+        buf = C.create_string_buffer(cap)
+        r = L.kco_zstd_encode_stream(self.h, src, len(src), cuts.ctypes.data if len(cuts) else None, len(cuts), buf, cap)
+        if r < 0:
+            raise RuntimeError("oracle encode_stream failed: %d" % r)
+        return buf.raw[:r]
+
     def encode_all(self, src: bytes) -> bytes:
         cap = self.max_encoded_size(len(src)) + 64
         buf = C.create_string_buffer(cap)

@@ -248,3 +248,49 @@ def test_begin_end_pipeline_two_contexts(oracle, kclib):
         encs[0].EncodeUnitsDeviceEnd()
     for e in encs + [ref_enc]:
         e.Close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_streams_bit_exact(oracle, kclib, level):
+    """N2: NewWriter(w).Write(...) / Close() streams (kc_zstd_encode_streams_dev) against the oracle's restatement of
+    Write -> nextBlock -> Close: EncodeAll frame below one block, streaming frame (no content size, history from the first
+    block, trailing empty raw block when the input ends on a block boundary) from one block on; both decoders round-trip."""
+    _torch()
+    import io
+    from compress_amd import zstd
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level))
+    bs = enc.o.block_size
+    t = corpora.corpus("T", 6, 131072, first_unit=40).tobytes()
+    m = corpora.corpus("M", 2, 131072, first_unit=3).tobytes()
+    units = [b"", t[:1], t[:100], t[:bs - 1], t[:bs], t[:bs + 1], t[:2 * bs], t[:2 * bs + 5], t[:3 * bs - 1], m[:bs], m, t[7:7 + 5 * bs], corpora.corpus("H", 1, 2 * bs).tobytes()]
+    ubuf, off = corpora.pack_units(units)
+    out, out_off = enc.EncodeStreams(ubuf, off)
+    ref = oracle.ZstdOracle(level=level)
+    for i, u in enumerate(units):
+        got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        assert got == ref.encode_stream(u), (i, len(u))
+        if u:
+            assert oracle.zstd_decompress(got, len(u) + 16) == u
+    # options that change the header / checksum
+    e2 = zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderCRC(False), zstd.WithZeroFrames(False))
+    o2, oo2 = e2.EncodeStreams(ubuf, off)
+    r2 = oracle.ZstdOracle(level=level, crc=False, full_zero=False)
+    for i, u in enumerate(units):
+        assert o2[int(oo2[i]):int(oo2[i + 1])].tobytes() == r2.encode_stream(u), (i, len(u))
+    # the io.Writer surface
+    sink = io.BytesIO()
+    w = zstd.NewWriter(sink, zstd.WithEncoderLevel(level))
+    for i in range(0, len(t[:2 * bs + 5]), 50000):
+        w.Write(t[i:min(i + 50000, 2 * bs + 5)])
+    w.Close()
+    assert sink.getvalue() == ref.encode_stream(t[:2 * bs + 5])
+    sink2 = io.BytesIO()
+    w.Reset(sink2)
+    w.ReadFrom(io.BytesIO(t[:1000]))
+    w.Close()
+    assert sink2.getvalue() == ref.encode_all(t[:1000])
+    with pytest.raises(IOError):
+        w.Write(b"x")
+    with pytest.raises(Exception):  # dictionaries: the caller must fall back
+        zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderDictRaw(1, t[:1000])).EncodeStreams(ubuf, off)
+    enc.Close(); e2.Close()
