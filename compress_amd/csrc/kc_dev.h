@@ -10,6 +10,7 @@ struct __attribute__((packed)) kc_u64u { uint64_t v; };
 struct __attribute__((packed)) kc_u32u { uint32_t v; };
 struct __attribute__((packed)) kc_u16u { uint16_t v; };
 __device__ __forceinline__ uint64_t ld64(const uint8_t* p) { return ((const kc_u64u*)p)->v; }
+__device__ __forceinline__ void st64(uint8_t* p, uint64_t v) { ((kc_u64u*)p)->v = v; }  // unaligned 8-byte store
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return ((const kc_u32u*)p)->v; }
 __device__ __forceinline__ uint16_t ld16(const uint8_t* p) { return ((const kc_u16u*)p)->v; }
 

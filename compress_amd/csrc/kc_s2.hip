@@ -65,7 +65,11 @@ __device__ __forceinline__ int s2_emit_literal(uint8_t* __restrict__ dst, const 
     else if (n < (1u << 16)) { i = 3; if (lig == 0) { dst[0] = 61 << 2; dst[1] = (uint8_t)n; dst[2] = (uint8_t)(n >> 8); } }
     else if (n < (1u << 24)) { i = 4; if (lig == 0) { dst[0] = 62 << 2; dst[1] = (uint8_t)n; dst[2] = (uint8_t)(n >> 8); dst[3] = (uint8_t)(n >> 16); } }
     else { i = 5; if (lig == 0) { dst[0] = 63 << 2; dst[1] = (uint8_t)n; dst[2] = (uint8_t)(n >> 8); dst[3] = (uint8_t)(n >> 16); dst[4] = (uint8_t)(n >> 24); } }
-    for (int k = lig; k < len; k += S2G) dst[i + k] = lit[k];
+    // 8 bytes per lane and pass (unaligned 8-byte loads/stores), then the tail bytewise: a byte per lane would be one
+    // memory instruction per 8 bytes of literals
+    const int body = len & ~7;
+    for (int k = lig * 8; k < body; k += S2G * 8) st64(dst + i + k, ld64(lit + k));
+    for (int k = body + lig; k < len; k += S2G) dst[i + k] = lit[k];
     return i + len;
 }
 // emitRepeat (encode_go.go:118); single lane writes. Returns bytes.
