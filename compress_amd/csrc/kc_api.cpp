@@ -745,6 +745,19 @@ kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* 
     return KC_OK;
 }
 
+kc_status kc_zstd_encode_streams(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units,
+                                 uint8_t* dst, uint64_t dst_cap, uint64_t* out_off) {
+    if (!c || !o) return KC_ERR_BAD_ARG;
+    if (o->dict != nullptr || o->dict_id != 0) {
+        c->err = "streaming with a dictionary is not served by the device path";
+        return KC_ERR_UNSUPPORTED;
+    }
+    c->stream_mode = 1;
+    const kc_status s = kc_zstd_encode_units(c, o, src, unit_off, n_units, dst, dst_cap, out_off);
+    c->stream_mode = 0;
+    return s;
+}
+
 kc_status kc_xxh64_units_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out_hash) {
     if (!c || !unit_off || !out_hash || (n_units && !d_src)) return KC_ERR_BAD_ARG;
     c->err.clear();

@@ -209,15 +209,18 @@ class Encoder:
     def EncodeStreams(self, src, unit_off):
         """Like EncodeUnits, but every unit is a stream: NewWriter(w).Write(unit) ... Close()."""
         import numpy as np
-        import torch
+        ctx = self.ctx()
         src = np.ascontiguousarray(src, dtype=np.uint8)
         unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
         n = len(unit_off) - 1
         cap = sum(((self.MaxEncodedSize(int(unit_off[i + 1] - unit_off[i])) + 15) & ~15) for i in range(n)) + 64
-        d_src = torch.from_numpy(src.copy() if len(src) else np.zeros(1, dtype=np.uint8)).cuda(self._device)
-        d_dst = torch.empty(cap, dtype=torch.uint8, device=d_src.device)
-        out_off = self.EncodeStreamsDevice(d_src.data_ptr(), unit_off, d_dst.data_ptr(), cap)
-        return d_dst[:int(out_off[n])].cpu().numpy(), out_off
+        dst = np.empty(cap, dtype=np.uint8)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        if len(src) == 0:
+            src = np.zeros(1, dtype=np.uint8)
+        ctx.check(ctx.L.kc_zstd_encode_streams(ctx.h, C.byref(self.o), src.ctypes.data, unit_off.ctypes.data, n,
+                                               dst.ctypes.data, cap, out_off.ctypes.data))
+        return dst[:int(out_off[n])], out_off
 
     def EncodeStreamsDevice(self, d_src_ptr, unit_off, d_dst_ptr, dst_cap):
         import numpy as np

@@ -116,6 +116,9 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uin
  * kc_zstd_encode_units_dev (a stream of more than 32 blocks is KC_ERR_UNSUPPORTED); dictionaries are KC_ERR_UNSUPPORTED. */
 kc_status kc_zstd_encode_streams_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
                                      uint32_t n_units, uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
+/* host-buffer form (src / dst in host memory), like kc_zstd_encode_units */
+kc_status kc_zstd_encode_streams(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off,
+                                 uint32_t n_units, uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
 /* Split form of kc_zstd_encode_units_dev for ONE device batch (<= 8 GiB): _begin enqueues everything up to and including
  * the match finder and returns without waiting; _end enqueues the entropy stage, waits, and returns the offsets.  With two
  * contexts (two streams, two sets of scratch) a caller pipelines consecutive batches:

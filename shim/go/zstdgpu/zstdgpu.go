@@ -12,6 +12,7 @@ package zstdgpu
 import "C"
 
 import (
+	"bytes"
 	"errors"
 	"unsafe"
 
@@ -156,6 +157,46 @@ func (e *Encoder) EncodeAll(src, dst []byte) []byte {
 		return e.cpu.EncodeAll(src, dst)
 	}
 	return append(dst, out...)
+}
+
+// EncodeStreams encodes src[off[i]:off[i+1]] as independent STREAMS, each identical to what
+// enc := zstd.NewWriter(w, opts...); enc.Write(unit); enc.Close() writes to w.
+func (e *Encoder) EncodeStreams(src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
+	n := len(off) - 1
+	need := 0
+	for i := 0; i < n; i++ {
+		need += (e.MaxEncodedSize(int(off[i+1]-off[i])) + 15) &^ 15
+	}
+	if cap(dst) < need+64 {
+		dst = make([]byte, need+64)
+	}
+	dst = dst[:cap(dst)]
+	outOff := make([]uint64, n+1)
+	if e.ctx != nil && n > 0 && len(src) > 0 {
+		st := C.kc_zstd_encode_streams(e.ctx, &e.opts,
+			(*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
+			(*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
+		if st == C.KC_OK {
+			return dst[:outOff[n]], outOff, nil
+		}
+		if st != C.KC_ERR_UNSUPPORTED && st != C.KC_ERR_NO_DEVICE {
+			return nil, nil, errors.New(C.GoString(C.kc_last_error(e.ctx)))
+		}
+	}
+	// reference path: a fresh stream per unit
+	var sink bytes.Buffer
+	for i := 0; i < n; i++ {
+		outOff[i] = uint64(sink.Len())
+		e.cpu.Reset(&sink)
+		if _, err := e.cpu.Write(src[off[i]:off[i+1]]); err != nil {
+			return nil, nil, err
+		}
+		if err := e.cpu.Close(); err != nil {
+			return nil, nil, err
+		}
+	}
+	outOff[n] = uint64(sink.Len())
+	return sink.Bytes(), outOff, nil
 }
 
 // EncodeUnits encodes src[off[i]:off[i+1]] as independent frames, each identical to EncodeAll(unit, nil).

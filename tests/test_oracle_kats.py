@@ -298,3 +298,32 @@ def test_in_repo_decoder_on_reference_regression_frames(oracle):
             assert oracle.zstd_decode(z, cap) == buf.raw[:r], (name, n)
             checked += 1
     assert checked >= 20
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_stream_restatement_structure_and_roundtrip(oracle, level):
+    """Write ... Flush ... Close (encoder.go:154-428, 567-649) as restated in OracleEncoder::encodeStream: below one block the
+    stream IS the EncodeAll frame; from one block on the frame has no content size and no single-segment flag, every cut
+    (block size or Flush) starts a block, an input ending on a cut gets a trailing empty raw last block; both decoders agree."""
+    import corpora
+    e = oracle.ZstdOracle(level=level)
+    bs = e.opts.block_size
+    t = corpora.corpus("T", 3, 131072, first_unit=11).tobytes()
+    assert e.encode_stream(t[:bs - 1]) == e.encode_all(t[:bs - 1])
+    assert e.encode_stream(b"").hex() == "28b52ffd04%02x01000099e9d851" % (((e.opts.window_size - 1).bit_length() - 10) << 3)
+    for n, cuts in ((bs, ()), (bs + 1, ()), (2 * bs, ()), (2 * bs + 7, ()), (1000, (10, 500)), (1000, (1000,)), (bs + 100, (50, bs + 100))):
+        fr = e.encode_stream(t[:n], cuts)
+        assert fr[:4] == b"\x28\xb5\x2f\xfd" and fr[4] == 0x04  # checksum flag only: no FCS, not single segment
+        assert oracle.zstd_decompress(fr, n + 16) == t[:n]
+        # walk the blocks: sizes follow the cuts, `last` is set exactly once, at the end
+        p, sizes, lasts = 6, [], []
+        while True:
+            bh = fr[p] | fr[p + 1] << 8 | fr[p + 2] << 16
+            typ, sz = (bh >> 1) & 3, bh >> 3
+            p += 3 + (sz if typ in (0, 2) else 1)
+            sizes.append((typ, sz)); lasts.append(bh & 1)
+            if bh & 1:
+                break
+        assert p + 4 == len(fr) and lasts.count(1) == 1
+        ends_on_cut = (n % bs == 0 and not cuts) or (cuts and cuts[-1] >= n)
+        assert (sizes[-1] == (0, 0)) == bool(ends_on_cut), (n, cuts, sizes)
