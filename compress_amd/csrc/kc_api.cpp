@@ -925,6 +925,39 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     return KC_OK;
 }
 
+// s2.Decode over N blocks on the device (verifier).  status[i] (host) receives 0 or the first error of block i.
+kc_status kc_s2_decode_blocks_dev(kc_ctx* c, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n, uint8_t* d_dst,
+                                  const uint64_t* dst_off, uint32_t* status) {
+    if (!c || !enc_off || !dst_off || !status || (n && (!d_enc || !d_dst))) return KC_ERR_BAD_ARG;
+    c->err.clear();
+    if (n == 0) return KC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    kc_status s;
+    if ((s = ensure(c, c->unit_off, (size_t)(n + 1) * 8)) || (s = ensure(c, c->stage_off, (size_t)(n + 1) * 8)) ||
+        (s = ensure(c, c->out_size, (size_t)n * 4)))
+        return s;
+    HIPCHK(c, hipMemcpyAsync(c->unit_off.p, enc_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->stage_off.p, dst_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    KcS2DecParams P;
+    P.enc = d_enc;
+    P.enc_off = (const uint64_t*)c->unit_off.p;
+    P.dst = d_dst;
+    P.dst_off = (const uint64_t*)c->stage_off.p;
+    P.status = (uint32_t*)c->out_size.p;
+    P.n_blocks = n;
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    kc_launch_s2_decode(P, st);
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipMemcpyAsync(status, c->out_size.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    float t = 0;
+    (void)hipEventElapsedTime(&t, c->ev[0], c->ev[1]);
+    c->last = kc_timings{t, t, 0, 0, 0};
+    return KC_OK;
+}
+
 kc_status kc_s2_encode_blocks_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
                                   uint64_t dst_cap, uint64_t* out_off) {
     return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 0, 0);

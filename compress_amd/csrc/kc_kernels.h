@@ -84,6 +84,15 @@ struct KcS2Params {
     int32_t framed;             // 1: emit s2.Writer chunks (type | len24 | masked CRC32C | body), s2/writer.go:414-451
 };
 void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st);
+struct KcS2DecParams {
+    const uint8_t* enc;         // encoded blocks (uvarint length + body each)
+    const uint64_t* enc_off;    // device, n+1
+    uint8_t* dst;
+    const uint64_t* dst_off;    // device, n+1: where each block decodes to, and how long it must be
+    uint32_t* status;           // device, n: 0 ok, else the first error met
+    uint32_t n_blocks;
+};
+void kc_launch_s2_decode(const KcS2DecParams& P, hipStream_t st);
 static inline size_t kc_s2_table_bytes() { return (size_t)4 << 14; }
 
 // ---- misc (kc_misc.hip) ----

@@ -46,6 +46,17 @@ class BlockEncoder:
                                                 int(with_stream_id)))
         return out_off
 
+    def DecodeBlocksDevice(self, d_enc_ptr, enc_off, d_dst_ptr, dst_off):
+        """N x s2.Decode on the device (verifier): returns uint32[n] status, 0 = block decoded to exactly its stated size."""
+        import numpy as np
+        ctx = self._ctx
+        enc_off = np.ascontiguousarray(enc_off, dtype=np.uint64)
+        dst_off = np.ascontiguousarray(dst_off, dtype=np.uint64)
+        n = len(enc_off) - 1
+        status = np.zeros(max(n, 1), dtype=np.uint32)
+        ctx.check(ctx.L.kc_s2_decode_blocks_dev(ctx.h, d_enc_ptr, enc_off.ctypes.data, n, d_dst_ptr, dst_off.ctypes.data, status.ctypes.data))
+        return status[:n]
+
     def Encode(self, dst, src):
         """s2.Encode(dst, src) (s2/encode.go:29): uvarint length + block body."""
         import numpy as np

@@ -14,6 +14,7 @@
  *   kc_s2_encode_block          == the s2.WriterCustomEncoder callback   s2/writer.go:1053-1064
  *   kc_s2_max_encoded_len       == s2.MaxEncodedLen                      s2/encode.go:389-418
  *   kc_s2_encode_stream_dev     == s2.Writer.EncodeBuffer framing        s2/writer.go:357-451
+ *   kc_s2_decode_blocks_dev     == N x s2.Decode (verifier)              s2/decode.go:58, decode_other.go:22
  *   kc_xxh64_units_dev          == xxhash.Digest over each unit          zstd/internal/xxhash/xxhash.go:27-230
  */
 #ifndef KCGPU_H
@@ -154,6 +155,12 @@ kc_status kc_s2_encode_blocks_dev(kc_ctx* ctx, const uint8_t* d_src, const uint6
  * stream; out_off[i] is the start of chunk i (out_off[0] == 10 with the identifier).  dst_cap >= sum(MaxEncodedLen+8)+10. */
 kc_status kc_s2_encode_stream_dev(kc_ctx* ctx, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
                                   uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off, int with_stream_id);
+/* s2.Decode (s2/decode.go:58 -> s2Decode, s2/decode_other.go:22) over N encoded blocks (uvarint length + body), for
+ * on-device round-trip verification: block i decodes to d_dst + dst_off[i] and must produce exactly dst_off[i+1]-dst_off[i]
+ * bytes.  enc_off / dst_off / status are host arrays; status[i] = 0 or the first error met in block i (corrupt input is
+ * reported, never written out of bounds). */
+kc_status kc_s2_decode_blocks_dev(kc_ctx* ctx, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n_blocks, uint8_t* d_dst,
+                                  const uint64_t* dst_off, uint32_t* status);
 /* Single-block form with the WriterCustomEncoder contract (s2/writer.go:1053-1064): no varint header;
  * returns bytes used, 0 = incompressible (store raw), <0 = fall back to the built-in encoder. */
 int64_t kc_s2_encode_block(kc_ctx* ctx, uint8_t* dst, uint64_t dst_cap, const uint8_t* src, uint64_t src_len);

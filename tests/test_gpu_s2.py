@@ -173,3 +173,46 @@ def test_s2_writer_chunking_and_bytes(oracle, kclib):
         s2.NewWriter(io.BytesIO(), s2.WriterBlockSize(1000))
     with pytest.raises(NotImplementedError):
         s2.NewWriter(io.BytesIO(), s2.WriterAddIndex())
+
+
+def test_s2_device_decoder_roundtrip_and_errors(oracle, kclib):
+    """N1 (GPU half) for S2: kc_s2_decode_blocks_dev decodes what kc_s2_encode_blocks_dev produced back to the source, on
+    the device, for every corpus kind and ragged block sizes; agrees with the oracle's s2.Decode on the oracle's own blocks;
+    corrupt blocks are reported per block without touching their neighbours."""
+    import torch
+    from compress_amd import s2
+    enc = s2.BlockEncoder()
+    for kind, bsz, nb in (("J", 65536, 256), ("T", 65536, 128), ("H", 65536, 32), ("M", 262144, 48), ("T", 1000, 200)):
+        buf = corpora.corpus(kind, nb, bsz)
+        off = np.arange(nb + 1, dtype=np.uint64) * bsz
+        d_src = torch.from_numpy(buf).cuda()
+        cap = nb * ((s2.MaxEncodedLen(bsz) + 15) & ~15) + 64
+        d_enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        eoff = enc.EncodeBlocksDevice(d_src.data_ptr(), off, d_enc.data_ptr(), cap)
+        d_out = torch.zeros(nb * bsz + 64, dtype=torch.uint8, device="cuda")
+        st = enc.DecodeBlocksDevice(d_enc.data_ptr(), eoff, d_out.data_ptr(), off)
+        assert not st.any(), (kind, np.nonzero(st)[0][:5], st[np.nonzero(st)[0][:5]])
+        assert torch.equal(d_out[:nb * bsz], d_src), kind
+    # ragged blocks incl. empty and tiny ones, encoded by the oracle
+    t = corpora.corpus("T", 4, 131072).tobytes()
+    blocks = [b"", t[:1], t[:5], t[:100], t[:70000], t[100:300000], b"\x00" * 5000, t[:65536], (t[:37] * 400)]
+    encs = [oracle.s2_encode(b) for b in blocks]
+    eoff = np.zeros(len(blocks) + 1, dtype=np.uint64); eoff[1:] = np.cumsum([len(e) for e in encs])
+    doff = np.zeros(len(blocks) + 1, dtype=np.uint64); doff[1:] = np.cumsum([len(b) for b in blocks])
+    d_enc = torch.from_numpy(np.frombuffer(b"".join(encs), dtype=np.uint8).copy()).cuda()
+    d_out = torch.zeros(int(doff[-1]) + 64, dtype=torch.uint8, device="cuda")
+    st = enc.DecodeBlocksDevice(d_enc.data_ptr(), eoff, d_out.data_ptr(), doff)
+    assert not st.any(), st
+    assert d_out[:int(doff[-1])].cpu().numpy().tobytes() == b"".join(blocks)
+    # corruption: truncated block, wrong stated size, zero offset; neighbours still decode
+    bad = [encs[3], encs[4][:-3], encs[5], bytes([encs[6][0] ^ 1]) + encs[6][1:], encs[7]]
+    want = [len(blocks[3]), len(blocks[4]), len(blocks[5]), len(blocks[6]), len(blocks[7])]
+    eoff = np.zeros(6, dtype=np.uint64); eoff[1:] = np.cumsum([len(e) for e in bad])
+    doff = np.zeros(6, dtype=np.uint64); doff[1:] = np.cumsum(want)
+    d_enc = torch.from_numpy(np.frombuffer(b"".join(bad), dtype=np.uint8).copy()).cuda()
+    d_out = torch.zeros(int(doff[-1]) + 64, dtype=torch.uint8, device="cuda")
+    st = enc.DecodeBlocksDevice(d_enc.data_ptr(), eoff, d_out.data_ptr(), doff)
+    assert st[0] == 0 and st[2] == 0 and st[4] == 0 and st[1] != 0 and st[3] != 0, st
+    out = d_out.cpu().numpy()
+    assert out[int(doff[2]):int(doff[3])].tobytes() == blocks[5] and out[int(doff[4]):int(doff[5])].tobytes() == blocks[7]
+    enc.Close()
