@@ -925,6 +925,53 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     return KC_OK;
 }
 
+// zstd frame decode over N units on the device (verifier): decode, then XXH64 of the output against the stored checksum.
+kc_status kc_zstd_decode_units_dev(kc_ctx* c, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n, uint8_t* d_dst,
+                                   const uint64_t* dst_off, uint32_t* status) {
+    if (!c || !enc_off || !dst_off || !status || (n && (!d_enc || !d_dst))) return KC_ERR_BAD_ARG;
+    c->err.clear();
+    if (n == 0) return KC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    kc_status s;
+    const uint32_t lit_stride = (128u << 10) + 64u;
+    if ((s = ensure(c, c->unit_off, (size_t)(n + 1) * 8)) || (s = ensure(c, c->stage_off, (size_t)(n + 1) * 8)) ||
+        (s = ensure(c, c->out_size, (size_t)n * 4)) || (s = ensure(c, c->redo, (size_t)n * 4)) || (s = ensure(c, c->popmask, (size_t)n * 4)) ||
+        (s = ensure(c, c->xxh, (size_t)n * 8)) || (s = ensure(c, c->lits, (size_t)n * lit_stride)))
+        return s;
+    HIPCHK(c, hipMemcpyAsync(c->unit_off.p, enc_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->stage_off.p, dst_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    KcZstdDecParams P;
+    P.enc = d_enc;
+    P.enc_off = (const uint64_t*)c->unit_off.p;
+    P.dst = d_dst;
+    P.dst_off = (const uint64_t*)c->stage_off.p;
+    P.lits = (uint8_t*)c->lits.p;
+    P.lit_stride = lit_stride;
+    P.status = (uint32_t*)c->out_size.p;
+    P.crc_stored = (uint32_t*)c->redo.p;
+    P.has_crc = (uint32_t*)c->popmask.p;
+    P.n_units = n;
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    kc_launch_zstd_decode(P, st);
+    kc_launch_xxh64(d_dst, (const uint64_t*)c->stage_off.p, n, (uint64_t*)c->xxh.p, st);
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    std::vector<uint32_t> stored(n), has(n);
+    std::vector<uint64_t> hashes(n);
+    HIPCHK(c, hipMemcpyAsync(status, c->out_size.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(stored.data(), c->redo.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(has.data(), c->popmask.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hashes.data(), c->xxh.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    for (uint32_t i = 0; i < n; i++)
+        if (status[i] == 0 && has[i] && (uint32_t)hashes[i] != stored[i]) status[i] = 30;  // checksum mismatch (framedec.go:310-325)
+    float t = 0;
+    (void)hipEventElapsedTime(&t, c->ev[0], c->ev[1]);
+    c->last = kc_timings{t, t, 0, 0, 0};
+    return KC_OK;
+}
+
 // s2.Decode over N blocks on the device (verifier).  status[i] (host) receives 0 or the first error of block i.
 kc_status kc_s2_decode_blocks_dev(kc_ctx* c, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n, uint8_t* d_dst,
                                   const uint64_t* dst_off, uint32_t* status) {

@@ -93,6 +93,19 @@ struct KcS2DecParams {
     uint32_t n_blocks;
 };
 void kc_launch_s2_decode(const KcS2DecParams& P, hipStream_t st);
+struct KcZstdDecParams {
+    const uint8_t* enc;         // one frame per unit
+    const uint64_t* enc_off;    // device, n+1
+    uint8_t* dst;
+    const uint64_t* dst_off;    // device, n+1: where each frame decodes to, and how long its content must be
+    uint8_t* lits;              // device scratch: lit_stride bytes per unit (Huffman-decoded literals of the current block)
+    uint32_t lit_stride;
+    uint32_t* status;           // device, n: 0 ok, else the first error met
+    uint32_t* crc_stored;       // device, n: the frame's stored XXH64 low word
+    uint32_t* has_crc;          // device, n
+    uint32_t n_units;
+};
+void kc_launch_zstd_decode(const KcZstdDecParams& P, hipStream_t st);
 static inline size_t kc_s2_table_bytes() { return (size_t)4 << 14; }
 
 // ---- misc (kc_misc.hip) ----

@@ -14,6 +14,7 @@
  *   kc_s2_encode_block          == the s2.WriterCustomEncoder callback   s2/writer.go:1053-1064
  *   kc_s2_max_encoded_len       == s2.MaxEncodedLen                      s2/encode.go:389-418
  *   kc_s2_encode_stream_dev     == s2.Writer.EncodeBuffer framing        s2/writer.go:357-451
+ *   kc_zstd_decode_units_dev    == N x Decoder.DecodeAll (verifier)       zstd/framedec.go, blockdec.go, seqdec_generic.go
  *   kc_s2_decode_blocks_dev     == N x s2.Decode (verifier)              s2/decode.go:58, decode_other.go:22
  *   kc_xxh64_units_dev          == xxhash.Digest over each unit          zstd/internal/xxhash/xxhash.go:27-230
  */
@@ -161,6 +162,12 @@ kc_status kc_s2_encode_stream_dev(kc_ctx* ctx, const uint8_t* d_src, const uint6
  * reported, never written out of bounds). */
 kc_status kc_s2_decode_blocks_dev(kc_ctx* ctx, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n_blocks, uint8_t* d_dst,
                                   const uint64_t* dst_off, uint32_t* status);
+/* zstd frame decoder (zstd/framedec.go:65-330, blockdec.go:227-690, seqdec_generic.go) over N units, one frame each, for
+ * on-device round-trip verification: unit i decodes to d_dst + dst_off[i] and must produce exactly dst_off[i+1]-dst_off[i]
+ * bytes; the frame checksum, if present, is checked against XXH64 of the decoded bytes (status 30 on mismatch).  All block,
+ * literal and sequence modes; no dictionaries (status 20).  enc_off / dst_off / status are host arrays. */
+kc_status kc_zstd_decode_units_dev(kc_ctx* ctx, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n_units, uint8_t* d_dst,
+                                   const uint64_t* dst_off, uint32_t* status);
 /* Single-block form with the WriterCustomEncoder contract (s2/writer.go:1053-1064): no varint header;
  * returns bytes used, 0 = incompressible (store raw), <0 = fall back to the built-in encoder. */
 int64_t kc_s2_encode_block(kc_ctx* ctx, uint8_t* dst, uint64_t dst_cap, const uint8_t* src, uint64_t src_len);

@@ -294,3 +294,70 @@ def test_streams_bit_exact(oracle, kclib, level):
     with pytest.raises(Exception):  # dictionaries: the caller must fall back
         zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderDictRaw(1, t[:1000])).EncodeStreams(ubuf, off)
     enc.Close(); e2.Close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_device_decoder_roundtrip(oracle, kclib, level):
+    """N1 (GPU half) for zstd: kc_zstd_decode_units_dev decodes the frames the device encoder produced back to the source,
+    on the device, checksum included — every corpus kind, edge units, adversarial mixes (raw / RLE / compressed blocks,
+    raw / RLE / 1-stream / 4-stream / treeless literals, predefined / RLE / FSE / repeat sequence tables)."""
+    torch = _torch()
+    enc = _enc(level)
+    units = corpora.edge_units() + corpora.stress_units(seed=3, n=24)
+    for k in "THJM":
+        b = corpora.corpus(k, 6, 131072, first_unit=9)
+        units += [b[i * 131072:(i + 1) * 131072].tobytes() for i in range(6)]
+    ubuf, off = corpora.pack_units(units)
+    n = len(units)
+    d_src = torch.from_numpy(ubuf).cuda()
+    cap = sum(((enc.MaxEncodedSize(len(u)) + 15) & ~15) for u in units) + 64
+    d_enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    eoff = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_enc.data_ptr(), cap)
+    d_out = torch.zeros(len(ubuf) + 64, dtype=torch.uint8, device="cuda")
+    st = enc.DecodeUnitsDevice(d_enc.data_ptr(), eoff, d_out.data_ptr(), off)
+    bad = np.nonzero(st)[0]
+    assert len(bad) == 0, [(int(i), int(st[i]), len(units[i])) for i in bad[:8]]
+    assert torch.equal(d_out[:len(ubuf)], d_src)
+    # corruption is detected per unit: a flipped payload byte (checksum or format error), a truncated frame, a wrong size
+    frames = d_enc[:int(eoff[n])].cpu().numpy()
+    pick = [i for i in range(n) if len(units[i]) >= 65536][:3]
+    parts, sizes = [], []
+    for j, i in enumerate(pick):
+        f = frames[int(eoff[i]):int(eoff[i + 1])].copy()
+        if j == 0:
+            f[len(f) // 2] ^= 0x10
+        elif j == 1:
+            f = f[:-5]
+        parts.append(f)
+        sizes.append(len(units[i]) + (1 if j == 2 else 0))
+    e2 = np.zeros(len(pick) + 1, dtype=np.uint64); e2[1:] = np.cumsum([len(p) for p in parts])
+    d2 = np.zeros(len(pick) + 1, dtype=np.uint64); d2[1:] = np.cumsum(sizes)
+    d_bad = torch.from_numpy(np.concatenate(parts)).cuda()
+    d_o2 = torch.zeros(int(d2[-1]) + 64, dtype=torch.uint8, device="cuda")
+    st2 = enc.DecodeUnitsDevice(d_bad.data_ptr(), e2, d_o2.data_ptr(), d2)
+    assert all(int(x) != 0 for x in st2), st2
+    enc.Close()
+
+
+def test_device_decoder_on_foreign_frames(oracle, kclib):
+    """Frames the device encoder did not write: streaming frames (no content size, window descriptor, trailing empty block)
+    from the oracle, and no-checksum / multi-block frames."""
+    torch = _torch()
+    enc = _enc(1)
+    t = corpora.corpus("T", 5, 131072, first_unit=70).tobytes()
+    srcs, frames = [], []
+    for lvl, kw in ((1, {}), (2, {}), (3, {}), (1, {"crc": False}), (2, {"no_entropy": True})):
+        o = oracle.ZstdOracle(level=lvl, **kw)
+        for n in (0, 1, 1000, 65536, 131072, 300000):
+            srcs.append(t[:n]); frames.append(o.encode_stream(t[:n]))
+            if n:
+                srcs.append(t[7:7 + n]); frames.append(o.encode_all(t[7:7 + n]))
+    eoff = np.zeros(len(frames) + 1, dtype=np.uint64); eoff[1:] = np.cumsum([len(f) for f in frames])
+    doff = np.zeros(len(frames) + 1, dtype=np.uint64); doff[1:] = np.cumsum([len(s) for s in srcs])
+    d_enc = torch.from_numpy(np.frombuffer(b"".join(frames), dtype=np.uint8).copy()).cuda()
+    d_out = torch.zeros(int(doff[-1]) + 64, dtype=torch.uint8, device="cuda")
+    st = enc.DecodeUnitsDevice(d_enc.data_ptr(), eoff, d_out.data_ptr(), doff)
+    bad = np.nonzero(st)[0]
+    assert len(bad) == 0, [(int(i), int(st[i]), len(srcs[i])) for i in bad[:8]]
+    assert d_out[:int(doff[-1])].cpu().numpy().tobytes() == b"".join(srcs)
+    enc.Close()
