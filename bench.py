@@ -39,6 +39,8 @@ def main():
                     help="two contexts on two streams: the match finder of step i+1 runs under the entropy stage of step i. "
                          "Measured on MI355X: 184.0 vs 184.7 ms/step — the two kernels only trade the same HBM/issue slots "
                          "(match 145 -> 170 ms, entropy 36 -> 112 ms when co-resident), so the default is one context.")
+    ap.add_argument("--no-device-verify", action="store_true",
+                    help="skip the on-device round trip (kc_zstd_decode_units_dev over ALL frames + compare with the input)")
     ap.add_argument("--cpu-sample-units", type=int, default=16384)
     ap.add_argument("--cpu-threads", type=int, default=0, help="override the CPU baseline thread count")
     args = ap.parse_args()
@@ -185,6 +187,18 @@ def main():
         got = d_dst[:int(out_off[sample])].cpu().numpy()
         parity = bool(np.array_equal(got, ref) and np.array_equal(out_off[:sample + 1], ref_off))
 
+    # ---- on-device round trip of EVERY frame of this rank (outside the timed region): decode + XXH64 check + compare ----
+    verified = None
+    verify_ms = None
+    if not args.no_device_verify:
+        d_back = torch.empty(in_bytes + 64, dtype=torch.uint8, device="cuda")
+        t0 = time.perf_counter()
+        st = enc.DecodeUnitsDevice(d_dst.data_ptr(), out_off, d_back.data_ptr(), unit_off)
+        torch.cuda.synchronize()
+        verify_ms = (time.perf_counter() - t0) * 1e3
+        verified = bool((not st.any()) and torch.equal(d_back[:in_bytes], d_src))
+        del d_back
+
     if rank == 0:
         line = {
             "metric": "encode MB/s (input) + ratio, zstd SpeedFastest 128KiB blocks, 1/2/4/8 GPU",
@@ -202,6 +216,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "bit_exact_vs_oracle_on_sample": parity,
+            "device_roundtrip_all_frames": verified,
+            "device_roundtrip_ms": None if verify_ms is None else round(verify_ms, 1),
             "redo_units": tm["redo_units"],
             "host": {"gen_s": round(gen_s, 2), "nproc": os.cpu_count()},
         }
