@@ -117,9 +117,81 @@ def _unsupported(name):
 WriterBetterCompression = _unsupported("WriterBetterCompression")
 WriterBestCompression = _unsupported("WriterBestCompression")
 WriterSnappyCompat = _unsupported("WriterSnappyCompat")
-WriterAddIndex = _unsupported("WriterAddIndex")
 WriterPadding = _unsupported("WriterPadding")
 WriterUncompressed = _unsupported("WriterUncompressed")
+
+
+def WriterAddIndex():
+    """s2.WriterAddIndex (writer.go:921): append the seek index to the stream on Close."""
+    return lambda w: setattr(w, "appendIndex", True)
+
+
+class Index:
+    """The writer side of s2.Index (s2/index.go:17-236): add / reduce / appendTo."""
+    MAX_ENTRIES, MIN_DIST = 1 << 16, 1 << 20
+
+    def __init__(self, max_block):
+        self.est = int(max_block)
+        self.info = []  # [compressedOffset, uncompressedOffset]
+
+    def add(self, comp, unc):
+        if self.info:
+            latest = self.info[-1]
+            if latest[1] == unc:
+                latest[0] = comp
+                return
+            if latest[1] > unc or latest[0] > comp:
+                raise ValueError("internal error: earlier offset received")
+            if latest[1] + self.MIN_DIST > unc:
+                return
+        self.info.append([comp, unc])
+
+    def _reduce(self):
+        if len(self.info) < self.MAX_ENTRIES and self.est >= self.MIN_DIST:
+            return
+        remove_n = (len(self.info) + 1) // self.MAX_ENTRIES
+        while self.est * (remove_n + 1) < self.MIN_DIST and len(self.info) // (remove_n + 1) > 1000:
+            remove_n += 1
+        self.info = self.info[::remove_n + 1]
+        self.est += self.est * remove_n
+
+    @staticmethod
+    def _varint(x):
+        ux = (x << 1) ^ (x >> 63) if x >= 0 else ((~x) << 1) | 1
+        ux &= (1 << 64) - 1
+        out = bytearray()
+        while ux >= 0x80:
+            out.append((ux & 0x7F) | 0x80)
+            ux >>= 7
+        out.append(ux)
+        return bytes(out)
+
+    def append_to(self, uncomp_total, comp_total):
+        self._reduce()
+        b = bytearray(b"\x99\x00\x00\x00s2idx\x00")
+        for v in (uncomp_total, comp_total, self.est, len(self.info)):
+            b += self._varint(v)
+        has_unc = 0
+        for i, (_, u) in enumerate(self.info):
+            if (i == 0 and u != 0) or (i > 0 and u != self.info[i - 1][1] + self.est):
+                has_unc = 1
+                break
+        b.append(has_unc)
+        if has_unc:
+            for i, (_, u) in enumerate(self.info):
+                b += self._varint(u - (self.info[i - 1][1] + self.est) if i else u)
+        c_predict = self.est // 2
+        for i, (c, _) in enumerate(self.info):
+            c_off = c
+            if i:
+                c_off -= self.info[i - 1][0] + c_predict
+                c_predict += c_off // 2 if c_off >= 0 else -((-c_off) // 2)  # Go integer division truncates toward zero
+            b += self._varint(c_off)
+        b += (len(b) + 4 + 6).to_bytes(4, "little")
+        b += b"\x00xdi2s"
+        n = len(b) - 4
+        b[1:4] = bytes([n & 0xFF, (n >> 8) & 0xFF, (n >> 16) & 0xFF])
+        return bytes(b)
 
 
 class Writer:
@@ -131,6 +203,7 @@ class Writer:
         self.blockSize = _DEFAULT_BLOCK
         self.concurrency = 1
         self.flushOnWrite = False
+        self.appendIndex = False
         for o in opts:
             o(self)
         self._enc = BlockEncoder(device, stream)
@@ -147,6 +220,8 @@ class Writer:
         self._closed = False
         self.written = 0
         self.uncompWritten = 0
+        self._index = Index(self.blockSize)
+        self._flushedUncomp = 0  # uncompressed start offset of the next chunk to be written out
 
     # -- chunk cutting, exactly as writer.go --
     def _write(self, p):  # writer.go:483 write(): everything in p becomes chunks now, the last one may be short
@@ -234,24 +309,39 @@ class Writer:
         self._drain()
 
     def Close(self):
+        """writer.go:787: Flush, then the index chunk if WriterAddIndex was given."""
+        self._close_index(self.appendIndex)
+
+    def CloseIndex(self):
+        """writer.go:794: Close and return the index (it is also appended to the stream only with WriterAddIndex)."""
+        return self._close_index(True)
+
+    def _close_index(self, want):
         if self._closed:
-            return
+            return None
         self.Flush()
         self._closed = True
+        index = None
+        if want:
+            index = self._index.append_to(self.uncompWritten, self.written)
+            if self.appendIndex:
+                self.writer.write(index)
+                self.written += len(index)
+        return index
 
     # -- device batch --
     def _drain(self):
         import numpy as np
         import torch
-        out = []
+        out = []  # (bytes, uncompressed start offset) per write to the underlying writer, in stream order
         i = 0
         q = self._queue
         while i < len(q):
             if q[i][0] == "r":
                 if not self._wroteHeader:  # the stream identifier precedes the first output of any kind
-                    out.append(_MAGIC)
+                    out.append((_MAGIC, self._flushedUncomp))
                     self._wroteHeader = True
-                out.append(q[i][1])
+                out.append((q[i][1], self._flushedUncomp))
                 i += 1
                 continue
             j = i
@@ -264,13 +354,20 @@ class Writer:
             d_src = torch.from_numpy(src.copy()).cuda(self._device)
             cap = sum(((MaxEncodedLen(len(c)) + 8 + 15) & ~15) for c in chunks) + 64
             d_dst = torch.empty(cap, dtype=torch.uint8, device=d_src.device)
-            oo = self._enc.EncodeStreamDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap, with_stream_id=not self._wroteHeader)
+            with_id = not self._wroteHeader
+            oo = self._enc.EncodeStreamDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap, with_stream_id=with_id)
             self._wroteHeader = True
-            out.append(d_dst[:int(oo[-1])].cpu().numpy().tobytes())
+            blob = d_dst[:int(oo[-1])].cpu().numpy().tobytes()
+            if with_id:
+                out.append((blob[:int(oo[0])], self._flushedUncomp))
+            for k, c in enumerate(chunks):
+                out.append((blob[int(oo[k]):int(oo[k + 1])], self._flushedUncomp))
+                self._flushedUncomp += len(c)
             i = j
         self._queue = []
         self._queued = 0
-        for b in out:
+        for b, start in out:  # the writer goroutine of writer.go:146-170: index entry, then the bytes
+            self._index.add(self.written, start)
             self.writer.write(b)
             self.written += len(b)
 

@@ -247,6 +247,20 @@ int64_t maxEncodedSize(const kco_zstd_opts* o, int64_t size) {
 
 extern "C" {
 
+// s2.Index: reset(block_size); add(comp[i], uncomp[i]) for each output write; appendTo(nil, uncomp_total, comp_total).
+int64_t kco_s2_index(int32_t block_size, const int64_t* comp, const int64_t* uncomp, uint64_t n, int64_t uncomp_total, int64_t comp_total,
+                     uint8_t* dst, uint64_t cap) {
+    s2::Index ix;
+    ix.reset(block_size);
+    for (uint64_t i = 0; i < n; i++)
+        if (ix.add(comp[i], uncomp[i]) != 0) return -1;
+    Bytes out;
+    ix.appendTo(&out, uncomp_total, comp_total);
+    if (out.size() > cap) return -2;
+    memcpy(dst, out.data(), out.size());
+    return (int64_t)out.size();
+}
+
 // NewWriter(w).Write(src[...]); Flush at each cuts[i]; Close() on a persistent encoder state.  Returns bytes or -1 / -2.
 int64_t kco_zstd_encode_stream(void* e, const uint8_t* src, uint64_t n, const uint64_t* cuts, uint64_t n_cuts, uint8_t* dst, uint64_t cap) {
     Bytes out;

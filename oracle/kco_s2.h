@@ -389,5 +389,81 @@ static inline int64_t DecodeStream(uint8_t* dst, uint64_t cap, const uint8_t* sr
     return s == n ? (int64_t)d : -1;
 }
 
+// s2/index.go:17-236: Index.add / reduce / appendTo (the writer side of the seek index).
+struct Index {
+    struct Info { int64_t compressedOffset, uncompressedOffset; };
+    std::vector<Info> info;
+    int64_t estBlockUncomp = 0;
+    static constexpr int64_t maxIndexEntries = 1 << 16, minIndexDist = 1 << 20;
+    void reset(int maxBlock) { estBlockUncomp = maxBlock; info.clear(); }  // :35
+    int add(int64_t compressedOffset, int64_t uncompressedOffset) {      // :57
+        if (!info.empty()) {
+            Info& latest = info.back();
+            if (latest.uncompressedOffset == uncompressedOffset) { latest.compressedOffset = compressedOffset; return 0; }
+            if (latest.uncompressedOffset > uncompressedOffset) return -1;
+            if (latest.compressedOffset > compressedOffset) return -1;
+            if (latest.uncompressedOffset + minIndexDist > uncompressedOffset) return 0;
+        }
+        info.push_back(Info{compressedOffset, uncompressedOffset});
+        return 0;
+    }
+    void reduce() {  // :130
+        if ((int64_t)info.size() < maxIndexEntries && estBlockUncomp >= minIndexDist) return;
+        int64_t removeN = ((int64_t)info.size() + 1) / maxIndexEntries;
+        while (estBlockUncomp * (removeN + 1) < minIndexDist && (int64_t)info.size() / (removeN + 1) > 1000) removeN++;
+        size_t j = 0;
+        for (size_t idx = 0; idx < info.size(); idx++) {
+            info[j++] = info[idx];
+            idx += (size_t)removeN;
+        }
+        info.resize(j);
+        estBlockUncomp += estBlockUncomp * removeN;
+    }
+    static void putVarint(Bytes* b, int64_t x) {  // encoding/binary PutVarint: zig-zag then uvarint
+        uint64_t ux = (uint64_t)x << 1;
+        if (x < 0) ux = ~ux;
+        while (ux >= 0x80) { b->push_back((uint8_t)ux | 0x80); ux >>= 7; }
+        b->push_back((uint8_t)ux);
+    }
+    void appendTo(Bytes* b, int64_t uncompTotal, int64_t compTotal) {  // :154
+        reduce();
+        const size_t initSize = b->size();
+        b->push_back(0x99); b->push_back(0); b->push_back(0); b->push_back(0);  // ChunkTypeIndex + length placeholder
+        const char hdr[6] = {'s', '2', 'i', 'd', 'x', 0};
+        b->insert(b->end(), hdr, hdr + 6);
+        putVarint(b, uncompTotal);
+        putVarint(b, compTotal);
+        putVarint(b, estBlockUncomp);
+        putVarint(b, (int64_t)info.size());
+        uint8_t hasUncompressed = 0;
+        for (size_t idx = 0; idx < info.size(); idx++) {
+            if (idx == 0) { if (info[idx].uncompressedOffset != 0) { hasUncompressed = 1; break; } continue; }
+            if (info[idx].uncompressedOffset != info[idx - 1].uncompressedOffset + estBlockUncomp) { hasUncompressed = 1; break; }
+        }
+        b->push_back(hasUncompressed);
+        if (hasUncompressed)
+            for (size_t idx = 0; idx < info.size(); idx++) {
+                int64_t uOff = info[idx].uncompressedOffset;
+                if (idx > 0) uOff -= info[idx - 1].uncompressedOffset + estBlockUncomp;
+                putVarint(b, uOff);
+            }
+        int64_t cPredict = estBlockUncomp / 2;
+        for (size_t idx = 0; idx < info.size(); idx++) {
+            int64_t cOff = info[idx].compressedOffset;
+            if (idx > 0) {
+                cOff -= info[idx - 1].compressedOffset + cPredict;
+                cPredict += cOff / 2;
+            }
+            putVarint(b, cOff);
+        }
+        const uint32_t total = (uint32_t)(b->size() - initSize + 4 + 6);
+        for (int k = 0; k < 4; k++) b->push_back((uint8_t)(total >> (8 * k)));
+        const char trl[6] = {0, 'x', 'd', 'i', '2', 's'};
+        b->insert(b->end(), trl, trl + 6);
+        const size_t chunkLen = b->size() - initSize - 4;
+        (*b)[initSize + 1] = (uint8_t)chunkLen; (*b)[initSize + 2] = (uint8_t)(chunkLen >> 8); (*b)[initSize + 3] = (uint8_t)(chunkLen >> 16);
+    }
+};
+
 }  // namespace s2
 }  // namespace kco

@@ -302,6 +302,22 @@ def s2_encode_stream(src, blk_off, with_stream_id=True):
     return dst[:r], oo
 
 
+def s2_index(block_size, adds, uncomp_total, comp_total) -> bytes:
+    """s2.Index after add(comp, uncomp) for each pair in `adds`, serialised by appendTo (s2/index.go:57-236)."""
+    import numpy as np
+    L = lib()
+    L.kco_s2_index.restype = C.c_int64
+    L.kco_s2_index.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_char_p, C.c_uint64]
+    comp = np.ascontiguousarray([a[0] for a in adds], dtype=np.int64)
+    unc = np.ascontiguousarray([a[1] for a in adds], dtype=np.int64)
+    cap = 64 + 20 * (len(adds) + 4)
+    buf = C.create_string_buffer(cap)
+    r = L.kco_s2_index(block_size, comp.ctypes.data, unc.ctypes.data, len(adds), uncomp_total, comp_total, buf, cap)
+    if r < 0:
+        raise RuntimeError("s2 index failed %d" % r)
+    return buf.raw[:r]
+
+
 def s2_decode_stream(enc: bytes, cap: int) -> bytes:
     buf = C.create_string_buffer(max(cap, 1))
     r = lib().kco_s2_decode_stream(enc, len(enc), buf, cap)

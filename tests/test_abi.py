@@ -130,3 +130,26 @@ def test_full_format_dictionary_loader_matches_oracle(oracle):
     # a raw dictionary afterwards resets offsets and drops the literal table (last option wins, like o.dict = ...)
     e = zstd.NewWriter(None, zstd.WithEncoderDict(blob), zstd.WithEncoderDictRaw(7, b"x" * 100))
     assert (list(e.o.dict_offsets), e.o.dict_huf_len, e.o.dict_id) == ([1, 4, 8], 0, 7)
+
+
+def test_s2_index_builder_matches_oracle(oracle):
+    """s2.Index add / reduce / appendTo (s2/index.go:57-236): the product's writer-side index (compress_amd/s2.py) against the
+    oracle's restatement on random write sequences, incl. skippable blocks, sub-MiB blocks and > 65536 entries (reduce)."""
+    import random
+    from compress_amd import s2
+    rnd = random.Random(5)
+    for trial in range(30):
+        bs = rnd.choice([4096, 65536, 1 << 20, 4 << 20])
+        n = rnd.choice([0, 1, 5, 300, 5000, 70000, 140000])
+        adds, c, u = [(0, 0)], 10, 0
+        for _ in range(n):
+            if rnd.random() < 0.02:
+                adds.append((c, u)); c += rnd.randint(5, 200)
+            adds.append((c, u)); c += rnd.randint(20, bs); u += rnd.randint(1, bs) if rnd.random() < 0.3 else bs
+        ix = s2.Index(bs)
+        for a in adds:
+            ix.add(*a)
+        assert ix.append_to(u, c) == oracle.s2_index(bs, adds, u, c), (trial, bs, n)
+    ix = s2.Index(1 << 20)
+    b = ix.append_to(0, 0)
+    assert b[:10] == b"\x99" + (len(b) - 4).to_bytes(3, "little") + b"s2idx\x00" and b[-6:] == b"\x00xdi2s"

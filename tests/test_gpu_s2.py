@@ -172,7 +172,7 @@ def test_s2_writer_chunking_and_bytes(oracle, kclib):
     with pytest.raises(ValueError):
         s2.NewWriter(io.BytesIO(), s2.WriterBlockSize(1000))
     with pytest.raises(NotImplementedError):
-        s2.NewWriter(io.BytesIO(), s2.WriterAddIndex())
+        s2.NewWriter(io.BytesIO(), s2.WriterBetterCompression())
 
 
 def test_s2_device_decoder_roundtrip_and_errors(oracle, kclib):
@@ -216,3 +216,43 @@ def test_s2_device_decoder_roundtrip_and_errors(oracle, kclib):
     out = d_out.cpu().numpy()
     assert out[int(doff[2]):int(doff[3])].tobytes() == blocks[5] and out[int(doff[4]):int(doff[5])].tobytes() == blocks[7]
     enc.Close()
+
+
+def test_s2_writer_index(oracle, kclib):
+    """WriterAddIndex / CloseIndex: the index chunk appended to the stream equals the oracle's Index fed with the same
+    (compressed offset, uncompressed offset) pairs; the stream (index chunk skipped) still decodes."""
+    import io
+    from compress_amd import s2
+    data = corpora.corpus("J", 40, 131072).tobytes()   # 5 MiB: several 1 MiB index steps with 256 KiB blocks
+    sink = io.BytesIO()
+    w = s2.NewWriter(sink, s2.WriterBlockSize(256 << 10), s2.WriterAddIndex())
+    w.Write(data[:3000000])
+    w.AddSkippableBlock(0x81, b"meta")
+    w.Write(data[3000000:])
+    idx = w.CloseIndex()
+    got = sink.getvalue()
+    assert got.endswith(idx) and idx[:1] == b"\x99"
+    body = got[:-len(idx)]
+    # rebuild the add() sequence from the stream itself: every chunk start with the uncompressed offset it begins at
+    adds, p, u = [], 0, 0
+    while p < len(body):
+        t, cl = body[p], int.from_bytes(body[p + 1:p + 4], "little")
+        adds.append((p, u))
+        if t == 0x00:
+            n, sh = 0, 0
+            q = p + 8
+            while True:
+                bb = body[q]; q += 1
+                n |= (bb & 0x7F) << sh; sh += 7
+                if not bb & 0x80:
+                    break
+            u += n
+        elif t == 0x01:
+            u += cl - 4
+        p += 4 + cl
+    assert u == len(data)
+    assert idx == oracle.s2_index(256 << 10, adds, len(data), len(body))
+    assert oracle.s2_decode_stream(got, len(data) + 16) == data
+    # without WriterAddIndex the index is returned but not written
+    sink2 = io.BytesIO(); w2 = s2.NewWriter(sink2); w2.Write(data[:100000]); idx2 = w2.CloseIndex()
+    assert idx2[:1] == b"\x99" and idx2 not in sink2.getvalue()
