@@ -327,3 +327,65 @@ def test_stream_restatement_structure_and_roundtrip(oracle, level):
         assert p + 4 == len(fr) and lasts.count(1) == 1
         ends_on_cut = (n % bs == 0 and not cuts) or (cuts and cuts[-1] >= n)
         assert (sizes[-1] == (0, 0)) == bool(ends_on_cut), (n, cuts, sizes)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_oracle_randomized_roundtrips(oracle, seed):
+    """Randomised oracle configurations (level, CRC, entropy switches, single segment, small windows, raw dictionaries,
+    EncodeAll vs Write/Flush/Close streams) on spliced inputs: every frame must decode to its input with libzstd AND with
+    the in-repo decoder (oracle_lib.zstd_decompress cross-checks the two)."""
+    import random
+    import corpora
+    rnd = random.Random(seed)
+    text = corpora.corpus("T", 4, 131072, first_unit=300).tobytes()
+    js = corpora.corpus("J", 2, 131072, first_unit=30).tobytes()
+
+    def make(n):
+        parts, tot = [], 0
+        while tot < n:
+            k = rnd.randint(0, 5)
+            if k == 0:
+                p = bytes(rnd.getrandbits(8) for _ in range(rnd.choice([1, 5, 40, 300, 3000])))
+            elif k == 1:
+                ln = rnd.randint(4, 4000); o = rnd.randint(0, len(text) - ln); p = text[o:o + ln]
+            elif k == 2:
+                p = bytes([rnd.getrandbits(8)]) * rnd.choice([3, 70, 1000, 70000])
+            elif k == 3:
+                ln = rnd.randint(4, 3000); o = rnd.randint(0, len(js) - ln); p = js[o:o + ln]
+            elif k == 4 and parts:
+                p = parts[rnd.randrange(len(parts))]
+            else:
+                p = bytes(rnd.choice(b"abcdefgh ") for _ in range(rnd.choice([10, 200, 5000])))
+            parts.append(p); tot += len(p)
+        return b"".join(parts)[:n]
+
+    for it in range(40):
+        lvl = rnd.choice([1, 2, 3])
+        n = rnd.choice([0, 1, 9, 100, 5000, 65535, 65536, 65537, 131072, 200000])
+        kw = dict(level=lvl, crc=rnd.random() < 0.7, no_entropy=rnd.random() < 0.15, full_zero=rnd.random() < 0.8)
+        if rnd.random() < 0.3:
+            kw["all_lit_entropy"] = rnd.random() < 0.5
+        if rnd.random() < 0.3:
+            kw["single"] = rnd.random() < 0.5
+        if rnd.random() < 0.25:
+            ws = 1 << rnd.choice([10, 12, 15, 17, 20])
+            kw["window_size"] = ws
+            kw["block_size"] = min(ws, (1 << 16) if lvl == 1 else (128 << 10))
+        d = make(n)
+        dct = None
+        if rnd.random() < 0.3 and n > 0:
+            dct = make(rnd.choice([100, 5000, 65536]))
+            kw["dict_id"] = rnd.choice([0, 0, 7])
+            kw["dict_content"] = dct
+        e = oracle.ZstdOracle(**kw)
+        stream = dct is None and rnd.random() < 0.4
+        cuts = tuple(sorted(rnd.sample(range(n + 1), min(n + 1, rnd.choice([0, 0, 1, 3])))))
+        fr = e.encode_stream(d, cuts) if stream else e.encode_all(d)
+        if not fr:
+            assert n == 0 and not kw["full_zero"]
+            continue
+        if dct is not None and kw["dict_id"] != 0:
+            got = oracle.zstd_decode(fr, n + 16, dict_content=dct)  # libzstd only takes raw dictionaries as ID 0
+        else:
+            got = oracle.zstd_decompress(fr, n + 16, dict_content=dct)
+        assert got == d, (it, sorted(kw), n, stream)
