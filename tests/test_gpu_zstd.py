@@ -361,3 +361,56 @@ def test_device_decoder_on_foreign_frames(oracle, kclib):
     assert len(bad) == 0, [(int(i), int(st[i]), len(srcs[i])) for i in bad[:8]]
     assert d_out[:int(doff[-1])].cpu().numpy().tobytes() == b"".join(srcs)
     enc.Close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_randomized_options_bit_exact(oracle, kclib, seed):
+    """Differential test over the option space: random level x CRC x entropy switches x single segment x window (hence block
+    size) x raw dictionary x EncodeAll / streams, on spliced adversarial units; every frame must equal the oracle's."""
+    _torch()
+    import random
+    from compress_amd import zstd
+    rnd = random.Random(seed)
+    pool = corpora.stress_units(seed=20 + seed, n=30) + corpora.edge_units()
+    for it in range(10):
+        lvl = rnd.choice([1, 2, 3])
+        ops = [zstd.WithEncoderLevel(lvl)]
+        kw = dict(level=lvl)
+        if rnd.random() < 0.4:
+            kw["crc"] = False; ops.append(zstd.WithEncoderCRC(False))
+        if rnd.random() < 0.2:
+            kw["no_entropy"] = True; ops.append(zstd.WithNoEntropyCompression(True))
+        if rnd.random() < 0.3:
+            v = rnd.random() < 0.5
+            kw["all_lit_entropy"] = v; ops.append(zstd.WithAllLitEntropyCompression(v))
+        if rnd.random() < 0.3:
+            v = rnd.random() < 0.5
+            kw["single"] = v; ops.append(zstd.WithSingleSegment(v))
+        if rnd.random() < 0.2:
+            kw["full_zero"] = False; ops.append(zstd.WithZeroFrames(False))
+        bs = (1 << 16) if lvl == 1 else (128 << 10)
+        if rnd.random() < 0.3:
+            ws = 1 << rnd.choice([15, 16, 17, 20])
+            # WithWindowSize before the level: the level then keeps the custom window AND the block size derived from the
+            # default 128 KiB (encoder_options.go:110-133, 236-266), also at SpeedFastest
+            bs = min(ws, 128 << 10)
+            kw["window_size"] = ws; kw["block_size"] = bs
+            ops.insert(0, zstd.WithWindowSize(ws))
+        units = [u for u in rnd.sample(pool, 14) if len(u) <= 32 * bs]
+        stream = rnd.random() < 0.35
+        dct = None
+        if not stream and rnd.random() < 0.35:
+            dct = rnd.choice(pool)[:rnd.choice([300, 20000, 65536])] or b"dictionary"
+            did = rnd.choice([0, 9, 70000])
+            kw["dict_id"] = did; kw["dict_content"] = dct
+            ops.append(zstd.WithEncoderDictRaw(did, dct))
+        ubuf, off = corpora.pack_units(units)
+        enc = zstd.NewWriter(None, *ops)
+        assert (enc.o.window_size, enc.o.block_size) == (kw.get("window_size", enc.o.window_size), kw.get("block_size", enc.o.block_size))
+        out, out_off = (enc.EncodeStreams if stream else enc.EncodeUnits)(ubuf, off)
+        ref = oracle.ZstdOracle(**kw)
+        for i, u in enumerate(units):
+            want = ref.encode_stream(u) if stream else ref.encode_all(u)
+            got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+            assert got == want, (seed, it, sorted(kw), stream, i, len(u), len(got), len(want))
+        enc.Close()
