@@ -71,6 +71,7 @@ class FrameGather:
         self._offs = offs
         self._reqs = []
         self._dev = buf.device
+        ops = []
         if self.rank == self.root:
             if self._out is None or self._out.numel() < offs[-1]:
                 self._out = torch.empty(max(offs[-1], 1), dtype=torch.uint8, device=buf.device)
@@ -78,9 +79,13 @@ class FrameGather:
             for r in range(self.world):
                 if r == self.root or sizes[r] == 0:
                     continue
-                self._reqs.append(dist.irecv(self._out[offs[r]:offs[r + 1]], src=r))
+                ops.append(dist.P2POp(dist.irecv, self._out[offs[r]:offs[r + 1]], r))
         elif nbytes > 0:
-            self._reqs.append(dist.isend(buf[:nbytes], dst=self.root))
+            ops.append(dist.P2POp(dist.isend, buf[:nbytes], self.root))
+        # one group per rank: over RCCL the root's receives from all peers proceed concurrently (one xGMI link each)
+        # instead of one after the other
+        if ops:
+            self._reqs = dist.batch_isend_irecv(ops)
         return self
 
     def wait(self):
