@@ -56,8 +56,6 @@ struct kc_ctx {
         predef, errflag, tmp_src, tmp_dst, tables, prof, work, work_off, dictbuf, proto, dicthuf;
     bool predef_ready = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipStream_t stream2 = nullptr;  // entropy kernels of chunk i overlap the match finder of chunk i+1
-    hipEvent_t evc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     kc_timings last = {0, 0, 0, 0, 0};
     size_t max_batch_bytes = (size_t)8 << 30;  // input bytes per device batch (scratch is ~6x this)
     int stream_mode = 0;             // set for the duration of kc_zstd_encode_streams_dev
@@ -188,9 +186,6 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
     }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return KC_ERR_HIP; }
-    for (auto& e : c->evc)
-        if (hipEventCreate(&e) != hipSuccess) { delete c; return KC_ERR_HIP; }
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return KC_ERR_HIP; }
     *out = c;
     return KC_OK;
 }
@@ -204,10 +199,7 @@ void kc_ctx_destroy(kc_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    for (auto& e : c->evc)
-        if (e) (void)hipEventDestroy(e);
     if (c->pend) { delete (Pending*)c->pend; c->pend = nullptr; }
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
