@@ -39,7 +39,7 @@ SYMBOLS = [
     "kc_zstd_opts_no_entropy", "kc_zstd_opts_all_lit_entropy", "kc_zstd_opts_single_segment", "kc_zstd_opts_dict_raw", "kc_zstd_opts_dict",
     "kc_zstd_max_encoded_size", "kc_ctx_create", "kc_ctx_destroy", "kc_last_error", "kc_device_info",
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
-    "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_s2_encode_block",
+    "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block",
     "kc_last_timings", "kc_corpus_fill",
 ]
 
@@ -112,6 +112,8 @@ def load():
     L.kc_s2_encode_stream_dev.restype = C.c_int
     L.kc_zstd_decode_units_dev.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp]
     L.kc_zstd_decode_units_dev.restype = C.c_int
+    L.kc_zstd_decode_units_dict_dev.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, u64]
+    L.kc_zstd_decode_units_dict_dev.restype = C.c_int
     L.kc_s2_decode_blocks_dev.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp]
     L.kc_s2_decode_blocks_dev.restype = C.c_int
     L.kc_s2_encode_block.argtypes = [vp, vp, u64, vp, u64]

@@ -920,7 +920,13 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
 // zstd frame decode over N units on the device (verifier): decode, then XXH64 of the output against the stored checksum.
 kc_status kc_zstd_decode_units_dev(kc_ctx* c, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n, uint8_t* d_dst,
                                    const uint64_t* dst_off, uint32_t* status) {
+    return kc_zstd_decode_units_dict_dev(c, d_enc, enc_off, n, d_dst, dst_off, status, nullptr, 0);
+}
+
+kc_status kc_zstd_decode_units_dict_dev(kc_ctx* c, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n, uint8_t* d_dst,
+                                        const uint64_t* dst_off, uint32_t* status, const uint8_t* dict, uint64_t dict_len) {
     if (!c || !enc_off || !dst_off || !status || (n && (!d_enc || !d_dst))) return KC_ERR_BAD_ARG;
+    if (dict_len > ((uint64_t)1 << 30)) return KC_ERR_BAD_ARG;
     c->err.clear();
     if (n == 0) return KC_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -944,6 +950,14 @@ kc_status kc_zstd_decode_units_dev(kc_ctx* c, const uint8_t* d_enc, const uint64
     P.crc_stored = (uint32_t*)c->redo.p;
     P.has_crc = (uint32_t*)c->popmask.p;
     P.n_units = n;
+    P.dict = nullptr;
+    P.dict_len = 0;
+    if (dict != nullptr && dict_len > 0) {
+        if ((s = ensure(c, c->dictbuf, (size_t)dict_len + 64))) return s;
+        HIPCHK(c, hipMemcpyAsync(c->dictbuf.p, dict, (size_t)dict_len, hipMemcpyHostToDevice, st));
+        P.dict = (const uint8_t*)c->dictbuf.p;
+        P.dict_len = (uint32_t)dict_len;
+    }
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     kc_launch_zstd_decode(P, st);
     kc_launch_xxh64(d_dst, (const uint64_t*)c->stage_off.p, n, (uint64_t*)c->xxh.p, st);

@@ -104,6 +104,8 @@ struct KcZstdDecParams {
     uint32_t* crc_stored;       // device, n: the frame's stored XXH64 low word
     uint32_t* has_crc;          // device, n
     uint32_t n_units;
+    const uint8_t* dict;        // device or null: raw dictionary content = history in front of every frame
+    uint32_t dict_len;
 };
 void kc_launch_zstd_decode(const KcZstdDecParams& P, hipStream_t st);
 static inline size_t kc_s2_table_bytes() { return (size_t)4 << 14; }

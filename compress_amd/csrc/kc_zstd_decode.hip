@@ -2,7 +2,7 @@
 // (zstd/framedec.go:65-330 -> blockdec.go:227-690 -> seqdec_generic.go:16,161, fse_decoder.go, huff0/decompress.go).
 // One wave per frame.  Serial format parsing (headers, FSE/Huffman table descriptions, the sequence bitstream) runs on lane 0
 // with the tables in LDS; Huffman streams decode on one lane per stream; literal and match copies use all 64 lanes, 64
-// decoded sequences at a time.  Dictionaries are not supported (status 20).  Not a throughput kernel: it exists so that a
+// decoded sequences at a time.  Raw-content dictionaries are supported as history; dictionary entropy tables are not (status 8/12).  Not a throughput kernel: it exists so that a
 // device-resident encode can be verified (decode + XXH64 compare) without leaving the GPU.
 #include "kc_dev.h"
 #include "kc_kernels.h"
@@ -228,7 +228,9 @@ __global__ __launch_bounds__(64) void kc_zstd_decode_kernel(KcZstdDecParams P) {
         checksum = (fhd >> 2) & 1;
         if (fhd & 8) err = 1;
         if (!single) p++;
-        if (fhd & 3) err = 20;  // dictionary frames are not decoded here
+        const int dsz = (fhd & 3) == 3 ? 4 : (fhd & 3);
+        if (dsz && P.dict == nullptr) err = 20;  // a dictionary frame needs the dictionary content (raw content only: no entropy tables)
+        p += dsz;
         fcsSize = (fhd >> 6) == 0 ? (single ? 1 : 0) : (1 << (fhd >> 6));
         if (p + fcsSize > n) err = 1;
         else {
@@ -466,13 +468,19 @@ __global__ __launch_bounds__(64) void kc_zstd_decode_kernel(KcZstdDecParams P) {
             if (S.iv[V_ERR]) { err = S.iv[V_ERR]; break; }
             for (int i = 0; i < cnt; i++) {
                 const uint32_t llen = S.seqLL[i], mlen = S.seqML[i], off = S.seqOF[i];
-                if ((uint64_t)lp + llen > (uint64_t)regen || d + llen + mlen > want || (uint64_t)off > d + llen) { err = 18; break; }
+                if ((uint64_t)lp + llen > (uint64_t)regen || d + llen + mlen > want || (uint64_t)off > d + llen + P.dict_len) { err = 18; break; }
                 if (litRle >= 0) { for (uint32_t k = (uint32_t)lane; k < llen; k += 64) out[d + k] = (uint8_t)litRle; }
                 else { for (uint32_t k = (uint32_t)lane; k < llen; k += 64) out[d + k] = L[lp + k]; }
                 lp += (int)llen;
                 d += llen;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                if (off >= mlen) { for (uint32_t k = (uint32_t)lane; k < mlen; k += 64) out[d + k] = out[d - off + k]; }
+                if ((uint64_t)off > d) {  // the match starts in the dictionary (history in front of the frame, dict.go / history.go)
+                    const uint32_t inDict = (uint32_t)((uint64_t)off - d);  // bytes of the match source that lie in the dictionary
+                    for (uint32_t k = (uint32_t)lane; k < mlen; k += 64) {
+                        const uint32_t j = off >= mlen ? k : k % off;  // an overlapping match repeats its first `off` bytes
+                        out[d + k] = j < inDict ? P.dict[P.dict_len - inDict + j] : out[j - inDict];
+                    }
+                } else if (off >= mlen) { for (uint32_t k = (uint32_t)lane; k < mlen; k += 64) out[d + k] = out[d - off + k]; }
                 else { for (uint32_t k = (uint32_t)lane; k < mlen; k += 64) out[d + k] = out[d - off + (k % off)]; }
                 d += mlen;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

@@ -232,15 +232,18 @@ class Encoder:
                                                    int(dst_cap), out_off.ctypes.data))
         return out_off
 
-    def DecodeUnitsDevice(self, d_enc_ptr, enc_off, d_dst_ptr, dst_off):
-        """Verifier: decode one frame per unit on the device; returns uint32[n] status (0 = content and checksum match)."""
+    def DecodeUnitsDevice(self, d_enc_ptr, enc_off, d_dst_ptr, dst_off, dict_content=None):
+        """Verifier: decode one frame per unit on the device; returns uint32[n] status (0 = content and checksum match).
+        dict_content: the (raw) dictionary content the frames were written with, if any."""
         import numpy as np
         ctx = self.ctx()
         enc_off = np.ascontiguousarray(enc_off, dtype=np.uint64)
         dst_off = np.ascontiguousarray(dst_off, dtype=np.uint64)
         n = len(enc_off) - 1
         status = np.zeros(max(n, 1), dtype=np.uint32)
-        ctx.check(ctx.L.kc_zstd_decode_units_dev(ctx.h, d_enc_ptr, enc_off.ctypes.data, n, d_dst_ptr, dst_off.ctypes.data, status.ctypes.data))
+        dc = bytes(dict_content) if dict_content else None
+        ctx.check(ctx.L.kc_zstd_decode_units_dict_dev(ctx.h, d_enc_ptr, enc_off.ctypes.data, n, d_dst_ptr, dst_off.ctypes.data, status.ctypes.data,
+                                                      dc, len(dc) if dc else 0))
         return status[:n]
 
     def EncodeUnitsDeviceBegin(self, d_src_ptr, unit_off, d_dst_ptr, dst_cap):

@@ -165,9 +165,13 @@ kc_status kc_s2_decode_blocks_dev(kc_ctx* ctx, const uint8_t* d_enc, const uint6
 /* zstd frame decoder (zstd/framedec.go:65-330, blockdec.go:227-690, seqdec_generic.go) over N units, one frame each, for
  * on-device round-trip verification: unit i decodes to d_dst + dst_off[i] and must produce exactly dst_off[i+1]-dst_off[i]
  * bytes; the frame checksum, if present, is checked against XXH64 of the decoded bytes (status 30 on mismatch).  All block,
- * literal and sequence modes; no dictionaries (status 20).  enc_off / dst_off / status are host arrays. */
+ * literal and sequence modes; dictionary frames need kc_zstd_decode_units_dict_dev (status 20 otherwise).  enc_off / dst_off / status are host arrays. */
 kc_status kc_zstd_decode_units_dev(kc_ctx* ctx, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n_units, uint8_t* d_dst,
                                    const uint64_t* dst_off, uint32_t* status);
+/* the same with a dictionary's CONTENT (host pointer) as history in front of every frame: frames written with
+ * WithEncoderDictRaw, or with WithEncoderDict as long as they do not reuse the dictionary's entropy tables */
+kc_status kc_zstd_decode_units_dict_dev(kc_ctx* ctx, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n_units, uint8_t* d_dst,
+                                        const uint64_t* dst_off, uint32_t* status, const uint8_t* dict, uint64_t dict_len);
 /* Single-block form with the WriterCustomEncoder contract (s2/writer.go:1053-1064): no varint header;
  * returns bytes used, 0 = incompressible (store raw), <0 = fall back to the built-in encoder. */
 int64_t kc_s2_encode_block(kc_ctx* ctx, uint8_t* dst, uint64_t dst_cap, const uint8_t* src, uint64_t src_len);

@@ -414,3 +414,29 @@ def test_randomized_options_bit_exact(oracle, kclib, seed):
             got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
             assert got == want, (seed, it, sorted(kw), stream, i, len(u), len(got), len(want))
         enc.Close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_device_decoder_with_dictionary(oracle, kclib, level):
+    """The device verifier with a raw-content dictionary as history (C5's configuration): frames written by the device encoder
+    with WithEncoderDictRaw decode back to the source; without the dictionary they are refused (status 20), not mis-decoded."""
+    torch = _torch()
+    from compress_amd import zstd
+    dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
+    buf = corpora.corpus("M", 24, 131072)
+    t = corpora.corpus("T", 4, 131072, first_unit=77).tobytes()
+    units = [buf[i * 131072:(i + 1) * 131072].tobytes() for i in range(24)] + [t[:200000], t[5:40000], t[:9], b"", dct[:50000], dct, dct[100:300] * 50]
+    ubuf, off = corpora.pack_units(units)
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderDictRaw(7, dct))
+    d_src = torch.from_numpy(ubuf).cuda()
+    cap = sum(((enc.MaxEncodedSize(len(u)) + 15) & ~15) for u in units) + 64
+    d_enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    eoff = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_enc.data_ptr(), cap)
+    d_out = torch.zeros(len(ubuf) + 64, dtype=torch.uint8, device="cuda")
+    st = enc.DecodeUnitsDevice(d_enc.data_ptr(), eoff, d_out.data_ptr(), off, dict_content=dct)
+    bad = np.nonzero(st)[0]
+    assert len(bad) == 0, [(int(i), int(st[i]), len(units[i])) for i in bad[:8]]
+    assert torch.equal(d_out[:len(ubuf)], d_src)
+    st2 = enc.DecodeUnitsDevice(d_enc.data_ptr(), eoff, d_out.data_ptr(), off)
+    assert all(int(x) == 20 for i, x in enumerate(st2) if len(units[i]) > 0), st2
+    enc.Close()
