@@ -492,6 +492,10 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         // ==================== compressed block attempt ====================
         // ---------- 1. gather literals + histogram ----------
         for (int i = tid; i < 4 * 256; i += ET) ((uint32_t*)S.whist)[i] = 0;
+        if (!litsOnly) {  // the sequence histograms may be filled early, under the Huffman tree build (see 2.)
+            for (int i = tid; i < 3 * 64; i += ET) ((uint32_t*)S.shist)[i] = 0;
+            if (tid < 3) S.smax[tid] = 0;
+        }
         if (tid == 0) S.longCnt = 0;
         __syncthreads();
         if (litsOnly) {
@@ -589,6 +593,52 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         __syncthreads();  // also makes the gathered literals visible workgroup-wide
 
         PROF_MARK(1);
+        // Sequence-side preparation that does not depend on the literals.  When a Huffman table is built for this block the
+        // two long single-lane phases of huff0 (tree build, weight-table FSE) run on wave 0, and waves 1-3 use that time:
+        // histograms under the tree build, normalizeCount + buildCTable under the table description.
+        auto seq_hist = [&](int t0, int stride) {
+            uint32_t mll = 0, mof = 0, mml = 0;
+            for (int i = t0; i < nseq; i += stride) {
+                const uint64_t s = sq[i];
+                const uint32_t cl = kc_ll_code(seq_ll(s)), co = kc_of_code(seq_of(s)), cm = kc_ml_code(seq_ml(s));
+                atomicAdd(&S.shist[0][cl], 1u);
+                atomicAdd(&S.shist[1][co], 1u);
+                atomicAdd(&S.shist[2][cm], 1u);
+                mll = cl > mll ? cl : mll;
+                mof = co > mof ? co : mof;
+                mml = cm > mml ? cm : mml;
+            }
+            mll = wave_reduce_max(mll); mof = wave_reduce_max(mof); mml = wave_reduce_max(mml);
+            if (lane == 0) { atomicMax(&S.smax[0], mll); atomicMax(&S.smax[1], mof); atomicMax(&S.smax[2], mml); }
+        };
+        auto seq_build = [&](int k) {  // whole wave: normalizeCount on lane 0, buildCTable on all lanes
+            KcFseT* f = &S.fse[S.curIdx[k]];
+            int doBuild = 0;
+            if (lane == 0) {
+                const int maxSym = (int)S.smax[k];
+                uint32_t maxCount = 0;
+                for (int i = 0; i <= maxSym; i++) if (S.shist[k][i] > maxCount) maxCount = S.shist[k][i];
+                f->symbolLen = (uint16_t)(maxSym + 1);  // HistogramFinished
+                if (!f->reUsed) {  // normalizeCount returns early for reused encoders (fse_encoder.go:260)
+                    f->tableLog = fse_optimal_table_log(nseq, f->symbolLen);
+                    f->stLen1 = 0;
+                    if ((int)maxCount == nseq) {
+                        f->useRLE = 1;
+                    } else {
+                        f->useRLE = 0;
+                        if (fse_normalize_core(S.shist[k], f->norm, f->symbolLen, nseq, f->tableLog)) doBuild = 1;
+                        else atomicExch(P.err_flag, 2u);
+                    }
+                }
+            }
+            doBuild = __shfl(doBuild, 0, 64);
+            if (doBuild) {
+                if (!fse_build_wave(f->norm, f->symbolLen, f->tableLog, S.tsym[k], S.cumul[k], S.posx[k], f->st, f->dnb, f->dfs, lane)) {
+                    if (lane == 0) atomicExch(P.err_flag, 2u);
+                }
+            }
+        };
+        bool seqHistDone = false, seqBuildDone = false;  // workgroup-uniform
         // ---------- 2. huff0.compress decisions (compress.go:43-163) ----------
         const bool wantHuf = litsOnly ? (nlitE > 16) : (!noEntropy && nlitE > 16);  // encodeLits ignores noEntropy (encoder.go:795)
         const bool four = nlitE >= 1024;
@@ -646,7 +696,10 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 const uint8_t tl = huf_build_serial(&S.nodes, &S.cur, symbolLen, nlitE);
                 if (tl == 0xFF) atomicExch(P.err_flag, 1u);
                 S.ivar[IV_TABLOG] = tl;
+            } else if (wv >= 1 && !litsOnly) {
+                seq_hist(tid - 64, ET - 64);
             }
+            seqHistDone = !litsOnly;
             __syncthreads();
             PROF_MARK(3);
             // estimateSize for old/new tables (huff0.go:308) — block reduction of nBits*count
@@ -674,6 +727,8 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 }
                 S.ivar[IV_DESCLEN] = descLen;  // -1: cTable.write failed (ErrIncompressible)
             }
+            if (wv >= 1 && seqHistDone) seq_build(wv - 1);
+            seqBuildDone = seqHistDone;
             __syncthreads();
             const bool usePrev = S.ivar[IV_USEPREV] != 0;
             const KcHufTable* T = usePrev ? &S.huf.prev : &S.cur;
@@ -800,56 +855,17 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         __syncthreads();
 
         PROF_MARK(6);
-        // ---------- 3. sequence codes + histograms (genCodes, blockenc.go:831-893) ----------
-        for (int i = tid; i < 3 * 64; i += ET) ((uint32_t*)S.shist)[i] = 0;
-        if (tid < 3) S.smax[tid] = 0;
-        __syncthreads();
-        {
-            uint32_t mll = 0, mof = 0, mml = 0;
-            for (int i = tid; i < nseq; i += ET) {
-                const uint64_t s = sq[i];
-                const uint32_t cl = kc_ll_code(seq_ll(s)), co = kc_of_code(seq_of(s)), cm = kc_ml_code(seq_ml(s));
-                atomicAdd(&S.shist[0][cl], 1u);
-                atomicAdd(&S.shist[1][co], 1u);
-                atomicAdd(&S.shist[2][cm], 1u);
-                mll = cl > mll ? cl : mll;
-                mof = co > mof ? co : mof;
-                mml = cm > mml ? cm : mml;
-            }
-            mll = wave_reduce_max(mll); mof = wave_reduce_max(mof); mml = wave_reduce_max(mml);
-            if (lane == 0) { atomicMax(&S.smax[0], mll); atomicMax(&S.smax[1], mof); atomicMax(&S.smax[2], mml); }
+        // ---------- 3. sequence codes + histograms (genCodes, blockenc.go:831-893), unless done under the Huffman build ----------
+        if (!seqHistDone) {
+            for (int i = tid; i < 3 * 64; i += ET) ((uint32_t*)S.shist)[i] = 0;
+            if (tid < 3) S.smax[tid] = 0;
+            __syncthreads();
+            seq_hist(tid, ET);
+            __syncthreads();
         }
-        __syncthreads();
         PROF_MARK(7);
         // ---------- 4. normalizeCount (one lane) + buildCTable (whole wave) for the three "cur" encoders, one wave each ----------
-        if (wv < 3) {
-            const int k = wv;
-            KcFseT* f = &S.fse[S.curIdx[k]];
-            int doBuild = 0;
-            if (lane == 0) {
-                const int maxSym = (int)S.smax[k];
-                uint32_t maxCount = 0;
-                for (int i = 0; i <= maxSym; i++) if (S.shist[k][i] > maxCount) maxCount = S.shist[k][i];
-                f->symbolLen = (uint16_t)(maxSym + 1);  // HistogramFinished
-                if (!f->reUsed) {  // normalizeCount returns early for reused encoders (fse_encoder.go:260)
-                    f->tableLog = fse_optimal_table_log(nseq, f->symbolLen);
-                    f->stLen1 = 0;
-                    if ((int)maxCount == nseq) {
-                        f->useRLE = 1;
-                    } else {
-                        f->useRLE = 0;
-                        if (fse_normalize_core(S.shist[k], f->norm, f->symbolLen, nseq, f->tableLog)) doBuild = 1;
-                        else atomicExch(P.err_flag, 2u);
-                    }
-                }
-            }
-            doBuild = __shfl(doBuild, 0, 64);
-            if (doBuild) {
-                if (!fse_build_wave(f->norm, f->symbolLen, f->tableLog, S.tsym[k], S.cumul[k], S.posx[k], f->st, f->dnb, f->dfs, lane)) {
-                    if (lane == 0) atomicExch(P.err_flag, 2u);
-                }
-            }
-        }
+        if (!seqBuildDone && wv < 3) seq_build(wv);
         __syncthreads();
         PROF_MARK(8);
         // ---------- 5. mode choice, mode byte, NCount headers (blockenc.go:633-722) ----------
