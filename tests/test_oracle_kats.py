@@ -389,3 +389,41 @@ def test_oracle_randomized_roundtrips(oracle, seed):
         else:
             got = oracle.zstd_decompress(fr, n + 16, dict_content=dct)
         assert got == d, (it, sorted(kw), n, stream)
+
+
+_HUF_TABLE = [  # huff0/compress_test.go:20-52: (name, input, err1X, err4X); 0 nil, 1 ErrIncompressible, 2 ErrUseRLE
+    ("digits", "e.txt", 0, 0), ("gettysburg", "gettysburg.txt", 0, 0), ("twain", "Mark.Twain-Tom.Sawyer.txt", 0, 0),
+    ("random", "sharnd.out", 1, 1), ("low-ent.10k", b"1221" * 10000, 0, 0), ("superlow-ent-10k", b"1" * 10000 + b"2" * 500, 0, 0),
+    ("zeroes", bytes(10000), 2, 2), ("crash1", "crash1.bin", 1, 1), ("crash2", "crash2.bin", 0, 1), ("crash3", "crash3.bin", 1, 1),
+    ("endzerobits", "endzerobits.bin", 0, 1), ("endnonzero", "endnonzero.bin", 0, 1), ("case1", "case1.bin", 0, 0),
+    ("case2", "case2.bin", 0, 0), ("case3", "case3.bin", 0, 0), ("pngdata.001", "pngdata.bin", 0, 0), ("normcount2", "normcount2.bin", 0, 0)]
+_FSE_TABLE = [  # fse/fse_test.go:19-50: (name, input, err)
+    ("gettysburg", "gettysburg.txt", 0), ("digits", "e.txt", 0), ("twain", "Mark.Twain-Tom.Sawyer.txt", 0), ("random", "sharnd.out", 1),
+    ("low-ent", b"1221" * 10000, 0), ("superlow-ent", b"1" * 10000 + b"2" * 500, 0), ("zeroes", bytes(10000), 2), ("crash1", "crash1.bin", 1),
+    ("crash2", "crash2.bin", 1), ("crash3", "crash3.bin", 1), ("endzerobits", "endzerobits.bin", 0), ("endnonzero", "endnonzero.bin", 1),
+    ("case1", "case1.bin", 1), ("case2", "case2.bin", 1), ("case3", "case3.bin", 1), ("pngdata.001", "pngdata.bin", 0), ("normcount2", "normcount2.bin", 0)]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference fixtures not present on this machine")
+def test_huff0_and_fse_outcome_tables(oracle):
+    """The reference's own expectation tables for huff0.Compress1X / Compress4X (huff0/compress_test.go:20-52,
+    TestCompress1X :225, TestCompress4X :361) and fse.Compress (fse/fse_test.go:19-50, TestCompress :68): which inputs
+    compress, which are ErrIncompressible, which are ErrUseRLE — on a fresh Scratch, inputs cut to BlockSizeMax for huff0."""
+    L = oracle.lib()
+
+    def load(x):
+        return x if isinstance(x, bytes) else open(os.path.join(REF, "testdata", x), "rb").read()
+
+    for name, src, e1, e4 in _HUF_TABLE:
+        d = load(src)[:(1 << 18) - 1]
+        buf = C.create_string_buffer(len(d) + 1024)
+        for four, want in ((0, e1), (1, e4)):
+            r = L.kco_huff0_compress(d, len(d), four, 0, buf, len(buf))
+            got = 0 if r >= 0 else -r
+            assert got == want, ("huff0", name, "4X" if four else "1X", got, want)
+    for name, src, e in _FSE_TABLE:
+        d = load(src)
+        buf = C.create_string_buffer(len(d) + 1024)
+        r = L.kco_fse_compress(d, len(d), buf, len(buf))
+        got = 0 if r >= 0 else -r
+        assert got == e, ("fse", name, got, e)
