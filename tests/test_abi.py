@@ -153,3 +153,20 @@ def test_s2_index_builder_matches_oracle(oracle):
     ix = s2.Index(1 << 20)
     b = ix.append_to(0, 0)
     assert b[:10] == b"\x99" + (len(b) - 4).to_bytes(3, "little") + b"s2idx\x00" and b[-6:] == b"\x00xdi2s"
+
+
+def test_reference_option_tables():
+    """The tables of zstd/encoder_options_test.go: TestEncoderLevelFromString (:9-85), TestEncoderLevelFromZstd (:87-124),
+    TestWindowSize (:126-155)."""
+    from compress_amd import zstd
+    for s, ok, lvl in (("fastest", True, 1), ("FASTEST", True, 1), ("default", True, 2), ("Default", True, 2), ("invalid", False, 2),
+                       ("unknown", False, 2), ("", False, 2)):
+        assert zstd.EncoderLevelFromString(s) == (ok, lvl), s
+    for z, lvl in ((1, 1), (-1, 1), (3, 2), (4, 2)):
+        assert zstd.EncoderLevelFromZstd(z) == lvl
+    for ws, err in ((1 << 9, True), (1 << 10, False), ((1 << 10) + 1, True), ((1 << 10) * 3, True), (zstd.MaxWindowSize, False)):
+        if err:
+            with pytest.raises(ValueError):
+                zstd.NewWriter(None, zstd.WithWindowSize(ws))
+        else:
+            assert zstd.NewWriter(None, zstd.WithWindowSize(ws)).o.window_size == ws
