@@ -117,13 +117,39 @@ def _unsupported(name):
 WriterBetterCompression = _unsupported("WriterBetterCompression")
 WriterBestCompression = _unsupported("WriterBestCompression")
 WriterSnappyCompat = _unsupported("WriterSnappyCompat")
-WriterPadding = _unsupported("WriterPadding")
 WriterUncompressed = _unsupported("WriterUncompressed")
 
 
 def WriterAddIndex():
     """s2.WriterAddIndex (writer.go:921): append the seek index to the stream on Close."""
     return lambda w: setattr(w, "appendIndex", True)
+
+
+def WriterPadding(n):
+    """s2.WriterPadding (writer.go:999): pad the output to a multiple of n with a skippable 0xfe chunk on Close."""
+    def apply(w):
+        if n <= 0:
+            raise ValueError("s2: padding must be at least 1")
+        if n > _MAX_BLOCK:
+            raise ValueError("s2: padding must less than 4MB")
+        w.pad = int(n)
+    return apply
+
+
+def WriterPaddingSrc(reader):
+    """s2.WriterPaddingSrc (writer.go:1018): where the padding bytes come from (default: os.urandom, like crypto/rand)."""
+    return lambda w: setattr(w, "randSrc", reader)
+
+
+def calc_skippable_frame(written, want_multiple):
+    """calcSkippableFrame (writer.go:858): bytes to add so that `written` becomes a multiple; 0 or >= 4."""
+    left = written % want_multiple
+    if left == 0:
+        return 0
+    add = want_multiple - left
+    while add < 4:
+        add += want_multiple
+    return add
 
 
 class Index:
@@ -204,6 +230,8 @@ class Writer:
         self.concurrency = 1
         self.flushOnWrite = False
         self.appendIndex = False
+        self.pad = 0
+        self.randSrc = None
         for o in opts:
             o(self)
         self._enc = BlockEncoder(device, stream)
@@ -322,11 +350,22 @@ class Writer:
         self.Flush()
         self._closed = True
         index = None
-        if want:
-            index = self._index.append_to(self.uncompWritten, self.written)
+        if want:  # writer.go:808-818: the compressed total is unknown to the index when padding follows
+            index = self._index.append_to(self.uncompWritten, self.written if self.pad <= 1 else -1)
             if self.appendIndex:
-                self.writer.write(index)
                 self.written += len(index)
+        if self.pad > 1:  # writer.go:820-836: the padding chunk goes out BEFORE the index, sized as if the index were written
+            add = calc_skippable_frame(self.written, self.pad)
+            if add:
+                if add >= _MAX_BLOCK + 4:
+                    raise ValueError("s2: requested skippable frame (%d) >= max 1<<24" % add)
+                f = add - 4
+                fill = self.randSrc.read(f) if self.randSrc is not None else __import__("os").urandom(f)
+                if len(fill) != f:
+                    raise IOError("short read from the padding source")
+                self.writer.write(bytes([0xfe, f & 0xFF, (f >> 8) & 0xFF, (f >> 16) & 0xFF]) + fill)
+        if index is not None and self.appendIndex:
+            self.writer.write(index)
         return index
 
     # -- device batch --

@@ -170,3 +170,14 @@ def test_reference_option_tables():
                 zstd.NewWriter(None, zstd.WithWindowSize(ws))
         else:
             assert zstd.NewWriter(None, zstd.WithWindowSize(ws)).o.window_size == ws
+
+
+def test_s2_calc_skippable_frame():
+    """calcSkippableFrame (s2/writer.go:858-875): the result makes the total a multiple and is 0 or at least a chunk header."""
+    from compress_amd import s2
+    for written in (0, 1, 3, 4, 5, 99, 100, 4095, 65536, 1234567):
+        for mult in (1, 2, 3, 4, 5, 7, 8, 100, 4096, 8000, 4 << 20):
+            add = s2.calc_skippable_frame(written, mult)
+            assert (written + add) % mult == 0 and (add == 0 or add >= 4), (written, mult, add)
+            assert add == 0 or add < mult + 4 or mult < 4
+    assert s2.calc_skippable_frame(10, 4) == 6 and s2.calc_skippable_frame(9, 4) == 7 and s2.calc_skippable_frame(8, 4) == 0

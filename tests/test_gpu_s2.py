@@ -256,3 +256,42 @@ def test_s2_writer_index(oracle, kclib):
     # without WriterAddIndex the index is returned but not written
     sink2 = io.BytesIO(); w2 = s2.NewWriter(sink2); w2.Write(data[:100000]); idx2 = w2.CloseIndex()
     assert idx2[:1] == b"\x99" and idx2 not in sink2.getvalue()
+
+
+def test_s2_writer_padding(oracle, kclib):
+    """TestWriterPadding (s2/writer_test.go:405): the padded stream is a multiple of the padding, decodes to the input (the
+    0xfe chunk is invisible), also after Reset; with WriterPaddingSrc the bytes equal stream + deterministic padding chunk,
+    and with an index the padding precedes it."""
+    import io
+    import random
+    from compress_amd import s2
+    rng = random.Random(0x1337)
+    for _ in range(4):
+        padding = (rng.getrandbits(16)) + 1
+        n = (rng.getrandbits(18)) + 1
+        src = bytes(rng.getrandbits(2) for _ in range(n))
+        dst = io.BytesIO()
+        e = s2.NewWriter(dst, s2.WriterPadding(padding))
+        e.ReadFrom(io.BytesIO(src))
+        e.Close(); e.Close()
+        assert len(dst.getvalue()) % padding == 0
+        assert oracle.s2_decode_stream(dst.getvalue(), n + 16) == src
+        dst2 = io.BytesIO()
+        e.Reset(dst2)
+        e.Write(src)
+        e.Close()
+        assert len(dst2.getvalue()) % padding == 0 and oracle.s2_decode_stream(dst2.getvalue(), n + 16) == src
+    # deterministic padding source: exact bytes
+    data = corpora.corpus("J", 3, 131072).tobytes()
+    plain = io.BytesIO(); w = s2.NewWriter(plain); w.Write(data); w.Close()
+    padded = io.BytesIO(); w = s2.NewWriter(padded, s2.WriterPadding(8000), s2.WriterPaddingSrc(io.BytesIO(bytes(1 << 20)))); w.Write(data); w.Close()
+    base = plain.getvalue()
+    add = s2.calc_skippable_frame(len(base), 8000)
+    assert padded.getvalue() == base + bytes([0xfe]) + (add - 4).to_bytes(3, "little") + bytes(add - 4)
+    both = io.BytesIO(); w = s2.NewWriter(both, s2.WriterPadding(4096), s2.WriterAddIndex(), s2.WriterPaddingSrc(io.BytesIO(bytes(1 << 20))))
+    w.Write(data); idx = w.CloseIndex()
+    got = both.getvalue()
+    assert got.endswith(idx) and len(got) % 4096 == 0 and got[len(base)] == 0xfe
+    assert oracle.s2_decode_stream(got, len(data) + 16) == data
+    with pytest.raises(ValueError):
+        s2.NewWriter(io.BytesIO(), s2.WriterPadding(0))
