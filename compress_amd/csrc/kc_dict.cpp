@@ -121,13 +121,17 @@ int fse_decode_weights(const uint8_t* p, size_t n, uint8_t* out, int cap) {
     uint32_t s1 = rd(tl), s2 = rd(tl);
     if (off < 0) return -1;
     int w = 0;
+    // fse/decompress.go:310-330: a state may only run dry exactly at the end of the stream — a read that starts with bits left
+    // and needs more than remain is an over-read (bitReader.close -> io.ErrUnexpectedEOF), not the end.
     for (;;) {
         if (w + 2 > cap) return -1;
         out[w++] = dt[s1].sym;
+        if (off > 0 && off < (long)dt[s1].nb) return -1;
         s1 = dt[s1].base + rd(dt[s1].nb);
         if (off < 0) { out[w++] = dt[s2].sym; break; }
         if (w + 2 > cap) return -1;
         out[w++] = dt[s2].sym;
+        if (off > 0 && off < (long)dt[s2].nb) return -1;
         s2 = dt[s2].base + rd(dt[s2].nb);
         if (off < 0) { out[w++] = dt[s1].sym; break; }
     }

@@ -335,6 +335,10 @@ inline bool loadDict(const uint8_t* b, size_t len, DictO* d, huff0::Scratch* lit
         std::vector<DecSymbol> dt;
         bool zb;
         if (!buildDtable(nc, &dt, &zb)) return false;
+        // dec.transform(symbolTableX[i]) (fse_decoder.go:274-290): every symbol that owns a decoding cell must be in the alphabet.
+        // readNCount itself lets a zero run carry the symbol count past maxSymbol (fse_decoder.go:105-108).
+        for (int i = maxTableSymbol[t] + 1; i < nc.symbolLen; i++)
+            if (nc.norm[i] != 0) return false;
     }
     if (br.remain() < 12) return false;
     for (int k = 0; k < 3; k++) {

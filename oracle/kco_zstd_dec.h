@@ -203,6 +203,8 @@ struct FrameDec {
             dictload::NCount nc;
             if (!dictload::readNCount(&br, &nc, 9, maxSym[kind], true)) return false;
             if (nc.actualTableLog > maxLog[kind]) return false;
+            for (int i = maxSym[kind] + 1; i < nc.symbolLen; i++)
+                if (nc.norm[i] != 0) return false;  // transform: "symbol >= max" (fse_decoder.go:279)
             if (!t->fromNorm(nc.norm, nc.symbolLen, nc.actualTableLog)) return false;
             *pp += br.off;
             return true;

@@ -181,3 +181,39 @@ def test_s2_calc_skippable_frame():
             assert (written + add) % mult == 0 and (add == 0 or add >= 4), (written, mult, add)
             assert add == 0 or add < mult + 4 or mult < 4
     assert s2.calc_skippable_frame(10, 4) == 6 and s2.calc_skippable_frame(9, 4) == 7 and s2.calc_skippable_frame(8, 4) == 0
+
+
+def test_dictionary_loader_differential_fuzz(oracle):
+    """Mutated copies of the reference's d0.dict (bit flips / byte changes in the entropy tables, offsets and header,
+    truncations): the product's loader (kc_dict.cpp, written from the format description) and the oracle's restatement of
+    loadDict must agree on accept / reject, and on every table and offset when they accept.  (This test found two bugs: the
+    product ended FSE weight streams on a partial read, the oracle skipped fseDecoder.transform's alphabet check.)"""
+    import random
+    from compress_amd import _lib
+    L = _lib.load()
+    blob = open(os.path.join(ROOT, "tests", "golden", "dict", "d0.dict"), "rb").read()
+    co = oracle.zstd_load_dict(blob)["content_off"]
+    rnd = random.Random(11)
+    accepted = 0
+    for it in range(2500):
+        b = bytearray(blob[:co + 40])
+        for _ in range(rnd.choice([1, 1, 2, 3, 8])):
+            p = rnd.randrange(4 if rnd.random() < 0.9 else 0, co + 12)
+            if rnd.random() < 0.5:
+                b[p] = rnd.getrandbits(8)
+            else:
+                b[p] ^= 1 << rnd.randrange(8)
+        if rnd.random() < 0.1:
+            b = b[:rnd.randrange(8, len(b))]
+        bb = bytes(b)
+        ref = oracle.zstd_load_dict(bb)
+        o = _lib.ZstdOpts()
+        L.kc_zstd_opts_default(C.byref(o))
+        buf = C.create_string_buffer(bb, len(bb))
+        ok = L.kc_zstd_opts_dict(C.byref(o), C.cast(buf, C.c_void_p), len(bb)) == 0
+        assert ok == (ref is not None), (it, ok)
+        if ok:
+            accepted += 1
+            assert list(o.dict_huf_val) == ref["val"] and list(o.dict_huf_nbits) == ref["nbits"], it
+            assert list(o.dict_offsets) == ref["offsets"] and o.dict_len == len(bb) - ref["content_off"], it
+    assert 100 < accepted < 2400
