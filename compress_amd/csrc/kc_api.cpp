@@ -306,10 +306,10 @@ kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
 }
 
 
-// Match-finder variant selection.  Default: sub-wave groups (8 lanes per unit, HBM tables);
-// KC_ZFAST_VARIANT=lds|v1|g8|g16 overrides (lds: packed LDS table + LDS-resident block, one wave per unit;
-// v1: u32 LDS table, source from global memory).
+// Match finders: sub-wave groups (8 lanes per unit), per-unit hash tables in an HBM arena that is zeroed (or primed from the
+// dictionary tables) before every launch.
 kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_off, uint32_t n_units, uint32_t n_launch, int bs, hipStream_t st, int level) {
+    (void)unit_off; (void)n_units; (void)bs;
     if (level == KC_SPEED_BETTER) {
         const size_t tb = kc_zbetter_table_bytes();
         kc_status s3 = ensure(c, c->tables, (size_t)n_launch * tb);
@@ -327,22 +327,11 @@ kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_
         kc_launch_zdfast_match_grp(mp, (uint32_t*)c->tables.p, n_launch, st);
         return KC_OK;
     }
-    const char* v = getenv("KC_ZFAST_VARIANT");
-    std::string var = v ? v : "g8";
-    if (mp.hist0 > 0 || mp.stream_mode) var = "g8";  // dictionary-primed tables / stream parsing exist for the group kernels only
-    if (var == "lds") {
-        bool ok = bs <= 65536;
-        for (uint32_t i = 0; i < n_units && ok; i++) if (unit_off[i + 1] - unit_off[i] > 131072) ok = false;
-        kc_launch_zfast_match(mp, n_launch, st, ok);
-        return KC_OK;
-    }
-    if (var == "v1") { kc_launch_zfast_match(mp, n_launch, st, false); return KC_OK; }
-    const int G = var == "g16" ? 16 : (var == "g4" ? 4 : (var == "g2" ? 2 : 8));
     kc_status s = ensure(c, c->tables, (size_t)n_launch * kc_zfast_table_bytes());
     if (s != KC_OK) return s;
     if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, kc_zfast_table_bytes(), n_launch, st);
     else HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * kc_zfast_table_bytes(), st));
-    kc_launch_zfast_match_grp(mp, (uint32_t*)c->tables.p, n_launch, G, st);
+    kc_launch_zfast_match_grp(mp, (uint32_t*)c->tables.p, n_launch, st);
     return KC_OK;
 }
 
@@ -430,6 +419,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     KcMatchParams mp;
     memset(&mp, 0, sizeof(mp));
     mp.src = k_src;
+    mp.src_end = k_src + (useDict ? pl.rel_off[n_units] + (uint64_t)n_units * (uint64_t)hist0 : pl.rel_off[n_units]);
     mp.unit_off = k_off;
     mp.hist0 = hist0;
     mp.pos_bits = pos_bits;
@@ -788,6 +778,7 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
     KcMatchParams mp;
     memset(&mp, 0, sizeof(mp));
     mp.src = d_src;
+    mp.src_end = d_src + unit_off[n_units];
     mp.unit_off = (const uint64_t*)c->unit_off.p;
     mp.unit_blk0 = (const uint32_t*)c->unit_blk0.p;
     mp.seqs = (uint64_t*)c->seqs.p;

@@ -7,6 +7,8 @@
 // ---- match finders (kc_zstd_match.hip) ----
 struct KcMatchParams {
     const uint8_t* src;         // device: concatenated units
+    const uint8_t* src_end;     // device: one past the last readable byte of src (kernels never load at or beyond it, nor below src,
+                                // except inside the 16-byte aligned granule of a readable byte)
     const uint64_t* unit_off;   // device: n_units+1
     const uint32_t* unit_blk0;  // device: n_units+1, first global block index of each unit
     uint64_t* seqs;             // device scratch: seq_stride packed sequences per block
@@ -24,10 +26,8 @@ struct KcMatchParams {
     int32_t rep1, rep2;         // initial recentOffsets[0..1]: {1,4} unless a full-format dictionary supplies its own
     int32_t stream_mode;        // units are Write+Close streams: a unit of >= one block is parsed with Encode (history) from its first block
 };
-// lds_variant: every unit <= 131064 bytes and block_size <= 65536 (packed 17-bit table + LDS-resident block)
-void kc_launch_zfast_match(const KcMatchParams& P, uint32_t grid, hipStream_t st, bool lds_variant);
-// sub-wave-group variant: G (8|16) lanes per unit, tables = n_launch x 2^15 x u32 in HBM, zeroed by the caller
-void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, int G, hipStream_t st);
+// SpeedFastest: 8 lanes per unit, tables = n_launch x 2^15 x u32 in HBM, zeroed by the caller
+void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st);
 static inline size_t kc_zfast_table_bytes() { return (size_t)4 << 15; }
 // SpeedDefault: long (2^17) + short (2^15) u32 tables per unit in HBM, zeroed by the caller
 void kc_launch_zdfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st);

@@ -1,557 +1,93 @@
-// kc_zstd_match.hip — SpeedFastest match finder for gfx950 (one wave64 per unit).
+// kc_zstd_match.hip — SpeedFastest match finder for gfx950: sub-wave groups, HBM tables, LDS source windows.
 //
-// Replaces fastEncoder.Encode / EncodeNoHist (zstd/enc_fast.go:39-289 / 294-531).
-// The reference parse is sequential; this kernel keeps its exact decisions and extracts
-// wave parallelism by *speculative probing with ordered commit*:
+// Replaces fastEncoder.Encode / EncodeNoHist (zstd/enc_fast.go:39-289 / 294-531) and the small-input dictionary
+// variant (enc_fast.go:534-790).  The reference parse is sequential; this kernel keeps its exact decisions and
+// extracts parallelism by *speculative probing with ordered commit* inside G-lane groups (G = 8: 8 units per wave):
 //   * while no match is found, probe positions are a pure function of (s, nextEmit)
-//     (s += 2 + ((s-nextEmit)>>5), enc_fast.go:207), so the 64 lanes evaluate the next
-//     probes of the current skip segment at once against the pre-round table;
-//   * a lane whose two table buckets were also touched by a lower lane in the same round
-//     (detected exactly-or-conservatively through a small LDS mark array) ends the round:
-//     only lanes below it are committed, so every committed lane saw exactly the table
-//     state the sequential encoder would have seen;
-//   * ballot + ctz picks the first committed lane with a hit in the reference's priority
-//     order (repeat at s+2, candidate at s, candidate at s+1); lanes up to and including
-//     the winner write their table entries (the reference writes before it checks);
-//   * forward / backward match extension are wave-wide 8 B-per-lane compares + ballot.
-// Hash table: 2^15 entries in LDS holding position+1 (0 = empty).  The reference's
-// tableEntry.val is redundant with the source bytes (enc_fast.go:130-131), so comparing
-// 4 source bytes at the candidate is exact; its `cur` epoch offset only invalidates stale
-// entries, which a zeroed per-unit table reproduces.
-// Output: per block, packed sequences (no literal bytes are copied here — the entropy
-// kernel gathers literals from the source using the sequence list) + a KcBlkMeta record.
+//     (s += 2 + ((s-nextEmit)>>5), enc_fast.go:207), so the lanes of a group evaluate the next probes of the
+//     current skip segment at once against the pre-round table;
+//   * a lane whose bucket was touched by a lower lane of its group in the same round ends the round (exact
+//     comparison of bucket indices via __shfl_up), so every committed lane saw the table state the sequential
+//     encoder would have seen;
+//   * group-ballot + ctz picks the first committed hit in the reference's priority order (repeat at s+2,
+//     candidate at s, candidate at s+1); lanes up to the winner commit their table writes (the reference
+//     writes before it checks).
+// Tables (2^15 x u32 per unit: position+1 | tag of the 4 source bytes) live in HBM: 32768 units must be in
+// flight to cover the latency of the dependent table -> candidate chain, and their tables (4 GiB) fit no
+// on-chip memory.  tools/mem_probe.hip measures what the memory system gives this access pattern (scattered
+// 4-byte read + write into per-unit 128 KiB tables over 4 GiB): 21 G read+write pairs/s, i.e. 65 k pairs per
+// unit x 32768 units = 101 ms per 4 GiB before any other access.  Round 2 therefore removes the *other*
+// accesses and dependent round trips of a probe round:
+//   * the source bytes around the parse position come from a per-unit ring buffer in LDS (1 KiB per unit,
+//     refilled 128 B at a time by the group's lanes with one aligned 16-byte load each, one round ahead of
+//     use) instead of per-round 8-byte global loads that missed the thrashed L1/L2;
+//   * a candidate is verified with ONE 16-byte load of [t-4, t+12): it yields the reference's 4-byte
+//     acceptance test, the forward match length when it is < 12 (85 % of matches in text) and the backward
+//     extension when it is < 4 (99 %); only longer matches enter the cooperative extension loops;
+//   * the repeat-offset candidate (known before the table lookup) and the offset-2 check after a match
+//     (enc_fast.go:250) are loaded in the same round trip as the table entries, the latter speculatively:
+//     the probes of the round are discarded when the offset-2 check hits (13 times per 128 KiB of text).
+// A probe round is thus: LDS window read -> {table, repeat, offset-2} loads -> candidate loads -> commit.
+// Output: per block, packed sequences (no literal bytes are copied here — the entropy kernel gathers
+// literals from the source using the sequence list) + a KcBlkMeta record.
 #include "kc_dev.h"
 #include "kc_kernels.h"
 
 #define ZF_TABLE_BITS 15
-#define ZF_MARK_SLOTS 1024
 #define ZF_MAX_MATCH_LENGTH 131074  // enc_fast.go:18
 
-__global__ __launch_bounds__(64) void kc_zfast_match_kernel(KcMatchParams P) {
-    __shared__ uint32_t tab[1 << ZF_TABLE_BITS];
-    __shared__ uint32_t mark[ZF_MARK_SLOTS];
-    const int lane = (int)threadIdx.x;
-    const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : P.unit_base + blockIdx.x;
-    const uint8_t* __restrict__ base = P.src + P.unit_off[u];
-    const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]);
-    const uint32_t blk0 = P.unit_blk0[u];
-    const int bs = P.block_size;
-    const int mmo = P.max_match_off;
-    const int nblk = (ulen + bs - 1) / bs;
-    const bool HIST = ulen > bs;  // encodeAll: Encode for multi-block units, EncodeNoHist otherwise (encoder.go:775-823)
-    const uint32_t pm = P.popmask ? P.popmask[u] : 0u;
-
-    for (int i = lane; i < (1 << ZF_TABLE_BITS); i += 64) tab[i] = 0;
-    for (int i = lane; i < ZF_MARK_SLOTS; i += 64) mark[i] = 0xFFFFFFFFu;
-    __syncthreads();
-
-    int o1 = 1, o2 = 4;  // blockEnc.initNewEncode: recentOffsets = {1,4,8} (blockenc.go:78)
-    for (int b = 0; b < nblk; b++) {
-        const int blkStart = b * bs;
-        const int blkEnd = (blkStart + bs < ulen) ? blkStart + bs : ulen;  // == len(e.hist) after addBlock
-        const int srcLen = blkEnd - blkStart;
-        const int o1_in = o1, o2_in = o2;
-        uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
-        int nseq = 0, sumLL = 0;
-        uint32_t rounds = 0;  // probe rounds (diagnostics: KcBlkMeta.flags bits 8..31)
-        int nextEmit = blkStart, s = blkStart;
-        uint32_t firstLL = 0, firstOf = 0;
-
-        auto emit = [&](int ll, int ml3, uint32_t of) {
-            if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
-            if (lane == 0) sq[nseq] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
-            nseq++;
-            sumLL += ll;
-        };
-
-        if (srcLen >= 10) {  // minNonLiteralBlockSize = 1 + 1 + inputMargin
-            const int sLimit = blkEnd - 8;
-            bool canRep = false;  // len(blk.sequences) > 2 snapshot at outer-loop start (enc_fast.go:117)
-            bool fin = false;
-            while (!fin) {
-                // ---------------- speculative probe round ----------------
-                rounds++;
-                const int d0 = s - nextEmit;
-                const int k0 = d0 >> 5;  // kSearchStrength-1 == 5
-                const int step = 2 + k0;
-                const int p = s + lane * step;
-                const bool valid = (lane == 0 || ((d0 + (lane - 1) * step) >> 5) == k0) && p < sLimit;
-                uint64_t cv = 0;
-                uint32_t h0 = 0, h1 = 0, c0 = 0, c1 = 0;
-                if (valid) {
-                    cv = ld64(base + p);
-                    h0 = hash6(cv, ZF_TABLE_BITS);
-                    h1 = hash6(cv >> 8, ZF_TABLE_BITS);
-                    c0 = tab[h0];
-                    c1 = tab[h1];
-                    atomicMin(&mark[h0 & (ZF_MARK_SLOTS - 1)], (uint32_t)lane);
-                    atomicMin(&mark[h1 & (ZF_MARK_SLOTS - 1)], (uint32_t)lane);
-                }
-                int kind = 0;  // 1 repeat (s+2), 2 candidate at s, 3 candidate2 at s+1
-                int t = 0;
-                if (valid) {
-                    const int repIndex = p - o1 + 2;
-                    if (canRep && repIndex >= 0 && ld32(base + repIndex) == (uint32_t)(cv >> 16)) {
-                        kind = 1;
-                    } else {
-                        const int t0 = (int)c0 - 1, t1 = (int)c1 - 1;
-                        if (c0 != 0 && (p - t0) < mmo && ld32(base + t0) == (uint32_t)cv) {
-                            kind = 2;
-                            t = t0;
-                        } else if (c1 != 0 && (p - t1 + 1) < mmo && ld32(base + t1) == (uint32_t)(cv >> 8)) {
-                            kind = 3;
-                            t = t1;
-                        }
-                    }
-                }
-                bool dep = false;
-                if (valid) {
-                    const uint32_t m0 = mark[h0 & (ZF_MARK_SLOTS - 1)], m1 = mark[h1 & (ZF_MARK_SLOTS - 1)];
-                    dep = m0 < (uint32_t)lane || m1 < (uint32_t)lane;
-                    mark[h0 & (ZF_MARK_SLOTS - 1)] = 0xFFFFFFFFu;
-                    mark[h1 & (ZF_MARK_SLOTS - 1)] = 0xFFFFFFFFu;
-                }
-                const uint64_t vm = ballot64(valid);
-                const uint64_t depm = ballot64(dep);
-                const uint64_t hm = ballot64(kind != 0);
-                const int nvalid = __popcll(vm);  // valid lanes form a prefix
-                const int c = depm ? ctz64(depm) : 64;
-                const uint64_t lowmask = c >= 64 ? ~0ull : ((1ull << c) - 1ull);
-                const uint64_t hmc = hm & lowmask;
-                const bool found = hmc != 0;
-                const int f = found ? ctz64(hmc) : 0;
-                const int commitUpTo = found ? f : ((c < nvalid ? c : nvalid) - 1);
-                if (valid && lane <= commitUpTo) {
-                    tab[h0] = (uint32_t)p + 1u;  // table[nextHash]  = {s}
-                    tab[h1] = (uint32_t)p + 2u;  // table[nextHash2] = {s+1}; later store wins when h0 == h1
-                }
-                if (!found) {
-                    if (c < nvalid) {
-                        s = s + c * step;  // first dependent lane restarts the next round as lane 0
-                    } else {
-                        const int pl = s + (nvalid - 1) * step;
-                        s = pl + 2 + ((pl - nextEmit) >> 5);
-                    }
-                    if (s >= sLimit) fin = true;
-                    continue;
-                }
-                const int mk = (int)bcast32((uint32_t)kind, f);
-                const int ps = s + f * step;
-                int mt = (int)bcast32((uint32_t)t, f);
-                if (mk == 1) {
-                    // ---------------- repeat match at s+2 (enc_fast.go:133-173) ----------------
-                    int repIndex = ps - o1 + 2;
-                    const int length = 4 + wave_matchlen(base + ps + 6, base + repIndex + 4, blkEnd - (ps + 6), lane);
-                    int start = ps + 2;
-                    const int startLimit = nextEmit + 1;
-                    const int sMin = (ps - mmo) > 0 ? (ps - mmo) : 0;
-                    int kmax = repIndex - sMin;
-                    if (start - startLimit < kmax) kmax = start - startLimit;
-                    if (HIST) {  // && seq.matchLen < maxMatchLength-zstdMinMatch (:147); EncodeNoHist has no cap (:385)
-                        const int cap = (ZF_MAX_MATCH_LENGTH - 3) - (length - 3);
-                        if (cap < kmax) kmax = cap;
-                    }
-                    if (kmax < 0) kmax = 0;
-                    const int back = wave_backlen(base, start, repIndex, kmax, lane);
-                    start -= back;
-                    emit(start - nextEmit, length - 3 + back, 1u);
-                    s = ps + length + 2;
-                    nextEmit = s;
-                    if (s >= sLimit) fin = true;
-                    continue;  // stays in the inner loop: canRepeat is not re-evaluated
-                }
-                // ---------------- regular match (enc_fast.go:211-247) ----------------
-                s = ps + (mk == 3 ? 1 : 0);
-                o2 = o1;
-                o1 = s - mt;
-                int l = wave_matchlen(base + s + 4, base + mt + 4, blkEnd - (s + 4), lane) + 4;
-                {
-                    const int tMin = (s - mmo) > 0 ? (s - mmo) : 0;
-                    int kmax = mt - tMin;
-                    if (s - nextEmit < kmax) kmax = s - nextEmit;
-                    if (HIST && (ZF_MAX_MATCH_LENGTH - l) < kmax) kmax = ZF_MAX_MATCH_LENGTH - l;  // && l < maxMatchLength (:230)
-                    if (kmax < 0) kmax = 0;
-                    const int back = wave_backlen(base, s, mt, kmax, lane);
-                    s -= back;
-                    mt -= back;
-                    l += back;
-                }
-                emit(s - nextEmit, l - 3, (uint32_t)(s - mt) + 3u);
-                s += l;
-                nextEmit = s;
-                // Encode uses the stale snapshot, EncodeNoHist re-evaluates (App. A-4; :251 vs :491)
-                const bool canRepO2 = HIST ? canRep : (nseq > 2);
-                canRep = nseq > 2;  // next outer iteration
-                if (s >= sLimit) { fin = true; continue; }
-                if (canRepO2) {
-                    const uint64_t cv2 = ld64(base + s);
-                    const int o2pos = s - o2;
-                    if (ld32(base + o2pos) == (uint32_t)cv2) {
-                        const int l2 = 4 + wave_matchlen(base + s + 4, base + o2pos + 4, blkEnd - (s + 4), lane);
-                        if (lane == 0) tab[hash6(cv2, ZF_TABLE_BITS)] = (uint32_t)s + 1u;
-                        emit(0, l2 - 3, 1u);
-                        s += l2;
-                        nextEmit = s;
-                        const int tmp = o1; o1 = o2; o2 = tmp;
-                        canRep = nseq > 2;
-                        if (s >= sLimit) fin = true;
-                    }
-                }
-            }
-        }
-        const int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
-        const int nlit = sumLL + extra;
-        // Verdicts of blockEnc.encode that the match finder can evaluate itself (blockenc.go:482-503):
-        const bool rle = nseq == 1 && nlit <= 1 && (int)firstLL == nlit && firstOf - 3u == 1u;
-        const int saved = srcLen - nlit - (srcLen >> 6);
-        uint32_t flags = 0;
-        if (nseq > 0 && !rle && saved < 16) flags |= KC_BF_POP_A;
-        if ((pm >> b) & 1u) flags |= KC_BF_FORCED;
-        const int o1c = o1, o2c = o2;
-        if (flags) { o1 = o1_in; o2 = o2_in; }  // popOffsets
-        flags |= rounds << 8;
-        if (lane == 0) {
-            KcBlkMeta m;
-            m.nseq = (uint32_t)nseq;
-            m.nlit = (uint32_t)nlit;
-            m.extra_lits = (uint32_t)extra;
-            m.flags = flags;
-            m.o1_in = (uint32_t)o1_in; m.o2_in = (uint32_t)o2_in;
-            m.o1_out = (uint32_t)o1c; m.o2_out = (uint32_t)o2c;
-            P.meta[blk0 + (uint32_t)b] = m;
-        }
-    }
-}
-
-
-// =======================================================================================
-// v2: LDS-resident current block + packed 17-bit table (units <= 128 KiB - 8, blocks <= 64 KiB)
-// =======================================================================================
-// LDS budget per workgroup (one wave64): 64 KiB table low halves (u16) + 4 KiB table high-bit
-// plane + 64 KiB source block (+ pad) + 4 KiB conflict marks = 136 KiB of the CU's 160 KiB.
-// Every read on the s side of the parse (probe bytes, forward/backward extension, offset-2
-// check) and every candidate inside the current block is an LDS access (~64 clk) instead of a
-// dependent global load (~500+ clk from L2/HBM); only candidates that point into the previous
-// block of a multi-block unit go to global memory (the whole unit is always there).
-#define ZL_SRC_WORDS ((65536 + 64) / 4)
-
-struct ZlSrc {
-    const uint32_t* w;      // LDS copy of [blkStart, blkEnd)
-    const uint8_t* base;    // global: whole unit
-    int blkStart;
-    // 8 / 4 / 1 bytes at absolute position `pos` of the unit
-    __device__ __forceinline__ uint64_t ld64l(int pos) const {  // pos inside the current block
-        const int o = pos - blkStart;
-        const int i = o >> 2, sh = o & 3;
-        const uint32_t a = w[i], b = w[i + 1], c = w[i + 2];
-        const uint32_t lo = __builtin_amdgcn_alignbyte(b, a, sh);
-        const uint32_t hi = __builtin_amdgcn_alignbyte(c, b, sh);
-        return ((uint64_t)hi << 32) | lo;
-    }
-    __device__ __forceinline__ uint32_t ld32l(int pos) const {
-        const int o = pos - blkStart;
-        const int i = o >> 2, sh = o & 3;
-        return __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
-    }
-    __device__ __forceinline__ uint8_t ld8l(int pos) const { return ((const uint8_t*)w)[pos - blkStart]; }
-    // anywhere in the unit: LDS when the whole access starts inside the current block
-    __device__ __forceinline__ uint64_t ld64(int pos) const { return pos >= blkStart ? ld64l(pos) : ::ld64(base + pos); }
-    __device__ __forceinline__ uint32_t ld32(int pos) const { return pos >= blkStart ? ld32l(pos) : ::ld32(base + pos); }
-    __device__ __forceinline__ uint8_t ld8(int pos) const { return pos >= blkStart ? ld8l(pos) : base[pos]; }
-};
-
-// common prefix of [a, a+left) (current block) and b (earlier, anywhere)
-__device__ __forceinline__ int zl_matchlen(const ZlSrc& S, int a, int b, int left, int lane) {
-    int n = 0;
-    int width = 8;
-    for (;;) {
-        const int words = (left - n) >> 3;
-        const int active = words < width ? words : width;
-        uint64_t diff = 0;
-        if (lane < active) diff = S.ld64l(a + n + 8 * lane) ^ S.ld64(b + n + 8 * lane);
-        const uint64_t m = ballot64(diff != 0);
-        if (m) {
-            const int fl = ctz64(m);
-            const uint64_t d = bcast64(diff, fl);
-            return n + 8 * fl + (ctz64(d) >> 3);
-        }
-        n += 8 * active;
-        if (active < width) break;
-        width = 64;
-    }
-    const int tail = left - n;
-    const bool ne = lane < tail && S.ld8l(a + n + lane) != S.ld8(b + n + lane);
-    const uint64_t m = ballot64(ne);
-    return n + (m ? ctz64(m) : tail);
-}
-__device__ __forceinline__ int zl_backlen(const ZlSrc& S, int s, int t, int kmax, int lane) {
-    int cnt = 0;
-    while (cnt < kmax) {
-        const int k = cnt + lane + 1;
-        bool ne = true;
-        if (k <= kmax) ne = S.ld8(t - k) != S.ld8l(s - k);
-        const uint64_t m = ballot64(ne);
-        const int c = m ? ctz64(m) : 64;
-        cnt += c;
-        if (c < 64) break;
-    }
-    return cnt < kmax ? cnt : kmax;
-}
-
-__global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P) {
-    __shared__ uint16_t tabLo[1 << ZF_TABLE_BITS];
-    __shared__ uint32_t tabHi[(1 << ZF_TABLE_BITS) / 32];
-    __shared__ uint32_t srcw[ZL_SRC_WORDS];
-    __shared__ uint32_t mark[ZF_MARK_SLOTS];
-    const int lane = (int)threadIdx.x;
-    const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : P.unit_base + blockIdx.x;
-    const uint8_t* __restrict__ base = P.src + P.unit_off[u];
-    const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]);
-    const uint32_t blk0 = P.unit_blk0[u];
-    const int bs = P.block_size;
-    const int mmo = P.max_match_off;
-    const int nblk = (ulen + bs - 1) / bs;
-    const bool HIST = ulen > bs;
-    const uint32_t pm = P.popmask ? P.popmask[u] : 0u;
-
-    for (int i = lane; i < (1 << ZF_TABLE_BITS) / 2; i += 64) ((uint32_t*)tabLo)[i] = 0;
-    for (int i = lane; i < (1 << ZF_TABLE_BITS) / 32; i += 64) tabHi[i] = 0;
-    for (int i = lane; i < ZF_MARK_SLOTS; i += 64) mark[i] = 0xFFFFFFFFu;
-    __syncthreads();
-
-    auto tab_get = [&](uint32_t h) -> uint32_t { return (uint32_t)tabLo[h] | (((tabHi[h >> 5] >> (h & 31)) & 1u) << 16); };
-    auto tab_put = [&](uint32_t h, uint32_t v, uint32_t old) {
-        tabLo[h] = (uint16_t)v;
-        if ((v ^ old) & 0x10000u) {
-            if (v & 0x10000u) atomicOr(&tabHi[h >> 5], 1u << (h & 31));
-            else atomicAnd(&tabHi[h >> 5], ~(1u << (h & 31)));
-        }
-    };
-
-    int o1 = 1, o2 = 4;
-    for (int b = 0; b < nblk; b++) {
-        const int blkStart = b * bs;
-        const int blkEnd = (blkStart + bs < ulen) ? blkStart + bs : ulen;
-        const int srcLen = blkEnd - blkStart;
-        const int o1_in = o1, o2_in = o2;
-        uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
-        int nseq = 0, sumLL = 0;
-        uint32_t rounds = 0;  // probe rounds (diagnostics: KcBlkMeta.flags bits 8..31)
-        int nextEmit = blkStart, s = blkStart;
-        uint32_t firstLL = 0, firstOf = 0;
-
-        // stage the block into LDS (coalesced dword loads; the global base may be unaligned)
-        __syncthreads();
-        {
-            const int nw = (srcLen + 3) >> 2;
-            const uint8_t* g = base + blkStart;
-            for (int i = lane; i < nw; i += 64) {
-                const int o = 4 * i;
-                uint32_t v;
-                if (o + 4 <= srcLen) v = ::ld32(g + o);
-                else { v = 0; for (int q = 0; o + q < srcLen; q++) v |= (uint32_t)g[o + q] << (8 * q); }
-                srcw[i] = v;
-            }
-            for (int i = nw + lane; i < nw + 8 && i < ZL_SRC_WORDS; i += 64) srcw[i] = 0;
-        }
-        __syncthreads();
-        ZlSrc S{srcw, base, blkStart};
-
-        auto emit = [&](int ll, int ml3, uint32_t of) {
-            if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
-            if (lane == 0) sq[nseq] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
-            nseq++;
-            sumLL += ll;
-        };
-
-        if (srcLen >= 10) {
-            const int sLimit = blkEnd - 8;
-            bool canRep = false;
-            bool fin = false;
-            bool pendO2 = false;  // offset-2 check (enc_fast.go:250) folded into the next probe round's loads
-            while (!fin) {
-                rounds++;
-                const int d0 = s - nextEmit;
-                const int k0 = d0 >> 5;
-                const int step = 2 + k0;
-                const int p = s + lane * step;
-                const bool valid = (lane == 0 || ((d0 + (lane - 1) * step) >> 5) == k0) && p < sLimit;
-                // ---- phase 1: source bytes at the probe positions (+ the offset-2 bytes) ----
-                const uint64_t cv = valid ? S.ld64l(p) : 0ull;
-                if (pendO2) {
-                    pendO2 = false;
-                    const int o2pos = s - o2;
-                    const uint32_t w2 = S.ld32(o2pos);
-                    const uint64_t cv0 = bcast64(cv, 0);
-                    if (w2 == (uint32_t)cv0) {
-                        const int l2 = 4 + zl_matchlen(S, s + 4, o2pos + 4, blkEnd - (s + 4), lane);
-                        if (lane == 0) { const uint32_t h = hash6(cv0, ZF_TABLE_BITS); tab_put(h, (uint32_t)s + 1u, tab_get(h)); }
-                        emit(0, l2 - 3, 1u);
-                        s += l2;
-                        nextEmit = s;
-                        const int tmp = o1; o1 = o2; o2 = tmp;
-                        canRep = nseq > 2;
-                        if (s >= sLimit) fin = true;
-                        continue;
-                    }
-                }
-                // ---- phase 2: table lookups + conflict marks ----
-                uint32_t h0 = 0, h1 = 0, c0 = 0, c1 = 0;
-                if (valid) {
-                    h0 = hash6(cv, ZF_TABLE_BITS);
-                    h1 = hash6(cv >> 8, ZF_TABLE_BITS);
-                    c0 = tab_get(h0);
-                    c1 = tab_get(h1);
-                    atomicMin(&mark[h0 & (ZF_MARK_SLOTS - 1)], (uint32_t)lane);
-                    atomicMin(&mark[h1 & (ZF_MARK_SLOTS - 1)], (uint32_t)lane);
-                }
-                // ---- phase 3: candidate bytes (all three loads issued unconditionally) ----
-                int kind = 0, t = 0;
-                bool dep = false;
-                if (valid) {
-                    const int repIndex = p - o1 + 2;
-                    const bool repOk = canRep && repIndex >= 0;
-                    const int t0 = (int)c0 - 1, t1 = (int)c1 - 1;
-                    const bool ok0 = c0 != 0 && (p - t0) < mmo;
-                    const bool ok1 = c1 != 0 && (p - t1 + 1) < mmo;
-                    const uint32_t wr = S.ld32(repOk ? repIndex : p);
-                    const uint32_t w0 = S.ld32(ok0 ? t0 : p);
-                    const uint32_t w1 = S.ld32(ok1 ? t1 : p);
-                    const uint32_t m0 = mark[h0 & (ZF_MARK_SLOTS - 1)], m1 = mark[h1 & (ZF_MARK_SLOTS - 1)];
-                    dep = m0 < (uint32_t)lane || m1 < (uint32_t)lane;
-                    mark[h0 & (ZF_MARK_SLOTS - 1)] = 0xFFFFFFFFu;
-                    mark[h1 & (ZF_MARK_SLOTS - 1)] = 0xFFFFFFFFu;
-                    if (repOk && wr == (uint32_t)(cv >> 16)) kind = 1;
-                    else if (ok0 && w0 == (uint32_t)cv) { kind = 2; t = t0; }
-                    else if (ok1 && w1 == (uint32_t)(cv >> 8)) { kind = 3; t = t1; }
-                }
-                const uint64_t vm = ballot64(valid);
-                const uint64_t depm = ballot64(dep);
-                const uint64_t hm = ballot64(kind != 0);
-                const int nvalid = __popcll(vm);
-                const int c = depm ? ctz64(depm) : 64;
-                const uint64_t lowmask = c >= 64 ? ~0ull : ((1ull << c) - 1ull);
-                const uint64_t hmc = hm & lowmask;
-                const bool found = hmc != 0;
-                const int f = found ? ctz64(hmc) : 0;
-                const int commitUpTo = found ? f : ((c < nvalid ? c : nvalid) - 1);
-                if (valid && lane <= commitUpTo) {
-                    tab_put(h0, (uint32_t)p + 1u, c0);
-                    // when h0 == h1 the second store must see the first one's high bit as "old"
-                    tab_put(h1, (uint32_t)p + 2u, h1 == h0 ? (uint32_t)p + 1u : c1);
-                }
-                if (!found) {
-                    if (c < nvalid) {
-                        s = s + c * step;
-                    } else {
-                        const int pl = s + (nvalid - 1) * step;
-                        s = pl + 2 + ((pl - nextEmit) >> 5);
-                    }
-                    if (s >= sLimit) fin = true;
-                    continue;
-                }
-                const int mk = (int)bcast32((uint32_t)kind, f);
-                const int ps = s + f * step;
-                int mt = (int)bcast32((uint32_t)t, f);
-                if (mk == 1) {
-                    int repIndex = ps - o1 + 2;
-                    const int length = 4 + zl_matchlen(S, ps + 6, repIndex + 4, blkEnd - (ps + 6), lane);
-                    int start = ps + 2;
-                    const int startLimit = nextEmit + 1;
-                    const int sMin = (ps - mmo) > 0 ? (ps - mmo) : 0;
-                    int kmax = repIndex - sMin;
-                    if (start - startLimit < kmax) kmax = start - startLimit;
-                    if (HIST) {
-                        const int cap = (ZF_MAX_MATCH_LENGTH - 3) - (length - 3);
-                        if (cap < kmax) kmax = cap;
-                    }
-                    if (kmax < 0) kmax = 0;
-                    const int back = zl_backlen(S, start, repIndex, kmax, lane);
-                    start -= back;
-                    emit(start - nextEmit, length - 3 + back, 1u);
-                    s = ps + length + 2;
-                    nextEmit = s;
-                    if (s >= sLimit) fin = true;
-                    continue;
-                }
-                s = ps + (mk == 3 ? 1 : 0);
-                o2 = o1;
-                o1 = s - mt;
-                int l = zl_matchlen(S, s + 4, mt + 4, blkEnd - (s + 4), lane) + 4;
-                {
-                    const int tMin = (s - mmo) > 0 ? (s - mmo) : 0;
-                    int kmax = mt - tMin;
-                    if (s - nextEmit < kmax) kmax = s - nextEmit;
-                    if (HIST && (ZF_MAX_MATCH_LENGTH - l) < kmax) kmax = ZF_MAX_MATCH_LENGTH - l;
-                    if (kmax < 0) kmax = 0;
-                    const int back = zl_backlen(S, s, mt, kmax, lane);
-                    s -= back;
-                    mt -= back;
-                    l += back;
-                }
-                emit(s - nextEmit, l - 3, (uint32_t)(s - mt) + 3u);
-                s += l;
-                nextEmit = s;
-                const bool canRepO2 = HIST ? canRep : (nseq > 2);
-                canRep = nseq > 2;
-                if (s >= sLimit) { fin = true; continue; }
-                pendO2 = canRepO2;
-            }
-        }
-        const int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
-        const int nlit = sumLL + extra;
-        const bool rle = nseq == 1 && nlit <= 1 && (int)firstLL == nlit && firstOf - 3u == 1u;
-        const int saved = srcLen - nlit - (srcLen >> 6);
-        uint32_t flags = 0;
-        if (nseq > 0 && !rle && saved < 16) flags |= KC_BF_POP_A;
-        if ((pm >> b) & 1u) flags |= KC_BF_FORCED;
-        const int o1c = o1, o2c = o2;
-        if (flags) { o1 = o1_in; o2 = o2_in; }
-        flags |= rounds << 8;
-        if (lane == 0) {
-            KcBlkMeta m;
-            m.nseq = (uint32_t)nseq;
-            m.nlit = (uint32_t)nlit;
-            m.extra_lits = (uint32_t)extra;
-            m.flags = flags;
-            m.o1_in = (uint32_t)o1_in; m.o2_in = (uint32_t)o2_in;
-            m.o1_out = (uint32_t)o1c; m.o2_out = (uint32_t)o2c;
-            P.meta[blk0 + (uint32_t)b] = m;
-        }
-    }
-}
-
-// =======================================================================================
-// v3: sub-wave groups — G lanes per unit, 64/G units per wave, hash tables in HBM
-// =======================================================================================
-// The wave-per-unit kernels above keep the table in LDS, which caps the chip at 256-512
-// resident units and leaves each unit on ONE in-order wave: the parse then runs at single-wave
-// issue latency (measured: ~3.5k cycles per sequence, LDS- or HBM-resident source alike).
-// This variant trades on-chip tables for residency and SIMD efficiency: every group of G
-// lanes runs the same speculative-probe / ordered-commit scheme for its own unit, so one
-// instruction stream advances 64/G units, 4-8 waves per SIMD hide the memory latency, and all
-// units of a 4 GiB batch are in flight at once.  Tables (2^15 x u32 position+1 per unit) live
-// in a scratch arena in HBM; conflicts inside a probe round are detected exactly by comparing
-// bucket indices across the group's lanes (no LDS at all).
-#ifndef ZG_W0
-#define ZG_W0 4  // initial speculation width after a match
+#define ZW_RB 1024      // ring bytes per unit (power of two)
+#define ZW_MIRROR 32    // the first 32 ring bytes are mirrored behind the ring: 24-byte reads never wrap
+#define ZW_STRIDE (ZW_RB + ZW_MIRROR)
+#define ZW_BK 4         // bytes in front of a probe / candidate position kept for the backward extension
+#ifndef ZW_AHEAD
+#define ZW_AHEAD 320    // refill while fewer than this many bytes are buffered ahead of s
 #endif
+
 #ifdef KC_TAB_NT
 #define KC_TAB_LD(p) __builtin_nontemporal_load(p)
-#define KC_TAB_ST(v, p) __builtin_nontemporal_store((uint32_t)(v), p)
 #else
 #define KC_TAB_LD(p) (*(p))
-#define KC_TAB_ST(v, p) (*(p) = (v))
 #endif
+#define KC_TAB_ST(v, p) (*(p) = (v))
+
+struct __attribute__((packed)) kc_u128u { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 ld128u(const uint8_t* p) {
+    const kc_u128u v = *(const kc_u128u*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// c = 16 bytes at [t-4, t+12), p0..p3 = the 16 bytes at [p'-4, p'+12):
+// fwd = equal bytes from t / p' on (0..12), back = equal bytes going down from t-1 / p'-1 (0..4).
+__device__ __forceinline__ void zf_cmp16(const uint4 c, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int& fwd, int& back) {
+    const uint32_t x0 = c.x ^ p0, x1 = c.y ^ p1, x2 = c.z ^ p2, x3 = c.w ^ p3;
+    back = x0 ? (__builtin_clz(x0) >> 3) : 4;
+    fwd = x1 ? (__builtin_ctz(x1) >> 3) : (x2 ? 4 + (__builtin_ctz(x2) >> 3) : (x3 ? 8 + (__builtin_ctz(x3) >> 3) : 12));
+}
+
+// 4 bytes at q, with bytes outside [lo, hi) read as zero (edges of the caller's buffer only).
+__device__ __noinline__ uint32_t zf_edge_dword(const uint8_t* q, const uint8_t* lo, const uint8_t* hi) {
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint8_t* a = q + k;
+        if (a >= lo && a < hi) v |= (uint32_t)(*a) << (8 * k);
+    }
+    return v;
+}
+
 template <int G>
 __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P, uint32_t* __restrict__ tables, uint32_t n_launch) {
     constexpr int UPW = 64 / G;
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[UPW * ZW_STRIDE];
     const int lane = (int)threadIdx.x;
     const int lig = lane % G, grp = lane / G;
+    uint8_t* const ring = ring_all + grp * ZW_STRIDE;
     const uint32_t ui = blockIdx.x * UPW + (uint32_t)grp;
     const bool gact = ui < n_launch;
     const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
+    const int boff = (int)((uintptr_t)base & 15);       // window positions are relative to the 16-byte aligned abase
+    const uint8_t* __restrict__ abase = base - boff;
     const int hist0 = P.hist0;  // dictionary content in front of the unit (history): fastEncoderDict (enc_fast.go:534-790)
     const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0 : 0;
     const uint32_t blk0 = P.unit_blk0[u];
@@ -569,9 +105,14 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const int TB = (32 - PB) > 16 ? 16 : (32 - PB);
     const uint32_t posMask = (PB >= 32) ? 0xFFFFFFFFu : ((1u << PB) - 1u);
     auto tagOf = [&](uint32_t v) -> uint32_t { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; };
+    const uint8_t* const srcLo = P.src;
+    const uint8_t* const srcHi = P.src_end;
 
     int o1 = P.rep1, o2 = P.rep2;  // {1,4} (blockenc.go:78) or the dictionary's offsets (enc_base.go:189-195)
     bool allDirty = false;  // fastEncoderDict.allDirty: small-input variant (kSearchStrength 7) only until a block > 32 KiB was seen
+    int wlo = 0, whi = 0;   // the ring holds the bytes abase[wlo .. whi)
+    bool pend = false;      // rf holds the 16*G bytes abase[whi ..) loaded during the previous round
+    uint4 rf = make_uint4(0, 0, 0, 0);
     for (int b = 0; b < nblk; b++) {  // group-uniform trip count; groups diverge freely
         const int blkStart = hist0 + b * bs;
         const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;
@@ -595,23 +136,115 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
         if (srcLen >= 10) {
             const int sLimit = blkEnd - 8;
             bool canRep = false, fin = false, pendO2 = false;
-            int W = G;  // speculation width: narrow right after a match (hits come early in text), doubling on a miss
+            int W = G;  // speculation width: narrow right after a match (hits come early in text), growing on a miss
             while (!fin) {
                 rounds++;
+                // ---------------- source window (LDS ring) ----------------
+                if (pend) {  // the refill issued one round ago has landed (its load precedes this round's loads in vmcnt order)
+                    const int ro = (whi + 16 * lig) & (ZW_RB - 1);
+                    *(uint4*)(ring + ro) = rf;
+                    if (ro < ZW_MIRROR) *(uint4*)(ring + ZW_RB + ro) = rf;
+                    whi += 16 * G;
+                    if (whi - wlo > ZW_RB) wlo = whi - ZW_RB;
+                    pend = false;
+                }
+                const int sa = s + boff;
+                if (sa >= whi || sa < wlo) {  // block start, or a match jumped past the window: restart it just behind s
+                    int w0 = (sa - 16) & ~15;
+                    if (w0 < 0) w0 = 0;
+                    wlo = whi = w0;
+                }
+                if (whi - sa < ZW_AHEAD) {
+                    const uint8_t* q = abase + whi + 16 * lig;
+                    rf = make_uint4(0, 0, 0, 0);
+                    if (q < srcHi) rf = *(const uint4*)q;  // aligned: never leaves the 16-byte granule of a readable byte
+                    pend = true;
+                }
+                // ---------------- probe positions of this round ----------------
                 const int d0 = s - nextEmit;
                 const int k0 = d0 >> SK;
                 const int step = 2 + k0;
                 const int p = s + lig * step;
                 const bool valid = lig < W && (lig == 0 || ((d0 + (lig - 1) * step) >> SK) == k0) && p < sLimit;
-                const uint64_t cv = valid ? ld64(base + p) : 0ull;
-                if (pendO2) {  // offset-2 check (enc_fast.go:250) sharing this round's source load
+                // R = the 20 source bytes [p-4, p+16): D1:D2 = cv, the rest feeds the fused candidate compares
+                uint32_t D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0;
+                if (valid) {
+                    const int a = p + boff - ZW_BK;
+                    const int a4 = a & ~3;
+                    if (a4 >= wlo && a4 + 24 <= whi) {
+                        const uint32_t* r = (const uint32_t*)(ring + (a4 & (ZW_RB - 1)));
+                        const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+                        const uint32_t sh = (uint32_t)(a & 3);
+                        D0 = __builtin_amdgcn_alignbyte(r1, r0, sh);
+                        D1 = __builtin_amdgcn_alignbyte(r2, r1, sh);
+                        D2 = __builtin_amdgcn_alignbyte(r3, r2, sh);
+                        D3 = __builtin_amdgcn_alignbyte(r4, r3, sh);
+                        D4 = __builtin_amdgcn_alignbyte(r5, r4, sh);
+                    } else {
+                        const uint8_t* q = base + p - ZW_BK;
+                        if (q >= srcLo && q + 20 <= srcHi) {
+                            const uint64_t qa = ld64(q), qb = ld64(q + 8);
+                            D0 = (uint32_t)qa; D1 = (uint32_t)(qa >> 32); D2 = (uint32_t)qb; D3 = (uint32_t)(qb >> 32); D4 = ld32(q + 16);
+                        } else {
+                            D0 = zf_edge_dword(q, srcLo, srcHi); D1 = zf_edge_dword(q + 4, srcLo, srcHi); D2 = zf_edge_dword(q + 8, srcLo, srcHi);
+                            D3 = zf_edge_dword(q + 12, srcLo, srcHi); D4 = zf_edge_dword(q + 16, srcLo, srcHi);
+                        }
+                    }
+                }
+                const uint64_t cv = (uint64_t)D1 | ((uint64_t)D2 << 32);
+                // ---------------- round trip 1: table entries, repeat candidate, offset-2 candidate ----------------
+                uint32_t h0 = 0xFFFFFFFFu, h1 = 0xFFFFFFFEu, c0 = 0, c1 = 0;
+                if (valid) {
+                    h0 = hash6(cv, ZF_TABLE_BITS);
+                    h1 = hash6(cv >> 8, ZF_TABLE_BITS);
+                    c0 = KC_TAB_LD(&tab[h0]);
+                    c1 = KC_TAB_LD(&tab[h1]);
+                }
+                const int repIndex = p - o1 + 2;
+                const bool repOk = valid && canRep && repIndex >= 0;
+                uint4 cr = make_uint4(0, 0, 0, 0);
+                bool repWide = false;
+                if (repOk) {
+                    const uint8_t* q = base + repIndex - ZW_BK;
+                    repWide = q >= srcLo && q + 16 <= srcHi;
+                    if (repWide) cr = ld128u(q);
+                    else cr.y = ld32(base + repIndex);
+                }
+                const bool doO2 = pendO2;
+                const int o2pos = s - o2;
+                uint4 co = make_uint4(0, 0, 0, 0);
+                bool o2Wide = false;
+                if (doO2 && lig == 0) {  // offset-2 check (enc_fast.go:250), speculatively in the same round trip as the probes
+                    const uint8_t* q = base + o2pos;
+                    o2Wide = q + 16 <= srcHi;
+                    if (o2Wide) co = ld128u(q);
+                    else co.x = ld32(q);
+                }
+                if (doO2) {
                     pendO2 = false;
-                    const int o2pos = s - o2;
-                    const uint32_t w2 = ld32(base + o2pos);
-                    const uint64_t cv0 = gbcast64<G>(cv, grp, 0);
-                    if (w2 == (uint32_t)cv0) {
-                        const int l2 = 4 + grp_matchlen<G>(base, s + 4, o2pos + 4, blkEnd - (s + 4), lig, grp);
-                        if (lig == 0) tab[hash6(cv0, ZF_TABLE_BITS)] = ((uint32_t)s + 1u) | (PB < 32 ? tagOf((uint32_t)cv0) << PB : 0u);
+                    uint32_t pk = 0;  // bit 0: hit, bit 1: length final, bits 8..: known length
+                    if (lig == 0) {
+                        int f;
+                        int fa;
+                        if (o2Wide) {
+                            const uint32_t x0 = co.x ^ D1, x1 = co.y ^ D2, x2 = co.z ^ D3, x3 = co.w ^ D4;
+                            f = x0 ? (__builtin_ctz(x0) >> 3) : (x1 ? 4 + (__builtin_ctz(x1) >> 3) : (x2 ? 8 + (__builtin_ctz(x2) >> 3) : (x3 ? 12 + (__builtin_ctz(x3) >> 3) : 16)));
+                            fa = 16;
+                        } else {
+                            const uint32_t x0 = co.x ^ D1;
+                            f = x0 ? (__builtin_ctz(x0) >> 3) : 4;
+                            fa = 4;
+                        }
+                        const int limit = blkEnd - s;
+                        const bool done = f < fa || f >= limit;
+                        const int fk = f < limit ? f : limit;
+                        pk = (f >= 4 ? 1u : 0u) | (done ? 2u : 0u) | ((uint32_t)fk << 8);
+                    }
+                    pk = gbcast32<G>(pk, grp, 0);
+                    if (pk & 1u) {
+                        int l2 = (int)(pk >> 8);
+                        if (!(pk & 2u)) l2 += grp_matchlen<G>(base, s + l2, o2pos + l2, blkEnd - (s + l2), lig, grp);
+                        if (lig == 0) KC_TAB_ST(((uint32_t)s + 1u) | (PB < 32 ? tagOf((uint32_t)cv) << PB : 0u), &tab[h0]);
                         emit(0, l2 - 3, 1u);
                         W = P.spec_w0;
                         s += l2;
@@ -619,15 +252,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                         const int tmp = o1; o1 = o2; o2 = tmp;
                         canRep = nseq > 2;
                         if (s >= sLimit) fin = true;
-                        continue;
+                        continue;  // the speculative probes of this round are dropped (nothing was committed)
                     }
-                }
-                uint32_t h0 = 0xFFFFFFFFu, h1 = 0xFFFFFFFEu, c0 = 0, c1 = 0;
-                if (valid) {
-                    h0 = hash6(cv, ZF_TABLE_BITS);
-                    h1 = hash6(cv >> 8, ZF_TABLE_BITS);
-                    c0 = KC_TAB_LD(&tab[h0]);
-                    c1 = KC_TAB_LD(&tab[h1]);
                 }
                 // exact in-round conflict detection: a lower lane of the group touches one of my buckets
                 bool dep = false;
@@ -636,22 +262,50 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     const uint32_t a0 = (uint32_t)__shfl_up((int)h0, d, G), a1 = (uint32_t)__shfl_up((int)h1, d, G);
                     if (lig >= d && (a0 == h0 || a0 == h1 || a1 == h0 || a1 == h1)) dep = true;
                 }
-                int kind = 0, t = 0;
-                if (valid) {
-                    const int repIndex = p - o1 + 2;
-                    const bool repOk = canRep && repIndex >= 0;
-                    const uint32_t e0 = c0 & posMask, e1 = c1 & posMask;
-                    const int t0 = (int)e0 - 1, t1 = (int)e1 - 1;
-                    const bool ok0 = e0 != 0 && (p - t0) < mmo && (PB >= 32 || (c0 >> PB) == tagOf((uint32_t)cv));
-                    const bool ok1 = e1 != 0 && (p - t1 + 1) < mmo && (PB >= 32 || (c1 >> PB) == tagOf((uint32_t)(cv >> 8)));
-                    // predicated candidate fetches: a masked-off lane costs no address slot in the texture path
-                    uint32_t wr = 0, w0 = 0, w1 = 0;
-                    if (repOk) wr = ld32(base + repIndex);
-                    if (ok0) w0 = ld32(base + t0);
-                    if (ok1) w1 = ld32(base + t1);
-                    if (repOk && wr == (uint32_t)(cv >> 16)) kind = 1;
-                    else if (ok0 && w0 == (uint32_t)cv) { kind = 2; t = t0; }
-                    else if (ok1 && w1 == (uint32_t)(cv >> 8)) { kind = 3; t = t1; }
+                // ---------------- round trip 2: tagged candidates, one 16-byte load each ----------------
+                const uint32_t e0 = c0 & posMask, e1 = c1 & posMask;
+                const int t0 = (int)e0 - 1, t1 = (int)e1 - 1;
+                const bool ok0 = valid && e0 != 0 && (p - t0) < mmo && (PB >= 32 || (c0 >> PB) == tagOf((uint32_t)cv));
+                const bool ok1 = valid && e1 != 0 && (p - t1 + 1) < mmo && (PB >= 32 || (c1 >> PB) == tagOf((uint32_t)(cv >> 8)));
+                uint4 ca = make_uint4(0, 0, 0, 0), cb = make_uint4(0, 0, 0, 0);
+                bool wide0 = false, wide1 = false;
+                if (ok0) {  // predicated: a masked-off lane costs no address slot in the texture path
+                    const uint8_t* q = base + t0 - ZW_BK;
+                    wide0 = q >= srcLo && q + 16 <= srcHi;
+                    if (wide0) ca = ld128u(q);
+                    else ca.y = ld32(base + t0);
+                }
+                if (ok1) {
+                    const uint8_t* q = base + t1 - ZW_BK;
+                    wide1 = q >= srcLo && q + 16 <= srcHi;
+                    if (wide1) cb = ld128u(q);
+                    else cb.y = ld32(base + t1);
+                }
+                // per-lane verdict: kind 1 repeat (s+2), 2 candidate at s, 3 candidate2 at s+1 (enc_fast.go:133,176,188)
+                int kind = 0, t = 0, fwd = 0, back = 0, ba = 0, fa = 0, kofs = 0;
+                if (repOk) {
+                    int f, bk;
+                    zf_cmp16(cr, __builtin_amdgcn_alignbyte(D1, D0, 2), __builtin_amdgcn_alignbyte(D2, D1, 2),
+                             __builtin_amdgcn_alignbyte(D3, D2, 2), __builtin_amdgcn_alignbyte(D4, D3, 2), f, bk);
+                    if (f >= 4) { kind = 1; fwd = repWide ? f : 4; back = repWide ? bk : 0; fa = repWide ? 12 : 4; ba = repWide ? ZW_BK : 0; kofs = 2; }
+                }
+                if (kind == 0 && ok0) {
+                    int f, bk;
+                    zf_cmp16(ca, D0, D1, D2, D3, f, bk);
+                    if (f >= 4) { kind = 2; t = t0; fwd = wide0 ? f : 4; back = wide0 ? bk : 0; fa = wide0 ? 12 : 4; ba = wide0 ? ZW_BK : 0; kofs = 0; }
+                }
+                if (kind == 0 && ok1) {
+                    int f, bk;
+                    zf_cmp16(cb, __builtin_amdgcn_alignbyte(D1, D0, 1), __builtin_amdgcn_alignbyte(D2, D1, 1),
+                             __builtin_amdgcn_alignbyte(D3, D2, 1), __builtin_amdgcn_alignbyte(D4, D3, 1), f, bk);
+                    if (f >= 4) { kind = 3; t = t1; fwd = wide1 ? f : 4; back = wide1 ? bk : 0; fa = wide1 ? 12 : 4; ba = wide1 ? ZW_BK : 0; kofs = 1; }
+                }
+                uint32_t vk = 0;  // kind:2 | length final:1 | known forward length:5 | equal bytes behind:3 | bytes behind examined:3
+                if (kind != 0) {
+                    const int limit = blkEnd - (p + kofs);
+                    const bool done = fwd < fa || fwd >= limit;
+                    const int fk = fwd < limit ? fwd : limit;
+                    vk = (uint32_t)kind | (done ? 4u : 0u) | ((uint32_t)fk << 3) | ((uint32_t)back << 8) | ((uint32_t)ba << 11);
                 }
                 const uint32_t vm = gballot<G>(valid, grp);
                 const uint32_t depm = gballot<G>(valid && dep, grp);
@@ -677,25 +331,36 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     if (s >= sLimit) fin = true;
                     continue;
                 }
-                const int mk = (int)gbcast32<G>((uint32_t)kind, grp, f);
+                const uint32_t wk = gbcast32<G>(vk, grp, f);
+                const int mk = (int)(wk & 3u);
+                const bool fdone = (wk & 4u) != 0;
+                const int fk = (int)((wk >> 3) & 31u);
+                const int bke = (int)((wk >> 8) & 7u), bav = (int)((wk >> 11) & 7u);
                 const int ps = s + f * step;
                 int mt = (int)gbcast32<G>((uint32_t)t, grp, f);
+                // backward extension given the bke equal bytes found among the bav bytes examined (enc_fast.go:152-157, 230-234)
+                auto backlen = [&](int sp, int tp, int kmax) -> int {
+                    if (kmax <= 0) return 0;
+                    if (bke < bav) return bke < kmax ? bke : kmax;
+                    if (kmax <= bav) return kmax;
+                    return bav + grp_backlen<G>(base, sp - bav, tp - bav, kmax - bav, lig, grp);
+                };
                 if (mk == 1) {
-                    int repIndex = ps - o1 + 2;
-                    const int length = 4 + grp_matchlen<G>(base, ps + 6, repIndex + 4, blkEnd - (ps + 6), lig, grp);
+                    const int rI = ps - o1 + 2;
+                    int length = fk;
+                    if (!fdone) length += grp_matchlen<G>(base, ps + 2 + fk, rI + fk, blkEnd - (ps + 2 + fk), lig, grp);
                     int start = ps + 2;
                     const int startLimit = nextEmit + 1;
                     const int sMin = (ps - mmo) > 0 ? (ps - mmo) : 0;
-                    int kmax = repIndex - sMin;
+                    int kmax = rI - sMin;
                     if (start - startLimit < kmax) kmax = start - startLimit;
                     if (HIST) {
                         const int cap = (ZF_MAX_MATCH_LENGTH - 3) - (length - 3);
                         if (cap < kmax) kmax = cap;
                     }
-                    if (kmax < 0) kmax = 0;
-                    const int back = grp_backlen<G>(base, start, repIndex, kmax, lig, grp);
-                    start -= back;
-                    emit(start - nextEmit, length - 3 + back, 1u);
+                    const int bk = backlen(start, rI, kmax);
+                    start -= bk;
+                    emit(start - nextEmit, length - 3 + bk, 1u);
                     W = P.spec_w0;
                     s = ps + length + 2;
                     nextEmit = s;
@@ -705,17 +370,17 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 s = ps + (mk == 3 ? 1 : 0);
                 o2 = o1;
                 o1 = s - mt;
-                int l = grp_matchlen<G>(base, s + 4, mt + 4, blkEnd - (s + 4), lig, grp) + 4;
+                int l = fk;
+                if (!fdone) l += grp_matchlen<G>(base, s + fk, mt + fk, blkEnd - (s + fk), lig, grp);
                 {
                     const int tMin = (s - mmo) > 0 ? (s - mmo) : 0;
                     int kmax = mt - tMin;
                     if (s - nextEmit < kmax) kmax = s - nextEmit;
                     if (HIST && (ZF_MAX_MATCH_LENGTH - l) < kmax) kmax = ZF_MAX_MATCH_LENGTH - l;
-                    if (kmax < 0) kmax = 0;
-                    const int back = grp_backlen<G>(base, s, mt, kmax, lig, grp);
-                    s -= back;
-                    mt -= back;
-                    l += back;
+                    const int bk = backlen(s, mt, kmax);
+                    s -= bk;
+                    mt -= bk;
+                    l += bk;
                 }
                 emit(s - nextEmit, l - 3, (uint32_t)(s - mt) + 3u);
                 W = P.spec_w0;
@@ -727,6 +392,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 pendO2 = canRepO2;
             }
         }
+        pend = false;  // a refill still in flight at the end of a block is dropped; the window itself stays valid
         const int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
         const int nlit = sumLL + extra;
         const bool rle = nseq == 1 && nlit <= 1 && (int)firstLL == nlit && firstOf - 3u == 1u;
@@ -750,14 +416,6 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     }
 }
 
-void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, int G, hipStream_t st) {
-    if (G == 16) hipLaunchKernelGGL(kc_zfast_match_grp_kernel<16>, dim3((n_launch + 3) / 4), dim3(64), 0, st, P, tables, n_launch);
-    else if (G == 4) hipLaunchKernelGGL(kc_zfast_match_grp_kernel<4>, dim3((n_launch + 15) / 16), dim3(64), 0, st, P, tables, n_launch);
-    else if (G == 2) hipLaunchKernelGGL(kc_zfast_match_grp_kernel<2>, dim3((n_launch + 31) / 32), dim3(64), 0, st, P, tables, n_launch);
-    else hipLaunchKernelGGL(kc_zfast_match_grp_kernel<8>, dim3((n_launch + 7) / 8), dim3(64), 0, st, P, tables, n_launch);
-}
-
-void kc_launch_zfast_match(const KcMatchParams& P, uint32_t grid, hipStream_t st, bool lds_variant) {
-    if (lds_variant) hipLaunchKernelGGL(kc_zfast_match_lds_kernel, dim3(grid), dim3(64), 0, st, P);
-    else hipLaunchKernelGGL(kc_zfast_match_kernel, dim3(grid), dim3(64), 0, st, P);
+void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st) {
+    hipLaunchKernelGGL(kc_zfast_match_grp_kernel<8>, dim3((n_launch + 7) / 8), dim3(64), 0, st, P, tables, n_launch);
 }

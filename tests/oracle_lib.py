@@ -225,6 +225,22 @@ def s2_encode(src: bytes) -> bytes:
     return buf.raw[:r]
 
 
+def s2_encode_blocks(src, blk_off, threads=1):
+    """N x s2.Encode on host threads.  src: numpy u8; blk_off: numpy u64 [n+1].  Returns (numpy u8, out_off numpy u64[n+1])."""
+    import numpy as np
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    blk_off = np.ascontiguousarray(blk_off, dtype=np.uint64)
+    n = len(blk_off) - 1
+    sizes = np.diff(blk_off.astype(np.int64)) if n else np.zeros(0, dtype=np.int64)
+    cap = int(sum(lib().kco_s2_max_encoded_len(int(z)) * int(c) for z, c in zip(*np.unique(sizes, return_counts=True)))) + 64
+    dst = np.empty(cap, dtype=np.uint8)
+    out_off = np.empty(n + 1, dtype=np.uint64)
+    r = lib().kco_s2_encode_blocks(src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, out_off.ctypes.data, int(threads))
+    if r < 0:
+        raise RuntimeError("oracle s2_encode_blocks failed: %d" % r)
+    return dst[:r], out_off
+
+
 def s2_encode_block(src: bytes) -> bytes:
     cap = lib().kco_s2_max_encoded_len(len(src))
     buf = C.create_string_buffer(max(cap, 1))
