@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X zstd encode hot path (BASELINE.json configs[1]).
+"""bench.py — benchmarks of the MI355X zstd / S2 encode hot path on the BASELINE.json configurations.
 
-Workload (C2): zstd SpeedFastest, synthetic enwik-style text 'T' in independent 128 KiB units
-(each unit == one reference EncodeAll call: 1 frame, 2 x 64 KiB blocks sharing history), 4 GiB
-per GPU, inputs resident in HBM before the timed region.  A "step" is one pass of the whole
-hot path (checksum + match finder + entropy/emit + compaction) over the batch; for N > 1 each
-rank encodes its own 4 GiB shard (weak scaling) and the compressed frames are gathered to
-rank 0 over RCCL (the only exchange step of this path).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C2H|C3|C4|C5] [--gib G] [--kind T|H|J|M]
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--gib G] [--kind T|H|J|M]
-
-Prints ONE JSON line on rank 0.
+Default (what the driver runs): C2 = BASELINE.json configs[1], the configuration the headline metric is quoted on:
+zstd SpeedFastest, synthetic enwik-style text 'T' in independent 128 KiB units (each unit == one reference EncodeAll
+call: 1 frame, 2 x 64 KiB blocks sharing history), 4 GiB per GPU, inputs resident in HBM before the timed region.
+The other configurations print the same JSON shape:
+    C2H  the same on the high-entropy corpus 'H' (north_star: "enwik-style and high-entropy buffers")
+    C3   zstd SpeedDefault (enc_dfast) on the C2 corpus
+    C4   s2.Encode, 64 KiB blocks of synthetic JSON 'J', 2 GiB per GPU (= 16 GiB over 8 GPUs)
+    C5   zstd SpeedBetterCompression with a 64 KiB raw dictionary on mixed text+binary 'M', 1 GiB per GPU (= 8 GiB over 8)
+A "step" is one pass of the whole hot path (checksum + match finder + entropy/emit + compaction) over the batch; for
+N > 1 each rank encodes its own shard (weak scaling) and the compressed frames are gathered to rank 0 over RCCL (the only
+exchange step of this path).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,27 +28,101 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
-UNIT = 128 << 10
 SEEDS = {"T": 0x5EED0001, "H": 0x5EED0002, "J": 0x5EED0003, "M": 0x5EED0004}
+DICT_SEED = 0x5EED0005
+
+CONFIGS = {
+    "C2": dict(codec="zstd", level=1, kind="T", unit=128 << 10, gib=4.0, dict_kib=0, kernel="kc_zfast_match_grp_kernel<8>",
+               src="kc_zstd_match.hip", what="zstd SpeedFastest EncodeAll"),
+    "C2H": dict(codec="zstd", level=1, kind="H", unit=128 << 10, gib=4.0, dict_kib=0, kernel="kc_zfast_match_grp_kernel<8>",
+                src="kc_zstd_match.hip", what="zstd SpeedFastest EncodeAll"),
+    "C3": dict(codec="zstd", level=2, kind="T", unit=128 << 10, gib=4.0, dict_kib=0, kernel="kc_zdfast_match_grp_kernel<8>",
+               src="kc_zstd_match_dfast.hip", what="zstd SpeedDefault EncodeAll"),
+    "C4": dict(codec="s2", level=0, kind="J", unit=64 << 10, gib=2.0, dict_kib=0, kernel="kc_s2_encode_kernel",
+               src="kc_s2.hip", what="s2.Encode (default level)"),
+    "C5": dict(codec="zstd", level=3, kind="M", unit=128 << 10, gib=1.0, dict_kib=64, kernel="kc_zbetter_match_grp_kernel<true>",
+               src="kc_zstd_match_better.hip", what="zstd SpeedBetterCompression EncodeAll, 64 KiB raw dictionary"),
+}
+METRIC = "encode MB/s (input) + ratio, zstd SpeedFastest 128KiB blocks, 1/2/4/8 GPU"
+
+
+def kernel_source_hash(name):
+    """sha256[:16] of the kernel's source file + the shared device header: stamps PMC summaries so that a stale one is not reported."""
+    h = hashlib.sha256()
+    for f in (name, "kc_dev.h"):
+        h.update(open(os.path.join(ROOT, "compress_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_quota():
+    cores = os.cpu_count() or 1
+    quota = None
+    try:  # cgroup v2 CPU quota of this container: more runnable threads than this only get throttled
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per))))
+    except Exception:
+        pass
+    return cores, quota
+
+
+def collect_pmc(argv, kernel_key):
+    """--pmc: re-run this command (1 step, rank 0, N == 1) under rocprofv3 once per counter and return the HBM bytes of the
+    dominant kernel's dispatch: FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots), both in KB."""
+    import glob
+    import sqlite3
+    import tempfile
+    res = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="kcpmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "--", sys.executable, os.path.abspath(__file__)] + argv + [
+            "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-device-verify", "--no-end-to-end"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400, check=False)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            c = sqlite3.connect(dbs[0])
+            cols = [x[1] for x in c.execute("pragma table_info(counters_collection)")]
+            ik, ic, iv, idp = cols.index("kernel_name"), cols.index("counter_name"), cols.index("value"), cols.index("dispatch_id")
+            acc = {}
+            for r in c.execute("select * from counters_collection"):
+                if r[ic] == ctr and kernel_key in r[ik]:
+                    acc[r[idp]] = acc.get(r[idp], 0.0) + float(r[iv])
+            res[ctr] = max(acc.values()) * 1024.0 if acc else None
+        except Exception as e:  # profiling is best effort: the bench line must still print
+            res[ctr] = None
+            res["error"] = repr(e)[:200]
+        finally:
+            subprocess.run(["rm", "-rf", d], check=False)
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--gib", type=float, default=4.0, help="input GiB per GPU")
-    ap.add_argument("--kind", default="T")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--gib", type=float, default=None, help="input GiB per GPU (default: the configuration's)")
+    ap.add_argument("--kind", default=None, help="corpus override (T|H|J|M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive host-buffer measurement after the timed region")
     ap.add_argument("--pipeline", action="store_true",
-                    help="two contexts on two streams: the match finder of step i+1 runs under the entropy stage of step i. "
-                         "Measured on MI355X: 184.0 vs 184.7 ms/step — the two kernels only trade the same HBM/issue slots "
-                         "(match 145 -> 170 ms, entropy 36 -> 112 ms when co-resident), so the default is one context.")
+                    help="zstd only: two contexts on two streams, the match finder of step i+1 under the entropy stage of step i. "
+                         "Measured on MI355X (round 1): 184.0 vs 184.7 ms/step, so the default is one context.")
     ap.add_argument("--no-device-verify", action="store_true",
-                    help="skip the on-device round trip (kc_zstd_decode_units_dev over ALL frames + compare with the input)")
-    ap.add_argument("--cpu-sample-units", type=int, default=16384)
+                    help="skip the on-device round trip (decode ALL frames on the device + compare with the input)")
+    ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic in this run (two extra rocprofv3 passes of one step each)")
+    ap.add_argument("--cpu-sample-units", type=int, default=0, help="units of the CPU-baseline / byte-compare sample (0: per configuration)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="override the CPU baseline thread count")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.gib is not None:
+        cfg["gib"] = args.gib
+    if args.kind is not None:
+        cfg["kind"] = args.kind
+    UNIT = cfg["unit"]
+    kind = cfg["kind"]
 
     import numpy as np
     import torch
@@ -62,67 +141,85 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from compress_amd import _lib, zstd
-    from compress_amd.shard import shard_range, gather_frames, FrameGather
+    from compress_amd import _lib, zstd, s2
+    from compress_amd.shard import FrameGather
 
-    n_units = int(args.gib * (1 << 30)) // UNIT
+    n_units = int(cfg["gib"] * (1 << 30)) // UNIT
     first_unit = rank * n_units  # contiguous shard per rank keeps output order == concatenation order
     t0 = time.time()
-    host = _lib.corpus_fill(args.kind, SEEDS[args.kind], first_unit, n_units, UNIT)
+    host = _lib.corpus_fill(kind, SEEDS[kind], first_unit, n_units, UNIT)
     gen_s = time.time() - t0
     d_src = torch.from_numpy(host).cuda(local_rank)
     unit_off = np.arange(n_units + 1, dtype=np.uint64) * UNIT
+    in_bytes = n_units * UNIT
+    dict_content = _lib.corpus_fill("T", DICT_SEED, 0, 1, cfg["dict_kib"] << 10).tobytes() if cfg["dict_kib"] else None
 
-    # Two encoder contexts on two streams (each with its own device scratch and output buffer) form a two-deep software
-    # pipeline over consecutive steps: begin(step i+1) enqueues its match finder — chained after step i's — before
-    # end(step i) enqueues step i's entropy stage, so the two run concurrently (--pipeline; off by default, see --help).
-    npipe = 2 if args.pipeline else 1
+    is_s2 = cfg["codec"] == "s2"
+    npipe = 2 if (args.pipeline and not is_s2) else 1
     streams = [torch.cuda.Stream() for _ in range(npipe)]
-    encs = [zstd.NewWriter(None, zstd.WithEncoderLevel(zstd.SpeedFastest), device=local_rank, stream=st.cuda_stream) for st in streams]
+    if is_s2:
+        encs = [s2.BlockEncoder(device=local_rank, stream=streams[0].cuda_stream)]
+        slot = (s2.MaxEncodedLen(UNIT) + 15) & ~15
+    else:
+        zopts = [zstd.WithEncoderLevel(cfg["level"])]
+        if dict_content:
+            zopts.append(zstd.WithEncoderDictRaw(1, dict_content))
+        encs = [zstd.NewWriter(None, *zopts, device=local_rank, stream=st.cuda_stream) for st in streams]
+        slot = (encs[0].MaxEncodedSize(UNIT) + 15) & ~15
     enc = encs[0]
-    cap = n_units * ((enc.MaxEncodedSize(UNIT) + 15) & ~15) + 64
+    cap = n_units * slot + 64
     ndst = 2 if (npipe == 2 or world > 1) else 1  # N > 1: the gather of step i reads one buffer while step i+1 fills the other
     d_dsts = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(ndst)]
     gather = FrameGather(rank, world) if world > 1 else None
     if npipe == 2:
         encs[0].ChainAfter(encs[1])
         encs[1].ChainAfter(encs[0])
-    info = enc.ctx().device_info()
+    ctx0 = enc._ctx if is_s2 else enc.ctx()
+    info = ctx0.device_info()
     torch.cuda.synchronize()
 
     def run_steps(k):
-        """k passes over the batch; returns (offsets of the last pass, its buffer index, per-pass kernel timings).
+        """k passes over the batch; returns (offsets of the last pass, its buffer index, per-pass kernel timings, per-pass wall ms).
         N > 1: the RCCL gather of step i's frames to rank 0 is posted after step i and completed after step i+1's encode,
         so the transfer over xGMI overlaps the next step's kernels; the last gather completes inside the timed region."""
-        tms, off, last = [], None, 0
+        tms, walls, off, last = [], [], None, 0
         if k <= 0:
-            return off, last, tms
+            return off, last, tms, walls
         pending = None
-        encs[0].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[0].data_ptr(), cap)
+        tw = time.perf_counter()
+        if not is_s2:
+            encs[0].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[0].data_ptr(), cap)
         for i in range(k):
             cur, nxt = i % npipe, (i + 1) % npipe
             db = i % ndst
-            if npipe == 2 and i + 1 < k:
-                encs[nxt].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[(i + 1) % ndst].data_ptr(), cap)
-            off = encs[cur].EncodeUnitsDeviceEnd()
-            tms.append(encs[cur].ctx().timings())
+            if is_s2:
+                off = enc.EncodeBlocksDevice(d_src.data_ptr(), unit_off, d_dsts[db].data_ptr(), cap)
+                tms.append(ctx0.timings())
+            else:
+                if npipe == 2 and i + 1 < k:
+                    encs[nxt].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[(i + 1) % ndst].data_ptr(), cap)
+                off = encs[cur].EncodeUnitsDeviceEnd()
+                tms.append(encs[cur].ctx().timings())
             if world > 1:
                 if pending is not None:
                     pending.wait()
                 pending = gather.start(d_dsts[db], int(off[n_units]))
-            if npipe == 1 and i + 1 < k:
+            if not is_s2 and npipe == 1 and i + 1 < k:
                 encs[0].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[(i + 1) % ndst].data_ptr(), cap)
             last = db
+            tn = time.perf_counter()  # the encode call returned the offsets: this step's frames are complete on the device
+            walls.append((tn - tw) * 1e3)
+            tw = tn
         if pending is not None:
             pending.wait()
-        return off, last, tms
+        return off, last, tms, walls
 
     run_steps(args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out_off, last_buf, match_ms = run_steps(args.steps)
+    out_off, last_buf, ktimes, walls = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -133,80 +230,114 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt * 1000.0 / args.steps
-    in_bytes = n_units * UNIT
     out_bytes = int(out_off[n_units])
     value = world * in_bytes / (ms_per_step / 1000.0) / 1e6  # MB/s (1e6) of input, whole job
 
-    # ---- roofline of the dominant kernel (match finder), from HIP events on the launch stream ----
-    tm = match_ms[-1]
-    k_match = sum(t["match_ms"] for t in match_ms) / len(match_ms)
-    k_entropy = sum(t["entropy_ms"] for t in match_ms) / len(match_ms)
-    k_total = sum(t["total_ms"] for t in match_ms) / len(match_ms)
+    # ---- roofline of the dominant kernel, from HIP events on the launch stream (kc_last_timings) ----
+    tm = ktimes[-1]
+    k_match = float(np.median([t["match_ms"] for t in ktimes]))
+    k_entropy = float(np.median([t["entropy_ms"] for t in ktimes]))
+    k_total = float(np.median([t["total_ms"] for t in ktimes]))
     algo_bytes = in_bytes + out_bytes  # 1 B read + ratio B written per input byte
     achieved = algo_bytes / (k_match / 1000.0) / 1e9
-    # HBM traffic of the dominant kernel from PMC counters (separate rocprofv3 --pmc passes, see profiles/): read from the
-    # committed summary when it was taken on this workload; FETCH_SIZE is reported raw (the x2 correction of
-    # MI355X_MICROARCH.md applies to wide coalesced reads; this kernel issues scattered 4-8 byte accesses: uncalibrated).
-    traffic = None
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if pj.get("units") == n_units and pj.get("corpus") == args.kind:
-            traffic = pj["match_kernel_hbm_bytes"]
-    except Exception:
-        pass
-    roofline = {"bound": "hbm", "kernel": "kc_zfast_match_grp_kernel<8>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+    # HBM traffic of the dominant kernel: measured in this run with --pmc (two rocprofv3 passes), else taken from the committed
+    # PMC summary when it was collected on this workload AND on this kernel source (sha256 stamp), else null.  FETCH_SIZE is
+    # reported raw: the x2 correction of MI355X_MICROARCH.md was calibrated on wide coalesced reads; tools/mem_probe.hip shows
+    # this kernel's scattered 4-byte accesses are 64-byte requests (TCC_EA0_RDREQ_32B == 0), which FETCH_SIZE tallies at 64 B.
+    khash = kernel_source_hash(cfg["src"])
+    traffic, traffic_src = None, None
+    if args.pmc and rank == 0 and world == 1:
+        argv = ["--config", args.config, "--gib", str(cfg["gib"]), "--kind", kind]
+        pm = collect_pmc(argv, cfg["kernel"].split("<")[0])
+        if pm.get("FETCH_SIZE") and pm.get("WRITE_SIZE"):
+            traffic, traffic_src = int(pm["FETCH_SIZE"] + pm["WRITE_SIZE"]), "measured in this run (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, 1 step each)"
+    if traffic is None:
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            for ent in pj.get("entries", [pj]):
+                if ent.get("config") == args.config and ent.get("units") == n_units and ent.get("corpus") == kind and ent.get("kernel_source_sha16") == khash:
+                    traffic, traffic_src = ent["kernel_hbm_bytes"], "profiles/pmc_traffic.json (same workload, same kernel source)"
+        except Exception:
+            pass
+    roofline = {"bound": "hbm", "kernel": cfg["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel_source_sha16": khash,
                 "kernel_ms": round(k_match, 3), "entropy_kernel_ms": round(k_entropy, 3), "pipeline_kernel_ms": round(k_total, 3),
                 "read_only_frac": round(in_bytes / (k_match / 1000.0) / 1e9 / HBM_PEAK_GBS, 5)}
 
-    # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement of the reference, all host threads ----
+    # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement of the reference on the host threads + byte compare ----
     cpu = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib
-        cores = os.cpu_count() or 1
-        quota = None
-        try:  # cgroup v2 CPU quota of this container: more runnable threads than this only get throttled
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            if q != "max":
-                quota = max(1, int(round(int(q) / int(per))))
-        except Exception:
-            pass
+        cores, quota = cpu_quota()
         host_threads = cores
         if quota is not None and quota < cores:
             cores = quota
         if args.cpu_threads > 0:
             cores = args.cpu_threads
-        sample = min(n_units, args.cpu_sample_units)
+        default_sample = {"C2": 16384, "C2H": 16384, "C3": 8192, "C4": 16384, "C5": 2048}[args.config]
+        sample = min(n_units, args.cpu_sample_units or default_sample)
         t0 = time.perf_counter()
-        ref, ref_off = oracle_lib.zstd_encode_units(host[:sample * UNIT], unit_off[:sample + 1], threads=cores, level=1)
+        if is_s2:
+            ref, ref_off = oracle_lib.s2_encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], threads=cores)
+        else:
+            kw = dict(level=cfg["level"])
+            if dict_content:
+                kw.update(dict_id=1, dict_content=dict_content)
+            ref, ref_off = oracle_lib.zstd_encode_units(host[:sample * UNIT], unit_off[:sample + 1], threads=cores, **kw)
         cdt = time.perf_counter() - t0
         cpu = {"value": round(sample * UNIT / cdt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
                "sample": "first %d units (%.2f GiB) of the same corpus, %d std::threads (host has %d hardware threads%s)"
                          % (sample, sample * UNIT / 2**30, cores, host_threads, ", cgroup cpu.max allows %d CPUs" % quota if quota else "")}
         got = d_dst[:int(out_off[sample])].cpu().numpy()
-        parity = bool(np.array_equal(got, ref) and np.array_equal(out_off[:sample + 1], ref_off))
+        parity = bool(np.array_equal(got, np.asarray(ref)) and np.array_equal(out_off[:sample + 1], ref_off))
 
-    # ---- on-device round trip of EVERY frame of this rank (outside the timed region): decode + XXH64 check + compare ----
+    # ---- on-device round trip of EVERY frame of this rank (outside the timed region): decode + checksum + compare ----
     verified = None
     verify_ms = None
     if not args.no_device_verify:
         d_back = torch.empty(in_bytes + 64, dtype=torch.uint8, device="cuda")
         t0 = time.perf_counter()
-        st = enc.DecodeUnitsDevice(d_dst.data_ptr(), out_off, d_back.data_ptr(), unit_off)
+        if is_s2:
+            st = enc.DecodeBlocksDevice(d_dst.data_ptr(), out_off, d_back.data_ptr(), unit_off)
+        else:
+            st = enc.DecodeUnitsDevice(d_dst.data_ptr(), out_off, d_back.data_ptr(), unit_off, dict_content=dict_content)
         torch.cuda.synchronize()
         verify_ms = (time.perf_counter() - t0) * 1e3
         verified = bool((not st.any()) and torch.equal(d_back[:in_bytes], d_src))
         del d_back
 
+    # ---- PCIe-inclusive rate of the host-buffer entry point (what the cgo shim calls), outside the timed region ----
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        ne = min(n_units, (1 << 30) // UNIT)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            if is_s2:
+                _, eo = enc.EncodeBlocks(host[:ne * UNIT], unit_off[:ne + 1])
+            else:
+                _, eo = enc.EncodeUnits(host[:ne * UNIT], unit_off[:ne + 1])
+            edt = time.perf_counter() - t0
+            best = edt if best is None else min(best, edt)
+        e2e = {"value": round(ne * UNIT / best / 1e6, 1), "unit": "MB/s",
+               "sample": "%d units (%.2f GiB) from pageable host memory through kc_%s: H2D + encode + D2H, best of 2"
+                         % (ne, ne * UNIT / 2**30, "s2_encode_blocks" if is_s2 else "zstd_encode_units"),
+               "same_bytes_as_device_path": bool(np.array_equal(eo, out_off[:ne + 1]))}
+
     if rank == 0:
+        wl = "%s, %.2f GiB/GPU synthetic '%s' corpus in %d KiB %s%s, device-resident" % (
+            cfg["what"], cfg["gib"], kind, UNIT >> 10,
+            "blocks" if is_s2 else "units (2 x 64 KiB blocks with history)" if cfg["level"] == 1 else "units",
+            "" if not dict_content else ", dictionary = 64 KiB of corpus 'T'")
         line = {
-            "metric": "encode MB/s (input) + ratio, zstd SpeedFastest 128KiB blocks, 1/2/4/8 GPU",
+            "metric": METRIC if args.config in ("C2", "C2H") else "encode MB/s (input) + ratio, %s" % cfg["what"],
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": round(float(np.median(walls)), 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "zstd SpeedFastest EncodeAll, %.2f GiB/GPU synthetic '%s' corpus in 128 KiB units (2 x 64 KiB blocks with history), device-resident"
-                       % (args.gib, args.kind), "units_per_gpu": n_units, "unit_bytes": UNIT, "corpus": args.kind,
+            "config": {"workload": wl, "name": args.config, "units_per_gpu": n_units, "unit_bytes": UNIT, "corpus": kind,
                        "parallelism": "units sharded contiguously over %d GPU(s); RCCL gather of frames to rank 0" % world if world > 1 else "1 GPU",
                        "pipeline": ("2 contexts / 2 streams: match finder of step i+1 overlaps the entropy stage of step i" if npipe == 2
                                     else "none: steps back to back on one stream"),
@@ -215,6 +346,7 @@ def main():
             "value_GiBps": round(value * 1e6 / 2**30, 3),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "end_to_end": e2e,
             "bit_exact_vs_oracle_on_sample": parity,
             "device_roundtrip_all_frames": verified,
             "device_roundtrip_ms": None if verify_ms is None else round(verify_ms, 1),

@@ -39,7 +39,7 @@ SYMBOLS = [
     "kc_zstd_opts_no_entropy", "kc_zstd_opts_all_lit_entropy", "kc_zstd_opts_single_segment", "kc_zstd_opts_dict_raw", "kc_zstd_opts_dict",
     "kc_zstd_max_encoded_size", "kc_ctx_create", "kc_ctx_destroy", "kc_last_error", "kc_device_info",
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
-    "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block",
+    "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats",
     "kc_last_timings", "kc_corpus_fill",
 ]
 
@@ -118,6 +118,8 @@ def load():
     L.kc_s2_decode_blocks_dev.restype = C.c_int
     L.kc_s2_encode_block.argtypes = [vp, vp, u64, vp, u64]
     L.kc_s2_encode_block.restype = C.c_int64
+    L.kc_s2_hook_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.kc_s2_hook_stats.restype = None
     L.kc_last_timings.argtypes = [vp, C.POINTER(Timings)]
     L.kc_last_timings.restype = C.c_int
     L.kc_corpus_fill.argtypes = [C.c_int, u64, u64, C.c_uint32, C.c_uint32, vp, C.c_int]

@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "libkcgpu.so")
 BDIR = os.path.join(HERE, "_build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-munsafe-fp-atomics"] + (["-DKC_TAB_NT"] if os.environ.get("KC_TAB_NT") else []) + os.environ.get("KC_EXTRA_FLAGS", "").split()
+         "-Wno-unused-variable", "-munsafe-fp-atomics"] + os.environ.get("KC_EXTRA_FLAGS", "").split()
 
 
 def _newer(a, b):

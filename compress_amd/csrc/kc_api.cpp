@@ -8,7 +8,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -61,6 +65,8 @@ struct kc_ctx {
     int stream_mode = 0;             // set for the duration of kc_zstd_encode_streams_dev
     void* pend = nullptr;            // batch between kc_zstd_encode_units_dev_begin and _end (Pending)
     kc_ctx* chain_after = nullptr;   // pipelining: this context's match finder waits for that context's last one
+    std::once_flag hook_once;        // kc_s2_encode_block: micro-batcher of concurrent callers (S2Hook), created on first use
+    void* hook = nullptr;
 };
 
 namespace {
@@ -86,6 +92,8 @@ kc_status ensure(kc_ctx* c, DevBuf& b, size_t bytes) {
 }
 
 inline int bitsLen32(uint32_t v) { return v == 0 ? 0 : 32 - __builtin_clz(v); }
+
+void s2_hook_free(void* h);  // S2Hook (kc_s2_encode_block's micro-batcher), defined with it
 
 }  // namespace
 
@@ -200,6 +208,7 @@ void kc_ctx_destroy(kc_ctx* c) {
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->pend) { delete (Pending*)c->pend; c->pend = nullptr; }
+    if (c->hook) { s2_hook_free(c->hook); c->hook = nullptr; }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1035,26 +1044,178 @@ kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk
     return KC_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// kc_s2_encode_block: the s2.WriterCustomEncoder hook (s2/writer.go:1053-1064).
+// "The function should expect to be called concurrently" — s2.Writer calls it from one goroutine per block
+// (writer.go:455-460).  Concurrent callers on ONE context are micro-batched (group commit): a caller appends its block
+// to the open slot and copies its bytes into the slot's pinned input; the first caller of a slot is its leader, which
+// takes the device lock (while the previous slot still runs, later callers keep joining this one), closes the slot and
+// runs ONE H2D -> kernel -> D2H for all blocks of the slot; every caller then copies its own block out.  An idle
+// context adds no waiting: a lone caller's slot closes at once.
+// ---------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct S2Hook {
+    struct Slot {
+        uint8_t* h_in = nullptr;   // pinned
+        uint8_t* h_out = nullptr;  // pinned
+        std::vector<uint64_t> in_off, out_off;
+        uint32_t n = 0, copied = 0, left = 0;
+        bool open = false, closed = false, done = false;
+        kc_status status = KC_OK;
+    };
+    static constexpr int kSlots = 3;
+    std::mutex m;
+    std::condition_variable cv;
+    std::mutex dev;  // one slot at a time on the context's stream and scratch
+    Slot slots[kSlots];
+    int cur = -1;
+    size_t in_cap = (size_t)16 << 20, out_cap = 0;
+    uint32_t max_n = 256;
+    int wait_us = 0;
+    bool ok = false;
+    std::atomic<uint64_t> n_calls{0}, n_batches{0};
+
+    bool init() {
+        if (const char* e = getenv("KC_S2_HOOK_WAIT_US")) wait_us = atoi(e);
+        if (const char* e = getenv("KC_S2_HOOK_BATCH")) max_n = (uint32_t)std::max(1, atoi(e));
+        out_cap = in_cap + (size_t)32 * max_n + 64;
+        for (auto& sl : slots) {
+            if (hipHostMalloc((void**)&sl.h_in, in_cap, hipHostMallocDefault) != hipSuccess) return false;
+            if (hipHostMalloc((void**)&sl.h_out, out_cap, hipHostMallocDefault) != hipSuccess) return false;
+            sl.in_off.assign(max_n + 1, 0);
+            sl.out_off.assign(max_n + 1, 0);
+        }
+        ok = true;
+        return true;
+    }
+    ~S2Hook() {
+        for (auto& sl : slots) {
+            if (sl.h_in) (void)hipHostFree(sl.h_in);
+            if (sl.h_out) (void)hipHostFree(sl.h_out);
+        }
+    }
+};
+
+void s2_hook_free(void* h) { delete (S2Hook*)h; }
+
+// one slot through the device: pinned input -> tmp_src, N x s2.Encode, tmp_dst -> pinned output
+kc_status s2_hook_run(kc_ctx* c, S2Hook::Slot& sl) {
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n = sl.n;
+    const uint64_t total = sl.in_off[n];
+    uint64_t need = 0;
+    for (uint32_t i = 0; i < n; i++) need += ((uint64_t)kc_s2_max_encoded_len((int64_t)(sl.in_off[i + 1] - sl.in_off[i])) + 15) & ~(uint64_t)15;
+    kc_status s;
+    if ((s = ensure(c, c->tmp_src, total + 64)) || (s = ensure(c, c->tmp_dst, need + 64))) return s;
+    HIPCHK(c, hipMemcpyAsync(c->tmp_src.p, sl.h_in, total, hipMemcpyHostToDevice, c->stream));
+    s = kc_s2_encode_blocks_dev(c, (const uint8_t*)c->tmp_src.p, sl.in_off.data(), n, (uint8_t*)c->tmp_dst.p, need, sl.out_off.data());
+    if (s != KC_OK) return s;
+    HIPCHK(c, hipMemcpyAsync(sl.h_out, c->tmp_dst.p, sl.out_off[n], hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int64_t kc_s2_encode_block(kc_ctx* c, uint8_t* dst, uint64_t dst_cap, const uint8_t* src, uint64_t src_len) {
     // WriterCustomEncoder contract (s2/writer.go:1053-1064): no varint header; 0 = incompressible; <0 = use built-in.
     if (!c || !dst || !src) return -1;
     if (src_len > (4u << 20) || src_len == 0) return -1;
-    const int64_t maxLen = kc_s2_max_encoded_len((int64_t)src_len);
-    std::vector<uint8_t> tmp((size_t)maxLen + 16);
-    uint64_t off[2] = {0, src_len}, oo[2];
-    if (kc_s2_encode_blocks(c, src, off, 1, tmp.data(), tmp.size(), oo) != KC_OK) return -1;
-    // strip the uvarint(len) header; a block stored as one literal run means "incompressible"
-    size_t h = 0;
-    while (tmp[h] & 0x80) h++;
-    h++;
-    const uint64_t body = oo[1] - h;
-    const uint64_t nm1 = src_len - 1;  // emitLiteral header size depends on len-1 (encode_go.go:86-113)
-    const uint64_t storedLen = src_len + (nm1 < 60 ? 1 : (nm1 < (1 << 8) ? 2 : (nm1 < (1 << 16) ? 3 : (nm1 < (1 << 24) ? 4 : 5))));
-    if (body == storedLen && src_len >= 32) return 0;  // encodeBlock returned 0 -> stored
-    if (src_len < 32) return 0;                        // encodeBlock: len < minNonLiteralBlockSize -> 0
-    if (body > dst_cap) return -1;
-    memcpy(dst, tmp.data() + h, body);
-    return (int64_t)body;
+    if (src_len < 32) return 0;  // encodeBlock: len < minNonLiteralBlockSize -> 0 (stored by the writer)
+    std::call_once(c->hook_once, [c] {
+        S2Hook* h = new S2Hook();
+        if (hipSetDevice(c->device) != hipSuccess || !h->init()) { delete h; return; }
+        c->hook = h;
+    });
+    S2Hook* h = (S2Hook*)c->hook;
+    if (!h) return -1;
+    h->n_calls++;
+    std::unique_lock<std::mutex> lk(h->m);
+    S2Hook::Slot* sl = nullptr;
+    for (;;) {
+        if (h->cur >= 0) {
+            S2Hook::Slot& cs = h->slots[h->cur];
+            if (!cs.closed && cs.n < h->max_n && cs.in_off[cs.n] + src_len <= h->in_cap) { sl = &cs; break; }
+            cs.closed = true;  // full: its leader will run it as it is
+            h->cur = -1;
+            h->cv.notify_all();
+        }
+        int fr = -1;
+        for (int i = 0; i < S2Hook::kSlots; i++)
+            if (!h->slots[i].open) { fr = i; break; }
+        if (fr < 0) { h->cv.wait(lk); continue; }
+        S2Hook::Slot& ns = h->slots[fr];
+        ns.open = true; ns.closed = false; ns.done = false; ns.n = 0; ns.copied = 0; ns.left = 0; ns.status = KC_OK;
+        ns.in_off[0] = 0;
+        h->cur = fr;
+    }
+    const uint32_t idx = sl->n++;
+    const uint64_t off = sl->in_off[idx];
+    sl->in_off[idx + 1] = off + src_len;
+    sl->left++;
+    const bool leader = idx == 0;
+    lk.unlock();
+    memcpy(sl->h_in + off, src, src_len);  // callers stage their own bytes in parallel
+    lk.lock();
+    sl->copied++;
+    h->cv.notify_all();
+    if (leader) {
+        lk.unlock();
+        h->dev.lock();  // while the previous slot is on the device, callers keep joining this one
+        lk.lock();
+        if (h->wait_us > 0 && !sl->closed && sl->n < h->max_n)
+            h->cv.wait_for(lk, std::chrono::microseconds(h->wait_us), [&] { return sl->closed || sl->n >= h->max_n; });
+        sl->closed = true;
+        if (h->cur >= 0 && &h->slots[h->cur] == sl) h->cur = -1;
+        h->cv.wait(lk, [&] { return sl->copied == sl->n; });
+        lk.unlock();
+        const kc_status st = s2_hook_run(c, *sl);
+        h->dev.unlock();
+        h->n_batches++;
+        lk.lock();
+        sl->status = st;
+        sl->done = true;
+        h->cv.notify_all();
+    } else {
+        h->cv.wait(lk, [&] { return sl->done; });
+    }
+    int64_t ret = -1;
+    const uint8_t* enc = nullptr;
+    uint64_t body = 0;
+    if (sl->status == KC_OK) {
+        enc = sl->h_out + sl->out_off[idx];
+        const uint64_t elen = sl->out_off[idx + 1] - sl->out_off[idx];
+        size_t hdr = 0;  // strip the uvarint(len) header
+        while (enc[hdr] & 0x80) hdr++;
+        hdr++;
+        body = elen - hdr;
+        enc += hdr;
+        const uint64_t nm1 = src_len - 1;  // emitLiteral header size depends on len-1 (encode_go.go:86-113)
+        const uint64_t storedLen = src_len + (nm1 < 60 ? 1 : (nm1 < (1 << 8) ? 2 : (nm1 < (1 << 16) ? 3 : (nm1 < (1 << 24) ? 4 : 5))));
+        if (body == storedLen) ret = 0;  // a block stored as one literal run: encodeBlock returned 0
+        else if (body > dst_cap) ret = -1;
+        else ret = (int64_t)body;
+    }
+    lk.unlock();
+    if (ret > 0) memcpy(dst, enc, body);
+    lk.lock();
+    if (--sl->left == 0) {
+        sl->open = false;
+        h->cv.notify_all();
+    }
+    return ret;
+}
+
+// diagnostics of the hook's micro-batcher: calls served and device batches run so far
+void kc_s2_hook_stats(const kc_ctx* c, uint64_t* calls, uint64_t* batches) {
+    const S2Hook* h = c ? (const S2Hook*)c->hook : nullptr;
+    if (calls) *calls = h ? h->n_calls.load() : 0;
+    if (batches) *batches = h ? h->n_batches.load() : 0;
 }
 
 }  // extern "C"

@@ -44,11 +44,8 @@
 #define ZW_AHEAD 320    // refill while fewer than this many bytes are buffered ahead of s
 #endif
 
-#ifdef KC_TAB_NT
-#define KC_TAB_LD(p) __builtin_nontemporal_load(p)
-#else
+// plain loads/stores: non-temporal table loads measured 174.7 vs 134.9 ms per 4 GiB (profiles/r02_match_finder_experiments.md)
 #define KC_TAB_LD(p) (*(p))
-#endif
 #define KC_TAB_ST(v, p) (*(p) = (v))
 
 struct __attribute__((packed)) kc_u128u { uint32_t x, y, z, w; };
@@ -79,9 +76,11 @@ template <int G>
 __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P, uint32_t* __restrict__ tables, uint32_t n_launch) {
     constexpr int UPW = 64 / G;
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[UPW * ZW_STRIDE];
+    __shared__ uint64_t sbuf_all[UPW * G];  // per unit: the last (nseq mod G) sequences, flushed G at a time as one 64-byte store
     const int lane = (int)threadIdx.x;
     const int lig = lane % G, grp = lane / G;
     uint8_t* const ring = ring_all + grp * ZW_STRIDE;
+    uint64_t* const sbuf = sbuf_all + grp * G;
     const uint32_t ui = blockIdx.x * UPW + (uint32_t)grp;
     const bool gact = ui < n_launch;
     const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
@@ -125,9 +124,14 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
         uint32_t firstLL = 0, firstOf = 0;
         auto emit = [&](int ll, int ml3, uint32_t of) {
             if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
-            if (lig == 0) sq[nseq] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
+            if (lig == 0) sbuf[nseq & (G - 1)] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
             nseq++;
             sumLL += ll;
+            if ((nseq & (G - 1)) == 0) {  // group-uniform: G sequences buffered -> one coalesced store (8-byte scattered stores cost a DRAM write each)
+                __builtin_amdgcn_wave_barrier();
+                sq[nseq - G + lig] = sbuf[lig];
+                __builtin_amdgcn_wave_barrier();
+            }
         };
         int SK = 5;  // kSearchStrength - 1
         if (hist0 > 0) {  // enc_fast.go:539-543,585
@@ -393,6 +397,10 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
             }
         }
         pend = false;  // a refill still in flight at the end of a block is dropped; the window itself stays valid
+        if (lig < (nseq & (G - 1))) {  // the buffered tail of the sequence list
+            __builtin_amdgcn_wave_barrier();
+            sq[(nseq & ~(G - 1)) + lig] = sbuf[lig];
+        }
         const int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
         const int nlit = sumLL + extra;
         const bool rle = nseq == 1 && nlit <= 1 && (int)firstLL == nlit && firstOf - 3u == 1u;

@@ -74,6 +74,12 @@ class BlockEncoder:
             return int(r)
         return fn
 
+    def HookStats(self):
+        """(calls, device batches) served by the CustomEncoder hook of this encoder so far."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ctx.L.kc_s2_hook_stats(self._ctx.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def Close(self):
         self._ctx.close()
 

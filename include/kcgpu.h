@@ -173,8 +173,16 @@ kc_status kc_zstd_decode_units_dev(kc_ctx* ctx, const uint8_t* d_enc, const uint
 kc_status kc_zstd_decode_units_dict_dev(kc_ctx* ctx, const uint8_t* d_enc, const uint64_t* enc_off, uint32_t n_units, uint8_t* d_dst,
                                         const uint64_t* dst_off, uint32_t* status, const uint8_t* dict, uint64_t dict_len);
 /* Single-block form with the WriterCustomEncoder contract (s2/writer.go:1053-1064): no varint header;
- * returns bytes used, 0 = incompressible (store raw), <0 = fall back to the built-in encoder. */
+ * returns bytes used, 0 = incompressible (store raw), <0 = fall back to the built-in encoder.
+ * "The function should expect to be called concurrently" (writer.go:1058; s2.Writer calls it from one goroutine per block,
+ * writer.go:455-460): this entry point — and only this one — is safe to call from any number of host threads on ONE
+ * context.  Concurrent callers are micro-batched: the blocks that arrive while the previous batch is on the device share
+ * one H2D copy, one kernel launch and one D2H copy (pinned staging; KC_S2_HOOK_WAIT_US adds an optional collection window,
+ * KC_S2_HOOK_BATCH caps the blocks per launch, default 256).  A context serving this hook must not be used for other calls
+ * at the same time. */
 int64_t kc_s2_encode_block(kc_ctx* ctx, uint8_t* dst, uint64_t dst_cap, const uint8_t* src, uint64_t src_len);
+/* hook diagnostics: calls served and device batches run on this context so far */
+void kc_s2_hook_stats(const kc_ctx* ctx, uint64_t* calls, uint64_t* batches);
 
 /* ---- timing of the last call (HIP events recorded on the launch stream) ---- */
 typedef struct {
