@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <algorithm>
 
@@ -48,6 +49,16 @@ struct Pending {
 };
 
 
+// Host-side layout of one device batch.  Lives in the context: the H2D copies of its arrays are asynchronous, so the arrays must
+// outlive batch_begin (they are overwritten by the next batch of the same context, after batch_end synchronised the stream).
+struct Plan {
+    uint32_t n_units = 0, n_blocks = 0;
+    std::vector<uint32_t> blk0;       // n+1
+    std::vector<uint64_t> stage_off;  // n+1
+    std::vector<uint64_t> rel_off;    // n+1 unit offsets relative to the batch base
+    uint32_t seq_stride = 0, lit_stride = 0;
+};
+
 }  // namespace
 
 struct kc_ctx {
@@ -61,10 +72,13 @@ struct kc_ctx {
     bool predef_ready = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     kc_timings last = {0, 0, 0, 0, 0};
-    size_t max_batch_bytes = (size_t)8 << 30;  // input bytes per device batch (scratch is ~6x this)
+    size_t max_batch_bytes = (size_t)8 << 30;  // input bytes per device batch (scratch is ~6x this for full-size units)
+    uint64_t max_scratch_bytes = (uint64_t)160 << 30;  // scratch per device batch (tables + per-block strides), further capped by the free device memory
     int stream_mode = 0;             // set for the duration of kc_zstd_encode_streams_dev
     void* pend = nullptr;            // batch between kc_zstd_encode_units_dev_begin and _end (Pending)
     kc_ctx* chain_after = nullptr;   // pipelining: this context's match finder waits for that context's last one
+    void* hpipe = nullptr;           // pinned staging ring + streams of the pipelined host path (HostPipe), created on first use
+    Plan plan;                       // layout arrays of the batch in flight (sources of asynchronous H2D copies)
     std::once_flag hook_once;        // kc_s2_encode_block: micro-batcher of concurrent callers (S2Hook), created on first use
     void* hook = nullptr;
 };
@@ -86,7 +100,23 @@ kc_status ensure(kc_ctx* c, DevBuf& b, size_t bytes) {
     b.p = nullptr;
     b.cap = 0;
     size_t want = bytes + (bytes >> 3) + 256;
-    HIPCHK(c, hipMalloc(&b.p, want));
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e == hipErrorOutOfMemory) {  // try the exact size before giving up
+        (void)hipGetLastError();
+        want = bytes + 256;
+        e = hipMalloc(&b.p, want);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        b.p = nullptr;
+        if (e == hipErrorOutOfMemory) {
+            // not an error of the request: the device path cannot serve it now, the caller uses the reference encoder
+            c->err = "device memory exhausted (" + std::to_string(want >> 20) + " MiB of scratch wanted)";
+            return KC_ERR_UNSUPPORTED;
+        }
+        c->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return KC_ERR_HIP;
+    }
     b.cap = want;
     return KC_OK;
 }
@@ -94,6 +124,7 @@ kc_status ensure(kc_ctx* c, DevBuf& b, size_t bytes) {
 inline int bitsLen32(uint32_t v) { return v == 0 ? 0 : 32 - __builtin_clz(v); }
 
 void s2_hook_free(void* h);  // S2Hook (kc_s2_encode_block's micro-batcher), defined with it
+void host_pipe_free(void* h); // HostPipe (kc_zstd_encode_units / kc_s2_encode_blocks), defined with it
 
 }  // namespace
 
@@ -209,6 +240,7 @@ void kc_ctx_destroy(kc_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->pend) { delete (Pending*)c->pend; c->pend = nullptr; }
     if (c->hook) { s2_hook_free(c->hook); c->hook = nullptr; }
+    if (c->hpipe) { host_pipe_free(c->hpipe); c->hpipe = nullptr; }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -236,14 +268,6 @@ kc_status kc_last_timings(const kc_ctx* c, kc_timings* t) {
 // zstd device pipeline
 // ---------------------------------------------------------------------------------------
 namespace {
-
-struct Plan {
-    uint32_t n_units = 0, n_blocks = 0;
-    std::vector<uint32_t> blk0;       // n+1
-    std::vector<uint64_t> stage_off;  // n+1
-    std::vector<uint64_t> rel_off;    // n+1 unit offsets relative to the batch base
-    uint32_t seq_stride = 0, lit_stride = 0;
-};
 
 
 // Host-side construction of the dictionary-primed tables of betterFastEncoderDict.Reset
@@ -349,7 +373,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     hipStream_t st = c->stream;
     if (c->pend) { c->err = "a batch is already in flight on this context"; return KC_ERR_BAD_ARG; }
     const int bs = o->block_size;
-    Plan pl;
+    Plan& pl = c->plan;
     pl.n_units = n_units;
     pl.blk0.resize(n_units + 1);
     pl.stage_off.resize(n_units + 1);
@@ -643,19 +667,58 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
     uint64_t pos = 0;
     uint32_t i0 = 0;
     std::vector<uint64_t> tmp;
-    while (i0 < n_units) {
-        uint32_t i1 = i0;
-        const uint64_t cap_bytes = o->level == KC_SPEED_BETTER ? ((uint64_t)1 << 30) : c->max_batch_bytes;  // better: 4 MiB of tables per unit
-        const uint32_t cap_units = o->level == KC_SPEED_BETTER ? 16384u : 0xFFFFFFFFu;
-        while (i1 < n_units && (i1 == i0 || (unit_off[i1 + 1] - unit_off[i0] <= cap_bytes && i1 - i0 < cap_units))) i1++;
-        const uint32_t nb = i1 - i0;
-        tmp.resize(nb + 1);
-        uint64_t produced = 0;
-        s = run_batch(c, o, d_src, unit_off + i0, nb, d_dst + pos, dst_cap - pos, tmp.data(), &produced);
-        if (s != KC_OK) return s;
-        for (uint32_t k = 0; k <= nb; k++) out_off[i0 + k] = pos + tmp[k];
-        pos += produced;
-        i0 = i1;
+    // A batch is bounded by its input bytes AND by the device scratch it needs: tables are per unit, sequences / literals /
+    // staging are per block at a fixed stride whatever the block's actual length, so many small units need far more than the
+    // "~6x input" of full-size units (1M x 4 KiB units at SpeedDefault would ask for hundreds of GiB in one batch).
+    const uint64_t bsz = (uint64_t)o->block_size;
+    const uint64_t table_b = o->level == KC_SPEED_BETTER ? kc_zbetter_table_bytes() : (o->level == KC_SPEED_DEFAULT ? kc_zdfast_table_bytes() : kc_zfast_table_bytes());
+    const uint64_t per_block = 2 * (bsz / 4 + 8) * 8 + (bsz + 64) + sizeof(KcBlkMeta);
+    const uint64_t hist0 = (o->dict != nullptr) ? o->dict_len : 0;
+    auto unit_scratch = [&](uint64_t len) -> uint64_t {
+        const uint64_t blocks = (len + bsz - 1) / bsz;
+        const uint64_t enc = ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)len) + 15) & ~(uint64_t)15;
+        return table_b + blocks * per_block + enc + (hist0 ? hist0 + len : 0) + 64;
+    };
+    uint64_t budget = c->max_scratch_bytes;
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            uint64_t held = 0;  // what this context already owns is re-used
+            const DevBuf* bufs[] = {&c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->tables, &c->work};
+            for (const DevBuf* b : bufs) held += b->cap;
+            const uint64_t avail = (uint64_t)((double)(fr + held) * 0.85);
+            if (avail < budget) budget = avail;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    for (int attempt = 0;; attempt++) {
+        bool oom = false;
+        while (i0 < n_units) {
+            uint32_t i1 = i0;
+            const uint64_t cap_bytes = o->level == KC_SPEED_BETTER ? ((uint64_t)1 << 30) : c->max_batch_bytes;  // better: 4 MiB of tables per unit
+            const uint32_t cap_units = o->level == KC_SPEED_BETTER ? 16384u : 0xFFFFFFFFu;
+            uint64_t scratch = 0;
+            while (i1 < n_units) {
+                const uint64_t us = unit_scratch(unit_off[i1 + 1] - unit_off[i1]);
+                // ensure() over-allocates by 1/8
+                if (i1 > i0 && (unit_off[i1 + 1] - unit_off[i0] > cap_bytes || i1 - i0 >= cap_units || (scratch + us) + ((scratch + us) >> 3) > budget)) break;
+                scratch += us;
+                i1++;
+            }
+            const uint32_t nb = i1 - i0;
+            tmp.resize(nb + 1);
+            uint64_t produced = 0;
+            s = run_batch(c, o, d_src, unit_off + i0, nb, d_dst + pos, dst_cap - pos, tmp.data(), &produced);
+            if (s == KC_ERR_UNSUPPORTED && c->err.compare(0, 23, "device memory exhausted") == 0 && nb > 1 && attempt < 6) { oom = true; break; }
+            if (s != KC_OK) return s;
+            for (uint32_t k = 0; k <= nb; k++) out_off[i0 + k] = pos + tmp[k];
+            pos += produced;
+            i0 = i1;
+        }
+        if (!oom) break;
+        budget /= 2;  // another process took device memory since hipMemGetInfo: retry this batch at half the size
+        c->err.clear();
     }
     if (n_units == 0) out_off[0] = 0;
     return KC_OK;
@@ -713,16 +776,228 @@ kc_status kc_zstd_encode_streams_dev(kc_ctx* c, const kc_zstd_opts* o, const uin
     return s;
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// Host-buffer path (what the cgo shim calls): a three-stage pipeline over sub-batches —
+//   stager thread : pageable source -> pinned slot (parallel memcpy) -> device (copy stream)
+//   caller thread : the device encode of the sub-batch (context stream)
+//   drainer thread: device -> pinned slot (copy-back stream) -> caller's dst (parallel memcpy)
+// so the PCIe transfers and the host copies of sub-batch k+1 / k-1 run under the kernels of sub-batch k.
+// Two slots per direction; the reference's own threading seam is EncodeAll being safe for concurrent use
+// (zstd/encoder.go:722-729) — here the concurrency is inside one call.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct HostPipe {
+    uint8_t* pin_in[2] = {nullptr, nullptr};
+    uint8_t* pin_out[2] = {nullptr, nullptr};
+    size_t in_cap = 0, out_cap = 0;
+    DevBuf d_in[2], d_out[2];
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    ~HostPipe() {
+        for (int i = 0; i < 2; i++) {
+            if (pin_in[i]) (void)hipHostFree(pin_in[i]);
+            if (pin_out[i]) (void)hipHostFree(pin_out[i]);
+            if (d_in[i].p) (void)hipFree(d_in[i].p);
+            if (d_out[i].p) (void)hipFree(d_out[i].p);
+        }
+        if (s_h2d) (void)hipStreamDestroy(s_h2d);
+        if (s_d2h) (void)hipStreamDestroy(s_d2h);
+    }
+};
+
+void host_pipe_free(void* h) { delete (HostPipe*)h; }
+
+int host_copy_threads() {
+    static int n = [] {
+        int t = (int)std::thread::hardware_concurrency();
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2 quota: more runnable threads only get throttled
+            long long q = 0, per = 0;
+            char qs[32];
+            if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0 && per > 0) {
+                q = atoll(qs);
+                const int lim = (int)((q + per - 1) / per);
+                if (lim >= 1 && lim < t) t = lim;
+            }
+            fclose(f);
+        }
+        if (const char* e = getenv("KC_HOST_COPY_THREADS")) t = atoi(e);
+        return t < 1 ? 1 : (t > 16 ? 16 : t);
+    }();
+    return n;
+}
+
+void parallel_memcpy(uint8_t* dst, const uint8_t* src, size_t n, int threads) {
+    if (n < ((size_t)8 << 20) || threads <= 1) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((n / (size_t)threads) + 4095) & ~(size_t)4095;
+    for (int t = 0; t < threads; t++) {
+        const size_t a = (size_t)t * per;
+        if (a >= n) break;
+        const size_t len = a + per < n ? per : n - a;
+        th.emplace_back([=] { memcpy(dst + a, src + a, len); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// enc(d_in, rel_off, n, d_out, out_cap, out_off_rel) runs one sub-batch on the device (synchronous); max_out(len) bounds a unit's output.
+template <class EncFn, class MaxFn>
+kc_status host_pipeline(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint8_t* dst, uint64_t dst_cap,
+                        uint64_t* out_off, uint64_t sub_bytes, EncFn enc, MaxFn max_out) {
+    // ---- cut into sub-batches of ~sub_bytes of input ----
+    std::vector<uint32_t> cut{0};
+    std::vector<uint64_t> need;  // device output capacity per sub-batch
+    {
+        uint64_t acc = 0, nd = 0;
+        for (uint32_t i = 0; i < n_units; i++) {
+            const uint64_t len = unit_off[i + 1] - unit_off[i];
+            if (i > cut.back() && acc + len > sub_bytes) { cut.push_back(i); need.push_back(nd); acc = 0; nd = 0; }
+            acc += len;
+            nd += ((uint64_t)max_out(len) + 15) & ~(uint64_t)15;
+        }
+        cut.push_back(n_units);
+        need.push_back(nd);
+    }
+    const size_t nsub = cut.size() - 1;
+    uint64_t max_in = 0, max_need = 0;
+    for (size_t k = 0; k < nsub; k++) {
+        max_in = std::max<uint64_t>(max_in, unit_off[cut[k + 1]] - unit_off[cut[k]]);
+        max_need = std::max<uint64_t>(max_need, need[k]);
+    }
+    if (!c->hpipe) c->hpipe = new HostPipe();
+    HostPipe* hp = (HostPipe*)c->hpipe;
+    if (!hp->s_h2d) {
+        HIPCHK(c, hipStreamCreateWithFlags(&hp->s_h2d, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&hp->s_d2h, hipStreamNonBlocking));
+    }
+    if (hp->in_cap < max_in + 64) {
+        for (int i = 0; i < 2; i++) { if (hp->pin_in[i]) (void)hipHostFree(hp->pin_in[i]); hp->pin_in[i] = nullptr; }
+        hp->in_cap = 0;
+        for (int i = 0; i < 2; i++) HIPCHK(c, hipHostMalloc((void**)&hp->pin_in[i], max_in + 64, hipHostMallocDefault));
+        hp->in_cap = max_in + 64;
+    }
+    if (hp->out_cap < max_need + 64) {
+        for (int i = 0; i < 2; i++) { if (hp->pin_out[i]) (void)hipHostFree(hp->pin_out[i]); hp->pin_out[i] = nullptr; }
+        hp->out_cap = 0;
+        for (int i = 0; i < 2; i++) HIPCHK(c, hipHostMalloc((void**)&hp->pin_out[i], max_need + 64, hipHostMallocDefault));
+        hp->out_cap = max_need + 64;
+    }
+    kc_status s;
+    for (int i = 0; i < 2; i++)
+        if ((s = ensure(c, hp->d_in[i], max_in + 64)) || (s = ensure(c, hp->d_out[i], max_need + 64))) return s;
+
+    const int T = host_copy_threads();
+    std::mutex m;
+    std::condition_variable cv;
+    size_t staged = 0, encoded = 0, drained = 0;  // sub-batches that passed each stage
+    bool fail = false;
+    std::string ferr;
+    std::vector<uint64_t> produced(nsub, 0), pos(nsub + 1, 0);
+    const int dev = c->device;
+
+    std::thread stager([&] {
+        (void)hipSetDevice(dev);
+        for (size_t k = 0; k < nsub; k++) {
+            {   // slot k&1 was last read by the encode of sub-batch k-2
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return fail || k < 2 || encoded >= k - 1; });
+                if (fail) return;
+            }
+            const uint64_t a = unit_off[cut[k]], len = unit_off[cut[k + 1]] - a;
+            parallel_memcpy(hp->pin_in[k & 1], src + a, (size_t)len, T);
+            hipError_t e = hipMemcpyAsync(hp->d_in[k & 1].p, hp->pin_in[k & 1], (size_t)len, hipMemcpyHostToDevice, hp->s_h2d);
+            if (e == hipSuccess) e = hipStreamSynchronize(hp->s_h2d);
+            std::lock_guard<std::mutex> lk(m);
+            if (e != hipSuccess) { fail = true; ferr = std::string("host pipeline H2D: ") + hipGetErrorString(e); }
+            else staged = k + 1;
+            cv.notify_all();
+            if (fail) return;
+        }
+    });
+    std::thread drainer([&] {
+        (void)hipSetDevice(dev);
+        for (size_t k = 0; k < nsub; k++) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return fail || encoded > k; });
+                if (fail) return;
+            }
+            hipError_t e = hipMemcpyAsync(hp->pin_out[k & 1], hp->d_out[k & 1].p, (size_t)produced[k], hipMemcpyDeviceToHost, hp->s_d2h);
+            if (e == hipSuccess) e = hipStreamSynchronize(hp->s_d2h);
+            if (e == hipSuccess) parallel_memcpy(dst + pos[k], hp->pin_out[k & 1], (size_t)produced[k], T);
+            std::lock_guard<std::mutex> lk(m);
+            if (e != hipSuccess) { fail = true; ferr = std::string("host pipeline D2H: ") + hipGetErrorString(e); }
+            else drained = k + 1;
+            cv.notify_all();
+            if (fail) return;
+        }
+    });
+    kc_status rs = KC_OK;
+    std::vector<uint64_t> rel, oo;
+    for (size_t k = 0; k < nsub && rs == KC_OK; k++) {
+        {   // input staged; output slot k&1 drained from sub-batch k-2
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return fail || (staged > k && (k < 2 || drained >= k - 1)); });
+            if (fail) break;
+        }
+        const uint32_t u0 = cut[k], nu = cut[k + 1] - cut[k];
+        rel.resize(nu + 1);
+        oo.resize(nu + 1);
+        for (uint32_t i = 0; i <= nu; i++) rel[i] = unit_off[u0 + i] - unit_off[u0];
+        rs = enc((const uint8_t*)hp->d_in[k & 1].p, rel.data(), nu, (uint8_t*)hp->d_out[k & 1].p, need[k], oo.data());
+        std::lock_guard<std::mutex> lk(m);
+        if (rs != KC_OK) { fail = true; }
+        else if (pos[k] + oo[nu] > dst_cap) { fail = true; rs = KC_ERR_DST_TOO_SMALL; c->err = "dst_cap too small"; }
+        else {
+            produced[k] = oo[nu];
+            pos[k + 1] = pos[k] + oo[nu];
+            for (uint32_t i = 0; i <= nu; i++) out_off[u0 + i] = pos[k] + oo[i];
+            encoded = k + 1;
+        }
+        cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return fail || drained == nsub; });
+        cv.notify_all();
+    }
+    stager.join();
+    drainer.join();
+    if (rs != KC_OK) return rs;
+    if (fail) { if (!ferr.empty()) c->err = ferr; return KC_ERR_HIP; }
+    return KC_OK;
+}
+
+uint64_t host_sub_bytes() {
+    if (const char* e = getenv("KC_HOST_PIPE_MIB")) { const long v = atol(e); if (v >= 16) return (uint64_t)v << 20; }
+    return (uint64_t)1 << 30;
+}
+
+}  // namespace
+
+extern "C" {
+
 kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units,
                                uint8_t* dst, uint64_t dst_cap, uint64_t* out_off) {
     if (!c || !o || !unit_off || !out_off || (n_units && (!src || !dst))) return KC_ERR_BAD_ARG;
     c->err.clear();
+    kc_status s = check_supported(c, o);  // before any byte moves: an unsupported request must not pay the PCIe copy
+    if (s != KC_OK) return s;
     HIPCHK(c, hipSetDevice(c->device));
     if (n_units == 0) { out_off[0] = 0; return KC_OK; }
+    if ((s = validate_units(c, o, unit_off, n_units)) != KC_OK) return s;
     const uint64_t total = unit_off[n_units] - unit_off[0];
+    const uint64_t sub = host_sub_bytes();
+    if (total >= 2 * sub && !getenv("KC_HOST_SERIAL")) {
+        auto enc = [&](const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
+            return kc_zstd_encode_units_dev(c, o, d_in, rel, nu, d_out, cap, oo);
+        };
+        auto mx = [&](uint64_t len) { return (uint64_t)kc_zstd_max_encoded_size(o, (int64_t)len); };
+        return host_pipeline(c, src, unit_off, n_units, dst, dst_cap, out_off, sub, enc, mx);
+    }
     uint64_t need = 0;
     for (uint32_t i = 0; i < n_units; i++) need += ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)(unit_off[i + 1] - unit_off[i])) + 15) & ~(uint64_t)15;
-    kc_status s;
     if ((s = ensure(c, c->tmp_src, total + 64)) || (s = ensure(c, c->tmp_dst, need + 64))) return s;
     HIPCHK(c, hipMemcpyAsync(c->tmp_src.p, src + unit_off[0], total, hipMemcpyHostToDevice, c->stream));
     std::vector<uint64_t> rel(n_units + 1);
@@ -1027,7 +1302,18 @@ kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk
     c->err.clear();
     HIPCHK(c, hipSetDevice(c->device));
     if (n == 0) { out_off[0] = 0; return KC_OK; }
+    for (uint32_t i = 0; i < n; i++) {  // before any byte moves
+        if (blk_off[i + 1] < blk_off[i]) { c->err = "blk_off not ascending"; return KC_ERR_BAD_ARG; }
+        if (blk_off[i + 1] - blk_off[i] > (uint64_t)(4 << 20)) { c->err = "S2 block larger than 4 MiB (s2.maxBlockSize) not served by the device path"; return KC_ERR_UNSUPPORTED; }
+    }
     const uint64_t total = blk_off[n] - blk_off[0];
+    if (total >= 2 * host_sub_bytes() && !getenv("KC_HOST_SERIAL")) {
+        auto enc = [&](const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
+            return kc_s2_encode_blocks_dev(c, d_in, rel, nu, d_out, cap, oo);
+        };
+        auto mx = [&](uint64_t len) { return (uint64_t)kc_s2_max_encoded_len((int64_t)len); };
+        return host_pipeline(c, src, blk_off, n, dst, dst_cap, out_off, host_sub_bytes(), enc, mx);
+    }
     uint64_t need = 0;
     for (uint32_t i = 0; i < n; i++) need += ((uint64_t)kc_s2_max_encoded_len((int64_t)(blk_off[i + 1] - blk_off[i])) + 15) & ~(uint64_t)15;
     kc_status s;

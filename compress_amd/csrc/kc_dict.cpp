@@ -203,8 +203,8 @@ extern "C" int kc_zstd_opts_dict(kc_zstd_opts* o, const uint8_t* blob, uint64_t 
     o->dict_huf_len = nw;
     o->dict_huf_log = tableLog;
 
-    // ---- three FSE table descriptions: offsets (<= 31, log <= 8... the reference accepts log <= 9), match lengths, literal lengths ----
-    const int maxSyms[3] = {31, 52, 35};
+    // ---- three FSE table descriptions: offsets (maxOffsetLengthSymbol = 30, zstd/fse_predefined.go:45), match lengths (52), literal lengths (35) ----
+    const int maxSyms[3] = {30, 52, 35};
     for (int t = 0; t < 3; t++) {
         int16_t norm[256];
         int ns = 0, tl = 0;

@@ -140,7 +140,7 @@ __constant__ uint32_t kMLBase[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 // One sequence table according to its mode (blockdec.go:560-640).  Lane 0 only.  Returns bytes consumed (>= 0) or -1.
 __device__ int zd_seq_table(int mode, int kind, const uint8_t* p, int n, ZdShared& S) {
     ZdSym* dt = kind == 0 ? S.ll : (kind == 1 ? S.of : S.ml);
-    const int maxSym = kind == 0 ? 35 : (kind == 1 ? 31 : 52);
+    const int maxSym = kind == 0 ? 35 : (kind == 1 ? 30 : 52);  // maxOffsetLengthSymbol = 30 (zstd/fse_predefined.go:45)
     const int maxLog = kind == 1 ? 8 : 9;
     if (mode == 0) {
         const int16_t* src = kind == 0 ? kLLNorm : (kind == 1 ? kOFNorm : kMLNorm);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void kc_zstd_decode_kernel(KcZstdDecParams P) {
     bool checksum = false;
     // ---- frame header (framedec.go:65-200), identical on all lanes ----
     if (n == 0) {  // nothing was emitted for an empty unit (WithZeroFrames(false))
-        if (lane == 0) { P.status[u] = want == 0 ? 0u : 2u; P.crc_stored[u] = 0xFFFFFFFFu; }
+        if (lane == 0) { P.status[u] = want == 0 ? 0u : 2u; P.crc_stored[u] = 0xFFFFFFFFu; P.has_crc[u] = 0u; }
         return;
     }
     if (n < 6 || ld32(in) != 0xFD2FB528u) err = 1;
@@ -269,7 +269,12 @@ __global__ __launch_bounds__(64) void kc_zstd_decode_kernel(KcZstdDecParams P) {
         const int bn = size;
         p += size;
         // ---- literals section (blockdec.go:275-460) ----
+        if (bn < 2) { err = 6; break; }  // ErrBlockTooSmall (blockdec.go:233): nothing below is read past the block
         const int ltype = b[0] & 3, sf = (b[0] >> 2) & 3;
+        {
+            const int need = ltype < 2 ? ((sf & 1) == 0 ? 1 : (sf == 1 ? 2 : 3)) : (sf < 2 ? 3 : (sf == 2 ? 4 : 5));
+            if (need > bn) { err = 6; break; }
+        }
         int hdr = 0, regen = 0, comp = 0;
         bool four = false;
         const uint8_t* L = nullptr;  // where the literals of this block can be read
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(64) void kc_zstd_decode_kernel(KcZstdDecParams P) {
                 int e2 = 0;
                 for (int i = 0; i < cnt && !e2; i++) {
                     const ZdSym cl = S.ll[llS], co = S.of[ofS], cm = S.ml[mlS];
-                    if (cl.sym > 35 || cm.sym > 52 || co.sym > 31) { e2 = 14; break; }
+                    if (cl.sym > 35 || cm.sym > 52 || co.sym > 30) { e2 = 14; break; }
                     uint32_t ofVal;
                     if (co.sym <= 24) ofVal = (1u << co.sym) + br.read(co.sym);
                     else { const uint32_t hi = br.read(co.sym - 16); const uint32_t lo = br.read(16); ofVal = (1u << co.sym) + ((hi << 16) | lo); }

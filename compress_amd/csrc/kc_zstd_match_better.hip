@@ -44,8 +44,10 @@ template <bool DICT>
 __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams P, uint8_t* __restrict__ tables, uint32_t n_launch) {
     constexpr int G = ZBG;
     constexpr int UPW = 64 / G;
+    __shared__ uint64_t sbuf_all[UPW * G];  // per unit: the last (nseq mod G) sequences
     const int lane = (int)threadIdx.x;
     const int lig = lane % G, grp = lane / G;
+    uint64_t* const sbuf = sbuf_all + grp * G;
     const uint32_t ui = blockIdx.x * UPW + (uint32_t)grp;
     const bool gact = ui < n_launch;
     const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
@@ -83,9 +85,14 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
         bool rleBlock = false;
         auto emit = [&](int ll, int ml3, uint32_t of) {
             if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
-            if (lig == 0) sq[nseq] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
+            if (lig == 0) sbuf[nseq & (G - 1)] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
             nseq++;
             sumLL += ll;
+            if ((nseq & (G - 1)) == 0) {  // group-uniform: G sequences buffered in LDS -> one coalesced 64-byte store
+                __builtin_amdgcn_wave_barrier();
+                sq[nseq - G + lig] = sbuf[lig];
+                __builtin_amdgcn_wave_barrier();
+            }
         };
         // dense re-indexing of [from, s-1) every 2nd byte (:438-447 / :157-165), group-parallel with in-order chaining
         auto reindex = [&](int from, int upto /* exclusive: s-1 */) {
@@ -280,6 +287,10 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     if (s >= sLimit) { fin = true; break; }
                 }
             }
+        }
+        if (lig < (nseq & (G - 1))) {  // the buffered tail of the sequence list
+            __builtin_amdgcn_wave_barrier();
+            sq[(nseq & ~(G - 1)) + lig] = sbuf[lig];
         }
         int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
         int nlit = sumLL + extra;

@@ -25,8 +25,10 @@
 template <int G>
 __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P, uint32_t* __restrict__ tables, uint32_t n_launch) {
     constexpr int UPW = 64 / G;
+    __shared__ uint64_t sbuf_all[UPW * G];  // per unit: the last (nseq mod G) sequences
     const int lane = (int)threadIdx.x;
     const int lig = lane % G, grp = lane / G;
+    uint64_t* const sbuf = sbuf_all + grp * G;
     const uint32_t ui = blockIdx.x * UPW + (uint32_t)grp;
     const bool gact = ui < n_launch;
     const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
@@ -62,9 +64,14 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
         uint32_t firstLL = 0, firstOf = 0;
         auto emit = [&](int ll, int ml3, uint32_t of) {
             if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
-            if (lig == 0) sq[nseq] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
+            if (lig == 0) sbuf[nseq & (G - 1)] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
             nseq++;
             sumLL += ll;
+            if ((nseq & (G - 1)) == 0) {  // group-uniform: G sequences buffered in LDS -> one coalesced 64-byte store (an 8-byte scattered store is a DRAM write each)
+                __builtin_amdgcn_wave_barrier();
+                sq[nseq - G + lig] = sbuf[lig];
+                __builtin_amdgcn_wave_barrier();
+            }
         };
         if (srcLen >= 16) {  // minNonLiteralBlockSize
             const int sLimit = blkEnd - 10;  // inputMargin = 8 + 2
@@ -229,6 +236,10 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
                     if (s >= sLimit) { fin = true; break; }
                 }
             }
+        }
+        if (lig < (nseq & (G - 1))) {  // the buffered tail of the sequence list
+            __builtin_amdgcn_wave_barrier();
+            sq[(nseq & ~(G - 1)) + lig] = sbuf[lig];
         }
         const int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
         const int nlit = sumLL + extra;

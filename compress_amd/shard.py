@@ -100,3 +100,21 @@ class FrameGather:
         if self.rank == self.root:
             return self._out[:self._offs[-1]], self._offs
         return None
+
+
+def write_shard(prefix, rank, buf, nbytes, out_off=None):
+    """No-gather mode for consumers that only need the shards: rank r writes its own frames to `<prefix>.<r:05d>.zst`
+    (and, when given, the frame offsets of its units to `<prefix>.<r:05d>.idx` as little-endian uint64).  zstd frames are
+    concatenable (zstd/encoder.go:719-720) and the shards are contiguous unit ranges, so `cat <prefix>.*.zst` in rank order is
+    the stream rank 0 would have gathered; nothing crosses xGMI."""
+    import numpy as np
+    path = "%s.%05d.zst" % (prefix, rank)
+    data = buf[:nbytes]
+    if hasattr(data, "cpu"):
+        data = data.cpu().numpy()
+    with open(path, "wb") as f:
+        f.write(memoryview(np.ascontiguousarray(data, dtype=np.uint8)))
+    if out_off is not None:
+        with open("%s.%05d.idx" % (prefix, rank), "wb") as f:
+            f.write(np.ascontiguousarray(out_off, dtype="<u8").tobytes())
+    return path

@@ -327,7 +327,7 @@ inline bool loadDict(const uint8_t* b, size_t len, DictO* d, huff0::Scratch* lit
     litEncStore->Reuse = huff0::ReusePolicyMust;
     d->litEnc = litEncStore;
     ByteReader br{b + 8 + used, (int)(len - 8) - used};
-    const int maxTableSymbol[3] = {31, 52, 35};  // tableOffsets, tableMatchLengths, tableLiteralLengths order of dict.go:120-128
+    const int maxTableSymbol[3] = {30, 52, 35};  // maxOffsetLengthSymbol = 30 (zstd/fse_predefined.go:45)  // tableOffsets, tableMatchLengths, tableLiteralLengths order of dict.go:120-128
     for (int t = 0; t < 3; t++) {
         NCount nc;
         if (!readNCount(&br, &nc, 9, maxTableSymbol[t], true)) return false;

@@ -1,0 +1,108 @@
+package s2gpu
+
+// Run with -tags noasm: the parity target is the portable Go encoder (encodeBlockGo / encodeBlockGo64K).
+
+import (
+	"bytes"
+	"crypto/sha256"
+	"encoding/hex"
+	"fmt"
+	"os"
+	"sort"
+	"testing"
+
+	"github.com/klauspost/compress/kcgpu"
+	"github.com/klauspost/compress/s2"
+)
+
+// TestBitExact: EncodeBlocks == N x s2.Encode(nil, block).
+func TestBitExact(t *testing.T) {
+	x, err := NewCtx(0)
+	if err != nil {
+		t.Skip(err)
+	}
+	defer x.Close()
+	for _, kind := range []byte{'J', 'T', 'M', 'H'} {
+		data, err := kcgpu.CorpusFill(kind, kcgpu.Seed(kind), 0, 128, 64<<10)
+		if err != nil {
+			t.Fatal(err)
+		}
+		off := kcgpu.Offsets(128, 64<<10)
+		dst := make([]byte, 128*(s2.MaxEncodedLen(64<<10)+16)+64)
+		out, outOff, err := EncodeBlocks(x, data, off, dst)
+		if err != nil {
+			t.Fatal(err)
+		}
+		for i := 0; i < 128; i++ {
+			want := s2.Encode(nil, data[off[i]:off[i+1]])
+			if !bytes.Equal(out[outOff[i]:outOff[i+1]], want) {
+				t.Fatalf("corpus %c block %d: GPU block differs from s2.Encode", kind, i)
+			}
+		}
+	}
+}
+
+// TestCustomEncoderWriter: an s2.Writer that encodes its blocks through the hook writes the same stream as the
+// built-in encoder, with the writer calling the hook from WriterConcurrency goroutines at once (s2/writer.go:455-460).
+func TestCustomEncoderWriter(t *testing.T) {
+	x, err := NewCtx(0)
+	if err != nil {
+		t.Skip(err)
+	}
+	defer x.Close()
+	data, err := kcgpu.CorpusFill('J', kcgpu.SeedJ, 0, 512, 64<<10)
+	if err != nil {
+		t.Fatal(err)
+	}
+	var want, got bytes.Buffer
+	w := s2.NewWriter(&want, s2.WriterBlockSize(64<<10), s2.WriterConcurrency(16))
+	w.Write(data)
+	w.Close()
+	g := s2.NewWriter(&got, s2.WriterBlockSize(64<<10), s2.WriterConcurrency(16), s2.WriterCustomEncoder(CustomEncoder(x)))
+	g.Write(data)
+	g.Close()
+	if !bytes.Equal(want.Bytes(), got.Bytes()) {
+		t.Fatalf("stream through the GPU hook (%d B) differs from the built-in encoder's (%d B)", got.Len(), want.Len())
+	}
+}
+
+// TestWriteGolden: sha256 of the REFERENCE's s2.Encode output on the seeded corpora, appended to
+// tests/golden/reference_sha256.txt (see zstdgpu.TestWriteGolden).
+func TestWriteGolden(t *testing.T) {
+	if os.Getenv("KC_WRITE_GOLDEN") == "" {
+		t.Skip("set KC_WRITE_GOLDEN=1 to write tests/golden/reference_sha256.txt")
+	}
+	path := "../../../tests/golden/reference_sha256.txt"
+	lines := map[string]string{}
+	if old, err := os.ReadFile(path); err == nil {
+		for _, l := range bytes.Split(old, []byte("\n")) {
+			f := bytes.Fields(l)
+			if len(f) == 2 {
+				lines[string(f[0])] = string(f[1])
+			}
+		}
+	}
+	for _, kind := range []byte{'J', 'T', 'M', 'H'} {
+		data, err := kcgpu.CorpusFill(kind, kcgpu.Seed(kind), 0, 128, 64<<10)
+		if err != nil {
+			t.Fatal(err)
+		}
+		h := sha256.New()
+		for i := 0; i < 128; i++ {
+			h.Write(s2.Encode(nil, data[i*(64<<10):(i+1)*(64<<10)]))
+		}
+		lines[fmt.Sprintf("s2.%c.128x65536", kind)] = hex.EncodeToString(h.Sum(nil))
+	}
+	names := make([]string, 0, len(lines))
+	for n := range lines {
+		names = append(names, n)
+	}
+	sort.Strings(names)
+	var b bytes.Buffer
+	for _, n := range names {
+		fmt.Fprintf(&b, "%s %s\n", n, lines[n])
+	}
+	if err := os.WriteFile(path, b.Bytes(), 0o644); err != nil {
+		t.Fatal(err)
+	}
+}

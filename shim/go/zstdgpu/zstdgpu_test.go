@@ -2,45 +2,196 @@ package zstdgpu
 
 import (
 	"bytes"
+	"crypto/sha256"
+	"encoding/hex"
+	"fmt"
 	"os"
 	"path/filepath"
+	"sort"
 	"testing"
 
+	"github.com/klauspost/compress/kcgpu"
 	"github.com/klauspost/compress/zstd"
 )
 
-// TestBitExact asserts that the GPU frames equal the reference encoder's frames (the parity
-// criterion of this project) over the reference's shared fixtures, cut into 128 KiB units.
+var levels = []zstd.EncoderLevel{zstd.SpeedFastest, zstd.SpeedDefault, zstd.SpeedBetterCompression}
+
+func cut(data []byte, unit int) []uint64 {
+	var off []uint64
+	for p := 0; p < len(data); p += unit {
+		off = append(off, uint64(p))
+	}
+	return append(off, uint64(len(data)))
+}
+
+// checkUnits asserts gpu.EncodeUnits == N x ref.EncodeAll, frame by frame.
+func checkUnits(t *testing.T, name string, gpu *Encoder, ref *zstd.Encoder, data []byte, off []uint64) {
+	t.Helper()
+	out, outOff, err := gpu.EncodeUnits(data, off, nil)
+	if err != nil {
+		t.Fatal(err)
+	}
+	for i := 0; i+1 < len(off); i++ {
+		want := ref.EncodeAll(data[off[i]:off[i+1]], nil)
+		if !bytes.Equal(out[outOff[i]:outOff[i+1]], want) {
+			t.Fatalf("%s unit %d: GPU frame (%d B) differs from the reference's (%d B)", name, i, outOff[i+1]-outOff[i], len(want))
+		}
+	}
+}
+
+// TestBitExact: GPU frames == the reference encoder's frames (the parity criterion of this project) over the
+// reference's shared fixtures cut into 128 KiB units and over the seeded corpora, at every level the device serves.
 func TestBitExact(t *testing.T) {
 	files, _ := filepath.Glob("../../../testdata/*")
-	for _, lvl := range []zstd.EncoderLevel{zstd.SpeedFastest} {
+	more, _ := filepath.Glob("../../../tests/golden/ref_inputs/*")
+	files = append(files, more...)
+	for _, lvl := range levels {
 		gpu, err := New(0, WithEncoderLevel(lvl))
 		if err != nil {
 			t.Fatal(err)
 		}
-		ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(lvl))
+		ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(1))
 		for _, f := range files {
 			data, err := os.ReadFile(f)
-			if err != nil || len(data) == 0 {
+			if err != nil || len(data) == 0 || filepath.Ext(f) == ".zip" {
 				continue
 			}
-			var off []uint64
-			for p := 0; p < len(data); p += 128 << 10 {
-				off = append(off, uint64(p))
-			}
-			off = append(off, uint64(len(data)))
-			out, outOff, err := gpu.EncodeUnits(data, off, nil)
+			checkUnits(t, fmt.Sprintf("%s level %v", f, lvl), gpu, ref, data, cut(data, 128<<10))
+		}
+		for _, kind := range []byte{'T', 'H', 'J', 'M'} {
+			data, err := kcgpu.CorpusFill(kind, kcgpu.Seed(kind), 0, 96, 128<<10)
 			if err != nil {
 				t.Fatal(err)
 			}
-			for i := 0; i+1 < len(off); i++ {
-				want := ref.EncodeAll(data[off[i]:off[i+1]], nil)
-				if !bytes.Equal(out[outOff[i]:outOff[i+1]], want) {
-					t.Fatalf("%s unit %d level %v: GPU frame differs from reference", f, i, lvl)
-				}
-			}
+			checkUnits(t, fmt.Sprintf("corpus %c level %v", kind, lvl), gpu, ref, data, kcgpu.Offsets(96, 128<<10))
+			// ragged units: sizes that are not multiples of anything, some above one block
+			checkUnits(t, fmt.Sprintf("corpus %c ragged level %v", kind, lvl), gpu, ref, data[:3000000], cut(data[:3000000], 99991))
 		}
 		gpu.Close()
 		ref.Close()
+	}
+}
+
+// TestBitExactDict: WithEncoderDictRaw and WithEncoderDict (the reference's d0.dict fixture when present).
+func TestBitExactDict(t *testing.T) {
+	raw, err := kcgpu.CorpusFill('T', kcgpu.SeedD, 0, 1, 64<<10)
+	if err != nil {
+		t.Fatal(err)
+	}
+	data, _ := kcgpu.CorpusFill('M', kcgpu.SeedM, 0, 64, 128<<10)
+	for _, lvl := range levels {
+		gpu, err := New(0, WithEncoderLevel(lvl), WithEncoderDictRaw(1, raw))
+		if err != nil {
+			t.Fatal(err)
+		}
+		ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(1), zstd.WithEncoderDictRaw(1, raw))
+		checkUnits(t, fmt.Sprintf("raw dict level %v", lvl), gpu, ref, data, kcgpu.Offsets(64, 128<<10))
+		checkUnits(t, fmt.Sprintf("raw dict small units level %v", lvl), gpu, ref, data[:400000], cut(data[:400000], 7001))
+		gpu.Close()
+		ref.Close()
+	}
+	full, err := os.ReadFile("../../../tests/golden/dict/d0.dict")
+	if err != nil {
+		t.Skip("d0.dict fixture not found")
+	}
+	for _, lvl := range levels {
+		gpu, err := New(0, WithEncoderLevel(lvl), WithEncoderDict(full))
+		if err != nil {
+			t.Fatal(err)
+		}
+		ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(1), zstd.WithEncoderDict(full))
+		checkUnits(t, fmt.Sprintf("full dict level %v", lvl), gpu, ref, data[:1<<20], cut(data[:1<<20], 20011))
+		gpu.Close()
+		ref.Close()
+	}
+}
+
+// TestBitExactStreams: EncodeStreams == NewWriter(w).Write(unit); Close() per unit.
+func TestBitExactStreams(t *testing.T) {
+	data, err := kcgpu.CorpusFill('T', kcgpu.SeedT, 0, 32, 128<<10)
+	if err != nil {
+		t.Fatal(err)
+	}
+	for _, lvl := range levels {
+		gpu, err := New(0, WithEncoderLevel(lvl))
+		if err != nil {
+			t.Fatal(err)
+		}
+		ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(1))
+		off := cut(data, 300001)
+		out, outOff, err := gpu.EncodeStreams(data, off, nil)
+		if err != nil {
+			t.Fatal(err)
+		}
+		for i := 0; i+1 < len(off); i++ {
+			var sink bytes.Buffer
+			ref.Reset(&sink)
+			ref.Write(data[off[i]:off[i+1]])
+			ref.Close()
+			if !bytes.Equal(out[outOff[i]:outOff[i+1]], sink.Bytes()) {
+				t.Fatalf("stream %d level %v differs from the reference's Write+Close", i, lvl)
+			}
+		}
+		gpu.Close()
+	}
+}
+
+// TestWriteGolden pins the whole-encoder bytes of the REFERENCE (not of the GPU path) on the seeded corpora:
+// one line "<name> <sha256 of the concatenated frames>" per corpus and level into tests/golden/reference_sha256.txt.
+// tests/test_reference_golden.py then gates the C++ oracle and the HIP path on these hashes — the step that turns
+// "parity unpinned" into a measurement (SURVEY.md §8c layer 4).  Set KC_WRITE_GOLDEN=1 to (re)write the file.
+func TestWriteGolden(t *testing.T) {
+	if os.Getenv("KC_WRITE_GOLDEN") == "" {
+		t.Skip("set KC_WRITE_GOLDEN=1 to write tests/golden/reference_sha256.txt")
+	}
+	lines := map[string]string{}
+	path := "../../../tests/golden/reference_sha256.txt"
+	if old, err := os.ReadFile(path); err == nil { // keep the lines other packages wrote (s2gpu)
+		for _, l := range bytes.Split(old, []byte("\n")) {
+			f := bytes.Fields(l)
+			if len(f) == 2 {
+				lines[string(f[0])] = string(f[1])
+			}
+		}
+	}
+	dict, _ := kcgpu.CorpusFill('T', kcgpu.SeedD, 0, 1, 64<<10)
+	for _, lvl := range levels {
+		for _, kind := range []byte{'T', 'H', 'J', 'M'} {
+			data, err := kcgpu.CorpusFill(kind, kcgpu.Seed(kind), 0, 96, 128<<10)
+			if err != nil {
+				t.Fatal(err)
+			}
+			for _, withDict := range []bool{false, true} {
+				opts := []zstd.EOption{zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(1)}
+				name := fmt.Sprintf("zstd.L%d.%c.96x131072", int(lvl), kind)
+				if withDict {
+					opts = append(opts, zstd.WithEncoderDictRaw(1, dict))
+					name += ".rawdict64k"
+				}
+				ref, _ := zstd.NewWriter(nil, opts...)
+				h := sha256.New()
+				for i := 0; i < 96; i++ {
+					h.Write(ref.EncodeAll(data[i*(128<<10):(i+1)*(128<<10)], nil))
+				}
+				ref.Close()
+				lines[name] = hex.EncodeToString(h.Sum(nil))
+			}
+		}
+	}
+	writeGolden(t, path, lines)
+}
+
+func writeGolden(t *testing.T, path string, lines map[string]string) {
+	names := make([]string, 0, len(lines))
+	for n := range lines {
+		names = append(names, n)
+	}
+	sort.Strings(names)
+	var b bytes.Buffer
+	for _, n := range names {
+		fmt.Fprintf(&b, "%s %s\n", n, lines[n])
+	}
+	if err := os.WriteFile(path, b.Bytes(), 0o644); err != nil {
+		t.Fatal(err)
 	}
 }

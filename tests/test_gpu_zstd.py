@@ -440,3 +440,52 @@ def test_device_decoder_with_dictionary(oracle, kclib, level):
     st2 = enc.DecodeUnitsDevice(d_enc.data_ptr(), eoff, d_out.data_ptr(), off)
     assert all(int(x) == 20 for i, x in enumerate(st2) if len(units[i]) > 0), st2
     enc.Close()
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_host_pipeline_equals_device_path(oracle, kclib, level, monkeypatch):
+    """kc_zstd_encode_units above two sub-batches runs the pinned three-stage pipeline (stager / encode / drainer threads):
+    its bytes must equal the device-resident path's, which the oracle pins on a sample."""
+    torch = _torch()
+    monkeypatch.setenv("KC_HOST_PIPE_MIB", "16")  # 16 MiB sub-batches: 96 MiB of input -> 6 stages in flight
+    n, usz = 768, 131072
+    buf = corpora.corpus("T", n, usz)
+    buf[5 * usz:9 * usz] = corpora.corpus("H", 4, usz)  # raw blocks in the middle of a sub-batch
+    sizes = np.full(n, usz, dtype=np.uint64)
+    sizes[::7] = 100000  # ragged units: offsets that are not multiples of anything
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)
+    buf = buf[:int(off[n])]
+    enc = _enc(level)
+    out, out_off = enc.EncodeUnits(buf, off)
+    d_src = torch.from_numpy(buf).cuda()
+    cap = n * ((enc.MaxEncodedSize(usz) + 15) & ~15) + 64
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    dev_off = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    assert np.array_equal(out_off, dev_off)
+    assert np.array_equal(out, d_dst[:int(dev_off[n])].cpu().numpy())
+    ref, ref_off = oracle.zstd_encode_units(buf[:int(off[64])], off[:65], threads=8, level=level)
+    assert np.array_equal(out[:int(out_off[64])], ref) and np.array_equal(out_off[:65], ref_off)
+    monkeypatch.setenv("KC_HOST_SERIAL", "1")
+    out2, out_off2 = enc.EncodeUnits(buf, off)
+    assert np.array_equal(out2, out) and np.array_equal(out_off2, out_off)
+    enc.Close()
+
+
+def test_many_small_units_fit_the_scratch_budget(oracle, kclib):
+    """A batch of many small units needs scratch per unit and per block, not per input byte (tables 640 KiB per unit at
+    SpeedDefault): batches are cut by a scratch budget instead of asking hipMalloc for hundreds of GiB."""
+    _torch()
+    n, usz = 40000, 256
+    rng = np.random.default_rng(5)
+    text = corpora.corpus("T", 80, 131072)
+    buf = text[:n * usz].copy()
+    off = np.arange(n + 1, dtype=np.uint64) * usz
+    enc = _enc(2)
+    enc.ctx()
+    out, out_off = enc.EncodeUnits(buf, off)
+    idx = rng.choice(n, 200, replace=False)
+    for i in idx:
+        a = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        assert a == oracle.ZstdOracle(level=2).encode_all(buf[i * usz:(i + 1) * usz].tobytes()), i
+    enc.Close()

@@ -76,3 +76,73 @@ def test_shard_range_partitions():
             for a, b in zip(rs, rs[1:]):
                 assert a[1] == b[0]
             assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
+
+
+def _worker_real(rank, world, port, n_units, usz, steps, tmpdir, ret):
+    """The multi-GPU bench loop on CPU: every rank encodes ITS shard of the corpus (the oracle stands in for the device
+    encoder — the exchange step does not care who produced the frames), posts the gather of step i after step i's encode and
+    completes it after step i+1's encode (two output buffers, as bench.py does), takes the MAX over ranks of the elapsed time."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_lib
+    from compress_amd import _lib
+    from compress_amd.shard import shard_range, FrameGather, write_shard
+    lo, hi = shard_range(n_units, rank, world)
+    host = _lib.corpus_fill("T", 0x5EED0001, lo, hi - lo, usz, threads=2)
+    off = np.arange(hi - lo + 1, dtype=np.uint64) * usz
+    bufs = [torch.zeros((hi - lo) * (usz + 64) + 64, dtype=torch.uint8) for _ in range(2)]
+    fg = FrameGather(rank, world)
+    pending, results = None, []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        frames, foff = oracle_lib.zstd_encode_units(host, off, threads=2, level=1)
+        db = i % 2
+        bufs[db][:len(frames)] = torch.from_numpy(np.asarray(frames))
+        if pending is not None:
+            results.append(pending.wait())   # step i-1's gather completes only now: its source buffer was bufs[1 - db]
+        pending = fg.start(bufs[db], len(frames))
+        bufs[1 - db].fill_(0xEE)             # the other buffer is free again: scribble on it
+    results.append(pending.wait())
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    write_shard(os.path.join(tmpdir, "shard"), rank, bufs[(steps - 1) % 2], len(frames), foff)
+    if rank == 0:
+        ret["max_s"] = float(tt.item())
+        for i, r in enumerate(results):
+            out, offs = r
+            ret["out_%d" % i] = out.numpy().copy()
+            ret["offs_%d" % i] = list(offs)
+    else:
+        assert all(r is None for r in results)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_encode_gather_equals_single_rank(tmp_path, oracle):
+    """Real frames through the multi-rank path: shard -> encode -> FrameGather (overlapped, double-buffered) -> concatenation
+    == the single-rank output, every step; it decodes back; the per-rank-writes mode concatenates to the same stream."""
+    world, n_units, usz, steps = 2, 37, 32768, 3
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_real, args=(world, port, n_units, usz, steps, str(tmp_path), ret), nprocs=world, join=True)
+    from compress_amd import _lib
+    host = _lib.corpus_fill("T", 0x5EED0001, 0, n_units, usz)
+    off = np.arange(n_units + 1, dtype=np.uint64) * usz
+    want, want_off = oracle.zstd_encode_units(host, off, threads=4, level=1)
+    want = np.asarray(want)
+    for i in range(steps):
+        assert np.array_equal(ret["out_%d" % i], want), "step %d" % i
+        assert ret["offs_%d" % i][-1] == len(want) and len(ret["offs_%d" % i]) == world + 1
+    assert ret["max_s"] > 0
+    cat = b"".join(open(os.path.join(str(tmp_path), "shard.%05d.zst" % r), "rb").read() for r in range(world))
+    assert cat == want.tobytes()
+    idx0 = np.frombuffer(open(os.path.join(str(tmp_path), "shard.00000.idx"), "rb").read(), dtype="<u8")
+    assert np.array_equal(idx0, want_off[:len(idx0)])
+    for u in (0, n_units // 2, n_units - 1):
+        frame = want[int(want_off[u]):int(want_off[u + 1])].tobytes()
+        assert oracle.zstd_decode(frame, usz + 16) == host[u * usz:(u + 1) * usz].tobytes()
