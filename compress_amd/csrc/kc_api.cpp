@@ -468,6 +468,8 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     mp.seq_stride = pl.seq_stride;
     mp.block_size = bs;
     mp.max_match_off = o->window_size;
+    // SpeedDefault, round 2 (ms per launch): at 4 GiB (32768 units: DRAM-transaction bound, wasted probes cost) width 2 / 3 / 4 then doubling
+    // 265.9 / 266.7 / 274.0, 2 then +1 264.1; at 2 GiB (latency bound) 163.6 / - / 155.4, fixed 1: 285.5.  The BASELINE size is 4 GiB.
     mp.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : (o->level == KC_SPEED_DEFAULT ? 2 : 1);
     // measured on C2 (ms per 4 GiB): width 1 then +1 per miss 137, fixed 2 136.5, 1 then doubling 140, fixed 1 167, fixed 4 157
     mp.spec_grow = getenv("KC_SPEC_GROW") ? atoi(getenv("KC_SPEC_GROW")) : (o->level == KC_SPEED_FASTEST ? 1 : 2);
@@ -1128,8 +1130,9 @@ int64_t kc_s2_max_encoded_len(int64_t srcLen) {  // s2/encode.go:389-418 (64-bit
 }
 
 static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
-                               uint64_t dst_cap, uint64_t* out_off, int framed, int with_stream_id) {
+                               uint64_t dst_cap, uint64_t* out_off, int framed, int with_stream_id, int level = KC_S2_LEVEL_DEFAULT) {
     if (!c || !blk_off || !out_off || (n && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
+    if (level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_BETTER) { c->err = "device path implements s2.Encode and s2.EncodeBetter"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
     c->last = kc_timings{0, 0, 0, 0, 0};
     HIPCHK(c, hipSetDevice(c->device));
@@ -1143,10 +1146,11 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     if (n == 0) { out_off[0] = lead; return KC_OK; }
     hipStream_t st = c->stream;
     std::vector<uint64_t> rel(n + 1), so(n + 1);
-    uint64_t acc = 0;
+    uint64_t acc = 0, maxLen = 0;
     for (uint32_t i = 0; i < n; i++) {
         if (blk_off[i + 1] < blk_off[i]) { c->err = "blk_off not ascending"; return KC_ERR_BAD_ARG; }
         const uint64_t len = blk_off[i + 1] - blk_off[i];
+        maxLen = std::max(maxLen, len);
         if (len > (uint64_t)(4 << 20)) { c->err = "S2 block larger than 4 MiB (s2.maxBlockSize) not served by the device path"; return KC_ERR_UNSUPPORTED; }
         rel[i] = blk_off[i] - blk_off[0];
         so[i] = acc;
@@ -1158,12 +1162,12 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     kc_status s;
     if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) || (s = ensure(c, c->out_off, (n + 1) * 8)) ||
         (s = ensure(c, c->stage, acc + 64)) || (s = ensure(c, c->out_size, (size_t)n * 4)) ||
-        (s = ensure(c, c->tables, (size_t)n * kc_s2_table_bytes())))
+        (s = ensure(c, c->tables, (size_t)n * kc_s2_table_bytes(level, maxLen))))
         return s;
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->stage_off.p, so.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(), st));
+    HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen), st));
     KcS2Params P;
     P.src = d_src + blk_off[0];
     P.blk_off = (const uint64_t*)c->unit_off.p;
@@ -1173,6 +1177,8 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     P.tables = (uint32_t*)c->tables.p;
     P.n_blocks = n;
     P.framed = framed;
+    P.level = level;
+    P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen) / 4);
     kc_launch_s2_encode(P, st);
     HIPCHK(c, hipEventRecord(c->ev[1], st));
     kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n, (uint64_t*)c->out_off.p, st);
@@ -1296,9 +1302,25 @@ kc_status kc_s2_encode_stream_dev(kc_ctx* c, const uint8_t* d_src, const uint64_
     return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 1, with_stream_id);
 }
 
+kc_status kc_s2_encode_blocks_lvl_dev(kc_ctx* c, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
+                                      uint64_t dst_cap, uint64_t* out_off) {
+    return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 0, 0, level);
+}
+
+kc_status kc_s2_encode_stream_lvl_dev(kc_ctx* c, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
+                                      uint64_t dst_cap, uint64_t* out_off, int with_stream_id) {
+    return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 1, with_stream_id, level);
+}
+
 kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* dst, uint64_t dst_cap,
                               uint64_t* out_off) {
+    return kc_s2_encode_blocks_lvl(c, KC_S2_LEVEL_DEFAULT, src, blk_off, n, dst, dst_cap, out_off);
+}
+
+kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* dst, uint64_t dst_cap,
+                                  uint64_t* out_off) {
     if (!c || !blk_off || !out_off || (n && (!src || !dst))) return KC_ERR_BAD_ARG;
+    if (level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_BETTER) { c->err = "device path implements s2.Encode and s2.EncodeBetter"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
     HIPCHK(c, hipSetDevice(c->device));
     if (n == 0) { out_off[0] = 0; return KC_OK; }
@@ -1309,7 +1331,7 @@ kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk
     const uint64_t total = blk_off[n] - blk_off[0];
     if (total >= 2 * host_sub_bytes() && !getenv("KC_HOST_SERIAL")) {
         auto enc = [&](const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
-            return kc_s2_encode_blocks_dev(c, d_in, rel, nu, d_out, cap, oo);
+            return kc_s2_encode_blocks_lvl_dev(c, level, d_in, rel, nu, d_out, cap, oo);
         };
         auto mx = [&](uint64_t len) { return (uint64_t)kc_s2_max_encoded_len((int64_t)len); };
         return host_pipeline(c, src, blk_off, n, dst, dst_cap, out_off, host_sub_bytes(), enc, mx);
@@ -1321,7 +1343,7 @@ kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk
     HIPCHK(c, hipMemcpyAsync(c->tmp_src.p, src + blk_off[0], total, hipMemcpyHostToDevice, c->stream));
     std::vector<uint64_t> rel(n + 1);
     for (uint32_t i = 0; i <= n; i++) rel[i] = blk_off[i] - blk_off[0];
-    s = kc_s2_encode_blocks_dev(c, (const uint8_t*)c->tmp_src.p, rel.data(), n, (uint8_t*)c->tmp_dst.p, need, out_off);
+    s = kc_s2_encode_blocks_lvl_dev(c, level, (const uint8_t*)c->tmp_src.p, rel.data(), n, (uint8_t*)c->tmp_dst.p, need, out_off);
     if (s != KC_OK) return s;
     const uint64_t outn = out_off[n];
     if (outn > dst_cap) { c->err = "dst_cap too small"; return KC_ERR_DST_TOO_SMALL; }

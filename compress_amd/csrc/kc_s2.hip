@@ -173,6 +173,7 @@ __device__ __forceinline__ uint32_t s2_crc32c(const uint8_t* __restrict__ p, int
     return c ^ 0xFFFFFFFFu;
 }
 
+template <int LEVEL>  // 0: s2.Encode (encodeBlockGo / encodeBlockGo64K), 1: s2.EncodeBetter (encodeBlockBetterGo / ...Go64K)
 __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     constexpr int G = S2G;
     __shared__ uint32_t crcT[4][256];
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     const int len = gact ? (int)(P.blk_off[bq + 1] - P.blk_off[bq]) : 0;
     uint8_t* __restrict__ slot = P.stage + P.stage_off[bq];
     uint8_t* __restrict__ out = slot + (P.framed ? 8 : 0);  // chunk header (type, len24, crc) goes in front
-    uint32_t* __restrict__ tab = P.tables + (size_t)bi * (1u << S2_TABLE_BITS);
+    uint32_t* __restrict__ tab = P.tables + (size_t)bi * P.table_stride;  // u32 entries per block
     if (!gact) return;  // whole group leaves together
 
     // uvarint(len) header (encode.go:39)
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     if (len == 0) stored = true;
     if (len < 32) stored = true;  // minNonLiteralBlockSize
 
-    if (!stored) {
+    if (LEVEL == 0 && !stored) {
         const int SKIP = len <= (64 << 10) ? 5 : 6;  // encodeBlockGo64K vs encodeBlockGo (encode_go.go:23-26)
         const int PB = bits_len32((uint32_t)len);
         const int TB = (32 - PB) > 16 ? 16 : (32 - PB);
@@ -361,6 +362,178 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
             }
         }
     }
+    if (LEVEL == 1 && !stored) {
+        // ---------------- s2.EncodeBetter: encodeBlockBetterGo (> 64 KiB) / encodeBlockBetterGo64K (s2/encode_better.go:50-307 / 485-730) ----------------
+        // Long table (7-byte hash, 2^17 / 2^16 entries) + short table (4-byte hash, 2^14 / 2^13), every position probed (step 1, skip >>7 / >>6),
+        // candidates accepted on 8 equal bytes (long, then short), then on 4 (long, then short with a lazy long lookup at s+1);
+        // after a match: s+1 / end-2 into both tables, then the long table sparsely from two starting points.  The repeat check
+        // inside the probe loop is dead code in the reference (`if false && ...`).  Entries: position | tag(4 bytes) << PB, 0 = empty
+        // (== candidate 0, verified on the bytes only, as the reference does).
+        const bool big = len > (64 << 10);
+        const int LB = big ? 17 : 16, SB = big ? 14 : 13, SKIP = big ? 7 : 6;
+        uint32_t* __restrict__ ltab = tab;
+        uint32_t* __restrict__ stab = tab + (1u << LB);
+        const int PB = bits_len32((uint32_t)len);
+        const int TB = (32 - PB) > 16 ? 16 : (32 - PB);
+        const uint32_t posMask = (1u << PB) - 1u;
+        auto tagOf = [&](uint32_t v) -> uint32_t { return (v * 2654435761u) >> (32 - TB); };
+        auto mk = [&](int pos, uint32_t val) -> uint32_t { return (uint32_t)pos | (tagOf(val) << PB); };
+        auto hL = [&](uint64_t v) -> uint32_t { return (uint32_t)(((v << 8) * 58295818150454627ULL) >> (64 - LB)); };  // hash7
+        auto hS = [&](uint64_t v) -> uint32_t { return ((uint32_t)v * KC_PRIME4) >> (32 - SB); };                      // hash4
+        const int sLimit = len - 8;
+        const int dstLimit = len - (len >> 5) - 6;
+        int nextEmit = 0, s = 1, repeat = 0;
+        bool fin = false;
+        int W = G;
+        while (!fin && !stored) {
+            const int d0 = s - nextEmit;
+            const int k0 = d0 >> SKIP;
+            const int step = 1 + k0;
+            const int p = s + lig * step;
+            const bool inseg = lig == 0 || ((d0 + (lig - 1) * step) >> SKIP) == k0;
+            const int nextS = p + ((p - nextEmit) >> SKIP) + 1;
+            const bool valid = lig < W && inseg && nextS <= sLimit;
+            const bool term = inseg && nextS > sLimit;  // this step would `goto emitRemainder`
+            uint64_t cv = 0;
+            uint32_t hl = 0xFFFFFFF0u, hs = 0xFFFFFFF1u, eL = 0, eS = 0;
+            if (valid) {
+                cv = ld64(src + p);
+                hl = hL(cv);
+                hs = hS(cv);
+                eL = ltab[hl];
+                eS = stab[hs];
+            }
+            bool dep = false;
+#pragma unroll
+            for (int dd = 1; dd < G; dd++) {
+                const uint32_t al = (uint32_t)__shfl_up((int)hl, dd, G), as = (uint32_t)__shfl_up((int)hs, dd, G);
+                if (lig >= dd && (al == hl || as == hs)) dep = true;
+            }
+            int kind = 0, cand = 0;  // 1: 8 bytes long, 2: 8 bytes short, 3: 4 bytes long, 4: 4 bytes short (lazy long lookup at s+1 follows)
+            if (valid) {
+                const int cL = (int)(eL & posMask), cS = (int)(eS & posMask);
+                const bool okL = eL == 0 || (eL >> PB) == tagOf((uint32_t)cv);
+                const bool okS = eS == 0 || (eS >> PB) == tagOf((uint32_t)cv);
+                const uint64_t vL = okL ? ld64(src + cL) : ~cv;
+                const uint64_t vS = okS ? ld64(src + cS) : ~cv;
+                if (cv == vL) { kind = 1; cand = cL; }
+                else if (cv == vS) { kind = 2; cand = cS; }
+                else if ((uint32_t)cv == (uint32_t)vL) { kind = 3; cand = cL; }
+                else if ((uint32_t)cv == (uint32_t)vS) { kind = 4; cand = cS; }
+            }
+            const uint32_t vm = s2g_ballot(valid, grp);
+            const uint32_t tm = s2g_ballot(term, grp);
+            const uint32_t depm = s2g_ballot(valid && dep, grp);
+            const uint32_t hm = s2g_ballot(kind != 0, grp);
+            const int nvalid = __popc(vm);
+            const int c = depm ? __builtin_ctz(depm) : G;
+            const uint32_t hmc = hm & ((1u << c) - 1u);
+            const bool found = hmc != 0;
+            const int f = found ? __builtin_ctz(hmc) : 0;
+            const int commitUpTo = found ? f : ((c < nvalid ? c : nvalid) - 1);
+            if (valid && lig <= commitUpTo) {
+                const uint32_t e = mk(p, (uint32_t)cv);
+                ltab[hl] = e;
+                stab[hs] = e;
+            }
+            if (!found) {
+                W = 2 * W < G ? 2 * W : G;
+                if (c < nvalid) {
+                    s = s + c * step;
+                } else if (nvalid < G && (tm & (1u << nvalid))) {
+                    fin = true;
+                } else {
+                    const int pl = s + (nvalid - 1) * step;  // nvalid >= 1: lane 0 is valid or terminates
+                    s = pl + ((pl - nextEmit) >> SKIP) + 1;
+                }
+                continue;
+            }
+            W = 4;
+            const int mkind = (int)s2g_bcast32((uint32_t)kind, grp, f);
+            int candidate = (int)s2g_bcast32((uint32_t)cand, grp, f);
+            const int ps = s + f * step;
+            const int nextSw = ps + ((ps - nextEmit) >> SKIP) + 1;
+            s = ps;
+            if (mkind == 4) {
+                // try a long candidate at s+1 (:186-196); the lookup stores s+1 and observes this round's committed writes
+                const uint64_t cv1 = s2g_bcast64(cv, grp, f) >> 8;
+                const uint32_t hn = hL(cv1);
+                const uint32_t en = ltab[hn];
+                if (lig == 0) ltab[hn] = mk(s + 1, (uint32_t)cv1);
+                const int cn = (int)(en & posMask);
+                const bool okn = en == 0 || (en >> PB) == tagOf((uint32_t)cv1);
+                if (okn && ld32(src + cn) == (uint32_t)cv1) { s++; candidate = cn; }
+            }
+            {
+                int kmax = candidate;  // candidateL > 0 && s > nextEmit
+                if (s - nextEmit < kmax) kmax = s - nextEmit;
+                const int back = grp_backlen<S2G>(src, s, candidate, kmax, lig, grp);
+                candidate -= back;
+                s -= back;
+            }
+            if (d + (s - nextEmit) > dstLimit) { stored = true; continue; }
+            const int base = s;
+            const int offset = base - candidate;
+            const int l = 4 + grp_matchlen<S2G>(src, s + 4, candidate + 4, len - (s + 4), lig, grp);
+            s = base + l;
+            if (big && offset > 65535 && l <= 5 && repeat != offset) {  // the match is equal or worse to the encoding (:221-229)
+                s = nextSw + 1;
+                if (s >= sLimit) fin = true;
+                continue;
+            }
+            d += s2_emit_literal(dst + d, src + nextEmit, base - nextEmit, lig);
+            if (repeat == offset) {
+                if (lig == 0) s2_emit_repeat1(dst + d, offset, l);
+                d += s2_repeat_size(offset, l);
+            } else {
+                if (lig == 0) s2_emit_copy1(dst + d, offset, l);
+                d += s2_copy_size(offset, l);
+                repeat = offset;
+            }
+            nextEmit = s;
+            if (s >= sLimit) { fin = true; continue; }
+            if (d > dstLimit) { stored = true; continue; }
+            // index short & long at base+1 and s-2 (:252-262), in program order on one lane
+            int index0 = base + 1, index1 = s - 2;
+            {
+                const uint64_t cv0 = ld64(src + index0), cv1 = ld64(src + index1);
+                if (lig == 0) {
+                    ltab[hL(cv0)] = mk(index0, (uint32_t)cv0);
+                    stab[hS(cv0 >> 8)] = mk(index0 + 1, (uint32_t)(cv0 >> 8));
+                    ltab[hL(cv1)] = mk(index1, (uint32_t)cv1);
+                    stab[hS(cv1 >> 8)] = mk(index1 + 1, (uint32_t)(cv1 >> 8));
+                }
+            }
+            index0 += 1;
+            index1 -= 1;
+            // long values sparsely in between, from two starting points (:266-274): the j-th store of the reference's loop is
+            // position (j odd ? index2 : index0) + 2*(j/2).  G stores per pass, one per lane; inside a pass only the LAST store to a
+            // bucket is issued, passes follow in program order: the table ends as after the sequential loop.
+            const int index2 = (index0 + index1 + 1) >> 1;
+            const int iters = index2 < index1 ? (index1 - index2 + 1) >> 1 : 0;
+            for (int j0 = 0; j0 < 2 * iters; j0 += G) {
+                const int j = j0 + lig;
+                const bool act = j < 2 * iters;
+                const int pos = ((j & 1) ? index2 : index0) + (j >> 1) * 2;
+                uint64_t v = 0;
+                uint32_t h = 0xFFFFFF00u + (uint32_t)lig;
+                if (act) { v = ld64(src + pos); h = hL(v); }
+                bool later = false;
+#pragma unroll
+                for (int dd = 1; dd < G; dd++) {
+                    const uint32_t bh = (uint32_t)__shfl_down((int)h, dd, G);
+                    if (lig + dd < G && bh == h) later = true;
+                }
+                if (act && !later) ltab[h] = mk(pos, (uint32_t)v);
+            }
+        }
+        if (!stored) {
+            if (nextEmit < len) {  // emitRemainder (:277-284)
+                if (d + len - nextEmit > dstLimit) stored = true;
+                else d += s2_emit_literal(dst + d, src + nextEmit, len - nextEmit, lig);
+            }
+        }
+    }
     if (!P.framed) {
         if (stored) d = s2_emit_literal(dst, src, len, lig);  // encode.go:44-55: not compressible -> one literal
         if (lig == 0) P.out_size[bi] = (uint32_t)(hdr + d);
@@ -389,5 +562,6 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
 
 void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st) {
     if (P.n_blocks == 0) return;
-    hipLaunchKernelGGL(kc_s2_encode_kernel, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
+    if (P.level == 1) hipLaunchKernelGGL(kc_s2_encode_kernel<1>, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL(kc_s2_encode_kernel<0>, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
 }

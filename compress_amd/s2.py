@@ -9,9 +9,13 @@ def MaxEncodedLen(src_len):
     return int(_lib.load().kc_s2_max_encoded_len(int(src_len)))
 
 
+LevelDefault, LevelBetter = 0, 1  # KC_S2_LEVEL_DEFAULT == s2.Encode, KC_S2_LEVEL_BETTER == s2.EncodeBetter (s2/encode.go:29, 117)
+
+
 class BlockEncoder:
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, level=LevelDefault):
         self._ctx = _lib.Context(device, stream)
+        self.level = int(level)
 
     def EncodeBlocks(self, src, blk_off):
         """N x s2.Encode(nil, block).  Returns (numpy uint8, uint64[n+1] offsets)."""
@@ -23,7 +27,7 @@ class BlockEncoder:
         cap = sum(((MaxEncodedLen(int(blk_off[i + 1] - blk_off[i])) + 15) & ~15) for i in range(n)) + 64
         dst = np.empty(cap, dtype=np.uint8)
         out_off = np.zeros(n + 1, dtype=np.uint64)
-        ctx.check(ctx.L.kc_s2_encode_blocks(ctx.h, src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, out_off.ctypes.data))
+        ctx.check(ctx.L.kc_s2_encode_blocks_lvl(ctx.h, self.level, src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, out_off.ctypes.data))
         return dst[:int(out_off[n])], out_off
 
     def EncodeBlocksDevice(self, d_src_ptr, blk_off, d_dst_ptr, dst_cap):
@@ -32,7 +36,7 @@ class BlockEncoder:
         blk_off = np.ascontiguousarray(blk_off, dtype=np.uint64)
         n = len(blk_off) - 1
         out_off = np.zeros(n + 1, dtype=np.uint64)
-        ctx.check(ctx.L.kc_s2_encode_blocks_dev(ctx.h, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data))
+        ctx.check(ctx.L.kc_s2_encode_blocks_lvl_dev(ctx.h, self.level, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data))
         return out_off
 
     def EncodeStreamDevice(self, d_src_ptr, blk_off, d_dst_ptr, dst_cap, with_stream_id=True):
@@ -42,8 +46,8 @@ class BlockEncoder:
         blk_off = np.ascontiguousarray(blk_off, dtype=np.uint64)
         n = len(blk_off) - 1
         out_off = np.zeros(n + 1, dtype=np.uint64)
-        ctx.check(ctx.L.kc_s2_encode_stream_dev(ctx.h, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data,
-                                                int(with_stream_id)))
+        ctx.check(ctx.L.kc_s2_encode_stream_lvl_dev(ctx.h, self.level, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data,
+                                                    int(with_stream_id)))
         return out_off
 
     def DecodeBlocksDevice(self, d_enc_ptr, enc_off, d_dst_ptr, dst_off):
@@ -58,7 +62,7 @@ class BlockEncoder:
         return status[:n]
 
     def Encode(self, dst, src):
-        """s2.Encode(dst, src) (s2/encode.go:29): uvarint length + block body."""
+        """s2.Encode(dst, src) (s2/encode.go:29) — or s2.EncodeBetter (:117) for a LevelBetter encoder: uvarint length + block body."""
         import numpy as np
         src = bytes(src)
         out, _ = self.EncodeBlocks(np.frombuffer(src, dtype=np.uint8), np.array([0, len(src)], dtype=np.uint64))
@@ -120,7 +124,11 @@ def _unsupported(name):
     return opt
 
 
-WriterBetterCompression = _unsupported("WriterBetterCompression")
+def WriterBetterCompression():
+    """s2.WriterBetterCompression (writer.go:931): blocks are encoded with encodeBlockBetter."""
+    return lambda w: setattr(w, "level", LevelBetter)
+
+
 WriterBestCompression = _unsupported("WriterBestCompression")
 WriterSnappyCompat = _unsupported("WriterSnappyCompat")
 WriterUncompressed = _unsupported("WriterUncompressed")
@@ -228,7 +236,7 @@ class Index:
 
 class Writer:
     """s2.Writer: Write / ReadFrom / EncodeBuffer / AddSkippableBlock / Flush / Close / Reset with the reference's chunk
-    boundaries (writer.go:182-218, 357-453, 483-571, 741-857); default level, no index, no padding.  Chunks are queued and
+    boundaries (writer.go:182-218, 357-453, 483-571, 741-857); default or better level (WriterBetterCompression).  Chunks are queued and
     encoded on the GPU in batches of `batch_bytes`; the bytes written equal the reference's for the same call sequence."""
 
     def __init__(self, w, *opts, device=0, stream=None, batch_bytes=256 << 20):
@@ -238,9 +246,10 @@ class Writer:
         self.appendIndex = False
         self.pad = 0
         self.randSrc = None
+        self.level = LevelDefault
         for o in opts:
             o(self)
-        self._enc = BlockEncoder(device, stream)
+        self._enc = BlockEncoder(device, stream, level=self.level)
         self._device = device
         self._batch = int(batch_bytes)
         self.Reset(w)

@@ -11,6 +11,7 @@
  *   kc_zstd_encode_units[_dev]  == N x (*Encoder).EncodeAll(unit, nil)   zstd/encoder.go:722-839
  *   kc_zstd_max_encoded_size    == (*Encoder).MaxEncodedSize             zstd/encoder.go:843-873
  *   kc_s2_encode_blocks[_dev]   == N x s2.Encode(nil, block)             s2/encode.go:29-56
+ *   kc_s2_encode_blocks_lvl[_dev] at KC_S2_LEVEL_BETTER == N x s2.EncodeBetter(nil, block)   s2/encode.go:117-144
  *   kc_s2_encode_block          == the s2.WriterCustomEncoder callback   s2/writer.go:1053-1064
  *   kc_s2_max_encoded_len       == s2.MaxEncodedLen                      s2/encode.go:389-418
  *   kc_s2_encode_stream_dev     == s2.Writer.EncodeBuffer framing        s2/writer.go:357-451
@@ -150,6 +151,18 @@ kc_status kc_s2_encode_blocks(kc_ctx* ctx, const uint8_t* src, const uint64_t* b
                               uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
 kc_status kc_s2_encode_blocks_dev(kc_ctx* ctx, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
                                   uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
+/* The same at a chosen level: KC_S2_LEVEL_DEFAULT == s2.Encode (encodeBlockGo / encodeBlockGo64K, s2/encode_all.go:72-500),
+ * KC_S2_LEVEL_BETTER == s2.EncodeBetter (s2/encode.go:117-144: encodeBlockBetterGo / encodeBlockBetterGo64K,
+ * s2/encode_better.go:50-307 / 485-730).  Other levels (best, snappy-compatible) return KC_ERR_UNSUPPORTED. */
+#define KC_S2_LEVEL_DEFAULT 0
+#define KC_S2_LEVEL_BETTER 1
+kc_status kc_s2_encode_blocks_lvl(kc_ctx* ctx, int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks,
+                                  uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
+kc_status kc_s2_encode_blocks_lvl_dev(kc_ctx* ctx, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
+                                      uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
+/* kc_s2_encode_stream_dev at a chosen level (s2.WriterBetterCompression, s2/writer.go:931) */
+kc_status kc_s2_encode_stream_lvl_dev(kc_ctx* ctx, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
+                                      uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off, int with_stream_id);
 /* s2.Writer framing on the device (s2/writer.go:394-451): every block becomes one chunk
  * `type(1) | len24 | masked CRC32C(4) | body` (compressed 0x00: uvarint(len) + block; incompressible 0x01: raw bytes),
  * optionally preceded by the stream identifier `ff 06 00 00 "S2sTwO"`.  The result is a complete, concatenable .s2

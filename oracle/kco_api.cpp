@@ -478,9 +478,25 @@ int64_t kco_fse_compress(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t c
 }
 
 // ---- S2 ----
+// Inspection of a zstd frame (analysis tooling, e.g. the provenance of zstd/testdata/z000028.zst): one text line per block
+// with its type, literal type, sequence count, compression modes and the first sequences (REPn = repeat-offset code n).
+int64_t kco_zstd_inspect(const uint8_t* enc, uint64_t n, char* out, uint64_t cap) {
+    zdec::FrameDec fd;
+    std::string tr;
+    fd.trace = &tr;
+    Bytes content;
+    const size_t used = fd.decodeFrame(enc, (size_t)n, nullptr, &content);
+    char tb[192];
+    snprintf(tb, sizeof(tb), "\nframe: consumed=%zu decoded=%zu repeat codes REP1=%zu REP2=%zu REP3=%zu", used, content.size(), fd.repSeen[1], fd.repSeen[2], fd.repSeen[3]);
+    tr += tb;
+    if (tr.size() + 1 > cap) return -2;
+    memcpy(out, tr.c_str(), tr.size() + 1);
+    return (int64_t)tr.size();
+}
 int64_t kco_s2_max_encoded_len(int64_t n) { return s2::MaxEncodedLen(n); }
 int64_t kco_s2_encode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::Encode(dst, cap, src, (size_t)n); }
 // encodeBlock only (no varint header); 0 == incompressible.  The WriterCustomEncoder contract.
+int64_t kco_s2_encode_better(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeBetter(dst, cap, src, (size_t)n); }
 int64_t kco_s2_encode_block(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
     if (cap < (uint64_t)s2::MaxEncodedLen((int64_t)n)) return -2;
     return s2::encodeBlock(dst, src, (size_t)n);
@@ -512,8 +528,8 @@ int64_t kco_s2_encode_stream(const uint8_t* src, const uint64_t* blk_off, uint32
 }
 int64_t kco_s2_decode_stream(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::DecodeStream(dst, cap, src, (size_t)n); }
 
-int64_t kco_s2_encode_blocks(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
-                             uint64_t* out_off, int threads) {
+static int64_t s2_encode_blocks_impl(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
+                                     uint64_t* out_off, int threads, bool better) {
     if (threads < 1) threads = 1;
     std::vector<Bytes> outs(n_blocks);
     std::atomic<uint32_t> next(0);
@@ -523,7 +539,8 @@ int64_t kco_s2_encode_blocks(const uint8_t* src, const uint64_t* blk_off, uint32
             if (i >= n_blocks) break;
             size_t n = (size_t)(blk_off[i + 1] - blk_off[i]);
             outs[i].resize((size_t)s2::MaxEncodedLen((int64_t)n));
-            int64_t r = s2::Encode(outs[i].data(), outs[i].size(), src + blk_off[i], n);
+            int64_t r = better ? s2::EncodeBetter(outs[i].data(), outs[i].size(), src + blk_off[i], n)
+                               : s2::Encode(outs[i].data(), outs[i].size(), src + blk_off[i], n);
             outs[i].resize((size_t)r);
         }
     };
@@ -539,6 +556,15 @@ int64_t kco_s2_encode_blocks(const uint8_t* src, const uint64_t* blk_off, uint32
     }
     out_off[n_blocks] = pos;
     return (int64_t)pos;
+}
+// N x s2.Encode(nil, block) / N x s2.EncodeBetter(nil, block) on `threads` host threads
+int64_t kco_s2_encode_blocks(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
+                             uint64_t* out_off, int threads) {
+    return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, false);
+}
+int64_t kco_s2_encode_blocks_better(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
+                                    uint64_t* out_off, int threads) {
+    return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, true);
 }
 
 }  // extern "C"

@@ -248,6 +248,135 @@ static inline int64_t Encode(uint8_t* dst, uint64_t cap, const uint8_t* src, siz
     return d;
 }
 
+// ---- s2.EncodeBetter (s2/encode.go:117-144): encodeBlockBetterGo / encodeBlockBetterGo64K (s2/encode_better.go:50-307 / 485-730) ----
+// s2/encode_better.go:15-40
+static inline uint32_t hash4(uint64_t u, uint8_t h) { return ((uint32_t)u * 2654435761u) >> ((32 - h) & 31); }
+static inline uint32_t hash7(uint64_t u, uint8_t h) { return (uint32_t)(((u << (64 - 56)) * 58295818150454627ULL) >> ((64 - h) & 63)); }
+
+// One body for both variants: T = uint32/uint16 tables, LBITS/SBITS = 17/14 or 16/13, SKIP = 7 or 6,
+// BIG = the "offset > 65535 && s-base <= 5 && repeat != offset" bail of the > 64 KiB variant (:221-229).
+// The repeat check inside the probe loop is disabled in the reference (`if false && ...`, :124 / :561) and is not restated.
+template <typename T, int LBITS, int SBITS, int SKIP, bool BIG>
+static int encodeBlockBetterGoT(uint8_t* dst, const uint8_t* src, size_t srcLen) {
+    const int len = (int)srcLen;
+    const int sLimit = len - inputMargin;
+    if (len < minNonLiteralBlockSize) return 0;
+    std::vector<T> lTable((size_t)1 << LBITS, (T)0), sTable((size_t)1 << SBITS, (T)0);
+    const int dstLimit = len - (len >> 5) - 6;
+    int nextEmit = 0;
+    int s = 1;
+    uint64_t cv = load64(src, s);
+    int repeat = 0;
+    int d = 0;
+    for (;;) {
+        int candidateL = 0;
+        int nextS = 0;
+        for (;;) {
+            nextS = s + ((s - nextEmit) >> SKIP) + 1;
+            if (nextS > sLimit) goto emitRemainder;
+            {
+                uint32_t hashL = hash7(cv, LBITS);
+                const uint32_t hashS = hash4(cv, SBITS);
+                candidateL = (int)lTable[hashL];
+                const int candidateS = (int)sTable[hashS];
+                lTable[hashL] = (T)s;
+                sTable[hashS] = (T)s;
+                const uint64_t valLong = load64(src, candidateL);
+                const uint64_t valShort = load64(src, candidateS);
+                if (cv == valLong) break;                          // long matches at least 8 bytes
+                if (cv == valShort) { candidateL = candidateS; break; }
+                if ((uint32_t)cv == (uint32_t)valLong) break;      // long likely matches 7
+                if ((uint32_t)cv == (uint32_t)valShort) {          // short candidate: try a long candidate at s+1 first
+                    hashL = hash7(cv >> 8, LBITS);
+                    candidateL = (int)lTable[hashL];
+                    lTable[hashL] = (T)(s + 1);
+                    if ((uint32_t)(cv >> 8) == load32(src, candidateL)) { s++; break; }
+                    candidateL = candidateS;
+                    break;
+                }
+            }
+            cv = load64(src, nextS);
+            s = nextS;
+        }
+        // extend backwards
+        while (candidateL > 0 && s > nextEmit && src[candidateL - 1] == src[s - 1]) { candidateL--; s--; }
+        if (d + (s - nextEmit) > dstLimit) return 0;
+        {
+            const int base = s;
+            const int offset = base - candidateL;
+            s += 4;
+            candidateL += 4;
+            while (s < len) {
+                if (len - s < 8) {
+                    if (src[s] == src[candidateL]) { s++; candidateL++; continue; }
+                    break;
+                }
+                const uint64_t diff = load64(src, s) ^ load64(src, candidateL);
+                if (diff != 0) { s += tz64(diff) >> 3; break; }
+                s += 8;
+                candidateL += 8;
+            }
+            if (BIG && offset > 65535 && s - base <= 5 && repeat != offset) {  // the match is equal or worse to the encoding
+                s = nextS + 1;
+                if (s >= sLimit) goto emitRemainder;
+                cv = load64(src, s);
+                continue;
+            }
+            d += emitLiteral(dst + d, src + nextEmit, (size_t)(base - nextEmit));
+            if (repeat == offset) d += emitRepeat(dst + d, offset, s - base);
+            else { d += emitCopy(dst + d, offset, s - base); repeat = offset; }
+            nextEmit = s;
+            if (s >= sLimit) goto emitRemainder;
+            if (d > dstLimit) return 0;
+            // index short & long at base+1 and s-2, then long values sparsely in between from two starting points
+            int index0 = base + 1;
+            int index1 = s - 2;
+            const uint64_t cv0 = load64(src, index0);
+            const uint64_t cv1 = load64(src, index1);
+            lTable[hash7(cv0, LBITS)] = (T)index0;
+            sTable[hash4(cv0 >> 8, SBITS)] = (T)(index0 + 1);
+            lTable[hash7(cv1, LBITS)] = (T)index1;
+            sTable[hash4(cv1 >> 8, SBITS)] = (T)(index1 + 1);
+            index0 += 1;
+            index1 -= 1;
+            cv = load64(src, s);
+            int index2 = (index0 + index1 + 1) >> 1;
+            while (index2 < index1) {
+                lTable[hash7(load64(src, index0), LBITS)] = (T)index0;
+                lTable[hash7(load64(src, index2), LBITS)] = (T)index2;
+                index0 += 2;
+                index2 += 2;
+            }
+        }
+    }
+emitRemainder:
+    if (nextEmit < len) {
+        if (d + len - nextEmit > dstLimit) return 0;
+        d += emitLiteral(dst + d, src + nextEmit, (size_t)(len - nextEmit));
+    }
+    return d;
+}
+
+// s2/encode_go.go:36 encodeBlockBetter
+static inline int encodeBlockBetter(uint8_t* dst, const uint8_t* src, size_t n) {
+    if (n <= ((size_t)64 << 10)) return encodeBlockBetterGoT<uint16_t, 16, 13, 6, false>(dst, src, n);
+    return encodeBlockBetterGoT<uint32_t, 17, 14, 7, true>(dst, src, n);
+}
+
+// s2/encode.go:117 EncodeBetter; returns bytes written or -1 (too large) / -2 (dst too small)
+static inline int64_t EncodeBetter(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n) {
+    int64_t m = MaxEncodedLen((int64_t)n);
+    if (m < 0) return -1;
+    if (cap < (uint64_t)m) return -2;
+    int d = putUvarint(dst, (uint64_t)n);
+    if (n == 0) return d;
+    if (n < (size_t)minNonLiteralBlockSize) { d += emitLiteral(dst + d, src, n); return d; }
+    int k = encodeBlockBetter(dst + d, src, n);
+    if (k > 0) return d + k;
+    d += emitLiteral(dst + d, src, n);
+    return d;
+}
+
 // CRC32C (Castagnoli) + s2/s2.go:120 crc masking: ((c>>15)|(c<<17)) + 0xa282ead8
 static inline uint32_t crc32c(const uint8_t* p, size_t n) {
     static uint32_t tab[256];

@@ -8,6 +8,8 @@
 //   zstd/dict.go                 dictionary content / tables / offsets as initial state
 // Written against the format description; every stage names the reference code it stands for.
 #pragma once
+#include <string>
+#include <stdio.h>
 #include "kco_common.h"
 #include "kco_xxhash.h"
 #include "kco_zstd_fse.h"
@@ -117,6 +119,8 @@ struct FrameDec {
     int hufLog = 0;
     Bytes out;          // regenerated content of the frame
     size_t histBase = 0;  // dictionary bytes logically in front of `out`
+    size_t repSeen[4] = {0, 0, 0, 0};  // inspection: sequences carrying repeat-offset code 1 / 2 / 3 in the whole frame
+    std::string* trace = nullptr;  // inspection (kco_zstd_inspect): one line per block with its modes and first sequences
 
     static uint32_t llBase(int c) { uint32_t b = 0; for (int i = 0; i < c; i++) b += 1u << zfse::llBitsTable[i]; return b; }
     static uint32_t mlBase(int c) { uint32_t b = 3; for (int i = 0; i < c; i++) b += 1u << zfse::mlBitsTable[i]; return b; }
@@ -185,7 +189,7 @@ struct FrameDec {
 
     // blockdec.go:560-640: one sequence table according to its compression mode.  Advances *pp.
     bool readSeqTable(int mode, int kind, const uint8_t** pp, const uint8_t* end, SeqTable* t) {
-        static const int maxSym[3] = {35, 31, 52}, maxLog[3] = {9, 8, 9};
+        static const int maxSym[3] = {35, 30, 52}, maxLog[3] = {9, 8, 9};  // maxOffsetLengthSymbol = 30 (zstd/fse_predefined.go:45)
         if (mode == 0) {  // predefined
             zfse::Predef& pd = zfse::predef();
             return t->fromNorm(pd.enc[kind].norm, pd.enc[kind].symbolLen, pd.enc[kind].actualTableLog);
@@ -225,6 +229,11 @@ struct FrameDec {
             if (nSeq < 255) { if (p >= end) return false; nSeq = ((nSeq - 128) << 8) + *p++; }
             else { if (p + 2 > end) return false; nSeq = (size_t)p[0] + ((size_t)p[1] << 8) + 0x7F00; p += 2; }
         }
+        if (trace) {
+            char tb[128];
+            snprintf(tb, sizeof(tb), " litType=%d litBytes=%zu nSeq=%zu", b[0] & 3, lits.size(), nSeq);
+            *trace += tb;
+        }
         if (nSeq == 0) {
             if (p != end) return false;
             out.insert(out.end(), lits.begin(), lits.end());
@@ -232,6 +241,11 @@ struct FrameDec {
         }
         if (p >= end) return false;
         const uint8_t modes = *p++;
+        if (trace) {
+            char tb[96];
+            snprintf(tb, sizeof(tb), " modes(ll,of,ml)=%d,%d,%d first:", (modes >> 6) & 3, (modes >> 4) & 3, (modes >> 2) & 3);
+            *trace += tb;
+        }
         if (modes & 3) return false;  // reserved bits
         if (!readSeqTable((modes >> 6) & 3, 0, &p, end, &ll)) return false;
         if (!readSeqTable((modes >> 4) & 3, 1, &p, end, &of)) return false;
@@ -242,10 +256,16 @@ struct FrameDec {
         size_t lp = 0;
         for (size_t i = 0; i < nSeq; i++) {
             const int lc = ll.dt[llS].symbol, oc = of.dt[ofS].symbol, mc = ml.dt[mlS].symbol;
-            if (lc > 35 || mc > 52 || oc > 31) return false;
+            if (lc > 35 || mc > 52 || oc > 30) return false;
             const uint64_t ofVal = ((uint64_t)1 << oc) + br.read(oc);
             const uint32_t mlen = mlBase(mc) + (uint32_t)br.read(zfse::mlBitsTable[mc]);
             const uint32_t llen = llBase(lc) + (uint32_t)br.read(zfse::llBitsTable[lc]);
+            if (trace && ofVal <= 3) repSeen[ofVal]++;
+            if (trace && i < 4) {
+                char tb[96];
+                snprintf(tb, sizeof(tb), " [ll=%u ml=%u %s%llu]", llen, mlen, ofVal > 3 ? "off=" : "REP", (unsigned long long)(ofVal > 3 ? ofVal - 3 : ofVal));
+                *trace += tb;
+            }
             uint32_t off;
             if (ofVal > 3) {  // seqdec.go: new offset
                 off = (uint32_t)(ofVal - 3);
@@ -317,6 +337,11 @@ struct FrameDec {
             const bool last = bh & 1;
             const int type = (bh >> 1) & 3;
             const size_t size = bh >> 3;
+            if (trace) {
+                char tb[96];
+                snprintf(tb, sizeof(tb), "%sblock type=%d size=%zu last=%d", trace->empty() ? "" : "\n", type, size, (int)last);
+                *trace += tb;
+            }
             if (type == 0) {
                 if (p + size > n) return 0;
                 out.insert(out.end(), in + p, in + p + size);

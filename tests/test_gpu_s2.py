@@ -223,7 +223,7 @@ def test_s2_writer_chunking_and_bytes(oracle, kclib):
     with pytest.raises(ValueError):
         s2.NewWriter(io.BytesIO(), s2.WriterBlockSize(1000))
     with pytest.raises(NotImplementedError):
-        s2.NewWriter(io.BytesIO(), s2.WriterBetterCompression())
+        s2.NewWriter(io.BytesIO(), s2.WriterBestCompression())
 
 
 def test_s2_device_decoder_roundtrip_and_errors(oracle, kclib):
@@ -346,3 +346,72 @@ def test_s2_writer_padding(oracle, kclib):
     assert oracle.s2_decode_stream(got, len(data) + 16) == data
     with pytest.raises(ValueError):
         s2.NewWriter(io.BytesIO(), s2.WriterPadding(0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# s2.EncodeBetter (KC_S2_LEVEL_BETTER): encodeBlockBetterGo64K / encodeBlockBetterGo
+# ---------------------------------------------------------------------------------------------------------------------
+def _check_better(oracle, blocks):
+    from compress_amd import s2
+    buf, off = corpora.pack_units(blocks)
+    enc = s2.BlockEncoder(level=s2.LevelBetter)
+    out, out_off = enc.EncodeBlocks(buf, off)
+    ref, ref_off = oracle.s2_encode_blocks(buf, off, threads=8, better=True)
+    bad = []
+    for i in range(len(blocks)):
+        a = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        b = np.asarray(ref)[int(ref_off[i]):int(ref_off[i + 1])].tobytes()
+        if a != b:
+            bad.append((i, len(blocks[i]), len(a), len(b)))
+    assert not bad, "blocks differing from the oracle's EncodeBetter (index, in_len, gpu_len, oracle_len): %r" % bad[:10]
+    for i in (0, len(blocks) // 2, len(blocks) - 1):
+        a = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        assert oracle.s2_decode(a, len(blocks[i]) + 8) == blocks[i]
+    enc.Close()
+
+
+@pytest.mark.parametrize("kind", ["J", "T", "M", "H"])
+def test_s2_better_64k_blocks_bit_exact(oracle, kclib, kind):
+    buf = corpora.corpus(kind, 128, 65536)
+    _check_better(oracle, [buf[i * 65536:(i + 1) * 65536].tobytes() for i in range(128)])
+
+
+def test_s2_better_edge_blocks_bit_exact(oracle, kclib):
+    _check_better(oracle, corpora.edge_units())
+
+
+def test_s2_better_large_blocks_bit_exact(oracle, kclib):
+    """Blocks > 64 KiB take encodeBlockBetterGo (2^17 / 2^14 tables, skip >>7, the offset > 65535 short-match bail)."""
+    j = corpora.corpus("J", 8, 1 << 20).tobytes()
+    t = corpora.corpus("T", 8, 1 << 20).tobytes()
+    m = corpora.corpus("M", 4, 1 << 20).tobytes()
+    blocks = [j[:65537], j[:200000], t[:1 << 20], j[1 << 20:3 << 20], m[:4 << 20], t[100:700000], (b"abcd" * 300000), bytes(1 << 20),
+              t[:70000] + j[:70000] + t[:70000]]
+    _check_better(oracle, blocks)
+
+
+def test_s2_better_reference_inputs_bit_exact(oracle, kclib):
+    import os
+    import zipfile
+    z = zipfile.ZipFile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_inputs", "enc_regressions.zip"))
+    blocks = [z.read(n) for n in z.namelist()]
+    blocks = [b for b in blocks if 0 < len(b) <= (4 << 20)]
+    _check_better(oracle, blocks)
+
+
+def test_s2_writer_better_stream_roundtrip(oracle, kclib):
+    """s2.NewWriter(w, WriterBetterCompression()): chunks carry EncodeBetter blocks; the stream decodes back."""
+    import io
+    from compress_amd import s2
+    data = corpora.corpus("J", 40, 65536).tobytes() + corpora.corpus("H", 2, 65536).tobytes()
+    sink = io.BytesIO()
+    w = s2.NewWriter(sink, s2.WriterBlockSize(64 << 10), s2.WriterBetterCompression())
+    w.Write(data)
+    w.Close()
+    enc = sink.getvalue()
+    assert oracle.s2_decode_stream(enc, len(data) + 16) == data
+    sink0 = io.BytesIO()
+    w0 = s2.NewWriter(sink0, s2.WriterBlockSize(64 << 10))
+    w0.Write(data)
+    w0.Close()
+    assert len(enc) < len(sink0.getvalue())

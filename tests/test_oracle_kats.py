@@ -427,3 +427,37 @@ def test_huff0_and_fse_outcome_tables(oracle):
         r = L.kco_fse_compress(d, len(d), buf, len(buf))
         got = 0 if r >= 0 else -r
         assert got == e, ("fse", name, got, e)
+
+
+def test_s2_encode_better_roundtrip_and_gain(oracle):
+    """s2.EncodeBetter restatement (oracle/kco_s2.h: encodeBlockBetterGoT): every block decodes back through the restated
+    decoder, is never larger than MaxEncodedLen, and is smaller than s2.Encode's block on compressible corpora — the reference's
+    own criterion for its levels is the round trip (s2/encode_test.go TestEncoderRegression runs Encode, EncodeBetter, EncodeBest
+    through Decode).  Both table variants: <= 64 KiB (u16 tables, 2^16 / 2^13) and larger (2^17 / 2^14 + the long-offset bail)."""
+    import corpora
+    for kind in "TJM":
+        for n in (65536, 65537, 1 << 20):
+            d = corpora.corpus(kind, 1, n).tobytes()
+            b = oracle.s2_encode_better(d)
+            assert oracle.s2_decode(b, n + 8) == d
+            assert len(b) <= oracle.lib().kco_s2_max_encoded_len(n)
+            assert len(b) < len(oracle.s2_encode(d)), (kind, n)
+    for u in corpora.edge_units():
+        b = oracle.s2_encode_better(u)
+        assert oracle.s2_decode(b, len(u) + 8) == u
+    h = corpora.corpus("H", 1, 65536).tobytes()
+    assert len(oracle.s2_encode_better(h)) == len(h) + 3 + 3  # incompressible: uvarint(3) + one literal (tag 61<<2 + 2 length bytes)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference fixtures not present on this machine")
+def test_s2_encode_better_reference_regressions_roundtrip(oracle):
+    import zipfile
+    z = zipfile.ZipFile(os.path.join(REF, "s2/testdata/enc_regressions.zip"))
+    n = 0
+    for name in z.namelist():
+        d = z.read(name)
+        if not d:
+            continue
+        assert oracle.s2_decode(oracle.s2_encode_better(d), len(d) + 8) == d, name
+        n += 1
+    assert n > 40
