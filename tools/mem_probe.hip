@@ -10,8 +10,8 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-enum { RD4 = 0, RD4_SC1, RD4_NT, RD4_ST4, EXCH, RD8, RD16, RD4_ST4_SC1, RD4_SYS, ST4_ONLY, NVAR };
-static const char* NAMES[NVAR] = {"rd4", "rd4_sc1", "rd4_nt", "rd4+st4", "atomic_exch", "rd8", "rd16", "rd4sc1+st4sc0sc1", "rd4_sys", "st4_only"};
+enum { RD4 = 0, RD4_SC1, RD4_NT, RD4_ST4, EXCH, RD8, RD16, RD4_ST4_SC1, RD4_SYS, ST4_ONLY, RD4_ST64, ST4_BOTH_ONLY, NVAR };
+static const char* NAMES[NVAR] = {"rd4", "rd4_sc1", "rd4_nt", "rd4+st4", "atomic_exch", "rd8", "rd16", "rd4sc1+st4sc0sc1", "rd4_sys", "st4_only", "rd4+st64B_line", "st4+sibling_only"};
 
 __device__ __forceinline__ uint32_t lcg(uint32_t& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
 
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void probe(uint32_t* __restrict__ arena, uint32
 #pragma unroll
         for (int k = 0; k < K; k++) {
             uint32_t* p = tab + idx[k];
-            if (V == RD4 || V == RD4_ST4) v[k] = *(volatile uint32_t*)p;
+            if (V == RD4 || V == RD4_ST4 || V == RD4_ST64) v[k] = *(volatile uint32_t*)p;
             else if (V == RD4_SC1 || V == RD4_ST4_SC1) v[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else if (V == RD4_SYS) v[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             else if (V == RD4_NT) v[k] = __builtin_nontemporal_load(p);
@@ -45,6 +45,12 @@ __global__ __launch_bounds__(64) void probe(uint32_t* __restrict__ arena, uint32
             if (V == RD4_ST4) tab[idx[k]] = v[k] + 1u;
             if (V == RD4_ST4_SC1) __hip_atomic_store(tab + idx[k], v[k] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (V == ST4_ONLY) tab[idx[k]] = idx[k] + it;
+            if (V == ST4_BOTH_ONLY) { tab[idx[k]] = idx[k] + it; tab[idx[k] ^ 8u] = idx[k] + it + 1u; }
+            if (V == RD4_ST64) {  // rewrite the whole 64-byte line
+                uint4* q = (uint4*)(tab + (idx[k] & ~15u));
+                const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+                q[0] = make_uint4(a.x + 1u, a.y, a.z, a.w); q[1] = b; q[2] = c; q[3] = d;
+            }
         }
     }
     if (acc == 0x12345678u) sink[0] = acc;
@@ -68,6 +74,7 @@ static double run(uint32_t* arena, uint32_t n_tables, uint32_t waves, uint32_t i
 int main(int argc, char** argv) {
     const uint32_t waves = argc > 1 ? (uint32_t)atoi(argv[1]) : 4096;
     const uint32_t iters = argc > 2 ? (uint32_t)atoi(argv[2]) : 512;
+    const uint32_t vmask = argc > 3 ? (uint32_t)strtoul(argv[3], nullptr, 0) : 0xFFFFFFFFu;
     const uint32_t max_tables = 32768;
     uint32_t* arena; uint32_t* sink;
     CK(hipMalloc(&arena, (size_t)max_tables * 131072));
@@ -79,6 +86,7 @@ int main(int argc, char** argv) {
     for (uint32_t nt : sizes) printf(" %9uMiB", nt / 8);
     printf("   (G requests/s)\n");
     for (int v = 0; v < NVAR; v++) {
+        if (!((vmask >> v) & 1u)) continue;
         printf("%-18s", NAMES[v]);
         for (uint32_t nt : sizes) {
             double ms = 0;
@@ -93,6 +101,8 @@ int main(int argc, char** argv) {
             case RD4_ST4_SC1: ms = run<RD4_ST4_SC1, 2>(arena, nt, waves, iters, sink); break;
             case RD4_SYS: ms = run<RD4_SYS, 2>(arena, nt, waves, iters, sink); break;
             case ST4_ONLY: ms = run<ST4_ONLY, 2>(arena, nt, waves, iters, sink); break;
+            case RD4_ST64: ms = run<RD4_ST64, 2>(arena, nt, waves, iters, sink); break;
+            case ST4_BOTH_ONLY: ms = run<ST4_BOTH_ONLY, 2>(arena, nt, waves, iters, sink); break;
             }
             const double req = (double)waves * 64.0 * iters * 2.0;
             printf(" %12.1f", req / (ms * 1e-3) / 1e9);
