@@ -1132,7 +1132,7 @@ int64_t kc_s2_max_encoded_len(int64_t srcLen) {  // s2/encode.go:389-418 (64-bit
 static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
                                uint64_t dst_cap, uint64_t* out_off, int framed, int with_stream_id, int level = KC_S2_LEVEL_DEFAULT) {
     if (!c || !blk_off || !out_off || (n && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
-    if (level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_BETTER) { c->err = "device path implements s2.Encode and s2.EncodeBetter"; return KC_ERR_UNSUPPORTED; }
+    if (level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_BETTER && level != KC_S2_LEVEL_SNAPPY) { c->err = "device path implements s2.Encode, s2.EncodeBetter and s2.EncodeSnappy"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
     c->last = kc_timings{0, 0, 0, 0, 0};
     HIPCHK(c, hipSetDevice(c->device));
@@ -1320,7 +1320,7 @@ kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk
 kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* dst, uint64_t dst_cap,
                                   uint64_t* out_off) {
     if (!c || !blk_off || !out_off || (n && (!src || !dst))) return KC_ERR_BAD_ARG;
-    if (level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_BETTER) { c->err = "device path implements s2.Encode and s2.EncodeBetter"; return KC_ERR_UNSUPPORTED; }
+    if (level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_BETTER && level != KC_S2_LEVEL_SNAPPY) { c->err = "device path implements s2.Encode, s2.EncodeBetter and s2.EncodeSnappy"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
     HIPCHK(c, hipSetDevice(c->device));
     if (n == 0) { out_off[0] = 0; return KC_OK; }

@@ -126,6 +126,51 @@ __device__ inline int s2_emit_copy1(uint8_t* dst, int offset, int length) {
     dst[1] = (uint8_t)offset; dst[0] = (uint8_t)((uint32_t)(offset >> 8) << 5 | (uint32_t)(length - 4) << 2 | 1);
     return 2;
 }
+// emitCopyNoRepeat (encode_go.go:241): the Snappy-compatible copy encoding; single lane writes.
+__device__ inline int s2_emit_copy_nr1(uint8_t* dst, int offset, int length) {
+    int total = 0;
+    for (;;) {
+        if (offset >= 65536) {
+            int i = 0;
+            if (length > 64) {
+                dst[4] = (uint8_t)(offset >> 24); dst[3] = (uint8_t)(offset >> 16); dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset; dst[0] = 63 << 2 | 3;
+                length -= 64;
+                if (length >= 4) { dst += 5; total += 5; continue; }  // tail call emitCopyNoRepeat(dst[5:], offset, length)
+                i = 5;
+            }
+            if (length == 0) return total + i;
+            dst[i + 0] = (uint8_t)((uint32_t)(length - 1) << 2 | 3);
+            dst[i + 1] = (uint8_t)offset; dst[i + 2] = (uint8_t)(offset >> 8); dst[i + 3] = (uint8_t)(offset >> 16); dst[i + 4] = (uint8_t)(offset >> 24);
+            return total + i + 5;
+        }
+        if (length > 64) {
+            dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset; dst[0] = 59 << 2 | 2;
+            length -= 60;
+            dst += 3; total += 3;
+            continue;
+        }
+        if (length >= 12 || offset >= 2048) {
+            dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset; dst[0] = (uint8_t)((uint32_t)(length - 1) << 2 | 2);
+            return total + 3;
+        }
+        dst[1] = (uint8_t)offset; dst[0] = (uint8_t)((uint32_t)(offset >> 8) << 5 | (uint32_t)(length - 4) << 2 | 1);
+        return total + 2;
+    }
+}
+__device__ inline int s2_copy_nr_size(int offset, int length) {
+    int total = 0;
+    for (;;) {
+        if (offset >= 65536) {
+            int i = 0;
+            if (length > 64) { length -= 64; if (length >= 4) { total += 5; continue; } i = 5; }
+            if (length == 0) return total + i;
+            return total + i + 5;
+        }
+        if (length > 64) { length -= 60; total += 3; continue; }
+        if (length >= 12 || offset >= 2048) return total + 3;
+        return total + 2;
+    }
+}
 // sizes without writing (every lane of the group needs the byte count; only lane 0 writes)
 __device__ inline int s2_repeat_size(int offset, int length) {
     int total = 0;
@@ -173,7 +218,7 @@ __device__ __forceinline__ uint32_t s2_crc32c(const uint8_t* __restrict__ p, int
     return c ^ 0xFFFFFFFFu;
 }
 
-template <int LEVEL>  // 0: s2.Encode (encodeBlockGo / encodeBlockGo64K), 1: s2.EncodeBetter (encodeBlockBetterGo / ...Go64K)
+template <int LEVEL>  // 0: s2.Encode (encodeBlockGo / ...64K), 1: s2.EncodeBetter (encodeBlockBetterGo / ...64K), 2: s2.EncodeSnappy (encodeBlockSnappyGo / ...64K)
 __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     constexpr int G = S2G;
     __shared__ uint32_t crcT[4][256];
@@ -217,7 +262,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     if (len == 0) stored = true;
     if (len < 32) stored = true;  // minNonLiteralBlockSize
 
-    if (LEVEL == 0 && !stored) {
+    if ((LEVEL == 0 || LEVEL == 2) && !stored) {
+        constexpr bool SNAPPY = LEVEL == 2;  // encode_all.go:502 / :692: the same parse, every copy through emitCopyNoRepeat
         const int SKIP = len <= (64 << 10) ? 5 : 6;  // encodeBlockGo64K vs encodeBlockGo (encode_go.go:23-26)
         const int PB = bits_len32((uint32_t)len);
         const int TB = (32 - PB) > 16 ? 16 : (32 - PB);
@@ -317,7 +363,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 d += s2_emit_literal(dst + d, src + nextEmit, base - nextEmit, lig);
                 const int cand2 = ps - repeat + 4 + 1;
                 s = s2_extend(src, ps + 4 + 1, cand2, sLimit, lig, grp);
-                if (nextEmit > 0) { if (lig == 0) s2_emit_repeat1(dst + d, repeat, s - base); d += s2_repeat_size(repeat, s - base); }
+                if (SNAPPY) { if (lig == 0) s2_emit_copy_nr1(dst + d, repeat, s - base); d += s2_copy_nr_size(repeat, s - base); }
+                else if (nextEmit > 0) { if (lig == 0) s2_emit_repeat1(dst + d, repeat, s - base); d += s2_repeat_size(repeat, s - base); }
                 else { if (lig == 0) s2_emit_copy1(dst + d, repeat, s - base); d += s2_copy_size(repeat, s - base); }
                 nextEmit = s;
                 if (s >= sLimit) fin = true;
@@ -338,8 +385,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 const int base = s;
                 repeat = base - candidate;
                 s = s2_extend(src, s + 4, candidate + 4, len - 8, lig, grp);
-                if (lig == 0) s2_emit_copy1(dst + d, repeat, s - base);
-                d += s2_copy_size(repeat, s - base);
+                if (SNAPPY) { if (lig == 0) s2_emit_copy_nr1(dst + d, repeat, s - base); d += s2_copy_nr_size(repeat, s - base); }
+                else { if (lig == 0) s2_emit_copy1(dst + d, repeat, s - base); d += s2_copy_size(repeat, s - base); }
                 nextEmit = s;
                 if (s >= sLimit) { fin = true; break; }
                 if (d > dstLimit) { stored = true; break; }
@@ -563,5 +610,6 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
 void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st) {
     if (P.n_blocks == 0) return;
     if (P.level == 1) hipLaunchKernelGGL(kc_s2_encode_kernel<1>, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
+    else if (P.level == 2) hipLaunchKernelGGL(kc_s2_encode_kernel<2>, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
     else hipLaunchKernelGGL(kc_s2_encode_kernel<0>, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
 }

@@ -497,6 +497,7 @@ int64_t kco_s2_max_encoded_len(int64_t n) { return s2::MaxEncodedLen(n); }
 int64_t kco_s2_encode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::Encode(dst, cap, src, (size_t)n); }
 // encodeBlock only (no varint header); 0 == incompressible.  The WriterCustomEncoder contract.
 int64_t kco_s2_encode_better(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeBetter(dst, cap, src, (size_t)n); }
+int64_t kco_s2_encode_snappy(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeSnappy(dst, cap, src, (size_t)n); }
 int64_t kco_s2_encode_block(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
     if (cap < (uint64_t)s2::MaxEncodedLen((int64_t)n)) return -2;
     return s2::encodeBlock(dst, src, (size_t)n);
@@ -529,7 +530,7 @@ int64_t kco_s2_encode_stream(const uint8_t* src, const uint64_t* blk_off, uint32
 int64_t kco_s2_decode_stream(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::DecodeStream(dst, cap, src, (size_t)n); }
 
 static int64_t s2_encode_blocks_impl(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
-                                     uint64_t* out_off, int threads, bool better) {
+                                     uint64_t* out_off, int threads, int level) {
     if (threads < 1) threads = 1;
     std::vector<Bytes> outs(n_blocks);
     std::atomic<uint32_t> next(0);
@@ -539,8 +540,9 @@ static int64_t s2_encode_blocks_impl(const uint8_t* src, const uint64_t* blk_off
             if (i >= n_blocks) break;
             size_t n = (size_t)(blk_off[i + 1] - blk_off[i]);
             outs[i].resize((size_t)s2::MaxEncodedLen((int64_t)n));
-            int64_t r = better ? s2::EncodeBetter(outs[i].data(), outs[i].size(), src + blk_off[i], n)
-                               : s2::Encode(outs[i].data(), outs[i].size(), src + blk_off[i], n);
+            int64_t r = level == 1 ? s2::EncodeBetter(outs[i].data(), outs[i].size(), src + blk_off[i], n)
+                      : level == 2 ? s2::EncodeSnappy(outs[i].data(), outs[i].size(), src + blk_off[i], n)
+                                   : s2::Encode(outs[i].data(), outs[i].size(), src + blk_off[i], n);
             outs[i].resize((size_t)r);
         }
     };
@@ -560,11 +562,15 @@ static int64_t s2_encode_blocks_impl(const uint8_t* src, const uint64_t* blk_off
 // N x s2.Encode(nil, block) / N x s2.EncodeBetter(nil, block) on `threads` host threads
 int64_t kco_s2_encode_blocks(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
                              uint64_t* out_off, int threads) {
-    return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, false);
+    return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, 0);
 }
 int64_t kco_s2_encode_blocks_better(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
                                     uint64_t* out_off, int threads) {
-    return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, true);
+    return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, 1);
+}
+int64_t kco_s2_encode_blocks_snappy(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
+                                    uint64_t* out_off, int threads) {
+    return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, 2);
 }
 
 }  // extern "C"

@@ -126,8 +126,39 @@ static inline uint32_t hash6(uint64_t u, uint8_t h) {
     return (uint32_t)(((u << (64 - 48)) * prime6bytes) >> ((64 - h) & 63));
 }
 
-// s2/encode_all.go:72 encodeBlockGo (T=uint32_t, SKIP=6) / :287 encodeBlockGo64K (T=uint16_t, SKIP=5)
-template <typename T, int SKIP>
+// s2/encode_go.go:241 emitCopyNoRepeat: the Snappy-compatible copy encoding (no repeat tags)
+static inline int emitCopyNoRepeat(uint8_t* dst, int offset, int length) {
+    if (offset >= 65536) {
+        int i = 0;
+        if (length > 64) {
+            dst[4] = (uint8_t)(offset >> 24); dst[3] = (uint8_t)(offset >> 16); dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset;
+            dst[0] = 63 << 2 | 3;
+            length -= 64;
+            if (length >= 4) return 5 + emitCopyNoRepeat(dst + 5, offset, length);
+            i = 5;
+        }
+        if (length == 0) return i;
+        dst[i + 0] = (uint8_t)((uint8_t)(length - 1) << 2 | 3);
+        dst[i + 1] = (uint8_t)offset; dst[i + 2] = (uint8_t)(offset >> 8); dst[i + 3] = (uint8_t)(offset >> 16); dst[i + 4] = (uint8_t)(offset >> 24);
+        return i + 5;
+    }
+    if (length > 64) {
+        dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset; dst[0] = 59 << 2 | 2;
+        length -= 60;
+        return 3 + emitCopyNoRepeat(dst + 3, offset, length);
+    }
+    if (length >= 12 || offset >= 2048) {
+        dst[2] = (uint8_t)(offset >> 8); dst[1] = (uint8_t)offset; dst[0] = (uint8_t)((uint8_t)(length - 1) << 2 | 2);
+        return 3;
+    }
+    dst[1] = (uint8_t)offset;
+    dst[0] = (uint8_t)((uint8_t)(offset >> 8) << 5 | (uint8_t)(length - 4) << 2 | 1);
+    return 2;
+}
+
+// s2/encode_all.go:72 encodeBlockGo (T=uint32_t, SKIP=6) / :287 encodeBlockGo64K (T=uint16_t, SKIP=5);
+// SNAPPY: :502 encodeBlockSnappyGo / :692 encodeBlockSnappyGo64K — the same parse, every copy through emitCopyNoRepeat
+template <typename T, int SKIP, bool SNAPPY = false>
 static int encodeBlockGoT(uint8_t* dst, const uint8_t* src, size_t srcLen) {
     const uint8_t tableBits = 14;
     const int maxTableSize = 1 << tableBits;
@@ -167,7 +198,8 @@ static int encodeBlockGoT(uint8_t* dst, const uint8_t* src, size_t srcLen) {
                         s += 8;
                         cand += 8;
                     }
-                    if (nextEmit > 0) d += emitRepeat(dst + d, repeat, s - base);
+                    if (SNAPPY) d += emitCopyNoRepeat(dst + d, repeat, s - base);
+                    else if (nextEmit > 0) d += emitRepeat(dst + d, repeat, s - base);
                     else d += emitCopy(dst + d, repeat, s - base);
                     nextEmit = s;
                     if (s >= sLimit) goto emitRemainder;
@@ -202,7 +234,7 @@ static int encodeBlockGoT(uint8_t* dst, const uint8_t* src, size_t srcLen) {
                 s += 8;
                 candidate += 8;
             }
-            d += emitCopy(dst + d, repeat, s - base);
+            d += SNAPPY ? emitCopyNoRepeat(dst + d, repeat, s - base) : emitCopy(dst + d, repeat, s - base);
             nextEmit = s;
             if (s >= sLimit) goto emitRemainder;
             if (d > dstLimit) return 0;
@@ -361,6 +393,20 @@ emitRemainder:
 static inline int encodeBlockBetter(uint8_t* dst, const uint8_t* src, size_t n) {
     if (n <= ((size_t)64 << 10)) return encodeBlockBetterGoT<uint16_t, 16, 13, 6, false>(dst, src, n);
     return encodeBlockBetterGoT<uint32_t, 17, 14, 7, true>(dst, src, n);
+}
+
+// s2/encode.go:204 EncodeSnappy (s2/encode_go.go:27 encodeBlockSnappy); returns bytes written or -1 / -2
+static inline int64_t EncodeSnappy(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n) {
+    int64_t m = MaxEncodedLen((int64_t)n);
+    if (m < 0) return -1;
+    if (cap < (uint64_t)m) return -2;
+    int d = putUvarint(dst, (uint64_t)n);
+    if (n == 0) return d;
+    if (n < (size_t)minNonLiteralBlockSize) { d += emitLiteral(dst + d, src, n); return d; }
+    int k = n <= ((size_t)64 << 10) ? encodeBlockGoT<uint16_t, 5, true>(dst + d, src, n) : encodeBlockGoT<uint32_t, 6, true>(dst + d, src, n);
+    if (k > 0) return d + k;
+    d += emitLiteral(dst + d, src, n);
+    return d;
 }
 
 // s2/encode.go:117 EncodeBetter; returns bytes written or -1 (too large) / -2 (dst too small)

@@ -37,11 +37,23 @@ func CustomEncoder(x *Ctx) func(dst, src []byte) int {
 	}
 }
 
+// Levels of EncodeBlocksLevel.
+const (
+	LevelDefault = 0 // s2.Encode
+	LevelBetter  = 1 // s2.EncodeBetter
+	LevelSnappy  = 2 // s2.EncodeSnappy
+)
+
 // EncodeBlocks == N x s2.Encode(nil, src[off[i]:off[i+1]]).
 func EncodeBlocks(x *Ctx, src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
+	return EncodeBlocksLevel(x, LevelDefault, src, off, dst)
+}
+
+// EncodeBlocksLevel == N x s2.Encode / s2.EncodeBetter / s2.EncodeSnappy (nil, src[off[i]:off[i+1]]).
+func EncodeBlocksLevel(x *Ctx, level int, src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
 	n := len(off) - 1
 	outOff := make([]uint64, n+1)
-	st := C.kc_s2_encode_blocks(x.c, (*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
+	st := C.kc_s2_encode_blocks_lvl(x.c, C.int(level), (*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
 		(*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
 	if st != C.KC_OK {
 		return nil, nil, errors.New(C.GoString(C.kc_last_error(x.c)))

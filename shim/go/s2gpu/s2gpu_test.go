@@ -42,6 +42,46 @@ func TestBitExact(t *testing.T) {
 	}
 }
 
+// TestBitExactLevels: the better and Snappy-compatible levels against s2.EncodeBetter / s2.EncodeSnappy.
+func TestBitExactLevels(t *testing.T) {
+	x, err := NewCtx(0)
+	if err != nil {
+		t.Skip(err)
+	}
+	defer x.Close()
+	for _, kind := range []byte{'J', 'T', 'M'} {
+		data, err := kcgpu.CorpusFill(kind, kcgpu.Seed(kind), 0, 64, 64<<10)
+		if err != nil {
+			t.Fatal(err)
+		}
+		for _, unit := range []int{64 << 10, 1 << 20} { // both table variants of every level
+			var off []uint64
+			for p := 0; p < len(data); p += unit {
+				off = append(off, uint64(p))
+			}
+			off = append(off, uint64(len(data)))
+			dst := make([]byte, len(off)*(s2.MaxEncodedLen(unit)+16)+64)
+			for _, lv := range []int{LevelBetter, LevelSnappy} {
+				out, outOff, err := EncodeBlocksLevel(x, lv, data, off, dst)
+				if err != nil {
+					t.Fatal(err)
+				}
+				for i := 0; i+1 < len(off); i++ {
+					var want []byte
+					if lv == LevelBetter {
+						want = s2.EncodeBetter(nil, data[off[i]:off[i+1]])
+					} else {
+						want = s2.EncodeSnappy(nil, data[off[i]:off[i+1]])
+					}
+					if !bytes.Equal(out[outOff[i]:outOff[i+1]], want) {
+						t.Fatalf("corpus %c unit %d level %d block %d differs from the reference", kind, unit, lv, i)
+					}
+				}
+			}
+		}
+	}
+}
+
 // TestCustomEncoderWriter: an s2.Writer that encodes its blocks through the hook writes the same stream as the
 // built-in encoder, with the writer calling the hook from WriterConcurrency goroutines at once (s2/writer.go:455-460).
 func TestCustomEncoderWriter(t *testing.T) {
@@ -92,6 +132,13 @@ func TestWriteGolden(t *testing.T) {
 			h.Write(s2.Encode(nil, data[i*(64<<10):(i+1)*(64<<10)]))
 		}
 		lines[fmt.Sprintf("s2.%c.128x65536", kind)] = hex.EncodeToString(h.Sum(nil))
+		hb, hs := sha256.New(), sha256.New()
+		for i := 0; i < 128; i++ {
+			hb.Write(s2.EncodeBetter(nil, data[i*(64<<10):(i+1)*(64<<10)]))
+			hs.Write(s2.EncodeSnappy(nil, data[i*(64<<10):(i+1)*(64<<10)]))
+		}
+		lines[fmt.Sprintf("s2better.%c.128x65536", kind)] = hex.EncodeToString(hb.Sum(nil))
+		lines[fmt.Sprintf("s2snappy.%c.128x65536", kind)] = hex.EncodeToString(hs.Sum(nil))
 	}
 	names := make([]string, 0, len(lines))
 	for n := range lines {

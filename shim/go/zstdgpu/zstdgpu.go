@@ -14,6 +14,7 @@ import "C"
 import (
 	"bytes"
 	"errors"
+	"io"
 	"unsafe"
 
 	"github.com/klauspost/compress/zstd"
@@ -230,4 +231,109 @@ func (e *Encoder) EncodeUnits(src []byte, off []uint64, dst []byte) ([]byte, []u
 	}
 	outOff[n] = uint64(len(out))
 	return out, outOff, nil
+}
+
+// Writer is the io.WriteCloser face of the engine: the drop-in for
+//
+//	enc, _ := zstd.NewWriter(w, opts...); enc.Write(p) ...; enc.Close()
+//
+// (zstd/encoder.go:140-253, 567-649).  The device encodes whole streams (kc_zstd_encode_streams: the bytes equal what the
+// reference writes for Write(everything) + Close()), so Write only buffers and Close submits.  Anything the device path does
+// not serve — a mid-stream Flush (it cuts a block early, encoder.go:547), streams longer than 32 blocks, dictionaries on the
+// streaming path — is handed to a reference encoder with the same options; the bytes on w are the reference's either way.
+type Writer struct {
+	e      *Encoder
+	w      io.Writer
+	buf    []byte
+	ref    *zstd.Encoder // set once the stream fell back to the reference encoder
+	closed bool
+}
+
+// NewWriter mirrors zstd.NewWriter(w, opts...) with this package's options.
+func NewWriter(w io.Writer, device int, opts ...Option) (*Writer, error) {
+	e, err := New(device, opts...)
+	if err != nil {
+		return nil, err
+	}
+	return &Writer{e: e, w: w}, nil
+}
+
+// Reset discards the state and starts a new stream on w (encoder.go:107).
+func (x *Writer) Reset(w io.Writer) {
+	x.w, x.buf, x.closed = w, x.buf[:0], false
+	x.ref = nil
+}
+
+func (x *Writer) fallback() error {
+	if x.ref == nil {
+		r, err := zstd.NewWriter(x.w, x.e.cpuOpts...)
+		if err != nil {
+			return err
+		}
+		x.ref = r
+		if len(x.buf) > 0 {
+			if _, err := r.Write(x.buf); err != nil {
+				return err
+			}
+			x.buf = x.buf[:0]
+		}
+	}
+	return nil
+}
+
+func (x *Writer) Write(p []byte) (int, error) {
+	if x.closed {
+		return 0, zstd.ErrEncoderClosed
+	}
+	if x.ref != nil {
+		return x.ref.Write(p)
+	}
+	x.buf = append(x.buf, p...)
+	return len(p), nil
+}
+
+// ReadFrom mirrors (*zstd.Encoder).ReadFrom (encoder.go:449).
+func (x *Writer) ReadFrom(r io.Reader) (int64, error) {
+	var n int64
+	chunk := make([]byte, 1<<20)
+	for {
+		k, err := r.Read(chunk)
+		if k > 0 {
+			if _, werr := x.Write(chunk[:k]); werr != nil {
+				return n, werr
+			}
+			n += int64(k)
+		}
+		if err == io.EOF {
+			return n, nil
+		}
+		if err != nil {
+			return n, err
+		}
+	}
+}
+
+// Flush (encoder.go:547) ends the current block early: not a device-path shape; the stream continues on the reference encoder.
+func (x *Writer) Flush() error {
+	if err := x.fallback(); err != nil {
+		return err
+	}
+	return x.ref.Flush()
+}
+
+// Close finishes the stream (encoder.go:567).
+func (x *Writer) Close() error {
+	if x.closed {
+		return nil
+	}
+	x.closed = true
+	if x.ref != nil {
+		return x.ref.Close()
+	}
+	out, _, err := x.e.EncodeStreams(x.buf, []uint64{0, uint64(len(x.buf))}, nil)
+	if err != nil {
+		return err
+	}
+	_, err = x.w.Write(out)
+	return err
 }

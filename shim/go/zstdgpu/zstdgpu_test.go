@@ -136,6 +136,44 @@ func TestBitExactStreams(t *testing.T) {
 	}
 }
 
+// TestWriterDropIn: zstdgpu.Writer writes what zstd.NewWriter(w).Write(p...)+Close() writes, for plain streams, for streams
+// written in pieces, and for streams with a mid-stream Flush (which continue on the reference encoder).
+func TestWriterDropIn(t *testing.T) {
+	data, err := kcgpu.CorpusFill('T', kcgpu.SeedT, 0, 24, 128<<10)
+	if err != nil {
+		t.Fatal(err)
+	}
+	for _, lvl := range levels {
+		for _, flushAt := range []int{-1, 300000} {
+			var want, got bytes.Buffer
+			ref, _ := zstd.NewWriter(&want, zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(1))
+			gw, err := NewWriter(&got, 0, WithEncoderLevel(lvl))
+			if err != nil {
+				t.Fatal(err)
+			}
+			for p := 0; p < len(data); p += 70001 {
+				end := p + 70001
+				if end > len(data) {
+					end = len(data)
+				}
+				ref.Write(data[p:end])
+				gw.Write(data[p:end])
+				if flushAt >= 0 && p <= flushAt && flushAt < end {
+					ref.Flush()
+					gw.Flush()
+				}
+			}
+			ref.Close()
+			if err := gw.Close(); err != nil {
+				t.Fatal(err)
+			}
+			if !bytes.Equal(want.Bytes(), got.Bytes()) {
+				t.Fatalf("level %v flushAt %d: Writer output differs from the reference's", lvl, flushAt)
+			}
+		}
+	}
+}
+
 // TestWriteGolden pins the whole-encoder bytes of the REFERENCE (not of the GPU path) on the seeded corpora:
 // one line "<name> <sha256 of the concatenated frames>" per corpus and level into tests/golden/reference_sha256.txt.
 // tests/test_reference_golden.py then gates the C++ oracle and the HIP path on these hashes — the step that turns

@@ -415,3 +415,20 @@ def test_s2_writer_better_stream_roundtrip(oracle, kclib):
     w0.Write(data)
     w0.Close()
     assert len(enc) < len(sink0.getvalue())
+
+
+@pytest.mark.parametrize("kind", ["J", "T", "M", "H"])
+def test_s2_snappy_blocks_bit_exact(oracle, kclib, kind):
+    """KC_S2_LEVEL_SNAPPY == s2.EncodeSnappy: same parse as the default level, copies through emitCopyNoRepeat."""
+    from compress_amd import s2
+    buf = corpora.corpus(kind, 96, 65536)
+    blocks = [buf[i * 65536:(i + 1) * 65536].tobytes() for i in range(96)]
+    big = corpora.corpus(kind, 2, 1 << 20).tobytes()
+    blocks += [big[:65537], big[:700000], big[1 << 20:]] + [u for u in corpora.edge_units() if len(u) < 70000]
+    b2, off = corpora.pack_units(blocks)
+    enc = s2.BlockEncoder(level=s2.LevelSnappy)
+    out, out_off = enc.EncodeBlocks(b2, off)
+    ref, ref_off = oracle.s2_encode_blocks(b2, off, threads=8, snappy=True)
+    assert np.array_equal(out_off, ref_off)
+    assert np.array_equal(out, np.asarray(ref))
+    enc.Close()

@@ -461,3 +461,66 @@ def test_s2_encode_better_reference_regressions_roundtrip(oracle):
         assert oracle.s2_decode(oracle.s2_encode_better(d), len(d) + 8) == d, name
         n += 1
     assert n > 40
+
+
+def _snappy_decode_strict(enc: bytes) -> bytes:
+    """A decoder of the ORIGINAL Snappy block format only (google/snappy format_description.txt): literals, copy1 (11-bit offset),
+    copy2, copy4 — offset 0 is invalid, which is exactly where S2's repeat tags live.  Independent of the oracle's S2 decoder."""
+    n, shift, p = 0, 0, 0
+    while True:
+        b = enc[p]; p += 1
+        n |= (b & 0x7F) << shift
+        if b < 0x80:
+            break
+        shift += 7
+    out = bytearray()
+    while p < len(enc):
+        tag = enc[p]; t = tag & 3
+        if t == 0:
+            ln = tag >> 2
+            p += 1
+            if ln >= 60:
+                k = ln - 59
+                ln = int.from_bytes(enc[p:p + k], "little"); p += k
+            ln += 1
+            out += enc[p:p + ln]; p += ln
+            continue
+        if t == 1:
+            ln = 4 + ((tag >> 2) & 7); off = ((tag >> 5) << 8) | enc[p + 1]; p += 2
+        elif t == 2:
+            ln = 1 + (tag >> 2); off = enc[p + 1] | (enc[p + 2] << 8); p += 3
+        else:
+            ln = 1 + (tag >> 2); off = int.from_bytes(enc[p + 1:p + 5], "little"); p += 5
+        assert 0 < off <= len(out), "not a Snappy block: offset %d (repeat tag or corrupt)" % off
+        for _ in range(ln):
+            out.append(out[-off])
+    assert len(out) == n
+    return bytes(out)
+
+
+def test_s2_encode_snappy_is_snappy_and_roundtrips(oracle):
+    """s2.EncodeSnappy restatement: a strict Snappy decoder (no S2 extensions) reads the blocks; the reference's golden
+    Snappy file (s2/testdata/Mark.Twain-Tom.Sawyer.txt.rawsnappy, s2_test.go:595-615) checks that decoder."""
+    import corpora
+    gold_dir = os.path.join(REF, "s2", "testdata")
+    if os.path.isdir(gold_dir):
+        want = open(os.path.join(gold_dir, "Mark.Twain-Tom.Sawyer.txt"), "rb").read()
+        assert _snappy_decode_strict(open(os.path.join(gold_dir, "Mark.Twain-Tom.Sawyer.txt.rawsnappy"), "rb").read()) == want
+    for kind in "TJMH":
+        for n in (65536, 65537, 300000):
+            d = corpora.corpus(kind, 1, n).tobytes()
+            b = oracle.s2_encode_snappy(d)
+            assert _snappy_decode_strict(b) == d
+            assert oracle.s2_decode(b, n + 8) == d
+            assert len(b) <= oracle.lib().kco_s2_max_encoded_len(n)
+    for u in corpora.edge_units():
+        b = oracle.s2_encode_snappy(u)
+        assert _snappy_decode_strict(b) == u
+    # the default level does use repeat tags on such data: the strict decoder must refuse at least one of these blocks
+    refused = 0
+    for kind in "TJ":
+        try:
+            _snappy_decode_strict(oracle.s2_encode(corpora.corpus(kind, 1, 65536).tobytes()))
+        except AssertionError:
+            refused += 1
+    assert refused > 0

@@ -1,51 +1,56 @@
 #!/bin/bash
-# Round profile on the GPU box: kernel-trace stats of the default bench command + separate PMC passes for HBM traffic.
-# Usage (from the repo root on the box): bash tools/profile_round.sh <tag>
-TAG=${1:-r01}
+# Round profile on the GPU box (repo root): one bench line per BASELINE configuration, rocprofv3 kernel-trace stats of the default
+# bench command and of the other configurations, and HBM traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes) of every
+# configuration's dominant kernel, stamped with the kernel source hash.  Usage: bash tools/profile_round.sh <tag>
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $R
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python bench.py --no-cpu-baseline > $OUT/kt.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pf.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pw.log 2>&1
+# 1. the default command, as the driver runs it (C2, 10 steps)
+python bench.py > $OUT/bench_C2.json 2> $OUT/bench_C2.err
+# 2. kernel-trace stats of the same command
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_C2 -- python bench.py --no-cpu-baseline --no-end-to-end > $OUT/kt_C2.log 2>&1
+# 3. the other configurations: bench line + kernel-trace stats
+for c in C2H C3 C4 C5; do
+  python bench.py --config $c --steps 5 --warmup 1 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_$c -- python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-device-verify > $OUT/kt_$c.log 2>&1
+done
+# 4. HBM traffic of the dominant kernels (bench.py --pmc: one rocprofv3 pass per counter, one step each)
+for c in C2 C3 C4 C5; do
+  python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-device-verify --pmc > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
+done
 python - <<PY
 import sqlite3, glob, json, csv, os
 out = "$OUT"
-def db(d):
-    f = glob.glob(os.path.join(out, d, "**", "*.db"), recursive=True)
-    return sqlite3.connect(f[0]) if f else None
-k = db("kt")
-rows = list(k.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
-with open(os.path.join(out, "kernel_stats.csv"), "w") as f:
-    w = csv.writer(f); w.writerow(["name", "total_calls", "total_duration_ms", "average_ms", "percentage"])
-    for r in rows: w.writerow([r[0], r[1], round(r[2] / 1e3, 3), round(r[3] / 1e3, 3), round(r[4], 3)])
-def pmc(d, counter):
-    c = db(d); res = {}
-    cols = [x[1] for x in c.execute("pragma table_info(counters_collection)")]
-    ik, ic, iv, idp = cols.index("kernel_name"), cols.index("counter_name"), cols.index("value"), cols.index("dispatch_id")
-    acc = {}
-    for r in c.execute("select * from counters_collection"):
-        if r[ic] != counter: continue
-        acc.setdefault(r[ik], {}).setdefault(r[idp], 0.0)
-        acc[r[ik]][r[idp]] += float(r[iv])
-    return {kname: sorted(v.values())[-1] for kname, v in acc.items()}   # the timed (largest) dispatch
-fs, ws = pmc("pf", "FETCH_SIZE"), pmc("pw", "WRITE_SIZE")
-bj = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
-mk = [n for n in fs if "match_grp" in n][0]; ek = [n for n in fs if "entropy" in n][0]
-pj = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline (two separate passes)",
-      "units": bj["config"]["units_per_gpu"], "corpus": bj["config"]["corpus"], "unit_bytes": bj["config"]["unit_bytes"],
-      "match_kernel": mk, "match_FETCH_SIZE_KB_per_dispatch": fs[mk], "match_WRITE_SIZE_KB_per_dispatch": ws[mk],
-      "match_kernel_hbm_bytes": int((fs[mk] + ws[mk]) * 1024),
-      "entropy_FETCH_SIZE_KB_per_dispatch": fs[ek], "entropy_WRITE_SIZE_KB_per_dispatch": ws[ek],
-      "entropy_kernel_hbm_bytes": int((fs[ek] + ws[ek]) * 1024),
-      "note": "raw (FETCH_SIZE+WRITE_SIZE)*1024; MI355X_MICROARCH.md: FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950 and is uncalibrated for the scattered 4-8 B accesses this kernel issues, so the true read traffic lies between 1x and 2x the FETCH figure",
-      "algorithmic_bytes": int(bj["config"]["units_per_gpu"] * bj["config"]["unit_bytes"] * (1 + bj["ratio"]))}
-json.dump(pj, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-print(open(os.path.join(out, "kernel_stats.csv")).read())
-print(json.dumps(pj, indent=1))
+def stats(tag):
+    f = glob.glob(os.path.join(out, "kt_" + tag, "**", "*.db"), recursive=True)
+    if not f: return
+    k = sqlite3.connect(f[0])
+    rows = list(k.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
+    with open(os.path.join(out, "kernel_stats_%s.csv" % tag), "w") as fo:
+        w = csv.writer(fo); w.writerow(["name", "total_calls", "total_duration_ms", "average_ms", "percentage"])
+        for r in rows: w.writerow([r[0][:120], r[1], round(r[2] / 1e3, 3), round(r[3] / 1e3, 3), round(r[4], 3)])
+for t in ("C2", "C2H", "C3", "C4", "C5"): stats(t)
+entries = []
+for t in ("C2", "C3", "C4", "C5"):
+    try:
+        j = json.loads(open(os.path.join(out, "pmc_%s.json" % t)).read().strip().splitlines()[-1])
+        r = j["roofline"]
+        if r["traffic"]:
+            entries.append({"config": t, "units": j["config"]["units_per_gpu"], "corpus": j["config"]["corpus"], "unit_bytes": j["config"]["unit_bytes"],
+                            "kernel": r["kernel"], "kernel_source_sha16": r["kernel_source_sha16"], "kernel_hbm_bytes": r["traffic"],
+                            "algorithmic_bytes": int(j["config"]["units_per_gpu"] * j["config"]["unit_bytes"] * (1 + j["ratio"])),
+                            "ratio_to_algorithmic": round(r["traffic"] / (j["config"]["units_per_gpu"] * j["config"]["unit_bytes"] * (1 + j["ratio"])), 2),
+                            "kernel_ms": r["kernel_ms"]})
+    except Exception as e:
+        print("pmc", t, "failed:", e)
+json.dump({"command": "python bench.py --config <C> --pmc  (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, one step each; raw (FETCH_SIZE+WRITE_SIZE)*1024)",
+           "entries": entries}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(entries, indent=1))
 PY
 find $OUT -name "*.db" -delete
-cat $OUT/bench.json
+find $OUT -type d -name "kt_*" | xargs rm -rf
+for c in C2 C2H C3 C4 C5; do tail -c 3000 $OUT/bench_$c.json | tail -1 | cut -c1-400; done
+head -8 $OUT/kernel_stats_C2.csv
