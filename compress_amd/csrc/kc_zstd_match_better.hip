@@ -6,10 +6,11 @@
 // short table 2^13 x u32 (5-byte hash).  Every stored position is (pos+1) | tag(4 source bytes) << PB, so
 // candidates that the reference would reject on its 8-byte / 4-byte compare are mostly rejected on the tag
 // without touching their (random) source line.
-// The probe loop advances one position per round (the reference steps by 1 and re-indexes densely, so
-// speculative multi-probe rounds would mostly be rolled back); the group's lanes cooperate on match
-// extension (8 B per lane) and on the dense re-indexing of every second byte of a match, where lanes that
-// hit the same long-table bucket are chained in order exactly as the sequential loop would chain them.
+// The probe loop runs speculative rounds with ordered commit like the other match finders (round 1 probed one position per
+// round: every literal position cost two dependent round trips, and with the 8192 units of a 1 GiB batch the kernel was
+// latency-bound at 0.27 TB/s of HBM traffic); the group's lanes also cooperate on match extension (8 B per lane) and on the
+// dense re-indexing of every second byte of a match, where lanes that hit the same long-table bucket are chained in order
+// exactly as the sequential loop would chain them.
 // Reproduced literally: RLE pre-check (non-dict), repeat at s+1, long / prev-long / short priority, the lazy
 // long lookup at s+1 after a short match (with its table write), the end-of-match re-search with
 // skipBeginning = 3 (non-dict) or 0 (dict), maxMatchLength caps, offset-2 loop, canRepeat snapshot.
@@ -137,23 +138,87 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
         if (!rleBlock && srcLen >= 16) {
             const int sLimit = blkEnd - 10;
             bool fin = false;
+            int W = G;  // speculation width of the probe rounds
             while (!fin) {  // encodeLoop
                 int t = 0, matched = 0, index0 = 0;
                 const bool canRep = nseq > 2;
                 bool brk = false;
-                for (;;) {  // search loop
+                for (;;) {  // search loop: speculative probe rounds with ordered commit (as in the other match finders)
                     rounds++;
-                    const uint64_t cv = ld64(base + s);
-                    const uint32_t nhL = hL(cv), nhS = hS(cv);
-                    const uint2 cL = C.ltab[nhL];
-                    const uint32_t cS = C.stab[nhS];
-                    const int repIndex = s - o1 + 1;
-                    if (lig == 0) {
-                        C.ltab[nhL] = make_uint2(C.mk(s, (uint32_t)cv), cL.x);
-                        C.stab[nhS] = C.mk(s, (uint32_t)cv);
+                    // While no match is found the probe positions are a pure function of (s, nextEmit): s += 1 + ((s-nextEmit)>>8).
+                    // The lanes probe the next W of them against the pre-round tables; a lane whose long or short bucket was
+                    // touched by a lower lane ends the round; lanes up to the first hit commit their table writes (the reference
+                    // writes both tables before it checks, :216-224); the hit is then processed for that one position exactly as
+                    // the sequential loop does, with the winner's loaded entries.
+                    const int d0 = s - nextEmit;
+                    const int k0 = d0 >> 8;  // kSearchStrength-1 == 8
+                    const int step = 1 + k0;
+                    const int pp = s + lig * step;
+                    const bool valid = lig < W && (lig == 0 || ((d0 + (lig - 1) * step) >> 8) == k0) && pp < sLimit;
+                    uint64_t cvl = 0;
+                    uint32_t hl = 0xFFFFFFFFu - (uint32_t)lig, hs = 0xFFFFFF00u - (uint32_t)lig;
+                    uint2 eL = make_uint2(0u, 0u);
+                    uint32_t eS = 0;
+                    if (valid) {
+                        cvl = ld64(base + pp);
+                        hl = hL(cvl);
+                        hs = hS(cvl);
+                        eL = C.ltab[hl];
+                        eS = C.stab[hs];
                     }
+                    bool dep = false;
+#pragma unroll
+                    for (int dd = 1; dd < G; dd++) {
+                        const uint32_t al = (uint32_t)__shfl_up((int)hl, dd, G), as = (uint32_t)__shfl_up((int)hs, dd, G);
+                        if (lig >= dd && (al == hl || as == hs)) dep = true;
+                    }
+                    uint32_t hit = 0;  // 1 repeat at s+1, 2 long (offset), 4 long (prev), 8 short
+                    if (valid) {
+                        const int ri = pp - o1 + 1;
+                        if (canRep && ri >= 0 && ld32(base + ri) == (uint32_t)(cvl >> 8)) hit = 1;
+                        else {
+                            if (C.long_ok(eL.x, pp, cvl)) hit |= 2;
+                            if (C.long_ok(eL.y, pp, cvl)) hit |= 4;
+                            if (hit == 0) {
+                                const int ts = C.posOf(eS);
+                                if (ts >= 0 && (pp - ts) < mmo && (eS >> C.PB) == C.tagOf((uint32_t)cvl) && ld32(base + ts) == (uint32_t)cvl) hit = 8;
+                            }
+                        }
+                    }
+                    const uint32_t vm = gballot<G>(valid, grp);
+                    const uint32_t depm = gballot<G>(valid && dep, grp);
+                    const uint32_t hm = gballot<G>(hit != 0, grp);
+                    const int nvalid = __popc(vm);
+                    const int cc = depm ? __builtin_ctz(depm) : G;
+                    const uint32_t hmc = hm & ((1u << cc) - 1u);
+                    const bool found = hmc != 0;
+                    const int f = found ? __builtin_ctz(hmc) : 0;
+                    const int commitUpTo = found ? f : ((cc < nvalid ? cc : nvalid) - 1);
+                    if (valid && lig <= commitUpTo) {
+                        const uint32_t e = C.mk(pp, (uint32_t)cvl);
+                        C.ltab[hl] = make_uint2(e, eL.x);
+                        C.stab[hs] = e;
+                    }
+                    if (!found) {
+                        W = P.spec_grow == 0 ? W : (P.spec_grow == 1 ? (W + 1 < G ? W + 1 : G) : ((2 * W < G) ? 2 * W : G));
+                        if (cc < nvalid) {
+                            s = s + cc * step;
+                        } else {
+                            const int pl = s + (nvalid - 1) * step;
+                            s = pl + 1 + ((pl - nextEmit) >> 8);
+                        }
+                        if (s >= sLimit) { fin = true; brk = true; break; }
+                        continue;
+                    }
+                    W = P.spec_w0;
+                    s = s + f * step;
+                    const uint64_t cv = gbcast64<G>(cvl, grp, f);
+                    const uint2 cL = make_uint2(gbcast32<G>(eL.x, grp, f), gbcast32<G>(eL.y, grp, f));
+                    const uint32_t cS = gbcast32<G>(eS, grp, f);
+                    const uint32_t whit = gbcast32<G>(hit, grp, f);
+                    const int repIndex = s - o1 + 1;
                     index0 = s + 1;
-                    if (canRep && repIndex >= 0 && ld32(base + repIndex) == (uint32_t)(cv >> 8)) {
+                    if (whit & 1u) {
                         int ri = repIndex;
                         const int length = 4 + grp_matchlen<G>(base, s + 5, ri + 4, blkEnd - (s + 5), lig, grp);
                         int start = s + 1;
@@ -175,8 +240,8 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                         continue;
                     }
                     // long match on offset, possibly improved by prev (:264-296)
-                    const bool okL = C.long_ok(cL.x, s, cv);
-                    const bool okP = C.long_ok(cL.y, s, cv);
+                    const bool okL = (whit & 2u) != 0;
+                    const bool okP = (whit & 4u) != 0;
                     if (okL) {
                         const int tl = C.posOf(cL.x);
                         matched = grp_matchlen<G>(base, s + 8, tl + 8, blkEnd - (s + 8), lig, grp) + 8;
@@ -196,7 +261,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     }
                     {
                         const int ts = C.posOf(cS);
-                        if (ts >= 0 && (s - ts) < mmo && (cS >> C.PB) == C.tagOf((uint32_t)cv) && ld32(base + ts) == (uint32_t)cv) {
+                        {  // whit == 8: the short candidate was accepted on its 4 bytes
                             matched = grp_matchlen<G>(base, s + 4, ts + 4, blkEnd - (s + 4), lig, grp) + 4;
                             // long match at s+1? (:309-343)
                             const uint64_t cv2 = ld64(base + s + 1);
@@ -223,8 +288,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                             break;
                         }
                     }
-                    s += 1 + ((s - nextEmit) >> 8);  // kSearchStrength-1 == 8
-                    if (s >= sLimit) { fin = true; brk = true; break; }
+                    // not reached: a found round always ends in one of the branches above
                 }
                 if (brk) continue;  // leaves encodeLoop when fin, or restarts the search after nothing (not reached)
                 // ---- end-of-match re-search (:419-460) ----
