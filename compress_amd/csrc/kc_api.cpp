@@ -471,12 +471,12 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     // SpeedDefault, round 2 (ms per launch): at 4 GiB (32768 units: DRAM-transaction bound, wasted probes cost) width 2 / 3 / 4 then doubling
     // 265.9 / 266.7 / 274.0, 2 then +1 264.1; at 2 GiB (latency bound) 163.6 / - / 155.4, fixed 1: 285.5.  The BASELINE size is 4 GiB.
     // SpeedBetterCompression (1 GiB = 8192 units: latency-bound, wide speculation pays): width 1 / 2 / 4 then doubling 98.6 / 91.5 / 86.0,
-    // fixed 4: 101.4, fixed 8: 80.4 ms (one probe per round, round 1: 181 ms)
-    mp.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : (o->level == KC_SPEED_DEFAULT ? 2 : (o->level == KC_SPEED_BETTER ? 8 : 1));
+    // fixed 4: 101.4, fixed 8: 80.4 ms with 8 lanes per unit; 16 lanes per unit, fixed 16: 61.1 ms (one probe per round, round 1: 181 ms)
+    mp.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : (o->level == KC_SPEED_DEFAULT ? 2 : (o->level == KC_SPEED_BETTER ? 16 : 1));
     // measured on C2 (ms per 4 GiB): width 1 then +1 per miss 137, fixed 2 136.5, 1 then doubling 140, fixed 1 167, fixed 4 157
     mp.spec_grow = getenv("KC_SPEC_GROW") ? atoi(getenv("KC_SPEC_GROW")) : (o->level == KC_SPEED_FASTEST ? 1 : (o->level == KC_SPEED_BETTER ? 0 : 2));
     if (mp.spec_w0 < 1) mp.spec_w0 = 1;
-    if (mp.spec_w0 > 8) mp.spec_w0 = 8;
+    if (mp.spec_w0 > 64) mp.spec_w0 = 64;  // the kernels clamp to their group size
 
     KcEntropyParams ep;
     memset(&ep, 0, sizeof(ep));

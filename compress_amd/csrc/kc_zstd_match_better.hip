@@ -1,7 +1,7 @@
 // kc_zstd_match_better.hip — SpeedBetterCompression match finder for gfx950.
 //
 // Replaces betterFastEncoder.Encode (zstd/enc_better.go:56-568; EncodeNoHist == ensureHist + Encode,
-// :573-576) and betterFastEncoderDict.Encode (:579-1091).  8 lanes per unit, 8 units per wave; tables in
+// :573-576) and betterFastEncoderDict.Encode (:579-1091).  16 lanes per unit, 4 units per wave; tables in
 // an HBM arena per unit: long table 2^19 x {offset, prev} (8-byte hash, chain of length 2) followed by the
 // short table 2^13 x u32 (5-byte hash).  Every stored position is (pos+1) | tag(4 source bytes) << PB, so
 // candidates that the reference would reject on its 8-byte / 4-byte compare are mostly rejected on the tag
@@ -20,7 +20,10 @@
 #define ZB_LONG_BITS 19
 #define ZB_SHORT_BITS 13
 #define ZB_MAX_MATCH_LENGTH 131074
-#define ZBG 8
+#ifndef ZBG
+#define ZBG 16  // lanes per unit: 16-wide speculation, 4 units per wave (ms per GiB of C5: G=8 80.4, G=16 61.1; 32 needs 64-bit lane masks)
+#endif
+static_assert(ZBG <= 16, "lane masks are built with 32-bit shifts");
 
 struct ZbCtx {
     const uint8_t* base;   // hist: (dict ||) unit
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
 }
 
 void kc_launch_zbetter_match_grp(const KcMatchParams& P, uint8_t* tables, uint32_t n_launch, bool dict, hipStream_t st) {
-    if (dict) hipLaunchKernelGGL(kc_zbetter_match_grp_kernel<true>, dim3((n_launch + 7) / 8), dim3(64), 0, st, P, tables, n_launch);
-    else hipLaunchKernelGGL(kc_zbetter_match_grp_kernel<false>, dim3((n_launch + 7) / 8), dim3(64), 0, st, P, tables, n_launch);
+    constexpr uint32_t UPW = 64 / ZBG;
+    if (dict) hipLaunchKernelGGL(kc_zbetter_match_grp_kernel<true>, dim3((n_launch + UPW - 1) / UPW), dim3(64), 0, st, P, tables, n_launch);
+    else hipLaunchKernelGGL(kc_zbetter_match_grp_kernel<false>, dim3((n_launch + UPW - 1) / UPW), dim3(64), 0, st, P, tables, n_launch);
 }
