@@ -1180,6 +1180,11 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     P.n_blocks = n;
     P.framed = framed;
     P.level = level;
+    P.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : 2;
+    P.spec_w0b = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : 4;
+    P.spec_grow = getenv("KC_SPEC_GROW") ? atoi(getenv("KC_SPEC_GROW")) : 1;
+    if (P.spec_w0 < 1) P.spec_w0 = 1;
+    if (P.spec_w0b < 1) P.spec_w0b = 1;
     P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen) / 4);
     kc_launch_s2_encode(P, st);
     HIPCHK(c, hipEventRecord(c->ev[1], st));

@@ -83,6 +83,8 @@ struct KcS2Params {
     uint32_t table_stride;      // u32 entries per block: kc_s2_table_bytes(level, max block length) / 4
     uint32_t n_blocks;
     int32_t level;              // 0: s2.Encode, 1: s2.EncodeBetter, 2: s2.EncodeSnappy
+    int32_t spec_w0, spec_w0b;  // speculation width after a match (default / better parse)
+    int32_t spec_grow;          // after a round without a match: 0 keep, 1 +1, 2 double
     int32_t framed;             // 1: emit s2.Writer chunks (type | len24 | masked CRC32C | body), s2/writer.go:414-451
 };
 void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st);

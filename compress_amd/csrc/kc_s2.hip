@@ -274,6 +274,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         const int dstLimit = len - (len >> 5) - 5;
         int nextEmit = 0, s = 1, repeat = 1;
         bool fin = false;   // goto emitRemainder
+        int W = G;  // speculation width: every speculative probe step costs three table lines from HBM, and matches come every few steps
         while (!fin && !stored) {
             // ---------------- speculative probe round ----------------
             const int d0 = s - nextEmit;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
             // lane i is a real probe step iff all earlier steps stayed in the skip segment and nextS(p) <= sLimit
             const bool inseg = lig == 0 || ((d0 + (lig - 1) * step) >> SKIP) == k0;
             const int nextS = p + ((p - nextEmit) >> SKIP) + 4;
-            const bool valid = inseg && nextS <= sLimit;
+            const bool valid = lig < W && inseg && nextS <= sLimit;
             const bool term = inseg && nextS > sLimit;  // this step would `goto emitRemainder`
             uint64_t cv = 0;
             uint32_t h0 = 0xFFFFFFF0u, h1 = 0xFFFFFFF1u, h2 = 0xFFFFFFF2u, e0 = 0, e1 = 0, e2 = 0;
@@ -335,9 +336,10 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 if (!(winner && (kind == 1 || kind == 2))) tab[h2] = mk(p + 2, (uint32_t)(cv >> 16));
             }
             if (!found) {
+                W = P.spec_grow == 0 ? W : (P.spec_grow == 1 ? (W + 1 < G ? W + 1 : G) : ((2 * W < G) ? 2 * W : G));
                 if (c < nvalid) {
                     s = s + c * step;  // first dependent lane restarts as lane 0
-                } else if (tm & (1u << nvalid)) {
+                } else if (nvalid < G && (tm & (1u << nvalid))) {
                     fin = true;        // the step after the last committed one hits `nextS > sLimit`
                 } else {
                     const int pl = s + (nvalid - 1) * step;  // nvalid >= 1 here
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 }
                 continue;
             }
+            W = P.spec_w0;
             const int mkind = (int)s2g_bcast32((uint32_t)kind, grp, f);
             int candidate = (int)s2g_bcast32((uint32_t)cand, grp, f);
             const int ps = s + f * step;
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 stab[hs] = e;
             }
             if (!found) {
-                W = 2 * W < G ? 2 * W : G;
+                W = P.spec_grow == 0 ? W : (P.spec_grow == 1 ? (W + 1 < G ? W + 1 : G) : ((2 * W < G) ? 2 * W : G));
                 if (c < nvalid) {
                     s = s + c * step;
                 } else if (nvalid < G && (tm & (1u << nvalid))) {
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 }
                 continue;
             }
-            W = 4;
+            W = P.spec_w0b;
             const int mkind = (int)s2g_bcast32((uint32_t)kind, grp, f);
             int candidate = (int)s2g_bcast32((uint32_t)cand, grp, f);
             const int ps = s + f * step;
