@@ -432,3 +432,24 @@ def test_s2_snappy_blocks_bit_exact(oracle, kclib, kind):
     assert np.array_equal(out_off, ref_off)
     assert np.array_equal(out, np.asarray(ref))
     enc.Close()
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_s2_levels_randomised_blocks_bit_exact(oracle, kclib, level):
+    """Differential test over adversarial block mixes (text / noise runs of every length class / low-entropy noise / long zero
+    runs / repeated parts, 300 B .. 300 KB: both table variants of every level) for s2.Encode, s2.EncodeBetter, s2.EncodeSnappy."""
+    from compress_amd import s2
+    blocks = corpora.stress_units(seed=11 + level, n=120)
+    rng = np.random.default_rng(100 + level)
+    for _ in range(40):  # short periodic and tiny blocks: repeat / long-offset edge cases
+        per = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+        blocks.append((per * 20000)[:int(rng.integers(1, 140000))])
+    buf, off = corpora.pack_units(blocks)
+    enc = s2.BlockEncoder(level=level)
+    out, out_off = enc.EncodeBlocks(buf, off)
+    ref, ref_off = oracle.s2_encode_blocks(buf, off, threads=8, better=level == 1, snappy=level == 2)
+    ref = np.asarray(ref)
+    bad = [(i, len(blocks[i])) for i in range(len(blocks))
+           if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
+    assert not bad, "level %d: blocks differing from the oracle (index, len): %r" % (level, bad[:10])
+    enc.Close()
