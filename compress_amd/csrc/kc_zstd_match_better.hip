@@ -21,9 +21,9 @@
 #define ZB_SHORT_BITS 13
 #define ZB_MAX_MATCH_LENGTH 131074
 #ifndef ZBG
-#define ZBG 16  // lanes per unit: 16-wide speculation, 4 units per wave (ms per GiB of C5: G=8 80.4, G=16 61.1; 32 needs 64-bit lane masks)
+#define ZBG 16  // lanes per unit: 16-wide speculation, 4 units per wave (ms per GiB of C5: 8 lanes 80.4, 16 lanes 61.1, 32 lanes 86.5)
 #endif
-static_assert(ZBG <= 16, "lane masks are built with 32-bit shifts");
+static_assert(ZBG <= 32, "group ballots are 32-bit");
 
 struct ZbCtx {
     const uint8_t* base;   // hist: (dict ||) unit
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     const uint32_t hm = gballot<G>(hit != 0, grp);
                     const int nvalid = __popc(vm);
                     const int cc = depm ? __builtin_ctz(depm) : G;
-                    const uint32_t hmc = hm & ((1u << cc) - 1u);
+                    const uint32_t hmc = hm & (uint32_t)((1ull << cc) - 1ull);
                     const bool found = hmc != 0;
                     const int f = found ? __builtin_ctz(hmc) : 0;
                     const int commitUpTo = found ? f : ((cc < nvalid ? cc : nvalid) - 1);
