@@ -973,9 +973,12 @@ kc_status host_pipeline(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off,
     return KC_OK;
 }
 
-uint64_t host_sub_bytes() {
+// Sub-batch of the host pipeline.  The device encode wants many units in flight (C2, ms per GiB: 4 GiB batch 42, 2 GiB 48, 1 GiB 58),
+// the pipeline wants several stages: measured PCIe-inclusive on 4 GiB of C2 — 256 MiB 4.0, 512 MiB 6.8, 1 GiB 10.8, 2 GiB 13.8 GB/s.
+// 2 GiB sub-batches pin 2 x (2 + 2.1) GiB of host memory per context; KC_HOST_PIPE_MIB overrides.
+uint64_t host_sub_bytes(uint64_t total) {
     if (const char* e = getenv("KC_HOST_PIPE_MIB")) { const long v = atol(e); if (v >= 16) return (uint64_t)v << 20; }
-    return (uint64_t)1 << 30;
+    return total >= ((uint64_t)4 << 30) ? ((uint64_t)2 << 30) : ((uint64_t)1 << 30);  // at least two stages from 2 GiB of input on
 }
 
 }  // namespace
@@ -992,7 +995,7 @@ kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* 
     if (n_units == 0) { out_off[0] = 0; return KC_OK; }
     if ((s = validate_units(c, o, unit_off, n_units)) != KC_OK) return s;
     const uint64_t total = unit_off[n_units] - unit_off[0];
-    const uint64_t sub = host_sub_bytes();
+    const uint64_t sub = host_sub_bytes(total);
     if (total >= 2 * sub && !getenv("KC_HOST_SERIAL")) {
         auto enc = [&](const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
             return kc_zstd_encode_units_dev(c, o, d_in, rel, nu, d_out, cap, oo);
@@ -1336,12 +1339,12 @@ kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, cons
         if (blk_off[i + 1] - blk_off[i] > (uint64_t)(4 << 20)) { c->err = "S2 block larger than 4 MiB (s2.maxBlockSize) not served by the device path"; return KC_ERR_UNSUPPORTED; }
     }
     const uint64_t total = blk_off[n] - blk_off[0];
-    if (total >= 2 * host_sub_bytes() && !getenv("KC_HOST_SERIAL")) {
+    if (total >= 2 * host_sub_bytes(total) && !getenv("KC_HOST_SERIAL")) {
         auto enc = [&](const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
             return kc_s2_encode_blocks_lvl_dev(c, level, d_in, rel, nu, d_out, cap, oo);
         };
         auto mx = [&](uint64_t len) { return (uint64_t)kc_s2_max_encoded_len((int64_t)len); };
-        return host_pipeline(c, src, blk_off, n, dst, dst_cap, out_off, host_sub_bytes(), enc, mx);
+        return host_pipeline(c, src, blk_off, n, dst, dst_cap, out_off, host_sub_bytes(total), enc, mx);
     }
     uint64_t need = 0;
     for (uint32_t i = 0; i < n; i++) need += ((uint64_t)kc_s2_max_encoded_len((int64_t)(blk_off[i + 1] - blk_off[i])) + 15) & ~(uint64_t)15;
