@@ -163,6 +163,203 @@ __device__ inline uint8_t huf_build_serial(KcHufNodes* N, KcHufTable* T, int sym
     return maxNbBits;
 }
 
+// ---------------------------------------------------------------------------------------
+// buildCTable (compress.go:457-567) on a whole wave.  Same results as huf_build_serial, which stays as the readable
+// statement of the algorithm; here only the two-queue merge (inherently sequential, 255 steps) runs on one lane, with the
+// two queue heads cached in registers, and everything around it is spread over the 64 lanes:
+//   * node depths: nBits(n) = nBits(parent(n)) + 1 is relaxed in parallel until nothing changes (a node's parent has a
+//     higher index, so iteration k fixes every node of depth <= k; typically 12-20 iterations instead of a 511-step chain);
+//   * nbPerRank / valPerRank / the table fill: ballots per code length give, for a symbol, the number of earlier symbols with
+//     the same length — the serial loop's running valPerRank counter;
+//   * setMaxHeight (only when the tree is deeper than tableLog) stays on lane 0, its work arrays in LDS instead of scratch.
+// All 64 lanes of ONE wave must call; LDS accesses of a wave execute in program order, the wave barriers keep the compiler
+// from moving them.  Returns actualTableLog, or 0xFF on internal error (wave-uniform).
+// ---------------------------------------------------------------------------------------
+struct KcHufWaveTmp {          // LDS scratch of the wave build
+    uint32_t rankLast[HUF_TABLELOG_MAX + 2];
+    uint16_t nbPerRank[HUF_TABLELOG_MAX + 5];
+    uint16_t valPerRank[16];
+};
+
+__device__ inline uint8_t huf_set_max_height_lds(KcHufNodes* N, int lastNonNull, uint8_t maxNbBits, uint32_t* rankLast) {
+    const uint8_t largestBits = HN_NB(lastNonNull);
+    if (largestBits <= maxNbBits) return largestBits;
+    int totalCost = 0;
+    const int baseCost = 1 << (largestBits - maxNbBits);
+    uint32_t n = (uint32_t)lastNonNull;
+    while (HN_NB(n) > maxNbBits) {
+        totalCost += baseCost - (1 << (largestBits - HN_NB(n)));
+        HN_NB(n) = maxNbBits;
+        n--;
+    }
+    while (HN_NB(n) == maxNbBits) n--;
+    totalCost >>= (largestBits - maxNbBits);
+    const uint32_t noSymbol = 0xF0F0F0F0u;
+    for (int i = 0; i < HUF_TABLELOG_MAX + 2; i++) rankLast[i] = noSymbol;
+    {
+        uint8_t currentNbBits = maxNbBits;
+        for (int pos = (int)n; pos >= 0; pos--) {
+            const uint8_t nbp = HN_NB(pos);
+            if (nbp >= currentNbBits) continue;
+            currentNbBits = nbp;
+            rankLast[maxNbBits - currentNbBits] = (uint32_t)pos;
+        }
+    }
+    while (totalCost > 0) {
+        uint8_t nBitsToDecrease = (uint8_t)((uint8_t)high_bit((uint32_t)totalCost) + 1);
+        for (; nBitsToDecrease > 1; nBitsToDecrease--) {
+            const uint32_t highPos = rankLast[nBitsToDecrease];
+            const uint32_t lowPos = rankLast[nBitsToDecrease - 1];
+            if (highPos == noSymbol) continue;
+            if (lowPos == noSymbol) break;
+            const uint32_t highTotal = HN_CNT(highPos);
+            const uint32_t lowTotal = 2 * HN_CNT(lowPos);
+            if (highTotal <= lowTotal) break;
+        }
+        while (nBitsToDecrease <= HUF_TABLELOG_MAX && rankLast[nBitsToDecrease] == noSymbol) nBitsToDecrease++;
+        totalCost -= 1 << (nBitsToDecrease - 1);
+        if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+        HN_NB(rankLast[nBitsToDecrease]) = (uint8_t)(1 + HN_NB(rankLast[nBitsToDecrease]));
+        if (rankLast[nBitsToDecrease] == 0) {
+            rankLast[nBitsToDecrease] = noSymbol;
+        } else {
+            rankLast[nBitsToDecrease]--;
+            if (HN_NB(rankLast[nBitsToDecrease]) != (uint8_t)(maxNbBits - nBitsToDecrease)) rankLast[nBitsToDecrease] = noSymbol;
+        }
+    }
+    while (totalCost < 0) {
+        if (rankLast[1] == noSymbol) {
+            while (HN_NB(n) == maxNbBits) n--;
+            HN_NB(n + 1) = (uint8_t)(HN_NB(n + 1) - 1);
+            rankLast[1] = n + 1;
+            totalCost++;
+            continue;
+        }
+        HN_NB(rankLast[1] + 1) = (uint8_t)(HN_NB(rankLast[1] + 1) - 1);
+        rankLast[1]++;
+        totalCost++;
+    }
+    return maxNbBits;
+}
+
+// LDS hand-off between the lanes of one wave: program order in hardware, this keeps the compiler from reordering
+#define KC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__device__ inline uint8_t huf_build_wave(KcHufNodes* N, KcHufTable* T, KcHufWaveTmp* W, int symbolLen, int srcLen, int lane) {
+    const uint8_t tableLog0 = huf_optimal_table_log(srcLen, symbolLen);
+    for (int i = lane; i < symbolLen; i += 64) { T->val[i] = 0; T->nb[i] = 0; }
+    // nonNullRank: the counts are sorted descending, the non-zero ones form a prefix
+    int nz = 0;
+    for (int i0 = 0; i0 < symbolLen; i0 += 64) {
+        const int i = i0 + lane;
+        nz += __popcll(ballot64(i < symbolLen && HN_CNT(i) != 0));
+    }
+    const int nonNullRank = nz - 1;
+    const int startNode = symbolLen;
+    const int nodeRoot = startNode + nonNullRank - 1;
+    for (int n = startNode + 1 + lane; n <= nodeRoot; n += 64) HN_CNT(n) = 1u << 30;
+    if (lane == 0) HN_CNT(-1) = 1u << 31;  // fake entry, strong barrier
+    KC_WAVE_SYNC();
+    if (lane == 0) {
+        // the two-queue merge: leaves from lowS downwards, internal nodes from lowN upwards; heads cached in cS / cN
+        int lowS = nonNullRank, lowN = startNode, nodeNb = startNode;
+        {
+            const uint32_t sum = HN_CNT(lowS) + HN_CNT(lowS - 1);
+            HN_CNT(nodeNb) = sum;
+            HN_PAR(lowS) = (uint16_t)nodeNb;
+            HN_PAR(lowS - 1) = (uint16_t)nodeNb;
+            nodeNb++;
+            lowS -= 2;
+        }
+        uint32_t cS = HN_CNT(lowS), cN = HN_CNT(lowN);
+        while (nodeNb <= nodeRoot) {
+            int n1, n2;
+            uint32_t c1, c2;
+            if (cS < cN) { n1 = lowS; c1 = cS; lowS--; cS = HN_CNT(lowS); } else { n1 = lowN; c1 = cN; lowN++; cN = HN_CNT(lowN); }
+            if (cS < cN) { n2 = lowS; c2 = cS; lowS--; cS = HN_CNT(lowS); } else { n2 = lowN; c2 = cN; lowN++; cN = HN_CNT(lowN); }
+            const uint32_t sum = c1 + c2;
+            HN_CNT(nodeNb) = sum;
+            if (lowN == nodeNb) cN = sum;  // the internal queue's head is the node just created
+            HN_PAR(n1) = (uint16_t)nodeNb;
+            HN_PAR(n2) = (uint16_t)nodeNb;
+            nodeNb++;
+        }
+        HN_NB(nodeRoot) = 0;
+    }
+    KC_WAVE_SYNC();
+    // depths of the internal nodes: relax nBits(n) = nBits(parent(n)) + 1 until stable
+    for (int n = startNode + lane; n < nodeRoot; n += 64) HN_NB(n) = 0xFF;
+    KC_WAVE_SYNC();
+    for (int iter = 0; iter < HUF_NODES; iter++) {
+        bool changed = false;
+        uint8_t nv[4];
+        int nn = 0;
+        for (int n = startNode + lane; n < nodeRoot; n += 64, nn++) {
+            const uint8_t pb = HN_NB(HN_PAR(n));
+            nv[nn] = pb == 0xFF ? (uint8_t)0xFF : (uint8_t)(pb + 1);
+        }
+        KC_WAVE_SYNC();
+        nn = 0;
+        for (int n = startNode + lane; n < nodeRoot; n += 64, nn++) {
+            if (HN_NB(n) != nv[nn]) { HN_NB(n) = nv[nn]; changed = true; }
+        }
+        KC_WAVE_SYNC();
+        if (ballot64(changed) == 0) break;
+    }
+    for (int n = lane; n <= nonNullRank; n += 64) HN_NB(n) = (uint8_t)(HN_NB(HN_PAR(n)) + 1);
+    KC_WAVE_SYNC();
+    uint8_t maxNbBits = 0;
+    if (lane == 0) maxNbBits = huf_set_max_height_lds(N, nonNullRank, tableLog0, W->rankLast);
+    maxNbBits = (uint8_t)bcast32(maxNbBits, 0);
+    KC_WAVE_SYNC();
+    if (maxNbBits > HUF_TABLELOG_MAX) return 0xFF;
+    // code lengths per symbol, then canonical values: valPerRank[n] = first value of length n (from nbPerRank), a symbol's
+    // value = valPerRank[its length] + number of lower-numbered symbols of the same length
+    for (int i = lane; i <= nonNullRank; i += 64) T->nb[HN_SYM(i)] = HN_NB(i);
+    if (lane <= HUF_TABLELOG_MAX) W->nbPerRank[lane] = 0;
+    KC_WAVE_SYNC();
+    uint32_t base[HUF_TABLELOG_MAX + 1];  // running count of symbols per length seen in earlier chunks (lane-uniform)
+#pragma unroll
+    for (int r = 0; r <= HUF_TABLELOG_MAX; r++) base[r] = 0;
+    uint32_t within[4] = {0, 0, 0, 0};   // for my symbol of chunk k: same-length symbols before it (all chunks)
+    uint8_t mynb[4] = {0, 0, 0, 0};
+    {
+        int k = 0;
+        for (int i0 = 0; i0 < symbolLen; i0 += 64, k++) {
+            const int i = i0 + lane;
+            const uint8_t b = i < symbolLen ? (uint8_t)(T->nb[i] & 15) : (uint8_t)0xFF;
+            mynb[k] = b;
+#pragma unroll
+            for (int r = 0; r <= HUF_TABLELOG_MAX; r++) {
+                const uint64_t m = ballot64(b == r);
+                if (b == r) within[k] = base[r] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                base[r] += (uint32_t)__popcll(m);
+            }
+        }
+    }
+    // nbPerRank counts the symbols 0..nonNullRank by length; symbols with a zero count have length 0 in T->nb as well,
+    // but the reference counts only ranks <= nonNullRank: length-0 entries never receive a value that is used.
+    if (lane == 0) {
+        uint16_t minv = 0;
+        for (int n = maxNbBits; n > 0; n--) {
+            W->valPerRank[n] = minv;
+            minv = (uint16_t)(minv + base[n]);
+            minv >>= 1;
+        }
+        W->valPerRank[0] = 0;
+    }
+    KC_WAVE_SYNC();
+    {
+        int k = 0;
+        for (int i0 = 0; i0 < symbolLen; i0 += 64, k++) {
+            const int i = i0 + lane;
+            if (i < symbolLen) T->val[i] = (uint16_t)(W->valPerRank[mynb[k] & 15] + within[k]);
+        }
+    }
+    KC_WAVE_SYNC();
+    return maxNbBits;
+}
+
 // ---- byte FSE of the Huffman weights (fse.Compress with TableLog 6; fse/compress.go:18-204) ----
 struct KcWeightFse {  // scratch, LDS
     uint32_t count[16];

@@ -163,6 +163,7 @@ struct Shared {
     HufState huf;
     uint8_t weights[256];
     KcWeightFse wfse;
+    KcHufWaveTmp hwt;   // work arrays of the wave-cooperative buildCTable
     uint8_t tdesc[192];  // serialised Huffman table description
     // --- sequences ---
     KcFseT fse[9];       // 0..5: ll/of/ml cur+prev pool, 6..8: predefined LL/OF/ML
@@ -692,11 +693,13 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 S.nodes.symbol[rank + 1] = (uint8_t)tid;
             }
             __syncthreads();
-            if (tid == 0) {
-                const uint8_t tl = huf_build_serial(&S.nodes, &S.cur, symbolLen, nlitE);
-                if (tl == 0xFF) atomicExch(P.err_flag, 1u);
-                S.ivar[IV_TABLOG] = tl;
-            } else if (wv >= 1 && !litsOnly) {
+            if (wv == 0) {  // buildCTable on wave 0 (only the two-queue merge is single-lane), waves 1-3 fill the sequence histograms
+                const uint8_t tl = huf_build_wave(&S.nodes, &S.cur, &S.hwt, symbolLen, nlitE, lane);
+                if (lane == 0) {
+                    if (tl == 0xFF) atomicExch(P.err_flag, 1u);
+                    S.ivar[IV_TABLOG] = tl;
+                }
+            } else if (!litsOnly) {
                 seq_hist(tid - 64, ET - 64);
             }
             seqHistDone = !litsOnly;
