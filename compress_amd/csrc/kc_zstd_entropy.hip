@@ -512,10 +512,12 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             constexpr int TILE = 8192;
             uint64_t run = 0;  // lo32: literal bytes so far, hi32: source bytes so far
             const uint8_t* __restrict__ bsrc = base + blkStart;
+            uint64_t sqNext = tid < nseq ? sq[tid] : 0ull;  // the next batch's sequence is loaded under the current batch's work
             for (int t0 = 0; t0 < nseq; t0 += ET) {
                 const int i = t0 + tid;
                 uint32_t ll = 0, adv = 0;
-                if (i < nseq) { const uint64_t s = sq[i]; ll = seq_ll(s); adv = ll + seq_ml(s) + 3u; }
+                if (i < nseq) { const uint64_t s = sqNext; ll = seq_ll(s); adv = ll + seq_ml(s) + 3u; }
+                sqNext = (i + ET < nseq) ? sq[i + ET] : 0ull;
                 if (tid == 0) S.longCnt = 0;
                 uint64_t tot;
                 const uint64_t ex = block_excl_scan64((uint64_t)ll | ((uint64_t)adv << 32), S.wsum, &tot) + run;
@@ -531,17 +533,33 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 const uint32_t endLo = begLo + (uint32_t)tot;  // literal bytes after this batch
                 for (uint32_t winBase = begLo & ~15u; winBase < endLo; winBase += TILE) {
                     if (mine && lo < winBase + TILE && lo + ll > winBase) {
-                        for (uint32_t k = 0; k < ll; k += 8) {
-                            uint64_t v;
-                            const uint32_t n8 = ll - k < 8u ? ll - k : 8u;
-                            if ((int)(sp + k) + 8 <= size) v = ld64(bsrc + sp + k);
-                            else { v = 0; for (uint32_t q = 0; q < n8; q++) v |= (uint64_t)bsrc[sp + k + q] << (8 * q); }
-                            for (uint32_t q = 0; q < n8; q++) {
-                                const uint32_t o = lo + k + q - winBase;
-                                if (o < (uint32_t)TILE) {
-                                    const uint32_t c = (uint32_t)(v >> (8 * q)) & 0xFFu;
-                                    tile[o] = (uint8_t)c;
-                                    atomicAdd(&S.whist[wv][c], 1u);
+                        // runs of up to LONG_RUN (32) bytes: all four 8-byte loads are issued before the first byte is used; a longer
+                        // run is only "mine" when the cooperative long-run list overflowed: chunks of 32 bytes the same way
+                        for (uint32_t k0 = 0; k0 < ll; k0 += 32) {
+                            uint64_t vv[4] = {0, 0, 0, 0};
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) {
+                                const uint32_t k = k0 + 8u * (uint32_t)kk;
+                                if (k < ll) {
+                                    const uint32_t n8 = ll - k < 8u ? ll - k : 8u;
+                                    if ((int)(sp + k) + 8 <= size) vv[kk] = ld64(bsrc + sp + k);
+                                    else { uint64_t t = 0; for (uint32_t q = 0; q < n8; q++) t |= (uint64_t)bsrc[sp + k + q] << (8 * q); vv[kk] = t; }
+                                }
+                            }
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) {
+                                const uint32_t k = k0 + 8u * (uint32_t)kk;
+                                if (k < ll) {
+                                    const uint64_t v = vv[kk];
+                                    const uint32_t n8 = ll - k < 8u ? ll - k : 8u;
+                                    for (uint32_t q = 0; q < n8; q++) {
+                                        const uint32_t o = lo + k + q - winBase;
+                                        if (o < (uint32_t)TILE) {
+                                            const uint32_t c = (uint32_t)(v >> (8 * q)) & 0xFFu;
+                                            tile[o] = (uint8_t)c;
+                                            atomicAdd(&S.whist[wv][c], 1u);
+                                        }
+                                    }
                                 }
                             }
                         }
