@@ -288,7 +288,7 @@ class Encoder:
         return [(seqs[int(first[b]):int(first[b + 1])].copy(), int(extra[b])) for b in range(nb.value)]
 
     def Close(self):
-        """Encoder.Close (encoder.go:567): finish the stream, if one was written to a writer; the device context is released
+        """Encoder.Close (encoder.go:589): finish the stream, if one was written to a writer; the device context is released
         and re-created on the next use (the encoder stays usable after Reset, like the reference's)."""
         self._finish_stream()
         if self._ctx is not None:

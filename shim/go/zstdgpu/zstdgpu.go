@@ -258,7 +258,7 @@ func NewWriter(w io.Writer, device int, opts ...Option) (*Writer, error) {
 	return &Writer{e: e, w: w}, nil
 }
 
-// Reset discards the state and starts a new stream on w (encoder.go:107).
+// Reset discards the state and starts a new stream on w (encoder.go:103).
 func (x *Writer) Reset(w io.Writer) {
 	x.w, x.buf, x.closed = w, x.buf[:0], false
 	x.ref = nil
@@ -292,7 +292,7 @@ func (x *Writer) Write(p []byte) (int, error) {
 	return len(p), nil
 }
 
-// ReadFrom mirrors (*zstd.Encoder).ReadFrom (encoder.go:449).
+// ReadFrom mirrors (*zstd.Encoder).ReadFrom (encoder.go:444).
 func (x *Writer) ReadFrom(r io.Reader) (int64, error) {
 	var n int64
 	chunk := make([]byte, 1<<20)
@@ -321,7 +321,7 @@ func (x *Writer) Flush() error {
 	return x.ref.Flush()
 }
 
-// Close finishes the stream (encoder.go:567).
+// Close finishes the stream (encoder.go:589).
 func (x *Writer) Close() error {
 	if x.closed {
 		return nil
