@@ -3,8 +3,8 @@
 // Follows huff0/compress.go: optimalTableLog :428, huffSort :570, buildCTable :457,
 // setMaxHeight :609, and huff0/huff0.go cTable.write :180 with fse.Compress of the weights
 // (fse/compress.go:18-204).  The symbol sort is computed as a parallel rank (stable by
-// count descending, symbol ascending == the reference's bucketed insertion sort); the
-// tree build, height limiting and weight-table serialisation are O(256) serial work done
+// count descending, symbol ascending == the reference's bucketed insertion sort); the tree is
+// built by one wave (huf_build_wave), the weight-table serialisation is O(256) serial work done
 // by one lane on LDS-resident arrays.
 #pragma once
 #include "kc_dev.h"
@@ -39,133 +39,15 @@ __device__ inline uint8_t huf_optimal_table_log(int srcLen, int symbolLen) {
     return tableLog;
 }
 
-// setMaxHeight (compress.go:609).  N: nodes (index+1 addressing handled by the macros below).
+// N: nodes (index+1 addressing handled by the macros below).
 #define HN_CNT(i) N->count[(i) + 1]
 #define HN_PAR(i) N->parent[(i) + 1]
 #define HN_NB(i) N->nbits[(i) + 1]
 #define HN_SYM(i) N->symbol[(i) + 1]
 
-__device__ inline uint8_t huf_set_max_height(KcHufNodes* N, int lastNonNull, uint8_t maxNbBits) {
-    const uint8_t largestBits = HN_NB(lastNonNull);
-    if (largestBits <= maxNbBits) return largestBits;
-    int totalCost = 0;
-    const int baseCost = 1 << (largestBits - maxNbBits);
-    uint32_t n = (uint32_t)lastNonNull;
-    while (HN_NB(n) > maxNbBits) {
-        totalCost += baseCost - (1 << (largestBits - HN_NB(n)));
-        HN_NB(n) = maxNbBits;
-        n--;
-    }
-    while (HN_NB(n) == maxNbBits) n--;
-    totalCost >>= (largestBits - maxNbBits);
-    const uint32_t noSymbol = 0xF0F0F0F0u;
-    uint32_t rankLast[HUF_TABLELOG_MAX + 2];
-    for (int i = 0; i < HUF_TABLELOG_MAX + 2; i++) rankLast[i] = noSymbol;
-    {
-        uint8_t currentNbBits = maxNbBits;
-        for (int pos = (int)n; pos >= 0; pos--) {
-            if (HN_NB(pos) >= currentNbBits) continue;
-            currentNbBits = HN_NB(pos);
-            rankLast[maxNbBits - currentNbBits] = (uint32_t)pos;
-        }
-    }
-    while (totalCost > 0) {
-        uint8_t nBitsToDecrease = (uint8_t)((uint8_t)high_bit((uint32_t)totalCost) + 1);
-        for (; nBitsToDecrease > 1; nBitsToDecrease--) {
-            const uint32_t highPos = rankLast[nBitsToDecrease];
-            const uint32_t lowPos = rankLast[nBitsToDecrease - 1];
-            if (highPos == noSymbol) continue;
-            if (lowPos == noSymbol) break;
-            const uint32_t highTotal = HN_CNT(highPos);
-            const uint32_t lowTotal = 2 * HN_CNT(lowPos);
-            if (highTotal <= lowTotal) break;
-        }
-        while (nBitsToDecrease <= HUF_TABLELOG_MAX && rankLast[nBitsToDecrease] == noSymbol) nBitsToDecrease++;
-        totalCost -= 1 << (nBitsToDecrease - 1);
-        if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
-        HN_NB(rankLast[nBitsToDecrease]) = (uint8_t)(1 + HN_NB(rankLast[nBitsToDecrease]));
-        if (rankLast[nBitsToDecrease] == 0) {
-            rankLast[nBitsToDecrease] = noSymbol;
-        } else {
-            rankLast[nBitsToDecrease]--;
-            if (HN_NB(rankLast[nBitsToDecrease]) != (uint8_t)(maxNbBits - nBitsToDecrease)) rankLast[nBitsToDecrease] = noSymbol;
-        }
-    }
-    while (totalCost < 0) {
-        if (rankLast[1] == noSymbol) {
-            while (HN_NB(n) == maxNbBits) n--;
-            HN_NB(n + 1) = (uint8_t)(HN_NB(n + 1) - 1);
-            rankLast[1] = n + 1;
-            totalCost++;
-            continue;
-        }
-        HN_NB(rankLast[1] + 1) = (uint8_t)(HN_NB(rankLast[1] + 1) - 1);
-        rankLast[1]++;
-        totalCost++;
-    }
-    return maxNbBits;
-}
-
-// Serial part of buildCTable (compress.go:457-567).  Precondition: nodes 0..symbolLen-1 hold
-// the symbols sorted by (count desc, symbol asc) (huffSort).  Produces T (val/nb for
-// symbols < symbolLen) and returns actualTableLog, or 0xFF on internal error.
-__device__ inline uint8_t huf_build_serial(KcHufNodes* N, KcHufTable* T, int symbolLen, int srcLen) {
-    const uint8_t tableLog0 = huf_optimal_table_log(srcLen, symbolLen);
-    for (int i = 0; i < symbolLen; i++) { T->val[i] = 0; T->nb[i] = 0; }
-    const int startNode = symbolLen;
-    int nonNullRank = symbolLen - 1;
-    while (HN_CNT(nonNullRank) == 0) nonNullRank--;
-    int lowS = nonNullRank;
-    int nodeNb = startNode;
-    const int nodeRoot = nodeNb + lowS - 1;
-    int lowN = nodeNb;
-    HN_CNT(nodeNb) = HN_CNT(lowS) + HN_CNT(lowS - 1);
-    HN_PAR(lowS) = (uint16_t)nodeNb;
-    HN_PAR(lowS - 1) = (uint16_t)nodeNb;
-    nodeNb++;
-    lowS -= 2;
-    for (int n = nodeNb; n <= nodeRoot; n++) HN_CNT(n) = 1u << 30;
-    HN_CNT(-1) = 1u << 31;  // fake entry, strong barrier
-    while (nodeNb <= nodeRoot) {
-        int n1, n2;
-        if (HN_CNT(lowS) < HN_CNT(lowN)) { n1 = lowS; lowS--; } else { n1 = lowN; lowN++; }
-        if (HN_CNT(lowS) < HN_CNT(lowN)) { n2 = lowS; lowS--; } else { n2 = lowN; lowN++; }
-        HN_CNT(nodeNb) = HN_CNT(n1) + HN_CNT(n2);
-        HN_PAR(n1) = (uint16_t)nodeNb;
-        HN_PAR(n2) = (uint16_t)nodeNb;
-        nodeNb++;
-    }
-    HN_NB(nodeRoot) = 0;
-    for (int n = nodeRoot - 1; n >= startNode; n--) HN_NB(n) = (uint8_t)(HN_NB(HN_PAR(n)) + 1);
-    for (int n = 0; n <= nonNullRank; n++) HN_NB(n) = (uint8_t)(HN_NB(HN_PAR(n)) + 1);
-    const uint8_t maxNbBits = huf_set_max_height(N, nonNullRank, tableLog0);
-    if (maxNbBits > HUF_TABLELOG_MAX) return 0xFF;
-    uint16_t nbPerRank[HUF_TABLELOG_MAX + 1];
-    uint16_t valPerRank[16];
-    for (int i = 0; i <= HUF_TABLELOG_MAX; i++) nbPerRank[i] = 0;
-    for (int i = 0; i < 16; i++) valPerRank[i] = 0;
-    for (int i = 0; i <= nonNullRank; i++) nbPerRank[HN_NB(i)]++;
-    {
-        uint16_t min = 0;
-        for (int n = maxNbBits; n > 0; n--) {
-            valPerRank[n] = min;
-            min = (uint16_t)(min + nbPerRank[n]);
-            min >>= 1;
-        }
-    }
-    for (int i = 0; i <= nonNullRank; i++) T->nb[HN_SYM(i)] = HN_NB(i);
-    for (int n = 0; n < symbolLen; n++) {
-        const uint8_t nbits = T->nb[n] & 15;
-        const uint16_t v = valPerRank[nbits];
-        T->val[n] = v;
-        valPerRank[nbits] = (uint16_t)(v + 1);
-    }
-    return maxNbBits;
-}
-
 // ---------------------------------------------------------------------------------------
-// buildCTable (compress.go:457-567) on a whole wave.  Same results as huf_build_serial, which stays as the readable
-// statement of the algorithm; here only the two-queue merge (inherently sequential, 255 steps) runs on one lane, with the
+// buildCTable (compress.go:457-567) on a whole wave.  Precondition: nodes 0..symbolLen-1 hold the symbols sorted by
+// (count desc, symbol asc) (huffSort).  Only the two-queue merge (inherently sequential, 255 steps) runs on one lane, with the
 // two queue heads cached in registers, and everything around it is spread over the 64 lanes:
 //   * node depths: nBits(n) = nBits(parent(n)) + 1 is relaxed in parallel until nothing changes (a node's parent has a
 //     higher index, so iteration k fixes every node of depth <= k; typically 12-20 iterations instead of a 511-step chain);

@@ -489,3 +489,46 @@ def test_many_small_units_fit_the_scratch_budget(oracle, kclib):
         a = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
         assert a == oracle.ZstdOracle(level=2).encode_all(buf[i * usz:(i + 1) * usz].tobytes()), i
     enc.Close()
+
+
+def test_device_decoder_empty_units_and_tiny_blocks(oracle, kclib):
+    """(1) an empty unit written with WithZeroFrames(false) is no bytes at all — the verifier must report it ok
+    whatever a previous decode left in its per-unit checksum flags; (2) a compressed block too small for its own literals
+    header must be rejected (blockdec.go ErrBlockTooSmall), never read past."""
+    torch = _torch()
+    from compress_amd import zstd
+    t = corpora.corpus("T", 2, 131072, first_unit=5).tobytes()
+    # poison the per-unit flags with a checksummed decode first
+    enc = _enc(1)
+    units = [t[:70000], t[:50], t[100:131072]]
+    ubuf, off = corpora.pack_units(units)
+    d_src = torch.from_numpy(ubuf).cuda()
+    cap = sum(((enc.MaxEncodedSize(len(u)) + 15) & ~15) for u in units) + 64
+    d_enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    eoff = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_enc.data_ptr(), cap)
+    d_out = torch.zeros(len(ubuf) + 64, dtype=torch.uint8, device="cuda")
+    assert not enc.DecodeUnitsDevice(d_enc.data_ptr(), eoff, d_out.data_ptr(), off).any()
+    # (1) empty units, no zero frames
+    enc0 = zstd.NewWriter(None, zstd.WithEncoderLevel(1), zstd.WithZeroFrames(False))
+    units0 = [b"", t[:1000], b"", b""]
+    ubuf0, off0 = corpora.pack_units(units0)
+    out0, eoff0 = enc0.EncodeUnits(ubuf0, off0)
+    assert int(eoff0[1]) == 0 and int(eoff0[3]) == int(eoff0[2]) == int(eoff0[4])
+    d_e0 = torch.from_numpy(np.concatenate([out0, np.zeros(16, dtype=np.uint8)])).cuda()
+    d_o0 = torch.zeros(len(ubuf0) + 64, dtype=torch.uint8, device="cuda")
+    st0 = enc.DecodeUnitsDevice(d_e0.data_ptr(), eoff0, d_o0.data_ptr(), off0)
+    assert not st0.any(), st0
+    # (2) frames whose single compressed block is cut to 0..4 bytes: magic + FHD(single segment, 1-byte FCS) + block header
+    bad_frames = []
+    for bn in range(0, 5):
+        body = bytes([0x02, 0xFF, 0xFF, 0xFF][:bn]) if bn else b""  # literals type 2 (compressed), size format 0: needs 3 header bytes
+        hdr = (bn << 3) | (2 << 1) | 1                              # last block, type 2 = compressed
+        bad_frames.append(bytes([0x28, 0xB5, 0x2F, 0xFD, 0x20, 10]) + bytes([hdr & 0xFF, (hdr >> 8) & 0xFF, (hdr >> 16) & 0xFF]) + body)
+    eo = np.zeros(len(bad_frames) + 1, dtype=np.uint64); eo[1:] = np.cumsum([len(f) for f in bad_frames])
+    do = np.arange(len(bad_frames) + 1, dtype=np.uint64) * 10
+    d_b = torch.from_numpy(np.frombuffer(b"".join(bad_frames), dtype=np.uint8).copy()).cuda()
+    d_bo = torch.zeros(int(do[-1]) + 64, dtype=torch.uint8, device="cuda")
+    stb = enc.DecodeUnitsDevice(d_b.data_ptr(), eo, d_bo.data_ptr(), do)
+    assert stb.all(), stb  # every one of them is refused
+    enc.Close()
+    enc0.Close()
