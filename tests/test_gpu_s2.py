@@ -123,6 +123,16 @@ def test_s2_custom_encoder_concurrent_callers(oracle, kclib):
     assert b2 - b1 == gpu_blocks            # a lone caller is never held back: one launch per call
     assert b1 - b0 < gpu_blocks             # concurrent callers shared launches
     print("hook: 16 threads %.1f blocks/s in %d launches, 1 thread %.1f blocks/s" % (len(blocks) / dt16, b1 - b0, len(blocks) / dt1))
+    # throughput on uniform 64 KiB blocks with many callers (what an s2.Writer with a high WriterConcurrency would offer)
+    jb = corpora.corpus("J", 1024, 65536, first_unit=300).tobytes()
+    blocks[:] = [jb[i * 65536:(i + 1) * 65536] for i in range(1024)]
+    wantj = [oracle.s2_encode_block(b) for b in blocks[:64]]
+    for nth in (16, 64):
+        c0, b0 = enc.HookStats()
+        res, dt = run(nth)
+        c1, b1 = enc.HookStats()
+        assert [r for r in res[:64]] == wantj
+        print("hook: %d threads on 1024 x 64 KiB blocks: %.0f blocks/s (%.1f MB/s) in %d launches" % (nth, 1024 / dt, 1024 * 65536 / dt / 1e6, b1 - b0))
     enc.Close()
 
 
