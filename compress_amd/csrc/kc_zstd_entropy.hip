@@ -1032,12 +1032,33 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     if (emit) sb[jj] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
                     st = f->st[dstState];
                 };
+                // 8 symbols per pass: their codes and per-symbol constants (deltaNbBits, deltaFindState) do not depend on the state and
+                // are fetched together; only the state-table lookups form the dependent chain (one LDS latency per symbol instead of three)
+                auto run = [&](int j0, int j1, bool emit) {
+                    int jj = j0;
+                    for (; jj + 8 <= j1; jj += 8) {
+                        uint32_t cc[8], dd[8];
+                        int32_t ff[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) cc[q] = cod[jj + q];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) { dd[q] = f->dnb[cc[q]]; ff[q] = (int32_t)f->dfs[cc[q]]; }
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const uint32_t nbBitsOut = ((uint32_t)st + dd[q]) >> 16;
+                            const int32_t dstState = (int32_t)(st >> (nbBitsOut & 15)) + ff[q];
+                            if (emit) sb[jj + q] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
+                            st = f->st[dstState];
+                        }
+                    }
+                    for (; jj < j1; jj++) step(jj, emit);
+                };
                 if (act) {
                     int w = a - KC_CHAIN_WARM;
                     if (w <= jb) w = jb; else st = f->st[0];  // any table entry is a valid state
-                    for (int jj = w; jj < a; jj++) step(jj, false);
+                    run(w, a, false);
                     assumed = st;
-                    for (int jj = a; jj < bnd; jj++) step(jj, true);
+                    run(a, bnd, true);
                     endSt = st;
                 }
                 for (;;) {
@@ -1055,7 +1076,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     if (act && assumed != prevEnd) {
                         st = prevEnd;
                         assumed = prevEnd;
-                        for (int jj = a; jj < bnd; jj++) step(jj, true);
+                        run(a, bnd, true);
                         endSt = st;
                     }
                 }
