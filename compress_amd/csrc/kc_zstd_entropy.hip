@@ -32,7 +32,7 @@
 #define KC_K2_WGS 4
 #endif
 #ifndef KC_CHAIN_WARM
-#define KC_CHAIN_WARM 48  // warm-up symbols per tANS chain segment (speculation, verified; any value is exact)
+#define KC_CHAIN_WARM 48  // warm-up symbols per tANS chain segment (speculation, verified; any value is exact; 16..48 measure the same)
 #endif
 #define LONG_RUN 32       // literal runs longer than this are copied cooperatively (256 x LONG_RUN fits one LDS window)
 #define LONG_CAP 64
