@@ -116,6 +116,8 @@ def main():
                     help="N > 1: 'root' gathers every step's frames to rank 0 over RCCL (the path's only exchange step, default); "
                          "'none' leaves each rank's contiguous shard of frames on its own GPU (consumers that write per-rank files: "
                          "compress_amd.shard.write_shard; the frames are concatenable in rank order)")
+    ap.add_argument("--s2-level", type=int, default=0, choices=[0, 1, 2],
+                    help="C4 only: 0 s2.Encode (the BASELINE configuration), 1 s2.EncodeBetter, 2 s2.EncodeSnappy")
     ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic in this run (two extra rocprofv3 passes of one step each)")
     ap.add_argument("--cpu-sample-units", type=int, default=0, help="units of the CPU-baseline / byte-compare sample (0: per configuration)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="override the CPU baseline thread count")
@@ -162,7 +164,9 @@ def main():
     npipe = 2 if (args.pipeline and not is_s2) else 1
     streams = [torch.cuda.Stream() for _ in range(npipe)]
     if is_s2:
-        encs = [s2.BlockEncoder(device=local_rank, stream=streams[0].cuda_stream)]
+        encs = [s2.BlockEncoder(device=local_rank, stream=streams[0].cuda_stream, level=args.s2_level)]
+        cfg["what"] = {0: cfg["what"], 1: "s2.EncodeBetter", 2: "s2.EncodeSnappy"}[args.s2_level]
+        cfg["kernel"] = "kc_s2_encode_kernel<%d>" % args.s2_level
         slot = (s2.MaxEncodedLen(UNIT) + 15) & ~15
     else:
         zopts = [zstd.WithEncoderLevel(cfg["level"])]
@@ -285,7 +289,8 @@ def main():
             sample = min(n_units, args.cpu_sample_units or default_sample)
             t0 = time.perf_counter()
             if is_s2:
-                ref, ref_off = oracle_lib.s2_encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], threads=cores)
+                ref, ref_off = oracle_lib.s2_encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], threads=cores,
+                                                           better=args.s2_level == 1, snappy=args.s2_level == 2)
             else:
                 kw = dict(level=cfg["level"])
                 if dict_content:
@@ -332,7 +337,7 @@ def main():
             for _ in range(2):
                 t0 = time.perf_counter()
                 if is_s2:
-                    ctx0.check(ctx0.L.kc_s2_encode_blocks(ctx0.h, host.ctypes.data, unit_off.ctypes.data, n_units, h_dst.ctypes.data, cap, eo.ctypes.data))
+                    ctx0.check(ctx0.L.kc_s2_encode_blocks_lvl(ctx0.h, args.s2_level, host.ctypes.data, unit_off.ctypes.data, n_units, h_dst.ctypes.data, cap, eo.ctypes.data))
                 else:
                     ctx0.check(ctx0.L.kc_zstd_encode_units(ctx0.h, C.byref(enc.o), host.ctypes.data, unit_off.ctypes.data, n_units,
                                                            h_dst.ctypes.data, cap, eo.ctypes.data))
