@@ -345,7 +345,7 @@ def main():
                 best = edt if best is None else min(best, edt)
             same = bool(np.array_equal(eo, out_off)) and bool(np.array_equal(h_dst[:int(eo[n_units])], d_dst[:out_bytes].cpu().numpy()))
             e2e = {"value": round(in_bytes / best / 1e6, 1), "unit": "MB/s", "frac_of_device_resident": round(in_bytes / best / 1e6 / (value / world), 3),
-                   "sample": "all %d units (%.2f GiB) from pageable host memory through kc_%s: H2D + encode + D2H pipelined over 1-2 GiB sub-batches, best of 2"
+                   "sample": "all %d units (%.2f GiB) from pageable host memory through kc_%s: source staged and frames drained chunk by chunk under the kernels (H2D + encode + D2H), best of 2"
                              % (n_units, in_bytes / 2**30, "s2_encode_blocks" if is_s2 else "zstd_encode_units"),
                    "same_bytes_as_device_path": same}
             del h_dst

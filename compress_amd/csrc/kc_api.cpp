@@ -11,6 +11,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -49,6 +50,21 @@ struct Pending {
 };
 
 
+// The source of a batch that arrives in chunks over PCIe (host path): the checksum + match-finder kernels of a chunk are
+// launched on their own stream as soon as the chunk's H2D copy has landed, so the transfers run under the kernels of the
+// chunks before while all units of the batch end up in flight together.
+struct ChunkFeed {
+    std::vector<uint32_t> cut;                   // unit index boundaries, nchunk + 1
+    std::vector<hipEvent_t> landed;              // recorded on the copy stream behind chunk k's H2D
+    std::vector<hipEvent_t> done;                // recorded behind chunk k's kernels
+    std::vector<hipStream_t> streams;            // kernels of chunk k run on streams[k % size]
+    std::function<bool(size_t)> wait_recorded;   // blocks until landed[k] HAS BEEN RECORDED (waiting on an unrecorded event is a no-op)
+    // chunk k's streams also run its entropy stage and compact its frames to d_dst + stage_off[cut[k]] (the chunk's worst-case
+    // region), local frame offsets in loc_off[cut[k] + k ... cut[k+1] + k]; the caller drains chunk by chunk and finishes with
+    // feed_finish() instead of batch_end()
+    uint64_t* loc_off = nullptr;
+};
+
 // Host-side layout of one device batch.  Lives in the context: the H2D copies of its arrays are asynchronous, so the arrays must
 // outlive batch_begin (they are overwritten by the next batch of the same context, after batch_end synchronised the stream).
 struct Plan {
@@ -70,7 +86,7 @@ struct kc_ctx {
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
         predef, errflag, tmp_src, tmp_dst, tables, prof, work, work_off, dictbuf, proto, dicthuf;
     bool predef_ready = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [6]: batch prepared (chunk-fed launches wait on it)
     kc_timings last = {0, 0, 0, 0, 0};
     size_t max_batch_bytes = (size_t)8 << 30;  // input bytes per device batch (scratch is ~6x this for full-size units)
     uint64_t max_scratch_bytes = (uint64_t)160 << 30;  // scratch per device batch (tables + per-block strides), further capped by the free device memory
@@ -341,35 +357,38 @@ kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
 
 // Match finders: sub-wave groups (8 lanes per unit), per-unit hash tables in an HBM arena that is zeroed (or primed from the
 // dictionary tables) before every launch.
+size_t match_table_bytes(int level) {
+    return level == KC_SPEED_BETTER ? kc_zbetter_table_bytes() : (level == KC_SPEED_DEFAULT ? kc_zdfast_table_bytes() : kc_zfast_table_bytes());
+}
+
+// per-unit tables of n_launch units: zeroed, or primed from the dictionary tables
+kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, hipStream_t st, int level) {
+    const size_t tb = match_table_bytes(level);
+    kc_status s = ensure(c, c->tables, (size_t)n_launch * tb);
+    if (s != KC_OK) return s;
+    if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, tb, n_launch, st);
+    else HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * tb, st));
+    return KC_OK;
+}
+
+// the match finder over n_launch units whose tables start at table slot `slot0` (unit = mp.unit_base + i or mp.unit_list[i])
+void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uint32_t n_launch, hipStream_t st, int level) {
+    uint8_t* tab = (uint8_t*)c->tables.p + (size_t)slot0 * match_table_bytes(level);
+    if (level == KC_SPEED_BETTER) kc_launch_zbetter_match_grp(mp, tab, n_launch, mp.hist0 > 0, st);
+    else if (level == KC_SPEED_DEFAULT) kc_launch_zdfast_match_grp(mp, (uint32_t*)tab, n_launch, st);
+    else kc_launch_zfast_match_grp(mp, (uint32_t*)tab, n_launch, st);
+}
+
 kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_off, uint32_t n_units, uint32_t n_launch, int bs, hipStream_t st, int level) {
     (void)unit_off; (void)n_units; (void)bs;
-    if (level == KC_SPEED_BETTER) {
-        const size_t tb = kc_zbetter_table_bytes();
-        kc_status s3 = ensure(c, c->tables, (size_t)n_launch * tb);
-        if (s3 != KC_OK) return s3;
-        if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, tb, n_launch, st);  // dictionary-primed tables
-        else HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * tb, st));
-        kc_launch_zbetter_match_grp(mp, (uint8_t*)c->tables.p, n_launch, mp.hist0 > 0, st);
-        return KC_OK;
-    }
-    if (level == KC_SPEED_DEFAULT) {
-        kc_status s2 = ensure(c, c->tables, (size_t)n_launch * kc_zdfast_table_bytes());
-        if (s2 != KC_OK) return s2;
-        if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, kc_zdfast_table_bytes(), n_launch, st);
-        else HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * kc_zdfast_table_bytes(), st));
-        kc_launch_zdfast_match_grp(mp, (uint32_t*)c->tables.p, n_launch, st);
-        return KC_OK;
-    }
-    kc_status s = ensure(c, c->tables, (size_t)n_launch * kc_zfast_table_bytes());
+    kc_status s = prepare_tables(c, mp, n_launch, st, level);
     if (s != KC_OK) return s;
-    if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, kc_zfast_table_bytes(), n_launch, st);
-    else HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * kc_zfast_table_bytes(), st));
-    kc_launch_zfast_match_grp(mp, (uint32_t*)c->tables.p, n_launch, st);
+    launch_match_kernel(c, mp, 0, n_launch, st, level);
     return KC_OK;
 }
 
 kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base, const uint64_t* unit_off, uint32_t n_units,
-                      uint8_t* d_dst, uint64_t dst_cap) {
+                      uint8_t* d_dst, uint64_t dst_cap, ChunkFeed* feed = nullptr) {
     hipStream_t st = c->stream;
     if (c->pend) { c->err = "a batch is already in flight on this context"; return KC_ERR_BAD_ARG; }
     const int bs = o->block_size;
@@ -398,7 +417,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
 
     kc_status s;
     if ((s = ensure(c, c->unit_off, (n_units + 1) * 8)) || (s = ensure(c, c->unit_blk0, (n_units + 1) * 4)) ||
-        (s = ensure(c, c->stage_off, (n_units + 1) * 8)) || (s = ensure(c, c->out_off, (n_units + 1) * 8)) ||
+        (s = ensure(c, c->stage_off, (n_units + 1) * 8)) || (s = ensure(c, c->out_off, (n_units + 1 + (feed ? feed->cut.size() : 0)) * 8)) ||
         (s = ensure(c, c->seqs, (size_t)nb * pl.seq_stride * 8)) || (s = ensure(c, c->aux, (size_t)nb * pl.seq_stride * 8)) ||
         (s = ensure(c, c->lits, (size_t)nb * pl.lit_stride)) || (s = ensure(c, c->meta, (size_t)nb * sizeof(KcBlkMeta))) ||
         (s = ensure(c, c->stage, so + 64)) || (s = ensure(c, c->out_size, (size_t)n_units * 4)) ||
@@ -531,11 +550,40 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
 
     if (c->chain_after) HIPCHK(c, hipStreamWaitEvent(st, c->chain_after->ev[2], 0));  // pipelined contexts: one match finder at a time
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    if (o->crc) kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p, n_units, (uint64_t*)c->xxh.p, st);
-    HIPCHK(c, hipEventRecord(c->ev[1], st));
     mp.unit_base = 0;
     ep.unit_base = 0;
-    if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, st, o->level)) != KC_OK) return s;
+    if (feed == nullptr) {
+        if (o->crc) kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p, n_units, (uint64_t*)c->xxh.p, st);
+        HIPCHK(c, hipEventRecord(c->ev[1], st));
+        if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, st, o->level)) != KC_OK) return s;
+    } else {
+        // the source is still arriving: per chunk, checksum + match finder on the chunk's stream behind its H2D copy
+        if (useDict) { c->err = "chunk feed does not take dictionaries"; return KC_ERR_INTERNAL; }
+        HIPCHK(c, hipEventRecord(c->ev[1], st));
+        if ((s = prepare_tables(c, mp, n_units, st, o->level)) != KC_OK) return s;
+        HIPCHK(c, hipEventRecord(c->ev[6], st));  // everything the chunk kernels need from this stream (offset arrays, tables)
+        const size_t nchunk = feed->cut.size() - 1;
+        for (size_t k = 0; k < nchunk; k++) {
+            if (!feed->wait_recorded(k)) { c->err = "host pipeline: staging failed"; return KC_ERR_HIP; }
+            hipStream_t sk = feed->streams[k % feed->streams.size()];
+            const uint32_t u0 = feed->cut[k], nk = feed->cut[k + 1] - feed->cut[k];
+            HIPCHK(c, hipStreamWaitEvent(sk, c->ev[6], 0));
+            HIPCHK(c, hipStreamWaitEvent(sk, feed->landed[k], 0));
+            if (o->crc) kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p + u0, nk, (uint64_t*)c->xxh.p + u0, sk);
+            KcMatchParams mk = mp;
+            mk.unit_base = u0;
+            launch_match_kernel(c, mk, u0, nk, sk, o->level);
+            KcEntropyParams ek = ep;
+            ek.unit_base = u0;
+            kc_launch_zstd_entropy(ek, nk, sk);
+            feed->loc_off = (uint64_t*)c->out_off.p;
+            kc_launch_scan_sizes((const uint32_t*)c->out_size.p + u0, nk, feed->loc_off + u0 + k, sk);
+            kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p + u0, (const uint32_t*)c->out_size.p + u0,
+                              feed->loc_off + u0 + k, d_dst + pl.stage_off[u0], nk, sk);
+            HIPCHK(c, hipEventRecord(feed->done[k], sk));
+        }
+        for (size_t k = 0; k < nchunk; k++) HIPCHK(c, hipStreamWaitEvent(st, feed->done[k], 0));
+    }
     HIPCHK(c, hipEventRecord(c->ev[2], st));
     HIPCHK(c, hipGetLastError());
     Pending* P = new Pending();
@@ -641,6 +689,60 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
     return KC_OK;
 }
 
+// A batch is bounded by its input bytes AND by the device scratch it needs: tables are per unit, sequences / literals /
+// staging are per block at a fixed stride whatever the block's actual length, so many small units need far more than the
+// "~6x input" of full-size units (1M x 4 KiB units at SpeedDefault would ask for hundreds of GiB in one batch).
+uint64_t zstd_unit_scratch(const kc_zstd_opts* o, uint64_t len) {
+    const uint64_t bsz = (uint64_t)o->block_size;
+    const uint64_t table_b = o->level == KC_SPEED_BETTER ? kc_zbetter_table_bytes() : (o->level == KC_SPEED_DEFAULT ? kc_zdfast_table_bytes() : kc_zfast_table_bytes());
+    const uint64_t per_block = 2 * (bsz / 4 + 8) * 8 + (bsz + 64) + sizeof(KcBlkMeta);
+    const uint64_t hist0 = (o->dict != nullptr) ? o->dict_len : 0;
+    const uint64_t blocks = (len + bsz - 1) / bsz;
+    const uint64_t enc = ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)len) + 15) & ~(uint64_t)15;
+    return table_b + blocks * per_block + enc + (hist0 ? hist0 + len : 0) + 64;
+}
+
+// Scratch a batch may ask for: the configured ceiling, or 85 % of what is free plus what this context already owns (re-used).
+uint64_t scratch_budget(kc_ctx* c) {
+    uint64_t budget = c->max_scratch_bytes;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        uint64_t held = 0;
+        const DevBuf* bufs[] = {&c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->tables, &c->work};
+        for (const DevBuf* b : bufs) held += b->cap;
+        const uint64_t avail = (uint64_t)((double)(fr + held) * 0.85);
+        if (avail < budget) budget = avail;
+    } else {
+        (void)hipGetLastError();
+    }
+    return budget;
+}
+
+// End of a chunk-fed batch (batch_begin with a ChunkFeed): every chunk has already been entropy coded and compacted on its own
+// stream.  *redo is set when a unit needs the speculation re-run (see batch_end): the caller encodes the batch again the plain way.
+kc_status feed_finish(kc_ctx* c, bool* redo_needed) {
+    if (!c->pend) { c->err = "no batch in flight on this context"; return KC_ERR_BAD_ARG; }
+    std::unique_ptr<Pending> P((Pending*)c->pend);
+    c->pend = nullptr;
+    hipStream_t st = c->stream;
+    const uint32_t n_units = P->n_units;
+    std::vector<uint32_t> redo(n_units);
+    uint32_t errv[16];
+    HIPCHK(c, hipMemcpyAsync(redo.data(), c->redo.p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(errv, c->errflag.p, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    if (errv[0] != 0) {
+        char b[96];
+        snprintf(b, sizeof(b), "device invariant violated (code %u)", errv[0]);
+        c->err = b;
+        return errv[0] == 100u ? KC_ERR_UNSUPPORTED : KC_ERR_INTERNAL;
+    }
+    *redo_needed = false;
+    for (uint32_t i = 0; i < n_units; i++) if (redo[i]) *redo_needed = true;
+    return KC_OK;
+}
+
 kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base, const uint64_t* unit_off, uint32_t n_units,
                     uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off_host, uint64_t* produced) {
     kc_status s = batch_begin(c, o, d_src_base, unit_off, n_units, d_dst, dst_cap);
@@ -671,31 +773,8 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
     uint64_t pos = 0;
     uint32_t i0 = 0;
     std::vector<uint64_t> tmp;
-    // A batch is bounded by its input bytes AND by the device scratch it needs: tables are per unit, sequences / literals /
-    // staging are per block at a fixed stride whatever the block's actual length, so many small units need far more than the
-    // "~6x input" of full-size units (1M x 4 KiB units at SpeedDefault would ask for hundreds of GiB in one batch).
-    const uint64_t bsz = (uint64_t)o->block_size;
-    const uint64_t table_b = o->level == KC_SPEED_BETTER ? kc_zbetter_table_bytes() : (o->level == KC_SPEED_DEFAULT ? kc_zdfast_table_bytes() : kc_zfast_table_bytes());
-    const uint64_t per_block = 2 * (bsz / 4 + 8) * 8 + (bsz + 64) + sizeof(KcBlkMeta);
-    const uint64_t hist0 = (o->dict != nullptr) ? o->dict_len : 0;
-    auto unit_scratch = [&](uint64_t len) -> uint64_t {
-        const uint64_t blocks = (len + bsz - 1) / bsz;
-        const uint64_t enc = ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)len) + 15) & ~(uint64_t)15;
-        return table_b + blocks * per_block + enc + (hist0 ? hist0 + len : 0) + 64;
-    };
-    uint64_t budget = c->max_scratch_bytes;
-    {
-        size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
-            uint64_t held = 0;  // what this context already owns is re-used
-            const DevBuf* bufs[] = {&c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->tables, &c->work};
-            for (const DevBuf* b : bufs) held += b->cap;
-            const uint64_t avail = (uint64_t)((double)(fr + held) * 0.85);
-            if (avail < budget) budget = avail;
-        } else {
-            (void)hipGetLastError();
-        }
-    }
+    auto unit_scratch = [&](uint64_t len) { return zstd_unit_scratch(o, len); };
+    uint64_t budget = scratch_budget(c);
     for (int attempt = 0;; attempt++) {
         bool oom = false;
         while (i0 < n_units) {
@@ -799,7 +878,11 @@ struct HostPipe {
     size_t in_cap = 0, out_cap = 0;
     DevBuf d_in[2], d_out[2];
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    std::vector<hipStream_t> kstreams;  // kernel streams of the chunk-fed batch
+    std::vector<hipEvent_t> events;
     ~HostPipe() {
+        for (hipStream_t t : kstreams) (void)hipStreamDestroy(t);
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
         for (int i = 0; i < 2; i++) {
             if (pin_in[i]) (void)hipHostFree(pin_in[i]);
             if (pin_out[i]) (void)hipHostFree(pin_out[i]);
@@ -872,8 +955,13 @@ kc_status host_pipeline(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off,
     if (!c->hpipe) c->hpipe = new HostPipe();
     HostPipe* hp = (HostPipe*)c->hpipe;
     if (!hp->s_h2d) {
-        HIPCHK(c, hipStreamCreateWithFlags(&hp->s_h2d, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&hp->s_d2h, hipStreamNonBlocking));
+        // high priority: the runtime keeps a separate pool of hardware queues per priority, so the copies never share a queue
+        // with (and wait in line behind) a match-finder launch; with the default 4 queues per pool and 7+ streams in the
+        // process they did (measured: the third chunk's copy landed 80 ms late)
+        int prLo = 0, prHi = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&prLo, &prHi));
+        HIPCHK(c, hipStreamCreateWithPriority(&hp->s_h2d, hipStreamNonBlocking, prHi));
+        HIPCHK(c, hipStreamCreateWithPriority(&hp->s_d2h, hipStreamNonBlocking, prHi));
     }
     if (hp->in_cap < max_in + 64) {
         for (int i = 0; i < 2; i++) { if (hp->pin_in[i]) (void)hipHostFree(hp->pin_in[i]); hp->pin_in[i] = nullptr; }
@@ -973,6 +1061,211 @@ kc_status host_pipeline(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off,
     return KC_OK;
 }
 
+// One device batch whose source arrives in chunks (a quarter of the batch each).  The stager thread copies pageable source ->
+// pinned slot -> device; the caller thread sets the batch up and, per chunk, launches the whole encode of the chunk's units on the
+// chunk's own stream behind its copy (enq: batch_begin / s2_encode_dev with a ChunkFeed), then drains chunk by chunk (device ->
+// pinned -> dst) as each finishes.  All units of the batch end up in flight together (zstd SpeedFastest: a 1 GiB batch encodes at
+// 58 ms/GiB, the 4 GiB batch at 41) and both transfers hide under the kernels of the other chunks.
+//   need        bytes of c->tmp_dst the batch may write (sum of the aligned per-unit bounds)
+//   enq(feed, d_in, rel_off, d_out)   enqueue everything; chunk k's output goes to d_out + region_of(feed.cut[k]), its local
+//                                     offsets to feed.loc_off[cut[k] + k ...]
+//   fin(&redo)  end of the batch on the context's stream; redo = encode again the plain way (returned as KC_ERR_UNSUPPORTED, no text)
+template <class Enq, class RegionOf, class Fin>
+kc_status host_chunk_fed(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint8_t* dst, uint64_t dst_cap,
+                         uint64_t* out_off, uint64_t need, Enq enq, RegionOf region_of, Fin fin) {
+    const uint64_t total = unit_off[n_units] - unit_off[0];
+    // kernel chunks: a quarter of the batch each, one per kernel stream so that none waits behind another.  Measured on the 4 GiB
+    // SpeedFastest batch (ms, pageable source to pageable frames): 4 x 1 GiB 215, 512M/512M/1G/2G 226, 1G/1G/2G 229, 2 x 2 GiB 235,
+    // 6 x 768 MiB 244 (two chunks queue behind others), 8 x 512 MiB 253; the plain sub-batch pipeline 305
+    std::vector<uint64_t> sched = {std::max<uint64_t>((total + 3) / 4, (uint64_t)64 << 20)};
+    if (const char* e = getenv("KC_HOST_CHUNKS_MIB")) {
+        sched.clear();
+        for (const char* q = e; *q;) { sched.push_back((uint64_t)strtoull(q, (char**)&q, 10) << 20); if (*q == ',') q++; }
+        if (sched.empty() || sched[0] == 0) sched = {(uint64_t)512 << 20};
+    }
+    ChunkFeed feed;
+    feed.cut.push_back(0);
+    {
+        uint64_t acc = 0;
+        for (uint32_t i = 0; i < n_units; i++) {
+            const uint64_t len = unit_off[i + 1] - unit_off[i];
+            const uint64_t lim = sched[std::min(feed.cut.size() - 1, sched.size() - 1)];
+            if (i > feed.cut.back() && acc + len > lim) { feed.cut.push_back(i); acc = 0; }
+            acc += len;
+        }
+        feed.cut.push_back(n_units);
+    }
+    const uint64_t piece = std::min<uint64_t>((uint64_t)256 << 20, std::max<uint64_t>(sched[0] / 2, 1 << 16));  // staging granularity: pageable -> pinned slot -> device
+    const uint64_t max_chunk = piece;
+    const size_t nchunk = feed.cut.size() - 1;
+    kc_status s;
+    if ((s = ensure(c, c->tmp_src, total + 64)) || (s = ensure(c, c->tmp_dst, need + 64))) return s;
+    if (!c->hpipe) c->hpipe = new HostPipe();
+    HostPipe* hp = (HostPipe*)c->hpipe;
+    if (!hp->s_h2d) {
+        // high priority: the runtime keeps a separate pool of hardware queues per priority, so the copies never share a queue
+        // with (and wait in line behind) a match-finder launch; with the default 4 queues per pool and 7+ streams in the
+        // process they did (measured: the third chunk's copy landed 80 ms late)
+        int prLo = 0, prHi = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&prLo, &prHi));
+        HIPCHK(c, hipStreamCreateWithPriority(&hp->s_h2d, hipStreamNonBlocking, prHi));
+        HIPCHK(c, hipStreamCreateWithPriority(&hp->s_d2h, hipStreamNonBlocking, prHi));
+    }
+    while (hp->kstreams.size() < 4) {  // low priority: a queue pool of their own again, one hardware queue per stream, so the chunk kernels overlap
+        hipStream_t t = nullptr;
+        int prLo = 0, prHi = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&prLo, &prHi));
+        HIPCHK(c, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, prLo));
+        hp->kstreams.push_back(t);
+    }
+    const size_t npiece_max = (size_t)(total / piece) + nchunk + 1;
+    while (hp->events.size() < 2 * nchunk + 2 + npiece_max) {
+        hipEvent_t e = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hp->events.push_back(e);
+    }
+    const uint64_t out_chunk = (uint64_t)256 << 20;
+    if (hp->in_cap < max_chunk + 64) {
+        for (int i = 0; i < 2; i++) { if (hp->pin_in[i]) (void)hipHostFree(hp->pin_in[i]); hp->pin_in[i] = nullptr; }
+        hp->in_cap = 0;
+        for (int i = 0; i < 2; i++) HIPCHK(c, hipHostMalloc((void**)&hp->pin_in[i], max_chunk + 64, hipHostMallocDefault));
+        hp->in_cap = max_chunk + 64;
+    }
+    if (hp->out_cap < out_chunk) {
+        for (int i = 0; i < 2; i++) { if (hp->pin_out[i]) (void)hipHostFree(hp->pin_out[i]); hp->pin_out[i] = nullptr; }
+        hp->out_cap = 0;
+        for (int i = 0; i < 2; i++) HIPCHK(c, hipHostMalloc((void**)&hp->pin_out[i], out_chunk, hipHostMallocDefault));
+        hp->out_cap = out_chunk;
+    }
+    for (size_t k = 0; k < nchunk; k++) { feed.landed.push_back(hp->events[2 * k]); feed.done.push_back(hp->events[2 * k + 1]); }
+    feed.streams = hp->kstreams;
+    const int T = host_copy_threads();
+    const bool trace = getenv("KC_HOST_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    std::mutex m;
+    std::condition_variable cv;
+    size_t recorded = 0;
+    bool fail = false;
+    const int dev = c->device;
+    uint8_t* d_in = (uint8_t*)c->tmp_src.p;
+    const uint64_t base0 = unit_off[0];
+    hipEvent_t* pe = hp->events.data() + 2 * nchunk + 2;  // per staged piece: its pinned slot is free again
+    std::thread stager([&] {
+        (void)hipSetDevice(dev);
+        size_t j = 0;
+        for (size_t k = 0; k < nchunk; k++) {
+            hipError_t e = hipSuccess;
+            const uint64_t a0 = unit_off[feed.cut[k]], a1 = unit_off[feed.cut[k + 1]];
+            for (uint64_t a = a0; a < a1 && e == hipSuccess; a += piece, j++) {
+                const uint64_t len = std::min(piece, a1 - a);
+                if (j >= 2) e = hipEventSynchronize(pe[j - 2]);
+                if (e != hipSuccess) break;
+                parallel_memcpy(hp->pin_in[j & 1], src + a, (size_t)len, T);
+                e = hipMemcpyAsync(d_in + (a - base0), hp->pin_in[j & 1], (size_t)len, hipMemcpyHostToDevice, hp->s_h2d);
+                if (e == hipSuccess) e = hipEventRecord(pe[j], hp->s_h2d);
+            }
+            if (e == hipSuccess) e = hipEventRecord(feed.landed[k], hp->s_h2d);
+            if (trace) fprintf(stderr, "[kc host] chunk %zu (%llu MiB) staged at %.1f ms\n", k, (unsigned long long)((a1 - a0) >> 20), ms_now());
+            std::lock_guard<std::mutex> lk(m);
+            if (e != hipSuccess) fail = true; else recorded = k + 1;
+            cv.notify_all();
+            if (fail) return;
+        }
+    });
+    feed.wait_recorded = [&](size_t k) {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return fail || recorded > k; });
+        return !fail;
+    };
+    std::vector<uint64_t> rel(n_units + 1);
+    for (uint32_t i = 0; i <= n_units; i++) rel[i] = unit_off[i] - base0;
+    c->last = kc_timings{0, 0, 0, 0, 0};
+    s = enq(feed, (const uint8_t*)d_in, (const uint64_t*)rel.data(), (uint8_t*)c->tmp_dst.p);
+    { std::lock_guard<std::mutex> lk(m); }
+    stager.join();  // enq returns after the last chunk was staged, or early on an error (then the stager runs out on its own buffers)
+    if (s != KC_OK) {
+        (void)hipStreamSynchronize(hp->s_h2d);
+        (void)hipDeviceSynchronize();
+        if (c->pend) { delete (Pending*)c->pend; c->pend = nullptr; }
+        return s;
+    }
+    if (trace) fprintf(stderr, "[kc host] batch enqueued at %.1f ms\n", ms_now());
+    // drain chunk by chunk as each finishes: local frame offsets, then device -> pinned -> dst in pieces, the DMA of a piece
+    // under the host copy of the one before
+    const uint8_t* d_out = (const uint8_t*)c->tmp_dst.p;
+    hipEvent_t evo[2] = {hp->events[2 * nchunk], hp->events[2 * nchunk + 1]};
+    struct Piece { uint64_t host_off, len; };
+    Piece fly[2];
+    size_t n_sub = 0, n_ret = 0;
+    hipError_t herr = hipSuccess;
+    auto retire = [&] {
+        const Piece& q = fly[n_ret & 1];
+        hipError_t e = hipEventSynchronize(evo[n_ret & 1]);
+        if (e != hipSuccess) herr = e;
+        else parallel_memcpy(dst + q.host_off, hp->pin_out[n_ret & 1], (size_t)q.len, T);
+        n_ret++;
+    };
+    uint64_t running = 0;
+    std::vector<uint64_t> loc;
+    kc_status ds = KC_OK;
+    for (size_t k = 0; k < nchunk && ds == KC_OK && herr == hipSuccess; k++) {
+        const uint32_t u0 = feed.cut[k], nk = feed.cut[k + 1] - u0;
+        loc.resize((size_t)nk + 1);
+        while (n_ret < n_sub && herr == hipSuccess) retire();  // host copies of the previous chunk while this one is still encoding
+        if (herr != hipSuccess) break;
+        if ((herr = hipEventSynchronize(feed.done[k])) != hipSuccess) break;
+        if ((herr = hipMemcpy(loc.data(), feed.loc_off + u0 + k, ((size_t)nk + 1) * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        const uint64_t Lk = loc[nk];
+        if (running + Lk > dst_cap) { c->err = "dst_cap too small"; ds = KC_ERR_DST_TOO_SMALL; break; }
+        for (uint32_t i = 0; i < nk; i++) out_off[u0 + i] = running + loc[i];
+        const uint8_t* d_chunk = d_out + region_of(u0);
+        for (uint64_t a = 0; a < Lk && herr == hipSuccess; a += out_chunk) {
+            const uint64_t len = std::min<uint64_t>(out_chunk, Lk - a);
+            if (n_sub - n_ret == 2) retire();
+            if (herr != hipSuccess) break;
+            herr = hipMemcpyAsync(hp->pin_out[n_sub & 1], d_chunk + a, (size_t)len, hipMemcpyDeviceToHost, hp->s_d2h);
+            if (herr == hipSuccess) herr = hipEventRecord(evo[n_sub & 1], hp->s_d2h);
+            fly[n_sub & 1] = Piece{running + a, len};
+            n_sub++;
+        }
+        running += Lk;
+        if (trace) fprintf(stderr, "[kc host] chunk %zu done, drain queued at %.1f ms\n", k, ms_now());
+    }
+    while (n_ret < n_sub && herr == hipSuccess) retire();
+    out_off[n_units] = running;
+    bool redo = false;
+    s = fin(&redo);  // synchronises the context's stream behind every chunk
+    if (getenv("KC_TEST_FEED_REDO")) redo = true;  // tests: exercise the fallback below
+    if (herr != hipSuccess) { (void)hipDeviceSynchronize(); c->err = std::string("HIP error: ") + hipGetErrorString(herr); return KC_ERR_HIP; }
+    if (s != KC_OK) return s;
+    if (ds != KC_OK) return ds;
+    if (trace) fprintf(stderr, "[kc host] drained at %.1f ms (produced %llu%s)\n", ms_now(), (unsigned long long)running, redo ? ", speculation redo: encoding again" : "");
+    if (redo) { c->err.clear(); return KC_ERR_UNSUPPORTED; }  // rare (batch_end's speculation check): the sub-batch pipeline encodes it again
+    return KC_OK;
+}
+
+// kc_zstd_encode_units as one chunk-fed batch.  KC_ERR_UNSUPPORTED with an empty error text: not a batch of this kind (dictionary:
+// the prefixed work buffer is built from the whole source; SpeedBetter: its scratch budget wants small batches; more than
+// max_batch_bytes or than the scratch budget) or a unit needed the speculation re-run - the sub-batch pipeline serves it.
+kc_status host_overlapped_zstd(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units,
+                               uint8_t* dst, uint64_t dst_cap, uint64_t* out_off) {
+    const uint64_t total = unit_off[n_units] - unit_off[0];
+    if (o->dict != nullptr || o->level == KC_SPEED_BETTER || total > c->max_batch_bytes) { c->err.clear(); return KC_ERR_UNSUPPORTED; }
+    uint64_t need = 0, scratch = 0;
+    for (uint32_t i = 0; i < n_units; i++) {
+        need += ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)(unit_off[i + 1] - unit_off[i])) + 15) & ~(uint64_t)15;
+        scratch += zstd_unit_scratch(o, unit_off[i + 1] - unit_off[i]);
+    }
+    if (scratch + (scratch >> 3) + total + need > scratch_budget(c)) { c->err.clear(); return KC_ERR_UNSUPPORTED; }  // many small units: several batches
+    auto enq = [&](ChunkFeed& feed, const uint8_t* d_in, const uint64_t* rel, uint8_t* d_out) {
+        return batch_begin(c, o, d_in, rel, n_units, d_out, need, &feed);
+    };
+    auto region = [&](uint32_t u0) { return c->plan.stage_off[u0]; };
+    auto fin = [&](bool* redo) { return feed_finish(c, redo); };
+    return host_chunk_fed(c, src, unit_off, n_units, dst, dst_cap, out_off, need, enq, region, fin);
+}
+
 // Sub-batch of the host pipeline.  The device encode wants many units in flight (C2, ms per GiB: 4 GiB batch 42, 2 GiB 48, 1 GiB 58),
 // the pipeline wants several stages: measured PCIe-inclusive on 4 GiB of C2 — 256 MiB 4.0, 512 MiB 6.8, 1 GiB 10.8, 2 GiB 13.8 GB/s.
 // 2 GiB sub-batches pin 2 x (2 + 2.1) GiB of host memory per context; KC_HOST_PIPE_MIB overrides.
@@ -995,6 +1288,11 @@ kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* 
     if (n_units == 0) { out_off[0] = 0; return KC_OK; }
     if ((s = validate_units(c, o, unit_off, n_units)) != KC_OK) return s;
     const uint64_t total = unit_off[n_units] - unit_off[0];
+    const uint64_t ov_min = getenv("KC_HOST_OVERLAP_MIN_MIB") ? (uint64_t)atoll(getenv("KC_HOST_OVERLAP_MIN_MIB")) << 20 : (uint64_t)1 << 30;
+    if (total >= ov_min && !getenv("KC_HOST_SERIAL") && !getenv("KC_HOST_PIPE_MIB")) {
+        s = host_overlapped_zstd(c, o, src, unit_off, n_units, dst, dst_cap, out_off);
+        if (s != KC_ERR_UNSUPPORTED || !c->err.empty()) return s;  // UNSUPPORTED with no message: shape not served by the one-batch path
+    }
     const uint64_t sub = host_sub_bytes(total);
     if (total >= 2 * sub && !getenv("KC_HOST_SERIAL")) {
         auto enc = [&](const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
@@ -1135,8 +1433,10 @@ int64_t kc_s2_max_encoded_len(int64_t srcLen) {  // s2/encode.go:389-418 (64-bit
 }
 
 static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
-                               uint64_t dst_cap, uint64_t* out_off, int framed, int with_stream_id, int level = KC_S2_LEVEL_DEFAULT) {
+                               uint64_t dst_cap, uint64_t* out_off, int framed, int with_stream_id, int level = KC_S2_LEVEL_DEFAULT,
+                               ChunkFeed* feed = nullptr) {
     if (!c || !blk_off || !out_off || (n && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
+    if (feed && (framed || n == 0)) { c->err = "chunk feed: bare blocks only"; return KC_ERR_INTERNAL; }
     if (level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_BETTER && level != KC_S2_LEVEL_SNAPPY) { c->err = "device path implements s2.Encode, s2.EncodeBetter and s2.EncodeSnappy"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
     c->last = kc_timings{0, 0, 0, 0, 0};
@@ -1150,7 +1450,10 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     }
     if (n == 0) { out_off[0] = lead; return KC_OK; }
     hipStream_t st = c->stream;
-    std::vector<uint64_t> rel(n + 1), so(n + 1);
+    std::vector<uint64_t>& rel = c->plan.rel_off;   // in the context: the asynchronous copies below outlive this call when chunk-fed
+    std::vector<uint64_t>& so = c->plan.stage_off;
+    rel.resize(n + 1);
+    so.resize(n + 1);
     uint64_t acc = 0, maxLen = 0;
     for (uint32_t i = 0; i < n; i++) {
         if (blk_off[i + 1] < blk_off[i]) { c->err = "blk_off not ascending"; return KC_ERR_BAD_ARG; }
@@ -1165,8 +1468,8 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     so[n] = acc;
     if (acc + lead > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
     kc_status s;
-    if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) || (s = ensure(c, c->out_off, (n + 1) * 8)) ||
-        (s = ensure(c, c->stage, acc + 64)) || (s = ensure(c, c->out_size, (size_t)n * 4)) ||
+    if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) ||
+        (s = ensure(c, c->out_off, (n + 1 + (feed ? feed->cut.size() : 0)) * 8)) || (s = ensure(c, c->stage, acc + 64)) || (s = ensure(c, c->out_size, (size_t)n * 4)) ||
         (s = ensure(c, c->tables, (size_t)n * kc_s2_table_bytes(level, maxLen))))
         return s;
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
@@ -1189,6 +1492,33 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     if (P.spec_w0 < 1) P.spec_w0 = 1;
     if (P.spec_w0b < 1) P.spec_w0b = 1;
     P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen) / 4);
+    if (feed) {
+        // the source is still arriving: per chunk, encode + compaction on the chunk's stream behind its H2D copy; frames of chunk k
+        // at d_dst + so[cut[k]], local offsets in out_off[cut[k] + k ...].  The caller synchronises (s2_feed_finish).
+        HIPCHK(c, hipEventRecord(c->ev[6], st));
+        feed->loc_off = (uint64_t*)c->out_off.p;
+        const size_t nchunk = feed->cut.size() - 1;
+        for (size_t k = 0; k < nchunk; k++) {
+            if (!feed->wait_recorded(k)) { c->err = "host pipeline: staging failed"; return KC_ERR_HIP; }
+            hipStream_t sk = feed->streams[k % feed->streams.size()];
+            const uint32_t u0 = feed->cut[k], nk = feed->cut[k + 1] - u0;
+            HIPCHK(c, hipStreamWaitEvent(sk, c->ev[6], 0));
+            HIPCHK(c, hipStreamWaitEvent(sk, feed->landed[k], 0));
+            KcS2Params Pk = P;
+            Pk.blk_off += u0;
+            Pk.stage_off += u0;
+            Pk.out_size += u0;
+            Pk.tables += (size_t)u0 * P.table_stride;
+            Pk.n_blocks = nk;
+            kc_launch_s2_encode(Pk, sk);
+            kc_launch_scan_sizes(Pk.out_size, nk, feed->loc_off + u0 + k, sk);
+            kc_launch_compact((const uint8_t*)c->stage.p, Pk.stage_off, Pk.out_size, feed->loc_off + u0 + k, d_dst + so[u0], nk, sk);
+            HIPCHK(c, hipEventRecord(feed->done[k], sk));
+        }
+        for (size_t k = 0; k < nchunk; k++) HIPCHK(c, hipStreamWaitEvent(st, feed->done[k], 0));
+        HIPCHK(c, hipGetLastError());
+        return KC_OK;
+    }
     kc_launch_s2_encode(P, st);
     HIPCHK(c, hipEventRecord(c->ev[1], st));
     kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n, (uint64_t*)c->out_off.p, st);
@@ -1339,6 +1669,22 @@ kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, cons
         if (blk_off[i + 1] - blk_off[i] > (uint64_t)(4 << 20)) { c->err = "S2 block larger than 4 MiB (s2.maxBlockSize) not served by the device path"; return KC_ERR_UNSUPPORTED; }
     }
     const uint64_t total = blk_off[n] - blk_off[0];
+    const uint64_t ov_min = getenv("KC_HOST_OVERLAP_MIN_MIB") ? (uint64_t)atoll(getenv("KC_HOST_OVERLAP_MIN_MIB")) << 20 : (uint64_t)512 << 20;
+    if (total >= ov_min && total <= c->max_batch_bytes && !getenv("KC_HOST_SERIAL") && !getenv("KC_HOST_PIPE_MIB")) {
+        uint64_t need = 0;
+        for (uint32_t i = 0; i < n; i++) need += ((uint64_t)kc_s2_max_encoded_len((int64_t)(blk_off[i + 1] - blk_off[i])) + 15) & ~(uint64_t)15;
+        auto enq = [&](ChunkFeed& feed, const uint8_t* d_in, const uint64_t* rel, uint8_t* d_out) {
+            return s2_encode_dev(c, d_in, rel, n, d_out, need, out_off, 0, 0, level, &feed);
+        };
+        auto region = [&](uint32_t u0) { return c->plan.stage_off[u0]; };
+        auto fin = [&](bool* redo) {
+            *redo = false;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipGetLastError());
+            return KC_OK;
+        };
+        return host_chunk_fed(c, src, blk_off, n, dst, dst_cap, out_off, need, enq, region, fin);
+    }
     if (total >= 2 * host_sub_bytes(total) && !getenv("KC_HOST_SERIAL")) {
         auto enc = [&](const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
             return kc_s2_encode_blocks_lvl_dev(c, level, d_in, rel, nu, d_out, cap, oo);

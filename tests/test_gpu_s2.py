@@ -463,3 +463,31 @@ def test_s2_levels_randomised_blocks_bit_exact(oracle, kclib, level):
            if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
     assert not bad, "level %d: blocks differing from the oracle (index, len): %r" % (level, bad[:10])
     enc.Close()
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_s2_host_chunk_fed_equals_oracle(oracle, kclib, level, monkeypatch):
+    """kc_s2_encode_blocks on a large host buffer: the source arrives in chunks, each chunk is encoded and compacted on its own
+    stream behind its copy and drained as it finishes.  Same bytes as the oracle's (and as the serial host path's), with ragged,
+    empty and large blocks across the chunk boundaries."""
+    from compress_amd import s2
+    monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_CHUNKS_MIB", "1,2,4")
+    blocks = corpora.stress_units(seed=31 + level, n=160)
+    j = corpora.corpus("J", 96, 65536).tobytes()
+    blocks += [j[i * 65536:(i + 1) * 65536] for i in range(96)]
+    blocks[7] = b""
+    blocks.append(j[:1 << 20])
+    blocks.append(b"x")
+    buf, off = corpora.pack_units(blocks)
+    enc = s2.BlockEncoder(level=level)
+    out, out_off = enc.EncodeBlocks(buf, off)
+    ref, ref_off = oracle.s2_encode_blocks(buf, off, threads=8, better=level == 1, snappy=level == 2)
+    assert np.array_equal(out_off, np.asarray(ref_off))
+    assert np.array_equal(out, np.asarray(ref))
+    out2, out_off2 = enc.EncodeBlocks(buf, off)
+    assert np.array_equal(out2, out) and np.array_equal(out_off2, out_off)
+    monkeypatch.setenv("KC_HOST_SERIAL", "1")
+    out3, out_off3 = enc.EncodeBlocks(buf, off)
+    assert np.array_equal(out3, out) and np.array_equal(out_off3, out_off)
+    enc.Close()

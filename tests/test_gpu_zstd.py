@@ -472,6 +472,44 @@ def test_host_pipeline_equals_device_path(oracle, kclib, level, monkeypatch):
     enc.Close()
 
 
+@pytest.mark.parametrize("level", [1, 2])
+def test_host_chunk_fed_batch_equals_device_path(oracle, kclib, level, monkeypatch):
+    """kc_zstd_encode_units on one device batch: the source arrives in chunks, each chunk's checksum / match finder / entropy
+    stage / compaction run on the chunk's own stream behind its copy and the frames drain chunk by chunk.  Same bytes and offsets
+    as the device-resident path (chunk boundaries fall inside the ragged part; empty and tiny units included)."""
+    torch = _torch()
+    monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_CHUNKS_MIB", "1,3,8,16")
+    n, usz = 512, 131072
+    buf = corpora.corpus("T", n, usz)
+    buf[5 * usz:9 * usz] = corpora.corpus("H", 4, usz)
+    buf[40 * usz:56 * usz] = corpora.corpus("M", 16, usz)
+    sizes = np.full(n, usz, dtype=np.uint64)
+    sizes[::7] = 100000
+    sizes[3] = 0
+    sizes[11] = 5
+    sizes[n - 1] = 17
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)
+    buf = buf[:int(off[n])]
+    enc = _enc(level)
+    out, out_off = enc.EncodeUnits(buf, off)
+    d_src = torch.from_numpy(buf).cuda()
+    cap = sum(((enc.MaxEncodedSize(int(x)) + 15) & ~15) for x in sizes) + 64
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    dev_off = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    assert np.array_equal(out_off, dev_off)
+    assert np.array_equal(out, d_dst[:int(dev_off[n])].cpu().numpy())
+    ref, ref_off = oracle.zstd_encode_units(buf[:int(off[64])], off[:65], threads=8, level=level)
+    assert np.array_equal(out[:int(out_off[64])], ref) and np.array_equal(out_off[:65], ref_off)
+    out3, out_off3 = enc.EncodeUnits(buf, off)  # buffers and events reused
+    assert np.array_equal(out3, out) and np.array_equal(out_off3, out_off)
+    monkeypatch.setenv("KC_TEST_FEED_REDO", "1")  # a unit needing the speculation re-run: the batch is encoded again the plain way
+    out4, out_off4 = enc.EncodeUnits(buf, off)
+    assert np.array_equal(out4, out) and np.array_equal(out_off4, out_off)
+    enc.Close()
+
+
 def test_many_small_units_fit_the_scratch_budget(oracle, kclib):
     """A batch of many small units needs scratch per unit and per block, not per input byte (tables 640 KiB per unit at
     SpeedDefault): batches are cut by a scratch budget instead of asking hipMalloc for hundreds of GiB."""
