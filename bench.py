@@ -109,7 +109,10 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive host-buffer measurement after the timed region")
     ap.add_argument("--pipeline", action="store_true",
                     help="zstd only: two contexts on two streams, the match finder of step i+1 under the entropy stage of step i. "
-                         "Measured on MI355X (round 1): 184.0 vs 184.7 ms/step, so the default is one context.")
+                         "Measured on MI355X: round 1 184.0 vs 184.7 ms/step (the kernels did not co-reside); round 2, with the two "
+                         "streams in different hardware-queue pools, the entropy stage does run under the next match finder and the "
+                         "match finder loses more than the entropy stage hides (C2 167.9 vs 162.6 ms/step, C3 344.0 vs 317.3): both "
+                         "compete for the same DRAM transaction queue.  The default is one context.")
     ap.add_argument("--no-device-verify", action="store_true",
                     help="skip the on-device round trip (decode ALL frames on the device + compare with the input)")
     ap.add_argument("--gather", default="root", choices=["root", "none"],
