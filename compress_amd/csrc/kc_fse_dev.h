@@ -8,6 +8,7 @@
 // integer-width wrap-arounds they rely on.
 #pragma once
 #include "kc_dev.h"
+#include "kc_wave.h"
 
 struct KcFseT {  // one fseEncoder (zstd/fse_encoder.go:23) — alphabet <= 64 symbols, tableLog <= 8
     uint32_t dnb[64];    // symbolTT[].deltaNbBits
@@ -255,12 +256,7 @@ __device__ inline bool fse_build_wave(const int16_t* norm, int symbolLen, uint8_
     const int v = isSym ? (int)norm[lane] : 0;
     const int cnt = v == -1 ? 1 : v;   // states owned by the symbol
     const int pcnt = v > 0 ? v : 0;    // cells placed by the spread walk
-    int incC = cnt, incP = pcnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int a = __shfl_up(incC, d, 64), b = __shfl_up(incP, d, 64);
-        if (lane >= d) { incC += a; incP += b; }
-    }
+    const int incC = (int)wave_incl_scan((uint32_t)cnt, lane), incP = (int)wave_incl_scan((uint32_t)pcnt, lane);
     const int exC = incC - cnt, exP = incP - pcnt;
     const int total = __shfl(incC, 63, 64);
     if ((uint32_t)total != tableSize) return false;

@@ -1,0 +1,21 @@
+// Wave-level scan / reduction primitives of the entropy stage (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Wave-wide scans and reductions on the DPP data path (row shifts inside the 16-lane rows, then the row_bcast:15 / row_bcast:31
+// steps across rows): six dependent VALU operations, where __shfl_up / __shfl_xor compile to six dependent ds_bpermute round trips
+// through the LDS crossbar.  All 64 lanes must be active (every caller is in wave-uniform control flow).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t kc_dpp_or0(uint32_t v) {  // the DPP-selected lane's v, 0 where there is none
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
+    v += kc_dpp_or0<0x111, 0xf>(v);  // row_shr:1
+    v += kc_dpp_or0<0x112, 0xf>(v);  // row_shr:2
+    v += kc_dpp_or0<0x114, 0xf>(v);  // row_shr:4
+    v += kc_dpp_or0<0x118, 0xf>(v);  // row_shr:8
+    v += kc_dpp_or0<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += kc_dpp_or0<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}

@@ -71,22 +71,10 @@ void kc_launch_fse_predef_init(void* d_predef, hipStream_t st) {
 // ---------------------------------------------------------------------------------------
 // workgroup primitives
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
-        if (lane >= d) v += o;
-    }
-    return v;
-}
+// Two independent 32-bit sums packed in one value: neither half may overflow (callers: byte and bit counts of one block).
 __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
-        uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
-        if (lane >= d) v += ((uint64_t)hi << 32) | lo;
-    }
-    return v;
+    const uint32_t lo = wave_incl_scan((uint32_t)v, lane), hi = wave_incl_scan((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
 }
 // Exclusive scan over the 256 threads; *total receives the block sum.  wsum: 4 x u64 LDS scratch.
 __device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t* wsum, uint64_t* total) {
@@ -102,17 +90,17 @@ __device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t* wsum
 }
 
 __device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, kc_dpp_or0<0x111, 0xf>(v));
+    v = mx(v, kc_dpp_or0<0x112, 0xf>(v));
+    v = mx(v, kc_dpp_or0<0x114, 0xf>(v));
+    v = mx(v, kc_dpp_or0<0x118, 0xf>(v));
+    v = mx(v, kc_dpp_or0<0x142, 0xa>(v));
+    v = mx(v, kc_dpp_or0<0x143, 0xc>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
 }
 
 // fseEncoder.approxSize (zstd/fse_encoder.go:603-660) with one lane per symbol: the sum is a wrapping uint32 sum, so
