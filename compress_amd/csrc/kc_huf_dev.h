@@ -248,9 +248,10 @@ struct KcWeightFse {  // scratch, LDS
     int16_t norm[16];
     uint16_t st[64];
     uint32_t dnb[16];
-    int32_t dfs[16];
+    int16_t dfs[16];
     uint8_t tsym[64];
     int16_t cumul[18];
+    int16_t posx[18];
 };
 
 struct KcBitW {  // serial LSB-first bit writer into a byte buffer (fse/bitwriter.go)
@@ -273,7 +274,9 @@ struct KcBitW {  // serial LSB-first bit writer into a byte buffer (fse/bitwrite
 // Returns compressed size (header + stream) written to out, or -1 when fse.Compress would
 // return an error (incompressible / RLE / internal), in which case huff0 falls back to raw
 // 4-bit weights.  W: scratch with count[] already holding the weight histogram.
-__device__ inline int huf_fse_compress_weights(const uint8_t* w, int n, int huffMax, int huffMaxCnt, KcWeightFse* W, uint8_t* out, int outCap) {
+__device__ inline int huf_fse_compress_weights(const uint8_t* w, int n, int huffMax, int huffMaxCnt, KcWeightFse* W, uint8_t* out, int outCap, int lane) {
+    // called by all 64 lanes of one wave: checks and tableLog are wave-uniform, normalizeCount / writeCount run on lane 0,
+    // buildCTable on the wave (fse_build_wave), the two-state encode loop on lane 0
     if (n <= 1) return -1;
     const int symbolLen = huffMax + 1;
     const int maxCount = huffMaxCnt;
@@ -292,11 +295,16 @@ __device__ inline int huf_fse_compress_weights(const uint8_t* w, int n, int huff
         if (tableLog > 12) tableLog = 12;
     }
     if (tableLog > 6) return -2;  // cannot happen for <=256 weights; guarded for the scratch sizes
-    if (!fse_normalize_core(W->count, W->norm, symbolLen, n, tableLog)) return -1;
-    int hdr = fse_write_ncount(W->norm, symbolLen, tableLog, out);
+    int hdr = -1;
+    if (lane == 0 && fse_normalize_core(W->count, W->norm, symbolLen, n, tableLog)) hdr = fse_write_ncount(W->norm, symbolLen, tableLog, out);
+    hdr = __shfl(hdr, 0, 64);
+    KC_WAVE_SYNC();
     if (hdr < 0) return -1;
-    if (!fse_build_core<int32_t>(W->norm, symbolLen, tableLog, W->tsym, W->cumul, W->st, W->dnb, W->dfs)) return -1;
+    if (!fse_build_wave(W->norm, symbolLen, tableLog, W->tsym, W->cumul, W->posx, W->st, W->dnb, W->dfs, lane)) return -1;
+    KC_WAVE_SYNC();
     if (n <= 2) return -1;  // compress: "src too small"
+    int res = 0;
+    if (lane == 0) {
     KcBitW bw;
     bw.acc = 0; bw.nb = 0; bw.out = out; bw.pos = hdr;
     uint16_t c1 = 0, c2 = 0;
@@ -338,45 +346,57 @@ __device__ inline int huf_fse_compress_weights(const uint8_t* w, int n, int huff
     bw.add(c2, tableLog);
     bw.add(c1, tableLog);
     bw.close();
-    if (bw.pos > outCap) return -2;
-    if (bw.pos >= n) return -1;  // "len(s.Out) >= len(in)" → ErrIncompressible
-    return bw.pos;
+    res = bw.pos > outCap ? -2 : (bw.pos >= n ? -1 : bw.pos);  // "len(s.Out) >= len(in)" → ErrIncompressible
+    }
+    res = __shfl(res, 0, 64);
+    KC_WAVE_SYNC();
+    return res;
 }
 
-// cTable.write (huff0/huff0.go:180): serialise the weights of table T into out.
-// Returns the description length, or -1 for ErrIncompressible (maxSymbolValue > 128 with
-// no FSE gain).  weights: 256-byte scratch.
-__device__ inline int huf_write_table(const KcHufTable* T, int symbolLen, uint8_t huffLog, uint8_t* weights, KcWeightFse* W, uint8_t* out, int outCap) {
-    uint8_t bitsToWeight[HUF_TABLELOG_MAX + 1];
-    bitsToWeight[0] = 0;
-    for (int n = 1; n <= HUF_TABLELOG_MAX; n++) bitsToWeight[n] = (n < (int)huffLog + 1) ? (uint8_t)(huffLog + 1 - n) : 0;
+// First half of cTable.write on a whole wave: weights[n] = bitsToWeight[nBits[n]] (huff0.go:186-199) for every symbol but the
+// last, and their histogram in W->count[0..15] (ballot counts; a serial loop over ~100 symbols with a dynamically indexed local
+// array, i.e. scratch memory, was the most expensive single-lane part of the table description).
+__device__ inline void huf_weights_wave(const KcHufTable* T, int symbolLen, uint8_t huffLog, uint8_t* weights, KcWeightFse* W, int lane) {
     const int maxSym = (int)(uint8_t)(symbolLen - 1);
-    for (int i = 0; i < 16; i++) W->count[i] = 0;
-    for (int n = 0; n < maxSym; n++) {
-        const uint8_t nbv = T->nb[n];
-        const uint8_t v = (nbv <= HUF_TABLELOG_MAX ? bitsToWeight[nbv] : 0) & 15;
-        weights[n] = v;
-        W->count[v]++;
-    }
-    if (maxSym >= 2) {
-        uint32_t huffMaxCnt = 0;
-        int huffMax = 0;
-        for (int i = 0; i < 16; i++) {
-            const uint32_t v = W->count[i];
-            if (v == 0) continue;
-            huffMax = i;
-            if (v > huffMaxCnt) huffMaxCnt = v;
+    uint32_t cnt = 0;
+    for (int n0 = 0; n0 < maxSym; n0 += 64) {
+        const int n = n0 + lane;
+        const bool act = n < maxSym;
+        const uint32_t nbv = act ? T->nb[n] : 0u;
+        const uint32_t v = (nbv >= 1 && nbv <= (uint32_t)huffLog) ? (uint32_t)huffLog + 1u - nbv : 0u;  // bitsToWeight
+        if (act) weights[n] = (uint8_t)(v & 15u);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint64_t m = ballot64(act && (v & 15u) == (uint32_t)k);
+            if (lane == k) cnt += (uint32_t)__popcll(m);
         }
-        const int r = huf_fse_compress_weights(weights, maxSym, huffMax, (int)huffMaxCnt, W, out + 1, outCap - 1);
+    }
+    if (lane < 16) W->count[lane] = cnt;
+    KC_WAVE_SYNC();
+}
+
+// cTable.write (huff0/huff0.go:180) on one wave: serialise the weights of the table into out; weights[] and W->count[] come from
+// huf_weights_wave.  Returns (wave-uniform) the description length, or -1 for ErrIncompressible (maxSymbolValue > 128 with no
+// FSE gain).
+__device__ inline int huf_write_table(int symbolLen, uint8_t* weights, KcWeightFse* W, uint8_t* out, int outCap, int lane) {
+    const int maxSym = (int)(uint8_t)(symbolLen - 1);
+    if (maxSym >= 2) {
+        const uint32_t c = lane < 16 ? W->count[lane] : 0u;
+        const uint32_t huffMaxCnt = wave_reduce_max(c);
+        const uint64_t nzm = ballot64(c != 0u);
+        const int huffMax = nzm ? 63 - __builtin_clzll(nzm) : 0;
+        const int r = huf_fse_compress_weights(weights, maxSym, huffMax, (int)huffMaxCnt, W, out + 1, outCap - 1, lane);
         if (r >= 0 && r < (symbolLen >> 1)) {
-            out[0] = (uint8_t)r;
+            if (lane == 0) out[0] = (uint8_t)r;
+            KC_WAVE_SYNC();
             return 1 + r;
         }
     }
     if (maxSym > (256 - 128)) return -1;
-    out[0] = (uint8_t)(128 | (maxSym - 1));
-    weights[maxSym] = 0;
-    int p = 1;
-    for (int n = 0; n < maxSym; n += 2) out[p++] = (uint8_t)((weights[n] << 4) | weights[n + 1]);
-    return p;
+    if (lane == 0) { out[0] = (uint8_t)(128 | (maxSym - 1)); weights[maxSym] = 0; }
+    KC_WAVE_SYNC();
+    const int np = (maxSym + 1) >> 1;
+    for (int j = lane; j < np; j += 64) out[1 + j] = (uint8_t)((weights[2 * j] << 4) | weights[2 * j + 1]);
+    KC_WAVE_SYNC();
+    return 1 + np;
 }

@@ -19,3 +19,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
     v += kc_dpp_or0<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
+__device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, kc_dpp_or0<0x111, 0xf>(v));
+    v = mx(v, kc_dpp_or0<0x112, 0xf>(v));
+    v = mx(v, kc_dpp_or0<0x114, 0xf>(v));
+    v = mx(v, kc_dpp_or0<0x118, 0xf>(v));
+    v = mx(v, kc_dpp_or0<0x142, 0xa>(v));
+    v = mx(v, kc_dpp_or0<0x143, 0xc>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
+}
+

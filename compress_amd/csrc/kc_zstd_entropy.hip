@@ -89,20 +89,6 @@ __device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t* wsum
     return base + inc - v;
 }
 
-__device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) {
-    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
-    v = mx(v, kc_dpp_or0<0x111, 0xf>(v));
-    v = mx(v, kc_dpp_or0<0x112, 0xf>(v));
-    v = mx(v, kc_dpp_or0<0x114, 0xf>(v));
-    v = mx(v, kc_dpp_or0<0x118, 0xf>(v));
-    v = mx(v, kc_dpp_or0<0x142, 0xa>(v));
-    v = mx(v, kc_dpp_or0<0x143, 0xc>(v));
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
-}
-
 // fseEncoder.approxSize (zstd/fse_encoder.go:603-660) with one lane per symbol: the sum is a wrapping uint32 sum, so
 // the lane order does not matter; any "impossible" symbol makes the whole estimate MaxUint32 like the serial code.
 __device__ __forceinline__ uint32_t wave_approx_size(const KcFseT* f, const uint32_t* hist, int histLen, int lane) {
@@ -719,22 +705,25 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 if (lane == 0) { S.wtot[wv] = nn; S.wsum[wv] = no; }
             }
             __syncthreads();
-            if (tid == 0) {
+            if (wv == 0) {  // wave 0: reuse decision + table description (cTable.write) as a wave; waves 1-3 build the sequence tables
                 const uint32_t newBits = 7 + S.wtot[0] + S.wtot[1] + S.wtot[2] + S.wtot[3];
                 const uint32_t oldBits = 7 + (uint32_t)(S.wsum[0] + S.wsum[1] + S.wsum[2] + S.wsum[3]);
                 const int newSize = (int)(newBits >> 3), oldSize = (int)(oldBits >> 3);
-                int wantSize = nlitE - (nlitE >> 4);  // WantLogLess = 4 (blockenc.go:72)
+                const int wantSize = nlitE - (nlitE >> 4);  // WantLogLess = 4 (blockenc.go:72)
                 int usePrev = 0;
                 // ReusePolicyAllow && canReuse: hSize == len(s.Out) == 0 at this point (App. A-12)
                 if (S.huf.reuse == 0 && S.ivar[IV_CANREUSE]) {
                     if (oldSize <= 0 + newSize || 0 + 12 >= wantSize) usePrev = 1;
                 }
-                S.ivar[IV_USEPREV] = usePrev;
                 int descLen = 0;
-                if (!usePrev) {
-                    descLen = huf_write_table(&S.cur, symbolLen, (uint8_t)S.ivar[IV_TABLOG], S.weights, &S.wfse, S.tdesc, (int)sizeof(S.tdesc));
+                if (!usePrev) {  // wave-uniform
+                    huf_weights_wave(&S.cur, symbolLen, (uint8_t)S.ivar[IV_TABLOG], S.weights, &S.wfse, lane);
+                    descLen = huf_write_table(symbolLen, S.weights, &S.wfse, S.tdesc, (int)sizeof(S.tdesc), lane);
                 }
-                S.ivar[IV_DESCLEN] = descLen;  // -1: cTable.write failed (ErrIncompressible)
+                if (lane == 0) {
+                    S.ivar[IV_USEPREV] = usePrev;
+                    S.ivar[IV_DESCLEN] = descLen;  // -1: cTable.write failed (ErrIncompressible)
+                }
             }
             if (wv >= 1 && seqHistDone) seq_build(wv - 1);
             seqBuildDone = seqHistDone;
