@@ -969,11 +969,20 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             const int loSeq = hiSeq - SEQ_CHUNK > 0 ? hiSeq - SEQ_CHUNK : 0;
             const int cn = hiSeq - loSeq;
             // stage codes of sequences [loSeq, hiSeq), stored in stream order: slot j <-> seq hiSeq-1-j
-            for (int j = tid; j < cn; j += ET) {
-                const uint64_t s = sq[hiSeq - 1 - j];
-                S.codes[0][j] = (uint8_t)kc_ll_code(seq_ll(s));
-                S.codes[1][j] = (uint8_t)kc_of_code(seq_of(s));
-                S.codes[2][j] = (uint8_t)kc_ml_code(seq_ml(s));
+            {
+                constexpr int R = SEQ_CHUNK / ET;  // all loads of the chunk are issued before the first code is computed
+                uint64_t sv[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) { const int j = tid + r * ET; sv[r] = j < cn ? sq[hiSeq - 1 - j] : 0ull; }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int j = tid + r * ET;
+                    if (j < cn) {
+                        S.codes[0][j] = (uint8_t)kc_ll_code(seq_ll(sv[r]));
+                        S.codes[1][j] = (uint8_t)kc_of_code(seq_of(sv[r]));
+                        S.codes[2][j] = (uint8_t)kc_ml_code(seq_ml(sv[r]));
+                    }
+                }
             }
             __syncthreads();
             PROF_MARK(10);
@@ -1044,13 +1053,16 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     const unsigned long long bad = __ballot(act && assumed != prevEnd);
                     if (bad == 0ull) break;
 #ifdef KC_CHAIN_STATS
-                    if (P.prof && lane == 0) atomicAdd(&P.prof[17], 1ull);
+                    if (P.prof && lane == 0) { atomicAdd(&P.prof[17], 1ull); atomicAdd(&P.prof[18 + k], 1ull); atomicAdd(&P.prof[24], (unsigned long long)__popcll(bad & ~(bad << 1))); if (f->useRLE) atomicAdd(&P.prof[25], 1ull); }
 #endif
-                    // Every lane that guessed wrong re-encodes its segment from its predecessor's current exit state, all at
-                    // once.  The lowest such lane has a proven predecessor, so each pass fixes at least that lane for good; a
-                    // lane whose predecessor changes again simply fails the next check.  On exit every entry state equals
-                    // the predecessor's exit state, i.e. the sequential chain.
-                    if (act && assumed != prevEnd) {
+                    // Of every run of consecutive lanes whose entry state disagrees with the predecessor's exit state, only the FIRST
+                    // re-encodes its segment in this pass: its predecessor is consistent, while the exit states of the others'
+                    // predecessors are about to change (re-running them too replaces a warm-up guess that may well be right by a
+                    // state that is certainly stale, and the error then cascades down the wave: measured 10 passes x 6.6 segments
+                    // per offset-code chunk, against ~10 genuinely wrong guesses).  The lowest wrong lane of the wave has a proven
+                    // predecessor, so each pass fixes at least that lane for good; on exit every entry state equals the
+                    // predecessor's exit state, i.e. the sequential chain.
+                    if ((bad & ~(bad << 1)) >> lane & 1ull) {
                         st = prevEnd;
                         assumed = prevEnd;
                         run(a, bnd, true);
@@ -1058,7 +1070,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     }
                 }
 #ifdef KC_CHAIN_STATS
-                if (P.prof && lane == 0) atomicAdd(&P.prof[16], 1ull);
+                if (P.prof && lane == 0) { atomicAdd(&P.prof[16], 1ull); if (f->useRLE) atomicAdd(&P.prof[26], 1ull); if (f->preDefined) atomicAdd(&P.prof[27], 1ull); }
 #endif
                 const uint16_t fin = (uint16_t)__shfl((int)endSt, nL > 0 ? nL - 1 : 0, 64);
                 if (lane == 0) S.state[k] = nL > 0 ? fin : trueIn;
