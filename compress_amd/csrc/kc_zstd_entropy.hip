@@ -957,13 +957,8 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         const int seqBudgetBytes = size - litSecLen - seqhdrLen;  // stream must be smaller than this to beat raw
         uint32_t* __restrict__ sw = (uint32_t*)lits;               // literals are consumed: reuse as bit staging
         uint64_t bitRun = 0;
+        uint32_t carry = 0;  // the partially filled staging word at bitRun >> 5 (workgroup-uniform); it is stored once it is complete
         bool overflow = seqBudgetBytes <= 0;
-        // zero the staging words the stream may touch, up front (bounded by the raw-size budget)
-        if (!overflow) {
-            const int zw = (seqBudgetBytes + 3 + 16) >> 2;
-            __syncthreads();
-            for (int i = tid; i < zw; i += ET) sw[i] = 0;
-        }
         __syncthreads();
         for (int hiSeq = nseq; hiSeq > 0 && !overflow; hiSeq -= SEQ_CHUNK) {
             const int loSeq = hiSeq - SEQ_CHUNK > 0 ? hiSeq - SEQ_CHUNK : 0;
@@ -1102,12 +1097,13 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 uint64_t tot;
                 const uint64_t ex = block_excl_scan64((uint64_t)(fb0 + fb1), S.wsum, &tot) + bitRun;
                 if ((int64_t)((bitRun + tot + 7) >> 3) >= (int64_t)seqBudgetBytes) { overflow = true; break; }
-                // Pack this step's fields in LDS (ds_or), then flush whole words to the staging stream with coalesced stores;
-                // only the first and last word of the step can be shared with the neighbouring steps (global atomicOr).
+                // Pack this step's fields in LDS (ds_or), then flush the complete words to the staging stream with coalesced stores.
+                // The word a step ends in the middle of is not stored: it is carried into the next step's first LDS word, so no
+                // staging word is ever written twice (no zero-fill of the staging area, no global atomics).
                 uint32_t* __restrict__ pk = (uint32_t*)S.whist;  // 1024 words, free during the sequence phase
                 const uint32_t wbase = (uint32_t)(bitRun >> 5);
                 const int nwords = (int)((((uint32_t)bitRun & 31u) + (uint32_t)tot + 31u) >> 5);
-                for (int i = tid; i < nwords + 2; i += ET) pk[i] = 0;
+                for (int i = tid; i < nwords + 2; i += ET) pk[i] = i == 0 ? carry : 0u;
                 __syncthreads();
                 if (j < cn) {
                     const uint64_t rel = ex - ((uint64_t)wbase << 5);
@@ -1116,11 +1112,10 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     else { lds_or_bits(pk, rel + fb0, fv1 & 0xFFFFFFFFull, 32); lds_or_bits(pk, rel + fb0 + 32, fv1 >> 32, fb1 - 32); }
                 }
                 __syncthreads();
-                for (int i = tid; i < nwords; i += ET) {
-                    const uint32_t v = pk[i];
-                    if (i == 0 || i == nwords - 1) { if (v) atomicOr(&sw[wbase + i], v); }
-                    else sw[wbase + i] = v;
-                }
+                const bool lastPartial = (((uint32_t)bitRun + (uint32_t)tot) & 31u) != 0u;
+                const int nstore = lastPartial ? nwords - 1 : nwords;
+                for (int i = tid; i < nstore; i += ET) sw[wbase + i] = pk[i];
+                carry = lastPartial ? pk[nwords - 1] : 0u;  // pk is rewritten only after the next step's scan barriers
                 bitRun += tot;
             }
             __syncthreads();
@@ -1134,6 +1129,8 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             else {
                 if (tid == 0) {
                     uint64_t bp = bitRun;
+                    sw[bitRun >> 5] = carry;       // the open word, then a clean one: the final states + end mark (<= 27 bits) may reach into it
+                    sw[(bitRun >> 5) + 1] = 0;
                     const int mlL = E[2]->tableLog, ofL = E[1]->tableLog, llL = E[0]->tableLog;
                     or_bits(sw, bp, (uint64_t)(S.state[2] & ((1u << mlL) - 1u)), mlL); bp += mlL;
                     or_bits(sw, bp, (uint64_t)(S.state[1] & ((1u << ofL) - 1u)), ofL); bp += ofL;
