@@ -467,6 +467,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         // ==================== compressed block attempt ====================
         // ---------- 1. gather literals + histogram ----------
         for (int i = tid; i < 4 * 256; i += ET) ((uint32_t*)S.whist)[i] = 0;
+        if (!litsOnly) for (int i = tid; i < (int)((sizeof(S.codes) + sizeof(S.sbits)) / 16); i += ET) ((uint4*)&S.codes[0][0])[i] = make_uint4(0, 0, 0, 0);  // gather window
         if (!litsOnly) {  // the sequence histograms may be filled early, under the Huffman tree build (see 2.)
             for (int i = tid; i < 3 * 64; i += ET) ((uint32_t*)S.shist)[i] = 0;
             if (tid < 3) S.smax[tid] = 0;
@@ -487,6 +488,8 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             uint64_t run = 0;  // lo32: literal bytes so far, hi32: source bytes so far
             const uint8_t* __restrict__ bsrc = base + blkStart;
             uint64_t sqNext = tid < nseq ? sq[tid] : 0ull;  // the next batch's sequence is loaded under the current batch's work
+            long long gq0 = 0, gq1 = 0, gq2 = 0, gq3 = 0, gq4 = 0, gt = P.prof ? clock64() : 0;
+#define GMARK(x) do { if (P.prof) { const long long n__ = clock64(); x += n__ - gt; gt = n__; } } while (0)
             for (int t0 = 0; t0 < nseq; t0 += ET) {
                 const int i = t0 + tid;
                 uint32_t ll = 0, adv = 0;
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     if (slot < LONG_CAP) { S.longList[slot][0] = sp; S.longList[slot][1] = lo; S.longList[slot][2] = ll; mine = false; }
                 }
                 __syncthreads();
+                GMARK(gq0);
                 const int nl = (int)(S.longCnt < LONG_CAP ? S.longCnt : LONG_CAP);
                 const uint32_t begLo = (uint32_t)run;
                 const uint32_t endLo = begLo + (uint32_t)tot;  // literal bytes after this batch
@@ -524,48 +528,71 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                             for (int kk = 0; kk < 4; kk++) {
                                 const uint32_t k = k0 + 8u * (uint32_t)kk;
                                 if (k < ll) {
-                                    const uint64_t v = vv[kk];
                                     const uint32_t n8 = ll - k < 8u ? ll - k : 8u;
-                                    for (uint32_t q = 0; q < n8; q++) {
-                                        const uint32_t o = lo + k + q - winBase;
-                                        if (o < (uint32_t)TILE) {
-                                            const uint32_t c = (uint32_t)(v >> (8 * q)) & 0xFFu;
-                                            tile[o] = (uint8_t)c;
-                                            atomicAdd(&S.whist[wv][c], 1u);
+                                    const uint64_t v = n8 < 8u ? vv[kk] & ((1ull << (8u * n8)) - 1ull) : vv[kk];
+                                    const uint32_t o = lo + k - winBase;  // wraps for bytes in front of the window
+                                    if (lo + k >= winBase && o + n8 <= (uint32_t)TILE) {
+                                        // the window is zero where nothing has been written yet: up to 8 bytes at any alignment are
+                                        // one or two 64-bit ORs (ds_or_b64) instead of 8 byte writes
+                                        unsigned long long* p = (unsigned long long*)(tile + (o & ~7u));
+                                        const uint32_t sh = (o & 7u) * 8u;
+                                        atomicOr(p, (unsigned long long)(v << sh));
+                                        if (sh != 0u && (v >> (64u - sh)) != 0ull) atomicOr(p + 1, (unsigned long long)(v >> (64u - sh)));
+                                    } else {  // run cut by a window edge (only when a batch holds more than TILE literal bytes)
+                                        for (uint32_t q = 0; q < n8; q++) {
+                                            const uint32_t oo = lo + k + q - winBase;
+                                            if (oo < (uint32_t)TILE) atomicOr((uint32_t*)(tile + (oo & ~3u)), (uint32_t)((v >> (8u * q)) & 0xFFu) << (8u * (oo & 3u)));
                                         }
                                     }
                                 }
                             }
                         }
                     }
+                    GMARK(gq1);
                     for (int e = 0; e < nl; e++) {
                         const uint32_t lsp = S.longList[e][0], llo = S.longList[e][1], lln = S.longList[e][2];
                         const uint32_t o0 = llo > winBase ? llo : winBase;
                         const uint32_t o1 = llo + lln < winBase + TILE ? llo + lln : winBase + TILE;
                         for (uint32_t o = o0 + tid; o < o1; o += ET) {
-                            const uint8_t c = bsrc[lsp + (o - llo)];
-                            tile[o - winBase] = c;
-                            atomicAdd(&S.whist[wv][c], 1u);
+                            const uint32_t oo = o - winBase;
+                            atomicOr((uint32_t*)(tile + (oo & ~3u)), (uint32_t)bsrc[lsp + (o - llo)] << (8u * (oo & 3u)));
                         }
                     }
                     __syncthreads();
+                    GMARK(gq2);
                     const uint32_t wEnd = endLo < winBase + TILE ? endLo : winBase + TILE;
                     const uint32_t nfull = (wEnd - winBase) >> 4;
                     for (uint32_t w = tid; w < nfull; w += ET) ((uint4*)(lits + winBase))[w] = ((const uint4*)tile)[w];
+                    // literal histogram from the flushed words, four bytes per thread and step: every lane active, where the per-run
+                    // loop above runs max(run length) steps with a handful of lanes each (the LDS pipe of the CU, shared by 16 waves,
+                    // is what bounds this phase)
+                    for (uint32_t d = tid; d < 4 * nfull; d += ET) {
+                        const uint32_t x = ((const uint32_t*)tile)[d];
+                        atomicAdd(&S.whist[wv][x & 0xFFu], 1u);
+                        atomicAdd(&S.whist[wv][(x >> 8) & 0xFFu], 1u);
+                        atomicAdd(&S.whist[wv][(x >> 16) & 0xFFu], 1u);
+                        atomicAdd(&S.whist[wv][x >> 24], 1u);
+                    }
                     const uint32_t tail = (wEnd - winBase) & 15u;  // only the last window of a batch has a tail
                     uint8_t carry = 0;
                     if (nfull > 0 && tid < (int)tail) carry = tile[(nfull << 4) + tid];
                     __syncthreads();
-                    if (nfull > 0 && tid < (int)tail) tile[tid] = carry;
+                    if (nfull > 0) {  // the flushed words become zero again; the tail moves to the window's first word
+                        for (uint32_t w = 1 + tid; w <= nfull; w += ET) ((uint4*)tile)[w] = make_uint4(0, 0, 0, 0);
+                        if (tid < 16) tile[tid] = carry;
+                    }
+                    if (winBase + TILE < endLo) __syncthreads();  // another window of this batch follows
                 }
                 run += tot;
                 __syncthreads();
+                GMARK(gq3);
             }
+            if (P.prof && tid == 0) { atomicAdd(&P.prof[28], (unsigned long long)gq0); atomicAdd(&P.prof[29], (unsigned long long)gq1); atomicAdd(&P.prof[30], (unsigned long long)gq2); atomicAdd(&P.prof[31], (unsigned long long)gq3); }
             // bytes still in LDS (less than one 16-byte word) + trailing literals after the last sequence
             {
                 const uint32_t total = (uint32_t)run;
                 const uint32_t rem = total & 15u;
-                if (tid < (int)rem) lits[(total & ~15u) + tid] = tile[tid];
+                if (tid < (int)rem) { const uint8_t c = tile[tid]; lits[(total & ~15u) + tid] = c; atomicAdd(&S.whist[wv][c], 1u); }
                 const uint32_t len = m.extra_lits, spos = (uint32_t)size - len, lo = (uint32_t)nlit - len;
                 for (uint32_t k = tid; k < len; k += ET) {
                     const uint8_t c = bsrc[spos + k];
