@@ -683,7 +683,6 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
         fprintf(stderr, "[K2 prof] shader-clock share per phase:");
         for (int i = 0; i < 14; i++) fprintf(stderr, " p%d=%.1f%%", i, tot ? 100.0 * (double)pv[i] / (double)tot : 0.0);
         fprintf(stderr, "  (total %.3g cycles over %u units)\n", (double)tot, n_units);
-        fprintf(stderr, "[K2 prof] gather sub-phases (cycles): scan %.3g, own runs %.3g, long runs + barrier %.3g, flush %.3g\n", (double)pv[28], (double)pv[29], (double)pv[30], (double)pv[31]);
         fprintf(stderr, "[K2 prof] tANS chains (counted with -DKC_CHAIN_STATS): %llu chunk-streams (%llu RLE, %llu predefined), %llu repair passes (LL %llu, OF %llu, ML %llu; %llu on RLE tables), %llu segments re-encoded\n",
                 pv[16], pv[26], pv[27], pv[17], pv[18], pv[19], pv[20], pv[25], pv[24]);
     }

@@ -488,8 +488,6 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             uint64_t run = 0;  // lo32: literal bytes so far, hi32: source bytes so far
             const uint8_t* __restrict__ bsrc = base + blkStart;
             uint64_t sqNext = tid < nseq ? sq[tid] : 0ull;  // the next batch's sequence is loaded under the current batch's work
-            long long gq0 = 0, gq1 = 0, gq2 = 0, gq3 = 0, gq4 = 0, gt = P.prof ? clock64() : 0;
-#define GMARK(x) do { if (P.prof) { const long long n__ = clock64(); x += n__ - gt; gt = n__; } } while (0)
             for (int t0 = 0; t0 < nseq; t0 += ET) {
                 const int i = t0 + tid;
                 uint32_t ll = 0, adv = 0;
@@ -505,7 +503,6 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     if (slot < LONG_CAP) { S.longList[slot][0] = sp; S.longList[slot][1] = lo; S.longList[slot][2] = ll; mine = false; }
                 }
                 __syncthreads();
-                GMARK(gq0);
                 const int nl = (int)(S.longCnt < LONG_CAP ? S.longCnt : LONG_CAP);
                 const uint32_t begLo = (uint32_t)run;
                 const uint32_t endLo = begLo + (uint32_t)tot;  // literal bytes after this batch
@@ -548,7 +545,6 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                             }
                         }
                     }
-                    GMARK(gq1);
                     for (int e = 0; e < nl; e++) {
                         const uint32_t lsp = S.longList[e][0], llo = S.longList[e][1], lln = S.longList[e][2];
                         const uint32_t o0 = llo > winBase ? llo : winBase;
@@ -559,7 +555,6 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                         }
                     }
                     __syncthreads();
-                    GMARK(gq2);
                     const uint32_t wEnd = endLo < winBase + TILE ? endLo : winBase + TILE;
                     const uint32_t nfull = (wEnd - winBase) >> 4;
                     for (uint32_t w = tid; w < nfull; w += ET) ((uint4*)(lits + winBase))[w] = ((const uint4*)tile)[w];
@@ -585,9 +580,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 }
                 run += tot;
                 __syncthreads();
-                GMARK(gq3);
             }
-            if (P.prof && tid == 0) { atomicAdd(&P.prof[28], (unsigned long long)gq0); atomicAdd(&P.prof[29], (unsigned long long)gq1); atomicAdd(&P.prof[30], (unsigned long long)gq2); atomicAdd(&P.prof[31], (unsigned long long)gq3); }
             // bytes still in LDS (less than one 16-byte word) + trailing literals after the last sequence
             {
                 const uint32_t total = (uint32_t)run;
