@@ -71,6 +71,7 @@ struct Plan {
     uint32_t n_units = 0, n_blocks = 0;
     std::vector<uint32_t> blk0;       // n+1
     std::vector<uint64_t> stage_off;  // n+1
+    std::vector<uint64_t> stage64;    // S2: n+1 staging slot offsets (64-byte aligned)
     std::vector<uint64_t> rel_off;    // n+1 unit offsets relative to the batch base
     uint32_t seq_stride = 0, lit_stride = 0;
 };
@@ -1452,10 +1453,12 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     if (n == 0) { out_off[0] = lead; return KC_OK; }
     hipStream_t st = c->stream;
     std::vector<uint64_t>& rel = c->plan.rel_off;   // in the context: the asynchronous copies below outlive this call when chunk-fed
-    std::vector<uint64_t>& so = c->plan.stage_off;
+    std::vector<uint64_t>& so = c->plan.stage64;     // staging slots: whole 64-byte lines (the kernel stores its output line by line)
+    std::vector<uint64_t>& reg = c->plan.stage_off;  // 16-byte aligned bounds: what dst_cap is checked against, chunk regions when chunk-fed
     rel.resize(n + 1);
     so.resize(n + 1);
-    uint64_t acc = 0, maxLen = 0;
+    reg.resize(n + 1);
+    uint64_t acc = 0, acc16 = 0, maxLen = 0;
     for (uint32_t i = 0; i < n; i++) {
         if (blk_off[i + 1] < blk_off[i]) { c->err = "blk_off not ascending"; return KC_ERR_BAD_ARG; }
         const uint64_t len = blk_off[i + 1] - blk_off[i];
@@ -1463,11 +1466,14 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
         if (len > (uint64_t)(4 << 20)) { c->err = "S2 block larger than 4 MiB (s2.maxBlockSize) not served by the device path"; return KC_ERR_UNSUPPORTED; }
         rel[i] = blk_off[i] - blk_off[0];
         so[i] = acc;
-        acc += ((uint64_t)kc_s2_max_encoded_len((int64_t)len) + (framed ? 8 : 0) + 15) & ~(uint64_t)15;
+        reg[i] = acc16;
+        acc += ((uint64_t)kc_s2_max_encoded_len((int64_t)len) + (framed ? 8 : 0) + 63) & ~(uint64_t)63;
+        acc16 += ((uint64_t)kc_s2_max_encoded_len((int64_t)len) + (framed ? 8 : 0) + 15) & ~(uint64_t)15;
     }
     rel[n] = blk_off[n] - blk_off[0];
     so[n] = acc;
-    if (acc + lead > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
+    reg[n] = acc16;
+    if (acc16 + lead > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
     kc_status s;
     if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) ||
         (s = ensure(c, c->out_off, (n + 1 + (feed ? feed->cut.size() : 0)) * 8)) || (s = ensure(c, c->stage, acc + 64)) || (s = ensure(c, c->out_size, (size_t)n * 4)) ||
@@ -1495,7 +1501,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen) / 4);
     if (feed) {
         // the source is still arriving: per chunk, encode + compaction on the chunk's stream behind its H2D copy; frames of chunk k
-        // at d_dst + so[cut[k]], local offsets in out_off[cut[k] + k ...].  The caller synchronises (s2_feed_finish).
+        // at d_dst + reg[cut[k]], local offsets in out_off[cut[k] + k ...].  The caller synchronises (s2_feed_finish).
         HIPCHK(c, hipEventRecord(c->ev[6], st));
         feed->loc_off = (uint64_t*)c->out_off.p;
         const size_t nchunk = feed->cut.size() - 1;
@@ -1513,7 +1519,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
             Pk.n_blocks = nk;
             kc_launch_s2_encode(Pk, sk);
             kc_launch_scan_sizes(Pk.out_size, nk, feed->loc_off + u0 + k, sk);
-            kc_launch_compact((const uint8_t*)c->stage.p, Pk.stage_off, Pk.out_size, feed->loc_off + u0 + k, d_dst + so[u0], nk, sk);
+            kc_launch_compact((const uint8_t*)c->stage.p, Pk.stage_off, Pk.out_size, feed->loc_off + u0 + k, d_dst + reg[u0], nk, sk);
             HIPCHK(c, hipEventRecord(feed->done[k], sk));
         }
         for (size_t k = 0; k < nchunk; k++) HIPCHK(c, hipStreamWaitEvent(st, feed->done[k], 0));
