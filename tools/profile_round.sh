@@ -18,7 +18,8 @@ for c in C2H C3 C4 C5; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_$c -- python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-device-verify > $OUT/kt_$c.log 2>&1
 done
 # 4. HBM traffic of the dominant kernels (bench.py --pmc: one rocprofv3 pass per counter, one step each)
-for c in C2 C3 C4 C5; do
+# PMC_CONFIGS: the configurations whose dominant kernel changed since profiles/pmc_traffic.json was stamped (default: all)
+for c in ${PMC_CONFIGS:-C2 C3 C4 C5}; do
   python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-device-verify --pmc > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
 done
 python - <<PY
@@ -34,7 +35,14 @@ def stats(tag):
         for r in rows: w.writerow([r[0][:120], r[1], round(r[2] / 1e3, 3), round(r[3] / 1e3, 3), round(r[4], 3)])
 for t in ("C2", "C2H", "C3", "C4", "C5"): stats(t)
 entries = []
+try:  # entries of configurations not measured in this run are kept (bench.py checks the kernel source hash of each)
+    old = {e["config"]: e for e in json.load(open(os.path.join("$R", "profiles", "pmc_traffic.json")))["entries"]}
+except Exception:
+    old = {}
 for t in ("C2", "C3", "C4", "C5"):
+    if not os.path.exists(os.path.join(out, "pmc_%s.json" % t)):
+        if t in old: entries.append(old[t])
+        continue
     try:
         j = json.loads(open(os.path.join(out, "pmc_%s.json" % t)).read().strip().splitlines()[-1])
         r = j["roofline"]
