@@ -119,7 +119,7 @@ def main():
                     help="N > 1: 'root' gathers every step's frames to rank 0 over RCCL (the path's only exchange step, default); "
                          "'none' leaves each rank's contiguous shard of frames on its own GPU (consumers that write per-rank files: "
                          "compress_amd.shard.write_shard; the frames are concatenable in rank order)")
-    ap.add_argument("--s2-level", type=int, default=0, choices=[0, 1, 2],
+    ap.add_argument("--s2-level", type=int, default=0, choices=[0, 1, 2, 3],
                     help="C4 only: 0 s2.Encode (the BASELINE configuration), 1 s2.EncodeBetter, 2 s2.EncodeSnappy")
     ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic in this run (two extra rocprofv3 passes of one step each)")
     ap.add_argument("--cpu-sample-units", type=int, default=0, help="units of the CPU-baseline / byte-compare sample (0: per configuration)")
@@ -168,7 +168,7 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(npipe)]
     if is_s2:
         encs = [s2.BlockEncoder(device=local_rank, stream=streams[0].cuda_stream, level=args.s2_level)]
-        cfg["what"] = {0: cfg["what"], 1: "s2.EncodeBetter", 2: "s2.EncodeSnappy"}[args.s2_level]
+        cfg["what"] = {0: cfg["what"], 1: "s2.EncodeBetter", 2: "s2.EncodeSnappy", 3: "s2.EncodeSnappyBetter"}[args.s2_level]
         cfg["kernel"] = "kc_s2_encode_kernel<%d>" % args.s2_level
         slot = (s2.MaxEncodedLen(UNIT) + 15) & ~15
     else:
@@ -293,7 +293,7 @@ def main():
             t0 = time.perf_counter()
             if is_s2:
                 ref, ref_off = oracle_lib.s2_encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], threads=cores,
-                                                           better=args.s2_level == 1, snappy=args.s2_level == 2)
+                                                           better=args.s2_level in (1, 3), snappy=args.s2_level in (2, 3))
             else:
                 kw = dict(level=cfg["level"])
                 if dict_content:

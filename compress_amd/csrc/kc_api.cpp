@@ -1439,7 +1439,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
                                ChunkFeed* feed = nullptr) {
     if (!c || !blk_off || !out_off || (n && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
     if (feed && (framed || n == 0)) { c->err = "chunk feed: bare blocks only"; return KC_ERR_INTERNAL; }
-    if (level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_BETTER && level != KC_S2_LEVEL_SNAPPY) { c->err = "device path implements s2.Encode, s2.EncodeBetter and s2.EncodeSnappy"; return KC_ERR_UNSUPPORTED; }
+    if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BETTER) { c->err = "device path implements s2.Encode, s2.EncodeBetter, s2.EncodeSnappy and s2.EncodeSnappyBetter"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
     c->last = kc_timings{0, 0, 0, 0, 0};
     HIPCHK(c, hipSetDevice(c->device));
@@ -1667,7 +1667,7 @@ kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk
 kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* dst, uint64_t dst_cap,
                                   uint64_t* out_off) {
     if (!c || !blk_off || !out_off || (n && (!src || !dst))) return KC_ERR_BAD_ARG;
-    if (level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_BETTER && level != KC_S2_LEVEL_SNAPPY) { c->err = "device path implements s2.Encode, s2.EncodeBetter and s2.EncodeSnappy"; return KC_ERR_UNSUPPORTED; }
+    if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BETTER) { c->err = "device path implements s2.Encode, s2.EncodeBetter, s2.EncodeSnappy and s2.EncodeSnappyBetter"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
     HIPCHK(c, hipSetDevice(c->device));
     if (n == 0) { out_off[0] = 0; return KC_OK; }

@@ -221,7 +221,7 @@ __device__ __forceinline__ uint32_t s2_crc32c(const uint8_t* __restrict__ p, int
     return c ^ 0xFFFFFFFFu;
 }
 
-template <int LEVEL>  // 0: s2.Encode (encodeBlockGo / ...64K), 1: s2.EncodeBetter (encodeBlockBetterGo / ...64K), 2: s2.EncodeSnappy (encodeBlockSnappyGo / ...64K)
+template <int LEVEL>  // 0: s2.Encode (encodeBlockGo / ...64K), 1: s2.EncodeBetter (encodeBlockBetterGo / ...64K), 2: s2.EncodeSnappy (encodeBlockSnappyGo / ...64K), 3: s2.EncodeSnappyBetter (encodeBlockBetterSnappyGo / ...64K)
 __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     constexpr int G = S2G;
     __shared__ uint32_t crcT[4][256];
@@ -513,7 +513,11 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
             }
         }
     }
-    if (LEVEL == 1 && !stored) {
+    if ((LEVEL == 1 || LEVEL == 3) && !stored) {
+        // LEVEL 3 = s2.EncodeSnappyBetter: encodeBlockBetterSnappyGo / ...64K (s2/encode_better.go:310-483 / 733-900): tables 2^16 + 2^14
+        // (2^15 + 2^13 up to 64 KiB), the skip capped at maxSkip = 100, candidates accepted on 4 equal bytes only, every copy
+        // through emitCopyNoRepeat.
+        constexpr bool SNB = LEVEL == 3;
         // ---------------- s2.EncodeBetter: encodeBlockBetterGo (> 64 KiB) / encodeBlockBetterGo64K (s2/encode_better.go:50-307 / 485-730) ----------------
         // Long table (7-byte hash, 2^17 / 2^16 entries) + short table (4-byte hash, 2^14 / 2^13), every position probed (step 1, skip >>7 / >>6),
         // candidates accepted on 8 equal bytes (long, then short), then on 4 (long, then short with a lazy long lookup at s+1);
@@ -521,7 +525,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         // inside the probe loop is dead code in the reference (`if false && ...`).  Entries: position | tag(4 bytes) << PB, 0 = empty
         // (== candidate 0, verified on the bytes only, as the reference does).
         const bool big = len > (64 << 10);
-        const int LB = big ? 17 : 16, SB = big ? 14 : 13, SKIP = big ? 7 : 6;
+        const int LB = SNB ? (big ? 16 : 15) : (big ? 17 : 16), SB = big ? 14 : 13, SKIP = big ? 7 : 6;
+        auto skipOf = [&](int dist) -> int { const int k = (dist >> SKIP) + 1; return SNB && k > 100 ? 100 : k; };  // nextS - s
         uint32_t* __restrict__ ltab = tab;
         uint32_t* __restrict__ stab = tab + (1u << LB);
         const int PB = bits_len32((uint32_t)len);
@@ -539,10 +544,10 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         while (!fin && !stored) {
             const int d0 = s - nextEmit;
             const int k0 = d0 >> SKIP;
-            const int step = 1 + k0;
+            const int step = skipOf(d0);
             const int p = s + lig * step;
             const bool inseg = lig == 0 || ((d0 + (lig - 1) * step) >> SKIP) == k0;
-            const int nextS = p + ((p - nextEmit) >> SKIP) + 1;
+            const int nextS = p + skipOf(p - nextEmit);
             const bool valid = lig < W && inseg && nextS <= sLimit;
             const bool term = inseg && nextS > sLimit;  // this step would `goto emitRemainder`
             uint64_t cv = 0;
@@ -567,8 +572,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 const bool okS = eS == 0 || (eS >> PB) == tagOf((uint32_t)cv);
                 const uint64_t vL = okL ? ld64(src + cL) : ~cv;
                 const uint64_t vS = okS ? ld64(src + cS) : ~cv;
-                if (cv == vL) { kind = 1; cand = cL; }
-                else if (cv == vS) { kind = 2; cand = cS; }
+                if (!SNB && cv == vL) { kind = 1; cand = cL; }
+                else if (!SNB && cv == vS) { kind = 2; cand = cS; }
                 else if ((uint32_t)cv == (uint32_t)vL) { kind = 3; cand = cL; }
                 else if ((uint32_t)cv == (uint32_t)vS) { kind = 4; cand = cS; }
             }
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                     fin = true;
                 } else {
                     const int pl = s + (nvalid - 1) * step;  // nvalid >= 1: lane 0 is valid or terminates
-                    s = pl + ((pl - nextEmit) >> SKIP) + 1;
+                    s = pl + skipOf(pl - nextEmit);
                 }
                 continue;
             }
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
             const int mkind = (int)s2g_bcast32((uint32_t)kind, grp, f);
             int candidate = (int)s2g_bcast32((uint32_t)cand, grp, f);
             const int ps = s + f * step;
-            const int nextSw = ps + ((ps - nextEmit) >> SKIP) + 1;
+            const int nextSw = ps + skipOf(ps - nextEmit);
             s = ps;
             if (mkind == 4) {
                 // try a long candidate at s+1 (:186-196); the lookup stores s+1 and observes this round's committed writes
@@ -633,7 +638,11 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 continue;
             }
             d += emit_lit(nextEmit, base - nextEmit);
-            if (repeat == offset) {
+            if (SNB) {
+                if (lig == 0) s2_emit_copy_nr1(dst + d, offset, l);
+                d += s2_copy_nr_size(offset, l);
+                repeat = offset;
+            } else if (repeat == offset) {
                 d += emit_repeat(offset, l);
             } else {
                 d += emit_copy(offset, l);
@@ -717,5 +726,6 @@ void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st) {
     if (P.n_blocks == 0) return;
     if (P.level == 1) hipLaunchKernelGGL(kc_s2_encode_kernel<1>, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
     else if (P.level == 2) hipLaunchKernelGGL(kc_s2_encode_kernel<2>, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
+    else if (P.level == 3) hipLaunchKernelGGL(kc_s2_encode_kernel<3>, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
     else hipLaunchKernelGGL(kc_s2_encode_kernel<0>, dim3((P.n_blocks + 7) / 8), dim3(64), 0, st, P);
 }

@@ -9,7 +9,7 @@ def MaxEncodedLen(src_len):
     return int(_lib.load().kc_s2_max_encoded_len(int(src_len)))
 
 
-LevelDefault, LevelBetter, LevelSnappy = 0, 1, 2  # s2.Encode / s2.EncodeBetter / s2.EncodeSnappy (s2/encode.go:29, 117, 204)
+LevelDefault, LevelBetter, LevelSnappy, LevelSnappyBetter = 0, 1, 2, 3  # s2.Encode / EncodeBetter / EncodeSnappy / EncodeSnappyBetter (s2/encode.go:29, 117, 204, 248)
 
 
 class BlockEncoder:

@@ -498,6 +498,7 @@ int64_t kco_s2_encode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap
 // encodeBlock only (no varint header); 0 == incompressible.  The WriterCustomEncoder contract.
 int64_t kco_s2_encode_better(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeBetter(dst, cap, src, (size_t)n); }
 int64_t kco_s2_encode_snappy(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeSnappy(dst, cap, src, (size_t)n); }
+int64_t kco_s2_encode_snappy_better(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeSnappyBetter(dst, cap, src, (size_t)n); }
 int64_t kco_s2_encode_block(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
     if (cap < (uint64_t)s2::MaxEncodedLen((int64_t)n)) return -2;
     return s2::encodeBlock(dst, src, (size_t)n);
@@ -542,6 +543,7 @@ static int64_t s2_encode_blocks_impl(const uint8_t* src, const uint64_t* blk_off
             outs[i].resize((size_t)s2::MaxEncodedLen((int64_t)n));
             int64_t r = level == 1 ? s2::EncodeBetter(outs[i].data(), outs[i].size(), src + blk_off[i], n)
                       : level == 2 ? s2::EncodeSnappy(outs[i].data(), outs[i].size(), src + blk_off[i], n)
+                      : level == 3 ? s2::EncodeSnappyBetter(outs[i].data(), outs[i].size(), src + blk_off[i], n)
                                    : s2::Encode(outs[i].data(), outs[i].size(), src + blk_off[i], n);
             outs[i].resize((size_t)r);
         }
@@ -571,6 +573,10 @@ int64_t kco_s2_encode_blocks_better(const uint8_t* src, const uint64_t* blk_off,
 int64_t kco_s2_encode_blocks_snappy(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
                                     uint64_t* out_off, int threads) {
     return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, 2);
+}
+int64_t kco_s2_encode_blocks_snappy_better(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
+                                           uint64_t* out_off, int threads) {
+    return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, 3);
 }
 
 }  // extern "C"

@@ -288,7 +288,9 @@ static inline uint32_t hash7(uint64_t u, uint8_t h) { return (uint32_t)(((u << (
 // One body for both variants: T = uint32/uint16 tables, LBITS/SBITS = 17/14 or 16/13, SKIP = 7 or 6,
 // BIG = the "offset > 65535 && s-base <= 5 && repeat != offset" bail of the > 64 KiB variant (:221-229).
 // The repeat check inside the probe loop is disabled in the reference (`if false && ...`, :124 / :561) and is not restated.
-template <typename T, int LBITS, int SBITS, int SKIP, bool BIG>
+// SNAPPY = encodeBlockBetterSnappyGo / ...64K (s2/encode_better.go:310-483 / 733-900): skip capped at maxSkip = 100, candidates
+// accepted on 4 equal bytes only (long, then short with the lazy long lookup), every copy through emitCopyNoRepeat.
+template <typename T, int LBITS, int SBITS, int SKIP, bool BIG, bool SNAPPY = false>
 static int encodeBlockBetterGoT(uint8_t* dst, const uint8_t* src, size_t srcLen) {
     const int len = (int)srcLen;
     const int sLimit = len - inputMargin;
@@ -305,6 +307,7 @@ static int encodeBlockBetterGoT(uint8_t* dst, const uint8_t* src, size_t srcLen)
         int nextS = 0;
         for (;;) {
             nextS = s + ((s - nextEmit) >> SKIP) + 1;
+            if (SNAPPY && nextS > s + 100) nextS = s + 100;  // maxSkip (:348, :356 / :775)
             if (nextS > sLimit) goto emitRemainder;
             {
                 uint32_t hashL = hash7(cv, LBITS);
@@ -315,8 +318,8 @@ static int encodeBlockBetterGoT(uint8_t* dst, const uint8_t* src, size_t srcLen)
                 sTable[hashS] = (T)s;
                 const uint64_t valLong = load64(src, candidateL);
                 const uint64_t valShort = load64(src, candidateS);
-                if (cv == valLong) break;                          // long matches at least 8 bytes
-                if (cv == valShort) { candidateL = candidateS; break; }
+                if (!SNAPPY && cv == valLong) break;               // long matches at least 8 bytes
+                if (!SNAPPY && cv == valShort) { candidateL = candidateS; break; }
                 if ((uint32_t)cv == (uint32_t)valLong) break;      // long likely matches 7
                 if ((uint32_t)cv == (uint32_t)valShort) {          // short candidate: try a long candidate at s+1 first
                     hashL = hash7(cv >> 8, LBITS);
@@ -355,7 +358,8 @@ static int encodeBlockBetterGoT(uint8_t* dst, const uint8_t* src, size_t srcLen)
                 continue;
             }
             d += emitLiteral(dst + d, src + nextEmit, (size_t)(base - nextEmit));
-            if (repeat == offset) d += emitRepeat(dst + d, offset, s - base);
+            if (SNAPPY) { d += emitCopyNoRepeat(dst + d, offset, s - base); repeat = offset; }
+            else if (repeat == offset) d += emitRepeat(dst + d, offset, s - base);
             else { d += emitCopy(dst + d, offset, s - base); repeat = offset; }
             nextEmit = s;
             if (s >= sLimit) goto emitRemainder;
@@ -393,6 +397,26 @@ emitRemainder:
 static inline int encodeBlockBetter(uint8_t* dst, const uint8_t* src, size_t n) {
     if (n <= ((size_t)64 << 10)) return encodeBlockBetterGoT<uint16_t, 16, 13, 6, false>(dst, src, n);
     return encodeBlockBetterGoT<uint32_t, 17, 14, 7, true>(dst, src, n);
+}
+
+// s2/encode_go.go:45 encodeBlockBetterSnappy: tables 2^16 + 2^14 (hashtable_pool.go:13-14), 2^15 + 2^13 up to 64 KiB
+static inline int encodeBlockBetterSnappy(uint8_t* dst, const uint8_t* src, size_t n) {
+    if (n <= ((size_t)64 << 10)) return encodeBlockBetterGoT<uint16_t, 15, 13, 6, false, true>(dst, src, n);
+    return encodeBlockBetterGoT<uint32_t, 16, 14, 7, true, true>(dst, src, n);
+}
+
+// s2/encode.go:248 EncodeSnappyBetter; returns bytes written or -1 / -2
+static inline int64_t EncodeSnappyBetter(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n) {
+    int64_t m = MaxEncodedLen((int64_t)n);
+    if (m < 0) return -1;
+    if (cap < (uint64_t)m) return -2;
+    int d = putUvarint(dst, (uint64_t)n);
+    if (n == 0) return d;
+    if (n < (size_t)minNonLiteralBlockSize) { d += emitLiteral(dst + d, src, n); return d; }
+    int k = encodeBlockBetterSnappy(dst + d, src, n);
+    if (k > 0) return d + k;
+    d += emitLiteral(dst + d, src, n);
+    return d;
 }
 
 // s2/encode.go:204 EncodeSnappy (s2/encode_go.go:27 encodeBlockSnappy); returns bytes written or -1 / -2

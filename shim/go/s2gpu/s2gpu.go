@@ -42,6 +42,7 @@ const (
 	LevelDefault = 0 // s2.Encode
 	LevelBetter  = 1 // s2.EncodeBetter
 	LevelSnappy  = 2 // s2.EncodeSnappy
+	LevelSnappyBetter = 3 // s2.EncodeSnappyBetter
 )
 
 // EncodeBlocks == N x s2.Encode(nil, src[off[i]:off[i+1]]).
@@ -49,7 +50,7 @@ func EncodeBlocks(x *Ctx, src []byte, off []uint64, dst []byte) ([]byte, []uint6
 	return EncodeBlocksLevel(x, LevelDefault, src, off, dst)
 }
 
-// EncodeBlocksLevel == N x s2.Encode / s2.EncodeBetter / s2.EncodeSnappy (nil, src[off[i]:off[i+1]]).
+// EncodeBlocksLevel == N x s2.Encode / s2.EncodeBetter / s2.EncodeSnappy / s2.EncodeSnappyBetter (nil, src[off[i]:off[i+1]]).
 func EncodeBlocksLevel(x *Ctx, level int, src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
 	n := len(off) - 1
 	outOff := make([]uint64, n+1)

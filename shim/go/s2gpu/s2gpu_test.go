@@ -42,7 +42,7 @@ func TestBitExact(t *testing.T) {
 	}
 }
 
-// TestBitExactLevels: the better and Snappy-compatible levels against s2.EncodeBetter / s2.EncodeSnappy.
+// TestBitExactLevels: the better and Snappy-compatible levels against s2.EncodeBetter / s2.EncodeSnappy / s2.EncodeSnappyBetter.
 func TestBitExactLevels(t *testing.T) {
 	x, err := NewCtx(0)
 	if err != nil {
@@ -61,17 +61,20 @@ func TestBitExactLevels(t *testing.T) {
 			}
 			off = append(off, uint64(len(data)))
 			dst := make([]byte, len(off)*(s2.MaxEncodedLen(unit)+16)+64)
-			for _, lv := range []int{LevelBetter, LevelSnappy} {
+			for _, lv := range []int{LevelBetter, LevelSnappy, LevelSnappyBetter} {
 				out, outOff, err := EncodeBlocksLevel(x, lv, data, off, dst)
 				if err != nil {
 					t.Fatal(err)
 				}
 				for i := 0; i+1 < len(off); i++ {
 					var want []byte
-					if lv == LevelBetter {
+					switch lv {
+					case LevelBetter:
 						want = s2.EncodeBetter(nil, data[off[i]:off[i+1]])
-					} else {
+					case LevelSnappy:
 						want = s2.EncodeSnappy(nil, data[off[i]:off[i+1]])
+					default:
+						want = s2.EncodeSnappyBetter(nil, data[off[i]:off[i+1]])
 					}
 					if !bytes.Equal(out[outOff[i]:outOff[i+1]], want) {
 						t.Fatalf("corpus %c unit %d level %d block %d differs from the reference", kind, unit, lv, i)
@@ -132,13 +135,15 @@ func TestWriteGolden(t *testing.T) {
 			h.Write(s2.Encode(nil, data[i*(64<<10):(i+1)*(64<<10)]))
 		}
 		lines[fmt.Sprintf("s2.%c.128x65536", kind)] = hex.EncodeToString(h.Sum(nil))
-		hb, hs := sha256.New(), sha256.New()
+		hb, hs, hsb := sha256.New(), sha256.New(), sha256.New()
 		for i := 0; i < 128; i++ {
 			hb.Write(s2.EncodeBetter(nil, data[i*(64<<10):(i+1)*(64<<10)]))
 			hs.Write(s2.EncodeSnappy(nil, data[i*(64<<10):(i+1)*(64<<10)]))
+			hsb.Write(s2.EncodeSnappyBetter(nil, data[i*(64<<10):(i+1)*(64<<10)]))
 		}
 		lines[fmt.Sprintf("s2better.%c.128x65536", kind)] = hex.EncodeToString(hb.Sum(nil))
 		lines[fmt.Sprintf("s2snappy.%c.128x65536", kind)] = hex.EncodeToString(hs.Sum(nil))
+		lines[fmt.Sprintf("s2snappybetter.%c.128x65536", kind)] = hex.EncodeToString(hsb.Sum(nil))
 	}
 	names := make([]string, 0, len(lines))
 	for n := range lines {

@@ -78,11 +78,11 @@ def lib():
         L.kco_s2_encode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.kco_s2_decode_stream.restype = C.c_int64
         L.kco_s2_decode_stream.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64]
-        for name in ("kco_s2_encode_blocks", "kco_s2_encode_blocks_better", "kco_s2_encode_blocks_snappy"):
+        for name in ("kco_s2_encode_blocks", "kco_s2_encode_blocks_better", "kco_s2_encode_blocks_snappy", "kco_s2_encode_blocks_snappy_better"):
             f = getattr(L, name)
             f.restype = C.c_int64
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
-        for name in ("kco_s2_encode_better", "kco_s2_encode_snappy"):
+        for name in ("kco_s2_encode_better", "kco_s2_encode_snappy", "kco_s2_encode_snappy_better"):
             f = getattr(L, name)
             f.restype = C.c_int64
             f.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64]
@@ -251,6 +251,16 @@ def s2_encode_snappy(src: bytes) -> bytes:
     return buf.raw[:r]
 
 
+def s2_encode_snappy_better(src: bytes) -> bytes:
+    """s2.EncodeSnappyBetter(nil, src) (s2/encode.go:248): the better parse, Snappy-compatible output."""
+    cap = lib().kco_s2_max_encoded_len(len(src))
+    buf = C.create_string_buffer(max(cap, 1))
+    r = lib().kco_s2_encode_snappy_better(src, len(src), buf, cap)
+    if r < 0:
+        raise RuntimeError("s2 encode_snappy_better failed %d" % r)
+    return buf.raw[:r]
+
+
 def s2_encode_blocks(src, blk_off, threads=1, better=False, snappy=False):
     """N x s2.Encode (or s2.EncodeBetter) on host threads.  src: numpy u8; blk_off: numpy u64 [n+1].  Returns (numpy u8, out_off numpy u64[n+1])."""
     import numpy as np
@@ -261,7 +271,9 @@ def s2_encode_blocks(src, blk_off, threads=1, better=False, snappy=False):
     cap = int(sum(lib().kco_s2_max_encoded_len(int(z)) * int(c) for z, c in zip(*np.unique(sizes, return_counts=True)))) + 64
     dst = np.empty(cap, dtype=np.uint8)
     out_off = np.empty(n + 1, dtype=np.uint64)
-    fn = lib().kco_s2_encode_blocks_better if better else (lib().kco_s2_encode_blocks_snappy if snappy else lib().kco_s2_encode_blocks)
+    L = lib()
+    fn = (L.kco_s2_encode_blocks_snappy_better if (better and snappy) else L.kco_s2_encode_blocks_better if better
+          else L.kco_s2_encode_blocks_snappy if snappy else L.kco_s2_encode_blocks)
     r = fn(src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, out_off.ctypes.data, int(threads))
     if r < 0:
         raise RuntimeError("oracle s2_encode_blocks failed: %d" % r)

@@ -444,10 +444,28 @@ def test_s2_snappy_blocks_bit_exact(oracle, kclib, kind):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["J", "T", "M", "H"])
+def test_s2_snappy_better_blocks_bit_exact(oracle, kclib, kind):
+    """KC_S2_LEVEL_SNAPPY_BETTER == s2.EncodeSnappyBetter (encodeBlockBetterSnappyGo / ...64K): 64 KiB blocks (2^15 + 2^13 tables),
+    larger ones (2^16 + 2^14, the long-offset bail), the reference's regression inputs and the edge units."""
+    from compress_amd import s2
+    buf = corpora.corpus(kind, 96, 65536)
+    blocks = [buf[i * 65536:(i + 1) * 65536].tobytes() for i in range(96)]
+    big = corpora.corpus(kind, 2, 1 << 20).tobytes()
+    blocks += [big[:65537], big[:700000], big[1 << 20:]] + [u for u in corpora.edge_units() if len(u) < 70000]
+    b2, off = corpora.pack_units(blocks)
+    enc = s2.BlockEncoder(level=s2.LevelSnappyBetter)
+    out, out_off = enc.EncodeBlocks(b2, off)
+    ref, ref_off = oracle.s2_encode_blocks(b2, off, threads=8, better=True, snappy=True)
+    assert np.array_equal(out_off, ref_off)
+    assert np.array_equal(out, np.asarray(ref))
+    enc.Close()
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
 def test_s2_levels_randomised_blocks_bit_exact(oracle, kclib, level):
     """Differential test over adversarial block mixes (text / noise runs of every length class / low-entropy noise / long zero
-    runs / repeated parts, 300 B .. 300 KB: both table variants of every level) for s2.Encode, s2.EncodeBetter, s2.EncodeSnappy."""
+    runs / repeated parts, 300 B .. 300 KB: both table variants of every level) for s2.Encode, s2.EncodeBetter, s2.EncodeSnappy, s2.EncodeSnappyBetter."""
     from compress_amd import s2
     blocks = corpora.stress_units(seed=11 + level, n=120)
     rng = np.random.default_rng(100 + level)
@@ -457,7 +475,7 @@ def test_s2_levels_randomised_blocks_bit_exact(oracle, kclib, level):
     buf, off = corpora.pack_units(blocks)
     enc = s2.BlockEncoder(level=level)
     out, out_off = enc.EncodeBlocks(buf, off)
-    ref, ref_off = oracle.s2_encode_blocks(buf, off, threads=8, better=level == 1, snappy=level == 2)
+    ref, ref_off = oracle.s2_encode_blocks(buf, off, threads=8, better=level in (1, 3), snappy=level in (2, 3))
     ref = np.asarray(ref)
     bad = [(i, len(blocks[i])) for i in range(len(blocks))
            if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
@@ -465,7 +483,7 @@ def test_s2_levels_randomised_blocks_bit_exact(oracle, kclib, level):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [0, 1, 2])
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
 def test_s2_host_chunk_fed_equals_oracle(oracle, kclib, level, monkeypatch):
     """kc_s2_encode_blocks on a large host buffer: the source arrives in chunks, each chunk is encoded and compacted on its own
     stream behind its copy and drained as it finishes.  Same bytes as the oracle's (and as the serial host path's), with ragged,
@@ -482,7 +500,7 @@ def test_s2_host_chunk_fed_equals_oracle(oracle, kclib, level, monkeypatch):
     buf, off = corpora.pack_units(blocks)
     enc = s2.BlockEncoder(level=level)
     out, out_off = enc.EncodeBlocks(buf, off)
-    ref, ref_off = oracle.s2_encode_blocks(buf, off, threads=8, better=level == 1, snappy=level == 2)
+    ref, ref_off = oracle.s2_encode_blocks(buf, off, threads=8, better=level in (1, 3), snappy=level in (2, 3))
     assert np.array_equal(out_off, np.asarray(ref_off))
     assert np.array_equal(out, np.asarray(ref))
     out2, out_off2 = enc.EncodeBlocks(buf, off)

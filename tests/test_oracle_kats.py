@@ -524,3 +524,21 @@ def test_s2_encode_snappy_is_snappy_and_roundtrips(oracle):
         except AssertionError:
             refused += 1
     assert refused > 0
+
+
+def test_s2_encode_snappy_better_is_snappy_and_not_larger(oracle):
+    """s2.EncodeSnappyBetter restatement (encodeBlockBetterSnappyGo / ...64K): strict Snappy blocks that round-trip; on compressible
+    corpora the better parse is not larger than s2.EncodeSnappy's by more than a percent (it searches every position)."""
+    import corpora
+    for kind in "TJMH":
+        for n in (65536, 65537, 300000):
+            d = corpora.corpus(kind, 1, n).tobytes()
+            b = oracle.s2_encode_snappy_better(d)
+            assert _snappy_decode_strict(b) == d
+            assert oracle.s2_decode(b, n + 8) == d
+            assert len(b) <= oracle.lib().kco_s2_max_encoded_len(n)
+            if kind in "TJ":
+                assert len(b) <= len(oracle.s2_encode_snappy(d)) * 1.01, (kind, n, len(b), len(oracle.s2_encode_snappy(d)))
+    for u in corpora.edge_units():
+        b = oracle.s2_encode_snappy_better(u)
+        assert _snappy_decode_strict(b) == u

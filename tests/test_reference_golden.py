@@ -36,7 +36,7 @@ def _parse(name):
         n, usz = p[3].split("x")
         return dict(codec="zstd", level=int(p[1][1:]), kind=p[2], n=int(n), unit=int(usz), rawdict=(len(p) > 4 and p[4] == "rawdict64k"))
     n, usz = p[2].split("x")
-    return dict(codec="s2", kind=p[1], n=int(n), unit=int(usz), level={"s2": 0, "s2better": 1, "s2snappy": 2}[p[0]])
+    return dict(codec="s2", kind=p[1], n=int(n), unit=int(usz), level={"s2": 0, "s2better": 1, "s2snappy": 2, "s2snappybetter": 3}[p[0]])
 
 
 def _dict():
@@ -56,7 +56,7 @@ def test_oracle_matches_reference_hashes(oracle):
                 kw.update(dict_id=1, dict_content=_dict())
             out, _ = oracle.zstd_encode_units(buf, off, threads=8, **kw)
         else:
-            out, _ = oracle.s2_encode_blocks(buf, off, threads=8, better=c["level"] == 1, snappy=c["level"] == 2)
+            out, _ = oracle.s2_encode_blocks(buf, off, threads=8, better=c["level"] in (1, 3), snappy=c["level"] in (2, 3))
         assert hashlib.sha256(np.asarray(out).tobytes()).hexdigest() == want, "oracle differs from the reference on " + name
 
 
