@@ -39,9 +39,9 @@ func CustomEncoder(x *Ctx) func(dst, src []byte) int {
 
 // Levels of EncodeBlocksLevel.
 const (
-	LevelDefault = 0 // s2.Encode
-	LevelBetter  = 1 // s2.EncodeBetter
-	LevelSnappy  = 2 // s2.EncodeSnappy
+	LevelDefault      = 0 // s2.Encode
+	LevelBetter       = 1 // s2.EncodeBetter
+	LevelSnappy       = 2 // s2.EncodeSnappy
 	LevelSnappyBetter = 3 // s2.EncodeSnappyBetter
 )
 
