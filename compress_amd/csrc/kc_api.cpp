@@ -71,6 +71,7 @@ struct Plan {
     uint32_t n_units = 0, n_blocks = 0;
     std::vector<uint32_t> blk0;       // n+1
     std::vector<uint64_t> stage_off;  // n+1
+    std::vector<uint32_t> blk_start, unit_flags;  // streams with Flush points: per block / per unit (see KcMatchParams)
     std::vector<uint64_t> stage64;    // S2: n+1 staging slot offsets (64-byte aligned)
     std::vector<uint64_t> rel_off;    // n+1 unit offsets relative to the batch base
     uint32_t seq_stride = 0, lit_stride = 0;
@@ -84,6 +85,7 @@ struct kc_ctx {
     bool own_stream = false;
     std::string err;
     hipDeviceProp_t prop;
+    DevBuf blk_start, unit_flags;
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
         predef, errflag, tmp_src, tmp_dst, tables, prof, work, work_off, dictbuf, proto, dicthuf;
     bool predef_ready = false;
@@ -92,6 +94,9 @@ struct kc_ctx {
     size_t max_batch_bytes = (size_t)8 << 30;  // input bytes per device batch (scratch is ~6x this for full-size units)
     uint64_t max_scratch_bytes = (uint64_t)160 << 30;  // scratch per device batch (tables + per-block strides), further capped by the free device memory
     int stream_mode = 0;             // set for the duration of kc_zstd_encode_streams_dev
+    const uint64_t* cut_off = nullptr;  // streams with Flush points (kc_zstd_encode_streams_cuts*): per stream the range of its cuts,
+    const uint64_t* cuts = nullptr;     // the cut positions (bytes written before the Flush), for the duration of the call
+    uint32_t cut_unit0 = 0;             // index of the running batch's first unit in cut_off
     void* pend = nullptr;            // batch between kc_zstd_encode_units_dev_begin and _end (Pending)
     kc_ctx* chain_after = nullptr;   // pipelining: this context's match finder waits for that context's last one
     void* hpipe = nullptr;           // pinned staging ring + streams of the pipelined host path (HostPipe), created on first use
@@ -250,7 +255,7 @@ void kc_ctx_destroy(kc_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
-                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf};
+                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
@@ -400,13 +405,41 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     pl.rel_off.resize(n_units + 1);
     uint64_t so = 0;
     uint32_t nb = 0;
+    const bool irregular = c->cuts != nullptr;
+    pl.blk_start.clear();
+    pl.unit_flags.clear();
     for (uint32_t i = 0; i < n_units; i++) {
         const uint64_t len = unit_off[i + 1] - unit_off[i];
         pl.blk0[i] = nb;
         pl.stage_off[i] = so;
         pl.rel_off[i] = unit_off[i] - unit_off[0];
-        nb += (uint32_t)((len + bs - 1) / bs);
-        so += ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)len) + 15) & ~(uint64_t)15;
+        uint32_t ub = (uint32_t)((len + bs - 1) / bs);
+        if (irregular) {
+            // writeBlocks cuts a block every blockSize bytes after the last Flush; a Flush that finds nothing buffered does nothing
+            // (encoder.go:552).  Close: a single block still buffered with no header written yet is the EncodeAll frame (:272-288).
+            const uint64_t* cp = c->cuts + c->cut_off[c->cut_unit0 + i];
+            const uint64_t nc = c->cut_off[c->cut_unit0 + i + 1] - c->cut_off[c->cut_unit0 + i];
+            uint64_t pos = 0, ci = 0, lastStart = 0;
+            ub = 0;
+            while (pos < len) {
+                uint64_t e = pos + (uint64_t)bs;
+                while (ci < nc && cp[ci] <= pos) ci++;
+                if (ci < nc && cp[ci] < e) e = cp[ci];
+                if (e > len) e = len;
+                pl.blk_start.push_back((uint32_t)pos);
+                lastStart = pos;
+                pos = e;
+                ub++;
+            }
+            const bool flushedAtEnd = nc > 0 && cp[nc - 1] >= len;
+            const bool tailBuffered = ub > 0 && !flushedAtEnd && (len - lastStart) < (uint64_t)bs;
+            const bool streamU = len > 0 && !(ub == 1 && tailBuffered);
+            pl.unit_flags.push_back((streamU ? 1u : 0u) | ((streamU && !tailBuffered) ? 2u : 0u));
+            if (ub > 32) { c->err = "stream of more than 32 blocks: not served by the device path"; return KC_ERR_UNSUPPORTED; }
+        }
+        nb += ub;
+        // every block costs a 3-byte header: Flush points add blocks that MaxEncodedSize(len) does not count
+        so += ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)len) + (irregular ? 3ull * (c->cut_off[c->cut_unit0 + i + 1] - c->cut_off[c->cut_unit0 + i]) + 3ull : 0ull) + 15) & ~(uint64_t)15;
     }
     pl.blk0[n_units] = nb;
     pl.stage_off[n_units] = so;
@@ -429,6 +462,11 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     if (!c->predef_ready) {
         kc_launch_fse_predef_init(c->predef.p, st);
         c->predef_ready = true;
+    }
+    if (irregular) {
+        if ((s = ensure(c, c->blk_start, ((size_t)nb + 1) * 4)) || (s = ensure(c, c->unit_flags, (size_t)n_units * 4))) return s;
+        if (nb) HIPCHK(c, hipMemcpyAsync(c->blk_start.p, pl.blk_start.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->unit_flags.p, pl.unit_flags.data(), (size_t)n_units * 4, hipMemcpyHostToDevice, st));
     }
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, pl.rel_off.data(), (n_units + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->unit_blk0.p, pl.blk0.data(), (n_units + 1) * 4, hipMemcpyHostToDevice, st));
@@ -485,6 +523,8 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     mp.meta = (KcBlkMeta*)c->meta.p;
     mp.popmask = nullptr;
     mp.unit_list = nullptr;
+    mp.blk_start = irregular ? (const uint32_t*)c->blk_start.p : nullptr;
+    mp.unit_flags = irregular ? (const uint32_t*)c->unit_flags.p : nullptr;
     mp.seq_stride = pl.seq_stride;
     mp.block_size = bs;
     mp.max_match_off = o->window_size;
@@ -528,6 +568,8 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     ep.out_size = (uint32_t*)c->out_size.p;
     ep.xxh = (const uint64_t*)c->xxh.p;
     ep.redo_mask = (uint32_t*)c->redo.p;
+    ep.blk_start = mp.blk_start;
+    ep.unit_flags = mp.unit_flags;
     ep.unit_list = nullptr;
     ep.predef = c->predef.p;
     ep.seq_stride = pl.seq_stride;
@@ -794,6 +836,7 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
             const uint32_t nb = i1 - i0;
             tmp.resize(nb + 1);
             uint64_t produced = 0;
+            c->cut_unit0 = i0;
             s = run_batch(c, o, d_src, unit_off + i0, nb, d_dst + pos, dst_cap - pos, tmp.data(), &produced);
             if (s == KC_ERR_UNSUPPORTED && c->err.compare(0, 23, "device memory exhausted") == 0 && nb > 1 && attempt < 6) { oom = true; break; }
             if (s != KC_OK) return s;
@@ -1291,12 +1334,12 @@ kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* 
     if ((s = validate_units(c, o, unit_off, n_units)) != KC_OK) return s;
     const uint64_t total = unit_off[n_units] - unit_off[0];
     const uint64_t ov_min = getenv("KC_HOST_OVERLAP_MIN_MIB") ? (uint64_t)atoll(getenv("KC_HOST_OVERLAP_MIN_MIB")) << 20 : (uint64_t)1 << 30;
-    if (total >= ov_min && !getenv("KC_HOST_SERIAL") && !getenv("KC_HOST_PIPE_MIB")) {
+    if (total >= ov_min && !getenv("KC_HOST_SERIAL") && !getenv("KC_HOST_PIPE_MIB") && c->cuts == nullptr) {
         s = host_overlapped_zstd(c, o, src, unit_off, n_units, dst, dst_cap, out_off);
         if (s != KC_ERR_UNSUPPORTED || !c->err.empty()) return s;  // UNSUPPORTED with no message: shape not served by the one-batch path
     }
     const uint64_t sub = host_sub_bytes(total);
-    if (total >= 2 * sub && !getenv("KC_HOST_SERIAL")) {
+    if (total >= 2 * sub && !getenv("KC_HOST_SERIAL") && c->cuts == nullptr) {  // (Flush points are indexed by unit: one batch loop)
         auto enc = [&](const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
             return kc_zstd_encode_units_dev(c, o, d_in, rel, nu, d_out, cap, oo);
         };
@@ -1304,7 +1347,8 @@ kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* 
         return host_pipeline(c, src, unit_off, n_units, dst, dst_cap, out_off, sub, enc, mx);
     }
     uint64_t need = 0;
-    for (uint32_t i = 0; i < n_units; i++) need += ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)(unit_off[i + 1] - unit_off[i])) + 15) & ~(uint64_t)15;
+    for (uint32_t i = 0; i < n_units; i++)
+        need += ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)(unit_off[i + 1] - unit_off[i])) + (c->cuts ? 3 * (c->cut_off[i + 1] - c->cut_off[i]) + 3 : 0) + 15) & ~(uint64_t)15;
     if ((s = ensure(c, c->tmp_src, total + 64)) || (s = ensure(c, c->tmp_dst, need + 64))) return s;
     HIPCHK(c, hipMemcpyAsync(c->tmp_src.p, src + unit_off[0], total, hipMemcpyHostToDevice, c->stream));
     std::vector<uint64_t> rel(n_units + 1);
@@ -1328,6 +1372,51 @@ kc_status kc_zstd_encode_streams(kc_ctx* c, const kc_zstd_opts* o, const uint8_t
     c->stream_mode = 1;
     const kc_status s = kc_zstd_encode_units(c, o, src, unit_off, n_units, dst, dst_cap, out_off);
     c->stream_mode = 0;
+    return s;
+}
+
+// Streams with Flush points.  cut_off: n_units+1 indices into cuts; cuts[cut_off[i] .. cut_off[i+1]) = for stream i, ascending, the
+// number of bytes that had been written when Flush was called.
+static kc_status check_cuts(kc_ctx* c, const uint64_t* unit_off, uint32_t n_units, const uint64_t* cut_off, const uint64_t* cuts) {
+    if (!cut_off || (cut_off[n_units] > cut_off[0] && !cuts)) return KC_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < n_units; i++) {
+        if (cut_off[i + 1] < cut_off[i]) { c->err = "cut_off not ascending"; return KC_ERR_BAD_ARG; }
+        for (uint64_t k = cut_off[i]; k + 1 < cut_off[i + 1]; k++)
+            if (cuts[k + 1] < cuts[k]) { c->err = "cuts of a stream not ascending"; return KC_ERR_BAD_ARG; }
+    }
+    (void)unit_off;
+    return KC_OK;
+}
+
+kc_status kc_zstd_encode_streams_cuts_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off, uint32_t n_units,
+                                          const uint64_t* cut_off, const uint64_t* cuts, uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off) {
+    if (!c || !o || !unit_off) return KC_ERR_BAD_ARG;
+    c->err.clear();
+    kc_status s = check_cuts(c, unit_off, n_units, cut_off, cuts);
+    if (s != KC_OK) return s;
+    static const uint64_t none = 0;
+    c->cut_off = cut_off;
+    c->cuts = cuts ? cuts : &none;
+    c->cut_unit0 = 0;
+    s = kc_zstd_encode_streams_dev(c, o, d_src, unit_off, n_units, d_dst, dst_cap, out_off);
+    c->cuts = nullptr;
+    c->cut_off = nullptr;
+    return s;
+}
+
+kc_status kc_zstd_encode_streams_cuts(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units,
+                                      const uint64_t* cut_off, const uint64_t* cuts, uint8_t* dst, uint64_t dst_cap, uint64_t* out_off) {
+    if (!c || !o || !unit_off) return KC_ERR_BAD_ARG;
+    c->err.clear();
+    kc_status s = check_cuts(c, unit_off, n_units, cut_off, cuts);
+    if (s != KC_OK) return s;
+    static const uint64_t none = 0;
+    c->cut_off = cut_off;
+    c->cuts = cuts ? cuts : &none;
+    c->cut_unit0 = 0;
+    s = kc_zstd_encode_streams(c, o, src, unit_off, n_units, dst, dst_cap, out_off);
+    c->cuts = nullptr;
+    c->cut_off = nullptr;
     return s;
 }
 

@@ -18,6 +18,34 @@ __device__ __forceinline__ uint16_t ld16(const uint8_t* p) { return ((const kc_u
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
 __device__ __forceinline__ int ctz64(uint64_t v) { return __builtin_ctzll(v); }
+// Block partition of a unit.  Regular: a block every block_size bytes (EncodeAll; Write ... Close).  With blk_start (streams
+// with Flush points, zstd/encoder.go:547-570: Flush ends the block being filled) the host lists every block's start and says
+// per unit whether a block was written before Close (stream frame) and whether Close found nothing buffered (empty last block).
+struct KcUnitBlocks { int nblk; bool streamU; bool emptyLast; };
+__device__ __forceinline__ KcUnitBlocks kc_unit_blocks(const uint32_t* blk_start, const uint32_t* unit_flags, const uint32_t* unit_blk0,
+                                                       uint32_t u, int ulen, int bs, int stream_mode) {
+    KcUnitBlocks r;
+    if (blk_start != nullptr) {
+        const uint32_t f = unit_flags[u];
+        r.nblk = (int)(unit_blk0[u + 1] - unit_blk0[u]);
+        r.streamU = (f & 1u) != 0u;
+        r.emptyLast = (f & 2u) != 0u;
+    } else {
+        r.nblk = (ulen + bs - 1) / bs;
+        r.streamU = stream_mode != 0 && ulen >= bs;
+        r.emptyLast = r.streamU && (ulen % bs) == 0;
+    }
+    return r;
+}
+__device__ __forceinline__ int kc_blk_begin(const uint32_t* blk_start, uint32_t blk0, int b, int bs) {
+    return blk_start != nullptr ? (int)blk_start[blk0 + (uint32_t)b] : b * bs;
+}
+__device__ __forceinline__ int kc_blk_end(const uint32_t* blk_start, uint32_t blk0, int b, int nblk, int bs, int ulen) {
+    if (blk_start != nullptr) return b + 1 < nblk ? (int)blk_start[blk0 + (uint32_t)b + 1u] : ulen;
+    const int e = (b + 1) * bs;
+    return e < ulen ? e : ulen;
+}
+
 __device__ __forceinline__ uint32_t bcast32(uint32_t v, int srcLane) { return (uint32_t)__shfl((int)v, srcLane, 64); }
 __device__ __forceinline__ uint64_t bcast64(uint64_t v, int srcLane) {
     uint32_t lo = bcast32((uint32_t)v, srcLane), hi = bcast32((uint32_t)(v >> 32), srcLane);

@@ -13,6 +13,8 @@ struct KcMatchParams {
     const uint32_t* unit_blk0;  // device: n_units+1, first global block index of each unit
     uint64_t* seqs;             // device scratch: seq_stride packed sequences per block
     KcBlkMeta* meta;            // device: one record per block
+    const uint32_t* blk_start;  // device or null: per block, its start inside the unit (streams with Flush points: irregular blocks)
+    const uint32_t* unit_flags; // device, with blk_start: bit 0 stream frame (a block was written before Close), bit 1 Close found nothing buffered
     const uint32_t* popmask;    // device or null: per-unit bitmask of blocks whose offsets must be popped (re-run)
     const uint32_t* unit_list;  // device or null: indirection for re-runs
     uint32_t unit_base;         // first unit of this launch when unit_list is null (chunked launches)
@@ -51,6 +53,8 @@ struct KcEntropyParams {
     uint32_t* out_size;     // device: encoded size per unit
     const uint64_t* xxh;    // device: XXH64 per unit (only read when crc != 0)
     uint32_t* redo_mask;    // device: per unit, blocks whose late raw fallback invalidated carried offsets
+    const uint32_t* blk_start;  // as in KcMatchParams
+    const uint32_t* unit_flags;
     const uint32_t* unit_list;
     uint32_t unit_base;     // first unit of this launch when unit_list is null
     const void* predef;     // device: KcFsePredef

@@ -325,7 +325,8 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
     const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0;
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
-    const int nblk = (ulen + bs - 1) / bs;
+    const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
+    const int nblk = UB.nblk;
     uint8_t* __restrict__ outp = P.stage + P.stage_off[u];
     const bool rawAllLits = !P.all_lit_entropy;  // blk.encode(src, noEntropy, !allLitEntropy) (encoder.go:795)
     const bool noEntropy = P.no_entropy != 0;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
     // ---- frame header (frameenc.go:25-92; encoder.go:756-772) ----
     // Streaming layout (Write ... Close, zstd/encoder.go:257-428) for units of at least one block: frame header without content
     // size or single segment, window = the encoder's, `last` only on a short final block, otherwise an empty raw last block.
-    const bool streamU = P.stream_mode && ulen >= bs;
+    const bool streamU = UB.streamU;
     if (ulen > 0) {
         bool single = ulen <= P.window_size && ulen > 1024;
         if (P.single >= 0) single = P.single != 0;
@@ -420,10 +421,10 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
 
     for (int b = 0; b < nblk; b++) {
         const KcBlkMeta m = P.meta[blk0 + (uint32_t)b];
-        const int blkStart = hist0 + b * bs;
-        const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;
+        const int blkStart = hist0 + kc_blk_begin(P.blk_start, blk0, b, bs);
+        const int blkEnd = hist0 + kc_blk_end(P.blk_start, blk0, b, nblk, bs, ulen);
         const int size = blkEnd - blkStart;
-        const bool last = b == nblk - 1 && !(streamU && (ulen % bs) == 0);
+        const bool last = b == nblk - 1 && !UB.emptyLast;
         const uint8_t* __restrict__ org = base + blkStart;
         const uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
         uint8_t* __restrict__ lits = P.lits + (size_t)(blk0 + (uint32_t)b) * P.lit_stride;
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         PROF_MARK(13);
     }
 
-    if (streamU && (ulen % bs) == 0) {  // Close found nothing buffered: final block without data (encoder.go:315-329)
+    if (UB.emptyLast) {  // Close found nothing buffered: final block without data (encoder.go:315-329)
         if (tid == 0) { outp[opos] = 0x01; outp[opos + 1] = 0x00; outp[opos + 2] = 0x00; }
         opos += 3;
     }

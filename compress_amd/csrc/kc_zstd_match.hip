@@ -92,8 +92,9 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
     const int mmo = P.max_match_off;
-    const int nblk = (ulen + bs - 1) / bs;
-    const bool HIST = ulen > bs || hist0 > 0 || (P.stream_mode && ulen >= bs);  // with a dictionary encodeAll always calls Encode (encoder.go:783-787)
+    const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
+    const int nblk = gact ? UB.nblk : 0;  // a group without a unit (the launch's tail) does nothing
+    const bool HIST = ulen > bs || hist0 > 0 || UB.streamU;  // with a dictionary encodeAll always calls Encode (encoder.go:783-787)
     const uint32_t pm = (gact && P.popmask) ? P.popmask[u] : 0u;
     uint32_t* __restrict__ tab = tables + (size_t)ui * (1u << ZF_TABLE_BITS);  // zeroed by the host before the launch
     // Table entry = (position+1) in the low PB bits | a TB-bit tag of the 4 source bytes at that position.
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     bool pend = false;      // rf holds the 16*G bytes abase[whi ..) loaded during the previous round
     uint4 rf = make_uint4(0, 0, 0, 0);
     for (int b = 0; b < nblk; b++) {  // group-uniform trip count; groups diverge freely
-        const int blkStart = hist0 + b * bs;
-        const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;
+        const int blkStart = hist0 + kc_blk_begin(P.blk_start, blk0, b, bs);
+        const int blkEnd = hist0 + kc_blk_end(P.blk_start, blk0, b, nblk, bs, ulen);
         const int srcLen = blkEnd - blkStart;
         const int o1_in = o1, o2_in = o2;
         uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
     const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0 : 0;
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
-    const int nblk = (ulen + bs - 1) / bs;
+    const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
+    const int nblk = gact ? UB.nblk : 0;  // a group without a unit (the launch's tail) does nothing
     const uint32_t pm = (gact && P.popmask) ? P.popmask[u] : 0u;
     const size_t tabBytes = ((size_t)8 << ZB_LONG_BITS) + ((size_t)4 << ZB_SHORT_BITS);
     ZbCtx C;
@@ -77,8 +78,8 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
 
     int o1 = P.rep1, o2 = P.rep2;  // {1,4} (blockenc.go:78) or the dictionary's offsets (enc_base.go:189-195)
     for (int b = 0; b < nblk; b++) {
-        const int blkStart = hist0 + b * bs;
-        const int blkEnd = (blkStart + bs < hist0 + ulen) ? blkStart + bs : hist0 + ulen;  // == len(e.hist)
+        const int blkStart = hist0 + kc_blk_begin(P.blk_start, blk0, b, bs);
+        const int blkEnd = hist0 + kc_blk_end(P.blk_start, blk0, b, nblk, bs, ulen);  // == len(e.hist)
         const int srcLen = blkEnd - blkStart;
         const int o1_in = o1, o2_in = o2;
         uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;

@@ -118,6 +118,7 @@ class Encoder:
     def __init__(self, *opts, device=0, stream=None, w=None):
         self._w = w
         self._buf = bytearray()
+        self._cuts = []
         self._closed = False
         L = _lib.load()
         self.o = _lib.ZstdOpts()
@@ -174,6 +175,7 @@ class Encoder:
     def Reset(self, w):
         self._w = w
         self._buf = bytearray()
+        self._cuts = []
         self._closed = False
 
     def Write(self, p):
@@ -183,6 +185,7 @@ class Encoder:
         return len(p)
 
     def ReadFrom(self, r):
+        self._cuts.append(len(self._buf))  # ReadFrom first ends the block being filled (encoder.go:482-486)
         n = 0
         while True:
             b = r.read(1 << 20)
@@ -191,8 +194,11 @@ class Encoder:
             n += self.Write(b)
 
     def Flush(self):
-        if self._buf:
-            raise NotImplementedError("mid-stream Flush cuts a block early; not served by the device path")
+        """Encoder.Flush (encoder.go:547): ends the block being filled.  The bytes reach w on Close (the device path encodes the
+        whole stream in one call); they are the bytes the reference's writer receives, block boundaries included."""
+        if self._closed:
+            return
+        self._cuts.append(len(self._buf))
 
     def _finish_stream(self):
         """The frame the reference writes for Write(everything) + Close() goes to w."""
@@ -201,25 +207,37 @@ class Encoder:
             return
         import numpy as np
         data = bytes(self._buf)
+        cuts, self._cuts = self._cuts, []
         self._buf = bytearray()
         self._closed = True
-        out, _ = self.EncodeStreams(np.frombuffer(data, dtype=np.uint8), np.array([0, len(data)], dtype=np.uint64))
+        out, _ = self.EncodeStreams(np.frombuffer(data, dtype=np.uint8), np.array([0, len(data)], dtype=np.uint64),
+                                    flush_at=[cuts] if cuts else None)
         self._w.write(out.tobytes())
 
-    def EncodeStreams(self, src, unit_off):
-        """Like EncodeUnits, but every unit is a stream: NewWriter(w).Write(unit) ... Close()."""
+    def EncodeStreams(self, src, unit_off, flush_at=None):
+        """Like EncodeUnits, but every unit is a stream: NewWriter(w).Write(unit) ... Close().  flush_at: per stream, the byte
+        counts at which Flush was called (kc_zstd_encode_streams_cuts)."""
         import numpy as np
         ctx = self.ctx()
         src = np.ascontiguousarray(src, dtype=np.uint8)
         unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
         n = len(unit_off) - 1
-        cap = sum(((self.MaxEncodedSize(int(unit_off[i + 1] - unit_off[i])) + 15) & ~15) for i in range(n)) + 64
+        ncut = [len(flush_at[i]) if flush_at is not None else 0 for i in range(n)]
+        cap = sum(((self.MaxEncodedSize(int(unit_off[i + 1] - unit_off[i])) + (3 * ncut[i] + 3 if flush_at is not None else 0) + 15) & ~15)
+                  for i in range(n)) + 64
         dst = np.empty(cap, dtype=np.uint8)
         out_off = np.zeros(n + 1, dtype=np.uint64)
         if len(src) == 0:
             src = np.zeros(1, dtype=np.uint8)
-        ctx.check(ctx.L.kc_zstd_encode_streams(ctx.h, C.byref(self.o), src.ctypes.data, unit_off.ctypes.data, n,
-                                               dst.ctypes.data, cap, out_off.ctypes.data))
+        if flush_at is None:
+            ctx.check(ctx.L.kc_zstd_encode_streams(ctx.h, C.byref(self.o), src.ctypes.data, unit_off.ctypes.data, n,
+                                                   dst.ctypes.data, cap, out_off.ctypes.data))
+        else:
+            cut_off = np.zeros(n + 1, dtype=np.uint64)
+            cut_off[1:] = np.cumsum(ncut)
+            cuts = np.array([int(x) for f in flush_at for x in sorted(f)] + [0], dtype=np.uint64)
+            ctx.check(ctx.L.kc_zstd_encode_streams_cuts(ctx.h, C.byref(self.o), src.ctypes.data, unit_off.ctypes.data, n,
+                                                        cut_off.ctypes.data, cuts.ctypes.data, dst.ctypes.data, cap, out_off.ctypes.data))
         return dst[:int(out_off[n])], out_off
 
     def EncodeStreamsDevice(self, d_src_ptr, unit_off, d_dst_ptr, dst_cap):

@@ -114,7 +114,7 @@ kc_status kc_zstd_encode_units(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t
 kc_status kc_zstd_encode_units_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
                                    uint32_t n_units, uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
 /* N independent STREAMS: unit i's output equals NewWriter(w).Write(unit_i) ... Close() (zstd/encoder.go:154-428, 567-649;
- * no Flush in between): below one block that is the EncodeAll frame; from one block on, a frame without content size whose
+ * no Flush in between — see kc_zstd_encode_streams_cuts): below one block that is the EncodeAll frame; from one block on, a frame without content size whose
  * blocks all see the history, with the `last` flag on a short final block or else a trailing empty raw block.  Same limits as
  * kc_zstd_encode_units_dev (a stream of more than 32 blocks is KC_ERR_UNSUPPORTED); dictionaries are KC_ERR_UNSUPPORTED. */
 kc_status kc_zstd_encode_streams_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
@@ -122,6 +122,17 @@ kc_status kc_zstd_encode_streams_dev(kc_ctx* ctx, const kc_zstd_opts* o, const u
 /* host-buffer form (src / dst in host memory), like kc_zstd_encode_units */
 kc_status kc_zstd_encode_streams(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off,
                                  uint32_t n_units, uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
+/* The same with Flush points (zstd/encoder.go:547-570: Flush ends the block being filled; a Flush that finds nothing buffered does
+ * nothing): cuts[cut_off[i] .. cut_off[i+1]) lists, ascending, how many bytes of stream i had been written at each Flush.  A Write
+ * that precedes ReadFrom is such a point too (ReadFrom first ends the block being filled, :482-486).  The output is the
+ * concatenation of what the reference's writer received, delivered when the call returns.
+ * dst_cap: >= sum_i (kc_zstd_max_encoded_size(unit_i) + 3 * ncuts_i + 3, rounded up to 16). */
+kc_status kc_zstd_encode_streams_cuts_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
+                                          uint32_t n_units, const uint64_t* cut_off, const uint64_t* cuts, uint8_t* d_dst,
+                                          uint64_t dst_cap, uint64_t* out_off);
+kc_status kc_zstd_encode_streams_cuts(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off,
+                                      uint32_t n_units, const uint64_t* cut_off, const uint64_t* cuts, uint8_t* dst,
+                                      uint64_t dst_cap, uint64_t* out_off);
 /* Split form of kc_zstd_encode_units_dev for ONE device batch (<= 8 GiB): _begin enqueues everything up to and including
  * the match finder and returns without waiting; _end enqueues the entropy stage, waits, and returns the offsets.  With two
  * contexts (two streams, two sets of scratch) a caller pipelines consecutive batches:

@@ -297,6 +297,56 @@ def test_streams_bit_exact(oracle, kclib, level):
 
 
 @pytest.mark.parametrize("level", [1, 2, 3])
+def test_streams_with_flush_points_bit_exact(oracle, kclib, level):
+    """Mid-stream Flush (zstd/encoder.go:547-570) ends the block being filled: kc_zstd_encode_streams_cuts against the oracle's
+    Write / Flush / Close restatement — cuts inside the first block (header written early: no EncodeAll frame), on block boundaries
+    (no-ops), at the very end (empty last block), repeated, many tiny blocks, and random mixes; the io.Writer surface
+    (Write + Flush + ReadFrom + Close) writes the same bytes."""
+    _torch()
+    import io
+    import random
+    from compress_amd import zstd
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level))
+    bs = enc.o.block_size
+    t = corpora.corpus("T", 6, 131072, first_unit=90).tobytes()
+    m = corpora.corpus("M", 3, 131072, first_unit=5).tobytes()
+    cases = [(t[:1000], [10, 500]), (t[:1000], [1000]), (t[:1000], [0]), (t[:1000], []), (t[:bs + 100], [50, bs + 100]),
+             (t[:bs], [bs]), (t[:2 * bs], [bs]), (t[:2 * bs + 9], [bs - 1, bs, bs + 1]), (t[:3 * bs], [7, 7, 7, 2 * bs + 7]),
+             (m[:bs + 5000], [100 * k for k in range(1, 25)]), (b"", [0]), (b"", []), (t[:5], [1, 2, 3, 4, 5]),
+             (corpora.corpus("H", 1, bs).tobytes(), [bs // 2]), (t[:4 * bs + 1], [3 * bs + 50000, 4 * bs + 1, 4 * bs + 9])]
+    rnd = random.Random(1234 + level)
+    for _ in range(25):
+        n = rnd.choice([rnd.randrange(1, 3000), rnd.randrange(bs - 2000, bs + 2000), rnd.randrange(2 * bs, 5 * bs)])
+        d = (t if rnd.random() < 0.6 else m)[:n]
+        cuts = sorted(rnd.randrange(0, n + 2) for _ in range(rnd.choice([1, 1, 2, 4, 9])))
+        cases.append((d, cuts))
+    units = [c[0] for c in cases]
+    ubuf, off = corpora.pack_units(units)
+    out, out_off = enc.EncodeStreams(ubuf, off, flush_at=[c[1] for c in cases])
+    ref = oracle.ZstdOracle(level=level)
+    for i, (u, cuts) in enumerate(cases):
+        got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        assert got == ref.encode_stream(u, cuts), (i, len(u), cuts)
+        if u:
+            assert oracle.zstd_decompress(got, len(u) + 16) == u
+    # no cuts given at all == the plain stream API
+    plain, plain_off = enc.EncodeStreams(ubuf, off)
+    none, none_off = enc.EncodeStreams(ubuf, off, flush_at=[[] for _ in cases])
+    assert np.array_equal(plain, none) and np.array_equal(plain_off, none_off)
+    # the io.Writer surface
+    sink = io.BytesIO()
+    w = zstd.NewWriter(sink, zstd.WithEncoderLevel(level))
+    w.Flush()                      # nothing buffered: no effect
+    w.Write(t[:70000]); w.Flush()
+    w.Write(t[70000:70010]); w.Flush(); w.Flush()
+    w.Write(t[70010:2 * bs + 30])
+    w.ReadFrom(io.BytesIO(t[2 * bs + 30:3 * bs]))   # ends the block being filled first
+    w.Close()
+    assert sink.getvalue() == ref.encode_stream(t[:3 * bs], [70000, 70010, 2 * bs + 30])
+    enc.Close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_device_decoder_roundtrip(oracle, kclib, level):
     """N1 (GPU half) for zstd: kc_zstd_decode_units_dev decodes the frames the device encoder produced back to the source,
     on the device, checksum included — every corpus kind, edge units, adversarial mixes (raw / RLE / compressed blocks,
