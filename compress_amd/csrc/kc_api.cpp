@@ -1260,7 +1260,10 @@ kc_status host_chunk_fed(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off
         while (n_ret < n_sub && herr == hipSuccess) retire();  // host copies of the previous chunk while this one is still encoding
         if (herr != hipSuccess) break;
         if ((herr = hipEventSynchronize(feed.done[k])) != hipSuccess) break;
-        if ((herr = hipMemcpy(loc.data(), feed.loc_off + u0 + k, ((size_t)nk + 1) * 8, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        // on the copy-back stream, not the null stream: hipMemcpy would first wait for every blocking stream, i.e. for a context
+        // stream created by kc_ctx_create, which is already waiting for the LAST chunk
+        if ((herr = hipMemcpyAsync(loc.data(), feed.loc_off + u0 + k, ((size_t)nk + 1) * 8, hipMemcpyDeviceToHost, hp->s_d2h)) != hipSuccess) break;
+        if ((herr = hipStreamSynchronize(hp->s_d2h)) != hipSuccess) break;
         const uint64_t Lk = loc[nk];
         if (running + Lk > dst_cap) { c->err = "dst_cap too small"; ds = KC_ERR_DST_TOO_SMALL; break; }
         for (uint32_t i = 0; i < nk; i++) out_off[u0 + i] = running + loc[i];
