@@ -94,6 +94,9 @@ struct kc_ctx {
     size_t max_batch_bytes = (size_t)8 << 30;  // input bytes per device batch (scratch is ~6x this for full-size units)
     uint64_t max_scratch_bytes = (uint64_t)160 << 30;  // scratch per device batch (tables + per-block strides), further capped by the free device memory
     int stream_mode = 0;             // set for the duration of kc_zstd_encode_streams_dev
+    std::thread job;                 // kc_*_submit: the host-buffer call running on its own thread until kc_wait
+    bool job_active = false;
+    kc_status job_status = KC_OK;
     const uint64_t* cut_off = nullptr;  // streams with Flush points (kc_zstd_encode_streams_cuts*): per stream the range of its cuts,
     const uint64_t* cuts = nullptr;     // the cut positions (bytes written before the Flush), for the duration of the call
     uint32_t cut_unit0 = 0;             // index of the running batch's first unit in cut_off
@@ -253,6 +256,7 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
 
 void kc_ctx_destroy(kc_ctx* c) {
     if (!c) return;
+    if (c->job_active && c->job.joinable()) c->job.join();
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
                       &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf};
@@ -1421,6 +1425,37 @@ kc_status kc_zstd_encode_streams_cuts(kc_ctx* c, const kc_zstd_opts* o, const ui
     c->cuts = nullptr;
     c->cut_off = nullptr;
     return s;
+}
+
+// Asynchronous form of the host-buffer entry points: submit returns at once, the call runs on a thread of its own (staging,
+// kernels and drain of a batch are already overlapped inside one call; with two contexts a caller also overlaps consecutive
+// batches: submit(A, batch k+1) while wait(B) drains batch k).  One job per context; every buffer, and the option struct's
+// dictionary, must stay valid until kc_wait returns the job's status.
+kc_status kc_zstd_encode_units_submit(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units,
+                                      uint8_t* dst, uint64_t dst_cap, uint64_t* out_off) {
+    if (!c || !o) return KC_ERR_BAD_ARG;
+    if (c->job_active) { c->err = "a submitted job is still in flight on this context: kc_wait first"; return KC_ERR_BAD_ARG; }
+    const kc_zstd_opts oc = *o;
+    c->job_active = true;
+    c->job = std::thread([=] { c->job_status = kc_zstd_encode_units(c, &oc, src, unit_off, n_units, dst, dst_cap, out_off); });
+    return KC_OK;
+}
+
+kc_status kc_s2_encode_blocks_lvl_submit(kc_ctx* c, int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* dst,
+                                         uint64_t dst_cap, uint64_t* out_off) {
+    if (!c) return KC_ERR_BAD_ARG;
+    if (c->job_active) { c->err = "a submitted job is still in flight on this context: kc_wait first"; return KC_ERR_BAD_ARG; }
+    c->job_active = true;
+    c->job = std::thread([=] { c->job_status = kc_s2_encode_blocks_lvl(c, level, src, blk_off, n, dst, dst_cap, out_off); });
+    return KC_OK;
+}
+
+kc_status kc_wait(kc_ctx* c) {
+    if (!c) return KC_ERR_BAD_ARG;
+    if (!c->job_active) { c->err = "no submitted job on this context"; return KC_ERR_BAD_ARG; }
+    c->job.join();
+    c->job_active = false;
+    return c->job_status;
 }
 
 kc_status kc_xxh64_units_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out_hash) {

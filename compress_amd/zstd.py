@@ -160,6 +160,30 @@ class Encoder:
                                              dst.ctypes.data, cap, out_off.ctypes.data))
         return dst[:int(out_off[n])], out_off
 
+    def EncodeUnitsSubmit(self, src, unit_off, dst=None):
+        """Asynchronous EncodeUnits (kc_zstd_encode_units_submit): returns at once; Wait() returns what EncodeUnits returns.
+        dst: optional pre-allocated (pre-faulted) uint8 array of at least the summed MaxEncodedSize."""
+        import numpy as np
+        ctx = self.ctx()
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
+        n = len(unit_off) - 1
+        cap = sum(((self.MaxEncodedSize(int(unit_off[i + 1] - unit_off[i])) + 15) & ~15) for i in range(n)) + 64
+        if dst is None:
+            dst = np.empty(cap, dtype=np.uint8)
+        assert dst.dtype == np.uint8 and dst.size >= cap
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        ctx.check(ctx.L.kc_zstd_encode_units_submit(ctx.h, C.byref(self.o), src.ctypes.data, unit_off.ctypes.data, n,
+                                                    dst.ctypes.data, dst.size, out_off.ctypes.data))
+        self._job = (src, unit_off, dst, out_off, n)  # kept alive until Wait
+
+    def Wait(self):
+        src, unit_off, dst, out_off, n = self._job
+        self._job = None
+        ctx = self.ctx()
+        ctx.check(ctx.L.kc_wait(ctx.h))
+        return dst[:int(out_off[n])], out_off
+
     def EncodeUnitsDevice(self, d_src_ptr, unit_off, d_dst_ptr, dst_cap):
         """Device-resident form (pointers are ints).  Returns uint64[n+1] offsets (host numpy)."""
         import numpy as np

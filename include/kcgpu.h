@@ -133,6 +133,16 @@ kc_status kc_zstd_encode_streams_cuts_dev(kc_ctx* ctx, const kc_zstd_opts* o, co
 kc_status kc_zstd_encode_streams_cuts(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off,
                                       uint32_t n_units, const uint64_t* cut_off, const uint64_t* cuts, uint8_t* dst,
                                       uint64_t dst_cap, uint64_t* out_off);
+/* Asynchronous form of the host-buffer entry points (SURVEY §8(b) "async submit/wait"): submit returns at once and the call runs
+ * on a thread of its own; kc_wait blocks until it is done and returns ITS status (kc_last_error for the text).  One job per
+ * context.  Inside one call the source staging, the kernels and the drain of the frames already overlap chunk by chunk; with
+ * two contexts the caller also overlaps consecutive batches (submit(A, batch k+1); wait(B) ...).  src, unit_off / blk_off, dst,
+ * out_off and a dictionary referenced by *o must stay valid until kc_wait returns; *o itself is copied. */
+kc_status kc_zstd_encode_units_submit(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off,
+                                      uint32_t n_units, uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
+kc_status kc_s2_encode_blocks_lvl_submit(kc_ctx* ctx, int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks,
+                                         uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
+kc_status kc_wait(kc_ctx* ctx);
 /* Split form of kc_zstd_encode_units_dev for ONE device batch (<= 8 GiB): _begin enqueues everything up to and including
  * the match finder and returns without waiting; _end enqueues the entropy stage, waits, and returns the offsets.  With two
  * contexts (two streams, two sets of scratch) a caller pipelines consecutive batches:

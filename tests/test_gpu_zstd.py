@@ -560,6 +560,37 @@ def test_host_chunk_fed_batch_equals_device_path(oracle, kclib, level, monkeypat
     enc.Close()
 
 
+def test_submit_wait_two_contexts_overlap(oracle, kclib, monkeypatch):
+    """kc_zstd_encode_units_submit / kc_wait: two contexts alternate over six batches, each call running its chunk-fed host path on
+    its own thread while the other context's call is in flight; the frames equal the synchronous call's, a second submit on a
+    busy context and a wait without a job are refused."""
+    _torch()
+    from compress_amd import zstd, _lib
+    monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_CHUNKS_MIB", "2")
+    n, usz = 128, 131072
+    batches = [corpora.corpus("TMJ"[k % 3], n, usz, first_unit=1000 * k) for k in range(6)]
+    off = np.arange(n + 1, dtype=np.uint64) * usz
+    sync = _enc(1)
+    want = [sync.EncodeUnits(b, off) for b in batches]
+    encs = [_enc(1), _enc(1)]
+    got = [None] * 6
+    encs[0].EncodeUnitsSubmit(batches[0], off)
+    with pytest.raises(_lib.KcError):
+        encs[0].EncodeUnitsSubmit(batches[1], off)
+    for k in range(1, 7):
+        if k < 6:
+            encs[k & 1].EncodeUnitsSubmit(batches[k], off)
+        got[k - 1] = encs[(k - 1) & 1].Wait()
+    for k in range(6):
+        assert np.array_equal(got[k][1], want[k][1]) and np.array_equal(got[k][0], want[k][0]), k
+    with pytest.raises(_lib.KcError):
+        ctx = encs[0].ctx()
+        ctx.check(ctx.L.kc_wait(ctx.h))
+    for e in encs + [sync]:
+        e.Close()
+
+
 def test_many_small_units_fit_the_scratch_budget(oracle, kclib):
     """A batch of many small units needs scratch per unit and per block, not per input byte (tables 640 KiB per unit at
     SpeedDefault): batches are cut by a scratch budget instead of asking hipMalloc for hundreds of GiB."""
