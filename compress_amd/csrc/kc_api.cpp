@@ -53,6 +53,9 @@ struct Pending {
 // The source of a batch that arrives in chunks over PCIe (host path): the checksum + match-finder kernels of a chunk are
 // launched on their own stream as soon as the chunk's H2D copy has landed, so the transfers run under the kernels of the
 // chunks before while all units of the batch end up in flight together.
+// A unit is parsed by one lane group, block after block: positions are 32-bit with a few tag bits to spare.
+static const uint64_t KC_MAX_UNIT_BYTES = (uint64_t)1 << 30;
+
 struct ChunkFeed {
     std::vector<uint32_t> cut;                   // unit index boundaries, nchunk + 1
     std::vector<hipEvent_t> landed;              // recorded on the copy stream behind chunk k's H2D
@@ -85,7 +88,7 @@ struct kc_ctx {
     bool own_stream = false;
     std::string err;
     hipDeviceProp_t prop;
-    DevBuf blk_start, unit_flags;
+    DevBuf blk_start, unit_flags, redo_blk, pop_blk;
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
         predef, errflag, tmp_src, tmp_dst, tables, prof, work, work_off, dictbuf, proto, dicthuf;
     bool predef_ready = false;
@@ -259,7 +262,7 @@ void kc_ctx_destroy(kc_ctx* c) {
     if (c->job_active && c->job.joinable()) c->job.join();
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
-                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf};
+                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->redo_blk, &c->pop_blk, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
@@ -439,7 +442,6 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
             const bool tailBuffered = ub > 0 && !flushedAtEnd && (len - lastStart) < (uint64_t)bs;
             const bool streamU = len > 0 && !(ub == 1 && tailBuffered);
             pl.unit_flags.push_back((streamU ? 1u : 0u) | ((streamU && !tailBuffered) ? 2u : 0u));
-            if (ub > 32) { c->err = "stream of more than 32 blocks: not served by the device path"; return KC_ERR_UNSUPPORTED; }
         }
         nb += ub;
         // every block costs a 3-byte header: Flush points add blocks that MaxEncodedSize(len) does not count
@@ -460,7 +462,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
         (s = ensure(c, c->lits, (size_t)nb * pl.lit_stride)) || (s = ensure(c, c->meta, (size_t)nb * sizeof(KcBlkMeta))) ||
         (s = ensure(c, c->stage, so + 64)) || (s = ensure(c, c->out_size, (size_t)n_units * 4)) ||
         (s = ensure(c, c->xxh, (size_t)n_units * 8)) || (s = ensure(c, c->redo, (size_t)n_units * 4)) ||
-        (s = ensure(c, c->popmask, (size_t)n_units * 4)) || (s = ensure(c, c->unit_list, (size_t)n_units * 4)) ||
+        (s = ensure(c, c->redo_blk, (size_t)nb + 1)) || (s = ensure(c, c->pop_blk, (size_t)nb + 1)) || (s = ensure(c, c->unit_list, (size_t)n_units * 4)) ||
         (s = ensure(c, c->predef, kc_fse_predef_bytes())) || (s = ensure(c, c->errflag, 64)))
         return s;
     if (!c->predef_ready) {
@@ -476,6 +478,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     HIPCHK(c, hipMemcpyAsync(c->unit_blk0.p, pl.blk0.data(), (n_units + 1) * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->stage_off.p, pl.stage_off.data(), (n_units + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(c->redo.p, 0, (size_t)n_units * 4, st));
+    HIPCHK(c, hipMemsetAsync(c->redo_blk.p, 0, (size_t)nb + 1, st));
     HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 64, st));
 
     const uint8_t* d_src = d_src_base + unit_off[0];
@@ -525,7 +528,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     mp.unit_blk0 = (const uint32_t*)c->unit_blk0.p;
     mp.seqs = (uint64_t*)c->seqs.p;
     mp.meta = (KcBlkMeta*)c->meta.p;
-    mp.popmask = nullptr;
+    mp.pop_blk = nullptr;
     mp.unit_list = nullptr;
     mp.blk_start = irregular ? (const uint32_t*)c->blk_start.p : nullptr;
     mp.unit_flags = irregular ? (const uint32_t*)c->unit_flags.p : nullptr;
@@ -572,6 +575,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     ep.out_size = (uint32_t*)c->out_size.p;
     ep.xxh = (const uint64_t*)c->xxh.p;
     ep.redo_mask = (uint32_t*)c->redo.p;
+    ep.redo_blk = (uint8_t*)c->redo_blk.p;
     ep.blk_start = mp.blk_start;
     ep.unit_flags = mp.unit_flags;
     ep.unit_list = nullptr;
@@ -669,9 +673,14 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
     // re-run with that verdict forced.  Rare (needs a compressible-looking block that ends larger than raw).
     uint32_t redo_units = 0;
     {
-        std::vector<uint32_t> redo(n_units), popmask(n_units, 0u), list;
+        const Plan& pl = c->plan;  // this batch's layout (one batch in flight per context)
+        const uint32_t nb = pl.n_blocks;
+        uint32_t maxBlocks = 1;
+        for (uint32_t i = 0; i < n_units; i++) maxBlocks = std::max(maxBlocks, pl.blk0[i + 1] - pl.blk0[i]);
+        std::vector<uint32_t> redo(n_units), list;
+        std::vector<uint8_t> redo_blk, pop_blk;
         uint32_t errv[16];
-        for (int iter = 0; iter < 40; iter++) {
+        for (uint32_t iter = 0;; iter++) {
             HIPCHK(c, hipMemcpyAsync(redo.data(), c->redo.p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipMemcpyAsync(errv, c->errflag.p, 64, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
@@ -682,23 +691,29 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
                 return errv[0] == 100u ? KC_ERR_UNSUPPORTED : KC_ERR_INTERNAL;
             }
             list.clear();
-            for (uint32_t i = 0; i < n_units; i++) {
-                if (redo[i]) {
-                    popmask[i] |= redo[i] & (~redo[i] + 1u);  // only the lowest flagged block is trustworthy
-                    list.push_back(i);
-                }
-            }
+            for (uint32_t i = 0; i < n_units; i++)
+                if (redo[i]) list.push_back(i);
             if (list.empty()) break;
+            if (iter > maxBlocks + 1) { c->err = "speculation re-run did not converge"; return KC_ERR_INTERNAL; }  // every pass settles one more block per unit
+            redo_blk.resize(nb);
+            if (pop_blk.empty()) pop_blk.assign(nb, 0);
+            HIPCHK(c, hipMemcpyAsync(redo_blk.data(), c->redo_blk.p, nb, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            for (uint32_t i : list)
+                for (uint32_t b = pl.blk0[i]; b < pl.blk0[i + 1]; b++)
+                    if (redo_blk[b]) { pop_blk[b] = 1; break; }  // only the lowest flagged block is trustworthy
             redo_units += (uint32_t)list.size();
-            HIPCHK(c, hipMemcpyAsync(c->popmask.p, popmask.data(), (size_t)n_units * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(c->pop_blk.p, pop_blk.data(), nb, hipMemcpyHostToDevice, st));
             HIPCHK(c, hipMemcpyAsync(c->unit_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, st));
             HIPCHK(c, hipMemsetAsync(c->redo.p, 0, (size_t)n_units * 4, st));
-            mp.popmask = (const uint32_t*)c->popmask.p;
+            HIPCHK(c, hipMemsetAsync(c->redo_blk.p, 0, (size_t)nb + 1, st));
+            mp.pop_blk = (const uint8_t*)c->pop_blk.p;
             mp.unit_list = (const uint32_t*)c->unit_list.p;
             ep.unit_list = mp.unit_list;
             if ((s = launch_match(c, mp, unit_off, n_units, (uint32_t)list.size(), bs, st, o->level)) != KC_OK) return s;
             kc_launch_zstd_entropy(ep, (uint32_t)list.size(), st);
             HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(st));  // pop_blk / list are host vectors: the copies above must have been taken before the next pass rewrites them
         }
     }
     HIPCHK(c, hipEventRecord(c->ev[4], st));
@@ -812,8 +827,8 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
     HIPCHK(c, hipSetDevice(c->device));
     for (uint32_t i = 0; i < n_units; i++) {
         if (unit_off[i + 1] < unit_off[i]) { c->err = "unit_off not ascending"; return KC_ERR_BAD_ARG; }
-        if (unit_off[i + 1] - unit_off[i] > (uint64_t)32 * (uint64_t)o->block_size) {
-            c->err = "unit larger than 32 blocks: not served by the device path";
+        if (unit_off[i + 1] - unit_off[i] > KC_MAX_UNIT_BYTES) {
+            c->err = "unit larger than 1 GiB: not served by the device path";
             return KC_ERR_UNSUPPORTED;
         }
     }
@@ -859,8 +874,8 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
 static kc_status validate_units(kc_ctx* c, const kc_zstd_opts* o, const uint64_t* unit_off, uint32_t n_units) {
     for (uint32_t i = 0; i < n_units; i++) {
         if (unit_off[i + 1] < unit_off[i]) { c->err = "unit_off not ascending"; return KC_ERR_BAD_ARG; }
-        if (unit_off[i + 1] - unit_off[i] > (uint64_t)32 * (uint64_t)o->block_size) {
-            c->err = "unit larger than 32 blocks: not served by the device path";
+        if (unit_off[i + 1] - unit_off[i] > KC_MAX_UNIT_BYTES) {
+            c->err = "unit larger than 1 GiB: not served by the device path";
             return KC_ERR_UNSUPPORTED;
         }
     }

@@ -15,7 +15,7 @@ struct KcMatchParams {
     KcBlkMeta* meta;            // device: one record per block
     const uint32_t* blk_start;  // device or null: per block, its start inside the unit (streams with Flush points: irregular blocks)
     const uint32_t* unit_flags; // device, with blk_start: bit 0 stream frame (a block was written before Close), bit 1 Close found nothing buffered
-    const uint32_t* popmask;    // device or null: per-unit bitmask of blocks whose offsets must be popped (re-run)
+    const uint8_t* pop_blk;     // device or null: per block (global index), 1 = its offsets must be popped (re-run)
     const uint32_t* unit_list;  // device or null: indirection for re-runs
     uint32_t unit_base;         // first unit of this launch when unit_list is null (chunked launches)
     uint32_t seq_stride;
@@ -52,7 +52,8 @@ struct KcEntropyParams {
     const uint64_t* stage_off;  // device: n_units+1 offsets into stage (16-byte aligned)
     uint32_t* out_size;     // device: encoded size per unit
     const uint64_t* xxh;    // device: XXH64 per unit (only read when crc != 0)
-    uint32_t* redo_mask;    // device: per unit, blocks whose late raw fallback invalidated carried offsets
+    uint32_t* redo_mask;    // device: per unit, non-zero when a block's late raw fallback invalidated carried offsets
+    uint8_t* redo_blk;      // device: per block (global index), 1 = that block
     const uint32_t* blk_start;  // as in KcMatchParams
     const uint32_t* unit_flags;
     const uint32_t* unit_list;

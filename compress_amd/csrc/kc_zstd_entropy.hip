@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 put_block_header(bout, last, 0u, (uint32_t)size);
                 S.huf.reuse = 2;  // litEnc.Reuse = ReusePolicyNone
                 if (!last) {
-                    if (!(m.flags & KC_BF_FORCED) && (m.o1_out != m.o1_in || m.o2_out != m.o2_in)) atomicOr(&P.redo_mask[u], 1u << b);
+                    if (!(m.flags & KC_BF_FORCED) && (m.o1_out != m.o1_in || m.o2_out != m.o2_in)) { P.redo_blk[blk0 + (uint32_t)b] = 1; atomicOr(&P.redo_mask[u], 1u); }
                 }
             }
             wg_copy(bout + 3, org, size);

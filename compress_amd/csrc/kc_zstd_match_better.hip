@@ -62,7 +62,6 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
     const int bs = P.block_size;
     const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
     const int nblk = gact ? UB.nblk : 0;  // a group without a unit (the launch's tail) does nothing
-    const uint32_t pm = (gact && P.popmask) ? P.popmask[u] : 0u;
     const size_t tabBytes = ((size_t)8 << ZB_LONG_BITS) + ((size_t)4 << ZB_SHORT_BITS);
     ZbCtx C;
     C.base = base;
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
         const int saved = srcLen - nlit - (srcLen >> 6);
         uint32_t flags = 0;
         if (nseq > 0 && !rle && saved < 16) flags |= KC_BF_POP_A;
-        if ((pm >> b) & 1u) flags |= KC_BF_FORCED;
+        if (P.pop_blk != nullptr && P.pop_blk[blk0 + (uint32_t)b] != 0) flags |= KC_BF_FORCED;
         const int o1c = o1, o2c = o2;
         if (flags) { o1 = o1_in; o2 = o2_in; }
         flags |= rounds << 8;

@@ -41,7 +41,6 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
     const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
     const int nblk = gact ? UB.nblk : 0;  // a group without a unit (the launch's tail) does nothing
     const bool HIST = ulen > bs || hist0 > 0 || UB.streamU;
-    const uint32_t pm = (gact && P.popmask) ? P.popmask[u] : 0u;
     uint32_t* __restrict__ ltab = tables + (size_t)ui * ((1u << ZD_LONG_BITS) + (1u << ZD_SHORT_BITS));
     uint32_t* __restrict__ stab = ltab + (1u << ZD_LONG_BITS);
     const int PB = P.pos_bits;
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
         const int saved = srcLen - nlit - (srcLen >> 6);
         uint32_t flags = 0;
         if (nseq > 0 && !rle && saved < 16) flags |= KC_BF_POP_A;
-        if ((pm >> b) & 1u) flags |= KC_BF_FORCED;
+        if (P.pop_blk != nullptr && P.pop_blk[blk0 + (uint32_t)b] != 0) flags |= KC_BF_FORCED;
         const int o1c = o1, o2c = o2;
         if (flags) { o1 = o1_in; o2 = o2_in; }
         flags |= rounds << 8;

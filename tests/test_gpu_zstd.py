@@ -560,6 +560,41 @@ def test_host_chunk_fed_batch_equals_device_path(oracle, kclib, level, monkeypat
     enc.Close()
 
 
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_long_units_and_streams_bit_exact(oracle, kclib, level):
+    """Units and streams of more than 32 blocks (the re-run bookkeeping is per block, not a 32-bit mask per unit), longer than the
+    window (matches beyond it are refused exactly like the reference's, whose history buffer has slid by then), with a small
+    window and small blocks as well; EncodeAll, Write/Close and Write/Flush/Close against the oracle, and the device decoder reads
+    the frames back."""
+    torch = _torch()
+    from compress_amd import zstd
+    t = corpora.corpus("T", 80, 131072, first_unit=300).tobytes()
+    m = corpora.corpus("M", 48, 131072, first_unit=30).tobytes()
+    for opts, okw in (((), {}), ((zstd.WithWindowSize(1 << 16),), {"window_size": 1 << 16})):
+        enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level), *opts)
+        ref = oracle.ZstdOracle(level=level, **okw)
+        bs = enc.o.block_size
+        units = [t[:33 * bs], t[5:5 + 70 * bs + 123], m[:40 * bs + 1], (t[:3 * bs] + m[:2 * bs]) * 8]
+        ubuf, off = corpora.pack_units(units)
+        out, out_off = enc.EncodeUnits(ubuf, off)
+        for i, u in enumerate(units):
+            assert out[int(out_off[i]):int(out_off[i + 1])].tobytes() == ref.encode_all(u), ("EncodeAll", i, len(u))
+        so, so_off = enc.EncodeStreams(ubuf, off)
+        for i, u in enumerate(units):
+            assert so[int(so_off[i]):int(so_off[i + 1])].tobytes() == ref.encode_stream(u), ("stream", i, len(u))
+        cuts = [[bs // 2, 20 * bs + 7], [], [40 * bs + 1], [k * bs * 3 + k for k in range(1, 12)]]
+        fo, fo_off = enc.EncodeStreams(ubuf, off, flush_at=cuts)
+        for i, u in enumerate(units):
+            assert fo[int(fo_off[i]):int(fo_off[i + 1])].tobytes() == ref.encode_stream(u, cuts[i]), ("flush", i, len(u))
+        # device verifier on the EncodeAll frames
+        d_enc = torch.from_numpy(np.ascontiguousarray(out)).cuda()
+        d_out = torch.zeros(len(ubuf) + 64, dtype=torch.uint8, device="cuda")
+        st = enc.DecodeUnitsDevice(d_enc.data_ptr(), out_off, d_out.data_ptr(), off)
+        assert not np.any(st), st
+        assert np.array_equal(d_out[:len(ubuf)].cpu().numpy(), ubuf)
+        enc.Close()
+
+
 def test_submit_wait_two_contexts_overlap(oracle, kclib, monkeypatch):
     """kc_zstd_encode_units_submit / kc_wait: two contexts alternate over six batches, each call running its chunk-fed host path on
     its own thread while the other context's call is in flight; the frames equal the synchronous call's, a second submit on a
