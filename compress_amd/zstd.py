@@ -112,7 +112,7 @@ def WithLowerEncoderMem(b):
 class Encoder:
     """zstd.Encoder: EncodeAll and its batched forms, plus the streaming surface Write / ReadFrom / Flush / Close / Reset
     (zstd/encoder.go:140-649).  A stream is buffered on the host and encoded on Close as ONE device unit whose bytes equal the
-    reference's for the same Write sequence; streams of more than 32 blocks, mid-stream Flush and dictionaries are not served
+    reference's for the same Write / Flush sequence; streams of more than 1 GiB and dictionaries are not served
     (the caller falls back to the reference).  EncodeStreams / EncodeStreamsDevice batch many streams per launch."""
 
     def __init__(self, *opts, device=0, stream=None, w=None):

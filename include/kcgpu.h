@@ -108,7 +108,9 @@ kc_status kc_device_info(const kc_ctx* ctx, int32_t* n_cu, int32_t* lds_per_cu, 
  * dst_cap:   must be >= sum_i kc_zstd_max_encoded_size(unit_i)
  * out_off:   n_units+1 offsets of the compacted frames (HOST memory in both variants)
  * The _dev variant leaves the frames in device memory (dst is a device pointer) and only
- * copies the n_units+1 offsets back; it synchronises the stream before returning. */
+ * copies the n_units+1 offsets back; it synchronises the stream before returning.
+ * A unit may have any number of blocks up to 1 GiB (beyond: KC_ERR_UNSUPPORTED); its blocks are parsed one after the other by
+ * one lane group, so the device pays with thousands of units in flight, not with a few long ones. */
 kc_status kc_zstd_encode_units(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off,
                                uint32_t n_units, uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
 kc_status kc_zstd_encode_units_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
@@ -116,7 +118,7 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uin
 /* N independent STREAMS: unit i's output equals NewWriter(w).Write(unit_i) ... Close() (zstd/encoder.go:154-428, 567-649;
  * no Flush in between — see kc_zstd_encode_streams_cuts): below one block that is the EncodeAll frame; from one block on, a frame without content size whose
  * blocks all see the history, with the `last` flag on a short final block or else a trailing empty raw block.  Same limits as
- * kc_zstd_encode_units_dev (a stream of more than 32 blocks is KC_ERR_UNSUPPORTED); dictionaries are KC_ERR_UNSUPPORTED. */
+ * kc_zstd_encode_units_dev (a stream of more than 1 GiB is KC_ERR_UNSUPPORTED); dictionaries are KC_ERR_UNSUPPORTED. */
 kc_status kc_zstd_encode_streams_dev(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
                                      uint32_t n_units, uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
 /* host-buffer form (src / dst in host memory), like kc_zstd_encode_units */

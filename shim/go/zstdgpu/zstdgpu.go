@@ -239,7 +239,7 @@ func (e *Encoder) EncodeUnits(src []byte, off []uint64, dst []byte) ([]byte, []u
 //
 // (zstd/encoder.go:140-253, 567-649).  The device encodes whole streams (kc_zstd_encode_streams: the bytes equal what the
 // reference writes for Write(everything) + Close()), so Write only buffers and Close submits.  Anything the device path does
-// not serve — a mid-stream Flush (it cuts a block early, encoder.go:547), streams longer than 32 blocks, dictionaries on the
+// not serve — a mid-stream Flush (the caller wants the bytes now, encoder.go:547), streams longer than 1 GiB, dictionaries on the
 // streaming path — is handed to a reference encoder with the same options; the bytes on w are the reference's either way.
 type Writer struct {
 	e      *Encoder
