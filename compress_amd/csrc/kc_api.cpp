@@ -489,6 +489,11 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     for (uint32_t i = 0; i < n_units; i++) maxLen = std::max<uint64_t>(maxLen, unit_off[i + 1] - unit_off[i]);
     int pos_bits = 1;
     while (((uint64_t)1 << pos_bits) <= (uint64_t)hist0 + maxLen + 2) pos_bits++;
+    // the packed sequences keep offset + 3 in 24 bits: fine for the default windows (4 / 8 MiB) and for any unit below 16 MiB
+    if (std::min<uint64_t>((uint64_t)o->window_size, (uint64_t)hist0 + maxLen) + 3 > 0xFFFFFFull) {
+        c->err = "window above 8 MiB with units above 16 MiB: offsets beyond the device path's 24-bit sequence field";
+        return KC_ERR_UNSUPPORTED;
+    }
     const uint8_t* k_src = d_src;               // what the match finder / entropy kernels read
     const uint64_t* k_off = (const uint64_t*)c->unit_off.p;
     if (useDict) {
