@@ -38,7 +38,7 @@ SYMBOLS = [
     "kc_zstd_opts_default", "kc_zstd_opts_level", "kc_zstd_opts_window", "kc_zstd_opts_crc", "kc_zstd_opts_zero_frames",
     "kc_zstd_opts_no_entropy", "kc_zstd_opts_all_lit_entropy", "kc_zstd_opts_single_segment", "kc_zstd_opts_dict_raw", "kc_zstd_opts_dict",
     "kc_zstd_max_encoded_size", "kc_ctx_create", "kc_ctx_destroy", "kc_last_error", "kc_device_info",
-    "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts", "kc_zstd_encode_units_submit", "kc_s2_encode_blocks_lvl_submit", "kc_wait", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
+    "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts", "kc_zstd_encode_units_submit", "kc_s2_encode_blocks_lvl_submit", "kc_wait", "kc_zstd_plan_stream_blocks", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
     "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats", "kc_s2_encode_blocks_lvl", "kc_s2_encode_blocks_lvl_dev", "kc_s2_encode_stream_lvl_dev",
     "kc_last_timings", "kc_corpus_fill",
 ]
@@ -96,6 +96,8 @@ def load():
     L.kc_zstd_encode_units_submit.restype = C.c_int
     L.kc_s2_encode_blocks_lvl_submit.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, vp, u64, vp]
     L.kc_s2_encode_blocks_lvl_submit.restype = C.c_int
+    L.kc_zstd_plan_stream_blocks.argtypes = [C.c_int32, u64, vp, u64, vp, u64, vp]
+    L.kc_zstd_plan_stream_blocks.restype = C.c_int64
     L.kc_wait.argtypes = [vp]
     L.kc_wait.restype = C.c_int
     for n in ("kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts"):

@@ -400,6 +400,30 @@ kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_
     return KC_OK;
 }
 
+// Blocks of one stream with Flush points (zstd/encoder.go): writeBlocks cuts a block every blockSize bytes after the last Flush
+// (:226-253); a Flush that finds nothing buffered does nothing (:552).  Close: a single block still buffered with no header
+// written yet is the EncodeAll frame (:272-288), otherwise the stream frame, with an empty last block when nothing is buffered
+// (:315-329).  Appends the block starts to *starts; *flags: bit 0 stream frame, bit 1 empty last block.  Returns the block count.
+uint32_t plan_stream_blocks(uint64_t bs, uint64_t len, const uint64_t* cuts, uint64_t n_cuts, std::vector<uint32_t>* starts, uint32_t* flags) {
+    uint64_t pos = 0, ci = 0, lastStart = 0;
+    uint32_t ub = 0;
+    while (pos < len) {
+        uint64_t e = pos + bs;
+        while (ci < n_cuts && cuts[ci] <= pos) ci++;
+        if (ci < n_cuts && cuts[ci] < e) e = cuts[ci];
+        if (e > len) e = len;
+        if (starts) starts->push_back((uint32_t)pos);
+        lastStart = pos;
+        pos = e;
+        ub++;
+    }
+    const bool flushedAtEnd = n_cuts > 0 && cuts[n_cuts - 1] >= len;
+    const bool tailBuffered = ub > 0 && !flushedAtEnd && (len - lastStart) < bs;
+    const bool streamU = len > 0 && !(ub == 1 && tailBuffered);
+    *flags = (streamU ? 1u : 0u) | ((streamU && !tailBuffered) ? 2u : 0u);
+    return ub;
+}
+
 kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base, const uint64_t* unit_off, uint32_t n_units,
                       uint8_t* d_dst, uint64_t dst_cap, ChunkFeed* feed = nullptr) {
     hipStream_t st = c->stream;
@@ -422,26 +446,11 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
         pl.rel_off[i] = unit_off[i] - unit_off[0];
         uint32_t ub = (uint32_t)((len + bs - 1) / bs);
         if (irregular) {
-            // writeBlocks cuts a block every blockSize bytes after the last Flush; a Flush that finds nothing buffered does nothing
-            // (encoder.go:552).  Close: a single block still buffered with no header written yet is the EncodeAll frame (:272-288).
             const uint64_t* cp = c->cuts + c->cut_off[c->cut_unit0 + i];
             const uint64_t nc = c->cut_off[c->cut_unit0 + i + 1] - c->cut_off[c->cut_unit0 + i];
-            uint64_t pos = 0, ci = 0, lastStart = 0;
-            ub = 0;
-            while (pos < len) {
-                uint64_t e = pos + (uint64_t)bs;
-                while (ci < nc && cp[ci] <= pos) ci++;
-                if (ci < nc && cp[ci] < e) e = cp[ci];
-                if (e > len) e = len;
-                pl.blk_start.push_back((uint32_t)pos);
-                lastStart = pos;
-                pos = e;
-                ub++;
-            }
-            const bool flushedAtEnd = nc > 0 && cp[nc - 1] >= len;
-            const bool tailBuffered = ub > 0 && !flushedAtEnd && (len - lastStart) < (uint64_t)bs;
-            const bool streamU = len > 0 && !(ub == 1 && tailBuffered);
-            pl.unit_flags.push_back((streamU ? 1u : 0u) | ((streamU && !tailBuffered) ? 2u : 0u));
+            uint32_t fl = 0;
+            ub = plan_stream_blocks((uint64_t)bs, len, cp, nc, &pl.blk_start, &fl);
+            pl.unit_flags.push_back(fl);
         }
         nb += ub;
         // every block costs a 3-byte header: Flush points add blocks that MaxEncodedSize(len) does not count
@@ -1413,6 +1422,16 @@ static kc_status check_cuts(kc_ctx* c, const uint64_t* unit_off, uint32_t n_unit
     }
     (void)unit_off;
     return KC_OK;
+}
+
+// The block plan of one stream with Flush points, as the device path lays it out (host logic only; tests without a GPU).
+int64_t kc_zstd_plan_stream_blocks(int32_t block_size, uint64_t len, const uint64_t* cuts, uint64_t n_cuts, uint32_t* starts, uint64_t starts_cap,
+                                   uint32_t* flags) {
+    if (block_size <= 0 || !flags || (n_cuts && !cuts)) return -1;
+    std::vector<uint32_t> st;
+    const uint32_t n = plan_stream_blocks((uint64_t)block_size, len, cuts, n_cuts, &st, flags);
+    if (starts) { if (st.size() > starts_cap) return -2; for (size_t i = 0; i < st.size(); i++) starts[i] = st[i]; }
+    return (int64_t)n;
 }
 
 kc_status kc_zstd_encode_streams_cuts_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off, uint32_t n_units,

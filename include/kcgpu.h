@@ -135,6 +135,11 @@ kc_status kc_zstd_encode_streams_cuts_dev(kc_ctx* ctx, const kc_zstd_opts* o, co
 kc_status kc_zstd_encode_streams_cuts(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off,
                                       uint32_t n_units, const uint64_t* cut_off, const uint64_t* cuts, uint8_t* dst,
                                       uint64_t dst_cap, uint64_t* out_off);
+/* Host logic only: the block plan of one stream with Flush points as kc_zstd_encode_streams_cuts lays it out — block starts
+ * (starts may be NULL), *flags bit 0 = stream frame (a block was written before Close), bit 1 = Close found nothing buffered
+ * (empty last block).  Returns the number of blocks, -1 bad argument, -2 starts_cap too small. */
+int64_t kc_zstd_plan_stream_blocks(int32_t block_size, uint64_t len, const uint64_t* cuts, uint64_t n_cuts, uint32_t* starts,
+                                   uint64_t starts_cap, uint32_t* flags);
 /* Asynchronous form of the host-buffer entry points (SURVEY §8(b) "async submit/wait"): submit returns at once and the call runs
  * on a thread of its own; kc_wait blocks until it is done and returns ITS status (kc_last_error for the text).  One job per
  * context.  Inside one call the source staging, the kernels and the drain of the frames already overlap chunk by chunk; with

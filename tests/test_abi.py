@@ -217,3 +217,53 @@ def test_dictionary_loader_differential_fuzz(oracle):
             assert list(o.dict_huf_val) == ref["val"] and list(o.dict_huf_nbits) == ref["nbits"], it
             assert list(o.dict_offsets) == ref["offsets"] and o.dict_len == len(bb) - ref["content_off"], it
     assert 100 < accepted < 2400
+
+
+def test_stream_block_plan_matches_the_oracle_frames():
+    """Host logic of kc_zstd_encode_streams_cuts without a GPU: kc_zstd_plan_stream_blocks (the function batch_begin lays the
+    blocks out with) against the block structure of the oracle's Write / Flush / Close frames — block count and decoded sizes,
+    stream frame vs EncodeAll frame, the empty last block."""
+    import ctypes as C
+    import random
+    import numpy as np
+    import corpora
+    import oracle_lib as oracle
+    from compress_amd import _lib
+    L = _lib.load()
+    e = oracle.ZstdOracle(level=2)
+    bs = e.opts.block_size
+    data = corpora.corpus("H", 5, 131072).tobytes()   # incompressible: every block is stored raw, so the frame shows the block sizes
+    rnd = random.Random(5)
+    cases = [(1000, [10, 500]), (1000, [1000]), (1000, [0]), (1000, []), (bs, []), (bs, [bs]), (2 * bs, [bs]), (bs + 100, [50, bs + 100]),
+             (3 * bs + 1, [7, 7, 2 * bs + 7, 3 * bs + 9]), (0, []), (0, [0]), (5, [1, 2, 3, 4, 5])]
+    for _ in range(60):
+        n = rnd.choice([rnd.randrange(1, 3000), rnd.randrange(bs - 100, bs + 100), rnd.randrange(2 * bs, 5 * bs)])
+        cases.append((n, sorted(rnd.randrange(0, n + 2) for _ in range(rnd.choice([0, 1, 2, 5])))))
+    for n, cuts in cases:
+        c = np.array(cuts + [0], dtype=np.uint64)
+        starts = np.zeros(64, dtype=np.uint32)
+        flags = C.c_uint32()
+        nb = L.kc_zstd_plan_stream_blocks(bs, n, c.ctypes.data, len(cuts), starts.ctypes.data, len(starts), C.byref(flags))
+        assert nb >= 0
+        fr = e.encode_stream(data[:n], cuts)
+        stream = bool(flags.value & 1)
+        if n == 0:
+            assert nb == 0 and not stream
+            continue
+        if not stream:
+            assert nb == 1 and fr == e.encode_all(data[:n]), (n, cuts)
+            continue
+        assert fr[4] == 0x04 and fr != e.encode_all(data[:n]), (n, cuts)
+        p, sizes = 6, []
+        while True:
+            bh = fr[p] | fr[p + 1] << 8 | fr[p + 2] << 16
+            typ, sz = (bh >> 1) & 3, bh >> 3
+            assert typ == 0, (n, cuts)
+            p += 3 + sz
+            sizes.append(sz)
+            if bh & 1:
+                break
+        want = [int(starts[i + 1]) - int(starts[i]) for i in range(nb - 1)] + [n - int(starts[nb - 1])]
+        if flags.value & 2:
+            want.append(0)
+        assert sizes == want, (n, cuts, sizes, want)
