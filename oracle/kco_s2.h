@@ -419,6 +419,215 @@ static inline int64_t EncodeSnappyBetter(uint8_t* dst, uint64_t cap, const uint8
     return d;
 }
 
+// ---- s2.EncodeBest (s2/encode_best.go:22-455 encodeBlockBest with dict == nil; size estimates :718-797) ----
+// Restated for the next device level (§8(f)); no device kernel uses it yet.  prime8bytes hash (encode_better.go:37-43).
+static inline uint32_t hash8(uint64_t u, uint8_t h) { return (uint32_t)((u * 0xcf1bbcdcb7a56463ULL) >> ((64 - h) & 63)); }
+
+static inline int emitRepeatSize(int offset, int length) {  // :776-797
+    if (length <= 4 + 4 || (length < 8 + 4 && offset < 2048)) return 2;
+    if (length < (1 << 8) + 4 + 4) return 3;
+    if (length < (1 << 16) + (1 << 8) + 4) return 4;
+    const int maxRepeat = (1 << 24) - 1;
+    length -= (1 << 16) - 4;
+    int left = 0;
+    if (length > maxRepeat) left = length - maxRepeat + 4;
+    if (left > 0) return 5 + emitRepeatSize(offset, left);
+    return 5;
+}
+static inline int emitCopySize(int offset, int length) {  // :718-749
+    if (offset >= 65536) {
+        int i = 0;
+        if (length > 64) {
+            length -= 64;
+            if (length >= 4) return 5 + emitRepeatSize(offset, length);
+            i = 5;
+        }
+        if (length == 0) return i;
+        return i + 5;
+    }
+    if (length > 64) {
+        if (offset < 2048) return 2 + emitRepeatSize(offset, length - 8);
+        return 3 + emitRepeatSize(offset, length - 60);
+    }
+    if (length >= 12 || offset >= 2048) return 3;
+    return 2;
+}
+
+static int encodeBlockBest(uint8_t* dst, const uint8_t* src, size_t srcLen) {
+    const int lTableBits = 19, sTableBits = 16;  // bestLongTableBits / bestShortTableBits (hashtable_pool.go:16-20)
+    const int inputMarginBest = 8 + 2;
+    const int len = (int)srcLen;
+    const int sLimit = len - inputMarginBest;
+    if (len < minNonLiteralBlockSize) return 0;
+    std::vector<uint64_t> lTable((size_t)1 << lTableBits, 0), sTable((size_t)1 << sTableBits, 0);
+    const int dstLimit = len - 5;
+    int nextEmit = 0;
+    int s = 1;
+    int repeat = 1;
+    uint64_t cv = load64(src, s);
+    int d = 0;
+    auto getCur = [](uint64_t x) { return (int)(x & 0xffffffffULL); };
+    auto getPrev = [](uint64_t x) { return (int)(x >> 32); };
+    const int maxSkip = 64;
+    struct match { int offset = 0, s = 0, length = 0, score = 0; bool rep = false; };
+    for (;;) {
+        match best;
+        for (;;) {
+            int nextS = ((s - nextEmit) >> 8) + 1;
+            if (nextS > maxSkip) nextS = s + maxSkip; else nextS += s;
+            if (nextS > sLimit) goto emitRemainder;
+            {
+                const uint32_t hashL = hash8(cv, lTableBits);
+                const uint32_t hashS = hash4(cv, sTableBits);
+                const uint64_t candidateL = lTable[hashL];
+                const uint64_t candidateS = sTable[hashS];
+                auto score = [&](const match& m) {
+                    int sc = m.length - m.s;            // matches that start later are penalised: the bytes before go out as literals
+                    if (nextEmit == m.s) sc++;          // no literals to emit: one byte saved
+                    const int offset = m.s - m.offset;
+                    if (m.rep) return sc - emitRepeatSize(offset, m.length);
+                    return sc - emitCopySize(offset, m.length);
+                };
+                auto matchAt = [&](int offset, int s_, uint32_t first, bool rep) {
+                    match m;
+                    m.offset = offset;
+                    m.s = s_;
+                    if (best.length != 0 && best.s - best.offset == s_ - offset) return m;  // same offset: not retested
+                    if (load32(src, offset) != first) return m;
+                    m.length = 4 + offset;
+                    m.rep = rep;
+                    int sp = s_ + 4;
+                    while (sp < len) {
+                        if (len - sp < 8) {
+                            if (src[sp] == src[m.length]) { m.length++; sp++; continue; }
+                            break;
+                        }
+                        const uint64_t diff = load64(src, sp) ^ load64(src, m.length);
+                        if (diff != 0) { m.length += tz64(diff) >> 3; break; }
+                        sp += 8;
+                        m.length += 8;
+                    }
+                    m.length -= offset;
+                    m.score = score(m);
+                    if (m.score <= -m.s) m.length = 0;  // no savings: maybe a better one turns up
+                    return m;
+                };
+                auto bestOf = [](const match& a, const match& b) {
+                    if (b.length == 0) return a;
+                    if (a.length == 0) return b;
+                    const int as = a.score + b.s, bs = b.score + a.s;
+                    return as >= bs ? a : b;
+                };
+                if (s > 0) {
+                    best = bestOf(matchAt(getCur(candidateL), s, (uint32_t)cv, false), matchAt(getPrev(candidateL), s, (uint32_t)cv, false));
+                    best = bestOf(best, matchAt(getCur(candidateS), s, (uint32_t)cv, false));
+                    best = bestOf(best, matchAt(getPrev(candidateS), s, (uint32_t)cv, false));
+                }
+                if (repeat > 0) best = bestOf(best, matchAt(s - repeat + 1, s + 1, (uint32_t)(cv >> 8), true));
+                if (best.length > 0) {
+                    uint32_t hS = hash4(cv >> 8, sTableBits);
+                    uint64_t nextShort = sTable[hS];       // s+1
+                    int s1 = s + 1;
+                    uint64_t cv1 = load64(src, s1);
+                    uint32_t hL = hash8(cv1, lTableBits);
+                    uint64_t nextLong = lTable[hL];
+                    best = bestOf(best, matchAt(getCur(nextShort), s1, (uint32_t)cv1, false));
+                    best = bestOf(best, matchAt(getPrev(nextShort), s1, (uint32_t)cv1, false));
+                    best = bestOf(best, matchAt(getCur(nextLong), s1, (uint32_t)cv1, false));
+                    best = bestOf(best, matchAt(getPrev(nextLong), s1, (uint32_t)cv1, false));
+                    {   // s+2
+                        hS = hash4(cv1 >> 8, sTableBits);
+                        nextShort = sTable[hS];
+                        s1++;
+                        cv1 = load64(src, s1);
+                        hL = hash8(cv1, lTableBits);
+                        nextLong = lTable[hL];
+                        if (repeat > 0) best = bestOf(best, matchAt(s1 - repeat, s1, (uint32_t)cv1, true));  // repeat at +2
+                        best = bestOf(best, matchAt(getCur(nextShort), s1, (uint32_t)cv1, false));
+                        best = bestOf(best, matchAt(getPrev(nextShort), s1, (uint32_t)cv1, false));
+                        best = bestOf(best, matchAt(getCur(nextLong), s1, (uint32_t)cv1, false));
+                        best = bestOf(best, matchAt(getPrev(nextLong), s1, (uint32_t)cv1, false));
+                    }
+                    // a match at the end of the best match, shifted back over it (:313-345)
+                    const int skipBeginning = 2, skipEnd = 1;
+                    const int sAt = best.s + best.length - skipEnd;
+                    if (sAt < sLimit) {
+                        const int sBack = best.s + skipBeginning - skipEnd;
+                        const int backL = best.length - skipBeginning;
+                        const uint64_t cvb = load64(src, sBack);
+                        const uint64_t next = lTable[hash8(load64(src, sAt), lTableBits)];
+                        int checkAt = getCur(next) - backL;
+                        if (checkAt > 0) best = bestOf(best, matchAt(checkAt, sBack, (uint32_t)cvb, false));
+                        checkAt = getPrev(next) - backL;
+                        if (checkAt > 0) best = bestOf(best, matchAt(checkAt, sBack, (uint32_t)cvb, false));
+                    }
+                }
+                // update tables
+                lTable[hashL] = (uint64_t)(uint32_t)s | candidateL << 32;
+                sTable[hashS] = (uint64_t)(uint32_t)s | candidateS << 32;
+            }
+            if (best.length > 0) break;
+            cv = load64(src, nextS);
+            s = nextS;
+        }
+        // extend backwards (not for repeats)
+        s = best.s;
+        if (!best.rep) {
+            while (best.offset > 0 && s > nextEmit && src[best.offset - 1] == src[s - 1]) { best.offset--; best.length++; s--; }
+        }
+        if (d + (s - nextEmit) > dstLimit) return 0;
+        {
+            const int base = s;
+            const int offset = s - best.offset;
+            s += best.length;
+            if (offset > 65535 && s - base <= 5 && !best.rep) {  // equal or worse than the encoding
+                s = best.s + 1;
+                if (s >= sLimit) goto emitRemainder;
+                cv = load64(src, s);
+                continue;
+            }
+            d += emitLiteral(dst + d, src + nextEmit, (size_t)(base - nextEmit));
+            if (best.rep) {
+                if (nextEmit > 0) d += emitRepeat(dst + d, offset, best.length);
+                else d += emitCopy(dst + d, offset, best.length);  // the first match cannot be a repeat
+            } else {
+                d += emitCopy(dst + d, offset, best.length);
+            }
+            repeat = offset;
+            nextEmit = s;
+            if (s >= sLimit) goto emitRemainder;
+            if (d > dstLimit) return 0;
+            for (int i = best.s + 1; i < s; i++) {  // fill tables: every position of the match
+                const uint64_t cv0 = load64(src, i);
+                const uint32_t long0 = hash8(cv0, lTableBits), short0 = hash4(cv0, sTableBits);
+                lTable[long0] = (uint64_t)(uint32_t)i | lTable[long0] << 32;
+                sTable[short0] = (uint64_t)(uint32_t)i | sTable[short0] << 32;
+            }
+            cv = load64(src, s);
+        }
+    }
+emitRemainder:
+    if (nextEmit < len) {
+        if (d + len - nextEmit > dstLimit) return 0;
+        d += emitLiteral(dst + d, src + nextEmit, (size_t)(len - nextEmit));
+    }
+    return d;
+}
+
+// s2/encode.go:161 EncodeBest; returns bytes written or -1 / -2
+static inline int64_t EncodeBest(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n) {
+    int64_t m = MaxEncodedLen((int64_t)n);
+    if (m < 0) return -1;
+    if (cap < (uint64_t)m) return -2;
+    int d = putUvarint(dst, (uint64_t)n);
+    if (n == 0) return d;
+    if (n < (size_t)minNonLiteralBlockSize) { d += emitLiteral(dst + d, src, n); return d; }
+    int k = encodeBlockBest(dst + d, src, n);
+    if (k > 0) return d + k;
+    d += emitLiteral(dst + d, src, n);
+    return d;
+}
+
 // s2/encode.go:204 EncodeSnappy (s2/encode_go.go:27 encodeBlockSnappy); returns bytes written or -1 / -2
 static inline int64_t EncodeSnappy(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n) {
     int64_t m = MaxEncodedLen((int64_t)n);

@@ -459,6 +459,8 @@ def test_s2_encode_better_reference_regressions_roundtrip(oracle):
         if not d:
             continue
         assert oracle.s2_decode(oracle.s2_encode_better(d), len(d) + 8) == d, name
+        assert oracle.s2_decode(oracle.s2_encode_best(d), len(d) + 8) == d, name
+        assert _snappy_decode_strict(oracle.s2_encode_snappy_better(d)) == d, name
         n += 1
     assert n > 40
 
@@ -542,3 +544,22 @@ def test_s2_encode_snappy_better_is_snappy_and_not_larger(oracle):
     for u in corpora.edge_units():
         b = oracle.s2_encode_snappy_better(u)
         assert _snappy_decode_strict(b) == u
+
+
+def test_s2_encode_best_restatement_roundtrips_and_is_smallest(oracle):
+    """s2.EncodeBest restatement (encodeBlockBest, no dictionary; oracle only — groundwork for the next device level): every block
+    decodes back, stays within MaxEncodedLen, and on compressible corpora is not larger than s2.EncodeBetter's (it scores up to
+    thirteen candidates per position and indexes every byte of a match)."""
+    import corpora
+    for kind in "TJMH":
+        for n in (65536, 65537, 300000):
+            d = corpora.corpus(kind, 1, n).tobytes()
+            b = oracle.s2_encode_best(d)
+            assert oracle.s2_decode(b, n + 8) == d, (kind, n)
+            assert len(b) <= oracle.lib().kco_s2_max_encoded_len(n)
+            if kind in "TJ":
+                assert len(b) <= len(oracle.s2_encode_better(d)), (kind, n, len(b), len(oracle.s2_encode_better(d)))
+    for u in corpora.edge_units():
+        assert oracle.s2_decode(oracle.s2_encode_best(u), len(u) + 8) == u
+    for u in corpora.stress_units(seed=77, n=40):
+        assert oracle.s2_decode(oracle.s2_encode_best(u), len(u) + 8) == u
