@@ -200,6 +200,72 @@ func (e *Encoder) EncodeStreams(src []byte, off []uint64, dst []byte) ([]byte, [
 	return sink.Bytes(), outOff, nil
 }
 
+// EncodeStreamsCuts is EncodeStreams with Flush points: flushAt[i] lists, ascending, how many bytes of stream i had been written
+// when Flush was called (a Write followed by ReadFrom is such a point too).  The bytes equal what the reference writes for that
+// Write / Flush / Close sequence; they are all delivered when the call returns (kc_zstd_encode_streams_cuts).
+func (e *Encoder) EncodeStreamsCuts(src []byte, off []uint64, flushAt [][]uint64, dst []byte) ([]byte, []uint64, error) {
+	n := len(off) - 1
+	if len(flushAt) != n {
+		return nil, nil, errors.New("zstdgpu: one flush list per stream")
+	}
+	cutOff := make([]uint64, n+1)
+	cuts := make([]uint64, 0, 16)
+	need := 0
+	for i := 0; i < n; i++ {
+		cuts = append(cuts, flushAt[i]...)
+		cutOff[i+1] = uint64(len(cuts))
+		need += (e.MaxEncodedSize(int(off[i+1]-off[i])) + 3*len(flushAt[i]) + 3 + 15) &^ 15
+	}
+	cuts = append(cuts, 0) // never empty: &cuts[0] below
+	if cap(dst) < need+64 {
+		dst = make([]byte, need+64)
+	}
+	dst = dst[:cap(dst)]
+	outOff := make([]uint64, n+1)
+	if e.ctx != nil && n > 0 && len(src) > 0 {
+		st := C.kc_zstd_encode_streams_cuts(e.ctx, &e.opts,
+			(*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
+			(*C.uint64_t)(unsafe.Pointer(&cutOff[0])), (*C.uint64_t)(unsafe.Pointer(&cuts[0])),
+			(*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
+		if st == C.KC_OK {
+			return dst[:outOff[n]], outOff, nil
+		}
+		if st != C.KC_ERR_UNSUPPORTED && st != C.KC_ERR_NO_DEVICE {
+			return nil, nil, errors.New(C.GoString(C.kc_last_error(e.ctx)))
+		}
+	}
+	// reference path: a fresh stream per unit, Flush at the recorded positions
+	var sink bytes.Buffer
+	for i := 0; i < n; i++ {
+		outOff[i] = uint64(sink.Len())
+		e.cpu.Reset(&sink)
+		unit := src[off[i]:off[i+1]]
+		pos := uint64(0)
+		for _, c := range flushAt[i] {
+			if c > uint64(len(unit)) {
+				c = uint64(len(unit))
+			}
+			if c > pos {
+				if _, err := e.cpu.Write(unit[pos:c]); err != nil {
+					return nil, nil, err
+				}
+				pos = c
+			}
+			if err := e.cpu.Flush(); err != nil {
+				return nil, nil, err
+			}
+		}
+		if _, err := e.cpu.Write(unit[pos:]); err != nil {
+			return nil, nil, err
+		}
+		if err := e.cpu.Close(); err != nil {
+			return nil, nil, err
+		}
+	}
+	outOff[n] = uint64(sink.Len())
+	return sink.Bytes(), outOff, nil
+}
+
 // EncodeUnits encodes src[off[i]:off[i+1]] as independent frames, each identical to EncodeAll(unit, nil).
 func (e *Encoder) EncodeUnits(src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
 	n := len(off) - 1

@@ -136,6 +136,59 @@ func TestBitExactStreams(t *testing.T) {
 	}
 }
 
+// TestBitExactStreamsFlush: EncodeStreamsCuts == NewWriter(w); Write ...; Flush at the given positions; Close() per unit —
+// flushes inside the first block (the header is written early: no EncodeAll frame), on block boundaries (no-ops), at the very
+// end (empty last block), repeated, and streams of more than 32 blocks.
+func TestBitExactStreamsFlush(t *testing.T) {
+	data, err := kcgpu.CorpusFill('T', kcgpu.SeedT, 0, 80, 128<<10)
+	if err != nil {
+		t.Fatal(err)
+	}
+	for _, lvl := range levels {
+		gpu, err := New(0, WithEncoderLevel(lvl))
+		if err != nil {
+			t.Fatal(err)
+		}
+		ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(1))
+		bs := uint64(128 << 10)
+		if lvl == zstd.SpeedFastest {
+			bs = 64 << 10
+		}
+		lens := []uint64{1000, 1000, 1000, bs, 2 * bs, 2*bs + 9, 3 * bs, 4*bs + 1, 40*bs + 123} // 52 blocks + 3 KiB of the 80 x 128 KiB corpus
+		flushAt := [][]uint64{{10, 500}, {1000}, {0}, {bs}, {bs}, {bs - 1, bs, bs + 1}, {7, 7, 7, 2*bs + 7}, {3*bs + 50000, 4*bs + 1, 4*bs + 9}, {bs / 2, 20*bs + 7}}
+		off := []uint64{0}
+		for _, l := range lens {
+			off = append(off, off[len(off)-1]+l)
+		}
+		out, outOff, err := gpu.EncodeStreamsCuts(data[:off[len(off)-1]], off, flushAt, nil)
+		if err != nil {
+			t.Fatal(err)
+		}
+		for i := range lens {
+			var sink bytes.Buffer
+			ref.Reset(&sink)
+			unit := data[off[i]:off[i+1]]
+			pos := uint64(0)
+			for _, c := range flushAt[i] {
+				if c > uint64(len(unit)) {
+					c = uint64(len(unit))
+				}
+				if c > pos {
+					ref.Write(unit[pos:c])
+					pos = c
+				}
+				ref.Flush()
+			}
+			ref.Write(unit[pos:])
+			ref.Close()
+			if !bytes.Equal(out[outOff[i]:outOff[i+1]], sink.Bytes()) {
+				t.Fatalf("stream %d (len %d, flush at %v) level %v differs from the reference's Write/Flush/Close", i, lens[i], flushAt[i], lvl)
+			}
+		}
+		gpu.Close()
+	}
+}
+
 // TestWriterDropIn: zstdgpu.Writer writes what zstd.NewWriter(w).Write(p...)+Close() writes, for plain streams, for streams
 // written in pieces, and for streams with a mid-stream Flush (which continue on the reference encoder).
 func TestWriterDropIn(t *testing.T) {
