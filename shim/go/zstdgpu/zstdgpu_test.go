@@ -269,6 +269,33 @@ func TestWriteGolden(t *testing.T) {
 			}
 		}
 	}
+	// streams with Flush points: 10 streams of 300001 bytes, Flush after 70000, 70010 and 200000+i bytes
+	for _, lvl := range levels {
+		for _, kind := range []byte{'T', 'M'} {
+			data, err := kcgpu.CorpusFill(kind, kcgpu.Seed(kind), 0, 24, 128<<10)
+			if err != nil {
+				t.Fatal(err)
+			}
+			ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(1))
+			h := sha256.New()
+			for i := 0; i < 10; i++ {
+				var sink bytes.Buffer
+				ref.Reset(&sink)
+				u := data[i*300001 : (i+1)*300001]
+				ref.Write(u[:70000])
+				ref.Flush()
+				ref.Write(u[70000:70010])
+				ref.Flush()
+				ref.Write(u[70010 : 200000+i])
+				ref.Flush()
+				ref.Write(u[200000+i:])
+				ref.Close()
+				h.Write(sink.Bytes())
+			}
+			ref.Close()
+			lines[fmt.Sprintf("zstdstream.L%d.%c.10x300001.flush", int(lvl), kind)] = hex.EncodeToString(h.Sum(nil))
+		}
+	}
 	writeGolden(t, path, lines)
 }
 

@@ -32,11 +32,18 @@ def _lines():
 
 def _parse(name):
     p = name.split(".")
+    if p[0] == "zstdstream":  # zstdstream.L<level>.<kind>.<n>x<len>.flush: streams with Flush after 70000, 70010 and 200000+i bytes
+        n, usz = p[3].split("x")
+        return dict(codec="zstdstream", level=int(p[1][1:]), kind=p[2], n=int(n), unit=int(usz))
     if p[0] == "zstd":
         n, usz = p[3].split("x")
         return dict(codec="zstd", level=int(p[1][1:]), kind=p[2], n=int(n), unit=int(usz), rawdict=(len(p) > 4 and p[4] == "rawdict64k"))
     n, usz = p[2].split("x")
     return dict(codec="s2", kind=p[1], n=int(n), unit=int(usz), level={"s2": 0, "s2better": 1, "s2snappy": 2, "s2snappybetter": 3}[p[0]])
+
+
+def _flush_points(i):
+    return [70000, 70010, 200000 + i]
 
 
 def _dict():
@@ -48,6 +55,14 @@ def test_oracle_matches_reference_hashes(oracle):
     lines = _lines()
     for name, want in sorted(lines.items()):
         c = _parse(name)
+        if c["codec"] == "zstdstream":
+            data = corpora.corpus(c["kind"], 24, 131072).tobytes()
+            e = oracle.ZstdOracle(level=c["level"])
+            h = hashlib.sha256()
+            for i in range(c["n"]):
+                h.update(e.encode_stream(data[i * c["unit"]:(i + 1) * c["unit"]], _flush_points(i)))
+            assert h.hexdigest() == want, "oracle differs from the reference on " + name
+            continue
         buf = corpora.corpus(c["kind"], c["n"], c["unit"])
         off = np.arange(c["n"] + 1, dtype=np.uint64) * c["unit"]
         if c["codec"] == "zstd":
@@ -66,6 +81,14 @@ def test_gpu_matches_reference_hashes(kclib):
     lines = _lines()
     for name, want in sorted(lines.items()):
         c = _parse(name)
+        if c["codec"] == "zstdstream":
+            data = corpora.corpus(c["kind"], 24, 131072)[:c["n"] * c["unit"]]
+            off = np.arange(c["n"] + 1, dtype=np.uint64) * c["unit"]
+            enc = zstd.NewWriter(None, zstd.WithEncoderLevel(c["level"]))
+            out, _ = enc.EncodeStreams(data, off, flush_at=[_flush_points(i) for i in range(c["n"])])
+            enc.Close()
+            assert hashlib.sha256(out.tobytes()).hexdigest() == want, "HIP path differs from the reference on " + name
+            continue
         buf = corpora.corpus(c["kind"], c["n"], c["unit"])
         off = np.arange(c["n"] + 1, dtype=np.uint64) * c["unit"]
         if c["codec"] == "zstd":
