@@ -11,7 +11,9 @@
  *   kc_zstd_encode_units[_dev]  == N x (*Encoder).EncodeAll(unit, nil)   zstd/encoder.go:722-839
  *   kc_zstd_max_encoded_size    == (*Encoder).MaxEncodedSize             zstd/encoder.go:843-873
  *   kc_s2_encode_blocks[_dev]   == N x s2.Encode(nil, block)             s2/encode.go:29-56
- *   kc_s2_encode_blocks_lvl[_dev] at KC_S2_LEVEL_BETTER == N x s2.EncodeBetter(nil, block)   s2/encode.go:117-144
+ *   kc_zstd_encode_streams[_dev]      == N x NewWriter(w); Write(unit); Close()                zstd/encoder.go:154-428, 589-649
+ *   kc_zstd_encode_streams_cuts[_dev] == the same with Flush() at given byte counts             zstd/encoder.go:547-570
+ *   kc_s2_encode_blocks_lvl[_dev]     == N x s2.EncodeBetter / EncodeSnappy / EncodeSnappyBetter(nil, block)   s2/encode.go:117-276
  *   kc_s2_encode_block          == the s2.WriterCustomEncoder callback   s2/writer.go:1053-1064
  *   kc_s2_max_encoded_len       == s2.MaxEncodedLen                      s2/encode.go:389-418
  *   kc_s2_encode_stream_dev     == s2.Writer.EncodeBuffer framing        s2/writer.go:357-451
