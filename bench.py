@@ -97,6 +97,82 @@ def collect_pmc(argv, kernel_key):
     return res
 
 
+def dry_run(args, cfg, rank, world):
+    """The multi-rank control flow of main() without a GPU and without the encoder: every rank fabricates the frames of its
+    contiguous shard of units (sizes and bytes are a function of the global unit index and the step), gathers them to rank 0
+    with the same FrameGather / two-buffer overlap as the timed loop, and rank 0 checks every step's gathered stream against
+    what the single-rank order gives.  Timing: barrier, K steps, barrier, MAX over ranks."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from compress_amd.shard import FrameGather, shard_range
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_total = 64 * world + 5  # not a multiple of the world size: ragged shards
+    lo, hi = shard_range(n_total, rank, world)
+
+    def frame(u, step):  # fabricated frame of global unit u at a step
+        n = 1 + (u * 2654435761 + step * 40503) % 997
+        return np.full(n, (u + 7 * step) & 0xFF, dtype=np.uint8)
+
+    def shard_bytes(a, b, step):
+        return np.concatenate([frame(u, step) for u in range(a, b)]) if b > a else np.zeros(0, dtype=np.uint8)
+
+    bufs = [torch.empty(1000 * (hi - lo) + 16, dtype=torch.uint8) for _ in range(2)]
+    gather = FrameGather(rank, world) if world > 1 else None
+    verified = True
+
+    def check(step, res):
+        nonlocal verified
+        if rank != 0:
+            return
+        want = shard_bytes(0, n_total, step)
+        got = res[0].numpy() if res is not None else None
+        if got is None or not np.array_equal(got[:len(want)], want) or res[1][-1] != len(want):
+            verified = False
+
+    def run(k, step0):
+        pending, pstep = None, None
+        for i in range(k):
+            db = i % 2
+            mine = shard_bytes(lo, hi, step0 + i)
+            bufs[db][:len(mine)] = torch.from_numpy(mine)  # "encode": the buffer that the gather of step i-2 has released
+            if gather is not None:
+                if pending is not None:
+                    check(pstep, pending.wait())
+                pending, pstep = gather.start(bufs[db], len(mine)), step0 + i
+            elif rank == 0:
+                check(step0 + i, (bufs[db][:len(mine)], [0, len(mine)]))
+        if pending is not None:
+            check(pstep, pending.wait())
+
+    run(args.warmup, 0)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ok = torch.tensor([1 if verified else 0], dtype=torch.int64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        verified = bool(ok.item())
+    if rank == 0:
+        print(json.dumps({"metric": cfg["metric"] if "metric" in cfg else "dry run", "value": None, "unit": "MB/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "u8", "data": "fabricated frames", "dry_run": True, "backend": "gloo" if world > 1 else "none",
+                          "units_total": n_total, "shard_of_rank0": [lo, hi], "gather_verified": verified,
+                          "config": {"workload": "rank plumbing only: sharding, overlapped frame gather over two buffers, barrier + MAX timing"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if verified else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +197,10 @@ def main():
                          "compress_amd.shard.write_shard; the frames are concatenable in rank order)")
     ap.add_argument("--s2-level", type=int, default=0, choices=[0, 1, 2, 3],
                     help="C4 only: 0 s2.Encode (the BASELINE configuration), 1 s2.EncodeBetter, 2 s2.EncodeSnappy")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the rank plumbing of the N > 1 path on the gloo backend with fabricated frames — contiguous sharding, "
+                         "FrameGather overlapped with the next step over two buffers, barrier + all_reduce(MAX) timing, one JSON line from "
+                         "rank 0 (value null).  Run under torch.distributed.run like the real bench.")
     ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic in this run (two extra rocprofv3 passes of one step each)")
     ap.add_argument("--cpu-sample-units", type=int, default=0, help="units of the CPU-baseline / byte-compare sample (0: per configuration)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="override the CPU baseline thread count")
@@ -143,6 +223,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.dry_run:
+        return dry_run(args, cfg, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)

@@ -146,3 +146,29 @@ def test_sharded_encode_gather_equals_single_rank(tmp_path, oracle):
     for u in (0, n_units // 2, n_units - 1):
         frame = want[int(want_off[u]):int(want_off[u + 1])].tobytes()
         assert oracle.zstd_decode(frame, usz + 16) == host[u * usz:(u + 1) * usz].tobytes()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_bench_dry_run_rank_plumbing(world):
+    """bench.py --dry-run, launched exactly like the driver launches the real bench (torch.distributed.run, one process per
+    rank): ragged contiguous shards, FrameGather overlapped with the next step over two buffers, barrier + all_reduce(MAX)
+    timing, one JSON line from rank 0 with every step's gathered stream verified."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable]
+    if world > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    cmd += [os.path.join(root, "bench.py"), "--gpus", str(world), "--dry-run", "--steps", "5", "--warmup", "2"]
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines  # exactly one JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["dry_run"] is True and j["n_gpus"] == world and j["steps"] == 5 and j["warmup"] == 2
+    assert j["gather_verified"] is True and j["value"] is None and j["scaling"] == "weak"
+    assert j["units_total"] == 64 * world + 5 and j["shard_of_rank0"] == [0, (64 * world + 5) // world]
