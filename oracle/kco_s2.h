@@ -614,6 +614,164 @@ emitRemainder:
     return d;
 }
 
+static inline int emitCopyNoRepeatSize(int offset, int length) {  // s2/encode_best.go:757-771 (an estimate, like the two above)
+    if (offset >= 65536) return 5 + 5 * (length / 64);
+    if (length > 64) return 3 + 3 * (length / 60);
+    if (length >= 12 || offset >= 2048) return 3;
+    return 2;
+}
+
+// s2/encode_best.go:457-710 encodeBlockBestSnappy: the best parse with Snappy-compatible output.  Differences from encodeBlockBest
+// that are restated literally: candidates are scored with emitCopyNoRepeatSize, extension runs in whole 8-byte steps while
+// s <= sLimit (no byte tail), the repeat candidate is always tried (also at +2, from the s+1 state), the end-of-match probe uses
+// no skips, every match is extended backwards, the long-offset bail ignores repeats, copies go through emitCopyNoRepeat.
+static int encodeBlockBestSnappy(uint8_t* dst, const uint8_t* src, size_t srcLen) {
+    const int lTableBits = 19, sTableBits = 16;
+    const int len = (int)srcLen;
+    const int sLimit = len - (8 + 2);
+    if (len < minNonLiteralBlockSize) return 0;
+    std::vector<uint64_t> lTable((size_t)1 << lTableBits, 0), sTable((size_t)1 << sTableBits, 0);
+    const int dstLimit = len - 5;
+    int nextEmit = 0;
+    int s = 1;
+    uint64_t cv = load64(src, s);
+    int repeat = 1;
+    int d = 0;
+    auto getCur = [](uint64_t x) { return (int)(x & 0xffffffffULL); };
+    auto getPrev = [](uint64_t x) { return (int)(x >> 32); };
+    const int maxSkip = 64;
+    struct match { int offset = 0, s = 0, length = 0, score = 0; };
+    for (;;) {
+        match best;
+        for (;;) {
+            int nextS = ((s - nextEmit) >> 8) + 1;
+            if (nextS > maxSkip) nextS = s + maxSkip; else nextS += s;
+            if (nextS > sLimit) goto emitRemainder;
+            {
+                const uint32_t hashL = hash8(cv, lTableBits);
+                const uint32_t hashS = hash4(cv, sTableBits);
+                const uint64_t candidateL = lTable[hashL];
+                const uint64_t candidateS = sTable[hashS];
+                auto score = [&](const match& m) {
+                    int sc = m.length - m.s;
+                    if (nextEmit == m.s) sc++;
+                    return sc - emitCopyNoRepeatSize(m.s - m.offset, m.length);
+                };
+                auto matchAt = [&](int offset, int s_, uint32_t first) {
+                    match m;
+                    m.offset = offset;
+                    m.s = s_;
+                    if (best.length != 0 && best.s - best.offset == s_ - offset) return m;
+                    if (load32(src, offset) != first) return m;
+                    m.length = 4 + offset;
+                    int sp = s_ + 4;
+                    while (sp <= sLimit) {
+                        const uint64_t diff = load64(src, sp) ^ load64(src, m.length);
+                        if (diff != 0) { m.length += tz64(diff) >> 3; break; }
+                        sp += 8;
+                        m.length += 8;
+                    }
+                    m.length -= offset;
+                    m.score = score(m);
+                    if (m.score <= -m.s) m.length = 0;
+                    return m;
+                };
+                auto bestOf = [](const match& a, const match& b) {
+                    if (b.length == 0) return a;
+                    if (a.length == 0) return b;
+                    const int as = a.score + b.s, bs = b.score + a.s;
+                    return as >= bs ? a : b;
+                };
+                best = bestOf(matchAt(getCur(candidateL), s, (uint32_t)cv), matchAt(getPrev(candidateL), s, (uint32_t)cv));
+                best = bestOf(best, matchAt(getCur(candidateS), s, (uint32_t)cv));
+                best = bestOf(best, matchAt(getPrev(candidateS), s, (uint32_t)cv));
+                best = bestOf(best, matchAt(s - repeat + 1, s + 1, (uint32_t)(cv >> 8)));
+                if (best.length > 0) {
+                    uint64_t nextShort = sTable[hash4(cv >> 8, sTableBits)];  // s+1
+                    int s1 = s + 1;
+                    uint64_t cv1 = load64(src, s1);
+                    uint64_t nextLong = lTable[hash8(cv1, lTableBits)];
+                    best = bestOf(best, matchAt(getCur(nextShort), s1, (uint32_t)cv1));
+                    best = bestOf(best, matchAt(getPrev(nextShort), s1, (uint32_t)cv1));
+                    best = bestOf(best, matchAt(getCur(nextLong), s1, (uint32_t)cv1));
+                    best = bestOf(best, matchAt(getPrev(nextLong), s1, (uint32_t)cv1));
+                    best = bestOf(best, matchAt(s1 - repeat + 1, s1 + 1, (uint32_t)(cv1 >> 8)));  // repeat at +2
+                    nextShort = sTable[hash4(cv1 >> 8, sTableBits)];                              // s+2
+                    s1++;
+                    cv1 = load64(src, s1);
+                    nextLong = lTable[hash8(cv1, lTableBits)];
+                    best = bestOf(best, matchAt(getCur(nextShort), s1, (uint32_t)cv1));
+                    best = bestOf(best, matchAt(getPrev(nextShort), s1, (uint32_t)cv1));
+                    best = bestOf(best, matchAt(getCur(nextLong), s1, (uint32_t)cv1));
+                    best = bestOf(best, matchAt(getPrev(nextLong), s1, (uint32_t)cv1));
+                    const int sAt = best.s + best.length;  // a match at the end of the best match
+                    if (sAt < sLimit) {
+                        const int sBack = best.s, backL = best.length;
+                        const uint64_t cvb = load64(src, sBack);
+                        const uint64_t next = lTable[hash8(load64(src, sAt), lTableBits)];
+                        int checkAt = getCur(next) - backL;
+                        if (checkAt > 0) best = bestOf(best, matchAt(checkAt, sBack, (uint32_t)cvb));
+                        checkAt = getPrev(next) - backL;
+                        if (checkAt > 0) best = bestOf(best, matchAt(checkAt, sBack, (uint32_t)cvb));
+                    }
+                }
+                lTable[hashL] = (uint64_t)(uint32_t)s | candidateL << 32;
+                sTable[hashS] = (uint64_t)(uint32_t)s | candidateS << 32;
+            }
+            if (best.length > 0) break;
+            cv = load64(src, nextS);
+            s = nextS;
+        }
+        s = best.s;
+        while (best.offset > 0 && s > nextEmit && src[best.offset - 1] == src[s - 1]) { best.offset--; best.length++; s--; }
+        if (d + (s - nextEmit) > dstLimit) return 0;
+        {
+            const int base = s;
+            const int offset = s - best.offset;
+            s += best.length;
+            if (offset > 65535 && s - base <= 5) {
+                s = best.s + 1;
+                if (s >= sLimit) goto emitRemainder;
+                cv = load64(src, s);
+                continue;
+            }
+            d += emitLiteral(dst + d, src + nextEmit, (size_t)(base - nextEmit));
+            d += emitCopyNoRepeat(dst + d, offset, best.length);
+            repeat = offset;
+            nextEmit = s;
+            if (s >= sLimit) goto emitRemainder;
+            if (d > dstLimit) return 0;
+            for (int i = best.s + 1; i < s; i++) {
+                const uint64_t cv0 = load64(src, i);
+                const uint32_t long0 = hash8(cv0, lTableBits), short0 = hash4(cv0, sTableBits);
+                lTable[long0] = (uint64_t)(uint32_t)i | lTable[long0] << 32;
+                sTable[short0] = (uint64_t)(uint32_t)i | sTable[short0] << 32;
+            }
+            cv = load64(src, s);
+        }
+    }
+emitRemainder:
+    if (nextEmit < len) {
+        if (d + len - nextEmit > dstLimit) return 0;
+        d += emitLiteral(dst + d, src + nextEmit, (size_t)(len - nextEmit));
+    }
+    return d;
+}
+
+// s2/encode.go:292 EncodeSnappyBest; returns bytes written or -1 / -2
+static inline int64_t EncodeSnappyBest(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n) {
+    int64_t m = MaxEncodedLen((int64_t)n);
+    if (m < 0) return -1;
+    if (cap < (uint64_t)m) return -2;
+    int d = putUvarint(dst, (uint64_t)n);
+    if (n == 0) return d;
+    if (n < (size_t)minNonLiteralBlockSize) { d += emitLiteral(dst + d, src, n); return d; }
+    int k = encodeBlockBestSnappy(dst + d, src, n);
+    if (k > 0) return d + k;
+    d += emitLiteral(dst + d, src, n);
+    return d;
+}
+
 // s2/encode.go:161 EncodeBest; returns bytes written or -1 / -2
 static inline int64_t EncodeBest(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n) {
     int64_t m = MaxEncodedLen((int64_t)n);

@@ -82,7 +82,7 @@ def lib():
             f = getattr(L, name)
             f.restype = C.c_int64
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
-        for name in ("kco_s2_encode_better", "kco_s2_encode_snappy", "kco_s2_encode_snappy_better", "kco_s2_encode_best"):
+        for name in ("kco_s2_encode_better", "kco_s2_encode_snappy", "kco_s2_encode_snappy_better", "kco_s2_encode_best", "kco_s2_encode_snappy_best"):
             f = getattr(L, name)
             f.restype = C.c_int64
             f.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64]
@@ -258,6 +258,16 @@ def s2_encode_best(src: bytes) -> bytes:
     r = lib().kco_s2_encode_best(src, len(src), buf, cap)
     if r < 0:
         raise RuntimeError("s2 encode_best failed %d" % r)
+    return buf.raw[:r]
+
+
+def s2_encode_snappy_best(src: bytes) -> bytes:
+    """s2.EncodeSnappyBest(nil, src) (s2/encode.go:292): oracle only."""
+    cap = lib().kco_s2_max_encoded_len(len(src))
+    buf = C.create_string_buffer(max(cap, 1))
+    r = lib().kco_s2_encode_snappy_best(src, len(src), buf, cap)
+    if r < 0:
+        raise RuntimeError("s2 encode_snappy_best failed %d" % r)
     return buf.raw[:r]
 
 

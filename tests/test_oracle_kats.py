@@ -563,3 +563,20 @@ def test_s2_encode_best_restatement_roundtrips_and_is_smallest(oracle):
         assert oracle.s2_decode(oracle.s2_encode_best(u), len(u) + 8) == u
     for u in corpora.stress_units(seed=77, n=40):
         assert oracle.s2_decode(oracle.s2_encode_best(u), len(u) + 8) == u
+
+
+def test_s2_encode_snappy_best_restatement_is_snappy_and_roundtrips(oracle):
+    """s2.EncodeSnappyBest restatement (encodeBlockBestSnappy; oracle only): strict Snappy blocks that round-trip, not larger than
+    s2.EncodeSnappyBetter's on compressible corpora."""
+    import corpora
+    for kind in "TJMH":
+        for n in (65536, 65537, 300000):
+            d = corpora.corpus(kind, 1, n).tobytes()
+            b = oracle.s2_encode_snappy_best(d)
+            assert _snappy_decode_strict(b) == d, (kind, n)
+            assert oracle.s2_decode(b, n + 8) == d
+            assert len(b) <= oracle.lib().kco_s2_max_encoded_len(n)
+            if kind in "TJ":
+                assert len(b) <= len(oracle.s2_encode_snappy_better(d)), (kind, n, len(b), len(oracle.s2_encode_snappy_better(d)))
+    for u in corpora.edge_units() + corpora.stress_units(seed=78, n=40):
+        assert _snappy_decode_strict(oracle.s2_encode_snappy_best(u)) == u
