@@ -498,6 +498,9 @@ int64_t kco_s2_encode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap
 // encodeBlock only (no varint header); 0 == incompressible.  The WriterCustomEncoder contract.
 int64_t kco_s2_encode_better(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeBetter(dst, cap, src, (size_t)n); }
 int64_t kco_s2_encode_snappy(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeSnappy(dst, cap, src, (size_t)n); }
+// test diagnostics: number of late raw fallbacks (blockenc.go:811-817) on non-last blocks that changed the carried offsets since the
+// last reset — the situation the device path's speculation re-run handles
+uint64_t kco_debug_late_raw_pops(int reset) { const uint64_t v = kco::lateRawPops().load(); if (reset) kco::lateRawPops().store(0); return v; }
 int64_t kco_s2_encode_snappy_best(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeSnappyBest(dst, cap, src, (size_t)n); }
 int64_t kco_s2_encode_best(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeBest(dst, cap, src, (size_t)n); }
 int64_t kco_s2_encode_snappy_better(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::EncodeSnappyBetter(dst, cap, src, (size_t)n); }

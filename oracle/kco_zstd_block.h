@@ -2,6 +2,7 @@
 // Restates zstd/blockenc.go (blockEnc: headers, encodeLits, encodeRLE, encode, genCodes),
 // zstd/seqenc.go:21-42 (seqCoders.setPrev) and zstd/seqdec.go:13-21 (seq).
 #pragma once
+#include <atomic>
 #include "kco_common.h"
 #include "kco_huff0.h"
 #include "kco_zstd_fse.h"
@@ -82,6 +83,8 @@ struct SeqCoders {  // zstd/seqenc.go:9
         compareSwap(of, &ofEnc, &ofPrev);
     }
 };
+
+inline std::atomic<uint64_t>& lateRawPops() { static std::atomic<uint64_t> c{0}; return c; }
 
 struct BlockEnc {  // zstd/blockenc.go:17
     int size = 0;
@@ -437,6 +440,9 @@ struct BlockEnc {  // zstd/blockenc.go:17
 
         if ((int64_t)output.size() - 3 - (int64_t)bhOffset >= (int64_t)size) {
             encodeRawTo(bhOffset, org, orgLen);
+            // test diagnostics: a late raw fallback that really changes the carried offsets of a non-last block is what the device
+            // path's speculation re-run (kc_api.cpp batch_end) exists for; tests use the counter to know their inputs reach it
+            if (!last && memcmp(recentOffsets, prevRecentOffsets, sizeof(recentOffsets)) != 0) lateRawPops()++;
             popOffsets();
             litEnc->Reuse = huff0::ReusePolicyNone;
             return 0;
