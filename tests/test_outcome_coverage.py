@@ -65,3 +65,82 @@ def test_parity_inputs_reach_these_outcomes(oracle, level):
     #   nseq:>=32512   - needs < 4.04 bytes per sequence in a 128 KiB block; the shortest findable match is 5-6 bytes
     #   repcode:2, 3   - the encoders only ever test offset1 (and offset2 right after a match, which is coded as code 1 with ll == 0)
     assert cov["nseq:>=32512"] == 0
+
+
+def _s2_tags(enc: bytes, cov, prefix):
+    """Walk an S2 block (s2/decode_other.go:22-260) and count the tag shapes."""
+    p, shift = 0, 0
+    while True:  # uvarint length
+        b = enc[p]; p += 1
+        if not b & 0x80:
+            break
+    n = len(enc)
+    while p < n:
+        tag = enc[p]
+        kind = tag & 3
+        if kind == 0:
+            x = tag >> 2
+            if x < 60:
+                cov[prefix + "literal:1-byte header"] += 1; ln = x + 1; p += 1
+            elif x == 60:
+                cov[prefix + "literal:2-byte header"] += 1; ln = enc[p + 1] + 1; p += 2
+            elif x == 61:
+                cov[prefix + "literal:3-byte header"] += 1; ln = (enc[p + 1] | enc[p + 2] << 8) + 1; p += 3
+            elif x == 62:
+                cov[prefix + "literal:4-byte header"] += 1; ln = (enc[p + 1] | enc[p + 2] << 8 | enc[p + 3] << 16) + 1; p += 4
+            else:
+                cov[prefix + "literal:5-byte header"] += 1; ln = int.from_bytes(enc[p + 1:p + 5], "little") + 1; p += 5
+            p += ln
+        elif kind == 1:
+            off = ((tag & 0xe0) << 3) | enc[p + 1]
+            length = (tag >> 2) & 7
+            if off == 0:  # repeat
+                if length < 5:
+                    cov[prefix + "repeat:2 bytes"] += 1; p += 2
+                elif length == 5:
+                    cov[prefix + "repeat:3 bytes"] += 1; p += 3
+                elif length == 6:
+                    cov[prefix + "repeat:4 bytes"] += 1; p += 4
+                else:
+                    cov[prefix + "repeat:5 bytes"] += 1; p += 5
+            else:
+                cov[prefix + "copy1"] += 1; p += 2
+        elif kind == 2:
+            cov[prefix + "copy2"] += 1; p += 3
+        else:
+            cov[prefix + "copy4"] += 1; p += 5
+    assert p == n
+
+
+def test_s2_parity_inputs_reach_these_tags(oracle):
+    """The same for the S2 levels: tag shapes in the oracle's blocks of the inputs the S2 GPU parity tests use (64 KiB corpus blocks,
+    > 64 KiB blocks, edge units, stress mixes with periodic blocks)."""
+    import numpy as np
+    blocks = []
+    for kind in "JTMH":
+        b = corpora.corpus(kind, 16, 65536)
+        blocks += [b[i * 65536:(i + 1) * 65536].tobytes() for i in range(16)]
+        big = corpora.corpus(kind, 2, 1 << 20).tobytes()
+        blocks += [big[:65537], big[:700000], big[1 << 20:]]
+    blocks += [u for u in corpora.edge_units() if 0 < len(u) < 70000]
+    blocks += corpora.stress_units(seed=11, n=60)
+    rng = np.random.default_rng(100)
+    for _ in range(40):
+        per = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+        blocks.append((per * 20000)[:int(rng.integers(1, 140000))])
+    cov = collections.Counter()
+    for blk in blocks:
+        _s2_tags(oracle.s2_encode(blk), cov, "s2:")
+        _s2_tags(oracle.s2_encode_better(blk), cov, "better:")
+        _s2_tags(oracle.s2_encode_snappy(blk), cov, "snappy:")
+        _s2_tags(oracle.s2_encode_snappy_better(blk), cov, "snappybetter:")
+    for lvl in ("s2:", "better:"):
+        for k in ("literal:1-byte header", "literal:2-byte header", "literal:3-byte header", "copy1", "copy2", "copy4",
+                  "repeat:2 bytes", "repeat:3 bytes", "repeat:4 bytes"):
+            assert cov[lvl + k] > 0, (lvl + k, dict(cov))
+    for lvl in ("snappy:", "snappybetter:"):
+        for k in ("literal:1-byte header", "literal:2-byte header", "literal:3-byte header", "copy1", "copy2", "copy4"):
+            assert cov[lvl + k] > 0, (lvl + k, dict(cov))
+        assert not any(cov[lvl + r] for r in ("repeat:2 bytes", "repeat:3 bytes", "repeat:4 bytes", "repeat:5 bytes"))  # Snappy has no repeats
+    # Not reached: 4/5-byte literal headers need a literal run of 64 KiB+ / 16 MiB+ inside a compressible block (a stored block is one
+    # 3- or 4-byte-header literal by itself); 5-byte repeats need a repeat longer than 65 KiB + 260.
