@@ -13,6 +13,25 @@ __device__ __forceinline__ uint64_t ld64(const uint8_t* p) { return ((const kc_u
 __device__ __forceinline__ void st64(uint8_t* p, uint64_t v) { ((kc_u64u*)p)->v = v; }  // unaligned 8-byte store
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return ((const kc_u32u*)p)->v; }
 __device__ __forceinline__ uint16_t ld16(const uint8_t* p) { return ((const kc_u16u*)p)->v; }
+struct __attribute__((packed)) kc_u128u { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 ld128u(const uint8_t* p) {  // unaligned 16-byte load
+    const kc_u128u v = *(const kc_u128u*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Lanes of one wave communicating through LDS: the hardware runs a wave's LDS instructions in program order, all lanes
+// of one instruction before the next, so no instruction is needed — only the compiler has to keep the order (and the
+// CPU emulator of the tests, tools/hipemu, which runs lanes out of lockstep, has to synchronise them here).
+#ifdef KC_HIPEMU
+#define KC_WAVE_SYNC() hipemu::wave_sync()
+#else
+#define KC_WAVE_SYNC()                                          \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+#endif
 
 // ---- wave primitives ----
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

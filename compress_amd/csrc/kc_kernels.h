@@ -93,6 +93,8 @@ struct KcS2Params {
     int32_t framed;             // 1: emit s2.Writer chunks (type | len24 | masked CRC32C | body), s2/writer.go:414-451
 };
 void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st);
+// LDS-table path (kc_s2_lds.hip): one wave per block, levels 0 and 2; any_small / any_big: the batch has blocks <= / > 64 KiB
+void kc_launch_s2_encode_lds(const KcS2Params& P, bool any_small, bool any_big, hipStream_t st);
 struct KcS2DecParams {
     const uint8_t* enc;         // encoded blocks (uvarint length + body each)
     const uint64_t* enc_off;    // device, n+1

@@ -1,0 +1,390 @@
+// kc_s2_lds.hip — S2 block encoder with LDS-resident tables: ONE WAVE PER BLOCK, the latency path.
+//
+// Same reference functions as kc_s2.hip (s2.Encode / s2.EncodeSnappy: encodeBlockGo / encodeBlockGo64K /
+// encodeBlockSnappyGo / ...64K, s2/encode_all.go:72-284, 287-500, 502-889; emit*: s2/encode_go.go:80-290) and the
+// same bytes.  kc_s2.hip keeps 8 blocks per wave in flight with their tables in HBM: it needs thousands of blocks to
+// cover the latency of its dependent table -> candidate chain and takes ~30 ms for one block.  Here the block's hash
+// table (2^14 x u32 = 64 KiB) AND, for blocks up to 64 KiB, the block itself live in the CU's LDS (128 KiB of its
+// 160 KiB), so a probe round is LDS-only: ~1 ms per 64 KiB block, whatever the number of blocks in flight.  The
+// dispatcher in kc_api.cpp picks the path by blocks in flight (measured crossover, profiles/r03_crossover_s2.csv).
+//
+// Execution scheme: the 64 lanes evaluate the next W probe steps of the reference's scan (positions follow
+// nextS = s + (s-nextEmit)>>skip + 4 exactly, each lane iterating the recurrence up to its own step) against the
+// pre-round table; ballot + ctz picks the first step that ends the scan the way the sequential encoder would; steps
+// up to it commit their table writes.  A step whose bucket is also touched by another step of the round is detected
+// through a marker byte: table entries are `position | marker << 24`; every lane stores its lane id into the marker
+// byte of its three buckets (ds_write_b8), then reads the entries back — a lane that does not find its own id in all
+// three shares a bucket with the lane whose id it finds, and tells it through a 64-bit mask in LDS (ds_or_b64, only in
+// rounds where some lane lost).  The round is cut at the lowest sharing lane other than lane 0 (the first step depends
+// on nothing), so no committed step ever saw a table that differs from the sequential encoder's.  No tags: candidates
+// are verified on the bytes, which sit in LDS.
+#include "kc_dev.h"
+#include "kc_kernels.h"
+#include "kc_s2_dev.h"
+
+#define S2L_SRC_MAX 65536
+#define S2L_POS_MASK 0xFFFFFFu
+
+// CRC32C of [0, len) read through rd32 / rdb, all 64 lanes cooperating: lane j takes bytes [j*C, (j+1)*C); the raw
+// (init 0) remainders are combined left to right, acc = advance(acc, C zero bytes) ^ part[j], with the 32 columns of
+// "advance by C zero bytes" computed by lanes 0..31.  The 0xFFFFFFFF initial value equals an XOR into the first word.
+template <class RD32, class RDB>
+__device__ __forceinline__ uint32_t s2_crc32c_wave(RD32 rd32, RDB rdb, int len, const uint32_t (*T)[256], uint32_t* colM, uint32_t* part, int lane) {
+    auto step4 = [&](uint32_t c) -> uint32_t { return T[3][c & 0xFF] ^ T[2][(c >> 8) & 0xFF] ^ T[1][(c >> 16) & 0xFF] ^ T[0][c >> 24]; };
+    if (len < 512) {  // short: every lane runs the plain loop (uniform)
+        uint32_t c = 0xFFFFFFFFu;
+        int i = 0;
+        for (; i + 4 <= len; i += 4) c = step4(c ^ rd32(i));
+        for (; i < len; i++) c = T[0][(c ^ rdb(i)) & 0xFF] ^ (c >> 8);
+        return c ^ 0xFFFFFFFFu;
+    }
+    const int C = ((len + 63) / 64 + 3) & ~3;
+    const int b = lane * C;
+    const int e = b + C < len ? b + C : len;
+    uint32_t c = 0;
+    if (b < len) {
+        int i = b;
+        for (; i + 4 <= e; i += 4) {
+            uint32_t w = rd32(i);
+            if (i == 0) w ^= 0xFFFFFFFFu;
+            c = step4(c ^ w);
+        }
+        for (; i < e; i++) c = T[0][(c ^ rdb(i)) & 0xFF] ^ (c >> 8);
+    }
+    if (lane < 32) {
+        uint32_t v = 1u << lane;
+        for (int i = 0; i < C; i += 4) v = step4(v);
+        colM[lane] = v;
+    }
+    part[lane] = c;
+    KC_WAVE_SYNC();
+    const int nfull = len / C;
+    uint32_t acc = 0;
+    for (int j = 0; j < nfull; j++) {
+        uint32_t a = 0;
+        for (int k = 0; k < 32; k++) if ((acc >> k) & 1u) a ^= colM[k];
+        acc = a ^ part[j];
+    }
+    const int r = len - nfull * C;
+    if (r > 0) {
+        int i = 0;
+        for (; i + 4 <= r; i += 4) acc = step4(acc);
+        for (; i < r; i++) acc = T[0][acc & 0xFF] ^ (acc >> 8);
+        acc ^= part[nfull];
+    }
+    KC_WAVE_SYNC();
+    return acc ^ 0xFFFFFFFFu;
+}
+
+template <int LEVEL, bool SRCLDS>  // LEVEL 0: s2.Encode, 2: s2.EncodeSnappy; SRCLDS: block <= 64 KiB, held in LDS
+__global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
+    constexpr bool SNAPPY = LEVEL == 2;
+    __shared__ uint32_t tab[1 << S2_TABLE_BITS];
+    __shared__ __attribute__((aligned(16))) uint8_t lsrc[SRCLDS ? S2L_SRC_MAX + 32 : 16];
+    __shared__ uint32_t crcT[4][256];
+    __shared__ uint32_t crcM[32];
+    __shared__ uint32_t crcP[64];
+    __shared__ unsigned long long shareMask;  // lanes that share a table bucket with another lane of the round
+    const int lane = (int)threadIdx.x;
+    const uint32_t bi = blockIdx.x;
+    if (bi >= P.n_blocks) return;
+    const uint8_t* __restrict__ src = P.src + P.blk_off[bi];
+    const int len = (int)(P.blk_off[bi + 1] - P.blk_off[bi]);
+    if ((len <= S2L_SRC_MAX) != SRCLDS) return;  // the other instantiation's block
+    uint8_t* __restrict__ slot = P.stage + P.stage_off[bi];
+    uint8_t* __restrict__ out = slot + (P.framed ? 8 : 0);
+
+    if (P.framed) {
+        for (int i = lane; i < 256; i += 64) {
+            uint32_t c = (uint32_t)i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            crcT[0][i] = c;
+        }
+        KC_WAVE_SYNC();
+        for (int i = lane; i < 256; i += 64) {
+            uint32_t c = crcT[0][i];
+            for (int t = 1; t < 4; t++) { c = crcT[0][c & 0xFF] ^ (c >> 8); crcT[t][i] = c; }
+        }
+    }
+    for (int i = lane * 4; i < (1 << S2_TABLE_BITS); i += 256) *(uint4*)&tab[i] = make_uint4(0, 0, 0, 0);
+    if (SRCLDS) {
+        const int body = len & ~15;
+        for (int o = lane * 16; o < body; o += 1024) *(uint4*)(lsrc + o) = ld128u(src + o);
+        for (int o = body + lane; o < len; o += 64) lsrc[o] = src[o];
+        if (lane < 32) lsrc[len + lane] = 0;  // reads of whole dwords around the last bytes stay inside the array
+    }
+    KC_WAVE_SYNC();
+
+    // ---- source access: LDS (aligned dwords + byte alignment) or global ----
+    auto rd32 = [&](int pos) -> uint32_t {
+        if (SRCLDS) {
+            const uint32_t* r = (const uint32_t*)(lsrc + (pos & ~3));
+            return __builtin_amdgcn_alignbyte(r[1], r[0], (uint32_t)(pos & 3));
+        }
+        return ld32(src + pos);
+    };
+    auto rd64 = [&](int pos) -> uint64_t {
+        if (SRCLDS) {
+            const uint32_t* r = (const uint32_t*)(lsrc + (pos & ~3));
+            const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], sh = (uint32_t)(pos & 3);
+            return (uint64_t)__builtin_amdgcn_alignbyte(r1, r0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(r2, r1, sh) << 32);
+        }
+        return ld64(src + pos);
+    };
+    auto rdb = [&](int pos) -> uint32_t { return SRCLDS ? (uint32_t)lsrc[pos] : (uint32_t)src[pos]; };
+
+    // uvarint(len) header (encode.go:39)
+    int hdr = 0;
+    {
+        uint64_t x = (uint64_t)len;
+        while (x >= 0x80) { if (lane == 0) out[hdr] = (uint8_t)x | 0x80; hdr++; x >>= 7; }
+        if (lane == 0) out[hdr] = (uint8_t)x;
+        hdr++;
+    }
+    uint8_t* __restrict__ dst = out + hdr;
+    int d = 0;
+    bool stored = false;  // encodeBlock returned 0 -> emit everything as one literal
+    if (len == 0 && !P.framed) { if (lane == 0) P.out_size[bi] = (uint32_t)hdr; return; }
+    if (len < 32) stored = true;  // minNonLiteralBlockSize (also len == 0 in a framed stream)
+
+    // emitLiteral(dst[d:], src[from:from+n]) (encode_go.go:80): lane 0 the tag, all lanes the bytes
+    auto emit_lit = [&](int from, int n) -> int {
+        if (n == 0) return 0;
+        const uint32_t m = (uint32_t)(n - 1);
+        uint8_t* __restrict__ o = dst + d;
+        int i;
+        if (m < 60) { i = 1; if (lane == 0) o[0] = (uint8_t)(m << 2); }
+        else if (m < (1u << 8)) { i = 2; if (lane == 0) { o[0] = 60 << 2; o[1] = (uint8_t)m; } }
+        else if (m < (1u << 16)) { i = 3; if (lane == 0) { o[0] = 61 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); } }
+        else if (m < (1u << 24)) { i = 4; if (lane == 0) { o[0] = 62 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); o[3] = (uint8_t)(m >> 16); } }
+        else { i = 5; if (lane == 0) { o[0] = 63 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); o[3] = (uint8_t)(m >> 16); o[4] = (uint8_t)(m >> 24); } }
+        const int body = n & ~7;
+        for (int k = lane * 8; k < body; k += 512) st64(o + i + k, rd64(from + k));
+        for (int k = body + lane; k < n; k += 64) o[i + k] = (uint8_t)rdb(from + k);
+        return i + n;
+    };
+    // forward extension in whole 8-byte steps while a <= limit (encode_all.go:353-360, :435-442); returns the new a
+    auto extend = [&](int a, int b, int limit) -> int {
+        for (;;) {
+            const int pa = a + 8 * lane, pb = b + 8 * lane;
+            const bool inb = pa <= limit;
+            uint64_t diff = 0;
+            if (inb) diff = rd64(pa) ^ rd64(pb);
+            const uint64_t oob = ballot64(!inb);
+            const uint64_t dm = ballot64(inb && diff != 0);
+            const int firstOob = oob ? ctz64(oob) : 64;
+            if (dm) {
+                const int fl = ctz64(dm);  // necessarily < firstOob
+                const uint64_t dd = bcast64(diff, fl);
+                return a + 8 * fl + (ctz64(dd) >> 3);
+            }
+            if (firstOob < 64) return a + 8 * firstOob;
+            a += 512;
+            b += 512;
+        }
+    };
+    // number of k = 1..kmax with src[t-k] == src[s-k], consecutively (the backward extension loops)
+    auto backlen = [&](int sp, int tp, int kmax) -> int {
+        int cnt = 0;
+        while (cnt < kmax) {
+            const int k = cnt + lane + 1;
+            bool ne = true;
+            if (k <= kmax) ne = rdb(tp - k) != rdb(sp - k);
+            const uint64_t m = ballot64(ne);
+            const int c = m ? ctz64(m) : 64;
+            cnt += c;
+            if (c < 64) break;
+        }
+        return cnt < kmax ? cnt : kmax;
+    };
+    auto emit_copy_any = [&](int offset, int length, bool asRepeat) -> int {
+        if (SNAPPY) { if (lane == 0) s2_emit_copy_nr1(dst + d, offset, length); return s2_copy_nr_size(offset, length); }
+        if (asRepeat) { if (lane == 0) s2_emit_repeat1(dst + d, offset, length); return s2_repeat_size(offset, length); }
+        if (lane == 0) s2_emit_copy1(dst + d, offset, length);
+        return s2_copy_size(offset, length);
+    };
+
+    if (!stored) {
+        const int SKIP = len <= (64 << 10) ? 5 : 6;  // encodeBlockGo64K vs encodeBlockGo (encode_go.go:23-26)
+        const int sLimit = len - 8;
+        const int dstLimit = len - (len >> 5) - 5;
+        int nextEmit = 0, s = 1, repeat = 1;
+        bool fin = false;  // goto emitRemainder
+        const int W0 = P.spec_w0 < 1 ? 1 : (P.spec_w0 > 64 ? 64 : P.spec_w0);
+        int W = W0;
+        uint8_t* const tabB = (uint8_t*)tab;
+        while (!fin && !stored) {
+            // ---------------- probe positions of this round: lane i = the i-th step from s ----------------
+            int p = s;
+            for (int k = 0; k + 1 < W; k++) if (k < lane) p += ((p - nextEmit) >> SKIP) + 4;
+            const int nextS = p + ((p - nextEmit) >> SKIP) + 4;
+            const bool inW = lane < W;
+            const bool valid = inW && nextS <= sLimit;  // a prefix of the lanes: nextS grows with the lane
+            const bool term = inW && nextS > sLimit;    // this step would `goto emitRemainder`
+            uint64_t cv = 0;
+            uint32_t h0 = 0, h1 = 0, h2 = 0, e0 = 0, e1 = 0, e2 = 0;
+            if (valid) {
+                cv = rd64(p);
+                h0 = s2_hash6(cv); h1 = s2_hash6(cv >> 8); h2 = s2_hash6(cv >> 16);
+                tabB[4 * h0 + 3] = (uint8_t)lane;
+                tabB[4 * h1 + 3] = (uint8_t)lane;
+                tabB[4 * h2 + 3] = (uint8_t)lane;
+            }
+            KC_WAVE_SYNC();
+            if (valid) { e0 = tab[h0]; e1 = tab[h1]; e2 = tab[h2]; }
+            // a lane that finds another lane's id in one of its buckets shares that bucket with it; it also tells that lane
+            const uint32_t m0 = e0 >> 24, m1 = e1 >> 24, m2 = e2 >> 24;
+            const bool lost = valid && (m0 != (uint32_t)lane || m1 != (uint32_t)lane || m2 != (uint32_t)lane);
+            bool dep = lost;
+            if (ballot64(lost) != 0) {  // rare: two steps of the round in one bucket
+                if (lane == 0) shareMask = 0ull;
+                KC_WAVE_SYNC();
+                if (lost) {
+                    if (m0 != (uint32_t)lane) atomicOr(&shareMask, 1ull << m0);
+                    if (m1 != (uint32_t)lane) atomicOr(&shareMask, 1ull << m1);
+                    if (m2 != (uint32_t)lane) atomicOr(&shareMask, 1ull << m2);
+                }
+                KC_WAVE_SYNC();
+                dep = lost || ((shareMask >> lane) & 1ull) != 0;
+            }
+            if (lane == 0) dep = false;  // the first step has no earlier step to depend on: every round commits at least one step
+            int kind = 0, cand = 0;  // 1 repeat at s+1, 2 match at s, 3 match at s+1, 4 match at s+2
+            if (valid) {
+                // the s+2 bucket is read after the s / s+1 buckets were written (encode_all.go:401)
+                int c2 = (int)(e2 & S2L_POS_MASK);
+                if (h2 == h1) c2 = p + 1;
+                else if (h2 == h0) c2 = p;
+                const int c0 = (int)(e0 & S2L_POS_MASK), c1 = (int)(e1 & S2L_POS_MASK);
+                const uint32_t wr = rd32(p - repeat + 1);
+                const uint32_t w0 = rd32(c0), w1 = rd32(c1), w2 = rd32(c2);
+                if ((uint32_t)(cv >> 8) == wr) kind = 1;
+                else if ((uint32_t)cv == w0) { kind = 2; cand = c0; }
+                else if ((uint32_t)(cv >> 8) == w1) { kind = 3; cand = c1; }
+                else if ((uint32_t)(cv >> 16) == w2) { kind = 4; cand = c2; }
+            }
+            const uint64_t vm = ballot64(valid);
+            const uint64_t tm = ballot64(term);
+            const uint64_t depm = ballot64(dep);
+            const uint64_t hm = ballot64(kind != 0);
+            const int nvalid = __popcll(vm);
+            const int c = depm ? ctz64(depm) : 64;
+            const uint64_t hmc = c >= 64 ? hm : (hm & ((1ull << c) - 1ull));
+            const bool found = hmc != 0;
+            const int f = found ? ctz64(hmc) : 0;
+            const int commitUpTo = found ? f : ((c < nvalid ? c : nvalid) - 1);
+            if (valid && lane <= commitUpTo) {
+                const bool winner = found && lane == f;
+                tab[h0] = (uint32_t)p;
+                tab[h1] = (uint32_t)(p + 1);
+                // table[hash2] = s+2 is skipped when the step ends on the repeat or on the match at s
+                if (!(winner && (kind == 1 || kind == 2))) tab[h2] = (uint32_t)(p + 2);
+            }
+            KC_WAVE_SYNC();
+            if (!found) {
+                W = 2 * W < 64 ? 2 * W : 64;
+                if (c < nvalid) {
+                    s = (int)bcast32((uint32_t)p, c);  // the first dependent step restarts as lane 0
+                } else if (nvalid < 64 && ((tm >> nvalid) & 1ull)) {
+                    fin = true;                        // the step after the last committed one hits `nextS > sLimit`
+                } else {
+                    s = (int)bcast32((uint32_t)nextS, nvalid - 1);  // nvalid >= 1: lane 0 is valid or terminates
+                }
+                continue;
+            }
+            W = W0;
+            const int mkind = (int)bcast32((uint32_t)kind, f);
+            int candidate = (int)bcast32((uint32_t)cand, f);
+            const int ps = (int)bcast32((uint32_t)p, f);
+            if (mkind == 1) {
+                // ---------------- repeat at s+1 (encode_all.go:336-384) ----------------
+                int base = ps + 1;
+                {
+                    const int i0 = base - repeat;
+                    int kmax = base - nextEmit;
+                    if (i0 < kmax) kmax = i0;
+                    base -= backlen(base, i0, kmax);
+                }
+                if (d + (base - nextEmit) > dstLimit) { stored = true; continue; }
+                d += emit_lit(nextEmit, base - nextEmit);
+                s = extend(ps + 4 + 1, ps - repeat + 4 + 1, sLimit);
+                d += emit_copy_any(repeat, s - base, nextEmit > 0);
+                nextEmit = s;
+                if (s >= sLimit) fin = true;
+                continue;
+            }
+            // ---------------- regular match (encode_all.go:387-489) ----------------
+            s = ps + (mkind - 2);
+            {
+                int kmax = candidate;
+                if (s - nextEmit < kmax) kmax = s - nextEmit;
+                const int back = backlen(s, candidate, kmax);
+                candidate -= back;
+                s -= back;
+            }
+            if (d + (s - nextEmit) > dstLimit) { stored = true; continue; }
+            d += emit_lit(nextEmit, s - nextEmit);
+            for (;;) {
+                const int base = s;
+                repeat = base - candidate;
+                s = extend(s + 4, candidate + 4, len - 8);
+                d += emit_copy_any(repeat, s - base, false);
+                nextEmit = s;
+                if (s >= sLimit) { fin = true; break; }
+                if (d > dstLimit) { stored = true; break; }
+                // check for an immediate match, otherwise start the search at s+1 (:474-488)
+                const uint64_t x = rd64(s - 2);
+                const uint32_t m2Hash = s2_hash6(x), currHash = s2_hash6(x >> 16);
+                const uint32_t ec = tab[currHash];
+                KC_WAVE_SYNC();
+                if (lane == 0) { tab[m2Hash] = (uint32_t)(s - 2); tab[currHash] = (uint32_t)s; }
+                KC_WAVE_SYNC();
+                candidate = (int)(ec & S2L_POS_MASK);
+                if ((uint32_t)(x >> 16) != rd32(candidate)) { s++; break; }
+            }
+        }
+        if (!stored) {
+            // emitRemainder (:491-499)
+            if (nextEmit < len) {
+                if (d + len - nextEmit > dstLimit) stored = true;
+                else d += emit_lit(nextEmit, len - nextEmit);
+            }
+        }
+    }
+    if (!P.framed) {
+        if (stored) { d = 0; d = emit_lit(0, len); }  // encode.go:44-55: not compressible -> one literal
+        if (lane == 0) P.out_size[bi] = (uint32_t)(hdr + d);
+        return;
+    }
+    // ---- s2.Writer chunk (s2/writer.go:414-451) ----
+    uint32_t chunkLen;
+    uint8_t chunkType;
+    if (stored) {  // encodeBlock returned 0: uncompressed chunk, raw copy
+        const int body = len & ~7;
+        for (int k = lane * 8; k < body; k += 512) st64(out + k, rd64(k));
+        for (int k = body + lane; k < len; k += 64) out[k] = (uint8_t)rdb(k);
+        chunkType = 0x01;
+        chunkLen = 4u + (uint32_t)len;
+    } else {
+        chunkType = 0x00;
+        chunkLen = 4u + (uint32_t)hdr + (uint32_t)d;
+    }
+    const uint32_t cc = s2_crc32c_wave(rd32, rdb, len, crcT, crcM, crcP, lane);
+    if (lane == 0) {
+        const uint32_t checksum = ((cc >> 15) | (cc << 17)) + 0xa282ead8u;
+        slot[0] = chunkType;
+        slot[1] = (uint8_t)chunkLen; slot[2] = (uint8_t)(chunkLen >> 8); slot[3] = (uint8_t)(chunkLen >> 16);
+        slot[4] = (uint8_t)checksum; slot[5] = (uint8_t)(checksum >> 8); slot[6] = (uint8_t)(checksum >> 16); slot[7] = (uint8_t)(checksum >> 24);
+        P.out_size[bi] = 4u + chunkLen;
+    }
+}
+
+void kc_launch_s2_encode_lds(const KcS2Params& P, bool any_small, bool any_big, hipStream_t st) {
+    if (P.n_blocks == 0) return;
+    if (P.level == 2) {
+        if (any_small) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, true>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_big) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
+    } else {
+        if (any_small) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, true>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_big) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
+    }
+}

@@ -48,11 +48,6 @@
 #define KC_TAB_LD(p) (*(p))
 #define KC_TAB_ST(v, p) (*(p) = (v))
 
-struct __attribute__((packed)) kc_u128u { uint32_t x, y, z, w; };
-__device__ __forceinline__ uint4 ld128u(const uint8_t* p) {
-    const kc_u128u v = *(const kc_u128u*)p;
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
 
 // c = 16 bytes at [t-4, t+12), p0..p3 = the 16 bytes at [p'-4, p'+12):
 // fwd = equal bytes from t / p' on (0..12), back = equal bytes going down from t-1 / p'-1 (0..4).

@@ -1,0 +1,70 @@
+"""The LDS-table kernels (kc_s2_lds.hip, kc_zstd_match_lds.hip) run on the CPU wave emulator and compared with the oracle.
+
+No GPU needed: the .hip sources are compiled by g++ against tools/hipemu (see tests/emu_lib.py).  These tests pin the
+device ALGORITHM (speculative rounds, marker-byte conflict detection, ordered commit, emit paths) bit for bit; the
+`-m gpu` tests run the same sources on the device through the C ABI."""
+import os
+import zipfile
+
+import numpy as np
+import pytest
+
+import corpora
+import emu_lib
+import oracle_lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _s2_blocks():
+    blocks = [corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("T", 1, 65536).tobytes(),
+              corpora.corpus("H", 1, 65536).tobytes(), corpora.corpus("M", 1, 65536, first_unit=2).tobytes(),
+              corpora.corpus("M", 1, 65536, first_unit=3).tobytes(), corpora.corpus("J", 1, 40000, first_unit=9).tobytes()]
+    blocks += corpora.edge_units()
+    blocks += [u[:70000] for u in corpora.stress_units(seed=11, n=6)]
+    return blocks
+
+
+def _cmp(blocks, got, ref_fn):
+    bad = []
+    for i, b in enumerate(blocks):
+        ref = ref_fn(b)
+        if ref != got[i]:
+            k = next((j for j in range(min(len(ref), len(got[i]))) if ref[j] != got[i][j]), -1)
+            bad.append((i, len(b), len(ref), len(got[i]), k))
+    assert not bad, "blocks differing from the oracle (index, len, oracle bytes, emulated bytes, first differing byte): %r" % bad[:8]
+
+
+@pytest.mark.parametrize("w0", [1, 8, 64])
+def test_s2_lds_blocks_bit_exact(w0):
+    """s2.Encode through kc_s2_encode_lds_kernel<0, *>: blocks below and above 64 KiB (LDS / global source), every
+    speculation width (1 = the sequential scan itself, 64 = a whole wave of steps per round)."""
+    blocks = _s2_blocks()
+    _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=0, spec_w0=w0), oracle_lib.s2_encode)
+
+
+def test_s2_lds_snappy_bit_exact():
+    blocks = _s2_blocks()
+    _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=2), oracle_lib.s2_encode_snappy)
+
+
+def test_s2_lds_framed_chunks_bit_exact():
+    """Framed mode: chunk header + masked CRC32C (wave-parallel CRC with the advance-by-zeros combine) + body."""
+    blocks = [b for b in _s2_blocks() if len(b) > 0]
+    buf, off = corpora.pack_units(blocks)
+    ref, ro = oracle_lib.s2_encode_stream(buf, off, with_stream_id=False)
+    got = emu_lib.s2_encode_blocks(blocks, level=0, framed=True)
+    for i in range(len(blocks)):
+        r = ref[int(ro[i]):int(ro[i + 1])].tobytes()
+        assert r == got[i], "chunk %d (len %d): header %r vs %r" % (i, len(blocks[i]), r[:8], got[i][:8])
+
+
+def test_s2_lds_reference_regressions():
+    """The reference's own encoder regression inputs (s2/testdata/enc_regressions.zip, committed copy)."""
+    zp = os.path.join(HERE, "golden", "ref_inputs", "enc_regressions.zip")
+    if not os.path.exists(zp):
+        pytest.skip("no committed copy of enc_regressions.zip")
+    with zipfile.ZipFile(zp) as z:
+        blocks = [z.read(n) for n in z.namelist() if not n.endswith("/")]
+    blocks = [b for b in blocks if len(b) < (1 << 20)]
+    _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=0), oracle_lib.s2_encode)

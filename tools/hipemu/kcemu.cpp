@@ -1,0 +1,33 @@
+// kcemu — the LDS-table kernels of compress_amd/csrc compiled for the hipemu CPU emulator, behind a small C API for the
+// tests (tests/test_emu_lds.py).  TEST INFRASTRUCTURE: the product (libkcgpu.so) never contains or loads this.
+#include <hip/hip_runtime.h>
+#include "../../compress_amd/csrc/kc_s2_lds.hip"
+#ifdef KCEMU_WITH_ZFAST
+#include "../../compress_amd/csrc/kc_zstd_match_lds.hip"
+#endif
+
+extern "C" {
+
+// N blocks through kc_s2_encode_lds_kernel; stage slots as the host library lays them out (stage_off, 64-byte aligned)
+int kcemu_s2_encode(int level, int framed, int spec_w0, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* stage,
+                    const uint64_t* stage_off, uint32_t* out_size) {
+    KcS2Params P;
+    memset(&P, 0, sizeof(P));
+    P.src = src;
+    P.blk_off = blk_off;
+    P.stage_off = stage_off;
+    P.stage = stage;
+    P.out_size = out_size;
+    P.n_blocks = n;
+    P.level = level;
+    P.spec_w0 = spec_w0;
+    P.framed = framed;
+    bool small = false, big = false;
+    for (uint32_t i = 0; i < n; i++) ((blk_off[i + 1] - blk_off[i]) <= 65536 ? small : big) = true;
+    kc_launch_s2_encode_lds(P, small, big, nullptr);
+    return 0;
+}
+
+uint64_t kcemu_collectives() { return hipemu::collectives(); }
+
+}  // extern "C"
