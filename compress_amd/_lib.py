@@ -40,8 +40,15 @@ SYMBOLS = [
     "kc_zstd_max_encoded_size", "kc_ctx_create", "kc_ctx_destroy", "kc_last_error", "kc_device_info",
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts", "kc_zstd_encode_units_submit", "kc_s2_encode_blocks_lvl_submit", "kc_wait", "kc_zstd_plan_stream_blocks", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
     "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats", "kc_s2_encode_blocks_lvl", "kc_s2_encode_blocks_lvl_dev", "kc_s2_encode_stream_lvl_dev",
-    "kc_last_timings", "kc_corpus_fill",
+    "kc_last_timings", "kc_corpus_fill", "kc_ctx_set_option", "kc_ctx_get_option",
 ]
+
+# kc_option / KC_PATH_* (include/kcgpu.h)
+PATH_AUTO, PATH_HBM, PATH_LDS = 0, 1, 2
+OPT_MATCH_PATH, OPT_ZFAST_LDS_MAX_UNITS, OPT_S2_LDS_MAX_BLOCKS, OPT_SPEC_W0, OPT_SPEC_GROW, OPT_LDS_SPEC_W0 = 1, 2, 3, 4, 5, 6
+OPT_HOST_SERIAL, OPT_HOST_PIPE_MIB, OPT_HOST_OVERLAP_MIN_MIB, OPT_HOST_COPY_THREADS, OPT_HOST_TRACE, OPT_HOST_CHUNK_MIB = 7, 8, 9, 10, 11, 12
+OPT_K2_PROF, OPT_S2_HOOK_WAIT_US, OPT_S2_HOOK_BATCH, OPT_TEST_FEED_REDO, OPT_LAST_PATH = 13, 14, 15, 16, 100
+_PATHS = {"auto": PATH_AUTO, "hbm": PATH_HBM, "lds": PATH_LDS, None: PATH_AUTO}
 
 _lib = None
 
@@ -140,6 +147,10 @@ def load():
     L.kc_s2_hook_stats.restype = None
     L.kc_last_timings.argtypes = [vp, C.POINTER(Timings)]
     L.kc_last_timings.restype = C.c_int
+    L.kc_ctx_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    L.kc_ctx_set_option.restype = C.c_int
+    L.kc_ctx_get_option.argtypes = [vp, C.c_int]
+    L.kc_ctx_get_option.restype = C.c_int64
     L.kc_corpus_fill.argtypes = [C.c_int, u64, u64, C.c_uint32, C.c_uint32, vp, C.c_int]
     L.kc_corpus_fill.restype = C.c_int
     _lib = L
@@ -171,6 +182,20 @@ class Context:
     def check(self, st):
         if st != KC_OK:
             raise KcError(st, self.L.kc_last_error(self.h).decode(errors="replace"))
+
+    def set_option(self, key, value):
+        """kc_ctx_set_option (keys: OPT_* above)."""
+        self.check(self.L.kc_ctx_set_option(self.h, int(key), int(value)))
+
+    def get_option(self, key):
+        return int(self.L.kc_ctx_get_option(self.h, int(key)))
+
+    def set_path(self, path):
+        """'auto' | 'hbm' | 'lds': which kernel family serves SpeedFastest / s2.Encode batches (KC_OPT_MATCH_PATH)."""
+        self.set_option(OPT_MATCH_PATH, _PATHS[path] if not isinstance(path, int) else path)
+
+    def last_path(self):
+        return {PATH_HBM: "hbm", PATH_LDS: "lds"}.get(self.get_option(OPT_LAST_PATH), "none")
 
     def device_info(self):
         ncu, lds, clk = C.c_int32(), C.c_int32(), C.c_int32()

@@ -78,11 +78,28 @@ struct Plan {
     std::vector<uint64_t> stage64;    // S2: n+1 staging slot offsets (64-byte aligned)
     std::vector<uint64_t> rel_off;    // n+1 unit offsets relative to the batch base
     uint32_t seq_stride = 0, lit_stride = 0;
+    uint64_t max_unit_bytes = 0;      // longest unit of the batch
 };
 
 }  // namespace
 
+// Tunables of one context.  Initialised ONCE, in kc_ctx_create, from the KC_* environment variables listed in
+// include/kcgpu.h (kc_option); changed afterwards only through kc_ctx_set_option.  No entry point reads the environment.
+struct KcCfg {
+    int64_t match_path = KC_PATH_AUTO;
+    int64_t zfast_lds_max_units = 1024;   // auto: SpeedFastest batches up to this many units take the LDS-table kernel (profiles/r03_crossover_zfast.csv)
+    int64_t s2_lds_max_blocks = 1024;     // auto: s2.Encode / EncodeSnappy batches up to this many blocks (profiles/r03_crossover_s2.csv)
+    int64_t spec_w0 = -1, spec_grow = -1; // HBM-table kernels: speculation width after a match / growth policy; -1 = the per-level defaults
+    int64_t lds_spec_w0 = 16;             // LDS-table kernels: probe steps per round after a match (doubles on a miss up to 64)
+    int64_t host_serial = 0, host_pipe_mib = 0, host_overlap_min_mib = -1, host_copy_threads = 0, host_trace = 0;
+    std::vector<uint64_t> host_chunks;    // chunk-fed host path: chunk sizes in bytes (empty: a quarter of the batch each)
+    int64_t k2_prof = 0;
+    int64_t hook_wait_us = 0, hook_batch = 256;
+    int64_t test_feed_redo = 0;           // diagnostics: force the chunk-fed path's re-encode fallback
+};
+
 struct kc_ctx {
+    KcCfg cfg;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -109,6 +126,7 @@ struct kc_ctx {
     Plan plan;                       // layout arrays of the batch in flight (sources of asynchronous H2D copies)
     std::once_flag hook_once;        // kc_s2_encode_block: micro-batcher of concurrent callers (S2Hook), created on first use
     void* hook = nullptr;
+    int last_path = 0;               // KC_PATH_HBM / KC_PATH_LDS: what the last batch's match finder / S2 encoder ran on
 };
 
 namespace {
@@ -253,8 +271,80 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
     }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return KC_ERR_HIP; }
+    {   // the environment seeds the tunables once; kc_ctx_set_option is the interface
+        KcCfg& g = c->cfg;
+        auto envi = [](const char* k, int64_t& v) { if (const char* e = getenv(k)) v = atoll(e); };
+        envi("KC_MATCH_PATH", g.match_path);
+        envi("KC_ZFAST_LDS_MAX_UNITS", g.zfast_lds_max_units);
+        envi("KC_S2_LDS_MAX_BLOCKS", g.s2_lds_max_blocks);
+        envi("KC_SPEC_W0", g.spec_w0);
+        envi("KC_SPEC_GROW", g.spec_grow);
+        envi("KC_LDS_SPEC_W0", g.lds_spec_w0);
+        if (getenv("KC_HOST_SERIAL")) g.host_serial = 1;
+        envi("KC_HOST_PIPE_MIB", g.host_pipe_mib);
+        envi("KC_HOST_OVERLAP_MIN_MIB", g.host_overlap_min_mib);
+        envi("KC_HOST_COPY_THREADS", g.host_copy_threads);
+        if (getenv("KC_HOST_TRACE")) g.host_trace = 1;
+        if (getenv("KC_K2_PROF")) g.k2_prof = 1;
+        envi("KC_S2_HOOK_WAIT_US", g.hook_wait_us);
+        envi("KC_S2_HOOK_BATCH", g.hook_batch);
+        if (const char* e = getenv("KC_HOST_CHUNKS_MIB")) {
+            for (const char* q = e; *q;) { g.host_chunks.push_back((uint64_t)strtoull(q, (char**)&q, 10) << 20); if (*q == ',') q++; else if (*q) break; }
+            if (g.host_chunks.empty() || g.host_chunks[0] == 0) g.host_chunks = {(uint64_t)512 << 20};
+        }
+    }
     *out = c;
     return KC_OK;
+}
+
+kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
+    if (!c) return KC_ERR_BAD_ARG;
+    KcCfg& g = c->cfg;
+    switch (key) {
+        case KC_OPT_MATCH_PATH: if (v < KC_PATH_AUTO || v > KC_PATH_LDS) return KC_ERR_BAD_ARG; g.match_path = v; break;
+        case KC_OPT_ZFAST_LDS_MAX_UNITS: g.zfast_lds_max_units = v; break;
+        case KC_OPT_S2_LDS_MAX_BLOCKS: g.s2_lds_max_blocks = v; break;
+        case KC_OPT_SPEC_W0: g.spec_w0 = v; break;
+        case KC_OPT_SPEC_GROW: g.spec_grow = v; break;
+        case KC_OPT_LDS_SPEC_W0: g.lds_spec_w0 = v; break;
+        case KC_OPT_HOST_SERIAL: g.host_serial = v; break;
+        case KC_OPT_HOST_PIPE_MIB: g.host_pipe_mib = v; break;
+        case KC_OPT_HOST_OVERLAP_MIN_MIB: g.host_overlap_min_mib = v; break;
+        case KC_OPT_HOST_COPY_THREADS: g.host_copy_threads = v; break;
+        case KC_OPT_HOST_TRACE: g.host_trace = v; break;
+        case KC_OPT_HOST_CHUNK_MIB: g.host_chunks.clear(); if (v > 0) g.host_chunks.push_back((uint64_t)v << 20); break;
+        case KC_OPT_K2_PROF: g.k2_prof = v; break;
+        case KC_OPT_S2_HOOK_WAIT_US: g.hook_wait_us = v; break;
+        case KC_OPT_S2_HOOK_BATCH: g.hook_batch = v < 1 ? 1 : v; break;
+        case KC_OPT_TEST_FEED_REDO: g.test_feed_redo = v; break;
+        default: return KC_ERR_BAD_ARG;
+    }
+    return KC_OK;
+}
+
+int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
+    if (!c) return -1;
+    const KcCfg& g = c->cfg;
+    switch (key) {
+        case KC_OPT_MATCH_PATH: return g.match_path;
+        case KC_OPT_ZFAST_LDS_MAX_UNITS: return g.zfast_lds_max_units;
+        case KC_OPT_S2_LDS_MAX_BLOCKS: return g.s2_lds_max_blocks;
+        case KC_OPT_SPEC_W0: return g.spec_w0;
+        case KC_OPT_SPEC_GROW: return g.spec_grow;
+        case KC_OPT_LDS_SPEC_W0: return g.lds_spec_w0;
+        case KC_OPT_HOST_SERIAL: return g.host_serial;
+        case KC_OPT_HOST_PIPE_MIB: return g.host_pipe_mib;
+        case KC_OPT_HOST_OVERLAP_MIN_MIB: return g.host_overlap_min_mib;
+        case KC_OPT_HOST_COPY_THREADS: return g.host_copy_threads;
+        case KC_OPT_HOST_TRACE: return g.host_trace;
+        case KC_OPT_HOST_CHUNK_MIB: return g.host_chunks.empty() ? 0 : (int64_t)(g.host_chunks[0] >> 20);
+        case KC_OPT_K2_PROF: return g.k2_prof;
+        case KC_OPT_S2_HOOK_WAIT_US: return g.hook_wait_us;
+        case KC_OPT_S2_HOOK_BATCH: return g.hook_batch;
+        case KC_OPT_TEST_FEED_REDO: return g.test_feed_redo;
+        case KC_OPT_LAST_PATH: return c->last_path;
+        default: return -1;
+    }
 }
 
 void kc_ctx_destroy(kc_ctx* c) {
@@ -374,8 +464,25 @@ size_t match_table_bytes(int level) {
     return level == KC_SPEED_BETTER ? kc_zbetter_table_bytes() : (level == KC_SPEED_DEFAULT ? kc_zdfast_table_bytes() : kc_zfast_table_bytes());
 }
 
+// SpeedFastest: which kernel serves a launch of n_launch units.  The LDS-table kernel (one wave per unit, a few ms per unit
+// whatever the batch) wins while the units in flight cannot cover the HBM-table kernel's latency; the crossover is measured
+// (profiles/r03_crossover_zfast.csv) and set by KC_OPT_ZFAST_LDS_MAX_UNITS; KC_OPT_MATCH_PATH forces a path.  Units (with their
+// dictionary history) of 256 KiB and more only fit the HBM path's position field: the HBM kernel takes those, the LDS kernel the rest.
+bool zfast_use_lds(const kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, int level) {
+    (void)mp;
+    if (level != KC_SPEED_FASTEST) return false;
+    if (c->cfg.match_path == KC_PATH_HBM) return false;
+    if (c->cfg.match_path == KC_PATH_LDS) return true;
+    return (int64_t)n_launch <= c->cfg.zfast_lds_max_units;
+}
+// with the LDS path chosen: some unit of the batch does not fit its position field and goes through the HBM-table kernel
+bool zfast_lds_needs_hbm(const kc_ctx* c, const KcMatchParams& mp) {
+    return (uint64_t)mp.hist0 + c->plan.max_unit_bytes > KC_ZFAST_LDS_MAX_UNIT;
+}
+
 // per-unit tables of n_launch units: zeroed, or primed from the dictionary tables
 kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, hipStream_t st, int level) {
+    if (zfast_use_lds(c, mp, n_launch, level) && !zfast_lds_needs_hbm(c, mp)) return KC_OK;  // the tables live in LDS
     const size_t tb = match_table_bytes(level);
     kc_status s = ensure(c, c->tables, (size_t)n_launch * tb);
     if (s != KC_OK) return s;
@@ -385,7 +492,20 @@ kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, 
 }
 
 // the match finder over n_launch units whose tables start at table slot `slot0` (unit = mp.unit_base + i or mp.unit_list[i])
-void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uint32_t n_launch, hipStream_t st, int level) {
+void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uint32_t n_launch, hipStream_t st, int level, bool lds = false) {
+    if (lds) {
+        KcMatchParams ml = mp;
+        ml.spec_w0 = (int32_t)c->cfg.lds_spec_w0;
+        kc_launch_zfast_match_lds(ml, mp.hist0 > 0 ? (const uint32_t*)c->proto.p : nullptr, n_launch, st);
+        c->last_path = KC_PATH_LDS;
+        if (zfast_lds_needs_hbm(c, mp)) {  // the units beyond the LDS kernel's position field
+            ml = mp;
+            ml.lds_split = 1;
+            kc_launch_zfast_match_grp(ml, (uint32_t*)((uint8_t*)c->tables.p + (size_t)slot0 * match_table_bytes(level)), n_launch, st);
+        }
+        return;
+    }
+    c->last_path = KC_PATH_HBM;
     uint8_t* tab = (uint8_t*)c->tables.p + (size_t)slot0 * match_table_bytes(level);
     if (level == KC_SPEED_BETTER) kc_launch_zbetter_match_grp(mp, tab, n_launch, mp.hist0 > 0, st);
     else if (level == KC_SPEED_DEFAULT) kc_launch_zdfast_match_grp(mp, (uint32_t*)tab, n_launch, st);
@@ -396,7 +516,7 @@ kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_
     (void)unit_off; (void)n_units; (void)bs;
     kc_status s = prepare_tables(c, mp, n_launch, st, level);
     if (s != KC_OK) return s;
-    launch_match_kernel(c, mp, 0, n_launch, st, level);
+    launch_match_kernel(c, mp, 0, n_launch, st, level, zfast_use_lds(c, mp, n_launch, level));
     return KC_OK;
 }
 
@@ -496,6 +616,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     const int hist0 = useDict ? (int)o->dict_len : 0;
     uint64_t maxLen = 16;
     for (uint32_t i = 0; i < n_units; i++) maxLen = std::max<uint64_t>(maxLen, unit_off[i + 1] - unit_off[i]);
+    pl.max_unit_bytes = maxLen;
     int pos_bits = 1;
     while (((uint64_t)1 << pos_bits) <= (uint64_t)hist0 + maxLen + 2) pos_bits++;
     // the packed sequences keep offset + 3 in 24 bits: fine for the default windows (4 / 8 MiB) and for any unit below 16 MiB
@@ -553,9 +674,9 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     // 265.9 / 266.7 / 274.0, 2 then +1 264.1; at 2 GiB (latency bound) 163.6 / - / 155.4, fixed 1: 285.5.  The BASELINE size is 4 GiB.
     // SpeedBetterCompression (1 GiB = 8192 units: latency-bound, wide speculation pays): width 1 / 2 / 4 then doubling 98.6 / 91.5 / 86.0,
     // fixed 4: 101.4, fixed 8: 80.4 ms with 8 lanes per unit; 16 lanes per unit, fixed 16: 61.1 ms (one probe per round, round 1: 181 ms)
-    mp.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : (o->level == KC_SPEED_DEFAULT ? 2 : (o->level == KC_SPEED_BETTER ? 16 : 1));
+    mp.spec_w0 = c->cfg.spec_w0 >= 0 ? (int)c->cfg.spec_w0 : (o->level == KC_SPEED_DEFAULT ? 2 : (o->level == KC_SPEED_BETTER ? 16 : 1));
     // measured on C2 (ms per 4 GiB): width 1 then +1 per miss 137, fixed 2 136.5, 1 then doubling 140, fixed 1 167, fixed 4 157
-    mp.spec_grow = getenv("KC_SPEC_GROW") ? atoi(getenv("KC_SPEC_GROW")) : (o->level == KC_SPEED_FASTEST ? 1 : (o->level == KC_SPEED_BETTER ? 0 : 2));
+    mp.spec_grow = c->cfg.spec_grow >= 0 ? (int)c->cfg.spec_grow : (o->level == KC_SPEED_FASTEST ? 1 : (o->level == KC_SPEED_BETTER ? 0 : 2));
     if (mp.spec_w0 < 1) mp.spec_w0 = 1;
     if (mp.spec_w0 > 64) mp.spec_w0 = 64;  // the kernels clamp to their group size
 
@@ -606,7 +727,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     ep.dict_id = o->dict_id;
     ep.err_flag = (uint32_t*)c->errflag.p;
     ep.prof = nullptr;
-    const bool k2prof = getenv("KC_K2_PROF") != nullptr;
+    const bool k2prof = c->cfg.k2_prof != 0;
     if (k2prof) {
         if ((s = ensure(c, c->prof, 32 * 8)) != KC_OK) return s;
         HIPCHK(c, hipMemsetAsync(c->prof.p, 0, 32 * 8, st));
@@ -626,6 +747,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
         if (useDict) { c->err = "chunk feed does not take dictionaries"; return KC_ERR_INTERNAL; }
         HIPCHK(c, hipEventRecord(c->ev[1], st));
         if ((s = prepare_tables(c, mp, n_units, st, o->level)) != KC_OK) return s;
+        const bool feed_lds = zfast_use_lds(c, mp, n_units, o->level);
         HIPCHK(c, hipEventRecord(c->ev[6], st));  // everything the chunk kernels need from this stream (offset arrays, tables)
         const size_t nchunk = feed->cut.size() - 1;
         for (size_t k = 0; k < nchunk; k++) {
@@ -637,7 +759,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
             if (o->crc) kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p + u0, nk, (uint64_t*)c->xxh.p + u0, sk);
             KcMatchParams mk = mp;
             mk.unit_base = u0;
-            launch_match_kernel(c, mk, u0, nk, sk, o->level);
+            launch_match_kernel(c, mk, u0, nk, sk, o->level, feed_lds);
             KcEntropyParams ek = ep;
             ek.unit_base = u0;
             kc_launch_zstd_entropy(ek, nk, sk);
@@ -987,10 +1109,13 @@ int host_copy_threads() {
             }
             fclose(f);
         }
-        if (const char* e = getenv("KC_HOST_COPY_THREADS")) t = atoi(e);
         return t < 1 ? 1 : (t > 16 ? 16 : t);
     }();
     return n;
+}
+int host_copy_threads(const kc_ctx* c) {
+    const int64_t t = c->cfg.host_copy_threads;
+    return t >= 1 ? (int)(t > 16 ? 16 : t) : host_copy_threads();
 }
 
 void parallel_memcpy(uint8_t* dst, const uint8_t* src, size_t n, int threads) {
@@ -1057,7 +1182,7 @@ kc_status host_pipeline(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off,
     for (int i = 0; i < 2; i++)
         if ((s = ensure(c, hp->d_in[i], max_in + 64)) || (s = ensure(c, hp->d_out[i], max_need + 64))) return s;
 
-    const int T = host_copy_threads();
+    const int T = host_copy_threads(c);
     std::mutex m;
     std::condition_variable cv;
     size_t staged = 0, encoded = 0, drained = 0;  // sub-batches that passed each stage
@@ -1156,11 +1281,7 @@ kc_status host_chunk_fed(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off
     // SpeedFastest batch (ms, pageable source to pageable frames): 4 x 1 GiB 215, 512M/512M/1G/2G 226, 1G/1G/2G 229, 2 x 2 GiB 235,
     // 6 x 768 MiB 244 (two chunks queue behind others), 8 x 512 MiB 253; the plain sub-batch pipeline 305
     std::vector<uint64_t> sched = {std::max<uint64_t>((total + 3) / 4, (uint64_t)64 << 20)};
-    if (const char* e = getenv("KC_HOST_CHUNKS_MIB")) {
-        sched.clear();
-        for (const char* q = e; *q;) { sched.push_back((uint64_t)strtoull(q, (char**)&q, 10) << 20); if (*q == ',') q++; }
-        if (sched.empty() || sched[0] == 0) sched = {(uint64_t)512 << 20};
-    }
+    if (!c->cfg.host_chunks.empty()) sched = c->cfg.host_chunks;
     ChunkFeed feed;
     feed.cut.push_back(0);
     {
@@ -1217,8 +1338,8 @@ kc_status host_chunk_fed(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off
     }
     for (size_t k = 0; k < nchunk; k++) { feed.landed.push_back(hp->events[2 * k]); feed.done.push_back(hp->events[2 * k + 1]); }
     feed.streams = hp->kstreams;
-    const int T = host_copy_threads();
-    const bool trace = getenv("KC_HOST_TRACE") != nullptr;
+    const int T = host_copy_threads(c);
+    const bool trace = c->cfg.host_trace != 0;
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     std::mutex m;
@@ -1317,7 +1438,7 @@ kc_status host_chunk_fed(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off
     out_off[n_units] = running;
     bool redo = false;
     s = fin(&redo);  // synchronises the context's stream behind every chunk
-    if (getenv("KC_TEST_FEED_REDO")) redo = true;  // tests: exercise the fallback below
+    if (c->cfg.test_feed_redo) redo = true;  // diagnostics (KC_OPT_TEST_FEED_REDO): exercise the fallback below
     if (herr != hipSuccess) { (void)hipDeviceSynchronize(); c->err = std::string("HIP error: ") + hipGetErrorString(herr); return KC_ERR_HIP; }
     if (s != KC_OK) return s;
     if (ds != KC_OK) return ds;
@@ -1350,8 +1471,8 @@ kc_status host_overlapped_zstd(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* 
 // Sub-batch of the host pipeline.  The device encode wants many units in flight (C2, ms per GiB: 4 GiB batch 42, 2 GiB 48, 1 GiB 58),
 // the pipeline wants several stages: measured PCIe-inclusive on 4 GiB of C2 — 256 MiB 4.0, 512 MiB 6.8, 1 GiB 10.8, 2 GiB 13.8 GB/s.
 // 2 GiB sub-batches pin 2 x (2 + 2.1) GiB of host memory per context; KC_HOST_PIPE_MIB overrides.
-uint64_t host_sub_bytes(uint64_t total) {
-    if (const char* e = getenv("KC_HOST_PIPE_MIB")) { const long v = atol(e); if (v >= 16) return (uint64_t)v << 20; }
+uint64_t host_sub_bytes(const kc_ctx* c, uint64_t total) {
+    if (c->cfg.host_pipe_mib >= 16) return (uint64_t)c->cfg.host_pipe_mib << 20;
     return total >= ((uint64_t)4 << 30) ? ((uint64_t)2 << 30) : ((uint64_t)1 << 30);  // at least two stages from 2 GiB of input on
 }
 
@@ -1369,13 +1490,13 @@ kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* 
     if (n_units == 0) { out_off[0] = 0; return KC_OK; }
     if ((s = validate_units(c, o, unit_off, n_units)) != KC_OK) return s;
     const uint64_t total = unit_off[n_units] - unit_off[0];
-    const uint64_t ov_min = getenv("KC_HOST_OVERLAP_MIN_MIB") ? (uint64_t)atoll(getenv("KC_HOST_OVERLAP_MIN_MIB")) << 20 : (uint64_t)1 << 30;
-    if (total >= ov_min && !getenv("KC_HOST_SERIAL") && !getenv("KC_HOST_PIPE_MIB") && c->cuts == nullptr) {
+    const uint64_t ov_min = c->cfg.host_overlap_min_mib >= 0 ? (uint64_t)c->cfg.host_overlap_min_mib << 20 : (uint64_t)1 << 30;
+    if (total >= ov_min && !c->cfg.host_serial && c->cfg.host_pipe_mib < 16 && c->cuts == nullptr) {
         s = host_overlapped_zstd(c, o, src, unit_off, n_units, dst, dst_cap, out_off);
         if (s != KC_ERR_UNSUPPORTED || !c->err.empty()) return s;  // UNSUPPORTED with no message: shape not served by the one-batch path
     }
-    const uint64_t sub = host_sub_bytes(total);
-    if (total >= 2 * sub && !getenv("KC_HOST_SERIAL") && c->cuts == nullptr) {  // (Flush points are indexed by unit: one batch loop)
+    const uint64_t sub = host_sub_bytes(c, total);
+    if (total >= 2 * sub && !c->cfg.host_serial && c->cuts == nullptr) {  // (Flush points are indexed by unit: one batch loop)
         auto enc = [&](const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
             return kc_zstd_encode_units_dev(c, o, d_in, rel, nu, d_out, cap, oo);
         };
@@ -1543,8 +1664,8 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
     mp.seq_stride = seq_stride;
     mp.block_size = bs;
     mp.max_match_off = o->window_size;
-    mp.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : 1;
-    mp.spec_grow = getenv("KC_SPEC_GROW") ? atoi(getenv("KC_SPEC_GROW")) : 2;
+    mp.spec_w0 = c->cfg.spec_w0 >= 0 ? (int)c->cfg.spec_w0 : 1;
+    mp.spec_grow = c->cfg.spec_grow >= 0 ? (int)c->cfg.spec_grow : 2;
     if (mp.spec_w0 < 1) mp.spec_w0 = 1;
     if (mp.spec_w0 > 8) mp.spec_w0 = 8;
     mp.hist0 = 0;
@@ -1553,6 +1674,7 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
     {
         uint64_t maxLen = 16;
         for (uint32_t i = 0; i < n_units; i++) maxLen = std::max<uint64_t>(maxLen, unit_off[i + 1] - unit_off[i]);
+        c->plan.max_unit_bytes = maxLen;
         int pb = 1;
         while (((uint64_t)1 << pb) <= maxLen + 2) pb++;
         mp.pos_bits = pb;
@@ -1640,15 +1762,20 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     so[n] = acc;
     reg[n] = acc16;
     if (acc16 + lead > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
+    // s2.Encode / s2.EncodeSnappy: the LDS-table kernel (one wave per block, ~1 ms per 64 KiB block whatever the batch) while the
+    // blocks in flight cannot cover the HBM-table kernel's latency (measured crossover: profiles/r03_crossover_s2.csv)
+    const bool lds = (level == KC_S2_LEVEL_DEFAULT || level == KC_S2_LEVEL_SNAPPY) && feed == nullptr && c->cfg.match_path != KC_PATH_HBM &&
+                     (c->cfg.match_path == KC_PATH_LDS || (int64_t)n <= c->cfg.s2_lds_max_blocks);
+    c->last_path = lds ? KC_PATH_LDS : KC_PATH_HBM;
     kc_status s;
     if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) ||
         (s = ensure(c, c->out_off, (n + 1 + (feed ? feed->cut.size() : 0)) * 8)) || (s = ensure(c, c->stage, acc + 64)) || (s = ensure(c, c->out_size, (size_t)n * 4)) ||
-        (s = ensure(c, c->tables, (size_t)n * kc_s2_table_bytes(level, maxLen))))
+        (!lds && (s = ensure(c, c->tables, (size_t)n * kc_s2_table_bytes(level, maxLen)))))
         return s;
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->stage_off.p, so.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen), st));
+    if (!lds) HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen), st));
     KcS2Params P;
     P.src = d_src + blk_off[0];
     P.blk_off = (const uint64_t*)c->unit_off.p;
@@ -1659,9 +1786,9 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     P.n_blocks = n;
     P.framed = framed;
     P.level = level;
-    P.spec_w0 = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : 2;
-    P.spec_w0b = getenv("KC_SPEC_W0") ? atoi(getenv("KC_SPEC_W0")) : 4;
-    P.spec_grow = getenv("KC_SPEC_GROW") ? atoi(getenv("KC_SPEC_GROW")) : 1;
+    P.spec_w0 = c->cfg.spec_w0 >= 0 ? (int)c->cfg.spec_w0 : 2;
+    P.spec_w0b = c->cfg.spec_w0 >= 0 ? (int)c->cfg.spec_w0 : 4;
+    P.spec_grow = c->cfg.spec_grow >= 0 ? (int)c->cfg.spec_grow : 1;
     if (P.spec_w0 < 1) P.spec_w0 = 1;
     if (P.spec_w0b < 1) P.spec_w0b = 1;
     P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen) / 4);
@@ -1692,7 +1819,14 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
         HIPCHK(c, hipGetLastError());
         return KC_OK;
     }
-    kc_launch_s2_encode(P, st);
+    if (lds) {
+        bool any_small = false, any_big = false;
+        for (uint32_t i = 0; i < n; i++) ((blk_off[i + 1] - blk_off[i]) <= ((uint64_t)64 << 10) ? any_small : any_big) = true;
+        P.spec_w0 = (int32_t)c->cfg.lds_spec_w0;
+        kc_launch_s2_encode_lds(P, any_small, any_big, st);
+    } else {
+        kc_launch_s2_encode(P, st);
+    }
     HIPCHK(c, hipEventRecord(c->ev[1], st));
     kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n, (uint64_t*)c->out_off.p, st);
     kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p, (const uint32_t*)c->out_size.p,
@@ -1842,8 +1976,8 @@ kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, cons
         if (blk_off[i + 1] - blk_off[i] > (uint64_t)(4 << 20)) { c->err = "S2 block larger than 4 MiB (s2.maxBlockSize) not served by the device path"; return KC_ERR_UNSUPPORTED; }
     }
     const uint64_t total = blk_off[n] - blk_off[0];
-    const uint64_t ov_min = getenv("KC_HOST_OVERLAP_MIN_MIB") ? (uint64_t)atoll(getenv("KC_HOST_OVERLAP_MIN_MIB")) << 20 : (uint64_t)512 << 20;
-    if (total >= ov_min && total <= c->max_batch_bytes && !getenv("KC_HOST_SERIAL") && !getenv("KC_HOST_PIPE_MIB")) {
+    const uint64_t ov_min = c->cfg.host_overlap_min_mib >= 0 ? (uint64_t)c->cfg.host_overlap_min_mib << 20 : (uint64_t)512 << 20;
+    if (total >= ov_min && total <= c->max_batch_bytes && !c->cfg.host_serial && c->cfg.host_pipe_mib < 16) {
         uint64_t need = 0;
         for (uint32_t i = 0; i < n; i++) need += ((uint64_t)kc_s2_max_encoded_len((int64_t)(blk_off[i + 1] - blk_off[i])) + 15) & ~(uint64_t)15;
         auto enq = [&](ChunkFeed& feed, const uint8_t* d_in, const uint64_t* rel, uint8_t* d_out) {
@@ -1858,12 +1992,12 @@ kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, cons
         };
         return host_chunk_fed(c, src, blk_off, n, dst, dst_cap, out_off, need, enq, region, fin);
     }
-    if (total >= 2 * host_sub_bytes(total) && !getenv("KC_HOST_SERIAL")) {
+    if (total >= 2 * host_sub_bytes(c, total) && !c->cfg.host_serial) {
         auto enc = [&](const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
             return kc_s2_encode_blocks_lvl_dev(c, level, d_in, rel, nu, d_out, cap, oo);
         };
         auto mx = [&](uint64_t len) { return (uint64_t)kc_s2_max_encoded_len((int64_t)len); };
-        return host_pipeline(c, src, blk_off, n, dst, dst_cap, out_off, host_sub_bytes(total), enc, mx);
+        return host_pipeline(c, src, blk_off, n, dst, dst_cap, out_off, host_sub_bytes(c, total), enc, mx);
     }
     uint64_t need = 0;
     for (uint32_t i = 0; i < n; i++) need += ((uint64_t)kc_s2_max_encoded_len((int64_t)(blk_off[i + 1] - blk_off[i])) + 15) & ~(uint64_t)15;
@@ -1915,9 +2049,9 @@ struct S2Hook {
     bool ok = false;
     std::atomic<uint64_t> n_calls{0}, n_batches{0};
 
-    bool init() {
-        if (const char* e = getenv("KC_S2_HOOK_WAIT_US")) wait_us = atoi(e);
-        if (const char* e = getenv("KC_S2_HOOK_BATCH")) max_n = (uint32_t)std::max(1, atoi(e));
+    bool init(const KcCfg& g) {
+        wait_us = (int)g.hook_wait_us;
+        max_n = (uint32_t)std::max<int64_t>(1, g.hook_batch);
         out_cap = in_cap + (size_t)32 * max_n + 64;
         for (auto& sl : slots) {
             if (hipHostMalloc((void**)&sl.h_in, in_cap, hipHostMallocDefault) != hipSuccess) return false;
@@ -1966,7 +2100,7 @@ int64_t kc_s2_encode_block(kc_ctx* c, uint8_t* dst, uint64_t dst_cap, const uint
     if (src_len < 32) return 0;  // encodeBlock: len < minNonLiteralBlockSize -> 0 (stored by the writer)
     std::call_once(c->hook_once, [c] {
         S2Hook* h = new S2Hook();
-        if (hipSetDevice(c->device) != hipSuccess || !h->init()) { delete h; return; }
+        if (hipSetDevice(c->device) != hipSuccess || !h->init(c->cfg)) { delete h; return; }
         c->hook = h;
     });
     S2Hook* h = (S2Hook*)c->hook;

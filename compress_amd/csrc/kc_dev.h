@@ -25,12 +25,7 @@ __device__ __forceinline__ uint4 ld128u(const uint8_t* p) {  // unaligned 16-byt
 #ifdef KC_HIPEMU
 #define KC_WAVE_SYNC() hipemu::wave_sync()
 #else
-#define KC_WAVE_SYNC()                                          \
-    do {                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
-        __builtin_amdgcn_wave_barrier();                        \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
-    } while (0)
+#define KC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
 // ---- wave primitives ----

@@ -124,8 +124,7 @@ __device__ inline uint8_t huf_set_max_height_lds(KcHufNodes* N, int lastNonNull,
     return maxNbBits;
 }
 
-// LDS hand-off between the lanes of one wave: program order in hardware, this keeps the compiler from reordering
-#define KC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// LDS hand-off between the lanes of one wave: KC_WAVE_SYNC (kc_dev.h)
 
 __device__ inline uint8_t huf_build_wave(KcHufNodes* N, KcHufTable* T, KcHufWaveTmp* W, int symbolLen, int srcLen, int lane) {
     const uint8_t tableLog0 = huf_optimal_table_log(srcLen, symbolLen);

@@ -27,10 +27,15 @@ struct KcMatchParams {
     int32_t pos_bits;           // bits reserved for position+1 in tagged table entries (better level)
     int32_t rep1, rep2;         // initial recentOffsets[0..1]: {1,4} unless a full-format dictionary supplies its own
     int32_t stream_mode;        // units are Write+Close streams: a unit of >= one block is parsed with Encode (history) from its first block
+    int32_t lds_split;          // SpeedFastest HBM kernel: 1 = skip the units the LDS-table kernel takes (those that fit KC_ZFAST_LDS_MAX_UNIT)
 };
 // SpeedFastest: 8 lanes per unit, tables = n_launch x 2^15 x u32 in HBM, zeroed by the caller
 void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st);
 static inline size_t kc_zfast_table_bytes() { return (size_t)4 << 15; }
+// SpeedFastest, LDS-table path (kc_zstd_match_lds.hip): one wave per unit, the 2^15 x u32 table in LDS; units (with their
+// dictionary history) below KC_ZFAST_LDS_MAX_UNIT bytes.  proto: null or the dictionary-primed table (HBM entry format, P.pos_bits)
+void kc_launch_zfast_match_lds(const KcMatchParams& P, const uint32_t* proto, uint32_t n_launch, hipStream_t st);
+#define KC_ZFAST_LDS_MAX_UNIT ((1u << 18) - 4u)
 // SpeedDefault: long (2^17) + short (2^15) u32 tables per unit in HBM, zeroed by the caller
 void kc_launch_zdfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st);
 static inline size_t kc_zdfast_table_bytes() { return ((size_t)4 << 17) + ((size_t)4 << 15); }

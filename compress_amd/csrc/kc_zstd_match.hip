@@ -32,9 +32,8 @@
 // literals from the source using the sequence list) + a KcBlkMeta record.
 #include "kc_dev.h"
 #include "kc_kernels.h"
+#include "kc_zfast_dev.h"
 
-#define ZF_TABLE_BITS 15
-#define ZF_MAX_MATCH_LENGTH 131074  // enc_fast.go:18
 
 #define ZW_RB 1024      // ring bytes per unit (power of two)
 #define ZW_MIRROR 32    // the first 32 ring bytes are mirrored behind the ring: 24-byte reads never wrap
@@ -48,24 +47,6 @@
 #define KC_TAB_LD(p) (*(p))
 #define KC_TAB_ST(v, p) (*(p) = (v))
 
-
-// c = 16 bytes at [t-4, t+12), p0..p3 = the 16 bytes at [p'-4, p'+12):
-// fwd = equal bytes from t / p' on (0..12), back = equal bytes going down from t-1 / p'-1 (0..4).
-__device__ __forceinline__ void zf_cmp16(const uint4 c, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int& fwd, int& back) {
-    const uint32_t x0 = c.x ^ p0, x1 = c.y ^ p1, x2 = c.z ^ p2, x3 = c.w ^ p3;
-    back = x0 ? (__builtin_clz(x0) >> 3) : 4;
-    fwd = x1 ? (__builtin_ctz(x1) >> 3) : (x2 ? 4 + (__builtin_ctz(x2) >> 3) : (x3 ? 8 + (__builtin_ctz(x3) >> 3) : 12));
-}
-
-// 4 bytes at q, with bytes outside [lo, hi) read as zero (edges of the caller's buffer only).
-__device__ __noinline__ uint32_t zf_edge_dword(const uint8_t* q, const uint8_t* lo, const uint8_t* hi) {
-    uint32_t v = 0;
-    for (int k = 0; k < 4; k++) {
-        const uint8_t* a = q + k;
-        if (a >= lo && a < hi) v |= (uint32_t)(*a) << (8 * k);
-    }
-    return v;
-}
 
 template <int G>
 __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P, uint32_t* __restrict__ tables, uint32_t n_launch) {
@@ -88,7 +69,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const int bs = P.block_size;
     const int mmo = P.max_match_off;
     const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
-    const int nblk = gact ? UB.nblk : 0;  // a group without a unit (the launch's tail) does nothing
+    const bool ldsUnit = P.lds_split != 0 && (uint32_t)(ulen + hist0) <= KC_ZFAST_LDS_MAX_UNIT;  // the LDS-table kernel's unit
+    const int nblk = (gact && !ldsUnit) ? UB.nblk : 0;  // a group without a unit (the launch's tail) does nothing
     const bool HIST = ulen > bs || hist0 > 0 || UB.streamU;  // with a dictionary encodeAll always calls Encode (encoder.go:783-787)
     uint32_t* __restrict__ tab = tables + (size_t)ui * (1u << ZF_TABLE_BITS);  // zeroed by the host before the launch
     // Table entry = (position+1) in the low PB bits | a TB-bit tag of the 4 source bytes at that position.

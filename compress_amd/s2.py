@@ -13,8 +13,12 @@ LevelDefault, LevelBetter, LevelSnappy, LevelSnappyBetter = 0, 1, 2, 3  # s2.Enc
 
 
 class BlockEncoder:
-    def __init__(self, device=0, stream=None, level=LevelDefault):
+    def __init__(self, device=0, stream=None, level=LevelDefault, path=None):
+        """path: None / 'auto' (by blocks in flight), 'hbm' or 'lds' — the kernel family of s2.Encode / s2.EncodeSnappy
+        (KC_OPT_MATCH_PATH, include/kcgpu.h); both give the reference's bytes."""
         self._ctx = _lib.Context(device, stream)
+        if path is not None:
+            self._ctx.set_path(path)
         self.level = int(level)
 
     def EncodeBlocks(self, src, blk_off):

@@ -98,6 +98,15 @@ def WithEncoderDict(dict):
     return apply
 
 
+def WithMatchPath(path):
+    """Not a reference option: which kernel family serves SpeedFastest ('auto' by units in flight, 'hbm', 'lds';
+    KC_OPT_MATCH_PATH in include/kcgpu.h).  The bytes are the reference's either way."""
+    def apply(o):
+        pass
+    apply._kc_path = path
+    return apply
+
+
 def WithEncoderConcurrency(n):
     """Accepted for API compatibility; the device path is batch-parallel (no bytes depend on it)."""
     if n <= 0:
@@ -115,7 +124,10 @@ class Encoder:
     reference's for the same Write / Flush sequence; streams of more than 1 GiB and dictionaries are not served
     (the caller falls back to the reference).  EncodeStreams / EncodeStreamsDevice batch many streams per launch."""
 
-    def __init__(self, *opts, device=0, stream=None, w=None):
+    def __init__(self, *opts, device=0, stream=None, w=None, path=None):
+        """path: None / 'auto' (by units in flight), 'hbm' or 'lds' — the kernel family of the SpeedFastest match finder
+        (KC_OPT_MATCH_PATH, include/kcgpu.h); both give the reference's bytes."""
+        self._path = path
         self._w = w
         self._buf = bytearray()
         self._cuts = []
@@ -124,6 +136,9 @@ class Encoder:
         self.o = _lib.ZstdOpts()
         L.kc_zstd_opts_default(C.byref(self.o))
         for op in opts:
+            if hasattr(op, "_kc_path"):
+                self._path = op._kc_path
+                continue
             op(self.o)
         self._device, self._stream = device, stream
         self._ctx = None
@@ -144,6 +159,8 @@ class Encoder:
     def ctx(self):
         if self._ctx is None:
             self._ctx = _lib.Context(self._device, self._stream)
+            if self._path is not None:
+                self._ctx.set_path(self._path)
         return self._ctx
 
     def EncodeUnits(self, src, unit_off):

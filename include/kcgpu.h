@@ -100,6 +100,38 @@ int64_t kc_zstd_max_encoded_size(const kc_zstd_opts* o, int64_t size);
 kc_status kc_ctx_create(kc_ctx** out, int device, void* stream);
 void kc_ctx_destroy(kc_ctx* ctx);
 const char* kc_last_error(const kc_ctx* ctx);
+/* ---- context options ----
+ * Every tunable of the library is a field of the context.  kc_ctx_create seeds them ONCE from the environment variable named
+ * beside each key (no entry point reads the environment afterwards); kc_ctx_set_option changes them.
+ *
+ * Two kernel families serve SpeedFastest and s2.Encode / s2.EncodeSnappy (KC_OPT_MATCH_PATH):
+ *   KC_PATH_HBM  per-unit hash tables in an HBM arena, 8 units per wave: the throughput path, needs ~10^4 units in flight;
+ *   KC_PATH_LDS  the unit's hash table (and, for S2 blocks up to 64 KiB, the block) in the CU's LDS, one wave per unit: the
+ *                latency path — one unit in a few ms instead of ~30 ms; also the faster one for sparse scans (high-entropy input);
+ *   KC_PATH_AUTO by units in flight, against the measured crossovers (profiles/r03_crossover_*.csv).
+ * Both produce the same bytes (the GPU parity tests run on both). */
+enum { KC_PATH_AUTO = 0, KC_PATH_HBM = 1, KC_PATH_LDS = 2 };
+typedef enum {
+    KC_OPT_MATCH_PATH = 1,           /* KC_MATCH_PATH             KC_PATH_* */
+    KC_OPT_ZFAST_LDS_MAX_UNITS = 2,  /* KC_ZFAST_LDS_MAX_UNITS    auto: SpeedFastest batches of at most this many units take KC_PATH_LDS */
+    KC_OPT_S2_LDS_MAX_BLOCKS = 3,    /* KC_S2_LDS_MAX_BLOCKS      auto: s2 block batches of at most this many blocks take KC_PATH_LDS */
+    KC_OPT_SPEC_W0 = 4,              /* KC_SPEC_W0                HBM kernels: probe steps per round after a match (-1: per-level default) */
+    KC_OPT_SPEC_GROW = 5,            /* KC_SPEC_GROW              HBM kernels: width after a miss: 0 keep, 1 +1, 2 double (-1: default) */
+    KC_OPT_LDS_SPEC_W0 = 6,          /* KC_LDS_SPEC_W0            LDS kernels: probe steps per round after a match (doubles on a miss, max 64) */
+    KC_OPT_HOST_SERIAL = 7,          /* KC_HOST_SERIAL            host-buffer entry points: no pipelining (copy, encode, copy) */
+    KC_OPT_HOST_PIPE_MIB = 8,        /* KC_HOST_PIPE_MIB          host-buffer entry points: sub-batch size of the three-stage pipeline */
+    KC_OPT_HOST_OVERLAP_MIN_MIB = 9, /* KC_HOST_OVERLAP_MIN_MIB   smallest input that takes the chunk-fed path (-1: default) */
+    KC_OPT_HOST_COPY_THREADS = 10,   /* KC_HOST_COPY_THREADS      threads of the pageable <-> pinned copies (0: the cgroup's CPUs, max 16) */
+    KC_OPT_HOST_TRACE = 11,          /* KC_HOST_TRACE             timeline of the chunk-fed path on stderr */
+    KC_OPT_HOST_CHUNK_MIB = 12,      /* KC_HOST_CHUNKS_MIB (list) chunk size of the chunk-fed path (0: a quarter of the batch) */
+    KC_OPT_K2_PROF = 13,             /* KC_K2_PROF                per-phase shader clocks of the entropy kernel on stderr */
+    KC_OPT_S2_HOOK_WAIT_US = 14,     /* KC_S2_HOOK_WAIT_US        kc_s2_encode_block: time a batch leader waits for more callers */
+    KC_OPT_S2_HOOK_BATCH = 15,       /* KC_S2_HOOK_BATCH          kc_s2_encode_block: most blocks per device batch */
+    KC_OPT_TEST_FEED_REDO = 16,      /* (no variable)             diagnostics: force the chunk-fed path's re-encode fallback */
+    KC_OPT_LAST_PATH = 100           /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
+} kc_option;
+kc_status kc_ctx_set_option(kc_ctx* ctx, int key, int64_t value);
+int64_t kc_ctx_get_option(const kc_ctx* ctx, int key);
 /* Device properties as probed (CU count, LDS bytes per CU, clock, name) */
 kc_status kc_device_info(const kc_ctx* ctx, int32_t* n_cu, int32_t* lds_per_cu, int32_t* clock_khz, char* name, size_t name_cap);
 

@@ -65,3 +65,40 @@ def s2_encode_blocks(blocks, level=0, framed=False, spec_w0=8):
     r = lib().kcemu_s2_encode(level, int(framed), spec_w0, src.ctypes.data, off.ctypes.data, n, stage.ctypes.data, soff.ctypes.data, sizes.ctypes.data)
     assert r == 0
     return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)]
+
+
+def zfast_parse(units, block_size=65536, window=4 << 20, spec_w0=8, stream_mode=0):
+    """kc_zfast_match_lds_kernel over `units` (list of bytes).  Returns, per block in unit order, (seqs [n,3] u32 as
+    (litLen, matchLen-3, offset code), nlit, extra_lits, flags)."""
+    n = len(units)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    blk0 = np.zeros(n + 1, dtype=np.uint32)
+    for i, u in enumerate(units):
+        off[i + 1] = off[i] + len(u)
+        blk0[i + 1] = blk0[i] + (len(u) + block_size - 1) // block_size
+    nb = int(blk0[n])
+    src = np.frombuffer(b"".join(units) + b"\0" * 64, dtype=np.uint8).copy()
+    # the kernels load whole 16-byte granules around readable bytes: keep the buffer 16-byte aligned like a device allocation
+    al = np.zeros(len(src) + 32, dtype=np.uint8)
+    o = (-al.ctypes.data) % 16
+    al[o:o + len(src)] = src
+    base = al.ctypes.data + o
+    stride = block_size // 4 + 8
+    seqs = np.zeros(max(nb, 1) * stride, dtype=np.uint64)
+    meta = np.zeros(max(nb, 1) * 8, dtype=np.uint32)
+    maxlen = max([len(u) for u in units] + [16])
+    pb = 1
+    while (1 << pb) <= maxlen + 2:
+        pb += 1
+    r = lib().kcemu_zfast_parse(base, off.ctypes.data, n, block_size, window, 0, 1, 4, stream_mode, None, seqs.ctypes.data, meta.ctypes.data, stride,
+                                blk0.ctypes.data, spec_w0, pb)
+    assert r == 0
+    out = []
+    for b in range(nb):
+        m = meta[8 * b:8 * b + 8]
+        ns = int(m[0])
+        v = seqs[b * stride:b * stride + ns]
+        tri = np.stack([(v >> np.uint64(44)).astype(np.uint32), ((v >> np.uint64(24)) & np.uint64(0xFFFFF)).astype(np.uint32),
+                        (v & np.uint64(0xFFFFFF)).astype(np.uint32)], axis=1) if ns else np.zeros((0, 3), dtype=np.uint32)
+        out.append((tri, int(m[1]), int(m[2]), int(m[3])))
+    return out

@@ -68,3 +68,32 @@ def test_s2_lds_reference_regressions():
         blocks = [z.read(n) for n in z.namelist() if not n.endswith("/")]
     blocks = [b for b in blocks if len(b) < (1 << 20)]
     _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=0), oracle_lib.s2_encode)
+
+
+def _zfast_units():
+    units = [corpora.corpus("T", 1, 131072, first_unit=k).tobytes() for k in range(2)]
+    units += [corpora.corpus("M", 1, 131072, first_unit=k).tobytes() for k in range(4)]
+    units += [corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("H", 1, 131072).tobytes()]
+    units += [u for u in corpora.edge_units() if 0 < len(u) < 262000]
+    units += [u for u in corpora.stress_units(seed=5, n=8) if len(u) < 262000]
+    return units
+
+
+@pytest.mark.parametrize("w0", [1, 8, 64])
+def test_zfast_lds_parse_matches_oracle(w0):
+    """kc_zfast_match_lds_kernel: the sequence list of every block equals the oracle's fastEncoder (EncodeNoHist for
+    one-block units, Encode with history for longer ones), at every speculation width."""
+    units = _zfast_units()
+    got = emu_lib.zfast_parse(units, spec_w0=w0)
+    bi = 0
+    for ui, u in enumerate(units):
+        ref = oracle_lib.zstd_parse_unit(u, level=1)
+        for rb, (rseqs, rlits) in enumerate(ref):
+            gseqs, gnlit, gextra, gflags = got[bi]
+            bi += 1
+            assert len(gseqs) == len(rseqs), "unit %d (len %d) block %d: nseq %d vs oracle %d" % (ui, len(u), rb, len(gseqs), len(rseqs))
+            if len(rseqs):
+                neq = np.nonzero((gseqs != rseqs).any(axis=1))[0]
+                assert len(neq) == 0, "unit %d block %d first differing seq %d: emulated %r oracle %r" % (ui, rb, neq[0], gseqs[neq[0]], rseqs[neq[0]])
+            assert gnlit == len(rlits), "unit %d block %d: nlit %d vs oracle %d" % (ui, rb, gnlit, len(rlits))
+    assert bi == len(got)

@@ -9,6 +9,13 @@ import corpora
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["hbm", "lds"])
+def s2path(request):
+    """Every parity test of s2.Encode / s2.EncodeSnappy runs on both kernel families: 'hbm' = kc_s2.hip (tables in HBM, 8 blocks
+    per wave), 'lds' = kc_s2_lds.hip (table and block in LDS, one wave per block); forced through KC_OPT_MATCH_PATH."""
+    return request.param
+
+
 def _oracle_blocks(oracle, buf, off):
     L = oracle.lib()
     n = len(off) - 1
@@ -21,11 +28,13 @@ def _oracle_blocks(oracle, buf, off):
     return dst[:r], oo
 
 
-def _check(oracle, blocks):
+def _check(oracle, blocks, path=None):
     from compress_amd import s2
     buf, off = corpora.pack_units(blocks)
-    enc = s2.BlockEncoder()
+    enc = s2.BlockEncoder(path=path)
     out, out_off = enc.EncodeBlocks(buf, off)
+    if path is not None:
+        assert enc._ctx.last_path() == path
     ref, ref_off = _oracle_blocks(oracle, buf, off)
     bad = []
     for i in range(len(blocks)):
@@ -42,16 +51,16 @@ def _check(oracle, blocks):
 
 
 @pytest.mark.parametrize("kind", ["J", "T", "M", "H"])
-def test_s2_64k_blocks_bit_exact(oracle, kclib, kind):
+def test_s2_64k_blocks_bit_exact(oracle, kclib, kind, s2path):
     buf = corpora.corpus(kind, 128, 65536)
     _check(oracle, [buf[i * 65536:(i + 1) * 65536].tobytes() for i in range(128)])
 
 
-def test_s2_edge_blocks_bit_exact(oracle, kclib):
+def test_s2_edge_blocks_bit_exact(oracle, kclib, s2path):
     _check(oracle, corpora.edge_units())
 
 
-def test_s2_large_blocks_bit_exact(oracle, kclib):
+def test_s2_large_blocks_bit_exact(oracle, kclib, s2path):
     """Blocks > 64 KiB take encodeBlockGo (u32 table, skip >>6) in the reference."""
     j = corpora.corpus("J", 8, 1 << 20).tobytes()
     t = corpora.corpus("T", 8, 1 << 20).tobytes()
@@ -60,10 +69,10 @@ def test_s2_large_blocks_bit_exact(oracle, kclib):
     _check(oracle, blocks)
 
 
-def test_s2_custom_encoder_contract(oracle, kclib):
+def test_s2_custom_encoder_contract(oracle, kclib, s2path):
     """WriterCustomEncoder contract (s2/writer.go:1053-1064): no varint header; 0 == incompressible."""
     from compress_amd import s2
-    enc = s2.BlockEncoder()
+    enc = s2.BlockEncoder(path=s2path)
     fn = enc.CustomEncoder()
     text = corpora.corpus("J", 1, 65536).tobytes()
     dst = bytearray(s2.MaxEncodedLen(len(text)))
@@ -75,14 +84,14 @@ def test_s2_custom_encoder_contract(oracle, kclib):
     enc.Close()
 
 
-def test_s2_custom_encoder_concurrent_callers(oracle, kclib):
+def test_s2_custom_encoder_concurrent_callers(oracle, kclib, s2path):
     """s2.Writer calls the WriterCustomEncoder hook from one goroutine per block (s2/writer.go:455-460, "should expect to be
     called concurrently", :1058): 16 host threads hammer ONE context; every result must equal the oracle's encodeBlock, and
     the hook must have batched concurrent callers into fewer device launches than calls."""
     import threading
     import time
     from compress_amd import s2
-    enc = s2.BlockEncoder()
+    enc = s2.BlockEncoder(path=s2path)
     fn = enc.CustomEncoder()
     j = corpora.corpus("J", 192, 65536).tobytes()
     t = corpora.corpus("T", 2, 1 << 20).tobytes()
@@ -136,7 +145,7 @@ def test_s2_custom_encoder_concurrent_callers(oracle, kclib):
     enc.Close()
 
 
-def test_s2_full_size_roundtrip(oracle, kclib):
+def test_s2_full_size_roundtrip(oracle, kclib, s2path):
     """C4-size property check: 16384 x 64 KiB JSON blocks, device resident, sample decodes back."""
     import torch
     from compress_amd import s2
@@ -144,7 +153,7 @@ def test_s2_full_size_roundtrip(oracle, kclib):
     buf = corpora.corpus("J", n, bsz)
     off = np.arange(n + 1, dtype=np.uint64) * bsz
     d_src = torch.from_numpy(buf).cuda()
-    enc = s2.BlockEncoder()
+    enc = s2.BlockEncoder(path=s2path)
     cap = n * ((s2.MaxEncodedLen(bsz) + 15) & ~15) + 64
     d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
     out_off = enc.EncodeBlocksDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
@@ -158,7 +167,7 @@ def test_s2_full_size_roundtrip(oracle, kclib):
 
 
 @pytest.mark.parametrize("with_id", [True, False])
-def test_s2_stream_framing_bit_exact(oracle, kclib, with_id):
+def test_s2_stream_framing_bit_exact(oracle, kclib, with_id, s2path):
     """s2.Writer framing (stream id, chunk header, masked CRC32C, stored chunks) equals the oracle's and decodes."""
     import torch
     from compress_amd import s2
@@ -167,7 +176,7 @@ def test_s2_stream_framing_bit_exact(oracle, kclib, with_id):
     blocks += [b"", b"abc", b"x" * 31, b"y" * 32, corpora.corpus("T", 1, 1 << 20).tobytes(), corpora.corpus("M", 1, 200000).tobytes()]
     buf, off = corpora.pack_units(blocks)
     d_src = torch.from_numpy(buf).cuda()
-    enc = s2.BlockEncoder()
+    enc = s2.BlockEncoder(path=s2path)
     cap = sum(((s2.MaxEncodedLen(len(b)) + 8 + 15) & ~15) for b in blocks) + 80
     d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
     out_off = enc.EncodeStreamDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap, with_stream_id=with_id)
@@ -428,7 +437,7 @@ def test_s2_writer_better_stream_roundtrip(oracle, kclib):
 
 
 @pytest.mark.parametrize("kind", ["J", "T", "M", "H"])
-def test_s2_snappy_blocks_bit_exact(oracle, kclib, kind):
+def test_s2_snappy_blocks_bit_exact(oracle, kclib, kind, s2path):
     """KC_S2_LEVEL_SNAPPY == s2.EncodeSnappy: same parse as the default level, copies through emitCopyNoRepeat."""
     from compress_amd import s2
     buf = corpora.corpus(kind, 96, 65536)
@@ -436,7 +445,7 @@ def test_s2_snappy_blocks_bit_exact(oracle, kclib, kind):
     big = corpora.corpus(kind, 2, 1 << 20).tobytes()
     blocks += [big[:65537], big[:700000], big[1 << 20:]] + [u for u in corpora.edge_units() if len(u) < 70000]
     b2, off = corpora.pack_units(blocks)
-    enc = s2.BlockEncoder(level=s2.LevelSnappy)
+    enc = s2.BlockEncoder(level=s2.LevelSnappy, path=s2path)
     out, out_off = enc.EncodeBlocks(b2, off)
     ref, ref_off = oracle.s2_encode_blocks(b2, off, threads=8, snappy=True)
     assert np.array_equal(out_off, ref_off)
@@ -463,7 +472,7 @@ def test_s2_snappy_better_blocks_bit_exact(oracle, kclib, kind):
 
 
 @pytest.mark.parametrize("level", [0, 1, 2, 3])
-def test_s2_levels_randomised_blocks_bit_exact(oracle, kclib, level):
+def test_s2_levels_randomised_blocks_bit_exact(oracle, kclib, level, s2path):
     """Differential test over adversarial block mixes (text / noise runs of every length class / low-entropy noise / long zero
     runs / repeated parts, 300 B .. 300 KB: both table variants of every level) for s2.Encode, s2.EncodeBetter, s2.EncodeSnappy, s2.EncodeSnappyBetter."""
     from compress_amd import s2
@@ -473,7 +482,7 @@ def test_s2_levels_randomised_blocks_bit_exact(oracle, kclib, level):
         per = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
         blocks.append((per * 20000)[:int(rng.integers(1, 140000))])
     buf, off = corpora.pack_units(blocks)
-    enc = s2.BlockEncoder(level=level)
+    enc = s2.BlockEncoder(level=level, path=s2path)
     out, out_off = enc.EncodeBlocks(buf, off)
     ref, ref_off = oracle.s2_encode_blocks(buf, off, threads=8, better=level in (1, 3), snappy=level in (2, 3))
     ref = np.asarray(ref)
@@ -505,7 +514,8 @@ def test_s2_host_chunk_fed_equals_oracle(oracle, kclib, level, monkeypatch):
     assert np.array_equal(out, np.asarray(ref))
     out2, out_off2 = enc.EncodeBlocks(buf, off)
     assert np.array_equal(out2, out) and np.array_equal(out_off2, out_off)
-    monkeypatch.setenv("KC_HOST_SERIAL", "1")
+    from compress_amd import _lib
+    enc._ctx.set_option(_lib.OPT_HOST_SERIAL, 1)
     out3, out_off3 = enc.EncodeBlocks(buf, off)
     assert np.array_equal(out3, out) and np.array_equal(out_off3, out_off)
     enc.Close()

@@ -13,16 +13,40 @@ def _torch():
     return torch
 
 
+# "1L" = SpeedFastest forced onto the LDS-table match finder (kc_zstd_match_lds.hip), 1 = forced onto the HBM-table one
+# (kc_zstd_match.hip): every parity test of this file runs on both (KC_OPT_MATCH_PATH, not an environment variable).
+LEVELS = [1, "1L", 2, 3]
+
+
+def _li(level):
+    return 1 if level == "1L" else int(level)
+
+
+def _lo(level):
+    from compress_amd import zstd
+    if level == "1L":
+        return [zstd.WithEncoderLevel(1), zstd.WithMatchPath("lds")]
+    if level == 1:
+        return [zstd.WithEncoderLevel(1), zstd.WithMatchPath("hbm")]
+    return [*_lo(level)]
+
+
 def _enc(level=1, **kw):
     from compress_amd import zstd
-    return zstd.NewWriter(None, zstd.WithEncoderLevel(level), **kw)
+    return zstd.NewWriter(None, *_lo(level), **kw)
+
+
+def _path_ran(enc, level):
+    """The forced path really ran (units of 256 KiB and more only fit the HBM path's position field)."""
+    if level in (1, "1L"):
+        assert enc.ctx().last_path() == ("lds" if level == "1L" else "hbm")
 
 
 def _check_units(oracle, units, level=1):
     buf, off = corpora.pack_units(units)
     enc = _enc(level)
     out, out_off = enc.EncodeUnits(buf, off)
-    ref, ref_off = oracle.zstd_encode_units(buf, off, threads=8, level=level)
+    ref, ref_off = oracle.zstd_encode_units(buf, off, threads=8, level=_li(level))
     bad = []
     for i in range(len(units)):
         a = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
@@ -34,7 +58,7 @@ def _check_units(oracle, units, level=1):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 def test_parse_matches_oracle(oracle, kclib, level):
     """Intermediate artefact parity: the sequence list of every block equals the oracle's."""
     torch = _torch()
@@ -48,7 +72,7 @@ def test_parse_matches_oracle(oracle, kclib, level):
     blocks = enc.DebugParseDevice(d.data_ptr(), off)
     bi = 0
     for ui, u in enumerate(units):
-        ref = oracle.zstd_parse_unit(u, level=level)
+        ref = oracle.zstd_parse_unit(u, level=_li(level))
         for rb, (rseqs, rlits) in enumerate(ref):
             gseqs, gextra = blocks[bi]
             bi += 1
@@ -61,13 +85,13 @@ def test_parse_matches_oracle(oracle, kclib, level):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 def test_edge_units_bit_exact(oracle, kclib, level):
     _torch()
     _check_units(oracle, corpora.edge_units(), level)
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 @pytest.mark.parametrize("kind", ["T", "H", "J", "M"])
 def test_corpus_units_bit_exact(oracle, kclib, kind, level):
     _torch()
@@ -76,7 +100,7 @@ def test_corpus_units_bit_exact(oracle, kclib, kind, level):
     _check_units(oracle, units, level)
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 def test_ragged_units_bit_exact(oracle, kclib, level):
     _torch()
     rng = np.random.default_rng(7)
@@ -106,7 +130,7 @@ def test_xxh64_units(oracle, kclib):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 def test_device_resident_roundtrip_full_size(oracle, kclib, level):
     """BASELINE-size property check (no oracle at this size): every frame decodes back with libzstd."""
     torch = _torch()
@@ -128,7 +152,7 @@ def test_device_resident_roundtrip_full_size(oracle, kclib, level):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 @pytest.mark.parametrize("dict_id", [0, 1, 70000])
 def test_with_raw_dictionary_bit_exact(oracle, kclib, dict_id, level):
     """C5: 64 KiB raw-content dictionary (WithEncoderDictRaw) at every level, mixed corpus.  Units <= 32 KiB take the
@@ -142,9 +166,9 @@ def test_with_raw_dictionary_bit_exact(oracle, kclib, dict_id, level):
     units += [t[:200000], t[5:40000], t[:9], t[:100], b"", t[100000:400000], dct[:50000], dct]
     units += [t[7:7 + n] for n in (32768, 32769, 20000, 4096, 1000, 17, 65536, 65537, 98304)] + [dct[1000:30000], buf[3000:30000].tobytes()]
     ubuf, off = corpora.pack_units(units)
-    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderDictRaw(dict_id, dct))
+    enc = zstd.NewWriter(None, *_lo(level), zstd.WithEncoderDictRaw(dict_id, dct))
     out, out_off = enc.EncodeUnits(ubuf, off)
-    ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=level, dict_id=dict_id, dict_content=dct)
+    ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=_li(level), dict_id=dict_id, dict_content=dct)
     bad = [i for i in range(len(units))
            if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
     assert not bad, bad[:10]
@@ -155,7 +179,7 @@ def test_with_raw_dictionary_bit_exact(oracle, kclib, dict_id, level):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 @pytest.mark.parametrize("which", ["d0", "skewed"])
 def test_with_full_format_dictionary_bit_exact(oracle, kclib, level, which):
     """a16: WithEncoderDict (zstd --train format): dictionary offsets, content as history and the literal Huffman table
@@ -171,9 +195,9 @@ def test_with_full_format_dictionary_bit_exact(oracle, kclib, level, which):
         units += tk.skewed_units(probs, seeds=4)
     units += [corpora.corpus("T", 3, 131072, first_unit=5).tobytes()[:n] for n in (300000, 131072, 65537, 31, 17)]
     ubuf, off = corpora.pack_units(units)
-    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderDict(blob))
+    enc = zstd.NewWriter(None, *_lo(level), zstd.WithEncoderDict(blob))
     out, out_off = enc.EncodeUnits(ubuf, off)
-    ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=level, dict_blob=blob)
+    ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=_li(level), dict_blob=blob)
     bad = [i for i in range(len(units))
            if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
     assert not bad, bad[:10]
@@ -183,12 +207,12 @@ def test_with_full_format_dictionary_bit_exact(oracle, kclib, level, which):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 def test_stress_mixes_bit_exact(oracle, kclib, level):
     """Adversarial literal/sequence mixes (corpora.stress_units): long literal runs across the LDS gather window,
     more cooperative runs than the per-batch list holds, Huffman-only blocks, RLE blocks, multi-block units."""
     _torch()
-    _check_units(oracle, corpora.stress_units(), level=level)
+    _check_units(oracle, corpora.stress_units(), level=_li(level))
 
 
 def test_stress_mixes_entropy_options(oracle, kclib):
@@ -250,7 +274,7 @@ def test_begin_end_pipeline_two_contexts(oracle, kclib):
         e.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 def test_streams_bit_exact(oracle, kclib, level):
     """N2: NewWriter(w).Write(...) / Close() streams (kc_zstd_encode_streams_dev) against the oracle's restatement of
     Write -> nextBlock -> Close: EncodeAll frame below one block, streaming frame (no content size, history from the first
@@ -258,28 +282,28 @@ def test_streams_bit_exact(oracle, kclib, level):
     _torch()
     import io
     from compress_amd import zstd
-    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level))
+    enc = zstd.NewWriter(None, *_lo(level))
     bs = enc.o.block_size
     t = corpora.corpus("T", 6, 131072, first_unit=40).tobytes()
     m = corpora.corpus("M", 2, 131072, first_unit=3).tobytes()
     units = [b"", t[:1], t[:100], t[:bs - 1], t[:bs], t[:bs + 1], t[:2 * bs], t[:2 * bs + 5], t[:3 * bs - 1], m[:bs], m, t[7:7 + 5 * bs], corpora.corpus("H", 1, 2 * bs).tobytes()]
     ubuf, off = corpora.pack_units(units)
     out, out_off = enc.EncodeStreams(ubuf, off)
-    ref = oracle.ZstdOracle(level=level)
+    ref = oracle.ZstdOracle(level=_li(level))
     for i, u in enumerate(units):
         got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
         assert got == ref.encode_stream(u), (i, len(u))
         if u:
             assert oracle.zstd_decompress(got, len(u) + 16) == u
     # options that change the header / checksum
-    e2 = zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderCRC(False), zstd.WithZeroFrames(False))
+    e2 = zstd.NewWriter(None, *_lo(level), zstd.WithEncoderCRC(False), zstd.WithZeroFrames(False))
     o2, oo2 = e2.EncodeStreams(ubuf, off)
-    r2 = oracle.ZstdOracle(level=level, crc=False, full_zero=False)
+    r2 = oracle.ZstdOracle(level=_li(level), crc=False, full_zero=False)
     for i, u in enumerate(units):
         assert o2[int(oo2[i]):int(oo2[i + 1])].tobytes() == r2.encode_stream(u), (i, len(u))
     # the io.Writer surface
     sink = io.BytesIO()
-    w = zstd.NewWriter(sink, zstd.WithEncoderLevel(level))
+    w = zstd.NewWriter(sink, *_lo(level))
     for i in range(0, len(t[:2 * bs + 5]), 50000):
         w.Write(t[i:min(i + 50000, 2 * bs + 5)])
     w.Close()
@@ -292,11 +316,11 @@ def test_streams_bit_exact(oracle, kclib, level):
     with pytest.raises(IOError):
         w.Write(b"x")
     with pytest.raises(Exception):  # dictionaries: the caller must fall back
-        zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderDictRaw(1, t[:1000])).EncodeStreams(ubuf, off)
+        zstd.NewWriter(None, *_lo(level), zstd.WithEncoderDictRaw(1, t[:1000])).EncodeStreams(ubuf, off)
     enc.Close(); e2.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 def test_streams_with_flush_points_bit_exact(oracle, kclib, level):
     """Mid-stream Flush (zstd/encoder.go:547-570) ends the block being filled: kc_zstd_encode_streams_cuts against the oracle's
     Write / Flush / Close restatement — cuts inside the first block (header written early: no EncodeAll frame), on block boundaries
@@ -306,7 +330,7 @@ def test_streams_with_flush_points_bit_exact(oracle, kclib, level):
     import io
     import random
     from compress_amd import zstd
-    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level))
+    enc = zstd.NewWriter(None, *_lo(level))
     bs = enc.o.block_size
     t = corpora.corpus("T", 6, 131072, first_unit=90).tobytes()
     m = corpora.corpus("M", 3, 131072, first_unit=5).tobytes()
@@ -314,7 +338,7 @@ def test_streams_with_flush_points_bit_exact(oracle, kclib, level):
              (t[:bs], [bs]), (t[:2 * bs], [bs]), (t[:2 * bs + 9], [bs - 1, bs, bs + 1]), (t[:3 * bs], [7, 7, 7, 2 * bs + 7]),
              (m[:bs + 5000], [100 * k for k in range(1, 25)]), (b"", [0]), (b"", []), (t[:5], [1, 2, 3, 4, 5]),
              (corpora.corpus("H", 1, bs).tobytes(), [bs // 2]), (t[:4 * bs + 1], [3 * bs + 50000, 4 * bs + 1, 4 * bs + 9])]
-    rnd = random.Random(1234 + level)
+    rnd = random.Random(1234 + _li(level))
     for _ in range(25):
         n = rnd.choice([rnd.randrange(1, 3000), rnd.randrange(bs - 2000, bs + 2000), rnd.randrange(2 * bs, 5 * bs)])
         d = (t if rnd.random() < 0.6 else m)[:n]
@@ -323,7 +347,7 @@ def test_streams_with_flush_points_bit_exact(oracle, kclib, level):
     units = [c[0] for c in cases]
     ubuf, off = corpora.pack_units(units)
     out, out_off = enc.EncodeStreams(ubuf, off, flush_at=[c[1] for c in cases])
-    ref = oracle.ZstdOracle(level=level)
+    ref = oracle.ZstdOracle(level=_li(level))
     for i, (u, cuts) in enumerate(cases):
         got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
         assert got == ref.encode_stream(u, cuts), (i, len(u), cuts)
@@ -335,7 +359,7 @@ def test_streams_with_flush_points_bit_exact(oracle, kclib, level):
     assert np.array_equal(plain, none) and np.array_equal(plain_off, none_off)
     # the io.Writer surface
     sink = io.BytesIO()
-    w = zstd.NewWriter(sink, zstd.WithEncoderLevel(level))
+    w = zstd.NewWriter(sink, *_lo(level))
     w.Flush()                      # nothing buffered: no effect
     w.Write(t[:70000]); w.Flush()
     w.Write(t[70000:70010]); w.Flush(); w.Flush()
@@ -346,7 +370,7 @@ def test_streams_with_flush_points_bit_exact(oracle, kclib, level):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 def test_device_decoder_roundtrip(oracle, kclib, level):
     """N1 (GPU half) for zstd: kc_zstd_decode_units_dev decodes the frames the device encoder produced back to the source,
     on the device, checksum included — every corpus kind, edge units, adversarial mixes (raw / RLE / compressed blocks,
@@ -466,7 +490,7 @@ def test_randomized_options_bit_exact(oracle, kclib, seed):
         enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 def test_device_decoder_with_dictionary(oracle, kclib, level):
     """The device verifier with a raw-content dictionary as history (C5's configuration): frames written by the device encoder
     with WithEncoderDictRaw decode back to the source; without the dictionary they are refused (status 20), not mis-decoded."""
@@ -477,7 +501,7 @@ def test_device_decoder_with_dictionary(oracle, kclib, level):
     t = corpora.corpus("T", 4, 131072, first_unit=77).tobytes()
     units = [buf[i * 131072:(i + 1) * 131072].tobytes() for i in range(24)] + [t[:200000], t[5:40000], t[:9], b"", dct[:50000], dct, dct[100:300] * 50]
     ubuf, off = corpora.pack_units(units)
-    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderDictRaw(7, dct))
+    enc = zstd.NewWriter(None, *_lo(level), zstd.WithEncoderDictRaw(7, dct))
     d_src = torch.from_numpy(ubuf).cuda()
     cap = sum(((enc.MaxEncodedSize(len(u)) + 15) & ~15) for u in units) + 64
     d_enc = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -492,7 +516,7 @@ def test_device_decoder_with_dictionary(oracle, kclib, level):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, "1L", 2])
 def test_host_pipeline_equals_device_path(oracle, kclib, level, monkeypatch):
     """kc_zstd_encode_units above two sub-batches runs the pinned three-stage pipeline (stager / encode / drainer threads):
     its bytes must equal the device-resident path's, which the oracle pins on a sample."""
@@ -514,15 +538,16 @@ def test_host_pipeline_equals_device_path(oracle, kclib, level, monkeypatch):
     dev_off = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
     assert np.array_equal(out_off, dev_off)
     assert np.array_equal(out, d_dst[:int(dev_off[n])].cpu().numpy())
-    ref, ref_off = oracle.zstd_encode_units(buf[:int(off[64])], off[:65], threads=8, level=level)
+    ref, ref_off = oracle.zstd_encode_units(buf[:int(off[64])], off[:65], threads=8, level=_li(level))
     assert np.array_equal(out[:int(out_off[64])], ref) and np.array_equal(out_off[:65], ref_off)
-    monkeypatch.setenv("KC_HOST_SERIAL", "1")
+    from compress_amd import _lib
+    enc.ctx().set_option(_lib.OPT_HOST_SERIAL, 1)
     out2, out_off2 = enc.EncodeUnits(buf, off)
     assert np.array_equal(out2, out) and np.array_equal(out_off2, out_off)
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, "1L", 2])
 def test_host_chunk_fed_batch_equals_device_path(oracle, kclib, level, monkeypatch):
     """kc_zstd_encode_units on one device batch: the source arrives in chunks, each chunk's checksum / match finder / entropy
     stage / compaction run on the chunk's own stream behind its copy and the frames drain chunk by chunk.  Same bytes and offsets
@@ -550,17 +575,18 @@ def test_host_chunk_fed_batch_equals_device_path(oracle, kclib, level, monkeypat
     dev_off = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
     assert np.array_equal(out_off, dev_off)
     assert np.array_equal(out, d_dst[:int(dev_off[n])].cpu().numpy())
-    ref, ref_off = oracle.zstd_encode_units(buf[:int(off[64])], off[:65], threads=8, level=level)
+    ref, ref_off = oracle.zstd_encode_units(buf[:int(off[64])], off[:65], threads=8, level=_li(level))
     assert np.array_equal(out[:int(out_off[64])], ref) and np.array_equal(out_off[:65], ref_off)
     out3, out_off3 = enc.EncodeUnits(buf, off)  # buffers and events reused
     assert np.array_equal(out3, out) and np.array_equal(out_off3, out_off)
-    monkeypatch.setenv("KC_TEST_FEED_REDO", "1")  # a unit needing the speculation re-run: the batch is encoded again the plain way
+    from compress_amd import _lib
+    enc.ctx().set_option(_lib.OPT_TEST_FEED_REDO, 1)  # a unit needing the speculation re-run: the batch is encoded again the plain way
     out4, out_off4 = enc.EncodeUnits(buf, off)
     assert np.array_equal(out4, out) and np.array_equal(out_off4, out_off)
     enc.Close()
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", LEVELS)
 def test_long_units_and_streams_bit_exact(oracle, kclib, level):
     """Units and streams of more than 32 blocks (the re-run bookkeeping is per block, not a 32-bit mask per unit), longer than the
     window (matches beyond it are refused exactly like the reference's, whose history buffer has slid by then), with a small
@@ -571,8 +597,8 @@ def test_long_units_and_streams_bit_exact(oracle, kclib, level):
     t = corpora.corpus("T", 80, 131072, first_unit=300).tobytes()
     m = corpora.corpus("M", 48, 131072, first_unit=30).tobytes()
     for opts, okw in (((), {}), ((zstd.WithWindowSize(1 << 16),), {"window_size": 1 << 16})):
-        enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level), *opts)
-        ref = oracle.ZstdOracle(level=level, **okw)
+        enc = zstd.NewWriter(None, *_lo(level), *opts)
+        ref = oracle.ZstdOracle(level=_li(level), **okw)
         bs = enc.o.block_size
         units = [t[:33 * bs], t[5:5 + 70 * bs + 123], m[:40 * bs + 1], (t[:3 * bs] + m[:2 * bs]) * 8]
         ubuf, off = corpora.pack_units(units)

@@ -61,12 +61,8 @@ def test_inputs_reach_the_late_raw_fallback(oracle, level, blk, nsnip, mlen):
     assert _late_raw_pops(oracle) == 0
 
 
-_NOT_RUN_YET = pytest.mark.xfail(strict=False, reason="written when the round's GPU minutes were all but spent: the SpeedDefault case ran on "
-                                 "the device (bit-exact, re-run taken), these SpeedBetterCompression cases have not yet.  XPASS = verified")
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("level,blk,nsnip,mlen", [CASES[0]] + [pytest.param(*c, marks=_NOT_RUN_YET) for c in CASES[1:]])
+@pytest.mark.parametrize("level,blk,nsnip,mlen", CASES)
 def test_device_re_run_path_bit_exact(oracle, kclib, level, blk, nsnip, mlen):
     """GPU: the streams go through kc_zstd_encode_streams_cuts, the batch takes the re-run (redo_units >= 1) and the frames equal
     the oracle's — per-block re-run flags, irregular blocks and units of more than 32 blocks in one test."""

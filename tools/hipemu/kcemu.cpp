@@ -2,9 +2,7 @@
 // tests (tests/test_emu_lds.py).  TEST INFRASTRUCTURE: the product (libkcgpu.so) never contains or loads this.
 #include <hip/hip_runtime.h>
 #include "../../compress_amd/csrc/kc_s2_lds.hip"
-#ifdef KCEMU_WITH_ZFAST
 #include "../../compress_amd/csrc/kc_zstd_match_lds.hip"
-#endif
 
 extern "C" {
 
@@ -25,6 +23,31 @@ int kcemu_s2_encode(int level, int framed, int spec_w0, const uint8_t* src, cons
     bool small = false, big = false;
     for (uint32_t i = 0; i < n; i++) ((blk_off[i + 1] - blk_off[i]) <= 65536 ? small : big) = true;
     kc_launch_s2_encode_lds(P, small, big, nullptr);
+    return 0;
+}
+
+// the SpeedFastest match finder (kc_zfast_match_lds_kernel) over n units: packed sequences + KcBlkMeta per block
+int kcemu_zfast_parse(const uint8_t* src, const uint64_t* unit_off, uint32_t n, int block_size, int window, int hist0, int rep1, int rep2,
+                      int stream_mode, const uint32_t* proto, uint64_t* seqs, KcBlkMeta* meta, uint32_t seq_stride, const uint32_t* unit_blk0,
+                      int spec_w0, int pos_bits) {
+    KcMatchParams P;
+    memset(&P, 0, sizeof(P));
+    P.src = src;
+    P.src_end = src + unit_off[n];
+    P.unit_off = unit_off;
+    P.unit_blk0 = unit_blk0;
+    P.seqs = seqs;
+    P.meta = meta;
+    P.seq_stride = seq_stride;
+    P.block_size = block_size;
+    P.max_match_off = window;
+    P.spec_w0 = spec_w0;
+    P.hist0 = hist0;
+    P.pos_bits = pos_bits;
+    P.rep1 = rep1;
+    P.rep2 = rep2;
+    P.stream_mode = stream_mode;
+    kc_launch_zfast_match_lds(P, proto, n, nullptr);
     return 0;
 }
 
