@@ -213,10 +213,20 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
         const int W0 = P.spec_w0 < 1 ? 1 : (P.spec_w0 > 64 ? 64 : P.spec_w0);
         int W = W0;
         uint8_t* const tabB = (uint8_t*)tab;
+        uint32_t rounds = 0;
         while (!fin && !stored) {
+            if (++rounds > (uint32_t)len + 16u) { stored = true; break; }  // every round advances s: cannot happen; never spin on the device
             // ---------------- probe positions of this round: lane i = the i-th step from s ----------------
-            int p = s;
-            for (int k = 0; k + 1 < W; k++) if (k < lane) p += ((p - nextEmit) >> SKIP) + 4;
+            int p;
+            {
+                const int d0 = s - nextEmit, step0 = 4 + (d0 >> SKIP);
+                if (((d0 + (W - 1) * step0) >> SKIP) == (d0 >> SKIP)) {
+                    p = s + lane * step0;  // all W steps inside one skip segment
+                } else {
+                    p = s;
+                    for (int k = 0; k + 1 < W; k++) if (k < lane) p += ((p - nextEmit) >> SKIP) + 4;
+                }
+            }
             const int nextS = p + ((p - nextEmit) >> SKIP) + 4;
             const bool inW = lane < W;
             const bool valid = inW && nextS <= sLimit;  // a prefix of the lanes: nextS grows with the lane

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
             bool canRep = false, fin = false, pendO2 = false;
             int W = W0;
             while (!fin) {
-                rounds++;
+                if (++rounds > (uint32_t)srcLen + 16u) break;  // every round advances s: cannot happen; never spin on the device
                 // ---------------- source window (LDS ring) ----------------
                 if (pend) {  // the refill issued one round ago has landed
                     const int ro = (whi + 16 * lane) & (ZL_RB - 1);
