@@ -729,9 +729,10 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     ep.prof = nullptr;
     const bool k2prof = c->cfg.k2_prof != 0;
     if (k2prof) {
-        if ((s = ensure(c, c->prof, 32 * 8)) != KC_OK) return s;
-        HIPCHK(c, hipMemsetAsync(c->prof.p, 0, 32 * 8, st));
+        if ((s = ensure(c, c->prof, 48 * 8)) != KC_OK) return s;
+        HIPCHK(c, hipMemsetAsync(c->prof.p, 0, 48 * 8, st));
         ep.prof = (unsigned long long*)c->prof.p;
+        mp.prof = (unsigned long long*)c->prof.p + 32;
     }
 
     if (c->chain_after) HIPCHK(c, hipStreamWaitEvent(st, c->chain_after->ev[2], 0));  // pipelined contexts: one match finder at a time
@@ -874,8 +875,17 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
     c->last.total_ms += t05;
     c->last.redo_units += redo_units;
     if (k2prof) {
-        unsigned long long pv[32];
+        unsigned long long pv[48];
         HIPCHK(c, hipMemcpy(pv, c->prof.p, sizeof(pv), hipMemcpyDeviceToHost));
+        {
+            unsigned long long lt = 0;
+            for (int i = 32; i < 40; i++) lt += pv[i];
+            if (lt) {
+                fprintf(stderr, "[LDS match prof] shader clocks per phase (window, probe bytes, table, candidates issued, verdicts, commit, -, round tail):");
+                for (int i = 32; i < 40; i++) fprintf(stderr, " %.1f%%", 100.0 * (double)pv[i] / (double)lt);
+                fprintf(stderr, "  (total %.4g cycles over %u units)\n", (double)lt, n_units);
+            }
+        }
         unsigned long long tot = 0;
         for (int i = 0; i < 16; i++) tot += pv[i];
         fprintf(stderr, "[K2 prof] shader-clock share per phase:");

@@ -65,6 +65,13 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t v, int srcLane) {
     uint32_t lo = bcast32((uint32_t)v, srcLane), hi = bcast32((uint32_t)(v >> 32), srcLane);
     return ((uint64_t)hi << 32) | lo;
 }
+// Value of lane `srcLane` when srcLane is the SAME in every lane (wave-uniform): v_readlane_b32, a few cycles, and the result is
+// a scalar to the compiler — state derived from it stays in SGPRs and branches on it are scalar branches.  (bcast32/__shfl is a
+// ds_bpermute round trip and its result counts as divergent.)
+__device__ __forceinline__ uint32_t rdlane32(uint32_t v, int srcLane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, srcLane); }
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, int srcLane) {
+    return (uint64_t)rdlane32((uint32_t)v, srcLane) | ((uint64_t)rdlane32((uint32_t)(v >> 32), srcLane) << 32);
+}
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -106,7 +113,7 @@ __device__ __forceinline__ int wave_matchlen(const uint8_t* a, const uint8_t* b,
         uint64_t m = ballot64(diff != 0);
         if (m) {
             int fl = ctz64(m);
-            uint64_t d = bcast64(diff, fl);
+            uint64_t d = rdlane64(diff, fl);
             return n + 8 * fl + (ctz64(d) >> 3);
         }
         n += 8 * active;

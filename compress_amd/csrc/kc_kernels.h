@@ -27,6 +27,7 @@ struct KcMatchParams {
     int32_t pos_bits;           // bits reserved for position+1 in tagged table entries (better level)
     int32_t rep1, rep2;         // initial recentOffsets[0..1]: {1,4} unless a full-format dictionary supplies its own
     int32_t stream_mode;        // units are Write+Close streams: a unit of >= one block is parsed with Encode (history) from its first block
+    unsigned long long* prof;   // device or null: per-phase shader-clock totals of the LDS-table kernel (built with -DKC_LDS_PROF, KC_OPT_K2_PROF)
     int32_t lds_split;          // SpeedFastest HBM kernel: 1 = skip the units the LDS-table kernel takes (those that fit KC_ZFAST_LDS_MAX_UNIT)
 };
 // SpeedFastest: 8 lanes per unit, tables = n_launch x 2^15 x u32 in HBM, zeroed by the caller

@@ -115,22 +115,9 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
     }
     KC_WAVE_SYNC();
 
-    // ---- source access: LDS (aligned dwords + byte alignment) or global ----
-    auto rd32 = [&](int pos) -> uint32_t {
-        if (SRCLDS) {
-            const uint32_t* r = (const uint32_t*)(lsrc + (pos & ~3));
-            return __builtin_amdgcn_alignbyte(r[1], r[0], (uint32_t)(pos & 3));
-        }
-        return ld32(src + pos);
-    };
-    auto rd64 = [&](int pos) -> uint64_t {
-        if (SRCLDS) {
-            const uint32_t* r = (const uint32_t*)(lsrc + (pos & ~3));
-            const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], sh = (uint32_t)(pos & 3);
-            return (uint64_t)__builtin_amdgcn_alignbyte(r1, r0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(r2, r1, sh) << 32);
-        }
-        return ld64(src + pos);
-    };
+    // ---- source access: LDS or global ----
+    auto rd32 = [&](int pos) -> uint32_t { return SRCLDS ? ld32(lsrc + pos) : ld32(src + pos); };  // LDS takes unaligned ds_read_b32 / b64
+    auto rd64 = [&](int pos) -> uint64_t { return SRCLDS ? ld64(lsrc + pos) : ld64(src + pos); };
     auto rdb = [&](int pos) -> uint32_t { return SRCLDS ? (uint32_t)lsrc[pos] : (uint32_t)src[pos]; };
 
     // uvarint(len) header (encode.go:39)
@@ -175,7 +162,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
             const int firstOob = oob ? ctz64(oob) : 64;
             if (dm) {
                 const int fl = ctz64(dm);  // necessarily < firstOob
-                const uint64_t dd = bcast64(diff, fl);
+                const uint64_t dd = rdlane64(diff, fl);
                 return a + 8 * fl + (ctz64(dd) >> 3);
             }
             if (firstOob < 64) return a + 8 * firstOob;
@@ -293,18 +280,18 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
             if (!found) {
                 W = 2 * W < 64 ? 2 * W : 64;
                 if (c < nvalid) {
-                    s = (int)bcast32((uint32_t)p, c);  // the first dependent step restarts as lane 0
+                    s = (int)rdlane32((uint32_t)p, c);  // the first dependent step restarts as lane 0
                 } else if (nvalid < 64 && ((tm >> nvalid) & 1ull)) {
                     fin = true;                        // the step after the last committed one hits `nextS > sLimit`
                 } else {
-                    s = (int)bcast32((uint32_t)nextS, nvalid - 1);  // nvalid >= 1: lane 0 is valid or terminates
+                    s = (int)rdlane32((uint32_t)nextS, nvalid - 1);  // nvalid >= 1: lane 0 is valid or terminates
                 }
                 continue;
             }
             W = W0;
-            const int mkind = (int)bcast32((uint32_t)kind, f);
-            int candidate = (int)bcast32((uint32_t)cand, f);
-            const int ps = (int)bcast32((uint32_t)p, f);
+            const int mkind = (int)rdlane32((uint32_t)kind, f);
+            int candidate = (int)rdlane32((uint32_t)cand, f);
+            const int ps = (int)rdlane32((uint32_t)p, f);
             if (mkind == 1) {
                 // ---------------- repeat at s+1 (encode_all.go:336-384) ----------------
                 int base = ps + 1;

@@ -32,6 +32,16 @@
 #define ZL_TAGB 6
 #define ZL_POS_MASK ((1u << ZL_PB) - 1u)
 
+#ifdef KC_LDS_PROF  // diagnostics: shader clocks per phase of a round, summed over the launch (lane 0 of every wave)
+#define LP_DECL unsigned long long lp_t = __builtin_amdgcn_s_memtime(), lp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define LP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); lp_acc[i] += t_ - lp_t; lp_t = t_; } while (0)
+#define LP_FLUSH(ptr) do { if (lane == 0 && (ptr) != nullptr) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&(ptr)[k_], lp_acc[k_]); } while (0)
+#else
+#define LP_DECL
+#define LP(i)
+#define LP_FLUSH(ptr)
+#endif
+
 __device__ __forceinline__ uint32_t zl_tag(uint32_t v) { return (v * 2654435761u) >> (32 - ZL_TAGB); }
 __device__ __forceinline__ uint32_t zl_entry(int pos, uint32_t v) { return ((uint32_t)pos + 1u) | (zl_tag(v) << ZL_PB); }
 
@@ -75,6 +85,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
         }
     }
     KC_WAVE_SYNC();
+    LP_DECL;
 
     int o1 = P.rep1, o2 = P.rep2;  // {1,4} (blockenc.go:78) or the dictionary's offsets (enc_base.go:189-195)
     bool allDirty = false;  // fastEncoderDict.allDirty: small-input variant (kSearchStrength 7) only until a block > 32 KiB was seen
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
             int W = W0;
             while (!fin) {
                 if (++rounds > (uint32_t)srcLen + 16u) break;  // every round advances s: cannot happen; never spin on the device
+                LP(7);  // the tail of the previous round: winner broadcast, match extension, sequence emit
                 // ---------------- source window (LDS ring) ----------------
                 if (pend) {  // the refill issued one round ago has landed
                     const int ro = (whi + 16 * lane) & (ZL_RB - 1);
@@ -146,42 +158,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                     for (int k = 0; k + 1 < W; k++) if (k < lane) p += 2 + ((p - nextEmit) >> SK);
                 }
                 const bool valid = lane < W && p < sLimit;  // a prefix of the lanes
-                // R = the 20 source bytes [p-4, p+16): D1:D2 = cv, the rest feeds the fused candidate compares
-                uint32_t D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0;
-                if (valid) {
-                    const int a = p + boff - ZL_BK;
-                    const int a4 = a & ~3;
-                    if (a4 >= wlo && a4 + 24 <= whi) {
-                        const uint32_t* r = (const uint32_t*)(ring + (a4 & (ZL_RB - 1)));
-                        const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
-                        const uint32_t sh = (uint32_t)(a & 3);
-                        D0 = __builtin_amdgcn_alignbyte(r1, r0, sh);
-                        D1 = __builtin_amdgcn_alignbyte(r2, r1, sh);
-                        D2 = __builtin_amdgcn_alignbyte(r3, r2, sh);
-                        D3 = __builtin_amdgcn_alignbyte(r4, r3, sh);
-                        D4 = __builtin_amdgcn_alignbyte(r5, r4, sh);
-                    } else {
-                        const uint8_t* q = base + p - ZL_BK;
-                        if (q >= srcLo && q + 20 <= srcHi) {
-                            const uint64_t qa = ld64(q), qb = ld64(q + 8);
-                            D0 = (uint32_t)qa; D1 = (uint32_t)(qa >> 32); D2 = (uint32_t)qb; D3 = (uint32_t)(qb >> 32); D4 = ld32(q + 16);
-                        } else {
-                            D0 = zf_edge_dword(q, srcLo, srcHi); D1 = zf_edge_dword(q + 4, srcLo, srcHi); D2 = zf_edge_dword(q + 8, srcLo, srcHi);
-                            D3 = zf_edge_dword(q + 12, srcLo, srcHi); D4 = zf_edge_dword(q + 16, srcLo, srcHi);
-                        }
-                    }
-                }
-                const uint64_t cv = (uint64_t)D1 | ((uint64_t)D2 << 32);
-                // ---------------- table entries (LDS), repeat candidate, offset-2 candidate ----------------
-                uint32_t h0 = 0, h1 = 0, c0 = 0, c1 = 0;
-                if (valid) {
-                    h0 = hash6(cv, ZF_TABLE_BITS);
-                    h1 = hash6(cv >> 8, ZF_TABLE_BITS);
-                    tabB[4 * h0 + 3] = (uint8_t)lane;
-                    tabB[4 * h1 + 3] = (uint8_t)lane;
-                }
-                KC_WAVE_SYNC();
-                if (valid) { c0 = tab[h0]; c1 = tab[h1]; }
+                LP(0);  // window upkeep
+                // repeat and offset-2 candidates first: their addresses need p, o1, o2 only, their latency hides under the table lookup
                 const int repIndex = p - o1 + 2;
                 const bool repOk = valid && canRep && repIndex >= 0;
                 uint4 cr = make_uint4(0, 0, 0, 0);
@@ -202,6 +180,40 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                     if (o2Wide) co = ld128u(q);
                     else co.x = ld32(q);
                 }
+                // R = the 20 source bytes [p-4, p+16): D1:D2 = cv, the rest feeds the fused candidate compares
+                uint32_t D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0;
+                if (valid) {
+                    const int a = p + boff - ZL_BK;
+                    const int a4 = a & ~3;
+                    if (a4 >= wlo && a4 + 24 <= whi) {
+                        const uint8_t* r = ring + (a & (ZL_RB - 1));  // unaligned ds_read_b128 + b32; the mirror keeps the 20 bytes contiguous
+                        const uint4 r4 = ld128u(r);
+                        D0 = r4.x; D1 = r4.y; D2 = r4.z; D3 = r4.w;
+                        D4 = ld32(r + 16);
+                    } else {
+                        const uint8_t* q = base + p - ZL_BK;
+                        if (q >= srcLo && q + 20 <= srcHi) {
+                            const uint64_t qa = ld64(q), qb = ld64(q + 8);
+                            D0 = (uint32_t)qa; D1 = (uint32_t)(qa >> 32); D2 = (uint32_t)qb; D3 = (uint32_t)(qb >> 32); D4 = ld32(q + 16);
+                        } else {
+                            D0 = zf_edge_dword(q, srcLo, srcHi); D1 = zf_edge_dword(q + 4, srcLo, srcHi); D2 = zf_edge_dword(q + 8, srcLo, srcHi);
+                            D3 = zf_edge_dword(q + 12, srcLo, srcHi); D4 = zf_edge_dword(q + 16, srcLo, srcHi);
+                        }
+                    }
+                }
+                const uint64_t cv = (uint64_t)D1 | ((uint64_t)D2 << 32);
+                LP(1);  // positions, repeat / offset-2 loads issued, probe bytes read
+                // ---------------- table entries (LDS) ----------------
+                uint32_t h0 = 0, h1 = 0, c0 = 0, c1 = 0;
+                if (valid) {
+                    h0 = hash6(cv, ZF_TABLE_BITS);
+                    h1 = hash6(cv >> 8, ZF_TABLE_BITS);
+                    tabB[4 * h0 + 3] = (uint8_t)lane;
+                    tabB[4 * h1 + 3] = (uint8_t)lane;
+                }
+                KC_WAVE_SYNC();
+                if (valid) { c0 = tab[h0]; c1 = tab[h1]; }
+                LP(2);  // hashes, markers, table entries
                 // candidates: one 16-byte load of [t-4, t+12) each, only where the tag matches
                 const uint32_t e0 = c0 & ZL_POS_MASK, e1 = c1 & ZL_POS_MASK;
                 const int t0 = (int)e0 - 1, t1 = (int)e1 - 1;
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                         const int fk = f < limit ? f : limit;
                         pk = (f >= 4 ? 1u : 0u) | (done ? 2u : 0u) | ((uint32_t)fk << 8);
                     }
-                    pk = bcast32(pk, 0);
+                    pk = rdlane32(pk, 0);
                     if (pk & 1u) {
                         int l2 = (int)(pk >> 8);
                         if (!(pk & 2u)) l2 += wave_matchlen(base + s + l2, base + o2pos + l2, blkEnd - (s + l2), lane);
@@ -257,6 +269,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                         continue;  // the speculative probes of this round are dropped (nothing was committed)
                     }
                 }
+                LP(3);  // candidate loads issued, offset-2 verdict
                 // steps of this round that share a bucket
                 const uint32_t m0 = c0 >> 24, m1 = c1 >> 24;
                 const bool lost = valid && (m0 != (uint32_t)lane || m1 != (uint32_t)lane);
@@ -298,6 +311,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                     const int fk = fwd < limit ? fwd : limit;
                     vk = (uint32_t)kind | (done ? 4u : 0u) | ((uint32_t)fk << 3) | ((uint32_t)back << 8) | ((uint32_t)ba << 11);
                 }
+                LP(4);  // bucket sharing, per-lane verdicts (waits for the candidate bytes)
                 const uint64_t vm = ballot64(valid);
                 const uint64_t depm = ballot64(valid && dep);
                 const uint64_t hm = ballot64(kind != 0);
@@ -312,24 +326,25 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                     tab[h1] = zl_entry(p + 1, (uint32_t)(cv >> 8));  // program order: wins when h0 == h1
                 }
                 KC_WAVE_SYNC();
+                LP(5);  // ballots, commit
                 if (!found) {
                     W = 2 * W < 64 ? 2 * W : 64;
                     if (c < nvalid) {
-                        s = (int)bcast32((uint32_t)p, c);
+                        s = (int)rdlane32((uint32_t)p, c);
                     } else {
-                        const int pl = (int)bcast32((uint32_t)p, nvalid - 1);  // nvalid >= 1: s < sLimit inside the loop
+                        const int pl = (int)rdlane32((uint32_t)p, nvalid - 1);  // nvalid >= 1: s < sLimit inside the loop
                         s = pl + 2 + ((pl - nextEmit) >> SK);
                     }
                     if (s >= sLimit) fin = true;
                     continue;
                 }
-                const uint32_t wk = bcast32(vk, f);
+                const uint32_t wk = rdlane32(vk, f);
                 const int mk = (int)(wk & 3u);
                 const bool fdone = (wk & 4u) != 0;
                 const int fk = (int)((wk >> 3) & 31u);
                 const int bke = (int)((wk >> 8) & 7u), bav = (int)((wk >> 11) & 7u);
-                const int ps = (int)bcast32((uint32_t)p, f);
-                int mt = (int)bcast32((uint32_t)t, f);
+                const int ps = (int)rdlane32((uint32_t)p, f);
+                int mt = (int)rdlane32((uint32_t)t, f);
                 // backward extension given the bke equal bytes found among the bav bytes examined (enc_fast.go:152-157, 230-234)
                 auto backlen = [&](int sp, int tp, int kmax) -> int {
                     if (kmax <= 0) return 0;
@@ -409,6 +424,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
             P.meta[blk0 + (uint32_t)b] = m;
         }
     }
+    LP_FLUSH(P.prof);
 }
 
 void kc_launch_zfast_match_lds(const KcMatchParams& P, const uint32_t* proto, uint32_t n_launch, hipStream_t st) {

@@ -28,7 +28,7 @@ def _lo(level):
         return [zstd.WithEncoderLevel(1), zstd.WithMatchPath("lds")]
     if level == 1:
         return [zstd.WithEncoderLevel(1), zstd.WithMatchPath("hbm")]
-    return [*_lo(level)]
+    return [zstd.WithEncoderLevel(level)]
 
 
 def _enc(level=1, **kw):

@@ -89,6 +89,7 @@ static inline int __shfl_xor(int v, int m, int width = 64) {
 }
 static inline void __syncthreads() { hipemu::block_sync(); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)hipemu::first_lane64((uint32_t)v); }
+static inline int __builtin_amdgcn_readlane(int v, int src) { return (int)(uint32_t)hipemu::shfl64((uint32_t)v, src & 63); }
 static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }
 static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3)));
