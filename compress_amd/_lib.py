@@ -30,7 +30,7 @@ class ZstdOpts(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("match_ms", C.c_float), ("entropy_ms", C.c_float), ("other_ms", C.c_float),
-                ("redo_units", C.c_uint32)]
+                ("redo_units", C.c_uint32), ("prep_ms", C.c_float)]
 
 
 # every symbol include/kcgpu.h declares (checked by tests/test_abi.py)
@@ -207,7 +207,7 @@ class Context:
         t = Timings()
         self.check(self.L.kc_last_timings(self.h, C.byref(t)))
         return {"total_ms": t.total_ms, "match_ms": t.match_ms, "entropy_ms": t.entropy_ms, "other_ms": t.other_ms,
-                "redo_units": t.redo_units}
+                "redo_units": t.redo_units, "prep_ms": t.prep_ms}
 
 
 def corpus_fill(kind, seed, first_unit, n_units, unit_size, threads=None):

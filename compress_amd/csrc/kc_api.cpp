@@ -87,8 +87,8 @@ struct Plan {
 // include/kcgpu.h (kc_option); changed afterwards only through kc_ctx_set_option.  No entry point reads the environment.
 struct KcCfg {
     int64_t match_path = KC_PATH_AUTO;
-    int64_t zfast_lds_max_units = 1024;   // auto: SpeedFastest batches up to this many units take the LDS-table kernel (profiles/r03_crossover_zfast.csv)
-    int64_t s2_lds_max_blocks = 1024;     // auto: s2.Encode / EncodeSnappy batches up to this many blocks (profiles/r03_crossover_s2.csv)
+    int64_t zfast_lds_max_units = 768;    // auto: SpeedFastest batches up to this many units take the LDS-table kernel (profiles/r03_crossover_zfast.csv)
+    int64_t s2_lds_max_blocks = 768;      // auto: s2.Encode / EncodeSnappy batches up to this many blocks (profiles/r03_crossover_s2.csv)
     int64_t spec_w0 = -1, spec_grow = -1; // HBM-table kernels: speculation width after a match / growth policy; -1 = the per-level defaults
     int64_t lds_spec_w0 = 16;             // LDS-table kernels: probe steps per round after a match (doubles on a miss up to 64)
     int64_t host_serial = 0, host_pipe_mib = 0, host_overlap_min_mib = -1, host_copy_threads = 0, host_trace = 0;
@@ -109,8 +109,8 @@ struct kc_ctx {
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
         predef, errflag, tmp_src, tmp_dst, tables, prof, work, work_off, dictbuf, proto, dicthuf;
     bool predef_ready = false;
-    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [6]: batch prepared (chunk-fed launches wait on it)
-    kc_timings last = {0, 0, 0, 0, 0};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [6]: batch prepared (chunk-fed launches wait on it); [7]: tables prepared
+    kc_timings last = {0, 0, 0, 0, 0, 0};
     size_t max_batch_bytes = (size_t)8 << 30;  // input bytes per device batch (scratch is ~6x this for full-size units)
     uint64_t max_scratch_bytes = (uint64_t)160 << 30;  // scratch per device batch (tables + per-block strides), further capped by the free device memory
     int stream_mode = 0;             // set for the duration of kc_zstd_encode_streams_dev
@@ -126,6 +126,7 @@ struct kc_ctx {
     Plan plan;                       // layout arrays of the batch in flight (sources of asynchronous H2D copies)
     std::once_flag hook_once;        // kc_s2_encode_block: micro-batcher of concurrent callers (S2Hook), created on first use
     void* hook = nullptr;
+    bool ev7_valid = false;          // ev[7] was recorded for the batch in flight
     int last_path = 0;               // KC_PATH_HBM / KC_PATH_LDS: what the last batch's match finder / S2 encoder ran on
 };
 
@@ -516,6 +517,8 @@ kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_
     (void)unit_off; (void)n_units; (void)bs;
     kc_status s = prepare_tables(c, mp, n_launch, st, level);
     if (s != KC_OK) return s;
+    HIPCHK(c, hipEventRecord(c->ev[7], st));
+    c->ev7_valid = true;
     launch_match_kernel(c, mp, 0, n_launch, st, level, zfast_use_lds(c, mp, n_launch, level));
     return KC_OK;
 }
@@ -868,6 +871,11 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
     (void)hipEventElapsedTime(&t34, c->ev[3], c->ev[4]);
     (void)hipEventElapsedTime(&t45, c->ev[4], c->ev[5]);
     (void)hipEventElapsedTime(&t05, c->ev[0], c->ev[5]);
+    if (c->ev7_valid) {  // (the speculation re-run records it again: then it brackets the re-run's preparation, a few units)
+        float t17 = 0;
+        if (hipEventElapsedTime(&t17, c->ev[1], c->ev[7]) == hipSuccess && t17 >= 0 && t17 <= t12) c->last.prep_ms += t17;
+        c->ev7_valid = false;
+    }
     tk2 = t23;
     c->last.match_ms += t12;       // all match-finder launches (with overlap: includes time shared with entropy kernels)
     c->last.entropy_ms += tk2;     // first to last entropy launch on its stream
@@ -967,7 +975,7 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
                                    uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off) {
     if (!c || !o || !unit_off || !out_off || (n_units && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
     c->err.clear();
-    c->last = kc_timings{0, 0, 0, 0, 0};
+    c->last = kc_timings{0, 0, 0, 0, 0, 0};
     kc_status s = check_supported(c, o);
     if (s != KC_OK) return s;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1032,7 +1040,7 @@ kc_status kc_zstd_encode_units_dev_begin(kc_ctx* c, const kc_zstd_opts* o, const
                                          uint8_t* d_dst, uint64_t dst_cap) {
     if (!c || !o || !unit_off || n_units == 0 || !d_src || !d_dst) return KC_ERR_BAD_ARG;
     c->err.clear();
-    c->last = kc_timings{0, 0, 0, 0, 0};
+    c->last = kc_timings{0, 0, 0, 0, 0, 0};
     kc_status s = check_supported(c, o);
     if (s != KC_OK) return s;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1389,7 +1397,7 @@ kc_status host_chunk_fed(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off
     };
     std::vector<uint64_t> rel(n_units + 1);
     for (uint32_t i = 0; i <= n_units; i++) rel[i] = unit_off[i] - base0;
-    c->last = kc_timings{0, 0, 0, 0, 0};
+    c->last = kc_timings{0, 0, 0, 0, 0, 0};
     s = enq(feed, (const uint8_t*)d_in, (const uint64_t*)rel.data(), (uint8_t*)c->tmp_dst.p);
     { std::lock_guard<std::mutex> lk(m); }
     stager.join();  // enq returns after the last chunk was staged, or early on an error (then the stager runs out on its own buffers)
@@ -1739,7 +1747,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     if (feed && (framed || n == 0)) { c->err = "chunk feed: bare blocks only"; return KC_ERR_INTERNAL; }
     if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BETTER) { c->err = "device path implements s2.Encode, s2.EncodeBetter, s2.EncodeSnappy and s2.EncodeSnappyBetter"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
-    c->last = kc_timings{0, 0, 0, 0, 0};
+    c->last = kc_timings{0, 0, 0, 0, 0, 0};
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t lead = (framed && with_stream_id) ? 10 : 0;
     if (lead) {

@@ -270,6 +270,7 @@ typedef struct {
     float entropy_ms; /* histogram + table build + bitstream emit kernel(s) */
     float other_ms;   /* checksum, scan, compaction */
     uint32_t redo_units; /* units re-run because a speculated block verdict was wrong */
+    float prep_ms;    /* part of match_ms: zeroing / dictionary-priming of the per-unit hash tables before the match finder */
 } kc_timings;
 kc_status kc_last_timings(const kc_ctx* ctx, kc_timings* t);
 

@@ -10,17 +10,25 @@ import "C"
 
 import (
 	"errors"
+	"sync"
 	"unsafe"
+
+	"github.com/klauspost/compress/s2"
 )
 
-type Ctx struct{ c *C.kc_ctx }
+// Ctx wraps one kc_ctx.  CustomEncoder's function is safe for any number of goroutines (the library micro-batches concurrent
+// callers); the batched forms hold mu (one device batch per context at a time).
+type Ctx struct {
+	c  *C.kc_ctx
+	mu sync.Mutex
+}
 
 func NewCtx(device int) (*Ctx, error) {
 	var c *C.kc_ctx
 	if st := C.kc_ctx_create(&c, C.int(device), nil); st != C.KC_OK {
 		return nil, errors.New("no MI355X device")
 	}
-	return &Ctx{c}, nil
+	return &Ctx{c: c}, nil
 }
 
 func (x *Ctx) Close() { C.kc_ctx_destroy(x.c) }
@@ -54,10 +62,30 @@ func EncodeBlocks(x *Ctx, src []byte, off []uint64, dst []byte) ([]byte, []uint6
 func EncodeBlocksLevel(x *Ctx, level int, src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
 	n := len(off) - 1
 	outOff := make([]uint64, n+1)
+	if n == 0 {
+		return dst[:0], outOff, nil
+	}
+	x.mu.Lock()
 	st := C.kc_s2_encode_blocks_lvl(x.c, C.int(level), (*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
 		(*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
+	var msg string
 	if st != C.KC_OK {
-		return nil, nil, errors.New(C.GoString(C.kc_last_error(x.c)))
+		msg = C.GoString(C.kc_last_error(x.c))
 	}
-	return dst[:outOff[n]], outOff, nil
+	x.mu.Unlock()
+	if st == C.KC_OK {
+		return dst[:outOff[n]], outOff, nil
+	}
+	if st != C.KC_ERR_UNSUPPORTED && st != C.KC_ERR_NO_DEVICE {
+		return nil, nil, errors.New(msg)
+	}
+	// not served by the device (block above 4 MiB, device memory exhausted, ...): the reference encoder, same bytes
+	enc := [...]func(dst, src []byte) []byte{s2.Encode, s2.EncodeBetter, s2.EncodeSnappy, s2.EncodeSnappyBetter}[level]
+	out := dst[:0]
+	for i := 0; i < n; i++ {
+		outOff[i] = uint64(len(out))
+		out = append(out, enc(nil, src[off[i]:off[i+1]])...)
+	}
+	outOff[n] = uint64(len(out))
+	return out, outOff, nil
 }

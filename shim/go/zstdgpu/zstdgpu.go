@@ -15,6 +15,8 @@ import (
 	"bytes"
 	"errors"
 	"io"
+	"runtime"
+	"sync"
 	"unsafe"
 
 	"github.com/klauspost/compress/zstd"
@@ -23,13 +25,88 @@ import (
 // Option mirrors zstd.EOption for the options that change output bytes.
 type Option func(e *Encoder) error
 
+// DefaultDeviceMinBytes is the call size from which the device path is taken.  Below it the reference encoder on the host cores
+// is faster: one 128 KiB unit takes ~0.3 ms on a CPU core and ~16 ms on the device (LDS-table kernel, profiles/r03_latency*.json),
+// a batch of 4096 units ~70 ms on either (16 host cores vs profiles/r03_crossover_zfast.csv), and from there on the device wins.
+const DefaultDeviceMinBytes = 512 << 20
+
+// writerBufferCap bounds what a Writer holds before it gives up on the device and streams through the reference encoder.
+const writerBufferCap = 1 << 30
+
+// Encoder is safe for concurrent use like (*zstd.Encoder).EncodeAll (zstd/encoder.go:90-99, 722-729: every call takes an
+// encoder state from a channel of `concurrent` states): every call here takes a kc_ctx from a pool of the same size
+// (WithEncoderConcurrency, default GOMAXPROCS); contexts are created on first use and returned after the call.
 type Encoder struct {
-	ctx     *C.kc_ctx
-	opts    C.kc_zstd_opts
-	cpuOpts []zstd.EOption
-	cpu     *zstd.Encoder
-	dictMem unsafe.Pointer // C copy of the dictionary (kc_zstd_opts.dict points into it)
+	device   int
+	opts     C.kc_zstd_opts
+	cpuOpts  []zstd.EOption
+	cpu      *zstd.Encoder  // EncodeAll on it is concurrency-safe; streaming use goes through refMu
+	refMu    sync.Mutex
+	dictMem  unsafe.Pointer // C copy of the dictionary (kc_zstd_opts.dict points into it)
+	conc     int
+	minBytes int
+	pool     chan *C.kc_ctx // idle contexts
+	poolMu   sync.Mutex
+	created  int  // contexts created so far (<= conc)
+	noDevice bool // kc_ctx_create failed once: reference only
 }
+
+// WithEncoderConcurrency mirrors zstd.WithEncoderConcurrency: how many calls may be in flight on this Encoder (device
+// contexts in the pool, and the reference encoder's own concurrency).
+func WithEncoderConcurrency(n int) Option {
+	return func(e *Encoder) error {
+		if n <= 0 {
+			return errors.New("concurrency must be at least 1")
+		}
+		e.cpuOpts = append(e.cpuOpts, zstd.WithEncoderConcurrency(n))
+		e.conc = n
+		return nil
+	}
+}
+
+// WithDeviceMinBytes sets the call size (sum of the unit lengths) from which the device path is taken; smaller calls go to the
+// reference encoder, which gives the same bytes faster at that size.  0 sends everything to the device (tests).
+func WithDeviceMinBytes(n int) Option {
+	return func(e *Encoder) error {
+		e.minBytes = n
+		return nil
+	}
+}
+
+// acquire returns a context for one call, or nil when this call should use the reference encoder (no device).
+func (e *Encoder) acquire() *C.kc_ctx {
+	select {
+	case c := <-e.pool:
+		return c
+	default:
+	}
+	e.poolMu.Lock()
+	if e.noDevice {
+		e.poolMu.Unlock()
+		return nil
+	}
+	if e.created < e.conc {
+		var c *C.kc_ctx
+		if st := C.kc_ctx_create(&c, C.int(e.device), nil); st != C.KC_OK {
+			e.noDevice = e.created == 0
+			e.poolMu.Unlock()
+			if e.noDevice {
+				return nil
+			}
+			return <-e.pool
+		}
+		e.created++
+		e.poolMu.Unlock()
+		return c
+	}
+	e.poolMu.Unlock()
+	return <-e.pool // all contexts busy: wait like a caller of EncodeAll waits for an encoder state
+}
+
+func (e *Encoder) release(c *C.kc_ctx) { e.pool <- c }
+
+// useDevice: the routing rule of every entry point.
+func (e *Encoder) useDevice(total int) bool { return total >= e.minBytes }
 
 func WithEncoderLevel(l zstd.EncoderLevel) Option {
 	return func(e *Encoder) error {
@@ -116,7 +193,7 @@ func boolInt(b bool) C.int {
 // New creates an encoder bound to GPU `device`. If no device is present the encoder still works
 // through the reference implementation.
 func New(device int, opts ...Option) (*Encoder, error) {
-	e := &Encoder{}
+	e := &Encoder{device: device, conc: runtime.GOMAXPROCS(0), minBytes: DefaultDeviceMinBytes}
 	C.kc_zstd_opts_default(&e.opts)
 	for _, o := range opts {
 		if err := o(e); err != nil {
@@ -128,17 +205,18 @@ func New(device int, opts ...Option) (*Encoder, error) {
 		return nil, err
 	}
 	e.cpu = cpu
-	if st := C.kc_ctx_create(&e.ctx, C.int(device), nil); st != C.KC_OK {
-		e.ctx = nil // CPU only
-	}
+	e.pool = make(chan *C.kc_ctx, e.conc)
 	return e, nil
 }
 
+// Close releases the device contexts.  No call may be in flight.
 func (e *Encoder) Close() {
-	if e.ctx != nil {
-		C.kc_ctx_destroy(e.ctx)
-		e.ctx = nil
+	e.poolMu.Lock()
+	for e.created > 0 {
+		C.kc_ctx_destroy(<-e.pool)
+		e.created--
 	}
+	e.poolMu.Unlock()
 	if e.dictMem != nil {
 		C.free(e.dictMem)
 		e.dictMem = nil
@@ -153,6 +231,9 @@ func (e *Encoder) MaxEncodedSize(size int) int {
 
 // EncodeAll == (*zstd.Encoder).EncodeAll for one unit (prefer EncodeUnits).
 func (e *Encoder) EncodeAll(src, dst []byte) []byte {
+	if !e.useDevice(len(src)) {
+		return e.cpu.EncodeAll(src, dst) // one unit: the reference encoder is faster (and concurrency-safe)
+	}
 	out, _, err := e.EncodeUnits(src, []uint64{0, uint64(len(src))}, nil)
 	if err != nil {
 		return e.cpu.EncodeAll(src, dst)
@@ -173,18 +254,25 @@ func (e *Encoder) EncodeStreams(src []byte, off []uint64, dst []byte) ([]byte, [
 	}
 	dst = dst[:cap(dst)]
 	outOff := make([]uint64, n+1)
-	if e.ctx != nil && n > 0 && len(src) > 0 {
-		st := C.kc_zstd_encode_streams(e.ctx, &e.opts,
+	var ctx *C.kc_ctx
+	if n > 0 && len(src) > 0 && e.useDevice(int(off[n]-off[0])) {
+		ctx = e.acquire()
+	}
+	if ctx != nil {
+		defer e.release(ctx)
+		st := C.kc_zstd_encode_streams(ctx, &e.opts,
 			(*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
 			(*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
 		if st == C.KC_OK {
 			return dst[:outOff[n]], outOff, nil
 		}
 		if st != C.KC_ERR_UNSUPPORTED && st != C.KC_ERR_NO_DEVICE {
-			return nil, nil, errors.New(C.GoString(C.kc_last_error(e.ctx)))
+			return nil, nil, errors.New(C.GoString(C.kc_last_error(ctx)))
 		}
 	}
-	// reference path: a fresh stream per unit
+	// reference path: a fresh stream per unit (the streaming state of e.cpu is one at a time)
+	e.refMu.Lock()
+	defer e.refMu.Unlock()
 	var sink bytes.Buffer
 	for i := 0; i < n; i++ {
 		outOff[i] = uint64(sink.Len())
@@ -222,8 +310,13 @@ func (e *Encoder) EncodeStreamsCuts(src []byte, off []uint64, flushAt [][]uint64
 	}
 	dst = dst[:cap(dst)]
 	outOff := make([]uint64, n+1)
-	if e.ctx != nil && n > 0 && len(src) > 0 {
-		st := C.kc_zstd_encode_streams_cuts(e.ctx, &e.opts,
+	var ctx *C.kc_ctx
+	if n > 0 && len(src) > 0 && e.useDevice(int(off[n]-off[0])) {
+		ctx = e.acquire()
+	}
+	if ctx != nil {
+		defer e.release(ctx)
+		st := C.kc_zstd_encode_streams_cuts(ctx, &e.opts,
 			(*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
 			(*C.uint64_t)(unsafe.Pointer(&cutOff[0])), (*C.uint64_t)(unsafe.Pointer(&cuts[0])),
 			(*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
@@ -231,10 +324,12 @@ func (e *Encoder) EncodeStreamsCuts(src []byte, off []uint64, flushAt [][]uint64
 			return dst[:outOff[n]], outOff, nil
 		}
 		if st != C.KC_ERR_UNSUPPORTED && st != C.KC_ERR_NO_DEVICE {
-			return nil, nil, errors.New(C.GoString(C.kc_last_error(e.ctx)))
+			return nil, nil, errors.New(C.GoString(C.kc_last_error(ctx)))
 		}
 	}
 	// reference path: a fresh stream per unit, Flush at the recorded positions
+	e.refMu.Lock()
+	defer e.refMu.Unlock()
 	var sink bytes.Buffer
 	for i := 0; i < n; i++ {
 		outOff[i] = uint64(sink.Len())
@@ -278,15 +373,20 @@ func (e *Encoder) EncodeUnits(src []byte, off []uint64, dst []byte) ([]byte, []u
 	}
 	dst = dst[:cap(dst)]
 	outOff := make([]uint64, n+1)
-	if e.ctx != nil && n > 0 && len(src) > 0 {
-		st := C.kc_zstd_encode_units(e.ctx, &e.opts,
+	var ctx *C.kc_ctx
+	if n > 0 && len(src) > 0 && e.useDevice(int(off[n]-off[0])) {
+		ctx = e.acquire()
+	}
+	if ctx != nil {
+		defer e.release(ctx)
+		st := C.kc_zstd_encode_units(ctx, &e.opts,
 			(*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
 			(*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), (*C.uint64_t)(unsafe.Pointer(&outOff[0])))
 		if st == C.KC_OK {
 			return dst[:outOff[n]], outOff, nil
 		}
 		if st != C.KC_ERR_UNSUPPORTED && st != C.KC_ERR_NO_DEVICE {
-			return nil, nil, errors.New(C.GoString(C.kc_last_error(e.ctx)))
+			return nil, nil, errors.New(C.GoString(C.kc_last_error(ctx)))
 		}
 	}
 	// reference path
@@ -303,15 +403,18 @@ func (e *Encoder) EncodeUnits(src []byte, off []uint64, dst []byte) ([]byte, []u
 //
 //	enc, _ := zstd.NewWriter(w, opts...); enc.Write(p) ...; enc.Close()
 //
-// (zstd/encoder.go:140-253, 567-649).  The device encodes whole streams (kc_zstd_encode_streams: the bytes equal what the
-// reference writes for Write(everything) + Close()), so Write only buffers and Close submits.  Anything the device path does
-// not serve — a mid-stream Flush (the caller wants the bytes now, encoder.go:547), streams longer than 1 GiB, dictionaries on the
-// streaming path — is handed to a reference encoder with the same options; the bytes on w are the reference's either way.
+// (zstd/encoder.go:140-253, 567-649).  One stream is one device unit, parsed by one wave: the device only pays with many units
+// per call, so a Writer goes to the device only when the caller lowers WithDeviceMinBytes below the stream's size (tests, or a
+// future job mode); by default Write streams straight through a reference encoder with the same options.  On the device path
+// Write buffers (up to 1 GiB, then the stream continues on the reference encoder), a Write followed by ReadFrom and every Flush
+// are recorded as block cuts, and Close submits the stream through kc_zstd_encode_streams_cuts.  The bytes on w are the
+// reference's either way.
 type Writer struct {
 	e      *Encoder
 	w      io.Writer
 	buf    []byte
-	ref    *zstd.Encoder // set once the stream fell back to the reference encoder
+	cuts   []uint64      // bytes written when a block was ended early (Flush; ReadFrom after Write)
+	ref    *zstd.Encoder // set once the stream goes through the reference encoder
 	closed bool
 }
 
@@ -321,15 +424,25 @@ func NewWriter(w io.Writer, device int, opts ...Option) (*Writer, error) {
 	if err != nil {
 		return nil, err
 	}
-	return &Writer{e: e, w: w}, nil
+	x := &Writer{e: e, w: w}
+	if e.minBytes > writerBufferCap {
+		if err := x.fallback(); err != nil { // no stream this Writer can hold reaches the device threshold
+			return nil, err
+		}
+	}
+	return x, nil
 }
 
 // Reset discards the state and starts a new stream on w (encoder.go:103).
 func (x *Writer) Reset(w io.Writer) {
-	x.w, x.buf, x.closed = w, x.buf[:0], false
+	x.w, x.buf, x.cuts, x.closed = w, x.buf[:0], x.cuts[:0], false
 	x.ref = nil
+	if x.e.minBytes > writerBufferCap {
+		_ = x.fallback()
+	}
 }
 
+// fallback moves the stream to a reference encoder, replaying what was buffered with its block cuts.
 func (x *Writer) fallback() error {
 	if x.ref == nil {
 		r, err := zstd.NewWriter(x.w, x.e.cpuOpts...)
@@ -337,12 +450,24 @@ func (x *Writer) fallback() error {
 			return err
 		}
 		x.ref = r
-		if len(x.buf) > 0 {
-			if _, err := r.Write(x.buf); err != nil {
+		pos := uint64(0)
+		for _, c := range x.cuts {
+			if c > pos {
+				if _, err := r.Write(x.buf[pos:c]); err != nil {
+					return err
+				}
+				pos = c
+			}
+			if err := r.Flush(); err != nil {
 				return err
 			}
-			x.buf = x.buf[:0]
 		}
+		if uint64(len(x.buf)) > pos {
+			if _, err := r.Write(x.buf[pos:]); err != nil {
+				return err
+			}
+		}
+		x.buf, x.cuts = x.buf[:0], x.cuts[:0]
 	}
 	return nil
 }
@@ -351,6 +476,11 @@ func (x *Writer) Write(p []byte) (int, error) {
 	if x.closed {
 		return 0, zstd.ErrEncoderClosed
 	}
+	if x.ref == nil && len(x.buf)+len(p) > writerBufferCap {
+		if err := x.fallback(); err != nil {
+			return 0, err
+		}
+	}
 	if x.ref != nil {
 		return x.ref.Write(p)
 	}
@@ -358,8 +488,18 @@ func (x *Writer) Write(p []byte) (int, error) {
 	return len(p), nil
 }
 
-// ReadFrom mirrors (*zstd.Encoder).ReadFrom (encoder.go:444).
+// ReadFrom mirrors (*zstd.Encoder).ReadFrom (encoder.go:444-480): it first ends the block being filled (:453-458), so bytes
+// written before it and bytes read by it never share a block.
 func (x *Writer) ReadFrom(r io.Reader) (int64, error) {
+	if x.closed {
+		return 0, zstd.ErrEncoderClosed
+	}
+	if x.ref != nil {
+		return x.ref.ReadFrom(r)
+	}
+	if len(x.buf) > 0 {
+		x.cuts = append(x.cuts, uint64(len(x.buf)))
+	}
 	var n int64
 	chunk := make([]byte, 1<<20)
 	for {
@@ -379,7 +519,8 @@ func (x *Writer) ReadFrom(r io.Reader) (int64, error) {
 	}
 }
 
-// Flush (encoder.go:547) ends the current block early: not a device-path shape; the stream continues on the reference encoder.
+// Flush (encoder.go:547) ends the current block early.  The caller wants the bytes on w now: the stream continues on the
+// reference encoder (the cut is replayed there).
 func (x *Writer) Flush() error {
 	if err := x.fallback(); err != nil {
 		return err
@@ -393,10 +534,15 @@ func (x *Writer) Close() error {
 		return nil
 	}
 	x.closed = true
+	if x.ref == nil && !x.e.useDevice(len(x.buf)) {
+		if err := x.fallback(); err != nil {
+			return err
+		}
+	}
 	if x.ref != nil {
 		return x.ref.Close()
 	}
-	out, _, err := x.e.EncodeStreams(x.buf, []uint64{0, uint64(len(x.buf))}, nil)
+	out, _, err := x.e.EncodeStreamsCuts(x.buf, []uint64{0, uint64(len(x.buf))}, [][]uint64{x.cuts}, nil)
 	if err != nil {
 		return err
 	}

@@ -2,6 +2,8 @@ package zstdgpu
 
 import (
 	"bytes"
+	"io"
+	"sync"
 	"crypto/sha256"
 	"encoding/hex"
 	"fmt"
@@ -46,7 +48,7 @@ func TestBitExact(t *testing.T) {
 	more, _ := filepath.Glob("../../../tests/golden/ref_inputs/*")
 	files = append(files, more...)
 	for _, lvl := range levels {
-		gpu, err := New(0, WithEncoderLevel(lvl))
+		gpu, err := New(0, WithDeviceMinBytes(0), WithEncoderLevel(lvl))
 		if err != nil {
 			t.Fatal(err)
 		}
@@ -80,7 +82,7 @@ func TestBitExactDict(t *testing.T) {
 	}
 	data, _ := kcgpu.CorpusFill('M', kcgpu.SeedM, 0, 64, 128<<10)
 	for _, lvl := range levels {
-		gpu, err := New(0, WithEncoderLevel(lvl), WithEncoderDictRaw(1, raw))
+		gpu, err := New(0, WithDeviceMinBytes(0), WithEncoderLevel(lvl), WithEncoderDictRaw(1, raw))
 		if err != nil {
 			t.Fatal(err)
 		}
@@ -95,7 +97,7 @@ func TestBitExactDict(t *testing.T) {
 		t.Skip("d0.dict fixture not found")
 	}
 	for _, lvl := range levels {
-		gpu, err := New(0, WithEncoderLevel(lvl), WithEncoderDict(full))
+		gpu, err := New(0, WithDeviceMinBytes(0), WithEncoderLevel(lvl), WithEncoderDict(full))
 		if err != nil {
 			t.Fatal(err)
 		}
@@ -113,7 +115,7 @@ func TestBitExactStreams(t *testing.T) {
 		t.Fatal(err)
 	}
 	for _, lvl := range levels {
-		gpu, err := New(0, WithEncoderLevel(lvl))
+		gpu, err := New(0, WithDeviceMinBytes(0), WithEncoderLevel(lvl))
 		if err != nil {
 			t.Fatal(err)
 		}
@@ -145,7 +147,7 @@ func TestBitExactStreamsFlush(t *testing.T) {
 		t.Fatal(err)
 	}
 	for _, lvl := range levels {
-		gpu, err := New(0, WithEncoderLevel(lvl))
+		gpu, err := New(0, WithDeviceMinBytes(0), WithEncoderLevel(lvl))
 		if err != nil {
 			t.Fatal(err)
 		}
@@ -200,7 +202,7 @@ func TestWriterDropIn(t *testing.T) {
 		for _, flushAt := range []int{-1, 300000} {
 			var want, got bytes.Buffer
 			ref, _ := zstd.NewWriter(&want, zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(1))
-			gw, err := NewWriter(&got, 0, WithEncoderLevel(lvl))
+			gw, err := NewWriter(&got, 0, WithDeviceMinBytes(0), WithEncoderLevel(lvl))
 			if err != nil {
 				t.Fatal(err)
 			}
@@ -312,4 +314,108 @@ func writeGolden(t *testing.T, path string, lines map[string]string) {
 	if err := os.WriteFile(path, b.Bytes(), 0o644); err != nil {
 		t.Fatal(err)
 	}
+}
+
+
+// TestConcurrentEncodeAll: (*zstd.Encoder).EncodeAll is safe for concurrent use on ONE encoder (zstd/encoder.go:90-99, 722-729);
+// so is the drop-in: 32 goroutines share one Encoder (4 device contexts in its pool) and every frame equals the reference's.
+// Run with -race.
+func TestConcurrentEncodeAll(t *testing.T) {
+	data := corpusT(8 << 20)
+	gpu, err := New(0, WithDeviceMinBytes(0), WithEncoderLevel(zstd.SpeedFastest), WithEncoderConcurrency(4))
+	if err != nil {
+		t.Fatal(err)
+	}
+	defer gpu.Close()
+	ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(zstd.SpeedFastest))
+	var wg sync.WaitGroup
+	errs := make(chan string, 64)
+	for g := 0; g < 32; g++ {
+		wg.Add(1)
+		go func(g int) {
+			defer wg.Done()
+			for k := 0; k < 4; k++ {
+				lo := ((g*4 + k) * 37 << 10) % (len(data) - (256 << 10))
+				unit := data[lo : lo+(64<<10)+g*1000]
+				if g%2 == 0 { // a batch through EncodeUnits
+					off := cut(unit, 32<<10)
+					out, oo, err := gpu.EncodeUnits(unit, off, nil)
+					if err != nil {
+						errs <- err.Error()
+						return
+					}
+					for i := 0; i+1 < len(off); i++ {
+						if !bytes.Equal(out[oo[i]:oo[i+1]], ref.EncodeAll(unit[off[i]:off[i+1]], nil)) {
+							errs <- fmt.Sprintf("goroutine %d: unit %d differs", g, i)
+							return
+						}
+					}
+				} else if !bytes.Equal(gpu.EncodeAll(unit, nil), ref.EncodeAll(unit, nil)) {
+					errs <- fmt.Sprintf("goroutine %d: EncodeAll differs", g)
+					return
+				}
+			}
+		}(g)
+	}
+	wg.Wait()
+	close(errs)
+	for e := range errs {
+		t.Error(e)
+	}
+}
+
+// TestRouting: below WithDeviceMinBytes the call never reaches the device (the reference encoder serves it, same bytes).
+func TestRouting(t *testing.T) {
+	data := corpusT(1 << 20)
+	gpu, err := New(0, WithEncoderLevel(zstd.SpeedDefault)) // default threshold: 512 MiB
+	if err != nil {
+		t.Fatal(err)
+	}
+	defer gpu.Close()
+	ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(zstd.SpeedDefault))
+	if !bytes.Equal(gpu.EncodeAll(data, nil), ref.EncodeAll(data, nil)) {
+		t.Fatal("EncodeAll below the threshold differs from the reference")
+	}
+	if gpu.created != 0 {
+		t.Fatalf("a call below the threshold created %d device context(s)", gpu.created)
+	}
+}
+
+// TestWriterWriteThenReadFrom: ReadFrom first ends the block being filled (zstd/encoder.go:453-458), so Write(p) followed by
+// ReadFrom(r) cuts a block at len(p) — on the device path too (the cut travels to kc_zstd_encode_streams_cuts).
+func TestWriterWriteThenReadFrom(t *testing.T) {
+	data := corpusT(400 << 10)
+	for _, lvl := range levels {
+		for _, first := range []int{1, 1000, 70000, 128 << 10, 200000} {
+			var want, got bytes.Buffer
+			ref, _ := zstd.NewWriter(&want, zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(1))
+			ref.Write(data[:first])
+			ref.ReadFrom(bytes.NewReader(data[first:]))
+			ref.Close()
+			gw, err := NewWriter(&got, 0, WithDeviceMinBytes(0), WithEncoderLevel(lvl))
+			if err != nil {
+				t.Fatal(err)
+			}
+			gw.Write(data[:first])
+			if _, err := gw.ReadFrom(io.LimitReader(bytes.NewReader(data[first:]), int64(len(data)))); err != nil {
+				t.Fatal(err)
+			}
+			if err := gw.Close(); err != nil {
+				t.Fatal(err)
+			}
+			if !bytes.Equal(got.Bytes(), want.Bytes()) {
+				t.Fatalf("level %v, Write(%d) + ReadFrom: %d bytes vs the reference's %d", lvl, first, got.Len(), want.Len())
+			}
+		}
+	}
+}
+
+// corpusT returns n bytes of the seeded text corpus.
+func corpusT(n int) []byte {
+	units := (n + (128 << 10) - 1) / (128 << 10)
+	data, err := kcgpu.CorpusFill('T', kcgpu.SeedT, 500, units, 128<<10)
+	if err != nil {
+		panic(err)
+	}
+	return data[:n]
 }
