@@ -248,7 +248,13 @@ def main():
     d_src = torch.from_numpy(host).cuda(local_rank)
     unit_off = np.arange(n_units + 1, dtype=np.uint64) * UNIT
     in_bytes = n_units * UNIT
-    dict_content = _lib.corpus_fill("T", DICT_SEED, 0, 1, cfg["dict_kib"] << 10).tobytes() if cfg["dict_kib"] else None
+    dict_content = None
+    if cfg["dict_kib"]:
+        # one dictionary for the whole job: rank 0 builds it, the others receive it (dist.broadcast over RCCL)
+        dict_content = _lib.corpus_fill("T", DICT_SEED, 0, 1, cfg["dict_kib"] << 10).tobytes() if rank == 0 else b""
+        if world > 1:
+            from compress_amd.shard import broadcast_bytes
+            dict_content = broadcast_bytes(dict_content, torch.device("cuda", local_rank))
 
     is_s2 = cfg["codec"] == "s2"
     npipe = 2 if (args.pipeline and not is_s2) else 1
@@ -268,7 +274,7 @@ def main():
     cap = n_units * slot + 64
     ndst = 2 if (npipe == 2 or world > 1) else 1  # N > 1: the gather of step i reads one buffer while step i+1 fills the other
     d_dsts = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(ndst)]
-    gather = FrameGather(rank, world) if (world > 1 and args.gather == "root") else None
+    gather = FrameGather(rank, world, bound_bytes=cap) if (world > 1 and args.gather == "root") else None
     if npipe == 2:
         encs[0].ChainAfter(encs[1])
         encs[1].ChainAfter(encs[0])

@@ -909,13 +909,13 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
 // A batch is bounded by its input bytes AND by the device scratch it needs: tables are per unit, sequences / literals /
 // staging are per block at a fixed stride whatever the block's actual length, so many small units need far more than the
 // "~6x input" of full-size units (1M x 4 KiB units at SpeedDefault would ask for hundreds of GiB in one batch).
-uint64_t zstd_unit_scratch(const kc_zstd_opts* o, uint64_t len) {
+uint64_t zstd_unit_scratch(const kc_zstd_opts* o, uint64_t len, uint64_t n_cuts = 0) {
     const uint64_t bsz = (uint64_t)o->block_size;
     const uint64_t table_b = o->level == KC_SPEED_BETTER ? kc_zbetter_table_bytes() : (o->level == KC_SPEED_DEFAULT ? kc_zdfast_table_bytes() : kc_zfast_table_bytes());
     const uint64_t per_block = 2 * (bsz / 4 + 8) * 8 + (bsz + 64) + sizeof(KcBlkMeta);
     const uint64_t hist0 = (o->dict != nullptr) ? o->dict_len : 0;
-    const uint64_t blocks = (len + bsz - 1) / bsz;
-    const uint64_t enc = ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)len) + 15) & ~(uint64_t)15;
+    const uint64_t blocks = (len + bsz - 1) / bsz + n_cuts;  // every Flush point can add a block, at the full per-block strides
+    const uint64_t enc = ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)len) + 3 * n_cuts + 3 + 15) & ~(uint64_t)15;
     return table_b + blocks * per_block + enc + (hist0 ? hist0 + len : 0) + 64;
 }
 
@@ -990,7 +990,10 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
     uint64_t pos = 0;
     uint32_t i0 = 0;
     std::vector<uint64_t> tmp;
-    auto unit_scratch = [&](uint64_t len) { return zstd_unit_scratch(o, len); };
+    auto unit_scratch = [&](uint32_t i) {
+        const uint64_t nc = c->cuts ? c->cut_off[i + 1] - c->cut_off[i] : 0;
+        return zstd_unit_scratch(o, unit_off[i + 1] - unit_off[i], nc);
+    };
     uint64_t budget = scratch_budget(c);
     for (int attempt = 0;; attempt++) {
         bool oom = false;
@@ -1000,7 +1003,7 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
             const uint32_t cap_units = o->level == KC_SPEED_BETTER ? 16384u : 0xFFFFFFFFu;
             uint64_t scratch = 0;
             while (i1 < n_units) {
-                const uint64_t us = unit_scratch(unit_off[i1 + 1] - unit_off[i1]);
+                const uint64_t us = unit_scratch(i1);
                 // ensure() over-allocates by 1/8
                 if (i1 > i0 && (unit_off[i1 + 1] - unit_off[i0] > cap_bytes || i1 - i0 >= cap_units || (scratch + us) + ((scratch + us) >> 3) > budget)) break;
                 scratch += us;
@@ -1612,7 +1615,7 @@ kc_status kc_zstd_encode_streams_cuts(kc_ctx* c, const kc_zstd_opts* o, const ui
 kc_status kc_zstd_encode_units_submit(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units,
                                       uint8_t* dst, uint64_t dst_cap, uint64_t* out_off) {
     if (!c || !o) return KC_ERR_BAD_ARG;
-    if (c->job_active) { c->err = "a submitted job is still in flight on this context: kc_wait first"; return KC_ERR_BAD_ARG; }
+    if (c->job_active) return KC_ERR_BAD_ARG;  // a submitted job is still in flight: kc_wait first (c->err belongs to the job's thread)
     const kc_zstd_opts oc = *o;
     c->job_active = true;
     c->job = std::thread([=] { c->job_status = kc_zstd_encode_units(c, &oc, src, unit_off, n_units, dst, dst_cap, out_off); });
@@ -1622,7 +1625,7 @@ kc_status kc_zstd_encode_units_submit(kc_ctx* c, const kc_zstd_opts* o, const ui
 kc_status kc_s2_encode_blocks_lvl_submit(kc_ctx* c, int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* dst,
                                          uint64_t dst_cap, uint64_t* out_off) {
     if (!c) return KC_ERR_BAD_ARG;
-    if (c->job_active) { c->err = "a submitted job is still in flight on this context: kc_wait first"; return KC_ERR_BAD_ARG; }
+    if (c->job_active) return KC_ERR_BAD_ARG;  // a submitted job is still in flight: kc_wait first (c->err belongs to the job's thread)
     c->job_active = true;
     c->job = std::thread([=] { c->job_status = kc_s2_encode_blocks_lvl(c, level, src, blk_off, n, dst, dst_cap, out_off); });
     return KC_OK;
@@ -1957,24 +1960,64 @@ kc_status kc_s2_decode_blocks_dev(kc_ctx* c, const uint8_t* d_enc, const uint64_
     return KC_OK;
 }
 
+// s2_encode_dev in batches that fit the scratch budget: the HBM path keeps a table per block (64 KiB default / snappy, 288-576 KiB
+// better), whatever the block's length, plus a MaxEncodedLen staging slot — half a million small blocks would ask for > 100 GiB.
+static kc_status s2_encode_dev_budgeted(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
+                                        uint64_t dst_cap, uint64_t* out_off, int framed, int with_stream_id, int level) {
+    if (!c || !blk_off || !out_off) return KC_ERR_BAD_ARG;
+    if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BETTER || n == 0) return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, framed, with_stream_id, level);
+    uint64_t maxLen = 0;
+    for (uint32_t i = 0; i < n; i++) if (blk_off[i + 1] >= blk_off[i]) maxLen = std::max(maxLen, blk_off[i + 1] - blk_off[i]);
+    const uint64_t tb = kc_s2_table_bytes(level, maxLen);
+    uint64_t budget = scratch_budget(c);
+    std::vector<uint64_t> tmp;
+    uint64_t pos = 0;
+    uint32_t i0 = 0;
+    while (i0 < n) {
+        uint32_t i1 = i0;
+        uint64_t scratch = 0;
+        while (i1 < n) {
+            const uint64_t len = blk_off[i1 + 1] >= blk_off[i1] ? blk_off[i1 + 1] - blk_off[i1] : 0;
+            const uint64_t us = tb + (((uint64_t)std::max<int64_t>(0, kc_s2_max_encoded_len((int64_t)len)) + 8 + 63) & ~(uint64_t)63);
+            if (i1 > i0 && (scratch + us) + ((scratch + us) >> 3) > budget) break;
+            scratch += us;
+            i1++;
+        }
+        if (i0 == 0 && i1 == n) return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, framed, with_stream_id, level);  // the usual case: one batch
+        const uint32_t nb = i1 - i0;
+        tmp.resize(nb + 1);
+        kc_status s = s2_encode_dev(c, d_src, blk_off + i0, nb, d_dst + pos, dst_cap - pos, tmp.data(), framed, i0 == 0 ? with_stream_id : 0, level);
+        if (s == KC_ERR_UNSUPPORTED && c->err.compare(0, 23, "device memory exhausted") == 0 && nb > 1 && budget > ((uint64_t)64 << 20)) {
+            budget /= 2;  // another process took device memory since hipMemGetInfo
+            c->err.clear();
+            continue;
+        }
+        if (s != KC_OK) return s;
+        for (uint32_t k = 0; k <= nb; k++) out_off[i0 + k] = pos + tmp[k];
+        pos += tmp[nb];
+        i0 = i1;
+    }
+    return KC_OK;
+}
+
 kc_status kc_s2_encode_blocks_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
                                   uint64_t dst_cap, uint64_t* out_off) {
-    return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 0, 0);
+    return s2_encode_dev_budgeted(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 0, 0, KC_S2_LEVEL_DEFAULT);
 }
 
 kc_status kc_s2_encode_stream_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
                                   uint64_t dst_cap, uint64_t* out_off, int with_stream_id) {
-    return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 1, with_stream_id);
+    return s2_encode_dev_budgeted(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 1, with_stream_id, KC_S2_LEVEL_DEFAULT);
 }
 
 kc_status kc_s2_encode_blocks_lvl_dev(kc_ctx* c, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
                                       uint64_t dst_cap, uint64_t* out_off) {
-    return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 0, 0, level);
+    return s2_encode_dev_budgeted(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 0, 0, level);
 }
 
 kc_status kc_s2_encode_stream_lvl_dev(kc_ctx* c, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
                                       uint64_t dst_cap, uint64_t* out_off, int with_stream_id) {
-    return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 1, with_stream_id, level);
+    return s2_encode_dev_budgeted(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 1, with_stream_id, level);
 }
 
 kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* dst, uint64_t dst_cap,

@@ -73,7 +73,10 @@ class BlockEncoder:
         return out.tobytes()
 
     def CustomEncoder(self):
-        """The function to hand to s2.WriterCustomEncoder (s2/writer.go:1053): fn(dst, src) -> int."""
+        """The function to hand to s2.WriterCustomEncoder (s2/writer.go:1053): fn(dst, src) -> int.  The hook (kc_s2_encode_block)
+        encodes at the default level, like the reference's built-in encodeBlock of a default Writer."""
+        if self.level != LevelDefault:
+            raise ValueError("the WriterCustomEncoder hook serves the default level only (s2.Encode); use EncodeBlocks for level %d" % self.level)
         ctx = self._ctx
 
         def fn(dst, src):

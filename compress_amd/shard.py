@@ -17,12 +17,37 @@ def shard_range(n_units, rank, world):
     return (n_units * rank) // world, (n_units * (rank + 1)) // world
 
 
-def gather_sizes(nbytes, device):
+def gather_sizes_start(nbytes, device):
+    """Post ONE all_gather_into_tensor of the per-rank byte counts (a device-side collective, nothing read back yet)."""
     world = dist.get_world_size()
     mine = torch.tensor([int(nbytes)], dtype=torch.int64, device=device)
-    allsz = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(allsz, mine)
-    return [int(t.item()) for t in allsz]
+    allsz = torch.empty(world, dtype=torch.int64, device=device)
+    work = dist.all_gather_into_tensor(allsz, mine, async_op=True)
+    return work, allsz, mine
+
+
+def gather_sizes_finish(h):
+    """Complete it and read the counts with one copy (a single host synchronisation, not one per rank)."""
+    work, allsz, _mine = h
+    work.wait()
+    return [int(x) for x in allsz.tolist()]
+
+
+def gather_sizes(nbytes, device):
+    return gather_sizes_finish(gather_sizes_start(nbytes, device))
+
+
+def broadcast_bytes(data, device, root=0):
+    """The dictionary of a sharded job comes from ONE place: rank `root` passes its bytes, every rank gets them back
+    ("Dict is broadcast once").  `data` is ignored on the other ranks."""
+    rank = dist.get_rank()
+    n = torch.tensor([len(data) if rank == root else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=root)
+    buf = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    if rank == root:
+        buf.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+    dist.broadcast(buf, src=root)
+    return bytes(buf.cpu().numpy().tobytes())
 
 
 def gather_frames(buf, nbytes, rank, world, root=0):
@@ -56,15 +81,21 @@ class FrameGather:
     source buffer may be overwritten and the result read).  One gather in flight per object; the root keeps one receive
     buffer and grows it on demand."""
 
-    def __init__(self, rank, world, root=0):
+    def __init__(self, rank, world, root=0, bound_bytes=None):
+        """bound_bytes: an upper bound of one rank's frames (the sum of MaxEncodedSize of its units): the root then allocates its
+        receive buffer once, world x bound, instead of growing it when a step's frames turn out larger."""
         self.rank, self.world, self.root = rank, world, root
+        self._bound = bound_bytes
         self._out = None
         self._reqs = None
         self._offs = None
 
     def start(self, buf, nbytes):
         assert self._reqs is None, "previous gather not waited for"
-        sizes = gather_sizes(nbytes, buf.device)
+        h = gather_sizes_start(nbytes, buf.device)
+        if self.rank == self.root and self._out is None and self._bound is not None:
+            self._out = torch.empty(max(self.world * int(self._bound), 1), dtype=torch.uint8, device=buf.device)  # under the collective
+        sizes = gather_sizes_finish(h)
         offs = [0]
         for s in sizes:
             offs.append(offs[-1] + s)
@@ -118,3 +149,28 @@ def write_shard(prefix, rank, buf, nbytes, out_off=None):
         with open("%s.%05d.idx" % (prefix, rank), "wb") as f:
             f.write(np.ascontiguousarray(out_off, dtype="<u8").tobytes())
     return path
+
+
+def selftest(device):
+    """World-size-1 exercise of every collective this module uses, on the real backend (RCCL on a GPU box): the byte-count
+    all_gather, a grouped send + receive (to self), a broadcast.  The N > 1 path cannot run on a one-GPU box; this at least runs
+    its calls through the backend every round.  Needs an initialised process group.  Returns a short report string."""
+    sizes = gather_sizes(1234, device)
+    assert sizes == [1234], sizes
+    src = torch.arange(4096, dtype=torch.int64, device=device).to(torch.uint8)
+    dst = torch.zeros(4096, dtype=torch.uint8, device=device)
+    me = dist.get_rank()
+    p2p = "skipped (gloo has no send-to-self)"
+    if dist.get_backend() == "nccl":  # RCCL: a grouped send + receive to the own rank
+        reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, src, me), dist.P2POp(dist.irecv, dst, me)])
+        for q in reqs:
+            q.wait()
+        torch.cuda.current_stream(device).synchronize()
+        assert torch.equal(src, dst), "send-to-self did not deliver the bytes"
+        p2p = "ok"
+    assert broadcast_bytes(b"dictionary", device) == b"dictionary"
+    g = FrameGather(me, dist.get_world_size(), bound_bytes=4096)
+    g.start(src, 1000)
+    out, offs = g.wait()
+    assert offs == [0, 1000] and torch.equal(out, src[:1000])
+    return "all_gather_into_tensor ok, batch_isend_irecv to self %s, broadcast ok, FrameGather ok (backend %s)" % (p2p, dist.get_backend())

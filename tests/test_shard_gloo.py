@@ -172,3 +172,29 @@ def test_bench_dry_run_rank_plumbing(world):
     assert j["dry_run"] is True and j["n_gpus"] == world and j["steps"] == 5 and j["warmup"] == 2
     assert j["gather_verified"] is True and j["value"] is None and j["scaling"] == "weak"
     assert j["units_total"] == 64 * world + 5 and j["shard_of_rank0"] == [0, (64 * world + 5) // world]
+
+
+def _selftest_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from compress_amd import shard
+    try:
+        q.put(shard.selftest(torch.device("cpu")))
+    except Exception as e:  # noqa: BLE001
+        q.put("ERR %r" % (e,))
+    dist.destroy_process_group()
+
+
+def test_selftest_world1_gloo():
+    """shard.selftest (what __graft_entry__.smoke() runs over RCCL on the GPU box) on gloo, world size 1."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_selftest_worker, args=(29571, q))
+    p.start()
+    msg = q.get(timeout=120)
+    p.join(60)
+    assert msg.startswith("all_gather_into_tensor ok"), msg
