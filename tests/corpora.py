@@ -68,3 +68,27 @@ def stress_units(seed=7, n=96):
             parts.append(p); tot += len(p)
         units.append(b"".join(parts)[:target])
     return units
+
+
+def rle_literal_units(n=12, seed=77):
+    """(dictionary content, units) whose blocks carry an RLE LITERALS SECTION (zstd/blockenc.go:554-561, huff0.ErrUseRLE): the
+    dictionary is noise; a unit is a chain of 12..24-byte snippets of it, each preceded by `gap` copies of ONE separator byte that
+    differs from the dictionary bytes around the snippet — every snippet is found in the dictionary (no backward extension, no
+    forward overrun), so the block's literals are the separators alone: more than 16 of them, all equal."""
+    rng = np.random.default_rng(seed)
+    # a SMALL dictionary: the encoders' tables keep the last position of a bucket only, and 4 KiB of noise rarely collide
+    dct = bytes(rng.integers(0, 256, 4096, dtype=np.uint8))
+    units = []
+    for k in range(n):
+        sep = int(rng.integers(0, 256))
+        sniplen = int(rng.choice([12, 16, 24]))
+        nsnip = int(rng.choice([20, 40, 300, 2500]))
+        gap = 1 + (k & 1)
+        out = bytearray()
+        for p in rng.integers(16, len(dct) - 64, nsnip):
+            p = int(p)
+            while dct[p - 1] == sep or dct[p + sniplen] == sep or dct[p] == sep:
+                p += 1
+            out += bytes([sep]) * gap + dct[p:p + sniplen]
+        units.append(bytes(out))
+    return dct, units

@@ -712,3 +712,21 @@ def test_device_decoder_empty_units_and_tiny_blocks(oracle, kclib):
     assert stb.all(), stb  # every one of them is refused
     enc.Close()
     enc0.Close()
+
+
+@pytest.mark.parametrize("level", LEVELS)
+def test_rle_literal_sections_bit_exact(oracle, kclib, level):
+    """RLE literal sections (zstd/blockenc.go:554-561: huff0.ErrUseRLE): units whose literals are one repeated byte between
+    dictionary matches (corpora.rle_literal_units; tests/test_outcome_coverage.py shows the oracle takes the RLE branch for them).
+    The device's RLE-literals code path against the oracle, at every level and on both SpeedFastest kernel families."""
+    _torch()
+    from compress_amd import zstd
+    dct, units = corpora.rle_literal_units()
+    buf, off = corpora.pack_units(units)
+    enc = zstd.NewWriter(None, *_lo(level), zstd.WithEncoderDictRaw(7, dct))
+    out, out_off = enc.EncodeUnits(buf, off)
+    _path_ran(enc, level)
+    ref, ref_off = oracle.zstd_encode_units(buf, off, threads=4, level=_li(level), dict_id=7, dict_content=dct)
+    assert np.array_equal(out_off, ref_off)
+    assert np.array_equal(out, ref)
+    enc.Close()

@@ -60,8 +60,8 @@ def test_parity_inputs_reach_these_outcomes(oracle, level):
     missing = sorted(w for w in want if cov[w] == 0)
     assert not missing, (level, missing, dict(cov))
     # Known to be out of reach of these inputs (and why):
-    #   literals:rle   - every literal of a block equal AND >16 of them: backward extension and the next probe swallow such runs
-    #                    (tried: separators between dictionary tokens, zero runs between tokens - the literals end up raw)
+    #   literals:rle   - not by these inputs; reached by corpora.rle_literal_units (dictionary matches separated by one repeated
+    #                    byte): test_rle_literal_sections_are_reachable below and its GPU twin
     #   nseq:>=32512   - needs < 4.04 bytes per sequence in a 128 KiB block; the shortest findable match is 5-6 bytes
     #   repcode:2, 3   - the encoders only ever test offset1 (and offset2 right after a match, which is coded as code 1 with ll == 0)
     assert cov["nseq:>=32512"] == 0
@@ -144,3 +144,34 @@ def test_s2_parity_inputs_reach_these_tags(oracle):
         assert not any(cov[lvl + r] for r in ("repeat:2 bytes", "repeat:3 bytes", "repeat:4 bytes", "repeat:5 bytes"))  # Snappy has no repeats
     # Not reached: 4/5-byte literal headers need a literal run of 64 KiB+ / 16 MiB+ inside a compressible block (a stored block is one
     # 3- or 4-byte-header literal by itself); 5-byte repeats need a repeat longer than 65 KiB + 260.
+
+
+def _first_block_literal_type(fr):
+    """Literal section type of a frame's first block, read off the bytes (zstd/frameenc.go:25-92, blockenc.go:109-238)."""
+    fhd = fr[4]
+    p = 5
+    single = (fhd >> 5) & 1
+    if not single:
+        p += 1
+    p += [0, 1, 2, 4][fhd & 3]
+    p += [1 if single else 0, 2, 4, 8][fhd >> 6]
+    bh = fr[p] | fr[p + 1] << 8 | fr[p + 2] << 16
+    if (bh >> 1) & 3 != 2:
+        return None
+    return ("raw", "rle", "compressed", "treeless")[fr[p + 3] & 3]
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_rle_literal_sections_are_reachable(oracle, level):
+    """literals:rle — the one literal-section type the corpus inputs never produce — IS reachable, with a dictionary:
+    corpora.rle_literal_units builds units whose literals are > 16 copies of one byte between dictionary matches.  The oracle emits
+    RLE literal sections for them at every level (the GPU twin of this test byte-compares the device frames:
+    tests/test_gpu_zstd.py::test_rle_literal_sections_bit_exact) and its own decoder restores the input."""
+    dct, units = corpora.rle_literal_units()
+    e = oracle.ZstdOracle(level=level, dict_id=7, dict_content=dct)
+    kinds = collections.Counter()
+    for u in units:
+        fr = e.encode_all(u)
+        kinds[_first_block_literal_type(fr)] += 1
+        assert oracle.zstd_decode(fr, len(u) + 16, dict_content=dct) == u
+    assert kinds["rle"] >= len(units) // 2, dict(kinds)
