@@ -40,7 +40,7 @@ SYMBOLS = [
     "kc_zstd_max_encoded_size", "kc_ctx_create", "kc_ctx_destroy", "kc_last_error", "kc_device_info",
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts", "kc_zstd_encode_units_submit", "kc_s2_encode_blocks_lvl_submit", "kc_wait", "kc_zstd_plan_stream_blocks", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
     "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats", "kc_s2_encode_blocks_lvl", "kc_s2_encode_blocks_lvl_dev", "kc_s2_encode_stream_lvl_dev",
-    "kc_last_timings", "kc_corpus_fill", "kc_ctx_set_option", "kc_ctx_get_option",
+    "kc_last_timings", "kc_corpus_fill", "kc_ctx_set_option", "kc_ctx_get_option", "kc_zstd_encode_jobs", "kc_zstd_job_size", "kc_zstd_overlap_size",
 ]
 
 # kc_option / KC_PATH_* (include/kcgpu.h)
@@ -147,6 +147,12 @@ def load():
     L.kc_s2_hook_stats.restype = None
     L.kc_last_timings.argtypes = [vp, C.POINTER(Timings)]
     L.kc_last_timings.restype = C.c_int
+    L.kc_zstd_encode_jobs.argtypes = [vp, po, vp, u64, vp, u64, vp, u64, C.POINTER(u64)]
+    L.kc_zstd_encode_jobs.restype = C.c_int
+    L.kc_zstd_job_size.argtypes = [po]
+    L.kc_zstd_job_size.restype = C.c_int64
+    L.kc_zstd_overlap_size.argtypes = [po]
+    L.kc_zstd_overlap_size.restype = C.c_int64
     L.kc_ctx_set_option.argtypes = [vp, C.c_int, C.c_int64]
     L.kc_ctx_set_option.restype = C.c_int
     L.kc_ctx_get_option.argtypes = [vp, C.c_int]

@@ -120,6 +120,12 @@ struct kc_ctx {
     const uint64_t* cut_off = nullptr;  // streams with Flush points (kc_zstd_encode_streams_cuts*): per stream the range of its cuts,
     const uint64_t* cuts = nullptr;     // the cut positions (bytes written before the Flush), for the duration of the call
     uint32_t cut_unit0 = 0;             // index of the running batch's first unit in cut_off
+    // a batch whose units are the jobs of ONE WithConcurrentBlocks stream (kc_zstd_encode_jobs), for the duration of that call:
+    const uint32_t* job_hist = nullptr;     // host, per unit: bytes of overlap prefix in front of the unit in the source buffer
+    const uint32_t* job_flags = nullptr;    // host, per unit: bit 0 = final job
+    const uint8_t* job_tables = nullptr;    // host: the units' tables primed from their prefixes (ResetPrefix), device entry format
+    DevBuf d_job_hist, d_job_flags;
+    std::vector<uint32_t> job_redo_list;    // units of the speculation re-run in progress (their tables are re-primed)
     void* pend = nullptr;            // batch between kc_zstd_encode_units_dev_begin and _end (Pending)
     kc_ctx* chain_after = nullptr;   // pipelining: this context's match finder waits for that context's last one
     void* hpipe = nullptr;           // pinned staging ring + streams of the pipelined host path (HostPipe), created on first use
@@ -471,7 +477,7 @@ size_t match_table_bytes(int level) {
 // dictionary history) of 256 KiB and more only fit the HBM path's position field: the HBM kernel takes those, the LDS kernel the rest.
 bool zfast_use_lds(const kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, int level) {
     (void)mp;
-    if (level != KC_SPEED_FASTEST) return false;
+    if (level != KC_SPEED_FASTEST || c->job_hist != nullptr) return false;
     if (c->cfg.match_path == KC_PATH_HBM) return false;
     if (c->cfg.match_path == KC_PATH_LDS) return true;
     return (int64_t)n_launch <= c->cfg.zfast_lds_max_units;
@@ -485,8 +491,20 @@ bool zfast_lds_needs_hbm(const kc_ctx* c, const KcMatchParams& mp) {
 kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, hipStream_t st, int level) {
     if (zfast_use_lds(c, mp, n_launch, level) && !zfast_lds_needs_hbm(c, mp)) return KC_OK;  // the tables live in LDS
     const size_t tb = match_table_bytes(level);
+    if (c->job_tables != nullptr && mp.unit_list == nullptr) {  // jobs: every unit's table was primed from its own prefix on the host
+        kc_status sj = ensure(c, c->tables, (size_t)n_launch * tb);
+        if (sj != KC_OK) return sj;
+        HIPCHK(c, hipMemcpyAsync(c->tables.p, c->job_tables, (size_t)n_launch * tb, hipMemcpyHostToDevice, st));
+        return KC_OK;
+    }
     kc_status s = ensure(c, c->tables, (size_t)n_launch * tb);
     if (s != KC_OK) return s;
+    if (c->job_tables != nullptr) {  // re-run of listed jobs: slot i holds the table of unit list[i]
+        if (c->job_redo_list.size() < n_launch) { c->err = "job re-run without its unit list"; return KC_ERR_INTERNAL; }
+        for (uint32_t i = 0; i < n_launch; i++)
+            HIPCHK(c, hipMemcpyAsync((uint8_t*)c->tables.p + (size_t)i * tb, c->job_tables + (size_t)c->job_redo_list[i] * tb, tb, hipMemcpyHostToDevice, st));
+        return KC_OK;
+    }
     if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, tb, n_launch, st);
     else HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * tb, st));
     return KC_OK;
@@ -567,7 +585,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
         pl.blk0[i] = nb;
         pl.stage_off[i] = so;
         pl.rel_off[i] = unit_off[i] - unit_off[0];
-        uint32_t ub = (uint32_t)((len + bs - 1) / bs);
+        uint32_t ub = (uint32_t)((len - (c->job_hist ? c->job_hist[i] : 0) + bs - 1) / bs);  // (a job's overlap prefix is history, not blocks)
         if (irregular) {
             const uint64_t* cp = c->cuts + c->cut_off[c->cut_unit0 + i];
             const uint64_t nc = c->cut_off[c->cut_unit0 + i + 1] - c->cut_off[c->cut_unit0 + i];
@@ -652,8 +670,16 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
         k_src = (const uint8_t*)c->work.p;
         k_off = (const uint64_t*)c->work_off.p;
     }
+    if (c->job_hist) {
+        if (useDict) { c->err = "jobs of a WithConcurrentBlocks stream take no dictionary"; return KC_ERR_INTERNAL; }
+        if ((s = ensure(c, c->d_job_hist, (size_t)n_units * 4)) || (s = ensure(c, c->d_job_flags, (size_t)n_units * 4))) return s;
+        HIPCHK(c, hipMemcpyAsync(c->d_job_hist.p, c->job_hist, (size_t)n_units * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_job_flags.p, c->job_flags, (size_t)n_units * 4, hipMemcpyHostToDevice, st));
+    }
     KcMatchParams mp;
     memset(&mp, 0, sizeof(mp));
+    mp.unit_hist = c->job_hist ? (const uint32_t*)c->d_job_hist.p : nullptr;
+    mp.job_flags = c->job_hist ? (const uint32_t*)c->d_job_flags.p : nullptr;
     mp.src = k_src;
     mp.src_end = k_src + (useDict ? pl.rel_off[n_units] + (uint64_t)n_units * (uint64_t)hist0 : pl.rel_off[n_units]);
     mp.unit_off = k_off;
@@ -685,6 +711,8 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
 
     KcEntropyParams ep;
     memset(&ep, 0, sizeof(ep));
+    ep.unit_hist = mp.unit_hist;
+    ep.job_flags = mp.job_flags;
     ep.src = k_src;
     ep.unit_off = k_off;
     ep.hist0 = hist0;
@@ -743,7 +771,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     mp.unit_base = 0;
     ep.unit_base = 0;
     if (feed == nullptr) {
-        if (o->crc) kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p, n_units, (uint64_t*)c->xxh.p, st);
+        if (o->crc && !c->job_hist) kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p, n_units, (uint64_t*)c->xxh.p, st);  // (a job stream's checksum is the host's)
         HIPCHK(c, hipEventRecord(c->ev[1], st));
         if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, st, o->level)) != KC_OK) return s;
     } else {
@@ -847,6 +875,7 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
             HIPCHK(c, hipMemcpyAsync(c->unit_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, st));
             HIPCHK(c, hipMemsetAsync(c->redo.p, 0, (size_t)n_units * 4, st));
             HIPCHK(c, hipMemsetAsync(c->redo_blk.p, 0, (size_t)nb + 1, st));
+            c->job_redo_list = list;
             mp.pop_blk = (const uint8_t*)c->pop_blk.p;
             mp.unit_list = (const uint32_t*)c->unit_list.p;
             ep.unit_list = mp.unit_list;
@@ -1606,6 +1635,199 @@ kc_status kc_zstd_encode_streams_cuts(kc_ctx* c, const kc_zstd_opts* o, const ui
     c->cuts = nullptr;
     c->cut_off = nullptr;
     return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// WithConcurrentBlocks (zstd/enc_jobs.go, encoder.go:214-247, 585-597, 652-700): ONE stream cut into jobs of
+// max(4 * window, 512 KiB) input bytes, each encoded on a freshly reset encoder whose history is the last overlapSize bytes of
+// the previous job's input (ResetPrefix), the job outputs concatenated behind one frame header.  The jobs are independent
+// units for the device: unit k = [overlap prefix || job input] in a work buffer, its table primed from the prefix on the host
+// exactly as ResetPrefix does (enc_fast.go:800-811, enc_dfast.go:1040-1050, enc_better.go:1099-1112).
+// ---------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+uint64_t xxh64_host(const uint8_t* p, size_t len) {  // zstd/internal/xxhash/xxhash.go:27-230, seed 0
+    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL, P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
+    auto rol = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    auto rd64 = [](const uint8_t* q) { uint64_t v; memcpy(&v, q, 8); return v; };
+    auto round = [&](uint64_t acc, uint64_t in) { return rol(acc + in * P2, 31) * P1; };
+    auto merge = [&](uint64_t acc, uint64_t v) { return (acc ^ round(0, v)) * P1 + P4; };
+    const uint8_t* end = p + len;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0 - P1;
+        for (; p + 32 <= end; p += 32) { v1 = round(v1, rd64(p)); v2 = round(v2, rd64(p + 8)); v3 = round(v3, rd64(p + 16)); v4 = round(v4, rd64(p + 24)); }
+        h = rol(v1, 1) + rol(v2, 7) + rol(v3, 12) + rol(v4, 18);
+        h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+    } else {
+        h = P5;
+    }
+    h += (uint64_t)len;
+    for (; p + 8 <= end; p += 8) { h ^= round(0, rd64(p)); h = rol(h, 27) * P1 + P4; }
+    if (p + 4 <= end) { uint32_t v; memcpy(&v, p, 4); h ^= (uint64_t)v * P1; h = rol(h, 23) * P2 + P3; p += 4; }
+    for (; p < end; p++) { h ^= (uint64_t)(*p) * P5; h = rol(h, 11) * P1; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+// One job's tables as ResetPrefix leaves them, in the device entry format ((position + 1) | tag << pos_bits, position counted
+// from the start of the prefix).  `out` = the unit's table slot (match_table_bytes(level)), zeroed by the caller.
+void build_prefix_tables(int level, const uint8_t* prefix, size_t n, int pos_bits, uint8_t* out) {
+    const int TB = (32 - pos_bits) > 16 ? 16 : (32 - pos_bits);
+    auto tagOf = [&](uint32_t v) -> uint32_t { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; };
+    auto mk = [&](size_t pos, uint32_t val) -> uint32_t { return ((uint32_t)pos + 1u) | (tagOf(val) << pos_bits); };
+    auto ld = [&](size_t i) -> uint64_t { uint64_t v; memcpy(&v, prefix + i, 8); return v; };
+    if (n < 8) return;
+    const size_t end = n - 8;
+    if (level == KC_SPEED_BETTER) {  // enc_better.go:1099-1112: i = 0, 2, ... : long table with its chain, short table one byte on
+        uint32_t* ltab = (uint32_t*)out;  // pairs {offset, prev}
+        uint32_t* stab = (uint32_t*)(out + ((size_t)8 << 19));
+        for (size_t i = 0; i < end; i += 2) {
+            const uint64_t cv = ld(i);
+            const uint32_t h = (uint32_t)((cv * 0xcf1bbcdcb7a56463ULL) >> (64 - 19));
+            const uint32_t old = ltab[2 * h];
+            ltab[2 * h] = mk(i, (uint32_t)cv);
+            ltab[2 * h + 1] = old;
+            const uint64_t v = cv >> 8;
+            stab[(uint32_t)(((v << 24) * 889523592379ULL) >> (64 - 13))] = mk(i + 1, (uint32_t)v);
+        }
+        return;
+    }
+    // fastEncoder.ResetPrefix (enc_fast.go:800-811): every 4th position from 1, 6-byte hash, 2^15 entries.  doubleFastEncoder embeds
+    // it (enc_dfast.go:1040-1041): the same entries land in ITS short table, although its lookups hash 5 bytes — kept as it is.
+    uint32_t* ftab = level == KC_SPEED_DEFAULT ? (uint32_t*)(out + ((size_t)4 << 17)) : (uint32_t*)out;
+    for (size_t i = 1; i < end; i += 4) {
+        const uint64_t cv = ld(i);
+        ftab[(uint32_t)(((cv << 16) * 227718039650203ULL) >> (64 - 15))] = mk(i, (uint32_t)cv);
+    }
+    if (level == KC_SPEED_DEFAULT) {  // enc_dfast.go:1042-1050: every 2nd position from 1 into the long table
+        uint32_t* ltab = (uint32_t*)out;
+        for (size_t i = 1; i < end; i += 2) {
+            const uint64_t cv = ld(i);
+            ltab[(uint32_t)((cv * 0xcf1bbcdcb7a56463ULL) >> (64 - 17))] = mk(i, (uint32_t)cv);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t kc_zstd_job_size(const kc_zstd_opts* o) {  // encoderOptions.jobSize, encoder_options.go:356-359
+    return o ? std::max<int64_t>((int64_t)o->window_size * 4, (int64_t)512 << 10) : -1;
+}
+int64_t kc_zstd_overlap_size(const kc_zstd_opts* o) {  // encoderOptions.overlapSize, encoder_options.go:362-371
+    if (!o) return -1;
+    return o->level == KC_SPEED_BETTER ? o->window_size / 4 : o->window_size / 8;
+}
+
+kc_status kc_zstd_encode_jobs(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, uint64_t len, const uint64_t* cuts, uint64_t n_cuts,
+                              uint8_t* dst, uint64_t dst_cap, uint64_t* out_len) {
+    if (!c || !o || !out_len || (len && (!src || !dst)) || (n_cuts && !cuts)) return KC_ERR_BAD_ARG;
+    c->err.clear();
+    *out_len = 0;
+    kc_status s = check_supported(c, o);
+    if (s != KC_OK) return s;
+    if (o->dict != nullptr && o->dict_len > 0) {
+        c->err = "the reference switches WithConcurrentBlocks off when a dictionary is set (zstd/encoder.go:81,174): use kc_zstd_encode_streams";
+        return KC_ERR_UNSUPPORTED;
+    }
+    for (uint64_t i = 1; i < n_cuts; i++) if (cuts[i] < cuts[i - 1]) { c->err = "flush points not ascending"; return KC_ERR_BAD_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t jobSize = (uint64_t)kc_zstd_job_size(o), overlap = (uint64_t)kc_zstd_overlap_size(o);
+    // jobs dispatched before Close: `filling` reached jobSize during Write (encoder.go:239-244), or a Flush found bytes in it (:587-591)
+    std::vector<uint64_t> lo, hi;
+    uint64_t pos = 0, ci = 0;
+    for (;;) {
+        while (ci < n_cuts && cuts[ci] <= pos) ci++;
+        uint64_t e = pos + jobSize;
+        bool dispatched = e <= len;
+        if (ci < n_cuts && cuts[ci] < e && cuts[ci] <= len) { e = cuts[ci]; dispatched = true; }
+        if (!dispatched) break;
+        lo.push_back(pos);
+        hi.push_back(e);
+        pos = e;
+    }
+    const uint64_t tail = len - pos;  // what Close finds in `filling`
+    if (lo.empty()) {  // dispatchJob(true) before any header was written (enc_jobs.go:263-289)
+        if (tail > 0 && tail <= (uint64_t)o->block_size) {  // single block: the EncodeAll frame
+            const uint64_t uo[2] = {0, len};
+            uint64_t oo[2] = {0, 0};
+            s = kc_zstd_encode_units(c, o, src, uo, 1, dst, dst_cap, oo);
+            if (s == KC_OK) *out_len = oo[1];
+            return s;
+        }
+        if (tail == 0 && !o->full_zero) return KC_OK;
+    }
+    lo.push_back(pos);
+    hi.push_back(len);  // the final job (possibly empty)
+    const uint32_t nj = (uint32_t)lo.size();
+    // frame header (enc_jobs.go:291-304): no content size, window = the encoder's, not single segment, no dictionary id
+    uint8_t hdr[8];
+    int hl = 0;
+    hdr[hl++] = 0x28; hdr[hl++] = 0xb5; hdr[hl++] = 0x2f; hdr[hl++] = 0xfd;
+    hdr[hl++] = o->crc ? (uint8_t)(1 << 2) : (uint8_t)0;
+    hdr[hl++] = (uint8_t)((bitsLen32((uint32_t)o->window_size - 1) - 10) << 3);
+    // work buffer: unit k = [prefix_k || job_k]; prefix_k = the last min(overlap, len(job k-1)) bytes of job k-1 (enc_jobs.go:325-331)
+    std::vector<uint64_t> woff(nj + 1);
+    std::vector<uint32_t> jhist(nj), jflags(nj);
+    uint64_t maxUnit = 16, need = 0;
+    for (uint32_t k = 0; k < nj; k++) {
+        const uint64_t ov = k == 0 ? 0 : std::min<uint64_t>(overlap, hi[k - 1] - lo[k - 1]);
+        jhist[k] = (uint32_t)ov;
+        jflags[k] = k + 1 == nj ? 1u : 0u;
+        woff[k + 1] = woff[k] + ov + (hi[k] - lo[k]);
+        maxUnit = std::max<uint64_t>(maxUnit, ov + (hi[k] - lo[k]));
+        need += ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)(ov + hi[k] - lo[k])) + 15) & ~(uint64_t)15;
+    }
+    if (maxUnit > KC_MAX_UNIT_BYTES) { c->err = "job larger than 1 GiB: not served by the device path"; return KC_ERR_UNSUPPORTED; }
+    int pos_bits = 1;
+    while (((uint64_t)1 << pos_bits) <= maxUnit + 2) pos_bits++;
+    const size_t tb = match_table_bytes(o->level);
+    std::vector<uint8_t> tabs;
+    try { tabs.assign((size_t)nj * tb, 0); } catch (...) { c->err = "host memory for the jobs' tables"; return KC_ERR_UNSUPPORTED; }
+    {
+        const int T = std::max(1, std::min<int>(host_copy_threads(c), (int)nj));
+        std::vector<std::thread> th;
+        std::atomic<uint32_t> next{0};
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&] {
+                for (uint32_t k = next++; k < nj; k = next++)
+                    if (jhist[k]) build_prefix_tables(o->level, src + lo[k] - jhist[k], jhist[k], pos_bits, tabs.data() + (size_t)k * tb);
+            });
+        for (auto& x : th) x.join();
+    }
+    if ((s = ensure(c, c->tmp_src, woff[nj] + 64)) || (s = ensure(c, c->tmp_dst, need + 64))) return s;
+    for (uint32_t k = 0; k < nj; k++) {
+        const uint64_t n = woff[k + 1] - woff[k];
+        if (n) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->tmp_src.p + woff[k], src + lo[k] - jhist[k], n, hipMemcpyHostToDevice, c->stream));
+    }
+    uint64_t crc = 0;
+    std::thread crcT;
+    if (o->crc) crcT = std::thread([&] { crc = xxh64_host(src, (size_t)len); });  // under the device work
+    std::vector<uint64_t> oo(nj + 1);
+    uint64_t produced = 0;
+    c->job_hist = jhist.data();
+    c->job_flags = jflags.data();
+    c->job_tables = tabs.data();
+    c->last = kc_timings{0, 0, 0, 0, 0, 0};
+    s = run_batch(c, o, (const uint8_t*)c->tmp_src.p, woff.data(), nj, (uint8_t*)c->tmp_dst.p, need, oo.data(), &produced);
+    c->job_hist = nullptr;
+    c->job_flags = nullptr;
+    c->job_tables = nullptr;
+    c->job_redo_list.clear();
+    if (crcT.joinable()) crcT.join();
+    if (s != KC_OK) return s;
+    const uint64_t total = (uint64_t)hl + produced + (o->crc ? 4 : 0);
+    if (total > dst_cap) { c->err = "dst_cap too small"; return KC_ERR_DST_TOO_SMALL; }
+    memcpy(dst, hdr, (size_t)hl);
+    if (produced) HIPCHK(c, hipMemcpyAsync(dst + hl, c->tmp_dst.p, produced, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (o->crc) for (int k = 0; k < 4; k++) dst[hl + produced + k] = (uint8_t)(crc >> (8 * k));
+    *out_len = total;
+    return KC_OK;
 }
 
 // Asynchronous form of the host-buffer entry points: submit returns at once, the call runs on a thread of its own (staging,

@@ -27,6 +27,8 @@ struct KcMatchParams {
     int32_t pos_bits;           // bits reserved for position+1 in tagged table entries (better level)
     int32_t rep1, rep2;         // initial recentOffsets[0..1]: {1,4} unless a full-format dictionary supplies its own
     int32_t stream_mode;        // units are Write+Close streams: a unit of >= one block is parsed with Encode (history) from its first block
+    const uint32_t* unit_hist;  // device or null: per-unit history bytes in front of the unit in `src` (jobs: the overlap prefix), replaces hist0
+    const uint32_t* job_flags;  // device or null: units are the jobs of ONE WithConcurrentBlocks stream (enc_jobs.go): bit 0 = final job
     unsigned long long* prof;   // device or null: per-phase shader-clock totals of the LDS-table kernel (built with -DKC_LDS_PROF, KC_OPT_K2_PROF)
     int32_t lds_split;          // SpeedFastest HBM kernel: 1 = skip the units the LDS-table kernel takes (those that fit KC_ZFAST_LDS_MAX_UNIT)
 };
@@ -72,6 +74,9 @@ struct KcEntropyParams {
     int32_t crc, single, no_entropy, all_lit_entropy, full_zero;
     uint32_t dict_id;
     int32_t hist0;          // bytes of dictionary content prepended to every unit in `src`
+    const uint32_t* unit_hist;  // as in KcMatchParams
+    const uint32_t* job_flags;  // as in KcMatchParams: the unit's output is its blocks alone (no frame header, no checksum), `last` only
+                                // on the final job's last block; an empty final job is one empty raw last block (enc_jobs.go:96-103)
     const uint8_t* dict_huf;   // device or null: dictionary literal table, 256 x u16 val then 256 x u8 nBits (KcHufTable layout)
     int32_t dict_huf_len, dict_huf_log;
     int32_t stream_mode;       // streaming frame layout for units >= one block (zstd/encoder.go:257-428): no content size, no single

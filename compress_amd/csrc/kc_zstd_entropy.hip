@@ -321,7 +321,9 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : P.unit_base + blockIdx.x;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
-    const int hist0 = P.hist0;  // dictionary content in front of the unit (history only; not part of the frame)
+    const int hist0 = P.unit_hist != nullptr ? (int)P.unit_hist[u] : P.hist0;  // history in front of the unit (dictionary content, or a job's overlap prefix): not part of the output
+    const bool JOB = P.job_flags != nullptr;  // the unit is a job of a WithConcurrentBlocks stream: blocks only (compressJob, enc_jobs.go:88-124)
+    const bool finalJob = JOB && (P.job_flags[u] & 1u) != 0;
     const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0;
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
     // Streaming layout (Write ... Close, zstd/encoder.go:257-428) for units of at least one block: frame header without content
     // size or single segment, window = the encoder's, `last` only on a short final block, otherwise an empty raw last block.
     const bool streamU = UB.streamU;
-    if (ulen > 0) {
+    if (ulen > 0 && !JOB) {
         bool single = ulen <= P.window_size && ulen > 1024;
         if (P.single >= 0) single = P.single != 0;
         if (streamU) single = false;
@@ -391,6 +393,14 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         opos = h;
     }
     __syncthreads();
+    if (ulen == 0 && JOB) {
+        // an empty job: nothing, or (final job) the stream's empty raw last block (enc_jobs.go:96-103)
+        if (tid == 0) {
+            if (finalJob) { outp[0] = 0x01; outp[1] = 0x00; outp[2] = 0x00; }
+            P.out_size[u] = finalJob ? 3u : 0u;
+        }
+        return;
+    }
     if (ulen == 0) {
         // zero-length input: optional 9-byte frame (encoder.go:732-752, App. A-18)
         if (tid == 0) {
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         const int blkStart = hist0 + kc_blk_begin(P.blk_start, blk0, b, bs);
         const int blkEnd = hist0 + kc_blk_end(P.blk_start, blk0, b, nblk, bs, ulen);
         const int size = blkEnd - blkStart;
-        const bool last = b == nblk - 1 && !UB.emptyLast;
+        const bool last = JOB ? (b == nblk - 1 && finalJob) : (b == nblk - 1 && !UB.emptyLast);  // jobs: blk.last = len(data) == 0 && job.last
         const uint8_t* __restrict__ org = base + blkStart;
         const uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
         uint8_t* __restrict__ lits = P.lits + (size_t)(blk0 + (uint32_t)b) * P.lit_stride;
@@ -1202,12 +1212,12 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         PROF_MARK(13);
     }
 
-    if (UB.emptyLast) {  // Close found nothing buffered: final block without data (encoder.go:315-329)
+    if (UB.emptyLast && !JOB) {  // Close found nothing buffered: final block without data (encoder.go:315-329)
         if (tid == 0) { outp[opos] = 0x01; outp[opos + 1] = 0x00; outp[opos + 2] = 0x00; }
         opos += 3;
     }
     // ---- checksum (enc_base.go:34-38) ----
-    if (ulen > 0 && P.crc) {
+    if (ulen > 0 && P.crc && !JOB) {  // (a job stream's checksum covers the whole stream: the host appends it)
         if (tid == 0) {
             const uint64_t h = P.xxh[u];
             outp[opos] = (uint8_t)h; outp[opos + 1] = (uint8_t)(h >> 8); outp[opos + 2] = (uint8_t)(h >> 16); outp[opos + 3] = (uint8_t)(h >> 24);

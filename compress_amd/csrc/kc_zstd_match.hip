@@ -63,7 +63,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
     const int boff = (int)((uintptr_t)base & 15);       // window positions are relative to the 16-byte aligned abase
     const uint8_t* __restrict__ abase = base - boff;
-    const int hist0 = P.hist0;  // dictionary content in front of the unit (history): fastEncoderDict (enc_fast.go:534-790)
+    // history in front of the unit: the dictionary content, or (jobs of a WithConcurrentBlocks stream) the unit's own overlap prefix
+    const int hist0 = P.unit_hist != nullptr ? (int)P.unit_hist[u] : P.hist0;
     const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0 : 0;
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
     const bool ldsUnit = P.lds_split != 0 && (uint32_t)(ulen + hist0) <= KC_ZFAST_LDS_MAX_UNIT;  // the LDS-table kernel's unit
     const int nblk = (gact && !ldsUnit) ? UB.nblk : 0;  // a group without a unit (the launch's tail) does nothing
-    const bool HIST = ulen > bs || hist0 > 0 || UB.streamU;  // with a dictionary encodeAll always calls Encode (encoder.go:783-787)
+    const bool HIST = ulen > bs || hist0 > 0 || UB.streamU || P.job_flags != nullptr;  // compressJob always calls Encode (enc_jobs.go:114)  // with a dictionary encodeAll always calls Encode (encoder.go:783-787)
     uint32_t* __restrict__ tab = tables + (size_t)ui * (1u << ZF_TABLE_BITS);  // zeroed by the host before the launch
     // Table entry = (position+1) in the low PB bits | a TB-bit tag of the 4 source bytes at that position.
     // The reference accepts a candidate iff its 4 bytes equal the probe's (tableEntry.val == uint32(cv),
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
             }
         };
         int SK = 5;  // kSearchStrength - 1
-        if (hist0 > 0) {  // enc_fast.go:539-543,585
+        if (hist0 > 0 && P.job_flags == nullptr) {  // fastEncoderDict only (enc_fast.go:539-543,585); a job's prefix goes through fastEncoder
             if (allDirty || srcLen > (32 << 10)) allDirty = true; else SK = 6;
         }
         if (srcLen >= 10) {

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
     const bool gact = ui < n_launch;
     const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
-    const int hist0 = P.hist0;  // bytes of dictionary content in front of the unit (0 without a dictionary)
+    // history in front of the unit: the dictionary content, or (jobs of a WithConcurrentBlocks stream) the unit's own overlap prefix
+    const int hist0 = P.unit_hist != nullptr ? (int)P.unit_hist[u] : P.hist0;
     const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0 : 0;
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;

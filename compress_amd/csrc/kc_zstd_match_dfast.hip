@@ -33,14 +33,15 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
     const bool gact = ui < n_launch;
     const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
-    const int hist0 = P.hist0;  // dictionary content in front of the unit: doubleFastEncoderDict (enc_dfast.go:678-1031)
+    // history in front of the unit: the dictionary content, or (jobs of a WithConcurrentBlocks stream) the unit's own overlap prefix
+    const int hist0 = P.unit_hist != nullptr ? (int)P.unit_hist[u] : P.hist0;
     const int ulen = gact ? (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0 : 0;
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
     const int mmo = P.max_match_off;
     const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
     const int nblk = gact ? UB.nblk : 0;  // a group without a unit (the launch's tail) does nothing
-    const bool HIST = ulen > bs || hist0 > 0 || UB.streamU;
+    const bool HIST = ulen > bs || hist0 > 0 || UB.streamU || P.job_flags != nullptr;  // compressJob always calls Encode (enc_jobs.go:114)
     uint32_t* __restrict__ ltab = tables + (size_t)ui * ((1u << ZD_LONG_BITS) + (1u << ZD_SHORT_BITS));
     uint32_t* __restrict__ stab = ltab + (1u << ZD_LONG_BITS);
     const int PB = P.pos_bits;

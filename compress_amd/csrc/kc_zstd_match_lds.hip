@@ -59,6 +59,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
     const int boff = (int)((uintptr_t)base & 15);  // window positions are relative to the 16-byte aligned abase
     const uint8_t* __restrict__ abase = base - boff;
+    if (P.unit_hist != nullptr || P.job_flags != nullptr) return;  // jobs carry per-unit history: the HBM-table kernel's (the host never launches this one for them)
     const int hist0 = P.hist0;
     const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0;
     if ((uint32_t)(ulen + hist0) > KC_ZFAST_LDS_MAX_UNIT) return;  // beyond the 18-bit position field: the HBM-table kernel's unit

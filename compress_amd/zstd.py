@@ -8,6 +8,7 @@ zstd/encoder_options.go; the bytes come from the HIP engine behind include/kcgpu
     frames, off = enc.EncodeUnits(buf, unit_off)        # N independent EncodeAll calls, one launch
 """
 import ctypes as C
+import os
 
 from . import _lib
 from ._lib import KcError
@@ -108,10 +109,26 @@ def WithMatchPath(path):
 
 
 def WithEncoderConcurrency(n):
-    """Accepted for API compatibility; the device path is batch-parallel (no bytes depend on it)."""
+    """zstd.WithEncoderConcurrency.  The device path is batch-parallel; the only bytes that depend on it are those of
+    WithConcurrentBlocks, which the reference switches off when the concurrency is 1 (zstd/encoder.go:81)."""
     if n <= 0:
         raise ValueError("concurrency must be at least 1")
-    return lambda o: None
+
+    def apply(o):
+        pass
+    apply._kc_concurrency = int(n)
+    return apply
+
+
+def WithConcurrentBlocks(b):
+    """zstd.WithConcurrentBlocks (zstd/encoder_options.go:340-353): the stream written through Write / ReadFrom / Flush / Close is
+    cut into jobs of max(4 * window, 512 KiB) bytes, each encoded with the tail of the previous job as its history
+    (zstd/enc_jobs.go) — independent units for the device (kc_zstd_encode_jobs).  As in the reference it has no effect with a
+    dictionary or with WithEncoderConcurrency(1)."""
+    def apply(o):
+        pass
+    apply._kc_conc_blocks = bool(b)
+    return apply
 
 
 def WithLowerEncoderMem(b):
@@ -135,9 +152,16 @@ class Encoder:
         L = _lib.load()
         self.o = _lib.ZstdOpts()
         L.kc_zstd_opts_default(C.byref(self.o))
+        self._conc_blocks, self._concurrency = False, os.cpu_count() or 1  # o.concurrent defaults to GOMAXPROCS (encoder_options.go:38)
         for op in opts:
             if hasattr(op, "_kc_path"):
                 self._path = op._kc_path
+                continue
+            if hasattr(op, "_kc_conc_blocks"):
+                self._conc_blocks = op._kc_conc_blocks
+                continue
+            if hasattr(op, "_kc_concurrency"):
+                self._concurrency = op._kc_concurrency
                 continue
             op(self.o)
         self._device, self._stream = device, stream
@@ -251,9 +275,36 @@ class Encoder:
         cuts, self._cuts = self._cuts, []
         self._buf = bytearray()
         self._closed = True
+        if self._conc_blocks and self._concurrency > 1 and not self.o.dict_len:  # zstd/encoder.go:81: else the option is off
+            self._w.write(self.EncodeJobs(data, cuts))
+            return
         out, _ = self.EncodeStreams(np.frombuffer(data, dtype=np.uint8), np.array([0, len(data)], dtype=np.uint64),
                                     flush_at=[cuts] if cuts else None)
         self._w.write(out.tobytes())
+
+    def JobSize(self):
+        return int(_lib.load().kc_zstd_job_size(C.byref(self.o)))
+
+    def OverlapSize(self):
+        return int(_lib.load().kc_zstd_overlap_size(C.byref(self.o)))
+
+    def EncodeJobs(self, src, flush_at=()):
+        """ONE stream with WithConcurrentBlocks(true): NewWriter(w, opts, WithConcurrentBlocks(true)); Write(src) with Flush at
+        flush_at; Close() (kc_zstd_encode_jobs: the jobs of zstd/enc_jobs.go are the device's units).  Returns bytes."""
+        import numpy as np
+        ctx = self.ctx()
+        src = np.frombuffer(bytes(src), dtype=np.uint8) if not isinstance(src, np.ndarray) else np.ascontiguousarray(src, dtype=np.uint8)
+        n = len(src)
+        cuts = np.ascontiguousarray(sorted(int(x) for x in flush_at), dtype=np.uint64)
+        js, ov = self.JobSize(), self.OverlapSize()
+        njobs = n // js + len(cuts) + 2
+        cap = njobs * (((self.MaxEncodedSize(js + ov) - js - ov) + 31) & ~15) + n + njobs * ov + 4096
+        dst = np.empty(cap, dtype=np.uint8)
+        out_len = C.c_uint64(0)
+        sp = src.ctypes.data if n else None
+        ctx.check(ctx.L.kc_zstd_encode_jobs(ctx.h, C.byref(self.o), sp, n, cuts.ctypes.data if len(cuts) else None, len(cuts),
+                                            dst.ctypes.data, cap, C.byref(out_len)))
+        return dst[:out_len.value].tobytes()
 
     def EncodeStreams(self, src, unit_off, flush_at=None):
         """Like EncodeUnits, but every unit is a stream: NewWriter(w).Write(unit) ... Close().  flush_at: per stream, the byte

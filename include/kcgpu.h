@@ -100,6 +100,21 @@ int64_t kc_zstd_max_encoded_size(const kc_zstd_opts* o, int64_t size);
 kc_status kc_ctx_create(kc_ctx** out, int device, void* stream);
 void kc_ctx_destroy(kc_ctx* ctx);
 const char* kc_last_error(const kc_ctx* ctx);
+/* ONE stream with WithConcurrentBlocks(true) (zstd/encoder_options.go:340-353; zstd/enc_jobs.go): the bytes equal
+ *   enc, _ := zstd.NewWriter(w, opts..., zstd.WithConcurrentBlocks(true))   (with WithEncoderConcurrency > 1)
+ *   enc.Write(src[...]) with enc.Flush() after cuts[0], cuts[1], ... bytes (ascending; a Write followed by ReadFrom is such a point, encoder.go:500-507); enc.Close()
+ * The reference cuts the stream into jobs of kc_zstd_job_size() input bytes (a Flush ends a job early), encodes each on a freshly
+ * reset encoder whose history is the last kc_zstd_overlap_size() bytes of the previous job's input (ResetPrefix,
+ * zstd/enc_fast.go:800-811, enc_dfast.go:1040-1050, enc_better.go:1099-1112) and concatenates the outputs behind one frame header:
+ * the jobs are independent units, which is what this engine wants: this is the reference's own way of turning ONE stream into
+ * device work.  src / dst are HOST buffers; dst_cap >= sum over jobs of kc_zstd_max_encoded_size(job + overlap) + 16.  A stream of
+ * at most one block is the EncodeAll frame (enc_jobs.go:263-279).  With a dictionary the reference switches the option off
+ * (zstd/encoder.go:81,174): KC_ERR_UNSUPPORTED. */
+kc_status kc_zstd_encode_jobs(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* src, uint64_t len, const uint64_t* cuts, uint64_t n_cuts,
+                              uint8_t* dst, uint64_t dst_cap, uint64_t* out_len);
+int64_t kc_zstd_job_size(const kc_zstd_opts* o);     /* encoderOptions.jobSize, zstd/encoder_options.go:356-359 */
+int64_t kc_zstd_overlap_size(const kc_zstd_opts* o); /* encoderOptions.overlapSize, zstd/encoder_options.go:362-371 */
+
 /* ---- context options ----
  * Every tunable of the library is a field of the context.  kc_ctx_create seeds them ONCE from the environment variable named
  * beside each key (no entry point reads the environment afterwards); kc_ctx_set_option changes them.

@@ -228,6 +228,78 @@ struct OracleEncoder {
         if (o.crc) enc->AppendCRC(dst);
         return 0;
     }
+
+    // WithConcurrentBlocks(true) (and concurrency > 1, no dictionary): NewWriter(w); Write(src[...]) with Flush at each cuts[i];
+    // Close().  Restates writeJobs (encoder.go:214-247), flushJobs (:585-597), closeJobs (:652-700), dispatchJob and compressJob
+    // (enc_jobs.go:251-352, 88-124) for that call sequence: jobs of jobSize = max(4 * window, 512 KiB) input bytes
+    // (encoder_options.go:356-359), each encoded on a freshly reset encoder whose history is the last overlapSize bytes of the
+    // previous job's input (:362-371; ResetPrefix), the job outputs concatenated behind one frame header.
+    int encodeJobs(const uint8_t* src, size_t n, const uint64_t* cuts, size_t n_cuts, Bytes* dst) {
+        if (hasDict) return -1;  // the reference switches the option off with a dictionary (encoder.go:81, :174)
+        const size_t jobSize = std::max<size_t>((size_t)o.window_size * 4, (size_t)512 << 10);
+        const size_t overlapSize = o.level == 4 ? (size_t)o.window_size / 2 : (o.level == 3 ? (size_t)o.window_size / 4 : (size_t)o.window_size / 8);
+        // non-final jobs: dispatched when `filling` reaches jobSize, or by a Flush that finds bytes in it
+        std::vector<std::pair<size_t, size_t>> jobs;
+        size_t pos = 0, ci = 0;
+        for (;;) {
+            while (ci < n_cuts && cuts[ci] <= pos) ci++;
+            size_t e = pos + jobSize;
+            bool dispatched = e <= n;  // filled up during Write
+            if (ci < n_cuts && cuts[ci] < e && cuts[ci] <= n) { e = (size_t)cuts[ci]; dispatched = true; }
+            if (!dispatched) break;
+            jobs.push_back({pos, e});
+            pos = e;
+        }
+        const size_t tail = n - pos;  // what Close finds in `filling`
+        bool headerWritten = !jobs.empty();
+        if (!headerWritten) {  // dispatchJob(true), :263-289
+            if (tail > 0 && tail <= (size_t)o.block_size) return encodeAll(src, n, dst);
+            if (tail == 0 && !o.full_zero) return 0;
+        }
+        enc->Reset(nullptr, false);  // (the encoder of the Encoder state: only its WindowSize and CRC are used below)
+        frameHeaderAppend(dst, 0, (uint32_t)enc->WindowSize(0), false, o.crc != 0, 0);
+        jobs.push_back({pos, n});  // the final job, possibly empty
+        XXH64 crcAll;
+        if (o.crc) crcAll.Write(src, n);
+        size_t prevLo = 0, prevHi = 0;
+        for (size_t j = 0; j < jobs.size(); j++) {
+            const bool last = j + 1 == jobs.size();
+            const size_t lo = jobs[j].first, hi = jobs[j].second;
+            // compressJob (enc_jobs.go:88)
+            if (j > 0 && prevHi > prevLo) {
+                const size_t ov = std::min(overlapSize, prevHi - prevLo);
+                enc->ResetPrefix(src + prevHi - ov, ov);
+            } else {
+                enc->Reset(nullptr, false);
+            }
+            BlockEnc* blk = &enc->blk;
+            if (hi == lo && last) {
+                blk->reset(nullptr);
+                blk->last = true;
+                blk->encodeRawTo(0, src, 0);  // blockenc.go:310 encodeRaw(nil): an empty raw block with the last flag
+                dst->insert(dst->end(), blk->output.begin(), blk->output.end());
+            } else {
+                size_t p = lo;
+                while (p < hi) {
+                    const size_t todo = std::min<size_t>(hi - p, (size_t)o.block_size);
+                    blk->pushOffsets();
+                    enc->Encode(blk, src + p, todo);
+                    blk->last = (p + todo == hi) && last;
+                    if (blk->encode(src + p, todo, o.no_entropy != 0, !o.all_lit_entropy) != 0) return -1;
+                    dst->insert(dst->end(), blk->output.begin(), blk->output.end());
+                    blk->reset(nullptr);
+                    p += todo;
+                }
+            }
+            prevLo = lo;
+            prevHi = hi;
+        }
+        if (o.crc) {
+            const uint64_t h = crcAll.Sum64();
+            for (int k = 0; k < 4; k++) dst->push_back((uint8_t)(h >> (8 * k)));
+        }
+        return 0;
+    }
 };
 
 // zstd/encoder.go:843 MaxEncodedSize (pad==0)
@@ -265,6 +337,15 @@ int64_t kco_s2_index(int32_t block_size, const int64_t* comp, const int64_t* unc
 int64_t kco_zstd_encode_stream(void* e, const uint8_t* src, uint64_t n, const uint64_t* cuts, uint64_t n_cuts, uint8_t* dst, uint64_t cap) {
     Bytes out;
     if (((OracleEncoder*)e)->encodeStream(src, (size_t)n, cuts, (size_t)n_cuts, &out) != 0) return -1;
+    if (out.size() > cap) return -2;
+    memcpy(dst, out.data(), out.size());
+    return (int64_t)out.size();
+}
+
+// The same with WithConcurrentBlocks(true) (OracleEncoder::encodeJobs).
+int64_t kco_zstd_encode_jobs(void* e, const uint8_t* src, uint64_t n, const uint64_t* cuts, uint64_t n_cuts, uint8_t* dst, uint64_t cap) {
+    Bytes out;
+    if (((OracleEncoder*)e)->encodeJobs(src, (size_t)n, cuts, (size_t)n_cuts, &out) != 0) return -1;
     if (out.size() > cap) return -2;
     memcpy(dst, out.data(), out.size());
     return (int64_t)out.size();

@@ -25,6 +25,18 @@ struct BetterFastEncoder : FastBase {  // enc_better.go:40
         Encode(blk, src, n);
     }
     void Reset(const DictO* d, bool singleBlock) override { resetBase(d, singleBlock); }  // :1092
+    // enc_better.go:1099 ResetPrefix: every 2nd position into the long table (with its chain) and, one byte on, the short table
+    void ResetPrefix(const uint8_t* prefix, size_t n) override {
+        resetBasePrefix(prefix, n);
+        if (n < 8) return;
+        const int32_t end = cur + (int32_t)n - 8;
+        for (int32_t i = cur; i < end; i += 2) {
+            const uint64_t cv = load64(prefix, i - cur);
+            const uint32_t h = hashLen(cv, betterLongTableBits, betterLongLen);
+            longTable[h] = PrevEntry{i, longTable[h].offset};
+            table[hashLen(cv >> 8, betterShortTableBits, betterShortLen)] = TableEntry{(uint32_t)(cv >> 8), i + 1};
+        }
+    }
 };
 
 template <bool DICT>

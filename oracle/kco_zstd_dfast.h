@@ -339,6 +339,18 @@ struct DoubleFastEncoder : DoubleFastT<FastEncoder> {  // enc_dfast.go:25
     void Encode(BlockEnc* blk, const uint8_t* src, size_t n) override { dfEncode(blk, src, n); }
     void EncodeNoHist(BlockEnc* blk, const uint8_t* src, size_t n) override { dfEncodeNoHist(blk, src, n); }
     void Reset(const DictO* d, bool singleBlock) override { FastEncoder::Reset(d, singleBlock); }  // :1033
+    // enc_dfast.go:1040 ResetPrefix: fastEncoder.ResetPrefix fills the SHORT table through the fast encoder's 6-byte hash (the
+    // lookups of this encoder hash 5 bytes: the entries sit in other buckets than a lookup of the same bytes would read — kept
+    // as the reference has it), then every 2nd position goes into the long table
+    void ResetPrefix(const uint8_t* prefix, size_t n) override {
+        FastEncoder::ResetPrefix(prefix, n);
+        if (n < 8) return;
+        const int32_t end = cur + (int32_t)n - 8;
+        for (int32_t i = cur + 1; i < end; i += 2) {
+            const uint64_t cv = load64(prefix, i - cur);
+            longTable[hashLen(cv, dFastLongTableBits, dFastLongLen)] = TableEntry{(uint32_t)cv, i};
+        }
+    }
 };
 
 struct DoubleFastEncoderDict : DoubleFastT<FastEncoderDict> {  // enc_dfast.go:30

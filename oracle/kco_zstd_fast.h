@@ -135,7 +135,20 @@ struct FastBase {  // zstd/enc_base.go:14
             hist.insert(hist.end(), d->content.begin(), d->content.end());
         }
     }
+    // enc_base.go:134 resetBasePrefix (WithConcurrentBlocks jobs: history = the overlap prefix of the previous job)
+    void resetBasePrefix(const uint8_t* prefix, size_t n) {
+        blk.reset(nullptr);
+        blk.initNewEncode();
+        crc.Reset();
+        blk.dictLitEnc = nullptr;
+        ensureHist((int)n + maxCompressedBlockSize);
+        // Bump cur so old table entries fall outside the window (:149-154)
+        if (cur < bufferReset) cur += maxMatchOff + (int32_t)hist.size();
+        hist.clear();
+        hist.insert(hist.end(), prefix, prefix + n);
+    }
     // zstd/encoder.go:32 encoder interface
+    virtual void ResetPrefix(const uint8_t* prefix, size_t n) = 0;
     virtual void Encode(BlockEnc* b, const uint8_t* src, size_t n) = 0;
     virtual void EncodeNoHist(BlockEnc* b, const uint8_t* src, size_t n) = 0;
     virtual void Reset(const DictO* d, bool singleBlock) = 0;
@@ -156,6 +169,16 @@ struct FastEncoder : FastBase {  // zstd/enc_fast.go:26
     void Encode(BlockEnc* blk, const uint8_t* src, size_t n) override { encodeImpl(blk, src, n, 6, false); }
     void EncodeNoHist(BlockEnc* blk, const uint8_t* src, size_t n) override;
     void Reset(const DictO* d, bool singleBlock) override { resetBase(d, singleBlock); }  // :793 (panics on dict)
+    // enc_fast.go:800 ResetPrefix: the prefix becomes history, every 4th position of it is indexed
+    void ResetPrefix(const uint8_t* prefix, size_t n) override {
+        resetBasePrefix(prefix, n);
+        if (n < 8) return;
+        const int32_t end = cur + (int32_t)n - 8;
+        for (int32_t i = cur + 1; i < end; i += 4) {
+            const uint64_t cv = load64(prefix, i - cur);
+            table[hashLen(cv, tableBits, tableFastHashLen)] = TableEntry{(uint32_t)cv, i};
+        }
+    }
     virtual void markShardDirty(uint32_t) {}
 };
 

@@ -146,6 +146,20 @@ class ZstdOracle:
             raise RuntimeError("oracle encode_stream failed: %d" % r)
         return buf.raw[:r]
 
+    def encode_jobs(self, src: bytes, flush_at=()) -> bytes:
+        """NewWriter(w, WithConcurrentBlocks(true), concurrency > 1); Write(src) with Flush at flush_at; Close()."""
+        import numpy as np
+        L = lib()
+        L.kco_zstd_encode_jobs.restype = C.c_int64
+        L.kco_zstd_encode_jobs.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
+        cuts = np.ascontiguousarray(sorted(flush_at), dtype=np.uint64)
+        cap = len(src) + len(src) // 64 + 3 * (len(src) // 1024 + len(cuts)) + 4096
+        buf = C.create_string_buffer(cap)
+        r = L.kco_zstd_encode_jobs(self.h, src, len(src), cuts.ctypes.data if len(cuts) else None, len(cuts), buf, cap)
+        if r < 0:
+            raise RuntimeError("oracle encode_jobs failed: %d" % r)
+        return buf.raw[:r]
+
     def encode_all(self, src: bytes) -> bytes:
         cap = self.max_encoded_size(len(src)) + 64
         buf = C.create_string_buffer(cap)

@@ -1,0 +1,124 @@
+"""WithConcurrentBlocks job mode (zstd/enc_jobs.go): the oracle's restatement, and the device path against it.
+
+One stream is cut into jobs of max(4 * window, 512 KiB) input bytes; each job is encoded on a freshly reset encoder whose
+history is the tail of the previous job (ResetPrefix); the outputs are concatenated behind one frame header.  The jobs are
+independent units, which is how ONE stream becomes device work (kc_zstd_encode_jobs)."""
+import numpy as np
+import pytest
+
+import corpora
+
+
+def _cases():
+    t = corpora.corpus("T", 24, 131072, first_unit=300).tobytes()  # 3 MiB
+    m = corpora.corpus("M", 24, 131072, first_unit=40).tobytes()
+    return t, m
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_oracle_jobs_frames_decode_and_have_the_documented_shape(oracle, level):
+    """CPU: the oracle's job-mode frames round-trip through the independent libzstd decoder for every job count, Flush pattern
+    and window; the special cases of dispatchJob hold (a one-block stream is the EncodeAll frame, an empty stream the 9-byte...
+    streaming frame, a stream of exactly k jobs ends in an empty raw last block)."""
+    t, m = _cases()
+    for win in (1 << 17, 1 << 18):  # jobs of 512 KiB / 1 MiB
+        e = oracle.ZstdOracle(level=level, window_size=win)
+        js = max(4 * win, 512 << 10)
+        for data in (t, m, t[:js], t[:2 * js], t[:js + 1], t[:js - 1], t[:70000], m[:1 << 20]):
+            for cuts in ((), (1000, 300000), (len(data),), (js // 2, js // 2 + 10, js + 77)):
+                fr = e.encode_jobs(data, cuts)
+                assert oracle.zstd_decompress(fr, len(data) + 16) == data, (level, win, len(data), cuts)
+        # a stream of at most one block with no Flush before Close is the EncodeAll frame (enc_jobs.go:263-279)
+        bs = 65536 if level == 1 else 131072
+        assert e.encode_jobs(t[:bs]) == e.encode_all(t[:bs])
+        assert e.encode_jobs(t[:100]) == e.encode_all(t[:100])
+        # ... but not when a Flush dispatched a job first: then a header was written and the blocks follow
+        assert e.encode_jobs(t[:100], (50,)) != e.encode_all(t[:100])
+        # exactly two jobs' worth of input: both are dispatched by Write, Close adds the empty raw last block + checksum
+        fr = e.encode_jobs(t[:2 * js])
+        assert fr[-7:-4] == b"\x01\x00\x00", fr[-8:].hex()
+        # no window descriptor games: same header as the plain stream's
+        assert fr[:6] == e.encode_stream(t[:2 * js])[:6]
+        assert e.encode_jobs(b"") == e.encode_stream(b"")
+
+
+def test_jobs_differ_from_the_plain_stream_only_in_history(oracle):
+    """Same blocks, different history: below one job the two modes give the same bytes, above they differ (the second job starts
+    from the overlap prefix alone)."""
+    t, _ = _cases()
+    e = oracle.ZstdOracle(level=1, window_size=1 << 17)
+    js = 512 << 10
+    assert e.encode_jobs(t[:js - 5]) == e.encode_stream(t[:js - 5])
+    assert e.encode_jobs(t[:3 * js]) != e.encode_stream(t[:3 * js])
+
+
+def _enc(level, **kw):
+    from compress_amd import zstd
+    opts = [zstd.WithEncoderLevel(level), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(4)]
+    if "window" in kw:
+        opts.append(zstd.WithWindowSize(kw["window"]))
+    return zstd.NewWriter(None, *opts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_device_jobs_bit_exact_small(oracle, kclib, level):
+    """GPU: kc_zstd_encode_jobs == the oracle's job mode for every job count / Flush pattern of the CPU test (small windows: many
+    jobs, short prefixes, prefixes shorter than the overlap, empty final jobs)."""
+    import torch
+    assert torch.cuda.is_available()
+    t, m = _cases()
+    for win in (1 << 17, 1 << 18):
+        e = oracle.ZstdOracle(level=level, window_size=win)
+        enc = _enc(level, window=win)
+        js = enc.JobSize()
+        assert js == max(4 * win, 512 << 10)
+        for data in (t, m, t[:js], t[:2 * js], t[:js + 1], t[:js - 1], t[:70000], t[:100], b""):
+            for cuts in ((), (1000, 300000), (len(data),), (js // 2, js // 2 + 10, js + 77)):
+                got = enc.EncodeJobs(data, cuts)
+                ref = e.encode_jobs(data, cuts)
+                assert got == ref, "level %d window %d len %d cuts %r: %d bytes vs oracle %d" % (level, win, len(data), cuts, len(got), len(ref))
+        enc.Close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_device_jobs_bit_exact_256mib_stream(oracle, kclib, level):
+    """GPU: a 256 MiB stream at every level, 1 MiB window -> 64 jobs of 4 MiB with 128 / 256 KiB of overlap; and through the
+    Write / Flush / Close face of the Encoder."""
+    import io
+    import torch
+    assert torch.cuda.is_available()
+    data = corpora.corpus("T" if level != 3 else "M", 2048, 131072, first_unit=7000).tobytes()
+    e = oracle.ZstdOracle(level=level, window_size=1 << 20)
+    ref = e.encode_jobs(data)
+    enc = _enc(level, window=1 << 20)
+    got = enc.EncodeJobs(data)
+    assert len(got) == len(ref) and got == ref
+    assert oracle.zstd_decompress(got[:], len(data) + 16) == data
+    enc.Close()
+    # the Writer face: Write, Flush, ReadFrom, Close
+    sink = io.BytesIO()
+    from compress_amd import zstd
+    w = zstd.NewWriter(sink, zstd.WithEncoderLevel(level), zstd.WithWindowSize(1 << 20), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(2))
+    w.Write(data[:5000000])
+    w.Flush()
+    w.Write(data[5000000:9000000])
+    w.ReadFrom(io.BytesIO(data[9000000:20000000]))
+    w.Close()
+    assert sink.getvalue() == e.encode_jobs(data[:20000000], (5000000, 9000000))
+
+
+@pytest.mark.gpu
+def test_device_jobs_default_window_speedfastest(oracle, kclib):
+    """GPU: SpeedFastest with its own 4 MiB window: jobs of 16 MiB, 512 KiB of overlap, 64 KiB blocks — 256 MiB = 16 jobs + the
+    empty final job."""
+    import torch
+    assert torch.cuda.is_available()
+    data = corpora.corpus("T", 2048, 131072, first_unit=11000).tobytes()
+    enc = _enc(1)
+    assert enc.JobSize() == 16 << 20 and enc.OverlapSize() == 512 << 10
+    got = enc.EncodeJobs(data)
+    ref = oracle.ZstdOracle(level=1).encode_jobs(data)
+    assert got == ref
+    enc.Close()
