@@ -49,6 +49,78 @@ type Encoder struct {
 	poolMu   sync.Mutex
 	created  int  // contexts created so far (<= conc)
 	noDevice bool // kc_ctx_create failed once: reference only
+	jobs     bool // WithConcurrentBlocks(true)
+	hasDict  bool
+}
+
+// WithConcurrentBlocks mirrors zstd.WithConcurrentBlocks (zstd/encoder_options.go:340-353): a Writer's stream is cut into jobs
+// of max(4 * window, 512 KiB) bytes, each encoded with the tail of the previous job as history (zstd/enc_jobs.go).  The jobs are
+// independent units: this is the mode in which ONE large stream is device work (kc_zstd_encode_jobs).  As in the reference it has
+// no effect with a dictionary or with WithEncoderConcurrency(1).
+func WithConcurrentBlocks(b bool) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithConcurrentBlocks(b))
+		e.jobs = b
+		return nil
+	}
+}
+
+// jobMode: the option is in force (zstd/encoder.go:81).
+func (e *Encoder) jobMode() bool { return e.jobs && !e.hasDict && e.conc > 1 }
+
+// EncodeJobs == zstd.NewWriter(w, opts..., zstd.WithConcurrentBlocks(true)); Write(src) with Flush after flushAt[i] bytes; Close().
+func (e *Encoder) EncodeJobs(src []byte, flushAt []uint64) ([]byte, error) {
+	var ctx *C.kc_ctx
+	if len(src) > 0 && e.useDevice(len(src)) && e.jobMode() {
+		ctx = e.acquire()
+	}
+	if ctx != nil {
+		defer e.release(ctx)
+		js := int(C.kc_zstd_job_size(&e.opts))
+		ov := int(C.kc_zstd_overlap_size(&e.opts))
+		njobs := len(src)/js + len(flushAt) + 2
+		dst := make([]byte, len(src)+njobs*(ov+(e.MaxEncodedSize(js+ov)-js-ov)+32)+4096)
+		cuts := append([]uint64{}, flushAt...)
+		cuts = append(cuts, 0) // never empty: &cuts[0] below
+		var outLen C.uint64_t
+		st := C.kc_zstd_encode_jobs(ctx, &e.opts, (*C.uint8_t)(unsafe.Pointer(&src[0])), C.uint64_t(len(src)),
+			(*C.uint64_t)(unsafe.Pointer(&cuts[0])), C.uint64_t(len(flushAt)),
+			(*C.uint8_t)(unsafe.Pointer(&dst[0])), C.uint64_t(len(dst)), &outLen)
+		if st == C.KC_OK {
+			return dst[:outLen], nil
+		}
+		if st != C.KC_ERR_UNSUPPORTED && st != C.KC_ERR_NO_DEVICE {
+			return nil, errors.New(C.GoString(C.kc_last_error(ctx)))
+		}
+	}
+	// reference path
+	var sink bytes.Buffer
+	r, err := zstd.NewWriter(&sink, e.cpuOpts...)
+	if err != nil {
+		return nil, err
+	}
+	pos := uint64(0)
+	for _, c := range flushAt {
+		if c > uint64(len(src)) {
+			c = uint64(len(src))
+		}
+		if c > pos {
+			if _, err := r.Write(src[pos:c]); err != nil {
+				return nil, err
+			}
+			pos = c
+		}
+		if err := r.Flush(); err != nil {
+			return nil, err
+		}
+	}
+	if _, err := r.Write(src[pos:]); err != nil {
+		return nil, err
+	}
+	if err := r.Close(); err != nil {
+		return nil, err
+	}
+	return sink.Bytes(), nil
 }
 
 // WithEncoderConcurrency mirrors zstd.WithEncoderConcurrency: how many calls may be in flight on this Encoder (device
@@ -156,6 +228,7 @@ func WithSingleSegment(b bool) Option {
 func WithEncoderDict(dict []byte) Option {
 	return func(e *Encoder) error {
 		e.cpuOpts = append(e.cpuOpts, zstd.WithEncoderDict(dict))
+		e.hasDict = true
 		e.setDictMem(dict)
 		if C.kc_zstd_opts_dict(&e.opts, (*C.uint8_t)(e.dictMem), C.uint64_t(len(dict))) != 0 {
 			return errors.New("invalid dictionary")
@@ -168,6 +241,7 @@ func WithEncoderDict(dict []byte) Option {
 func WithEncoderDictRaw(id uint32, content []byte) Option {
 	return func(e *Encoder) error {
 		e.cpuOpts = append(e.cpuOpts, zstd.WithEncoderDictRaw(id, content))
+		e.hasDict = true
 		e.setDictMem(content)
 		if C.kc_zstd_opts_dict_raw(&e.opts, C.uint32_t(id), (*C.uint8_t)(e.dictMem), C.uint64_t(len(content))) != 0 {
 			return errors.New("invalid dictionary")
@@ -522,6 +596,14 @@ func (x *Writer) ReadFrom(r io.Reader) (int64, error) {
 // Flush (encoder.go:547) ends the current block early.  The caller wants the bytes on w now: the stream continues on the
 // reference encoder (the cut is replayed there).
 func (x *Writer) Flush() error {
+	if x.ref == nil && x.e.jobMode() {
+		// job mode keeps the stream for the device: the Flush is recorded as a job cut (enc_jobs.go: a Flush dispatches the
+		// job being filled) and the bytes reach w on Close
+		if len(x.buf) > 0 {
+			x.cuts = append(x.cuts, uint64(len(x.buf)))
+		}
+		return nil
+	}
 	if err := x.fallback(); err != nil {
 		return err
 	}
@@ -542,7 +624,13 @@ func (x *Writer) Close() error {
 	if x.ref != nil {
 		return x.ref.Close()
 	}
-	out, _, err := x.e.EncodeStreamsCuts(x.buf, []uint64{0, uint64(len(x.buf))}, [][]uint64{x.cuts}, nil)
+	var out []byte
+	var err error
+	if x.e.jobMode() {
+		out, err = x.e.EncodeJobs(x.buf, x.cuts)
+	} else {
+		out, _, err = x.e.EncodeStreamsCuts(x.buf, []uint64{0, uint64(len(x.buf))}, [][]uint64{x.cuts}, nil)
+	}
 	if err != nil {
 		return err
 	}

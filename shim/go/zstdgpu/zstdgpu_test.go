@@ -419,3 +419,44 @@ func corpusT(n int) []byte {
 	}
 	return data[:n]
 }
+
+
+// TestConcurrentBlocks: the job mode (zstd.WithConcurrentBlocks) through the device == the reference's, for plain streams, with
+// Flush points and through the Writer face.
+func TestConcurrentBlocks(t *testing.T) {
+	data := corpusT(48 << 20)
+	for _, lvl := range levels {
+		for _, win := range []int{1 << 17, 1 << 20, 0} {
+			ropts := []zstd.EOption{zstd.WithEncoderLevel(lvl), zstd.WithConcurrentBlocks(true), zstd.WithEncoderConcurrency(4)}
+			gopts := []Option{WithDeviceMinBytes(0), WithEncoderLevel(lvl), WithConcurrentBlocks(true), WithEncoderConcurrency(4)}
+			if win > 0 {
+				ropts = append(ropts, zstd.WithWindowSize(win))
+				gopts = append(gopts, WithWindowSize(win))
+			}
+			for _, cuts := range [][]uint64{nil, {1000, 3 << 20}, {uint64(len(data))}} {
+				var want bytes.Buffer
+				ref, _ := zstd.NewWriter(&want, ropts...)
+				pos := uint64(0)
+				for _, c := range cuts {
+					ref.Write(data[pos:c])
+					ref.Flush()
+					pos = c
+				}
+				ref.Write(data[pos:])
+				ref.Close()
+				gpu, err := New(0, gopts...)
+				if err != nil {
+					t.Fatal(err)
+				}
+				got, err := gpu.EncodeJobs(data, cuts)
+				gpu.Close()
+				if err != nil {
+					t.Fatal(err)
+				}
+				if !bytes.Equal(got, want.Bytes()) {
+					t.Fatalf("level %v window %d cuts %v: %d bytes vs the reference's %d", lvl, win, cuts, len(got), want.Len())
+				}
+			}
+		}
+	}
+}
