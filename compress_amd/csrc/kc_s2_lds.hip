@@ -135,19 +135,31 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
     if (len < 32) stored = true;  // minNonLiteralBlockSize (also len == 0 in a framed stream)
 
     // emitLiteral(dst[d:], src[from:from+n]) (encode_go.go:80): lane 0 the tag, all lanes the bytes
+    // Tag bytes are assembled in a register by every lane (the values are wave-uniform: scalar code) and stored by lane 0 as ONE
+    // 8-byte word together with the first literal bytes; the bytes of that word past the emit's end are overwritten by the next
+    // emit (emission is strictly sequential, the slot has MaxEncodedLen - dstLimit bytes of slack).
     auto emit_lit = [&](int from, int n) -> int {
         if (n == 0) return 0;
         const uint32_t m = (uint32_t)(n - 1);
         uint8_t* __restrict__ o = dst + d;
         int i;
-        if (m < 60) { i = 1; if (lane == 0) o[0] = (uint8_t)(m << 2); }
-        else if (m < (1u << 8)) { i = 2; if (lane == 0) { o[0] = 60 << 2; o[1] = (uint8_t)m; } }
-        else if (m < (1u << 16)) { i = 3; if (lane == 0) { o[0] = 61 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); } }
-        else if (m < (1u << 24)) { i = 4; if (lane == 0) { o[0] = 62 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); o[3] = (uint8_t)(m >> 16); } }
-        else { i = 5; if (lane == 0) { o[0] = 63 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); o[3] = (uint8_t)(m >> 16); o[4] = (uint8_t)(m >> 24); } }
-        const int body = n & ~7;
-        for (int k = lane * 8; k < body; k += 512) st64(o + i + k, rd64(from + k));
-        for (int k = body + lane; k < n; k += 64) o[i + k] = (uint8_t)rdb(from + k);
+        uint64_t tag;
+        if (m < 60) { i = 1; tag = m << 2; }
+        else if (m < (1u << 8)) { i = 2; tag = (60u << 2) | ((uint64_t)m << 8); }
+        else if (m < (1u << 16)) { i = 3; tag = (61u << 2) | ((uint64_t)m << 8); }
+        else if (m < (1u << 24)) { i = 4; tag = (62u << 2) | ((uint64_t)m << 8); }
+        else { i = 5; tag = (63u << 2) | ((uint64_t)m << 8); }
+        const int head = n < 8 - i ? n : 8 - i;  // literal bytes that share the tag's word
+        if (lane == 0) {
+            uint64_t hv = 0;
+            if (SRCLDS || from + 8 <= len) hv = rd64(from);
+            else for (int k = 0; k < head; k++) hv |= (uint64_t)rdb(from + k) << (8 * k);
+            st64(o, tag | (hv << (8 * i)));
+        }
+        const int rest = n - head;
+        const int body = rest & ~7;
+        for (int k = lane * 8; k < body; k += 512) st64(o + 8 + k, rd64(from + head + k));
+        for (int k = body + lane; k < rest; k += 64) o[8 + k] = (uint8_t)rdb(from + head + k);
         return i + n;
     };
     // forward extension in whole 8-byte steps while a <= limit (encode_all.go:353-360, :435-442); returns the new a
@@ -172,6 +184,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
     };
     // number of k = 1..kmax with src[t-k] == src[s-k], consecutively (the backward extension loops)
     auto backlen = [&](int sp, int tp, int kmax) -> int {
+        if (kmax <= 0 || rdb(tp - 1) != rdb(sp - 1)) return 0;  // the usual case, decided on one (wave-uniform) byte pair
         int cnt = 0;
         while (cnt < kmax) {
             const int k = cnt + lane + 1;
@@ -184,11 +197,18 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
         }
         return cnt < kmax ? cnt : kmax;
     };
+    // emitCopy / emitRepeat (encode_go.go:118-234): at most 10 bytes for blocks below 16 MiB, assembled in two registers by every
+    // lane (uniform), stored by lane 0 as one or two 8-byte words
     auto emit_copy_any = [&](int offset, int length, bool asRepeat) -> int {
-        if (SNAPPY) { if (lane == 0) s2_emit_copy_nr1(dst + d, offset, length); return s2_copy_nr_size(offset, length); }
-        if (asRepeat) { if (lane == 0) s2_emit_repeat1(dst + d, offset, length); return s2_repeat_size(offset, length); }
-        if (lane == 0) s2_emit_copy1(dst + d, offset, length);
-        return s2_copy_size(offset, length);
+        if (SNAPPY) { if (lane == 0) s2_emit_copy_nr1(dst + d, offset, length); return s2_copy_nr_size(offset, length); }  // (can be hundreds of 3-byte operations)
+        uint64_t lo = 0, hi = 0;
+        auto sink = [&](int k, uint8_t v) { if (k < 8) lo |= (uint64_t)v << (8 * k); else hi |= (uint64_t)v << (8 * (k - 8)); };
+        const int n = asRepeat ? s2_put_repeat(sink, offset, length) : s2_put_copy(sink, offset, length);
+        if (lane == 0) {
+            st64(dst + d, lo);
+            if (n > 8) st64(dst + d + 8, hi);
+        }
+        return n;
     };
 
     if (!stored) {
