@@ -142,6 +142,18 @@ def main():
             dt = time.perf_counter() - t0
             lat["hook_%s_%dcallers_MBps" % (p, nthr)] = round(len(todo) * bsz / dt / 1e6, 1)
             enc.Close()
+    # ---------------- ONE stream as jobs (WithConcurrentBlocks): 1 GiB, SpeedFastest, its own 4 MiB window -> 64 jobs of 16 MiB ----------------
+    if a.max_units >= 8192:
+        stream = buf[:8192 * usz]
+        enc = zstd.NewWriter(None, zstd.WithEncoderLevel(1), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(4))
+        enc.EncodeJobs(stream[:64 << 20])
+        t0 = time.perf_counter()
+        out = enc.EncodeJobs(stream)
+        dt = time.perf_counter() - t0
+        lat["jobs_1GiB_speedfastest_MBps"] = round(len(stream) / dt / 1e6, 1)
+        lat["jobs_1GiB_ratio"] = round(len(out) / len(stream), 4)
+        lat["jobs_1GiB_match_ms"] = round(enc.ctx().timings()["match_ms"], 1)
+        enc.Close()
     print(json.dumps(lat), flush=True)
     with open(os.path.join(a.out, "r03_latency.json"), "w") as f:
         json.dump(lat, f, indent=1)
