@@ -50,7 +50,19 @@ type Encoder struct {
 	created  int  // contexts created so far (<= conc)
 	noDevice bool // kc_ctx_create failed once: reference only
 	jobs     bool // WithConcurrentBlocks(true)
+	devJobs  bool // WithDeviceJobs(true)
 	hasDict  bool
+}
+
+// WithDeviceJobs sends WithConcurrentBlocks streams to the device (kc_zstd_encode_jobs).  Off by default: the jobs of a stream are
+// few and long (64 jobs of 16 MiB per GiB at SpeedFastest), and a long unit is parsed by one lane group — 1 GiB takes ~7 s on the
+// device (profiles/r03_latency.json: 143 MB/s) where the reference's own job workers take a fraction of a second.  The bytes are
+// the same either way; the device path is there for parity and for hosts without spare cores.
+func WithDeviceJobs(b bool) Option {
+	return func(e *Encoder) error {
+		e.devJobs = b
+		return nil
+	}
 }
 
 // WithConcurrentBlocks mirrors zstd.WithConcurrentBlocks (zstd/encoder_options.go:340-353): a Writer's stream is cut into jobs
@@ -71,7 +83,7 @@ func (e *Encoder) jobMode() bool { return e.jobs && !e.hasDict && e.conc > 1 }
 // EncodeJobs == zstd.NewWriter(w, opts..., zstd.WithConcurrentBlocks(true)); Write(src) with Flush after flushAt[i] bytes; Close().
 func (e *Encoder) EncodeJobs(src []byte, flushAt []uint64) ([]byte, error) {
 	var ctx *C.kc_ctx
-	if len(src) > 0 && e.useDevice(len(src)) && e.jobMode() {
+	if len(src) > 0 && e.devJobs && e.useDevice(len(src)) && e.jobMode() {
 		ctx = e.acquire()
 	}
 	if ctx != nil {

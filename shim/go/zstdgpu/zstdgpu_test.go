@@ -428,7 +428,7 @@ func TestConcurrentBlocks(t *testing.T) {
 	for _, lvl := range levels {
 		for _, win := range []int{1 << 17, 1 << 20, 0} {
 			ropts := []zstd.EOption{zstd.WithEncoderLevel(lvl), zstd.WithConcurrentBlocks(true), zstd.WithEncoderConcurrency(4)}
-			gopts := []Option{WithDeviceMinBytes(0), WithEncoderLevel(lvl), WithConcurrentBlocks(true), WithEncoderConcurrency(4)}
+			gopts := []Option{WithDeviceMinBytes(0), WithDeviceJobs(true), WithEncoderLevel(lvl), WithConcurrentBlocks(true), WithEncoderConcurrency(4)}
 			if win > 0 {
 				ropts = append(ropts, zstd.WithWindowSize(win))
 				gopts = append(gopts, WithWindowSize(win))
