@@ -477,7 +477,7 @@ size_t match_table_bytes(int level) {
 // dictionary history) of 256 KiB and more only fit the HBM path's position field: the HBM kernel takes those, the LDS kernel the rest.
 bool zfast_use_lds(const kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, int level) {
     (void)mp;
-    if (level != KC_SPEED_FASTEST || c->job_hist != nullptr) return false;
+    if (level != KC_SPEED_FASTEST) return false;
     if (c->cfg.match_path == KC_PATH_HBM) return false;
     if (c->cfg.match_path == KC_PATH_LDS) return true;
     return (int64_t)n_launch <= c->cfg.zfast_lds_max_units;
@@ -489,7 +489,7 @@ bool zfast_lds_needs_hbm(const kc_ctx* c, const KcMatchParams& mp) {
 
 // per-unit tables of n_launch units: zeroed, or primed from the dictionary tables
 kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, hipStream_t st, int level) {
-    if (zfast_use_lds(c, mp, n_launch, level) && !zfast_lds_needs_hbm(c, mp)) return KC_OK;  // the tables live in LDS
+    if (zfast_use_lds(c, mp, n_launch, level) && !zfast_lds_needs_hbm(c, mp) && c->job_tables == nullptr) return KC_OK;  // the tables live in LDS
     const size_t tb = match_table_bytes(level);
     if (c->job_tables != nullptr && mp.unit_list == nullptr) {  // jobs: every unit's table was primed from its own prefix on the host
         kc_status sj = ensure(c, c->tables, (size_t)n_launch * tb);
@@ -515,7 +515,10 @@ void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uin
     if (lds) {
         KcMatchParams ml = mp;
         ml.spec_w0 = (int32_t)c->cfg.lds_spec_w0;
-        kc_launch_zfast_match_lds(ml, mp.hist0 > 0 ? (const uint32_t*)c->proto.p : nullptr, n_launch, st);
+        if (c->job_tables != nullptr)  // jobs: slot i of the arena holds the table primed from unit i's prefix (prepare_tables)
+            kc_launch_zfast_match_lds(ml, (const uint32_t*)((uint8_t*)c->tables.p + (size_t)slot0 * match_table_bytes(level)), 1u << 15, n_launch, st);
+        else
+            kc_launch_zfast_match_lds(ml, mp.hist0 > 0 ? (const uint32_t*)c->proto.p : nullptr, 0u, n_launch, st);
         c->last_path = KC_PATH_LDS;
         if (zfast_lds_needs_hbm(c, mp)) {  // the units beyond the LDS kernel's position field
             ml = mp;

@@ -36,9 +36,10 @@ struct KcMatchParams {
 void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st);
 static inline size_t kc_zfast_table_bytes() { return (size_t)4 << 15; }
 // SpeedFastest, LDS-table path (kc_zstd_match_lds.hip): one wave per unit, the 2^15 x u32 table in LDS; units (with their
-// dictionary history) below KC_ZFAST_LDS_MAX_UNIT bytes.  proto: null or the dictionary-primed table (HBM entry format, P.pos_bits)
-void kc_launch_zfast_match_lds(const KcMatchParams& P, const uint32_t* proto, uint32_t n_launch, hipStream_t st);
-#define KC_ZFAST_LDS_MAX_UNIT ((1u << 18) - 4u)
+// history) below KC_ZFAST_LDS_MAX_UNIT bytes.  proto: null or primed tables in the HBM entry format (P.pos_bits): one for all units
+// (dictionary; proto_stride 0) or one per launch slot (jobs: proto_stride = 2^15 entries)
+void kc_launch_zfast_match_lds(const KcMatchParams& P, const uint32_t* proto, uint32_t proto_stride, uint32_t n_launch, hipStream_t st);
+#define KC_ZFAST_LDS_MAX_UNIT ((1u << 26) - 4u)
 // SpeedDefault: long (2^17) + short (2^15) u32 tables per unit in HBM, zeroed by the caller
 void kc_launch_zdfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st);
 static inline size_t kc_zdfast_table_bytes() { return ((size_t)4 << 17) + ((size_t)4 << 15); }

@@ -14,12 +14,14 @@
 // each lane iterating the recurrence up to its own step when the steps leave the first skip segment) against the
 // pre-round table; ballot + ctz picks the first step that ends the scan in the reference's priority order (repeat at
 // s+2, candidate at s, candidate at s+1); steps up to it commit their table writes.  Table entry =
-// (position+1):18 | tag:6 | marker:8 — the tag (top bits of a multiplicative hash of the 4 source bytes) stands for
-// tableEntry.val: a mismatch skips the candidate fetch exactly when the reference would reject; the marker byte is how
-// two steps of one round that share a bucket find each other: every lane stores its lane id into the marker byte of
-// its two buckets (ds_write_b8), reads the entries back, and a lane that finds another lane's id tells that lane
-// through a 64-bit mask (ds_or_b64; only in rounds where some lane lost).  The round is cut at the lowest sharing lane
-// other than lane 0, so every committed step saw the table the sequential encoder would have seen.
+// (position+1):26 | tag:6 — the tag (top bits of a multiplicative hash of the 4 source bytes) stands for
+// tableEntry.val: a mismatch skips the candidate fetch exactly when the reference would reject.  Two steps of one round
+// that share a bucket find each other through marker bytes (16 KiB of LDS, one byte per pair of buckets): every lane
+// stores its lane id into the markers of its two buckets (ds_write_b8), reads them back, and a lane that finds another
+// lane's id tells that lane through a 64-bit mask (ds_or_b64; only in rounds where some lane lost).  The round is cut at
+// the lowest sharing lane other than lane 0, so every committed step saw the table the sequential encoder would have
+// seen.  Units of any length up to 64 MiB: long streams and the jobs of a WithConcurrentBlocks stream (their overlap
+// prefix is the unit's history, the table arrives primed from it) run here too.
 #include "kc_dev.h"
 #include "kc_kernels.h"
 #include "kc_zfast_dev.h"
@@ -28,8 +30,9 @@
 #define ZL_MIRROR 32    // the first 32 ring bytes are mirrored behind the ring: 24-byte reads never wrap
 #define ZL_BK 4         // bytes in front of a probe / candidate position kept for the backward extension
 #define ZL_AHEAD 1536   // refill (1 KiB per round) while fewer than this many bytes are buffered ahead of s
-#define ZL_PB 18        // position+1 bits: units (with dictionary history) below 256 KiB
+#define ZL_PB 26        // position+1 bits: units (with their history) below 64 MiB
 #define ZL_TAGB 6
+#define ZL_MARK_BITS 14 // marker bytes: one per PAIR of buckets (two buckets sharing a marker are a false, harmless, conflict)
 #define ZL_POS_MASK ((1u << ZL_PB) - 1u)
 
 #ifdef KC_LDS_PROF  // diagnostics: shader clocks per phase of a round, summed over the launch (lane 0 of every wave)
@@ -45,10 +48,12 @@
 __device__ __forceinline__ uint32_t zl_tag(uint32_t v) { return (v * 2654435761u) >> (32 - ZL_TAGB); }
 __device__ __forceinline__ uint32_t zl_entry(int pos, uint32_t v) { return ((uint32_t)pos + 1u) | (zl_tag(v) << ZL_PB); }
 
-// proto: null, or the dictionary-primed table in the HBM kernels' format ((position+1) | tag << pos_bits, tag = top
-// bits of the same hash), converted while it is loaded.
-__global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P, const uint32_t* __restrict__ proto, uint32_t n_launch) {
+// proto: null, or primed tables in the HBM kernels' format ((position+1) | tag << pos_bits, tag = top bits of the same hash),
+// converted while loaded: ONE table for all units (dictionary), or one per launch slot (proto_stride = 2^15: the jobs of a
+// WithConcurrentBlocks stream, each primed from its own overlap prefix).
+__global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P, const uint32_t* __restrict__ proto, uint32_t proto_stride, uint32_t n_launch) {
     __shared__ uint32_t tab[1 << ZF_TABLE_BITS];
+    __shared__ uint8_t mark[1 << ZL_MARK_BITS];
     __shared__ __attribute__((aligned(16))) uint8_t ring[ZL_RB + ZL_MIRROR];
     __shared__ uint64_t sbuf[64];  // the last (nseq mod 64) sequences, flushed 64 at a time as one 512-byte store
     __shared__ unsigned long long shareMask;
@@ -59,8 +64,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
     const int boff = (int)((uintptr_t)base & 15);  // window positions are relative to the 16-byte aligned abase
     const uint8_t* __restrict__ abase = base - boff;
-    if (P.unit_hist != nullptr || P.job_flags != nullptr) return;  // jobs carry per-unit history: the HBM-table kernel's (the host never launches this one for them)
-    const int hist0 = P.hist0;
+    const int hist0 = P.unit_hist != nullptr ? (int)P.unit_hist[u] : P.hist0;  // dictionary content, or a job's overlap prefix
     const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0;
     if ((uint32_t)(ulen + hist0) > KC_ZFAST_LDS_MAX_UNIT) return;  // beyond the 18-bit position field: the HBM-table kernel's unit
     const uint32_t blk0 = P.unit_blk0[u];
@@ -68,10 +72,10 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
     const int mmo = P.max_match_off;
     const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
     const int nblk = UB.nblk;
-    const bool HIST = ulen > bs || hist0 > 0 || UB.streamU;  // with a dictionary encodeAll always calls Encode (encoder.go:783-787)
+    const bool HIST = ulen > bs || hist0 > 0 || UB.streamU || P.job_flags != nullptr;  // with a dictionary encodeAll always calls Encode (encoder.go:783-787), and so does compressJob
     const uint8_t* const srcLo = P.src;
     const uint8_t* const srcHi = P.src_end;
-    uint8_t* const tabB = (uint8_t*)tab;
+    if (proto != nullptr) proto += (size_t)ui * proto_stride;
 
     if (proto == nullptr) {
         for (int i = lane * 4; i < (1 << ZF_TABLE_BITS); i += 256) *(uint4*)&tab[i] = make_uint4(0, 0, 0, 0);
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
             }
         };
         int SK = 5;  // kSearchStrength - 1
-        if (hist0 > 0) {  // enc_fast.go:539-543,585
+        if (hist0 > 0 && P.job_flags == nullptr) {  // fastEncoderDict only (enc_fast.go:539-543,585); a job's prefix goes through fastEncoder
             if (allDirty || srcLen > (32 << 10)) allDirty = true; else SK = 6;
         }
         if (srcLen >= 10) {
@@ -209,17 +213,21 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                 if (valid) {
                     h0 = hash6(cv, ZF_TABLE_BITS);
                     h1 = hash6(cv >> 8, ZF_TABLE_BITS);
-                    tabB[4 * h0 + 3] = (uint8_t)lane;
-                    tabB[4 * h1 + 3] = (uint8_t)lane;
+                    mark[h0 >> (ZF_TABLE_BITS - ZL_MARK_BITS)] = (uint8_t)lane;
+                    mark[h1 >> (ZF_TABLE_BITS - ZL_MARK_BITS)] = (uint8_t)lane;
                 }
                 KC_WAVE_SYNC();
-                if (valid) { c0 = tab[h0]; c1 = tab[h1]; }
+                uint32_t m0 = (uint32_t)lane, m1 = (uint32_t)lane;
+                if (valid) {
+                    c0 = tab[h0]; c1 = tab[h1];
+                    m0 = mark[h0 >> (ZF_TABLE_BITS - ZL_MARK_BITS)]; m1 = mark[h1 >> (ZF_TABLE_BITS - ZL_MARK_BITS)];
+                }
                 LP(2);  // hashes, markers, table entries
                 // candidates: one 16-byte load of [t-4, t+12) each, only where the tag matches
                 const uint32_t e0 = c0 & ZL_POS_MASK, e1 = c1 & ZL_POS_MASK;
                 const int t0 = (int)e0 - 1, t1 = (int)e1 - 1;
-                const bool ok0 = valid && e0 != 0 && (p - t0) < mmo && ((c0 >> ZL_PB) & ((1u << ZL_TAGB) - 1u)) == zl_tag((uint32_t)cv);
-                const bool ok1 = valid && e1 != 0 && (p - t1 + 1) < mmo && ((c1 >> ZL_PB) & ((1u << ZL_TAGB) - 1u)) == zl_tag((uint32_t)(cv >> 8));
+                const bool ok0 = valid && e0 != 0 && (p - t0) < mmo && (c0 >> ZL_PB) == zl_tag((uint32_t)cv);
+                const bool ok1 = valid && e1 != 0 && (p - t1 + 1) < mmo && (c1 >> ZL_PB) == zl_tag((uint32_t)(cv >> 8));
                 uint4 ca = make_uint4(0, 0, 0, 0), cb = make_uint4(0, 0, 0, 0);
                 bool wide0 = false, wide1 = false;
                 if (ok0) {
@@ -272,7 +280,6 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                 }
                 LP(3);  // candidate loads issued, offset-2 verdict
                 // steps of this round that share a bucket
-                const uint32_t m0 = c0 >> 24, m1 = c1 >> 24;
                 const bool lost = valid && (m0 != (uint32_t)lane || m1 != (uint32_t)lane);
                 bool dep = lost;
                 if (ballot64(lost) != 0) {  // rare
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
     LP_FLUSH(P.prof);
 }
 
-void kc_launch_zfast_match_lds(const KcMatchParams& P, const uint32_t* proto, uint32_t n_launch, hipStream_t st) {
+void kc_launch_zfast_match_lds(const KcMatchParams& P, const uint32_t* proto, uint32_t proto_stride, uint32_t n_launch, hipStream_t st) {
     if (n_launch == 0) return;
-    hipLaunchKernelGGL(kc_zfast_match_lds_kernel, dim3(n_launch), dim3(64), 0, st, P, proto, n_launch);
+    hipLaunchKernelGGL(kc_zfast_match_lds_kernel, dim3(n_launch), dim3(64), 0, st, P, proto, proto_stride, n_launch);
 }

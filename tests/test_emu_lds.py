@@ -75,7 +75,8 @@ def _zfast_units():
     units += [corpora.corpus("M", 1, 131072, first_unit=k).tobytes() for k in range(4)]
     units += [corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("H", 1, 131072).tobytes()]
     units += [u for u in corpora.edge_units() if 0 < len(u) < 262000]
-    units += [u for u in corpora.stress_units(seed=5, n=8) if len(u) < 262000]
+    units += corpora.stress_units(seed=5, n=8)          # up to 300001 bytes: five blocks with history
+    units += [corpora.corpus("T", 8, 131072, first_unit=77).tobytes()]  # one 1 MiB unit: 16 blocks, positions beyond 2^18
     return units
 
 

@@ -52,16 +52,27 @@ def test_jobs_differ_from_the_plain_stream_only_in_history(oracle):
     assert e.encode_jobs(t[:3 * js]) != e.encode_stream(t[:3 * js])
 
 
+# level 1 runs on both SpeedFastest kernel families: "1L" the LDS-table kernel (what the dispatcher picks for a few hundred jobs:
+# a job is one wave's unit, its table primed from the overlap prefix), "1H" the HBM-table kernel
+GPU_LEVELS = ["1L", "1H", 2, 3]
+
+
+def _li(level):
+    return 1 if level in ("1L", "1H") else int(level)
+
+
 def _enc(level, **kw):
     from compress_amd import zstd
-    opts = [zstd.WithEncoderLevel(level), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(4)]
+    opts = [zstd.WithEncoderLevel(_li(level)), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(4)]
+    if level in ("1L", "1H"):
+        opts.append(zstd.WithMatchPath("lds" if level == "1L" else "hbm"))
     if "window" in kw:
         opts.append(zstd.WithWindowSize(kw["window"]))
     return zstd.NewWriter(None, *opts)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", GPU_LEVELS)
 def test_device_jobs_bit_exact_small(oracle, kclib, level):
     """GPU: kc_zstd_encode_jobs == the oracle's job mode for every job count / Flush pattern of the CPU test (small windows: many
     jobs, short prefixes, prefixes shorter than the overlap, empty final jobs)."""
@@ -69,7 +80,7 @@ def test_device_jobs_bit_exact_small(oracle, kclib, level):
     assert torch.cuda.is_available()
     t, m = _cases()
     for win in (1 << 17, 1 << 18):
-        e = oracle.ZstdOracle(level=level, window_size=win)
+        e = oracle.ZstdOracle(level=_li(level), window_size=win)
         enc = _enc(level, window=win)
         js = enc.JobSize()
         assert js == max(4 * win, 512 << 10)
@@ -77,12 +88,12 @@ def test_device_jobs_bit_exact_small(oracle, kclib, level):
             for cuts in ((), (1000, 300000), (len(data),), (js // 2, js // 2 + 10, js + 77)):
                 got = enc.EncodeJobs(data, cuts)
                 ref = e.encode_jobs(data, cuts)
-                assert got == ref, "level %d window %d len %d cuts %r: %d bytes vs oracle %d" % (level, win, len(data), cuts, len(got), len(ref))
+                assert got == ref, "level %s window %d len %d cuts %r: %d bytes vs oracle %d" % (level, win, len(data), cuts, len(got), len(ref))
         enc.Close()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", GPU_LEVELS)
 def test_device_jobs_bit_exact_256mib_stream(oracle, kclib, level):
     """GPU: a 256 MiB stream at every level, 1 MiB window -> 64 jobs of 4 MiB with 128 / 256 KiB of overlap; and through the
     Write / Flush / Close face of the Encoder."""
@@ -90,17 +101,19 @@ def test_device_jobs_bit_exact_256mib_stream(oracle, kclib, level):
     import torch
     assert torch.cuda.is_available()
     data = corpora.corpus("T" if level != 3 else "M", 2048, 131072, first_unit=7000).tobytes()
-    e = oracle.ZstdOracle(level=level, window_size=1 << 20)
+    e = oracle.ZstdOracle(level=_li(level), window_size=1 << 20)
     ref = e.encode_jobs(data)
     enc = _enc(level, window=1 << 20)
     got = enc.EncodeJobs(data)
     assert len(got) == len(ref) and got == ref
+    if level in ("1L", "1H"):
+        assert enc.ctx().last_path() == ("lds" if level == "1L" else "hbm")
     assert oracle.zstd_decompress(got[:], len(data) + 16) == data
     enc.Close()
     # the Writer face: Write, Flush, ReadFrom, Close
     sink = io.BytesIO()
     from compress_amd import zstd
-    w = zstd.NewWriter(sink, zstd.WithEncoderLevel(level), zstd.WithWindowSize(1 << 20), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(2))
+    w = zstd.NewWriter(sink, zstd.WithEncoderLevel(_li(level)), zstd.WithWindowSize(1 << 20), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(2))
     w.Write(data[:5000000])
     w.Flush()
     w.Write(data[5000000:9000000])
@@ -121,4 +134,5 @@ def test_device_jobs_default_window_speedfastest(oracle, kclib):
     got = enc.EncodeJobs(data)
     ref = oracle.ZstdOracle(level=1).encode_jobs(data)
     assert got == ref
+    assert enc.ctx().last_path() == "lds"  # 17 jobs: the dispatcher's choice
     enc.Close()

@@ -47,7 +47,7 @@ int kcemu_zfast_parse(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     P.rep1 = rep1;
     P.rep2 = rep2;
     P.stream_mode = stream_mode;
-    kc_launch_zfast_match_lds(P, proto, n, nullptr);
+    kc_launch_zfast_match_lds(P, proto, 0u, n, nullptr);
     return 0;
 }
 
