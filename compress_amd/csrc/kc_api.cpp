@@ -124,7 +124,7 @@ struct kc_ctx {
     const uint32_t* job_hist = nullptr;     // host, per unit: bytes of overlap prefix in front of the unit in the source buffer
     const uint32_t* job_flags = nullptr;    // host, per unit: bit 0 = final job
     const uint8_t* job_tables = nullptr;    // host: the units' tables primed from their prefixes (ResetPrefix), device entry format
-    DevBuf d_job_hist, d_job_flags;
+    DevBuf d_job_hist, d_job_flags, rawdef;
     std::vector<uint32_t> job_redo_list;    // units of the speculation re-run in progress (their tables are re-primed)
     void* pend = nullptr;            // batch between kc_zstd_encode_units_dev_begin and _end (Pending)
     kc_ctx* chain_after = nullptr;   // pipelining: this context's match finder waits for that context's last one
@@ -760,6 +760,10 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     ep.full_zero = o->full_zero;
     ep.dict_id = o->dict_id;
     ep.err_flag = (uint32_t*)c->errflag.p;
+    // raw blocks are copied once, by the compaction, from the source (KcRawDef): the entries of blocks that are not raw stay zero
+    if ((s = ensure(c, c->rawdef, ((size_t)nb + 1) * sizeof(KcRawDef))) != KC_OK) return s;
+    HIPCHK(c, hipMemsetAsync(c->rawdef.p, 0, ((size_t)nb + 1) * sizeof(KcRawDef), st));
+    ep.rawdef = (KcRawDef*)c->rawdef.p;
     ep.prof = nullptr;
     const bool k2prof = c->cfg.k2_prof != 0;
     if (k2prof) {
@@ -801,7 +805,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
             feed->loc_off = (uint64_t*)c->out_off.p;
             kc_launch_scan_sizes((const uint32_t*)c->out_size.p + u0, nk, feed->loc_off + u0 + k, sk);
             kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p + u0, (const uint32_t*)c->out_size.p + u0,
-                              feed->loc_off + u0 + k, d_dst + pl.stage_off[u0], nk, sk);
+                              feed->loc_off + u0 + k, d_dst + pl.stage_off[u0], nk, sk, ep.src, ep.unit_off + u0, ep.unit_blk0 + u0, ep.rawdef);
             HIPCHK(c, hipEventRecord(feed->done[k], sk));
         }
         for (size_t k = 0; k < nchunk; k++) HIPCHK(c, hipStreamWaitEvent(st, feed->done[k], 0));
@@ -891,7 +895,7 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
     HIPCHK(c, hipEventRecord(c->ev[4], st));
     kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n_units, (uint64_t*)c->out_off.p, st);
     kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p, (const uint32_t*)c->out_size.p,
-                      (const uint64_t*)c->out_off.p, d_dst, n_units, st);
+                      (const uint64_t*)c->out_off.p, d_dst, n_units, st, ep.src, ep.unit_off, ep.unit_blk0, ep.rawdef);
     HIPCHK(c, hipEventRecord(c->ev[5], st));
     HIPCHK(c, hipMemcpyAsync(out_off_host, c->out_off.p, (n_units + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));

@@ -47,6 +47,14 @@ static inline size_t kc_zdfast_table_bytes() { return ((size_t)4 << 17) + ((size
 void kc_launch_zbetter_match_grp(const KcMatchParams& P, uint8_t* tables, uint32_t n_launch, bool dict, hipStream_t st);
 static inline size_t kc_zbetter_table_bytes() { return ((size_t)8 << 19) + ((size_t)4 << 13); }
 
+// A raw block whose payload the compaction copies straight from the source (KcEntropyParams.rawdef)
+struct KcRawDef {
+    uint32_t frame_pos;  // position of the payload in the unit's frame
+    uint32_t src_pos;    // position of the block in the unit (history included)
+    uint32_t size;       // 0: nothing deferred for this block
+    uint32_t pad;
+};
+
 // ---- entropy + emit (kc_zstd_entropy.hip) ----
 struct KcFsePredef;  // opaque device blob built by kc_launch_fse_predef_init
 struct KcEntropyParams {
@@ -82,6 +90,9 @@ struct KcEntropyParams {
     int32_t dict_huf_len, dict_huf_log;
     int32_t stream_mode;       // streaming frame layout for units >= one block (zstd/encoder.go:257-428): no content size, no single
                                // segment, last flag only on a short final block, else an empty raw last block
+    KcRawDef* rawdef;       // device or null: per block (global index), where a RAW block's payload goes in the frame and where it comes
+                            // from in the unit: the entropy kernel then writes the 3-byte header only and kc_compact_kernel copies
+                            // the payload once, from the source (instead of source -> staging slot -> output)
     uint32_t* err_flag;     // device: set non-zero on a device-side invariant violation
     unsigned long long* prof;  // device or null: per-phase shader-clock totals (diagnostics, KC_K2_PROF=1)
 };
@@ -147,6 +158,8 @@ void kc_launch_bcast(const uint8_t* proto, uint8_t* dst, size_t bytes, uint32_t 
 void kc_launch_xxh64(const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out, hipStream_t st);
 // exclusive scan of sizes (u32) into offsets (u64, n+1 entries)
 void kc_launch_scan_sizes(const uint32_t* sizes, uint32_t n, uint64_t* out_off, hipStream_t st);
-// dst[out_off[i] .. ) = stage[stage_off[i] .. +sizes[i])
+// dst[out_off[i] .. ) = stage[stage_off[i] .. +sizes[i]); with rawdef: except the deferred raw-block payloads, which come from
+// src[unit_off[i] + src_pos ..) (unit_blk0[i] .. unit_blk0[i+1] are unit i's entries of rawdef)
 void kc_launch_compact(const uint8_t* stage, const uint64_t* stage_off, const uint32_t* sizes, const uint64_t* out_off,
-                       uint8_t* dst, uint32_t n, hipStream_t st);
+                       uint8_t* dst, uint32_t n, hipStream_t st, const uint8_t* src = nullptr, const uint64_t* unit_off = nullptr,
+                       const uint32_t* unit_blk0 = nullptr, const KcRawDef* rawdef = nullptr);

@@ -29,8 +29,34 @@ __global__ __launch_bounds__(256) void kc_xxh64_kernel(const uint8_t* __restrict
     if (active) { p = src + unit_off[u]; len = unit_off[u + 1] - unit_off[u]; }
     uint64_t v = a == 0 ? XP1 + XP2 : (a == 1 ? XP2 : (a == 2 ? 0ULL : 0ULL - XP1));
     const uint64_t stripes = len >> 5;
+    // Two stripes (64 bytes) per step: the four lanes of a unit load 16 bytes each — one 64-byte line per unit and load instead of
+    // four 8-byte pieces 32 bytes apart — and every lane picks its accumulator's word of either stripe out of its quad with DPP
+    // quad permutes (stripe 0 sits in lanes 0,1, stripe 1 in lanes 2,3; word a of a stripe is the (a & 1) half of lane a >> 1).
+    // Four steps are in flight per lane (256 bytes per unit): with 8 waves per CU the kernel is bound by bytes in flight.
+    const uint64_t pairs = stripes >> 1;
+    auto quad = [&](uint32_t x, bool second) -> uint32_t {  // lane a reads lane (second ? 2 : 0) + (a >> 1) of its quad
+        return second ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xFA, 0xF, 0xF, true)   // quad_perm:[2,2,3,3]
+                      : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x50, 0xF, 0xF, true);  // quad_perm:[0,0,1,1]
+    };
+    auto word = [&](const uint4 w, bool second) -> uint64_t {
+        const uint32_t x = quad(w.x, second), y = quad(w.y, second), z = quad(w.z, second), t = quad(w.w, second);
+        return (a & 1) ? ((uint64_t)z | ((uint64_t)t << 32)) : ((uint64_t)x | ((uint64_t)y << 32));
+    };
+    const uint8_t* q16 = p + 16 * a;
+    uint64_t i = 0;
+    for (; i + 4 <= pairs; i += 4) {  // (the trip count is the same for the four lanes of a unit; other units' lanes run on under the mask)
+        const uint4 w0 = ld128u(q16 + (i << 6)), w1 = ld128u(q16 + ((i + 1) << 6)), w2 = ld128u(q16 + ((i + 2) << 6)), w3 = ld128u(q16 + ((i + 3) << 6));
+        v = xround(v, word(w0, false)); v = xround(v, word(w0, true));
+        v = xround(v, word(w1, false)); v = xround(v, word(w1, true));
+        v = xround(v, word(w2, false)); v = xround(v, word(w2, true));
+        v = xround(v, word(w3, false)); v = xround(v, word(w3, true));
+    }
+    for (; i < pairs; i++) {
+        const uint4 w0 = ld128u(q16 + (i << 6));
+        v = xround(v, word(w0, false)); v = xround(v, word(w0, true));
+    }
     const uint8_t* q = p + 8 * a;
-    for (uint64_t i = 0; i < stripes; i++) v = xround(v, ld64(q + (i << 5)));
+    if (stripes & 1) v = xround(v, ld64(q + ((stripes - 1) << 5)));
     // combine the 4 accumulators of this unit (4 adjacent lanes)
     const int lane = (int)(threadIdx.x & 63);
     const int l0 = lane & ~3;
@@ -95,34 +121,49 @@ void kc_launch_scan_sizes(const uint32_t* sizes, uint32_t n, uint64_t* out_off, 
 // ---------------------------------------------------------------------------------------
 // compaction: variable-size frames from the per-unit staging slots to the contiguous output
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kc_compact_kernel(const uint8_t* __restrict__ stage, const uint64_t* __restrict__ stage_off,
-                                                         const uint32_t* __restrict__ sizes, const uint64_t* __restrict__ out_off,
-                                                         uint8_t* __restrict__ dst, uint32_t n) {
-    const uint32_t u = blockIdx.x;
-    if (u >= n) return;
-    const uint8_t* s = stage + stage_off[u];  // 16-byte aligned
-    uint8_t* d = dst + out_off[u];
-    const uint32_t len = sizes[u];
-    const int tid = threadIdx.x;
-    // align destination to 16 bytes, then 16-byte stores with unaligned source loads
+// s[0, len) -> d[0, len): 16-byte stores once the destination is aligned, unaligned source loads
+__device__ __forceinline__ void kc_copy_bytes(uint8_t* __restrict__ d, const uint8_t* __restrict__ s, uint32_t len, int tid) {
+    if (len == 0) return;
     uint32_t head = (uint32_t)((16 - ((uintptr_t)d & 15)) & 15);
     if (head > len) head = len;
     for (uint32_t i = tid; i < head; i += 256) d[i] = s[i];
     const uint32_t body = (len - head) >> 4;
     const uint8_t* sb = s + head;
     uint4* db = (uint4*)(d + head);
-    for (uint32_t i = tid; i < body; i += 256) {
-        uint4 v;
-        const uint8_t* q = sb + ((size_t)i << 4);
-        v.x = ld32(q); v.y = ld32(q + 4); v.z = ld32(q + 8); v.w = ld32(q + 12);
-        db[i] = v;
-    }
+    for (uint32_t i = tid; i < body; i += 256) db[i] = ld128u(sb + ((size_t)i << 4));
     for (uint32_t i = head + (body << 4) + tid; i < len; i += 256) d[i] = s[i];
 }
+
+__global__ __launch_bounds__(256) void kc_compact_kernel(const uint8_t* __restrict__ stage, const uint64_t* __restrict__ stage_off,
+                                                         const uint32_t* __restrict__ sizes, const uint64_t* __restrict__ out_off,
+                                                         uint8_t* __restrict__ dst, uint32_t n, const uint8_t* __restrict__ src,
+                                                         const uint64_t* __restrict__ unit_off, const uint32_t* __restrict__ unit_blk0,
+                                                         const KcRawDef* __restrict__ rawdef) {
+    const uint32_t u = blockIdx.x;
+    if (u >= n) return;
+    const uint8_t* s = stage + stage_off[u];  // 16-byte aligned
+    uint8_t* d = dst + out_off[u];
+    const uint32_t len = sizes[u];
+    const int tid = threadIdx.x;
+    uint32_t cursor = 0;
+    if (rawdef != nullptr) {  // raw blocks: the staging slot holds their 3-byte header, the payload comes from the source, once
+        const uint8_t* us = src + unit_off[u];
+        const uint32_t b1 = unit_blk0[u + 1];
+        for (uint32_t b = unit_blk0[u]; b < b1; b++) {
+            const KcRawDef r = rawdef[b];
+            if (r.size == 0 || r.frame_pos < cursor || r.frame_pos + r.size > len) continue;
+            kc_copy_bytes(d + cursor, s + cursor, r.frame_pos - cursor, tid);
+            kc_copy_bytes(d + r.frame_pos, us + r.src_pos, r.size, tid);
+            cursor = r.frame_pos + r.size;
+        }
+    }
+    kc_copy_bytes(d + cursor, s + cursor, len - cursor, tid);
+}
 void kc_launch_compact(const uint8_t* stage, const uint64_t* stage_off, const uint32_t* sizes, const uint64_t* out_off,
-                       uint8_t* dst, uint32_t n, hipStream_t st) {
+                       uint8_t* dst, uint32_t n, hipStream_t st, const uint8_t* src, const uint64_t* unit_off, const uint32_t* unit_blk0,
+                       const KcRawDef* rawdef) {
     if (n == 0) return;
-    hipLaunchKernelGGL(kc_compact_kernel, dim3(n), dim3(256), 0, st, stage, stage_off, sizes, out_off, dst, n);
+    hipLaunchKernelGGL(kc_compact_kernel, dim3(n), dim3(256), 0, st, stage, stage_off, sizes, out_off, dst, n, src, unit_off, unit_blk0, rawdef);
 }
 
 // ---------------------------------------------------------------------------------------

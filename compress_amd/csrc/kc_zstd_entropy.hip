@@ -442,6 +442,19 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         const int nseq = (int)m.nseq;
         const int nlit = (int)m.nlit;
         uint8_t* bout = outp + opos;  // block header goes here
+        if (P.rawdef != nullptr && tid == 0) P.rawdef[blk0 + (uint32_t)b].size = 0;
+        // a raw block's payload: copied here, or (rawdef) left to the compaction, which takes it from the source once
+        auto raw_payload = [&]() {
+            if (P.rawdef != nullptr) {
+                if (tid == 0) {
+                    KcRawDef r;
+                    r.frame_pos = (uint32_t)(opos + 3); r.src_pos = (uint32_t)blkStart; r.size = (uint32_t)size; r.pad = 0;
+                    P.rawdef[blk0 + (uint32_t)b] = r;
+                }
+            } else {
+                wg_copy(bout + 3, org, size);
+            }
+        };
 
         // ---------- literals-only / RLE / incompressible verdicts (blockenc.go:482-503) ----------
         bool litsOnly = false;  // encodeLits path: no sequences, or saved < 16 (offsets popped by the match finder)
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         const bool dictLit = b == 0 && P.dict_huf != nullptr;  // blk.dictLitEnc: first block only (reset clears it, blockenc.go:97)
         if (litsOnly && (rawAllLits || size < (dictLit ? 8 : 32))) {
             if (tid == 0) put_block_header(bout, last, 0u, (uint32_t)size);
-            wg_copy(bout + 3, org, size);
+            raw_payload();
             opos += 3 + size;
             __syncthreads();
             continue;
@@ -855,7 +868,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             const int litMode = S.ivar[IV_LITMODE];
             if (litMode == 0) {  // ErrIncompressible -> raw block
                 if (tid == 0) put_block_header(bout, last, 0u, (uint32_t)size);
-                wg_copy(bout + 3, org, size);
+                raw_payload();
                 opos += 3 + size;
             } else if (litMode == 1) {  // ErrUseRLE -> RLE block
                 if (tid == 0) { put_block_header(bout, last, 1u, (uint32_t)size); bout[3] = org[0]; }
@@ -1183,7 +1196,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     if (!(m.flags & KC_BF_FORCED) && (m.o1_out != m.o1_in || m.o2_out != m.o2_in)) { P.redo_blk[blk0 + (uint32_t)b] = 1; atomicOr(&P.redo_mask[u], 1u); }
                 }
             }
-            wg_copy(bout + 3, org, size);
+            raw_payload();
             opos += 3 + size;
             __syncthreads();
             continue;
