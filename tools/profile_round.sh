@@ -2,7 +2,7 @@
 # Round profile on the GPU box (repo root): one bench line per BASELINE configuration, rocprofv3 kernel-trace stats of the default
 # bench command and of the other configurations, and HBM traffic (FETCH_SIZE / WRITE_SIZE, separate --pmc passes) of every
 # configuration's dominant kernel, stamped with the kernel source hash.  Usage: bash tools/profile_round.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
@@ -17,6 +17,8 @@ for c in C2H C3 C4 C5; do
   python bench.py --config $c --steps 5 --warmup 1 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_$c -- python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-device-verify > $OUT/kt_$c.log 2>&1
 done
+# 3b. the LDS-table kernels at small batches (one wave per unit): kernel-trace stats of the crossover sweep up to 256 units
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_LDS -- python tools/crossover.py --max-units 256 --reps 1 --out $OUT/lds_sweep > $OUT/kt_LDS.log 2>&1
 # 4. HBM traffic of the dominant kernels (bench.py --pmc: one rocprofv3 pass per counter, one step each)
 # PMC_CONFIGS: the configurations whose dominant kernel changed since profiles/pmc_traffic.json was stamped (default: all)
 for c in ${PMC_CONFIGS:-C2 C3 C4 C5}; do
@@ -33,7 +35,7 @@ def stats(tag):
     with open(os.path.join(out, "kernel_stats_%s.csv" % tag), "w") as fo:
         w = csv.writer(fo); w.writerow(["name", "total_calls", "total_duration_ms", "average_ms", "percentage"])
         for r in rows: w.writerow([r[0][:120], r[1], round(r[2] / 1e3, 3), round(r[3] / 1e3, 3), round(r[4], 3)])
-for t in ("C2", "C2H", "C3", "C4", "C5"): stats(t)
+for t in ("C2", "C2H", "C3", "C4", "C5", "LDS"): stats(t)
 entries = []
 try:  # entries of configurations not measured in this run are kept (bench.py checks the kernel source hash of each)
     old = {e["config"]: e for e in json.load(open(os.path.join("$R", "profiles", "pmc_traffic.json")))["entries"]}
