@@ -76,7 +76,7 @@ def collect_pmc(argv, kernel_key):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="kcpmc_", dir="/tmp")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "--", sys.executable, os.path.abspath(__file__)] + argv + [
-            "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-device-verify", "--no-end-to-end"]
+            "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-device-verify", "--no-end-to-end", "--no-also"]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400, check=False)

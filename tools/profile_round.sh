@@ -11,7 +11,7 @@ cd $R
 # 1. the default command, as the driver runs it (C2, 10 steps)
 python bench.py > $OUT/bench_C2.json 2> $OUT/bench_C2.err
 # 2. kernel-trace stats of the same command
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_C2 -- python bench.py --no-cpu-baseline --no-end-to-end > $OUT/kt_C2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_C2 -- python bench.py --no-also --no-cpu-baseline --no-end-to-end > $OUT/kt_C2.log 2>&1
 # 3. the other configurations: bench line + kernel-trace stats
 for c in C2H C3 C4 C5; do
   python bench.py --config $c --steps 5 --warmup 1 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
@@ -22,7 +22,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_LDS -- python tools/cros
 # 4. HBM traffic of the dominant kernels (bench.py --pmc: one rocprofv3 pass per counter, one step each)
 # PMC_CONFIGS: the configurations whose dominant kernel changed since profiles/pmc_traffic.json was stamped (default: all)
 for c in ${PMC_CONFIGS:-C2 C3 C4 C5}; do
-  python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-device-verify --pmc > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
+  python bench.py --config $c --steps 2 --warmup 1 --no-also --no-cpu-baseline --no-end-to-end --no-device-verify --pmc > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
 done
 python - <<PY
 import sqlite3, glob, json, csv, os
