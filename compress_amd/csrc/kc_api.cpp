@@ -90,7 +90,8 @@ struct KcCfg {
     int64_t zfast_lds_max_units = 768;    // auto: SpeedFastest batches up to this many units take the LDS-table kernel (profiles/r03_crossover_zfast.csv)
     int64_t s2_lds_max_blocks = 768;      // auto: s2.Encode / EncodeSnappy batches up to this many blocks (profiles/r03_crossover_s2.csv)
     int64_t spec_w0 = -1, spec_grow = -1; // HBM-table kernels: speculation width after a match / growth policy; -1 = the per-level defaults
-    int64_t lds_spec_w0 = 16;             // LDS-table kernels: probe steps per round after a match (doubles on a miss up to 64)
+    int64_t lds_spec_w0 = 16;             // SpeedFastest LDS-table kernel: probe steps per round after a match (doubles on a miss up to 64)
+    int64_t s2_lds_spec_w0 = 1;           // S2 LDS-table kernel: the same; 1 = blocks held in LDS take one wave-uniform step at a time
     int64_t host_serial = 0, host_pipe_mib = 0, host_overlap_min_mib = -1, host_copy_threads = 0, host_trace = 0;
     std::vector<uint64_t> host_chunks;    // chunk-fed host path: chunk sizes in bytes (empty: a quarter of the batch each)
     int64_t k2_prof = 0;
@@ -287,6 +288,7 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
         envi("KC_SPEC_W0", g.spec_w0);
         envi("KC_SPEC_GROW", g.spec_grow);
         envi("KC_LDS_SPEC_W0", g.lds_spec_w0);
+        envi("KC_S2_LDS_SPEC_W0", g.s2_lds_spec_w0);
         if (getenv("KC_HOST_SERIAL")) g.host_serial = 1;
         envi("KC_HOST_PIPE_MIB", g.host_pipe_mib);
         envi("KC_HOST_OVERLAP_MIN_MIB", g.host_overlap_min_mib);
@@ -314,6 +316,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_SPEC_W0: g.spec_w0 = v; break;
         case KC_OPT_SPEC_GROW: g.spec_grow = v; break;
         case KC_OPT_LDS_SPEC_W0: g.lds_spec_w0 = v; break;
+        case KC_OPT_S2_LDS_SPEC_W0: g.s2_lds_spec_w0 = v; break;
         case KC_OPT_HOST_SERIAL: g.host_serial = v; break;
         case KC_OPT_HOST_PIPE_MIB: g.host_pipe_mib = v; break;
         case KC_OPT_HOST_OVERLAP_MIN_MIB: g.host_overlap_min_mib = v; break;
@@ -339,6 +342,7 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_SPEC_W0: return g.spec_w0;
         case KC_OPT_SPEC_GROW: return g.spec_grow;
         case KC_OPT_LDS_SPEC_W0: return g.lds_spec_w0;
+        case KC_OPT_S2_LDS_SPEC_W0: return g.s2_lds_spec_w0;
         case KC_OPT_HOST_SERIAL: return g.host_serial;
         case KC_OPT_HOST_PIPE_MIB: return g.host_pipe_mib;
         case KC_OPT_HOST_OVERLAP_MIN_MIB: return g.host_overlap_min_mib;
@@ -2072,7 +2076,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     if (lds) {
         bool any_small = false, any_big = false;
         for (uint32_t i = 0; i < n; i++) ((blk_off[i + 1] - blk_off[i]) <= ((uint64_t)64 << 10) ? any_small : any_big) = true;
-        P.spec_w0 = (int32_t)c->cfg.lds_spec_w0;
+        P.spec_w0 = (int32_t)c->cfg.s2_lds_spec_w0;
         kc_launch_s2_encode_lds(P, any_small, any_big, st);
     } else {
         kc_launch_s2_encode(P, st);

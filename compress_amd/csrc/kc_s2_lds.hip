@@ -76,7 +76,11 @@ __device__ __forceinline__ uint32_t s2_crc32c_wave(RD32 rd32, RDB rdb, int len, 
     return acc ^ 0xFFFFFFFFu;
 }
 
-template <int LEVEL, bool SRCLDS>  // LEVEL 0: s2.Encode, 2: s2.EncodeSnappy; SRCLDS: block <= 64 KiB, held in LDS
+// LEVEL 0: s2.Encode, 2: s2.EncodeSnappy; SRCLDS: block <= 64 KiB, held in LDS; ONESTEP (with SRCLDS): one probe step at a time,
+// every lane the same — with the block in LDS a step is two LDS round trips whether or not other steps run beside it, so the
+// speculative round's machinery (positions, markers, ballots, winner selection: ~600 instructions for one sequence) buys nothing
+// and a wave-uniform step (scalar hashes, broadcast LDS reads, scalar branches) is what is left on the critical path.
+template <int LEVEL, bool SRCLDS, bool ONESTEP>
 __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
     constexpr bool SNAPPY = LEVEL == 2;
     __shared__ uint32_t tab[1 << S2_TABLE_BITS];
@@ -223,95 +227,124 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
         uint32_t rounds = 0;
         while (!fin && !stored) {
             if (++rounds > (uint32_t)len + 16u) { stored = true; break; }  // every round advances s: cannot happen; never spin on the device
-            // ---------------- probe positions of this round: lane i = the i-th step from s ----------------
-            int p;
-            {
-                const int d0 = s - nextEmit, step0 = 4 + (d0 >> SKIP);
-                if (((d0 + (W - 1) * step0) >> SKIP) == (d0 >> SKIP)) {
-                    p = s + lane * step0;  // all W steps inside one skip segment
-                } else {
-                    p = s;
-                    for (int k = 0; k + 1 < W; k++) if (k < lane) p += ((p - nextEmit) >> SKIP) + 4;
-                }
-            }
-            const int nextS = p + ((p - nextEmit) >> SKIP) + 4;
-            const bool inW = lane < W;
-            const bool valid = inW && nextS <= sLimit;  // a prefix of the lanes: nextS grows with the lane
-            const bool term = inW && nextS > sLimit;    // this step would `goto emitRemainder`
-            uint64_t cv = 0;
-            uint32_t h0 = 0, h1 = 0, h2 = 0, e0 = 0, e1 = 0, e2 = 0;
-            if (valid) {
-                cv = rd64(p);
-                h0 = s2_hash6(cv); h1 = s2_hash6(cv >> 8); h2 = s2_hash6(cv >> 16);
-                tabB[4 * h0 + 3] = (uint8_t)lane;
-                tabB[4 * h1 + 3] = (uint8_t)lane;
-                tabB[4 * h2 + 3] = (uint8_t)lane;
-            }
-            KC_WAVE_SYNC();
-            if (valid) { e0 = tab[h0]; e1 = tab[h1]; e2 = tab[h2]; }
-            // a lane that finds another lane's id in one of its buckets shares that bucket with it; it also tells that lane
-            const uint32_t m0 = e0 >> 24, m1 = e1 >> 24, m2 = e2 >> 24;
-            const bool lost = valid && (m0 != (uint32_t)lane || m1 != (uint32_t)lane || m2 != (uint32_t)lane);
-            bool dep = lost;
-            if (ballot64(lost) != 0) {  // rare: two steps of the round in one bucket
-                if (lane == 0) shareMask = 0ull;
+            int mkind = 0, candidate = 0, ps = 0;
+            if (ONESTEP) {
+                // ---------------- one probe step, wave-uniform (encode_all.go:318-412) ----------------
+                const int nextS = s + ((s - nextEmit) >> SKIP) + 4;
+                if (nextS > sLimit) { fin = true; continue; }
+                const uint64_t cv = rdlane64(rd64(s), 0);
+                const uint32_t h0 = s2_hash6(cv), h1 = s2_hash6(cv >> 8), h2 = s2_hash6(cv >> 16);
+                const uint32_t e0 = rdlane32(tab[h0], 0), e1 = rdlane32(tab[h1], 0);
+                const uint32_t wr = rdlane32(rd32(s - repeat + 1), 0);
                 KC_WAVE_SYNC();
-                if (lost) {
-                    if (m0 != (uint32_t)lane) atomicOr(&shareMask, 1ull << m0);
-                    if (m1 != (uint32_t)lane) atomicOr(&shareMask, 1ull << m1);
-                    if (m2 != (uint32_t)lane) atomicOr(&shareMask, 1ull << m2);
-                }
+                if (lane == 0) { tab[h0] = (uint32_t)s; tab[h1] = (uint32_t)(s + 1); }
                 KC_WAVE_SYNC();
-                dep = lost || ((shareMask >> lane) & 1ull) != 0;
-            }
-            if (lane == 0) dep = false;  // the first step has no earlier step to depend on: every round commits at least one step
-            int kind = 0, cand = 0;  // 1 repeat at s+1, 2 match at s, 3 match at s+1, 4 match at s+2
-            if (valid) {
-                // the s+2 bucket is read after the s / s+1 buckets were written (encode_all.go:401)
-                int c2 = (int)(e2 & S2L_POS_MASK);
-                if (h2 == h1) c2 = p + 1;
-                else if (h2 == h0) c2 = p;
                 const int c0 = (int)(e0 & S2L_POS_MASK), c1 = (int)(e1 & S2L_POS_MASK);
-                const uint32_t wr = rd32(p - repeat + 1);
-                const uint32_t w0 = rd32(c0), w1 = rd32(c1), w2 = rd32(c2);
+                const int c2 = (int)(rdlane32(tab[h2], 0) & S2L_POS_MASK);  // read after the s / s+1 buckets were written (encode_all.go:401)
+                const uint32_t w0 = rdlane32(rd32(c0), 0), w1 = rdlane32(rd32(c1), 0), w2 = rdlane32(rd32(c2), 0);
+                int kind = 0;  // 1 repeat at s+1, 2 match at s, 3 match at s+1, 4 match at s+2
                 if ((uint32_t)(cv >> 8) == wr) kind = 1;
-                else if ((uint32_t)cv == w0) { kind = 2; cand = c0; }
-                else if ((uint32_t)(cv >> 8) == w1) { kind = 3; cand = c1; }
-                else if ((uint32_t)(cv >> 16) == w2) { kind = 4; cand = c2; }
-            }
-            const uint64_t vm = ballot64(valid);
-            const uint64_t tm = ballot64(term);
-            const uint64_t depm = ballot64(dep);
-            const uint64_t hm = ballot64(kind != 0);
-            const int nvalid = __popcll(vm);
-            const int c = depm ? ctz64(depm) : 64;
-            const uint64_t hmc = c >= 64 ? hm : (hm & ((1ull << c) - 1ull));
-            const bool found = hmc != 0;
-            const int f = found ? ctz64(hmc) : 0;
-            const int commitUpTo = found ? f : ((c < nvalid ? c : nvalid) - 1);
-            if (valid && lane <= commitUpTo) {
-                const bool winner = found && lane == f;
-                tab[h0] = (uint32_t)p;
-                tab[h1] = (uint32_t)(p + 1);
+                else if ((uint32_t)cv == w0) { kind = 2; candidate = c0; }
+                else if ((uint32_t)(cv >> 8) == w1) { kind = 3; candidate = c1; }
+                else if ((uint32_t)(cv >> 16) == w2) { kind = 4; candidate = c2; }
+                KC_WAVE_SYNC();
                 // table[hash2] = s+2 is skipped when the step ends on the repeat or on the match at s
-                if (!(winner && (kind == 1 || kind == 2))) tab[h2] = (uint32_t)(p + 2);
-            }
-            KC_WAVE_SYNC();
-            if (!found) {
-                W = 2 * W < 64 ? 2 * W : 64;
-                if (c < nvalid) {
-                    s = (int)rdlane32((uint32_t)p, c);  // the first dependent step restarts as lane 0
-                } else if (nvalid < 64 && ((tm >> nvalid) & 1ull)) {
-                    fin = true;                        // the step after the last committed one hits `nextS > sLimit`
-                } else {
-                    s = (int)rdlane32((uint32_t)nextS, nvalid - 1);  // nvalid >= 1: lane 0 is valid or terminates
+                if (lane == 0 && kind != 1 && kind != 2) tab[h2] = (uint32_t)(s + 2);
+                KC_WAVE_SYNC();
+                if (kind == 0) { s = nextS; continue; }
+                mkind = kind;
+                ps = s;
+            } else {
+                // ---------------- probe positions of this round: lane i = the i-th step from s ----------------
+                int p;
+                {
+                    const int d0 = s - nextEmit, step0 = 4 + (d0 >> SKIP);
+                    if (((d0 + (W - 1) * step0) >> SKIP) == (d0 >> SKIP)) {
+                        p = s + lane * step0;  // all W steps inside one skip segment
+                    } else {
+                        p = s;
+                        for (int k = 0; k + 1 < W; k++) if (k < lane) p += ((p - nextEmit) >> SKIP) + 4;
+                    }
                 }
-                continue;
+                const int nextS = p + ((p - nextEmit) >> SKIP) + 4;
+                const bool inW = lane < W;
+                const bool valid = inW && nextS <= sLimit;  // a prefix of the lanes: nextS grows with the lane
+                const bool term = inW && nextS > sLimit;    // this step would `goto emitRemainder`
+                uint64_t cv = 0;
+                uint32_t h0 = 0, h1 = 0, h2 = 0, e0 = 0, e1 = 0, e2 = 0;
+                if (valid) {
+                    cv = rd64(p);
+                    h0 = s2_hash6(cv); h1 = s2_hash6(cv >> 8); h2 = s2_hash6(cv >> 16);
+                    tabB[4 * h0 + 3] = (uint8_t)lane;
+                    tabB[4 * h1 + 3] = (uint8_t)lane;
+                    tabB[4 * h2 + 3] = (uint8_t)lane;
+                }
+                KC_WAVE_SYNC();
+                if (valid) { e0 = tab[h0]; e1 = tab[h1]; e2 = tab[h2]; }
+                // a lane that finds another lane's id in one of its buckets shares that bucket with it; it also tells that lane
+                const uint32_t m0 = e0 >> 24, m1 = e1 >> 24, m2 = e2 >> 24;
+                const bool lost = valid && (m0 != (uint32_t)lane || m1 != (uint32_t)lane || m2 != (uint32_t)lane);
+                bool dep = lost;
+                if (ballot64(lost) != 0) {  // rare: two steps of the round in one bucket
+                    if (lane == 0) shareMask = 0ull;
+                    KC_WAVE_SYNC();
+                    if (lost) {
+                        if (m0 != (uint32_t)lane) atomicOr(&shareMask, 1ull << m0);
+                        if (m1 != (uint32_t)lane) atomicOr(&shareMask, 1ull << m1);
+                        if (m2 != (uint32_t)lane) atomicOr(&shareMask, 1ull << m2);
+                    }
+                    KC_WAVE_SYNC();
+                    dep = lost || ((shareMask >> lane) & 1ull) != 0;
+                }
+                if (lane == 0) dep = false;  // the first step has no earlier step to depend on: every round commits at least one step
+                int kind = 0, cand = 0;  // 1 repeat at s+1, 2 match at s, 3 match at s+1, 4 match at s+2
+                if (valid) {
+                    // the s+2 bucket is read after the s / s+1 buckets were written (encode_all.go:401)
+                    int c2 = (int)(e2 & S2L_POS_MASK);
+                    if (h2 == h1) c2 = p + 1;
+                    else if (h2 == h0) c2 = p;
+                    const int c0 = (int)(e0 & S2L_POS_MASK), c1 = (int)(e1 & S2L_POS_MASK);
+                    const uint32_t wr = rd32(p - repeat + 1);
+                    const uint32_t w0 = rd32(c0), w1 = rd32(c1), w2 = rd32(c2);
+                    if ((uint32_t)(cv >> 8) == wr) kind = 1;
+                    else if ((uint32_t)cv == w0) { kind = 2; cand = c0; }
+                    else if ((uint32_t)(cv >> 8) == w1) { kind = 3; cand = c1; }
+                    else if ((uint32_t)(cv >> 16) == w2) { kind = 4; cand = c2; }
+                }
+                const uint64_t vm = ballot64(valid);
+                const uint64_t tm = ballot64(term);
+                const uint64_t depm = ballot64(dep);
+                const uint64_t hm = ballot64(kind != 0);
+                const int nvalid = __popcll(vm);
+                const int c = depm ? ctz64(depm) : 64;
+                const uint64_t hmc = c >= 64 ? hm : (hm & ((1ull << c) - 1ull));
+                const bool found = hmc != 0;
+                const int f = found ? ctz64(hmc) : 0;
+                const int commitUpTo = found ? f : ((c < nvalid ? c : nvalid) - 1);
+                if (valid && lane <= commitUpTo) {
+                    const bool winner = found && lane == f;
+                    tab[h0] = (uint32_t)p;
+                    tab[h1] = (uint32_t)(p + 1);
+                    // table[hash2] = s+2 is skipped when the step ends on the repeat or on the match at s
+                    if (!(winner && (kind == 1 || kind == 2))) tab[h2] = (uint32_t)(p + 2);
+                }
+                KC_WAVE_SYNC();
+                if (!found) {
+                    W = 2 * W < 64 ? 2 * W : 64;
+                    if (c < nvalid) {
+                        s = (int)rdlane32((uint32_t)p, c);  // the first dependent step restarts as lane 0
+                    } else if (nvalid < 64 && ((tm >> nvalid) & 1ull)) {
+                        fin = true;                        // the step after the last committed one hits `nextS > sLimit`
+                    } else {
+                        s = (int)rdlane32((uint32_t)nextS, nvalid - 1);  // nvalid >= 1: lane 0 is valid or terminates
+                    }
+                    continue;
+                }
+                W = W0;
+                mkind = (int)rdlane32((uint32_t)kind, f);
+                candidate = (int)rdlane32((uint32_t)cand, f);
+                ps = (int)rdlane32((uint32_t)p, f);
             }
-            W = W0;
-            const int mkind = (int)rdlane32((uint32_t)kind, f);
-            int candidate = (int)rdlane32((uint32_t)cand, f);
-            const int ps = (int)rdlane32((uint32_t)p, f);
             if (mkind == 1) {
                 // ---------------- repeat at s+1 (encode_all.go:336-384) ----------------
                 int base = ps + 1;
@@ -367,6 +400,14 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
             }
         }
     }
+    if (stored) {
+        // the block is emitted again from the start of the slot, by other lanes than those that wrote the abandoned attempt:
+        // order the two (same wave, different lanes, same addresses)
+#ifndef KC_HIPEMU
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+        KC_WAVE_SYNC();
+    }
     if (!P.framed) {
         if (stored) { d = 0; d = emit_lit(0, len); }  // encode.go:44-55: not compressible -> one literal
         if (lane == 0) P.out_size[bi] = (uint32_t)(hdr + d);
@@ -397,11 +438,14 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
 
 void kc_launch_s2_encode_lds(const KcS2Params& P, bool any_small, bool any_big, hipStream_t st) {
     if (P.n_blocks == 0) return;
+    const bool one = P.spec_w0 <= 1;  // blocks held in LDS: one wave-uniform step at a time unless a speculation width is asked for
     if (P.level == 2) {
-        if (any_small) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, true>), dim3(P.n_blocks), dim3(64), 0, st, P);
-        if (any_big) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_small && one) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, true, true>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_small && !one) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, true, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_big) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, false, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
     } else {
-        if (any_small) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, true>), dim3(P.n_blocks), dim3(64), 0, st, P);
-        if (any_big) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_small && one) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, true, true>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_small && !one) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, true, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_big) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, false, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
     }
 }

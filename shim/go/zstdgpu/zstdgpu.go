@@ -55,9 +55,9 @@ type Encoder struct {
 }
 
 // WithDeviceJobs sends WithConcurrentBlocks streams to the device (kc_zstd_encode_jobs).  Off by default: the jobs of a stream are
-// few and long (64 jobs of 16 MiB per GiB at SpeedFastest), and a long unit is parsed by one lane group — 1 GiB takes ~7 s on the
-// device (profiles/r03_latency.json: 143 MB/s) where the reference's own job workers take a fraction of a second.  The bytes are
-// the same either way; the device path is there for parity and for hosts without spare cores.
+// few and long (64 jobs of 16 MiB per GiB at SpeedFastest), and a job is parsed by ONE wave — 1 GiB takes ~2.5 s on the device
+// (419 MB/s on the LDS-table kernel, DESIGN.md 4.4) where the reference's own job workers take a fraction of a second.  The bytes
+// are the same either way; the device path is there for parity and for hosts without spare cores.
 func WithDeviceJobs(b bool) Option {
 	return func(e *Encoder) error {
 		e.devJobs = b

@@ -38,28 +38,32 @@ def _cmp(blocks, got, ref_fn):
 @pytest.mark.parametrize("w0", [1, 8, 64])
 def test_s2_lds_blocks_bit_exact(w0):
     """s2.Encode through kc_s2_encode_lds_kernel<0, *>: blocks below and above 64 KiB (LDS / global source), every
-    speculation width (1 = the sequential scan itself, 64 = a whole wave of steps per round)."""
+    speculation width (1 = blocks in LDS take the wave-uniform one-step path, longer ones one-step rounds; 64 = a whole wave
+    of steps per round)."""
     blocks = _s2_blocks()
     _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=0, spec_w0=w0), oracle_lib.s2_encode)
 
 
-def test_s2_lds_snappy_bit_exact():
+@pytest.mark.parametrize("w0", [1, 8])
+def test_s2_lds_snappy_bit_exact(w0):
     blocks = _s2_blocks()
-    _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=2), oracle_lib.s2_encode_snappy)
+    _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=2, spec_w0=w0), oracle_lib.s2_encode_snappy)
 
 
-def test_s2_lds_framed_chunks_bit_exact():
+@pytest.mark.parametrize("w0", [1, 8])
+def test_s2_lds_framed_chunks_bit_exact(w0):
     """Framed mode: chunk header + masked CRC32C (wave-parallel CRC with the advance-by-zeros combine) + body."""
     blocks = [b for b in _s2_blocks() if len(b) > 0]
     buf, off = corpora.pack_units(blocks)
     ref, ro = oracle_lib.s2_encode_stream(buf, off, with_stream_id=False)
-    got = emu_lib.s2_encode_blocks(blocks, level=0, framed=True)
+    got = emu_lib.s2_encode_blocks(blocks, level=0, framed=True, spec_w0=w0)
     for i in range(len(blocks)):
         r = ref[int(ro[i]):int(ro[i + 1])].tobytes()
         assert r == got[i], "chunk %d (len %d): header %r vs %r" % (i, len(blocks[i]), r[:8], got[i][:8])
 
 
-def test_s2_lds_reference_regressions():
+@pytest.mark.parametrize("w0", [1, 8])
+def test_s2_lds_reference_regressions(w0):
     """The reference's own encoder regression inputs (s2/testdata/enc_regressions.zip, committed copy)."""
     zp = os.path.join(HERE, "golden", "ref_inputs", "enc_regressions.zip")
     if not os.path.exists(zp):
@@ -67,7 +71,7 @@ def test_s2_lds_reference_regressions():
     with zipfile.ZipFile(zp) as z:
         blocks = [z.read(n) for n in z.namelist() if not n.endswith("/")]
     blocks = [b for b in blocks if len(b) < (1 << 20)]
-    _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=0), oracle_lib.s2_encode)
+    _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=0, spec_w0=w0), oracle_lib.s2_encode)
 
 
 def _zfast_units():
