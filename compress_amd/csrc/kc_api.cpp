@@ -134,6 +134,7 @@ struct kc_ctx {
     std::once_flag hook_once;        // kc_s2_encode_block: micro-batcher of concurrent callers (S2Hook), created on first use
     void* hook = nullptr;
     bool ev7_valid = false;          // ev[7] was recorded for the batch in flight
+    int last_batches = 0;            // device batches the last zstd / S2 _dev call was cut into (scratch budget)
     int last_path = 0;               // KC_PATH_HBM / KC_PATH_LDS: what the last batch's match finder / S2 encoder ran on
 };
 
@@ -327,6 +328,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_S2_HOOK_WAIT_US: g.hook_wait_us = v; break;
         case KC_OPT_S2_HOOK_BATCH: g.hook_batch = v < 1 ? 1 : v; break;
         case KC_OPT_TEST_FEED_REDO: g.test_feed_redo = v; break;
+        case KC_OPT_MAX_SCRATCH_MIB: if (v < 1) return KC_ERR_BAD_ARG; c->max_scratch_bytes = (uint64_t)v << 20; break;
         default: return KC_ERR_BAD_ARG;
     }
     return KC_OK;
@@ -353,7 +355,9 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_S2_HOOK_WAIT_US: return g.hook_wait_us;
         case KC_OPT_S2_HOOK_BATCH: return g.hook_batch;
         case KC_OPT_TEST_FEED_REDO: return g.test_feed_redo;
+        case KC_OPT_MAX_SCRATCH_MIB: return (int64_t)(c->max_scratch_bytes >> 20);
         case KC_OPT_LAST_PATH: return c->last_path;
+        case KC_OPT_LAST_BATCHES: return c->last_batches;
         default: return -1;
     }
 }
@@ -1027,6 +1031,7 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
         }
     }
     out_off[0] = 0;
+    c->last_batches = 0;
     uint64_t pos = 0;
     uint32_t i0 = 0;
     std::vector<uint64_t> tmp;
@@ -1056,6 +1061,7 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
             s = run_batch(c, o, d_src, unit_off + i0, nb, d_dst + pos, dst_cap - pos, tmp.data(), &produced);
             if (s == KC_ERR_UNSUPPORTED && c->err.compare(0, 23, "device memory exhausted") == 0 && nb > 1 && attempt < 6) { oom = true; break; }
             if (s != KC_OK) return s;
+            c->last_batches++;
             for (uint32_t k = 0; k <= nb; k++) out_off[i0 + k] = pos + tmp[k];
             pos += produced;
             i0 = i1;
@@ -2216,7 +2222,8 @@ static kc_status s2_encode_dev_budgeted(kc_ctx* c, const uint8_t* d_src, const u
             scratch += us;
             i1++;
         }
-        if (i0 == 0 && i1 == n) return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, framed, with_stream_id, level);  // the usual case: one batch
+        if (i0 == 0 && i1 == n) { c->last_batches = 1; return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, framed, with_stream_id, level); }  // the usual case: one batch
+        if (i0 == 0) c->last_batches = 0;
         const uint32_t nb = i1 - i0;
         tmp.resize(nb + 1);
         kc_status s = s2_encode_dev(c, d_src, blk_off + i0, nb, d_dst + pos, dst_cap - pos, tmp.data(), framed, i0 == 0 ? with_stream_id : 0, level);
@@ -2229,6 +2236,7 @@ static kc_status s2_encode_dev_budgeted(kc_ctx* c, const uint8_t* d_src, const u
         for (uint32_t k = 0; k <= nb; k++) out_off[i0 + k] = pos + tmp[k];
         pos += tmp[nb];
         i0 = i1;
+        c->last_batches++;
     }
     return KC_OK;
 }

@@ -144,7 +144,9 @@ typedef enum {
     KC_OPT_S2_HOOK_WAIT_US = 14,     /* KC_S2_HOOK_WAIT_US        kc_s2_encode_block: time a batch leader waits for more callers */
     KC_OPT_S2_HOOK_BATCH = 15,       /* KC_S2_HOOK_BATCH          kc_s2_encode_block: most blocks per device batch */
     KC_OPT_TEST_FEED_REDO = 16,      /* (no variable)             diagnostics: force the chunk-fed path's re-encode fallback */
-    KC_OPT_LAST_PATH = 100           /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
+    KC_OPT_MAX_SCRATCH_MIB = 18,     /* (no variable)             ceiling of the device scratch one batch may take (default 160 GiB, and 85 % of the free memory): larger calls are cut into several batches */
+    KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
+    KC_OPT_LAST_BATCHES = 101        /* read-only: device batches the last kc_zstd_encode_units_dev / kc_s2_encode_*_dev call was cut into */
 } kc_option;
 kc_status kc_ctx_set_option(kc_ctx* ctx, int key, int64_t value);
 int64_t kc_ctx_get_option(const kc_ctx* ctx, int key);

@@ -519,3 +519,47 @@ def test_s2_host_chunk_fed_equals_oracle(oracle, kclib, level, monkeypatch):
     out3, out_off3 = enc.EncodeBlocks(buf, off)
     assert np.array_equal(out3, out) and np.array_equal(out_off3, out_off)
     enc.Close()
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_s2_batches_cut_by_the_scratch_budget(oracle, kclib, level):
+    """the S2 device path cuts a call into several batches when its tables + staging slots exceed the scratch budget
+    (here forced down to 64 MiB through KC_OPT_MAX_SCRATCH_MIB) instead of asking for all of it at once; same bytes as one batch."""
+    import torch
+    from compress_amd import s2, _lib
+    n, bsz = 1200, 65536
+    buf = corpora.corpus("J", n, bsz)
+    off = np.arange(n + 1, dtype=np.uint64) * bsz
+    d_src = torch.from_numpy(buf).cuda()
+    cap = n * ((s2.MaxEncodedLen(bsz) + 15) & ~15) + 64
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    enc = s2.BlockEncoder(level=level, path="hbm")
+    one = enc.EncodeBlocksDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    assert enc._ctx.get_option(_lib.OPT_LAST_BATCHES) == 1
+    want = d_dst[:int(one[n])].cpu().numpy().copy()
+    enc._ctx.set_option(_lib.OPT_MAX_SCRATCH_MIB, 64)
+    d_dst.zero_()
+    cut = enc.EncodeBlocksDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    assert enc._ctx.get_option(_lib.OPT_LAST_BATCHES) > 1
+    assert np.array_equal(cut, one) and np.array_equal(d_dst[:int(cut[n])].cpu().numpy(), want)
+    ref, ref_off = oracle.s2_encode_blocks(buf[:64 * bsz], off[:65], threads=8, better=level == 1)
+    assert np.array_equal(want[:int(one[64])], np.asarray(ref))
+    enc.Close()
+
+
+def test_context_options_roundtrip(kclib):
+    """kc_ctx_set_option / kc_ctx_get_option: every key reads back what was set; unknown keys and bad paths are refused."""
+    from compress_amd import _lib
+    ctx = _lib.Context()
+    for key, val in ((_lib.OPT_MATCH_PATH, _lib.PATH_LDS), (_lib.OPT_ZFAST_LDS_MAX_UNITS, 5), (_lib.OPT_S2_LDS_MAX_BLOCKS, 7), (_lib.OPT_SPEC_W0, 3),
+                     (_lib.OPT_SPEC_GROW, 1), (_lib.OPT_LDS_SPEC_W0, 32), (_lib.OPT_S2_LDS_SPEC_W0, 8), (_lib.OPT_HOST_SERIAL, 1), (_lib.OPT_HOST_PIPE_MIB, 64),
+                     (_lib.OPT_HOST_OVERLAP_MIN_MIB, 9), (_lib.OPT_HOST_COPY_THREADS, 4), (_lib.OPT_HOST_TRACE, 1), (_lib.OPT_HOST_CHUNK_MIB, 12),
+                     (_lib.OPT_K2_PROF, 0), (_lib.OPT_S2_HOOK_WAIT_US, 50), (_lib.OPT_S2_HOOK_BATCH, 33), (_lib.OPT_TEST_FEED_REDO, 1), (_lib.OPT_MAX_SCRATCH_MIB, 4096)):
+        ctx.set_option(key, val)
+        assert ctx.get_option(key) == val, key
+    with pytest.raises(_lib.KcError):
+        ctx.set_option(999, 1)
+    with pytest.raises(_lib.KcError):
+        ctx.set_option(_lib.OPT_MATCH_PATH, 7)
+    assert ctx.get_option(999) == -1
+    ctx.close()
