@@ -37,8 +37,9 @@ __global__ void k_unfenced(uint32_t* out) {
 __global__ void k_diverge(uint32_t* out) {
     const int lane = (int)threadIdx.x;
     uint64_t m = 0;
-    if (lane < 32) m = __ballot(true);          // half the wave never arrives
-    out[lane] = (uint32_t)m;
+    if (lane < 32) m = __ballot(true);          // half the wave goes through a collective the other half skips ...
+    const int v = __shfl(lane, 3);              // ... and meets it again at a different one
+    out[lane] = (uint32_t)m + (uint32_t)v;
 }
 
 int main(int argc, char** argv) {
