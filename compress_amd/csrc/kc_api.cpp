@@ -1987,7 +1987,8 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
                                ChunkFeed* feed = nullptr) {
     if (!c || !blk_off || !out_off || (n && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
     if (feed && (framed || n == 0)) { c->err = "chunk feed: bare blocks only"; return KC_ERR_INTERNAL; }
-    if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BETTER) { c->err = "device path implements s2.Encode, s2.EncodeBetter, s2.EncodeSnappy and s2.EncodeSnappyBetter"; return KC_ERR_UNSUPPORTED; }
+    if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BEST) { c->err = "unknown S2 level"; return KC_ERR_UNSUPPORTED; }
+    if (level >= KC_S2_LEVEL_BEST && (framed || feed)) { c->err = "the best levels are served as bare blocks (kc_s2_encode_blocks_lvl[_dev])"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
     c->last = kc_timings{0, 0, 0, 0, 0, 0};
     HIPCHK(c, hipSetDevice(c->device));
@@ -2079,7 +2080,9 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
         HIPCHK(c, hipGetLastError());
         return KC_OK;
     }
-    if (lds) {
+    if (level >= KC_S2_LEVEL_BEST) {
+        kc_launch_s2_best(P, st);
+    } else if (lds) {
         bool any_small = false, any_big = false;
         for (uint32_t i = 0; i < n; i++) ((blk_off[i + 1] - blk_off[i]) <= ((uint64_t)64 << 10) ? any_small : any_big) = true;
         P.spec_w0 = (int32_t)c->cfg.s2_lds_spec_w0;
@@ -2204,7 +2207,7 @@ kc_status kc_s2_decode_blocks_dev(kc_ctx* c, const uint8_t* d_enc, const uint64_
 static kc_status s2_encode_dev_budgeted(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
                                         uint64_t dst_cap, uint64_t* out_off, int framed, int with_stream_id, int level) {
     if (!c || !blk_off || !out_off) return KC_ERR_BAD_ARG;
-    if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BETTER || n == 0) return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, framed, with_stream_id, level);
+    if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BEST || n == 0) return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, framed, with_stream_id, level);
     uint64_t maxLen = 0;
     for (uint32_t i = 0; i < n; i++) if (blk_off[i + 1] >= blk_off[i]) maxLen = std::max(maxLen, blk_off[i + 1] - blk_off[i]);
     const uint64_t tb = kc_s2_table_bytes(level, maxLen);
@@ -2269,7 +2272,7 @@ kc_status kc_s2_encode_blocks(kc_ctx* c, const uint8_t* src, const uint64_t* blk
 kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* dst, uint64_t dst_cap,
                                   uint64_t* out_off) {
     if (!c || !blk_off || !out_off || (n && (!src || !dst))) return KC_ERR_BAD_ARG;
-    if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BETTER) { c->err = "device path implements s2.Encode, s2.EncodeBetter, s2.EncodeSnappy and s2.EncodeSnappyBetter"; return KC_ERR_UNSUPPORTED; }
+    if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BEST) { c->err = "unknown S2 level"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
     HIPCHK(c, hipSetDevice(c->device));
     if (n == 0) { out_off[0] = 0; return KC_OK; }
@@ -2279,7 +2282,7 @@ kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, cons
     }
     const uint64_t total = blk_off[n] - blk_off[0];
     const uint64_t ov_min = c->cfg.host_overlap_min_mib >= 0 ? (uint64_t)c->cfg.host_overlap_min_mib << 20 : (uint64_t)512 << 20;
-    if (total >= ov_min && total <= c->max_batch_bytes && !c->cfg.host_serial && c->cfg.host_pipe_mib < 16) {
+    if (total >= ov_min && total <= c->max_batch_bytes && !c->cfg.host_serial && c->cfg.host_pipe_mib < 16 && level < KC_S2_LEVEL_BEST) {  // (the best levels: 4.5 MiB of tables per block, several device batches)
         uint64_t need = 0;
         for (uint32_t i = 0; i < n; i++) need += ((uint64_t)kc_s2_max_encoded_len((int64_t)(blk_off[i + 1] - blk_off[i])) + 15) & ~(uint64_t)15;
         auto enq = [&](ChunkFeed& feed, const uint8_t* d_in, const uint64_t* rel, uint8_t* d_out) {

@@ -110,12 +110,14 @@ struct KcS2Params {
     uint32_t* tables;           // n x table_stride u32, zeroed by the caller
     uint32_t table_stride;      // u32 entries per block: kc_s2_table_bytes(level, max block length) / 4
     uint32_t n_blocks;
-    int32_t level;              // 0: s2.Encode, 1: s2.EncodeBetter, 2: s2.EncodeSnappy, 3: s2.EncodeSnappyBetter
+    int32_t level;              // 0: s2.Encode, 1: s2.EncodeBetter, 2: s2.EncodeSnappy, 3: s2.EncodeSnappyBetter, 4: s2.EncodeBest, 5: s2.EncodeSnappyBest
     int32_t spec_w0, spec_w0b;  // speculation width after a match (default / better parse)
     int32_t spec_grow;          // after a round without a match: 0 keep, 1 +1, 2 double
     int32_t framed;             // 1: emit s2.Writer chunks (type | len24 | masked CRC32C | body), s2/writer.go:414-451
 };
 void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st);
+// s2.EncodeBest (level 4) / s2.EncodeSnappyBest (level 5): kc_s2_best.hip, one wave per block, 4.5 MiB of {cur, prev} tables per block
+void kc_launch_s2_best(const KcS2Params& P, hipStream_t st);
 // LDS-table path (kc_s2_lds.hip): one wave per block, levels 0 and 2; any_small / any_big: the batch has blocks <= / > 64 KiB
 void kc_launch_s2_encode_lds(const KcS2Params& P, bool any_small, bool any_big, hipStream_t st);
 struct KcS2DecParams {
@@ -144,6 +146,7 @@ struct KcZstdDecParams {
 void kc_launch_zstd_decode(const KcZstdDecParams& P, hipStream_t st);
 // default: 2^14 entries; better: long 2^17 + short 2^14 (blocks > 64 KiB), long 2^16 + short 2^13 (all blocks <= 64 KiB)
 static inline size_t kc_s2_table_bytes(int level, uint64_t max_block_len) {
+    if (level >= 4) return ((size_t)8 << 19) + ((size_t)8 << 16);  // best: long 2^19 + short 2^16 entries of {cur, prev}
     if (level == 3) return max_block_len > ((uint64_t)64 << 10) ? (((size_t)4 << 16) + ((size_t)4 << 14)) : (((size_t)4 << 15) + ((size_t)4 << 13));
     if (level != 1) return (size_t)4 << 14;
     return max_block_len > ((uint64_t)64 << 10) ? (((size_t)4 << 17) + ((size_t)4 << 14)) : (((size_t)4 << 16) + ((size_t)4 << 13));

@@ -1,0 +1,357 @@
+// kc_s2_best.hip — s2.EncodeBest / s2.EncodeSnappyBest on the device: one wave per block.
+//
+// Replaces encodeBlockBest (s2/encode_best.go:22-455, dict == nil) and encodeBlockBestSnappy (:457-710) with their size
+// estimates (:715-797), behind s2.EncodeBest / s2.EncodeSnappyBest (s2/encode.go:146-202, 278-305).  The best level keeps, per
+// block, a long (8-byte hash, 2^19) and a short (4-byte hash, 2^16) table of {cur, prev} position pairs — 4.5 MiB, in an HBM
+// arena — scores up to five candidates at a position and, once one matches, up to eleven more at s+1, s+2 and behind the end of
+// the best match, and indexes every position of every match.
+//
+// Mapping: the control flow is wave-uniform (the sequential algorithm, state in scalar registers); the lanes are used where
+// the reference has independent work: every candidate of a phase is evaluated by its own lane (4-byte check, match extension,
+// score), the winner is then folded in the reference's order — including its "same offset as the current best: not retested"
+// rule, which is what makes the fold order-dependent —, literals are copied 8 bytes per lane, and the table updates after a
+// match take 64 positions per pass (positions whose bucket an earlier position of the pass also hits are applied afterwards, in
+// order: the {cur, prev} chain is order-dependent).  Tables are read and written with plain loads / stores: a wave's accesses to
+// one address are performed in program order.
+#include "kc_dev.h"
+#include "kc_kernels.h"
+#include "kc_s2_dev.h"
+
+#define SB_LBITS 19
+#define SB_SBITS 16
+
+__device__ __forceinline__ uint32_t sb_hash8(uint64_t u) { return (uint32_t)((u * KC_PRIME8) >> (64 - SB_LBITS)); }
+__device__ __forceinline__ uint32_t sb_hash4(uint64_t u) { return ((uint32_t)u * KC_PRIME4) >> (32 - SB_SBITS); }
+
+// size estimates of the best level (encode_best.go:715-797): NOT the sizes emitCopy / emitRepeat produce in every case
+__device__ inline int sb_repeat_size(int offset, int length) {
+    int total = 0;
+    for (;;) {
+        if (length <= 4 + 4 || (length < 8 + 4 && offset < 2048)) return total + 2;
+        if (length < (1 << 8) + 4 + 4) return total + 3;
+        if (length < (1 << 16) + (1 << 8) + 4) return total + 4;
+        const int maxRepeat = (1 << 24) - 1;
+        length -= (1 << 16) - 4;
+        int left = 0;
+        if (length > maxRepeat) left = length - maxRepeat + 4;
+        total += 5;
+        if (left <= 0) return total;
+        length = left;
+    }
+}
+__device__ inline int sb_copy_size(int offset, int length) {
+    if (offset >= 65536) {
+        int i = 0;
+        if (length > 64) {
+            length -= 64;
+            if (length >= 4) return 5 + sb_repeat_size(offset, length);
+            i = 5;
+        }
+        if (length == 0) return i;
+        return i + 5;
+    }
+    if (length > 64) {
+        if (offset < 2048) return 2 + sb_repeat_size(offset, length - 8);
+        return 3 + sb_repeat_size(offset, length - 60);
+    }
+    if (length >= 12 || offset >= 2048) return 3;
+    return 2;
+}
+__device__ inline int sb_copy_nr_size(int offset, int length) {  // emitCopyNoRepeatSize (:757-771)
+    if (offset >= 65536) return 5 + 5 * (length / 64);
+    if (length > 64) return 3 + 3 * (length / 60);
+    if (length >= 12 || offset >= 2048) return 3;
+    return 2;
+}
+
+struct SbMatch { int offset, s, length, score, rep; };
+
+template <bool SNAPPY>
+__global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
+    const int lane = (int)threadIdx.x;
+    const uint32_t bi = blockIdx.x;
+    if (bi >= P.n_blocks) return;
+    const uint8_t* __restrict__ src = P.src + P.blk_off[bi];
+    const int len = (int)(P.blk_off[bi + 1] - P.blk_off[bi]);
+    uint8_t* __restrict__ slot = P.stage + P.stage_off[bi];
+    uint8_t* __restrict__ out = slot;
+    uint64_t* const lT = (uint64_t*)(P.tables + (size_t)bi * P.table_stride);  // zeroed by the host
+    uint64_t* const sT = lT + ((size_t)1 << SB_LBITS);
+
+    // uvarint(len) header (encode.go:161-176)
+    int hdr = 0;
+    {
+        uint64_t x = (uint64_t)len;
+        while (x >= 0x80) { if (lane == 0) out[hdr] = (uint8_t)x | 0x80; hdr++; x >>= 7; }
+        if (lane == 0) out[hdr] = (uint8_t)x;
+        hdr++;
+    }
+    uint8_t* __restrict__ dst = out + hdr;
+    int d = 0;
+    if (len == 0) { if (lane == 0) P.out_size[bi] = (uint32_t)hdr; return; }
+    bool stored = len < 32;  // minNonLiteralBlockSize
+
+    auto emit_lit = [&](int from, int n) -> int {  // emitLiteral (encode_go.go:80)
+        if (n == 0) return 0;
+        const uint32_t m = (uint32_t)(n - 1);
+        uint8_t* __restrict__ o = dst + d;
+        int i;
+        if (m < 60) { i = 1; if (lane == 0) o[0] = (uint8_t)(m << 2); }
+        else if (m < (1u << 8)) { i = 2; if (lane == 0) { o[0] = 60 << 2; o[1] = (uint8_t)m; } }
+        else if (m < (1u << 16)) { i = 3; if (lane == 0) { o[0] = 61 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); } }
+        else if (m < (1u << 24)) { i = 4; if (lane == 0) { o[0] = 62 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); o[3] = (uint8_t)(m >> 16); } }
+        else { i = 5; if (lane == 0) { o[0] = 63 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); o[3] = (uint8_t)(m >> 16); o[4] = (uint8_t)(m >> 24); } }
+        const int body = n & ~7;
+        for (int k = lane * 8; k < body; k += 512) st64(o + i + k, ld64(src + from + k));
+        for (int k = body + lane; k < n; k += 64) o[i + k] = src[from + k];
+        return i + n;
+    };
+
+    if (!stored) {
+        const int sLimit = len - (8 + 2);  // inputMarginBest
+        const int dstLimit = len - 5;
+        int nextEmit = 0, s = 1, repeat = 1;
+        bool fin = false;
+        // one candidate per lane: the match matchAt would return WITHOUT its same-offset shortcut (applied by the fold below)
+        auto eval = [&](bool act, int offset, int s_, uint32_t first, bool rep) -> SbMatch {
+            SbMatch m;
+            m.offset = offset; m.s = s_; m.length = 0; m.score = 0; m.rep = rep ? 1 : 0;
+            if (!act) return m;
+            if (ld32(src + offset) != first) return m;
+            int la = 4 + offset;  // m.length while it is an absolute position
+            int sp = s_ + 4;
+            if (SNAPPY) {
+                while (sp <= sLimit) {
+                    const uint64_t diff = ld64(src + sp) ^ ld64(src + la);
+                    if (diff != 0) { la += ctz64(diff) >> 3; break; }
+                    sp += 8; la += 8;
+                }
+            } else {
+                while (sp < len) {
+                    if (len - sp < 8) {
+                        if (src[sp] == src[la]) { la++; sp++; continue; }
+                        break;
+                    }
+                    const uint64_t diff = ld64(src + sp) ^ ld64(src + la);
+                    if (diff != 0) { la += ctz64(diff) >> 3; break; }
+                    sp += 8; la += 8;
+                }
+            }
+            m.length = la - offset;
+            int sc = m.length - m.s;     // matches that start later are penalised: the bytes before go out as literals
+            if (nextEmit == m.s) sc++;   // no literals to emit: one byte saved
+            const int off = m.s - m.offset;
+            if (SNAPPY) sc -= sb_copy_nr_size(off, m.length);
+            else if (rep) sc -= sb_repeat_size(off, m.length);
+            else sc -= sb_copy_size(off, m.length);
+            m.score = sc;
+            if (m.score <= -m.s) m.length = 0;  // no savings: maybe a better one turns up
+            return m;
+        };
+        auto pick = [&](const SbMatch& mine, int j) -> SbMatch {  // lane j's candidate, wave-uniform
+            SbMatch r;
+            r.offset = (int)rdlane32((uint32_t)mine.offset, j); r.s = (int)rdlane32((uint32_t)mine.s, j);
+            r.length = (int)rdlane32((uint32_t)mine.length, j); r.score = (int)rdlane32((uint32_t)mine.score, j);
+            r.rep = (int)rdlane32((uint32_t)mine.rep, j);
+            return r;
+        };
+        auto best_of = [&](const SbMatch& a, const SbMatch& b) -> SbMatch {
+            if (b.length == 0) return a;
+            if (a.length == 0) return b;
+            const int as = a.score + b.s, bs = b.score + a.s;
+            return as >= bs ? a : b;
+        };
+        // best = bestOf(best, matchAt(candidate j)) with matchAt's shortcut: same offset as the current best -> not retested
+        auto fold = [&](SbMatch& best, SbMatch m) {
+            if (best.length != 0 && best.s - best.offset == m.s - m.offset) m.length = 0;
+            best = best_of(best, m);
+        };
+        uint32_t guard = 0;
+        while (!fin && !stored) {
+            SbMatch best;
+            best.offset = 0; best.s = 0; best.length = 0; best.score = 0; best.rep = 0;
+            for (;;) {
+                if (++guard > 2u * (uint32_t)len + 64u) { stored = true; break; }  // every step advances s: cannot happen; never spin on the device
+                int nextS = ((s - nextEmit) >> 8) + 1;
+                if (nextS > 64) nextS = s + 64; else nextS += s;  // maxSkip
+                if (nextS > sLimit) { fin = true; break; }
+                const uint64_t cv = ld64(src + s);
+                const uint32_t hashL = sb_hash8(cv), hashS = sb_hash4(cv);
+                const uint64_t candidateL = lT[hashL], candidateS = sT[hashS];
+                // ---- phase A: the four table candidates at s, the repeat at s+1 (:232-250) ----
+                {
+                    int off = 0, sp = s; uint32_t first = (uint32_t)cv; bool rep = false, act = lane < 5;
+                    if (lane == 0) off = (int)(uint32_t)candidateL;
+                    else if (lane == 1) off = (int)(candidateL >> 32);
+                    else if (lane == 2) off = (int)(uint32_t)candidateS;
+                    else if (lane == 3) off = (int)(candidateS >> 32);
+                    else if (lane == 4) { off = s - repeat + 1; sp = s + 1; first = (uint32_t)(cv >> 8); rep = !SNAPPY; act = SNAPPY || repeat > 0; }
+                    const SbMatch mine = eval(act, off, sp, first, rep);
+                    // bestOf(matchAt(cur L), matchAt(prev L)): both evaluated against the (empty) best of the step's start
+                    best = best_of(pick(mine, 0), pick(mine, 1));
+                    fold(best, pick(mine, 2));
+                    fold(best, pick(mine, 3));
+                    if (SNAPPY || repeat > 0) fold(best, pick(mine, 4));
+                }
+                if (best.length > 0) {
+                    // ---- phase B: s+1 and s+2 (:252-311) ----
+                    const uint64_t nextShort1 = sT[sb_hash4(cv >> 8)];
+                    const int s1 = s + 1;
+                    const uint64_t cv1 = ld64(src + s1);
+                    const uint64_t nextLong1 = lT[sb_hash8(cv1)];
+                    const uint64_t nextShort2 = sT[sb_hash4(cv1 >> 8)];
+                    const int s2 = s + 2;
+                    const uint64_t cv2 = ld64(src + s2);
+                    const uint64_t nextLong2 = lT[sb_hash8(cv2)];
+                    {
+                        int off = 0, sp = s1; uint32_t first = (uint32_t)cv1; bool rep = false, act = lane < 10;
+                        // lanes 0-3: s+1 table candidates; lane 4: the repeat of the s+1 / s+2 state; lanes 5-8: s+2 table candidates
+                        if (lane == 0) off = (int)(uint32_t)nextShort1;
+                        else if (lane == 1) off = (int)(nextShort1 >> 32);
+                        else if (lane == 2) off = (int)(uint32_t)nextLong1;
+                        else if (lane == 3) off = (int)(nextLong1 >> 32);
+                        else if (lane == 4) {
+                            if (SNAPPY) { off = s1 - repeat + 1; sp = s1 + 1; first = (uint32_t)(cv1 >> 8); }    // repeat at +2, from the s+1 state (:571)
+                            else { off = s2 - repeat; sp = s2; first = (uint32_t)cv2; rep = true; act = repeat > 0; }  // repeat at +2 (:286-289)
+                        }
+                        else if (lane == 5) { off = (int)(uint32_t)nextShort2; sp = s2; first = (uint32_t)cv2; }
+                        else if (lane == 6) { off = (int)(nextShort2 >> 32); sp = s2; first = (uint32_t)cv2; }
+                        else if (lane == 7) { off = (int)(uint32_t)nextLong2; sp = s2; first = (uint32_t)cv2; }
+                        else if (lane == 8) { off = (int)(nextLong2 >> 32); sp = s2; first = (uint32_t)cv2; }
+                        else act = false;
+                        const SbMatch mine = eval(act, off, sp, first, rep);
+                        fold(best, pick(mine, 0));
+                        fold(best, pick(mine, 1));
+                        fold(best, pick(mine, 2));
+                        fold(best, pick(mine, 3));
+                        if (SNAPPY || repeat > 0) fold(best, pick(mine, 4));  // (both variants take it before the s+2 table candidates)
+                        fold(best, pick(mine, 5));
+                        fold(best, pick(mine, 6));
+                        fold(best, pick(mine, 7));
+                        fold(best, pick(mine, 8));
+                    }
+                    // ---- phase C: a match at the end of the best match, shifted back over it (:313-345) ----
+                    const int skipBeginning = SNAPPY ? 0 : 2, skipEnd = SNAPPY ? 0 : 1;
+                    const int sAt = best.s + best.length - skipEnd;
+                    if (sAt < sLimit) {
+                        const int sBack = best.s + skipBeginning - skipEnd;
+                        const int backL = best.length - skipBeginning;
+                        const uint64_t cvb = ld64(src + sBack);
+                        const uint64_t next = lT[sb_hash8(ld64(src + sAt))];
+                        const int chk0 = (int)(uint32_t)next - backL, chk1 = (int)(next >> 32) - backL;
+                        const bool act = (lane == 0 && chk0 > 0) || (lane == 1 && chk1 > 0);
+                        const SbMatch mine = eval(act, lane == 0 ? chk0 : chk1, sBack, (uint32_t)cvb, false);
+                        if (chk0 > 0) fold(best, pick(mine, 0));
+                        if (chk1 > 0) fold(best, pick(mine, 1));
+                    }
+                }
+                // update the tables (:348-350), after every lane has read what this step looks up
+                KC_WAVE_SYNC();
+                if (lane == 0) {
+                    lT[hashL] = (uint64_t)(uint32_t)s | (candidateL << 32);
+                    sT[hashS] = (uint64_t)(uint32_t)s | (candidateS << 32);
+                }
+                KC_WAVE_SYNC();
+                if (best.length > 0) break;
+                s = nextS;
+            }
+            if (fin || stored) break;
+            // ---- the match: extend backwards (not for repeats; always at the Snappy level), bail-outs, emit (:358-420) ----
+            s = best.s;
+            if (SNAPPY || !best.rep) {
+                int kmax = best.offset < s - nextEmit ? best.offset : s - nextEmit;
+                int cnt = 0;
+                while (cnt < kmax) {
+                    const int k = cnt + lane + 1;
+                    bool ne = true;
+                    if (k <= kmax) ne = src[best.offset - k] != src[s - k];
+                    const uint64_t mm = ballot64(ne);
+                    const int c = mm ? ctz64(mm) : 64;
+                    cnt += c;
+                    if (c < 64) break;
+                }
+                if (cnt > kmax) cnt = kmax;
+                best.offset -= cnt; best.length += cnt; s -= cnt;
+            }
+            if (d + (s - nextEmit) > dstLimit) { stored = true; break; }
+            const int base = s;
+            const int offset = s - best.offset;
+            s += best.length;
+            if (offset > 65535 && s - base <= 5 && (SNAPPY || !best.rep)) {  // equal or worse than the encoding
+                s = best.s + 1;
+                if (s >= sLimit) fin = true;
+                continue;
+            }
+            d += emit_lit(nextEmit, base - nextEmit);
+            if (SNAPPY) {
+                if (lane == 0) s2_emit_copy_nr1(dst + d, offset, best.length);
+                d += s2_copy_nr_size(offset, best.length);
+            } else {
+                uint64_t lo = 0, hi = 0;
+                auto sink = [&](int k, uint8_t v) { if (k < 8) lo |= (uint64_t)v << (8 * k); else hi |= (uint64_t)v << (8 * (k - 8)); };
+                const bool asRepeat = best.rep && nextEmit > 0;  // the first match cannot be a repeat
+                const int n = asRepeat ? s2_put_repeat(sink, offset, best.length) : s2_put_copy(sink, offset, best.length);
+                if (lane == 0) {
+                    for (int k = 0; k < n && k < 8; k++) dst[d + k] = (uint8_t)(lo >> (8 * k));
+                    for (int k = 8; k < n; k++) dst[d + k] = (uint8_t)(hi >> (8 * (k - 8)));
+                }
+                d += n;
+            }
+            repeat = offset;
+            nextEmit = s;
+            if (s >= sLimit) { fin = true; break; }
+            if (d > dstLimit) { stored = true; break; }
+            // ---- index every position of the match (:422-432): 64 positions per pass, chain order kept ----
+            for (int i0 = best.s + 1; i0 < s; i0 += 64) {
+                const int i = i0 + lane;
+                const bool act = i < s;
+                uint32_t hl = 0xFFFFFFFFu, hs = 0xFFFFFFFFu;
+                if (act) { const uint64_t cv0 = ld64(src + i); hl = sb_hash8(cv0); hs = sb_hash4(cv0); }
+                // does an earlier position of this pass hit the same bucket?
+                bool dupL = false, dupS = false;
+                const int npass = s - i0 < 64 ? s - i0 : 64;
+                for (int k = 0; k + 1 < npass; k++) {
+                    const uint32_t kl = rdlane32(hl, k), ks = rdlane32(hs, k);
+                    if (k < lane) { dupL = dupL || kl == hl; dupS = dupS || ks == hs; }
+                }
+                if (act && !dupL) { const uint64_t old = lT[hl]; lT[hl] = (uint64_t)(uint32_t)i | (old << 32); }
+                if (act && !dupS) { const uint64_t old = sT[hs]; sT[hs] = (uint64_t)(uint32_t)i | (old << 32); }
+                uint64_t mL = ballot64(act && dupL), mS = ballot64(act && dupS);
+                while (mL) {  // in order: each sees the entry its predecessors of the pass left
+                    const int k = ctz64(mL);
+                    mL &= mL - 1;
+                    KC_WAVE_SYNC();
+                    if (lane == k) { const uint64_t old = lT[hl]; lT[hl] = (uint64_t)(uint32_t)i | (old << 32); }
+                }
+                while (mS) {
+                    const int k = ctz64(mS);
+                    mS &= mS - 1;
+                    KC_WAVE_SYNC();
+                    if (lane == k) { const uint64_t old = sT[hs]; sT[hs] = (uint64_t)(uint32_t)i | (old << 32); }
+                }
+                KC_WAVE_SYNC();
+            }
+        }
+        if (!stored) {  // emitRemainder (:435-450)
+            if (nextEmit < len) {
+                if (d + len - nextEmit > dstLimit) stored = true;
+                else d += emit_lit(nextEmit, len - nextEmit);
+            }
+        }
+    }
+    if (stored) {
+#ifndef KC_HIPEMU
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+        KC_WAVE_SYNC();
+        d = 0;
+        d = emit_lit(0, len);  // encode.go:170-176: not compressible -> one literal
+    }
+    if (lane == 0) P.out_size[bi] = (uint32_t)(hdr + d);
+}
+
+void kc_launch_s2_best(const KcS2Params& P, hipStream_t st) {
+    if (P.n_blocks == 0) return;
+    if (P.level == 5) hipLaunchKernelGGL((kc_s2_best_kernel<true>), dim3(P.n_blocks), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL((kc_s2_best_kernel<false>), dim3(P.n_blocks), dim3(64), 0, st, P);
+}

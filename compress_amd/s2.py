@@ -10,6 +10,7 @@ def MaxEncodedLen(src_len):
 
 
 LevelDefault, LevelBetter, LevelSnappy, LevelSnappyBetter = 0, 1, 2, 3  # s2.Encode / EncodeBetter / EncodeSnappy / EncodeSnappyBetter (s2/encode.go:29, 117, 204, 248)
+LevelBest, LevelSnappyBest = 4, 5  # s2.EncodeBest / EncodeSnappyBest (s2/encode.go:146, 278): bare blocks only (EncodeBlocks / EncodeBlocksDevice)
 
 
 class BlockEncoder:

@@ -235,10 +235,14 @@ kc_status kc_s2_encode_blocks_dev(kc_ctx* ctx, const uint8_t* d_src, const uint6
  * KC_S2_LEVEL_BETTER == s2.EncodeBetter (s2/encode.go:117-144: encodeBlockBetterGo / encodeBlockBetterGo64K,
  * s2/encode_better.go:50-307 / 485-730), KC_S2_LEVEL_SNAPPY == s2.EncodeSnappy (s2/encode.go:204-232: encodeBlockSnappyGo /
  * encodeBlockSnappyGo64K, s2/encode_all.go:502-690 / 692-880 — blocks a Snappy decoder reads: no repeat tags),
- * KC_S2_LEVEL_SNAPPY_BETTER == s2.EncodeSnappyBetter.  Other levels (best, snappy-best) return KC_ERR_UNSUPPORTED. */
+ * KC_S2_LEVEL_SNAPPY_BETTER == s2.EncodeSnappyBetter, KC_S2_LEVEL_BEST == s2.EncodeBest (s2/encode.go:146-202: encodeBlockBest,
+ * s2/encode_best.go:22-455), KC_S2_LEVEL_SNAPPY_BEST == s2.EncodeSnappyBest (s2/encode.go:278-305: encodeBlockBestSnappy,
+ * s2/encode_best.go:457-710).  The best levels take 4.5 MiB of tables per block: large calls are cut into batches. */
 #define KC_S2_LEVEL_DEFAULT 0
 #define KC_S2_LEVEL_BETTER 1
 #define KC_S2_LEVEL_SNAPPY 2
+#define KC_S2_LEVEL_BEST 4
+#define KC_S2_LEVEL_SNAPPY_BEST 5
 #define KC_S2_LEVEL_SNAPPY_BETTER 3   /* s2.EncodeSnappyBetter (s2/encode.go:248-276: encodeBlockBetterSnappyGo / ...64K, s2/encode_better.go:310-483 / 733-900) */
 kc_status kc_s2_encode_blocks_lvl(kc_ctx* ctx, int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks,
                                   uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);

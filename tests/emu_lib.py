@@ -36,6 +36,8 @@ def lib():
         _L.kcemu_s2_encode.restype = C.c_int
         _L.kcemu_s2_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _L.kcemu_collectives.restype = C.c_uint64
+        _L.kcemu_s2_best.restype = C.c_int
+        _L.kcemu_s2_best.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if hasattr(_L, "kcemu_zfast_parse"):
             _L.kcemu_zfast_parse.restype = C.c_int
             _L.kcemu_zfast_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -101,4 +103,29 @@ def zfast_parse(units, block_size=65536, window=4 << 20, spec_w0=8, stream_mode=
         tri = np.stack([(v >> np.uint64(44)).astype(np.uint32), ((v >> np.uint64(24)) & np.uint64(0xFFFFF)).astype(np.uint32),
                         (v & np.uint64(0xFFFFFF)).astype(np.uint32)], axis=1) if ns else np.zeros((0, 3), dtype=np.uint32)
         out.append((tri, int(m[1]), int(m[2]), int(m[3])))
+    return out
+
+
+def s2_best_blocks(blocks, snappy=False):
+    """kc_s2_best_kernel (s2.EncodeBest / s2.EncodeSnappyBest) over `blocks` (list of bytes) -> list of bytes (uvarint + body)."""
+    n = len(blocks)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    for i, b in enumerate(blocks):
+        off[i + 1] = off[i] + len(b)
+    src = np.frombuffer(b"".join(blocks) + b"\0" * 64, dtype=np.uint8).copy()
+    soff = np.zeros(n + 1, dtype=np.uint64)
+    for i, b in enumerate(blocks):
+        soff[i + 1] = soff[i] + ((s2_max_encoded_len(len(b)) + 8 + 63) & ~63)
+    stage = np.zeros(int(soff[n]) + 64, dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.uint32)
+    out = []
+    tab = np.zeros((4 << 20 | 512 << 10) // 4, dtype=np.uint32)
+    for i in range(n):  # one block per launch: the table arena stays at 4.5 MiB
+        tab[:] = 0
+        o2 = np.array([off[i], off[i + 1]], dtype=np.uint64) - off[i]
+        s2 = np.array([0, soff[i + 1] - soff[i]], dtype=np.uint64)
+        r = lib().kcemu_s2_best(5 if snappy else 4, src.ctypes.data + int(off[i]), o2.ctypes.data, 1, stage.ctypes.data + int(soff[i]), s2.ctypes.data,
+                                sizes[i:].ctypes.data, tab.ctypes.data)
+        assert r == 0
+        out.append(stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes())
     return out

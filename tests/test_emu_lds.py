@@ -102,3 +102,14 @@ def test_zfast_lds_parse_matches_oracle(w0):
                 assert len(neq) == 0, "unit %d block %d first differing seq %d: emulated %r oracle %r" % (ui, rb, neq[0], gseqs[neq[0]], rseqs[neq[0]])
             assert gnlit == len(rlits), "unit %d block %d: nlit %d vs oracle %d" % (ui, rb, gnlit, len(rlits))
     assert bi == len(got)
+
+
+@pytest.mark.parametrize("snappy", [False, True])
+def test_s2_best_kernel_bit_exact(snappy):
+    """kc_s2_best_kernel (s2.EncodeBest / s2.EncodeSnappyBest: candidates of a phase evaluated one per lane, folded in the
+    reference's order with its same-offset rule; chain-ordered table updates, 64 positions per pass) against the oracle."""
+    blocks = [corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("T", 1, 65536).tobytes(), corpora.corpus("H", 1, 20000).tobytes(),
+              corpora.corpus("M", 1, 65536, first_unit=2).tobytes(), corpora.corpus("T", 2, 131072, first_unit=9).tobytes()[:150000]]
+    blocks += [u for u in corpora.edge_units() if len(u) <= 70000]
+    blocks += [u[:40000] for u in corpora.stress_units(seed=13, n=6)]
+    _cmp(blocks, emu_lib.s2_best_blocks(blocks, snappy=snappy), oracle_lib.s2_encode_snappy_best if snappy else oracle_lib.s2_encode_best)

@@ -563,3 +563,59 @@ def test_context_options_roundtrip(kclib):
         ctx.set_option(_lib.OPT_MATCH_PATH, 7)
     assert ctx.get_option(999) == -1
     ctx.close()
+
+
+@pytest.mark.parametrize("snappy", [False, True])
+def test_s2_best_blocks_bit_exact(oracle, kclib, snappy):
+    """s2.EncodeBest / s2.EncodeSnappyBest on the device (kc_s2_best.hip: one wave per block, 4.5 MiB of {cur, prev} tables) against
+    the oracle's restatement of encodeBlockBest / encodeBlockBestSnappy: corpus blocks, blocks above 64 KiB, edge units, stress
+    mixes; the Snappy variant also through the strict Snappy decoder of the oracle tests (no S2 extensions)."""
+    from compress_amd import s2
+    blocks = []
+    for kind in "JTMH":
+        b = corpora.corpus(kind, 12, 65536, first_unit=4)
+        blocks += [b[i * 65536:(i + 1) * 65536].tobytes() for i in range(12)]
+    big = corpora.corpus("T", 3, 1 << 20).tobytes()
+    blocks += [big[:65537], big[:300000], big[1 << 20:2 << 20], corpora.corpus("J", 1, 1 << 20).tobytes()[:700000]]
+    blocks += corpora.edge_units()
+    blocks += [u for u in corpora.stress_units(seed=17, n=24)]
+    buf, off = corpora.pack_units(blocks)
+    enc = s2.BlockEncoder(level=s2.LevelSnappyBest if snappy else s2.LevelBest)
+    out, out_off = enc.EncodeBlocks(buf, off)
+    ref_fn = oracle.s2_encode_snappy_best if snappy else oracle.s2_encode_best
+    bad = []
+    for i, blk in enumerate(blocks):
+        a = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        r = ref_fn(blk)
+        if a != r:
+            bad.append((i, len(blk), len(a), len(r)))
+    assert not bad, "blocks differing from the oracle (index, in_len, gpu_len, oracle_len): %r" % bad[:10]
+    for i in (0, 13, len(blocks) - 1):
+        a = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        assert oracle.s2_decode(a, len(blocks[i]) + 8) == blocks[i]
+    enc.Close()
+
+
+def test_s2_best_many_blocks_in_budgeted_batches(oracle, kclib):
+    """4.5 MiB of tables per block: 2048 blocks ask for 9 GiB; with the scratch ceiling at 2 GiB the call is cut into batches and
+    gives the same bytes (sample against the oracle, all blocks round-tripped on the device)."""
+    import torch
+    from compress_amd import s2, _lib
+    n, bsz = 2048, 65536
+    buf = corpora.corpus("J", n, bsz, first_unit=100)
+    off = np.arange(n + 1, dtype=np.uint64) * bsz
+    d_src = torch.from_numpy(buf).cuda()
+    cap = n * ((s2.MaxEncodedLen(bsz) + 15) & ~15) + 64
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    enc = s2.BlockEncoder(level=s2.LevelBest)
+    enc._ctx.set_option(_lib.OPT_MAX_SCRATCH_MIB, 2048)
+    oo = enc.EncodeBlocksDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    assert enc._ctx.get_option(_lib.OPT_LAST_BATCHES) > 1
+    out = d_dst[:int(oo[n])].cpu().numpy()
+    for i in (0, 500, 1023, 1024, 2047):
+        assert out[int(oo[i]):int(oo[i + 1])].tobytes() == oracle.s2_encode_best(buf[i * bsz:(i + 1) * bsz].tobytes()), i
+    d_back = torch.empty(n * bsz + 64, dtype=torch.uint8, device="cuda")
+    st = enc.DecodeBlocksDevice(d_dst.data_ptr(), oo, d_back.data_ptr(), off)
+    assert not st.any() and torch.equal(d_back[:n * bsz], d_src)
+    assert float(oo[n]) / (n * bsz) < 0.33  # better than the default level's 0.354 on this corpus
+    enc.Close()

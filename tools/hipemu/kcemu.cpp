@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "../../compress_amd/csrc/kc_s2_lds.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_lds.hip"
+#include "../../compress_amd/csrc/kc_s2_best.hip"
 
 extern "C" {
 
@@ -48,6 +49,24 @@ int kcemu_zfast_parse(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     P.rep2 = rep2;
     P.stream_mode = stream_mode;
     kc_launch_zfast_match_lds(P, proto, 0u, n, nullptr);
+    return 0;
+}
+
+// N blocks through kc_s2_best_kernel (level 4: s2.EncodeBest, 5: s2.EncodeSnappyBest); tables: n x (4.5 MiB / 4) u32, zeroed by the caller
+int kcemu_s2_best(int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* stage, const uint64_t* stage_off, uint32_t* out_size,
+                  uint32_t* tables) {
+    KcS2Params P;
+    memset(&P, 0, sizeof(P));
+    P.src = src;
+    P.blk_off = blk_off;
+    P.stage_off = stage_off;
+    P.stage = stage;
+    P.out_size = out_size;
+    P.tables = tables;
+    P.table_stride = (uint32_t)(kc_s2_table_bytes(level, 0) / 4);
+    P.n_blocks = n;
+    P.level = level;
+    kc_launch_s2_best(P, nullptr);
     return 0;
 }
 
