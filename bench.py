@@ -195,8 +195,9 @@ def main():
                     help="N > 1: 'root' gathers every step's frames to rank 0 over RCCL (the path's only exchange step, default); "
                          "'none' leaves each rank's contiguous shard of frames on its own GPU (consumers that write per-rank files: "
                          "compress_amd.shard.write_shard; the frames are concatenable in rank order)")
-    ap.add_argument("--s2-level", type=int, default=0, choices=[0, 1, 2, 3],
-                    help="C4 only: 0 s2.Encode (the BASELINE configuration), 1 s2.EncodeBetter, 2 s2.EncodeSnappy")
+    ap.add_argument("--s2-level", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="C4 only: 0 s2.Encode (the BASELINE configuration), 1 s2.EncodeBetter, 2 s2.EncodeSnappy, 3 s2.EncodeSnappyBetter, "
+                         "4 s2.EncodeBest, 5 s2.EncodeSnappyBest")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the rank plumbing of the N > 1 path on the gloo backend with fabricated frames — contiguous sharding, "
                          "FrameGather overlapped with the next step over two buffers, barrier + all_reduce(MAX) timing, one JSON line from "
@@ -261,8 +262,10 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(npipe)]
     if is_s2:
         encs = [s2.BlockEncoder(device=local_rank, stream=streams[0].cuda_stream, level=args.s2_level, path=args.path)]
-        cfg["what"] = {0: cfg["what"], 1: "s2.EncodeBetter", 2: "s2.EncodeSnappy", 3: "s2.EncodeSnappyBetter"}[args.s2_level]
-        cfg["kernel"] = "kc_s2_encode_kernel<%d>" % args.s2_level
+        cfg["what"] = {0: cfg["what"], 1: "s2.EncodeBetter", 2: "s2.EncodeSnappy", 3: "s2.EncodeSnappyBetter", 4: "s2.EncodeBest", 5: "s2.EncodeSnappyBest"}[args.s2_level]
+        cfg["kernel"] = "kc_s2_encode_kernel<%d>" % args.s2_level if args.s2_level < 4 else "kc_s2_best_kernel<%s>" % ("true" if args.s2_level == 5 else "false")
+        if args.s2_level >= 4:
+            cfg["src"] = "kc_s2_best.hip"
         slot = (s2.MaxEncodedLen(UNIT) + 15) & ~15
     else:
         zopts = [zstd.WithEncoderLevel(cfg["level"]), zstd.WithMatchPath(args.path)]
@@ -395,7 +398,7 @@ def main():
             t0 = time.perf_counter()
             if is_s2:
                 ref, ref_off = oracle_lib.s2_encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], threads=cores,
-                                                           better=args.s2_level in (1, 3), snappy=args.s2_level in (2, 3))
+                                                           level=args.s2_level)
             else:
                 kw = dict(level=cfg["level"])
                 if dict_content:

@@ -630,6 +630,8 @@ static int64_t s2_encode_blocks_impl(const uint8_t* src, const uint64_t* blk_off
             int64_t r = level == 1 ? s2::EncodeBetter(outs[i].data(), outs[i].size(), src + blk_off[i], n)
                       : level == 2 ? s2::EncodeSnappy(outs[i].data(), outs[i].size(), src + blk_off[i], n)
                       : level == 3 ? s2::EncodeSnappyBetter(outs[i].data(), outs[i].size(), src + blk_off[i], n)
+                      : level == 4 ? s2::EncodeBest(outs[i].data(), outs[i].size(), src + blk_off[i], n)
+                      : level == 5 ? s2::EncodeSnappyBest(outs[i].data(), outs[i].size(), src + blk_off[i], n)
                                    : s2::Encode(outs[i].data(), outs[i].size(), src + blk_off[i], n);
             outs[i].resize((size_t)r);
         }
@@ -663,6 +665,11 @@ int64_t kco_s2_encode_blocks_snappy(const uint8_t* src, const uint64_t* blk_off,
 int64_t kco_s2_encode_blocks_snappy_better(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
                                            uint64_t* out_off, int threads) {
     return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, 3);
+}
+// the same at any level 0..5 (4: s2.EncodeBest, 5: s2.EncodeSnappyBest)
+int64_t kco_s2_encode_blocks_level(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
+                                   uint64_t* out_off, int threads, int level) {
+    return s2_encode_blocks_impl(src, blk_off, n_blocks, dst, dst_cap, out_off, threads, level);
 }
 
 }  // extern "C"

@@ -295,7 +295,7 @@ def s2_encode_snappy_better(src: bytes) -> bytes:
     return buf.raw[:r]
 
 
-def s2_encode_blocks(src, blk_off, threads=1, better=False, snappy=False):
+def s2_encode_blocks(src, blk_off, threads=1, better=False, snappy=False, level=None):
     """N x s2.Encode (or s2.EncodeBetter) on host threads.  src: numpy u8; blk_off: numpy u64 [n+1].  Returns (numpy u8, out_off numpy u64[n+1])."""
     import numpy as np
     src = np.ascontiguousarray(src, dtype=np.uint8)
@@ -306,6 +306,13 @@ def s2_encode_blocks(src, blk_off, threads=1, better=False, snappy=False):
     dst = np.empty(cap, dtype=np.uint8)
     out_off = np.empty(n + 1, dtype=np.uint64)
     L = lib()
+    if level is not None:  # 0..5 (4: s2.EncodeBest, 5: s2.EncodeSnappyBest)
+        L.kco_s2_encode_blocks_level.restype = C.c_int64
+        L.kco_s2_encode_blocks_level.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int]
+        r = L.kco_s2_encode_blocks_level(src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, out_off.ctypes.data, int(threads), int(level))
+        if r < 0:
+            raise RuntimeError("oracle s2_encode_blocks failed: %d" % r)
+        return dst[:r], out_off
     fn = (L.kco_s2_encode_blocks_snappy_better if (better and snappy) else L.kco_s2_encode_blocks_better if better
           else L.kco_s2_encode_blocks_snappy if snappy else L.kco_s2_encode_blocks)
     r = fn(src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, out_off.ctypes.data, int(threads))
