@@ -24,7 +24,7 @@ class ZstdOpts(C.Structure):
         ("low_mem", C.c_int32), ("custom_window", C.c_int32), ("custom_block", C.c_int32), ("custom_alent", C.c_int32),
         ("dict_id", C.c_uint32), ("dict", C.c_void_p), ("dict_len", C.c_uint64),
         ("dict_offsets", C.c_uint32 * 3), ("dict_huf_len", C.c_int32), ("dict_huf_log", C.c_int32),
-        ("dict_huf_val", C.c_uint16 * 256), ("dict_huf_nbits", C.c_uint8 * 256),
+        ("dict_huf_val", C.c_uint16 * 256), ("dict_huf_nbits", C.c_uint8 * 256), ("concurrent", C.c_int32),
     ]
 
 
@@ -36,7 +36,7 @@ class Timings(C.Structure):
 # every symbol include/kcgpu.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "kc_zstd_opts_default", "kc_zstd_opts_level", "kc_zstd_opts_window", "kc_zstd_opts_crc", "kc_zstd_opts_zero_frames",
-    "kc_zstd_opts_no_entropy", "kc_zstd_opts_all_lit_entropy", "kc_zstd_opts_single_segment", "kc_zstd_opts_dict_raw", "kc_zstd_opts_dict",
+    "kc_zstd_opts_no_entropy", "kc_zstd_opts_all_lit_entropy", "kc_zstd_opts_single_segment", "kc_zstd_opts_concurrency", "kc_zstd_opts_dict_raw", "kc_zstd_opts_dict",
     "kc_zstd_max_encoded_size", "kc_ctx_create", "kc_ctx_destroy", "kc_last_error", "kc_device_info",
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts", "kc_zstd_encode_units_submit", "kc_s2_encode_blocks_lvl_submit", "kc_wait", "kc_zstd_plan_stream_blocks", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
     "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats", "kc_s2_encode_blocks_lvl", "kc_s2_encode_blocks_lvl_dev", "kc_s2_encode_stream_lvl_dev",
@@ -77,7 +77,7 @@ def load():
     po = C.POINTER(ZstdOpts)
     L.kc_zstd_opts_default.argtypes = [po]
     L.kc_zstd_opts_default.restype = None
-    for n in ("level", "window", "crc", "zero_frames", "no_entropy", "all_lit_entropy", "single_segment"):
+    for n in ("level", "window", "crc", "zero_frames", "no_entropy", "all_lit_entropy", "single_segment", "concurrency"):
         f = getattr(L, "kc_zstd_opts_" + n)
         f.argtypes = [po, C.c_int]
         f.restype = C.c_int

@@ -200,6 +200,13 @@ void kc_zstd_opts_default(kc_zstd_opts* o) {  // setDefault :36-48
     o->all_lit_entropy = 0;
     o->low_mem = 0;
     o->dict_offsets[0] = 1; o->dict_offsets[1] = 4; o->dict_offsets[2] = 8;
+    o->concurrent = 0;
+}
+
+int kc_zstd_opts_concurrency(kc_zstd_opts* o, int n) {  // WithEncoderConcurrency :76-87
+    if (n < 1) return KC_ERR_BAD_ARG;
+    o->concurrent = n;
+    return KC_OK;
 }
 
 int kc_zstd_opts_level(kc_zstd_opts* o, int l) {  // WithEncoderLevel :236-266
@@ -728,6 +735,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     ep.unit_off = k_off;
     ep.hist0 = hist0;
     ep.stream_mode = c->stream_mode;
+    ep.stream_sync = o->concurrent == 1;
     ep.dict_huf = nullptr;
     ep.dict_huf_len = 0;
     ep.dict_huf_log = 0;
@@ -1116,10 +1124,6 @@ void kc_ctx_chain_after(kc_ctx* c, kc_ctx* prev) {
 kc_status kc_zstd_encode_streams_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off, uint32_t n_units,
                                      uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off) {
     if (!c || !o) return KC_ERR_BAD_ARG;
-    if (o->dict != nullptr || o->dict_id != 0) {
-        c->err = "streaming with a dictionary is not served by the device path (the reference's sync and async block paths disagree on the dictionary literal table)";
-        return KC_ERR_UNSUPPORTED;
-    }
     c->stream_mode = 1;
     const kc_status s = kc_zstd_encode_units_dev(c, o, d_src, unit_off, n_units, d_dst, dst_cap, out_off);
     c->stream_mode = 0;
@@ -1589,10 +1593,6 @@ kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* 
 kc_status kc_zstd_encode_streams(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units,
                                  uint8_t* dst, uint64_t dst_cap, uint64_t* out_off) {
     if (!c || !o) return KC_ERR_BAD_ARG;
-    if (o->dict != nullptr || o->dict_id != 0) {
-        c->err = "streaming with a dictionary is not served by the device path";
-        return KC_ERR_UNSUPPORTED;
-    }
     c->stream_mode = 1;
     const kc_status s = kc_zstd_encode_units(c, o, src, unit_off, n_units, dst, dst_cap, out_off);
     c->stream_mode = 0;

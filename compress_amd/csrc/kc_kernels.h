@@ -90,6 +90,8 @@ struct KcEntropyParams {
     int32_t dict_huf_len, dict_huf_log;
     int32_t stream_mode;       // streaming frame layout for units >= one block (zstd/encoder.go:257-428): no content size, no single
                                // segment, last flag only on a short final block, else an empty raw last block
+    int32_t stream_sync;       // WithEncoderConcurrency(1): the synchronous nextBlock form (zstd/encoder.go:364-391) resets the block
+                               // before its first Encode too, so a stream frame never sees the dictionary literal table
     KcRawDef* rawdef;       // device or null: per block (global index), where a RAW block's payload goes in the frame and where it comes
                             // from in the unit: the entropy kernel then writes the 3-byte header only and kc_compact_kernel copies
                             // the payload once, from the source (instead of source -> staging slot -> output)

@@ -475,7 +475,9 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             if (m.flags & KC_BF_POP_A) litsOnly = true;  // saved < 16: popOffsets + encodeLits(org, rawAllLits)
         }
         // encodeLits (blockenc.go:337-352): extremely small blocks and rawAllLits go out as raw blocks
-        const bool dictLit = b == 0 && P.dict_huf != nullptr;  // blk.dictLitEnc: first block only (reset clears it, blockenc.go:97)
+        // blk.dictLitEnc: first block only (reset clears it, blockenc.go:97); in a stream frame written by the synchronous nextBlock
+        // form not even that one (blk.reset(nil) before the first Encode, encoder.go:371)
+        const bool dictLit = b == 0 && P.dict_huf != nullptr && !(streamU && P.stream_sync);
         if (litsOnly && (rawAllLits || size < (dictLit ? 8 : 32))) {
             if (tid == 0) put_block_header(bout, last, 0u, (uint32_t)size);
             raw_payload();

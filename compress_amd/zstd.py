@@ -109,13 +109,15 @@ def WithMatchPath(path):
 
 
 def WithEncoderConcurrency(n):
-    """zstd.WithEncoderConcurrency.  The device path is batch-parallel; the only bytes that depend on it are those of
-    WithConcurrentBlocks, which the reference switches off when the concurrency is 1 (zstd/encoder.go:81)."""
+    """zstd.WithEncoderConcurrency (zstd/encoder_options.go:76-87).  The device path is batch-parallel; the bytes that depend on
+    it are those of WithConcurrentBlocks, which the reference switches off when the concurrency is 1 (zstd/encoder.go:81), and
+    those of dictionary streams: with 1 the reference's synchronous nextBlock form drops the dictionary's literal table before
+    the first block (zstd/encoder.go:371)."""
     if n <= 0:
         raise ValueError("concurrency must be at least 1")
 
     def apply(o):
-        pass
+        o.concurrent = int(n)
     apply._kc_concurrency = int(n)
     return apply
 
@@ -138,7 +140,7 @@ def WithLowerEncoderMem(b):
 class Encoder:
     """zstd.Encoder: EncodeAll and its batched forms, plus the streaming surface Write / ReadFrom / Flush / Close / Reset
     (zstd/encoder.go:140-649).  A stream is buffered on the host and encoded on Close as ONE device unit whose bytes equal the
-    reference's for the same Write / Flush sequence; streams of more than 1 GiB and dictionaries are not served
+    reference's for the same Write / Flush sequence, dictionaries included; streams of more than 1 GiB are not served
     (the caller falls back to the reference).  EncodeStreams / EncodeStreamsDevice batch many streams per launch."""
 
     def __init__(self, *opts, device=0, stream=None, w=None, path=None):
@@ -162,6 +164,7 @@ class Encoder:
                 continue
             if hasattr(op, "_kc_concurrency"):
                 self._concurrency = op._kc_concurrency
+                op(self.o)
                 continue
             op(self.o)
         self._device, self._stream = device, stream

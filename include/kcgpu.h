@@ -69,6 +69,10 @@ typedef struct {
     int32_t dict_huf_log;         /* dict.litEnc.prevTableLog */
     uint16_t dict_huf_val[256];   /* cTableEntry.val  (huff0/decompress.go:142-165) */
     uint8_t dict_huf_nbits[256];  /* cTableEntry.nBits */
+    int32_t concurrent;           /* o.concurrent (WithEncoderConcurrency); 0 = the default (> 1).  Only "1 or not" changes bytes, and
+                                   * only of dictionary streams: with 1 the reference takes nextBlock's synchronous form
+                                   * (zstd/encoder.go:364-391), whose blk.reset(nil) drops the dictionary's literal table before the
+                                   * first block; otherwise the first block starts from it (kc_zstd_encode_streams*) */
 } kc_zstd_opts;
 
 /* encoderOptions.setDefault, zstd/encoder_options.go:36-48 */
@@ -83,6 +87,8 @@ int kc_zstd_opts_zero_frames(kc_zstd_opts* o, int b);
 int kc_zstd_opts_no_entropy(kc_zstd_opts* o, int b);
 int kc_zstd_opts_all_lit_entropy(kc_zstd_opts* o, int b);
 int kc_zstd_opts_single_segment(kc_zstd_opts* o, int b);
+/* WithEncoderConcurrency, zstd/encoder_options.go:76-87 (n < 1: error) */
+int kc_zstd_opts_concurrency(kc_zstd_opts* o, int n);
 /* WithEncoderDictRaw, zstd/encoder_options.go:398-406 */
 int kc_zstd_opts_dict_raw(kc_zstd_opts* o, uint32_t id, const uint8_t* content, uint64_t len);
 /* WithEncoderDict, zstd/encoder_options.go:382-391: a dictionary in the "zstd --train" format.  Parses it like loadDict

@@ -38,6 +38,8 @@ typedef struct {
     const uint8_t* dict;      // dict content
     uint64_t dict_len;
     int32_t dict_full;        // 1: dict/dict_len is a full-format dictionary blob (WithEncoderDict -> loadDict)
+    int32_t concurrent;       // o.concurrent (WithEncoderConcurrency); 0 = the default (GOMAXPROCS > 1).  Only "1 or not" changes bytes,
+                              // and only of dictionary streams (encodeStream)
 } kco_zstd_opts;
 
 }  // extern "C"
@@ -169,14 +171,19 @@ struct OracleEncoder {
         return 0;
     }
 
-    // Streaming use of the encoder (zstd/encoder.go: Write :154-253 -> nextBlock :257-428 -> Close :567-649), synchronous
-    // form.  `cuts` lists the input positions at which Flush was called (ascending, may be empty); full blocks are cut every
-    // blockSize bytes after the last cut, as writeBlocks does.  The asynchronous form (concurrent > 1) differs only in which
-    // stale repeat offsets a block starts with, and no matcher reads them before it has found three sequences of its own
-    // (`canRepeat := len(blk.sequences) > 2`), so both forms give these bytes.  Dictionaries are not served here: the two
-    // forms disagree on whether the dictionary's literal table reaches the first block (blk.reset(nil) at :371 clears it).
+    // Streaming use of the encoder (zstd/encoder.go: Write :154-253 -> nextBlock :257-428 -> Close :567-649).  `cuts` lists the
+    // input positions at which Flush was called (ascending, may be empty); full blocks are cut every blockSize bytes after the
+    // last cut, as writeBlocks does.  nextBlock has a synchronous form (o.concurrent == 1, :364-391) and an asynchronous one
+    // (:393-428, two blockEnc objects that swap their entropy coders).  Without a dictionary they differ only in which stale repeat
+    // offsets a block starts with, and no matcher reads them before it has found three sequences of its own
+    // (`canRepeat := len(blk.sequences) > 2`), so both forms give the same bytes.  With a dictionary they differ in one more
+    // thing: the synchronous form calls blk.reset(nil) before the FIRST Encode too (:371), which clears blk.dictLitEnc
+    // (blockenc.go:97), so the dictionary's literal table never reaches a block; the asynchronous form takes enc.Block() as
+    // Reset left it (enc_base.go:196), and the first block's literals start from the dictionary table like EncodeAll's
+    // (blockenc.go:518-522; swapEncoders :103-106 exchanges litEnc, not dictLitEnc).  o.concurrent selects the form.
     int encodeStream(const uint8_t* src, size_t n, const uint64_t* cuts, size_t n_cuts, Bytes* dst) {
-        if (hasDict) return -1;
+        const DictO* d = hasDict ? &dict : nullptr;
+        const bool syncForm = o.concurrent == 1;
         // block boundaries
         std::vector<size_t> ends;
         {
@@ -204,14 +211,14 @@ struct OracleEncoder {
                 return encodeAll(src, n, dst);  // :272-288 single block: a complete EncodeAll frame
             }
         }
-        enc->Reset(nullptr, false);
-        frameHeaderAppend(dst, 0, (uint32_t)enc->WindowSize(0), false, o.crc != 0, 0);  // :290-297
+        enc->Reset(d, false);  // Encoder.Reset, encoder.go:138
+        frameHeaderAppend(dst, 0, (uint32_t)enc->WindowSize(0), false, o.crc != 0, d ? d->id : 0);  // :290-297
         BlockEnc* blk = &enc->blk;
         size_t pos = 0;
         for (size_t bi = 0; bi < ends.size(); bi++) {
             const size_t todo = ends[bi] - pos;
             if (o.crc) enc->crc.Write(src + pos, todo);
-            blk->reset(nullptr);
+            if (bi > 0 || syncForm) blk->reset(nullptr);  // asynchronous form: the first block is enc.Block() as Reset left it
             enc->Encode(blk, src + pos, todo);
             blk->last = (bi + 1 == ends.size()) && tailBuffered;
             if (blk->encode(src + pos, todo, o.no_entropy != 0, !o.all_lit_entropy) != 0) return -1;

@@ -291,6 +291,9 @@ func New(device int, opts ...Option) (*Encoder, error) {
 		return nil, err
 	}
 	e.cpu = cpu
+	// o.concurrent: 1 selects the synchronous nextBlock form, which writes other first blocks for dictionary streams
+	// (zstd/encoder.go:364-391); the default is GOMAXPROCS like the reference's (encoder_options.go:40)
+	C.kc_zstd_opts_concurrency(&e.opts, C.int(e.conc))
 	e.pool = make(chan *C.kc_ctx, e.conc)
 	return e, nil
 }

@@ -138,6 +138,73 @@ func TestBitExactStreams(t *testing.T) {
 	}
 }
 
+// TestBitExactDictStreams: streams of an encoder with a dictionary, in both of nextBlock's forms: WithEncoderConcurrency(1) (the
+// synchronous form resets the block before the first Encode, so the dictionary's literal table is never used) and
+// WithEncoderConcurrency(4) (the first block starts from it).  The device path follows the option.
+func TestBitExactDictStreams(t *testing.T) {
+	data, err := kcgpu.CorpusFill('T', kcgpu.SeedT, 0, 16, 128<<10)
+	if err != nil {
+		t.Fatal(err)
+	}
+	raw, _ := kcgpu.CorpusFill('T', kcgpu.SeedD, 0, 1, 64<<10)
+	full, ferr := os.ReadFile("../../../tests/golden/dict/d0.dict")
+	for _, lvl := range levels {
+		for _, conc := range []int{1, 4} {
+			for which := 0; which < 2; which++ {
+				var gopt Option
+				var ropt zstd.EOption
+				if which == 0 {
+					gopt, ropt = WithEncoderDictRaw(9, raw), zstd.WithEncoderDictRaw(9, raw)
+				} else {
+					if ferr != nil {
+						continue
+					}
+					gopt, ropt = WithEncoderDict(full), zstd.WithEncoderDict(full)
+				}
+				gpu, err := New(0, WithDeviceMinBytes(0), WithEncoderLevel(lvl), WithEncoderConcurrency(conc), gopt)
+				if err != nil {
+					t.Fatal(err)
+				}
+				ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(lvl), zstd.WithEncoderConcurrency(conc), ropt)
+				off := cut(data, 250003)
+				flushAt := make([][]uint64, len(off)-1)
+				for i := range flushAt {
+					if i%2 == 1 {
+						flushAt[i] = []uint64{uint64(100 * (i + 1)), 70000}
+					}
+				}
+				out, outOff, err := gpu.EncodeStreamsCuts(data, off, flushAt, nil)
+				if err != nil {
+					t.Fatal(err)
+				}
+				for i := 0; i+1 < len(off); i++ {
+					var sink bytes.Buffer
+					ref.Reset(&sink)
+					unit := data[off[i]:off[i+1]]
+					pos := uint64(0)
+					for _, c := range flushAt[i] {
+						if c > uint64(len(unit)) {
+							c = uint64(len(unit))
+						}
+						if c > pos {
+							ref.Write(unit[pos:c])
+							pos = c
+						}
+						ref.Flush()
+					}
+					ref.Write(unit[pos:])
+					ref.Close()
+					if !bytes.Equal(out[outOff[i]:outOff[i+1]], sink.Bytes()) {
+						t.Fatalf("dictionary stream %d level %v concurrency %d dict %d differs from the reference's", i, lvl, conc, which)
+					}
+				}
+				gpu.Close()
+				ref.Close()
+			}
+		}
+	}
+}
+
 // TestBitExactStreamsFlush: EncodeStreamsCuts == NewWriter(w); Write ...; Flush at the given positions; Close() per unit —
 // flushes inside the first block (the header is written early: no EncodeAll frame), on block boundaries (no-ops), at the very
 // end (empty last block), repeated, and streams of more than 32 blocks.

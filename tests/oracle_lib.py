@@ -16,7 +16,7 @@ class ZstdOpts(C.Structure):
         ("level", C.c_int32), ("window_size", C.c_int32), ("block_size", C.c_int32), ("crc", C.c_int32),
         ("single", C.c_int32), ("full_zero", C.c_int32), ("no_entropy", C.c_int32), ("all_lit_entropy", C.c_int32),
         ("low_mem", C.c_int32), ("dict_id", C.c_uint32), ("dict", C.c_char_p), ("dict_len", C.c_uint64),
-        ("dict_full", C.c_int32),
+        ("dict_full", C.c_int32), ("concurrent", C.c_int32),
     ]
 
 
@@ -91,7 +91,7 @@ def lib():
 
 
 def make_opts(level=2, window_size=None, block_size=None, crc=True, single=None, full_zero=True,
-              no_entropy=False, all_lit_entropy=None, low_mem=False, dict_id=0, dict_content=None, dict_blob=None):
+              no_entropy=False, all_lit_entropy=None, low_mem=False, dict_id=0, dict_content=None, dict_blob=None, concurrent=0):
     """Resolved options.  Defaults follow encoderOptions.setDefault + WithEncoderLevel
     (zstd/encoder_options.go:36-48,236-266)."""
     if window_size is None:
@@ -106,6 +106,7 @@ def make_opts(level=2, window_size=None, block_size=None, crc=True, single=None,
     o.single = -1 if single is None else int(single)
     o.full_zero, o.no_entropy, o.all_lit_entropy, o.low_mem = int(full_zero), int(no_entropy), int(all_lit_entropy), int(low_mem)
     o.dict_id = dict_id
+    o.concurrent = int(concurrent)  # WithEncoderConcurrency: 1 = the synchronous nextBlock form (dictionary streams differ)
     o._keep = dict_content
     o.dict = dict_content
     o.dict_len = len(dict_content) if dict_content else 0

@@ -315,8 +315,6 @@ def test_streams_bit_exact(oracle, kclib, level):
     assert sink2.getvalue() == ref.encode_all(t[:1000])
     with pytest.raises(IOError):
         w.Write(b"x")
-    with pytest.raises(Exception):  # dictionaries: the caller must fall back
-        zstd.NewWriter(None, *_lo(level), zstd.WithEncoderDictRaw(1, t[:1000])).EncodeStreams(ubuf, off)
     enc.Close(); e2.Close()
 
 
@@ -368,6 +366,84 @@ def test_streams_with_flush_points_bit_exact(oracle, kclib, level):
     w.Close()
     assert sink.getvalue() == ref.encode_stream(t[:3 * bs], [70000, 70010, 2 * bs + 30])
     enc.Close()
+
+
+def _dict_stream_cases(bs, kind):
+    """(dictionary option kwargs for the oracle, dictionary bytes for the decoders, streams with their Flush points)."""
+    import random
+    import test_oracle_kats as tk
+    t = corpora.corpus("T", 6, 131072, first_unit=21).tobytes()
+    if kind == "raw":
+        dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
+        okw, extra = dict(dict_id=7, dict_content=dct), [dct[100:40000], dct]
+    else:
+        blob, ins = tk._dict_fixture(oracle_mod())
+        extra = [ins[1], ins[2] + ins[4], ins[3][:50000]]
+        if kind == "skewed":  # a literal table huff0 actually keeps: the two nextBlock forms then write different first blocks
+            blob, probs = tk.skewed_dict(blob)
+            extra += tk.skewed_units(probs, sizes=(40, 300, 1000, 4000, 70000), seeds=2)
+        dct, okw = blob, dict(dict_blob=blob)
+    cases = [(u, []) for u in extra] + [(u, [len(u) // 3]) for u in extra if len(u) > 30]
+    cases += [(t[:bs], []), (t[:bs - 1], []), (t[:bs + 1], []), (t[:3 * bs + 77], []), (t[:1000], [10, 500]), (t[:2 * bs + 9], [bs - 1, bs + 1]),
+              (t[:2 * bs], [2 * bs]), (b"", []), (b"", [0]), (t[:20000], [20000])]
+    rnd = random.Random(99)
+    for _ in range(10):
+        n = rnd.choice([rnd.randrange(1, 3000), rnd.randrange(bs - 2000, bs + 2000), rnd.randrange(2 * bs, 4 * bs)])
+        cases.append((t[5:5 + n], sorted(rnd.randrange(0, n + 2) for _ in range(rnd.choice([1, 2, 4])))))
+    return okw, dct, cases
+
+
+def oracle_mod():
+    import oracle_lib
+    return oracle_lib
+
+
+@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("kind", ["raw", "d0", "skewed"])
+def test_dictionary_streams_bit_exact(oracle, kclib, level, kind):
+    """N2: Write / Flush / Close streams of an encoder with a dictionary (zstd/encoder.go:257-428 after Reset(dict)): the frame
+    carries the dictionary id, the first block's history is the dictionary content, and — which of nextBlock's two forms wrote
+    it decides — the first block's literals start from the dictionary table (default, asynchronous form) or never see it
+    (WithEncoderConcurrency(1), synchronous form).  Both against the oracle's restatement, with Flush points."""
+    _torch()
+    import io
+    from compress_amd import zstd
+    bs = zstd.NewWriter(None, *_lo(level)).o.block_size
+    okw, dct, cases = _dict_stream_cases(bs, kind)
+    dopt = zstd.WithEncoderDictRaw(7, dct) if kind == "raw" else zstd.WithEncoderDict(dct)
+    ubuf, off = corpora.pack_units([c[0] for c in cases])
+    frames = {}
+    for conc in (None, 1, 4):
+        enc = zstd.NewWriter(None, *_lo(level), dopt, *([zstd.WithEncoderConcurrency(conc)] if conc else []))
+        out, out_off = enc.EncodeStreams(ubuf, off, flush_at=[c[1] for c in cases])
+        ref = oracle.ZstdOracle(level=_li(level), concurrent=conc or 0, **okw)
+        for i, (u, cuts) in enumerate(cases):
+            got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+            assert got == ref.encode_stream(u, cuts), (conc, i, len(u), cuts)
+        frames[conc] = out.tobytes()
+        if conc is None:  # the plain entry point (no cut list) is the same thing
+            p_out, p_off = enc.EncodeStreams(ubuf, off)
+            for i, (u, _c) in enumerate(cases):
+                assert p_out[int(p_off[i]):int(p_off[i + 1])].tobytes() == ref.encode_stream(u), (i, len(u))
+            for i in (0, 3, len(cases) - 1):
+                u = cases[i][0]
+                got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+                if u and kind == "raw":
+                    assert oracle.zstd_decode(got, len(u) + 16, dict_content=dct) == u
+                elif u:
+                    assert oracle.zstd_decompress(got, len(u) + 16, dict_content=dct) == u
+        enc.Close()
+    assert frames[None] == frames[4]
+    if kind == "skewed":
+        assert frames[None] != frames[1]  # the dictionary literal table reached some first block
+    else:
+        assert kind != "raw" or frames[None] == frames[1]  # no literal table in a raw-content dictionary
+    # the io.Writer face
+    t = cases[-1][0] + cases[0][0]
+    sink = io.BytesIO()
+    w = zstd.NewWriter(sink, *_lo(level), dopt)
+    w.Write(t[:700]); w.Flush(); w.Write(t[700:]); w.Close()
+    assert sink.getvalue() == oracle.ZstdOracle(level=_li(level), **okw).encode_stream(t, [700])
 
 
 @pytest.mark.parametrize("level", LEVELS)
