@@ -97,6 +97,7 @@ struct KcCfg {
     int64_t k2_prof = 0;
     int64_t hook_wait_us = 0, hook_batch = 256;
     int64_t test_feed_redo = 0;           // diagnostics: force the chunk-fed path's re-encode fallback
+    int64_t best_slots = 1024;            // SpeedBestCompression: table slots (34 MiB each) = units encoded at a time
 };
 
 struct kc_ctx {
@@ -110,6 +111,8 @@ struct kc_ctx {
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
         predef, errflag, tmp_src, tmp_dst, tables, prof, work, work_off, dictbuf, proto, dicthuf;
     bool predef_ready = false;
+    DevBuf best_tables, best_cur, best_cost;  // SpeedBestCompression: persistent table slots, their position-space counters, the bit costs
+    uint32_t best_n = 0;                      // slots allocated (and zeroed) so far
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [6]: batch prepared (chunk-fed launches wait on it); [7]: tables prepared
     kc_timings last = {0, 0, 0, 0, 0, 0};
     size_t max_batch_bytes = (size_t)8 << 30;  // input bytes per device batch (scratch is ~6x this for full-size units)
@@ -336,6 +339,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_S2_HOOK_BATCH: g.hook_batch = v < 1 ? 1 : v; break;
         case KC_OPT_TEST_FEED_REDO: g.test_feed_redo = v; break;
         case KC_OPT_MAX_SCRATCH_MIB: if (v < 1) return KC_ERR_BAD_ARG; c->max_scratch_bytes = (uint64_t)v << 20; break;
+        case KC_OPT_BEST_SLOTS: if (v < 1 || v > 8192) return KC_ERR_BAD_ARG; g.best_slots = v; break;
         default: return KC_ERR_BAD_ARG;
     }
     return KC_OK;
@@ -363,6 +367,7 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_S2_HOOK_BATCH: return g.hook_batch;
         case KC_OPT_TEST_FEED_REDO: return g.test_feed_redo;
         case KC_OPT_MAX_SCRATCH_MIB: return (int64_t)(c->max_scratch_bytes >> 20);
+        case KC_OPT_BEST_SLOTS: return g.best_slots;
         case KC_OPT_LAST_PATH: return c->last_path;
         case KC_OPT_LAST_BATCHES: return c->last_batches;
         default: return -1;
@@ -374,7 +379,8 @@ void kc_ctx_destroy(kc_ctx* c) {
     if (c->job_active && c->job.joinable()) c->job.join();
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
-                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->redo_blk, &c->pop_blk, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf};
+                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->redo_blk, &c->pop_blk, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf,
+                      &c->d_job_hist, &c->d_job_flags, &c->rawdef, &c->best_tables, &c->best_cur, &c->best_cost};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
@@ -473,7 +479,7 @@ void build_dfast_dict_long(const uint8_t* dict, size_t len, int pos_bits, uint32
 }
 
 kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
-    if (o->level < KC_SPEED_FASTEST || o->level > KC_SPEED_BETTER) { c->err = "device path implements SpeedFastest, SpeedDefault and SpeedBetterCompression"; return KC_ERR_UNSUPPORTED; }
+    if (o->level < KC_SPEED_FASTEST || o->level > KC_SPEED_BEST) { c->err = "unknown encoder level"; return KC_ERR_UNSUPPORTED; }
     if (o->dict_len > ((uint64_t)1 << 20)) { c->err = "dictionary larger than 1 MiB not served by the device path"; return KC_ERR_UNSUPPORTED; }
     if (o->block_size < 1024 || o->block_size > kMaxCompressedBlockSize || o->window_size < kMinWindowSize) { c->err = "bad block/window size"; return KC_ERR_BAD_ARG; }
     return KC_OK;
@@ -483,6 +489,7 @@ kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
 // Match finders: sub-wave groups (8 lanes per unit), per-unit hash tables in an HBM arena that is zeroed (or primed from the
 // dictionary tables) before every launch.
 size_t match_table_bytes(int level) {
+    if (level == KC_SPEED_BEST) return 0;  // persistent slots (ensure_best_slots), not per unit
     return level == KC_SPEED_BETTER ? kc_zbetter_table_bytes() : (level == KC_SPEED_DEFAULT ? kc_zdfast_table_bytes() : kc_zfast_table_bytes());
 }
 
@@ -503,7 +510,53 @@ bool zfast_lds_needs_hbm(const kc_ctx* c, const KcMatchParams& mp) {
 }
 
 // per-unit tables of n_launch units: zeroed, or primed from the dictionary tables
+// SpeedBestCompression: min(n_launch, KC_OPT_BEST_SLOTS) persistent table slots, zeroed when allocated; a unit starts from whatever
+// the slot's earlier units left, past which its position space has moved (kc_zstd_match_best.hip)
+kc_status ensure_best_slots(kc_ctx* c, uint32_t n_launch, hipStream_t st) {
+    uint32_t want = (uint32_t)std::min<int64_t>((int64_t)n_launch, c->cfg.best_slots);
+    if (want < 1) want = 1;
+    if (!c->best_cost.p) {
+        kc_status s = ensure(c, c->best_cost, 96 * 4);
+        if (s != KC_OK) return s;
+        kc_launch_zbest_cost(c->predef.p, (int32_t*)c->best_cost.p, st);  // (batch_begin has built the predefined tables on this stream)
+    }
+    if (want <= c->best_n) return KC_OK;
+    // grow in powers of two so that a sequence of growing batches re-allocates a few times at most
+    uint32_t n = 1;
+    while (n < want) n <<= 1;
+    if ((int64_t)n > c->cfg.best_slots) n = (uint32_t)c->cfg.best_slots;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        const uint64_t room = (uint64_t)((double)(fr + c->best_tables.cap) * 0.8) / kc_zbest_table_bytes();
+        if (room < 1) { c->err = "device memory exhausted: no room for one SpeedBestCompression table slot (34 MiB)"; return KC_ERR_UNSUPPORTED; }
+        if ((uint64_t)n > room) n = (uint32_t)room;
+    } else (void)hipGetLastError();
+    if (n <= c->best_n) return KC_OK;
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (c->best_tables.p) HIPCHK(c, hipFree(c->best_tables.p));
+    c->best_tables.p = nullptr;
+    c->best_tables.cap = 0;
+    c->best_n = 0;
+    {   // exactly n slots (ensure() rounds up by an eighth: 4 GiB at 1024 slots)
+        const hipError_t e = hipMalloc(&c->best_tables.p, (size_t)n * kc_zbest_table_bytes());
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            c->best_tables.p = nullptr;
+            c->err = "device memory exhausted (" + std::to_string(((size_t)n * kc_zbest_table_bytes()) >> 20) + " MiB of SpeedBestCompression tables wanted)";
+            return KC_ERR_UNSUPPORTED;
+        }
+        c->best_tables.cap = (size_t)n * kc_zbest_table_bytes();
+    }
+    kc_status s;
+    if ((s = ensure(c, c->best_cur, (size_t)8192 * 4)) != KC_OK) return s;
+    HIPCHK(c, hipMemsetAsync(c->best_tables.p, 0, (size_t)n * kc_zbest_table_bytes(), st));
+    HIPCHK(c, hipMemsetAsync(c->best_cur.p, 0, (size_t)8192 * 4, st));
+    c->best_n = n;
+    return KC_OK;
+}
+
 kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, hipStream_t st, int level) {
+    if (level == KC_SPEED_BEST) return ensure_best_slots(c, n_launch, st);
     if (zfast_use_lds(c, mp, n_launch, level) && !zfast_lds_needs_hbm(c, mp) && c->job_tables == nullptr) return KC_OK;  // the tables live in LDS
     const size_t tb = match_table_bytes(level);
     if (c->job_tables != nullptr && mp.unit_list == nullptr) {  // jobs: every unit's table was primed from its own prefix on the host
@@ -543,6 +596,10 @@ void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uin
         return;
     }
     c->last_path = KC_PATH_HBM;
+    if (level == KC_SPEED_BEST) {
+        kc_launch_zbest_match(mp, (uint64_t*)c->best_tables.p, (uint32_t*)c->best_cur.p, (const int32_t*)c->best_cost.p, n_launch, c->best_n, st);
+        return;
+    }
     uint8_t* tab = (uint8_t*)c->tables.p + (size_t)slot0 * match_table_bytes(level);
     if (level == KC_SPEED_BETTER) kc_launch_zbetter_match_grp(mp, tab, n_launch, mp.hist0 > 0, st);
     else if (level == KC_SPEED_DEFAULT) kc_launch_zdfast_match_grp(mp, (uint32_t*)tab, n_launch, st);
@@ -678,7 +735,8 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
                                (uint32_t)hist0, (uint8_t*)c->work.p, n_units, st);
         // pristine dictionary tables (betterFastEncoderDict.Reset, enc_better.go:1114-1183) in the device entry format
         std::vector<uint8_t> proto(kc_zbetter_table_bytes(), 0);
-        if (o->level == KC_SPEED_BETTER) build_better_dict_tables(o->dict, (size_t)hist0, pos_bits, proto.data());
+        if (o->level == KC_SPEED_BEST) { /* the kernel indexes the dictionary itself, per unit (bestFastEncoder.Reset) */ }
+        else if (o->level == KC_SPEED_BETTER) build_better_dict_tables(o->dict, (size_t)hist0, pos_bits, proto.data());
         else if (o->level == KC_SPEED_DEFAULT) {
             build_dfast_dict_long(o->dict, (size_t)hist0, pos_bits, (uint32_t*)proto.data());
             build_fast_dict_table(o->dict, (size_t)hist0, pos_bits, (uint32_t*)(proto.data() + ((size_t)4 << 17)));
@@ -706,7 +764,8 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     mp.stream_mode = c->stream_mode;
     mp.rep1 = (int32_t)o->dict_offsets[0];
     mp.rep2 = (int32_t)o->dict_offsets[1];
-    if (mp.rep1 <= 0 || mp.rep2 <= 0) { mp.rep1 = 1; mp.rep2 = 4; }  // opts not initialised through kc_zstd_opts_default
+    mp.rep3 = (int32_t)o->dict_offsets[2];
+    if (mp.rep1 <= 0 || mp.rep2 <= 0 || mp.rep3 <= 0) { mp.rep1 = 1; mp.rep2 = 4; mp.rep3 = 8; }  // opts not initialised through kc_zstd_opts_default
     mp.unit_blk0 = (const uint32_t*)c->unit_blk0.p;
     mp.seqs = (uint64_t*)c->seqs.p;
     mp.meta = (KcBlkMeta*)c->meta.p;
@@ -963,7 +1022,7 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
 // "~6x input" of full-size units (1M x 4 KiB units at SpeedDefault would ask for hundreds of GiB in one batch).
 uint64_t zstd_unit_scratch(const kc_zstd_opts* o, uint64_t len, uint64_t n_cuts = 0) {
     const uint64_t bsz = (uint64_t)o->block_size;
-    const uint64_t table_b = o->level == KC_SPEED_BETTER ? kc_zbetter_table_bytes() : (o->level == KC_SPEED_DEFAULT ? kc_zdfast_table_bytes() : kc_zfast_table_bytes());
+    const uint64_t table_b = o->level == KC_SPEED_BEST ? 0 : o->level == KC_SPEED_BETTER ? kc_zbetter_table_bytes() : (o->level == KC_SPEED_DEFAULT ? kc_zdfast_table_bytes() : kc_zfast_table_bytes());
     const uint64_t per_block = 2 * (bsz / 4 + 8) * 8 + (bsz + 64) + sizeof(KcBlkMeta);
     const uint64_t hist0 = (o->dict != nullptr) ? o->dict_len : 0;
     const uint64_t blocks = (len + bsz - 1) / bsz + n_cuts;  // every Flush point can add a block, at the full per-block strides
@@ -1737,7 +1796,7 @@ int64_t kc_zstd_job_size(const kc_zstd_opts* o) {  // encoderOptions.jobSize, en
 }
 int64_t kc_zstd_overlap_size(const kc_zstd_opts* o) {  // encoderOptions.overlapSize, encoder_options.go:362-371
     if (!o) return -1;
-    return o->level == KC_SPEED_BETTER ? o->window_size / 4 : o->window_size / 8;
+    return o->level == KC_SPEED_BEST ? o->window_size / 2 : (o->level == KC_SPEED_BETTER ? o->window_size / 4 : o->window_size / 8);
 }
 
 kc_status kc_zstd_encode_jobs(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, uint64_t len, const uint64_t* cuts, uint64_t n_cuts,
@@ -1812,7 +1871,7 @@ kc_status kc_zstd_encode_jobs(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* s
         for (int t = 0; t < T; t++)
             th.emplace_back([&] {
                 for (uint32_t k = next++; k < nj; k = next++)
-                    if (jhist[k]) build_prefix_tables(o->level, src + lo[k] - jhist[k], jhist[k], pos_bits, tabs.data() + (size_t)k * tb);
+                    if (jhist[k] && tb) build_prefix_tables(o->level, src + lo[k] - jhist[k], jhist[k], pos_bits, tabs.data() + (size_t)k * tb);
             });
         for (auto& x : th) x.join();
     }
@@ -1828,7 +1887,7 @@ kc_status kc_zstd_encode_jobs(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* s
     uint64_t produced = 0;
     c->job_hist = jhist.data();
     c->job_flags = jflags.data();
-    c->job_tables = tabs.data();
+    c->job_tables = tb ? tabs.data() : nullptr;  // (SpeedBestCompression: the kernel indexes each job's prefix itself)
     c->last = kc_timings{0, 0, 0, 0, 0, 0};
     s = run_batch(c, o, (const uint8_t*)c->tmp_src.p, woff.data(), nj, (uint8_t*)c->tmp_dst.p, need, oo.data(), &produced);
     c->job_hist = nullptr;

@@ -26,6 +26,7 @@ struct KcMatchParams {
     int32_t hist0;              // bytes of dictionary content prepended to every unit in `src` (0: no dictionary)
     int32_t pos_bits;           // bits reserved for position+1 in tagged table entries (better level)
     int32_t rep1, rep2;         // initial recentOffsets[0..1]: {1,4} unless a full-format dictionary supplies its own
+    int32_t rep3;               // recentOffsets[2] (SpeedBestCompression only)
     int32_t stream_mode;        // units are Write+Close streams: a unit of >= one block is parsed with Encode (history) from its first block
     const uint32_t* unit_hist;  // device or null: per-unit history bytes in front of the unit in `src` (jobs: the overlap prefix), replaces hist0
     const uint32_t* job_flags;  // device or null: units are the jobs of ONE WithConcurrentBlocks stream (enc_jobs.go): bit 0 = final job
@@ -46,6 +47,13 @@ static inline size_t kc_zdfast_table_bytes() { return ((size_t)4 << 17) + ((size
 // SpeedBetterCompression: long 2^19 x {offset,prev} + short 2^13 x u32 per unit
 void kc_launch_zbetter_match_grp(const KcMatchParams& P, uint8_t* tables, uint32_t n_launch, bool dict, hipStream_t st);
 static inline size_t kc_zbetter_table_bytes() { return ((size_t)8 << 19) + ((size_t)4 << 13); }
+// SpeedBestCompression (kc_zstd_match_best.hip): one wave per unit over n_slots persistent table slots of long 2^22 + short 2^18
+// {offset, prev} pairs (34 MiB each, zeroed once); slot_cur: per slot, where its position space stands (0: fresh); cost: 96 int32
+// built by kc_launch_zbest_cost from the predefined FSE tables
+void kc_launch_zbest_match(const KcMatchParams& P, uint64_t* tables, uint32_t* slot_cur, const int32_t* cost, uint32_t n_launch, uint32_t n_slots,
+                           hipStream_t st);
+void kc_launch_zbest_cost(const void* d_predef, int32_t* d_cost, hipStream_t st);
+static inline size_t kc_zbest_table_bytes() { return ((size_t)8 << 22) + ((size_t)8 << 18); }
 
 // A raw block whose payload the compaction copies straight from the source (KcEntropyParams.rawdef)
 struct KcRawDef {

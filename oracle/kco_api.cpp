@@ -12,6 +12,7 @@
 #include "kco_zstd_better.h"
 #include "kco_s2.h"
 #include "kco_dict.h"
+#include "kco_zstd_best.h"
 #include "kco_zstd_dec.h"
 #include <thread>
 #include <atomic>
@@ -112,6 +113,7 @@ struct OracleEncoder {
         case 1: if (hasDict) enc.reset(new FastEncoderDict()); else enc.reset(new FastEncoder()); break;
         case 2: if (hasDict) enc.reset(new DoubleFastEncoderDict()); else enc.reset(new DoubleFastEncoder()); break;
         case 3: if (hasDict) enc.reset(new BetterFastEncoderDict()); else enc.reset(new BetterFastEncoder()); break;
+        case 4: enc.reset(new BestFastEncoder()); break;
         default: enc.reset(new FastEncoder());
         }
         enc->setup(o.window_size, o.low_mem != 0);
@@ -526,6 +528,24 @@ int64_t kco_zstd_parse_unit(const kco_zstd_opts* opts, const uint8_t* src, uint6
     }
     return (int64_t)nb;
 }
+
+// The per-code bit costs match.estBits reads from the predefined FSE tables (enc_best.go:48-53): cost[0..31] offset codes,
+// cost[32..95] match-length codes.  (For the emulator test of the device kernel, which takes them as an input.)
+void kco_zstd_best_costs(int32_t* cost) {
+    for (int i = 0; i < 96; i++) cost[i] = 0;
+    for (int i = 0; i <= zfse::maxOffsetLengthSymbol; i++) {
+        const zfse::SymbolTransform t = zfse::predef().enc[1].symbolTT[i];
+        cost[i] = (int32_t)t.outBits + (int32_t)(t.deltaNbBits >> 16);
+    }
+    for (int i = 0; i <= zfse::maxMatchLengthSymbol; i++) {
+        const zfse::SymbolTransform t = zfse::predef().enc[2].symbolTT[i];
+        cost[32 + i] = (int32_t)t.outBits + (int32_t)(t.deltaNbBits >> 16);
+    }
+}
+
+// compress.ShannonEntropyBits (compressible.go:68-85)
+int64_t kco_shannon_entropy_bits(const uint8_t* p, uint64_t n) { return (int64_t)ShannonEntropyBits(p, (size_t)n); }
+double kco_go_log2(double x) { return golog::log2(x); }
 
 uint64_t kco_xxh64(const uint8_t* p, uint64_t n) {
     XXH64 h;

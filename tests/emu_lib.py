@@ -106,6 +106,59 @@ def zfast_parse(units, block_size=65536, window=4 << 20, spec_w0=8, stream_mode=
     return out
 
 
+_zbest_state = {}
+
+
+def zbest_parse(units, block_size=131072, window=8 << 20, stream_mode=0, n_slots=2, hist=b"", jobs=False, rep=(1, 4, 8), fresh=False):
+    """kc_zbest_match_kernel (SpeedBestCompression) over `units` (list of bytes), each preceded by the history `hist` (a dictionary's
+    content, or with jobs=True a job's overlap prefix).  The table slots persist between calls like the context's (fresh=True
+    starts from zeroed ones).  Returns, per block in unit order, (seqs [n,3] u32, nlit, extra_lits, flags)."""
+    import oracle_lib
+    n = len(units)
+    h = len(hist)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    blk0 = np.zeros(n + 1, dtype=np.uint32)
+    for i, u in enumerate(units):
+        off[i + 1] = off[i] + h + len(u)
+        blk0[i + 1] = blk0[i] + (len(u) + block_size - 1) // block_size
+    nb = int(blk0[n])
+    src = np.frombuffer(b"".join(hist + u for u in units) + b"\0" * 64, dtype=np.uint8).copy()
+    al = np.zeros(len(src) + 32, dtype=np.uint8)
+    o = (-al.ctypes.data) % 16
+    al[o:o + len(src)] = src
+    base = al.ctypes.data + o
+    stride = block_size // 4 + 8
+    seqs = np.zeros(max(nb, 1) * stride, dtype=np.uint64)
+    meta = np.zeros(max(nb, 1) * 8, dtype=np.uint32)
+    st = _zbest_state
+    if fresh or st.get("n_slots") != n_slots:
+        st["n_slots"] = n_slots
+        st["tables"] = np.zeros(n_slots * ((1 << 22) + (1 << 18)), dtype=np.uint64)
+        st["cur"] = np.zeros(n_slots, dtype=np.uint32)
+        cost = np.zeros(96, dtype=np.int32)
+        oracle_lib.lib().kco_zstd_best_costs(C.c_void_p(cost.ctypes.data))
+        st["cost"] = cost
+    uh = np.full(n, h, dtype=np.uint32)
+    jf = np.zeros(n, dtype=np.uint32)
+    L = lib()
+    L.kcemu_zbest_parse.restype = C.c_int
+    L.kcemu_zbest_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    r = L.kcemu_zbest_parse(base, off.ctypes.data, n, block_size, window, 0 if jobs else h, rep[0], rep[1], rep[2], stream_mode, seqs.ctypes.data,
+                            meta.ctypes.data, stride, blk0.ctypes.data, uh.ctypes.data if jobs else None, jf.ctypes.data if jobs else None,
+                            st["tables"].ctypes.data, st["cur"].ctypes.data, st["cost"].ctypes.data, n_slots)
+    assert r == 0
+    out = []
+    for b in range(nb):
+        m = meta[8 * b:8 * b + 8]
+        ns = int(m[0])
+        v = seqs[b * stride:b * stride + ns]
+        tri = np.stack([(v >> np.uint64(44)).astype(np.uint32), ((v >> np.uint64(24)) & np.uint64(0xFFFFF)).astype(np.uint32),
+                        (v & np.uint64(0xFFFFFF)).astype(np.uint32)], axis=1) if ns else np.zeros((0, 3), dtype=np.uint32)
+        out.append((tri, int(m[1]), int(m[2]), int(m[3])))
+    return out
+
+
 def s2_best_blocks(blocks, snappy=False):
     """kc_s2_best_kernel (s2.EncodeBest / s2.EncodeSnappyBest) over `blocks` (list of bytes) -> list of bytes (uvarint + body)."""
     n = len(blocks)

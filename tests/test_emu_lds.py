@@ -113,3 +113,65 @@ def test_s2_best_kernel_bit_exact(snappy):
     blocks += [u for u in corpora.edge_units() if len(u) <= 70000]
     blocks += [u[:40000] for u in corpora.stress_units(seed=13, n=6)]
     _cmp(blocks, emu_lib.s2_best_blocks(blocks, snappy=snappy), oracle_lib.s2_encode_snappy_best if snappy else oracle_lib.s2_encode_best)
+
+
+def _cmp_parse(units, got, **okw):
+    bi = 0
+    for ui, u in enumerate(units):
+        if len(u) == 0:
+            continue
+        ref = oracle_lib.zstd_parse_unit(u, **okw)
+        for rb, (rseqs, rlits) in enumerate(ref):
+            gseqs, gnlit, gextra, gflags = got[bi]
+            bi += 1
+            k = min(len(gseqs), len(rseqs))
+            neq = np.nonzero((gseqs[:k] != rseqs[:k]).any(axis=1))[0] if k else []
+            assert len(neq) == 0, "unit %d (len %d) block %d first differing seq %d: emulated %r oracle %r" % (ui, len(u), rb, neq[0], gseqs[neq[0]], rseqs[neq[0]])
+            assert len(gseqs) == len(rseqs), "unit %d (len %d) block %d: nseq %d vs oracle %d" % (ui, len(u), rb, len(gseqs), len(rseqs))
+            assert gnlit == len(rlits), "unit %d block %d: nlit %d vs oracle %d" % (ui, rb, gnlit, len(rlits))
+    assert bi == len(got)
+
+
+def _zbest_units():
+    units = [corpora.corpus("T", 1, 131072, first_unit=1).tobytes(), corpora.corpus("M", 1, 131072, first_unit=2).tobytes()[:90000],
+             corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("H", 1, 40000).tobytes()]
+    units += [u for u in corpora.edge_units() if 0 < len(u) < 140000]
+    units += [u[:150000] for u in corpora.stress_units(seed=5, n=6)]   # two blocks with history
+    units += [corpora.corpus("T", 3, 131072, first_unit=77).tobytes()[:300000]]
+    # long repeats: matches beyond goodEnough, repeat-offset forms straight after a match, period-1..7 runs
+    rng = np.random.default_rng(3)
+    pat = bytes(rng.integers(0, 256, 700, dtype=np.uint8))
+    units += [(pat * 40)[:24000], b"abcabcabcabd" * 1500, b"".join(pat[:k] * 9 for k in range(3, 60)), b"x" * 5000 + pat + b"x" * 300 + pat[:100] + b"y" * 40]
+    return units
+
+
+def test_zbest_parse_matches_oracle():
+    """kc_zbest_match_kernel (SpeedBestCompression): the sequence list of every block equals the oracle's bestFastEncoder — the
+    candidates of a phase priced one per lane, improve()'s order-dependent part replayed in the reference's order, the entropy
+    estimate through the restated math.Log2 — on two persistent table slots that many units pass through."""
+    units = _zbest_units()
+    got = emu_lib.zbest_parse(units, n_slots=2, fresh=True)
+    _cmp_parse(units, got, level=4)
+
+
+def test_zbest_parse_history_forms():
+    """The same with history in front of the units: a raw-content dictionary (Reset with a dictionary: every position of it in
+    the long table, the short one filled four positions per step), a full-format dictionary's repeat offsets, a job's overlap
+    prefix (ResetPrefix), stream mode, a small window (matches beyond it refused), and a window so large that the slot is cleared
+    before every unit (the cur wrap-around path)."""
+    t = corpora.corpus("T", 2, 131072, first_unit=11).tobytes()
+    dct = corpora.corpus("T", 1, 20000, seed=0x5EED0005).tobytes()
+    units = [t[:30000], t[100:9000], dct[500:9000] + t[:100], t[:7], t[131072:131072 + 140000]]
+    got = emu_lib.zbest_parse(units, n_slots=1, hist=dct, fresh=True)
+    _cmp_parse(units, got, level=4, dict_id=9, dict_content=dct)
+    for hl in (8, 9, 12, 13, 20):  # the edges of the two index ranges
+        got = emu_lib.zbest_parse(units[:2], n_slots=1, hist=dct[:hl])
+        _cmp_parse(units[:2], got, level=4, dict_id=9, dict_content=dct[:hl])
+    # stream mode (Encode from the first block on) and a small window
+    u2 = [t[:200000], t[:65536]]
+    got = emu_lib.zbest_parse(u2, n_slots=2, window=1 << 15, block_size=1 << 15, stream_mode=1)
+    _cmp_parse(u2, got, level=4, window_size=1 << 15, block_size=1 << 15)
+    # the clear path: window 2^29 -> bufferReset 2^30, reached by the second unit of a slot
+    u3 = [t[:20000], t[20000:50000], t[:20000]]
+    got = emu_lib.zbest_parse(u3, n_slots=1, window=1 << 29, fresh=True)
+    _cmp_parse(u3, got, level=4, window_size=1 << 29)

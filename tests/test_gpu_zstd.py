@@ -16,6 +16,7 @@ def _torch():
 # "1L" = SpeedFastest forced onto the LDS-table match finder (kc_zstd_match_lds.hip), 1 = forced onto the HBM-table one
 # (kc_zstd_match.hip): every parity test of this file runs on both (KC_OPT_MATCH_PATH, not an environment variable).
 LEVELS = [1, "1L", 2, 3]
+LEVELS_B = LEVELS + [4]  # + SpeedBestCompression (one wave per unit: the smaller tests)
 
 
 def _li(level):
@@ -85,13 +86,13 @@ def test_parse_matches_oracle(oracle, kclib, level):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 def test_edge_units_bit_exact(oracle, kclib, level):
     _torch()
     _check_units(oracle, corpora.edge_units(), level)
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 @pytest.mark.parametrize("kind", ["T", "H", "J", "M"])
 def test_corpus_units_bit_exact(oracle, kclib, kind, level):
     _torch()
@@ -100,7 +101,7 @@ def test_corpus_units_bit_exact(oracle, kclib, kind, level):
     _check_units(oracle, units, level)
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 def test_ragged_units_bit_exact(oracle, kclib, level):
     _torch()
     rng = np.random.default_rng(7)
@@ -152,7 +153,7 @@ def test_device_resident_roundtrip_full_size(oracle, kclib, level):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 @pytest.mark.parametrize("dict_id", [0, 1, 70000])
 def test_with_raw_dictionary_bit_exact(oracle, kclib, dict_id, level):
     """C5: 64 KiB raw-content dictionary (WithEncoderDictRaw) at every level, mixed corpus.  Units <= 32 KiB take the
@@ -179,7 +180,7 @@ def test_with_raw_dictionary_bit_exact(oracle, kclib, dict_id, level):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 @pytest.mark.parametrize("which", ["d0", "skewed"])
 def test_with_full_format_dictionary_bit_exact(oracle, kclib, level, which):
     """a16: WithEncoderDict (zstd --train format): dictionary offsets, content as history and the literal Huffman table
@@ -207,7 +208,7 @@ def test_with_full_format_dictionary_bit_exact(oracle, kclib, level, which):
     enc.Close()
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 def test_stress_mixes_bit_exact(oracle, kclib, level):
     """Adversarial literal/sequence mixes (corpora.stress_units): long literal runs across the LDS gather window,
     more cooperative runs than the per-batch list holds, Huffman-only blocks, RLE blocks, multi-block units."""
@@ -274,7 +275,7 @@ def test_begin_end_pipeline_two_contexts(oracle, kclib):
         e.Close()
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 def test_streams_bit_exact(oracle, kclib, level):
     """N2: NewWriter(w).Write(...) / Close() streams (kc_zstd_encode_streams_dev) against the oracle's restatement of
     Write -> nextBlock -> Close: EncodeAll frame below one block, streaming frame (no content size, history from the first
@@ -318,7 +319,7 @@ def test_streams_bit_exact(oracle, kclib, level):
     enc.Close(); e2.Close()
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 def test_streams_with_flush_points_bit_exact(oracle, kclib, level):
     """Mid-stream Flush (zstd/encoder.go:547-570) ends the block being filled: kc_zstd_encode_streams_cuts against the oracle's
     Write / Flush / Close restatement — cuts inside the first block (header written early: no EncodeAll frame), on block boundaries
@@ -398,7 +399,7 @@ def oracle_mod():
     return oracle_lib
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 @pytest.mark.parametrize("kind", ["raw", "d0", "skewed"])
 def test_dictionary_streams_bit_exact(oracle, kclib, level, kind):
     """N2: Write / Flush / Close streams of an encoder with a dictionary (zstd/encoder.go:257-428 after Reset(dict)): the frame
@@ -790,7 +791,7 @@ def test_device_decoder_empty_units_and_tiny_blocks(oracle, kclib):
     enc0.Close()
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 def test_rle_literal_sections_bit_exact(oracle, kclib, level):
     """RLE literal sections (zstd/blockenc.go:554-561: huff0.ErrUseRLE): units whose literals are one repeated byte between
     dictionary matches (corpora.rle_literal_units; tests/test_outcome_coverage.py shows the oracle takes the RLE branch for them).

@@ -15,7 +15,7 @@ def _cases():
     return t, m
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
 def test_oracle_jobs_frames_decode_and_have_the_documented_shape(oracle, level):
     """CPU: the oracle's job-mode frames round-trip through the independent libzstd decoder for every job count, Flush pattern
     and window; the special cases of dispatchJob hold (a one-block stream is the EncodeAll frame, an empty stream the 9-byte...
@@ -72,7 +72,7 @@ def _enc(level, **kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("level", GPU_LEVELS)
+@pytest.mark.parametrize("level", GPU_LEVELS + [4])
 def test_device_jobs_bit_exact_small(oracle, kclib, level):
     """GPU: kc_zstd_encode_jobs == the oracle's job mode for every job count / Flush pattern of the CPU test (small windows: many
     jobs, short prefixes, prefixes shorter than the overlap, empty final jobs)."""

@@ -4,6 +4,7 @@
 #include "../../compress_amd/csrc/kc_s2_lds.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_lds.hip"
 #include "../../compress_amd/csrc/kc_s2_best.hip"
+#include "../../compress_amd/csrc/kc_zstd_match_best.hip"
 
 extern "C" {
 
@@ -67,6 +68,33 @@ int kcemu_s2_best(int level, const uint8_t* src, const uint64_t* blk_off, uint32
     P.n_blocks = n;
     P.level = level;
     kc_launch_s2_best(P, nullptr);
+    return 0;
+}
+
+// n units through kc_zbest_match_kernel (SpeedBestCompression) on n_slots persistent table slots; tables: n_slots x 34 MiB / 8 u64,
+// slot_cur: n_slots u32 (0 = fresh); cost: 96 int32 (the predefined-table bit costs)
+int kcemu_zbest_parse(const uint8_t* src, const uint64_t* unit_off, uint32_t n, int block_size, int window, int hist0, int rep1, int rep2, int rep3,
+                      int stream_mode, uint64_t* seqs, KcBlkMeta* meta, uint32_t seq_stride, const uint32_t* unit_blk0, const uint32_t* unit_hist,
+                      const uint32_t* job_flags, uint64_t* tables, uint32_t* slot_cur, const int32_t* cost, uint32_t n_slots) {
+    KcMatchParams P;
+    memset(&P, 0, sizeof(P));
+    P.src = src;
+    P.src_end = src + unit_off[n];
+    P.unit_off = unit_off;
+    P.unit_blk0 = unit_blk0;
+    P.seqs = seqs;
+    P.meta = meta;
+    P.seq_stride = seq_stride;
+    P.block_size = block_size;
+    P.max_match_off = window;
+    P.hist0 = hist0;
+    P.rep1 = rep1;
+    P.rep2 = rep2;
+    P.rep3 = rep3;
+    P.stream_mode = stream_mode;
+    P.unit_hist = unit_hist;
+    P.job_flags = job_flags;
+    kc_launch_zbest_match(P, tables, slot_cur, cost, n, n_slots, nullptr);
     return 0;
 }
 
