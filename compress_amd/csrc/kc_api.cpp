@@ -516,9 +516,14 @@ kc_status ensure_best_slots(kc_ctx* c, uint32_t n_launch, hipStream_t st) {
     uint32_t want = (uint32_t)std::min<int64_t>((int64_t)n_launch, c->cfg.best_slots);
     if (want < 1) want = 1;
     if (!c->best_cost.p) {
-        kc_status s = ensure(c, c->best_cost, 96 * 4);
+        kc_status s = ensure(c, c->predef, kc_fse_predef_bytes());
         if (s != KC_OK) return s;
-        kc_launch_zbest_cost(c->predef.p, (int32_t*)c->best_cost.p, st);  // (batch_begin has built the predefined tables on this stream)
+        if (!c->predef_ready) {
+            kc_launch_fse_predef_init(c->predef.p, st);
+            c->predef_ready = true;
+        }
+        if ((s = ensure(c, c->best_cost, 96 * 4)) != KC_OK) return s;
+        kc_launch_zbest_cost(c->predef.p, (int32_t*)c->best_cost.p, st);
     }
     if (want <= c->best_n) return KC_OK;
     // grow in powers of two so that a sequence of growing batches re-allocates a few times at most
@@ -1990,6 +1995,7 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
     mp.hist0 = 0;
     mp.rep1 = 1;
     mp.rep2 = 4;
+    mp.rep3 = 8;
     {
         uint64_t maxLen = 16;
         for (uint32_t i = 0; i < n_units; i++) maxLen = std::max<uint64_t>(maxLen, unit_off[i + 1] - unit_off[i]);

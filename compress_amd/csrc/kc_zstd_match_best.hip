@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64) void kc_zbest_match_kernel(KcMatchParams P, uin
             const int o1_in = o1, o2_in = o2;
             uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
             int nseq = 0, sumLL = 0;
-            uint32_t firstLL = 0, firstOf = 0;
+            uint32_t firstLL = 0, firstOf = 0, diag = 0;
             int nextEmit = blkStart, s = blkStart;
             auto emit = [&](int ll, int ml3, uint32_t of) {
                 if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
@@ -251,6 +251,7 @@ __global__ __launch_bounds__(64) void kc_zbest_match_kernel(KcMatchParams P, uin
                 const long long bits = (long long)shsum;
                 int bpb = (int)((bits * 1024) / (long long)srcLen);
                 if (bpb < 1024) bpb = 1024;
+                diag = (uint32_t)bpb;
 
                 const int sLimit = blkEnd - 12;  // inputMargin = 8 + 4
                 // ---- per-lane candidate: everything of improve() that does not depend on the current best ----
@@ -414,9 +415,14 @@ __global__ __launch_bounds__(64) void kc_zbest_match_kernel(KcMatchParams P, uin
                         s = best.s + best.length;
                         nextEmit = s;
                         end = s < sLimit + 4 ? s : sLimit + 4;
-                        if (best.rep == 2 || best.rep == 5) { const int t = o1; o1 = o2; o2 = t; }
-                        else if (best.rep == 3 || best.rep == 6) { const int a1 = o1, a2 = o2; o1 = o3; o2 = a1; o3 = a2; }
-                        else if (best.rep == 7) { const int a1 = o1, a2 = o2; o1 = a1 - 1; o2 = a1; o3 = a2; }
+                        {   // :397-404.  Written as selects: hipcc (ROCm 7.2) left the new offset3 undefined on the rep == 2|4 path of the
+                            // equivalent if / else-if chain (found on the device: offset3 kept a stale register)
+                            const int kind = best.rep == 1 ? 0 : ((best.rep == 2 || best.rep == 5) ? 1 : ((best.rep == 3 || best.rep == 6) ? 2 : 3));
+                            const int a1 = o1, a2 = o2, a3 = o3;
+                            o1 = kind == 0 ? a1 : (kind == 1 ? a2 : (kind == 2 ? a3 : a1 - 1));
+                            o2 = kind == 0 ? a2 : a1;
+                            o3 = kind <= 1 ? a3 : a2;
+                        }
                     } else {
                         o3 = o2; o2 = o1; o1 = s - best.offset;
                         emit(s - nextEmit, best.length - 3, (uint32_t)(s - best.offset) + 3u);
@@ -438,6 +444,7 @@ __global__ __launch_bounds__(64) void kc_zbest_match_kernel(KcMatchParams P, uin
             uint32_t flags = 0;
             if (nseq > 0 && !rle && saved < 16) flags |= KC_BF_POP_A;
             if (P.pop_blk != nullptr && P.pop_blk[blk0 + (uint32_t)b] != 0) flags |= KC_BF_FORCED;
+            flags |= diag << 8;  // (diagnostics, like the other finders' round counts: the block's literal cost estimate)
             // No sequence of a block reads the repeat offsets before the block has three sequences of its own (canRepeat), and
             // three non-repeat sequences replace all three: what a block inherits never reaches its output, so a block re-emitted
             // raw (popOffsets) needs no re-run of its successors — o?_out is reported equal to o?_in.
