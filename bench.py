@@ -42,6 +42,9 @@ CONFIGS = {
                src="kc_s2.hip", what="s2.Encode (default level)"),
     "C5": dict(codec="zstd", level=3, kind="M", unit=128 << 10, gib=1.0, dict_kib=64, kernel="kc_zbetter_match_grp_kernel<true>",
                src="kc_zstd_match_better.hip", what="zstd SpeedBetterCompression EncodeAll, 64 KiB raw dictionary"),
+    # not a BASELINE configuration (and not part of the default run's "also"): the best level, one wave per unit on persistent table slots
+    "B4": dict(codec="zstd", level=4, kind="T", unit=128 << 10, gib=0.5, dict_kib=0, kernel="kc_zbest_match_kernel",
+               src="kc_zstd_match_best.hip", what="zstd SpeedBestCompression EncodeAll"),
 }
 METRIC = "encode MB/s (input) + ratio, zstd SpeedFastest 128KiB blocks, 1/2/4/8 GPU"
 

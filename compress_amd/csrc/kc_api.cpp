@@ -97,7 +97,7 @@ struct KcCfg {
     int64_t k2_prof = 0;
     int64_t hook_wait_us = 0, hook_batch = 256;
     int64_t test_feed_redo = 0;           // diagnostics: force the chunk-fed path's re-encode fallback
-    int64_t best_slots = 1024;            // SpeedBestCompression: table slots (34 MiB each) = units encoded at a time
+    int64_t best_slots = 2048;            // SpeedBestCompression: table slots (34 MiB each) = units encoded at a time
 };
 
 struct kc_ctx {

@@ -16,7 +16,7 @@ import (
 	"github.com/klauspost/compress/zstd"
 )
 
-var levels = []zstd.EncoderLevel{zstd.SpeedFastest, zstd.SpeedDefault, zstd.SpeedBetterCompression}
+var levels = []zstd.EncoderLevel{zstd.SpeedFastest, zstd.SpeedDefault, zstd.SpeedBetterCompression, zstd.SpeedBestCompression}
 
 func cut(data []byte, unit int) []uint64 {
 	var off []uint64
