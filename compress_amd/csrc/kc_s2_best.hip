@@ -148,23 +148,30 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
             if (m.score <= -m.s) m.length = 0;  // no savings: maybe a better one turns up
             return m;
         };
-        auto pick = [&](const SbMatch& mine, int j) -> SbMatch {  // lane j's candidate, wave-uniform
-            SbMatch r;
-            r.offset = (int)rdlane32((uint32_t)mine.offset, j); r.s = (int)rdlane32((uint32_t)mine.s, j);
-            r.length = (int)rdlane32((uint32_t)mine.length, j); r.score = (int)rdlane32((uint32_t)mine.score, j);
-            r.rep = (int)rdlane32((uint32_t)mine.rep, j);
-            return r;
-        };
-        auto best_of = [&](const SbMatch& a, const SbMatch& b) -> SbMatch {
-            if (b.length == 0) return a;
-            if (a.length == 0) return b;
-            const int as = a.score + b.s, bs = b.score + a.s;
-            return as >= bs ? a : b;
-        };
-        // best = bestOf(best, matchAt(candidate j)) with matchAt's shortcut: same offset as the current best -> not retested
-        auto fold = [&](SbMatch& best, SbMatch m) {
-            if (best.length != 0 && best.s - best.offset == m.s - m.offset) m.length = 0;
-            best = best_of(best, m);
+        // best = bestOf(best, matchAt(candidate)) over the candidates held by lanes [lo, hi), in lane order, with matchAt's shortcut
+        // (same offset as the current best: not retested; not applied to the lanes of `nosame`: bestOf(matchAt(cur L), matchAt(prev L))
+        // evaluates both against the empty best of the step's start).  Every remaining lane tests its candidate against the current
+        // best; the first lane that would replace it does, and the rest test again: one ballot per replacement instead of five
+        // cross-lane reads per candidate.
+        auto fold = [&](SbMatch& best, const SbMatch& mine, int lo, int hi, uint64_t enabled, uint64_t nosame) {
+            int j = lo;
+            while (j < hi) {
+                bool ok = false;
+                if (lane >= j && lane < hi && mine.length != 0 && ((enabled >> lane) & 1ull)) {
+                    if (best.length == 0) ok = true;
+                    else {
+                        const bool same = best.s - best.offset == mine.s - mine.offset && !((nosame >> lane) & 1ull);
+                        ok = !same && best.score + mine.s < mine.score + best.s;  // bestOf keeps a when a.score + b.s >= b.score + a.s
+                    }
+                }
+                const uint64_t mask = ballot64(ok);
+                if (mask == 0) break;
+                const int k = ctz64(mask);
+                best.offset = (int)rdlane32((uint32_t)mine.offset, k); best.s = (int)rdlane32((uint32_t)mine.s, k);
+                best.length = (int)rdlane32((uint32_t)mine.length, k); best.score = (int)rdlane32((uint32_t)mine.score, k);
+                best.rep = (int)rdlane32((uint32_t)mine.rep, k);
+                j = k + 1;
+            }
         };
         uint32_t guard = 0;
         while (!fin && !stored) {
@@ -187,11 +194,7 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
                     else if (lane == 3) off = (int)(candidateS >> 32);
                     else if (lane == 4) { off = s - repeat + 1; sp = s + 1; first = (uint32_t)(cv >> 8); rep = !SNAPPY; act = SNAPPY || repeat > 0; }
                     const SbMatch mine = eval(act, off, sp, first, rep);
-                    // bestOf(matchAt(cur L), matchAt(prev L)): both evaluated against the (empty) best of the step's start
-                    best = best_of(pick(mine, 0), pick(mine, 1));
-                    fold(best, pick(mine, 2));
-                    fold(best, pick(mine, 3));
-                    if (SNAPPY || repeat > 0) fold(best, pick(mine, 4));
+                    fold(best, mine, 0, 5, (SNAPPY || repeat > 0) ? ~0ull : ~(1ull << 4), 1ull << 1);
                 }
                 if (best.length > 0) {
                     // ---- phase B: s+1 and s+2 (:252-311) ----
@@ -220,15 +223,8 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
                         else if (lane == 8) { off = (int)(nextLong2 >> 32); sp = s2; first = (uint32_t)cv2; }
                         else act = false;
                         const SbMatch mine = eval(act, off, sp, first, rep);
-                        fold(best, pick(mine, 0));
-                        fold(best, pick(mine, 1));
-                        fold(best, pick(mine, 2));
-                        fold(best, pick(mine, 3));
-                        if (SNAPPY || repeat > 0) fold(best, pick(mine, 4));  // (both variants take it before the s+2 table candidates)
-                        fold(best, pick(mine, 5));
-                        fold(best, pick(mine, 6));
-                        fold(best, pick(mine, 7));
-                        fold(best, pick(mine, 8));
+                        // (both variants take the repeat before the s+2 table candidates)
+                        fold(best, mine, 0, 9, (SNAPPY || repeat > 0) ? ~0ull : ~(1ull << 4), 0ull);
                     }
                     // ---- phase C: a match at the end of the best match, shifted back over it (:313-345) ----
                     const int skipBeginning = SNAPPY ? 0 : 2, skipEnd = SNAPPY ? 0 : 1;
@@ -241,8 +237,7 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
                         const int chk0 = (int)(uint32_t)next - backL, chk1 = (int)(next >> 32) - backL;
                         const bool act = (lane == 0 && chk0 > 0) || (lane == 1 && chk1 > 0);
                         const SbMatch mine = eval(act, lane == 0 ? chk0 : chk1, sBack, (uint32_t)cvb, false);
-                        if (chk0 > 0) fold(best, pick(mine, 0));
-                        if (chk1 > 0) fold(best, pick(mine, 1));
+                        fold(best, mine, 0, 2, (chk0 > 0 ? 1ull : 0ull) | (chk1 > 0 ? 2ull : 0ull), 0ull);
                     }
                 }
                 // update the tables (:348-350), after every lane has read what this step looks up
