@@ -2053,7 +2053,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     if (!c || !blk_off || !out_off || (n && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
     if (feed && (framed || n == 0)) { c->err = "chunk feed: bare blocks only"; return KC_ERR_INTERNAL; }
     if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BEST) { c->err = "unknown S2 level"; return KC_ERR_UNSUPPORTED; }
-    if (level >= KC_S2_LEVEL_BEST && (framed || feed)) { c->err = "the best levels are served as bare blocks (kc_s2_encode_blocks_lvl[_dev])"; return KC_ERR_UNSUPPORTED; }
+    if (level >= KC_S2_LEVEL_BEST && feed) { c->err = "the best levels are not chunk-fed"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
     c->last = kc_timings{0, 0, 0, 0, 0, 0};
     HIPCHK(c, hipSetDevice(c->device));

@@ -71,10 +71,24 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
     const int lane = (int)threadIdx.x;
     const uint32_t bi = blockIdx.x;
     if (bi >= P.n_blocks) return;
+    __shared__ uint32_t crcT[4][256];
+    if (P.framed) {  // s2.Writer chunks carry the masked CRC32C of the uncompressed block (slice-by-4 tables, as kc_s2_encode_kernel)
+        for (int i = lane; i < 256; i += 64) {
+            uint32_t c = (uint32_t)i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            crcT[0][i] = c;
+        }
+        KC_WAVE_SYNC();
+        for (int i = lane; i < 256; i += 64) {
+            uint32_t c = crcT[0][i];
+            for (int t = 1; t < 4; t++) { c = crcT[0][c & 0xFF] ^ (c >> 8); crcT[t][i] = c; }
+        }
+        KC_WAVE_SYNC();
+    }
     const uint8_t* __restrict__ src = P.src + P.blk_off[bi];
     const int len = (int)(P.blk_off[bi + 1] - P.blk_off[bi]);
     uint8_t* __restrict__ slot = P.stage + P.stage_off[bi];
-    uint8_t* __restrict__ out = slot;
+    uint8_t* __restrict__ out = slot + (P.framed ? 8 : 0);  // chunk header (type, len24, crc) goes in front
     uint64_t* const lT = (uint64_t*)(P.tables + (size_t)bi * P.table_stride);  // zeroed by the host
     uint64_t* const sT = lT + ((size_t)1 << SB_LBITS);
 
@@ -88,7 +102,7 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
     }
     uint8_t* __restrict__ dst = out + hdr;
     int d = 0;
-    if (len == 0) { if (lane == 0) P.out_size[bi] = (uint32_t)hdr; return; }
+    if (len == 0 && !P.framed) { if (lane == 0) P.out_size[bi] = (uint32_t)hdr; return; }
     bool stored = len < 32;  // minNonLiteralBlockSize
 
     auto emit_lit = [&](int from, int n) -> int {  // emitLiteral (encode_go.go:80)
@@ -339,10 +353,31 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #endif
         KC_WAVE_SYNC();
-        d = 0;
-        d = emit_lit(0, len);  // encode.go:170-176: not compressible -> one literal
     }
-    if (lane == 0) P.out_size[bi] = (uint32_t)(hdr + d);
+    if (!P.framed) {
+        if (stored) { d = 0; d = emit_lit(0, len); }  // encode.go:170-176: not compressible -> one literal
+        if (lane == 0) P.out_size[bi] = (uint32_t)(hdr + d);
+        return;
+    }
+    // ---- s2.Writer chunk (s2/writer.go:414-451): encodeBlock returned 0 -> uncompressed chunk, the raw bytes ----
+    uint32_t chunkLen;
+    uint8_t chunkType;
+    if (stored) {
+        for (int k = lane; k < len; k += 64) out[k] = src[k];
+        chunkType = 0x01;
+        chunkLen = 4u + (uint32_t)len;
+    } else {
+        chunkType = 0x00;
+        chunkLen = 4u + (uint32_t)hdr + (uint32_t)d;
+    }
+    if (lane == 0) {
+        const uint32_t c = s2_crc32c(src, len, crcT);
+        const uint32_t checksum = ((c >> 15) | (c << 17)) + 0xa282ead8u;
+        slot[0] = chunkType;
+        slot[1] = (uint8_t)chunkLen; slot[2] = (uint8_t)(chunkLen >> 8); slot[3] = (uint8_t)(chunkLen >> 16);
+        slot[4] = (uint8_t)checksum; slot[5] = (uint8_t)(checksum >> 8); slot[6] = (uint8_t)(checksum >> 16); slot[7] = (uint8_t)(checksum >> 24);
+        P.out_size[bi] = 4u + chunkLen;
+    }
 }
 
 void kc_launch_s2_best(const KcS2Params& P, hipStream_t st) {

@@ -10,7 +10,7 @@ def MaxEncodedLen(src_len):
 
 
 LevelDefault, LevelBetter, LevelSnappy, LevelSnappyBetter = 0, 1, 2, 3  # s2.Encode / EncodeBetter / EncodeSnappy / EncodeSnappyBetter (s2/encode.go:29, 117, 204, 248)
-LevelBest, LevelSnappyBest = 4, 5  # s2.EncodeBest / EncodeSnappyBest (s2/encode.go:146, 278): bare blocks only (EncodeBlocks / EncodeBlocksDevice)
+LevelBest, LevelSnappyBest = 4, 5  # s2.EncodeBest / EncodeSnappyBest (s2/encode.go:146, 278)
 
 
 class BlockEncoder:
@@ -137,7 +137,11 @@ def WriterBetterCompression():
     return lambda w: setattr(w, "level", LevelBetter)
 
 
-WriterBestCompression = _unsupported("WriterBestCompression")
+def WriterBestCompression():
+    """s2.WriterBestCompression (writer.go:945): blocks are encoded with encodeBlockBest."""
+    return lambda w: setattr(w, "level", LevelBest)
+
+
 WriterSnappyCompat = _unsupported("WriterSnappyCompat")
 WriterUncompressed = _unsupported("WriterUncompressed")
 
@@ -244,7 +248,7 @@ class Index:
 
 class Writer:
     """s2.Writer: Write / ReadFrom / EncodeBuffer / AddSkippableBlock / Flush / Close / Reset with the reference's chunk
-    boundaries (writer.go:182-218, 357-453, 483-571, 741-857); default or better level (WriterBetterCompression).  Chunks are queued and
+    boundaries (writer.go:182-218, 357-453, 483-571, 741-857); default, better or best level (WriterBetterCompression / WriterBestCompression).  Chunks are queued and
     encoded on the GPU in batches of `batch_bytes`; the bytes written equal the reference's for the same call sequence."""
 
     def __init__(self, w, *opts, device=0, stream=None, batch_bytes=256 << 20):

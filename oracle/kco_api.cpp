@@ -641,6 +641,46 @@ int64_t kco_s2_encode_stream(const uint8_t* src, const uint64_t* blk_off, uint32
     out_off[n_blocks] = pos;
     return (int64_t)pos;
 }
+// The same for a Writer at any level: 0 default, 1 WriterBetterCompression, 2 WriterSnappyCompat, 3 both, 4 WriterBestCompression,
+// 5 best + Snappy compatible — (*Writer).encodeBlock, s2/writer.go:1053-1091, inside the chunk framing of :414-451.
+int64_t kco_s2_encode_stream_level(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,
+                                   uint64_t* out_off, int with_stream_id, int level) {
+    static const uint8_t magic[10] = {0xff, 0x06, 0x00, 0x00, 'S', '2', 's', 'T', 'w', 'O'};
+    uint64_t pos = 0;
+    if (with_stream_id) { if (dst_cap < 10) return -2; memcpy(dst, magic, 10); pos = 10; }
+    std::vector<uint8_t> tmp;
+    for (uint32_t i = 0; i < n_blocks; i++) {
+        const size_t n = (size_t)(blk_off[i + 1] - blk_off[i]);
+        const uint8_t* p = src + blk_off[i];
+        tmp.assign((size_t)s2::MaxEncodedLen((int64_t)n) + 32, 0);
+        uint8_t* o = tmp.data();
+        const uint32_t checksum = s2::crc(p, n);
+        uint8_t chunkType = 0x01;
+        size_t chunkLen = 4 + n;
+        const int v = s2::putUvarint(o + 8, (uint64_t)n);
+        int n2 = 0;
+        switch (level) {
+        case 1: n2 = n < (size_t)s2::minNonLiteralBlockSize ? 0 : s2::encodeBlockBetter(o + 8 + v, p, n); break;
+        case 2: n2 = n < (size_t)s2::minNonLiteralBlockSize ? 0 : (n <= ((size_t)64 << 10) ? s2::encodeBlockGoT<uint16_t, 5, true>(o + 8 + v, p, n) : s2::encodeBlockGoT<uint32_t, 6, true>(o + 8 + v, p, n)); break;
+        case 3: n2 = n < (size_t)s2::minNonLiteralBlockSize ? 0 : s2::encodeBlockBetterSnappy(o + 8 + v, p, n); break;
+        case 4: n2 = n < (size_t)s2::minNonLiteralBlockSize ? 0 : s2::encodeBlockBest(o + 8 + v, p, n); break;
+        case 5: n2 = n < (size_t)s2::minNonLiteralBlockSize ? 0 : s2::encodeBlockBestSnappy(o + 8 + v, p, n); break;
+        default: n2 = s2::encodeBlock(o + 8 + v, p, n);
+        }
+        if (n2 > 0) { chunkType = 0x00; chunkLen = 4 + (size_t)v + (size_t)n2; }
+        else memcpy(o + 8, p, n);
+        o[0] = chunkType;
+        o[1] = (uint8_t)chunkLen; o[2] = (uint8_t)(chunkLen >> 8); o[3] = (uint8_t)(chunkLen >> 16);
+        o[4] = (uint8_t)checksum; o[5] = (uint8_t)(checksum >> 8); o[6] = (uint8_t)(checksum >> 16); o[7] = (uint8_t)(checksum >> 24);
+        const uint64_t r = 4 + chunkLen;
+        out_off[i] = pos;
+        if (pos + r > dst_cap) return -2;
+        memcpy(dst + pos, o, (size_t)r);
+        pos += r;
+    }
+    out_off[n_blocks] = pos;
+    return (int64_t)pos;
+}
 int64_t kco_s2_decode_stream(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::DecodeStream(dst, cap, src, (size_t)n); }
 
 static int64_t s2_encode_blocks_impl(const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks, uint8_t* dst, uint64_t dst_cap,

@@ -384,8 +384,9 @@ def zstd_decompress(enc: bytes, cap: int, dict_content: bytes = None) -> bytes:
     return buf.raw[:r]
 
 
-def s2_encode_stream(src, blk_off, with_stream_id=True):
-    """Reference s2.Writer framing of the given blocks: (numpy u8 stream, out_off[n+1])."""
+def s2_encode_stream(src, blk_off, with_stream_id=True, level=0):
+    """Reference s2.Writer framing of the given blocks: (numpy u8 stream, out_off[n+1]).  level: 0 default, 1 better, 2 Snappy
+    compatible, 3 both, 4 best, 5 best + Snappy compatible."""
     import numpy as np
     src = np.ascontiguousarray(src, dtype=np.uint8)
     blk_off = np.ascontiguousarray(blk_off, dtype=np.uint64)
@@ -393,6 +394,14 @@ def s2_encode_stream(src, blk_off, with_stream_id=True):
     cap = int(blk_off[n] - blk_off[0]) + 16 * n + 64
     dst = np.empty(cap, dtype=np.uint8)
     oo = np.empty(n + 1, dtype=np.uint64)
+    L = lib()
+    if level:
+        L.kco_s2_encode_stream_level.restype = C.c_int64
+        L.kco_s2_encode_stream_level.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int]
+        r = L.kco_s2_encode_stream_level(src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, oo.ctypes.data, int(with_stream_id), int(level))
+        if r < 0:
+            raise RuntimeError("s2 encode_stream failed %d" % r)
+        return dst[:r], oo
     r = lib().kco_s2_encode_stream(src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, oo.ctypes.data, int(with_stream_id))
     if r < 0:
         raise RuntimeError("s2 encode_stream failed %d" % r)

@@ -241,8 +241,8 @@ def test_s2_writer_chunking_and_bytes(oracle, kclib):
     assert sink3.getvalue() == ref3.tobytes()
     with pytest.raises(ValueError):
         s2.NewWriter(io.BytesIO(), s2.WriterBlockSize(1000))
-    with pytest.raises(NotImplementedError):
-        s2.NewWriter(io.BytesIO(), s2.WriterBestCompression())
+    with pytest.raises(NotImplementedError):  # (the Snappy-compatible framing is not served: another stream identifier, no index)
+        s2.NewWriter(io.BytesIO(), s2.WriterSnappyCompat())
 
 
 def test_s2_device_decoder_roundtrip_and_errors(oracle, kclib):
@@ -434,6 +434,41 @@ def test_s2_writer_better_stream_roundtrip(oracle, kclib):
     w0.Write(data)
     w0.Close()
     assert len(enc) < len(sink0.getvalue())
+
+
+@pytest.mark.parametrize("level", [1, 3, 4, 5])
+def test_s2_stream_framing_other_levels_bit_exact(oracle, kclib, level):
+    """s2.Writer chunks (type | len24 | masked CRC32C | uvarint + block, or the raw bytes when encodeBlock returns 0) at the better
+    and best levels and their Snappy-compatible forms: (*Writer).encodeBlock (s2/writer.go:1053-1091) inside the framing of
+    :414-451, against the oracle chunk by chunk; and the Python Writer with WriterBestCompression writes the same stream."""
+    import io
+    torch = pytest.importorskip("torch")
+    from compress_amd import s2
+    j = corpora.corpus("J", 24, 65536).tobytes()
+    blocks = [j[i * 65536:(i + 1) * 65536] for i in range(24)]
+    blocks += [corpora.corpus("H", 1, 65536).tobytes(), corpora.corpus("T", 1, 65536).tobytes()[:31], b"a", corpora.corpus("T", 2, 131072).tobytes()[:150000],
+               corpora.corpus("M", 1, 65536, first_unit=2).tobytes()]
+    b2, off = corpora.pack_units(blocks)
+    d_src = torch.from_numpy(b2).cuda()
+    cap = sum(((s2.MaxEncodedLen(len(b)) + 8 + 15) & ~15) for b in blocks) + 64
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    enc = s2.BlockEncoder(level=level)
+    oo = enc.EncodeStreamDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap, with_stream_id=True)
+    got = d_dst[:int(oo[-1])].cpu().numpy()
+    ref, ref_off = oracle.s2_encode_stream(b2, off, with_stream_id=True, level=level)
+    assert np.array_equal(oo, ref_off)
+    assert np.array_equal(got, np.asarray(ref))
+    assert oracle.s2_decode_stream(got.tobytes(), len(b2) + 16) == b2.tobytes()
+    enc.Close()
+    if level == 4:
+        sink = io.BytesIO()
+        w = s2.NewWriter(sink, s2.WriterBlockSize(64 << 10), s2.WriterBestCompression())
+        w.Write(j)
+        w.Close()
+        jb = np.frombuffer(j, dtype=np.uint8)
+        joff = np.arange(25, dtype=np.uint64) * 65536
+        rj, _ = oracle.s2_encode_stream(jb, joff, with_stream_id=True, level=4)
+        assert sink.getvalue()[:len(rj)] == np.asarray(rj).tobytes()
 
 
 @pytest.mark.parametrize("kind", ["J", "T", "M", "H"])
