@@ -51,6 +51,8 @@ const (
 	LevelBetter       = 1 // s2.EncodeBetter
 	LevelSnappy       = 2 // s2.EncodeSnappy
 	LevelSnappyBetter = 3 // s2.EncodeSnappyBetter
+	LevelBest         = 4 // s2.EncodeBest
+	LevelSnappyBest   = 5 // s2.EncodeSnappyBest
 )
 
 // EncodeBlocks == N x s2.Encode(nil, src[off[i]:off[i+1]]).
@@ -58,7 +60,7 @@ func EncodeBlocks(x *Ctx, src []byte, off []uint64, dst []byte) ([]byte, []uint6
 	return EncodeBlocksLevel(x, LevelDefault, src, off, dst)
 }
 
-// EncodeBlocksLevel == N x s2.Encode / s2.EncodeBetter / s2.EncodeSnappy / s2.EncodeSnappyBetter (nil, src[off[i]:off[i+1]]).
+// EncodeBlocksLevel == N x s2.Encode / EncodeBetter / EncodeSnappy / EncodeSnappyBetter / EncodeBest / EncodeSnappyBest (nil, src[off[i]:off[i+1]]).
 func EncodeBlocksLevel(x *Ctx, level int, src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
 	n := len(off) - 1
 	outOff := make([]uint64, n+1)
@@ -80,7 +82,7 @@ func EncodeBlocksLevel(x *Ctx, level int, src []byte, off []uint64, dst []byte) 
 		return nil, nil, errors.New(msg)
 	}
 	// not served by the device (block above 4 MiB, device memory exhausted, ...): the reference encoder, same bytes
-	enc := [...]func(dst, src []byte) []byte{s2.Encode, s2.EncodeBetter, s2.EncodeSnappy, s2.EncodeSnappyBetter}[level]
+	enc := [...]func(dst, src []byte) []byte{s2.Encode, s2.EncodeBetter, s2.EncodeSnappy, s2.EncodeSnappyBetter, s2.EncodeBest, s2.EncodeSnappyBest}[level]
 	out := dst[:0]
 	for i := 0; i < n; i++ {
 		outOff[i] = uint64(len(out))

@@ -61,7 +61,7 @@ func TestBitExactLevels(t *testing.T) {
 			}
 			off = append(off, uint64(len(data)))
 			dst := make([]byte, len(off)*(s2.MaxEncodedLen(unit)+16)+64)
-			for _, lv := range []int{LevelBetter, LevelSnappy, LevelSnappyBetter} {
+			for _, lv := range []int{LevelBetter, LevelSnappy, LevelSnappyBetter, LevelBest, LevelSnappyBest} {
 				out, outOff, err := EncodeBlocksLevel(x, lv, data, off, dst)
 				if err != nil {
 					t.Fatal(err)
@@ -73,6 +73,10 @@ func TestBitExactLevels(t *testing.T) {
 						want = s2.EncodeBetter(nil, data[off[i]:off[i+1]])
 					case LevelSnappy:
 						want = s2.EncodeSnappy(nil, data[off[i]:off[i+1]])
+					case LevelBest:
+						want = s2.EncodeBest(nil, data[off[i]:off[i+1]])
+					case LevelSnappyBest:
+						want = s2.EncodeSnappyBest(nil, data[off[i]:off[i+1]])
 					default:
 						want = s2.EncodeSnappyBetter(nil, data[off[i]:off[i+1]])
 					}
