@@ -1,0 +1,121 @@
+// oracle/ref_s2asm/s2ref_shim.c — TEST INFRASTRUCTURE ONLY: C entry points over the reference's own amd64 S2 block encoders
+// (oracle/_ref/s2ref_amd64.S, made from /root/reference/s2/encodeblock_amd64.s by plan9_to_gas.py).  What is restated here is only
+// the Go glue around them: the size dispatch of s2/encode_amd64.go:23-316 and s2.Encode / EncodeBetter / EncodeSnappy /
+// EncodeSnappyBetter (s2/encode.go:29-57, 117-144, 204-246, 248-276) — uvarint length, the block, or one literal when the block
+// encoder returns 0.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define P9(name) extern void p9_##name(uint64_t* frame)
+P9(encodeBlockAsm); P9(encodeBlockAsm4MB); P9(encodeBlockAsm12B); P9(encodeBlockAsm10B); P9(encodeBlockAsm8B);
+P9(encodeBetterBlockAsm); P9(encodeBetterBlockAsm4MB); P9(encodeBetterBlockAsm12B); P9(encodeBetterBlockAsm10B); P9(encodeBetterBlockAsm8B);
+P9(encodeSnappyBlockAsm); P9(encodeSnappyBlockAsm64K); P9(encodeSnappyBlockAsm12B); P9(encodeSnappyBlockAsm10B); P9(encodeSnappyBlockAsm8B);
+P9(encodeSnappyBetterBlockAsm); P9(encodeSnappyBetterBlockAsm64K); P9(encodeSnappyBetterBlockAsm12B); P9(encodeSnappyBetterBlockAsm10B);
+P9(encodeSnappyBetterBlockAsm8B);
+P9(emitLiteral); P9(emitRepeat); P9(emitCopy); P9(emitCopyNoRepeat); P9(matchLen); P9(calcBlockSize); P9(calcBlockSizeSmall);
+
+// func encodeXxx(dst []byte, src []byte, tmp *[N]byte) int: frame = dst base/len/cap, src base/len/cap, tmp, ret
+static int64_t call_block(void (*fn)(uint64_t*), uint8_t* dst, uint64_t dst_len, const uint8_t* src, uint64_t n, size_t tmp_bytes) {
+    uint64_t f[8];
+    void* tmp = aligned_alloc(64, (tmp_bytes + 63) & ~(size_t)63);
+    if (!tmp) return -1;
+    memset(tmp, 0xA5, tmp_bytes);  // (the encoders clear their table themselves)
+    f[0] = (uint64_t)(uintptr_t)dst; f[1] = dst_len; f[2] = dst_len;
+    f[3] = (uint64_t)(uintptr_t)src; f[4] = n; f[5] = n;
+    f[6] = (uint64_t)(uintptr_t)tmp; f[7] = 0;
+    fn(f);
+    free(tmp);
+    return (int64_t)f[7];
+}
+
+enum { minNonLiteralBlockSize = 32 };
+
+// level: 0 encodeBlock, 1 encodeBlockBetter, 2 encodeBlockSnappy, 3 encodeBlockBetterSnappy (s2/encode_amd64.go)
+int64_t s2ref_encode_block(int level, uint8_t* dst, uint64_t dst_len, const uint8_t* src, uint64_t n) {
+    const uint64_t limit12B = 16 << 10, limit10B = 4 << 10, limit8B = 512;
+    switch (level) {
+    case 0:
+        if (n >= (4u << 20)) return call_block(p9_encodeBlockAsm, dst, dst_len, src, n, 65536);
+        if (n >= limit12B) return call_block(p9_encodeBlockAsm4MB, dst, dst_len, src, n, 65536);
+        if (n >= limit10B) return call_block(p9_encodeBlockAsm12B, dst, dst_len, src, n, 16384);
+        if (n >= limit8B) return call_block(p9_encodeBlockAsm10B, dst, dst_len, src, n, 4096);
+        if (n < minNonLiteralBlockSize) return 0;
+        return call_block(p9_encodeBlockAsm8B, dst, dst_len, src, n, 1024);
+    case 1:
+        if (n > (4u << 20)) return call_block(p9_encodeBetterBlockAsm, dst, dst_len, src, n, 589824);
+        if (n >= limit12B) return call_block(p9_encodeBetterBlockAsm4MB, dst, dst_len, src, n, 589824);
+        if (n >= limit10B) return call_block(p9_encodeBetterBlockAsm12B, dst, dst_len, src, n, 81920);
+        if (n >= limit8B) return call_block(p9_encodeBetterBlockAsm10B, dst, dst_len, src, n, 20480);
+        if (n < minNonLiteralBlockSize) return 0;
+        return call_block(p9_encodeBetterBlockAsm8B, dst, dst_len, src, n, 5120);
+    case 2:
+        if (n > 65536) return call_block(p9_encodeSnappyBlockAsm, dst, dst_len, src, n, 65536);
+        if (n >= limit12B) return call_block(p9_encodeSnappyBlockAsm64K, dst, dst_len, src, n, 65536);
+        if (n >= limit10B) return call_block(p9_encodeSnappyBlockAsm12B, dst, dst_len, src, n, 16384);
+        if (n >= limit8B) return call_block(p9_encodeSnappyBlockAsm10B, dst, dst_len, src, n, 4096);
+        if (n < minNonLiteralBlockSize) return 0;
+        return call_block(p9_encodeSnappyBlockAsm8B, dst, dst_len, src, n, 1024);
+    case 3:
+        if (n > 65536) return call_block(p9_encodeSnappyBetterBlockAsm, dst, dst_len, src, n, 589824);
+        if (n >= limit12B) return call_block(p9_encodeSnappyBetterBlockAsm64K, dst, dst_len, src, n, 294912);
+        if (n >= limit10B) return call_block(p9_encodeSnappyBetterBlockAsm12B, dst, dst_len, src, n, 81920);
+        if (n >= limit8B) return call_block(p9_encodeSnappyBetterBlockAsm10B, dst, dst_len, src, n, 20480);
+        if (n < minNonLiteralBlockSize) return 0;
+        return call_block(p9_encodeSnappyBetterBlockAsm8B, dst, dst_len, src, n, 5120);
+    }
+    return -1;
+}
+
+// func emitLiteral(dst []byte, lit []byte) int
+int64_t s2ref_emit_literal(uint8_t* dst, uint64_t dst_len, const uint8_t* lit, uint64_t n) {
+    uint64_t f[7] = {(uint64_t)(uintptr_t)dst, dst_len, dst_len, (uint64_t)(uintptr_t)lit, n, n, 0};
+    p9_emitLiteral(f);
+    return (int64_t)f[6];
+}
+// func emitRepeat / emitCopy / emitCopyNoRepeat(dst []byte, offset int, length int) int
+static int64_t call_emit(void (*fn)(uint64_t*), uint8_t* dst, uint64_t dst_len, int64_t offset, int64_t length) {
+    uint64_t f[6] = {(uint64_t)(uintptr_t)dst, dst_len, dst_len, (uint64_t)offset, (uint64_t)length, 0};
+    fn(f);
+    return (int64_t)f[5];
+}
+int64_t s2ref_emit_repeat(uint8_t* dst, uint64_t dst_len, int64_t offset, int64_t length) { return call_emit(p9_emitRepeat, dst, dst_len, offset, length); }
+int64_t s2ref_emit_copy(uint8_t* dst, uint64_t dst_len, int64_t offset, int64_t length) { return call_emit(p9_emitCopy, dst, dst_len, offset, length); }
+int64_t s2ref_emit_copy_norepeat(uint8_t* dst, uint64_t dst_len, int64_t offset, int64_t length) { return call_emit(p9_emitCopyNoRepeat, dst, dst_len, offset, length); }
+// func matchLen(a []byte, b []byte) int
+int64_t s2ref_match_len(const uint8_t* a, uint64_t an, const uint8_t* b, uint64_t bn) {
+    uint64_t f[7] = {(uint64_t)(uintptr_t)a, an, an, (uint64_t)(uintptr_t)b, bn, bn, 0};
+    p9_matchLen(f);
+    return (int64_t)f[6];
+}
+
+static int put_uvarint(uint8_t* dst, uint64_t x) {
+    int i = 0;
+    while (x >= 0x80) { dst[i++] = (uint8_t)x | 0x80; x >>= 7; }
+    dst[i++] = (uint8_t)x;
+    return i;
+}
+
+// s2.Encode (level 0), EncodeBetter (1), EncodeSnappy (2), EncodeSnappyBetter (3) on amd64.  dst_len >= MaxEncodedLen(n).
+int64_t s2ref_encode(int level, uint8_t* dst, uint64_t dst_len, const uint8_t* src, uint64_t n) {
+    int64_t d = put_uvarint(dst, n);
+    if (n == 0) return d;
+    if (n < minNonLiteralBlockSize) return d + s2ref_emit_literal(dst + d, dst_len - (uint64_t)d, src, n);
+    const int64_t k = s2ref_encode_block(level, dst + d, dst_len - (uint64_t)d, src, n);
+    if (k < 0) return k;
+    if (k > 0) return d + k;
+    return d + s2ref_emit_literal(dst + d, dst_len - (uint64_t)d, src, n);  // not compressible
+}
+
+// Blocks src[off[i] .. off[i+1]) encoded back to back on `threads` host threads is the caller's business (tests/oracle_ref.py);
+// this one is the single-call form for timing loops: returns the total bytes, writes nothing but `scratch` (>= MaxEncodedLen of
+// the largest block).
+int64_t s2ref_encode_blocks_size(int level, const uint8_t* src, const uint64_t* off, uint32_t n, uint8_t* scratch, uint64_t scratch_len) {
+    int64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const int64_t r = s2ref_encode(level, scratch, scratch_len, src + off[i], off[i + 1] - off[i]);
+        if (r < 0) return r;
+        total += r;
+    }
+    return total;
+}

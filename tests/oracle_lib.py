@@ -331,6 +331,24 @@ def s2_encode_block(src: bytes) -> bytes:
     return buf.raw[:r]
 
 
+def s2_emit_literal(lit: bytes) -> bytes:
+    buf = C.create_string_buffer(len(lit) + 16)
+    r = lib().kco_s2_emit_literal(buf, lit, len(lit))
+    return buf.raw[:r]
+
+
+def s2_emit_copy(offset: int, length: int) -> bytes:
+    buf = C.create_string_buffer(64)
+    r = lib().kco_s2_emit_copy(buf, offset, length)
+    return buf.raw[:r]
+
+
+def s2_emit_repeat(offset: int, length: int) -> bytes:
+    buf = C.create_string_buffer(64)
+    r = lib().kco_s2_emit_repeat(buf, offset, length)
+    return buf.raw[:r]
+
+
 def s2_decode(enc: bytes, cap: int) -> bytes:
     buf = C.create_string_buffer(max(cap, 1))
     r = lib().kco_s2_decode(enc, len(enc), buf, cap)
