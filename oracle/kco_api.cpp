@@ -11,6 +11,7 @@
 #include "kco_zstd_dfast.h"
 #include "kco_zstd_better.h"
 #include "kco_s2.h"
+#include "kco_s2_asm.h"
 #include "kco_dict.h"
 #include "kco_zstd_best.h"
 #include "kco_zstd_dec.h"
@@ -620,6 +621,11 @@ int64_t kco_s2_emit_literal(uint8_t* dst, const uint8_t* lit, uint64_t n) { retu
 int64_t kco_s2_emit_copy(uint8_t* dst, int64_t offset, int64_t length) { return s2::emitCopy(dst, (int)offset, (int)length); }
 int64_t kco_s2_emit_repeat(uint8_t* dst, int64_t offset, int64_t length) { return s2::emitRepeat(dst, (int)offset, (int)length); }
 int64_t kco_s2_decode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) { return s2::Decode(dst, cap, src, (size_t)n); }
+// s2.Encode (snappy 0) / s2.EncodeSnappy (1) as an amd64 build of the reference writes them (kco_s2_asm.h)
+int64_t kco_s2_encode_asm(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap, int snappy) {
+    return s2::EncodeAsm(dst, cap, src, (size_t)n, snappy != 0);
+}
+
 uint32_t kco_s2_crc(const uint8_t* p, uint64_t n) { return s2::crc(p, (size_t)n); }
 
 // s2.Writer output for the blocks (stream identifier optional): chunks back to back; out_off[i] = start of chunk i.
