@@ -97,6 +97,7 @@ struct KcCfg {
     int64_t k2_prof = 0;
     int64_t hook_wait_us = 0, hook_batch = 256;
     int64_t test_feed_redo = 0;           // diagnostics: force the chunk-fed path's re-encode fallback
+    int64_t s2_variant = 0;               // S2 levels 0 / 2: 0 = the portable Go encoders' bytes, 1 = the amd64 assembly encoders' bytes
     int64_t best_slots = 2048;            // SpeedBestCompression: table slots (34 MiB each) = units encoded at a time
 };
 
@@ -340,6 +341,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_TEST_FEED_REDO: g.test_feed_redo = v; break;
         case KC_OPT_MAX_SCRATCH_MIB: if (v < 1) return KC_ERR_BAD_ARG; c->max_scratch_bytes = (uint64_t)v << 20; break;
         case KC_OPT_BEST_SLOTS: if (v < 1 || v > 8192) return KC_ERR_BAD_ARG; g.best_slots = v; break;
+        case KC_OPT_S2_VARIANT: if (v != KC_S2_VARIANT_GO && v != KC_S2_VARIANT_AMD64) return KC_ERR_BAD_ARG; g.s2_variant = v; break;
         default: return KC_ERR_BAD_ARG;
     }
     return KC_OK;
@@ -368,6 +370,7 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_TEST_FEED_REDO: return g.test_feed_redo;
         case KC_OPT_MAX_SCRATCH_MIB: return (int64_t)(c->max_scratch_bytes >> 20);
         case KC_OPT_BEST_SLOTS: return g.best_slots;
+        case KC_OPT_S2_VARIANT: return g.s2_variant;
         case KC_OPT_LAST_PATH: return c->last_path;
         case KC_OPT_LAST_BATCHES: return c->last_batches;
         default: return -1;
@@ -2090,8 +2093,13 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     if (acc16 + lead > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
     // s2.Encode / s2.EncodeSnappy: the LDS-table kernel (one wave per block, ~1 ms per 64 KiB block whatever the batch) while the
     // blocks in flight cannot cover the HBM-table kernel's latency (measured crossover: profiles/r03_crossover_s2.csv)
+    const bool asmv = c->cfg.s2_variant == KC_S2_VARIANT_AMD64;
+    if (asmv && level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_SNAPPY) {
+        c->err = "KC_S2_VARIANT_AMD64 serves s2.Encode and s2.EncodeSnappy (the assembly forms of the other levels are not built)";
+        return KC_ERR_UNSUPPORTED;
+    }
     const bool lds = (level == KC_S2_LEVEL_DEFAULT || level == KC_S2_LEVEL_SNAPPY) && feed == nullptr && c->cfg.match_path != KC_PATH_HBM &&
-                     (c->cfg.match_path == KC_PATH_LDS || (int64_t)n <= c->cfg.s2_lds_max_blocks);
+                     (c->cfg.match_path == KC_PATH_LDS || (int64_t)n <= c->cfg.s2_lds_max_blocks) && !asmv;  // (the assembly variant: HBM-table kernel)
     c->last_path = lds ? KC_PATH_LDS : KC_PATH_HBM;
     kc_status s;
     if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) ||
@@ -2118,6 +2126,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     if (P.spec_w0 < 1) P.spec_w0 = 1;
     if (P.spec_w0b < 1) P.spec_w0b = 1;
     P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen) / 4);
+    P.variant = (int32_t)c->cfg.s2_variant;
     if (feed) {
         // the source is still arriving: per chunk, encode + compaction on the chunk's stream behind its H2D copy; frames of chunk k
         // at d_dst + reg[cut[k]], local offsets in out_off[cut[k] + k ...].  The caller synchronises (s2_feed_finish).

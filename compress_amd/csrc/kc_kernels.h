@@ -124,6 +124,8 @@ struct KcS2Params {
     int32_t spec_w0, spec_w0b;  // speculation width after a match (default / better parse)
     int32_t spec_grow;          // after a round without a match: 0 keep, 1 +1, 2 double
     int32_t framed;             // 1: emit s2.Writer chunks (type | len24 | masked CRC32C | body), s2/writer.go:414-451
+    int32_t variant;            // levels 0 and 2: 0 = the bytes of the portable Go encoders (encode_all.go; arm64 and noasm builds),
+                                // 1 = the bytes of the amd64 assembly encoders (encode_amd64.go + encodeblock_amd64.s)
 };
 void kc_launch_s2_encode(const KcS2Params& P, hipStream_t st);
 // s2.EncodeBest (level 4) / s2.EncodeSnappyBest (level 5): kc_s2_best.hip, one wave per block, 4.5 MiB of {cur, prev} tables per block

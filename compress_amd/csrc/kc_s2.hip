@@ -56,6 +56,35 @@ __device__ __forceinline__ int s2_extend(const uint8_t* __restrict__ base, int a
 }
 
 
+// The assembly's matchLen (s2/_generate/gen.go:2778-2880): the exact common prefix, up to the end of the block.  Whole 8-byte
+// steps while 8 bytes are left, then the tail byte by byte.  Returns the new a.
+__device__ __forceinline__ int s2_extend_exact(const uint8_t* __restrict__ base, int a, int b, int len, int lig, int grp) {
+    for (;;) {
+        const int pa = a + 8 * lig, pb = b + 8 * lig;
+        const bool inb = pa + 8 <= len;
+        uint64_t diff = 0;
+        if (inb) diff = ld64(base + pa) ^ ld64(base + pb);
+        const uint32_t oob = s2g_ballot(!inb, grp);
+        const uint32_t dm = s2g_ballot(inb && diff != 0, grp);
+        const int firstOob = oob ? __builtin_ctz(oob) : S2G;
+        if (dm) {
+            const int fl = __builtin_ctz(dm);
+            const uint64_t d = s2g_bcast64(diff, grp, fl);
+            return a + 8 * fl + (ctz64(d) >> 3);
+        }
+        if (firstOob < S2G) {
+            const int t = a + 8 * firstOob, tb = b + 8 * firstOob;
+            const int rem = len - t;  // 0..7
+            const bool ne = lig < rem && base[t + lig] != base[tb + lig];
+            const uint32_t nm = s2g_ballot(ne, grp);
+            const int k = nm ? __builtin_ctz(nm) : rem;
+            return t + (k < rem ? k : rem);
+        }
+        a += 8 * S2G;
+        b += 8 * S2G;
+    }
+}
+
 template <int LEVEL>  // 0: s2.Encode (encodeBlockGo / ...64K), 1: s2.EncodeBetter (encodeBlockBetterGo / ...64K), 2: s2.EncodeSnappy (encodeBlockSnappyGo / ...64K), 3: s2.EncodeSnappyBetter (encodeBlockBetterSnappyGo / ...64K)
 __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     constexpr int G = S2G;
@@ -183,7 +212,12 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         if (lig == 0) { ring_or(q, lo); if (n > 8) ring_or(q + 8, hi); }
         ring_flush(q + n);
     };
+    bool smallRep = false;  // the assembly's emitRepeat as generated into encodeBlockAsm8B (see below)
     auto emit_repeat = [&](int offset, int length) -> int {
+        if (smallRep && length > 8 && length < 12) {  // no two-byte offset form there: gen.go:1991-1994 leaves its test (and jump) out
+            if (lig == 0) { dst[d] = (uint8_t)(5 << 2 | 1); dst[d + 1] = 0; dst[d + 2] = (uint8_t)(length - 8); }
+            return 3;
+        }
         if (!RING) { if (lig == 0) s2_emit_repeat1(dst + d, offset, length); return s2_repeat_size(offset, length); }
         uint64_t lo = 0, hi = 0;
         const int n = s2_put_repeat([&](int k, uint8_t v) { if (k < 8) lo |= (uint64_t)v << (8 * k); else hi |= (uint64_t)v << (8 * (k - 8)); }, offset, length);
@@ -200,14 +234,31 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
 
     if ((LEVEL == 0 || LEVEL == 2) && !stored) {
         constexpr bool SNAPPY = LEVEL == 2;  // encode_all.go:502 / :692: the same parse, every copy through emitCopyNoRepeat
-        const int SKIP = len <= (64 << 10) ? 5 : 6;  // encodeBlockGo64K vs encodeBlockGo (encode_go.go:23-26)
+        int SKIP = len <= (64 << 10) ? 5 : 6;  // encodeBlockGo64K vs encodeBlockGo (encode_go.go:23-26)
+        // P.variant 1: the bytes of the amd64 ASSEMBLY encoders (s2/encode_amd64.go:23-87, 176-239; generator s2/_generate/gen.go:170-855)
+        // — the same algorithm with, per size class, another table size / hash length / skip rate, matches extended to the very end
+        // of the block, `nextS >= sLimit`, output margin 9 and the literal header's worst case in every bail-out test.
+        const bool AX = P.variant == 1;
+        int HSHL = 16, HSHR = 64 - S2_TABLE_BITS, LITOVH = 0;
+        uint64_t HPRIME = KC_PRIME6;
+        if (AX) {
+            const bool top = SNAPPY ? len > 65536 : len >= (4 << 20);
+            if (top || len >= (16 << 10)) { SKIP = 6; LITOVH = top ? 5 : (SNAPPY ? 3 : 4); }                                    // ...Asm / ...Asm4MB / ...Asm64K
+            else if (len >= (4 << 10)) { SKIP = 5; HSHL = 24; HPRIME = KC_PRIME5; HSHR = 64 - 12; LITOVH = 3; }                   // ...Asm12B
+            else if (len >= 512) { SKIP = 5; HSHL = 32; HPRIME = (uint64_t)KC_PRIME4; HSHR = 64 - 10; LITOVH = 3; }              // ...Asm10B
+            else { SKIP = 4; HSHL = 32; HPRIME = (uint64_t)KC_PRIME4; HSHR = 64 - 8; LITOVH = 3; smallRep = !SNAPPY; }            // ...Asm8B
+        }
+        auto hashOf = [&](uint64_t v) -> uint32_t { return (uint32_t)(((v << HSHL) * HPRIME) >> HSHR); };
         const int PB = bits_len32((uint32_t)len);
         const int TB = (32 - PB) > 16 ? 16 : (32 - PB);
         const uint32_t posMask = (1u << PB) - 1u;
         auto tagOf = [&](uint32_t v) -> uint32_t { return (v * 2654435761u) >> (32 - TB); };
         auto mk = [&](int pos, uint32_t val) -> uint32_t { return (uint32_t)pos | (tagOf(val) << PB); };
         const int sLimit = len - 8;
-        const int dstLimit = len - (len >> 5) - 5;
+        const int sLimT = AX ? sLimit - 1 : sLimit;                     // a step is taken while nextS <= sLimT
+        const int dstLimit = AX ? (len - 9) - (len >> 5) : len - (len >> 5) - 5;
+        const int bailLim = AX ? dstLimit - LITOVH - 1 : dstLimit;      // literals of n bytes are refused when d + n > bailLim
+        const int cpLim = AX ? dstLimit - 1 : dstLimit;                 // after a copy: d > cpLim
         int nextEmit = 0, s = 1, repeat = 1;
         bool fin = false;   // goto emitRemainder
         int W = G;  // speculation width: every speculative probe step costs three table lines from HBM, and matches come every few steps
@@ -220,13 +271,13 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
             // lane i is a real probe step iff all earlier steps stayed in the skip segment and nextS(p) <= sLimit
             const bool inseg = lig == 0 || ((d0 + (lig - 1) * step) >> SKIP) == k0;
             const int nextS = p + ((p - nextEmit) >> SKIP) + 4;
-            const bool valid = lig < W && inseg && nextS <= sLimit;
-            const bool term = inseg && nextS > sLimit;  // this step would `goto emitRemainder`
+            const bool valid = lig < W && inseg && nextS <= sLimT;
+            const bool term = inseg && nextS > sLimT;  // this step would `goto emitRemainder`
             uint64_t cv = 0;
             uint32_t h0 = 0xFFFFFFF0u, h1 = 0xFFFFFFF1u, h2 = 0xFFFFFFF2u, e0 = 0, e1 = 0, e2 = 0;
             if (valid) {
                 cv = ld64(src + p);
-                h0 = s2_hash6(cv); h1 = s2_hash6(cv >> 8); h2 = s2_hash6(cv >> 16);
+                h0 = hashOf(cv); h1 = hashOf(cv >> 8); h2 = hashOf(cv >> 16);
                 e0 = tab[h0]; e1 = tab[h1]; e2 = tab[h2];
             }
             bool dep = false;
@@ -298,15 +349,15 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                     const int back = grp_backlen<S2G>(src, base, i0, kmax, lig, grp);
                     base -= back;
                 }
-                if (d + (base - nextEmit) > dstLimit) { stored = true; continue; }
+                if (d + (base - nextEmit) > bailLim) { stored = true; continue; }
                 d += emit_lit(nextEmit, base - nextEmit);
                 const int cand2 = ps - repeat + 4 + 1;
-                s = s2_extend(src, ps + 4 + 1, cand2, sLimit, lig, grp);
+                s = AX ? s2_extend_exact(src, ps + 4 + 1, cand2, len, lig, grp) : s2_extend(src, ps + 4 + 1, cand2, sLimit, lig, grp);
                 if (SNAPPY) { if (lig == 0) s2_emit_copy_nr1(dst + d, repeat, s - base); d += s2_copy_nr_size(repeat, s - base); }
                 else if (nextEmit > 0) d += emit_repeat(repeat, s - base);
                 else d += emit_copy(repeat, s - base);
                 nextEmit = s;
-                if (s >= sLimit) fin = true;
+                if (s >= sLimit) fin = true;  // (the assembly has no such test: its next step's nextS = s + 4 >= sLimit says the same)
                 continue;
             }
             // ---------------- regular match (encode_all.go:387-489) ----------------
@@ -318,20 +369,20 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 candidate -= back;
                 s -= back;
             }
-            if (d + (s - nextEmit) > dstLimit) { stored = true; continue; }
+            if (d + (s - nextEmit) > bailLim) { stored = true; continue; }
             d += emit_lit(nextEmit, s - nextEmit);
             for (;;) {
                 const int base = s;
                 repeat = base - candidate;
-                s = s2_extend(src, s + 4, candidate + 4, len - 8, lig, grp);
+                s = AX ? s2_extend_exact(src, s + 4, candidate + 4, len, lig, grp) : s2_extend(src, s + 4, candidate + 4, len - 8, lig, grp);
                 if (SNAPPY) { if (lig == 0) s2_emit_copy_nr1(dst + d, repeat, s - base); d += s2_copy_nr_size(repeat, s - base); }
                 else d += emit_copy(repeat, s - base);
                 nextEmit = s;
                 if (s >= sLimit) { fin = true; break; }
-                if (d > dstLimit) { stored = true; break; }
+                if (d > cpLim) { stored = true; break; }
                 // check for an immediate match, otherwise start the search at s+1 (:474-488)
                 const uint64_t x = ld64(src + s - 2);
-                const uint32_t m2Hash = s2_hash6(x), currHash = s2_hash6(x >> 16);
+                const uint32_t m2Hash = hashOf(x), currHash = hashOf(x >> 16);
                 const uint32_t ec = tab[currHash];
                 if (lig == 0) { tab[m2Hash] = mk(s - 2, (uint32_t)x); tab[currHash] = mk(s, (uint32_t)(x >> 16)); }
                 // make the writes visible to the group's next reads of these buckets (same wave: program order)
@@ -342,9 +393,9 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         }
         if (!stored) {
             // emitRemainder (:491-499)
-            if (nextEmit < len) {
-                if (d + len - nextEmit > dstLimit) stored = true;
-                else d += emit_lit(nextEmit, len - nextEmit);
+            if (AX || nextEmit < len) {  // (the assembly tests the bail-out even when nothing is left to emit)
+                if (d + len - nextEmit > bailLim) stored = true;
+                else if (nextEmit < len) d += emit_lit(nextEmit, len - nextEmit);
             }
         }
     }

@@ -14,12 +14,18 @@ LevelBest, LevelSnappyBest = 4, 5  # s2.EncodeBest / EncodeSnappyBest (s2/encode
 
 
 class BlockEncoder:
-    def __init__(self, device=0, stream=None, level=LevelDefault, path=None):
+    def __init__(self, device=0, stream=None, level=LevelDefault, path=None, variant=None):
         """path: None / 'auto' (by blocks in flight), 'hbm' or 'lds' — the kernel family of s2.Encode / s2.EncodeSnappy
-        (KC_OPT_MATCH_PATH, include/kcgpu.h); both give the reference's bytes."""
+        (KC_OPT_MATCH_PATH, include/kcgpu.h); both give the reference's bytes.
+        variant: None / 'go' — the bytes of the reference's portable Go block encoders (arm64, noasm builds); 'amd64' — the bytes
+        of its amd64 assembly encoders (KC_OPT_S2_VARIANT; s2.Encode and s2.EncodeSnappy)."""
         self._ctx = _lib.Context(device, stream)
         if path is not None:
             self._ctx.set_path(path)
+        if variant not in (None, "go", "amd64"):
+            raise ValueError("variant must be 'go' or 'amd64'")
+        if variant == "amd64":
+            self._ctx.set_option(20, 1)
         self.level = int(level)
 
     def EncodeBlocks(self, src, blk_off):

@@ -43,6 +43,13 @@ typedef enum {
     KC_ERR_INTERNAL = -6       /* device-side invariant violated (reported, never silently ignored) */
 } kc_status;
 
+/* Which build of the reference the S2 default / Snappy-compatible levels are byte-identical to.  The reference has two block
+ * encoders for them: portable Go (s2/encode_all.go: arm64, noasm and every non-amd64 build) and generated amd64 assembly
+ * (s2/encode_amd64.go + encodeblock_amd64.s: other table sizes, hash lengths and skip rates per input size class, matches extended
+ * to the very end of the block).  Both write valid, different streams.  KC_OPT_S2_VARIANT picks the one to match. */
+#define KC_S2_VARIANT_GO 0
+#define KC_S2_VARIANT_AMD64 1
+
 /* zstd.EncoderLevel (zstd/encoder_options.go:163-179) */
 typedef enum { KC_SPEED_FASTEST = 1, KC_SPEED_DEFAULT = 2, KC_SPEED_BETTER = 3, KC_SPEED_BEST = 4 } kc_level;
 
@@ -152,6 +159,7 @@ typedef enum {
     KC_OPT_TEST_FEED_REDO = 16,      /* (no variable)             diagnostics: force the chunk-fed path's re-encode fallback */
     KC_OPT_MAX_SCRATCH_MIB = 18,     /* (no variable)             ceiling of the device scratch one batch may take (default 160 GiB, and 85 % of the free memory): larger calls are cut into several batches */
     KC_OPT_BEST_SLOTS = 19,          /* (no variable)             SpeedBestCompression: table slots of 34 MiB = units encoded at a time (default 2048 = 68 GiB, allocated on demand) */
+    KC_OPT_S2_VARIANT = 20,          /* (no variable)             s2.Encode / s2.EncodeSnappy: KC_S2_VARIANT_GO (default) or KC_S2_VARIANT_AMD64 */
     KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
     KC_OPT_LAST_BATCHES = 101        /* read-only: device batches the last kc_zstd_encode_units_dev / kc_s2_encode_*_dev call was cut into */
 } kc_option;

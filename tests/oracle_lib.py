@@ -331,6 +331,20 @@ def s2_encode_block(src: bytes) -> bytes:
     return buf.raw[:r]
 
 
+def s2_encode_asm(src: bytes, snappy=False) -> bytes:
+    """s2.Encode / s2.EncodeSnappy as an amd64 build of the reference writes them: the oracle's restatement of the assembly
+    encoders (oracle/kco_s2_asm.h), pinned against the assembly itself by tests/test_ref_s2asm.py."""
+    L = lib()
+    L.kco_s2_encode_asm.restype = C.c_int64
+    L.kco_s2_encode_asm.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int]
+    cap = L.kco_s2_max_encoded_len(len(src)) + 64
+    buf = C.create_string_buffer(cap)
+    r = L.kco_s2_encode_asm(src, len(src), buf, cap, int(bool(snappy)))
+    if r < 0:
+        raise RuntimeError("s2 encode_asm failed %d" % r)
+    return buf.raw[:r]
+
+
 def s2_emit_literal(lit: bytes) -> bytes:
     buf = C.create_string_buffer(len(lit) + 16)
     r = lib().kco_s2_emit_literal(buf, lit, len(lit))

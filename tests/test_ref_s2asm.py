@@ -59,3 +59,58 @@ def test_oracle_emit_helpers_equal_the_assembly(oracle):
             b[k] ^= 0x40
         want = next((i for i in range(n) if a[i] != b[i]), n)
         assert oracle_ref.match_len(a, bytes(b)) == want
+
+
+def _pin_inputs():
+    import os
+    import zipfile
+    rng = np.random.default_rng(7)
+    out = []
+    for kind in "JTMH":
+        d = corpora.corpus(kind, 40, 131072).tobytes()
+        for n in [32, 33, 100, 511, 512, 513, 2000, 4095, 4096, 5000, 16383, 16384, 20000, 65535, 65536, 65537, 300000, 1 << 20, (4 << 20) - 1, 4 << 20] + [
+                int(x) for x in rng.integers(32, 70000, 40)]:
+            start = int(rng.integers(0, len(d) - n)) if n < len(d) else 0
+            out.append(d[start:start + n])
+    z = zipfile.ZipFile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_inputs", "enc_regressions.zip"))
+    out += [z.read(n) for n in z.namelist() if 0 < len(z.read(n)) <= (4 << 20)]
+    out += [u for u in corpora.edge_units() + corpora.stress_units(seed=5, n=8) if u]
+    for _ in range(200):  # low-entropy noise: repeats of every length, the 8B encoder's three-byte repeat form among them
+        out.append(bytes(rng.integers(0, int(rng.integers(2, 6)), int(rng.integers(32, 3000)), dtype=np.uint8)))
+    return out
+
+
+def test_oracle_restatement_of_the_assembly_is_pinned(oracle):
+    """oracle/kco_s2_asm.h (the assembly encoders restated from their generator) == the assembly itself, byte for byte, for
+    s2.Encode and s2.EncodeSnappy: every size class of encode_amd64.go, the reference's regression inputs, edge and stress units,
+    low-entropy noise.  This is the one whole-encoder path of the oracle that is PINNED by running the reference."""
+    bad = []
+    ins = _pin_inputs()
+    for i, u in enumerate(ins):
+        for snappy, lvl in ((False, 0), (True, 2)):
+            if oracle.s2_encode_asm(u, snappy) != oracle_ref.encode(u, lvl):
+                bad.append((i, len(u), snappy))
+    assert not bad, bad[:10]
+    assert len(ins) > 500
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("snappy", [False, True])
+def test_device_amd64_variant_equals_the_assembly(oracle, kclib, snappy):
+    """KC_S2_VARIANT_AMD64 on the device == the reference's assembly encoders (and the oracle's restatement of them), on the same
+    inputs: bytes produced by hand-written HIP against bytes produced by the reference's own code."""
+    pytest.importorskip("torch")
+    from compress_amd import s2
+    ins = _pin_inputs()
+    b2, off = corpora.pack_units(ins)
+    enc = s2.BlockEncoder(level=s2.LevelSnappy if snappy else s2.LevelDefault, variant="amd64")
+    out, out_off = enc.EncodeBlocks(b2, off)
+    bad = []
+    for i, u in enumerate(ins):
+        got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        want = oracle_ref.encode(u, 2 if snappy else 0)
+        assert oracle.s2_encode_asm(u, snappy) == want
+        if got != want:
+            bad.append((i, len(u), len(got), len(want)))
+    assert not bad, bad[:10]
+    enc.Close()
