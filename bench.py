@@ -42,6 +42,10 @@ CONFIGS = {
                src="kc_s2.hip", what="s2.Encode (default level)"),
     "C5": dict(codec="zstd", level=3, kind="M", unit=128 << 10, gib=1.0, dict_kib=64, kernel="kc_zbetter_match_grp_kernel<true>",
                src="kc_zstd_match_better.hip", what="zstd SpeedBetterCompression EncodeAll, 64 KiB raw dictionary"),
+    # C4 matched against the reference's amd64 ASSEMBLY encoders (KC_S2_VARIANT_AMD64) instead of its portable Go encoders: the
+    # build an amd64 user of s2.Encode runs, and the one oracle/_ref executes — cpu_baseline.kind "reference", bytes compared
+    "C4A": dict(codec="s2", level=0, kind="J", unit=64 << 10, gib=2.0, dict_kib=0, kernel="kc_s2_encode_kernel",
+                src="kc_s2.hip", what="s2.Encode, amd64 assembly variant", variant="amd64"),
     # not a BASELINE configuration (and not part of the default run's "also"): the best level, one wave per unit on persistent table slots
     "B4": dict(codec="zstd", level=4, kind="T", unit=128 << 10, gib=0.5, dict_kib=0, kernel="kc_zbest_match_kernel",
                src="kc_zstd_match_best.hip", what="zstd SpeedBestCompression EncodeAll"),
@@ -264,7 +268,7 @@ def main():
     npipe = 2 if (args.pipeline and not is_s2) else 1
     streams = [torch.cuda.Stream() for _ in range(npipe)]
     if is_s2:
-        encs = [s2.BlockEncoder(device=local_rank, stream=streams[0].cuda_stream, level=args.s2_level, path=args.path)]
+        encs = [s2.BlockEncoder(device=local_rank, stream=streams[0].cuda_stream, level=args.s2_level, path=args.path, variant=cfg.get("variant"))]
         cfg["what"] = {0: cfg["what"], 1: "s2.EncodeBetter", 2: "s2.EncodeSnappy", 3: "s2.EncodeSnappyBetter", 4: "s2.EncodeBest", 5: "s2.EncodeSnappyBest"}[args.s2_level]
         cfg["kernel"] = "kc_s2_encode_kernel<%d>" % args.s2_level if args.s2_level < 4 else "kc_s2_best_kernel<%s>" % ("true" if args.s2_level == 5 else "false")
         if args.s2_level >= 4:
@@ -396,10 +400,15 @@ def main():
                 cores = quota
             if args.cpu_threads > 0:
                 cores = args.cpu_threads
-            default_sample = {"C2": 16384, "C2H": 16384, "C3": 8192, "C4": 16384, "C5": 2048}[args.config]
+            default_sample = {"C2": 16384, "C2H": 16384, "C3": 8192, "C4": 16384, "C4A": 16384, "C5": 2048, "B4": 256}[args.config]
             sample = min(n_units, args.cpu_sample_units or default_sample)
             t0 = time.perf_counter()
-            if is_s2:
+            kind_cpu = "port"
+            if is_s2 and cfg.get("variant") == "amd64":
+                import oracle_ref  # oracle/_ref: the reference's own assembly encoders
+                ref, ref_off = oracle_ref.encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], level=args.s2_level, threads=cores)
+                kind_cpu = "reference"
+            elif is_s2:
                 ref, ref_off = oracle_lib.s2_encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], threads=cores,
                                                            level=args.s2_level)
             else:
@@ -408,7 +417,7 @@ def main():
                     kw.update(dict_id=1, dict_content=dict_content)
                 ref, ref_off = oracle_lib.zstd_encode_units(host[:sample * UNIT], unit_off[:sample + 1], threads=cores, **kw)
             cdt = time.perf_counter() - t0
-            cpu = {"value": round(sample * UNIT / cdt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
+            cpu = {"value": round(sample * UNIT / cdt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": kind_cpu,
                    "sample": "first %d units (%.2f GiB) of the same corpus, %d std::threads (host has %d hardware threads%s)"
                              % (sample, sample * UNIT / 2**30, cores, host_threads, ", cgroup cpu.max allows %d CPUs" % quota if quota else "")}
             got = d_dst[:int(out_off[sample])].cpu().numpy()
@@ -469,7 +478,7 @@ def main():
         del d_dsts, d_dst, d_src
         torch.cuda.empty_cache()
         also = {}
-        for name in ("C2H", "C3", "C4", "C5"):
+        for name in ("C2H", "C3", "C4", "C4A", "C5"):
             cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(args.also_steps), "--warmup", "1", "--no-end-to-end",
                    "--no-also", "--cpu-sample-units", "1024", "--path", args.path]
             t0 = time.perf_counter()

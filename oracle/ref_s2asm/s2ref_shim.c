@@ -20,7 +20,7 @@ static int64_t call_block(void (*fn)(uint64_t*), uint8_t* dst, uint64_t dst_len,
     uint64_t f[8];
     void* tmp = aligned_alloc(64, (tmp_bytes + 63) & ~(size_t)63);
     if (!tmp) return -1;
-    memset(tmp, 0xA5, tmp_bytes);  // (the encoders clear their table themselves)
+    // (not cleared: the encoders clear their table themselves — the parity tests ran with this buffer poisoned)
     f[0] = (uint64_t)(uintptr_t)dst; f[1] = dst_len; f[2] = dst_len;
     f[3] = (uint64_t)(uintptr_t)src; f[4] = n; f[5] = n;
     f[6] = (uint64_t)(uintptr_t)tmp; f[7] = 0;
@@ -118,4 +118,65 @@ int64_t s2ref_encode_blocks_size(int level, const uint8_t* src, const uint64_t* 
         total += r;
     }
     return total;
+}
+
+// N blocks through s2ref_encode on `threads` host threads (the bench's cpu_baseline of kind "reference" and the byte compare of its
+// sample): the encoded blocks back to back in dst, out_off[i] = start of block i.  Returns the total, -2 when dst is too small.
+#include <pthread.h>
+struct blk_job {
+    int level;
+    const uint8_t* src;
+    const uint64_t* off;
+    uint32_t n;
+    uint8_t** outs;
+    int64_t* sizes;
+    uint32_t next;
+    pthread_mutex_t mu;
+    uint64_t maxlen;
+};
+static void* blk_worker(void* arg) {
+    struct blk_job* j = (struct blk_job*)arg;
+    const uint64_t cap = j->maxlen + j->maxlen / 6 + 64;
+    uint8_t* scratch = (uint8_t*)malloc(cap);
+    for (;;) {
+        pthread_mutex_lock(&j->mu);
+        const uint32_t i = j->next++;
+        pthread_mutex_unlock(&j->mu);
+        if (i >= j->n) break;
+        const uint64_t len = j->off[i + 1] - j->off[i];
+        const int64_t r = s2ref_encode(j->level, scratch, cap, j->src + j->off[i], len);
+        j->sizes[i] = r;
+        if (r > 0) {
+            j->outs[i] = (uint8_t*)malloc((size_t)r);
+            memcpy(j->outs[i], scratch, (size_t)r);
+        }
+    }
+    free(scratch);
+    return 0;
+}
+int64_t s2ref_encode_blocks(int level, const uint8_t* src, const uint64_t* off, uint32_t n, uint8_t* dst, uint64_t dst_cap, uint64_t* out_off,
+                            int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    struct blk_job j;
+    j.level = level; j.src = src; j.off = off; j.n = n; j.next = 0; j.maxlen = 32;
+    for (uint32_t i = 0; i < n; i++) if (off[i + 1] - off[i] > j.maxlen) j.maxlen = off[i + 1] - off[i];
+    j.outs = (uint8_t**)calloc(n ? n : 1, sizeof(uint8_t*));
+    j.sizes = (int64_t*)calloc(n ? n : 1, sizeof(int64_t));
+    pthread_mutex_init(&j.mu, 0);
+    pthread_t th[256];
+    for (int t = 0; t < threads; t++) pthread_create(&th[t], 0, blk_worker, &j);
+    for (int t = 0; t < threads; t++) pthread_join(th[t], 0);
+    int64_t pos = 0, rc = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        out_off[i] = (uint64_t)pos;
+        if (j.sizes[i] <= 0) rc = -1;
+        else if ((uint64_t)(pos + j.sizes[i]) > dst_cap) rc = -2;
+        else { memcpy(dst + pos, j.outs[i], (size_t)j.sizes[i]); pos += j.sizes[i]; }
+        free(j.outs[i]);
+    }
+    out_off[n] = (uint64_t)pos;
+    free(j.outs); free(j.sizes);
+    pthread_mutex_destroy(&j.mu);
+    return rc < 0 ? rc : pos;
 }

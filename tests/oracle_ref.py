@@ -63,6 +63,25 @@ def encode(src: bytes, level=0) -> bytes:
     return buf.raw[:r]
 
 
+def encode_blocks(src, blk_off, level=0, threads=1):
+    """N x s2.Encode / ... of the amd64 build on `threads` host threads: (numpy u8 of the blocks back to back, out_off[n+1])."""
+    import numpy as np
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    blk_off = np.ascontiguousarray(blk_off, dtype=np.uint64)
+    n = len(blk_off) - 1
+    cap = sum(max_encoded_len(int(blk_off[i + 1] - blk_off[i])) for i in range(n)) + 64 if n < 100000 else int((blk_off[n] - blk_off[0]) * 1.2) + 64 * n
+    dst = np.empty(cap, dtype=np.uint8)
+    oo = np.zeros(n + 1, dtype=np.uint64)
+    L = lib()
+    L.s2ref_encode_blocks.restype = C.c_int64
+    L.s2ref_encode_blocks.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+    pad = np.concatenate([src, np.zeros(16, dtype=np.uint8)])
+    r = L.s2ref_encode_blocks(level, pad.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, oo.ctypes.data, int(threads))
+    if r < 0:
+        raise RuntimeError("s2ref_encode_blocks failed: %d" % r)
+    return dst[:r], oo
+
+
 def emit(kind, offset, length) -> bytes:
     """emitRepeat / emitCopy / emitCopyNoRepeat of the assembly (kind: 'repeat', 'copy', 'copy_norepeat')."""
     buf = C.create_string_buffer(64)
