@@ -5,7 +5,9 @@
 // as the checker for tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 // Nothing under compress_amd/ (the product) may include, link or call it.
 //
-// PARITY STATUS: "parity unpinned" at whole-encoder level — the reference has no test
+// PARITY STATUS: s2.Encode / s2.EncodeSnappy in their amd64 assembly form are PINNED: oracle/_ref runs the reference's own
+// assembly encoders and kco_s2_asm.h equals them byte for byte (tests/test_ref_s2asm.py).  Everything else is
+// "parity unpinned" at whole-encoder level — the reference has no test
 // that fixes encoder output bytes and no Go toolchain exists here, so the
 // oracle is pinned by (1) the reference's KATs (XXH64, matchLen, S2 emitLiteral/emitCopy,
 // MaxEncodedLen), (2) frame-boundary KATs for C1 (e.txt header/trailer), and (3) every
