@@ -625,6 +625,10 @@ int64_t kco_s2_decode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap
 int64_t kco_s2_encode_asm(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap, int snappy) {
     return s2::EncodeAsm(dst, cap, src, (size_t)n, snappy != 0);
 }
+// level: 0 s2.Encode, 1 EncodeBetter, 2 EncodeSnappy, 3 EncodeSnappyBetter
+int64_t kco_s2_encode_asm_level(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap, int level) {
+    return s2::EncodeAsm(dst, cap, src, (size_t)n, level == 2 || level == 3, level == 1 || level == 3);
+}
 
 uint32_t kco_s2_crc(const uint8_t* p, uint64_t n) { return s2::crc(p, (size_t)n); }
 

@@ -171,15 +171,150 @@ static inline int encodeBlockAsm(uint8_t* dst, const uint8_t* src, size_t n, boo
     return encodeBlockAsmT<8, 4, 4, 3, true>(dst, src, n);
 }
 
-// s2.Encode / s2.EncodeSnappy of an amd64 build (s2/encode.go:29-57, 204-246)
-static inline int64_t EncodeAsm(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n, bool snappy) {
+
+// genEncodeBetterBlockAsm(name, lTableBits LB, sTableBits SB, skipLog SKIP, lHashBytes LHB, maxLen) (gen.go:873-1655), o.maxSkip
+// MAXSKIP (0: none), output margin OM (6; 9 for the Snappy-compatible forms), BIGOFF: maxLen - 1 > 65535
+template <int LB, int SB, int SKIP, int LHB, int LITOVH, int MAXSKIP, int OM, bool BIGOFF, bool SNAPPY>
+static int encodeBetterBlockAsmT(uint8_t* dst, const uint8_t* src, size_t srcLen) {
+    std::vector<uint32_t> lTable((size_t)1 << LB, 0u), sTable((size_t)1 << SB, 0u);
+    const int len = (int)srcLen;
+    const int sLimit = len - 8;
+    const int dstLimit = (len - OM) - (len >> 5);
+    int nextEmit = 0, s = 1, repeat = 0, d = 0;
+    auto HL = [](uint64_t v) -> uint32_t {
+        const uint64_t prime = LHB == 5 ? 889523592379ULL : (LHB == 6 ? 227718039650203ULL : 58295818150454627ULL);
+        return (uint32_t)(((v << (64 - 8 * LHB)) * prime) >> (64 - LB));
+    };
+    auto HS = [](uint64_t v) -> uint32_t { return (uint32_t)(((v << 32) * 2654435761ULL) >> (64 - SB)); };
+    auto emitLits = [&](int until) {
+        if (until == nextEmit) return;
+        d += emitLiteral(dst + d, src + nextEmit, (size_t)(until - nextEmit));
+        nextEmit = until;
+    };
+    for (;;) {  // search_loop
+        int nextS;
+        {
+            const int t = (s - nextEmit) >> SKIP;
+            if (MAXSKIP != 0 && t > MAXSKIP - 1) nextS = s + MAXSKIP;
+            else nextS = s + 1 + t;
+        }
+        if (nextS >= sLimit) break;
+        uint64_t cv = load64(src, s);
+        const uint32_t hashL = HL(cv), hashS = HS(cv);
+        int candidate = (int)lTable[hashL];
+        const int candidateS = (int)sTable[hashS];
+        lTable[hashL] = (uint32_t)s;
+        sTable[hashS] = (uint32_t)s;
+        const uint64_t longVal = load64(src, candidate), shortVal = load64(src, candidateS);
+        if (longVal == cv) {
+        } else if (shortVal == cv) {
+            candidate = candidateS;
+        } else if ((uint32_t)longVal == (uint32_t)cv) {
+        } else if ((uint32_t)shortVal == (uint32_t)cv) {
+            // short match at s: try a long candidate at s+1 (:1268-1288)
+            cv >>= 8;
+            const uint32_t h = HL(cv);
+            candidate = (int)lTable[h];
+            s++;
+            lTable[h] = (uint32_t)s;
+            if (load32(src, candidate) != (uint32_t)cv) {
+                s--;
+                candidate = candidateS;
+            }
+        } else {
+            s = nextS;
+            continue;
+        }
+        // candidate_match: extend backwards
+        if (candidate != 0) {
+            for (;;) {
+                if (s <= nextEmit) break;
+                if (src[candidate - 1] != src[s - 1]) break;
+                s--;
+                candidate--;
+                if (candidate == 0) break;
+            }
+        }
+        if (d + (s - nextEmit) + LITOVH >= dstLimit) return 0;
+        const int base = s;
+        s += 4;
+        candidate += 4;
+        int length = asmMatchLen(src + s, src + candidate, len - s);
+        const int offset = s - candidate;
+        if (!SNAPPY && repeat == offset) {
+            emitLits(base);
+            s += length;
+            length += 4;
+            nextEmit = s;
+            d += emitRepeat(dst + d, offset, length);
+        } else {
+            if (BIGOFF && length <= 1 && offset > 65535) {  // equal or worse than the encoding (:1369-1379)
+                s = nextS + 1;
+                continue;
+            }
+            repeat = offset;
+            emitLits(base);
+            s += length;
+            length += 4;
+            nextEmit = s;
+            d += SNAPPY ? emitCopyNoRepeat(dst + d, offset, length) : emitCopy(dst + d, offset, length);
+        }
+        if (s >= sLimit) break;
+        if (d >= dstLimit) return 0;
+        {   // index base+1 / s-2 into both tables, then the long table sparsely from both ends (:1429-1484)
+            int64_t index0 = base + 1, index1 = s - 2;
+            const uint32_t h0l = HL(load64(src, index0)), h0s = HS(load64(src, index0 + 1));
+            const uint32_t h1l = HL(load64(src, index1)), h1s = HS(load64(src, index1 + 1));
+            lTable[h0l] = (uint32_t)index0;
+            lTable[h1l] = (uint32_t)index1;
+            sTable[h0s] = (uint32_t)(index0 + 1);
+            sTable[h1s] = (uint32_t)(index1 + 1);
+            int64_t index2 = (index0 + index1 + 1) >> 1;
+            index0 += 1;
+            index1 -= 1;
+            while (index2 < index1) {
+                const uint32_t a = HL(load64(src, index0)), b = HL(load64(src, index2));
+                lTable[a] = (uint32_t)index0;
+                lTable[b] = (uint32_t)index2;
+                index0 += 2;
+                index2 += 2;
+            }
+        }
+    }
+    if (d + (len - nextEmit) + LITOVH >= dstLimit) return 0;
+    emitLits(len);
+    return d;
+}
+
+// s2/encode_amd64.go:99-166 encodeBlockBetter and :249-316 encodeBlockBetterSnappy
+static inline int encodeBlockBetterAsm(uint8_t* dst, const uint8_t* src, size_t n, bool snappy) {
+    const size_t limit12B = 16 << 10, limit10B = 4 << 10, limit8B = 512;
+    if (!snappy) {
+        if (n > ((size_t)4 << 20)) return encodeBetterBlockAsmT<17, 14, 7, 7, 5, 100, 6, true, false>(dst, src, n);   // encodeBetterBlockAsm
+        if (n >= limit12B) return encodeBetterBlockAsmT<17, 14, 7, 7, 4, 100, 6, true, false>(dst, src, n);           // ...4MB
+        if (n >= limit10B) return encodeBetterBlockAsmT<14, 12, 6, 6, 3, 0, 6, false, false>(dst, src, n);            // ...12B
+        if (n >= limit8B) return encodeBetterBlockAsmT<12, 10, 5, 6, 3, 0, 6, false, false>(dst, src, n);             // ...10B
+        if (n < (size_t)minNonLiteralBlockSize) return 0;
+        return encodeBetterBlockAsmT<10, 8, 4, 6, 3, 0, 6, false, false>(dst, src, n);                                // ...8B
+    }
+    if (n > 65536) return encodeBetterBlockAsmT<17, 14, 7, 7, 5, 100, 9, true, true>(dst, src, n);                    // encodeSnappyBetterBlockAsm
+    if (n >= limit12B) return encodeBetterBlockAsmT<16, 13, 7, 7, 3, 0, 9, false, true>(dst, src, n);                 // ...64K
+    if (n >= limit10B) return encodeBetterBlockAsmT<14, 12, 6, 6, 3, 0, 9, false, true>(dst, src, n);
+    if (n >= limit8B) return encodeBetterBlockAsmT<12, 10, 5, 6, 3, 0, 9, false, true>(dst, src, n);
+    if (n < (size_t)minNonLiteralBlockSize) return 0;
+    return encodeBetterBlockAsmT<10, 8, 4, 6, 3, 0, 9, false, true>(dst, src, n);
+}
+
+// s2.Encode / s2.EncodeSnappy (better = false), s2.EncodeBetter / s2.EncodeSnappyBetter (true) of an amd64 build
+// (s2/encode.go:29-57, 117-144, 204-276)
+static inline int64_t EncodeAsm(uint8_t* dst, uint64_t cap, const uint8_t* src, size_t n, bool snappy, bool better = false) {
     const int64_t m = MaxEncodedLen((int64_t)n);
     if (m < 0) return -1;
     if (cap < (uint64_t)m) return -2;
     int d = putUvarint(dst, (uint64_t)n);
     if (n == 0) return d;
     if (n < (size_t)minNonLiteralBlockSize) { d += emitLiteral(dst + d, src, n); return d; }
-    const int k = encodeBlockAsm(dst + d, src, n, snappy);
+    const int k = better ? encodeBlockBetterAsm(dst + d, src, n, snappy) : encodeBlockAsm(dst + d, src, n, snappy);
     if (k > 0) return d + k;
     d += emitLiteral(dst + d, src, n);
     return d;

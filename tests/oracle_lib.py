@@ -331,15 +331,15 @@ def s2_encode_block(src: bytes) -> bytes:
     return buf.raw[:r]
 
 
-def s2_encode_asm(src: bytes, snappy=False) -> bytes:
-    """s2.Encode / s2.EncodeSnappy as an amd64 build of the reference writes them: the oracle's restatement of the assembly
-    encoders (oracle/kco_s2_asm.h), pinned against the assembly itself by tests/test_ref_s2asm.py."""
+def s2_encode_asm(src: bytes, snappy=False, better=False) -> bytes:
+    """s2.Encode / EncodeBetter / EncodeSnappy / EncodeSnappyBetter as an amd64 build of the reference writes them: the oracle's
+    restatement of the assembly encoders (oracle/kco_s2_asm.h), pinned against the assembly itself by tests/test_ref_s2asm.py."""
     L = lib()
-    L.kco_s2_encode_asm.restype = C.c_int64
-    L.kco_s2_encode_asm.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int]
+    L.kco_s2_encode_asm_level.restype = C.c_int64
+    L.kco_s2_encode_asm_level.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int]
     cap = L.kco_s2_max_encoded_len(len(src)) + 64
     buf = C.create_string_buffer(cap)
-    r = L.kco_s2_encode_asm(src, len(src), buf, cap, int(bool(snappy)))
+    r = L.kco_s2_encode_asm_level(src, len(src), buf, cap, (2 if snappy else 0) + (1 if better else 0))
     if r < 0:
         raise RuntimeError("s2 encode_asm failed %d" % r)
     return buf.raw[:r]

@@ -82,14 +82,14 @@ def _pin_inputs():
 
 def test_oracle_restatement_of_the_assembly_is_pinned(oracle):
     """oracle/kco_s2_asm.h (the assembly encoders restated from their generator) == the assembly itself, byte for byte, for
-    s2.Encode and s2.EncodeSnappy: every size class of encode_amd64.go, the reference's regression inputs, edge and stress units,
+    s2.Encode, s2.EncodeBetter, s2.EncodeSnappy and s2.EncodeSnappyBetter: every size class of encode_amd64.go, the reference's regression inputs, edge and stress units,
     low-entropy noise.  This is the one whole-encoder path of the oracle that is PINNED by running the reference."""
     bad = []
     ins = _pin_inputs()
     for i, u in enumerate(ins):
-        for snappy, lvl in ((False, 0), (True, 2)):
-            if oracle.s2_encode_asm(u, snappy) != oracle_ref.encode(u, lvl):
-                bad.append((i, len(u), snappy))
+        for lvl in range(4):  # s2.Encode, EncodeBetter, EncodeSnappy, EncodeSnappyBetter
+            if oracle.s2_encode_asm(u, snappy=lvl >= 2, better=bool(lvl & 1)) != oracle_ref.encode(u, lvl):
+                bad.append((i, len(u), lvl))
     assert not bad, bad[:10]
     assert len(ins) > 500
 
