@@ -2094,8 +2094,8 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     // s2.Encode / s2.EncodeSnappy: the LDS-table kernel (one wave per block, ~1 ms per 64 KiB block whatever the batch) while the
     // blocks in flight cannot cover the HBM-table kernel's latency (measured crossover: profiles/r03_crossover_s2.csv)
     const bool asmv = c->cfg.s2_variant == KC_S2_VARIANT_AMD64;
-    if (asmv && level != KC_S2_LEVEL_DEFAULT && level != KC_S2_LEVEL_SNAPPY) {
-        c->err = "KC_S2_VARIANT_AMD64 serves s2.Encode and s2.EncodeSnappy (the assembly forms of the other levels are not built)";
+    if (asmv && level >= KC_S2_LEVEL_BEST) {
+        c->err = "KC_S2_VARIANT_AMD64 does not apply to the best levels (pure Go in the reference: one form only)";
         return KC_ERR_UNSUPPORTED;
     }
     const bool lds = (level == KC_S2_LEVEL_DEFAULT || level == KC_S2_LEVEL_SNAPPY) && feed == nullptr && c->cfg.match_path != KC_PATH_HBM &&
@@ -2104,12 +2104,12 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     kc_status s;
     if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) ||
         (s = ensure(c, c->out_off, (n + 1 + (feed ? feed->cut.size() : 0)) * 8)) || (s = ensure(c, c->stage, acc + 64)) || (s = ensure(c, c->out_size, (size_t)n * 4)) ||
-        (!lds && (s = ensure(c, c->tables, (size_t)n * kc_s2_table_bytes(level, maxLen)))))
+        (!lds && (s = ensure(c, c->tables, (size_t)n * kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant)))))
         return s;
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->stage_off.p, so.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    if (!lds) HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen), st));
+    if (!lds) HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant), st));
     KcS2Params P;
     P.src = d_src + blk_off[0];
     P.blk_off = (const uint64_t*)c->unit_off.p;
@@ -2125,7 +2125,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     P.spec_grow = c->cfg.spec_grow >= 0 ? (int)c->cfg.spec_grow : 1;
     if (P.spec_w0 < 1) P.spec_w0 = 1;
     if (P.spec_w0b < 1) P.spec_w0b = 1;
-    P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen) / 4);
+    P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant) / 4);
     P.variant = (int32_t)c->cfg.s2_variant;
     if (feed) {
         // the source is still arriving: per chunk, encode + compaction on the chunk's stream behind its H2D copy; frames of chunk k
@@ -2284,7 +2284,7 @@ static kc_status s2_encode_dev_budgeted(kc_ctx* c, const uint8_t* d_src, const u
     if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BEST || n == 0) return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, framed, with_stream_id, level);
     uint64_t maxLen = 0;
     for (uint32_t i = 0; i < n; i++) if (blk_off[i + 1] >= blk_off[i]) maxLen = std::max(maxLen, blk_off[i + 1] - blk_off[i]);
-    const uint64_t tb = kc_s2_table_bytes(level, maxLen);
+    const uint64_t tb = kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant);
     uint64_t budget = scratch_budget(c);
     std::vector<uint64_t> tmp;
     uint64_t pos = 0;

@@ -157,7 +157,10 @@ struct KcZstdDecParams {
 };
 void kc_launch_zstd_decode(const KcZstdDecParams& P, hipStream_t st);
 // default: 2^14 entries; better: long 2^17 + short 2^14 (blocks > 64 KiB), long 2^16 + short 2^13 (all blocks <= 64 KiB)
-static inline size_t kc_s2_table_bytes(int level, uint64_t max_block_len) {
+static inline size_t kc_s2_table_bytes(int level, uint64_t max_block_len, int variant = 0) {
+    // the assembly forms of the better levels take 2^17 + 2^14 entries from 16 KiB on (Snappy-compatible: above 64 KiB; 2^16 + 2^13 below)
+    if (variant == 1 && level == 1 && max_block_len >= ((uint64_t)16 << 10)) return ((size_t)4 << 17) + ((size_t)4 << 14);
+    if (variant == 1 && level == 3) return max_block_len > ((uint64_t)64 << 10) ? (((size_t)4 << 17) + ((size_t)4 << 14)) : (((size_t)4 << 16) + ((size_t)4 << 13));
     if (level >= 4) return ((size_t)8 << 19) + ((size_t)8 << 16);  // best: long 2^19 + short 2^16 entries of {cur, prev}
     if (level == 3) return max_block_len > ((uint64_t)64 << 10) ? (((size_t)4 << 16) + ((size_t)4 << 14)) : (((size_t)4 << 15) + ((size_t)4 << 13));
     if (level != 1) return (size_t)4 << 14;

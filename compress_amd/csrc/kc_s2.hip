@@ -215,7 +215,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     bool smallRep = false;  // the assembly's emitRepeat as generated into encodeBlockAsm8B (see below)
     auto emit_repeat = [&](int offset, int length) -> int {
         if (smallRep && length > 8 && length < 12) {  // no two-byte offset form there: gen.go:1991-1994 leaves its test (and jump) out
-            if (lig == 0) { dst[d] = (uint8_t)(5 << 2 | 1); dst[d + 1] = 0; dst[d + 2] = (uint8_t)(length - 8); }
+            if (RING) emit_op((uint64_t)(5 << 2 | 1) | ((uint64_t)(length - 8) << 16), 0, 3);
+            else if (lig == 0) { dst[d] = (uint8_t)(5 << 2 | 1); dst[d + 1] = 0; dst[d + 2] = (uint8_t)(length - 8); }
             return 3;
         }
         if (!RING) { if (lig == 0) s2_emit_repeat1(dst + d, offset, length); return s2_repeat_size(offset, length); }
@@ -411,8 +412,28 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         // inside the probe loop is dead code in the reference (`if false && ...`).  Entries: position | tag(4 bytes) << PB, 0 = empty
         // (== candidate 0, verified on the bytes only, as the reference does).
         const bool big = len > (64 << 10);
-        const int LB = SNB ? (big ? 16 : 15) : (big ? 17 : 16), SB = big ? 14 : 13, SKIP = big ? 7 : 6;
-        auto skipOf = [&](int dist) -> int { const int k = (dist >> SKIP) + 1; return SNB && k > 100 ? 100 : k; };  // nextS - s
+        int LB = SNB ? (big ? 16 : 15) : (big ? 17 : 16), SB = big ? 14 : 13, SKIP = big ? 7 : 6;
+        int MAXSKIP = SNB ? 100 : 0, LSHL = 8, LITOVH = 0, OM = 6;
+        uint64_t LPRIME = 58295818150454627ULL;  // hash7
+        bool bigoff = big;
+        // P.variant 1: the amd64 assembly forms (s2/encode_amd64.go:99-166, 249-316; generator gen.go:873-1655): per size class other
+        // table sizes / long-hash length / skip rate, the skip capped at 100 in the large classes of BOTH levels, the 8-byte
+        // candidate tests also at the Snappy-compatible level, output margin 6 (9 Snappy-compatible) with the literal header's
+        // worst case in every bail-out test, `nextS >= sLimit`.
+        const bool AX = P.variant == 1;
+        if (AX) {
+            OM = SNB ? 9 : 6;
+            const bool top = SNB ? len > 65536 : len > (4 << 20);
+            if (top) { LB = 17; SB = 14; SKIP = 7; MAXSKIP = 100; LITOVH = 5; bigoff = true; }
+            else if (len >= (16 << 10)) {
+                if (SNB) { LB = 16; SB = 13; SKIP = 7; MAXSKIP = 0; LITOVH = 3; bigoff = false; }       // encodeSnappyBetterBlockAsm64K
+                else { LB = 17; SB = 14; SKIP = 7; MAXSKIP = 100; LITOVH = 4; bigoff = true; }          // encodeBetterBlockAsm4MB
+            }
+            else if (len >= (4 << 10)) { LB = 14; SB = 12; SKIP = 6; MAXSKIP = 0; LITOVH = 3; bigoff = false; LSHL = 16; LPRIME = KC_PRIME6; }
+            else if (len >= 512) { LB = 12; SB = 10; SKIP = 5; MAXSKIP = 0; LITOVH = 3; bigoff = false; LSHL = 16; LPRIME = KC_PRIME6; }
+            else { LB = 10; SB = 8; SKIP = 4; MAXSKIP = 0; LITOVH = 3; bigoff = false; LSHL = 16; LPRIME = KC_PRIME6; smallRep = !SNB; }
+        }
+        auto skipOf = [&](int dist) -> int { const int k = (dist >> SKIP) + 1; return MAXSKIP != 0 && k > MAXSKIP ? MAXSKIP : k; };  // nextS - s
         uint32_t* __restrict__ ltab = tab;
         uint32_t* __restrict__ stab = tab + (1u << LB);
         const int PB = bits_len32((uint32_t)len);
@@ -420,10 +441,13 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         const uint32_t posMask = (1u << PB) - 1u;
         auto tagOf = [&](uint32_t v) -> uint32_t { return (v * 2654435761u) >> (32 - TB); };
         auto mk = [&](int pos, uint32_t val) -> uint32_t { return (uint32_t)pos | (tagOf(val) << PB); };
-        auto hL = [&](uint64_t v) -> uint32_t { return (uint32_t)(((v << 8) * 58295818150454627ULL) >> (64 - LB)); };  // hash7
+        auto hL = [&](uint64_t v) -> uint32_t { return (uint32_t)(((v << LSHL) * LPRIME) >> (64 - LB)); };  // hash7 (hash6 in the small assembly classes)
         auto hS = [&](uint64_t v) -> uint32_t { return ((uint32_t)v * KC_PRIME4) >> (32 - SB); };                      // hash4
         const int sLimit = len - 8;
-        const int dstLimit = len - (len >> 5) - 6;
+        const int sLimT = AX ? sLimit - 1 : sLimit;
+        const int dstLimit = (len - OM) - (len >> 5);
+        const int bailLim = AX ? dstLimit - LITOVH - 1 : dstLimit;
+        const int cpLim = AX ? dstLimit - 1 : dstLimit;
         int nextEmit = 0, s = 1, repeat = 0;
         bool fin = false;
         int W = G;
@@ -434,8 +458,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
             const int p = s + lig * step;
             const bool inseg = lig == 0 || ((d0 + (lig - 1) * step) >> SKIP) == k0;
             const int nextS = p + skipOf(p - nextEmit);
-            const bool valid = lig < W && inseg && nextS <= sLimit;
-            const bool term = inseg && nextS > sLimit;  // this step would `goto emitRemainder`
+            const bool valid = lig < W && inseg && nextS <= sLimT;
+            const bool term = inseg && nextS > sLimT;  // this step would `goto emitRemainder`
             uint64_t cv = 0;
             uint32_t hl = 0xFFFFFFF0u, hs = 0xFFFFFFF1u, eL = 0, eS = 0;
             if (valid) {
@@ -458,8 +482,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 const bool okS = eS == 0 || (eS >> PB) == tagOf((uint32_t)cv);
                 const uint64_t vL = okL ? ld64(src + cL) : ~cv;
                 const uint64_t vS = okS ? ld64(src + cS) : ~cv;
-                if (!SNB && cv == vL) { kind = 1; cand = cL; }
-                else if (!SNB && cv == vS) { kind = 2; cand = cS; }
+                if ((AX || !SNB) && cv == vL) { kind = 1; cand = cL; }
+                else if ((AX || !SNB) && cv == vS) { kind = 2; cand = cS; }
                 else if ((uint32_t)cv == (uint32_t)vL) { kind = 3; cand = cL; }
                 else if ((uint32_t)cv == (uint32_t)vS) { kind = 4; cand = cS; }
             }
@@ -513,14 +537,14 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 candidate -= back;
                 s -= back;
             }
-            if (d + (s - nextEmit) > dstLimit) { stored = true; continue; }
+            if (d + (s - nextEmit) > bailLim) { stored = true; continue; }
             const int base = s;
             const int offset = base - candidate;
             const int l = 4 + grp_matchlen<S2G>(src, s + 4, candidate + 4, len - (s + 4), lig, grp);
             s = base + l;
-            if (big && offset > 65535 && l <= 5 && repeat != offset) {  // the match is equal or worse to the encoding (:221-229)
+            if (bigoff && offset > 65535 && l <= 5 && ((AX && SNB) || repeat != offset)) {  // the match is equal or worse to the encoding (:221-229)
                 s = nextSw + 1;
-                if (s >= sLimit) fin = true;
+                if (!AX && s >= sLimit) fin = true;  // (the assembly goes back to the search loop, whose nextS test ends the block)
                 continue;
             }
             d += emit_lit(nextEmit, base - nextEmit);
@@ -536,7 +560,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
             }
             nextEmit = s;
             if (s >= sLimit) { fin = true; continue; }
-            if (d > dstLimit) { stored = true; continue; }
+            if (d > cpLim) { stored = true; continue; }
             // index short & long at base+1 and s-2 (:252-262), in program order on one lane
             int index0 = base + 1, index1 = s - 2;
             {
@@ -572,9 +596,9 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
             }
         }
         if (!stored) {
-            if (nextEmit < len) {  // emitRemainder (:277-284)
-                if (d + len - nextEmit > dstLimit) stored = true;
-                else d += emit_lit(nextEmit, len - nextEmit);
+            if (AX || nextEmit < len) {  // emitRemainder (:277-284); the assembly tests the bail-out even with nothing left
+                if (d + len - nextEmit > bailLim) stored = true;
+                else if (nextEmit < len) d += emit_lit(nextEmit, len - nextEmit);
             }
         }
     }

@@ -95,6 +95,25 @@ def test_oracle_restatement_of_the_assembly_is_pinned(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 3])
+def test_device_amd64_variant_better_levels_equal_the_assembly(oracle, kclib, level):
+    """The same for s2.EncodeBetter (1) and s2.EncodeSnappyBetter (3)."""
+    pytest.importorskip("torch")
+    from compress_amd import s2
+    ins = _pin_inputs()
+    b2, off = corpora.pack_units(ins)
+    enc = s2.BlockEncoder(level=level, variant="amd64")
+    out, out_off = enc.EncodeBlocks(b2, off)
+    bad = []
+    for i, u in enumerate(ins):
+        got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+        if got != oracle_ref.encode(u, level):
+            bad.append((i, len(u), len(got), len(oracle_ref.encode(u, level))))
+    assert not bad, bad[:10]
+    enc.Close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("snappy", [False, True])
 def test_device_amd64_variant_equals_the_assembly(oracle, kclib, snappy):
     """KC_S2_VARIANT_AMD64 on the device == the reference's assembly encoders (and the oracle's restatement of them), on the same
