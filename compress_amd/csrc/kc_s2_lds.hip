@@ -186,6 +186,33 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
             b += 512;
         }
     };
+    // the assembly's matchLen (gen.go:2778-2880): the exact common prefix up to the end of the block; returns the new a
+    auto extend_exact = [&](int a, int b) -> int {
+        for (;;) {
+            const int pa = a + 8 * lane, pb = b + 8 * lane;
+            const bool inb = pa + 8 <= len;
+            uint64_t diff = 0;
+            if (inb) diff = rd64(pa) ^ rd64(pb);
+            const uint64_t oob = ballot64(!inb);
+            const uint64_t dm = ballot64(inb && diff != 0);
+            const int firstOob = oob ? ctz64(oob) : 64;
+            if (dm) {
+                const int fl = ctz64(dm);
+                const uint64_t dd = rdlane64(diff, fl);
+                return a + 8 * fl + (ctz64(dd) >> 3);
+            }
+            if (firstOob < 64) {
+                const int t = a + 8 * firstOob, tb = b + 8 * firstOob;
+                const int rem = len - t;  // 0..7
+                const bool ne = lane < rem && rdb(t + lane) != rdb(tb + lane);
+                const uint64_t nm = ballot64(ne);
+                const int k = nm ? ctz64(nm) : rem;
+                return t + (k < rem ? k : rem);
+            }
+            a += 512;
+            b += 512;
+        }
+    };
     // number of k = 1..kmax with src[t-k] == src[s-k], consecutively (the backward extension loops)
     auto backlen = [&](int sp, int tp, int kmax) -> int {
         if (kmax <= 0 || rdb(tp - 1) != rdb(sp - 1)) return 0;  // the usual case, decided on one (wave-uniform) byte pair
@@ -203,7 +230,12 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
     };
     // emitCopy / emitRepeat (encode_go.go:118-234): at most 10 bytes for blocks below 16 MiB, assembled in two registers by every
     // lane (uniform), stored by lane 0 as one or two 8-byte words
+    bool smallRep = false;  // the assembly's emitRepeat as generated into encodeBlockAsm8B: no two-byte offset form (kc_s2.hip)
     auto emit_copy_any = [&](int offset, int length, bool asRepeat) -> int {
+        if (asRepeat && smallRep && length > 8 && length < 12) {
+            if (lane == 0) { dst[d] = (uint8_t)(5 << 2 | 1); dst[d + 1] = 0; dst[d + 2] = (uint8_t)(length - 8); }
+            return 3;
+        }
         if (SNAPPY) { if (lane == 0) s2_emit_copy_nr1(dst + d, offset, length); return s2_copy_nr_size(offset, length); }  // (can be hundreds of 3-byte operations)
         uint64_t lo = 0, hi = 0;
         auto sink = [&](int k, uint8_t v) { if (k < 8) lo |= (uint64_t)v << (8 * k); else hi |= (uint64_t)v << (8 * (k - 8)); };
@@ -216,9 +248,24 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
     };
 
     if (!stored) {
-        const int SKIP = len <= (64 << 10) ? 5 : 6;  // encodeBlockGo64K vs encodeBlockGo (encode_go.go:23-26)
+        int SKIP = len <= (64 << 10) ? 5 : 6;  // encodeBlockGo64K vs encodeBlockGo (encode_go.go:23-26)
+        // P.variant 1: the amd64 assembly encoders' bytes (kc_s2.hip has the list of differences)
+        const bool AX = P.variant == 1;
+        int HSHL = 16, HSHR = 64 - S2_TABLE_BITS, LITOVH = 0;
+        uint64_t HPRIME = KC_PRIME6;
+        if (AX) {
+            const bool top = SNAPPY ? len > 65536 : len >= (4 << 20);
+            if (top || len >= (16 << 10)) { SKIP = 6; LITOVH = top ? 5 : (SNAPPY ? 3 : 4); }
+            else if (len >= (4 << 10)) { SKIP = 5; HSHL = 24; HPRIME = KC_PRIME5; HSHR = 64 - 12; LITOVH = 3; }
+            else if (len >= 512) { SKIP = 5; HSHL = 32; HPRIME = (uint64_t)KC_PRIME4; HSHR = 64 - 10; LITOVH = 3; }
+            else { SKIP = 4; HSHL = 32; HPRIME = (uint64_t)KC_PRIME4; HSHR = 64 - 8; LITOVH = 3; smallRep = !SNAPPY; }
+        }
+        auto hashOf = [&](uint64_t v) -> uint32_t { return (uint32_t)(((v << HSHL) * HPRIME) >> HSHR); };
         const int sLimit = len - 8;
-        const int dstLimit = len - (len >> 5) - 5;
+        const int sLimT = AX ? sLimit - 1 : sLimit;
+        const int dstLimit = AX ? (len - 9) - (len >> 5) : len - (len >> 5) - 5;
+        const int bailLim = AX ? dstLimit - LITOVH - 1 : dstLimit;
+        const int cpLim = AX ? dstLimit - 1 : dstLimit;
         int nextEmit = 0, s = 1, repeat = 1;
         bool fin = false;  // goto emitRemainder
         const int W0 = P.spec_w0 < 1 ? 1 : (P.spec_w0 > 64 ? 64 : P.spec_w0);
@@ -231,9 +278,9 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
             if (ONESTEP) {
                 // ---------------- one probe step, wave-uniform (encode_all.go:318-412) ----------------
                 const int nextS = s + ((s - nextEmit) >> SKIP) + 4;
-                if (nextS > sLimit) { fin = true; continue; }
+                if (nextS > sLimT) { fin = true; continue; }
                 const uint64_t cv = rdlane64(rd64(s), 0);
-                const uint32_t h0 = s2_hash6(cv), h1 = s2_hash6(cv >> 8), h2 = s2_hash6(cv >> 16);
+                const uint32_t h0 = hashOf(cv), h1 = hashOf(cv >> 8), h2 = hashOf(cv >> 16);
                 const uint32_t e0 = rdlane32(tab[h0], 0), e1 = rdlane32(tab[h1], 0);
                 const uint32_t wr = rdlane32(rd32(s - repeat + 1), 0);
                 KC_WAVE_SYNC();
@@ -268,13 +315,13 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
                 }
                 const int nextS = p + ((p - nextEmit) >> SKIP) + 4;
                 const bool inW = lane < W;
-                const bool valid = inW && nextS <= sLimit;  // a prefix of the lanes: nextS grows with the lane
-                const bool term = inW && nextS > sLimit;    // this step would `goto emitRemainder`
+                const bool valid = inW && nextS <= sLimT;  // a prefix of the lanes: nextS grows with the lane
+                const bool term = inW && nextS > sLimT;    // this step would `goto emitRemainder`
                 uint64_t cv = 0;
                 uint32_t h0 = 0, h1 = 0, h2 = 0, e0 = 0, e1 = 0, e2 = 0;
                 if (valid) {
                     cv = rd64(p);
-                    h0 = s2_hash6(cv); h1 = s2_hash6(cv >> 8); h2 = s2_hash6(cv >> 16);
+                    h0 = hashOf(cv); h1 = hashOf(cv >> 8); h2 = hashOf(cv >> 16);
                     tabB[4 * h0 + 3] = (uint8_t)lane;
                     tabB[4 * h1 + 3] = (uint8_t)lane;
                     tabB[4 * h2 + 3] = (uint8_t)lane;
@@ -354,9 +401,9 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
                     if (i0 < kmax) kmax = i0;
                     base -= backlen(base, i0, kmax);
                 }
-                if (d + (base - nextEmit) > dstLimit) { stored = true; continue; }
+                if (d + (base - nextEmit) > bailLim) { stored = true; continue; }
                 d += emit_lit(nextEmit, base - nextEmit);
-                s = extend(ps + 4 + 1, ps - repeat + 4 + 1, sLimit);
+                s = AX ? extend_exact(ps + 4 + 1, ps - repeat + 4 + 1) : extend(ps + 4 + 1, ps - repeat + 4 + 1, sLimit);
                 d += emit_copy_any(repeat, s - base, nextEmit > 0);
                 nextEmit = s;
                 if (s >= sLimit) fin = true;
@@ -371,19 +418,19 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
                 candidate -= back;
                 s -= back;
             }
-            if (d + (s - nextEmit) > dstLimit) { stored = true; continue; }
+            if (d + (s - nextEmit) > bailLim) { stored = true; continue; }
             d += emit_lit(nextEmit, s - nextEmit);
             for (;;) {
                 const int base = s;
                 repeat = base - candidate;
-                s = extend(s + 4, candidate + 4, len - 8);
+                s = AX ? extend_exact(s + 4, candidate + 4) : extend(s + 4, candidate + 4, len - 8);
                 d += emit_copy_any(repeat, s - base, false);
                 nextEmit = s;
                 if (s >= sLimit) { fin = true; break; }
-                if (d > dstLimit) { stored = true; break; }
+                if (d > cpLim) { stored = true; break; }
                 // check for an immediate match, otherwise start the search at s+1 (:474-488)
                 const uint64_t x = rd64(s - 2);
-                const uint32_t m2Hash = s2_hash6(x), currHash = s2_hash6(x >> 16);
+                const uint32_t m2Hash = hashOf(x), currHash = hashOf(x >> 16);
                 const uint32_t ec = tab[currHash];
                 KC_WAVE_SYNC();
                 if (lane == 0) { tab[m2Hash] = (uint32_t)(s - 2); tab[currHash] = (uint32_t)s; }
@@ -394,9 +441,9 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
         }
         if (!stored) {
             // emitRemainder (:491-499)
-            if (nextEmit < len) {
-                if (d + len - nextEmit > dstLimit) stored = true;
-                else d += emit_lit(nextEmit, len - nextEmit);
+            if (AX || nextEmit < len) {  // (the assembly tests the bail-out even when nothing is left to emit)
+                if (d + len - nextEmit > bailLim) stored = true;
+                else if (nextEmit < len) d += emit_lit(nextEmit, len - nextEmit);
             }
         }
     }

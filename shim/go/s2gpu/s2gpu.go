@@ -10,6 +10,7 @@ import "C"
 
 import (
 	"errors"
+	"runtime"
 	"sync"
 	"unsafe"
 
@@ -23,13 +24,30 @@ type Ctx struct {
 	mu sync.Mutex
 }
 
+// NewCtx creates a device context whose S2 blocks are byte-identical to what THIS build of the reference writes: on amd64 the
+// reference's block encoders are generated assembly with their own table sizes, hash lengths and skip rates per input size
+// (s2/encode_amd64.go), elsewhere — and under the `noasm` build tag — portable Go (s2/encode_all.go).  The device implements both
+// (KC_OPT_S2_VARIANT); a `noasm` amd64 build must call SetVariant(VariantGo), which a program cannot detect for itself.
 func NewCtx(device int) (*Ctx, error) {
 	var c *C.kc_ctx
 	if st := C.kc_ctx_create(&c, C.int(device), nil); st != C.KC_OK {
 		return nil, errors.New("no MI355X device")
 	}
-	return &Ctx{c: c}, nil
+	x := &Ctx{c: c}
+	if runtime.GOARCH == "amd64" {
+		x.SetVariant(VariantAMD64)
+	}
+	return x, nil
 }
+
+// Variants of the reference's block encoders (levels default, better and their Snappy-compatible forms; the best levels are
+// pure Go everywhere).
+const (
+	VariantGo    = 0 // s2/encode_all.go, s2/encode_better.go
+	VariantAMD64 = 1 // s2/encodeblock_amd64.s
+)
+
+func (x *Ctx) SetVariant(v int) { C.kc_ctx_set_option(x.c, C.KC_OPT_S2_VARIANT, C.int64_t(v)) }
 
 func (x *Ctx) Close() { C.kc_ctx_destroy(x.c) }
 

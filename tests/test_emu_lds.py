@@ -175,3 +175,22 @@ def test_zbest_parse_history_forms():
     u3 = [t[:20000], t[20000:50000], t[:20000]]
     got = emu_lib.zbest_parse(u3, n_slots=1, window=1 << 29, fresh=True)
     _cmp_parse(u3, got, level=4, window_size=1 << 29)
+
+
+@pytest.mark.parametrize("level,w0", [(0, 1), (0, 8), (2, 1), (2, 64)])
+def test_s2_lds_amd64_variant_equals_the_assembly_restatement(level, w0):
+    """KC_S2_VARIANT_AMD64 in the LDS-table kernel (one wave-uniform step at a time, and speculative rounds): every size class of
+    s2/encode_amd64.go against the oracle's restatement of the assembly encoders — which tests/test_ref_s2asm.py pins to the
+    assembly itself."""
+    rng = np.random.default_rng(11)
+    blocks = []
+    for kind in "JTM":
+        d = corpora.corpus(kind, 4, 131072).tobytes()
+        for n in (32, 100, 511, 512, 2000, 4095, 4096, 16383, 16384, 65535, 65536, 65537, 150000):
+            st = int(rng.integers(0, len(d) - n))
+            blocks.append(d[st:st + n])
+    blocks += [bytes(rng.integers(0, 4, int(rng.integers(32, 1500)), dtype=np.uint8)) for _ in range(60)]
+    blocks += [u for u in corpora.edge_units() if 0 < len(u) < 70000]
+    got = emu_lib.s2_encode_blocks(blocks, level=level, spec_w0=w0, variant=1)
+    bad = [(i, len(b)) for i, b in enumerate(blocks) if got[i] != oracle_lib.s2_encode_asm(b, snappy=level == 2)]
+    assert not bad, bad[:10]

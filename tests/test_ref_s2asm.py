@@ -114,16 +114,18 @@ def test_device_amd64_variant_better_levels_equal_the_assembly(oracle, kclib, le
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["hbm", "lds"])
 @pytest.mark.parametrize("snappy", [False, True])
-def test_device_amd64_variant_equals_the_assembly(oracle, kclib, snappy):
+def test_device_amd64_variant_equals_the_assembly(oracle, kclib, snappy, path):
     """KC_S2_VARIANT_AMD64 on the device == the reference's assembly encoders (and the oracle's restatement of them), on the same
     inputs: bytes produced by hand-written HIP against bytes produced by the reference's own code."""
     pytest.importorskip("torch")
     from compress_amd import s2
     ins = _pin_inputs()
     b2, off = corpora.pack_units(ins)
-    enc = s2.BlockEncoder(level=s2.LevelSnappy if snappy else s2.LevelDefault, variant="amd64")
+    enc = s2.BlockEncoder(level=s2.LevelSnappy if snappy else s2.LevelDefault, variant="amd64", path=path)
     out, out_off = enc.EncodeBlocks(b2, off)
+    assert enc._ctx.last_path() == path
     bad = []
     for i, u in enumerate(ins):
         got = out[int(out_off[i]):int(out_off[i + 1])].tobytes()

@@ -19,7 +19,8 @@ int kcemu_s2_encode(int level, int framed, int spec_w0, const uint8_t* src, cons
     P.stage = stage;
     P.out_size = out_size;
     P.n_blocks = n;
-    P.level = level;
+    P.level = level & 0xFF;
+    P.variant = level >> 8;  // (bits 8+: KC_S2_VARIANT_*)
     P.spec_w0 = spec_w0;
     P.framed = framed;
     bool small = false, big = false;
