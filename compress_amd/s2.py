@@ -108,6 +108,7 @@ class BlockEncoder:
 # ---------------------------------------------------------------------------------------------------------------------
 _MIN_BLOCK, _MAX_BLOCK, _DEFAULT_BLOCK = 4 << 10, 4 << 20, 1 << 20  # s2/encode.go minBlockSize/maxBlockSize, writer.go defaultBlockSize
 _MAGIC = b"\xff\x06\x00\x00S2sTwO"                                   # magicChunk (s2/s2.go)
+_MAGIC_SNAPPY = b"\xff\x06\x00\x00sNaPpY"                            # magicChunkSnappy (s2/s2.go:79-80)
 
 
 def WriterBlockSize(n):
@@ -148,7 +149,16 @@ def WriterBestCompression():
     return lambda w: setattr(w, "level", LevelBest)
 
 
-WriterSnappyCompat = _unsupported("WriterSnappyCompat")
+def WriterSnappyCompat():
+    """s2.WriterSnappyCompat (writer.go:1025-1037): Snappy-compatible output — the blocks through encodeBlockSnappy /
+    encodeBlockBetterSnappy / encodeBlockBestSnappy (no repeat codes), the "sNaPpY" stream identifier, blocks of at most 64 KiB - 8."""
+    def apply(w):
+        w.snappy = True
+        if w.blockSize > (64 << 10):
+            w.blockSize = (64 << 10) - 8
+    return apply
+
+
 WriterUncompressed = _unsupported("WriterUncompressed")
 
 
@@ -257,7 +267,7 @@ class Writer:
     boundaries (writer.go:182-218, 357-453, 483-571, 741-857); default, better or best level (WriterBetterCompression / WriterBestCompression).  Chunks are queued and
     encoded on the GPU in batches of `batch_bytes`; the bytes written equal the reference's for the same call sequence."""
 
-    def __init__(self, w, *opts, device=0, stream=None, batch_bytes=256 << 20):
+    def __init__(self, w, *opts, device=0, stream=None, batch_bytes=256 << 20, variant=None):
         self.blockSize = _DEFAULT_BLOCK
         self.concurrency = 1
         self.flushOnWrite = False
@@ -265,9 +275,14 @@ class Writer:
         self.pad = 0
         self.randSrc = None
         self.level = LevelDefault
+        self.snappy = False
         for o in opts:
             o(self)
-        self._enc = BlockEncoder(device, stream, level=self.level)
+        if self.snappy:  # (*Writer).encodeBlock, writer.go:1053-1091: the Snappy-compatible block encoder of the level
+            if self.blockSize > (64 << 10):
+                raise ValueError("s2: block size too large. Must be <= 64K and >=4KB on for snappy compatible output")  # writer.go:982
+            self.level = {LevelDefault: LevelSnappy, LevelBetter: LevelSnappyBetter, LevelBest: LevelSnappyBest}[self.level]
+        self._enc = BlockEncoder(device, stream, level=self.level, variant=variant)  # variant: see BlockEncoder
         self._device = device
         self._batch = int(batch_bytes)
         self.Reset(w)
@@ -411,7 +426,7 @@ class Writer:
         while i < len(q):
             if q[i][0] == "r":
                 if not self._wroteHeader:  # the stream identifier precedes the first output of any kind
-                    out.append((_MAGIC, self._flushedUncomp))
+                    out.append((_MAGIC_SNAPPY if self.snappy else _MAGIC, self._flushedUncomp))
                     self._wroteHeader = True
                 out.append((q[i][1], self._flushedUncomp))
                 i += 1
@@ -427,10 +442,12 @@ class Writer:
             cap = sum(((MaxEncodedLen(len(c)) + 8 + 15) & ~15) for c in chunks) + 64
             d_dst = torch.empty(cap, dtype=torch.uint8, device=d_src.device)
             with_id = not self._wroteHeader
-            oo = self._enc.EncodeStreamDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap, with_stream_id=with_id)
+            oo = self._enc.EncodeStreamDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap, with_stream_id=with_id and not self.snappy)
             self._wroteHeader = True
             blob = d_dst[:int(oo[-1])].cpu().numpy().tobytes()
-            if with_id:
+            if with_id and self.snappy:
+                out.append((_MAGIC_SNAPPY, self._flushedUncomp))
+            elif with_id:
                 out.append((blob[:int(oo[0])], self._flushedUncomp))
             for k, c in enumerate(chunks):
                 out.append((blob[int(oo[k]):int(oo[k + 1])], self._flushedUncomp))

@@ -241,8 +241,20 @@ def test_s2_writer_chunking_and_bytes(oracle, kclib):
     assert sink3.getvalue() == ref3.tobytes()
     with pytest.raises(ValueError):
         s2.NewWriter(io.BytesIO(), s2.WriterBlockSize(1000))
-    with pytest.raises(NotImplementedError):  # (the Snappy-compatible framing is not served: another stream identifier, no index)
-        s2.NewWriter(io.BytesIO(), s2.WriterSnappyCompat())
+    # WriterSnappyCompat: the "sNaPpY" stream identifier, blocks through the Snappy-compatible encoder of the level, at most 64 KiB - 8
+    for lvl_opt, lvl in (([], 2), ([s2.WriterBetterCompression()], 3), ([s2.WriterBestCompression()], 5)):
+        sink4 = io.BytesIO()
+        w4 = s2.NewWriter(sink4, s2.WriterSnappyCompat(), *lvl_opt)
+        assert w4.blockSize == (64 << 10) - 8
+        w4.Write(big[:300000])
+        w4.Close()
+        bs4 = (64 << 10) - 8
+        sz4 = [min(bs4, 300000 - i) for i in range(0, 300000, bs4)]
+        off4 = np.zeros(len(sz4) + 1, dtype=np.uint64); off4[1:] = np.cumsum(sz4)
+        ref4, _ = oracle.s2_encode_stream(np.frombuffer(big[:300000], dtype=np.uint8), off4, False, level=lvl)
+        assert sink4.getvalue() == b"\xff\x06\x00\x00sNaPpY" + np.asarray(ref4).tobytes(), lvl
+    with pytest.raises(NotImplementedError):
+        s2.NewWriter(io.BytesIO(), s2.WriterUncompressed())
 
 
 def test_s2_device_decoder_roundtrip_and_errors(oracle, kclib):
