@@ -10,7 +10,6 @@ import "C"
 
 import (
 	"errors"
-	"runtime"
 	"sync"
 	"unsafe"
 
@@ -26,17 +25,15 @@ type Ctx struct {
 
 // NewCtx creates a device context whose S2 blocks are byte-identical to what THIS build of the reference writes: on amd64 the
 // reference's block encoders are generated assembly with their own table sizes, hash lengths and skip rates per input size
-// (s2/encode_amd64.go), elsewhere — and under the `noasm` build tag — portable Go (s2/encode_all.go).  The device implements both
-// (KC_OPT_S2_VARIANT); a `noasm` amd64 build must call SetVariant(VariantGo), which a program cannot detect for itself.
+// (s2/encode_amd64.go), elsewhere — and under the `noasm` / `appengine` build tags — portable Go (s2/encode_all.go).  The device
+// implements both (KC_OPT_S2_VARIANT); defaultVariant follows the build constraints of s2/encode_amd64.go (variant_*.go).
 func NewCtx(device int) (*Ctx, error) {
 	var c *C.kc_ctx
 	if st := C.kc_ctx_create(&c, C.int(device), nil); st != C.KC_OK {
 		return nil, errors.New("no MI355X device")
 	}
 	x := &Ctx{c: c}
-	if runtime.GOARCH == "amd64" {
-		x.SetVariant(VariantAMD64)
-	}
+	x.SetVariant(defaultVariant)
 	return x, nil
 }
 

@@ -1,6 +1,8 @@
 package s2gpu
 
-// Run with -tags noasm: the parity target is the portable Go encoder (encodeBlockGo / encodeBlockGo64K).
+// The parity target is whatever this build of the reference runs: on amd64 its assembly block encoders (the device's
+// KC_S2_VARIANT_AMD64), with -tags noasm or elsewhere the portable Go ones (encodeBlockGo / encodeBlockGo64K); the best levels are
+// pure Go in every build.
 
 import (
 	"bytes"
