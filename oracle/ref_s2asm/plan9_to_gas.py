@@ -37,12 +37,12 @@ BYSIZE = {8: REG64, 4: REG32, 2: REG16, 1: REG8}
 OPS = {}
 for base, gas in (("MOV", "mov"), ("ADD", "add"), ("SUB", "sub"), ("CMP", "cmp"), ("SHR", "shr"), ("SHL", "shl"), ("SAR", "sar"),
                   ("XOR", "xor"), ("OR", "or"), ("AND", "and"), ("DEC", "dec"), ("INC", "inc"), ("TEST", "test"), ("LEA", "lea"),
-                  ("IMUL", "imul"), ("BSF", "bsf")):
+                  ("IMUL", "imul"), ("BSF", "bsf"), ("ROL", "rol")):
     for suf, sz in (("B", 1), ("W", 2), ("L", 4), ("Q", 8)):
         OPS[base + suf] = (gas + suf.lower(), sz)
 SSE = {"MOVOU": "movdqu", "MOVOA": "movdqa", "PXOR": "pxor"}
 JCC = {"JMP": "jmp", "JEQ": "je", "JE": "je", "JNE": "jne", "JZ": "jz", "JNZ": "jnz", "JB": "jb", "JBE": "jbe", "JNA": "jna", "JA": "ja",
-       "JAE": "jae"}
+       "JAE": "jae", "JLE": "jle", "JG": "jg", "JL": "jl", "JLT": "jl", "JGE": "jge"}
 
 
 class Fn:
@@ -70,7 +70,11 @@ def split_operands(s):
     return out
 
 
-MEM = re.compile(r"^(?:(?P<sym>[A-Za-z_][A-Za-z0-9_]*)\+)?(?P<disp>-?(?:0x[0-9a-fA-F]+|\d+))?\((?P<base>[A-Z0-9]+)\)(?:\((?P<idx>[A-Z0-9]+)\*(?P<scale>[1248])\))?$")
+MEM = re.compile(r"^(?:(?P<sym>[A-Za-z_][A-Za-z0-9_]*)\+)?(?P<disp>[-+]?(?:0x[0-9a-fA-F]+|\d+))?\((?P<base>[A-Z0-9]+)\)(?:\((?P<idx>[A-Z0-9]+)\*(?P<scale>[1248])\))?$")
+DATA = re.compile(r"^\xb7(?P<sym>\w+)\+(?P<disp>\d+)\(SB\)$")  # a package-level variable of the reference: provided by the C shim as p9data_<name>
+
+
+DATA_SYMS = set()
 
 
 def operand(fn, op, size):
@@ -86,6 +90,10 @@ def operand(fn, op, size):
         if size is None:
             raise ValueError("register width unknown: " + op)
         return "%" + BYSIZE[size][op]
+    m = DATA.match(op)
+    if m:
+        DATA_SYMS.add(m.group("sym"))
+        return "p9data_%s+%s(%%rip)" % (m.group("sym"), m.group("disp"))
     m = MEM.match(op)
     if not m:
         raise ValueError("operand not understood: " + op)
@@ -110,7 +118,69 @@ def operand(fn, op, size):
     return s + ")"
 
 
+def expand_macros(lines):
+    """The Go assembler's preprocessor, as far as the reference's files use it: `#define NAME text` and `#define name(a, b) body`
+    with backslash continuations (a body's line breaks separate instructions), expanded until nothing changes."""
+    obj, fun, out = {}, {}, []
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        if ln.lstrip().startswith("#define"):
+            body = ln
+            while body.rstrip().endswith("\\"):
+                i += 1
+                body = body.rstrip()[:-1] + "\n" + lines[i]
+            m = re.match(r"\s*#define\s+(\w+)\(([^)]*)\)\s*(.*)$", body, re.S)
+            if m:
+                fun[m.group(1)] = ([a.strip() for a in m.group(2).split(",") if a.strip()], m.group(3))
+            else:
+                m = re.match(r"\s*#define\s+(\w+)\s*(.*)$", body, re.S)
+                if m and m.group(2).strip():
+                    obj[m.group(1)] = m.group(2).split("//")[0].strip()
+                else:
+                    out.append(ln)  # a bare flag (#define GOAMD64_v3): left to the conditional logic below
+            i += 1
+            continue
+        out.append(ln)
+        i += 1
+    if not obj and not fun:
+        return out
+
+    def expand(text):
+        for _ in range(20):
+            before = text
+            for name, (params, body) in fun.items():
+                def sub(m):
+                    args = [a.strip() for a in m.group(1).split(",")] if m.group(1).strip() else []
+                    b = body
+                    for pn, av in zip(params, args):
+                        b = re.sub(r"\b%s\b" % re.escape(pn), av, b)
+                    return b
+                text = re.sub(r"\b%s\(([^()]*)\)" % re.escape(name), sub, text)
+            for name, val in obj.items():
+                text = re.sub(r"(?<![\w\xb7])%s\b(?!\+)" % re.escape(name), val, text)
+            if text == before:
+                break
+        return text
+    res = []
+    for ln in out:
+        if ln.lstrip().startswith(("#", "//")) or ln.lstrip().startswith("TEXT"):
+            res.append(ln)
+            continue
+        code = ln.split("//")[0]
+        for piece in expand(code).split("\n"):
+            # a label and an instruction may share a line after expansion ("loop: MOVQ ...")
+            m = re.match(r"^(\s*\w+:)\s*(\S.*)$", piece)
+            if m:
+                res.append(m.group(1))
+                res.append("\t" + m.group(2))
+            else:
+                res.append(piece)
+    return res
+
+
 def translate(src_lines):
+    src_lines = expand_macros(src_lines)
     out = [".text"]
     fn = None
     skip = []  # preprocessor state: True while inside a dropped branch
@@ -137,7 +207,7 @@ def translate(src_lines):
         if any(skip):
             continue
         if t.startswith("TEXT"):
-            m = re.match(r"TEXT\s+\xb7(\w+)\(SB\),\s*(?:NOSPLIT,\s*)?\$(\d+)(?:-(\d+))?", t)
+            m = re.match(r"TEXT\s+\xb7(\w+)\(SB\),\s*(?:[A-Z|]+,\s*)?\$(\d+)(?:-(\d+))?", t)
             if not m:
                 raise ValueError("line %d: %s" % (ln, t))
             if fn is not None and fn != "skip":
@@ -176,6 +246,9 @@ def translate(src_lines):
         if mn in SSE:
             out.append("    %s %s" % (SSE[mn], ", ".join(operand(fn, o, None) for o in ops)))
             continue
+        if mn == "MOVBQZX":
+            out.append("    movzbq %s, %s" % (operand(fn, ops[0], 1), operand(fn, ops[1], 8)))
+            continue
         if mn not in OPS:
             raise ValueError("line %d: mnemonic %s not handled" % (ln, mn))
         gas, size = OPS[mn]
@@ -196,6 +269,8 @@ def translate(src_lines):
         out.append("    %s %s" % (gas, ", ".join(o)))
     if fn is not None and fn != "skip":
         out.append("    ud2")
+    for sym in sorted(DATA_SYMS):  # defined by the C shim in the same library: PC-relative access needs a non-preemptible symbol
+        out.append(".hidden p9data_%s" % sym)
     out.append('.section .note.GNU-stack,"",@progbits')
     return "\n".join(out) + "\n"
 

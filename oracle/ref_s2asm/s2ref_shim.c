@@ -180,3 +180,15 @@ int64_t s2ref_encode_blocks(int level, const uint8_t* src, const uint64_t* off, 
     pthread_mutex_destroy(&j.mu);
     return rc < 0 ? rc : pos;
 }
+
+
+// ---- zstd/internal/xxhash/xxhash_amd64.s: the XXH64 the reference's zstd encoder checksums frames with on amd64 ----
+// var primes = [...]uint64{prime1, prime2, prime3, prime4, prime5} (xxhash.go:13-25), read by the assembly as ·primes+off(SB)
+__attribute__((visibility("hidden"))) uint64_t p9data_primes[5] = {11400714785074694791ULL, 14029467366897019727ULL, 1609587929392839161ULL, 9650029242287828579ULL, 2870177450012600261ULL};
+extern void p9_Sum64(uint64_t* frame);
+// func Sum64(b []byte) uint64
+uint64_t zref_xxh64_sum(const uint8_t* b, uint64_t n) {
+    uint64_t f[4] = {(uint64_t)(uintptr_t)b, n, n, 0};
+    p9_Sum64(f);
+    return f[3];
+}

@@ -82,6 +82,14 @@ def encode_blocks(src, blk_off, level=0, threads=1):
     return dst[:r], oo
 
 
+def xxh64(b: bytes) -> int:
+    """xxhash.Sum64 of an amd64 build of the reference (zstd/internal/xxhash/xxhash_amd64.s): the frame checksum's hash."""
+    L = lib()
+    L.zref_xxh64_sum.restype = C.c_uint64
+    L.zref_xxh64_sum.argtypes = [C.c_char_p, C.c_uint64]
+    return int(L.zref_xxh64_sum(b, len(b)))
+
+
 def emit(kind, offset, length) -> bytes:
     """emitRepeat / emitCopy / emitCopyNoRepeat of the assembly (kind: 'repeat', 'copy', 'copy_norepeat')."""
     buf = C.create_string_buffer(64)

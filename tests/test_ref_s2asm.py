@@ -61,6 +61,34 @@ def test_oracle_emit_helpers_equal_the_assembly(oracle):
         assert oracle_ref.match_len(a, bytes(b)) == want
 
 
+def test_xxh64_equals_the_reference_assembly(oracle):
+    """a15: the oracle's XXH64 == xxhash.Sum64 of the reference's amd64 assembly (zstd/internal/xxhash/xxhash_amd64.s, assembled
+    into oracle/_ref like the S2 encoders), at every length through the 32-byte stripe, 8-, 4- and 1-byte tails."""
+    rng = np.random.default_rng(3)
+    assert oracle_ref.xxh64(b"") == 0xEF46DB3751D8E999
+    for n in list(range(0, 200)) + [255, 256, 1000, 4095, 65536, 131072, 1000003]:
+        b = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        assert oracle_ref.xxh64(b) == oracle.lib().kco_xxh64(b, n), n
+
+
+@pytest.mark.gpu
+def test_device_xxh64_equals_the_reference_assembly(oracle, kclib):
+    """The device's XXH64 kernel (frame content checksums) against the reference's assembly on ragged units."""
+    torch = pytest.importorskip("torch")
+    from compress_amd import zstd
+    rng = np.random.default_rng(5)
+    units = [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in list(range(0, 70)) + [int(x) for x in rng.integers(70, 300000, 60)]]
+    buf, off = corpora.pack_units(units)
+    d = torch.from_numpy(buf).cuda()
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(1))
+    ctx = enc.ctx()
+    out = np.zeros(len(units), dtype=np.uint64)
+    ctx.check(ctx.L.kc_xxh64_units_dev(ctx.h, d.data_ptr(), off.ctypes.data, len(units), out.ctypes.data))
+    for i, u in enumerate(units):
+        assert int(out[i]) == oracle_ref.xxh64(u), (i, len(u))
+    enc.Close()
+
+
 def _pin_inputs():
     import os
     import zipfile
