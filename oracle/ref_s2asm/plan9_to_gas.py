@@ -42,7 +42,9 @@ for base, gas in (("MOV", "mov"), ("ADD", "add"), ("SUB", "sub"), ("CMP", "cmp")
         OPS[base + suf] = (gas + suf.lower(), sz)
 SSE = {"MOVOU": "movdqu", "MOVOA": "movdqa", "PXOR": "pxor"}
 JCC = {"JMP": "jmp", "JEQ": "je", "JE": "je", "JNE": "jne", "JZ": "jz", "JNZ": "jnz", "JB": "jb", "JBE": "jbe", "JNA": "jna", "JA": "ja",
-       "JAE": "jae", "JLE": "jle", "JG": "jg", "JL": "jl", "JLT": "jl", "JGE": "jge"}
+       "JAE": "jae", "JLE": "jle", "JG": "jg", "JGT": "jg", "JL": "jl", "JLT": "jl", "JGE": "jge"}
+# zero-extending moves: Plan 9 name -> (gas mnemonic, source width, destination width)
+ZX = {"MOVBQZX": ("movzbq", 1, 8), "MOVBLZX": ("movzbl", 1, 4), "MOVWQZX": ("movzwq", 2, 8), "MOVWLZX": ("movzwl", 2, 4), "MOVLQZX": ("movl", 4, 4)}
 
 
 class Fn:
@@ -246,8 +248,15 @@ def translate(src_lines):
         if mn in SSE:
             out.append("    %s %s" % (SSE[mn], ", ".join(operand(fn, o, None) for o in ops)))
             continue
-        if mn == "MOVBQZX":
-            out.append("    movzbq %s, %s" % (operand(fn, ops[0], 1), operand(fn, ops[1], 8)))
+        if mn in ZX:
+            g, sw, dw = ZX[mn]
+            out.append("    %s %s, %s" % (g, operand(fn, ops[0], sw), operand(fn, ops[1], dw)))
+            continue
+        if mn == "CALL":  # only runtime.memmove(to, from, n), arguments at 0 / 8 / 16(SP) (Go's stack-based ABI0); every register is dead after it
+            if ops != ["runtime\xb7memmove(SB)"]:
+                raise ValueError("line %d: CALL %s" % (ln, ops))
+            out += ["    movq %d(%%rsp), %%rdi" % fn.lbase, "    movq %d(%%rsp), %%rsi" % (fn.lbase + 8), "    movq %d(%%rsp), %%rdx" % (fn.lbase + 16),
+                    "    call memmove@PLT"]
             continue
         if mn not in OPS:
             raise ValueError("line %d: mnemonic %s not handled" % (ln, mn))

@@ -192,3 +192,26 @@ uint64_t zref_xxh64_sum(const uint8_t* b, uint64_t n) {
     p9_Sum64(f);
     return f[3];
 }
+
+
+// ---- s2/decode_amd64.s: the reference's own block decoder (s2.Decode, s2/decode.go:58-76: decodedLen + s2Decode) ----
+extern void p9_s2Decode(uint64_t* frame);
+// Returns the decoded length, -1 for a corrupt block (the reference's ErrCorrupt), -2 when dst is too small.
+int64_t s2ref_decode(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
+    uint64_t v = 0;
+    int shift = 0;
+    uint64_t s = 0;
+    for (;;) {  // binary.Uvarint
+        if (s >= n || shift > 63) return -1;
+        const uint8_t b = src[s++];
+        v |= (uint64_t)(b & 0x7f) << shift;
+        if (b < 0x80) break;
+        shift += 7;
+    }
+    if (v > 0xffffffffULL) return -1;  // decodedLen: ErrTooLarge / ErrCorrupt
+    if (v > cap) return -2;
+    // func s2Decode(dst, src []byte) int
+    uint64_t f[7] = {(uint64_t)(uintptr_t)dst, v, v, (uint64_t)(uintptr_t)(src + s), n - s, n - s, 0};
+    p9_s2Decode(f);
+    return f[6] != 0 ? -1 : (int64_t)v;
+}

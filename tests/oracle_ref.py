@@ -82,6 +82,19 @@ def encode_blocks(src, blk_off, level=0, threads=1):
     return dst[:r], oo
 
 
+def decode(enc: bytes, cap: int):
+    """s2.Decode of an amd64 build of the reference (its assembly block decoder): the bytes, or None for ErrCorrupt."""
+    L = lib()
+    L.s2ref_decode.restype = C.c_int64
+    L.s2ref_decode.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    buf = C.create_string_buffer(max(int(cap), 1) + 32)
+    sb = C.create_string_buffer(enc, len(enc) + 32)
+    r = L.s2ref_decode(sb, len(enc), buf, int(cap))
+    if r < 0:  # -1: ErrCorrupt; -2: the block states more bytes than `cap` (for a caller that knows the size: corrupt as well)
+        return None
+    return buf.raw[:r]
+
+
 def xxh64(b: bytes) -> int:
     """xxhash.Sum64 of an amd64 build of the reference (zstd/internal/xxhash/xxhash_amd64.s): the frame checksum's hash."""
     L = lib()

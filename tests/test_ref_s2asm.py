@@ -89,6 +89,72 @@ def test_device_xxh64_equals_the_reference_assembly(oracle, kclib):
     enc.Close()
 
 
+def test_reference_decoder_accepts_every_oracle_level(oracle):
+    """s2.Decode of the reference itself (its assembly block decoder, oracle/_ref) decodes what the oracle's encoders write — all six
+    levels in their portable-Go form and the four assembly forms — back to the input; and on damaged blocks the in-repo decoder
+    (the verifier of the other tests) and the reference's agree: both refuse, or both return the same bytes."""
+    rng = np.random.default_rng(2)
+    for kind in "JTMH":
+        d = corpora.corpus(kind, 12, 131072).tobytes()
+        for n in (0, 1, 31, 32, 100, 511, 5000, 65536, 300000, 1 << 20):
+            u = d[:n]
+            encs = [oracle.s2_encode(u), oracle.s2_encode_better(u), oracle.s2_encode_snappy(u), oracle.s2_encode_snappy_better(u),
+                    oracle.s2_encode_best(u), oracle.s2_encode_snappy_best(u)]
+            encs += [oracle.s2_encode_asm(u, snappy=l >= 2, better=bool(l & 1)) for l in range(4)]
+            for i, e in enumerate(encs):
+                assert oracle_ref.decode(e, len(u)) == u, (kind, n, i)
+                if len(e) > 8:
+                    for _ in range(3):
+                        bad = bytearray(e)
+                        bad[int(rng.integers(1, len(e)))] ^= int(rng.integers(1, 256))
+                        a = oracle_ref.decode(bytes(bad), len(u))
+                        try:
+                            b = oracle.s2_decode(bytes(bad), len(u) + 16)
+                        except RuntimeError:
+                            b = None
+                        assert (a is None) == (b is None) and (a is None or a == b), (kind, n, i)
+
+
+@pytest.mark.gpu
+def test_reference_decoder_accepts_every_device_level(oracle, kclib):
+    """The same from the other side: blocks the DEVICE writes, at every level and in both variants, decoded by the reference's own
+    decoder; and the device decoder's verdict on damaged blocks equals the reference decoder's."""
+    torch = pytest.importorskip("torch")
+    from compress_amd import s2
+    rng = np.random.default_rng(4)
+    blocks = []
+    for kind in "JTMH":
+        d = corpora.corpus(kind, 6, 131072).tobytes()
+        blocks += [d[:n] for n in (32, 100, 511, 5000, 65536, 150000)]
+    b2, off = corpora.pack_units(blocks)
+    for level in range(6):
+        for variant in ((None, "amd64") if level < 4 else (None,)):
+            enc = s2.BlockEncoder(level=level, variant=variant)
+            out, oo = enc.EncodeBlocks(b2, off)
+            for i, u in enumerate(blocks):
+                assert oracle_ref.decode(out[int(oo[i]):int(oo[i + 1])].tobytes(), len(u)) == u, (level, variant, i)
+            enc.Close()
+    # damaged blocks: device decoder status vs the reference decoder
+    enc = s2.BlockEncoder(level=0)
+    out, oo = enc.EncodeBlocks(b2, off)
+    dam = out.copy()
+    for i in range(len(blocks)):
+        a, b = int(oo[i]), int(oo[i + 1])
+        if b - a > 8 and i % 2 == 0:
+            dam[a + int(rng.integers(1, b - a))] ^= np.uint8(rng.integers(1, 256))
+    d_enc = torch.from_numpy(dam).cuda()
+    d_dst = torch.zeros(len(b2) + 64, dtype=torch.uint8, device="cuda")
+    st = enc.DecodeBlocksDevice(d_enc.data_ptr(), oo, d_dst.data_ptr(), off)
+    back = d_dst.cpu().numpy()
+    for i, u in enumerate(blocks):
+        ref = oracle_ref.decode(dam[int(oo[i]):int(oo[i + 1])].tobytes(), len(u))
+        ok_ref = ref is not None and len(ref) == len(u)
+        assert (st[i] == 0) == ok_ref, (i, int(st[i]), ok_ref)
+        if ok_ref:
+            assert back[int(off[i]):int(off[i + 1])].tobytes() == ref, i
+    enc.Close()
+
+
 def _pin_inputs():
     import os
     import zipfile
