@@ -663,7 +663,7 @@ def test_host_chunk_fed_batch_equals_device_path(oracle, kclib, level, monkeypat
     enc.Close()
 
 
-@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("level", LEVELS_B)
 def test_long_units_and_streams_bit_exact(oracle, kclib, level):
     """Units and streams of more than 32 blocks (the re-run bookkeeping is per block, not a 32-bit mask per unit), longer than the
     window (matches beyond it are refused exactly like the reference's, whose history buffer has slid by then), with a small

@@ -123,6 +123,24 @@ def test_device_jobs_bit_exact_256mib_stream(oracle, kclib, level):
 
 
 @pytest.mark.gpu
+def test_device_jobs_best_level_stream(oracle, kclib):
+    """SpeedBestCompression jobs: overlap = window / 2 (encoder_options.go:364), every position of a job's prefix indexed by the
+    job's wave itself (ResetPrefix, enc_best.go:554-568): a 20 MiB stream at a 1 MiB window = five jobs of 4 MiB with 512 KiB of
+    overlap, plus Flush cuts."""
+    import torch
+    assert torch.cuda.is_available()
+    data = corpora.corpus("T", 160, 131072, first_unit=9000).tobytes()
+    e = oracle.ZstdOracle(level=4, window_size=1 << 20)
+    enc = _enc(4, window=1 << 20)
+    assert enc.JobSize() == 4 << 20 and enc.OverlapSize() == 512 << 10
+    for cuts in ((), (3000000, 9000000)):
+        got = enc.EncodeJobs(data, cuts)
+        assert got == e.encode_jobs(data, cuts), cuts
+    assert oracle.zstd_decompress(got, len(data) + 16) == data
+    enc.Close()
+
+
+@pytest.mark.gpu
 def test_device_jobs_default_window_speedfastest(oracle, kclib):
     """GPU: SpeedFastest with its own 4 MiB window: jobs of 16 MiB, 512 KiB of overlap, 64 KiB blocks — 256 MiB = 16 jobs + the
     empty final job."""
