@@ -97,6 +97,7 @@ struct KcCfg {
     int64_t k2_prof = 0;
     int64_t hook_wait_us = 0, hook_batch = 256;
     int64_t test_feed_redo = 0;           // diagnostics: force the chunk-fed path's re-encode fallback
+    int64_t better_dict_epoch = 0;        // SpeedBetterCompression with a dictionary: epoch-stamped tables + shared dictionary table instead of the per-batch copy
     int64_t s2_variant = 0;               // S2 levels 0 / 2: 0 = the portable Go encoders' bytes, 1 = the amd64 assembly encoders' bytes
     int64_t best_slots = 2048;            // SpeedBestCompression: table slots (34 MiB each) = units encoded at a time
 };
@@ -112,6 +113,12 @@ struct kc_ctx {
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
         predef, errflag, tmp_src, tmp_dst, tables, prof, work, work_off, dictbuf, proto, dicthuf;
     bool predef_ready = false;
+    // SpeedBetterCompression epoch stamps: what the table arena holds (kc_zstd_match_better.hip)
+    int tab_owner = 0;          // 1: the arena holds better-level tables of tab_units units, stamped up to tab_ep, written with tab_pb position bits
+    int tab_pb = 0;
+    uint32_t tab_units = 0, tab_ep = 0, better_epoch_now = 0;
+    void* tab_ptr = nullptr;
+    uint64_t proto_key = 0;     // the dictionary tables in c->proto were built for this (content hash, level, position bits, stamp mode)
     DevBuf best_tables, best_cur, best_cost;  // SpeedBestCompression: persistent table slots, their position-space counters, the bit costs
     uint32_t best_n = 0;                      // slots allocated (and zeroed) so far
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [6]: batch prepared (chunk-fed launches wait on it); [7]: tables prepared
@@ -342,6 +349,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_MAX_SCRATCH_MIB: if (v < 1) return KC_ERR_BAD_ARG; c->max_scratch_bytes = (uint64_t)v << 20; break;
         case KC_OPT_BEST_SLOTS: if (v < 1 || v > 8192) return KC_ERR_BAD_ARG; g.best_slots = v; break;
         case KC_OPT_S2_VARIANT: if (v != KC_S2_VARIANT_GO && v != KC_S2_VARIANT_AMD64) return KC_ERR_BAD_ARG; g.s2_variant = v; break;
+        case KC_OPT_BETTER_DICT_EPOCH: g.better_dict_epoch = v != 0; break;
         default: return KC_ERR_BAD_ARG;
     }
     return KC_OK;
@@ -371,6 +379,7 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_MAX_SCRATCH_MIB: return (int64_t)(c->max_scratch_bytes >> 20);
         case KC_OPT_BEST_SLOTS: return g.best_slots;
         case KC_OPT_S2_VARIANT: return g.s2_variant;
+        case KC_OPT_BETTER_DICT_EPOCH: return g.better_dict_epoch;
         case KC_OPT_LAST_PATH: return c->last_path;
         case KC_OPT_LAST_BATCHES: return c->last_batches;
         default: return -1;
@@ -422,8 +431,8 @@ namespace {
 
 // Host-side construction of the dictionary-primed tables of betterFastEncoderDict.Reset
 // (zstd/enc_better.go:1114-1183) in the device entry format (position+1 | tag << pos_bits).
-void build_better_dict_tables(const uint8_t* dict, size_t len, int pos_bits, uint8_t* out) {
-    const int TB = (32 - pos_bits) > 16 ? 16 : (32 - pos_bits);
+void build_better_dict_tables(const uint8_t* dict, size_t len, int pos_bits, uint8_t* out, int reserved_bits = 0) {
+    const int TB = (32 - pos_bits - reserved_bits) > 16 ? 16 : (32 - pos_bits - reserved_bits);  // reserved: the epoch stamp's bits (kc_zstd_match_better.hip)
     auto tagOf = [&](uint32_t v) -> uint32_t { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; };
     auto mk = [&](uint64_t pos, uint32_t val) -> uint32_t { return ((uint32_t)pos + 1u) | (tagOf(val) << pos_bits); };
     auto ld64h = [&](size_t i) -> uint64_t { uint64_t v; memcpy(&v, dict + i, 8); return v; };
@@ -563,8 +572,37 @@ kc_status ensure_best_slots(kc_ctx* c, uint32_t n_launch, hipStream_t st) {
     return KC_OK;
 }
 
+// SpeedBetterCompression batches whose tables carry epoch stamps instead of being cleared per launch: not the jobs of a
+// WithConcurrentBlocks stream (their tables are primed per unit on the host), only while the stamp fits above position and tag, and
+// — measured — not with a dictionary: there every lookup has to read the shared dictionary table beside the unit's own bucket, and
+// on C5 that costs more (match finder 52.9 -> 63.7 ms per GiB) than the 7.7 ms of copying the dictionary tables it saves
+// (KC_OPT_BETTER_DICT_EPOCH = 1 turns it on for measurements).
+bool better_epoch_mode(const kc_ctx* c, int level, int pos_bits, int hist0) {
+    return level == KC_SPEED_BETTER && c->job_tables == nullptr && c->job_hist == nullptr && pos_bits <= 22 && (hist0 == 0 || c->cfg.better_dict_epoch != 0);
+}
+
 kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, hipStream_t st, int level) {
     if (level == KC_SPEED_BEST) return ensure_best_slots(c, n_launch, st);
+    c->better_epoch_now = 0;
+    if (better_epoch_mode(c, level, mp.pos_bits, mp.hist0)) {
+        const size_t tbb = match_table_bytes(level);
+        kc_status se = ensure(c, c->tables, (size_t)n_launch * tbb);
+        if (se != KC_OK) return se;
+        const bool fresh = c->tab_owner != 1 || c->tab_pb != mp.pos_bits || n_launch > c->tab_units || c->tab_ep >= 15u || c->tab_ptr != c->tables.p;
+        if (fresh) {
+            HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * tbb, st));
+            c->tab_owner = 1;
+            c->tab_pb = mp.pos_bits;
+            c->tab_units = n_launch;
+            c->tab_ep = 1;
+            c->tab_ptr = c->tables.p;
+        } else {
+            c->tab_ep++;
+        }
+        c->better_epoch_now = c->tab_ep;
+        return KC_OK;  // no dictionary copy either: the kernel reads the shared dictionary tables for buckets it has not written
+    }
+    c->tab_owner = 0;
     if (zfast_use_lds(c, mp, n_launch, level) && !zfast_lds_needs_hbm(c, mp) && c->job_tables == nullptr) return KC_OK;  // the tables live in LDS
     const size_t tb = match_table_bytes(level);
     if (c->job_tables != nullptr && mp.unit_list == nullptr) {  // jobs: every unit's table was primed from its own prefix on the host
@@ -609,7 +647,12 @@ void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uin
         return;
     }
     uint8_t* tab = (uint8_t*)c->tables.p + (size_t)slot0 * match_table_bytes(level);
-    if (level == KC_SPEED_BETTER) kc_launch_zbetter_match_grp(mp, tab, n_launch, mp.hist0 > 0, st);
+    if (level == KC_SPEED_BETTER) {
+        KcMatchParams mb = mp;
+        mb.epoch = c->better_epoch_now;
+        mb.proto = (mb.epoch != 0u && mp.hist0 > 0) ? (const uint8_t*)c->proto.p : nullptr;
+        kc_launch_zbetter_match_grp(mb, tab, n_launch, mp.hist0 > 0, st);
+    }
     else if (level == KC_SPEED_DEFAULT) kc_launch_zdfast_match_grp(mp, (uint32_t*)tab, n_launch, st);
     else kc_launch_zfast_match_grp(mp, (uint32_t*)tab, n_launch, st);
 }
@@ -744,7 +787,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
         // pristine dictionary tables (betterFastEncoderDict.Reset, enc_better.go:1114-1183) in the device entry format
         std::vector<uint8_t> proto(kc_zbetter_table_bytes(), 0);
         if (o->level == KC_SPEED_BEST) { /* the kernel indexes the dictionary itself, per unit (bestFastEncoder.Reset) */ }
-        else if (o->level == KC_SPEED_BETTER) build_better_dict_tables(o->dict, (size_t)hist0, pos_bits, proto.data());
+        else if (o->level == KC_SPEED_BETTER) build_better_dict_tables(o->dict, (size_t)hist0, pos_bits, proto.data(), better_epoch_mode(c, o->level, pos_bits, hist0) ? 4 : 0);
         else if (o->level == KC_SPEED_DEFAULT) {
             build_dfast_dict_long(o->dict, (size_t)hist0, pos_bits, (uint32_t*)proto.data());
             build_fast_dict_table(o->dict, (size_t)hist0, pos_bits, (uint32_t*)(proto.data() + ((size_t)4 << 17)));
@@ -2109,7 +2152,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->stage_off.p, so.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    if (!lds) HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant), st));
+    if (!lds) { c->tab_owner = 0; HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant), st)); }
     KcS2Params P;
     P.src = d_src + blk_off[0];
     P.blk_off = (const uint64_t*)c->unit_off.p;

@@ -31,6 +31,9 @@ struct KcMatchParams {
     const uint32_t* unit_hist;  // device or null: per-unit history bytes in front of the unit in `src` (jobs: the overlap prefix), replaces hist0
     const uint32_t* job_flags;  // device or null: units are the jobs of ONE WithConcurrentBlocks stream (enc_jobs.go): bit 0 = final job
     unsigned long long* prof;   // device or null: per-phase shader-clock totals of the LDS-table kernel (built with -DKC_LDS_PROF, KC_OPT_K2_PROF)
+    uint32_t epoch;             // SpeedBetterCompression: 0 = the tables were fully initialised by the host; else this launch's stamp
+                                // (entries with another stamp read as the dictionary's entry or as empty: kc_zstd_match_better.hip)
+    const uint8_t* proto;       // device or null: with epoch != 0 and a dictionary, the dictionary's tables (long then short)
     int32_t lds_split;          // SpeedFastest HBM kernel: 1 = skip the units the LDS-table kernel takes (those that fit KC_ZFAST_LDS_MAX_UNIT)
 };
 // SpeedFastest: 8 lanes per unit, tables = n_launch x 2^15 x u32 in HBM, zeroed by the caller

@@ -25,13 +25,48 @@
 #endif
 static_assert(ZBG <= 32, "group ballots are 32-bit");
 
+// Epoch stamps (round 3).  The tables are 4 MiB per unit: zeroing them — or, with a dictionary, copying the dictionary's tables
+// into them — for every batch is 33 GB of writes per GiB of input (7.7 ms of a 68 ms step).  With P.epoch != 0 the top ZB_EPOCH_BITS
+// bits of a long entry's `offset` word and of a short entry carry the stamp of the launch that wrote it: an entry with another
+// stamp is one left by an earlier launch and reads as the dictionary's entry for that bucket (a shared, read-only table that
+// stays in L2) or as empty.  The host advances the stamp per launch and clears the arena only when it wraps, when the position
+// width changes or when the arena was used by something else.  `prev` words are stored resolved and unstamped: they are only read
+// together with a valid `offset` word.  P.epoch == 0 is the old contract (tables fully initialised by the host): jobs, whose
+// tables the host primes per unit, and units too long for the stamp to fit.
+#define ZB_EPOCH_BITS 4
+#define ZB_EPOCH_SHIFT (32 - ZB_EPOCH_BITS)
+
 struct ZbCtx {
     const uint8_t* base;   // hist: (dict ||) unit
     uint2* ltab;           // {offset, prev}
     uint32_t* stab;
+    const uint2* pl;       // dictionary tables (epoch mode with a dictionary) or null
+    const uint32_t* ps;
+    uint32_t ep;           // this launch's stamp, 0 = none
     int PB, TB;
     uint32_t posMask;
     int mmo;
+    __device__ __forceinline__ uint2 rdL(uint32_t h) const {
+        uint2 e = ltab[h];
+        if (ep == 0u) return e;
+        const uint2 p = pl != nullptr ? pl[h] : make_uint2(0u, 0u);  // (issued beside the own load, not after it)
+        if ((e.x >> ZB_EPOCH_SHIFT) == ep) { e.x &= (1u << ZB_EPOCH_SHIFT) - 1u; return e; }
+        return p;
+    }
+    __device__ __forceinline__ uint32_t rdLx(uint32_t h) const {
+        const uint32_t e = ltab[h].x;
+        if (ep == 0u) return e;
+        const uint32_t p = pl != nullptr ? pl[h].x : 0u;
+        return (e >> ZB_EPOCH_SHIFT) == ep ? (e & ((1u << ZB_EPOCH_SHIFT) - 1u)) : p;
+    }
+    __device__ __forceinline__ uint32_t rdS(uint32_t h) const {
+        const uint32_t e = stab[h];
+        if (ep == 0u) return e;
+        const uint32_t p = ps != nullptr ? ps[h] : 0u;
+        return (e >> ZB_EPOCH_SHIFT) == ep ? (e & ((1u << ZB_EPOCH_SHIFT) - 1u)) : p;
+    }
+    __device__ __forceinline__ void wrL(uint32_t h, uint32_t x, uint32_t y) const { ltab[h] = make_uint2(x | (ep << ZB_EPOCH_SHIFT), y); }
+    __device__ __forceinline__ void wrS(uint32_t h, uint32_t x) const { stab[h] = x | (ep << ZB_EPOCH_SHIFT); }
     __device__ __forceinline__ uint32_t tagOf(uint32_t v) const { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; }
     __device__ __forceinline__ uint32_t mk(int pos, uint32_t val) const { return ((uint32_t)pos + 1u) | (tagOf(val) << PB); }
     __device__ __forceinline__ int posOf(uint32_t e) const { return (int)(e & posMask) - 1; }  // -1 == empty
@@ -69,7 +104,13 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
     C.ltab = (uint2*)(tables + (size_t)ui * tabBytes);
     C.stab = (uint32_t*)(tables + (size_t)ui * tabBytes + ((size_t)8 << ZB_LONG_BITS));
     C.PB = P.pos_bits;  // per-launch constant so that dictionary-primed tables can be shared by all units
-    C.TB = (32 - C.PB) > 16 ? 16 : (32 - C.PB);
+    C.ep = P.epoch;
+    C.pl = (P.epoch != 0u && P.proto != nullptr) ? (const uint2*)P.proto : nullptr;
+    C.ps = (P.epoch != 0u && P.proto != nullptr) ? (const uint32_t*)(P.proto + ((size_t)8 << ZB_LONG_BITS)) : nullptr;
+    {
+        const int avail = 32 - C.PB - (P.epoch != 0u ? ZB_EPOCH_BITS : 0);
+        C.TB = avail > 16 ? 16 : avail;
+    }
     C.posMask = (1u << C.PB) - 1u;
     C.mmo = P.max_match_off;
     const int mmo = C.mmo;
@@ -108,7 +149,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                 uint32_t h0 = 0xFFFFFFFFu - (uint32_t)lig, h1 = 0xFFFFFF00u - (uint32_t)lig;
                 if (act) { cv0 = ld64(base + idx); h0 = hL(cv0); h1 = hS(cv0 >> 8); }
                 uint32_t oldOff = 0;
-                if (act) oldOff = C.ltab[h0].x;
+                if (act) oldOff = C.rdLx(h0);
                 // nearest lower lane with the same long bucket supplies `prev`; a higher lane with the same bucket owns the store
                 uint32_t prevE = oldOff;
                 bool laterL = false, laterS = false;
@@ -126,8 +167,8 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     if (lig + d < G && b0 == h0) laterL = true;
                     if (lig + d < G && b1 == h1) laterS = true;
                 }
-                if (act && !laterL) C.ltab[h0] = make_uint2(myE, prevE);
-                if (act && !laterS) C.stab[h1] = C.mk(idx + 1, (uint32_t)(cv0 >> 8));
+                if (act && !laterL) C.wrL(h0, myE, prevE);
+                if (act && !laterS) C.wrS(h1, C.mk(idx + 1, (uint32_t)(cv0 >> 8)));
             }
         };
 
@@ -167,8 +208,8 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                         cvl = ld64(base + pp);
                         hl = hL(cvl);
                         hs = hS(cvl);
-                        eL = C.ltab[hl];
-                        eS = C.stab[hs];
+                        eL = C.rdL(hl);
+                        eS = C.rdS(hs);
                     }
                     bool dep = false;
 #pragma unroll
@@ -200,8 +241,8 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     const int commitUpTo = found ? f : ((cc < nvalid ? cc : nvalid) - 1);
                     if (valid && lig <= commitUpTo) {
                         const uint32_t e = C.mk(pp, (uint32_t)cvl);
-                        C.ltab[hl] = make_uint2(e, eL.x);
-                        C.stab[hs] = e;
+                        C.wrL(hl, e, eL.x);
+                        C.wrS(hs, e);
                     }
                     if (!found) {
                         W = P.spec_grow == 0 ? W : (P.spec_grow == 1 ? (W + 1 < G ? W + 1 : G) : ((2 * W < G) ? 2 * W : G));
@@ -270,8 +311,8 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                             // long match at s+1? (:309-343)
                             const uint64_t cv2 = ld64(base + s + 1);
                             const uint32_t nh2 = hL(cv2);
-                            const uint2 c2 = C.ltab[nh2];
-                            if (lig == 0) C.ltab[nh2] = make_uint2(C.mk(s + 1, (uint32_t)cv2), c2.x);
+                            const uint2 c2 = C.rdL(nh2);
+                            if (lig == 0) C.wrL(nh2, C.mk(s + 1, (uint32_t)cv2), c2.x);
                             // s-coffsetL < maxMatchOff is evaluated with s (not s+1) in the reference
                             bool taken = false;
                             {
@@ -301,7 +342,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     const uint32_t nh = hL(ld64(base + s + matched));
                     const int s2 = s + skipBeginning;
                     const uint32_t cv4 = ld32(base + s2);
-                    const uint2 cE = C.ltab[nh];
+                    const uint2 cE = C.rdL(nh);
                     {
                         const int co = C.posOf(cE.x) - matched + skipBeginning;
                         if (C.posOf(cE.x) >= 0 && co >= 0 && co < s2 && (s2 - co) < mmo && cv4 == ld32(base + co)) {
@@ -343,10 +384,10 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     if (ld32(base + o2pos) != (uint32_t)cvs) break;
                     const uint32_t nhL2 = hL(cvs), nhS2 = hS(cvs);
                     const int l2 = 4 + grp_matchlen<G>(base, s + 4, o2pos + 4, blkEnd - (s + 4), lig, grp);
-                    const uint32_t oldx = C.ltab[nhL2].x;
+                    const uint32_t oldx = C.rdLx(nhL2);
                     if (lig == 0) {
-                        C.ltab[nhL2] = make_uint2(C.mk(s, (uint32_t)cvs), oldx);
-                        C.stab[nhS2] = C.mk(s, (uint32_t)cvs);
+                        C.wrL(nhL2, C.mk(s, (uint32_t)cvs), oldx);
+                        C.wrS(nhS2, C.mk(s, (uint32_t)cvs));
                     }
                     emit(0, l2 - 3, 1u);
                     s += l2;

@@ -160,6 +160,7 @@ typedef enum {
     KC_OPT_MAX_SCRATCH_MIB = 18,     /* (no variable)             ceiling of the device scratch one batch may take (default 160 GiB, and 85 % of the free memory): larger calls are cut into several batches */
     KC_OPT_BEST_SLOTS = 19,          /* (no variable)             SpeedBestCompression: table slots of 34 MiB = units encoded at a time (default 2048 = 68 GiB, allocated on demand) */
     KC_OPT_S2_VARIANT = 20,          /* (no variable)             s2.Encode / s2.EncodeSnappy: KC_S2_VARIANT_GO (default) or KC_S2_VARIANT_AMD64 */
+    KC_OPT_BETTER_DICT_EPOCH = 21,   /* (no variable)             SpeedBetterCompression with a dictionary: 1 = epoch-stamped tables + shared dictionary table (measurements; default 0: per-batch copy) */
     KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
     KC_OPT_LAST_BATCHES = 101        /* read-only: device batches the last kc_zstd_encode_units_dev / kc_s2_encode_*_dev call was cut into */
 } kc_option;

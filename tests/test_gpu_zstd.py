@@ -698,6 +698,34 @@ def test_long_units_and_streams_bit_exact(oracle, kclib, level):
         enc.Close()
 
 
+@pytest.mark.parametrize("with_dict", [False, True])
+def test_better_level_epoch_stamped_tables_over_many_batches(oracle, kclib, with_dict):
+    """SpeedBetterCompression keeps its 4 MiB-per-unit tables between batches and tells old entries from new by an epoch stamp
+    instead of clearing them: twenty batches on one context — more than the stamp's 15 values (wrap: the arena is cleared), growing
+    and shrinking unit counts, unit lengths that change the position width — each bit-exact.  With a dictionary the stamped form
+    reads the shared dictionary table for buckets the unit has not written (KC_OPT_BETTER_DICT_EPOCH; off by default: measured
+    slower than copying the dictionary tables)."""
+    _torch()
+    from compress_amd import zstd
+    t = corpora.corpus("T", 40, 131072, first_unit=4).tobytes()
+    m = corpora.corpus("M", 40, 131072, first_unit=9).tobytes()
+    dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
+    opts = [zstd.WithEncoderLevel(3)] + ([zstd.WithEncoderDictRaw(3, dct)] if with_dict else [])
+    enc = zstd.NewWriter(None, *opts)
+    if with_dict:
+        enc.ctx().set_option(21, 1)
+    okw = dict(dict_id=3, dict_content=dct) if with_dict else {}
+    shapes = [(8, 131072), (40, 131072), (3, 131072), (12, 40000), (5, 400000), (40, 131072), (1, 700)] * 3
+    for k, (n, ln) in enumerate(shapes[:20]):
+        src = t if k % 2 == 0 else m
+        units = [src[(i * 7919 + k * 131) % (len(src) - ln):][:ln] for i in range(n)]
+        ubuf, off = corpora.pack_units(units)
+        out, out_off = enc.EncodeUnits(ubuf, off)
+        ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=3, **okw)
+        assert np.array_equal(out_off, ref_off) and np.array_equal(out, np.asarray(ref)), (k, n, ln)
+    enc.Close()
+
+
 def test_submit_wait_two_contexts_overlap(oracle, kclib, monkeypatch):
     """kc_zstd_encode_units_submit / kc_wait: two contexts alternate over six batches, each call running its chunk-fed host path on
     its own thread while the other context's call is in flight; the frames equal the synchronous call's, a second submit on a
