@@ -44,7 +44,7 @@ const (
 	VariantAMD64 = 1 // s2/encodeblock_amd64.s
 )
 
-func (x *Ctx) SetVariant(v int) { C.kc_ctx_set_option(x.c, C.KC_OPT_S2_VARIANT, C.int64_t(v)) }
+func (x *Ctx) SetVariant(v int) { C.kc_ctx_set_option(x.c, C.int(C.KC_OPT_S2_VARIANT), C.int64_t(v)) }
 
 func (x *Ctx) Close() { C.kc_ctx_destroy(x.c) }
 
