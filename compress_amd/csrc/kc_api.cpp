@@ -100,6 +100,9 @@ struct KcCfg {
     int64_t better_dict_epoch = 0;        // SpeedBetterCompression with a dictionary: epoch-stamped tables + shared dictionary table instead of the per-batch copy
     int64_t s2_variant = 0;               // S2 levels 0 / 2: 0 = the portable Go encoders' bytes, 1 = the amd64 assembly encoders' bytes
     int64_t best_slots = 2048;            // SpeedBestCompression: table slots (34 MiB each) = units encoded at a time
+    int64_t zfast_epoch = 1;              // SpeedFastest HBM-table kernel without a dictionary: epoch-stamped tables instead of clearing 128 KiB per unit per batch
+    int64_t zfast_xseg_k = 0;             // SpeedFastest HBM-table kernel: probe rounds cross skip-segment boundaries once (s - nextEmit) >> 5 reaches this (0: always)
+    int64_t fuse_raw_xxh = 1;             // frames made of raw blocks only: checksum and payload copy in one pass over the source (kc_xxh64_copy_kernel)
 };
 
 struct kc_ctx {
@@ -116,7 +119,7 @@ struct kc_ctx {
     // SpeedBetterCompression epoch stamps: what the table arena holds (kc_zstd_match_better.hip)
     int tab_owner = 0;          // 1: the arena holds better-level tables of tab_units units, stamped up to tab_ep, written with tab_pb position bits
     int tab_pb = 0;
-    uint32_t tab_units = 0, tab_ep = 0, better_epoch_now = 0;
+    uint32_t tab_units = 0, tab_ep = 0, better_epoch_now = 0, fast_epoch_now = 0;  // (tab_owner 2: SpeedFastest tables, kc_zstd_match.hip)
     void* tab_ptr = nullptr;
     uint64_t proto_key = 0;     // the dictionary tables in c->proto were built for this (content hash, level, position bits, stamp mode)
     DevBuf best_tables, best_cur, best_cost;  // SpeedBestCompression: persistent table slots, their position-space counters, the bit costs
@@ -136,7 +139,7 @@ struct kc_ctx {
     const uint32_t* job_hist = nullptr;     // host, per unit: bytes of overlap prefix in front of the unit in the source buffer
     const uint32_t* job_flags = nullptr;    // host, per unit: bit 0 = final job
     const uint8_t* job_tables = nullptr;    // host: the units' tables primed from their prefixes (ResetPrefix), device entry format
-    DevBuf d_job_hist, d_job_flags, rawdef;
+    DevBuf d_job_hist, d_job_flags, rawdef, unit_raw;
     std::vector<uint32_t> job_redo_list;    // units of the speculation re-run in progress (their tables are re-primed)
     void* pend = nullptr;            // batch between kc_zstd_encode_units_dev_begin and _end (Pending)
     kc_ctx* chain_after = nullptr;   // pipelining: this context's match finder waits for that context's last one
@@ -147,6 +150,8 @@ struct kc_ctx {
     bool ev7_valid = false;          // ev[7] was recorded for the batch in flight
     int last_batches = 0;            // device batches the last zstd / S2 _dev call was cut into (scratch budget)
     int last_path = 0;               // KC_PATH_HBM / KC_PATH_LDS: what the last batch's match finder / S2 encoder ran on
+    std::vector<uint8_t> up_unit_off, up_blk0, up_stage_off;  // zstd batches: what unit_off / unit_blk0 / stage_off hold on the device ...
+    const void* up_ptr[3] = {nullptr, nullptr, nullptr};     // ... and in which allocation (re-uploaded only when they change)
 };
 
 namespace {
@@ -316,6 +321,9 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
         if (getenv("KC_K2_PROF")) g.k2_prof = 1;
         envi("KC_S2_HOOK_WAIT_US", g.hook_wait_us);
         envi("KC_S2_HOOK_BATCH", g.hook_batch);
+        envi("KC_ZFAST_EPOCH", g.zfast_epoch);
+        envi("KC_ZFAST_XSEG_K", g.zfast_xseg_k);
+        envi("KC_FUSE_RAW_XXH", g.fuse_raw_xxh);
         if (const char* e = getenv("KC_HOST_CHUNKS_MIB")) {
             for (const char* q = e; *q;) { g.host_chunks.push_back((uint64_t)strtoull(q, (char**)&q, 10) << 20); if (*q == ',') q++; else if (*q) break; }
             if (g.host_chunks.empty() || g.host_chunks[0] == 0) g.host_chunks = {(uint64_t)512 << 20};
@@ -350,6 +358,9 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_BEST_SLOTS: if (v < 1 || v > 8192) return KC_ERR_BAD_ARG; g.best_slots = v; break;
         case KC_OPT_S2_VARIANT: if (v != KC_S2_VARIANT_GO && v != KC_S2_VARIANT_AMD64) return KC_ERR_BAD_ARG; g.s2_variant = v; break;
         case KC_OPT_BETTER_DICT_EPOCH: g.better_dict_epoch = v != 0; break;
+        case KC_OPT_ZFAST_EPOCH: g.zfast_epoch = v != 0; break;
+        case KC_OPT_ZFAST_XSEG_K: if (v < 0) return KC_ERR_BAD_ARG; g.zfast_xseg_k = v > (1 << 30) ? (1 << 30) : v; break;
+        case KC_OPT_FUSE_RAW_XXH: g.fuse_raw_xxh = v != 0; break;
         default: return KC_ERR_BAD_ARG;
     }
     return KC_OK;
@@ -380,6 +391,9 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_BEST_SLOTS: return g.best_slots;
         case KC_OPT_S2_VARIANT: return g.s2_variant;
         case KC_OPT_BETTER_DICT_EPOCH: return g.better_dict_epoch;
+        case KC_OPT_ZFAST_EPOCH: return g.zfast_epoch;
+        case KC_OPT_ZFAST_XSEG_K: return g.zfast_xseg_k;
+        case KC_OPT_FUSE_RAW_XXH: return g.fuse_raw_xxh;
         case KC_OPT_LAST_PATH: return c->last_path;
         case KC_OPT_LAST_BATCHES: return c->last_batches;
         default: return -1;
@@ -392,7 +406,7 @@ void kc_ctx_destroy(kc_ctx* c) {
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
                       &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->redo_blk, &c->pop_blk, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf,
-                      &c->d_job_hist, &c->d_job_flags, &c->rawdef, &c->best_tables, &c->best_cur, &c->best_cost};
+                      &c->d_job_hist, &c->d_job_flags, &c->rawdef, &c->unit_raw, &c->best_tables, &c->best_cur, &c->best_cost};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
@@ -602,8 +616,10 @@ kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, 
         c->better_epoch_now = c->tab_ep;
         return KC_OK;  // no dictionary copy either: the kernel reads the shared dictionary tables for buckets it has not written
     }
-    c->tab_owner = 0;
-    if (zfast_use_lds(c, mp, n_launch, level) && !zfast_lds_needs_hbm(c, mp) && c->job_tables == nullptr) return KC_OK;  // the tables live in LDS
+    if (zfast_use_lds(c, mp, n_launch, level) && !zfast_lds_needs_hbm(c, mp) && c->job_tables == nullptr) return KC_OK;  // the tables live in LDS (the arena is not touched)
+    const bool fastEpoch = level == KC_SPEED_FASTEST && c->cfg.zfast_epoch != 0 && mp.hist0 == 0 && c->job_tables == nullptr && mp.pos_bits + KC_ZF_EPOCH_BITS + 4 <= 32;
+    if (!fastEpoch) c->tab_owner = 0;  // (whatever follows rewrites the arena)
+    c->fast_epoch_now = 0;
     const size_t tb = match_table_bytes(level);
     if (c->job_tables != nullptr && mp.unit_list == nullptr) {  // jobs: every unit's table was primed from its own prefix on the host
         kc_status sj = ensure(c, c->tables, (size_t)n_launch * tb);
@@ -620,6 +636,22 @@ kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, 
         return KC_OK;
     }
     if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, tb, n_launch, st);
+    else if (fastEpoch) {
+        // SpeedFastest, no dictionary: the entries carry this launch's stamp (kc_zstd_match.hip), so what earlier launches left in
+        // the slots reads as empty and nothing is cleared (4 GiB of stores per 4 GiB batch: 0.65 ms) until the stamp wraps
+        const bool fresh = c->tab_owner != 2 || c->tab_pb != mp.pos_bits || n_launch > c->tab_units || c->tab_ep >= (1u << KC_ZF_EPOCH_BITS) - 1u || c->tab_ptr != c->tables.p;
+        if (fresh) {
+            HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * tb, st));
+            c->tab_owner = 2;
+            c->tab_pb = mp.pos_bits;
+            c->tab_units = n_launch;
+            c->tab_ep = 1;
+            c->tab_ptr = c->tables.p;
+        } else {
+            c->tab_ep++;
+        }
+        c->fast_epoch_now = c->tab_ep;
+    }
     else HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * tb, st));
     return KC_OK;
 }
@@ -637,6 +669,8 @@ void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uin
         if (zfast_lds_needs_hbm(c, mp)) {  // the units beyond the LDS kernel's position field
             ml = mp;
             ml.lds_split = 1;
+            ml.epoch = c->fast_epoch_now;
+            ml.xseg_k = (int32_t)c->cfg.zfast_xseg_k;
             kc_launch_zfast_match_grp(ml, (uint32_t*)((uint8_t*)c->tables.p + (size_t)slot0 * match_table_bytes(level)), n_launch, st);
         }
         return;
@@ -654,7 +688,12 @@ void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uin
         kc_launch_zbetter_match_grp(mb, tab, n_launch, mp.hist0 > 0, st);
     }
     else if (level == KC_SPEED_DEFAULT) kc_launch_zdfast_match_grp(mp, (uint32_t*)tab, n_launch, st);
-    else kc_launch_zfast_match_grp(mp, (uint32_t*)tab, n_launch, st);
+    else {
+        KcMatchParams mf = mp;
+        mf.epoch = c->fast_epoch_now;
+        mf.xseg_k = (int32_t)c->cfg.zfast_xseg_k;
+        kc_launch_zfast_match_grp(mf, (uint32_t*)tab, n_launch, st);
+    }
 }
 
 kc_status launch_match(kc_ctx* c, const KcMatchParams& mp, const uint64_t* unit_off, uint32_t n_units, uint32_t n_launch, int bs, hipStream_t st, int level) {
@@ -750,12 +789,30 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
         if (nb) HIPCHK(c, hipMemcpyAsync(c->blk_start.p, pl.blk_start.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->unit_flags.p, pl.unit_flags.data(), (size_t)n_units * 4, hipMemcpyHostToDevice, st));
     }
-    HIPCHK(c, hipMemcpyAsync(c->unit_off.p, pl.rel_off.data(), (n_units + 1) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->unit_blk0.p, pl.blk0.data(), (n_units + 1) * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->stage_off.p, pl.stage_off.data(), (n_units + 1) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(c->redo.p, 0, (size_t)n_units * 4, st));
-    HIPCHK(c, hipMemsetAsync(c->redo_blk.p, 0, (size_t)nb + 1, st));
-    HIPCHK(c, hipMemsetAsync(c->errflag.p, 0, 64, st));
+    {   // the layout arrays: batches of equal-sized units repeat them exactly (every step of a fixed-size workload), and a copy from
+        // pageable memory stalls the host for tens of microseconds each — upload only what differs from what the device holds
+        auto same = [](const std::vector<uint8_t>& held, const void* p, size_t n, const void* dev, const void* held_dev) {
+            return dev == held_dev && held.size() == n && memcmp(held.data(), p, n) == 0;
+        };
+        auto keep = [](std::vector<uint8_t>& held, const void* p, size_t n) { held.assign((const uint8_t*)p, (const uint8_t*)p + n); };
+        const size_t n8 = (size_t)(n_units + 1) * 8, n4 = (size_t)(n_units + 1) * 4;
+        if (!same(c->up_unit_off, pl.rel_off.data(), n8, c->unit_off.p, c->up_ptr[0])) {
+            HIPCHK(c, hipMemcpyAsync(c->unit_off.p, pl.rel_off.data(), n8, hipMemcpyHostToDevice, st));
+            keep(c->up_unit_off, pl.rel_off.data(), n8);
+            c->up_ptr[0] = c->unit_off.p;
+        }
+        if (!same(c->up_blk0, pl.blk0.data(), n4, c->unit_blk0.p, c->up_ptr[1])) {
+            HIPCHK(c, hipMemcpyAsync(c->unit_blk0.p, pl.blk0.data(), n4, hipMemcpyHostToDevice, st));
+            keep(c->up_blk0, pl.blk0.data(), n4);
+            c->up_ptr[1] = c->unit_blk0.p;
+        }
+        if (!same(c->up_stage_off, pl.stage_off.data(), n8, c->stage_off.p, c->up_ptr[2])) {
+            HIPCHK(c, hipMemcpyAsync(c->stage_off.p, pl.stage_off.data(), n8, hipMemcpyHostToDevice, st));
+            keep(c->up_stage_off, pl.stage_off.data(), n8);
+            c->up_ptr[2] = c->stage_off.p;
+        }
+    }
+    // (the flag arrays of the batch are zeroed by one launch further down: kc_launch_clear)
 
     const uint8_t* d_src = d_src_base + unit_off[0];
     // ---- dictionary (raw content, WithEncoderDictRaw): history = dict || unit (enc_base.go:189-198) ----
@@ -888,8 +945,27 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     ep.err_flag = (uint32_t*)c->errflag.p;
     // raw blocks are copied once, by the compaction, from the source (KcRawDef): the entries of blocks that are not raw stay zero
     if ((s = ensure(c, c->rawdef, ((size_t)nb + 1) * sizeof(KcRawDef))) != KC_OK) return s;
-    HIPCHK(c, hipMemsetAsync(c->rawdef.p, 0, ((size_t)nb + 1) * sizeof(KcRawDef), st));
     ep.rawdef = (KcRawDef*)c->rawdef.p;
+    // The checksum moves behind the entropy stage (kc_xxh64_fin_kernel) where the batch has a regular block grid and no history in
+    // front of its units: frames that turn out to be raw blocks only then get their payload copied by the pass that hashes it.
+    const bool fuse_xxh = c->cfg.fuse_raw_xxh != 0 && o->crc && !c->job_hist && !useDict && hist0 == 0 && !irregular && (bs % 512) == 0 && feed == nullptr;
+    ep.unit_raw = nullptr;
+    if (fuse_xxh) {
+        if ((s = ensure(c, c->unit_raw, (size_t)n_units * 4 + 4)) != KC_OK) return s;
+        ep.unit_raw = (uint32_t*)c->unit_raw.p;
+        ep.xxh = nullptr;
+    }
+    {   // the batch's flag arrays, zeroed by one launch (every DevBuf has at least 256 bytes of slack behind the size asked for)
+        KcClearList cl;
+        memset(&cl, 0, sizeof(cl));
+        auto add = [&](void* q, size_t bytes) { cl.p[cl.count] = q; cl.n16[cl.count] = (bytes + 15) / 16; cl.count++; };
+        add(c->redo.p, (size_t)n_units * 4);
+        add(c->redo_blk.p, (size_t)nb + 1);
+        add(c->errflag.p, 64);
+        add(c->rawdef.p, ((size_t)nb + 1) * sizeof(KcRawDef));
+        if (fuse_xxh) add(c->unit_raw.p, (size_t)n_units * 4);
+        kc_launch_clear(cl, st);
+    }
     ep.prof = nullptr;
     const bool k2prof = c->cfg.k2_prof != 0;
     if (k2prof) {
@@ -904,7 +980,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     mp.unit_base = 0;
     ep.unit_base = 0;
     if (feed == nullptr) {
-        if (o->crc && !c->job_hist) kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p, n_units, (uint64_t*)c->xxh.p, st);  // (a job stream's checksum is the host's)
+        if (o->crc && !c->job_hist && !fuse_xxh) kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p, n_units, (uint64_t*)c->xxh.p, st);  // (a job stream's checksum is the host's)
         HIPCHK(c, hipEventRecord(c->ev[1], st));
         if ((s = launch_match(c, mp, unit_off, n_units, n_units, bs, st, o->level)) != KC_OK) return s;
     } else {
@@ -969,6 +1045,35 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
     HIPCHK(c, hipEventRecord(c->ev[3], st));
     HIPCHK(c, hipGetLastError());
 
+    // sizes -> offsets, checksum (+ payload of the raw-only frames), compaction.  Enqueued right behind the entropy stage, before the
+    // host has looked at the re-run flags: a re-run is rare, and when one happens the pass simply runs again behind it (it rewrites
+    // every byte of dst) — so the device does not idle through the flag read-back of every batch.
+    auto finish_pass = [&]() -> kc_status {
+        kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n_units, (uint64_t*)c->out_off.p, st);
+        if (ep.unit_raw != nullptr) {  // the checksum, and with it the payload of the frames that are raw blocks only
+            KcXxhFinParams xf;
+            xf.src = ep.src;
+            xf.unit_off = ep.unit_off;
+            xf.n_units = n_units;
+            xf.stage = (uint8_t*)c->stage.p;
+            xf.stage_off = (const uint64_t*)c->stage_off.p;
+            xf.out_size = (const uint32_t*)c->out_size.p;
+            xf.out_off = (const uint64_t*)c->out_off.p;
+            xf.dst = d_dst;
+            xf.unit_raw = ep.unit_raw;
+            xf.rawdef = ep.rawdef;
+            xf.unit_blk0 = ep.unit_blk0;
+            xf.xxh_out = (uint64_t*)c->xxh.p;
+            kc_launch_xxh64_fin(xf, st);
+        }
+        kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p, (const uint32_t*)c->out_size.p,
+                          (const uint64_t*)c->out_off.p, d_dst, n_units, st, ep.src, ep.unit_off, ep.unit_blk0, ep.rawdef, ep.unit_raw);
+        HIPCHK(c, hipGetLastError());
+        return KC_OK;
+    };
+    HIPCHK(c, hipEventRecord(c->ev[4], st));
+    if ((s = finish_pass()) != KC_OK) return s;
+    HIPCHK(c, hipEventRecord(c->ev[5], st));
     // Speculation check: a block that fell back to raw only after entropy coding (blockenc.go:811-817)
     // pops the repeat offsets; if the following block was parsed with the un-popped offsets the unit is
     // re-run with that verdict forced.  Rare (needs a compressible-looking block that ends larger than raw).
@@ -1018,11 +1123,11 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
             HIPCHK(c, hipStreamSynchronize(st));  // pop_blk / list are host vectors: the copies above must have been taken before the next pass rewrites them
         }
     }
-    HIPCHK(c, hipEventRecord(c->ev[4], st));
-    kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n_units, (uint64_t*)c->out_off.p, st);
-    kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p, (const uint32_t*)c->out_size.p,
-                      (const uint64_t*)c->out_off.p, d_dst, n_units, st, ep.src, ep.unit_off, ep.unit_blk0, ep.rawdef);
-    HIPCHK(c, hipEventRecord(c->ev[5], st));
+    if (redo_units != 0) {  // the frames of the re-run units changed: sizes, offsets and everything behind them
+        HIPCHK(c, hipEventRecord(c->ev[4], st));
+        if ((s = finish_pass()) != KC_OK) return s;
+        HIPCHK(c, hipEventRecord(c->ev[5], st));
+    }
     HIPCHK(c, hipMemcpyAsync(out_off_host, c->out_off.p, (n_units + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
@@ -1996,6 +2101,7 @@ kc_status kc_xxh64_units_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* un
     kc_status s;
     if ((s = ensure(c, c->unit_off, (n_units + 1) * 8)) || (s = ensure(c, c->xxh, (size_t)n_units * 8))) return s;
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, unit_off, (n_units + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    c->up_ptr[0] = c->up_ptr[1] = c->up_ptr[2] = nullptr;  // (the zstd batch path re-uploads its layout arrays)
     kc_launch_xxh64(d_src, (const uint64_t*)c->unit_off.p, n_units, (uint64_t*)c->xxh.p, c->stream);
     HIPCHK(c, hipMemcpyAsync(out_hash, c->xxh.p, (size_t)n_units * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2023,6 +2129,7 @@ kc_status kc_zstd_debug_parse_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8_
         return s;
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, unit_off, (n_units + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->unit_blk0.p, blk0.data(), (n_units + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    c->up_ptr[0] = c->up_ptr[1] = c->up_ptr[2] = nullptr;  // (the zstd batch path re-uploads its layout arrays)
     KcMatchParams mp;
     memset(&mp, 0, sizeof(mp));
     mp.src = d_src;
@@ -2151,6 +2258,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
         return s;
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->stage_off.p, so.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    c->up_ptr[0] = c->up_ptr[1] = c->up_ptr[2] = nullptr;  // (the zstd batch path re-uploads its layout arrays)
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (!lds) { c->tab_owner = 0; HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant), st)); }
     KcS2Params P;
@@ -2247,6 +2355,7 @@ kc_status kc_zstd_decode_units_dict_dev(kc_ctx* c, const uint8_t* d_enc, const u
         return s;
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, enc_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->stage_off.p, dst_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    c->up_ptr[0] = c->up_ptr[1] = c->up_ptr[2] = nullptr;  // (the zstd batch path re-uploads its layout arrays)
     KcZstdDecParams P;
     P.enc = d_enc;
     P.enc_off = (const uint64_t*)c->unit_off.p;
@@ -2300,6 +2409,7 @@ kc_status kc_s2_decode_blocks_dev(kc_ctx* c, const uint8_t* d_enc, const uint64_
         return s;
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, enc_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->stage_off.p, dst_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    c->up_ptr[0] = c->up_ptr[1] = c->up_ptr[2] = nullptr;  // (the zstd batch path re-uploads its layout arrays)
     KcS2DecParams P;
     P.enc = d_enc;
     P.enc_off = (const uint64_t*)c->unit_off.p;

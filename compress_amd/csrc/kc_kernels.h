@@ -31,14 +31,18 @@ struct KcMatchParams {
     const uint32_t* unit_hist;  // device or null: per-unit history bytes in front of the unit in `src` (jobs: the overlap prefix), replaces hist0
     const uint32_t* job_flags;  // device or null: units are the jobs of ONE WithConcurrentBlocks stream (enc_jobs.go): bit 0 = final job
     unsigned long long* prof;   // device or null: per-phase shader-clock totals of the LDS-table kernel (built with -DKC_LDS_PROF, KC_OPT_K2_PROF)
-    uint32_t epoch;             // SpeedBetterCompression: 0 = the tables were fully initialised by the host; else this launch's stamp
-                                // (entries with another stamp read as the dictionary's entry or as empty: kc_zstd_match_better.hip)
+    uint32_t epoch;             // SpeedBetterCompression, SpeedFastest (HBM-table kernel): 0 = the tables were fully initialised by the
+                                // host; else this launch's stamp (entries with another stamp read as empty — at SpeedBetterCompression
+                                // with a dictionary as the dictionary's entry: kc_zstd_match_better.hip, kc_zstd_match.hip)
     const uint8_t* proto;       // device or null: with epoch != 0 and a dictionary, the dictionary's tables (long then short)
     int32_t lds_split;          // SpeedFastest HBM kernel: 1 = skip the units the LDS-table kernel takes (those that fit KC_ZFAST_LDS_MAX_UNIT)
+    int32_t xseg_k;             // SpeedFastest HBM kernel: a probe round continues across a skip-segment boundary once (s - nextEmit) >> 5
+                                // has reached this value (0: always; a large value: never, round 2's rounds)
 };
 // SpeedFastest: 8 lanes per unit, tables = n_launch x 2^15 x u32 in HBM, zeroed by the caller
 void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st);
 static inline size_t kc_zfast_table_bytes() { return (size_t)4 << 15; }
+#define KC_ZF_EPOCH_BITS 4  // bits of the launch stamp in a table entry (stamps 1..15; KcMatchParams.epoch 0 = tables cleared per launch)
 // SpeedFastest, LDS-table path (kc_zstd_match_lds.hip): one wave per unit, the 2^15 x u32 table in LDS; units (with their
 // history) below KC_ZFAST_LDS_MAX_UNIT bytes.  proto: null or primed tables in the HBM entry format (P.pos_bits): one for all units
 // (dictionary; proto_stride 0) or one per launch slot (jobs: proto_stride = 2^15 entries)
@@ -103,6 +107,8 @@ struct KcEntropyParams {
                                // segment, last flag only on a short final block, else an empty raw last block
     int32_t stream_sync;       // WithEncoderConcurrency(1): the synchronous nextBlock form (zstd/encoder.go:364-391) resets the block
                                // before its first Encode too, so a stream frame never sees the dictionary literal table
+    uint32_t* unit_raw;     // device or null: per unit, 1 = every block of the frame is raw with its payload deferred (rawdef) — then
+                            // kc_xxh64_fin_kernel copies the payloads; with xxh == null (and crc) the checksum field is left to it too
     KcRawDef* rawdef;       // device or null: per block (global index), where a RAW block's payload goes in the frame and where it comes
                             // from in the unit: the entropy kernel then writes the 3-byte header only and kc_compact_kernel copies
                             // the payload once, from the source (instead of source -> staging slot -> output)
@@ -177,10 +183,31 @@ void kc_launch_prefix_units(const uint8_t* src, const uint64_t* unit_off, const 
 // dst[i*bytes ..] = proto[0 .. bytes) for i < n  (bytes multiple of 16)
 void kc_launch_bcast(const uint8_t* proto, uint8_t* dst, size_t bytes, uint32_t n, hipStream_t st);
 void kc_launch_xxh64(const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out, hipStream_t st);
+// XXH64 behind the entropy stage and the size scan (kc_misc.hip): writes the frame's checksum field into its staging slot and, for
+// the units flagged in unit_raw (every block raw with a deferred payload: KcEntropyParams.unit_raw), copies the payloads from the
+// source into dst while hashing them.  Regular block grid, block size a multiple of 512, no history in front of the units.
+struct KcXxhFinParams {
+    const uint8_t* src;
+    const uint64_t* unit_off;   // n_units + 1
+    uint32_t n_units;
+    uint8_t* stage;
+    const uint64_t* stage_off;
+    const uint32_t* out_size;   // frame sizes (checksum field included)
+    const uint64_t* out_off;    // frame positions in dst (the size scan's result)
+    uint8_t* dst;
+    const uint32_t* unit_raw;   // or null: no payload is copied here
+    const KcRawDef* rawdef;
+    const uint32_t* unit_blk0;
+    uint64_t* xxh_out;          // or null
+};
+void kc_launch_xxh64_fin(const KcXxhFinParams& P, hipStream_t st);
+// up to 8 device ranges zeroed by one launch: p[k] 16-byte aligned, n16[k] 16-byte words
+struct KcClearList { void* p[8]; uint64_t n16[8]; int count; };
+void kc_launch_clear(const KcClearList& L, hipStream_t st);
 // exclusive scan of sizes (u32) into offsets (u64, n+1 entries)
 void kc_launch_scan_sizes(const uint32_t* sizes, uint32_t n, uint64_t* out_off, hipStream_t st);
 // dst[out_off[i] .. ) = stage[stage_off[i] .. +sizes[i]); with rawdef: except the deferred raw-block payloads, which come from
 // src[unit_off[i] + src_pos ..) (unit_blk0[i] .. unit_blk0[i+1] are unit i's entries of rawdef)
 void kc_launch_compact(const uint8_t* stage, const uint64_t* stage_off, const uint32_t* sizes, const uint64_t* out_off,
                        uint8_t* dst, uint32_t n, hipStream_t st, const uint8_t* src = nullptr, const uint64_t* unit_off = nullptr,
-                       const uint32_t* unit_blk0 = nullptr, const KcRawDef* rawdef = nullptr);
+                       const uint32_t* unit_blk0 = nullptr, const KcRawDef* rawdef = nullptr, const uint32_t* unit_raw = nullptr);

@@ -85,6 +85,161 @@ void kc_launch_xxh64(const uint8_t* src, const uint64_t* unit_off, uint32_t n_un
 }
 
 // ---------------------------------------------------------------------------------------
+// XXH64 at the END of the pipeline (round 3): the checksum is the last field of the frame, so nothing needs it before the frame
+// is assembled.  Run behind the entropy stage and the size scan, this kernel knows which frames consist of raw blocks only
+// (incompressible units) and copies their payload into the final output WHILE it hashes it — the bytes are read once instead of
+// twice (checksum pass + compaction).  The four lanes of a unit hold one 64-byte line per load (see kc_xxh64_kernel); each lane
+// stores its 16 bytes at the line's place in the frame.  The low 32 bits of the hash go into the frame's staging slot, from where
+// the compaction takes them with the headers.
+// ---------------------------------------------------------------------------------------
+struct __attribute__((packed)) kc_u128s { uint32_t x, y, z, w; };
+__device__ __forceinline__ void st128u(uint8_t* p, const uint4 v) {  // unaligned 16-byte store
+    kc_u128s t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *(kc_u128s*)p = t;
+}
+
+__global__ __launch_bounds__(256) void kc_xxh64_fin_kernel(KcXxhFinParams P) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t u = gt >> 2;
+    const int a = (int)(gt & 3);
+    const bool active = u < P.n_units;
+    const uint8_t* p = P.src;
+    uint64_t len = 0;
+    bool raw = false;
+    if (active) {
+        p = P.src + P.unit_off[u];
+        len = P.unit_off[u + 1] - P.unit_off[u];
+        raw = P.unit_raw != nullptr && P.unit_raw[u] != 0u && len > 0;
+    }
+    // raw units: source byte x of block b goes to dst + out_off[u] + rawdef[b].frame_pos + (x - rawdef[b].src_pos); the block size
+    // is a multiple of 512 (host), so neither a 512-byte step nor a 64-byte line straddles two blocks
+    uint8_t* dbase = raw ? P.dst + P.out_off[u] : nullptr;
+    uint32_t rb = raw ? P.unit_blk0[u] : 0u;
+    uint64_t bend = 0;       // end (unit offset) of the block the shift below belongs to
+    int64_t shift = 0;       // frame position minus unit offset inside the current block
+    auto block_of = [&](uint64_t x) {  // x is the first byte of a new block (x == bend)
+        const KcRawDef r = P.rawdef[rb++];
+        shift = (int64_t)r.frame_pos - (int64_t)r.src_pos;
+        bend = (uint64_t)r.src_pos + r.size;
+    };
+    uint64_t v = a == 0 ? XP1 + XP2 : (a == 1 ? XP2 : (a == 2 ? 0ULL : 0ULL - XP1));
+    const uint64_t stripes = len >> 5;
+    const uint64_t pairs = stripes >> 1;
+    auto quad = [&](uint32_t x, bool second) -> uint32_t {
+        return second ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xFA, 0xF, 0xF, true)
+                      : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x50, 0xF, 0xF, true);
+    };
+    auto word = [&](const uint4 w, bool second) -> uint64_t {
+        const uint32_t x = quad(w.x, second), y = quad(w.y, second), z = quad(w.z, second), t = quad(w.w, second);
+        return (a & 1) ? ((uint64_t)z | ((uint64_t)t << 32)) : ((uint64_t)x | ((uint64_t)y << 32));
+    };
+    const uint8_t* q16 = p + 16 * a;
+    uint64_t i = 0;
+    // 512 bytes of a unit per step (eight loads in flight per lane): all 2048 waves of a 4 GiB batch are resident at once (8 per
+    // CU), so the bytes in flight — not the lane count — set the rate (four loads: 2.09 ms per 4 GiB read + written)
+    for (; i + 8 <= pairs; i += 8) {
+        const uint8_t* qq = q16 + (i << 6);
+        const uint4 w0 = ld128u(qq), w1 = ld128u(qq + 64), w2 = ld128u(qq + 128), w3 = ld128u(qq + 192);
+        const uint4 w4 = ld128u(qq + 256), w5 = ld128u(qq + 320), w6 = ld128u(qq + 384), w7 = ld128u(qq + 448);
+        if (raw) {
+            const uint64_t x = i << 6;
+            if (x >= bend) block_of(x);
+            uint8_t* d = dbase + (int64_t)x + shift + 16 * a;
+            st128u(d, w0); st128u(d + 64, w1); st128u(d + 128, w2); st128u(d + 192, w3);
+            st128u(d + 256, w4); st128u(d + 320, w5); st128u(d + 384, w6); st128u(d + 448, w7);
+        }
+        v = xround(v, word(w0, false)); v = xround(v, word(w0, true));
+        v = xround(v, word(w1, false)); v = xround(v, word(w1, true));
+        v = xround(v, word(w2, false)); v = xround(v, word(w2, true));
+        v = xround(v, word(w3, false)); v = xround(v, word(w3, true));
+        v = xround(v, word(w4, false)); v = xround(v, word(w4, true));
+        v = xround(v, word(w5, false)); v = xround(v, word(w5, true));
+        v = xround(v, word(w6, false)); v = xround(v, word(w6, true));
+        v = xround(v, word(w7, false)); v = xround(v, word(w7, true));
+    }
+    for (; i + 4 <= pairs; i += 4) {
+        const uint4 w0 = ld128u(q16 + (i << 6)), w1 = ld128u(q16 + ((i + 1) << 6)), w2 = ld128u(q16 + ((i + 2) << 6)), w3 = ld128u(q16 + ((i + 3) << 6));
+        if (raw) {
+            const uint64_t x = i << 6;
+            if (x >= bend) block_of(x);
+            uint8_t* d = dbase + (int64_t)x + shift + 16 * a;
+            st128u(d, w0); st128u(d + 64, w1); st128u(d + 128, w2); st128u(d + 192, w3);
+        }
+        v = xround(v, word(w0, false)); v = xround(v, word(w0, true));
+        v = xround(v, word(w1, false)); v = xround(v, word(w1, true));
+        v = xround(v, word(w2, false)); v = xround(v, word(w2, true));
+        v = xround(v, word(w3, false)); v = xround(v, word(w3, true));
+    }
+    for (; i < pairs; i++) {
+        const uint4 w0 = ld128u(q16 + (i << 6));
+        if (raw) {
+            const uint64_t x = i << 6;
+            if (x >= bend) block_of(x);
+            st128u(dbase + (int64_t)x + shift + 16 * a, w0);
+        }
+        v = xround(v, word(w0, false)); v = xround(v, word(w0, true));
+    }
+    const uint8_t* q = p + 8 * a;
+    if (stripes & 1) v = xround(v, ld64(q + ((stripes - 1) << 5)));
+    const int lane = (int)(threadIdx.x & 63);
+    const int l0 = lane & ~3;
+    const uint64_t v1 = bcast64(v, l0), v2 = bcast64(v, l0 + 1), v3 = bcast64(v, l0 + 2), v4 = bcast64(v, l0 + 3);
+    if (!active || a != 0) return;
+    if (raw) {  // the last (len mod 64) bytes of the unit
+        for (uint64_t x = pairs << 6; x < len; x++) {
+            if (x >= bend) block_of(x);
+            dbase[(int64_t)x + shift] = p[x];
+        }
+    }
+    uint64_t h;
+    if (len >= 32) {
+        h = xrol(v1, 1) + xrol(v2, 7) + xrol(v3, 12) + xrol(v4, 18);
+        h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+    } else {
+        h = XP5;
+    }
+    h += len;
+    const uint8_t* t = p + (stripes << 5);
+    int rem = (int)(len & 31);
+    for (; rem >= 8; t += 8, rem -= 8) { h ^= xround(0, ld64(t)); h = xrol(h, 27) * XP1 + XP4; }
+    if (rem >= 4) { h ^= (uint64_t)ld32(t) * XP1; h = xrol(h, 23) * XP2 + XP3; t += 4; rem -= 4; }
+    for (; rem > 0; t++, rem--) { h ^= (uint64_t)t[0] * XP5; h = xrol(h, 11) * XP1; }
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    if (P.xxh_out != nullptr) P.xxh_out[u] = h;
+    const uint32_t fsz = P.out_size[u];
+    if (len > 0 && fsz >= 4) {  // enc_base.go:34-38: the frame ends in the low four bytes of the digest
+        uint8_t* c = P.stage + P.stage_off[u] + fsz - 4;
+        c[0] = (uint8_t)h; c[1] = (uint8_t)(h >> 8); c[2] = (uint8_t)(h >> 16); c[3] = (uint8_t)(h >> 24);
+    }
+}
+void kc_launch_xxh64_fin(const KcXxhFinParams& P, hipStream_t st) {
+    if (P.n_units == 0) return;
+    const uint32_t threads = P.n_units * 4;
+    hipLaunchKernelGGL(kc_xxh64_fin_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, P);
+}
+
+// ---------------------------------------------------------------------------------------
+// the small per-batch flag arrays (re-run masks, error flag, raw-block descriptors, ...) zeroed by ONE launch: five
+// hipMemsetAsync calls cost ~30 us each on the stream, which is 4 % of a 4 ms high-entropy batch
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kc_clear_kernel(KcClearList L) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < L.count; k++) {
+        uint4* p = (uint4*)L.p[k];
+        const uint64_t n16 = L.n16[k];
+        for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) p[i] = z;
+    }
+}
+void kc_launch_clear(const KcClearList& L, hipStream_t st) {
+    uint64_t mx = 0;
+    for (int k = 0; k < L.count; k++) mx = L.n16[k] > mx ? L.n16[k] : mx;
+    if (mx == 0) return;
+    uint64_t grid = (mx + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(kc_clear_kernel, dim3((unsigned)grid), dim3(256), 0, st, L);
+}
+
+// ---------------------------------------------------------------------------------------
 // exclusive scan of per-unit sizes -> output offsets (single workgroup; n is at most a few 1e5)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void kc_scan_sizes_kernel(const uint32_t* __restrict__ sizes, uint32_t n, uint64_t* __restrict__ out_off) {
@@ -138,7 +293,7 @@ __global__ __launch_bounds__(256) void kc_compact_kernel(const uint8_t* __restri
                                                          const uint32_t* __restrict__ sizes, const uint64_t* __restrict__ out_off,
                                                          uint8_t* __restrict__ dst, uint32_t n, const uint8_t* __restrict__ src,
                                                          const uint64_t* __restrict__ unit_off, const uint32_t* __restrict__ unit_blk0,
-                                                         const KcRawDef* __restrict__ rawdef) {
+                                                         const KcRawDef* __restrict__ rawdef, const uint32_t* __restrict__ unit_raw) {
     const uint32_t u = blockIdx.x;
     if (u >= n) return;
     const uint8_t* s = stage + stage_off[u];  // 16-byte aligned
@@ -149,11 +304,12 @@ __global__ __launch_bounds__(256) void kc_compact_kernel(const uint8_t* __restri
     if (rawdef != nullptr) {  // raw blocks: the staging slot holds their 3-byte header, the payload comes from the source, once
         const uint8_t* us = src + unit_off[u];
         const uint32_t b1 = unit_blk0[u + 1];
+        const bool placed = unit_raw != nullptr && unit_raw[u] != 0u;  // kc_xxh64_fin_kernel has put the payloads where they belong
         for (uint32_t b = unit_blk0[u]; b < b1; b++) {
             const KcRawDef r = rawdef[b];
             if (r.size == 0 || r.frame_pos < cursor || r.frame_pos + r.size > len) continue;
             kc_copy_bytes(d + cursor, s + cursor, r.frame_pos - cursor, tid);
-            kc_copy_bytes(d + r.frame_pos, us + r.src_pos, r.size, tid);
+            if (!placed) kc_copy_bytes(d + r.frame_pos, us + r.src_pos, r.size, tid);
             cursor = r.frame_pos + r.size;
         }
     }
@@ -161,9 +317,9 @@ __global__ __launch_bounds__(256) void kc_compact_kernel(const uint8_t* __restri
 }
 void kc_launch_compact(const uint8_t* stage, const uint64_t* stage_off, const uint32_t* sizes, const uint64_t* out_off,
                        uint8_t* dst, uint32_t n, hipStream_t st, const uint8_t* src, const uint64_t* unit_off, const uint32_t* unit_blk0,
-                       const KcRawDef* rawdef) {
+                       const KcRawDef* rawdef, const uint32_t* unit_raw) {
     if (n == 0) return;
-    hipLaunchKernelGGL(kc_compact_kernel, dim3(n), dim3(256), 0, st, stage, stage_off, sizes, out_off, dst, n, src, unit_off, unit_blk0, rawdef);
+    hipLaunchKernelGGL(kc_compact_kernel, dim3(n), dim3(256), 0, st, stage, stage_off, sizes, out_off, dst, n, src, unit_off, unit_blk0, rawdef, unit_raw);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -429,6 +429,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         return;
     }
 
+    int nRawDef = 0;  // blocks that went out raw with their payload left to the copy kernels
     for (int b = 0; b < nblk; b++) {
         const KcBlkMeta m = P.meta[blk0 + (uint32_t)b];
         const int blkStart = hist0 + kc_blk_begin(P.blk_start, blk0, b, bs);
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         // a raw block's payload: copied here, or (rawdef) left to the compaction, which takes it from the source once
         auto raw_payload = [&]() {
             if (P.rawdef != nullptr) {
+                nRawDef++;
                 if (tid == 0) {
                     KcRawDef r;
                     r.frame_pos = (uint32_t)(opos + 3); r.src_pos = (uint32_t)blkStart; r.size = (uint32_t)size; r.pad = 0;
@@ -1233,13 +1235,16 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
     }
     // ---- checksum (enc_base.go:34-38) ----
     if (ulen > 0 && P.crc && !JOB) {  // (a job stream's checksum covers the whole stream: the host appends it)
-        if (tid == 0) {
+        if (tid == 0 && P.xxh != nullptr) {  // (null: kc_xxh64_fin_kernel fills the field in, behind this kernel)
             const uint64_t h = P.xxh[u];
             outp[opos] = (uint8_t)h; outp[opos + 1] = (uint8_t)(h >> 8); outp[opos + 2] = (uint8_t)(h >> 16); outp[opos + 3] = (uint8_t)(h >> 24);
         }
         opos += 4;
     }
-    if (tid == 0) P.out_size[u] = (uint32_t)opos;
+    if (tid == 0) {
+        P.out_size[u] = (uint32_t)opos;
+        if (P.unit_raw != nullptr) P.unit_raw[u] = (nblk > 0 && nRawDef == nblk && !JOB && hist0 == 0) ? 1u : 0u;
+    }
 }
 
 void kc_launch_zstd_entropy(const KcEntropyParams& P, uint32_t grid, hipStream_t st) {

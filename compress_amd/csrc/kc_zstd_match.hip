@@ -78,10 +78,16 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     // The reference accepts a candidate iff its 4 bytes equal the probe's (tableEntry.val == uint32(cv),
     // enc_fast.go:176,188); a tag mismatch proves they differ, so the (random, HBM-bound) candidate fetch is
     // skipped exactly when the reference would reject anyway; equal tags are still verified on the bytes.
+    // Epoch stamps (round 3): with P.epoch != 0 the low KC_ZF_EPOCH_BITS of the field above the position hold this launch's
+    // stamp and the tag loses those bits; an entry with another stamp — left by an earlier launch in a slot that is no longer
+    // cleared per batch — fails the tag test like a mismatching tag and reads as "no candidate", exactly what a zeroed
+    // bucket gives the reference (the host clears the arena when the stamp wraps).
     const int PB = P.pos_bits;  // per-launch constant (dictionary-primed tables are shared by all units)
-    const int TB = (32 - PB) > 16 ? 16 : (32 - PB);
+    const int EB = P.epoch != 0u ? KC_ZF_EPOCH_BITS : 0;
+    const int TB = (32 - PB - EB) > 16 ? 16 : (32 - PB - EB);
     const uint32_t posMask = (PB >= 32) ? 0xFFFFFFFFu : ((1u << PB) - 1u);
-    auto tagOf = [&](uint32_t v) -> uint32_t { return TB > 0 ? ((v * 2654435761u) >> (32 - TB)) : 0u; };
+    const uint32_t stamp = P.epoch;
+    auto tagOf = [&](uint32_t v) -> uint32_t { return (TB > 0 ? (((v * 2654435761u) >> (32 - TB)) << EB) : 0u) | stamp; };
     const uint8_t* const srcLo = P.src;
     const uint8_t* const srcHi = P.src_end;
 
@@ -130,6 +136,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     if (whi - wlo > ZW_RB) wlo = whi - ZW_RB;
                     pend = false;
                 }
+                KC_EMU_SYNC();  // (the ring is written by all lanes of the group and read by all of them)
                 const int sa = s + boff;
                 if (sa >= whi || sa < wlo) {  // block start, or a match jumped past the window: restart it just behind s
                     int w0 = (sa - 16) & ~15;
@@ -143,11 +150,21 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     pend = true;
                 }
                 // ---------------- probe positions of this round ----------------
+                // Lane i evaluates the i-th next probe of the scan.  The positions follow the reference's recurrence
+                // s += 2 + ((s - nextEmit) >> SK) (enc_fast.go:207) step by step, so a round is not confined to one skip
+                // segment (where the step is constant): on data without matches the step soon exceeds a segment's 32 bytes and
+                // a segment-bound round is ONE probe (round 2: 250 rounds per 128 KiB of high-entropy input, now ~35).
+                // P.xseg_k: a round crosses into the next segment only once the step has grown to 2 + xseg_k.
                 const int d0 = s - nextEmit;
                 const int k0 = d0 >> SK;
                 const int step = 2 + k0;
-                const int p = s + lig * step;
-                const bool valid = lig < W && (lig == 0 || ((d0 + (lig - 1) * step) >> SK) == k0) && p < sLimit;
+                int p = s, pprev = s;
+#pragma unroll
+                for (int j = 1; j < G; j++) {
+                    if (lig >= j) { pprev = p; p += 2 + ((p - nextEmit) >> SK); }
+                }
+                const int pnext = p + 2 + ((p - nextEmit) >> SK);  // where the scan continues when this lane is the round's last
+                const bool valid = lig < W && (lig == 0 || k0 >= P.xseg_k || ((pprev - nextEmit) >> SK) == k0) && p < sLimit;
                 // R = the 20 source bytes [p-4, p+16): D1:D2 = cv, the rest feeds the fused candidate compares
                 uint32_t D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0;
                 if (valid) {
@@ -304,12 +321,9 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 }
                 if (!found) {
                     W = P.spec_grow == 0 ? W : (P.spec_grow == 1 ? (W + 1 < G ? W + 1 : G) : ((2 * W < G) ? 2 * W : G));
-                    if (c < nvalid) {
-                        s = s + c * step;
-                    } else {
-                        const int pl = s + (nvalid - 1) * step;
-                        s = pl + 2 + ((pl - nextEmit) >> SK);
-                    }
+                    const int m = c < nvalid ? c : nvalid;  // the scan continues behind lane m - 1 (m >= 1: lane 0 depends on nobody; nvalid >= 1)
+                    if (((d0 + (m - 1) * step) >> SK) == k0) s = s + m * step;  // lanes 0 .. m-1 in lane 0's skip segment: no cross-lane read
+                    else s = (int)gbcast32<G>((uint32_t)pnext, grp, m - 1);
                     if (s >= sLimit) fin = true;
                     continue;
                 }
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 const bool fdone = (wk & 4u) != 0;
                 const int fk = (int)((wk >> 3) & 31u);
                 const int bke = (int)((wk >> 8) & 7u), bav = (int)((wk >> 11) & 7u);
-                const int ps = s + f * step;
+                const int ps = (f == 0 || ((d0 + (f - 1) * step) >> SK) == k0) ? s + f * step : (int)gbcast32<G>((uint32_t)p, grp, f);
                 int mt = (int)gbcast32<G>((uint32_t)t, grp, f);
                 // backward extension given the bke equal bytes found among the bav bytes examined (enc_fast.go:152-157, 230-234)
                 auto backlen = [&](int sp, int tp, int kmax) -> int {
@@ -375,10 +389,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
             }
         }
         pend = false;  // a refill still in flight at the end of a block is dropped; the window itself stays valid
-        if (lig < (nseq & (G - 1))) {  // the buffered tail of the sequence list
-            __builtin_amdgcn_wave_barrier();
-            sq[(nseq & ~(G - 1)) + lig] = sbuf[lig];
-        }
+        __builtin_amdgcn_wave_barrier();
+        if (lig < (nseq & (G - 1))) sq[(nseq & ~(G - 1)) + lig] = sbuf[lig];  // the buffered tail of the sequence list
         const int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
         const int nlit = sumLL + extra;
         const bool rle = nseq == 1 && nlit <= 1 && (int)firstLL == nlit && firstOf - 3u == 1u;

@@ -161,6 +161,9 @@ typedef enum {
     KC_OPT_BEST_SLOTS = 19,          /* (no variable)             SpeedBestCompression: table slots of 34 MiB = units encoded at a time (default 2048 = 68 GiB, allocated on demand) */
     KC_OPT_S2_VARIANT = 20,          /* (no variable)             s2.Encode / s2.EncodeSnappy: KC_S2_VARIANT_GO (default) or KC_S2_VARIANT_AMD64 */
     KC_OPT_BETTER_DICT_EPOCH = 21,   /* (no variable)             SpeedBetterCompression with a dictionary: 1 = epoch-stamped tables + shared dictionary table (measurements; default 0: per-batch copy) */
+    KC_OPT_ZFAST_EPOCH = 22,         /* KC_ZFAST_EPOCH            SpeedFastest HBM-table kernel, no dictionary: 1 (default) = epoch-stamped table entries, the arena is cleared every 15 batches instead of every batch */
+    KC_OPT_ZFAST_XSEG_K = 23,        /* KC_ZFAST_XSEG_K           SpeedFastest HBM-table kernel: a probe round crosses skip-segment boundaries once (s - nextEmit) >> 5 has reached this value (default 0: always; large: never) */
+    KC_OPT_FUSE_RAW_XXH = 24,        /* KC_FUSE_RAW_XXH           frames made of raw blocks only: 1 (default) = XXH64 and the payload copy in one pass over the source */
     KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
     KC_OPT_LAST_BATCHES = 101        /* read-only: device batches the last kc_zstd_encode_units_dev / kc_s2_encode_*_dev call was cut into */
 } kc_option;

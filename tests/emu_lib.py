@@ -106,6 +106,56 @@ def zfast_parse(units, block_size=65536, window=4 << 20, spec_w0=8, stream_mode=
     return out
 
 
+_grp_tables = {}
+
+
+def zfast_parse_grp(units, block_size=65536, window=4 << 20, spec_w0=1, spec_grow=1, stream_mode=0, epoch=0, xseg_k=0, slots=None, fresh=False):
+    """kc_zfast_match_grp_kernel<8> (HBM tables, 8 lanes per unit) over `units`.  epoch 0: zeroed tables; else the tables of the
+    previous calls are kept (as the context keeps its arena between batches) and `epoch` is this launch's stamp."""
+    n = len(units)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    blk0 = np.zeros(n + 1, dtype=np.uint32)
+    for i, u in enumerate(units):
+        off[i + 1] = off[i] + len(u)
+        blk0[i + 1] = blk0[i] + (len(u) + block_size - 1) // block_size
+    nb = int(blk0[n])
+    src = np.frombuffer(b"".join(units) + b"\0" * 64, dtype=np.uint8).copy()
+    al = np.zeros(len(src) + 32, dtype=np.uint8)
+    o = (-al.ctypes.data) % 16
+    al[o:o + len(src)] = src
+    base = al.ctypes.data + o
+    stride = block_size // 4 + 8
+    seqs = np.zeros(max(nb, 1) * stride, dtype=np.uint64)
+    meta = np.zeros(max(nb, 1) * 8, dtype=np.uint32)
+    maxlen = max([len(u) for u in units] + [16])
+    pb = 1
+    while (1 << pb) <= maxlen + 2:
+        pb += 1
+    if slots is not None:
+        pb = slots
+    nslot = (n + 7) // 8 * 8
+    key = "t"
+    if epoch == 0 or fresh or key not in _grp_tables or len(_grp_tables[key]) < nslot << 15:  # (the host clears the arena when it changes hands)
+        _grp_tables[key] = np.zeros(nslot << 15, dtype=np.uint32)
+    tab = _grp_tables[key]
+    L = lib()
+    L.kcemu_zfast_parse_grp.restype = C.c_int
+    L.kcemu_zfast_parse_grp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int]
+    r = L.kcemu_zfast_parse_grp(base, off.ctypes.data, n, block_size, window, stream_mode, seqs.ctypes.data, meta.ctypes.data, stride, blk0.ctypes.data,
+                                spec_w0, spec_grow, pb, tab.ctypes.data, epoch, xseg_k)
+    assert r == 0
+    out = []
+    for b in range(nb):
+        m = meta[8 * b:8 * b + 8]
+        ns = int(m[0])
+        v = seqs[b * stride:b * stride + ns]
+        tri = np.stack([(v >> np.uint64(44)).astype(np.uint32), ((v >> np.uint64(24)) & np.uint64(0xFFFFF)).astype(np.uint32),
+                        (v & np.uint64(0xFFFFFF)).astype(np.uint32)], axis=1) if ns else np.zeros((0, 3), dtype=np.uint32)
+        out.append((tri, int(m[1]), int(m[2]), int(m[3]) & 0xFF))
+    return out
+
+
 _zbest_state = {}
 
 

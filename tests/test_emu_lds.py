@@ -115,6 +115,26 @@ def test_s2_best_kernel_bit_exact(snappy):
     _cmp(blocks, emu_lib.s2_best_blocks(blocks, snappy=snappy), oracle_lib.s2_encode_snappy_best if snappy else oracle_lib.s2_encode_best)
 
 
+@pytest.mark.parametrize("w0,grow,xseg", [(1, 1, 0), (1, 1, 2), (1, 1, 1 << 20), (8, 0, 0), (2, 2, 1 << 20)])
+def test_zfast_grp_parse_matches_oracle(w0, grow, xseg):
+    """kc_zfast_match_grp_kernel<8> (the HBM-table throughput kernel, 8 lanes per unit): every block's sequence list equals the
+    oracle's fastEncoder — at every speculation policy, with rounds confined to one skip segment (round 2), crossing segments
+    always, or only once the step has grown (xseg_k)."""
+    units = _zfast_units()
+    _cmp_parse(units, emu_lib.zfast_parse_grp(units, spec_w0=w0, spec_grow=grow, xseg_k=xseg), level=1)
+
+
+def test_zfast_grp_epoch_stamped_tables():
+    """The table arena is not cleared between launches: entries carry the launch's stamp, and what earlier launches left in a slot
+    (other units' positions and tags) reads as empty.  Same slots, other units, consecutive stamps — and the stamp's bits taken
+    from the tag at the position width of 128 KiB units and of a 1 MiB unit."""
+    sets = [_zfast_units()[:8], _zfast_units()[4:12], list(reversed(_zfast_units()[:8])),
+            [corpora.corpus("T", 8, 131072, first_unit=77).tobytes()] + _zfast_units()[:3]]
+    for ep in range(1, 16):
+        units = sets[ep % len(sets)]
+        _cmp_parse(units, emu_lib.zfast_parse_grp(units, epoch=ep, slots=21, fresh=ep == 1), level=1)
+
+
 def _cmp_parse(units, got, **okw):
     bi = 0
     for ui, u in enumerate(units):

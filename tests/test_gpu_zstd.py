@@ -726,6 +726,81 @@ def test_better_level_epoch_stamped_tables_over_many_batches(oracle, kclib, with
     enc.Close()
 
 
+def test_fastest_epoch_stamped_tables_over_many_batches(oracle, kclib):
+    """SpeedFastest, HBM-table kernel: the 128 KiB-per-unit tables are not cleared per batch; entries carry the launch's stamp
+    (KC_OPT_ZFAST_EPOCH, default on).  Twenty-odd batches on one context — past the stamp's 15 values (wrap: the arena is cleared),
+    growing and shrinking unit counts, unit lengths that change the position width, one batch in between with the stamps switched
+    off (the arena changes hands and must be cleared before the next stamped batch) — each bit-exact."""
+    _torch()
+    t = corpora.corpus("T", 40, 131072, first_unit=4).tobytes()
+    m = corpora.corpus("M", 40, 131072, first_unit=9).tobytes()
+    h = corpora.corpus("H", 8, 131072, first_unit=2).tobytes()
+    enc = _enc(1)
+    assert enc.ctx().get_option(22) == 1
+    shapes = [(8, 131072), (40, 131072), (3, 131072), (12, 40000), (5, 400000), (40, 131072), (1, 700), (9, 131072)] * 3
+    for k, (n, ln) in enumerate(shapes[:22]):
+        src = (t, m, h)[k % 3]
+        units = [src[(i * 7919 + k * 131) % (len(src) - ln):][:ln] for i in range(n)]
+        ubuf, off = corpora.pack_units(units)
+        if k == 6:
+            enc.ctx().set_option(22, 0)
+        out, out_off = enc.EncodeUnits(ubuf, off)
+        if k == 6:
+            enc.ctx().set_option(22, 1)
+        _path_ran(enc, 1)
+        ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=1)
+        assert np.array_equal(out_off, ref_off) and np.array_equal(out, np.asarray(ref)), (k, n, ln)
+    enc.Close()
+
+
+@pytest.mark.parametrize("xseg", [0, 2, 1 << 20])
+def test_probe_rounds_across_skip_segments(oracle, kclib, xseg):
+    """SpeedFastest, HBM-table kernel: a probe round follows the reference's position recurrence across skip-segment boundaries
+    (KC_OPT_ZFAST_XSEG_K: always, once the step has grown, never = round 2's rounds) — the same bytes every way, on text, mixed,
+    high-entropy and edge inputs, with and without history."""
+    _torch()
+    units = [corpora.corpus(k, 1, 131072, first_unit=f).tobytes() for k, f in (("T", 1), ("H", 0), ("H", 5), ("M", 2), ("M", 3), ("J", 4))]
+    units += [corpora.corpus("H", 4, 131072, first_unit=9).tobytes()[:300001], corpora.corpus("M", 8, 131072, first_unit=1).tobytes()]
+    units += [u for u in corpora.edge_units() if len(u) < 200000] + corpora.stress_units(seed=11, n=10)
+    buf, off = corpora.pack_units(units)
+    enc = _enc(1)
+    enc.ctx().set_option(23, xseg)
+    out, out_off = enc.EncodeUnits(buf, off)
+    _path_ran(enc, 1)
+    ref, ref_off = oracle.zstd_encode_units(buf, off, threads=8, level=1)
+    assert np.array_equal(out_off, ref_off) and np.array_equal(out, np.asarray(ref))
+    enc.Close()
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("level", [1, "1L", 2, 3])
+def test_raw_only_frames_checksum_and_copy_in_one_pass(oracle, kclib, level, fuse):
+    """Frames that end up as raw blocks only get their payload copied by the kernel that hashes it, behind the entropy stage
+    (kc_xxh64_fin_kernel, KC_OPT_FUSE_RAW_XXH); every other frame gets its checksum field from the same kernel.  Incompressible
+    units of one and several blocks, ragged lengths, exact block multiples, tiny and empty units, units whose blocks are raw and
+    compressed in turn, next to compressible ones; with the default and with a small window (64 KiB blocks); without the
+    checksum."""
+    _torch()
+    from compress_amd import zstd
+    h = corpora.corpus("H", 12, 131072, first_unit=3).tobytes()
+    t = corpora.corpus("T", 4, 131072, first_unit=8).tobytes()
+    units = [h[:131072], h[7:7 + 131071], h[100:100 + 65536 + 13], h[:400000], h[131072:131072 + 262144], h[5:305], h[9:40], h[3:4], b"",
+             h[:1 << 20], h[:131072] + t[:131072], t[:131072] + h[:131072] + t[:50000], t[:131072], h[1:1 + 131072 + 255], h[2:2 + 256]]
+    buf, off = corpora.pack_units(units)
+    for opts, okw in (((), {}), ((zstd.WithWindowSize(1 << 16),), {"window_size": 1 << 16}), ((zstd.WithEncoderCRC(False),), {"crc": False})):
+        enc = zstd.NewWriter(None, *_lo(level), *opts)
+        enc.ctx().set_option(24, fuse)
+        out, out_off = enc.EncodeUnits(buf, off)
+        ref, ref_off = oracle.zstd_encode_units(buf, off, threads=8, level=_li(level), **okw)
+        bad = [i for i in range(len(units)) if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
+        assert not bad and np.array_equal(out_off, ref_off), (okw, bad)
+        so, so_off = enc.EncodeStreams(buf, off)  # Write ... Close: stream frames (an empty last block behind exact block multiples)
+        sref = oracle.ZstdOracle(level=_li(level), **okw)
+        for i, u in enumerate(units):
+            assert so[int(so_off[i]):int(so_off[i + 1])].tobytes() == sref.encode_stream(u), ("stream", okw, i, len(u))
+        enc.Close()
+
+
 def test_submit_wait_two_contexts_overlap(oracle, kclib, monkeypatch):
     """kc_zstd_encode_units_submit / kc_wait: two contexts alternate over six batches, each call running its chunk-fed host path on
     its own thread while the other context's call is in flight; the frames equal the synchronous call's, a second submit on a

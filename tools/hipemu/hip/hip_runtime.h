@@ -46,6 +46,7 @@ void wave_sync();
 void block_sync();
 int lane();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void set_group(unsigned g);  // sub-wave groups of g lanes rendezvous among themselves (kernels whose groups diverge); 64: whole waves
 uint64_t collectives();   // cross-lane operations executed so far (diagnostics)
 }  // namespace hipemu
 

@@ -64,6 +64,7 @@ struct Block {
 Block* g_blk = nullptr;
 uint64_t g_coll = 0;
 bool g_check_site = true;
+unsigned g_group = 64;  // lanes that rendezvous with each other: 64, or the sub-wave group size of a kernel whose groups diverge freely
 std::vector<char*> g_stacks;  // reused across launches
 
 void yield() { hipemu_switch(&g_blk->cur->sp, g_blk->sched_sp); }
@@ -135,6 +136,10 @@ const dim3& block_dim() { return g_blk->bdim; }
 const dim3& grid_dim() { return g_blk->gdim; }
 int lane() { return g_blk->cur->lane; }
 uint64_t collectives() { return g_coll; }
+// Kernels that give each G-lane group of a wave its own work item (kc_zstd_match.hip: 8 units per wave) let the groups diverge; the
+// hardware then runs them one after the other under the execution mask, and a ballot / shuffle of one group sees only its own
+// lanes.  With set_group(G) the lanes of a group rendezvous among themselves (G must divide 64; 64 restores whole waves).
+void set_group(unsigned g) { g_group = (g == 0 || g > 64 || (64 % g) != 0) ? 64 : g; }
 
 __attribute__((noinline)) void wave_sync() {
     g_coll++;
@@ -214,14 +219,14 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             for (unsigned bx = 0; bx < grid.x; bx++) {
                 B.bid = dim3(bx, by, bz);
                 B.fibers.assign(nt, Fiber());
-                B.waves.assign((nt + 63) / 64, Wave());
+                B.waves.assign((nt + g_group - 1) / g_group, Wave());
                 B.live = (int)nt;
                 B.b_arrived = 0;
                 for (unsigned t = 0; t < nt; t++) {
                     Fiber& f = B.fibers[t];
                     f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
                     f.lane = (int)(t & 63);
-                    f.wave = (int)(t >> 6);
+                    f.wave = (int)(t / g_group);  // (lane numbers stay those of the 64-wide wave: ballot bits and shuffle sources are absolute)
                     f.stack = g_stacks[t];
                     Wave& w = B.waves[f.wave];
                     w.live++;

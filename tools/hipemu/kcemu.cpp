@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "../../compress_amd/csrc/kc_s2_lds.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_lds.hip"
+#include "../../compress_amd/csrc/kc_zstd_match.hip"
 #include "../../compress_amd/csrc/kc_s2_best.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_best.hip"
 
@@ -51,6 +52,36 @@ int kcemu_zfast_parse(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     P.rep2 = rep2;
     P.stream_mode = stream_mode;
     kc_launch_zfast_match_lds(P, proto, 0u, n, nullptr);
+    return 0;
+}
+
+// the SpeedFastest HBM-table group kernel (kc_zfast_match_grp_kernel<8>) over n units; tables: n x 2^15 u32 kept by the caller between
+// calls (epoch 0: zeroed by the caller; else the launch's stamp)
+int kcemu_zfast_parse_grp(const uint8_t* src, const uint64_t* unit_off, uint32_t n, int block_size, int window, int stream_mode, uint64_t* seqs,
+                          KcBlkMeta* meta, uint32_t seq_stride, const uint32_t* unit_blk0, int spec_w0, int spec_grow, int pos_bits, uint32_t* tables,
+                          uint32_t epoch, int xseg_k) {
+    KcMatchParams P;
+    memset(&P, 0, sizeof(P));
+    P.src = src;
+    P.src_end = src + unit_off[n];
+    P.unit_off = unit_off;
+    P.unit_blk0 = unit_blk0;
+    P.seqs = seqs;
+    P.meta = meta;
+    P.seq_stride = seq_stride;
+    P.block_size = block_size;
+    P.max_match_off = window;
+    P.spec_w0 = spec_w0;
+    P.spec_grow = spec_grow;
+    P.pos_bits = pos_bits;
+    P.rep1 = 1;
+    P.rep2 = 4;
+    P.stream_mode = stream_mode;
+    P.epoch = epoch;
+    P.xseg_k = xseg_k;
+    hipemu::set_group(8);  // 8 units per wave, the groups diverge freely
+    kc_launch_zfast_match_grp(P, tables, n, nullptr);
+    hipemu::set_group(64);
     return 0;
 }
 
