@@ -102,6 +102,8 @@ struct KcCfg {
     int64_t best_slots = 2048;            // SpeedBestCompression: table slots (34 MiB each) = units encoded at a time
     int64_t zfast_epoch = 1;              // SpeedFastest HBM-table kernel without a dictionary: epoch-stamped tables instead of clearing 128 KiB per unit per batch
     int64_t zfast_xseg_k = 0;             // SpeedFastest HBM-table kernel: probe rounds cross skip-segment boundaries once (s - nextEmit) >> 5 reaches this (0: always)
+    int64_t zfast_filter = 1;             // SpeedFastest HBM-table kernel: "nothing written there yet" filter in the idle sequence buffer (units without a sequence so far)
+    int64_t xxh_fin_mode = 1;             // kc_xxh64_fin_kernel: how the payload of raw-only frames is stored (KcXxhFinParams.mode)
     int64_t fuse_raw_xxh = 1;             // frames made of raw blocks only: checksum and payload copy in one pass over the source (kc_xxh64_copy_kernel)
 };
 
@@ -324,6 +326,8 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
         envi("KC_ZFAST_EPOCH", g.zfast_epoch);
         envi("KC_ZFAST_XSEG_K", g.zfast_xseg_k);
         envi("KC_FUSE_RAW_XXH", g.fuse_raw_xxh);
+        envi("KC_ZFAST_FILTER", g.zfast_filter);
+        envi("KC_XXH_FIN_MODE", g.xxh_fin_mode);
         if (const char* e = getenv("KC_HOST_CHUNKS_MIB")) {
             for (const char* q = e; *q;) { g.host_chunks.push_back((uint64_t)strtoull(q, (char**)&q, 10) << 20); if (*q == ',') q++; else if (*q) break; }
             if (g.host_chunks.empty() || g.host_chunks[0] == 0) g.host_chunks = {(uint64_t)512 << 20};
@@ -361,6 +365,8 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_ZFAST_EPOCH: g.zfast_epoch = v != 0; break;
         case KC_OPT_ZFAST_XSEG_K: if (v < 0) return KC_ERR_BAD_ARG; g.zfast_xseg_k = v > (1 << 30) ? (1 << 30) : v; break;
         case KC_OPT_FUSE_RAW_XXH: g.fuse_raw_xxh = v != 0; break;
+        case KC_OPT_ZFAST_FILTER: g.zfast_filter = v != 0; break;
+        case KC_OPT_XXH_FIN_MODE: if (v < 0 || v > 2) return KC_ERR_BAD_ARG; g.xxh_fin_mode = v; break;
         default: return KC_ERR_BAD_ARG;
     }
     return KC_OK;
@@ -394,6 +400,8 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_ZFAST_EPOCH: return g.zfast_epoch;
         case KC_OPT_ZFAST_XSEG_K: return g.zfast_xseg_k;
         case KC_OPT_FUSE_RAW_XXH: return g.fuse_raw_xxh;
+        case KC_OPT_ZFAST_FILTER: return g.zfast_filter;
+        case KC_OPT_XXH_FIN_MODE: return g.xxh_fin_mode;
         case KC_OPT_LAST_PATH: return c->last_path;
         case KC_OPT_LAST_BATCHES: return c->last_batches;
         default: return -1;
@@ -671,6 +679,7 @@ void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uin
             ml.lds_split = 1;
             ml.epoch = c->fast_epoch_now;
             ml.xseg_k = (int32_t)c->cfg.zfast_xseg_k;
+            ml.empty_filter = c->cfg.zfast_filter != 0;
             kc_launch_zfast_match_grp(ml, (uint32_t*)((uint8_t*)c->tables.p + (size_t)slot0 * match_table_bytes(level)), n_launch, st);
         }
         return;
@@ -692,6 +701,7 @@ void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uin
         KcMatchParams mf = mp;
         mf.epoch = c->fast_epoch_now;
         mf.xseg_k = (int32_t)c->cfg.zfast_xseg_k;
+        mf.empty_filter = c->cfg.zfast_filter != 0;
         kc_launch_zfast_match_grp(mf, (uint32_t*)tab, n_launch, st);
     }
 }
@@ -948,7 +958,7 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     ep.rawdef = (KcRawDef*)c->rawdef.p;
     // The checksum moves behind the entropy stage (kc_xxh64_fin_kernel) where the batch has a regular block grid and no history in
     // front of its units: frames that turn out to be raw blocks only then get their payload copied by the pass that hashes it.
-    const bool fuse_xxh = c->cfg.fuse_raw_xxh != 0 && o->crc && !c->job_hist && !useDict && hist0 == 0 && !irregular && (bs % 512) == 0 && feed == nullptr;
+    const bool fuse_xxh = c->cfg.fuse_raw_xxh != 0 && o->crc && !c->job_hist && !useDict && hist0 == 0 && !irregular && (bs % 256) == 0 && feed == nullptr;
     ep.unit_raw = nullptr;
     if (fuse_xxh) {
         if ((s = ensure(c, c->unit_raw, (size_t)n_units * 4 + 4)) != KC_OK) return s;
@@ -1064,6 +1074,7 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
             xf.rawdef = ep.rawdef;
             xf.unit_blk0 = ep.unit_blk0;
             xf.xxh_out = (uint64_t*)c->xxh.p;
+            xf.mode = (int32_t)c->cfg.xxh_fin_mode;
             kc_launch_xxh64_fin(xf, st);
         }
         kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p, (const uint32_t*)c->out_size.p,

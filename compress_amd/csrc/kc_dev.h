@@ -24,9 +24,7 @@ __device__ __forceinline__ uint4 ld128u(const uint8_t* p) {  // unaligned 16-byt
 // CPU emulator of the tests, tools/hipemu, which runs lanes out of lockstep, has to synchronise them here).
 #ifdef KC_HIPEMU
 #define KC_WAVE_SYNC() hipemu::wave_sync()
-#define KC_EMU_SYNC() hipemu::wave_sync()   // the emulator only: an exchange through LDS the hardware orders by itself, in a kernel where KC_WAVE_SYNC's fence is not wanted
 #else
-#define KC_EMU_SYNC() do { } while (0)
 #define KC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 

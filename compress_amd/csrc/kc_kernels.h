@@ -36,6 +36,8 @@ struct KcMatchParams {
                                 // with a dictionary as the dictionary's entry: kc_zstd_match_better.hip, kc_zstd_match.hip)
     const uint8_t* proto;       // device or null: with epoch != 0 and a dictionary, the dictionary's tables (long then short)
     int32_t lds_split;          // SpeedFastest HBM kernel: 1 = skip the units the LDS-table kernel takes (those that fit KC_ZFAST_LDS_MAX_UNIT)
+    int32_t empty_filter;       // SpeedFastest HBM kernel: 1 = skip the table loads of bucket groups the unit has not written yet, while it has
+                                // emitted no sequence (kc_zstd_match.hip; the tables must start empty: no dictionary, no job prefix)
     int32_t xseg_k;             // SpeedFastest HBM kernel: a probe round continues across a skip-segment boundary once (s - nextEmit) >> 5
                                 // has reached this value (0: always; a large value: never, round 2's rounds)
 };
@@ -185,7 +187,7 @@ void kc_launch_bcast(const uint8_t* proto, uint8_t* dst, size_t bytes, uint32_t 
 void kc_launch_xxh64(const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint64_t* out, hipStream_t st);
 // XXH64 behind the entropy stage and the size scan (kc_misc.hip): writes the frame's checksum field into its staging slot and, for
 // the units flagged in unit_raw (every block raw with a deferred payload: KcEntropyParams.unit_raw), copies the payloads from the
-// source into dst while hashing them.  Regular block grid, block size a multiple of 512, no history in front of the units.
+// source into dst while hashing them.  Regular block grid, block size a multiple of 256, no history in front of the units.
 struct KcXxhFinParams {
     const uint8_t* src;
     const uint64_t* unit_off;   // n_units + 1
@@ -199,6 +201,8 @@ struct KcXxhFinParams {
     const KcRawDef* rawdef;
     const uint32_t* unit_blk0;
     uint64_t* xxh_out;          // or null
+    int32_t mode;               // payload copy of the raw-only frames: 0 stored straight from the registers, 1 the same with the next step's
+                                // loads issued before the current step's stores, 2 through an LDS ring as 16-byte aligned stores
 };
 void kc_launch_xxh64_fin(const KcXxhFinParams& P, hipStream_t st);
 // up to 8 device ranges zeroed by one launch: p[k] 16-byte aligned, n16[k] 16-byte words

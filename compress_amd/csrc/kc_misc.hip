@@ -92,13 +92,26 @@ void kc_launch_xxh64(const uint8_t* src, const uint64_t* unit_off, uint32_t n_un
 // stores its 16 bytes at the line's place in the frame.  The low 32 bits of the hash go into the frame's staging slot, from where
 // the compaction takes them with the headers.
 // ---------------------------------------------------------------------------------------
+#ifdef KC_HIPEMU
+#define KC_QUAD_SYNC() hipemu::wave_sync()  // (the emulator runs this kernel with the quads as rendezvous groups)
+#else
+#define KC_QUAD_SYNC() __builtin_amdgcn_wave_barrier()  // the hardware runs a wave's LDS instructions in order: only the compiler must not reorder
+#endif
 struct __attribute__((packed)) kc_u128s { uint32_t x, y, z, w; };
 __device__ __forceinline__ void st128u(uint8_t* p, const uint4 v) {  // unaligned 16-byte store
     kc_u128s t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
     *(kc_u128s*)p = t;
 }
 
+#define XF_RING 512  // MODE 2: bytes of a unit staged in LDS (two 256-byte steps; the last 16 bytes of the previous step are still needed)
+// MODE 0: four loads, four stores, sixteen hash rounds per 256-byte step.  MODE 1: the same, software-pipelined.  MODE 2: the step's
+// bytes go through an LDS ring per unit and leave as 16-byte ALIGNED stores (the payload's place in the frame is not aligned to the
+// source: stored straight from the registers, every 64-byte store of a quad straddles two lines and every line is written twice).
+template <int MODE>
 __global__ __launch_bounds__(256) void kc_xxh64_fin_kernel(KcXxhFinParams P) {
+    constexpr bool PIPE = MODE == 1;
+    __shared__ __attribute__((aligned(16))) uint8_t stg_all[MODE == 2 ? 64 * (XF_RING + 16) : 16];
+    uint8_t* const stg = stg_all + (MODE == 2 ? (threadIdx.x >> 2) * (XF_RING + 16) : 0);
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t u = gt >> 2;
     const int a = (int)(gt & 3);
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256) void kc_xxh64_fin_kernel(KcXxhFinParams P) {
         raw = P.unit_raw != nullptr && P.unit_raw[u] != 0u && len > 0;
     }
     // raw units: source byte x of block b goes to dst + out_off[u] + rawdef[b].frame_pos + (x - rawdef[b].src_pos); the block size
-    // is a multiple of 512 (host), so neither a 512-byte step nor a 64-byte line straddles two blocks
+    // is a multiple of 256 (host), so neither a 256-byte step nor a 64-byte line straddles two blocks
     uint8_t* dbase = raw ? P.dst + P.out_off[u] : nullptr;
     uint32_t rb = raw ? P.unit_blk0[u] : 0u;
     uint64_t bend = 0;       // end (unit offset) of the block the shift below belongs to
@@ -135,28 +148,78 @@ __global__ __launch_bounds__(256) void kc_xxh64_fin_kernel(KcXxhFinParams P) {
     };
     const uint8_t* q16 = p + 16 * a;
     uint64_t i = 0;
-    // 512 bytes of a unit per step (eight loads in flight per lane): all 2048 waves of a 4 GiB batch are resident at once (8 per
-    // CU), so the bytes in flight — not the lane count — set the rate (four loads: 2.09 ms per 4 GiB read + written)
-    for (; i + 8 <= pairs; i += 8) {
-        const uint8_t* qq = q16 + (i << 6);
-        const uint4 w0 = ld128u(qq), w1 = ld128u(qq + 64), w2 = ld128u(qq + 128), w3 = ld128u(qq + 192);
-        const uint4 w4 = ld128u(qq + 256), w5 = ld128u(qq + 320), w6 = ld128u(qq + 384), w7 = ld128u(qq + 448);
-        if (raw) {
-            const uint64_t x = i << 6;
-            if (x >= bend) block_of(x);
-            uint8_t* d = dbase + (int64_t)x + shift + 16 * a;
-            st128u(d, w0); st128u(d + 64, w1); st128u(d + 128, w2); st128u(d + 192, w3);
-            st128u(d + 256, w4); st128u(d + 320, w5); st128u(d + 384, w6); st128u(d + 448, w7);
+    if (MODE == 2) {
+        uint8_t* dcur = nullptr;  // where unit byte 0 would sit in the frame under the current block's shift
+        int64_t hi = 0;           // aligned stores have covered the frame up to dcur + hi (a 16-byte aligned address)
+        uint32_t al = 0;          // dcur modulo 16
+        bool staged = false;
+        auto bytes_out = [&](int64_t from, int64_t to) {  // unit bytes [from, to): fewer than 16, lane 0 of the quad
+            if (a == 0) for (int64_t q = from; q < to; q++) dcur[q] = p[q];
+        };
+        for (; i + 4 <= pairs; i += 4) {
+            const uint4 c0 = ld128u(q16 + (i << 6)), c1 = ld128u(q16 + ((i + 1) << 6)), c2 = ld128u(q16 + ((i + 2) << 6)), c3 = ld128u(q16 + ((i + 3) << 6));
+            if (raw) {
+                const int64_t x = (int64_t)(i << 6);
+                if ((uint64_t)x >= bend) {  // a new block (its first byte is the first byte of this step)
+                    if (staged) bytes_out(hi, x);  // what the previous block's last aligned word did not reach
+                    block_of((uint64_t)x);
+                    dcur = dbase + shift;
+                    al = (uint32_t)((uintptr_t)dcur & 15);
+                    hi = ((x + al + 15) & ~(int64_t)15) - al;
+                    bytes_out(x, hi);
+                    staged = true;
+                }
+                const uint32_t o = ((uint32_t)x + 16u * (uint32_t)a) & (XF_RING - 1);
+                *(uint4*)(stg + o) = c0;
+                *(uint4*)(stg + ((o + 64) & (XF_RING - 1))) = c1;
+                *(uint4*)(stg + ((o + 128) & (XF_RING - 1))) = c2;
+                *(uint4*)(stg + ((o + 192) & (XF_RING - 1))) = c3;
+                if (o == 0) *(uint4*)(stg + XF_RING) = c0;  // the ring's first 16 bytes again behind its end: a 16-byte read never wraps
+                KC_QUAD_SYNC();
+                const int64_t nhi = ((x + 256 + al) & ~(int64_t)15) - al;
+                const bool last = a < 3 || (nhi - hi) == 256;  // 15 or 16 aligned words: only the quad's very last one may be missing
+                const int64_t s0 = hi + 16 * a;                // this lane's words: s0, s0 + 64, s0 + 128, s0 + 192 (unit offsets)
+                const uint4 w0 = ld128u(stg + ((uint32_t)s0 & (XF_RING - 1)));
+                const uint4 w1 = ld128u(stg + ((uint32_t)(s0 + 64) & (XF_RING - 1)));
+                const uint4 w2 = ld128u(stg + ((uint32_t)(s0 + 128) & (XF_RING - 1)));
+                const uint4 w3 = ld128u(stg + ((uint32_t)(s0 + 192) & (XF_RING - 1)));
+                uint4* dq = (uint4*)(dcur + s0);  // 16-byte aligned
+                dq[0] = w0; dq[4] = w1; dq[8] = w2;
+                if (last) dq[12] = w3;
+                hi = nhi;
+                KC_QUAD_SYNC();
+            }
+            v = xround(v, word(c0, false)); v = xround(v, word(c0, true));
+            v = xround(v, word(c1, false)); v = xround(v, word(c1, true));
+            v = xround(v, word(c2, false)); v = xround(v, word(c2, true));
+            v = xround(v, word(c3, false)); v = xround(v, word(c3, true));
         }
-        v = xround(v, word(w0, false)); v = xround(v, word(w0, true));
-        v = xround(v, word(w1, false)); v = xround(v, word(w1, true));
-        v = xround(v, word(w2, false)); v = xround(v, word(w2, true));
-        v = xround(v, word(w3, false)); v = xround(v, word(w3, true));
-        v = xround(v, word(w4, false)); v = xround(v, word(w4, true));
-        v = xround(v, word(w5, false)); v = xround(v, word(w5, true));
-        v = xround(v, word(w6, false)); v = xround(v, word(w6, true));
-        v = xround(v, word(w7, false)); v = xround(v, word(w7, true));
-    }
+        if (raw && staged) bytes_out(hi, (int64_t)(i << 6));  // (the rest of the unit, below, is stored straight from the registers)
+    } else if (PIPE) {
+        // software-pipelined: the loads of step i+1 are issued BEFORE the stores of step i.  gfx9 counts loads and stores in one
+        // in-order counter (vmcnt), so with the stores first every wait for a load also waits for the (slower, misaligned) stores in
+        // front of it; this way the stores of a step drain under its sixteen hash rounds and under the next step's loads.
+        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
+        if (pairs >= 4) { c0 = ld128u(q16); c1 = ld128u(q16 + 64); c2 = ld128u(q16 + 128); c3 = ld128u(q16 + 192); }
+        for (; i + 4 <= pairs; i += 4) {
+            uint4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+            if (i + 8 <= pairs) {
+                const uint8_t* qq = q16 + ((i + 4) << 6);
+                n0 = ld128u(qq); n1 = ld128u(qq + 64); n2 = ld128u(qq + 128); n3 = ld128u(qq + 192);
+            }
+            if (raw) {
+                const uint64_t x = i << 6;
+                if (x >= bend) block_of(x);
+                uint8_t* d = dbase + (int64_t)x + shift + 16 * a;
+                st128u(d, c0); st128u(d + 64, c1); st128u(d + 128, c2); st128u(d + 192, c3);
+            }
+            v = xround(v, word(c0, false)); v = xround(v, word(c0, true));
+            v = xround(v, word(c1, false)); v = xround(v, word(c1, true));
+            v = xround(v, word(c2, false)); v = xround(v, word(c2, true));
+            v = xround(v, word(c3, false)); v = xround(v, word(c3, true));
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+    } else
     for (; i + 4 <= pairs; i += 4) {
         const uint4 w0 = ld128u(q16 + (i << 6)), w1 = ld128u(q16 + ((i + 1) << 6)), w2 = ld128u(q16 + ((i + 2) << 6)), w3 = ld128u(q16 + ((i + 3) << 6));
         if (raw) {
@@ -215,7 +278,9 @@ __global__ __launch_bounds__(256) void kc_xxh64_fin_kernel(KcXxhFinParams P) {
 void kc_launch_xxh64_fin(const KcXxhFinParams& P, hipStream_t st) {
     if (P.n_units == 0) return;
     const uint32_t threads = P.n_units * 4;
-    hipLaunchKernelGGL(kc_xxh64_fin_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, P);
+    if (P.mode == 2) hipLaunchKernelGGL(kc_xxh64_fin_kernel<2>, dim3((threads + 255) / 256), dim3(256), 0, st, P);
+    else if (P.mode == 1) hipLaunchKernelGGL(kc_xxh64_fin_kernel<1>, dim3((threads + 255) / 256), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL(kc_xxh64_fin_kernel<0>, dim3((threads + 255) / 256), dim3(256), 0, st, P);
 }
 
 // ---------------------------------------------------------------------------------------

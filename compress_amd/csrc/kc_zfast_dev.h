@@ -3,6 +3,14 @@
 #pragma once
 #include "kc_dev.h"
 
+// The emulator only (tools/hipemu runs lanes out of lockstep): an exchange through LDS that the hardware orders by itself, in a
+// kernel where KC_WAVE_SYNC's compiler fence is not wanted.
+#ifdef KC_HIPEMU
+#define KC_EMU_SYNC() hipemu::wave_sync()
+#else
+#define KC_EMU_SYNC() do { } while (0)
+#endif
+
 #define ZF_TABLE_BITS 15
 #define ZF_MAX_MATCH_LENGTH 131074  // enc_fast.go:18
 

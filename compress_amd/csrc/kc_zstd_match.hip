@@ -91,6 +91,17 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const uint8_t* const srcLo = P.src;
     const uint8_t* const srcHi = P.src_end;
 
+    // "Nothing written there yet" filter (round 3): until the unit emits its first sequence the 64 bytes of its sequence buffer are
+    // idle; they hold one bit per 64 consecutive buckets (4 table lines), set when the unit writes into them.  A lookup whose bit is
+    // clear needs no load: the bucket is empty (zeroed, or stale-stamped) — on input without matches (high-entropy units: ~900
+    // inserts into 2048 lines, no sequence ever) that is about half of the table reads, on a kernel bound by DRAM transactions.
+    // Units whose tables arrive primed (dictionary, job prefix) do not use it; the first emit() ends it for good.
+    uint32_t* const fw = (uint32_t*)sbuf;
+    bool useF = gact && P.empty_filter != 0 && P.hist0 == 0 && P.unit_hist == nullptr;
+    {
+        sbuf[lig] = 0;  // (G == 8 lanes x 8 bytes: the whole buffer)
+        KC_EMU_SYNC();
+    }
     int o1 = P.rep1, o2 = P.rep2;  // {1,4} (blockenc.go:78) or the dictionary's offsets (enc_base.go:189-195)
     bool allDirty = false;  // fastEncoderDict.allDirty: small-input variant (kSearchStrength 7) only until a block > 32 KiB was seen
     int wlo = 0, whi = 0;   // the ring holds the bytes abase[wlo .. whi)
@@ -107,6 +118,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
         int nextEmit = blkStart, s = blkStart;
         uint32_t firstLL = 0, firstOf = 0;
         auto emit = [&](int ll, int ml3, uint32_t of) {
+            useF = false;  // the buffer is the sequence buffer from here on
             if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
             if (lig == 0) sbuf[nseq & (G - 1)] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
             nseq++;
@@ -196,8 +208,14 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 if (valid) {
                     h0 = hash6(cv, ZF_TABLE_BITS);
                     h1 = hash6(cv >> 8, ZF_TABLE_BITS);
-                    c0 = KC_TAB_LD(&tab[h0]);
-                    c1 = KC_TAB_LD(&tab[h1]);
+                    if (useF) {  // group-uniform
+                        const uint32_t g0 = h0 >> 6, g1 = h1 >> 6;
+                        if ((fw[g0 >> 5] >> (g0 & 31u)) & 1u) c0 = KC_TAB_LD(&tab[h0]);
+                        if ((fw[g1 >> 5] >> (g1 & 31u)) & 1u) c1 = KC_TAB_LD(&tab[h1]);
+                    } else {
+                        c0 = KC_TAB_LD(&tab[h0]);
+                        c1 = KC_TAB_LD(&tab[h1]);
+                    }
                 }
                 const int repIndex = p - o1 + 2;
                 const bool repOk = valid && canRep && repIndex >= 0;
@@ -318,6 +336,10 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 if (valid && lig <= commitUpTo) {
                     KC_TAB_ST(((uint32_t)p + 1u) | (PB < 32 ? tagOf((uint32_t)cv) << PB : 0u), &tab[h0]);
                     KC_TAB_ST(((uint32_t)p + 2u) | (PB < 32 ? tagOf((uint32_t)(cv >> 8)) << PB : 0u), &tab[h1]);  // program order: wins when h0 == h1
+                    if (useF) {
+                        atomicOr(&fw[h0 >> 11], 1u << ((h0 >> 6) & 31u));
+                        atomicOr(&fw[h1 >> 11], 1u << ((h1 >> 6) & 31u));
+                    }
                 }
                 if (!found) {
                     W = P.spec_grow == 0 ? W : (P.spec_grow == 1 ? (W + 1 < G ? W + 1 : G) : ((2 * W < G) ? 2 * W : G));

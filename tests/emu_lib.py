@@ -232,3 +232,41 @@ def s2_best_blocks(blocks, snappy=False):
         assert r == 0
         out.append(stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes())
     return out
+
+
+def xxh_fin(units, raw_flags, block_size, out_positions, mode, frame_header=9):
+    """kc_xxh64_fin_kernel on frames laid out as the entropy stage leaves them: per unit a frame header of `frame_header` bytes, per
+    block a 3-byte header + the payload, 4 bytes of checksum.  raw_flags[i]: the unit's frame is raw blocks only (its payloads are
+    copied by the kernel).  out_positions[i]: where the frame starts in dst.  Returns (dst, stage, stage_off, sizes, xxh)."""
+    n = len(units)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    blk0 = np.zeros(n + 1, dtype=np.uint32)
+    sizes = np.zeros(n, dtype=np.uint32)
+    soff = np.zeros(n + 1, dtype=np.uint64)
+    raw = []
+    for i, u in enumerate(units):
+        off[i + 1] = off[i] + len(u)
+        nb = (len(u) + block_size - 1) // block_size
+        blk0[i + 1] = blk0[i] + nb
+        pos = frame_header
+        for b in range(nb):
+            sz = min(block_size, len(u) - b * block_size)
+            raw.append((pos + 3, b * block_size, sz, 0) if raw_flags[i] else (0, 0, 0, 0))
+            pos += 3 + sz
+        sizes[i] = pos + 4 if len(u) else 0
+        soff[i + 1] = soff[i] + ((int(sizes[i]) + 15) & ~15) + 16
+    rawdef = np.array(raw if raw else [(0, 0, 0, 0)], dtype=np.uint32).reshape(-1, 4)
+    rawdef = np.ascontiguousarray(np.vstack([rawdef, np.zeros((1, 4), dtype=np.uint32)]))
+    src = np.frombuffer(b"".join(units) + b"\0" * 64, dtype=np.uint8).copy()
+    stage = np.full(int(soff[n]) + 64, 0x55, dtype=np.uint8)
+    oo = np.ascontiguousarray(list(out_positions) + [0], dtype=np.uint64)
+    dst = np.full(int(max(int(oo[i]) + int(sizes[i]) for i in range(n))) + 64, 0xAA, dtype=np.uint8)
+    flags = np.ascontiguousarray([1 if f else 0 for f in raw_flags], dtype=np.uint32)
+    xxh = np.zeros(n, dtype=np.uint64)
+    L = lib()
+    L.kcemu_xxh_fin.restype = C.c_int
+    L.kcemu_xxh_fin.argtypes = [C.c_void_p] * 2 + [C.c_uint32] + [C.c_void_p] * 9 + [C.c_int]
+    r = L.kcemu_xxh_fin(src.ctypes.data, off.ctypes.data, n, stage.ctypes.data, soff.ctypes.data, sizes.ctypes.data, oo.ctypes.data, dst.ctypes.data,
+                        flags.ctypes.data, rawdef.ctypes.data, blk0.ctypes.data, xxh.ctypes.data, mode)
+    assert r == 0
+    return dst, stage, soff, sizes, xxh

@@ -115,11 +115,12 @@ def test_s2_best_kernel_bit_exact(snappy):
     _cmp(blocks, emu_lib.s2_best_blocks(blocks, snappy=snappy), oracle_lib.s2_encode_snappy_best if snappy else oracle_lib.s2_encode_best)
 
 
-@pytest.mark.parametrize("w0,grow,xseg", [(1, 1, 0), (1, 1, 2), (1, 1, 1 << 20), (8, 0, 0), (2, 2, 1 << 20)])
+@pytest.mark.parametrize("w0,grow,xseg", [(1, 1, 0), (1, 1, 2), (1, 1, 1 << 20), (8, 0, 0), (2, 2, 1 << 20), (1, 1, 1 << 24)])
 def test_zfast_grp_parse_matches_oracle(w0, grow, xseg):
     """kc_zfast_match_grp_kernel<8> (the HBM-table throughput kernel, 8 lanes per unit): every block's sequence list equals the
     oracle's fastEncoder — at every speculation policy, with rounds confined to one skip segment (round 2), crossing segments
-    always, or only once the step has grown (xseg_k)."""
+    always, or only once the step has grown (xseg_k); with the "nothing written there yet" filter of units that have no sequence yet
+    (default) and without it (bit 24 of the last argument)."""
     units = _zfast_units()
     _cmp_parse(units, emu_lib.zfast_parse_grp(units, spec_w0=w0, spec_grow=grow, xseg_k=xseg), level=1)
 
@@ -214,3 +215,47 @@ def test_s2_lds_amd64_variant_equals_the_assembly_restatement(level, w0):
     got = emu_lib.s2_encode_blocks(blocks, level=level, spec_w0=w0, variant=1)
     bad = [(i, len(b)) for i, b in enumerate(blocks) if got[i] != oracle_lib.s2_encode_asm(b, snappy=level == 2)]
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_xxh_fin_kernel_checksum_and_raw_payload_copy(mode):
+    """kc_xxh64_fin_kernel (checksum behind the entropy stage; the payload of raw-only frames copied by the pass that hashes it) in its
+    three store schedules: every unit's XXH64 equals the oracle's and lands in the frame's last four bytes; the payloads of the flagged
+    frames arrive at their place — every alignment of the frame in the output, one and several blocks, ragged ends, lengths around
+    every loop boundary — and not one byte outside them is touched; frames that are not flagged get no payload."""
+    rng = np.random.default_rng(1234 + mode)
+    lens = [0, 1, 31, 32, 63, 64, 65, 255, 256, 257, 300, 511, 512, 1023, 1024, 1025, 4096, 4097 + 13, 65536, 65536 + 255, 65536 + 256, 131072, 131071,
+            3 * 65536, 3 * 65536 + 17, 200000]
+    units = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for n in lens]
+    flags = [(i % 5) != 3 for i in range(len(units))]
+    pos, outp = 0, []
+    for i, u in enumerate(units):
+        pos += int(rng.integers(0, 40))  # (gaps: every residue of the frame start modulo 64 shows up)
+        outp.append(pos)
+        pos += len(u) + 9 + 3 * ((len(u) + 65535) // 65536) + 4
+    bs = 65536
+    dst, stage, soff, sizes, xxh = emu_lib.xxh_fin(units, flags, bs, outp, mode)
+    for i, u in enumerate(units):
+        want = int(oracle_lib.lib().kco_xxh64(u, len(u)))
+        assert int(xxh[i]) == want, (i, len(u))
+        if len(u) == 0:
+            continue
+        fs = int(sizes[i])
+        ck = stage[int(soff[i]) + fs - 4:int(soff[i]) + fs].tobytes()
+        assert ck == (want & 0xFFFFFFFF).to_bytes(4, "little"), (i, len(u))
+        assert np.all(stage[int(soff[i]):int(soff[i]) + fs - 4] == 0x55)
+        frame = dst[outp[i]:outp[i] + fs]
+        expect = np.full(fs, 0xAA, dtype=np.uint8)
+        if flags[i]:
+            p = 9
+            for b in range((len(u) + bs - 1) // bs):
+                blk = u[b * bs:(b + 1) * bs]
+                expect[p + 3:p + 3 + len(blk)] = np.frombuffer(blk, dtype=np.uint8)
+                p += 3 + len(blk)
+        bad = np.nonzero(frame != expect)[0]
+        assert len(bad) == 0, (i, len(u), flags[i], bad[:8], outp[i] % 64)
+    # nothing between or behind the frames was written
+    mask = np.ones(len(dst), dtype=bool)
+    for i in range(len(units)):
+        mask[outp[i]:outp[i] + int(sizes[i])] = False
+    assert np.all(dst[mask] == 0xAA)

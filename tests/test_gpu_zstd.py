@@ -753,11 +753,11 @@ def test_fastest_epoch_stamped_tables_over_many_batches(oracle, kclib):
     enc.Close()
 
 
-@pytest.mark.parametrize("xseg", [0, 2, 1 << 20])
-def test_probe_rounds_across_skip_segments(oracle, kclib, xseg):
+@pytest.mark.parametrize("xseg,filt", [(0, 1), (2, 1), (1 << 20, 1), (0, 0)])
+def test_probe_rounds_across_skip_segments(oracle, kclib, xseg, filt):
     """SpeedFastest, HBM-table kernel: a probe round follows the reference's position recurrence across skip-segment boundaries
     (KC_OPT_ZFAST_XSEG_K: always, once the step has grown, never = round 2's rounds) — the same bytes every way, on text, mixed,
-    high-entropy and edge inputs, with and without history."""
+    high-entropy and edge inputs, with and without history; with and without the empty-group filter (KC_OPT_ZFAST_FILTER)."""
     _torch()
     units = [corpora.corpus(k, 1, 131072, first_unit=f).tobytes() for k, f in (("T", 1), ("H", 0), ("H", 5), ("M", 2), ("M", 3), ("J", 4))]
     units += [corpora.corpus("H", 4, 131072, first_unit=9).tobytes()[:300001], corpora.corpus("M", 8, 131072, first_unit=1).tobytes()]
@@ -765,6 +765,7 @@ def test_probe_rounds_across_skip_segments(oracle, kclib, xseg):
     buf, off = corpora.pack_units(units)
     enc = _enc(1)
     enc.ctx().set_option(23, xseg)
+    enc.ctx().set_option(25, filt)  # the "nothing written there yet" filter of units without a sequence so far
     out, out_off = enc.EncodeUnits(buf, off)
     _path_ran(enc, 1)
     ref, ref_off = oracle.zstd_encode_units(buf, off, threads=8, level=1)
@@ -772,9 +773,9 @@ def test_probe_rounds_across_skip_segments(oracle, kclib, xseg):
     enc.Close()
 
 
-@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("fuse,mode", [(1, 0), (1, 1), (1, 2), (0, 0)])
 @pytest.mark.parametrize("level", [1, "1L", 2, 3])
-def test_raw_only_frames_checksum_and_copy_in_one_pass(oracle, kclib, level, fuse):
+def test_raw_only_frames_checksum_and_copy_in_one_pass(oracle, kclib, level, fuse, mode):
     """Frames that end up as raw blocks only get their payload copied by the kernel that hashes it, behind the entropy stage
     (kc_xxh64_fin_kernel, KC_OPT_FUSE_RAW_XXH); every other frame gets its checksum field from the same kernel.  Incompressible
     units of one and several blocks, ragged lengths, exact block multiples, tiny and empty units, units whose blocks are raw and
@@ -790,6 +791,7 @@ def test_raw_only_frames_checksum_and_copy_in_one_pass(oracle, kclib, level, fus
     for opts, okw in (((), {}), ((zstd.WithWindowSize(1 << 16),), {"window_size": 1 << 16}), ((zstd.WithEncoderCRC(False),), {"crc": False})):
         enc = zstd.NewWriter(None, *_lo(level), *opts)
         enc.ctx().set_option(24, fuse)
+        enc.ctx().set_option(26, mode)  # the kernel's three store schedules (KC_OPT_XXH_FIN_MODE)
         out, out_off = enc.EncodeUnits(buf, off)
         ref, ref_off = oracle.zstd_encode_units(buf, off, threads=8, level=_li(level), **okw)
         bad = [i for i in range(len(units)) if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]

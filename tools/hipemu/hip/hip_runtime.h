@@ -89,6 +89,13 @@ static inline int __shfl_xor(int v, int m, int width = 64) {
     return (int)(uint32_t)hipemu::shfl64((uint32_t)v, emu_src_lane(l, (l & (width - 1)) ^ m, width));
 }
 static inline void __syncthreads() { hipemu::block_sync(); }
+// v_mov_b32 with a DPP quad permute (control word below 0x100: two bits per lane of the quad select the source lane)
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+    const int lane = hipemu::lane();
+    if (ctrl < 0 || ctrl >= 0x100) { fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl); abort(); }
+    return (int)(uint32_t)hipemu::shfl64((uint32_t)src, (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3));
+}
 static inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)hipemu::first_lane64((uint32_t)v); }
 static inline int __builtin_amdgcn_readlane(int v, int src) { return (int)(uint32_t)hipemu::shfl64((uint32_t)v, src & 63); }
 static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }

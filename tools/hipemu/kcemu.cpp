@@ -4,6 +4,7 @@
 #include "../../compress_amd/csrc/kc_s2_lds.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_lds.hip"
 #include "../../compress_amd/csrc/kc_zstd_match.hip"
+#include "../../compress_amd/csrc/kc_misc.hip"
 #include "../../compress_amd/csrc/kc_s2_best.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_best.hip"
 
@@ -78,9 +79,24 @@ int kcemu_zfast_parse_grp(const uint8_t* src, const uint64_t* unit_off, uint32_t
     P.rep2 = 4;
     P.stream_mode = stream_mode;
     P.epoch = epoch;
-    P.xseg_k = xseg_k;
+    P.xseg_k = xseg_k & 0xFFFFFF;
+    P.empty_filter = (xseg_k >> 24) & 1 ? 0 : 1;  // (bit 24 of the argument switches the filter off)
     hipemu::set_group(8);  // 8 units per wave, the groups diverge freely
     kc_launch_zfast_match_grp(P, tables, n, nullptr);
+    hipemu::set_group(64);
+    return 0;
+}
+
+// kc_xxh64_fin_kernel: the checksum field of every frame, and the payload of the frames flagged in unit_raw copied from the source
+int kcemu_xxh_fin(const uint8_t* src, const uint64_t* unit_off, uint32_t n, uint8_t* stage, const uint64_t* stage_off, const uint32_t* out_size,
+                  const uint64_t* out_off, uint8_t* dst, const uint32_t* unit_raw, const KcRawDef* rawdef, const uint32_t* unit_blk0, uint64_t* xxh_out,
+                  int mode) {
+    KcXxhFinParams P;
+    memset(&P, 0, sizeof(P));
+    P.src = src; P.unit_off = unit_off; P.n_units = n; P.stage = stage; P.stage_off = stage_off; P.out_size = out_size; P.out_off = out_off;
+    P.dst = dst; P.unit_raw = unit_raw; P.rawdef = rawdef; P.unit_blk0 = unit_blk0; P.xxh_out = xxh_out; P.mode = mode;
+    hipemu::set_group(4);  // one unit per quad; the quads' trip counts differ
+    kc_launch_xxh64_fin(P, nullptr);
     hipemu::set_group(64);
     return 0;
 }
