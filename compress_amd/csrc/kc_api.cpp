@@ -101,7 +101,9 @@ struct KcCfg {
     int64_t s2_variant = 0;               // S2 levels 0 / 2: 0 = the portable Go encoders' bytes, 1 = the amd64 assembly encoders' bytes
     int64_t best_slots = 2048;            // SpeedBestCompression: table slots (34 MiB each) = units encoded at a time
     int64_t zfast_epoch = 1;              // SpeedFastest HBM-table kernel without a dictionary: epoch-stamped tables instead of clearing 128 KiB per unit per batch
-    int64_t zfast_xseg_k = 0;             // SpeedFastest HBM-table kernel: probe rounds cross skip-segment boundaries once (s - nextEmit) >> 5 reaches this (0: always)
+    int64_t zfast_xseg_k = 0;             // SpeedFastest HBM-table kernel, tuned form: probe rounds cross skip-segment boundaries once (s - nextEmit) >> 5 reaches this (0: always)
+    int64_t zfast_variant = -1;           // SpeedFastest HBM-table kernel: 0 the plain form, 1 the form for input without matches (cross-segment rounds + empty-group
+                                          // filter), -1 (default) chosen per batch: the tuned form when the context's previous batch did not compress (ratio >= 0.98)
     int64_t zfast_filter = 1;             // SpeedFastest HBM-table kernel: "nothing written there yet" filter in the idle sequence buffer (units without a sequence so far)
     int64_t xxh_fin_mode = 1;             // kc_xxh64_fin_kernel: how the payload of raw-only frames is stored (KcXxhFinParams.mode)
     int64_t fuse_raw_xxh = 1;             // frames made of raw blocks only: checksum and payload copy in one pass over the source (kc_xxh64_copy_kernel)
@@ -152,6 +154,7 @@ struct kc_ctx {
     bool ev7_valid = false;          // ev[7] was recorded for the batch in flight
     int last_batches = 0;            // device batches the last zstd / S2 _dev call was cut into (scratch budget)
     int last_path = 0;               // KC_PATH_HBM / KC_PATH_LDS: what the last batch's match finder / S2 encoder ran on
+    bool last_incompressible = false;  // the previous zstd batch of this context came out at >= 98 % of its input (picks the match finder's form)
     std::vector<uint8_t> up_unit_off, up_blk0, up_stage_off;  // zstd batches: what unit_off / unit_blk0 / stage_off hold on the device ...
     const void* up_ptr[3] = {nullptr, nullptr, nullptr};     // ... and in which allocation (re-uploaded only when they change)
 };
@@ -327,6 +330,7 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
         envi("KC_ZFAST_XSEG_K", g.zfast_xseg_k);
         envi("KC_FUSE_RAW_XXH", g.fuse_raw_xxh);
         envi("KC_ZFAST_FILTER", g.zfast_filter);
+        envi("KC_ZFAST_VARIANT", g.zfast_variant);
         envi("KC_XXH_FIN_MODE", g.xxh_fin_mode);
         if (const char* e = getenv("KC_HOST_CHUNKS_MIB")) {
             for (const char* q = e; *q;) { g.host_chunks.push_back((uint64_t)strtoull(q, (char**)&q, 10) << 20); if (*q == ',') q++; else if (*q) break; }
@@ -366,6 +370,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_ZFAST_XSEG_K: if (v < 0) return KC_ERR_BAD_ARG; g.zfast_xseg_k = v > (1 << 30) ? (1 << 30) : v; break;
         case KC_OPT_FUSE_RAW_XXH: g.fuse_raw_xxh = v != 0; break;
         case KC_OPT_ZFAST_FILTER: g.zfast_filter = v != 0; break;
+        case KC_OPT_ZFAST_VARIANT: if (v < -1 || v > 1) return KC_ERR_BAD_ARG; g.zfast_variant = v; break;
         case KC_OPT_XXH_FIN_MODE: if (v < 0 || v > 2) return KC_ERR_BAD_ARG; g.xxh_fin_mode = v; break;
         default: return KC_ERR_BAD_ARG;
     }
@@ -401,6 +406,7 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_ZFAST_XSEG_K: return g.zfast_xseg_k;
         case KC_OPT_FUSE_RAW_XXH: return g.fuse_raw_xxh;
         case KC_OPT_ZFAST_FILTER: return g.zfast_filter;
+        case KC_OPT_ZFAST_VARIANT: return g.zfast_variant;
         case KC_OPT_XXH_FIN_MODE: return g.xxh_fin_mode;
         case KC_OPT_LAST_PATH: return c->last_path;
         case KC_OPT_LAST_BATCHES: return c->last_batches;
@@ -680,6 +686,7 @@ void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uin
             ml.epoch = c->fast_epoch_now;
             ml.xseg_k = (int32_t)c->cfg.zfast_xseg_k;
             ml.empty_filter = c->cfg.zfast_filter != 0;
+            ml.tuned = c->cfg.zfast_variant < 0 ? (c->last_incompressible ? 1 : 0) : (int32_t)c->cfg.zfast_variant;
             kc_launch_zfast_match_grp(ml, (uint32_t*)((uint8_t*)c->tables.p + (size_t)slot0 * match_table_bytes(level)), n_launch, st);
         }
         return;
@@ -702,6 +709,7 @@ void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uin
         mf.epoch = c->fast_epoch_now;
         mf.xseg_k = (int32_t)c->cfg.zfast_xseg_k;
         mf.empty_filter = c->cfg.zfast_filter != 0;
+        mf.tuned = c->cfg.zfast_variant < 0 ? (c->last_incompressible ? 1 : 0) : (int32_t)c->cfg.zfast_variant;
         kc_launch_zfast_match_grp(mf, (uint32_t*)tab, n_launch, st);
     }
 }
@@ -1181,6 +1189,10 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
                 pv[16], pv[26], pv[27], pv[17], pv[18], pv[19], pv[20], pv[25], pv[24]);
     }
     *produced = out_off_host[n_units];
+    {
+        const uint64_t in_total = unit_off[n_units] - unit_off[0];
+        c->last_incompressible = in_total >= (1u << 20) && (double)*produced >= 0.98 * (double)in_total;
+    }
     return KC_OK;
 }
 

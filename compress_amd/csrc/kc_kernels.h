@@ -38,6 +38,7 @@ struct KcMatchParams {
     int32_t lds_split;          // SpeedFastest HBM kernel: 1 = skip the units the LDS-table kernel takes (those that fit KC_ZFAST_LDS_MAX_UNIT)
     int32_t empty_filter;       // SpeedFastest HBM kernel: 1 = skip the table loads of bucket groups the unit has not written yet, while it has
                                 // emitted no sequence (kc_zstd_match.hip; the tables must start empty: no dictionary, no job prefix)
+    int32_t tuned;              // SpeedFastest HBM kernel: 1 = the form compiled with cross-segment rounds (xseg_k) and the empty-group filter
     int32_t xseg_k;             // SpeedFastest HBM kernel: a probe round continues across a skip-segment boundary once (s - nextEmit) >> 5
                                 // has reached this value (0: always; a large value: never, round 2's rounds)
 };

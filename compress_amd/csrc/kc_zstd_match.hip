@@ -48,7 +48,7 @@
 #define KC_TAB_ST(v, p) (*(p) = (v))
 
 
-template <int G>
+template <int G, bool XSEG, bool FILT>
 __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P, uint32_t* __restrict__ tables, uint32_t n_launch) {
     constexpr int UPW = 64 / G;
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[UPW * ZW_STRIDE];
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     // inserts into 2048 lines, no sequence ever) that is about half of the table reads, on a kernel bound by DRAM transactions.
     // Units whose tables arrive primed (dictionary, job prefix) do not use it; the first emit() ends it for good.
     uint32_t* const fw = (uint32_t*)sbuf;
-    bool useF = gact && P.empty_filter != 0 && P.hist0 == 0 && P.unit_hist == nullptr;
-    {
+    bool useF = FILT && gact && P.empty_filter != 0 && P.hist0 == 0 && P.unit_hist == nullptr;
+    if (FILT) {
         sbuf[lig] = 0;  // (G == 8 lanes x 8 bytes: the whole buffer)
         KC_EMU_SYNC();
     }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
         int nextEmit = blkStart, s = blkStart;
         uint32_t firstLL = 0, firstOf = 0;
         auto emit = [&](int ll, int ml3, uint32_t of) {
-            useF = false;  // the buffer is the sequence buffer from here on
+            if (FILT) useF = false;  // the buffer is the sequence buffer from here on
             if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
             if (lig == 0) sbuf[nseq & (G - 1)] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
             nseq++;
@@ -170,13 +170,21 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 const int d0 = s - nextEmit;
                 const int k0 = d0 >> SK;
                 const int step = 2 + k0;
-                int p = s, pprev = s;
+                int p, pnext = 0;
+                bool valid;
+                if (XSEG) {
+                    int pprev = s;
+                    p = s;
 #pragma unroll
-                for (int j = 1; j < G; j++) {
-                    if (lig >= j) { pprev = p; p += 2 + ((p - nextEmit) >> SK); }
+                    for (int j = 1; j < G; j++) {
+                        if (lig >= j) { pprev = p; p += 2 + ((p - nextEmit) >> SK); }
+                    }
+                    pnext = p + 2 + ((p - nextEmit) >> SK);  // where the scan continues when this lane is the round's last
+                    valid = lig < W && (lig == 0 || k0 >= P.xseg_k || ((pprev - nextEmit) >> SK) == k0) && p < sLimit;
+                } else {  // rounds confined to one skip segment (constant step): measured 2 % faster on text (no recurrence, no cross-lane read)
+                    p = s + lig * step;
+                    valid = lig < W && (lig == 0 || ((d0 + (lig - 1) * step) >> SK) == k0) && p < sLimit;
                 }
-                const int pnext = p + 2 + ((p - nextEmit) >> SK);  // where the scan continues when this lane is the round's last
-                const bool valid = lig < W && (lig == 0 || k0 >= P.xseg_k || ((pprev - nextEmit) >> SK) == k0) && p < sLimit;
                 // R = the 20 source bytes [p-4, p+16): D1:D2 = cv, the rest feeds the fused candidate compares
                 uint32_t D0 = 0, D1 = 0, D2 = 0, D3 = 0, D4 = 0;
                 if (valid) {
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 if (valid) {
                     h0 = hash6(cv, ZF_TABLE_BITS);
                     h1 = hash6(cv >> 8, ZF_TABLE_BITS);
-                    if (useF) {  // group-uniform
+                    if (FILT && useF) {  // group-uniform
                         const uint32_t g0 = h0 >> 6, g1 = h1 >> 6;
                         if ((fw[g0 >> 5] >> (g0 & 31u)) & 1u) c0 = KC_TAB_LD(&tab[h0]);
                         if ((fw[g1 >> 5] >> (g1 & 31u)) & 1u) c1 = KC_TAB_LD(&tab[h1]);
@@ -336,16 +344,23 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 if (valid && lig <= commitUpTo) {
                     KC_TAB_ST(((uint32_t)p + 1u) | (PB < 32 ? tagOf((uint32_t)cv) << PB : 0u), &tab[h0]);
                     KC_TAB_ST(((uint32_t)p + 2u) | (PB < 32 ? tagOf((uint32_t)(cv >> 8)) << PB : 0u), &tab[h1]);  // program order: wins when h0 == h1
-                    if (useF) {
+                    if (FILT && useF) {
                         atomicOr(&fw[h0 >> 11], 1u << ((h0 >> 6) & 31u));
                         atomicOr(&fw[h1 >> 11], 1u << ((h1 >> 6) & 31u));
                     }
                 }
                 if (!found) {
                     W = P.spec_grow == 0 ? W : (P.spec_grow == 1 ? (W + 1 < G ? W + 1 : G) : ((2 * W < G) ? 2 * W : G));
-                    const int m = c < nvalid ? c : nvalid;  // the scan continues behind lane m - 1 (m >= 1: lane 0 depends on nobody; nvalid >= 1)
-                    if (((d0 + (m - 1) * step) >> SK) == k0) s = s + m * step;  // lanes 0 .. m-1 in lane 0's skip segment: no cross-lane read
-                    else s = (int)gbcast32<G>((uint32_t)pnext, grp, m - 1);
+                    if (XSEG) {
+                        const int m = c < nvalid ? c : nvalid;  // the scan continues behind lane m - 1 (m >= 1: lane 0 depends on nobody; nvalid >= 1)
+                        if (((d0 + (m - 1) * step) >> SK) == k0) s = s + m * step;  // lanes 0 .. m-1 in lane 0's skip segment: no cross-lane read
+                        else s = (int)gbcast32<G>((uint32_t)pnext, grp, m - 1);
+                    } else if (c < nvalid) {
+                        s = s + c * step;
+                    } else {
+                        const int pl = s + (nvalid - 1) * step;
+                        s = pl + 2 + ((pl - nextEmit) >> SK);
+                    }
                     if (s >= sLimit) fin = true;
                     continue;
                 }
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                 const bool fdone = (wk & 4u) != 0;
                 const int fk = (int)((wk >> 3) & 31u);
                 const int bke = (int)((wk >> 8) & 7u), bav = (int)((wk >> 11) & 7u);
-                const int ps = (f == 0 || ((d0 + (f - 1) * step) >> SK) == k0) ? s + f * step : (int)gbcast32<G>((uint32_t)p, grp, f);
+                const int ps = (!XSEG || f == 0 || ((d0 + (f - 1) * step) >> SK) == k0) ? s + f * step : (int)gbcast32<G>((uint32_t)p, grp, f);
                 int mt = (int)gbcast32<G>((uint32_t)t, grp, f);
                 // backward extension given the bke equal bytes found among the bav bytes examined (enc_fast.go:152-157, 230-234)
                 auto backlen = [&](int sp, int tp, int kmax) -> int {
@@ -437,5 +452,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
 }
 
 void kc_launch_zfast_match_grp(const KcMatchParams& P, uint32_t* tables, uint32_t n_launch, hipStream_t st) {
-    hipLaunchKernelGGL(kc_zfast_match_grp_kernel<8>, dim3((n_launch + 7) / 8), dim3(64), 0, st, P, tables, n_launch);
+    // Two compiled forms, the same bytes: the plain one (rounds inside one skip segment, no filter) is ~1 % faster on compressible
+    // input, where neither addition ever acts; the other one is for input that yields no matches (P.tuned: the host's choice).
+    if (P.tuned) hipLaunchKernelGGL((kc_zfast_match_grp_kernel<8, true, true>), dim3((n_launch + 7) / 8), dim3(64), 0, st, P, tables, n_launch);
+    else hipLaunchKernelGGL((kc_zfast_match_grp_kernel<8, false, false>), dim3((n_launch + 7) / 8), dim3(64), 0, st, P, tables, n_launch);
 }

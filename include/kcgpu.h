@@ -162,10 +162,11 @@ typedef enum {
     KC_OPT_S2_VARIANT = 20,          /* (no variable)             s2.Encode / s2.EncodeSnappy: KC_S2_VARIANT_GO (default) or KC_S2_VARIANT_AMD64 */
     KC_OPT_BETTER_DICT_EPOCH = 21,   /* (no variable)             SpeedBetterCompression with a dictionary: 1 = epoch-stamped tables + shared dictionary table (measurements; default 0: per-batch copy) */
     KC_OPT_ZFAST_EPOCH = 22,         /* KC_ZFAST_EPOCH            SpeedFastest HBM-table kernel, no dictionary: 1 (default) = epoch-stamped table entries, the arena is cleared every 15 batches instead of every batch */
-    KC_OPT_ZFAST_XSEG_K = 23,        /* KC_ZFAST_XSEG_K           SpeedFastest HBM-table kernel: a probe round crosses skip-segment boundaries once (s - nextEmit) >> 5 has reached this value (default 0: always; large: never) */
+    KC_OPT_ZFAST_XSEG_K = 23,        /* KC_ZFAST_XSEG_K           SpeedFastest HBM-table kernel: a probe round crosses skip-segment boundaries once (s - nextEmit) >> 5 has reached this value (default 0: always; large: never); acts in the kernel form KC_OPT_ZFAST_VARIANT selects */
     KC_OPT_FUSE_RAW_XXH = 24,        /* KC_FUSE_RAW_XXH           frames made of raw blocks only: 1 (default) = XXH64 and the payload copy in one pass over the source */
     KC_OPT_ZFAST_FILTER = 25,        /* KC_ZFAST_FILTER           SpeedFastest HBM-table kernel: 1 (default) = units that have emitted no sequence yet skip the table loads of bucket groups they have not written (a 512-bit map in their idle sequence buffer) */
     KC_OPT_XXH_FIN_MODE = 26,        /* KC_XXH_FIN_MODE           checksum-and-copy kernel, payload of raw-only frames: 0 stored from the registers, 1 the same software-pipelined, 2 through an LDS ring as aligned stores */
+    KC_OPT_ZFAST_VARIANT = 27,       /* KC_ZFAST_VARIANT          SpeedFastest HBM-table kernel: 0 the plain form, 1 the form for input without matches (KC_OPT_ZFAST_XSEG_K, KC_OPT_ZFAST_FILTER), -1 (default) per batch: form 1 when the context's previous batch did not compress */
     KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
     KC_OPT_LAST_BATCHES = 101        /* read-only: device batches the last kc_zstd_encode_units_dev / kc_s2_encode_*_dev call was cut into */
 } kc_option;

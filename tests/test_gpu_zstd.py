@@ -730,7 +730,8 @@ def test_fastest_epoch_stamped_tables_over_many_batches(oracle, kclib):
     """SpeedFastest, HBM-table kernel: the 128 KiB-per-unit tables are not cleared per batch; entries carry the launch's stamp
     (KC_OPT_ZFAST_EPOCH, default on).  Twenty-odd batches on one context — past the stamp's 15 values (wrap: the arena is cleared),
     growing and shrinking unit counts, unit lengths that change the position width, one batch in between with the stamps switched
-    off (the arena changes hands and must be cleared before the next stamped batch) — each bit-exact."""
+    off (the arena changes hands and must be cleared before the next stamped batch) — each bit-exact.  The kernel's form is left to the
+    context (KC_OPT_ZFAST_VARIANT -1): a batch behind one that did not compress runs the form for input without matches."""
     _torch()
     t = corpora.corpus("T", 40, 131072, first_unit=4).tobytes()
     m = corpora.corpus("M", 40, 131072, first_unit=9).tobytes()
@@ -753,8 +754,8 @@ def test_fastest_epoch_stamped_tables_over_many_batches(oracle, kclib):
     enc.Close()
 
 
-@pytest.mark.parametrize("xseg,filt", [(0, 1), (2, 1), (1 << 20, 1), (0, 0)])
-def test_probe_rounds_across_skip_segments(oracle, kclib, xseg, filt):
+@pytest.mark.parametrize("variant,xseg,filt", [(1, 0, 1), (1, 2, 1), (1, 1 << 20, 1), (1, 0, 0), (0, 0, 1)])
+def test_probe_rounds_across_skip_segments(oracle, kclib, variant, xseg, filt):
     """SpeedFastest, HBM-table kernel: a probe round follows the reference's position recurrence across skip-segment boundaries
     (KC_OPT_ZFAST_XSEG_K: always, once the step has grown, never = round 2's rounds) — the same bytes every way, on text, mixed,
     high-entropy and edge inputs, with and without history; with and without the empty-group filter (KC_OPT_ZFAST_FILTER)."""
@@ -764,6 +765,7 @@ def test_probe_rounds_across_skip_segments(oracle, kclib, xseg, filt):
     units += [u for u in corpora.edge_units() if len(u) < 200000] + corpora.stress_units(seed=11, n=10)
     buf, off = corpora.pack_units(units)
     enc = _enc(1)
+    enc.ctx().set_option(27, variant)  # the kernel's compiled form: 1 = cross-segment rounds + filter, 0 = plain (default: chosen per batch)
     enc.ctx().set_option(23, xseg)
     enc.ctx().set_option(25, filt)  # the "nothing written there yet" filter of units without a sequence so far
     out, out_off = enc.EncodeUnits(buf, off)

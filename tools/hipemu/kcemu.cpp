@@ -80,6 +80,7 @@ int kcemu_zfast_parse_grp(const uint8_t* src, const uint64_t* unit_off, uint32_t
     P.stream_mode = stream_mode;
     P.epoch = epoch;
     P.xseg_k = xseg_k & 0xFFFFFF;
+    P.tuned = P.xseg_k < (1 << 20) ? 1 : 0;  // (2^20: the plain form, rounds inside one skip segment, no filter)
     P.empty_filter = (xseg_k >> 24) & 1 ? 0 : 1;  // (bit 24 of the argument switches the filter off)
     hipemu::set_group(8);  // 8 units per wave, the groups diverge freely
     kc_launch_zfast_match_grp(P, tables, n, nullptr);
