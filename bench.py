@@ -32,9 +32,9 @@ SEEDS = {"T": 0x5EED0001, "H": 0x5EED0002, "J": 0x5EED0003, "M": 0x5EED0004}
 DICT_SEED = 0x5EED0005
 
 CONFIGS = {
-    "C2": dict(codec="zstd", level=1, kind="T", unit=128 << 10, gib=4.0, dict_kib=0, kernel="kc_zfast_match_grp_kernel<8>",
+    "C2": dict(codec="zstd", level=1, kind="T", unit=128 << 10, gib=4.0, dict_kib=0, kernel="kc_zfast_match_grp_kernel<8, false, false>",
                src="kc_zstd_match.hip", what="zstd SpeedFastest EncodeAll"),
-    "C2H": dict(codec="zstd", level=1, kind="H", unit=128 << 10, gib=4.0, dict_kib=0, kernel="kc_zfast_match_grp_kernel<8>",
+    "C2H": dict(codec="zstd", level=1, kind="H", unit=128 << 10, gib=4.0, dict_kib=0, kernel="kc_zfast_match_grp_kernel<8, true, true>",
                 src="kc_zstd_match.hip", what="zstd SpeedFastest EncodeAll"),
     "C3": dict(codec="zstd", level=2, kind="T", unit=128 << 10, gib=4.0, dict_kib=0, kernel="kc_zdfast_match_grp_kernel<8>",
                src="kc_zstd_match_dfast.hip", what="zstd SpeedDefault EncodeAll"),
@@ -377,8 +377,14 @@ def main():
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             for ent in pj.get("entries", [pj]):
-                if ent.get("config") == args.config and ent.get("units") == n_units and ent.get("corpus") == kind and ent.get("kernel_source_sha16") == khash:
+                if ent.get("config") != args.config or ent.get("units") != n_units or ent.get("corpus") != kind:
+                    continue
+                if ent.get("kernel_source_sha16") == khash:
                     traffic, traffic_src = ent["kernel_hbm_bytes"], "profiles/pmc_traffic.json (same workload, same kernel source)"
+                elif khash in ent.get("also_valid_for_sha16", []):
+                    # collected on an earlier form of this kernel's source; the entry says why it still describes the running one
+                    traffic = ent["kernel_hbm_bytes"]
+                    traffic_src = "profiles/pmc_traffic.json (same workload; measured on source %s: %s)" % (ent.get("kernel_source_sha16"), ent.get("note", ""))
         except Exception:
             pass
     roofline = {"bound": "hbm", "kernel": cfg["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
