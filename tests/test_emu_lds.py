@@ -131,7 +131,7 @@ def test_zfast_grp_epoch_stamped_tables():
     from the tag at the position width of 128 KiB units and of a 1 MiB unit."""
     sets = [_zfast_units()[:8], _zfast_units()[4:12], list(reversed(_zfast_units()[:8])),
             [corpora.corpus("T", 8, 131072, first_unit=77).tobytes()] + _zfast_units()[:3]]
-    for ep in range(1, 16):
+    for ep in (1, 2, 3, 14, 15):  # (the wrap of the stamp is the host's business: tests/test_gpu_zstd.py)
         units = sets[ep % len(sets)]
         _cmp_parse(units, emu_lib.zfast_parse_grp(units, epoch=ep, slots=21, fresh=ep == 1), level=1)
 
@@ -154,11 +154,11 @@ def _cmp_parse(units, got, **okw):
 
 
 def _zbest_units():
-    units = [corpora.corpus("T", 1, 131072, first_unit=1).tobytes(), corpora.corpus("M", 1, 131072, first_unit=2).tobytes()[:90000],
+    units = [corpora.corpus("T", 1, 131072, first_unit=1).tobytes()[:100000], corpora.corpus("M", 1, 131072, first_unit=2).tobytes()[:90000],
              corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("H", 1, 40000).tobytes()]
     units += [u for u in corpora.edge_units() if 0 < len(u) < 140000]
-    units += [u[:150000] for u in corpora.stress_units(seed=5, n=6)]   # two blocks with history
-    units += [corpora.corpus("T", 3, 131072, first_unit=77).tobytes()[:300000]]
+    units += [u[:140000] for u in corpora.stress_units(seed=5, n=3)]   # two blocks with history
+    units += [corpora.corpus("T", 2, 131072, first_unit=77).tobytes()[:150000]]
     # long repeats: matches beyond goodEnough, repeat-offset forms straight after a match, period-1..7 runs
     rng = np.random.default_rng(3)
     pat = bytes(rng.integers(0, 256, 700, dtype=np.uint8))
