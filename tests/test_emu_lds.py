@@ -156,7 +156,8 @@ def _cmp_parse(units, got, **okw):
 def _zbest_units():
     units = [corpora.corpus("T", 1, 131072, first_unit=1).tobytes()[:100000], corpora.corpus("M", 1, 131072, first_unit=2).tobytes()[:90000],
              corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("H", 1, 40000).tobytes()]
-    units += [u for u in corpora.edge_units() if 0 < len(u) < 140000]
+    # (tiny alphabets make the longest candidate chains: 27 s of emulation for 128 KiB of two symbols — a third of that is plenty here)
+    units += [u[:48000] if len(set(u[:4096])) <= 4 else u for u in corpora.edge_units() if 0 < len(u) < 140000]
     units += [u[:140000] for u in corpora.stress_units(seed=5, n=3)]   # two blocks with history
     units += [corpora.corpus("T", 2, 131072, first_unit=77).tobytes()[:150000]]
     # long repeats: matches beyond goodEnough, repeat-offset forms straight after a match, period-1..7 runs
