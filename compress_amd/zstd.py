@@ -99,6 +99,83 @@ def WithEncoderDict(dict):
     return apply
 
 
+SKIPPABLE_FRAME_HEADER = 8  # zstd/frameenc.go: skippableFrameHeader = 4 + 4
+
+
+def calc_skippable_frame(written, want_multiple):
+    """calcSkippableFrame (zstd/frameenc.go:100-116): bytes of skippable frame that bring `written` to a multiple of
+    `want_multiple`; a frame needs its 8-byte header, so a remainder below that is padded by one more multiple."""
+    if want_multiple <= 0:
+        raise ValueError("wantMultiple <= 0")
+    if written < 0:
+        raise ValueError("written < 0")
+    left_over = written % want_multiple
+    if left_over == 0:
+        return 0
+    to_add = want_multiple - left_over
+    while to_add < SKIPPABLE_FRAME_HEADER:
+        to_add += want_multiple
+    return to_add
+
+
+def skippable_frame(total, rand=os.urandom):
+    """skippableFrame (zstd/frameenc.go:118-137): a skippable frame of `total` bytes in all — magic 0x184D2A50, the 32-bit size of what
+    follows, and that many bytes from `rand` (the reference reads crypto/rand.Reader: the padding is not reproducible by design)."""
+    if total == 0:
+        return b""
+    if total < SKIPPABLE_FRAME_HEADER:
+        raise ValueError("requested skippable frame (%d) < 8" % total)
+    if total > 0xFFFFFFFF:
+        raise ValueError("requested skippable frame (%d) > max uint32" % total)
+    f = total - SKIPPABLE_FRAME_HEADER
+    return bytes([0x50, 0x2A, 0x4D, 0x18]) + int(f).to_bytes(4, "little") + bytes(rand(f))
+
+
+def pad_frames(out, out_off, pad, rand=os.urandom):
+    """Every frame of a batch followed by the skippable frame that WithEncoderPadding(pad) appends to it — per frame what EncodeAll
+    does with an empty dst (zstd/encoder.go:829-837).  A zero-length frame (empty input without WithZeroFrames) stays empty:
+    EncodeAll returns before the padding there (zstd/encoder.go:732-752).  Returns (bytes, offsets)."""
+    import numpy as np
+    n = len(out_off) - 1
+    parts, offs, pos = [], [0], 0
+    for i in range(n):
+        fr = bytes(out[int(out_off[i]):int(out_off[i + 1])])
+        if fr:
+            fr += skippable_frame(calc_skippable_frame(len(fr), pad), rand)
+        parts.append(fr)
+        pos += len(fr)
+        offs.append(pos)
+    return np.frombuffer(b"".join(parts), dtype=np.uint8), np.asarray(offs, dtype=np.uint64)
+
+
+def WithEncoderPadding(n):
+    """zstd.WithEncoderPadding (encoder_options.go:142-158): the output of EncodeAll / of a stream is padded to a multiple of n with a
+    skippable frame of random bytes.  Host-side: the device frames are the unpadded ones."""
+    n = int(n)
+    if n <= 0:
+        raise ValueError("padding must be at least 1")
+    if n > 1 << 30:
+        raise ValueError("padding must less than 1GB (1<<30 bytes) ")
+
+    def apply(o):
+        pass
+    apply._kc_pad = 0 if n == 1 else n  # "No need to waste our time."
+    return apply
+
+
+def WithEncoderDictDelete():
+    """zstd.WithEncoderDictDelete (encoder_options.go:408-415): no dictionary from here on."""
+    def apply(o):  # every field a dictionary sets, back to kc_zstd_opts_default's
+        o.dict = None
+        o.dict_len = 0
+        o.dict_id = 0
+        o.dict_offsets[0], o.dict_offsets[1], o.dict_offsets[2] = 1, 4, 8  # blockenc.go:78
+        o.dict_huf_len = 0
+        o.dict_huf_log = 0
+    apply._kc_dict_delete = True
+    return apply
+
+
 def WithMatchPath(path):
     """Not a reference option: which kernel family serves SpeedFastest ('auto' by units in flight, 'hbm', 'lds';
     KC_OPT_MATCH_PATH in include/kcgpu.h).  The bytes are the reference's either way."""
@@ -155,7 +232,11 @@ class Encoder:
         self.o = _lib.ZstdOpts()
         L.kc_zstd_opts_default(C.byref(self.o))
         self._conc_blocks, self._concurrency = False, os.cpu_count() or 1  # o.concurrent defaults to GOMAXPROCS (encoder_options.go:38)
+        self._pad = 0
         for op in opts:
+            if hasattr(op, "_kc_pad"):
+                self._pad = op._kc_pad
+                continue
             if hasattr(op, "_kc_path"):
                 self._path = op._kc_path
                 continue
@@ -172,15 +253,21 @@ class Encoder:
 
     # -- reference API --
     def MaxEncodedSize(self, size):
-        return int(_lib.load().kc_zstd_max_encoded_size(C.byref(self.o), int(size)))
+        m = int(_lib.load().kc_zstd_max_encoded_size(C.byref(self.o), int(size)))
+        if self._pad > 1:  # zstd/encoder.go:867-871
+            m += calc_skippable_frame(m, self._pad)
+        return m
 
     def EncodeAll(self, src, dst=b""):
         """Encode all of src as one frame and append to dst (zstd/encoder.go:722)."""
         import numpy as np
         src = bytes(src)
         off = np.array([0, len(src)], dtype=np.uint64)
-        out, _ = self.EncodeUnits(np.frombuffer(src, dtype=np.uint8), off)
-        return bytes(dst) + out.tobytes()
+        out, _ = self._encode_units_unpadded(np.frombuffer(src, dtype=np.uint8), off)
+        res = bytes(dst) + out.tobytes()
+        if self._pad > 0 and len(out):  # the TOTAL size becomes a multiple (dst included: encoder_options.go:140, encoder.go:829-837)
+            res += skippable_frame(calc_skippable_frame(len(res), self._pad))
+        return res
 
     # -- batched form: what the cgo shim calls --
     def ctx(self):
@@ -191,7 +278,14 @@ class Encoder:
         return self._ctx
 
     def EncodeUnits(self, src, unit_off):
-        """src: numpy uint8 (host); unit_off: uint64[n+1].  Returns (numpy uint8 frames, uint64[n+1] offsets)."""
+        """src: numpy uint8 (host); unit_off: uint64[n+1].  Returns (numpy uint8 frames, uint64[n+1] offsets).  With
+        WithEncoderPadding every frame is followed by its skippable frame (N x EncodeAll(unit, nil))."""
+        out, out_off = self._encode_units_unpadded(src, unit_off)
+        if self._pad > 0:
+            return pad_frames(out, out_off, self._pad)
+        return out, out_off
+
+    def _encode_units_unpadded(self, src, unit_off):
         import numpy as np
         ctx = self.ctx()
         src = np.ascontiguousarray(src, dtype=np.uint8)
@@ -279,11 +373,14 @@ class Encoder:
         self._buf = bytearray()
         self._closed = True
         if self._conc_blocks and self._concurrency > 1 and not self.o.dict_len:  # zstd/encoder.go:81: else the option is off
-            self._w.write(self.EncodeJobs(data, cuts))
-            return
-        out, _ = self.EncodeStreams(np.frombuffer(data, dtype=np.uint8), np.array([0, len(data)], dtype=np.uint64),
-                                    flush_at=[cuts] if cuts else None)
-        self._w.write(out.tobytes())
+            frame = bytes(self.EncodeJobs(data, cuts))
+        else:
+            out, _ = self.EncodeStreams(np.frombuffer(data, dtype=np.uint8), np.array([0, len(data)], dtype=np.uint64),
+                                        flush_at=[cuts] if cuts else None)
+            frame = out.tobytes()
+        if self._pad > 0:  # Close: padding from the bytes written in this stream (zstd/encoder.go:637-645, 700-708)
+            frame += skippable_frame(calc_skippable_frame(len(frame), self._pad))
+        self._w.write(frame)
 
     def JobSize(self):
         return int(_lib.load().kc_zstd_job_size(C.byref(self.o)))

@@ -13,6 +13,7 @@ import "C"
 
 import (
 	"bytes"
+	"crypto/rand"
 	"errors"
 	"io"
 	"runtime"
@@ -52,6 +53,7 @@ type Encoder struct {
 	jobs     bool // WithConcurrentBlocks(true)
 	devJobs  bool // WithDeviceJobs(true)
 	hasDict  bool
+	pad      int // WithEncoderPadding: applied on the host, behind the frames of either path
 }
 
 // WithDeviceJobs sends WithConcurrentBlocks streams to the device (kc_zstd_encode_jobs).  Off by default: the jobs of a stream are
@@ -236,6 +238,95 @@ func WithSingleSegment(b bool) Option {
 	}
 }
 
+// WithNoEntropyCompression mirrors zstd.WithNoEntropyCompression (zstd/encoder_options.go:297-313).
+func WithNoEntropyCompression(b bool) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithNoEntropyCompression(b))
+		C.kc_zstd_opts_no_entropy(&e.opts, boolInt(b))
+		return nil
+	}
+}
+
+// WithAllLitEntropyCompression mirrors zstd.WithAllLitEntropyCompression (zstd/encoder_options.go:285-295).
+func WithAllLitEntropyCompression(b bool) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithAllLitEntropyCompression(b))
+		C.kc_zstd_opts_all_lit_entropy(&e.opts, boolInt(b))
+		return nil
+	}
+}
+
+// WithLowerEncoderMem mirrors zstd.WithLowerEncoderMem (zstd/encoder_options.go:327-338): buffer sizing of the reference encoder
+// only, no effect on the bytes and none on the device path.
+func WithLowerEncoderMem(b bool) Option {
+	return func(e *Encoder) error {
+		e.cpuOpts = append(e.cpuOpts, zstd.WithLowerEncoderMem(b))
+		return nil
+	}
+}
+
+// WithEncoderPadding mirrors zstd.WithEncoderPadding (zstd/encoder_options.go:142-158): every EncodeAll result and every stream is
+// brought to a multiple of n bytes by a skippable frame of random bytes.  The padding is added on the host behind the frames of
+// either path (the reference encoder held by this type does not get the option, its streaming Writer does), so a frame is the
+// same bytes with and without it.
+func WithEncoderPadding(n int) Option {
+	return func(e *Encoder) error {
+		if n <= 0 {
+			return errors.New("padding must be at least 1")
+		}
+		if n > 1<<30 {
+			return errors.New("padding must less than 1GB (1<<30 bytes) ")
+		}
+		if n == 1 {
+			n = 0
+		}
+		e.pad = n
+		return nil
+	}
+}
+
+const skippableFrameHeader = 4 + 4
+
+// calcSkippableFrame restates the unexported zstd/frameenc.go:100-116.
+func calcSkippableFrame(written, wantMultiple int64) int {
+	leftOver := written % wantMultiple
+	if leftOver == 0 {
+		return 0
+	}
+	toAdd := wantMultiple - leftOver
+	for toAdd < skippableFrameHeader {
+		toAdd += wantMultiple
+	}
+	return int(toAdd)
+}
+
+// appendPadding appends the skippable frame (zstd/frameenc.go:118-137) that brings len(dst) to a multiple of e.pad.
+func (e *Encoder) appendPadding(dst []byte) []byte {
+	if e.pad <= 0 {
+		return dst
+	}
+	total := calcSkippableFrame(int64(len(dst)), int64(e.pad))
+	if total == 0 {
+		return dst
+	}
+	f := uint32(total - skippableFrameHeader)
+	dst = append(dst, 0x50, 0x2a, 0x4d, 0x18, uint8(f), uint8(f>>8), uint8(f>>16), uint8(f>>24))
+	start := len(dst)
+	dst = append(dst, make([]byte, f)...)
+	if _, err := io.ReadFull(rand.Reader, dst[start:]); err != nil {
+		panic(err) // as the reference does (zstd/encoder.go:833-836)
+	}
+	return dst
+}
+
+// streamOpts: the options of a streaming reference Writer (the padding included: it is part of what Close writes).
+func (e *Encoder) streamOpts() []zstd.EOption {
+	if e.pad > 0 {
+		return append(append([]zstd.EOption{}, e.cpuOpts...), zstd.WithEncoderPadding(e.pad))
+	}
+	return e.cpuOpts
+}
+
 // WithEncoderDict registers a dictionary in the "zstd --train" format (zstd.WithEncoderDict).
 func WithEncoderDict(dict []byte) Option {
 	return func(e *Encoder) error {
@@ -315,19 +406,27 @@ func (e *Encoder) Close() {
 
 // MaxEncodedSize == (*zstd.Encoder).MaxEncodedSize.
 func (e *Encoder) MaxEncodedSize(size int) int {
-	return int(C.kc_zstd_max_encoded_size(&e.opts, C.int64_t(size)))
+	m := int(C.kc_zstd_max_encoded_size(&e.opts, C.int64_t(size)))
+	if e.pad > 1 { // zstd/encoder.go:867-871
+		m += calcSkippableFrame(int64(m), int64(e.pad))
+	}
+	return m
 }
 
 // EncodeAll == (*zstd.Encoder).EncodeAll for one unit (prefer EncodeUnits).
 func (e *Encoder) EncodeAll(src, dst []byte) []byte {
+	before := len(dst)
 	if !e.useDevice(len(src)) {
-		return e.cpu.EncodeAll(src, dst) // one unit: the reference encoder is faster (and concurrency-safe)
+		dst = e.cpu.EncodeAll(src, dst) // one unit: the reference encoder is faster (and concurrency-safe)
+	} else if out, _, err := e.encodeUnits(src, []uint64{0, uint64(len(src))}, nil); err != nil {
+		dst = e.cpu.EncodeAll(src, dst)
+	} else {
+		dst = append(dst, out...)
 	}
-	out, _, err := e.EncodeUnits(src, []uint64{0, uint64(len(src))}, nil)
-	if err != nil {
-		return e.cpu.EncodeAll(src, dst)
+	if len(dst) > before { // (an empty input without WithZeroFrames returns before the padding: zstd/encoder.go:732-752)
+		dst = e.appendPadding(dst) // the TOTAL becomes a multiple, dst included (zstd/encoder.go:829-837)
 	}
-	return append(dst, out...)
+	return dst
 }
 
 // EncodeStreams encodes src[off[i]:off[i+1]] as independent STREAMS, each identical to what
@@ -452,6 +551,29 @@ func (e *Encoder) EncodeStreamsCuts(src []byte, off []uint64, flushAt [][]uint64
 
 // EncodeUnits encodes src[off[i]:off[i+1]] as independent frames, each identical to EncodeAll(unit, nil).
 func (e *Encoder) EncodeUnits(src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
+	out, outOff, err := e.encodeUnits(src, off, dst)
+	if err != nil || e.pad <= 0 {
+		return out, outOff, err
+	}
+	// WithEncoderPadding: every frame followed by its skippable frame, as n x EncodeAll(unit, nil) gives them
+	n := len(off) - 1
+	padded := make([]byte, 0, len(out)+n*(e.pad+skippableFrameHeader))
+	pOff := make([]uint64, n+1)
+	for i := 0; i < n; i++ {
+		pOff[i] = uint64(len(padded))
+		fr := out[outOff[i]:outOff[i+1]]
+		if len(fr) == 0 {
+			continue
+		}
+		one := e.appendPadding(append([]byte{}, fr...))
+		padded = append(padded, one...)
+	}
+	pOff[n] = uint64(len(padded))
+	return padded, pOff, nil
+}
+
+// encodeUnits: the frames without padding.
+func (e *Encoder) encodeUnits(src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
 	n := len(off) - 1
 	need := 0
 	for i := 0; i < n; i++ {
@@ -534,7 +656,7 @@ func (x *Writer) Reset(w io.Writer) {
 // fallback moves the stream to a reference encoder, replaying what was buffered with its block cuts.
 func (x *Writer) fallback() error {
 	if x.ref == nil {
-		r, err := zstd.NewWriter(x.w, x.e.cpuOpts...)
+		r, err := zstd.NewWriter(x.w, x.e.streamOpts()...)
 		if err != nil {
 			return err
 		}
@@ -649,6 +771,7 @@ func (x *Writer) Close() error {
 	if err != nil {
 		return err
 	}
+	out = x.e.appendPadding(out) // Close pads what the stream wrote (zstd/encoder.go:637-645, 700-708)
 	_, err = x.w.Write(out)
 	return err
 }

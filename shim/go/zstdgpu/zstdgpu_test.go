@@ -527,3 +527,92 @@ func TestConcurrentBlocks(t *testing.T) {
 		}
 	}
 }
+
+// TestEntropyOptionsAndPadding: WithNoEntropyCompression / WithAllLitEntropyCompression through the device == the reference's bytes;
+// WithEncoderPadding: the padding is random by design (crypto/rand), so what is compared with the reference is everything else —
+// the frame in front of it, the total length, the skippable frame's header — for EncodeAll (with bytes already in dst), the batch
+// form and a Writer.
+func TestEntropyOptionsAndPadding(t *testing.T) {
+	data := corpusT(5 << 20)
+	off := cut(data, 128<<10)
+	for _, c := range []struct {
+		name string
+		gpu  []Option
+		ref  []zstd.EOption
+	}{
+		{"no entropy", []Option{WithNoEntropyCompression(true)}, []zstd.EOption{zstd.WithNoEntropyCompression(true)}},
+		{"all literals entropy off", []Option{WithAllLitEntropyCompression(false)}, []zstd.EOption{zstd.WithAllLitEntropyCompression(false)}},
+		{"all literals entropy on, fastest", []Option{WithEncoderLevel(zstd.SpeedFastest), WithAllLitEntropyCompression(true)},
+			[]zstd.EOption{zstd.WithEncoderLevel(zstd.SpeedFastest), zstd.WithAllLitEntropyCompression(true)}},
+		{"lower mem", []Option{WithLowerEncoderMem(true)}, []zstd.EOption{zstd.WithLowerEncoderMem(true)}},
+	} {
+		gpu, err := New(0, append([]Option{WithDeviceMinBytes(0)}, c.gpu...)...)
+		if err != nil {
+			t.Fatal(err)
+		}
+		ref, _ := zstd.NewWriter(nil, append([]zstd.EOption{zstd.WithEncoderConcurrency(1)}, c.ref...)...)
+		checkUnits(t, c.name, gpu, ref, data, off)
+		gpu.Close()
+		ref.Close()
+	}
+	for _, pad := range []int{2, 13, 512, 4096} {
+		gpu, err := New(0, WithDeviceMinBytes(0), WithEncoderPadding(pad))
+		if err != nil {
+			t.Fatal(err)
+		}
+		plain, _ := zstd.NewWriter(nil, zstd.WithEncoderConcurrency(1))
+		padded, _ := zstd.NewWriter(nil, zstd.WithEncoderConcurrency(1), zstd.WithEncoderPadding(pad))
+		for _, n := range []int{1, 1000, 128 << 10, 300000} {
+			src := data[:n]
+			for _, pre := range [][]byte{nil, []byte("seven b")} {
+				got := gpu.EncodeAll(src, append([]byte{}, pre...))
+				want := padded.EncodeAll(src, append([]byte{}, pre...))
+				frame := plain.EncodeAll(src, nil)
+				if len(got) != len(want) || len(got)%pad != 0 {
+					t.Fatalf("pad %d, %d bytes: length %d, the reference's %d", pad, n, len(got), len(want))
+				}
+				if !bytes.HasPrefix(got[len(pre):], frame) || !bytes.Equal(got[:len(pre)], pre) {
+					t.Fatalf("pad %d, %d bytes: the frame in front of the padding is not the reference's", pad, n)
+				}
+				k := len(pre) + len(frame)
+				if k < len(got) && !bytes.Equal(got[k:k+8], want[k:k+8]) {
+					t.Fatalf("pad %d, %d bytes: skippable frame header % x, the reference's % x", pad, n, got[k:k+8], want[k:k+8])
+				}
+			}
+		}
+		out, outOff, err := gpu.EncodeUnits(data, off, nil)
+		if err != nil {
+			t.Fatal(err)
+		}
+		for i := 0; i+1 < len(off); i++ {
+			want := padded.EncodeAll(data[off[i]:off[i+1]], nil)
+			got := out[outOff[i]:outOff[i+1]]
+			frame := plain.EncodeAll(data[off[i]:off[i+1]], nil)
+			if len(got) != len(want) || !bytes.HasPrefix(got, frame) {
+				t.Fatalf("pad %d, unit %d of the batch: %d bytes, the reference's %d", pad, i, len(got), len(want))
+			}
+		}
+		var a, b bytes.Buffer
+		w, err := NewWriter(&a, 0, WithDeviceMinBytes(0), WithEncoderPadding(pad))
+		if err != nil {
+			t.Fatal(err)
+		}
+		r, _ := zstd.NewWriter(&b, zstd.WithEncoderPadding(pad))
+		w.Write(data[:700000])
+		r.Write(data[:700000])
+		w.Close()
+		r.Close()
+		if a.Len() != b.Len() || a.Len()%pad != 0 {
+			t.Fatalf("pad %d, Writer: %d bytes, the reference's %d", pad, a.Len(), b.Len())
+		}
+		dec, _ := zstd.NewReader(nil)
+		back, err := dec.DecodeAll(a.Bytes(), nil)
+		if err != nil || !bytes.Equal(back, data[:700000]) {
+			t.Fatalf("pad %d, Writer: the padded stream does not decode to the input (%v)", pad, err)
+		}
+		dec.Close()
+		gpu.Close()
+		plain.Close()
+		padded.Close()
+	}
+}
