@@ -106,7 +106,7 @@ struct KcCfg {
                                           // filter), -1 (default) chosen per batch: the tuned form when the context's previous batch did not compress (ratio >= 0.98)
     int64_t zfast_filter = 1;             // SpeedFastest HBM-table kernel: "nothing written there yet" filter in the idle sequence buffer (units without a sequence so far)
     int64_t xxh_fin_mode = 1;             // kc_xxh64_fin_kernel: how the payload of raw-only frames is stored (KcXxhFinParams.mode)
-    int64_t fuse_raw_xxh = 1;             // frames made of raw blocks only: checksum and payload copy in one pass over the source (kc_xxh64_copy_kernel)
+    int64_t fuse_raw_xxh = 1;             // frames made of raw blocks only: checksum and payload copy in one pass over the source (kc_xxh64_fin_kernel)
 };
 
 struct kc_ctx {
