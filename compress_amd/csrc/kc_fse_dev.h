@@ -318,6 +318,7 @@ __device__ inline bool fse_build_wave(const int16_t* norm, int symbolLen, uint8_
             const int ls = __shfl(sy, leader, 64);
             const unsigned long long m = __ballot(act && sy == ls);
             const int base = (int)cumul[ls];
+            KC_EMU_SYNC();  // (every lane has read the counter before the leader advances it)
             if (act && sy == ls) slot = base + __popcll(m & ltMask);
             if (lane == leader) cumul[ls] = (int16_t)(base + __popcll(m));
             rem &= ~m;

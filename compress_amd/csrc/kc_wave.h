@@ -3,6 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The emulator only (tools/hipemu runs the lanes of a wave out of lockstep between two cross-lane operations): a point where the
+// hardware's lockstep orders an exchange through LDS by itself — every lane reads before any lane writes — and nothing is wanted
+// in the device code.
+#ifndef KC_EMU_SYNC
+#ifdef KC_HIPEMU
+#define KC_EMU_SYNC() hipemu::wave_sync()
+#else
+#define KC_EMU_SYNC() do { } while (0)
+#endif
+#endif
+
 // Wave-wide scans and reductions on the DPP data path (row shifts inside the 16-lane rows, then the row_bcast:15 / row_bcast:31
 // steps across rows): six dependent VALU operations, where __shfl_up / __shfl_xor compile to six dependent ds_bpermute round trips
 // through the LDS crossbar.  All 64 lanes must be active (every caller is in wave-uniform control flow).

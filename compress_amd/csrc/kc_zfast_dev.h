@@ -5,10 +5,12 @@
 
 // The emulator only (tools/hipemu runs lanes out of lockstep): an exchange through LDS that the hardware orders by itself, in a
 // kernel where KC_WAVE_SYNC's compiler fence is not wanted.
+#ifndef KC_EMU_SYNC
 #ifdef KC_HIPEMU
 #define KC_EMU_SYNC() hipemu::wave_sync()
 #else
 #define KC_EMU_SYNC() do { } while (0)
+#endif
 #endif
 
 #define ZF_TABLE_BITS 15

@@ -270,3 +270,34 @@ def xxh_fin(units, raw_flags, block_size, out_positions, mode, frame_header=9):
                         flags.ctypes.data, rawdef.ctypes.data, blk0.ctypes.data, xxh.ctypes.data, mode)
     assert r == 0
     return dst, stage, soff, sizes, xxh
+
+
+def zstd_frames(units, block_size=None, window=None, crc=True, single=-1, full_zero=True, stream_mode=0, use_grp=False, tuned=0,
+                max_encoded_size=None, level=1):
+    """The device's whole SpeedFastest EncodeAll pipeline on the emulator (checksum, match finder, entropy stage): one frame per unit.
+    Returns (list of frames, error flag, re-run flag)."""
+    if window is None:
+        window = (4 << 20) if level == 1 else (8 << 20)  # encoder_options.go:254-266
+    if block_size is None:
+        block_size = min(65536 if level == 1 else 131072, window)
+    n = len(units)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    soff = np.zeros(n + 1, dtype=np.uint64)
+    for i, u in enumerate(units):
+        off[i + 1] = off[i] + len(u)
+        mes = max_encoded_size(len(u)) if max_encoded_size else len(u) + 64 + 3 * (len(u) // block_size + 2)
+        soff[i + 1] = soff[i] + ((mes + 15) & ~15)
+    src = np.frombuffer(b"".join(units) + b"\0" * 64, dtype=np.uint8).copy()
+    al = np.zeros(len(src) + 32, dtype=np.uint8)
+    o = (-al.ctypes.data) % 16
+    al[o:o + len(src)] = src
+    stage = np.zeros(int(soff[n]) + 64, dtype=np.uint8)
+    sizes = np.zeros(n + 1, dtype=np.uint32)
+    err = np.zeros(2, dtype=np.uint32)
+    L = lib()
+    L.kcemu_zstd_frames.restype = C.c_int
+    L.kcemu_zstd_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_int] * 9 + [C.c_void_p] * 4
+    r = L.kcemu_zstd_frames(al.ctypes.data + o, off.ctypes.data, n, block_size, window, int(crc), single, int(full_zero), stream_mode, int(use_grp), tuned,
+                            level, stage.ctypes.data, soff.ctypes.data, sizes.ctypes.data, err.ctypes.data)
+    assert r == 0
+    return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)], int(err[0]), int(err[1])

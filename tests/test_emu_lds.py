@@ -260,3 +260,46 @@ def test_xxh_fin_kernel_checksum_and_raw_payload_copy(mode):
     for i in range(len(units)):
         mask[outp[i]:outp[i] + int(sizes[i])] = False
     assert np.all(dst[mask] == 0xAA)
+
+
+def _pipeline_units():
+    units = [corpora.corpus("T", 1, 131072, first_unit=5).tobytes(), corpora.corpus("M", 1, 131072, first_unit=1).tobytes(),
+             corpora.corpus("M", 1, 131072, first_unit=2).tobytes()[:70001], corpora.corpus("J", 1, 65536, first_unit=3).tobytes(),
+             corpora.corpus("H", 1, 131072).tobytes()[:66000], corpora.corpus("T", 2, 131072, first_unit=40).tobytes()[:200000]]
+    units += [u for u in corpora.edge_units() if len(u) < 140000]
+    units += [u[:150000] for u in corpora.stress_units(seed=9, n=8)]
+    return units
+
+
+@pytest.mark.parametrize("finder", ["lds", "grp", "grp-tuned"])
+def test_whole_pipeline_frames_equal_the_oracle(finder):
+    """The device's whole SpeedFastest EncodeAll pipeline on the wave emulator — XXH64 kernel, match finder (LDS-table kernel, or the
+    HBM-table group kernel in either of its forms), entropy stage with its Huffman / FSE table construction, literal and sequence
+    bitstreams, block and frame assembly — frame for frame against the oracle: what the GPU suite checks on the device, here without
+    one.  (Units whose late raw fallback asks for the speculation re-run are the host's business; none of these does.)"""
+    units = _pipeline_units()
+    ref = oracle_lib.ZstdOracle(level=1)
+    frames, err, redo = emu_lib.zstd_frames(units, use_grp=finder != "lds", tuned=int(finder == "grp-tuned"), max_encoded_size=ref.max_encoded_size)
+    assert err == 0 and redo == 0
+    bad = [(i, len(u), len(f)) for i, (u, f) in enumerate(zip(units, frames)) if f != ref.encode_all(u)]
+    assert not bad, "units whose emulated frame differs from the oracle's (index, length, frame length): %r" % bad[:8]
+
+
+def test_whole_pipeline_options_and_streams():
+    """The same with the options that change the frame: no checksum, single segment forced on and off, a small window (= small
+    blocks), zero-length input with and without WithZeroFrames, and the Write ... Close stream form."""
+    units = [corpora.corpus("T", 1, 131072, first_unit=6).tobytes()[:90000], corpora.corpus("M", 1, 131072, first_unit=4).tobytes()[:50000], b"",
+             b"abc", corpora.corpus("J", 1, 65536, first_unit=1).tobytes()[:20000], corpora.corpus("H", 1, 8192).tobytes()]
+    cases = [(dict(crc=False), dict(crc=False)), (dict(single=1), dict(single=True)), (dict(single=0), dict(single=False)),
+             (dict(window=1 << 14, block_size=1 << 14), dict(window_size=1 << 14)), (dict(full_zero=False), dict(full_zero=False))]
+    for ekw, okw in cases:
+        ref = oracle_lib.ZstdOracle(level=1, **okw)
+        frames, err, redo = emu_lib.zstd_frames(units, max_encoded_size=ref.max_encoded_size, **ekw)
+        assert err == 0 and redo == 0
+        bad = [(i, len(u)) for i, (u, f) in enumerate(zip(units, frames)) if f != ref.encode_all(u)]
+        assert not bad, (okw, bad)
+    ref = oracle_lib.ZstdOracle(level=1)
+    frames, err, redo = emu_lib.zstd_frames(units, stream_mode=1, max_encoded_size=lambda n: ref.max_encoded_size(n) + 8)
+    assert err == 0 and redo == 0
+    bad = [(i, len(u)) for i, (u, f) in enumerate(zip(units, frames)) if f != ref.encode_stream(u)]
+    assert not bad, ("stream", bad)

@@ -44,6 +44,7 @@ uint64_t shfl64(uint64_t v, int src_lane);           // absolute lane 0..63 of t
 uint64_t first_lane64(uint64_t v);
 void wave_sync();
 void block_sync();
+int block_or(int p);  // __syncthreads_or
 int lane();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void set_group(unsigned g);  // sub-wave groups of g lanes rendezvous among themselves (kernels whose groups diverge); 64: whole waves
@@ -89,13 +90,25 @@ static inline int __shfl_xor(int v, int m, int width = 64) {
     return (int)(uint32_t)hipemu::shfl64((uint32_t)v, emu_src_lane(l, (l & (width - 1)) ^ m, width));
 }
 static inline void __syncthreads() { hipemu::block_sync(); }
-// v_mov_b32 with a DPP quad permute (control word below 0x100: two bits per lane of the quad select the source lane)
+// v_mov_b32 with a DPP control word: quad_perm (below 0x100: two bits per lane of the quad select the source lane), row_shr:n
+// (0x111..0x11f), row_bcast:15 (0x142: lane 15 of a row to the whole next row), row_bcast:31 (0x143: lane 31 to rows 2 and 3).  A lane
+// whose row / bank is masked off, or that has no source lane, keeps `old` (0 with bound_ctrl when only the source is missing).
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-    (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
     const int lane = hipemu::lane();
-    if (ctrl < 0 || ctrl >= 0x100) { fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl); abort(); }
-    return (int)(uint32_t)hipemu::shfl64((uint32_t)src, (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3));
+    int from = -1;
+    if (ctrl >= 0 && ctrl < 0x100) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl & 15; if ((lane & 15) >= n) from = lane - n; }
+    else if (ctrl == 0x142) { if (lane >= 16) from = (lane & ~15) - 1; }
+    else if (ctrl == 0x143) { if (lane >= 32) from = 31; }
+    else { fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl); abort(); }
+    const uint32_t v = (uint32_t)hipemu::shfl64((uint32_t)src, from < 0 ? lane : from);  // (every lane takes part in the exchange)
+    if (!((row_mask >> (lane >> 4)) & 1) || !((bank_mask >> ((lane >> 2) & 3)) & 1)) return old;
+    if (from < 0) return bound_ctrl ? 0 : old;
+    return (int)v;
 }
+static inline void __builtin_amdgcn_fence(int, const char*) {}  // (always next to a wave barrier, which is the rendezvous here)
+static inline long long clock64() { return 0; }
+static inline int __syncthreads_or(int p) { return hipemu::block_or(p); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)hipemu::first_lane64((uint32_t)v); }
 static inline int __builtin_amdgcn_readlane(int v, int src) { return (int)(uint32_t)hipemu::shfl64((uint32_t)v, src & 63); }
 static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }

@@ -55,6 +55,7 @@ struct Block {
     std::vector<Fiber> fibers;
     std::vector<Wave> waves;
     int live = 0, b_arrived = 0;
+    int or_acc = 0;  // __syncthreads_or
     unsigned b_gen = 0;
     dim3 bid, bdim, gdim;
     const std::function<void()>* body = nullptr;
@@ -200,6 +201,17 @@ __attribute__((noinline)) void block_sync() {
     }
 }
 
+// __syncthreads_or: barrier + block-wide OR of the predicate
+int block_or(int p) {
+    block_sync();  // every fiber is past its reset of the previous use
+    if (p) g_blk->or_acc = 1;
+    block_sync();
+    const int r = g_blk->or_acc;
+    block_sync();  // every fiber has read
+    g_blk->or_acc = 0;
+    return r;
+}
+
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     if (const char* e = getenv("HIPEMU_NO_SITE_CHECK")) g_check_site = atoi(e) == 0;
     const unsigned nt = block.x * block.y * block.z;
@@ -222,6 +234,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                 B.waves.assign((nt + g_group - 1) / g_group, Wave());
                 B.live = (int)nt;
                 B.b_arrived = 0;
+                B.or_acc = 0;
                 for (unsigned t = 0; t < nt; t++) {
                     Fiber& f = B.fibers[t];
                     f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));

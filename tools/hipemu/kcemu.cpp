@@ -5,6 +5,8 @@
 #include "../../compress_amd/csrc/kc_zstd_match_lds.hip"
 #include "../../compress_amd/csrc/kc_zstd_match.hip"
 #include "../../compress_amd/csrc/kc_misc.hip"
+#include "../../compress_amd/csrc/kc_zstd_entropy.hip"
+#include <vector>
 #include "../../compress_amd/csrc/kc_s2_best.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_best.hip"
 
@@ -99,6 +101,63 @@ int kcemu_xxh_fin(const uint8_t* src, const uint64_t* unit_off, uint32_t n, uint
     hipemu::set_group(4);  // one unit per quad; the quads' trip counts differ
     kc_launch_xxh64_fin(P, nullptr);
     hipemu::set_group(64);
+    return 0;
+}
+
+// The whole SpeedFastest EncodeAll pipeline of the device on the emulator: checksum kernel, match finder (LDS-table kernel, or with
+// use_grp the HBM-table group kernel in the form `tuned`), entropy stage — the frames as they sit in the staging slots (raw blocks'
+// payloads included: no rawdef), with the host's layout rules (seq_stride, lit_stride: kc_api.cpp batch_begin).
+int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, int block_size, int window, int crc, int single, int full_zero,
+                      int stream_mode, int use_grp, int tuned, int level /* 1: the other levels' match finders are not on the emulator */, uint8_t* stage, const uint64_t* stage_off, uint32_t* out_size, uint32_t* err_out) {
+    std::vector<uint32_t> blk0(n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t len = unit_off[i + 1] - unit_off[i];
+        blk0[i + 1] = blk0[i] + (uint32_t)((len + (uint64_t)block_size - 1) / (uint64_t)block_size);
+    }
+    const uint32_t nb = blk0[n];
+    const uint32_t seq_stride = (uint32_t)(block_size / 4 + 8), lit_stride = (uint32_t)(block_size + 64);
+    std::vector<uint64_t> seqs((size_t)(nb + 1) * seq_stride, 0), aux((size_t)(nb + 1) * seq_stride, 0), xxh(n + 1, 0);
+    std::vector<uint8_t> lits((size_t)(nb + 1) * lit_stride, 0), redo_blk(nb + 1, 0), predef(kc_fse_predef_bytes() + 64, 0);
+    std::vector<KcBlkMeta> meta(nb + 1);
+    std::vector<uint32_t> redo(n + 1, 0), tables;
+    uint32_t err[16] = {0};
+    uint64_t maxlen = 16;
+    for (uint32_t i = 0; i < n; i++) maxlen = std::max<uint64_t>(maxlen, unit_off[i + 1] - unit_off[i]);
+    int pb = 1;
+    while (((uint64_t)1 << pb) <= maxlen + 2) pb++;
+    KcMatchParams M;
+    memset(&M, 0, sizeof(M));
+    M.src = src; M.src_end = src + unit_off[n]; M.unit_off = unit_off; M.unit_blk0 = blk0.data(); M.seqs = seqs.data(); M.meta = meta.data();
+    M.seq_stride = seq_stride; M.block_size = block_size; M.max_match_off = window; M.pos_bits = pb; M.rep1 = 1; M.rep2 = 4; M.rep3 = 8;
+    M.stream_mode = stream_mode;
+    kc_launch_fse_predef_init(predef.data(), nullptr);
+    if (crc) {
+        hipemu::set_group(4);
+        kc_launch_xxh64(src, unit_off, n, xxh.data(), nullptr);
+        hipemu::set_group(64);
+    }
+    if (use_grp) {
+        tables.assign((size_t)((n + 7) / 8 * 8) << 15, 0);
+        M.spec_w0 = 1; M.spec_grow = 1; M.tuned = tuned; M.empty_filter = 1;
+        hipemu::set_group(8);
+        kc_launch_zfast_match_grp(M, tables.data(), n, nullptr);
+        hipemu::set_group(64);
+    } else {
+        M.spec_w0 = 16;
+        kc_launch_zfast_match_lds(M, nullptr, 0u, n, nullptr);
+    }
+    KcEntropyParams E;
+    memset(&E, 0, sizeof(E));
+    E.src = src; E.unit_off = unit_off; E.unit_blk0 = blk0.data(); E.seqs = seqs.data(); E.meta = meta.data(); E.lits = lits.data(); E.aux = aux.data();
+    E.stage = stage; E.stage_off = stage_off; E.out_size = out_size; E.xxh = xxh.data(); E.redo_mask = redo.data(); E.redo_blk = redo_blk.data();
+    E.predef = predef.data(); E.seq_stride = seq_stride; E.lit_stride = lit_stride; E.block_size = block_size; E.window_size = window;
+    E.crc = crc; E.single = single; E.no_entropy = 0; E.all_lit_entropy = 0; E.full_zero = full_zero; E.stream_mode = stream_mode;
+    E.err_flag = err;
+    kc_launch_zstd_entropy(E, n, nullptr);
+    uint32_t anyredo = 0;
+    for (uint32_t i = 0; i < n; i++) anyredo |= redo[i];
+    err_out[0] = err[0];
+    err_out[1] = anyredo;  // (a unit that needs the speculation re-run: the host would run it again; the test picks inputs that do not)
     return 0;
 }
 
