@@ -273,9 +273,10 @@ def xxh_fin(units, raw_flags, block_size, out_positions, mode, frame_header=9):
 
 
 def zstd_frames(units, block_size=None, window=None, crc=True, single=-1, full_zero=True, stream_mode=0, use_grp=False, tuned=0,
-                max_encoded_size=None, level=1):
+                max_encoded_size=None, level=1, no_entropy=False, all_lit_entropy=False):
     """The device's whole SpeedFastest EncodeAll pipeline on the emulator (checksum, match finder, entropy stage): one frame per unit.
     Returns (list of frames, error flag, re-run flag)."""
+    assert level == 1, "the other levels' match finders are not on the emulator"
     if window is None:
         window = (4 << 20) if level == 1 else (8 << 20)  # encoder_options.go:254-266
     if block_size is None:
@@ -298,6 +299,6 @@ def zstd_frames(units, block_size=None, window=None, crc=True, single=-1, full_z
     L.kcemu_zstd_frames.restype = C.c_int
     L.kcemu_zstd_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_int] * 9 + [C.c_void_p] * 4
     r = L.kcemu_zstd_frames(al.ctypes.data + o, off.ctypes.data, n, block_size, window, int(crc), single, int(full_zero), stream_mode, int(use_grp), tuned,
-                            level, stage.ctypes.data, soff.ctypes.data, sizes.ctypes.data, err.ctypes.data)
+                            int(no_entropy) | (int(all_lit_entropy) << 1), stage.ctypes.data, soff.ctypes.data, sizes.ctypes.data, err.ctypes.data)
     assert r == 0
     return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)], int(err[0]), int(err[1])

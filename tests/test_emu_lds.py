@@ -287,11 +287,13 @@ def test_whole_pipeline_frames_equal_the_oracle(finder):
 
 def test_whole_pipeline_options_and_streams():
     """The same with the options that change the frame: no checksum, single segment forced on and off, a small window (= small
-    blocks), zero-length input with and without WithZeroFrames, and the Write ... Close stream form."""
+    blocks), zero-length input with and without WithZeroFrames, WithNoEntropyCompression, WithAllLitEntropyCompression, and the
+    Write ... Close stream form."""
     units = [corpora.corpus("T", 1, 131072, first_unit=6).tobytes()[:90000], corpora.corpus("M", 1, 131072, first_unit=4).tobytes()[:50000], b"",
              b"abc", corpora.corpus("J", 1, 65536, first_unit=1).tobytes()[:20000], corpora.corpus("H", 1, 8192).tobytes()]
     cases = [(dict(crc=False), dict(crc=False)), (dict(single=1), dict(single=True)), (dict(single=0), dict(single=False)),
-             (dict(window=1 << 14, block_size=1 << 14), dict(window_size=1 << 14)), (dict(full_zero=False), dict(full_zero=False))]
+             (dict(window=1 << 14, block_size=1 << 14), dict(window_size=1 << 14)), (dict(full_zero=False), dict(full_zero=False)),
+             (dict(no_entropy=True), dict(no_entropy=True)), (dict(all_lit_entropy=True), dict(all_lit_entropy=True))]
     for ekw, okw in cases:
         ref = oracle_lib.ZstdOracle(level=1, **okw)
         frames, err, redo = emu_lib.zstd_frames(units, max_encoded_size=ref.max_encoded_size, **ekw)

@@ -108,7 +108,7 @@ int kcemu_xxh_fin(const uint8_t* src, const uint64_t* unit_off, uint32_t n, uint
 // use_grp the HBM-table group kernel in the form `tuned`), entropy stage — the frames as they sit in the staging slots (raw blocks'
 // payloads included: no rawdef), with the host's layout rules (seq_stride, lit_stride: kc_api.cpp batch_begin).
 int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, int block_size, int window, int crc, int single, int full_zero,
-                      int stream_mode, int use_grp, int tuned, int level /* 1: the other levels' match finders are not on the emulator */, uint8_t* stage, const uint64_t* stage_off, uint32_t* out_size, uint32_t* err_out) {
+                      int stream_mode, int use_grp, int tuned, int entropy_opts /* bit 0: no_entropy, bit 1: all_lit_entropy */, uint8_t* stage, const uint64_t* stage_off, uint32_t* out_size, uint32_t* err_out) {
     std::vector<uint32_t> blk0(n + 1, 0);
     for (uint32_t i = 0; i < n; i++) {
         const uint64_t len = unit_off[i + 1] - unit_off[i];
@@ -151,7 +151,7 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     E.src = src; E.unit_off = unit_off; E.unit_blk0 = blk0.data(); E.seqs = seqs.data(); E.meta = meta.data(); E.lits = lits.data(); E.aux = aux.data();
     E.stage = stage; E.stage_off = stage_off; E.out_size = out_size; E.xxh = xxh.data(); E.redo_mask = redo.data(); E.redo_blk = redo_blk.data();
     E.predef = predef.data(); E.seq_stride = seq_stride; E.lit_stride = lit_stride; E.block_size = block_size; E.window_size = window;
-    E.crc = crc; E.single = single; E.no_entropy = 0; E.all_lit_entropy = 0; E.full_zero = full_zero; E.stream_mode = stream_mode;
+    E.crc = crc; E.single = single; E.no_entropy = entropy_opts & 1; E.all_lit_entropy = (entropy_opts >> 1) & 1; E.full_zero = full_zero; E.stream_mode = stream_mode;
     E.err_flag = err;
     kc_launch_zstd_entropy(E, n, nullptr);
     uint32_t anyredo = 0;
