@@ -273,7 +273,7 @@ def xxh_fin(units, raw_flags, block_size, out_positions, mode, frame_header=9):
 
 
 def zstd_frames(units, block_size=None, window=None, crc=True, single=-1, full_zero=True, stream_mode=0, use_grp=False, tuned=0,
-                max_encoded_size=None, level=1, no_entropy=False, all_lit_entropy=False):
+                max_encoded_size=None, level=1, no_entropy=False, all_lit_entropy=False, fused=None):
     """The device's whole SpeedFastest EncodeAll pipeline on the emulator (checksum, match finder, entropy stage): one frame per unit.
     Returns (list of frames, error flag, re-run flag)."""
     assert level == 1, "the other levels' match finders are not on the emulator"
@@ -294,11 +294,17 @@ def zstd_frames(units, block_size=None, window=None, crc=True, single=-1, full_z
     al[o:o + len(src)] = src
     stage = np.zeros(int(soff[n]) + 64, dtype=np.uint8)
     sizes = np.zeros(n + 1, dtype=np.uint32)
-    err = np.zeros(2, dtype=np.uint32)
+    err = np.zeros(4, dtype=np.uint32)
+    dst = np.full(int(soff[n]) + 64, 0xAA, dtype=np.uint8) if fused is not None else None
+    doff = np.zeros(n + 2, dtype=np.uint64)
     L = lib()
     L.kcemu_zstd_frames.restype = C.c_int
-    L.kcemu_zstd_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_int] * 9 + [C.c_void_p] * 4
+    L.kcemu_zstd_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_int] * 9 + [C.c_void_p] * 6 + [C.c_int]
     r = L.kcemu_zstd_frames(al.ctypes.data + o, off.ctypes.data, n, block_size, window, int(crc), single, int(full_zero), stream_mode, int(use_grp), tuned,
-                            int(no_entropy) | (int(all_lit_entropy) << 1), stage.ctypes.data, soff.ctypes.data, sizes.ctypes.data, err.ctypes.data)
+                            int(no_entropy) | (int(all_lit_entropy) << 1), stage.ctypes.data, soff.ctypes.data, sizes.ctypes.data, err.ctypes.data,
+                            dst.ctypes.data if dst is not None else None, doff.ctypes.data, int(fused or 0))
     assert r == 0
+    if fused is not None:  # batch_end's sequence: size scan, checksum (+ raw payloads), compaction -> the contiguous output
+        assert int(doff[n]) == int(sizes[:n].sum()) and np.all(dst[int(doff[n]):] == 0xAA)
+        return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)], int(err[0]), int(err[1]), int(err[2])
     return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)], int(err[0]), int(err[1])

@@ -305,3 +305,21 @@ def test_whole_pipeline_options_and_streams():
     assert err == 0 and redo == 0
     bad = [(i, len(u)) for i, (u, f) in enumerate(zip(units, frames)) if f != ref.encode_stream(u)]
     assert not bad, ("stream", bad)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_whole_pipeline_with_the_checksum_behind_the_entropy_stage(mode):
+    """batch_end's sequence on the emulator — entropy stage with the raw payloads deferred and the checksum field left open, size scan,
+    kc_xxh64_fin_kernel (checksum of every frame, payload of the raw-only ones, in each store schedule), kc_compact_kernel — gives
+    the oracle's frames back to back: compressible units, incompressible ones of one and several blocks, units whose blocks are raw
+    and compressed in turn, tiny and empty ones."""
+    h = corpora.corpus("H", 4, 131072, first_unit=3).tobytes()
+    t = corpora.corpus("T", 2, 131072, first_unit=8).tobytes()
+    units = [h[:131072], t[:100000], h[7:7 + 65536 + 13], h[:200000], b"", h[5:305], h[9:40], h[:65536] + t[:65536], t[:65536] + h[:65536] + t[:30000],
+             h[3:4], t[:3000], h[1:1 + 131072 + 255]]
+    ref = oracle_lib.ZstdOracle(level=1)
+    frames, err, redo, nraw = emu_lib.zstd_frames(units, max_encoded_size=ref.max_encoded_size, fused=mode)
+    assert err == 0 and redo == 0
+    assert nraw >= 5  # the incompressible units took the fused copy
+    bad = [(i, len(u), len(f)) for i, (u, f) in enumerate(zip(units, frames)) if f != ref.encode_all(u)]
+    assert not bad, bad

@@ -108,7 +108,8 @@ int kcemu_xxh_fin(const uint8_t* src, const uint64_t* unit_off, uint32_t n, uint
 // use_grp the HBM-table group kernel in the form `tuned`), entropy stage — the frames as they sit in the staging slots (raw blocks'
 // payloads included: no rawdef), with the host's layout rules (seq_stride, lit_stride: kc_api.cpp batch_begin).
 int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, int block_size, int window, int crc, int single, int full_zero,
-                      int stream_mode, int use_grp, int tuned, int entropy_opts /* bit 0: no_entropy, bit 1: all_lit_entropy */, uint8_t* stage, const uint64_t* stage_off, uint32_t* out_size, uint32_t* err_out) {
+                      int stream_mode, int use_grp, int tuned, int entropy_opts /* bit 0: no_entropy, bit 1: all_lit_entropy */, uint8_t* stage, const uint64_t* stage_off, uint32_t* out_size, uint32_t* err_out,
+                      uint8_t* fused_dst /* or null */, uint64_t* fused_off, int fused_mode) {
     std::vector<uint32_t> blk0(n + 1, 0);
     for (uint32_t i = 0; i < n; i++) {
         const uint64_t len = unit_off[i + 1] - unit_off[i];
@@ -153,7 +154,32 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     E.predef = predef.data(); E.seq_stride = seq_stride; E.lit_stride = lit_stride; E.block_size = block_size; E.window_size = window;
     E.crc = crc; E.single = single; E.no_entropy = entropy_opts & 1; E.all_lit_entropy = (entropy_opts >> 1) & 1; E.full_zero = full_zero; E.stream_mode = stream_mode;
     E.err_flag = err;
+    std::vector<KcRawDef> rawdef;
+    std::vector<uint32_t> unit_raw;
+    if (fused_dst != nullptr) {  // the layout of kc_api.cpp batch_end: raw payloads deferred, checksum behind the entropy stage
+        rawdef.assign(nb + 1, KcRawDef{0, 0, 0, 0});
+        unit_raw.assign(n + 1, 0);
+        E.rawdef = rawdef.data();
+        E.unit_raw = unit_raw.data();
+        if (crc) E.xxh = nullptr;
+    }
     kc_launch_zstd_entropy(E, n, nullptr);
+    if (fused_dst != nullptr) {
+        kc_launch_scan_sizes(out_size, n, fused_off, nullptr);
+        if (crc) {
+            KcXxhFinParams X;
+            memset(&X, 0, sizeof(X));
+            X.src = src; X.unit_off = unit_off; X.n_units = n; X.stage = stage; X.stage_off = stage_off; X.out_size = out_size; X.out_off = fused_off;
+            X.dst = fused_dst; X.unit_raw = unit_raw.data(); X.rawdef = rawdef.data(); X.unit_blk0 = blk0.data(); X.xxh_out = xxh.data(); X.mode = fused_mode;
+            hipemu::set_group(4);
+            kc_launch_xxh64_fin(X, nullptr);
+            hipemu::set_group(64);
+        }
+        kc_launch_compact(stage, stage_off, out_size, fused_off, fused_dst, n, nullptr, src, unit_off, blk0.data(), rawdef.data(), crc ? unit_raw.data() : nullptr);
+        uint32_t nraw = 0;
+        for (uint32_t i = 0; i < n; i++) nraw += unit_raw[i];
+        err_out[2] = nraw;
+    }
     uint32_t anyredo = 0;
     for (uint32_t i = 0; i < n; i++) anyredo |= redo[i];
     err_out[0] = err[0];
