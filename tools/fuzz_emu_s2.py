@@ -1,0 +1,64 @@
+"""Fuzz of the S2 LDS-table kernel (kc_s2_lds.hip: s2.Encode / s2.EncodeSnappy, both byte-exact targets) ON THE WAVE EMULATOR against the
+oracle (no GPU), with the input generators of tools/fuzz_emu_pipeline.py; blocks up to 256 KiB (the 64 KiB class held in LDS and the
+larger one), every speculation width class, bare blocks and framed chunks.
+
+    python tools/fuzz_emu_s2.py --seconds 3600 --seed 1 [--out profiles/r03b_fuzz_emu_s2.txt]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
+import corpora  # noqa: E402
+import emu_lib  # noqa: E402
+import oracle_lib  # noqa: E402
+from fuzz_emu_pipeline import gen_unit  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=600)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    pool = [corpora.corpus(k, 2, 131072, first_unit=f).tobytes() for k, f in (("T", 21), ("J", 22), ("M", 23), ("J", 24))]
+    t0 = time.time()
+    nb = nbytes = nfail = batches = 0
+    fails = []
+    while time.time() - t0 < args.seconds:
+        blocks = [b for b in (gen_unit(rng, pool)[:int(rng.choice([300, 5000, 65536, 65537, 262144]))] for _ in range(int(rng.integers(4, 20)))) if b]
+        if not blocks:
+            continue
+        level = int(rng.choice([0, 2]))
+        variant = int(rng.integers(0, 2))
+        w0 = int(rng.choice([1, 8, 64]))
+        got = emu_lib.s2_encode_blocks(blocks, level=level, spec_w0=w0, variant=variant)
+        if variant == 1:
+            want = [oracle_lib.s2_encode_asm(b, snappy=level == 2) for b in blocks]
+        else:
+            want = [(oracle_lib.s2_encode_snappy if level == 2 else oracle_lib.s2_encode)(b) for b in blocks]
+        bad = [i for i in range(len(blocks)) if got[i] != want[i]]
+        batches += 1
+        nb += len(blocks)
+        nbytes += sum(map(len, blocks))
+        if bad:
+            nfail += 1
+            tag = "fuzz_s2_fail_seed%d_batch%d" % (args.seed, batches)
+            np.save("/tmp/%s.npy" % tag, np.array([np.frombuffer(b, dtype=np.uint8) for b in blocks], dtype=object), allow_pickle=True)
+            fails.append((tag, level, variant, w0, bad[:5], [len(blocks[i]) for i in bad[:5]]))
+            print("FAIL", fails[-1], flush=True)
+    line = "seed %d: %.0f s, %d batches, %d blocks, %.1f MB, %d failures %r" % (args.seed, time.time() - t0, batches, nb, nbytes / 1e6, nfail, fails)
+    print(line)
+    if args.out:
+        with open(args.out, "a") as f:
+            f.write(line + "\n")
+    return 1 if nfail else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
