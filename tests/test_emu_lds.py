@@ -323,3 +323,17 @@ def test_whole_pipeline_with_the_checksum_behind_the_entropy_stage(mode):
     assert nraw >= 5  # the incompressible units took the fused copy
     bad = [(i, len(u), len(f)) for i, (u, f) in enumerate(zip(units, frames)) if f != ref.encode_all(u)]
     assert not bad, bad
+
+
+def test_whole_pipeline_speed_best_compression():
+    """SpeedBestCompression end to end on the emulator: kc_zbest_cost_kernel (the bit costs from the predefined FSE tables),
+    kc_zbest_match_kernel on two persistent table slots, the entropy stage with allLitEntropy — the oracle's frames."""
+    t = corpora.corpus("T", 1, 131072, first_unit=3).tobytes()
+    m = corpora.corpus("M", 1, 131072, first_unit=2).tobytes()
+    units = [t[:50000], m[:30000], b"", b"a", b"abcabcabcabc" * 50, corpora.corpus("J", 1, 65536, first_unit=5).tobytes()[:20000],
+             corpora.corpus("H", 1, 8192).tobytes()[:5000], t[100000:131072] + t[:20000]]
+    ref = oracle_lib.ZstdOracle(level=4)
+    frames, err, redo = emu_lib.zstd_frames(units, level=4, max_encoded_size=ref.max_encoded_size)
+    assert err == 0 and redo == 0
+    bad = [(i, len(u), len(f)) for i, (u, f) in enumerate(zip(units, frames)) if f != ref.encode_all(u)]
+    assert not bad, bad

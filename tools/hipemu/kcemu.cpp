@@ -137,7 +137,15 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
         kc_launch_xxh64(src, unit_off, n, xxh.data(), nullptr);
         hipemu::set_group(64);
     }
-    if (use_grp) {
+    std::vector<uint64_t> btab;
+    if (use_grp == 4) {  // SpeedBestCompression: kc_zbest_match_kernel on two persistent table slots, the bit costs from the device's own kernel
+        btab.assign((size_t)2 * (kc_zbest_table_bytes() / 8), 0);
+        uint32_t cur[2] = {0, 0};
+        int32_t cost[96];
+        memset(cost, 0, sizeof(cost));
+        kc_launch_zbest_cost(predef.data(), cost, nullptr);
+        kc_launch_zbest_match(M, btab.data(), cur, cost, n, 2, nullptr);
+    } else if (use_grp) {
         tables.assign((size_t)((n + 7) / 8 * 8) << 15, 0);
         M.spec_w0 = 1; M.spec_grow = 1; M.tuned = tuned; M.empty_filter = 1;
         hipemu::set_group(8);
@@ -152,7 +160,7 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     E.src = src; E.unit_off = unit_off; E.unit_blk0 = blk0.data(); E.seqs = seqs.data(); E.meta = meta.data(); E.lits = lits.data(); E.aux = aux.data();
     E.stage = stage; E.stage_off = stage_off; E.out_size = out_size; E.xxh = xxh.data(); E.redo_mask = redo.data(); E.redo_blk = redo_blk.data();
     E.predef = predef.data(); E.seq_stride = seq_stride; E.lit_stride = lit_stride; E.block_size = block_size; E.window_size = window;
-    E.crc = crc; E.single = single; E.no_entropy = entropy_opts & 1; E.all_lit_entropy = (entropy_opts >> 1) & 1; E.full_zero = full_zero; E.stream_mode = stream_mode;
+    E.crc = crc; E.single = single; E.no_entropy = entropy_opts & 1; E.all_lit_entropy = ((entropy_opts >> 1) & 1) | (use_grp == 4 ? 1 : 0) /* allLitEntropy: levels above SpeedDefault */; E.full_zero = full_zero; E.stream_mode = stream_mode;
     E.err_flag = err;
     std::vector<KcRawDef> rawdef;
     std::vector<uint32_t> unit_raw;
