@@ -16,6 +16,7 @@
 // skipBeginning = 3 (non-dict) or 0 (dict), maxMatchLength caps, offset-2 loop, canRepeat snapshot.
 #include "kc_dev.h"
 #include "kc_kernels.h"
+#include "kc_wave.h"
 
 #define ZB_LONG_BITS 19
 #define ZB_SHORT_BITS 13
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                 }
                 if (act && !laterL) C.wrL(h0, myE, prevE);
                 if (act && !laterS) C.wrS(h1, C.mk(idx + 1, (uint32_t)(cv0 >> 8)));
+                KC_EMU_SYNC();
             }
         };
 
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                 bool brk = false;
                 for (;;) {  // search loop: speculative probe rounds with ordered commit (as in the other match finders)
                     rounds++;
+                    KC_EMU_SYNC();
                     // While no match is found the probe positions are a pure function of (s, nextEmit): s += 1 + ((s-nextEmit)>>8).
                     // The lanes probe the next W of them against the pre-round tables; a lane whose long or short bucket was
                     // touched by a lower lane ends the round; lanes up to the first hit commit their table writes (the reference
@@ -312,6 +315,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                             const uint64_t cv2 = ld64(base + s + 1);
                             const uint32_t nh2 = hL(cv2);
                             const uint2 c2 = C.rdL(nh2);
+                            KC_EMU_SYNC();
                             if (lig == 0) C.wrL(nh2, C.mk(s + 1, (uint32_t)cv2), c2.x);
                             // s-coffsetL < maxMatchOff is evaluated with s (not s+1) in the reference
                             bool taken = false;
@@ -342,6 +346,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     const uint32_t nh = hL(ld64(base + s + matched));
                     const int s2 = s + skipBeginning;
                     const uint32_t cv4 = ld32(base + s2);
+                    KC_EMU_SYNC();
                     const uint2 cE = C.rdL(nh);
                     {
                         const int co = C.posOf(cE.x) - matched + skipBeginning;
@@ -397,10 +402,8 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                 }
             }
         }
-        if (lig < (nseq & (G - 1))) {  // the buffered tail of the sequence list
-            __builtin_amdgcn_wave_barrier();
-            sq[(nseq & ~(G - 1)) + lig] = sbuf[lig];
-        }
+        __builtin_amdgcn_wave_barrier();
+        if (lig < (nseq & (G - 1))) sq[(nseq & ~(G - 1)) + lig] = sbuf[lig];  // the buffered tail of the sequence list
         int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
         int nlit = sumLL + extra;
         if (rleBlock) { extra = 0; nlit = 1; }  // literals = src[0]; recentOffsets untouched (early return, :114)

@@ -14,6 +14,7 @@
 // (enc_dfast.go:630).
 #include "kc_dev.h"
 #include "kc_kernels.h"
+#include "kc_wave.h"
 
 #define ZD_LONG_BITS 17
 #define ZD_SHORT_BITS 15
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
             int W = G;
             while (!fin) {
                 rounds++;
+                KC_EMU_SYNC();  // (lane 0's table stores behind the previous match precede this round's lookups)
                 const int d0 = s - nextEmit;
                 const int k0 = d0 >> 7;  // kSearchStrength-1 == 7
                 const int step = 1 + k0;
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
                     const uint64_t cvn = ld64(base + s + 1);
                     const uint32_t hn = hL(cvn);
                     const uint32_t cn = ltab[hn];
+                    KC_EMU_SYNC();
                     if (lig == 0) ltab[hn] = mk(s + 1, (uint32_t)cvn);
                     const uint32_t en = cn & posMask;
                     const int tn = (int)en - 1;
@@ -238,10 +241,8 @@ __global__ __launch_bounds__(64) void kc_zdfast_match_grp_kernel(KcMatchParams P
                 }
             }
         }
-        if (lig < (nseq & (G - 1))) {  // the buffered tail of the sequence list
-            __builtin_amdgcn_wave_barrier();
-            sq[(nseq & ~(G - 1)) + lig] = sbuf[lig];
-        }
+        __builtin_amdgcn_wave_barrier();
+        if (lig < (nseq & (G - 1))) sq[(nseq & ~(G - 1)) + lig] = sbuf[lig];  // the buffered tail of the sequence list
         const int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
         const int nlit = sumLL + extra;
         const bool rle = nseq == 1 && nlit <= 1 && (int)firstLL == nlit && firstOf - 3u == 1u;

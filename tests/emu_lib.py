@@ -276,9 +276,8 @@ def zstd_frames(units, block_size=None, window=None, crc=True, single=-1, full_z
                 max_encoded_size=None, level=1, no_entropy=False, all_lit_entropy=False, fused=None):
     """The device's whole SpeedFastest EncodeAll pipeline on the emulator (checksum, match finder, entropy stage): one frame per unit.
     Returns (list of frames, error flag, re-run flag)."""
-    assert level in (1, 4), "the SpeedDefault / SpeedBetterCompression match finders are not on the emulator"
-    if level == 4:
-        use_grp = 4  # (selects kc_zbest_match_kernel in kcemu_zstd_frames)
+    if level != 1:
+        use_grp = level  # (selects the level's match finder in kcemu_zstd_frames)
     if window is None:
         window = (4 << 20) if level == 1 else (8 << 20)  # encoder_options.go:254-266
     if block_size is None:

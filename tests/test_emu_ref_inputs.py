@@ -19,10 +19,11 @@ def _zip_inputs(name, every, max_len):
     return [(name + ":" + n, z.read(n)) for n in names[::every] if z.getinfo(n).file_size <= max_len]
 
 
-def _check(named, finder="lds"):
-    ref = oracle_lib.ZstdOracle(level=1)
+def _check(named, finder="lds", level=1):
+    ref = oracle_lib.ZstdOracle(level=level)
     units = [d for _, d in named]
-    frames, err, redo = emu_lib.zstd_frames(units, use_grp=finder != "lds", tuned=int(finder == "grp-tuned"), max_encoded_size=ref.max_encoded_size)
+    frames, err, redo = emu_lib.zstd_frames(units, use_grp=finder != "lds", tuned=int(finder == "grp-tuned"), max_encoded_size=ref.max_encoded_size,
+                                            level=level)
     assert err == 0
     # a unit that asks for the speculation re-run is the host's business (tests/test_redo_path.py): none of these may
     assert redo == 0
@@ -50,3 +51,13 @@ def test_reference_fuzz_and_regression_corpora_on_the_emulator():
     named = _zip_inputs("encode-corpus-raw.zip", 9, 200000) + _zip_inputs("comp-crashers.zip", 9, 200000)
     assert _check(named) > 300
     assert _check(named[::4], finder="grp-tuned") > 80
+
+
+def test_reference_inputs_at_the_other_levels_on_the_emulator():
+    """SpeedDefault, SpeedBetterCompression and SpeedBestCompression on the reference's files and a slice of its corpora."""
+    plain = [(n, open(os.path.join(REFIN, n), "rb").read()) for n in PLAIN]
+    plain = [(n, d) for n, d in plain if len(d) <= 160 << 10]
+    corp = _zip_inputs("encode-corpus-raw.zip", 23, 100000) + _zip_inputs("comp-crashers.zip", 23, 100000)
+    for level in (2, 3):
+        assert _check(plain + corp, level=level) > 100
+    assert _check(plain[:2] + corp[::6], level=4) > 20

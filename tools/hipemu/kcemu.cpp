@@ -6,6 +6,8 @@
 #include "../../compress_amd/csrc/kc_zstd_match.hip"
 #include "../../compress_amd/csrc/kc_misc.hip"
 #include "../../compress_amd/csrc/kc_zstd_entropy.hip"
+#include "../../compress_amd/csrc/kc_zstd_match_dfast.hip"
+#include "../../compress_amd/csrc/kc_zstd_match_better.hip"
 #include <vector>
 #include "../../compress_amd/csrc/kc_s2_best.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_best.hip"
@@ -105,7 +107,8 @@ int kcemu_xxh_fin(const uint8_t* src, const uint64_t* unit_off, uint32_t n, uint
 }
 
 // The whole SpeedFastest EncodeAll pipeline of the device on the emulator: checksum kernel, match finder (LDS-table kernel, or with
-// use_grp the HBM-table group kernel in the form `tuned`), entropy stage — the frames as they sit in the staging slots (raw blocks'
+// use_grp = 1 the HBM-table group kernel in the form `tuned`; use_grp = 2 / 3 / 4: the SpeedDefault / SpeedBetterCompression /
+// SpeedBestCompression match finders), entropy stage — the frames as they sit in the staging slots (raw blocks'
 // payloads included: no rawdef), with the host's layout rules (seq_stride, lit_stride: kc_api.cpp batch_begin).
 int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, int block_size, int window, int crc, int single, int full_zero,
                       int stream_mode, int use_grp, int tuned, int entropy_opts /* bit 0: no_entropy, bit 1: all_lit_entropy */, uint8_t* stage, const uint64_t* stage_off, uint32_t* out_size, uint32_t* err_out,
@@ -145,6 +148,18 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
         memset(cost, 0, sizeof(cost));
         kc_launch_zbest_cost(predef.data(), cost, nullptr);
         kc_launch_zbest_match(M, btab.data(), cur, cost, n, 2, nullptr);
+    } else if (use_grp == 2) {  // SpeedDefault: kc_zdfast_match_grp_kernel, 8 lanes per unit
+        tables.assign((size_t)((n + 7) / 8 * 8) * (kc_zdfast_table_bytes() / 4), 0);
+        M.spec_w0 = 2; M.spec_grow = 2;
+        hipemu::set_group(8);
+        kc_launch_zdfast_match_grp(M, tables.data(), n, nullptr);
+        hipemu::set_group(64);
+    } else if (use_grp == 3) {  // SpeedBetterCompression: kc_zbetter_match_grp_kernel, 16 lanes per unit, tables cleared (no stamps)
+        tables.assign((size_t)((n + 3) / 4 * 4) * (kc_zbetter_table_bytes() / 4), 0);
+        M.spec_w0 = 16; M.spec_grow = 0;
+        hipemu::set_group(16);
+        kc_launch_zbetter_match_grp(M, (uint8_t*)tables.data(), n, false, nullptr);
+        hipemu::set_group(64);
     } else if (use_grp) {
         tables.assign((size_t)((n + 7) / 8 * 8) << 15, 0);
         M.spec_w0 = 1; M.spec_grow = 1; M.tuned = tuned; M.empty_filter = 1;
@@ -160,7 +175,7 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     E.src = src; E.unit_off = unit_off; E.unit_blk0 = blk0.data(); E.seqs = seqs.data(); E.meta = meta.data(); E.lits = lits.data(); E.aux = aux.data();
     E.stage = stage; E.stage_off = stage_off; E.out_size = out_size; E.xxh = xxh.data(); E.redo_mask = redo.data(); E.redo_blk = redo_blk.data();
     E.predef = predef.data(); E.seq_stride = seq_stride; E.lit_stride = lit_stride; E.block_size = block_size; E.window_size = window;
-    E.crc = crc; E.single = single; E.no_entropy = entropy_opts & 1; E.all_lit_entropy = ((entropy_opts >> 1) & 1) | (use_grp == 4 ? 1 : 0) /* allLitEntropy: levels above SpeedDefault */; E.full_zero = full_zero; E.stream_mode = stream_mode;
+    E.crc = crc; E.single = single; E.no_entropy = entropy_opts & 1; E.all_lit_entropy = ((entropy_opts >> 1) & 1) | (use_grp >= 3 && use_grp <= 4 ? 1 : 0) /* allLitEntropy: levels above SpeedDefault */; E.full_zero = full_zero; E.stream_mode = stream_mode;
     E.err_flag = err;
     std::vector<KcRawDef> rawdef;
     std::vector<uint32_t> unit_raw;
