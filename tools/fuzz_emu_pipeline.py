@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=600)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--level", type=int, default=1, choices=[1, 2, 3, 4], help="zstd level (1: also both kernel families and the fused checksum path)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     pool = [corpora.corpus(k, 2, 131072, first_unit=f).tobytes() for k, f in (("T", 11), ("J", 12), ("M", 13), ("M", 14))]
@@ -84,20 +85,23 @@ def main():
         if rng.integers(0, 4) == 0:
             w = 1 << int(rng.integers(10, 17))
             okw["window_size"] = w
-            ekw["window"], ekw["block_size"] = w, min(w, 65536)
+            ekw["window"], ekw["block_size"] = w, min(w, 65536 if args.level == 1 else 131072)
         if rng.integers(0, 5) == 0:
             okw["full_zero"] = ekw["full_zero"] = False
         if rng.integers(0, 6) == 0:
             okw["no_entropy"] = ekw["no_entropy"] = True
-        if rng.integers(0, 6) == 0:
+        if rng.integers(0, 6) == 0 and args.level <= 2:  # (on by default above SpeedDefault)
             okw["all_lit_entropy"] = ekw["all_lit_entropy"] = True
         stream = rng.integers(0, 4) == 0
         finder = ["lds", "grp", "grp-tuned"][int(rng.integers(0, 3))]
         fused = None if (stream or rng.integers(0, 2) == 0) else int(rng.integers(0, 3))
-        ref = oracle_lib.ZstdOracle(level=1, **okw)
+        if args.level != 1:
+            finder = "lds"  # (ignored: the level's own match finder runs)
+            units = [u[:120000] for u in units[:10]] if args.level == 4 else units
+        ref = oracle_lib.ZstdOracle(level=args.level, **okw)
         mes = (lambda n: ref.max_encoded_size(n) + 8)
         res = emu_lib.zstd_frames(units, use_grp=finder != "lds", tuned=int(finder == "grp-tuned"), stream_mode=int(stream), fused=fused,
-                                  max_encoded_size=mes, **ekw)
+                                  max_encoded_size=mes, level=args.level, **ekw)
         frames, err, redo = res[0], res[1], res[2]
         stats["batches"] += 1
         stats["units"] += len(units)
@@ -115,8 +119,8 @@ def main():
             np.save("/tmp/%s.npy" % tag, np.array([np.frombuffer(u, dtype=np.uint8) for u in units], dtype=object), allow_pickle=True)
             fails.append((tag, err, bad[:5], okw, finder, stream, fused, [len(units[i]) for i in bad[:5]]))
             print("FAIL", fails[-1], flush=True)
-    line = "seed %d: %.0f s, %d batches, %d units, %.1f MB, %d batches skipped for a re-run request, %d raw-only frames through the fused copy, %d failures %r" % (
-        args.seed, time.time() - t0, stats["batches"], stats["units"], stats["bytes"] / 1e6, stats["redo_units"], stats["raw_fused"], stats["failures"], fails)
+    line = "level %d, seed %d: %.0f s, %d batches, %d units, %.1f MB, %d batches skipped for a re-run request, %d raw-only frames through the fused copy, %d failures %r" % (
+        args.level, args.seed, time.time() - t0, stats["batches"], stats["units"], stats["bytes"] / 1e6, stats["redo_units"], stats["raw_fused"], stats["failures"], fails)
     print(line)
     if args.out:
         with open(args.out, "a") as f:
