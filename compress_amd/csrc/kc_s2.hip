@@ -22,6 +22,7 @@
 #include "kc_dev.h"
 #include "kc_kernels.h"
 #include "kc_s2_dev.h"
+#include "kc_wave.h"
 
 #define S2G 8
 
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         bool fin = false;   // goto emitRemainder
         int W = G;  // speculation width: every speculative probe step costs three table lines from HBM, and matches come every few steps
         while (!fin && !stored) {
+            KC_EMU_SYNC();  // (lane 0's table stores behind a match precede the next round's lookups)
             // ---------------- speculative probe round ----------------
             const int d0 = s - nextEmit;
             const int k0 = d0 >> SKIP;
@@ -385,6 +387,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 const uint64_t x = ld64(src + s - 2);
                 const uint32_t m2Hash = hashOf(x), currHash = hashOf(x >> 16);
                 const uint32_t ec = tab[currHash];
+                KC_EMU_SYNC();
                 if (lig == 0) { tab[m2Hash] = mk(s - 2, (uint32_t)x); tab[currHash] = mk(s, (uint32_t)(x >> 16)); }
                 // make the writes visible to the group's next reads of these buckets (same wave: program order)
                 candidate = (int)(ec & posMask);
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         bool fin = false;
         int W = G;
         while (!fin && !stored) {
+            KC_EMU_SYNC();  // (lane 0's table stores behind a match precede the next round's lookups)
             const int d0 = s - nextEmit;
             const int k0 = d0 >> SKIP;
             const int step = skipOf(d0);
@@ -525,6 +529,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 const uint64_t cv1 = s2g_bcast64(cv, grp, f) >> 8;
                 const uint32_t hn = hL(cv1);
                 const uint32_t en = ltab[hn];
+                KC_EMU_SYNC();
                 if (lig == 0) ltab[hn] = mk(s + 1, (uint32_t)cv1);
                 const int cn = (int)(en & posMask);
                 const bool okn = en == 0 || (en >> PB) == tagOf((uint32_t)cv1);
@@ -606,6 +611,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         __builtin_amdgcn_wave_barrier();
         st64(slot + flushedQ + 8 * lig, *(const uint64_t*)(oring + ((flushedQ + 8 * lig) & (ORING - 1))));
     }
+    KC_EMU_SYNC();  // (an abandoned attempt's stores, lane 0's among them, precede the stored form's: program order on the hardware)
     if (!P.framed) {
         if (stored) d = s2_emit_literal<S2G>(dst, src, len, lig);  // encode.go:44-55: not compressible -> one literal
         if (lig == 0) P.out_size[bi] = (uint32_t)(hdr + d);

@@ -174,7 +174,9 @@ static inline int encodeBlockAsm(uint8_t* dst, const uint8_t* src, size_t n, boo
 
 // genEncodeBetterBlockAsm(name, lTableBits LB, sTableBits SB, skipLog SKIP, lHashBytes LHB, maxLen) (gen.go:873-1655), o.maxSkip
 // MAXSKIP (0: none), output margin OM (6; 9 for the Snappy-compatible forms), BIGOFF: maxLen - 1 > 65535
-template <int LB, int SB, int SKIP, int LHB, int LITOVH, int MAXSKIP, int OM, bool BIGOFF, bool SNAPPY>
+// SMALLREP: maxLen below 2048 (only encodeBetterBlockAsm8B, blocks below 512 bytes): the inlined emitRepeat has no two-byte offset form
+// (gen.go:1991-1994, as in encodeBlockAsm8B) — found by tools/fuzz_emu_s2.py: the device kernel and the assembly agreed, this file did not.
+template <int LB, int SB, int SKIP, int LHB, int LITOVH, int MAXSKIP, int OM, bool BIGOFF, bool SNAPPY, bool SMALLREP = false>
 static int encodeBetterBlockAsmT(uint8_t* dst, const uint8_t* src, size_t srcLen) {
     std::vector<uint32_t> lTable((size_t)1 << LB, 0u), sTable((size_t)1 << SB, 0u);
     const int len = (int)srcLen;
@@ -246,7 +248,7 @@ static int encodeBetterBlockAsmT(uint8_t* dst, const uint8_t* src, size_t srcLen
             s += length;
             length += 4;
             nextEmit = s;
-            d += emitRepeat(dst + d, offset, length);
+            d += SMALLREP ? emitRepeatAsmSmall(dst + d, offset, length) : emitRepeat(dst + d, offset, length);
         } else {
             if (BIGOFF && length <= 1 && offset > 65535) {  // equal or worse than the encoding (:1369-1379)
                 s = nextS + 1;
@@ -295,7 +297,7 @@ static inline int encodeBlockBetterAsm(uint8_t* dst, const uint8_t* src, size_t 
         if (n >= limit10B) return encodeBetterBlockAsmT<14, 12, 6, 6, 3, 0, 6, false, false>(dst, src, n);            // ...12B
         if (n >= limit8B) return encodeBetterBlockAsmT<12, 10, 5, 6, 3, 0, 6, false, false>(dst, src, n);             // ...10B
         if (n < (size_t)minNonLiteralBlockSize) return 0;
-        return encodeBetterBlockAsmT<10, 8, 4, 6, 3, 0, 6, false, false>(dst, src, n);                                // ...8B
+        return encodeBetterBlockAsmT<10, 8, 4, 6, 3, 0, 6, false, false, true>(dst, src, n);                          // ...8B
     }
     if (n > 65536) return encodeBetterBlockAsmT<17, 14, 7, 7, 5, 100, 9, true, true>(dst, src, n);                    // encodeSnappyBetterBlockAsm
     if (n >= limit12B) return encodeBetterBlockAsmT<16, 13, 7, 7, 3, 0, 9, false, true>(dst, src, n);                 // ...64K

@@ -11,6 +11,13 @@ def corpus(kind, n_units, unit_size, first_unit=0, seed=None):
     return _lib.corpus_fill(kind, seed, first_unit, n_units, unit_size)
 
 
+def small_alphabet_blocks(k, n, ln):
+    """n blocks of ln random bytes over k symbols (one seeded stream per (k, ln)): short matches at short offsets.  Returns (uint8 buffer,
+    block offsets)."""
+    rng = np.random.default_rng(0xA1FA0000 + k * 65536 + ln)
+    return rng.integers(0, k, n * ln, dtype=np.uint8), np.arange(n + 1, dtype=np.uint64) * ln
+
+
 def edge_units():
     """Small and pathological units: empty, tiny, RLE, periodic, noise+repeat, boundary sizes."""
     rng = np.random.default_rng(1234)

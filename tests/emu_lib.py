@@ -69,6 +69,28 @@ def s2_encode_blocks(blocks, level=0, framed=False, spec_w0=8, variant=0):
     return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)]
 
 
+def s2_encode_blocks_hbm(blocks, level=0, framed=False, variant=0, w0=2, w0b=4, grow=1):
+    """kc_s2_encode_kernel<level> (HBM tables, 8 lanes per block) over `blocks`: level 0 s2.Encode, 1 EncodeBetter, 2 EncodeSnappy,
+    3 EncodeSnappyBetter; variant 1: the amd64 assembly bytes; w0 / w0b / grow: the speculation policy (the library's defaults)."""
+    n = len(blocks)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    for i, b in enumerate(blocks):
+        off[i + 1] = off[i] + len(b)
+    src = np.frombuffer(b"".join(blocks) + b"\0" * 64, dtype=np.uint8).copy()
+    soff = np.zeros(n + 1, dtype=np.uint64)
+    for i, b in enumerate(blocks):
+        soff[i + 1] = soff[i] + ((s2_max_encoded_len(len(b)) + 8 + 63) & ~63)
+    stage = np.zeros(int(soff[n]) + 64, dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.uint32)
+    L = lib()
+    L.kcemu_s2_hbm.restype = C.c_int
+    L.kcemu_s2_hbm.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    r = L.kcemu_s2_hbm(level | (variant << 8), int(framed), w0, w0b, grow, src.ctypes.data, off.ctypes.data, n, stage.ctypes.data, soff.ctypes.data,
+                       sizes.ctypes.data)
+    assert r == 0
+    return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)]
+
+
 def zfast_parse(units, block_size=65536, window=4 << 20, spec_w0=8, stream_mode=0):
     """kc_zfast_match_lds_kernel over `units` (list of bytes).  Returns, per block in unit order, (seqs [n,3] u32 as
     (litLen, matchLen-3, offset code), nlit, extra_lits, flags)."""

@@ -352,3 +352,38 @@ def test_whole_pipeline_speed_best_compression():
     assert err == 0 and redo == 0
     bad = [(i, len(u), len(f)) for i, (u, f) in enumerate(zip(units, frames)) if f != ref.encode_all(u)]
     assert not bad, bad
+
+
+_S2_REF = {0: "s2_encode", 1: "s2_encode_better", 2: "s2_encode_snappy", 3: "s2_encode_snappy_better"}
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
+def test_s2_hbm_kernel_blocks_bit_exact(level):
+    """kc_s2_encode_kernel<level> — the HBM-table throughput kernel of BASELINE configuration C4, 8 blocks per wave — on the emulator:
+    s2.Encode, s2.EncodeBetter, s2.EncodeSnappy, s2.EncodeSnappyBetter blocks against the oracle, at two speculation policies."""
+    blocks = _s2_blocks()
+    ref = getattr(oracle_lib, _S2_REF[level])
+    _cmp(blocks, emu_lib.s2_encode_blocks_hbm(blocks, level=level), ref)
+    _cmp(blocks[:10], emu_lib.s2_encode_blocks_hbm(blocks[:10], level=level, w0=8, w0b=8, grow=0), ref)
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
+def test_s2_hbm_kernel_amd64_variant(level):
+    """The same kernel writing the bytes of the reference's amd64 assembly encoders (KC_S2_VARIANT_AMD64), against the oracle's
+    restatement of them (pinned to the assembly itself by tests/test_ref_s2asm.py); every size class of encode_amd64.go."""
+    blocks = [b for b in _s2_blocks() if len(b) > 0]
+    t = corpora.corpus("T", 1, 65536, first_unit=4).tobytes()
+    blocks += [t[:n] for n in (100, 511, 512, 4095, 4096, 16383, 16384, 65535)]
+    got = emu_lib.s2_encode_blocks_hbm(blocks, level=level, variant=1)
+    bad = [(i, len(b)) for i, b in enumerate(blocks) if got[i] != oracle_lib.s2_encode_asm(b, snappy=level in (2, 3), better=level in (1, 3))]
+    assert not bad, bad[:8]
+
+
+def test_s2_hbm_kernel_framed_chunks():
+    """s2.Writer chunks (type, length, masked CRC32C, body) from the HBM-table kernel."""
+    blocks = [b for b in _s2_blocks() if len(b) > 0]
+    buf, off = corpora.pack_units(blocks)
+    ref, ro = oracle_lib.s2_encode_stream(buf, off, with_stream_id=False)
+    got = emu_lib.s2_encode_blocks_hbm(blocks, level=0, framed=True)
+    for i in range(len(blocks)):
+        assert ref[int(ro[i]):int(ro[i + 1])].tobytes() == got[i], "chunk %d (len %d)" % (i, len(blocks[i]))

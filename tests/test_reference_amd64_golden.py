@@ -26,6 +26,8 @@ def _lines():
 
 
 def _blocks(kind, n, ln):
+    if kind[0] == "A":  # random bytes over 2 / 4 / 8 symbols (tools/write_asm_golden.py)
+        return corpora.small_alphabet_blocks(int(kind[1:]), n, ln)
     buf = corpora.corpus(kind, (n * ln + 131071) // 131072, 131072, first_unit=11)
     return buf[:n * ln], np.arange(n + 1, dtype=np.uint64) * ln
 
@@ -68,3 +70,28 @@ def test_device_matches_the_reference_hashes(oracle, kclib):
         assert hashlib.sha256(out[:int(oo[n])].tobytes()).hexdigest() == want, name
     for e in encs.values():
         e.Close()
+
+
+def test_device_kernels_on_the_emulator_match_the_reference_hashes():
+    """No GPU, no reference: the DEVICE kernels (compiled for the wave emulator) must hash to what the reference's assembly wrote —
+    the HBM-table kernel at the four levels and the LDS-table kernel at s2.Encode / s2.EncodeSnappy, on the small-alphabet blocks of
+    every size class and on the short shapes of the corpora."""
+    import emu_lib
+    checked = 0
+    for name, want in sorted(_lines().items()):
+        p = name.split(".")
+        if p[0] == "xxh64":
+            continue
+        n, ln = (int(x) for x in p[3].split("x"))
+        if n * ln > 100000 or (p[2][0] != "A" and ln > 2000):
+            continue  # (emulation time: the long shapes stay with the GPU test)
+        buf, off = _blocks(p[2], n, ln)
+        blocks = [buf[int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
+        lvl = LEVEL[p[0]]
+        got = emu_lib.s2_encode_blocks_hbm(blocks, level=lvl, variant=1)
+        assert hashlib.sha256(b"".join(got)).hexdigest() == want, ("HBM-table kernel", name)
+        if lvl in (0, 2):
+            got = emu_lib.s2_encode_blocks(blocks, level=lvl, variant=1, spec_w0=1 if ln <= 65536 else 8)
+            assert hashlib.sha256(b"".join(got)).hexdigest() == want, ("LDS-table kernel", name)
+        checked += 1
+    assert checked >= 60

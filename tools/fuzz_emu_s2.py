@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=600)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--kernel", default="lds", choices=["lds", "hbm"], help="kc_s2_lds.hip (levels 0, 2) or kc_s2.hip (the throughput kernel: levels 0-3)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     pool = [corpora.corpus(k, 2, 131072, first_unit=f).tobytes() for k, f in (("T", 21), ("J", 22), ("M", 23), ("J", 24))]
@@ -34,14 +35,19 @@ def main():
         blocks = [b for b in (gen_unit(rng, pool)[:int(rng.choice([300, 5000, 65536, 65537, 262144]))] for _ in range(int(rng.integers(4, 20)))) if b]
         if not blocks:
             continue
-        level = int(rng.choice([0, 2]))
         variant = int(rng.integers(0, 2))
-        w0 = int(rng.choice([1, 8, 64]))
-        got = emu_lib.s2_encode_blocks(blocks, level=level, spec_w0=w0, variant=variant)
-        if variant == 1:
-            want = [oracle_lib.s2_encode_asm(b, snappy=level == 2) for b in blocks]
+        if args.kernel == "hbm":  # kc_s2_encode_kernel<level>: all four levels, three speculation policies
+            level = int(rng.integers(0, 4))
+            w0, w0b, grow = [(2, 4, 1), (8, 8, 0), (1, 1, 2)][int(rng.integers(0, 3))]
+            got = emu_lib.s2_encode_blocks_hbm(blocks, level=level, variant=variant, w0=w0, w0b=w0b, grow=grow)
         else:
-            want = [(oracle_lib.s2_encode_snappy if level == 2 else oracle_lib.s2_encode)(b) for b in blocks]
+            level = int(rng.choice([0, 2]))
+            w0 = int(rng.choice([1, 8, 64]))
+            got = emu_lib.s2_encode_blocks(blocks, level=level, spec_w0=w0, variant=variant)
+        if variant == 1:
+            want = [oracle_lib.s2_encode_asm(b, snappy=level in (2, 3), better=level in (1, 3)) for b in blocks]
+        else:
+            want = [getattr(oracle_lib, {0: "s2_encode", 1: "s2_encode_better", 2: "s2_encode_snappy", 3: "s2_encode_snappy_better"}[level])(b) for b in blocks]
         bad = [i for i in range(len(blocks)) if got[i] != want[i]]
         batches += 1
         nb += len(blocks)
@@ -52,7 +58,7 @@ def main():
             np.save("/tmp/%s.npy" % tag, np.array([np.frombuffer(b, dtype=np.uint8) for b in blocks], dtype=object), allow_pickle=True)
             fails.append((tag, level, variant, w0, bad[:5], [len(blocks[i]) for i in bad[:5]]))
             print("FAIL", fails[-1], flush=True)
-    line = "seed %d: %.0f s, %d batches, %d blocks, %.1f MB, %d failures %r" % (args.seed, time.time() - t0, batches, nb, nbytes / 1e6, nfail, fails)
+    line = "kernel " + args.kernel + ", seed %d: %.0f s, %d batches, %d blocks, %.1f MB, %d failures %r" % (args.seed, time.time() - t0, batches, nb, nbytes / 1e6, nfail, fails)
     print(line)
     if args.out:
         with open(args.out, "a") as f:

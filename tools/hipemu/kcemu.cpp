@@ -2,6 +2,7 @@
 // tests (tests/test_emu_lds.py).  TEST INFRASTRUCTURE: the product (libkcgpu.so) never contains or loads this.
 #include <hip/hip_runtime.h>
 #include "../../compress_amd/csrc/kc_s2_lds.hip"
+#include "../../compress_amd/csrc/kc_s2.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_lds.hip"
 #include "../../compress_amd/csrc/kc_zstd_match.hip"
 #include "../../compress_amd/csrc/kc_misc.hip"
@@ -32,6 +33,25 @@ int kcemu_s2_encode(int level, int framed, int spec_w0, const uint8_t* src, cons
     bool small = false, big = false;
     for (uint32_t i = 0; i < n; i++) ((blk_off[i + 1] - blk_off[i]) <= 65536 ? small : big) = true;
     kc_launch_s2_encode_lds(P, small, big, nullptr);
+    return 0;
+}
+
+// N blocks through kc_s2_encode_kernel<LEVEL> (the HBM-table throughput kernel, 8 lanes per block: s2.Encode / EncodeBetter / EncodeSnappy /
+// EncodeSnappyBetter; level bits 8+: KC_S2_VARIANT_*), tables as the host sizes and zeroes them
+int kcemu_s2_hbm(int level, int framed, int w0, int w0b, int grow, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* stage,
+                 const uint64_t* stage_off, uint32_t* out_size) {
+    KcS2Params P;
+    memset(&P, 0, sizeof(P));
+    P.src = src; P.blk_off = blk_off; P.stage_off = stage_off; P.stage = stage; P.out_size = out_size; P.n_blocks = n;
+    P.level = level & 0xFF; P.variant = level >> 8; P.spec_w0 = w0; P.spec_w0b = w0b; P.spec_grow = grow; P.framed = framed;
+    uint64_t mx = 0;
+    for (uint32_t i = 0; i < n; i++) mx = std::max<uint64_t>(mx, blk_off[i + 1] - blk_off[i]);
+    const size_t tb = kc_s2_table_bytes(P.level, mx, P.variant);
+    std::vector<uint32_t> tab((size_t)((n + 7) / 8 * 8) * (tb / 4), 0);
+    P.tables = tab.data(); P.table_stride = (uint32_t)(tb / 4);
+    hipemu::set_group(8);  // 8 blocks per wave, the groups diverge freely
+    kc_launch_s2_encode(P, nullptr);
+    hipemu::set_group(64);
     return 0;
 }
 

@@ -19,7 +19,15 @@ NAMES = {0: "s2", 1: "s2better", 2: "s2snappy", 3: "s2snappybetter"}
 SHAPES = [(64, 65536), (48, 300), (48, 2000), (48, 9000), (32, 40000), (8, 1 << 20), (2, 4 << 20), (1, (4 << 20) - 1)]
 
 
+# "A<k>": random bytes over k symbols — short matches at short offsets, i.e. every form of emitRepeat / emitCopy in every size class
+# (added in round 3 after tools/fuzz_emu_s2.py found the oracle's restatement of encodeBetterBlockAsm8B using a repeat form the assembly
+# does not have below 512 bytes: none of the corpora above produced a 9..11-byte repeat there)
+ASHAPES = [(64, 100), (64, 300), (64, 511), (32, 2000), (16, 9000), (8, 40000)]
+
+
 def blocks_of(kind, n, ln):
+    if kind[0] == "A":
+        return corpora.small_alphabet_blocks(int(kind[1:]), n, ln)
     buf = corpora.corpus(kind, (n * ln + 131071) // 131072, 131072, first_unit=11)
     return buf[:n * ln], np.arange(n + 1, dtype=np.uint64) * ln
 
@@ -28,6 +36,12 @@ def main():
     out = []
     for kind in "JTMH":
         for n, ln in SHAPES:
+            buf, off = blocks_of(kind, n, ln)
+            for level in range(4):
+                enc, _ = oracle_ref.encode_blocks(buf, off, level=level, threads=8)
+                out.append("%s.amd64.%s.%dx%d %s" % (NAMES[level], kind, n, ln, hashlib.sha256(enc.tobytes()).hexdigest()))
+    for kind in ("A2", "A4", "A8"):
+        for n, ln in ASHAPES:
             buf, off = blocks_of(kind, n, ln)
             for level in range(4):
                 enc, _ = oracle_ref.encode_blocks(buf, off, level=level, threads=8)
