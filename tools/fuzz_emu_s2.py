@@ -18,6 +18,12 @@ import emu_lib  # noqa: E402
 import oracle_lib  # noqa: E402
 from fuzz_emu_pipeline import gen_unit  # noqa: E402
 
+try:  # the reference's own assembly (oracle/_ref), where it has been built: the third voice for the amd64 variant
+    import oracle_ref
+    HAVE_REF = oracle_ref.available()
+except Exception:
+    HAVE_REF = False
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -29,7 +35,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     pool = [corpora.corpus(k, 2, 131072, first_unit=f).tobytes() for k, f in (("T", 21), ("J", 22), ("M", 23), ("J", 24))]
     t0 = time.time()
-    nb = nbytes = nfail = batches = 0
+    nb = nbytes = nfail = batches = nref = 0
     fails = []
     while time.time() - t0 < args.seconds:
         blocks = [b for b in (gen_unit(rng, pool)[:int(rng.choice([300, 5000, 65536, 65537, 262144]))] for _ in range(int(rng.integers(4, 20)))) if b]
@@ -49,6 +55,13 @@ def main():
         else:
             want = [getattr(oracle_lib, {0: "s2_encode", 1: "s2_encode_better", 2: "s2_encode_snappy", 3: "s2_encode_snappy_better"}[level])(b) for b in blocks]
         bad = [i for i in range(len(blocks)) if got[i] != want[i]]
+        if variant == 1 and HAVE_REF:  # oracle restatement vs the assembly itself (a slip of the restatement shows here even when the device agrees with it)
+            buf = np.frombuffer(b"".join(blocks), dtype=np.uint8)
+            off = np.zeros(len(blocks) + 1, dtype=np.uint64)
+            off[1:] = np.cumsum([len(b) for b in blocks])
+            enc, eo = oracle_ref.encode_blocks(buf, off, level=level, threads=1)
+            bad += [i for i in range(len(blocks)) if bytes(enc[int(eo[i]):int(eo[i + 1])]) != want[i] and i not in bad]
+            nref += len(blocks)
         batches += 1
         nb += len(blocks)
         nbytes += sum(map(len, blocks))
@@ -58,7 +71,7 @@ def main():
             np.save("/tmp/%s.npy" % tag, np.array([np.frombuffer(b, dtype=np.uint8) for b in blocks], dtype=object), allow_pickle=True)
             fails.append((tag, level, variant, w0, bad[:5], [len(blocks[i]) for i in bad[:5]]))
             print("FAIL", fails[-1], flush=True)
-    line = "kernel " + args.kernel + ", seed %d: %.0f s, %d batches, %d blocks, %.1f MB, %d failures %r" % (args.seed, time.time() - t0, batches, nb, nbytes / 1e6, nfail, fails)
+    line = "kernel " + args.kernel + ", seed %d: %.0f s, %d batches, %d blocks, %.1f MB, %d failures %r; %d blocks also against the reference's assembly" % (args.seed, time.time() - t0, batches, nb, nbytes / 1e6, nfail, fails, nref)
     print(line)
     if args.out:
         with open(args.out, "a") as f:
