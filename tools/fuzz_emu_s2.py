@@ -30,7 +30,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=600)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--kernel", default="lds", choices=["lds", "hbm"], help="kc_s2_lds.hip (levels 0, 2) or kc_s2.hip (the throughput kernel: levels 0-3)")
+    ap.add_argument("--kernel", default="lds", choices=["lds", "hbm", "best"],
+                    help="kc_s2_lds.hip (levels 0, 2), kc_s2.hip (the throughput kernel: levels 0-3) or kc_s2_best.hip (s2.EncodeBest / EncodeSnappyBest)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     pool = [corpora.corpus(k, 2, 131072, first_unit=f).tobytes() for k, f in (("T", 21), ("J", 22), ("M", 23), ("J", 24))]
@@ -42,7 +43,12 @@ def main():
         if not blocks:
             continue
         variant = int(rng.integers(0, 2))
-        if args.kernel == "hbm":  # kc_s2_encode_kernel<level>: all four levels, three speculation policies
+        if args.kernel == "best":  # one wave per block, every candidate of a phase on its own lane: short blocks keep the emulation fast
+            blocks = [b[:int(rng.choice([300, 3000, 20000]))] for b in blocks[:8]]
+            level, variant, w0 = int(rng.choice([4, 5])), 0, 0
+            got = emu_lib.s2_best_blocks(blocks, snappy=level == 5)
+            want = [(oracle_lib.s2_encode_snappy_best if level == 5 else oracle_lib.s2_encode_best)(b) for b in blocks]
+        elif args.kernel == "hbm":  # kc_s2_encode_kernel<level>: all four levels, three speculation policies
             level = int(rng.integers(0, 4))
             w0, w0b, grow = [(2, 4, 1), (8, 8, 0), (1, 1, 2)][int(rng.integers(0, 3))]
             got = emu_lib.s2_encode_blocks_hbm(blocks, level=level, variant=variant, w0=w0, w0b=w0b, grow=grow)
@@ -50,7 +56,9 @@ def main():
             level = int(rng.choice([0, 2]))
             w0 = int(rng.choice([1, 8, 64]))
             got = emu_lib.s2_encode_blocks(blocks, level=level, spec_w0=w0, variant=variant)
-        if variant == 1:
+        if args.kernel == "best":
+            pass
+        elif variant == 1:
             want = [oracle_lib.s2_encode_asm(b, snappy=level in (2, 3), better=level in (1, 3)) for b in blocks]
         else:
             want = [getattr(oracle_lib, {0: "s2_encode", 1: "s2_encode_better", 2: "s2_encode_snappy", 3: "s2_encode_snappy_better"}[level])(b) for b in blocks]
