@@ -7,8 +7,10 @@ zstd/encoder_options.go; the bytes come from the HIP engine behind include/kcgpu
     frame = enc.EncodeAll(src, b"")                     # == reference EncodeAll(src, nil)
     frames, off = enc.EncodeUnits(buf, unit_off)        # N independent EncodeAll calls, one launch
 """
+import contextlib
 import ctypes as C
 import os
+import threading
 
 from . import _lib
 from ._lib import KcError
@@ -250,6 +252,9 @@ class Encoder:
             op(self.o)
         self._device, self._stream = device, stream
         self._ctx = None
+        self._lock = threading.Lock()
+        self._primary_busy = False
+        self._spare = []  # contexts of concurrent EncodeAll / EncodeUnits callers (see _held)
 
     # -- reference API --
     def MaxEncodedSize(self, size):
@@ -270,12 +275,42 @@ class Encoder:
         return res
 
     # -- batched form: what the cgo shim calls --
+    def _new_ctx(self):
+        c = _lib.Context(self._device, self._stream)
+        if self._path is not None:
+            c.set_path(self._path)
+        return c
+
     def ctx(self):
+        """The encoder's own context (options set on it, timings, the streaming / device-resident / asynchronous calls)."""
         if self._ctx is None:
-            self._ctx = _lib.Context(self._device, self._stream)
-            if self._path is not None:
-                self._ctx.set_path(self._path)
+            self._ctx = self._new_ctx()
         return self._ctx
+
+    @contextlib.contextmanager
+    def _held(self):
+        """EncodeAll "can be called concurrently" on one Encoder (zstd/encoder.go:717): every call takes an encoder state from
+        e.encoders and puts it back (encoder.go:90-99, 722-729).  Here the state is a kc_ctx: a lone caller always gets the
+        encoder's own context; a caller that finds it taken gets a spare one (created on demand, at most WithEncoderConcurrency
+        kept), with the kernel-family choice of the constructor — options set on ctx() afterwards stay with ctx()."""
+        with self._lock:
+            if not self._primary_busy:
+                self._primary_busy = True
+                c = self.ctx()
+            else:
+                c = self._spare.pop() if self._spare else None
+        if c is None:
+            c = self._new_ctx()
+        try:
+            yield c
+        finally:
+            with self._lock:
+                if c is self._ctx:
+                    self._primary_busy = False
+                elif self._ctx is not None and len(self._spare) < max(1, self._concurrency):
+                    self._spare.append(c)
+                else:
+                    c.close()
 
     def EncodeUnits(self, src, unit_off):
         """src: numpy uint8 (host); unit_off: uint64[n+1].  Returns (numpy uint8 frames, uint64[n+1] offsets).  With
@@ -287,15 +322,15 @@ class Encoder:
 
     def _encode_units_unpadded(self, src, unit_off):
         import numpy as np
-        ctx = self.ctx()
         src = np.ascontiguousarray(src, dtype=np.uint8)
         unit_off = np.ascontiguousarray(unit_off, dtype=np.uint64)
         n = len(unit_off) - 1
         cap = sum(((self.MaxEncodedSize(int(unit_off[i + 1] - unit_off[i])) + 15) & ~15) for i in range(n)) + 64
         dst = np.empty(cap, dtype=np.uint8)
         out_off = np.zeros(n + 1, dtype=np.uint64)
-        ctx.check(ctx.L.kc_zstd_encode_units(ctx.h, C.byref(self.o), src.ctypes.data, unit_off.ctypes.data, n,
-                                             dst.ctypes.data, cap, out_off.ctypes.data))
+        with self._held() as ctx:
+            ctx.check(ctx.L.kc_zstd_encode_units(ctx.h, C.byref(self.o), src.ctypes.data, unit_off.ctypes.data, n,
+                                                 dst.ctypes.data, cap, out_off.ctypes.data))
         return dst[:int(out_off[n])], out_off
 
     def EncodeUnitsSubmit(self, src, unit_off, dst=None):
@@ -501,9 +536,13 @@ class Encoder:
         """Encoder.Close (encoder.go:589): finish the stream, if one was written to a writer; the device context is released
         and re-created on the next use (the encoder stays usable after Reset, like the reference's)."""
         self._finish_stream()
-        if self._ctx is not None:
-            self._ctx.close()
-            self._ctx = None
+        with self._lock:
+            spare, self._spare = self._spare, []
+            c, self._ctx = self._ctx, None
+        for x in spare:
+            x.close()
+        if c is not None:
+            c.close()
 
 
 def NewWriter(w, *opts, **kw):

@@ -134,6 +134,14 @@ def test_empty_and_tiny_frames(oracle):
         d = bytes((i * 7) & 0xFF for i in range(n))
         out = enc.encode_all(d)
         assert oracle.zstd_decompress(out, n + 16) == d
+    # The one whole frame the reference's tests spell out byte for byte (zstd/decoder_test.go:2093, TestIgnoreChecksum: "zstd file
+    # containing text 'compress\n' and has an xxhash checksum"): single-segment header with a 1-byte content size, one raw last
+    # block, the low four bytes of XXH64 — what EncodeAll writes for the same nine bytes with WithSingleSegment(true) (by default inputs
+    # of at most MinWindowSize get a window descriptor instead: encoder.go:755-759) and the default WithEncoderCRC(true).
+    blob = bytes([0x28, 0xb5, 0x2f, 0xfd, 0x24, 0x09, 0x49, 0x00, 0x00]) + b"compress\n" + bytes([0x79, 0x6e, 0xe0, 0xd2])
+    for level in (1, 2, 3, 4):
+        assert oracle.ZstdOracle(level=level, single=True).encode_all(b"compress\n") == blob
+        assert oracle.ZstdOracle(level=level).encode_all(b"compress\n") == blob[:4] + b"\x04\x00" + blob[6:]
 
 
 def test_s2_roundtrip_and_bounds(oracle):
