@@ -5,6 +5,7 @@ tools/hipemu/hip/hip_runtime.h, which runs every lane of a wave as a fiber and e
 rendezvous; lanes run maximally out of lockstep in between, so an unfenced exchange through LDS shows up as a wrong
 result.  This is how the device algorithms are checked against the oracle without a GPU (tests/test_emu_lds.py)."""
 import ctypes as C
+import functools
 import os
 import subprocess
 
@@ -45,6 +46,71 @@ def lib():
     return _L
 
 
+PROCS = int(os.environ.get("KC_EMU_PROCS", str(min(8, os.cpu_count() or 1))))
+
+
+def _fanned(min_bytes=200000, procs=None, serial_if=None):
+    """The units / blocks of one emulated launch are independent work items (one wave each, or one 8-/16-lane group of a wave):
+    run contiguous chunks of the list in forked children, one emulator each, and join the results in order — wall-clock time of the
+    CPU suite only; KC_EMU_PROCS=1 runs everything in this process.  The wrapped function returns a list (per item, or per block
+    in item order), or a tuple of such a list and integer flags (joined with max)."""
+    def deco(fn):
+        @functools.wraps(fn)
+        def run(items, *a, **kw):
+            np_ = min(procs or PROCS, PROCS, len(items))
+            total = sum(len(x) for x in items)
+            if np_ <= 1 or total < min_bytes or (serial_if is not None and serial_if(kw)):
+                return fn(items, *a, **kw)
+            # contiguous chunks of about equal bytes
+            chunks, cur, acc, goal = [], [], 0, total / np_
+            for x in items:
+                cur.append(x)
+                acc += len(x)
+                if acc >= goal * (len(chunks) + 1) and len(chunks) < np_ - 1:
+                    chunks.append(cur)
+                    cur = []
+            if cur:
+                chunks.append(cur)
+            lib()  # built and loaded before the fork
+            import multiprocessing as mp
+            ctx = mp.get_context("fork")  # (the children inherit fn, its arguments and the loaded emulator: nothing is pickled on the way in)
+
+            def child(conn, chunk):
+                try:
+                    conn.send(("ok", fn(chunk, *a, **kw)))
+                except BaseException as e:
+                    conn.send(("err", repr(e)))
+                finally:
+                    conn.close()
+
+            kids = []
+            for c in chunks:
+                pr, pw = ctx.Pipe(duplex=False)
+                p = ctx.Process(target=child, args=(pw, c), daemon=True)
+                p.start()
+                pw.close()
+                kids.append((p, pr))
+            parts, failed = [], False
+            for p, pr in kids:
+                try:
+                    tag, val = pr.recv() if pr.poll(900) else ("err", "timeout")
+                except (EOFError, OSError):
+                    tag, val = "err", "child died"  # e.g. the emulator's abort on a divergent collective
+                failed = failed or tag != "ok"
+                parts.append(val)
+                p.join(5)
+                if p.is_alive():
+                    p.kill()
+            if failed:
+                return fn(items, *a, **kw)  # in this process, where the assertion / the emulator's message is seen
+            if isinstance(parts[0], tuple):
+                out = [y for p in parts for y in p[0]]
+                return (out,) + tuple(max(p[k] for p in parts) for k in range(1, len(parts[0])))
+            return [y for p in parts for y in p]
+        return run
+    return deco
+
+
 def s2_max_encoded_len(n):
     # s2/encode.go:389-418 (the product's kc_s2_max_encoded_len restates the same)
     n = int(n)
@@ -52,6 +118,7 @@ def s2_max_encoded_len(n):
     return x + 16
 
 
+@_fanned()
 def s2_encode_blocks(blocks, level=0, framed=False, spec_w0=8, variant=0):
     """blocks: list of bytes -> list of bytes (uvarint + body, or the framed chunk).  variant 1: KC_S2_VARIANT_AMD64."""
     n = len(blocks)
@@ -69,6 +136,7 @@ def s2_encode_blocks(blocks, level=0, framed=False, spec_w0=8, variant=0):
     return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)]
 
 
+@_fanned()
 def s2_encode_blocks_hbm(blocks, level=0, framed=False, variant=0, w0=2, w0b=4, grow=1):
     """kc_s2_encode_kernel<level> (HBM tables, 8 lanes per block) over `blocks`: level 0 s2.Encode, 1 EncodeBetter, 2 EncodeSnappy,
     3 EncodeSnappyBetter; variant 1: the amd64 assembly bytes; w0 / w0b / grow: the speculation policy (the library's defaults)."""
@@ -91,6 +159,7 @@ def s2_encode_blocks_hbm(blocks, level=0, framed=False, variant=0, w0=2, w0b=4, 
     return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)]
 
 
+@_fanned()
 def zfast_parse(units, block_size=65536, window=4 << 20, spec_w0=8, stream_mode=0):
     """kc_zfast_match_lds_kernel over `units` (list of bytes).  Returns, per block in unit order, (seqs [n,3] u32 as
     (litLen, matchLen-3, offset code), nlit, extra_lits, flags)."""
@@ -231,6 +300,17 @@ def zbest_parse(units, block_size=131072, window=8 << 20, stream_mode=0, n_slots
     return out
 
 
+def zbest_parse_fresh(units, **kw):
+    """zbest_parse from zeroed slots, the unit list in chunks (each chunk passes its units through n_slots slots of its own)."""
+    return _zbest_fresh(units, **kw)
+
+
+@_fanned(procs=4)
+def _zbest_fresh(units, **kw):
+    return zbest_parse(units, fresh=True, **kw)
+
+
+@_fanned(min_bytes=100000)
 def s2_best_blocks(blocks, snappy=False):
     """kc_s2_best_kernel (s2.EncodeBest / s2.EncodeSnappyBest) over `blocks` (list of bytes) -> list of bytes (uvarint + body)."""
     n = len(blocks)
@@ -294,6 +374,7 @@ def xxh_fin(units, raw_flags, block_size, out_positions, mode, frame_header=9):
     return dst, stage, soff, sizes, xxh
 
 
+@_fanned(serial_if=lambda kw: kw.get("fused") is not None)  # (batch_end's sequence is one batch: its counters and the contiguous output)
 def zstd_frames(units, block_size=None, window=None, crc=True, single=-1, full_zero=True, stream_mode=0, use_grp=False, tuned=0,
                 max_encoded_size=None, level=1, no_entropy=False, all_lit_entropy=False, fused=None):
     """The device's whole SpeedFastest EncodeAll pipeline on the emulator (checksum, match finder, entropy stage): one frame per unit.

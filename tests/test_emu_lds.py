@@ -14,9 +14,18 @@ import emu_lib
 import oracle_lib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# KC_TEST_FULL=1: the long forms of the emulated cases (about four more minutes; the default run keeps every kernel, level, path and
+# edge shape but takes the slowest emulations — speculation width 1, SpeedBestCompression, SpeedBetterCompression — on shorter inputs)
+FULL = os.environ.get("KC_TEST_FULL", "0") == "1"
 
 
-def _s2_blocks():
+def _s2_blocks(small=False):
+    if small and not FULL:
+        blocks = [corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("T", 1, 65536).tobytes()[:30000],
+                  corpora.corpus("H", 1, 65536).tobytes()[:20000], corpora.corpus("M", 1, 65536, first_unit=3).tobytes()[:30000]]
+        blocks += corpora.edge_units()
+        blocks += [u[:70000] for u in corpora.stress_units(seed=11, n=2)]
+        return blocks
     blocks = [corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("T", 1, 65536).tobytes(),
               corpora.corpus("H", 1, 65536).tobytes(), corpora.corpus("M", 1, 65536, first_unit=2).tobytes(),
               corpora.corpus("M", 1, 65536, first_unit=3).tobytes(), corpora.corpus("J", 1, 40000, first_unit=9).tobytes()]
@@ -46,14 +55,14 @@ def test_s2_lds_blocks_bit_exact(w0):
 
 @pytest.mark.parametrize("w0", [1, 8])
 def test_s2_lds_snappy_bit_exact(w0):
-    blocks = _s2_blocks()
+    blocks = _s2_blocks(small=w0 == 1)
     _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=2, spec_w0=w0), oracle_lib.s2_encode_snappy)
 
 
 @pytest.mark.parametrize("w0", [1, 8])
 def test_s2_lds_framed_chunks_bit_exact(w0):
     """Framed mode: chunk header + masked CRC32C (wave-parallel CRC with the advance-by-zeros combine) + body."""
-    blocks = [b for b in _s2_blocks() if len(b) > 0]
+    blocks = [b for b in _s2_blocks(small=w0 == 1) if len(b) > 0]
     buf, off = corpora.pack_units(blocks)
     ref, ro = oracle_lib.s2_encode_stream(buf, off, with_stream_id=False)
     got = emu_lib.s2_encode_blocks(blocks, level=0, framed=True, spec_w0=w0)
@@ -74,13 +83,15 @@ def test_s2_lds_reference_regressions(w0):
     _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=0, spec_w0=w0), oracle_lib.s2_encode)
 
 
-def _zfast_units():
+def _zfast_units(big=True):
+    big = big or FULL
     units = [corpora.corpus("T", 1, 131072, first_unit=k).tobytes() for k in range(2)]
-    units += [corpora.corpus("M", 1, 131072, first_unit=k).tobytes() for k in range(4)]
+    units += [corpora.corpus("M", 1, 131072, first_unit=k).tobytes() for k in range(4 if big else 2)]
     units += [corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("H", 1, 131072).tobytes()]
     units += [u for u in corpora.edge_units() if 0 < len(u) < 262000]
-    units += corpora.stress_units(seed=5, n=8)          # up to 300001 bytes: five blocks with history
-    units += [corpora.corpus("T", 8, 131072, first_unit=77).tobytes()]  # one 1 MiB unit: 16 blocks, positions beyond 2^18
+    units += corpora.stress_units(seed=5, n=8 if big else 4)          # up to 300001 bytes: five blocks with history
+    if big:
+        units += [corpora.corpus("T", 8, 131072, first_unit=77).tobytes()]  # one 1 MiB unit: 16 blocks, positions beyond 2^18
     return units
 
 
@@ -88,7 +99,7 @@ def _zfast_units():
 def test_zfast_lds_parse_matches_oracle(w0):
     """kc_zfast_match_lds_kernel: the sequence list of every block equals the oracle's fastEncoder (EncodeNoHist for
     one-block units, Encode with history for longer ones), at every speculation width."""
-    units = _zfast_units()
+    units = _zfast_units(big=w0 == 64)
     got = emu_lib.zfast_parse(units, spec_w0=w0)
     bi = 0
     for ui, u in enumerate(units):
@@ -109,9 +120,9 @@ def test_s2_best_kernel_bit_exact(snappy):
     """kc_s2_best_kernel (s2.EncodeBest / s2.EncodeSnappyBest: candidates of a phase evaluated one per lane, folded in the
     reference's order with its same-offset rule; chain-ordered table updates, 64 positions per pass) against the oracle."""
     blocks = [corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("T", 1, 65536).tobytes(), corpora.corpus("H", 1, 20000).tobytes(),
-              corpora.corpus("M", 1, 65536, first_unit=2).tobytes(), corpora.corpus("T", 2, 131072, first_unit=9).tobytes()[:150000]]
+              corpora.corpus("M", 1, 65536, first_unit=2).tobytes(), corpora.corpus("T", 2, 131072, first_unit=9).tobytes()[:150000 if FULL else 80000]]
     blocks += [u for u in corpora.edge_units() if len(u) <= 70000]
-    blocks += [u[:40000] for u in corpora.stress_units(seed=13, n=6)]
+    blocks += [u[:40000] for u in corpora.stress_units(seed=13, n=6 if FULL else 3)]
     _cmp(blocks, emu_lib.s2_best_blocks(blocks, snappy=snappy), oracle_lib.s2_encode_snappy_best if snappy else oracle_lib.s2_encode_best)
 
 
@@ -154,12 +165,13 @@ def _cmp_parse(units, got, **okw):
 
 
 def _zbest_units():
-    units = [corpora.corpus("T", 1, 131072, first_unit=1).tobytes()[:100000], corpora.corpus("M", 1, 131072, first_unit=2).tobytes()[:90000],
-             corpora.corpus("J", 1, 65536, first_unit=3).tobytes(), corpora.corpus("H", 1, 40000).tobytes()]
-    # (tiny alphabets make the longest candidate chains: 27 s of emulation for 128 KiB of two symbols — a third of that is plenty here)
-    units += [u[:48000] if len(set(u[:4096])) <= 4 else u for u in corpora.edge_units() if 0 < len(u) < 140000]
-    units += [u[:140000] for u in corpora.stress_units(seed=5, n=3)]   # two blocks with history
-    units += [corpora.corpus("T", 2, 131072, first_unit=77).tobytes()[:150000]]
+    c = (lambda n: n) if FULL else (lambda n: n // 2)
+    units = [corpora.corpus("T", 1, 131072, first_unit=1).tobytes()[:c(100000)], corpora.corpus("M", 1, 131072, first_unit=2).tobytes()[:c(90000)],
+             corpora.corpus("J", 1, 65536, first_unit=3).tobytes()[:c(65536)], corpora.corpus("H", 1, 40000).tobytes()[:c(40000)]]
+    # (tiny alphabets make the longest candidate chains: 27 s of emulation for 128 KiB of two symbols — a fraction of that is plenty here)
+    units += [u[:c(48000)] if len(set(u[:4096])) <= 4 else u[:c(140000)] for u in corpora.edge_units() if 0 < len(u) < 140000]
+    units += [u[:140000 if (FULL or k == 0) else 40000] for k, u in enumerate(corpora.stress_units(seed=5, n=3))]   # two blocks with history
+    units += [corpora.corpus("T", 2, 131072, first_unit=77).tobytes()[:150000 if FULL else 135000]]
     # long repeats: matches beyond goodEnough, repeat-offset forms straight after a match, period-1..7 runs
     rng = np.random.default_rng(3)
     pat = bytes(rng.integers(0, 256, 700, dtype=np.uint8))
@@ -172,7 +184,7 @@ def test_zbest_parse_matches_oracle():
     candidates of a phase priced one per lane, improve()'s order-dependent part replayed in the reference's order, the entropy
     estimate through the restated math.Log2 — on two persistent table slots that many units pass through."""
     units = _zbest_units()
-    got = emu_lib.zbest_parse(units, n_slots=2, fresh=True)
+    got = emu_lib.zbest_parse_fresh(units, n_slots=2)
     _cmp_parse(units, got, level=4)
 
 
@@ -186,11 +198,11 @@ def test_zbest_parse_history_forms():
     units = [t[:30000], t[100:9000], dct[500:9000] + t[:100], t[:7], t[131072:131072 + 140000]]
     got = emu_lib.zbest_parse(units, n_slots=1, hist=dct, fresh=True)
     _cmp_parse(units, got, level=4, dict_id=9, dict_content=dct)
-    for hl in (8, 9, 12, 13, 20):  # the edges of the two index ranges
+    for hl in ((8, 9, 12, 13, 20) if FULL else (8, 13, 20)):  # the edges of the two index ranges
         got = emu_lib.zbest_parse(units[:2], n_slots=1, hist=dct[:hl])
         _cmp_parse(units[:2], got, level=4, dict_id=9, dict_content=dct[:hl])
     # stream mode (Encode from the first block on) and a small window
-    u2 = [t[:200000], t[:65536]]
+    u2 = [t[:200000 if FULL else 120000], t[:65536]]
     got = emu_lib.zbest_parse(u2, n_slots=2, window=1 << 15, block_size=1 << 15, stream_mode=1)
     _cmp_parse(u2, got, level=4, window_size=1 << 15, block_size=1 << 15)
     # the clear path: window 2^29 -> bufferReset 2^30, reached by the second unit of a slot
@@ -210,6 +222,8 @@ def test_s2_lds_amd64_variant_equals_the_assembly_restatement(level, w0):
         d = corpora.corpus(kind, 4, 131072).tobytes()
         for n in (32, 100, 511, 512, 2000, 4095, 4096, 16383, 16384, 65535, 65536, 65537, 150000):
             st = int(rng.integers(0, len(d) - n))
+            if w0 == 1 and not FULL and kind != "J" and n >= 65535:
+                continue  # (the one-step path's emulation is the slowest: the large size classes on one corpus)
             blocks.append(d[st:st + n])
     blocks += [bytes(rng.integers(0, 4, int(rng.integers(32, 1500)), dtype=np.uint8)) for _ in range(60)]
     blocks += [u for u in corpora.edge_units() if 0 < len(u) < 70000]
@@ -262,7 +276,14 @@ def test_xxh_fin_kernel_checksum_and_raw_payload_copy(mode):
     assert np.all(dst[mask] == 0xAA)
 
 
-def _pipeline_units():
+def _pipeline_units(small=False):
+    if small and not FULL:
+        units = [corpora.corpus("T", 1, 131072, first_unit=5).tobytes(), corpora.corpus("M", 1, 131072, first_unit=2).tobytes()[:70001],
+                 corpora.corpus("J", 1, 65536, first_unit=3).tobytes()[:30000], corpora.corpus("H", 1, 131072).tobytes()[:20000],
+                 corpora.corpus("T", 2, 131072, first_unit=40).tobytes()[:140000]]
+        units += [u[:70000] for u in corpora.edge_units() if len(u) < 140000]
+        units += [u[:150000 if k == 0 else 50000] for k, u in enumerate(corpora.stress_units(seed=9, n=4))]
+        return units
     units = [corpora.corpus("T", 1, 131072, first_unit=5).tobytes(), corpora.corpus("M", 1, 131072, first_unit=1).tobytes(),
              corpora.corpus("M", 1, 131072, first_unit=2).tobytes()[:70001], corpora.corpus("J", 1, 65536, first_unit=3).tobytes(),
              corpora.corpus("H", 1, 131072).tobytes()[:66000], corpora.corpus("T", 2, 131072, first_unit=40).tobytes()[:200000]]
@@ -275,7 +296,7 @@ def _pipeline_units():
 def test_whole_pipeline_speed_default_and_better(level):
     """SpeedDefault (kc_zdfast_match_grp_kernel) and SpeedBetterCompression (kc_zbetter_match_grp_kernel, 16 lanes per unit) end to
     end on the emulator, frames against the oracle's."""
-    units = _pipeline_units()
+    units = _pipeline_units(small=level == 3)
     ref = oracle_lib.ZstdOracle(level=level)
     frames, err, redo = emu_lib.zstd_frames(units, level=level, max_encoded_size=ref.max_encoded_size)
     assert err == 0
