@@ -31,6 +31,13 @@ type Option func(e *Encoder) error
 // a batch of 4096 units ~70 ms on either (16 host cores vs profiles/r03_crossover_zfast.csv), and from there on the device wins.
 const DefaultDeviceMinBytes = 512 << 20
 
+// DefaultDeviceMinUnits is the number of independent units (frames, streams) a call must carry to be device work whatever its
+// size: a unit is parsed by one 8-lane group or one wave, so ONE stream of 1 GiB is minutes on the device and seconds on a host
+// core, while 2048 units in flight is where the device overtakes 16 host cores (profiles/r03_crossover_zfast.csv).  A Writer's
+// stream is one unit: it stays on the reference encoder unless the caller lowers this (WithDeviceMinUnits; WithDeviceMinBytes(0)
+// lowers both) or asks for device jobs (WithConcurrentBlocks + WithDeviceJobs: the jobs are the units).
+const DefaultDeviceMinUnits = 2048
+
 // writerBufferCap bounds what a Writer holds before it gives up on the device and streams through the reference encoder.
 const writerBufferCap = 1 << 30
 
@@ -46,6 +53,7 @@ type Encoder struct {
 	dictMem  unsafe.Pointer // C copy of the dictionary (kc_zstd_opts.dict points into it)
 	conc     int
 	minBytes int
+	minUnits int
 	pool     chan *C.kc_ctx // idle contexts
 	poolMu   sync.Mutex
 	created  int  // contexts created so far (<= conc)
@@ -85,7 +93,7 @@ func (e *Encoder) jobMode() bool { return e.jobs && !e.hasDict && e.conc > 1 }
 // EncodeJobs == zstd.NewWriter(w, opts..., zstd.WithConcurrentBlocks(true)); Write(src) with Flush after flushAt[i] bytes; Close().
 func (e *Encoder) EncodeJobs(src []byte, flushAt []uint64) ([]byte, error) {
 	var ctx *C.kc_ctx
-	if len(src) > 0 && e.devJobs && e.useDevice(len(src)) && e.jobMode() {
+	if len(src) > 0 && e.devJobs && e.useDevice(len(src), e.minUnits) && e.jobMode() { // (asked for: the jobs are the units)
 		ctx = e.acquire()
 	}
 	if ctx != nil {
@@ -151,10 +159,22 @@ func WithEncoderConcurrency(n int) Option {
 }
 
 // WithDeviceMinBytes sets the call size (sum of the unit lengths) from which the device path is taken; smaller calls go to the
-// reference encoder, which gives the same bytes faster at that size.  0 sends everything to the device (tests).
+// reference encoder, which gives the same bytes faster at that size.  0 sends everything to the device (tests): it also drops the
+// unit-count rule (WithDeviceMinUnits).
 func WithDeviceMinBytes(n int) Option {
 	return func(e *Encoder) error {
 		e.minBytes = n
+		if n == 0 {
+			e.minUnits = 0
+		}
+		return nil
+	}
+}
+
+// WithDeviceMinUnits sets how many units a call must carry to be device work (DefaultDeviceMinUnits).
+func WithDeviceMinUnits(n int) Option {
+	return func(e *Encoder) error {
+		e.minUnits = n
 		return nil
 	}
 }
@@ -191,8 +211,35 @@ func (e *Encoder) acquire() *C.kc_ctx {
 
 func (e *Encoder) release(c *C.kc_ctx) { e.pool <- c }
 
-// useDevice: the routing rule of every entry point.
-func (e *Encoder) useDevice(total int) bool { return total >= e.minBytes }
+// useDevice: the routing rule of every entry point — enough bytes AND enough independent units to fill the chip.
+func (e *Encoder) useDevice(total, units int) bool { return total >= e.minBytes && units >= e.minUnits }
+
+// streamOnDevice: can ONE stream of a Writer be device work at all?  (Else the Writer streams through the reference encoder from
+// its first byte instead of buffering.)
+func (e *Encoder) streamOnDevice() bool {
+	if e.minBytes > writerBufferCap {
+		return false
+	}
+	if e.jobMode() {
+		return e.devJobs
+	}
+	return e.minUnits <= 1
+}
+
+// trim destroys the idle device contexts (a Writer's Close: the stream is over; the next use creates them again).
+func (e *Encoder) trim() {
+	e.poolMu.Lock()
+	defer e.poolMu.Unlock()
+	for {
+		select {
+		case c := <-e.pool:
+			C.kc_ctx_destroy(c)
+			e.created--
+		default:
+			return
+		}
+	}
+}
 
 func WithEncoderLevel(l zstd.EncoderLevel) Option {
 	return func(e *Encoder) error {
@@ -370,7 +417,7 @@ func boolInt(b bool) C.int {
 // New creates an encoder bound to GPU `device`. If no device is present the encoder still works
 // through the reference implementation.
 func New(device int, opts ...Option) (*Encoder, error) {
-	e := &Encoder{device: device, conc: runtime.GOMAXPROCS(0), minBytes: DefaultDeviceMinBytes}
+	e := &Encoder{device: device, conc: runtime.GOMAXPROCS(0), minBytes: DefaultDeviceMinBytes, minUnits: DefaultDeviceMinUnits}
 	C.kc_zstd_opts_default(&e.opts)
 	for _, o := range opts {
 		if err := o(e); err != nil {
@@ -416,7 +463,7 @@ func (e *Encoder) MaxEncodedSize(size int) int {
 // EncodeAll == (*zstd.Encoder).EncodeAll for one unit (prefer EncodeUnits).
 func (e *Encoder) EncodeAll(src, dst []byte) []byte {
 	before := len(dst)
-	if !e.useDevice(len(src)) {
+	if !e.useDevice(len(src), 1) {
 		dst = e.cpu.EncodeAll(src, dst) // one unit: the reference encoder is faster (and concurrency-safe)
 	} else if out, _, err := e.encodeUnits(src, []uint64{0, uint64(len(src))}, nil); err != nil {
 		dst = e.cpu.EncodeAll(src, dst)
@@ -443,7 +490,7 @@ func (e *Encoder) EncodeStreams(src []byte, off []uint64, dst []byte) ([]byte, [
 	dst = dst[:cap(dst)]
 	outOff := make([]uint64, n+1)
 	var ctx *C.kc_ctx
-	if n > 0 && len(src) > 0 && e.useDevice(int(off[n]-off[0])) {
+	if n > 0 && len(src) > 0 && e.useDevice(int(off[n]-off[0]), n) {
 		ctx = e.acquire()
 	}
 	if ctx != nil {
@@ -499,7 +546,7 @@ func (e *Encoder) EncodeStreamsCuts(src []byte, off []uint64, flushAt [][]uint64
 	dst = dst[:cap(dst)]
 	outOff := make([]uint64, n+1)
 	var ctx *C.kc_ctx
-	if n > 0 && len(src) > 0 && e.useDevice(int(off[n]-off[0])) {
+	if n > 0 && len(src) > 0 && e.useDevice(int(off[n]-off[0]), n) {
 		ctx = e.acquire()
 	}
 	if ctx != nil {
@@ -585,7 +632,7 @@ func (e *Encoder) encodeUnits(src []byte, off []uint64, dst []byte) ([]byte, []u
 	dst = dst[:cap(dst)]
 	outOff := make([]uint64, n+1)
 	var ctx *C.kc_ctx
-	if n > 0 && len(src) > 0 && e.useDevice(int(off[n]-off[0])) {
+	if n > 0 && len(src) > 0 && e.useDevice(int(off[n]-off[0]), n) {
 		ctx = e.acquire()
 	}
 	if ctx != nil {
@@ -636,8 +683,8 @@ func NewWriter(w io.Writer, device int, opts ...Option) (*Writer, error) {
 		return nil, err
 	}
 	x := &Writer{e: e, w: w}
-	if e.minBytes > writerBufferCap {
-		if err := x.fallback(); err != nil { // no stream this Writer can hold reaches the device threshold
+	if !e.streamOnDevice() {
+		if err := x.fallback(); err != nil { // no stream of this Writer is device work: do not buffer it
 			return nil, err
 		}
 	}
@@ -648,7 +695,7 @@ func NewWriter(w io.Writer, device int, opts ...Option) (*Writer, error) {
 func (x *Writer) Reset(w io.Writer) {
 	x.w, x.buf, x.cuts, x.closed = w, x.buf[:0], x.cuts[:0], false
 	x.ref = nil
-	if x.e.minBytes > writerBufferCap {
+	if !x.e.streamOnDevice() {
 		_ = x.fallback()
 	}
 }
@@ -753,7 +800,7 @@ func (x *Writer) Close() error {
 		return nil
 	}
 	x.closed = true
-	if x.ref == nil && !x.e.useDevice(len(x.buf)) {
+	if x.ref == nil && !x.e.useDevice(len(x.buf), x.e.minUnits) { // (streamOnDevice has dealt with the unit rule)
 		if err := x.fallback(); err != nil {
 			return err
 		}
@@ -761,6 +808,7 @@ func (x *Writer) Close() error {
 	if x.ref != nil {
 		return x.ref.Close()
 	}
+	defer x.e.trim()
 	var out []byte
 	var err error
 	if x.e.jobMode() {

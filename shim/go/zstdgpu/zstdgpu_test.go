@@ -448,6 +448,59 @@ func TestRouting(t *testing.T) {
 	}
 }
 
+// TestRoutingUnits: a call must also carry enough independent units (a unit is one wave's work: one stream of any size is not
+// device work), and a Writer whose stream cannot be device work does not buffer it.
+func TestRoutingUnits(t *testing.T) {
+	data := corpusT(1 << 20)
+	off := []uint64{0, 1 << 18, 1 << 19, 3 << 18, 1 << 20}
+	ref, _ := zstd.NewWriter(nil, zstd.WithEncoderLevel(zstd.SpeedFastest))
+	var want []byte
+	for i := 0; i+1 < len(off); i++ {
+		want = ref.EncodeAll(data[off[i]:off[i+1]], want)
+	}
+	few, err := New(0, WithDeviceMinBytes(1), WithEncoderLevel(zstd.SpeedFastest)) // bytes rule passed, DefaultDeviceMinUnits not
+	if err != nil {
+		t.Fatal(err)
+	}
+	defer few.Close()
+	out, _, err := few.EncodeUnits(data, off, nil)
+	if err != nil || !bytes.Equal(out, want) {
+		t.Fatalf("4 units on the reference path: err %v, equal %v", err, bytes.Equal(out, want))
+	}
+	if few.created != 0 {
+		t.Fatalf("4 units created %d device context(s)", few.created)
+	}
+	many, err := New(0, WithDeviceMinBytes(1), WithDeviceMinUnits(4), WithEncoderLevel(zstd.SpeedFastest))
+	if err != nil {
+		t.Fatal(err)
+	}
+	defer many.Close()
+	out, _, err = many.EncodeUnits(data, off, nil)
+	if err != nil || !bytes.Equal(out, want) {
+		t.Fatalf("4 units past WithDeviceMinUnits(4): err %v, equal %v", err, bytes.Equal(out, want))
+	}
+	if many.created == 0 && !many.noDevice {
+		t.Fatal("4 units past WithDeviceMinUnits(4) did not reach the device")
+	}
+	var sink bytes.Buffer
+	w, err := NewWriter(&sink, 0, WithEncoderLevel(zstd.SpeedFastest)) // defaults: one stream is one unit
+	if err != nil {
+		t.Fatal(err)
+	}
+	if w.ref == nil {
+		t.Fatal("a default Writer buffers its stream for the device")
+	}
+	w.Write(data)
+	w.Close()
+	var wantS bytes.Buffer
+	rw, _ := zstd.NewWriter(&wantS, zstd.WithEncoderLevel(zstd.SpeedFastest))
+	rw.Write(data)
+	rw.Close()
+	if !bytes.Equal(sink.Bytes(), wantS.Bytes()) {
+		t.Fatal("default Writer differs from the reference Writer")
+	}
+}
+
 // TestWriterWriteThenReadFrom: ReadFrom first ends the block being filled (zstd/encoder.go:453-458), so Write(p) followed by
 // ReadFrom(r) cuts a block at len(p) — on the device path too (the cut travels to kc_zstd_encode_streams_cuts).
 func TestWriterWriteThenReadFrom(t *testing.T) {
