@@ -79,8 +79,19 @@ func EncodeBlocks(x *Ctx, src []byte, off []uint64, dst []byte) ([]byte, []uint6
 func EncodeBlocksLevel(x *Ctx, level int, src []byte, off []uint64, dst []byte) ([]byte, []uint64, error) {
 	n := len(off) - 1
 	outOff := make([]uint64, n+1)
-	if n == 0 {
-		return dst[:0], outOff, nil
+	if n <= 0 {
+		return dst[:0], []uint64{0}, nil
+	}
+	need := 0
+	for i := 0; i < n; i++ {
+		need += (s2.MaxEncodedLen(int(off[i+1]-off[i])) + 15) &^ 15 // (block slots are 16-byte aligned on the device)
+	}
+	if cap(dst) < need+64 {
+		dst = make([]byte, need+64) // dst may be nil or short, like the dst of s2.Encode
+	}
+	dst = dst[:cap(dst)]
+	if len(src) == 0 { // n empty blocks: nothing to point the device at
+		return encodeRef(level, src, off, dst, outOff)
 	}
 	x.mu.Lock()
 	st := C.kc_s2_encode_blocks_lvl(x.c, C.int(level), (*C.uint8_t)(unsafe.Pointer(&src[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint32_t(n),
@@ -97,6 +108,11 @@ func EncodeBlocksLevel(x *Ctx, level int, src []byte, off []uint64, dst []byte) 
 		return nil, nil, errors.New(msg)
 	}
 	// not served by the device (block above 4 MiB, device memory exhausted, ...): the reference encoder, same bytes
+	return encodeRef(level, src, off, dst, outOff)
+}
+
+func encodeRef(level int, src []byte, off []uint64, dst []byte, outOff []uint64) ([]byte, []uint64, error) {
+	n := len(off) - 1
 	enc := [...]func(dst, src []byte) []byte{s2.Encode, s2.EncodeBetter, s2.EncodeSnappy, s2.EncodeSnappyBetter, s2.EncodeBest, s2.EncodeSnappyBest}[level]
 	out := dst[:0]
 	for i := 0; i < n; i++ {
