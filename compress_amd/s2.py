@@ -1,5 +1,6 @@
 """Host mirror of the reference's S2 block API (s2/encode.go) over include/kcgpu.h."""
 import ctypes as C
+import threading
 
 from . import _lib
 
@@ -27,6 +28,9 @@ class BlockEncoder:
         if variant == "amd64":
             self._ctx.set_option(20, 1)
         self.level = int(level)
+        # the batched calls use the context's stream and scratch: one at a time per encoder (the Go shim's Ctx.mu); the
+        # CustomEncoder hook does not take it — the library batches its concurrent callers itself
+        self._mu = threading.Lock()
 
     def EncodeBlocks(self, src, blk_off):
         """N x s2.Encode(nil, block).  Returns (numpy uint8, uint64[n+1] offsets)."""
@@ -38,7 +42,8 @@ class BlockEncoder:
         cap = sum(((MaxEncodedLen(int(blk_off[i + 1] - blk_off[i])) + 15) & ~15) for i in range(n)) + 64
         dst = np.empty(cap, dtype=np.uint8)
         out_off = np.zeros(n + 1, dtype=np.uint64)
-        ctx.check(ctx.L.kc_s2_encode_blocks_lvl(ctx.h, self.level, src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, out_off.ctypes.data))
+        with self._mu:
+            ctx.check(ctx.L.kc_s2_encode_blocks_lvl(ctx.h, self.level, src.ctypes.data, blk_off.ctypes.data, n, dst.ctypes.data, cap, out_off.ctypes.data))
         return dst[:int(out_off[n])], out_off
 
     def EncodeBlocksDevice(self, d_src_ptr, blk_off, d_dst_ptr, dst_cap):
@@ -47,7 +52,8 @@ class BlockEncoder:
         blk_off = np.ascontiguousarray(blk_off, dtype=np.uint64)
         n = len(blk_off) - 1
         out_off = np.zeros(n + 1, dtype=np.uint64)
-        ctx.check(ctx.L.kc_s2_encode_blocks_lvl_dev(ctx.h, self.level, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data))
+        with self._mu:
+            ctx.check(ctx.L.kc_s2_encode_blocks_lvl_dev(ctx.h, self.level, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data))
         return out_off
 
     def EncodeStreamDevice(self, d_src_ptr, blk_off, d_dst_ptr, dst_cap, with_stream_id=True):
@@ -57,8 +63,9 @@ class BlockEncoder:
         blk_off = np.ascontiguousarray(blk_off, dtype=np.uint64)
         n = len(blk_off) - 1
         out_off = np.zeros(n + 1, dtype=np.uint64)
-        ctx.check(ctx.L.kc_s2_encode_stream_lvl_dev(ctx.h, self.level, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data,
-                                                    int(with_stream_id)))
+        with self._mu:
+            ctx.check(ctx.L.kc_s2_encode_stream_lvl_dev(ctx.h, self.level, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data,
+                                                        int(with_stream_id)))
         return out_off
 
     def DecodeBlocksDevice(self, d_enc_ptr, enc_off, d_dst_ptr, dst_off):
@@ -69,7 +76,8 @@ class BlockEncoder:
         dst_off = np.ascontiguousarray(dst_off, dtype=np.uint64)
         n = len(enc_off) - 1
         status = np.zeros(max(n, 1), dtype=np.uint32)
-        ctx.check(ctx.L.kc_s2_decode_blocks_dev(ctx.h, d_enc_ptr, enc_off.ctypes.data, n, d_dst_ptr, dst_off.ctypes.data, status.ctypes.data))
+        with self._mu:
+            ctx.check(ctx.L.kc_s2_decode_blocks_dev(ctx.h, d_enc_ptr, enc_off.ctypes.data, n, d_dst_ptr, dst_off.ctypes.data, status.ctypes.data))
         return status[:n]
 
     def Encode(self, dst, src):
