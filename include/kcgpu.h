@@ -109,7 +109,10 @@ int64_t kc_zstd_max_encoded_size(const kc_zstd_opts* o, int64_t size);
 
 /* ---- context ---- */
 /* device: HIP device ordinal.  stream: a hipStream_t to launch on (NULL = the context's own stream).
- * The context owns all device scratch; it is safe to use one context per host thread. */
+ * The context owns all device scratch: one call at a time per context (kc_s2_encode_block excepted, see there); any number of
+ * contexts may work on one device at the same time from different host threads — how the drop-ins make EncodeAll safe for concurrent
+ * callers on ONE encoder like the reference's (zstd/encoder.go:90-99, 722-729: a channel of encoder states; here a pool of contexts:
+ * shim/go/zstdgpu, compress_amd/zstd.py; tests/test_zz_gpu_threads.py runs 8 threads on one encoder on the device). */
 kc_status kc_ctx_create(kc_ctx** out, int device, void* stream);
 void kc_ctx_destroy(kc_ctx* ctx);
 const char* kc_last_error(const kc_ctx* ctx);
