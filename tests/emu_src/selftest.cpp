@@ -42,6 +42,41 @@ __global__ void k_diverge(uint32_t* out) {
     out[lane] = (uint32_t)m + (uint32_t)v;
 }
 
+// Two waves of one workgroup, a one-way queue in LDS between them (the producer / consumer arrangement of a parse wave feeding an
+// emit wave): wave 0 appends records and publishes the count, wave 1 polls the count around s_sleep and folds the records.  Needs
+// hipemu::pause() — a wait that is neither a wave-wide nor a block-wide rendezvous.
+#define QN 1000
+#define QRING 64
+__global__ void k_queue(uint32_t* out) {
+    __shared__ uint32_t ring[QRING];
+    __shared__ uint32_t head, tail;  // records published / records consumed
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    if (threadIdx.x == 0) { head = 0; tail = 0; }
+    __syncthreads();
+    if (wave == 0) {
+        for (uint32_t base = 0; base < QN; base += 16) {  // 16 records per step, one per lane
+            while (base + 16 > *(volatile uint32_t*)&tail + QRING) __builtin_amdgcn_s_sleep(1);  // ring full: wait for the consumer
+            if (lane < 16 && base + lane < QN) ring[(base + lane) % QRING] = (base + lane) * 2654435761u;
+            hipemu::wave_sync();  // the records before the count
+            if (lane == 0) head = base + 16 < QN ? base + 16 : QN;
+            hipemu::wave_sync();
+        }
+    } else {
+        uint32_t acc = 0, done = 0;
+        while (done < QN) {
+            while (*(volatile uint32_t*)&head == done) __builtin_amdgcn_s_sleep(1);
+            // one reading for the whole wave (the lanes poll out of lockstep here and could see different counts)
+            const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&head);
+            for (uint32_t i = done + lane; i < h; i += 64) acc += ring[i % QRING];
+            hipemu::wave_sync();  // every lane has read its records before the slots are handed back
+            if (lane == 0) tail = h;
+            done = h;
+            hipemu::wave_sync();
+        }
+        out[lane] = acc;
+    }
+}
+
 int main(int argc, char** argv) {
     static uint32_t out[64 * 8];
     uint32_t* o = out;
@@ -66,6 +101,11 @@ int main(int argc, char** argv) {
     for (int l = 0; l < 64; l++) stale += out[l] == 0u;   // lane l read its neighbour's slot before the neighbour ran
     // (all but one: the lane that completes the rendezvous runs on first, so one neighbour pair sees the new value)
     if (stale < 60) { printf("lanes did not run out of lockstep: %d stale\n", stale); return 2; }
+    hipLaunchKernelGGL(k_queue, dim3(1), dim3(128), 0, 0, o);
+    uint32_t got = 0, wantq = 0;
+    for (int l = 0; l < 64; l++) got += out[l];
+    for (uint32_t i = 0; i < QN; i++) wantq += i * 2654435761u;
+    if (got != wantq) { printf("two-wave queue: %u vs %u\n", got, wantq); return 3; }
     printf("hipemu selftest ok\n");
     return 0;
 }

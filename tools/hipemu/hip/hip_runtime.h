@@ -49,6 +49,7 @@ int lane();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void set_group(unsigned g);  // sub-wave groups of g lanes rendezvous among themselves (kernels whose groups diverge); 64: whole waves
 uint64_t collectives();   // cross-lane operations executed so far (diagnostics)
+void pause();             // s_sleep: the lane gives way without a rendezvous (a wave polling a flag another wave of the block sets)
 }  // namespace hipemu
 
 #define threadIdx (hipemu::thread_idx())
@@ -108,6 +109,7 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
 }
 static inline void __builtin_amdgcn_fence(int, const char*) {}  // (always next to a wave barrier, which is the rendezvous here)
 static inline long long clock64() { return 0; }
+static inline void __builtin_amdgcn_s_sleep(int) { hipemu::pause(); }
 static inline int __syncthreads_or(int p) { return hipemu::block_or(p); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)hipemu::first_lane64((uint32_t)v); }
 static inline int __builtin_amdgcn_readlane(int v, int src) { return (int)(uint32_t)hipemu::shfl64((uint32_t)v, src & 63); }

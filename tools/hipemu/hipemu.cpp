@@ -142,6 +142,11 @@ uint64_t collectives() { return g_coll; }
 // lanes.  With set_group(G) the lanes of a group rendezvous among themselves (G must divide 64; 64 restores whole waves).
 void set_group(unsigned g) { g_group = (g == 0 || g > 64 || (64 % g) != 0) ? 64 : g; }
 
+// A wave that waits for another wave of its workgroup (a flag or a queue index in LDS, polled around s_sleep): no rendezvous, the
+// lane just gives way; the scheduler's round robin runs every other fiber of the block before it returns here.  The caller's loop
+// re-reads the flag after the call (the call is opaque to the compiler, like the hardware's volatile / atomic load).
+__attribute__((noinline)) void pause() { yield(); }
+
 __attribute__((noinline)) void wave_sync() {
     g_coll++;
     wsync(__builtin_return_address(0), 1);
