@@ -180,6 +180,26 @@ def dry_run(args, cfg, rank, world):
     return 0 if verified else 1
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` without a launcher's environment: re-run this command as N ranks under
+    torch.distributed.run on this node (rendezvous on 127.0.0.1, a free port), stream the ranks' output through, return
+    their exit code.  Rank 0 of the child job prints the one JSON line (n_gpus: N)."""
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs the dmabuf IPC mode on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,9 +253,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` from a bare shell: become the launcher — N ranks of this very command under
+        # torch.distributed.run (one process per GPU; rank 0 prints the one JSON line), the form the driver would have typed
+        return self_launch(args.gpus)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...)"
+                         % (world, args.gpus, args.gpus, args.gpus))
     if args.dry_run:
         return dry_run(args, cfg, rank, world)
     if not torch.cuda.is_available():

@@ -106,6 +106,7 @@ struct KcCfg {
                                           // filter), -1 (default) chosen per batch: the tuned form when the context's previous batch did not compress (ratio >= 0.98)
     int64_t zfast_filter = 1;             // SpeedFastest HBM-table kernel: "nothing written there yet" filter in the idle sequence buffer (units without a sequence so far)
     int64_t xxh_fin_mode = 1;             // kc_xxh64_fin_kernel: how the payload of raw-only frames is stored (KcXxhFinParams.mode)
+    int64_t zfast_prescan = -1;           // SpeedFastest: the no-match pre-scan (kc_zstd_prescan.hip): 0 off, 1 on, -1 when the previous batch did not compress
     int64_t fuse_raw_xxh = 1;             // frames made of raw blocks only: checksum and payload copy in one pass over the source (kc_xxh64_fin_kernel)
 };
 
@@ -144,6 +145,11 @@ struct kc_ctx {
     const uint32_t* job_flags = nullptr;    // host, per unit: bit 0 = final job
     const uint8_t* job_tables = nullptr;    // host: the units' tables primed from their prefixes (ResetPrefix), device entry format
     DevBuf d_job_hist, d_job_flags, rawdef, unit_raw;
+    DevBuf unit_done, probe_rel;         // no-match pre-scan (kc_zstd_prescan.hip): per-unit verdicts; the probe positions of one block
+    int probe_bs = 0;                    // block size probe_rel was built for
+    uint32_t probe_n = 0;
+    bool prescan_ran = false;            // the batch in flight ran the pre-scan (its verdicts are counted at the batch's end)
+    int64_t last_prescan_units = 0;      // units of the last batch the pre-scan settled
     std::vector<uint32_t> job_redo_list;    // units of the speculation re-run in progress (their tables are re-primed)
     void* pend = nullptr;            // batch between kc_zstd_encode_units_dev_begin and _end (Pending)
     kc_ctx* chain_after = nullptr;   // pipelining: this context's match finder waits for that context's last one
@@ -331,6 +337,7 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
         envi("KC_FUSE_RAW_XXH", g.fuse_raw_xxh);
         envi("KC_ZFAST_FILTER", g.zfast_filter);
         envi("KC_ZFAST_VARIANT", g.zfast_variant);
+        envi("KC_ZFAST_PRESCAN", g.zfast_prescan);
         envi("KC_XXH_FIN_MODE", g.xxh_fin_mode);
         if (const char* e = getenv("KC_HOST_CHUNKS_MIB")) {
             for (const char* q = e; *q;) { g.host_chunks.push_back((uint64_t)strtoull(q, (char**)&q, 10) << 20); if (*q == ',') q++; else if (*q) break; }
@@ -371,6 +378,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_FUSE_RAW_XXH: g.fuse_raw_xxh = v != 0; break;
         case KC_OPT_ZFAST_FILTER: g.zfast_filter = v != 0; break;
         case KC_OPT_ZFAST_VARIANT: if (v < -1 || v > 1) return KC_ERR_BAD_ARG; g.zfast_variant = v; break;
+        case KC_OPT_ZFAST_PRESCAN: if (v < -1 || v > 1) return KC_ERR_BAD_ARG; g.zfast_prescan = v; break;
         case KC_OPT_XXH_FIN_MODE: if (v < 0 || v > 2) return KC_ERR_BAD_ARG; g.xxh_fin_mode = v; break;
         default: return KC_ERR_BAD_ARG;
     }
@@ -407,8 +415,10 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_FUSE_RAW_XXH: return g.fuse_raw_xxh;
         case KC_OPT_ZFAST_FILTER: return g.zfast_filter;
         case KC_OPT_ZFAST_VARIANT: return g.zfast_variant;
+        case KC_OPT_ZFAST_PRESCAN: return g.zfast_prescan;
         case KC_OPT_XXH_FIN_MODE: return g.xxh_fin_mode;
         case KC_OPT_LAST_PATH: return c->last_path;
+        case KC_OPT_LAST_PRESCAN_UNITS: return c->last_prescan_units;
         case KC_OPT_LAST_BATCHES: return c->last_batches;
         default: return -1;
     }
@@ -420,7 +430,7 @@ void kc_ctx_destroy(kc_ctx* c) {
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
                       &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->redo_blk, &c->pop_blk, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf,
-                      &c->d_job_hist, &c->d_job_flags, &c->rawdef, &c->unit_raw, &c->best_tables, &c->best_cur, &c->best_cost};
+                      &c->d_job_hist, &c->d_job_flags, &c->rawdef, &c->unit_raw, &c->unit_done, &c->probe_rel, &c->best_tables, &c->best_cur, &c->best_cost};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
@@ -995,6 +1005,54 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
 
     if (c->chain_after) HIPCHK(c, hipStreamWaitEvent(st, c->chain_after->ev[2], 0));  // pipelined contexts: one match finder at a time
     HIPCHK(c, hipEventRecord(c->ev[0], st));
+    // The no-match pre-scan (kc_zstd_prescan.hip): SpeedFastest EncodeAll batches whose frames take the deferred-payload path
+    // (fuse_xxh: checksum on, regular block grid, no dictionary / job prefix / chunk feed), literal-only blocks going out raw
+    // (rawAllLits, the default below SpeedBetterCompression).  On by option, or per batch when the context's previous batch did not
+    // compress (the same signal that picks the match finder's form for such input).
+    c->prescan_ran = false;
+    {
+        const bool tuned_now = c->cfg.zfast_variant < 0 ? c->last_incompressible : c->cfg.zfast_variant == 1;
+        const bool want = c->cfg.zfast_prescan > 0 || (c->cfg.zfast_prescan < 0 && tuned_now);
+        if (want && o->level == KC_SPEED_FASTEST && fuse_xxh && !c->stream_mode && !o->all_lit_entropy && bs >= 16 && n_units > 0) {
+            if (c->probe_bs != bs || c->probe_rel.p == nullptr) {
+                std::vector<uint32_t> rel(4096);
+                uint32_t n = kc_zfast_probe_positions(bs, rel.data(), (uint32_t)rel.size());
+                if (n > rel.size()) { rel.resize(n); n = kc_zfast_probe_positions(bs, rel.data(), (uint32_t)rel.size()); }
+                if ((s = ensure(c, c->probe_rel, (size_t)n * 4 + 16)) != KC_OK) return s;
+                HIPCHK(c, hipMemcpyAsync(c->probe_rel.p, rel.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+                HIPCHK(c, hipStreamSynchronize(st));  // rel is a local
+                c->probe_bs = bs;
+                c->probe_n = n;
+            }
+            if ((s = ensure(c, c->unit_done, (size_t)n_units * 4 + 16)) != KC_OK) return s;
+            KcPrescanParams pp;
+            memset(&pp, 0, sizeof(pp));
+            pp.src = k_src;
+            pp.unit_off = k_off;
+            pp.unit_blk0 = mp.unit_blk0;
+            pp.n_units = n_units;
+            pp.block_size = bs;
+            pp.probe_rel = (const uint32_t*)c->probe_rel.p;
+            pp.n_probe = c->probe_n;
+            pp.rep1 = mp.rep1;
+            pp.rep2 = mp.rep2;
+            pp.meta = mp.meta;
+            pp.unit_done = (uint32_t*)c->unit_done.p;
+            pp.stage = ep.stage;
+            pp.stage_off = ep.stage_off;
+            pp.out_size = ep.out_size;
+            pp.rawdef = ep.rawdef;
+            pp.unit_raw = ep.unit_raw;
+            pp.window_size = o->window_size;
+            pp.crc = o->crc;
+            pp.single = o->single;
+            pp.dict_id = o->dict_id;
+            kc_launch_zfast_prescan(pp, st);
+            mp.unit_done = pp.unit_done;
+            ep.unit_done = pp.unit_done;
+            c->prescan_ran = true;
+        }
+    }
     mp.unit_base = 0;
     ep.unit_base = 0;
     if (feed == nullptr) {
@@ -1108,7 +1166,16 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
         for (uint32_t iter = 0;; iter++) {
             HIPCHK(c, hipMemcpyAsync(redo.data(), c->redo.p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipMemcpyAsync(errv, c->errflag.p, 64, hipMemcpyDeviceToHost, st));
+            std::vector<uint32_t> doneh;
+            if (iter == 0 && c->prescan_ran) {
+                doneh.resize(n_units);
+                HIPCHK(c, hipMemcpyAsync(doneh.data(), c->unit_done.p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+            }
             HIPCHK(c, hipStreamSynchronize(st));
+            if (iter == 0) {
+                c->last_prescan_units = 0;
+                for (uint32_t v : doneh) c->last_prescan_units += v != 0u;
+            }
             if (errv[0] != 0) {
                 char b[96];
                 snprintf(b, sizeof(b), "device invariant violated (code %u)", errv[0]);

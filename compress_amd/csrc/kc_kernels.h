@@ -39,6 +39,8 @@ struct KcMatchParams {
     int32_t empty_filter;       // SpeedFastest HBM kernel: 1 = skip the table loads of bucket groups the unit has not written yet, while it has
                                 // emitted no sequence (kc_zstd_match.hip; the tables must start empty: no dictionary, no job prefix)
     int32_t tuned;              // SpeedFastest HBM kernel: 1 = the form compiled with cross-segment rounds (xseg_k) and the empty-group filter
+    const uint32_t* unit_done;  // device or null: per unit, 1 = the pre-scan (kc_zstd_prescan.hip) proved that no probe of the unit finds a
+                                // match and wrote the unit's block records: the match finder skips it
     int32_t xseg_k;             // SpeedFastest HBM kernel: a probe round continues across a skip-segment boundary once (s - nextEmit) >> 5
                                 // has reached this value (0: always; a large value: never, round 2's rounds)
 };
@@ -117,10 +119,44 @@ struct KcEntropyParams {
                             // the payload once, from the source (instead of source -> staging slot -> output)
     uint32_t* err_flag;     // device: set non-zero on a device-side invariant violation
     unsigned long long* prof;  // device or null: per-phase shader-clock totals (diagnostics, KC_K2_PROF=1)
+    const uint32_t* unit_done;  // device or null: per unit, 1 = the pre-scan wrote the unit's whole frame (raw blocks only): nothing to do here
 };
 size_t kc_fse_predef_bytes();
 void kc_launch_fse_predef_init(void* d_predef, hipStream_t st);
 void kc_launch_zstd_entropy(const KcEntropyParams& P, uint32_t grid, hipStream_t st);
+
+// ---- SpeedFastest pre-scan for input without matches (kc_zstd_prescan.hip) ----
+// While a block has produced no sequence, the probe positions of fastEncoder.Encode are a function of the block start alone
+// (s += 2 + ((s - nextEmit) >> 5), enc_fast.go:207), and a probe can only find a candidate that an EARLIER probe of the unit
+// inserted into the same bucket with the same 4 bytes (tableEntry.val == uint32(cv), enc_fast.go:176,188; no repeat check before
+// the third sequence).  So "no two probe inserts of the unit share (bucket, 4 bytes)" proves that the whole unit parses to zero
+// sequences — without a table in HBM.  Such a unit's frame is fully determined (every block raw: blockenc.go:337-352 with
+// rawAllLits): the kernel writes the block records, the frame header, the block headers and the raw-payload descriptors, and
+// flags the unit done; the match finder and the entropy kernel skip it, kc_xxh64_fin_kernel hashes and copies the payload.
+// Units with a possible match (or too many probes for the on-chip set) are left to the regular kernels, untouched.
+struct KcPrescanParams {
+    const uint8_t* src;
+    const uint64_t* unit_off;   // n_units + 1
+    const uint32_t* unit_blk0;  // n_units + 1
+    uint32_t n_units;
+    int32_t block_size;
+    const uint32_t* probe_rel;  // device: the probe positions of a block of block_size bytes relative to its start, ascending
+    uint32_t n_probe;           // how many (those below block_size - 8)
+    int32_t rep1, rep2;         // recentOffsets the unit starts with (carried through blocks without sequences)
+    KcBlkMeta* meta;
+    uint32_t* unit_done;        // out, per unit: 1 = done here
+    uint8_t* stage;
+    const uint64_t* stage_off;
+    uint32_t* out_size;
+    KcRawDef* rawdef;
+    uint32_t* unit_raw;
+    int32_t window_size, crc, single;
+    uint32_t dict_id;
+};
+#define KC_PRESCAN_MAX_KEYS 1024  // (bucket, value) pairs one unit may insert: two per probe; the on-chip set has twice as many slots
+void kc_launch_zfast_prescan(const KcPrescanParams& P, hipStream_t st);
+// the probe positions of a block of `block_size` bytes relative to its start (host helper: fills rel[], returns the count)
+uint32_t kc_zfast_probe_positions(int block_size, uint32_t* rel, uint32_t cap);
 
 // ---- S2 block encoder (kc_s2.hip) ----
 struct KcS2Params {

@@ -23,6 +23,7 @@
 #include "kc_kernels.h"
 #include "kc_fse_dev.h"
 #include "kc_huf_dev.h"
+#include "kc_frame_dev.h"
 
 #define ET 256            // threads per workgroup
 #ifndef SEQ_CHUNK
@@ -171,11 +172,6 @@ enum { IV_SYMLEN = 0, IV_MAXCNT, IV_CANREUSE, IV_LITMODE, IV_USEPREV, IV_TABLOG,
 // ---------------------------------------------------------------------------------------
 // byte helpers
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void put_block_header(uint8_t* p, bool last, uint32_t type, uint32_t size) {
-    // blockHeader (zstd/blockenc.go:109-136): last(1) | type(2) | size(21)
-    const uint32_t h = (last ? 1u : 0u) | (type << 1) | (size << 3);
-    p[0] = (uint8_t)h; p[1] = (uint8_t)(h >> 8); p[2] = (uint8_t)(h >> 16);
-}
 // literalsHeader.setSize (blockenc.go:150): raw / RLE literal sections. Returns header size.
 __device__ __forceinline__ int lit_header_size1(int regenLen) {
     const int inBits = bits_len32((uint32_t)regenLen);
@@ -320,6 +316,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : P.unit_base + blockIdx.x;
+    if (P.unit_done != nullptr && P.unit_done[u] != 0u) return;  // the pre-scan proved the unit free of matches and wrote its frame (kc_zstd_prescan.hip)
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
     const int hist0 = P.unit_hist != nullptr ? (int)P.unit_hist[u] : P.hist0;  // history in front of the unit (dictionary content, or a job's overlap prefix): not part of the output
     const bool JOB = P.job_flags != nullptr;  // the unit is a job of a WithConcurrentBlocks stream: blocks only (compressJob, enc_jobs.go:88-124)
@@ -358,37 +355,8 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
     // size or single segment, window = the encoder's, `last` only on a short final block, otherwise an empty raw last block.
     const bool streamU = UB.streamU;
     if (ulen > 0 && !JOB) {
-        bool single = ulen <= P.window_size && ulen > 1024;
-        if (P.single >= 0) single = P.single != 0;
-        if (streamU) single = false;
-        // fastBase.WindowSize (enc_base.go:42)
-        uint32_t windowSize = (uint32_t)P.window_size;
-        if (ulen < P.window_size && !streamU) {
-            uint32_t bsz = 1u << bits_len32((uint32_t)ulen);
-            windowSize = bsz < 1024u ? 1024u : bsz;
-        }
         uint8_t hdr[16];
-        int h = 0;
-        hdr[h++] = 0x28; hdr[h++] = 0xb5; hdr[h++] = 0x2f; hdr[h++] = 0xfd;
-        uint8_t fhd = 0;
-        if (P.crc) fhd |= 1 << 2;
-        if (single) fhd |= 1 << 5;
-        const uint32_t did = P.dict_id;
-        int didLen = 0;
-        if (did > 0) { if (did < 256) { fhd |= 1; didLen = 1; } else if (did < (1u << 16)) { fhd |= 2; didLen = 2; } else { fhd |= 3; didLen = 4; } }
-        uint8_t fcs = 0;
-        if (!streamU) {  // streaming: ContentSize 0 -> no FCS field (frameenc.go:40-58)
-            if (ulen >= 256) fcs++;
-            if (ulen >= 65536 + 256) fcs++;
-        }
-        fhd |= (uint8_t)(fcs << 6);
-        hdr[h++] = fhd;
-        if (!single) hdr[h++] = (uint8_t)((bits_len32(windowSize - 1) - 10) << 3);
-        for (int i = 0; i < didLen; i++) hdr[h++] = (uint8_t)(did >> (8 * i));
-        if (streamU) { /* no content size */ }
-        else if (fcs == 0) { if (single) hdr[h++] = (uint8_t)ulen; }
-        else if (fcs == 1) { const uint32_t c = (uint32_t)ulen - 256; hdr[h++] = (uint8_t)c; hdr[h++] = (uint8_t)(c >> 8); }
-        else { for (int i = 0; i < 4; i++) hdr[h++] = (uint8_t)((uint32_t)ulen >> (8 * i)); }
+        const int h = kc_frame_header(hdr, ulen, P.window_size, P.single, P.crc, P.dict_id, streamU);
         if (tid == 0) for (int i = 0; i < h; i++) outp[i] = hdr[i];
         opos = h;
     }

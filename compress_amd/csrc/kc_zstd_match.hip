@@ -71,7 +71,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     const int mmo = P.max_match_off;
     const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
     const bool ldsUnit = P.lds_split != 0 && (uint32_t)(ulen + hist0) <= KC_ZFAST_LDS_MAX_UNIT;  // the LDS-table kernel's unit
-    const int nblk = (gact && !ldsUnit) ? UB.nblk : 0;  // a group without a unit (the launch's tail) does nothing
+    const bool doneU = gact && P.unit_done != nullptr && P.unit_done[u] != 0u;  // the pre-scan proved the unit free of matches (kc_zstd_prescan.hip)
+    const int nblk = (gact && !ldsUnit && !doneU) ? UB.nblk : 0;  // a group without a unit (the launch's tail) does nothing
     const bool HIST = ulen > bs || hist0 > 0 || UB.streamU || P.job_flags != nullptr;  // compressJob always calls Encode (enc_jobs.go:114)  // with a dictionary encodeAll always calls Encode (encoder.go:783-787)
     uint32_t* __restrict__ tab = tables + (size_t)ui * (1u << ZF_TABLE_BITS);  // zeroed by the host before the launch
     // Table entry = (position+1) in the low PB bits | a TB-bit tag of the 4 source bytes at that position.

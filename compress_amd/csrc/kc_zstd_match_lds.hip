@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
     const int bs = P.block_size;
     const int mmo = P.max_match_off;
     const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
-    const int nblk = UB.nblk;
+    const int nblk = (P.unit_done != nullptr && P.unit_done[u] != 0u) ? 0 : UB.nblk;  // (done: the pre-scan proved the unit free of matches, kc_zstd_prescan.hip)
     const bool HIST = ulen > bs || hist0 > 0 || UB.streamU || P.job_flags != nullptr;  // with a dictionary encodeAll always calls Encode (encoder.go:783-787), and so does compressJob
     const uint8_t* const srcLo = P.src;
     const uint8_t* const srcHi = P.src_end;

@@ -43,7 +43,10 @@ def broadcast_bytes(data, device, root=0):
     rank = dist.get_rank()
     n = torch.tensor([len(data) if rank == root else 0], dtype=torch.int64, device=device)
     dist.broadcast(n, src=root)
-    buf = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    nb = int(n.item())
+    if nb == 0:  # an empty dictionary (or none): nothing to send — and torch.frombuffer refuses a zero-length buffer
+        return b""
+    buf = torch.empty(nb, dtype=torch.uint8, device=device)
     if rank == root:
         buf.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
     dist.broadcast(buf, src=root)

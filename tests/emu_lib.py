@@ -410,5 +410,7 @@ def zstd_frames(units, block_size=None, window=None, crc=True, single=-1, full_z
     assert r == 0
     if fused is not None:  # batch_end's sequence: size scan, checksum (+ raw payloads), compaction -> the contiguous output
         assert int(doff[n]) == int(sizes[:n].sum()) and np.all(dst[int(doff[n]):] == 0xAA)
+        if tuned & 0x100:  # (with the pre-scan: how many units it settled)
+            return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)], int(err[0]), int(err[1]), int(err[2]), int(err[3])
         return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)], int(err[0]), int(err[1]), int(err[2])
     return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)], int(err[0]), int(err[1])

@@ -361,6 +361,29 @@ def test_whole_pipeline_with_the_checksum_behind_the_entropy_stage(mode):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("use_grp,tuned", [(1, 1), (1, 0), (0, 0)])
+def test_whole_pipeline_with_the_no_match_prescan(use_grp, tuned):
+    """kc_zfast_prescan_kernel in front of the match finder (KC_OPT_ZFAST_PRESCAN): units whose probe inserts never repeat a (bucket,
+    4 bytes) pair are settled by the pre-scan — block records, frame header, raw block headers, payload descriptors — and skipped by
+    the match finder and the entropy stage; everything else goes the regular way.  High-entropy units of one, two and three blocks,
+    ragged and tiny ones, next to text, and high-entropy units with ONE planted repetition (at a probed position: must not be
+    settled; at an unprobed one: may be): every frame equals the oracle's."""
+    h = corpora.corpus("H", 6, 131072, first_unit=3).tobytes()
+    t = corpora.corpus("T", 2, 131072, first_unit=8).tobytes()
+    planted = bytearray(h[:131072])
+    planted[70000:70008] = planted[0:8]          # position 0 is probed in block 0, 70000 - 65536 = 4464 ... (probed or not: the oracle decides)
+    planted2 = bytearray(h[131072:262144])
+    planted2[2:10] = planted2[0:8]                # probes at 0 and 2: the same 6 bytes -> a real candidate
+    units = [h[:131072], t[:100000], h[7:7 + 65536 + 13], h[:196608], b"", h[5:305], h[9:40], h[:65536] + t[:65536], h[3:4], h[1:1 + 131072 + 255],
+             bytes(planted), bytes(planted2), h[11:11 + 65536], h[13:13 + 9], h[17:17 + 10], h[19:19 + 65545]]
+    ref = oracle_lib.ZstdOracle(level=1)
+    frames, err, redo, nraw, ndone = emu_lib.zstd_frames(units, max_encoded_size=ref.max_encoded_size, fused=1, use_grp=use_grp, tuned=tuned | 0x100)
+    assert err == 0 and redo == 0
+    bad = [(i, len(u), len(f)) for i, (u, f) in enumerate(zip(units, frames)) if f != ref.encode_all(u)]
+    assert not bad, bad
+    assert ndone >= 9, ndone  # the plain high-entropy units (the three-block one has too many probes for the on-chip set: 1 332 keys)
+
+
 def test_whole_pipeline_speed_best_compression():
     """SpeedBestCompression end to end on the emulator: kc_zbest_cost_kernel (the bit costs from the predefined FSE tables),
     kc_zbest_match_kernel on two persistent table slots, the entropy stage with allLitEntropy — the oracle's frames."""

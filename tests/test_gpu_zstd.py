@@ -775,6 +775,48 @@ def test_probe_rounds_across_skip_segments(oracle, kclib, variant, xseg, filt):
     enc.Close()
 
 
+@pytest.mark.parametrize("level", [1, "1L"])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_no_match_prescan_settles_incompressible_units(oracle, kclib, level, variant):
+    """KC_OPT_ZFAST_PRESCAN (kc_zstd_prescan.hip): units whose probe inserts never repeat a (bucket, 4 bytes) pair are settled
+    before the match finder — their frames are raw blocks, written by the pre-scan, hashed and copied by kc_xxh64_fin_kernel — and
+    every other unit goes the regular way; the output is the oracle's either way.  High-entropy units of one to three blocks, ragged,
+    tiny and empty ones, text and mixed units, high-entropy units with a planted repetition at probed positions; with the default
+    and a small window, and (checksum off: the deferred-payload path is off) with the pre-scan not eligible."""
+    _torch()
+    from compress_amd import zstd
+    h = corpora.corpus("H", 40, 131072, first_unit=3).tobytes()
+    t = corpora.corpus("T", 4, 131072, first_unit=8).tobytes()
+    m = corpora.corpus("M", 4, 131072, first_unit=5).tobytes()
+    planted = bytearray(h[:131072]); planted[2:10] = planted[0:8]
+    planted_b = bytearray(h[131072:262144]); planted_b[65536 + 2:65536 + 10] = planted_b[0:8]   # block 1 repeats a probed 8 bytes of block 0
+    units = [h[:131072], h[7:7 + 131071], h[100:100 + 65536 + 13], h[:196608], h[5:305], h[9:40], h[3:4], b"", bytes(planted), bytes(planted_b),
+             t[:131072], h[:65536] + t[:65536], t[:65536] + h[:65536], m[:131072], h[13:13 + 9], h[17:17 + 10], h[19:19 + 65545]]
+    units += [h[i * 131072:(i + 1) * 131072] for i in range(2, 34)]
+    buf, off = corpora.pack_units(units)
+    for opts, okw, eligible in (((), {}, True), ((zstd.WithWindowSize(1 << 16),), {"window_size": 1 << 16}, True), ((zstd.WithEncoderCRC(False),), {"crc": False}, False)):
+        enc = zstd.NewWriter(None, *_lo(level), *opts)
+        enc.ctx().set_option(27, variant)
+        enc.ctx().set_option(28, 1)
+        out, out_off = enc.EncodeUnits(buf, off)
+        ref, ref_off = oracle.zstd_encode_units(buf, off, threads=8, level=1, **okw)
+        bad = [i for i in range(len(units)) if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
+        assert not bad and np.array_equal(out_off, ref_off), (okw, bad)
+        settled = enc.ctx().get_option(102)
+        assert (settled >= 38) if eligible else (settled == 0), (okw, settled)
+        assert settled <= len(units) - 7  # text, mixed, planted and empty units are never settled
+        enc.Close()
+    # the default: the pre-scan follows the context's "previous batch did not compress" signal
+    enc = zstd.NewWriter(None, *_lo(level))
+    hb, hoff = corpora.pack_units([h[i * 131072:(i + 1) * 131072] for i in range(16)])
+    for k in range(3):
+        out, out_off = enc.EncodeUnits(hb, hoff)
+        ref, ref_off = oracle.zstd_encode_units(hb, hoff, threads=8, level=1)
+        assert np.array_equal(out_off, ref_off) and np.array_equal(out, np.asarray(ref))
+        assert enc.ctx().get_option(102) == (0 if k == 0 else 16), k
+    enc.Close()
+
+
 @pytest.mark.parametrize("fuse,mode", [(1, 0), (1, 1), (1, 2), (0, 0)])
 @pytest.mark.parametrize("level", [1, "1L", 2, 3])
 def test_raw_only_frames_checksum_and_copy_in_one_pass(oracle, kclib, level, fuse, mode):

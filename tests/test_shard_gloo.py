@@ -174,6 +174,109 @@ def test_bench_dry_run_rank_plumbing(world):
     assert j["units_total"] == 64 * world + 5 and j["shard_of_rank0"] == [0, (64 * world + 5) // world]
 
 
+def test_bench_self_launches_its_ranks_from_a_bare_shell():
+    """`python3 bench.py --gpus 2 --dry-run` with no launcher environment (the shape of the driver's N-GPU command): bench.py
+    re-runs itself as 2 ranks under torch.distributed.run; one JSON line with n_gpus 2 comes back."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["gather_verified"] is True and j["steps"] == 3
+
+
+def _bcast_payload(n):
+    return bytes((i * 7 + 3) & 0xFF for i in range(n))
+
+
+def _bcast_worker(rank, world, port, nbytes, ret):
+    payload = _bcast_payload(nbytes)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from compress_amd.shard import broadcast_bytes
+    got = broadcast_bytes(payload if rank == 0 else b"", torch.device("cpu"))
+    ret[rank] = bytes(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nbytes", [0, 1, 76800])
+def test_broadcast_bytes_world2(nbytes):
+    """The dictionary broadcast, including the empty dictionary: every rank returns rank 0's bytes."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bcast_worker, args=(world, _free_port(), nbytes, ret), nprocs=world, join=True)
+    payload = _bcast_payload(nbytes)
+    assert ret[0] == payload and ret[1] == payload
+
+
+def _rccl_worker(rank, world, port, n_units, usz, ret):
+    """Two GPUs, RCCL: each rank encodes its shard on its own device, FrameGather brings the frames to rank 0."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from compress_amd import _lib, zstd
+    from compress_amd.shard import shard_range, FrameGather, broadcast_bytes
+    lo, hi = shard_range(n_units, rank, world)
+    host = _lib.corpus_fill("T", 0x5EED0001, lo, hi - lo, usz, threads=2)
+    off = np.arange(hi - lo + 1, dtype=np.uint64) * usz
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(zstd.SpeedFastest), device=rank)
+    d_src = torch.from_numpy(host).to(dev)
+    cap = (hi - lo) * ((enc.MaxEncodedSize(usz) + 15) & ~15) + 64
+    bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+    fg = FrameGather(rank, world, bound_bytes=cap)
+    pending, results = None, []
+    for i in range(3):
+        out_off = enc.EncodeUnitsDevice(d_src.data_ptr(), off, bufs[i % 2].data_ptr(), cap)
+        if pending is not None:
+            results.append(pending.wait())
+        pending = fg.start(bufs[i % 2], int(out_off[hi - lo]))
+    results.append(pending.wait())
+    bc = broadcast_bytes(b"dictionary-bytes" * 4096 if rank == 0 else b"", dev)
+    assert bytes(bc) == b"dictionary-bytes" * 4096
+    if rank == 0:
+        for i, r in enumerate(results):
+            ret["out_%d" % i] = r[0].cpu().numpy().copy()
+            ret["offs_%d" % i] = list(r[1])
+    enc.Close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_frame_gather_world2_real_frames():
+    """FrameGather + broadcast_bytes over RCCL at world size 2 with real device frames == the single-rank output.  Needs two
+    GPUs in one box; on the one-GPU boxes of this pool it is collected and skips."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (torch.cuda.device_count() = %d)" % (torch.cuda.device_count() if torch.cuda.is_available() else 0))
+    world, n_units, usz = 2, 301, 128 << 10
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(world, _free_port(), n_units, usz, ret), nprocs=world, join=True)
+    from compress_amd import _lib, zstd
+    host = _lib.corpus_fill("T", 0x5EED0001, 0, n_units, usz)
+    off = np.arange(n_units + 1, dtype=np.uint64) * usz
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(zstd.SpeedFastest), device=0)
+    want, want_off = enc.EncodeUnits(host, off)
+    want = np.asarray(want)[:int(want_off[n_units])]
+    for i in range(3):
+        assert np.array_equal(ret["out_%d" % i], want), "step %d" % i
+        assert ret["offs_%d" % i][-1] == len(want)
+
+
 def _selftest_worker(port, q):
     import torch
     import torch.distributed as dist

@@ -7,6 +7,7 @@
 #include "../../compress_amd/csrc/kc_zstd_match.hip"
 #include "../../compress_amd/csrc/kc_misc.hip"
 #include "../../compress_amd/csrc/kc_zstd_entropy.hip"
+#include "../../compress_amd/csrc/kc_zstd_prescan.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_dfast.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_better.hip"
 #include <vector>
@@ -160,6 +161,30 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
         kc_launch_xxh64(src, unit_off, n, xxh.data(), nullptr);
         hipemu::set_group(64);
     }
+    // the no-match pre-scan in front of the match finder (tuned bit 8; kc_api.cpp batch_begin runs it on fused batches only)
+    const bool prescan = (tuned & 0x100) != 0 && fused_dst != nullptr && crc && use_grp <= 1;
+    tuned &= 0xFF;
+    std::vector<KcRawDef> rawdef;
+    std::vector<uint32_t> unit_raw, unit_done, probe_rel;
+    if (fused_dst != nullptr) {
+        rawdef.assign(nb + 1, KcRawDef{0, 0, 0, 0});
+        unit_raw.assign(n + 1, 0);
+    }
+    if (prescan) {
+        probe_rel.resize(8192);
+        const uint32_t np = kc_zfast_probe_positions(block_size, probe_rel.data(), (uint32_t)probe_rel.size());
+        unit_done.assign(n + 1, 0xFFFFFFFFu);
+        KcPrescanParams Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.src = src; Q.unit_off = unit_off; Q.unit_blk0 = blk0.data(); Q.n_units = n; Q.block_size = block_size; Q.probe_rel = probe_rel.data();
+        Q.n_probe = np; Q.rep1 = 1; Q.rep2 = 4; Q.meta = meta.data(); Q.unit_done = unit_done.data(); Q.stage = stage; Q.stage_off = stage_off;
+        Q.out_size = out_size; Q.rawdef = rawdef.data(); Q.unit_raw = unit_raw.data(); Q.window_size = window; Q.crc = crc; Q.single = single;
+        kc_launch_zfast_prescan(Q, nullptr);
+        M.unit_done = unit_done.data();
+        uint32_t nd = 0;
+        for (uint32_t i = 0; i < n; i++) nd += unit_done[i] == 1u;
+        err_out[3] = nd;
+    }
     std::vector<uint64_t> btab;
     if (use_grp == 4) {  // SpeedBestCompression: kc_zbest_match_kernel on two persistent table slots, the bit costs from the device's own kernel
         btab.assign((size_t)2 * (kc_zbest_table_bytes() / 8), 0);
@@ -197,11 +222,8 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     E.predef = predef.data(); E.seq_stride = seq_stride; E.lit_stride = lit_stride; E.block_size = block_size; E.window_size = window;
     E.crc = crc; E.single = single; E.no_entropy = entropy_opts & 1; E.all_lit_entropy = ((entropy_opts >> 1) & 1) | (use_grp >= 3 && use_grp <= 4 ? 1 : 0) /* allLitEntropy: levels above SpeedDefault */; E.full_zero = full_zero; E.stream_mode = stream_mode;
     E.err_flag = err;
-    std::vector<KcRawDef> rawdef;
-    std::vector<uint32_t> unit_raw;
+    if (prescan) E.unit_done = unit_done.data();
     if (fused_dst != nullptr) {  // the layout of kc_api.cpp batch_end: raw payloads deferred, checksum behind the entropy stage
-        rawdef.assign(nb + 1, KcRawDef{0, 0, 0, 0});
-        unit_raw.assign(n + 1, 0);
         E.rawdef = rawdef.data();
         E.unit_raw = unit_raw.data();
         if (crc) E.xxh = nullptr;
