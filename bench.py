@@ -508,15 +508,19 @@ def main():
         del d_dsts, d_dst, d_src
         torch.cuda.empty_cache()
         also = {}
-        for name in ("C2H", "C3", "C4", "C4A", "C5"):
-            cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(args.also_steps), "--warmup", "1", "--no-end-to-end",
-                   "--no-also", "--cpu-sample-units", "1024", "--path", args.path]
+        # the five BASELINE configurations at their per-GPU sizes, then the N3 levels at small sizes (not BASELINE configurations:
+        # zstd SpeedBestCompression, s2.EncodeBetter, s2.EncodeBest) so that the driver's one run times those too
+        for name, extra in (("C2H", []), ("C3", []), ("C4", []), ("C4A", []), ("C5", []), ("B4", ["--gib", "0.25"]),
+                            ("C4/s2.EncodeBetter", ["--s2-level", "1", "--gib", "1.0"]), ("C4/s2.EncodeBest", ["--s2-level", "4", "--gib", "0.25"])):
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("/")[0], "--steps", str(args.also_steps), "--warmup", "1", "--no-end-to-end",
+                   "--no-also", "--cpu-sample-units", "1024" if not extra else "256", "--path", args.path] + extra
             t0 = time.perf_counter()
             try:
                 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, check=False)
                 js = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
                 j = json.loads(js[-1])
                 also[name] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "steps": j["steps"], "ms_per_step": j["ms_per_step"],
+                              "ms_per_step_spread": j.get("ms_per_step_spread"),
                               "ratio": j["ratio"], "roofline": j["roofline"], "bit_exact_vs_oracle_on_sample": j["bit_exact_vs_oracle_on_sample"],
                               "device_roundtrip_all_frames": j["device_roundtrip_all_frames"], "cpu_baseline": j["cpu_baseline"],
                               "wall_s": round(time.perf_counter() - t0, 1)}
@@ -532,6 +536,8 @@ def main():
             "metric": METRIC if args.config in ("C2", "C2H") else "encode MB/s (input) + ratio, %s" % cfg["what"],
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": round(float(np.median(walls)), 3),
+            # the spread over the timed steps of THIS run on THIS box (boxes of the pool differ by more than steps do: DESIGN.md 5)
+            "ms_per_step_spread": {"min": round(float(np.min(walls)), 3), "median": round(float(np.median(walls)), 3), "max": round(float(np.max(walls)), 3)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "name": args.config, "units_per_gpu": n_units, "unit_bytes": UNIT, "corpus": kind,

@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libkcgpu.so")
+# KC_LIB_TAG=<tag>: a measurement build of the same sources with other compile-time constants (compress_amd/build.py, KC_BUILD_TAG)
+_SO = os.path.join(_HERE, "libkcgpu%s.so" % ("_" + os.environ["KC_LIB_TAG"] if os.environ.get("KC_LIB_TAG") else ""))
 
 KC_OK = 0
 KC_ERR_BAD_ARG, KC_ERR_DST_TOO_SMALL, KC_ERR_HIP, KC_ERR_UNSUPPORTED, KC_ERR_NO_DEVICE, KC_ERR_INTERNAL = -1, -2, -3, -4, -5, -6

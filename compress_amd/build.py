@@ -10,8 +10,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libkcgpu.so")
-BDIR = os.path.join(HERE, "_build")
+# KC_BUILD_TAG=<tag> (measurement builds only: tools/ A/B scripts): objects under _build_<tag>/, library libkcgpu_<tag>.so, loaded
+# when KC_LIB_TAG=<tag> is set (compress_amd/_lib.py); the product is the untagged library
+TAG = os.environ.get("KC_BUILD_TAG", "")
+OUT = os.path.join(HERE, "libkcgpu%s.so" % ("_" + TAG if TAG else ""))
+BDIR = os.path.join(HERE, "_build" + ("_" + TAG if TAG else ""))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-munsafe-fp-atomics"] + os.environ.get("KC_EXTRA_FLAGS", "").split()

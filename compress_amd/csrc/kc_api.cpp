@@ -165,6 +165,11 @@ struct kc_ctx {
     const void* up_ptr[3] = {nullptr, nullptr, nullptr};     // ... and in which allocation (re-uploaded only when they change)
 };
 
+// s2.Encode takes any input MaxEncodedLen accepts (~4 GiB, s2/encode.go:29-56: above 64 KiB encodeBlockGo, on amd64 encodeBlockAsm from
+// 4 MiB on); the device kernels keep positions in 31 bits and sizes in 32: blocks up to 1 GiB are served, larger ones are refused
+// (KC_ERR_UNSUPPORTED: the Go shim then calls the reference encoder).  s2.Writer never cuts blocks above 4 MiB (s2.maxBlockSize).
+#define KC_S2_MAX_BLOCK ((uint64_t)1 << 30)
+
 namespace {
 
 #define HIPCHK(ctx, call)                                                                              \
@@ -2320,7 +2325,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
         if (blk_off[i + 1] < blk_off[i]) { c->err = "blk_off not ascending"; return KC_ERR_BAD_ARG; }
         const uint64_t len = blk_off[i + 1] - blk_off[i];
         maxLen = std::max(maxLen, len);
-        if (len > (uint64_t)(4 << 20)) { c->err = "S2 block larger than 4 MiB (s2.maxBlockSize) not served by the device path"; return KC_ERR_UNSUPPORTED; }
+        if (len > KC_S2_MAX_BLOCK) { c->err = "S2 block larger than 1 GiB not served by the device path"; return KC_ERR_UNSUPPORTED; }
         rel[i] = blk_off[i] - blk_off[0];
         so[i] = acc;
         reg[i] = acc16;
@@ -2333,24 +2338,23 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     if (acc16 + lead > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
     // s2.Encode / s2.EncodeSnappy: the LDS-table kernel (one wave per block, ~1 ms per 64 KiB block whatever the batch) while the
     // blocks in flight cannot cover the HBM-table kernel's latency (measured crossover: profiles/r03_crossover_s2.csv)
-    const bool asmv = c->cfg.s2_variant == KC_S2_VARIANT_AMD64;
-    if (asmv && level >= KC_S2_LEVEL_BEST) {
-        c->err = "KC_S2_VARIANT_AMD64 does not apply to the best levels (pure Go in the reference: one form only)";
-        return KC_ERR_UNSUPPORTED;
-    }
+    // The best levels are pure Go in the reference — one form on every platform (s2/encode_best.go) — so the variant does not
+    // apply to them: an amd64 context (the Go shim's default on amd64 builds) encodes them like any other.
+    const int s2var = level >= KC_S2_LEVEL_BEST ? KC_S2_VARIANT_GO : (int)c->cfg.s2_variant;
+    // (the LDS kernel keeps positions in 24 bits: a batch with a block of 16 MiB or more goes through the HBM-table kernel whole)
     const bool lds = (level == KC_S2_LEVEL_DEFAULT || level == KC_S2_LEVEL_SNAPPY) && feed == nullptr && c->cfg.match_path != KC_PATH_HBM &&
-                     (c->cfg.match_path == KC_PATH_LDS || (int64_t)n <= c->cfg.s2_lds_max_blocks);
+                     maxLen < ((uint64_t)1 << 24) && (c->cfg.match_path == KC_PATH_LDS || (int64_t)n <= c->cfg.s2_lds_max_blocks);
     c->last_path = lds ? KC_PATH_LDS : KC_PATH_HBM;
     kc_status s;
     if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) ||
         (s = ensure(c, c->out_off, (n + 1 + (feed ? feed->cut.size() : 0)) * 8)) || (s = ensure(c, c->stage, acc + 64)) || (s = ensure(c, c->out_size, (size_t)n * 4)) ||
-        (!lds && (s = ensure(c, c->tables, (size_t)n * kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant)))))
+        (!lds && (s = ensure(c, c->tables, (size_t)n * kc_s2_table_bytes(level, maxLen, s2var)))))
         return s;
     HIPCHK(c, hipMemcpyAsync(c->unit_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->stage_off.p, so.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     c->up_ptr[0] = c->up_ptr[1] = c->up_ptr[2] = nullptr;  // (the zstd batch path re-uploads its layout arrays)
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    if (!lds) { c->tab_owner = 0; HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant), st)); }
+    if (!lds) { c->tab_owner = 0; HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen, s2var), st)); }
     KcS2Params P;
     P.src = d_src + blk_off[0];
     P.blk_off = (const uint64_t*)c->unit_off.p;
@@ -2366,8 +2370,8 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     P.spec_grow = c->cfg.spec_grow >= 0 ? (int)c->cfg.spec_grow : 1;
     if (P.spec_w0 < 1) P.spec_w0 = 1;
     if (P.spec_w0b < 1) P.spec_w0b = 1;
-    P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant) / 4);
-    P.variant = (int32_t)c->cfg.s2_variant;
+    P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen, s2var) / 4);
+    P.variant = (int32_t)s2var;
     if (feed) {
         // the source is still arriving: per chunk, encode + compaction on the chunk's stream behind its H2D copy; frames of chunk k
         // at d_dst + reg[cut[k]], local offsets in out_off[cut[k] + k ...].  The caller synchronises (s2_feed_finish).
@@ -2527,7 +2531,7 @@ static kc_status s2_encode_dev_budgeted(kc_ctx* c, const uint8_t* d_src, const u
     if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BEST || n == 0) return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, framed, with_stream_id, level);
     uint64_t maxLen = 0;
     for (uint32_t i = 0; i < n; i++) if (blk_off[i + 1] >= blk_off[i]) maxLen = std::max(maxLen, blk_off[i + 1] - blk_off[i]);
-    const uint64_t tb = kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant);
+    const uint64_t tb = kc_s2_table_bytes(level, maxLen, level >= KC_S2_LEVEL_BEST ? KC_S2_VARIANT_GO : (int)c->cfg.s2_variant);
     uint64_t budget = scratch_budget(c);
     std::vector<uint64_t> tmp;
     uint64_t pos = 0;
@@ -2542,7 +2546,11 @@ static kc_status s2_encode_dev_budgeted(kc_ctx* c, const uint8_t* d_src, const u
             scratch += us;
             i1++;
         }
-        if (i0 == 0 && i1 == n) { c->last_batches = 1; return s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, framed, with_stream_id, level); }  // the usual case: one batch
+        if (i0 == 0 && i1 == n) {  // the usual case: one batch
+            const kc_status s1 = s2_encode_dev(c, d_src, blk_off, n, d_dst, dst_cap, out_off, framed, with_stream_id, level);
+            c->last_batches = s1 == KC_OK ? 1 : 0;  // (0: nothing was encoded on the device — the Go shim's tests tell a fallback by it)
+            return s1;
+        }
         if (i0 == 0) c->last_batches = 0;
         const uint32_t nb = i1 - i0;
         tmp.resize(nb + 1);
@@ -2595,7 +2603,7 @@ kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, cons
     if (n == 0) { out_off[0] = 0; return KC_OK; }
     for (uint32_t i = 0; i < n; i++) {  // before any byte moves
         if (blk_off[i + 1] < blk_off[i]) { c->err = "blk_off not ascending"; return KC_ERR_BAD_ARG; }
-        if (blk_off[i + 1] - blk_off[i] > (uint64_t)(4 << 20)) { c->err = "S2 block larger than 4 MiB (s2.maxBlockSize) not served by the device path"; return KC_ERR_UNSUPPORTED; }
+        if (blk_off[i + 1] - blk_off[i] > KC_S2_MAX_BLOCK) { c->err = "S2 block larger than 1 GiB not served by the device path"; return KC_ERR_UNSUPPORTED; }
     }
     const uint64_t total = blk_off[n] - blk_off[0];
     const uint64_t ov_min = c->cfg.host_overlap_min_mib >= 0 ? (uint64_t)c->cfg.host_overlap_min_mib << 20 : (uint64_t)512 << 20;

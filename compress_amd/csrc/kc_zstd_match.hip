@@ -35,7 +35,9 @@
 #include "kc_zfast_dev.h"
 
 
+#ifndef ZW_RB
 #define ZW_RB 1024      // ring bytes per unit (power of two)
+#endif
 #define ZW_MIRROR 32    // the first 32 ring bytes are mirrored behind the ring: 24-byte reads never wrap
 #define ZW_STRIDE (ZW_RB + ZW_MIRROR)
 #define ZW_BK 4         // bytes in front of a probe / candidate position kept for the backward extension
@@ -53,6 +55,9 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
     constexpr int UPW = 64 / G;
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[UPW * ZW_STRIDE];
     __shared__ uint64_t sbuf_all[UPW * G];  // per unit: the last (nseq mod G) sequences, flushed G at a time as one 64-byte store
+#ifdef KC_MATCH_PRIO
+    __builtin_amdgcn_s_setprio(KC_MATCH_PRIO);  // (measurement builds: the wave's issue priority beside a co-resident entropy kernel)
+#endif
     const int lane = (int)threadIdx.x;
     const int lig = lane % G, grp = lane / G;
     uint8_t* const ring = ring_all + grp * ZW_STRIDE;

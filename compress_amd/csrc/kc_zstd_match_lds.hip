@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
     const uint8_t* __restrict__ abase = base - boff;
     const int hist0 = P.unit_hist != nullptr ? (int)P.unit_hist[u] : P.hist0;  // dictionary content, or a job's overlap prefix
     const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0;
-    if ((uint32_t)(ulen + hist0) > KC_ZFAST_LDS_MAX_UNIT) return;  // beyond the 18-bit position field: the HBM-table kernel's unit
+    if ((uint32_t)(ulen + hist0) > KC_ZFAST_LDS_MAX_UNIT) return;  // beyond the 26-bit position field (64 MiB): the HBM-table kernel's unit
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
     const int mmo = P.max_match_off;
@@ -85,7 +85,10 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
         const uint32_t pmh = (1u << PBh) - 1u;
         for (int i = lane; i < (1 << ZF_TABLE_BITS); i += 64) {
             const uint32_t e = proto[i];
-            const uint32_t tg = TBh >= ZL_TAGB ? ((e >> PBh) >> (TBh - ZL_TAGB)) : 0u;
+            // the HBM format's tag is the top TBh bits of the same hash; where the batch's position field leaves fewer than ZL_TAGB of
+            // them (a unit of 64 MiB and more beside this one: pos_bits >= 27) the tag is taken from the entry's source bytes instead
+            uint32_t tg = 0u;
+            if (e != 0u) tg = TBh >= ZL_TAGB ? ((e >> PBh) >> (TBh - ZL_TAGB)) : zl_tag(ld32(base + ((e & pmh) - 1u)));
             tab[i] = e == 0u ? 0u : ((e & pmh) | (tg << ZL_PB));
         }
     }

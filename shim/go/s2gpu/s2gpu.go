@@ -46,6 +46,11 @@ const (
 
 func (x *Ctx) SetVariant(v int) { C.kc_ctx_set_option(x.c, C.int(C.KC_OPT_S2_VARIANT), C.int64_t(v)) }
 
+// LastBatches reports how many device batches the last EncodeBlocks* call was cut into (0: the call did not reach the device).
+func (x *Ctx) LastBatches() int {
+	return int(C.kc_ctx_get_option(x.c, C.int(C.KC_OPT_LAST_BATCHES)))
+}
+
 func (x *Ctx) Close() { C.kc_ctx_destroy(x.c) }
 
 // CustomEncoder returns the function to pass to s2.WriterCustomEncoder: bytes used, 0 = incompressible,

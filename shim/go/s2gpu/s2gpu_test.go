@@ -91,6 +91,45 @@ func TestBitExactLevels(t *testing.T) {
 	}
 }
 
+// TestBestLevelsReachTheDeviceInEveryVariant: the best encoders are pure Go in the reference (one form on every platform), so a
+// context in the amd64 variant — NewCtx's default on amd64 builds — must serve them on the device, not fall back to the CPU.
+func TestBestLevelsReachTheDeviceInEveryVariant(t *testing.T) {
+	x, err := NewCtx(0)
+	if err != nil {
+		t.Skip(err)
+	}
+	defer x.Close()
+	data, err := kcgpu.CorpusFill('J', kcgpu.Seed('J'), 0, 32, 64<<10)
+	if err != nil {
+		t.Fatal(err)
+	}
+	var off []uint64
+	for p := 0; p <= len(data); p += 64 << 10 {
+		off = append(off, uint64(p))
+	}
+	for _, variant := range []int{VariantGo, VariantAMD64} {
+		x.SetVariant(variant)
+		for _, lv := range []int{LevelBest, LevelSnappyBest} {
+			out, outOff, err := EncodeBlocksLevel(x, lv, data, off, nil)
+			if err != nil {
+				t.Fatal(err)
+			}
+			if x.LastBatches() < 1 {
+				t.Fatalf("variant %d level %d: the call did not reach the device", variant, lv)
+			}
+			for i := 0; i+1 < len(off); i++ {
+				want := s2.EncodeBest(nil, data[off[i]:off[i+1]])
+				if lv == LevelSnappyBest {
+					want = s2.EncodeSnappyBest(nil, data[off[i]:off[i+1]])
+				}
+				if !bytes.Equal(out[outOff[i]:outOff[i+1]], want) {
+					t.Fatalf("variant %d level %d block %d differs from the reference", variant, lv, i)
+				}
+			}
+		}
+	}
+}
+
 // TestCustomEncoderWriter: an s2.Writer that encodes its blocks through the hook writes the same stream as the
 // built-in encoder, with the writer calling the hook from WriterConcurrency goroutines at once (s2/writer.go:455-460).
 func TestCustomEncoderWriter(t *testing.T) {

@@ -612,11 +612,44 @@ def test_context_options_roundtrip(kclib):
     ctx.close()
 
 
+@pytest.mark.parametrize("variant", [None, "amd64"])
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
+def test_s2_blocks_above_4_mib(oracle, kclib, level, variant):
+    """s2.Encode* takes inputs far above the stream writer's 4 MiB maxBlockSize (s2/encode.go:29-56; above 64 KiB encodeBlockGo, on
+    amd64 encodeBlockAsm from 4 MiB on): blocks of 4 MiB + 1, 6 MiB, 17 MiB (beyond the LDS kernel's 24-bit positions: the batch goes
+    through the HBM-table kernel whole) and 40 MiB next to small ones, every level with an assembly form, both byte-exact targets;
+    the amd64 variant also against the reference's own assembly where oracle/_ref is present."""
+    from compress_amd import s2
+    t = corpora.corpus("T", 24, 1 << 20, first_unit=2).tobytes()
+    j = corpora.corpus("J", 16, 1 << 20, first_unit=7).tobytes()
+    blocks = [t[:(4 << 20) + 1], j[:6 << 20], t[1000:1000 + 70000], (t + j)[:17 << 20], j[5:5 + 300], t + j]
+    buf, off = corpora.pack_units(blocks)
+    enc = s2.BlockEncoder(level=level, variant=variant)
+    out, out_off = enc.EncodeBlocks(buf, off)
+    assert enc._ctx.last_path() == "hbm"
+    snappy, better = level in (2, 3), level in (1, 3)
+    if variant == "amd64":
+        ref_fn = lambda b: oracle.s2_encode_asm(b, snappy=snappy, better=better)  # noqa: E731
+    else:
+        ref_fn = {0: oracle.s2_encode, 1: oracle.s2_encode_better, 2: oracle.s2_encode_snappy, 3: oracle.s2_encode_snappy_better}[level]
+    bad = [(i, len(b)) for i, b in enumerate(blocks) if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref_fn(b)]
+    assert not bad, bad
+    if variant == "amd64":
+        import oracle_ref
+        if oracle_ref.available():
+            for i in (0, 3):
+                assert out[int(out_off[i]):int(out_off[i + 1])].tobytes() == oracle_ref.encode(blocks[i], level=level), i
+    enc.Close()
+
+
+@pytest.mark.parametrize("variant", [None, "amd64"])
 @pytest.mark.parametrize("snappy", [False, True])
-def test_s2_best_blocks_bit_exact(oracle, kclib, snappy):
+def test_s2_best_blocks_bit_exact(oracle, kclib, snappy, variant):
     """s2.EncodeBest / s2.EncodeSnappyBest on the device (kc_s2_best.hip: one wave per block, 4.5 MiB of {cur, prev} tables) against
     the oracle's restatement of encodeBlockBest / encodeBlockBestSnappy: corpus blocks, blocks above 64 KiB, edge units, stress
-    mixes; the Snappy variant also through the strict Snappy decoder of the oracle tests (no S2 extensions)."""
+    mixes; the Snappy variant also through the strict Snappy decoder of the oracle tests (no S2 extensions).  The best encoders are
+    pure Go in the reference — one form on every platform — so a context in the amd64 variant (the Go shim's default on amd64
+    builds) serves them with the same bytes instead of refusing."""
     from compress_amd import s2
     blocks = []
     for kind in "JTMH":
@@ -624,10 +657,11 @@ def test_s2_best_blocks_bit_exact(oracle, kclib, snappy):
         blocks += [b[i * 65536:(i + 1) * 65536].tobytes() for i in range(12)]
     big = corpora.corpus("T", 3, 1 << 20).tobytes()
     blocks += [big[:65537], big[:300000], big[1 << 20:2 << 20], corpora.corpus("J", 1, 1 << 20).tobytes()[:700000]]
+    blocks += [big + big[:(1 << 20) + 4321]]  # above 4 MiB (s2.EncodeBest takes any input MaxEncodedLen accepts)
     blocks += corpora.edge_units()
     blocks += [u for u in corpora.stress_units(seed=17, n=24)]
     buf, off = corpora.pack_units(blocks)
-    enc = s2.BlockEncoder(level=s2.LevelSnappyBest if snappy else s2.LevelBest)
+    enc = s2.BlockEncoder(level=s2.LevelSnappyBest if snappy else s2.LevelBest, variant=variant)
     out, out_off = enc.EncodeBlocks(buf, off)
     ref_fn = oracle.s2_encode_snappy_best if snappy else oracle.s2_encode_best
     bad = []
