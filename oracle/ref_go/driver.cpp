@@ -1,0 +1,114 @@
+// driver.cpp — the C entry points of oracle/_ref/libzstdref.so around the TRANSLATED reference encoder (go2cpp.py's output is
+// #included below; nothing of it is in the repository).  TEST INFRASTRUCTURE.  What is hand-written here is what a Go caller of the
+// reference writes: zstd.NewWriter(nil, opts...) — i.e. encoderOptions.setDefault() and the With* option functions, in the
+// caller's order — then EncodeAll(src, nil), which is encodeAll on a fresh encoder of the chosen level (encoder.go:71-99, 722-729).
+#include GOREF_GENERATED
+#include <pthread.h>
+
+namespace {
+struct Call {
+    const uint8_t* src; int64_t n; uint8_t* dst; int64_t cap;
+    int level, window, crc, single, full_zero, no_entropy, all_lit, lowmem;
+    const uint8_t* dict; int64_t dict_len; uint32_t dict_id;
+    int64_t result; char err[256];
+};
+
+void run(Call* c) {
+    using namespace go;
+    try {
+        fse::go_init(); huff0::go_init(); xxhash::go_init(); compress::go_init(); zstd::go_init();
+        zstd::initPredefined();  // NewWriter's first statement (encoder.go:72)
+        zstd::Encoder e;
+        e.o.setDefault();
+        auto apply = [&](zstd::EOption opt) { error er = opt(&e.o); if (er != nil) panic(er); };
+        // (the order NewWriter's caller would write them in: level first — it sets window / block size / allLitEntropy defaults —
+        // then the explicit overrides)
+        if (c->level > 0) apply(zstd::WithEncoderLevel(zstd::EncoderLevel(K((long long)c->level))));
+        if (c->window > 0) apply(zstd::WithWindowSize(Int(K((long long)c->window))));
+        if (c->crc >= 0) apply(zstd::WithEncoderCRC(c->crc != 0));
+        if (c->single >= 0) apply(zstd::WithSingleSegment(c->single != 0));
+        if (c->full_zero >= 0) apply(zstd::WithZeroFrames(c->full_zero != 0));
+        if (c->no_entropy >= 0) apply(zstd::WithNoEntropyCompression(c->no_entropy != 0));
+        if (c->all_lit >= 0) apply(zstd::WithAllLitEntropyCompression(c->all_lit != 0));
+        if (c->lowmem > 0) apply(zstd::WithLowerEncoderMem(true));
+        if (c->dict != nullptr && c->dict_len > 0) {
+            Slice<byte> d = make_slice<byte>(c->dict_len);
+            memcpy((void*)d.p, c->dict, (size_t)c->dict_len);
+            apply(zstd::WithEncoderDictRaw(uint32::raw(c->dict_id), d));
+        }
+        auto enc = e.o.encoder();
+        Slice<byte> src = make_slice<byte>(c->n);
+        if (c->n) memcpy((void*)src.p, c->src, (size_t)c->n);
+        Slice<byte> out = e.encodeAll(enc, src, Slice<byte>());
+        if (out.n > c->cap) { snprintf(c->err, sizeof c->err, "output of %lld bytes does not fit %lld", out.n, (long long)c->cap); c->result = -2; return; }
+        if (out.n) memcpy(c->dst, out.p, (size_t)out.n);
+        c->result = out.n;
+    } catch (const go::Panic& p) {
+        snprintf(c->err, sizeof c->err, "panic: %s", p.msg.c_str());
+        c->result = -1;
+    }
+}
+void* thread_main(void* a) { run((Call*)a); return nullptr; }
+}  // namespace
+
+namespace {
+struct S2Call { int level; const uint8_t* src; int64_t n; uint8_t* dst; int64_t cap; int64_t result; char err[256]; };
+void* s2_thread(void* a) {
+    using namespace go;
+    S2Call* c = (S2Call*)a;
+    try {
+        s2::go_init();
+        Slice<byte> src = make_slice<byte>(c->n);
+        if (c->n) memcpy((void*)src.p, c->src, (size_t)c->n);
+        Slice<byte> out;
+        switch (c->level) {  // s2.Encode / EncodeBetter / EncodeSnappy / EncodeSnappyBetter / EncodeBest / EncodeSnappyBest (dst = nil)
+            case 0: out = s2::Encode(Slice<byte>(), src); break;
+            case 1: out = s2::EncodeBetter(Slice<byte>(), src); break;
+            case 2: out = s2::EncodeSnappy(Slice<byte>(), src); break;
+            case 3: out = s2::EncodeSnappyBetter(Slice<byte>(), src); break;
+            case 4: out = s2::EncodeBest(Slice<byte>(), src); break;
+            case 5: out = s2::EncodeSnappyBest(Slice<byte>(), src); break;
+            default: c->result = -4; return nullptr;
+        }
+        if (out.n > c->cap) { c->result = -2; return nullptr; }
+        if (out.n) memcpy(c->dst, out.p, (size_t)out.n);
+        c->result = out.n;
+    } catch (const go::Panic& p) {
+        snprintf(c->err, sizeof c->err, "panic: %s", p.msg.c_str());
+        c->result = -1;
+    }
+    return nullptr;
+}
+}  // namespace
+
+extern "C" {
+// s2.Encode* (nil, src) of a build WITHOUT the assembly (encode_go.go: the portable Go encoders, what arm64 / noasm builds run)
+long long goref_s2_encode(int level, const uint8_t* src, long long n, uint8_t* dst, long long cap, char* err, int err_cap) {
+    S2Call c{level, src, n, dst, cap, 0, {0}};
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, (size_t)1 << 30);
+    pthread_t th;
+    if (pthread_create(&th, &at, s2_thread, &c) != 0) return -3;
+    pthread_join(th, nullptr);
+    pthread_attr_destroy(&at);
+    if (err && err_cap > 0) { strncpy(err, c.err, (size_t)err_cap - 1); err[err_cap - 1] = 0; }
+    return c.result;
+}
+// EncodeAll(src, nil) of zstd.NewWriter(nil, <options>); options < 0 (or 0 for level / window / dict): the reference's defaults.
+// Runs on a thread with a large stack (the translated encoders hold their tables by value, like the Go structs do on Go's heap).
+long long goref_zstd_encode_all(const uint8_t* src, long long n, uint8_t* dst, long long cap, int level, int window, int crc, int single,
+                                int full_zero, int no_entropy, int all_lit, int lowmem, const uint8_t* dict, long long dict_len,
+                                unsigned dict_id, char* err, int err_cap) {
+    Call c{src, n, dst, cap, level, window, crc, single, full_zero, no_entropy, all_lit, lowmem, dict, dict_len, dict_id, 0, {0}};
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, (size_t)1 << 30);
+    pthread_t th;
+    if (pthread_create(&th, &at, thread_main, &c) != 0) return -3;
+    pthread_join(th, nullptr);
+    pthread_attr_destroy(&at);
+    if (err && err_cap > 0) { strncpy(err, c.err, (size_t)err_cap - 1); err[err_cap - 1] = 0; }
+    return c.result;
+}
+}

@@ -627,7 +627,7 @@ class Parser:
             saved = self.exprlev
             self.exprlev = 1
             # a parenthesised type, e.g. (*T)(x)
-            if self.is_op("*") or self.is_op("["):
+            if self.is_op("["):  # ((*T)(x) is told from (*p) by the translator, which knows the type names)
                 save_i = self.i
                 try:
                     ty = self.type_()

@@ -1,0 +1,79 @@
+"""ctypes binding of oracle/_ref/libzstdref.so — TEST INFRASTRUCTURE ONLY: the reference's OWN pure-Go encoders, translated.
+
+The library is the reference's Go source for the zstd encode path (encoder.go encodeAll, enc_fast / enc_dfast / enc_better /
+enc_best, blockenc, fse_encoder, huff0, fse, xxhash) and for its portable-Go S2 block encoders (encode_all / encode_better /
+encode_best, encode_go), translated statement by statement into C++ at build time (oracle/ref_go/go2cpp.py; Go's integer,
+slice and array semantics in oracle/ref_go/gort.h) and compiled here (oracle/Makefile `ref`).  It is built where /root/reference
+exists (this container) and travels to the GPU box as a built file; nothing of the reference is stored in the repository."""
+import ctypes as C
+import os
+import subprocess
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ODIR = os.path.join(_ROOT, "oracle")
+_SO = os.path.join(_ODIR, "_ref", "libzstdref.so")
+_REFSRC = "/root/reference/zstd/encoder.go"
+_lib = None
+
+
+def available():
+    return os.path.exists(_SO) or os.path.exists(_REFSRC)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if os.path.exists(_REFSRC):
+            subprocess.check_call(["make", "-C", _ODIR, "-s", "_ref/libzstdref.so"])
+        L = C.CDLL(_SO)
+        L.goref_zstd_encode_all.restype = C.c_longlong
+        L.goref_zstd_encode_all.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 8 + [C.c_char_p, C.c_longlong, C.c_uint,
+                                            C.c_char_p, C.c_int]
+        L.goref_s2_encode.restype = C.c_longlong
+        L.goref_s2_encode.argtypes = [C.c_int, C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _flag(v):
+    return -1 if v is None else int(bool(v))
+
+
+def zstd_encode_all(src: bytes, level=1, window_size=None, crc=None, single=None, full_zero=None, no_entropy=None, all_lit_entropy=None,
+                    low_mem=False, dict_id=0, dict_content=None) -> bytes:
+    """zstd.NewWriter(nil, WithEncoderLevel(level), <the options given>).EncodeAll(src, nil) of the reference (None: its default)."""
+    src = bytes(src)
+    cap = len(src) + (len(src) >> 6) + 1024
+    out = C.create_string_buffer(cap)
+    err = C.create_string_buffer(256)
+    d = bytes(dict_content) if dict_content else None
+    n = lib().goref_zstd_encode_all(src, len(src), out, cap, int(level), int(window_size or 0), _flag(crc), _flag(single), _flag(full_zero),
+                                    _flag(no_entropy), _flag(all_lit_entropy), int(bool(low_mem)), d, len(d) if d else 0, int(dict_id), err, 256)
+    if n < 0:
+        raise RuntimeError("translated reference failed (%d): %s" % (n, err.value.decode(errors="replace")))
+    return out.raw[:n]
+
+
+def zstd_encode_units(src, unit_off, **kw):
+    """N x EncodeAll: (bytes, offsets) like oracle_lib.zstd_encode_units."""
+    import numpy as np
+    buf = bytes(memoryview(np.ascontiguousarray(src, dtype=np.uint8)))
+    outs, off = [], [0]
+    for i in range(len(unit_off) - 1):
+        f = zstd_encode_all(buf[int(unit_off[i]):int(unit_off[i + 1])], **kw)
+        outs.append(f)
+        off.append(off[-1] + len(f))
+    return b"".join(outs), np.array(off, dtype=np.uint64)
+
+
+def s2_encode(src: bytes, level=0) -> bytes:
+    """s2.Encode (0) / EncodeBetter (1) / EncodeSnappy (2) / EncodeSnappyBetter (3) / EncodeBest (4) / EncodeSnappyBest (5) of a build
+    of the reference without its assembly (the portable Go encoders)."""
+    src = bytes(src)
+    cap = len(src) + len(src) // 6 + 64
+    out = C.create_string_buffer(cap)
+    err = C.create_string_buffer(256)
+    n = lib().goref_s2_encode(int(level), src, len(src), out, cap, err, 256)
+    if n < 0:
+        raise RuntimeError("translated reference failed (%d): %s" % (n, err.value.decode(errors="replace")))
+    return out.raw[:n]

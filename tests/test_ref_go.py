@@ -1,0 +1,165 @@
+"""The oracle — and the device — against the reference's OWN Go encoders, translated and compiled (oracle/_ref/libzstdref.so).
+
+Whole-encoder bytes of every zstd level used to be "parity unpinned": the reference is pure Go there and the image has no Go
+toolchain.  oracle/ref_go translates the reference's Go source statement by statement into C++ at build time (like
+oracle/ref_s2asm re-spells its assembly); these tests hold the hand-written oracle (CPU) and the HIP path (GPU) to that library's
+bytes: EncodeAll at SpeedFastest / Default / BetterCompression / BestCompression over the synthetic corpora, the edge and stress
+sets, the frame options, raw dictionaries and the reference's own test inputs, and the six s2.Encode* levels in their portable
+Go form."""
+import io
+import os
+import zipfile
+
+import numpy as np
+import pytest
+
+import corpora
+import oracle_goref
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFIN = os.path.join(HERE, "golden", "ref_inputs")
+
+pytestmark = pytest.mark.skipif(not oracle_goref.available(), reason="oracle/_ref/libzstdref.so neither present nor buildable (no /root/reference)")
+
+
+def _units():
+    u = []
+    for kind, first in (("T", 1), ("M", 2), ("J", 3), ("H", 4)):
+        c = corpora.corpus(kind, 3, 131072, first_unit=first).tobytes()
+        u += [c[:131072], c[131072:131072 + 70001], c[5:5 + 300000], c[1000:1000 + 4096]]
+    u += corpora.edge_units()
+    u += corpora.stress_units(seed=23, n=40)
+    u += corpora.rle_literal_units(n=6, seed=5)[1]
+    return u
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_oracle_equals_the_translated_reference_encode_all(oracle, level):
+    ref = oracle.ZstdOracle(level=level)
+    bad = []
+    for i, u in enumerate(_units()):
+        if oracle_goref.zstd_encode_all(u, level=level) != ref.encode_all(u):
+            bad.append((i, len(u)))
+    assert not bad, "oracle differs from the reference's own Go encoder (unit, length): %r" % bad[:10]
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_oracle_equals_the_translated_reference_with_options(oracle, level):
+    """The encoderOptions that change bytes: window size (block size follows it below 128 KiB), checksum off, single segment forced
+    on / off, zero frames, WithNoEntropyCompression, WithAllLitEntropyCompression on / off, WithLowerEncoderMem."""
+    t = corpora.corpus("T", 3, 131072, first_unit=6).tobytes()
+    m = corpora.corpus("M", 2, 131072, first_unit=1).tobytes()
+    units = [t[:131072], t[:200001], m[:90000], t[:3000], b"", t[:1], m[:1025]]
+    cases = [dict(window_size=1 << 16), dict(window_size=1 << 20), dict(crc=False), dict(single=True), dict(single=False), dict(full_zero=False),
+             dict(no_entropy=True), dict(all_lit_entropy=True), dict(all_lit_entropy=False), dict(low_mem=True), dict(window_size=1 << 10, crc=False)]
+    bad = []
+    for kw in cases:
+        ref = oracle.ZstdOracle(level=level, **kw)
+        for i, u in enumerate(units):
+            if oracle_goref.zstd_encode_all(u, level=level, **kw) != ref.encode_all(u):
+                bad.append((sorted(kw.items()), i, len(u)))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_oracle_equals_the_translated_reference_with_a_raw_dictionary(oracle, level):
+    """WithEncoderDictRaw: the dictionary content is history in front of every frame (fastEncoderDict, doubleFastEncoderDict,
+    betterFastEncoderDict, bestFastEncoder.Reset with a dictionary)."""
+    from compress_amd import _lib
+    dct = _lib.corpus_fill("T", 0x5EED0005, 0, 1, 64 << 10).tobytes()
+    t = corpora.corpus("T", 3, 131072, first_unit=2).tobytes()
+    units = [t[:131072], t[:20000], t[7:7 + 250000], t[:100], dct[1000:9000] + t[:5000]]
+    rd, runits = corpora.rle_literal_units(n=6, seed=9)   # blocks with an RLE literals section (huff0.ErrUseRLE) need their dictionary
+    for d, us in ((dct, units), (dct[:4096], units), (dct[:9], units), (rd, runits)):
+        ref = oracle.ZstdOracle(level=level, dict_id=7, dict_content=d)
+        bad = [(len(d), i, len(u)) for i, u in enumerate(us) if oracle_goref.zstd_encode_all(u, level=level, dict_id=7, dict_content=d) != ref.encode_all(u)]
+        assert not bad, bad
+
+
+def _ref_inputs(limit):
+    out = []
+    for name in ("encode-corpus-raw.zip", "comp-crashers.zip", "enc_regressions.zip"):
+        p = os.path.join(REFIN, name)
+        if not os.path.exists(p):
+            continue
+        with zipfile.ZipFile(p) as z:
+            names = sorted(z.namelist())
+            step = max(1, len(names) // limit)
+            for n in names[::step]:
+                if not n.endswith("/"):
+                    out.append((name + ":" + n, z.read(n)))
+    for f in ("e.txt", "gettysburg.txt", "Mark.Twain-Tom.Sawyer.txt", "sharnd.out", "pi.txt", "html.txt", "pngdata.bin"):
+        p = os.path.join(REFIN, f)
+        if os.path.exists(p):
+            out.append((f, open(p, "rb").read()))
+    return out
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_oracle_equals_the_translated_reference_on_the_references_own_inputs(oracle, level):
+    """The reference's fuzz corpora, regression inputs and shared testdata files (tests/golden/ref_inputs): a sample of ~300 per zip at
+    the three fast levels, ~60 at SpeedBestCompression."""
+    ref = oracle.ZstdOracle(level=level)
+    bad = []
+    n = 0
+    for name, data in _ref_inputs(300 if level < 4 else 60):
+        if len(data) > (4 << 20):
+            continue
+        n += 1
+        if oracle_goref.zstd_encode_all(data, level=level) != ref.encode_all(data):
+            bad.append((name, len(data)))
+    assert n > 100 and not bad, bad[:10]
+
+
+_S2 = {0: "s2_encode", 1: "s2_encode_better", 2: "s2_encode_snappy", 3: "s2_encode_snappy_better", 4: "s2_encode_best", 5: "s2_encode_snappy_best"}
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5])
+def test_oracle_equals_the_translated_reference_s2(oracle, level):
+    """s2.Encode / EncodeBetter / EncodeSnappy / EncodeSnappyBetter / EncodeBest / EncodeSnappyBest, portable Go form: blocks of every
+    size class (below 32 bytes: literals only; 64 KiB; above 64 KiB; 1 MiB), four corpora, edge and stress blocks, the reference's
+    enc_regressions inputs."""
+    blocks = []
+    for kind in "JTMH":
+        c = corpora.corpus(kind, 2, 1 << 20, first_unit=3).tobytes()
+        blocks += [c[:65536], c[65536:65536 + 65537], c[:300000], c[100:131], c[:32], c[:1 << 20] if level < 4 else c[:200000], c[7000:7000 + 5000]]
+    blocks += corpora.edge_units() + corpora.stress_units(seed=31, n=24)
+    p = os.path.join(REFIN, "enc_regressions.zip")
+    if os.path.exists(p):
+        with zipfile.ZipFile(p) as z:
+            blocks += [z.read(n) for n in sorted(z.namelist())[::4] if not n.endswith("/")]
+    fn = getattr(oracle, _S2[level])
+    bad = [(i, len(b)) for i, b in enumerate(blocks) if len(b) < (4 << 20) and oracle_goref.s2_encode(b, level) != fn(b)]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, "1L", 2, 3, 4])
+def test_device_equals_the_translated_reference_encode_all(kclib, level):
+    """The HIP path against the reference's own Go encoder directly (no hand-written oracle in between)."""
+    from compress_amd import zstd
+    lv = 1 if level == "1L" else level
+    opts = [zstd.WithEncoderLevel(lv)] + ([zstd.WithMatchPath("lds")] if level == "1L" else ([zstd.WithMatchPath("hbm")] if level == 1 else []))
+    units = [u for u in _units() if len(u) <= 300000][:60 if lv < 4 else 24]
+    buf, off = corpora.pack_units(units)
+    enc = zstd.NewWriter(None, *opts)
+    out, out_off = enc.EncodeUnits(buf, off)
+    enc.Close()
+    bad = [(i, len(u)) for i, u in enumerate(units) if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != oracle_goref.zstd_encode_all(u, level=lv)]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5])
+def test_device_equals_the_translated_reference_s2(kclib, level):
+    from compress_amd import s2
+    blocks = []
+    for kind in "JTM":
+        c = corpora.corpus(kind, 8, 65536, first_unit=5).tobytes()
+        blocks += [c[i * 65536:(i + 1) * 65536] for i in range(8 if level < 4 else 3)] + [c[:200000], c[9:40], c[:5000]]
+    buf, off = corpora.pack_units(blocks)
+    enc = s2.BlockEncoder(level=level)
+    out, out_off = enc.EncodeBlocks(buf, off)
+    enc.Close()
+    bad = [(i, len(b)) for i, b in enumerate(blocks) if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != oracle_goref.s2_encode(b, level)]
+    assert not bad, bad[:10]

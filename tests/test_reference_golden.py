@@ -1,4 +1,9 @@
-"""Gate on the REAL reference's bytes, when they are available.
+"""Gate on the REAL reference's bytes.
+
+tests/golden/reference_go_sha256.txt (committed) is written in the build container by tests/golden/make_reference_go_golden.py
+from oracle/_ref/libzstdref.so — the reference's own Go source for EncodeAll / s2.Encode*, translated statement by statement
+into C++ at build time (oracle/ref_go) — so the GPU box, which has no /root/reference, still holds the oracle and the HIP path to
+the reference's bytes.  The second file below is the same thing from a real Go toolchain, when somebody has one:
 
 tests/golden/reference_sha256.txt is written by the Go tests of shim/go (zstdgpu.TestWriteGolden, s2gpu.TestWriteGolden:
 `KC_WRITE_GOLDEN=1 go test -tags noasm ./...` on a host with Go): one line `<name> <sha256>` per seeded corpus and level,
@@ -15,18 +20,22 @@ import corpora
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden", "reference_sha256.txt")
+GOLD_GO = os.path.join(HERE, "golden", "reference_go_sha256.txt")
+S2_LEVELS = {"s2": 0, "s2better": 1, "s2snappy": 2, "s2snappybetter": 3, "s2best": 4, "s2snappybest": 5}
 DICT_SEED = 0x5EED0005
 
 
 def _lines():
-    if not os.path.exists(GOLD):
-        pytest.skip("parity unpinned: tests/golden/reference_sha256.txt is written by `KC_WRITE_GOLDEN=1 go test -tags noasm ./...` "
-                    "in shim/go on a host with Go (none in this image)")
     out = {}
-    for l in open(GOLD):
-        f = l.split()
-        if len(f) == 2:
-            out[f[0]] = f[1]
+    for p in (GOLD_GO, GOLD):
+        if not os.path.exists(p):
+            continue
+        for l in open(p):
+            f = l.split()
+            if len(f) == 2:
+                assert out.get(f[0], f[1]) == f[1], "the two golden files disagree on " + f[0]
+                out[f[0]] = f[1]
+    assert out, "tests/golden/reference_go_sha256.txt is a committed fixture"
     return out
 
 
@@ -39,7 +48,7 @@ def _parse(name):
         n, usz = p[3].split("x")
         return dict(codec="zstd", level=int(p[1][1:]), kind=p[2], n=int(n), unit=int(usz), rawdict=(len(p) > 4 and p[4] == "rawdict64k"))
     n, usz = p[2].split("x")
-    return dict(codec="s2", kind=p[1], n=int(n), unit=int(usz), level={"s2": 0, "s2better": 1, "s2snappy": 2, "s2snappybetter": 3}[p[0]])
+    return dict(codec="s2", kind=p[1], n=int(n), unit=int(usz), level=S2_LEVELS[p[0]])
 
 
 def _flush_points(i):
@@ -70,6 +79,10 @@ def test_oracle_matches_reference_hashes(oracle):
             if c["rawdict"]:
                 kw.update(dict_id=1, dict_content=_dict())
             out, _ = oracle.zstd_encode_units(buf, off, threads=8, **kw)
+        elif c["level"] >= 4:
+            b = buf.tobytes()
+            fn = oracle.s2_encode_best if c["level"] == 4 else oracle.s2_encode_snappy_best
+            out = np.frombuffer(b"".join(fn(b[i * c["unit"]:(i + 1) * c["unit"]]) for i in range(c["n"])), dtype=np.uint8)
         else:
             out, _ = oracle.s2_encode_blocks(buf, off, threads=8, better=c["level"] in (1, 3), snappy=c["level"] in (2, 3))
         assert hashlib.sha256(np.asarray(out).tobytes()).hexdigest() == want, "oracle differs from the reference on " + name
