@@ -24,6 +24,7 @@
 
 #define S2L_SRC_MAX 65536
 #define S2L_POS_MASK 0xFFFFFFu
+#define S2L_TAIL 544  // bytes behind the block in LDS: the fused step loads up to 63 x 8 bytes past a position before it looks at the bounds
 
 // CRC32C of [0, len) read through rd32 / rdb, all 64 lanes cooperating: lane j takes bytes [j*C, (j+1)*C); the raw
 // (init 0) remainders are combined left to right, acc = advance(acc, C zero bytes) ^ part[j], with the 32 columns of
@@ -80,11 +81,26 @@ __device__ __forceinline__ uint32_t s2_crc32c_wave(RD32 rd32, RDB rdb, int len, 
 // every lane the same — with the block in LDS a step is two LDS round trips whether or not other steps run beside it, so the
 // speculative round's machinery (positions, markers, ballots, winner selection: ~600 instructions for one sequence) buys nothing
 // and a wave-uniform step (scalar hashes, broadcast LDS reads, scalar branches) is what is left on the critical path.
-template <int LEVEL, bool SRCLDS, bool ONESTEP>
+//
+// MODE 2 (with SRCLDS; the default for blocks held in LDS), "fused step": the same wave-uniform step, laid out for the fewest
+// DEPENDENT LDS round trips and instructions — one wave issues one instruction per ~4 clocks and an LDS round trip costs ~30 of
+// them, so both count.  A probe step is two trips: (1) lanes 0 / 1 / 2 hash the bytes at s / s+1 / s+2 (their own 8-byte loads,
+// issued one step ahead) and read their buckets, lanes 0 / 1 write s / s+1, lane 2 reads its bucket again behind the writes
+// (encode_all.go:401: table[hash2] is read after the two stores); (2) four 16-lane groups — the candidates of s, s+1, s+2 and
+// the repeat candidate of s+1 — each load 8 bytes per lane on both sides: lane 0 of a group the 4 bytes before and the 4 bytes
+// at the candidate (backward extension + the 4-byte verification), lanes 1..15 the 120 bytes behind them (forward extension).
+// ONE ballot then holds which candidates verify and how far each match runs; the reference's priority order picks the winner in
+// scalar code.  The immediate re-match test after a copy (:474-488) is the same two trips with one 64-lane group.
+template <int LEVEL, bool SRCLDS, int MODE>
 __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
     constexpr bool SNAPPY = LEVEL == 2;
+    constexpr bool ONESTEP = MODE == 1;
+    constexpr bool FUSED = MODE == 2;
+    constexpr int FRONT = 16;  // bytes in front of the block in LDS: the fused step reads the 4 bytes before a candidate unconditionally
     __shared__ uint32_t tab[1 << S2_TABLE_BITS];
-    __shared__ __attribute__((aligned(16))) uint8_t lsrc[SRCLDS ? S2L_SRC_MAX + 32 : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t lbuf[SRCLDS ? FRONT + S2L_SRC_MAX + S2L_TAIL : 16];
+    __shared__ uint32_t sink[64];  // where the lanes without a table store of their own write (one store instruction, no exec masking)
+    uint8_t* const lsrc = lbuf + (SRCLDS ? FRONT : 0);
     __shared__ uint32_t crcT[4][256];
     __shared__ uint32_t crcM[32];
     __shared__ uint32_t crcP[64];
@@ -115,7 +131,8 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
         const int body = len & ~15;
         for (int o = lane * 16; o < body; o += 1024) *(uint4*)(lsrc + o) = ld128u(src + o);
         for (int o = body + lane; o < len; o += 64) lsrc[o] = src[o];
-        if (lane < 32) lsrc[len + lane] = 0;  // reads of whole dwords around the last bytes stay inside the array
+        for (int o = lane; o < S2L_TAIL; o += 64) lsrc[len + o] = 0;  // reads of whole words around and past the last bytes stay inside the array
+        if (lane < FRONT) lbuf[lane] = 0;
     }
     KC_WAVE_SYNC();
 
@@ -272,6 +289,125 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
         int W = W0;
         uint8_t* const tabB = (uint8_t*)tab;
         uint32_t rounds = 0;
+        if (FUSED) {
+            const int g4 = lane >> 4, j16 = lane & 15;
+            const int off16 = j16 == 0 ? -4 : 8 * j16 - 4;  // a lane's 8 bytes inside its 16-lane group: [-4, +4) then [+4, +124) from the position
+            const int soff16 = (g4 == 3 ? 1 : g4) + off16;   // groups 0..2: the candidates of s, s+1, s+2; group 3: the repeat candidate of s+1
+            const int off64 = lane == 0 ? -4 : 8 * lane - 4; // the immediate re-match test: one 64-lane group, [+4, +508)
+            const int q = g4 < 3 ? g4 : 0;                   // groups 0 / 1 / 2 hash the bytes at s / s+1 / s+2, every lane for itself (group 3 repeats group 0's work)
+            const uint32_t hiOnly = j16 == 0 ? 0u : ~0u;     // a group's lane 0 verifies on the upper four bytes of its difference only
+            const uint32_t hiOnly64 = lane == 0 ? 0u : ~0u;
+            uint32_t* const sinkL = &sink[lane];
+            const int lenM8 = len - 8;
+            uint64_t cvL = rd64(s + q);
+            while (!fin && !stored) {
+                if (++rounds > (uint32_t)len + 16u) { stored = true; break; }  // every round advances s: cannot happen; never spin on the device
+                // ---------------- one probe step (encode_all.go:318-412): trip 1, the table ----------------
+                const int nextS = s + ((s - nextEmit) >> SKIP) + 4;
+                if (nextS > sLimT) { fin = true; break; }
+                const uint32_t hL = hashOf(cvL);
+                uint32_t* const tabL = &tab[hL];
+                const uint32_t e1 = *tabL;
+                KC_WAVE_SYNC();
+                *(lane == 0 ? tabL : sinkL) = (uint32_t)s;         // table[hash0] = s
+                KC_WAVE_SYNC();
+                *(lane == 16 ? tabL : sinkL) = (uint32_t)(s + 1);  // table[hash1] = s + 1 (behind the first store: one bucket for both keeps s + 1)
+                KC_WAVE_SYNC();
+                const uint32_t e2 = *tabL;               // group 2: table[hash2] behind the two stores (:401)
+                const uint64_t cvN = rd64(nextS + q);    // the next step's bytes travel with this step's table entries
+                const int cr = s + 1 - repeat;
+                // ---------------- trip 2: the four candidates, verification and both extensions at once ----------------
+                const int cL = g4 == 3 ? cr : (int)((g4 == 2 ? e2 : e1) & S2L_POS_MASK);
+                const uint64_t diff = rd64(cL + off16) ^ rd64(s + soff16);
+                const uint64_t B = ballot64((((uint32_t)diff & hiOnly) | (uint32_t)(diff >> 32)) != 0u);
+                int kind = 0, gs = 0;  // 1 repeat at s+1, 2 match at s, 3 match at s+1, 4 match at s+2 — in the reference's order
+                if (!((B >> 48) & 1ull)) { kind = 1; gs = 3; }
+                else if (!(B & 1ull)) { kind = 2; gs = 0; }
+                else if (!((B >> 16) & 1ull)) { kind = 3; gs = 1; }
+                else if (!((B >> 32) & 1ull)) { kind = 4; gs = 2; }
+                // table[hash2] = s+2 is skipped when the step ends on the repeat or on the match at s
+                if (kind != 1 && kind != 2) { if (lane == 32) *tabL = (uint32_t)(s + 2); }
+                KC_WAVE_SYNC();
+                if (kind == 0) { s = nextS; cvL = cvN; continue; }
+                const int p = s + (gs == 3 ? 1 : gs);
+                const int gb = 16 * gs;
+                const int csel = (int)rdlane32((uint32_t)cL, gb);
+                int back;
+                {   // backward extension: the 4 bytes in front of both positions are in the group's lane 0; beyond them (rare) bytewise
+                    const uint32_t dlo = rdlane32((uint32_t)diff, gb);
+                    const int kmax = csel < p - nextEmit ? csel : p - nextEmit;
+                    const int nb = dlo == 0u ? 4 : (__builtin_clz(dlo) >> 3);
+                    back = nb < kmax ? nb : kmax;
+                    if (nb == 4 && kmax > 4) back = 4 + backlen(p - 4, csel - 4, kmax - 4);
+                }
+                // Forward extension.  The reference compares 8 bytes at a time from (match start + 4) while the position is <= len - 8
+                // (:353-360, :441-448; the assembly: the exact common prefix): it ends on the first differing byte M, or on aK, the first
+                // 8-byte position behind len - 8 in ITS phase — the match start moved by `back`, the lanes' chunks did not.  Bytes past the
+                // end of the block are zero padding: a difference found there is >= len >= aK.
+                auto fwd_end = [&](int ms, int pp, int cc, uint64_t fw, uint64_t dfw, int span) -> int {
+                    int aK = len;
+                    if (!AX) aK = ms + 4 > lenM8 ? ms + 4 : ms + 4 + 8 * (((lenM8 - ms - 4) >> 3) + 1);
+                    if (fw != 0ull) {
+                        const int M = pp + 4 + 8 * ctz64(fw) + (ctz64(dfw) >> 3);
+                        return M < aK ? M : aK;
+                    }
+                    if (pp + 4 + span >= aK) return aK;
+                    const int sh = (pp - ms) & 7;  // back into the reference's phase (re-reads up to 7 bytes known to be equal)
+                    return AX ? extend_exact(pp + 4 + span, cc + 4 + span) : extend(pp + 4 + span - sh, cc + 4 + span - sh, lenM8);
+                };
+                int send;  // where the match ends
+                {
+                    const uint64_t fwd = (uint64_t)(((uint32_t)(B >> gb) >> 1) & 0x7FFFu);
+                    const uint64_t dfw = fwd != 0ull ? rdlane64(diff, gb + 1 + ctz64(fwd)) : 0ull;
+                    send = fwd_end(kind == 1 ? p : p - back, p, csel, fwd, dfw, 120);  // (the repeat's backward extension moves only its base, :349-352)
+                }
+                if (kind == 1) {
+                    // ---------------- repeat at s+1 (:336-384) ----------------
+                    const int base = p - back;
+                    if (d + (base - nextEmit) > bailLim) { stored = true; break; }
+                    s = send;
+                    cvL = rd64(s + q);  // issued ahead of the emission work
+                    d += emit_lit(nextEmit, base - nextEmit);
+                    d += emit_copy_any(repeat, s - base, nextEmit > 0);
+                    nextEmit = s;
+                    if (s >= sLimit) fin = true;
+                    continue;
+                }
+                // ---------------- regular match (:387-489) ----------------
+                int cand = csel - back, ms = p - back;
+                if (d + (ms - nextEmit) > bailLim) { stored = true; break; }
+                bool first = true;
+                for (;;) {
+                    const int base = ms;
+                    repeat = base - cand;
+                    s = send;
+                    // the bytes of the immediate re-match test (lane 0: s-2, lane 1: s) and of the probe step behind it, ahead of the emission work
+                    const uint64_t xL = rd64(s - 2 + (lane == 1 ? 2 : 0));
+                    const uint64_t cvP = rd64(s + 1 + q);
+                    if (first) { d += emit_lit(nextEmit, base - nextEmit); first = false; }
+                    d += emit_copy_any(repeat, s - base, false);
+                    nextEmit = s;
+                    if (s >= sLimit) { fin = true; break; }
+                    if (d > cpLim) { stored = true; break; }
+                    // check for an immediate match, otherwise start the search at s+1 (:474-488)
+                    const uint32_t hx = hashOf(xL);
+                    const uint32_t ec = tab[hx];
+                    KC_WAVE_SYNC();
+                    *(lane == 0 ? &tab[hx] : sinkL) = (uint32_t)(s - 2);  // table[m2Hash] = s - 2
+                    KC_WAVE_SYNC();
+                    *(lane == 1 ? &tab[hx] : sinkL) = (uint32_t)s;        // table[currHash] = s
+                    KC_WAVE_SYNC();
+                    cand = (int)(rdlane32(ec, 1) & S2L_POS_MASK);
+                    const uint64_t dx = rd64(cand + off64) ^ rd64(s + off64);
+                    const uint64_t BX = ballot64((((uint32_t)dx & hiOnly64) | (uint32_t)(dx >> 32)) != 0u);
+                    if (BX & 1ull) { s++; cvL = cvP; break; }
+                    ms = s;
+                    const uint64_t fw = BX >> 1;
+                    const uint64_t dfw = fw != 0ull ? rdlane64(dx, 1 + ctz64(fw)) : 0ull;
+                    send = fwd_end(s, s, cand, fw, dfw, 504);
+                }
+            }
+        } else
         while (!fin && !stored) {
             if (++rounds > (uint32_t)len + 16u) { stored = true; break; }  // every round advances s: cannot happen; never spin on the device
             int mkind = 0, candidate = 0, ps = 0;
@@ -485,14 +621,17 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
 
 void kc_launch_s2_encode_lds(const KcS2Params& P, bool any_small, bool any_big, hipStream_t st) {
     if (P.n_blocks == 0) return;
-    const bool one = P.spec_w0 <= 1;  // blocks held in LDS: one wave-uniform step at a time unless a speculation width is asked for
+    // blocks held in LDS: spec_w0 0 (the default) the fused step, 1 one wave-uniform step at a time in its first form, above that speculative rounds
+    const int mode = P.spec_w0 <= 0 ? 2 : (P.spec_w0 == 1 ? 1 : 0);
     if (P.level == 2) {
-        if (any_small && one) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, true, true>), dim3(P.n_blocks), dim3(64), 0, st, P);
-        if (any_small && !one) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, true, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
-        if (any_big) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, false, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_small && mode == 2) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, true, 2>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_small && mode == 1) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, true, 1>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_small && mode == 0) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, true, 0>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_big) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<2, false, 0>), dim3(P.n_blocks), dim3(64), 0, st, P);
     } else {
-        if (any_small && one) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, true, true>), dim3(P.n_blocks), dim3(64), 0, st, P);
-        if (any_small && !one) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, true, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
-        if (any_big) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, false, false>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_small && mode == 2) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, true, 2>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_small && mode == 1) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, true, 1>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_small && mode == 0) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, true, 0>), dim3(P.n_blocks), dim3(64), 0, st, P);
+        if (any_big) hipLaunchKernelGGL((kc_s2_encode_lds_kernel<0, false, 0>), dim3(P.n_blocks), dim3(64), 0, st, P);
     }
 }

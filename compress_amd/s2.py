@@ -32,6 +32,9 @@ class BlockEncoder:
         # CustomEncoder hook does not take it — the library batches its concurrent callers itself
         self._mu = threading.Lock()
 
+    def ctx(self):
+        return self._ctx
+
     def EncodeBlocks(self, src, blk_off):
         """N x s2.Encode(nil, block).  Returns (numpy uint8, uint64[n+1] offsets)."""
         import numpy as np

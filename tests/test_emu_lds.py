@@ -44,22 +44,22 @@ def _cmp(blocks, got, ref_fn):
     assert not bad, "blocks differing from the oracle (index, len, oracle bytes, emulated bytes, first differing byte): %r" % bad[:8]
 
 
-@pytest.mark.parametrize("w0", [1, 8, 64])
+@pytest.mark.parametrize("w0", [0, 1, 8, 64])
 def test_s2_lds_blocks_bit_exact(w0):
     """s2.Encode through kc_s2_encode_lds_kernel<0, *>: blocks below and above 64 KiB (LDS / global source), every
-    speculation width (1 = blocks in LDS take the wave-uniform one-step path, longer ones one-step rounds; 64 = a whole wave
+    speculation width (0 = blocks in LDS take the fused wave-uniform step, 1 = its first form, longer ones one-step rounds; 64 = a whole wave
     of steps per round)."""
     blocks = _s2_blocks()
     _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=0, spec_w0=w0), oracle_lib.s2_encode)
 
 
-@pytest.mark.parametrize("w0", [1, 8])
+@pytest.mark.parametrize("w0", [0, 1, 8])
 def test_s2_lds_snappy_bit_exact(w0):
     blocks = _s2_blocks(small=w0 == 1)
     _cmp(blocks, emu_lib.s2_encode_blocks(blocks, level=2, spec_w0=w0), oracle_lib.s2_encode_snappy)
 
 
-@pytest.mark.parametrize("w0", [1, 8])
+@pytest.mark.parametrize("w0", [0, 1, 8])
 def test_s2_lds_framed_chunks_bit_exact(w0):
     """Framed mode: chunk header + masked CRC32C (wave-parallel CRC with the advance-by-zeros combine) + body."""
     blocks = [b for b in _s2_blocks(small=w0 == 1) if len(b) > 0]
@@ -71,7 +71,7 @@ def test_s2_lds_framed_chunks_bit_exact(w0):
         assert r == got[i], "chunk %d (len %d): header %r vs %r" % (i, len(blocks[i]), r[:8], got[i][:8])
 
 
-@pytest.mark.parametrize("w0", [1, 8])
+@pytest.mark.parametrize("w0", [0, 1, 8])
 def test_s2_lds_reference_regressions(w0):
     """The reference's own encoder regression inputs (s2/testdata/enc_regressions.zip, committed copy)."""
     zp = os.path.join(HERE, "golden", "ref_inputs", "enc_regressions.zip")
@@ -211,7 +211,7 @@ def test_zbest_parse_history_forms():
     _cmp_parse(u3, got, level=4, window_size=1 << 29)
 
 
-@pytest.mark.parametrize("level,w0", [(0, 1), (0, 8), (2, 1), (2, 64)])
+@pytest.mark.parametrize("level,w0", [(0, 0), (2, 0), (0, 1), (0, 8), (2, 1), (2, 64)])
 def test_s2_lds_amd64_variant_equals_the_assembly_restatement(level, w0):
     """KC_S2_VARIANT_AMD64 in the LDS-table kernel (one wave-uniform step at a time, and speculative rounds): every size class of
     s2/encode_amd64.go against the oracle's restatement of the assembly encoders — which tests/test_ref_s2asm.py pins to the
