@@ -95,7 +95,7 @@ struct KcCfg {
     int64_t host_serial = 0, host_pipe_mib = 0, host_overlap_min_mib = -1, host_copy_threads = 0, host_trace = 0;
     std::vector<uint64_t> host_chunks;    // chunk-fed host path: chunk sizes in bytes (empty: a quarter of the batch each)
     int64_t k2_prof = 0;
-    int64_t hook_wait_us = 0, hook_batch = 256;
+    int64_t hook_wait_us = 0, hook_batch = 256, hook_lanes = 4;
     int64_t test_feed_redo = 0;           // diagnostics: force the chunk-fed path's re-encode fallback
     int64_t better_dict_epoch = 0;        // SpeedBetterCompression with a dictionary: epoch-stamped tables + shared dictionary table instead of the per-batch copy
     int64_t s2_variant = 0;               // S2 levels 0 / 2: 0 = the portable Go encoders' bytes, 1 = the amd64 assembly encoders' bytes
@@ -337,6 +337,7 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
         if (getenv("KC_K2_PROF")) g.k2_prof = 1;
         envi("KC_S2_HOOK_WAIT_US", g.hook_wait_us);
         envi("KC_S2_HOOK_BATCH", g.hook_batch);
+        envi("KC_S2_HOOK_LANES", g.hook_lanes);
         envi("KC_ZFAST_EPOCH", g.zfast_epoch);
         envi("KC_ZFAST_XSEG_K", g.zfast_xseg_k);
         envi("KC_FUSE_RAW_XXH", g.fuse_raw_xxh);
@@ -373,6 +374,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_K2_PROF: g.k2_prof = v; break;
         case KC_OPT_S2_HOOK_WAIT_US: g.hook_wait_us = v; break;
         case KC_OPT_S2_HOOK_BATCH: g.hook_batch = v < 1 ? 1 : v; break;
+        case KC_OPT_S2_HOOK_LANES: g.hook_lanes = v < 1 ? 1 : (v > 8 ? 8 : v); break;
         case KC_OPT_TEST_FEED_REDO: g.test_feed_redo = v; break;
         case KC_OPT_MAX_SCRATCH_MIB: if (v < 1) return KC_ERR_BAD_ARG; c->max_scratch_bytes = (uint64_t)v << 20; break;
         case KC_OPT_BEST_SLOTS: if (v < 1 || v > 8192) return KC_ERR_BAD_ARG; g.best_slots = v; break;
@@ -410,6 +412,7 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_K2_PROF: return g.k2_prof;
         case KC_OPT_S2_HOOK_WAIT_US: return g.hook_wait_us;
         case KC_OPT_S2_HOOK_BATCH: return g.hook_batch;
+        case KC_OPT_S2_HOOK_LANES: return g.hook_lanes;
         case KC_OPT_TEST_FEED_REDO: return g.test_feed_redo;
         case KC_OPT_MAX_SCRATCH_MIB: return (int64_t)(c->max_scratch_bytes >> 20);
         case KC_OPT_BEST_SLOTS: return g.best_slots;
@@ -2666,24 +2669,36 @@ struct S2Hook {
         uint32_t n = 0, copied = 0, left = 0;
         bool open = false, closed = false, done = false;
         kc_status status = KC_OK;
+        std::condition_variable cv;  // the slot's own callers: its leader (all bytes staged?) and its followers (done?)
     };
-    static constexpr int kSlots = 3;
+    static constexpr int kMaxLanes = 8;
+    static constexpr int kSlots = kMaxLanes + 2;  // one per lane on the device, one filling, one draining
     std::mutex m;
     std::condition_variable cv;
-    std::mutex dev;  // one slot at a time on the context's stream and scratch
+    // Lanes: contexts of the hook's own (stream + scratch each), so that several slots are on the device at once — a slot of a few
+    // blocks keeps a few CUs busy for the ~3 ms of one block, and a caller that arrives meanwhile need not wait for it to finish.
+    kc_ctx* lanes[kMaxLanes] = {nullptr};
+    bool lane_busy[kMaxLanes] = {false};
+    int n_lanes = 1;
     Slot slots[kSlots];
+    int n_slots = 3;
     int cur = -1;
-    size_t in_cap = (size_t)16 << 20, out_cap = 0;
+    size_t in_cap = (size_t)8 << 20, out_cap = 0;
     uint32_t max_n = 256;
     int wait_us = 0;
     bool ok = false;
     std::atomic<uint64_t> n_calls{0}, n_batches{0};
 
-    bool init(const KcCfg& g) {
+    bool init(const KcCfg& g, int device) {
         wait_us = (int)g.hook_wait_us;
         max_n = (uint32_t)std::max<int64_t>(1, g.hook_batch);
+        n_lanes = (int)std::min<int64_t>(kMaxLanes, std::max<int64_t>(1, g.hook_lanes));
+        n_slots = n_lanes + 2;
         out_cap = in_cap + (size_t)32 * max_n + 64;
-        for (auto& sl : slots) {
+        for (int i = 0; i < n_lanes; i++)
+            if (kc_ctx_create(&lanes[i], device, nullptr) != KC_OK) return false;
+        for (int i = 0; i < n_slots; i++) {
+            Slot& sl = slots[i];
             if (hipHostMalloc((void**)&sl.h_in, in_cap, hipHostMallocDefault) != hipSuccess) return false;
             if (hipHostMalloc((void**)&sl.h_out, out_cap, hipHostMallocDefault) != hipSuccess) return false;
             sl.in_off.assign(max_n + 1, 0);
@@ -2697,6 +2712,8 @@ struct S2Hook {
             if (sl.h_in) (void)hipHostFree(sl.h_in);
             if (sl.h_out) (void)hipHostFree(sl.h_out);
         }
+        for (kc_ctx* l : lanes)
+            if (l) kc_ctx_destroy(l);
     }
 };
 
@@ -2730,7 +2747,7 @@ int64_t kc_s2_encode_block(kc_ctx* c, uint8_t* dst, uint64_t dst_cap, const uint
     if (src_len < 32) return 0;  // encodeBlock: len < minNonLiteralBlockSize -> 0 (stored by the writer)
     std::call_once(c->hook_once, [c] {
         S2Hook* h = new S2Hook();
-        if (hipSetDevice(c->device) != hipSuccess || !h->init(c->cfg)) { delete h; return; }
+        if (hipSetDevice(c->device) != hipSuccess || !h->init(c->cfg, c->device)) { delete h; return; }
         c->hook = h;
     });
     S2Hook* h = (S2Hook*)c->hook;
@@ -2744,10 +2761,10 @@ int64_t kc_s2_encode_block(kc_ctx* c, uint8_t* dst, uint64_t dst_cap, const uint
             if (!cs.closed && cs.n < h->max_n && cs.in_off[cs.n] + src_len <= h->in_cap) { sl = &cs; break; }
             cs.closed = true;  // full: its leader will run it as it is
             h->cur = -1;
-            h->cv.notify_all();
+            cs.cv.notify_all();
         }
         int fr = -1;
-        for (int i = 0; i < S2Hook::kSlots; i++)
+        for (int i = 0; i < h->n_slots; i++)
             if (!h->slots[i].open) { fr = i; break; }
         if (fr < 0) { h->cv.wait(lk); continue; }
         S2Hook::Slot& ns = h->slots[fr];
@@ -2764,26 +2781,35 @@ int64_t kc_s2_encode_block(kc_ctx* c, uint8_t* dst, uint64_t dst_cap, const uint
     memcpy(sl->h_in + off, src, src_len);  // callers stage their own bytes in parallel
     lk.lock();
     sl->copied++;
-    h->cv.notify_all();
+    if (!leader && (sl->closed || sl->n >= h->max_n)) sl->cv.notify_all();  // (the leader may be waiting for the last bytes, or for a full slot)
     if (leader) {
-        lk.unlock();
-        h->dev.lock();  // while the previous slot is on the device, callers keep joining this one
-        lk.lock();
+        // take a lane; while all of them are on the device, callers keep joining this slot
+        int ln = -1;
+        h->cv.wait(lk, [&] {
+            for (int i = 0; i < h->n_lanes; i++)
+                if (!h->lane_busy[i]) { ln = i; return true; }
+            return false;
+        });
+        h->lane_busy[ln] = true;
         if (h->wait_us > 0 && !sl->closed && sl->n < h->max_n)
-            h->cv.wait_for(lk, std::chrono::microseconds(h->wait_us), [&] { return sl->closed || sl->n >= h->max_n; });
+            sl->cv.wait_for(lk, std::chrono::microseconds(h->wait_us), [&] { return sl->closed || sl->n >= h->max_n; });
         sl->closed = true;
         if (h->cur >= 0 && &h->slots[h->cur] == sl) h->cur = -1;
-        h->cv.wait(lk, [&] { return sl->copied == sl->n; });
+        sl->cv.wait(lk, [&] { return sl->copied == sl->n; });
+        kc_ctx* const lc = h->lanes[ln];
+        lc->cfg = c->cfg;  // the caller's options (variant, kernel family, ...) as they are now
         lk.unlock();
-        const kc_status st = s2_hook_run(c, *sl);
-        h->dev.unlock();
+        const kc_status st = s2_hook_run(lc, *sl);
         h->n_batches++;
         lk.lock();
+        if (st != KC_OK) c->err = lc->err;
+        h->lane_busy[ln] = false;
         sl->status = st;
         sl->done = true;
-        h->cv.notify_all();
+        sl->cv.notify_all();
+        h->cv.notify_all();  // a lane is free
     } else {
-        h->cv.wait(lk, [&] { return sl->done; });
+        sl->cv.wait(lk, [&] { return sl->done; });
     }
     int64_t ret = -1;
     const uint8_t* enc = nullptr;

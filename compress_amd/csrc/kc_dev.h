@@ -12,6 +12,7 @@ struct __attribute__((packed)) kc_u16u { uint16_t v; };
 __device__ __forceinline__ uint64_t ld64(const uint8_t* p) { return ((const kc_u64u*)p)->v; }
 __device__ __forceinline__ void st64(uint8_t* p, uint64_t v) { ((kc_u64u*)p)->v = v; }  // unaligned 8-byte store
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return ((const kc_u32u*)p)->v; }
+__device__ __forceinline__ void st32(uint8_t* p, uint32_t v) { ((kc_u32u*)p)->v = v; }  // unaligned 4-byte store
 __device__ __forceinline__ uint16_t ld16(const uint8_t* p) { return ((const kc_u16u*)p)->v; }
 struct __attribute__((packed)) kc_u128u { uint32_t x, y, z, w; };
 __device__ __forceinline__ uint4 ld128u(const uint8_t* p) {  // unaligned 16-byte load

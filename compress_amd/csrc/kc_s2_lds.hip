@@ -23,6 +23,12 @@
 #include "kc_s2_dev.h"
 
 #define S2L_SRC_MAX 65536
+#ifdef KC_S2_PROF  // diagnostics (tools/s2_lds_prof.hip): shader clocks and event counts per phase of the fused step, block 0 only
+__device__ unsigned long long kc_s2_prof[16];
+#define S2PROF(k) do { const unsigned long long t1__ = __builtin_readcyclecounter(); pacc[k] += t1__ - pt0; pcnt[k]++; pt0 = __builtin_readcyclecounter(); } while (0)
+#else
+#define S2PROF(k) do { } while (0)
+#endif
 #define S2L_POS_MASK 0xFFFFFFu
 #define S2L_TAIL 544  // bytes behind the block in LDS: the fused step loads up to 63 x 8 bytes past a position before it looks at the bounds
 
@@ -299,36 +305,103 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
             const uint32_t hiOnly64 = lane == 0 ? 0u : ~0u;
             uint32_t* const sinkL = &sink[lane];
             const int lenM8 = len - 8;
+            // emitLiteral in one LDS trip: lane 0 stores the tag and the literal bytes that share its 8-byte word (what it stores past a
+            // short literal's end is overwritten by the next emit, which lane 0 starts too); lane k >= 1 the 8 output bytes at 8k, the
+            // last of them moved back to end exactly on the literal's end — it overlaps its neighbour with the same bytes, so no lane
+            // ever stores a byte that a LATER emit's other lane has to overwrite.  Literals above ~500 bytes loop.
+            auto emit_lit2 = [&](int from, int n) -> int {
+                if (n == 0) return 0;
+                const uint32_t m = (uint32_t)(n - 1);
+                int i;
+                uint64_t tag;
+                if (m < 60) { i = 1; tag = m << 2; }
+                else if (m < (1u << 8)) { i = 2; tag = (60u << 2) | ((uint64_t)m << 8); }
+                else if (m < (1u << 16)) { i = 3; tag = (61u << 2) | ((uint64_t)m << 8); }
+                else if (m < (1u << 24)) { i = 4; tag = (62u << 2) | ((uint64_t)m << 8); }
+                else { i = 5; tag = (63u << 2) | ((uint64_t)m << 8); }
+                uint8_t* __restrict__ o = dst + d;
+                const int end = i + n;  // output bytes of this emit
+                for (int ob = 0; ob < end; ob += 512) {
+                    int oo = ob + 8 * lane;                // this lane's 8 output bytes
+                    const bool act = oo < end;
+                    if (oo + 8 > end && oo != 0) oo = end - 8;
+                    const bool tagw = oo == 0;             // (lane 0 of the first pass)
+                    uint64_t v = rd64(from + (tagw ? 0 : oo - i));
+                    if (tagw) v = tag | (v << (8 * i));
+                    if (act) st64(o + oo, v);
+                }
+                return i + n;
+            };
+            // emitCopy / emitRepeat / emitCopyNoRepeat: the two- and three-byte forms (offset below 64 KiB, length up to 64 — nearly all of
+            // them) in one word; the rest through the byte sinks
+            auto emit_copy2 = [&](int offset, int length, bool asRepeat) -> int {
+                if (SNAPPY || !asRepeat) {
+                    if (length <= 64 && offset < 65536) {
+                        uint32_t w;
+                        int n;
+                        if (length >= 12 || offset >= 2048) { w = ((uint32_t)(length - 1) << 2 | 2u) | (uint32_t)offset << 8; n = 3; }
+                        else { w = ((uint32_t)(offset >> 8) << 5 | (uint32_t)(length - 4) << 2 | 1u) | ((uint32_t)offset & 0xFFu) << 8; n = 2; }
+                        if (lane == 0) st32(dst + d, w);
+                        return n;
+                    }
+                } else if (!smallRep || length <= 8 || length >= 12) {
+                    const int l4 = length - 4;
+                    uint32_t w = 0;
+                    int n = 0;
+                    if (l4 <= 4) { w = (uint32_t)l4 << 2 | 1u; n = 2; }
+                    else if (l4 < 8 && offset < 2048) { w = ((uint32_t)(offset >> 8) << 5 | (uint32_t)l4 << 2 | 1u) | ((uint32_t)offset & 0xFFu) << 8; n = 2; }
+                    else if (l4 < (1 << 8) + 4) { w = (5u << 2 | 1u) | (uint32_t)(l4 - 4) << 16; n = 3; }
+                    if (n) {
+                        if (lane == 0) st32(dst + d, w);
+                        return n;
+                    }
+                }
+                return emit_copy_any(offset, length, asRepeat);
+            };
             uint64_t cvL = rd64(s + q);
-            while (!fin && !stored) {
+#ifdef KC_S2_PROF
+            unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_readcyclecounter();
+#endif
+            while (!stored) {
                 if (++rounds > (uint32_t)len + 16u) { stored = true; break; }  // every round advances s: cannot happen; never spin on the device
-                // ---------------- one probe step (encode_all.go:318-412): trip 1, the table ----------------
-                const int nextS = s + ((s - nextEmit) >> SKIP) + 4;
-                if (nextS > sLimT) { fin = true; break; }
-                const uint32_t hL = hashOf(cvL);
-                uint32_t* const tabL = &tab[hL];
-                const uint32_t e1 = *tabL;
-                KC_WAVE_SYNC();
-                *(lane == 0 ? tabL : sinkL) = (uint32_t)s;         // table[hash0] = s
-                KC_WAVE_SYNC();
-                *(lane == 16 ? tabL : sinkL) = (uint32_t)(s + 1);  // table[hash1] = s + 1 (behind the first store: one bucket for both keeps s + 1)
-                KC_WAVE_SYNC();
-                const uint32_t e2 = *tabL;               // group 2: table[hash2] behind the two stores (:401)
-                const uint64_t cvN = rd64(nextS + q);    // the next step's bytes travel with this step's table entries
-                const int cr = s + 1 - repeat;
-                // ---------------- trip 2: the four candidates, verification and both extensions at once ----------------
-                const int cL = g4 == 3 ? cr : (int)((g4 == 2 ? e2 : e1) & S2L_POS_MASK);
-                const uint64_t diff = rd64(cL + off16) ^ rd64(s + soff16);
-                const uint64_t B = ballot64((((uint32_t)diff & hiOnly) | (uint32_t)(diff >> 32)) != 0u);
-                int kind = 0, gs = 0;  // 1 repeat at s+1, 2 match at s, 3 match at s+1, 4 match at s+2 — in the reference's order
+                // ---------------- probe steps (encode_all.go:318-412) up to the first one that ends the scan ----------------
+                uint64_t B, diff;
+                uint32_t* tabL;
+                int cL;
+                for (;;) {
+                    S2PROF(0);  // loop overhead + whatever ran since the last mark
+                    const int nextS = s + ((s - nextEmit) >> SKIP) + 4;
+                    if (nextS > sLimT) { fin = true; break; }
+                    // trip 1, the table
+                    tabL = &tab[hashOf(cvL)];
+                    const uint32_t e1 = *tabL;
+                    KC_WAVE_SYNC();
+                    *(lane == 0 ? tabL : sinkL) = (uint32_t)s;         // table[hash0] = s
+                    KC_WAVE_SYNC();
+                    *(lane == 16 ? tabL : sinkL) = (uint32_t)(s + 1);  // table[hash1] = s + 1 (behind the first store: one bucket for both keeps s + 1)
+                    KC_WAVE_SYNC();
+                    const uint32_t e2 = *tabL;               // group 2: table[hash2] behind the two stores (:401)
+                    const uint64_t cvN = rd64(nextS + q);    // the next step's bytes travel with this step's table entries
+                    // trip 2: the four candidates, verification and both extensions at once
+                    cL = g4 == 3 ? s + 1 - repeat : (int)((g4 == 2 ? e2 : e1) & S2L_POS_MASK);
+                    diff = rd64(cL + off16) ^ rd64(s + soff16);
+                    B = ballot64((((uint32_t)diff & hiOnly) | (uint32_t)(diff >> 32)) != 0u);
+                    S2PROF(1);  // the probe step: hashes, table trip, candidate trip, ballot
+                    if ((~B & 0x0001000100010001ull) != 0ull) break;   // a candidate verified
+                    *(lane == 32 ? tabL : sinkL) = (uint32_t)(s + 2);  // table[hash2] = s + 2
+                    KC_WAVE_SYNC();
+                    s = nextS;
+                    cvL = cvN;
+                }
+                if (fin) break;
+                int kind, gs;  // 1 repeat at s+1, 2 match at s, 3 match at s+1, 4 match at s+2 — in the reference's order
                 if (!((B >> 48) & 1ull)) { kind = 1; gs = 3; }
                 else if (!(B & 1ull)) { kind = 2; gs = 0; }
                 else if (!((B >> 16) & 1ull)) { kind = 3; gs = 1; }
-                else if (!((B >> 32) & 1ull)) { kind = 4; gs = 2; }
+                else { kind = 4; gs = 2; }
                 // table[hash2] = s+2 is skipped when the step ends on the repeat or on the match at s
-                if (kind != 1 && kind != 2) { if (lane == 32) *tabL = (uint32_t)(s + 2); }
+                if (kind > 2) { *(lane == 32 ? tabL : sinkL) = (uint32_t)(s + 2); }
                 KC_WAVE_SYNC();
-                if (kind == 0) { s = nextS; cvL = cvN; continue; }
                 const int p = s + (gs == 3 ? 1 : gs);
                 const int gb = 16 * gs;
                 const int csel = (int)rdlane32((uint32_t)cL, gb);
@@ -361,16 +434,18 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
                     const uint64_t dfw = fwd != 0ull ? rdlane64(diff, gb + 1 + ctz64(fwd)) : 0ull;
                     send = fwd_end(kind == 1 ? p : p - back, p, csel, fwd, dfw, 120);  // (the repeat's backward extension moves only its base, :349-352)
                 }
+                S2PROF(2);  // the match's two ends
                 if (kind == 1) {
                     // ---------------- repeat at s+1 (:336-384) ----------------
                     const int base = p - back;
                     if (d + (base - nextEmit) > bailLim) { stored = true; break; }
                     s = send;
-                    cvL = rd64(s + q);  // issued ahead of the emission work
-                    d += emit_lit(nextEmit, base - nextEmit);
-                    d += emit_copy_any(repeat, s - base, nextEmit > 0);
+                    cvL = rd64(s + q);  // travels with the literal bytes
+                    d += emit_lit2(nextEmit, base - nextEmit);
+                    d += emit_copy2(repeat, s - base, nextEmit > 0);
                     nextEmit = s;
-                    if (s >= sLimit) fin = true;
+                    S2PROF(3);  // emission (repeat)
+                    if (s >= sLimit) { fin = true; break; }
                     continue;
                 }
                 // ---------------- regular match (:387-489) ----------------
@@ -381,32 +456,39 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
                     const int base = ms;
                     repeat = base - cand;
                     s = send;
-                    // the bytes of the immediate re-match test (lane 0: s-2, lane 1: s) and of the probe step behind it, ahead of the emission work
+                    // the bytes of the immediate re-match test (lane 0: s-2, lane 1: s) and of the probe step behind it travel with the literal bytes
                     const uint64_t xL = rd64(s - 2 + (lane == 1 ? 2 : 0));
                     const uint64_t cvP = rd64(s + 1 + q);
-                    if (first) { d += emit_lit(nextEmit, base - nextEmit); first = false; }
-                    d += emit_copy_any(repeat, s - base, false);
+                    if (first) { d += emit_lit2(nextEmit, base - nextEmit); first = false; }
+                    d += emit_copy2(repeat, s - base, false);
                     nextEmit = s;
+                    S2PROF(4);  // emission (literals + copy)
                     if (s >= sLimit) { fin = true; break; }
                     if (d > cpLim) { stored = true; break; }
                     // check for an immediate match, otherwise start the search at s+1 (:474-488)
-                    const uint32_t hx = hashOf(xL);
-                    const uint32_t ec = tab[hx];
+                    uint32_t* const tabX = &tab[hashOf(xL)];
+                    const uint32_t ec = *tabX;
                     KC_WAVE_SYNC();
-                    *(lane == 0 ? &tab[hx] : sinkL) = (uint32_t)(s - 2);  // table[m2Hash] = s - 2
+                    *(lane == 0 ? tabX : sinkL) = (uint32_t)(s - 2);  // table[m2Hash] = s - 2
                     KC_WAVE_SYNC();
-                    *(lane == 1 ? &tab[hx] : sinkL) = (uint32_t)s;        // table[currHash] = s
+                    *(lane == 1 ? tabX : sinkL) = (uint32_t)s;        // table[currHash] = s
                     KC_WAVE_SYNC();
                     cand = (int)(rdlane32(ec, 1) & S2L_POS_MASK);
                     const uint64_t dx = rd64(cand + off64) ^ rd64(s + off64);
                     const uint64_t BX = ballot64((((uint32_t)dx & hiOnly64) | (uint32_t)(dx >> 32)) != 0u);
+                    S2PROF(5);  // the immediate re-match test
                     if (BX & 1ull) { s++; cvL = cvP; break; }
                     ms = s;
                     const uint64_t fw = BX >> 1;
                     const uint64_t dfw = fw != 0ull ? rdlane64(dx, 1 + ctz64(fw)) : 0ull;
                     send = fwd_end(s, s, cand, fw, dfw, 504);
+                    S2PROF(6);  // an immediate match's end
                 }
+                if (fin) break;
             }
+#ifdef KC_S2_PROF
+            if (lane == 0 && bi == 0) for (int k = 0; k < 8; k++) { kc_s2_prof[k] = pacc[k]; kc_s2_prof[8 + k] = pcnt[k]; }
+#endif
         } else
         while (!fin && !stored) {
             if (++rounds > (uint32_t)len + 16u) { stored = true; break; }  // every round advances s: cannot happen; never spin on the device
