@@ -2303,6 +2303,13 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
                                ChunkFeed* feed = nullptr) {
     if (!c || !blk_off || !out_off || (n && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
     if (feed && (framed || n == 0)) { c->err = "chunk feed: bare blocks only"; return KC_ERR_INTERNAL; }
+    // s2.WriterUncompressed: a level of the writer (writer.go:951; encodeBlock returns 0 for it, :455-480): framed only, every block one
+    // uncompressed chunk — served by the LDS-table kernels' stored path (wave-parallel CRC32C + copy), whatever the batch
+    const bool stored_only = level == KC_S2_LEVEL_UNCOMPRESSED;
+    if (stored_only) {
+        if (!framed) { c->err = "KC_S2_LEVEL_UNCOMPRESSED is a level of the framed stream (s2.WriterUncompressed)"; return KC_ERR_BAD_ARG; }
+        level = KC_S2_LEVEL_DEFAULT;
+    }
     if (level < KC_S2_LEVEL_DEFAULT || level > KC_S2_LEVEL_SNAPPY_BEST) { c->err = "unknown S2 level"; return KC_ERR_UNSUPPORTED; }
     if (level >= KC_S2_LEVEL_BEST && feed) { c->err = "the best levels are not chunk-fed"; return KC_ERR_UNSUPPORTED; }
     c->err.clear();
@@ -2345,8 +2352,8 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     // apply to them: an amd64 context (the Go shim's default on amd64 builds) encodes them like any other.
     const int s2var = level >= KC_S2_LEVEL_BEST ? KC_S2_VARIANT_GO : (int)c->cfg.s2_variant;
     // (the LDS kernel keeps positions in 24 bits: a batch with a block of 16 MiB or more goes through the HBM-table kernel whole)
-    const bool lds = (level == KC_S2_LEVEL_DEFAULT || level == KC_S2_LEVEL_SNAPPY) && feed == nullptr && c->cfg.match_path != KC_PATH_HBM &&
-                     maxLen < ((uint64_t)1 << 24) && (c->cfg.match_path == KC_PATH_LDS || (int64_t)n <= c->cfg.s2_lds_max_blocks);
+    const bool lds = stored_only || ((level == KC_S2_LEVEL_DEFAULT || level == KC_S2_LEVEL_SNAPPY) && feed == nullptr && c->cfg.match_path != KC_PATH_HBM &&
+                     maxLen < ((uint64_t)1 << 24) && (c->cfg.match_path == KC_PATH_LDS || (int64_t)n <= c->cfg.s2_lds_max_blocks));
     c->last_path = lds ? KC_PATH_LDS : KC_PATH_HBM;
     kc_status s;
     if ((s = ensure(c, c->unit_off, (n + 1) * 8)) || (s = ensure(c, c->stage_off, (n + 1) * 8)) ||
@@ -2375,6 +2382,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     if (P.spec_w0b < 1) P.spec_w0b = 1;
     P.table_stride = (uint32_t)(kc_s2_table_bytes(level, maxLen, s2var) / 4);
     P.variant = (int32_t)s2var;
+    P.stored_only = stored_only ? 1 : 0;
     if (feed) {
         // the source is still arriving: per chunk, encode + compaction on the chunk's stream behind its H2D copy; frames of chunk k
         // at d_dst + reg[cut[k]], local offsets in out_off[cut[k] + k ...].  The caller synchronises (s2_feed_finish).

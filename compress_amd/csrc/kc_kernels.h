@@ -172,6 +172,7 @@ struct KcS2Params {
     int32_t spec_w0, spec_w0b;  // speculation width after a match (default / better parse)
     int32_t spec_grow;          // after a round without a match: 0 keep, 1 +1, 2 double
     int32_t framed;             // 1: emit s2.Writer chunks (type | len24 | masked CRC32C | body), s2/writer.go:414-451
+    int32_t stored_only;        // framed mode, s2.WriterUncompressed (s2/writer.go:951): every block becomes an uncompressed chunk (type 0x01 | len | CRC32C | bytes)
     int32_t variant;            // levels 0 and 2: 0 = the bytes of the portable Go encoders (encode_all.go; arm64 and noasm builds),
                                 // 1 = the bytes of the amd64 assembly encoders (encode_amd64.go + encodeblock_amd64.s)
 };

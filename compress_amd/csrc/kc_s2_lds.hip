@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_lds_kernel(KcS2Params P) {
     int d = 0;
     bool stored = false;  // encodeBlock returned 0 -> emit everything as one literal
     if (len == 0 && !P.framed) { if (lane == 0) P.out_size[bi] = (uint32_t)hdr; return; }
-    if (len < 32) stored = true;  // minNonLiteralBlockSize (also len == 0 in a framed stream)
+    if (len < 32 || P.stored_only) stored = true;  // minNonLiteralBlockSize (also len == 0 in a framed stream); s2.WriterUncompressed
 
     // emitLiteral(dst[d:], src[from:from+n]) (encode_go.go:80): lane 0 the tag, all lanes the bytes
     // Tag bytes are assembled in a register by every lane (the values are wave-uniform: scalar code) and stored by lane 0 as ONE

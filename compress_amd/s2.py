@@ -12,6 +12,7 @@ def MaxEncodedLen(src_len):
 
 LevelDefault, LevelBetter, LevelSnappy, LevelSnappyBetter = 0, 1, 2, 3  # s2.Encode / EncodeBetter / EncodeSnappy / EncodeSnappyBetter (s2/encode.go:29, 117, 204, 248)
 LevelBest, LevelSnappyBest = 4, 5  # s2.EncodeBest / EncodeSnappyBest (s2/encode.go:146, 278)
+LevelUncompressed = 6              # s2.WriterUncompressed (writer.go:951): a level of the stream writer only — every block an uncompressed chunk
 
 
 class BlockEncoder:
@@ -170,7 +171,10 @@ def WriterSnappyCompat():
     return apply
 
 
-WriterUncompressed = _unsupported("WriterUncompressed")
+def WriterUncompressed():
+    """s2.WriterUncompressed (writer.go:948-956): bypass compression — the stream is uncompressed chunks only (type 0x01 | length |
+    masked CRC32C | bytes; the checksum and the copy run on the device).  A level like the others: a later level option replaces it."""
+    return lambda w: setattr(w, "level", LevelUncompressed)
 
 
 def WriterAddIndex():
@@ -292,7 +296,7 @@ class Writer:
         if self.snappy:  # (*Writer).encodeBlock, writer.go:1053-1091: the Snappy-compatible block encoder of the level
             if self.blockSize > (64 << 10):
                 raise ValueError("s2: block size too large. Must be <= 64K and >=4KB on for snappy compatible output")  # writer.go:982
-            self.level = {LevelDefault: LevelSnappy, LevelBetter: LevelSnappyBetter, LevelBest: LevelSnappyBest}[self.level]
+            self.level = {LevelDefault: LevelSnappy, LevelBetter: LevelSnappyBetter, LevelBest: LevelSnappyBest, LevelUncompressed: LevelUncompressed}[self.level]
         self._enc = BlockEncoder(device, stream, level=self.level, variant=variant)  # variant: see BlockEncoder
         self._device = device
         self._batch = int(batch_bytes)

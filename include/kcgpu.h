@@ -271,6 +271,7 @@ kc_status kc_s2_encode_blocks_dev(kc_ctx* ctx, const uint8_t* d_src, const uint6
 #define KC_S2_LEVEL_SNAPPY 2
 #define KC_S2_LEVEL_BEST 4
 #define KC_S2_LEVEL_SNAPPY_BEST 5
+#define KC_S2_LEVEL_UNCOMPRESSED 6 /* kc_s2_encode_stream_lvl_dev only: s2.WriterUncompressed (s2/writer.go:951) — every block an uncompressed chunk */
 #define KC_S2_LEVEL_SNAPPY_BETTER 3   /* s2.EncodeSnappyBetter (s2/encode.go:248-276: encodeBlockBetterSnappyGo / ...64K, s2/encode_better.go:310-483 / 733-900) */
 kc_status kc_s2_encode_blocks_lvl(kc_ctx* ctx, int level, const uint8_t* src, const uint64_t* blk_off, uint32_t n_blocks,
                                   uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);

@@ -119,7 +119,7 @@ def s2_max_encoded_len(n):
 
 
 @_fanned()
-def s2_encode_blocks(blocks, level=0, framed=False, spec_w0=8, variant=0):
+def s2_encode_blocks(blocks, level=0, framed=False, spec_w0=8, variant=0, stored_only=False):
     """blocks: list of bytes -> list of bytes (uvarint + body, or the framed chunk).  variant 1: KC_S2_VARIANT_AMD64."""
     n = len(blocks)
     off = np.zeros(n + 1, dtype=np.uint64)
@@ -131,7 +131,7 @@ def s2_encode_blocks(blocks, level=0, framed=False, spec_w0=8, variant=0):
         soff[i + 1] = soff[i] + ((s2_max_encoded_len(len(b)) + 8 + 63) & ~63)
     stage = np.zeros(int(soff[n]) + 64, dtype=np.uint8)
     sizes = np.zeros(n, dtype=np.uint32)
-    r = lib().kcemu_s2_encode(level | (variant << 8), int(framed), spec_w0, src.ctypes.data, off.ctypes.data, n, stage.ctypes.data, soff.ctypes.data, sizes.ctypes.data)
+    r = lib().kcemu_s2_encode(level | (variant << 8) | (int(stored_only) << 16), int(framed), spec_w0, src.ctypes.data, off.ctypes.data, n, stage.ctypes.data, soff.ctypes.data, sizes.ctypes.data)
     assert r == 0
     return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)]
 

@@ -71,6 +71,35 @@ def test_s2_lds_framed_chunks_bit_exact(w0):
         assert r == got[i], "chunk %d (len %d): header %r vs %r" % (i, len(blocks[i]), r[:8], got[i][:8])
 
 
+def _crc32c(b):
+    t = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        t.append(c)
+    c = 0xFFFFFFFF
+    for x in b:
+        c = t[(c ^ x) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def uncompressed_chunk(b):
+    """s2.Writer with WriterUncompressed (writer.go:414-451 with encodeBlock returning 0): 0x01 | len24(4 + n) | masked CRC32C | bytes."""
+    c = _crc32c(b)
+    m = (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xFFFFFFFF
+    n = 4 + len(b)
+    return bytes([1, n & 0xFF, (n >> 8) & 0xFF, (n >> 16) & 0xFF]) + m.to_bytes(4, "little") + b
+
+
+def test_s2_lds_uncompressed_chunks():
+    """s2.WriterUncompressed: every block an uncompressed chunk (the kernels' stored path forced), blocks of every size class."""
+    blocks = [b for b in _s2_blocks(small=True) if len(b) > 0]
+    got = emu_lib.s2_encode_blocks(blocks, level=0, framed=True, spec_w0=0, stored_only=True)
+    for i, b in enumerate(blocks):
+        assert got[i] == uncompressed_chunk(b), (i, len(b))
+
+
 @pytest.mark.parametrize("w0", [0, 1, 8])
 def test_s2_lds_reference_regressions(w0):
     """The reference's own encoder regression inputs (s2/testdata/enc_regressions.zip, committed copy)."""

@@ -253,8 +253,22 @@ def test_s2_writer_chunking_and_bytes(oracle, kclib):
         off4 = np.zeros(len(sz4) + 1, dtype=np.uint64); off4[1:] = np.cumsum(sz4)
         ref4, _ = oracle.s2_encode_stream(np.frombuffer(big[:300000], dtype=np.uint8), off4, False, level=lvl)
         assert sink4.getvalue() == b"\xff\x06\x00\x00sNaPpY" + np.asarray(ref4).tobytes(), lvl
-    with pytest.raises(NotImplementedError):
-        s2.NewWriter(io.BytesIO(), s2.WriterUncompressed())
+    # WriterUncompressed (writer.go:948-956): uncompressed chunks only — checksum and copy on the device; a level like the others
+    from test_emu_lds import uncompressed_chunk
+    sink5 = io.BytesIO()
+    w5 = s2.NewWriter(sink5, s2.WriterUncompressed(), s2.WriterBlockSize(64 << 10))
+    w5.Write(big[:300000])
+    w5.Write(b"tail")
+    w5.Close()
+    want5 = b"\xff\x06\x00\x00S2sTwO" + b"".join(uncompressed_chunk(big[i:i + 65536]) for i in range(0, 262144, 65536)) + uncompressed_chunk(big[262144:300000]) + uncompressed_chunk(b"tail")  # (a large Write into an empty buffer goes out whole, writer.go:190-200)
+    assert sink5.getvalue() == want5
+    assert oracle.s2_decode_stream(sink5.getvalue(), 300100) == big[:300000] + b"tail"
+    sink6 = io.BytesIO()
+    w6 = s2.NewWriter(sink6, s2.WriterUncompressed(), s2.WriterBetterCompression())  # the later level option wins
+    w6.Write(big[:100000]); w6.Close()
+    off6 = np.array([0, 100000], dtype=np.uint64)
+    ref6, _ = oracle.s2_encode_stream(np.frombuffer(big[:100000], dtype=np.uint8), off6, True, level=1)
+    assert sink6.getvalue() == ref6.tobytes()
 
 
 def test_s2_device_decoder_roundtrip_and_errors(oracle, kclib):

@@ -28,7 +28,8 @@ int kcemu_s2_encode(int level, int framed, int spec_w0, const uint8_t* src, cons
     P.out_size = out_size;
     P.n_blocks = n;
     P.level = level & 0xFF;
-    P.variant = level >> 8;  // (bits 8+: KC_S2_VARIANT_*)
+    P.variant = (level >> 8) & 0xFF;  // (bits 8..15: KC_S2_VARIANT_*)
+    P.stored_only = (level >> 16) & 1; // (bit 16: s2.WriterUncompressed)
     P.spec_w0 = spec_w0;
     P.framed = framed;
     bool small = false, big = false;
