@@ -538,7 +538,9 @@ void build_dfast_dict_long(const uint8_t* dict, size_t len, int pos_bits, uint32
 
 kc_status check_supported(kc_ctx* c, const kc_zstd_opts* o) {
     if (o->level < KC_SPEED_FASTEST || o->level > KC_SPEED_BEST) { c->err = "unknown encoder level"; return KC_ERR_UNSUPPORTED; }
-    if (o->dict_len > ((uint64_t)1 << 20)) { c->err = "dictionary larger than 1 MiB not served by the device path"; return KC_ERR_UNSUPPORTED; }
+    // (the reference takes any dictionary below 2 GiB as history, zstd/dict.go:27, enc_base.go:160-198; here the dictionary is staged in
+    // front of every unit of a batch, which the scratch budget accounts for — 64 MiB keeps positions inside the LDS kernel's field too)
+    if (o->dict_len > ((uint64_t)64 << 20)) { c->err = "dictionary larger than 64 MiB not served by the device path"; return KC_ERR_UNSUPPORTED; }
     if (o->block_size < 1024 || o->block_size > kMaxCompressedBlockSize || o->window_size < kMinWindowSize) { c->err = "bad block/window size"; return KC_ERR_BAD_ARG; }
     return KC_OK;
 }

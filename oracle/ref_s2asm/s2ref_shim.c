@@ -89,6 +89,14 @@ int64_t s2ref_match_len(const uint8_t* a, uint64_t an, const uint8_t* b, uint64_
     return (int64_t)f[6];
 }
 
+// zstd's matchLen (zstd/matchlen_amd64.s:8; what fastBase.matchlen calls on amd64, zstd/enc_base.go:117-131)
+extern void p9_zstd_matchLen(uint64_t* frame);
+int64_t zstdref_match_len(const uint8_t* a, uint64_t an, const uint8_t* b, uint64_t bn) {
+    uint64_t f[7] = {(uint64_t)(uintptr_t)a, an, an, (uint64_t)(uintptr_t)b, bn, bn, 0};
+    p9_zstd_matchLen(f);
+    return (int64_t)f[6];
+}
+
 static int put_uvarint(uint8_t* dst, uint64_t x) {
     int i = 0;
     while (x >= 0x80) { dst[i++] = (uint8_t)x | 0x80; x >>= 7; }

@@ -120,3 +120,11 @@ def emit_literal(lit: bytes) -> bytes:
 
 def match_len(a: bytes, b: bytes) -> int:
     return int(lib().s2ref_match_len(a, len(a), b, len(b)))
+
+
+def zstd_match_len(a: bytes, b: bytes) -> int:
+    """matchLen of zstd/matchlen_amd64.s (the zstd package's own copy of the routine)."""
+    L = lib()
+    L.zstdref_match_len.restype = C.c_int64
+    L.zstdref_match_len.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    return int(L.zstdref_match_len(a, len(a), b, len(b)))

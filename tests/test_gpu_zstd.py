@@ -181,6 +181,27 @@ def test_with_raw_dictionary_bit_exact(oracle, kclib, dict_id, level):
 
 
 @pytest.mark.parametrize("level", LEVELS_B)
+def test_with_a_dictionary_above_one_mib_bit_exact(oracle, kclib, level):
+    """Raw dictionaries of 1.5 and 3 MiB (the reference takes any dictionary below 2 GiB as history, zstd/dict.go:27; the window still
+    bounds the offsets): units that repeat dictionary content from its start, its middle and its end."""
+    _torch()
+    from compress_amd import zstd
+    big = corpora.corpus("T", 24, 131072, seed=0x5EED0009).tobytes()
+    t = corpora.corpus("T", 4, 131072, first_unit=31).tobytes()
+    for dl in ((3 << 19), (3 << 20)):
+        dct = big[:dl]
+        units = [t[:131072], dct[1000:60000] + t[:30000], dct[dl // 2:dl // 2 + 70000], dct[-50000:] + t[5:5000], t[:100], dct[:131072], t[131072:131072 + 200000]]
+        ubuf, off = corpora.pack_units(units)
+        enc = zstd.NewWriter(None, *_lo(level), zstd.WithEncoderDictRaw(9, dct))
+        out, out_off = enc.EncodeUnits(ubuf, off)
+        ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=_li(level), dict_id=9, dict_content=dct)
+        bad = [i for i in range(len(units))
+               if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != ref[int(ref_off[i]):int(ref_off[i + 1])].tobytes()]
+        assert not bad, (dl, bad)
+        enc.Close()
+
+
+@pytest.mark.parametrize("level", LEVELS_B)
 @pytest.mark.parametrize("which", ["d0", "skewed"])
 def test_with_full_format_dictionary_bit_exact(oracle, kclib, level, which):
     """a16: WithEncoderDict (zstd --train format): dictionary offsets, content as history and the literal Huffman table

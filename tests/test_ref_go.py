@@ -76,6 +76,17 @@ def test_oracle_equals_the_translated_reference_with_a_raw_dictionary(oracle, le
         assert not bad, bad
 
 
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_oracle_equals_the_translated_reference_with_a_dictionary_above_one_mib(oracle, level):
+    big = corpora.corpus("T", 12, 131072, seed=0x5EED0009).tobytes()
+    t = corpora.corpus("T", 2, 131072, first_unit=31).tobytes()
+    dct = big[:3 << 19]
+    units = [t[:131072], dct[1000:60000] + t[:30000], dct[-50000:] + t[5:5000], t[:100]]
+    ref = oracle.ZstdOracle(level=level, dict_id=9, dict_content=dct)
+    bad = [(i, len(u)) for i, u in enumerate(units) if oracle_goref.zstd_encode_all(u, level=level, dict_id=9, dict_content=dct) != ref.encode_all(u)]
+    assert not bad, bad
+
+
 def _ref_inputs(limit):
     out = []
     for name in ("encode-corpus-raw.zip", "comp-crashers.zip", "enc_regressions.zip"):

@@ -61,6 +61,24 @@ def test_oracle_emit_helpers_equal_the_assembly(oracle):
         assert oracle_ref.match_len(a, bytes(b)) == want
 
 
+def test_zstd_matchlen_equals_the_reference_assembly(oracle):
+    """a8: the oracle's matchLen (what every zstd match finder extends matches with; the device's grp_matchlen / wave_matchlen are held
+    to it through the parse tests) == matchLen of zstd/matchlen_amd64.s, assembled into oracle/_ref: lengths through the 8-, 4-, 2- and
+    1-byte tails, first difference at every position."""
+    rng = np.random.default_rng(5)
+    L = oracle.lib()
+    for _ in range(600):
+        n = int(rng.integers(0, 200))
+        a = bytes(rng.integers(0, 3, n, dtype=np.uint8))
+        b = bytearray(a + bytes(rng.integers(0, 3, 40, dtype=np.uint8)))
+        k = int(rng.integers(0, n + 1))
+        if k < n:
+            b[k] ^= 0x40
+        want = next((i for i in range(n) if a[i] != b[i]), n)
+        assert oracle_ref.zstd_match_len(a, bytes(b)) == want
+        assert L.kco_zstd_matchlen(a, n, bytes(b)) == want
+
+
 def test_xxh64_equals_the_reference_assembly(oracle):
     """a15: the oracle's XXH64 == xxhash.Sum64 of the reference's amd64 assembly (zstd/internal/xxhash/xxhash_amd64.s, assembled
     into oracle/_ref like the S2 encoders), at every length through the 32-byte stripe, 8-, 4- and 1-byte tails."""
