@@ -35,6 +35,7 @@ struct KcMatchParams {
                                 // host; else this launch's stamp (entries with another stamp read as empty — at SpeedBetterCompression
                                 // with a dictionary as the dictionary's entry: kc_zstd_match_better.hip, kc_zstd_match.hip)
     const uint8_t* proto;       // device or null: with epoch != 0 and a dictionary, the dictionary's tables (long then short)
+    int32_t lds_any_big;        // SpeedFastest LDS kernels: 1 = the launch has a unit above 128 KiB (the first form runs beside the fused one)
     int32_t lds_split;          // SpeedFastest HBM kernel: 1 = skip the units the LDS-table kernel takes (those that fit KC_ZFAST_LDS_MAX_UNIT)
     int32_t empty_filter;       // SpeedFastest HBM kernel: 1 = skip the table loads of bucket groups the unit has not written yet, while it has
                                 // emitted no sequence (kc_zstd_match.hip; the tables must start empty: no dictionary, no job prefix)

@@ -78,6 +78,7 @@ int kcemu_zfast_parse(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     P.rep1 = rep1;
     P.rep2 = rep2;
     P.stream_mode = stream_mode;
+    for (uint32_t i = 0; i < n; i++) if (unit_off[i + 1] - unit_off[i] > 131072) P.lds_any_big = 1;
     kc_launch_zfast_match_lds(P, proto, 0u, n, nullptr);
     return 0;
 }
