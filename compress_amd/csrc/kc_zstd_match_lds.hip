@@ -27,6 +27,8 @@
 #include "kc_zfast_dev.h"
 
 #define ZL_RB 4096      // source ring bytes (power of two)
+#define ZL_RB_SMALL 65536          // ... of the instantiation for units up to ZL_SMALL_MAX_UNIT bytes without history: table 2^15 x 17 bits
+#define ZL_SMALL_MAX_UNIT 131072   // (positions + 1 below 2^17)
 #define ZL_MIRROR 32    // the first 32 ring bytes are mirrored behind the ring: 24-byte reads never wrap
 #define ZL_BK 4         // bytes in front of a probe / candidate position kept for the backward extension
 #define ZL_AHEAD 1536   // refill (1 KiB per round) while fewer than this many bytes are buffered ahead of s
@@ -51,10 +53,15 @@ __device__ __forceinline__ uint32_t zl_entry(int pos, uint32_t v) { return ((uin
 // proto: null, or primed tables in the HBM kernels' format ((position+1) | tag << pos_bits, tag = top bits of the same hash),
 // converted while loaded: ONE table for all units (dictionary), or one per launch slot (proto_stride = 2^15: the jobs of a
 // WithConcurrentBlocks stream, each primed from its own overlap prefix).
+template <bool SMALL>
 __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P, const uint32_t* __restrict__ proto, uint32_t proto_stride, uint32_t n_launch, bool skip_small) {
-    __shared__ uint32_t tab[1 << ZF_TABLE_BITS];
+    constexpr int RB = SMALL ? ZL_RB_SMALL : ZL_RB;
+    constexpr int AHEAD = SMALL ? 4096 : ZL_AHEAD;
+    __shared__ uint32_t tab[SMALL ? (1 << ZF_TABLE_BITS) / 2 : (1 << ZF_TABLE_BITS)];  // SMALL: 2^15 x u16, (position + 1) & 0xFFFF
+    __shared__ uint32_t hib[SMALL ? (1 << ZF_TABLE_BITS) / 32 : 1];                    // SMALL: bit 16 of position + 1, one bit per entry
     __shared__ uint8_t mark[1 << ZL_MARK_BITS];
-    __shared__ __attribute__((aligned(16))) uint8_t ring[ZL_RB + ZL_MIRROR];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[RB + ZL_MIRROR];
+    uint16_t* const tab16 = (uint16_t*)tab;
     __shared__ uint64_t sbuf[64];  // the last (nseq mod 64) sequences, flushed 64 at a time as one 512-byte store
     __shared__ unsigned long long shareMask;
     const int lane = (int)threadIdx.x;
@@ -67,7 +74,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
     const int hist0 = P.unit_hist != nullptr ? (int)P.unit_hist[u] : P.hist0;  // dictionary content, or a job's overlap prefix
     const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]) - hist0;
     if ((uint32_t)(ulen + hist0) > KC_ZFAST_LDS_MAX_UNIT) return;  // beyond the 26-bit position field (64 MiB): the HBM-table kernel's unit
-    if (skip_small && ulen <= 131072) return;                       // the fused form's unit (kc_zfast_match_lds2_kernel)
+    if (SMALL ? (ulen > ZL_SMALL_MAX_UNIT) : (skip_small && ulen <= ZL_SMALL_MAX_UNIT)) return;  // the other instantiation's unit
     const uint32_t blk0 = P.unit_blk0[u];
     const int bs = P.block_size;
     const int mmo = P.max_match_off;
@@ -78,7 +85,10 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
     const uint8_t* const srcHi = P.src_end;
     if (proto != nullptr) proto += (size_t)ui * proto_stride;
 
-    if (proto == nullptr) {
+    if (SMALL) {
+        for (int i = lane * 4; i < (1 << ZF_TABLE_BITS) / 2; i += 256) *(uint4*)&tab[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < (1 << ZF_TABLE_BITS) / 32; i += 64) hib[i] = 0u;
+    } else if (proto == nullptr) {
         for (int i = lane * 4; i < (1 << ZF_TABLE_BITS); i += 256) *(uint4*)&tab[i] = make_uint4(0, 0, 0, 0);
     } else {
         const int PBh = P.pos_bits;
@@ -95,6 +105,21 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
     }
     KC_WAVE_SYNC();
     LP_DECL;
+    // SMALL: entries are position + 1 in 17 bits and carry no tag — with the source in LDS a candidate is verified on its bytes at the
+    // price of an LDS read; bit 16 lives in `hib` and is only ever set (positions grow), so the first 64 KiB never touch it
+    auto tab_get = [&](uint32_t h, bool hiLive) -> uint32_t {
+        if (!SMALL) return tab[h];
+        uint32_t e = tab16[h];
+        if (hiLive) e |= ((hib[h >> 5] >> (h & 31u)) & 1u) << 16;
+        return e;
+    };
+    auto tab_put = [&](uint32_t h, int pos, uint32_t v) {
+        if (!SMALL) { tab[h] = zl_entry(pos, v); return; }
+        tab16[h] = (uint16_t)(pos + 1);
+        if (pos + 1 >= 65536) atomicOr(&hib[h >> 5], 1u << (h & 31u));
+    };
+    // 16 bytes at unit position x (x - 4 for the callers' [t-4, t+12) windows): from the ring where it holds them (SMALL: 64 KiB of it)
+    auto in_ring = [&](int x, int n, int wlo_, int whi_) -> bool { return SMALL && x + boff >= wlo_ && x + boff + n <= whi_; };
 
     int o1 = P.rep1, o2 = P.rep2;  // {1,4} (blockenc.go:78) or the dictionary's offsets (enc_base.go:189-195)
     bool allDirty = false;  // fastEncoderDict.allDirty: small-input variant (kSearchStrength 7) only until a block > 32 KiB was seen
@@ -136,11 +161,11 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                 LP(7);  // the tail of the previous round: winner broadcast, match extension, sequence emit
                 // ---------------- source window (LDS ring) ----------------
                 if (pend) {  // the refill issued one round ago has landed
-                    const int ro = (whi + 16 * lane) & (ZL_RB - 1);
+                    const int ro = (whi + 16 * lane) & (RB - 1);
                     *(uint4*)(ring + ro) = rf;
-                    if (ro < ZL_MIRROR) *(uint4*)(ring + ZL_RB + ro) = rf;
+                    if (ro < ZL_MIRROR) *(uint4*)(ring + RB + ro) = rf;
                     whi += 1024;
-                    if (whi - wlo > ZL_RB) wlo = whi - ZL_RB;
+                    if (whi - wlo > RB) wlo = whi - RB;
                     pend = false;
                     KC_WAVE_SYNC();
                 }
@@ -150,7 +175,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                     if (w0 < 0) w0 = 0;
                     wlo = whi = w0;
                 }
-                if (whi - sa < ZL_AHEAD) {
+                if (whi - sa < AHEAD) {
                     const uint8_t* q = abase + whi + 16 * lane;
                     rf = make_uint4(0, 0, 0, 0);
                     if (q < srcHi) rf = *(const uint4*)q;  // aligned: never leaves the 16-byte granule of a readable byte
@@ -176,7 +201,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                 if (repOk) {
                     const uint8_t* q = base + repIndex - ZL_BK;
                     repWide = q >= srcLo && q + 16 <= srcHi;
-                    if (repWide) cr = ld128u(q);
+                    if (in_ring(repIndex - ZL_BK, 16, wlo, whi)) { cr = ld128u(ring + ((repIndex - ZL_BK + boff) & (RB - 1))); repWide = true; }
+                    else if (repWide) cr = ld128u(q);
                     else cr.y = ld32(base + repIndex);
                 }
                 const bool doO2 = pendO2;
@@ -186,7 +212,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                 if (doO2 && lane == 0) {  // offset-2 check (enc_fast.go:250), speculatively in the same round trip as the probes
                     const uint8_t* q = base + o2pos;
                     o2Wide = q + 16 <= srcHi;
-                    if (o2Wide) co = ld128u(q);
+                    if (in_ring(o2pos, 16, wlo, whi)) { co = ld128u(ring + ((o2pos + boff) & (RB - 1))); o2Wide = true; }
+                    else if (o2Wide) co = ld128u(q);
                     else co.x = ld32(q);
                 }
                 // R = the 20 source bytes [p-4, p+16): D1:D2 = cv, the rest feeds the fused candidate compares
@@ -195,7 +222,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                     const int a = p + boff - ZL_BK;
                     const int a4 = a & ~3;
                     if (a4 >= wlo && a4 + 24 <= whi) {
-                        const uint8_t* r = ring + (a & (ZL_RB - 1));  // unaligned ds_read_b128 + b32; the mirror keeps the 20 bytes contiguous
+                        const uint8_t* r = ring + (a & (RB - 1));  // unaligned ds_read_b128 + b32; the mirror keeps the 20 bytes contiguous
                         const uint4 r4 = ld128u(r);
                         D0 = r4.x; D1 = r4.y; D2 = r4.z; D3 = r4.w;
                         D4 = ld32(r + 16);
@@ -223,27 +250,30 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                 KC_WAVE_SYNC();
                 uint32_t m0 = (uint32_t)lane, m1 = (uint32_t)lane;
                 if (valid) {
-                    c0 = tab[h0]; c1 = tab[h1];
+                    const bool hiLive = SMALL && s >= 65000;  // (some entry may carry bit 16 once a position + 1 reached 2^16)
+                    c0 = tab_get(h0, hiLive); c1 = tab_get(h1, hiLive);
                     m0 = mark[h0 >> (ZF_TABLE_BITS - ZL_MARK_BITS)]; m1 = mark[h1 >> (ZF_TABLE_BITS - ZL_MARK_BITS)];
                 }
                 LP(2);  // hashes, markers, table entries
                 // candidates: one 16-byte load of [t-4, t+12) each, only where the tag matches
-                const uint32_t e0 = c0 & ZL_POS_MASK, e1 = c1 & ZL_POS_MASK;
+                const uint32_t e0 = SMALL ? c0 : (c0 & ZL_POS_MASK), e1 = SMALL ? c1 : (c1 & ZL_POS_MASK);
                 const int t0 = (int)e0 - 1, t1 = (int)e1 - 1;
-                const bool ok0 = valid && e0 != 0 && (p - t0) < mmo && (c0 >> ZL_PB) == zl_tag((uint32_t)cv);
-                const bool ok1 = valid && e1 != 0 && (p - t1 + 1) < mmo && (c1 >> ZL_PB) == zl_tag((uint32_t)(cv >> 8));
+                const bool ok0 = valid && e0 != 0 && (p - t0) < mmo && (SMALL || (c0 >> ZL_PB) == zl_tag((uint32_t)cv));
+                const bool ok1 = valid && e1 != 0 && (p - t1 + 1) < mmo && (SMALL || (c1 >> ZL_PB) == zl_tag((uint32_t)(cv >> 8)));
                 uint4 ca = make_uint4(0, 0, 0, 0), cb = make_uint4(0, 0, 0, 0);
                 bool wide0 = false, wide1 = false;
                 if (ok0) {
                     const uint8_t* q = base + t0 - ZL_BK;
                     wide0 = q >= srcLo && q + 16 <= srcHi;
-                    if (wide0) ca = ld128u(q);
+                    if (in_ring(t0 - ZL_BK, 16, wlo, whi)) { ca = ld128u(ring + ((t0 - ZL_BK + boff) & (RB - 1))); wide0 = true; }
+                    else if (wide0) ca = ld128u(q);
                     else ca.y = ld32(base + t0);
                 }
                 if (ok1) {
                     const uint8_t* q = base + t1 - ZL_BK;
                     wide1 = q >= srcLo && q + 16 <= srcHi;
-                    if (wide1) cb = ld128u(q);
+                    if (in_ring(t1 - ZL_BK, 16, wlo, whi)) { cb = ld128u(ring + ((t1 - ZL_BK + boff) & (RB - 1))); wide1 = true; }
+                    else if (wide1) cb = ld128u(q);
                     else cb.y = ld32(base + t1);
                 }
                 if (doO2) {
@@ -270,7 +300,7 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                     if (pk & 1u) {
                         int l2 = (int)(pk >> 8);
                         if (!(pk & 2u)) l2 += wave_matchlen(base + s + l2, base + o2pos + l2, blkEnd - (s + l2), lane);
-                        if (lane == 0) tab[h0] = zl_entry(s, (uint32_t)cv);
+                        if (lane == 0) tab_put(h0, s, (uint32_t)cv);
                         KC_WAVE_SYNC();
                         emit(0, l2 - 3, 1u);
                         W = W0;
@@ -334,8 +364,8 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
                 const int f = found ? ctz64(hmc) : 0;
                 const int commitUpTo = found ? f : ((c < nvalid ? c : nvalid) - 1);
                 if (valid && lane <= commitUpTo) {
-                    tab[h0] = zl_entry(p, (uint32_t)cv);
-                    tab[h1] = zl_entry(p + 1, (uint32_t)(cv >> 8));  // program order: wins when h0 == h1
+                    tab_put(h0, p, (uint32_t)cv);
+                    tab_put(h1, p + 1, (uint32_t)(cv >> 8));  // program order: wins when h0 == h1
                 }
                 KC_WAVE_SYNC();
                 LP(5);  // ballots, commit
@@ -736,10 +766,15 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds2_kernel(KcMatchParams P
 
 void kc_launch_zfast_match_lds(const KcMatchParams& P, const uint32_t* proto, uint32_t proto_stride, uint32_t n_launch, hipStream_t st) {
     if (n_launch == 0) return;
-    // spec_w0 0 (the default): units up to 128 KiB without history take the fused-step kernel, the others the first form at width 16
-    const bool fused = P.spec_w0 <= 0 && proto == nullptr && P.hist0 == 0 && P.unit_hist == nullptr && P.job_flags == nullptr;
+    // spec_w0 0 (the default): units up to 128 KiB without history take the instantiation with the source ring (width 16), the others
+    // the first form at width 16; -1: the fused single-step kernel instead (measured slower on text: kept for the record); > 0: the
+    // first form for every unit at that width
+    const bool eligible = proto == nullptr && P.hist0 == 0 && P.unit_hist == nullptr && P.job_flags == nullptr;
+    const bool small = P.spec_w0 == 0 && eligible, fused = P.spec_w0 < 0 && eligible;
     KcMatchParams Q = P;
     if (Q.spec_w0 <= 0) Q.spec_w0 = 16;
     if (fused) hipLaunchKernelGGL(kc_zfast_match_lds2_kernel, dim3(n_launch), dim3(64), 0, st, P, n_launch);
-    if (!fused || P.lds_any_big != 0) hipLaunchKernelGGL(kc_zfast_match_lds_kernel, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, fused);
+    if (small) hipLaunchKernelGGL(kc_zfast_match_lds_kernel<true>, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, true);
+    if (!(fused || small) || P.lds_any_big != 0)
+        hipLaunchKernelGGL(kc_zfast_match_lds_kernel<false>, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, fused || small);
 }

@@ -16,7 +16,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 OPT_S2_LDS_SPEC_W0 = 17
-OPT_LDS_SPEC_W0 = 16
+OPT_LDS_SPEC_W0 = 6
 
 
 def main():
