@@ -764,17 +764,354 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds2_kernel(KcMatchParams P
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// kc_zfast_match_lds3_kernel — four probe steps per round in the fused layout.  The lone wave is issue-bound (~4.7 clocks per
+// instruction, whatever it is), so the round is built for the fewest instructions per step, not for the fewest lanes:
+//  * 16 lanes per step (step k = lanes 16k..16k+15), three groups inside: candidate at s_k (5 lanes), candidate2 at s_k+1 (5 lanes),
+//    repeat at s_k+2 (6 lanes); every lane hashes its own group's position — one hash, one table read, two chunk loads and one compare
+//    instruction stream serve all twelve candidates of the round;
+//  * the table accesses of the four steps are ISSUED in the sequential encoder's order — read_k, store s_k, store s_k+1, k = 0..3 —
+//    and LDS runs one wave's instructions in order, so step k sees what the steps before it wrote with no conflict detection at all;
+//    the stores are speculative: every lane keeps what it read, and the steps behind the first hit are undone by storing those values
+//    back, last step first (a handful of stores, only in rounds that end on a hit before the fourth step);
+//  * one ballot carries the twelve verdicts and the forward lengths (36 / 44 bytes per candidate; longer matches take the generic
+//    matchlen), the reference's order — first step, then repeat, candidate, candidate2 (enc_fast.go:133, 176, 188) — picks the winner.
+// Units up to 128 KiB without history, window not smaller than the unit; table and source ring as in kc_zfast_match_lds2_kernel.
+#define ZF3_K 4
+__global__ __launch_bounds__(64) void kc_zfast_match_lds3_kernel(KcMatchParams P, uint32_t n_launch) {
+    __shared__ uint16_t tab[1 << ZF_TABLE_BITS];          // (position + 1) & 0xFFFF
+    __shared__ uint32_t hib[(1 << ZF_TABLE_BITS) / 32];   // bit 16 of position + 1
+    __shared__ __attribute__((aligned(16))) uint8_t ring[ZF2_RING + ZF2_MIRROR];
+    __shared__ uint64_t sbuf[64];
+    __shared__ uint32_t sink[64];
+    const int lane = (int)threadIdx.x;
+    const uint32_t ui = blockIdx.x;
+    if (ui >= n_launch) return;
+    const uint32_t u = P.unit_list ? P.unit_list[ui] : P.unit_base + ui;
+    const uint8_t* __restrict__ base = P.src + P.unit_off[u];
+    const int boff = (int)((uintptr_t)base & 15);
+    const uint8_t* __restrict__ abase = base - boff;
+    const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]);
+    const int mmo = P.max_match_off;
+    if (ulen > ZF2_MAX_UNIT) return;  // the first form's unit (the launcher sends windows below 128 KiB there too: every offset of these units is inside the window)
+    const uint32_t blk0 = P.unit_blk0[u];
+    const int bs = P.block_size;
+    const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
+    const int nblk = (P.unit_done != nullptr && P.unit_done[u] != 0u) ? 0 : UB.nblk;
+    const bool HIST = ulen > bs || UB.streamU;
+    const uint8_t* const srcHi = P.src_end;
+    for (int i = lane * 8; i < (1 << ZF_TABLE_BITS); i += 512) *(uint4*)&tab[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < (1 << ZF_TABLE_BITS) / 32; i += 64) hib[i] = 0u;
+    KC_WAVE_SYNC();
+
+    const int k4 = lane >> 4, j = lane & 15;
+    const int gi = j >= 10 ? 2 : (j >= 5 ? 1 : 0);  // 0: candidate at s_k, 1: candidate2 at s_k+1, 2: repeat at s_k+2
+    const int jj = j - 5 * gi;                       // 0: the 4 bytes before and at the position; 1..: the 8-byte chunks behind them
+    const int off = jj == 0 ? -4 : 8 * jj - 4;
+    const int soff = gi + off;
+    const int hq = gi == 1 ? 1 : 0;                  // group 1 hashes the bytes at s_k + 1, the others those at s_k
+    const uint32_t hiOnly = jj == 0 ? 0u : ~0u;
+    const bool own0 = j == 0, own1 = j == 5;        // the lanes that store s_k / s_k + 1
+    const int off64 = lane == 0 ? -4 : 8 * lane - 4;
+    const uint32_t hiOnly64 = lane == 0 ? 0u : ~0u;
+    uint32_t* const sinkL = &sink[lane];
+    uint16_t* const sink16 = (uint16_t*)sinkL;
+    const uint64_t VER = 0x0421042104210421ull;      // the verification lanes: bits 0 / 5 / 10 of every step
+    const uint64_t REP = 0x0400040004000400ull;
+
+    const int alen = boff + ulen;
+    int wlo = 0, whi = 0;
+    bool pend = false;
+    uint4 rf = make_uint4(0, 0, 0, 0);
+    auto ring_store = [&](int at, const uint4 v) {
+        const int ro = (at + 16 * lane) & (ZF2_RING - 1);
+        *(uint4*)(ring + ro) = v;
+        if (ro < ZF2_MIRROR) *(uint4*)(ring + ZF2_RING + ro) = v;
+    };
+    auto gload16 = [&](int at) -> uint4 {
+        const uint8_t* qq = abase + at + 16 * lane;
+        return qq < srcHi ? *(const uint4*)qq : make_uint4(0, 0, 0, 0);
+    };
+    auto fill_to = [&](int upto) {
+        if (pend) { ring_store(whi, rf); whi += ZF2_FILL; pend = false; }
+        while (whi < upto && whi < alen) {
+            const uint4 v0 = gload16(whi), v1 = gload16(whi + ZF2_FILL), v2 = gload16(whi + 2 * ZF2_FILL), v3 = gload16(whi + 3 * ZF2_FILL);
+            ring_store(whi, v0); ring_store(whi + ZF2_FILL, v1); ring_store(whi + 2 * ZF2_FILL, v2); ring_store(whi + 3 * ZF2_FILL, v3);
+            whi += 4 * ZF2_FILL;
+        }
+        if (whi - wlo > ZF2_RING) wlo = whi - ZF2_RING;
+        KC_WAVE_SYNC();
+    };
+    auto rd64r = [&](int pos) -> uint64_t { return ld64(ring + ((pos + boff) & (ZF2_RING - 1))); };
+    // a candidate chunk the ring no longer holds (second half of a unit, candidate more than ~60 KiB back): through L2
+    auto cand8g = [&](int c, int o) -> uint64_t {
+        if (o < 0) {
+            const uint32_t hi = ld32(base + c);
+            const uint32_t lo = c >= 4 ? ld32(base + c - 4) : (c > 0 ? ld32(base) << (8 * (4 - c)) : 0u);
+            return (uint64_t)lo | ((uint64_t)hi << 32);
+        }
+        const uint8_t* qq = base + c + o;
+        return qq + 8 <= srcHi ? ld64(qq) : 0ull;
+    };
+
+    int o1 = P.rep1, o2 = P.rep2;
+    for (int b = 0; b < nblk; b++) {
+        const int blkStart = kc_blk_begin(P.blk_start, blk0, b, bs);
+        const int blkEnd = kc_blk_end(P.blk_start, blk0, b, nblk, bs, ulen);
+        const int srcLen = blkEnd - blkStart;
+        const int o1_in = o1, o2_in = o2;
+        uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
+        int nseq = 0, sumLL = 0;
+        uint32_t rounds = 0;
+        int nextEmit = blkStart, s = blkStart;
+        uint32_t firstLL = 0, firstOf = 0;
+        auto emit = [&](int ll, int ml3, uint32_t of) {
+            if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
+            if (lane == 0) sbuf[nseq & 63] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
+            nseq++;
+            sumLL += ll;
+            if ((nseq & 63) == 0) {
+                KC_WAVE_SYNC();
+                sq[nseq - 64 + lane] = sbuf[lane];
+                KC_WAVE_SYNC();
+            }
+        };
+        if (srcLen >= 10) {
+            const int sLimit = blkEnd - 8;
+            bool canRep = false, fin = false, pendO2 = false, haveCv = false;
+            if (whi - (s + boff) < 4 * ZF2_FILL && whi < alen) fill_to(s + boff + 12 * ZF2_FILL);
+            uint64_t cvL = 0;
+            while (!fin) {
+                if (++rounds > (uint32_t)srcLen + 16u) break;  // every round advances s: cannot happen; never spin on the device
+                // ---------------- source window ----------------
+                if (pend) {
+                    ring_store(whi, rf);
+                    whi += ZF2_FILL;
+                    if (whi - wlo > ZF2_RING) wlo = whi - ZF2_RING;
+                    pend = false;
+                    KC_WAVE_SYNC();
+                }
+                // ---------------- the round's positions: s_0 .. s_3 (and s_4 .. s_7 for the bytes of the next round) ----------------
+                int sk[2 * ZF3_K];
+                sk[0] = s;
+                for (int k = 1; k < 2 * ZF3_K; k++) sk[k] = sk[k - 1] + 2 + ((sk[k - 1] - nextEmit) >> 5);
+                int nv = 1;  // steps of this round inside the block (s_0 < sLimit holds)
+                for (int k = 1; k < ZF3_K; k++) if (sk[k] < sLimit) nv = k + 1;
+                if (whi < alen) {  // (long literal runs take long steps: what the round reads ahead is measured from its last step)
+                    const int need = sk[nv - 1] + boff + 64;
+                    const int ahead = whi - need;
+                    if (ahead < ZF2_FILL) {
+                        if (whi < s + boff) { wlo = whi = (s + boff - 64) & ~15; if (wlo < 0) wlo = whi = 0; }
+                        fill_to(need + 8 * ZF2_FILL);
+                        haveCv = false;
+                    } else if (ahead < 5 * ZF2_FILL) {
+                        rf = gload16(whi);
+                        pend = true;
+                    }
+                }
+                const bool prefOk = whi >= alen || sk[2 * ZF3_K - 1] + boff + 16 <= whi;  // the next round's bytes are in the ring already
+                const int skL = k4 == 0 ? sk[0] : (k4 == 1 ? sk[1] : (k4 == 2 ? sk[2] : sk[3]));
+                if (!haveCv) cvL = rd64r(skL + hq);
+                const uint64_t cvN = rd64r((k4 == 0 ? sk[4] : (k4 == 1 ? sk[5] : (k4 == 2 ? sk[6] : sk[7]))) + hq);
+                // ---------------- trip 1: the table, in the sequential encoder's order ----------------
+                const bool hiMode = sk[ZF3_K - 1] + 2 >= 65536;
+                const uint32_t hL = hash6(cvL, ZF_TABLE_BITS);
+                uint16_t* const tp = &tab[hL];
+                const uint32_t* const tp32 = (const uint32_t*)&tab[hL & ~1u];  // the entry is read as half of an aligned word and cut out behind the last store
+                uint32_t* const hp = &hib[hL >> 5];
+                const uint32_t hbit = 1u << (hL & 31u);
+                const uint32_t myVal = (uint32_t)(skL + hq + 1);  // what this lane's group stores: position + 1
+                uint64_t dO = 0;
+                const bool doO2 = pendO2;
+                const int o2pos = s - o2;
+                if (doO2) {
+                    const bool inR = wlo == 0 || o2pos + boff - 4 >= wlo;
+                    dO = (inR ? rd64r(o2pos + off64) : cand8g(o2pos, off64)) ^ rd64r(s + off64);
+                }
+                uint32_t rr[ZF3_K] = {0, 0, 0, 0}, rh[ZF3_K] = {0, 0, 0, 0};  // what the steps read (used only behind the last store: one wait for all)
+#pragma unroll
+                for (int k = 0; k < ZF3_K; k++) {
+                    if (k < nv) {
+                        rr[k] = *tp32;
+                        if (hiMode) rh[k] = *hp;
+                        KC_WAVE_SYNC();
+                        *((k4 == k && own0) ? tp : sink16) = (uint16_t)myVal;   // table[nextHash] = s_k
+                        if (hiMode && sk[k] + 1 >= 65536) atomicOr((k4 == k && own0) ? hp : sinkL, hbit);
+                        KC_WAVE_SYNC();
+                        *((k4 == k && own1) ? tp : sink16) = (uint16_t)myVal;   // table[nextHash2] = s_k + 1
+                        if (hiMode && sk[k] + 2 >= 65536) atomicOr((k4 == k && own1) ? hp : sinkL, hbit);
+                        KC_WAVE_SYNC();
+                    }
+                }
+                uint32_t eOwn = ((k4 == 0 ? rr[0] : (k4 == 1 ? rr[1] : (k4 == 2 ? rr[2] : rr[3]))) >> ((hL & 1u) << 4)) & 0xFFFFu;
+                if (hiMode) eOwn |= (((k4 == 0 ? rh[0] : (k4 == 1 ? rh[1] : (k4 == 2 ? rh[2] : rh[3]))) & hbit) != 0u ? 1u : 0u) << 16;
+                // undo the table stores of steps [from, nv), last first (every lane kept what it read in front of its step's stores)
+                auto undo = [&](int from) {
+                    for (int k = nv - 1; k >= from; k--) {
+                        KC_WAVE_SYNC();
+                        *((k4 == k && own1) ? tp : sink16) = (uint16_t)eOwn;
+                        if (hiMode && !(eOwn >> 16)) atomicAnd((k4 == k && own1) ? hp : sinkL, ~hbit);
+                        KC_WAVE_SYNC();
+                        *((k4 == k && own0) ? tp : sink16) = (uint16_t)eOwn;
+                        if (hiMode && !(eOwn >> 16)) atomicAnd((k4 == k && own0) ? hp : sinkL, ~hbit);
+                        KC_WAVE_SYNC();
+                    }
+                };
+                if (doO2) {
+                    pendO2 = false;
+                    const uint64_t BO = ballot64((((uint32_t)dO & hiOnly64) | (uint32_t)(dO >> 32)) != 0u);
+                    if (!(BO & 1ull)) {  // four equal bytes at s and s - offset2 (enc_fast.go:250): only table[hash(cv)] = s stays
+                        undo(1);
+                        {   // ... and step 0's second store: back to what it read — or, where both stores hit one bucket, to the first store's s + 1
+                            const bool same = rdlane32(hL, 0) == rdlane32(hL, 5);
+                            const uint32_t rv = same ? (uint32_t)(s + 1) : eOwn;
+                            KC_WAVE_SYNC();
+                            *((lane == 5) ? tp : sink16) = (uint16_t)rv;
+                            if (hiMode && !(rv >> 16)) atomicAnd((lane == 5) ? hp : sinkL, ~hbit);
+                            KC_WAVE_SYNC();
+                        }
+                        const uint64_t fw = BO >> 1;
+                        int M;
+                        if (fw != 0ull) M = s + 4 + 8 * ctz64(fw) + (ctz64(rdlane64(dO, 1 + ctz64(fw))) >> 3);
+                        else if (s + 508 >= blkEnd) M = blkEnd;
+                        else M = s + 508 + wave_matchlen(base + s + 508, base + o2pos + 508, blkEnd - (s + 508), lane);
+                        const int l2 = (M < blkEnd ? M : blkEnd) - s;
+                        emit(0, l2 - 3, 1u);
+                        s += l2;
+                        nextEmit = s;
+                        const int tmp = o1; o1 = o2; o2 = tmp;
+                        canRep = nseq > 2;
+                        haveCv = false;
+                        if (s >= sLimit) fin = true;
+                        continue;
+                    }
+                }
+                // ---------------- trip 2: the twelve candidates — verification and both extensions ----------------
+                const int cL = gi == 2 ? skL - o1 + 2 : (int)eOwn - 1;   // (an empty entry gives -1: not a candidate)
+                const bool inRL = wlo == 0 || cL + boff - 4 >= wlo;
+                uint64_t diff = (inRL ? rd64r(cL + off) : cand8g(cL < 0 ? 0 : cL, off)) ^ rd64r(skL + soff);
+                const uint32_t bad = cL < 0 ? ~0u : 0u;
+                const uint64_t B = ballot64(((((uint32_t)diff & hiOnly) | (uint32_t)(diff >> 32)) | bad) != 0u);
+                uint64_t m = ~B & VER;
+                if (nv < ZF3_K) m &= (1ull << (16 * nv)) - 1ull;
+                if (!canRep) m &= ~REP;
+                if (m == 0ull) {  // no candidate verified: all steps of the round stand
+                    s = sk[nv];   // (nv < 4: the step behind the last one is at or past sLimit)
+                    cvL = cvN;
+                    haveCv = prefOk;
+                    if (nv < ZF3_K || s >= sLimit) fin = true;
+                    continue;
+                }
+                const int ks = ctz64(m) >> 4;
+                undo(ks + 1);
+                const uint32_t vb = (uint32_t)(m >> (16 * ks)) & 0x421u;
+                int kind, g;  // 1 repeat at s+2, 2 candidate at s, 3 candidate2 at s+1 — the reference's order (:133, 176, 188)
+                if (vb & 0x400u) { kind = 1; g = 2; }
+                else if (vb & 1u) { kind = 2; g = 0; }
+                else { kind = 3; g = 1; }
+                const int sx = ks == 0 ? sk[0] : (ks == 1 ? sk[1] : (ks == 2 ? sk[2] : sk[3]));
+                const int gb = 16 * ks + 5 * g;
+                const int p = sx + g;
+                int mt = (int)rdlane32((uint32_t)cL, gb);
+                int mEnd;
+                {
+                    const int nch = g == 2 ? 5 : 4;  // forward chunks the group holds
+                    const uint32_t fwd = ((uint32_t)(B >> (gb + 1))) & ((1u << nch) - 1u);
+                    const int span = 4 + 8 * nch;
+                    if (fwd != 0u) {
+                        const int f = __builtin_ctz(fwd);
+                        mEnd = p + 4 + 8 * f + (ctz64(rdlane64(diff, gb + 1 + f)) >> 3);
+                    } else if (p + span >= blkEnd) mEnd = blkEnd;
+                    else mEnd = p + span + wave_matchlen(base + p + span, base + mt + span, blkEnd - (p + span), lane);
+                    if (mEnd > blkEnd) mEnd = blkEnd;
+                }
+                const uint32_t dlo = rdlane32((uint32_t)diff, gb);
+                const int nb = dlo == 0u ? 4 : (__builtin_clz(dlo) >> 3);
+                auto backlen = [&](int kmax) -> int {
+                    if (kmax <= 0) return 0;
+                    if (nb < 4 || kmax <= 4) return nb < kmax ? nb : kmax;
+                    return 4 + wave_backlen(base, p - 4, mt - 4, kmax - 4, lane);
+                };
+                haveCv = false;
+                if (kind == 1) {
+                    // ---------------- repeat at s+2 (:133-173) ----------------
+                    const int length = mEnd - p;
+                    const int sMin = (sx - mmo) > 0 ? (sx - mmo) : 0;
+                    int kmax = mt - sMin;
+                    if (p - (nextEmit + 1) < kmax) kmax = p - (nextEmit + 1);
+                    if (HIST) {
+                        const int cap = (ZF_MAX_MATCH_LENGTH - 3) - (length - 3);
+                        if (cap < kmax) kmax = cap;
+                    }
+                    const int bk = backlen(kmax);
+                    emit(p - bk - nextEmit, length - 3 + bk, 1u);
+                    s = p + length;
+                    nextEmit = s;
+                    if (s >= sLimit) fin = true;
+                    continue;
+                }
+                // ---------------- candidate / candidate2 (:176-247) ----------------
+                o2 = o1;
+                o1 = p - mt;
+                int l = mEnd - p;
+                int ms = p;
+                {
+                    const int tMin = (p - mmo) > 0 ? (p - mmo) : 0;
+                    int kmax = mt - tMin;
+                    if (p - nextEmit < kmax) kmax = p - nextEmit;
+                    if (HIST && (ZF_MAX_MATCH_LENGTH - l) < kmax) kmax = ZF_MAX_MATCH_LENGTH - l;
+                    const int bk = backlen(kmax);
+                    ms -= bk;
+                    mt -= bk;
+                    l += bk;
+                }
+                emit(ms - nextEmit, l - 3, (uint32_t)(ms - mt) + 3u);
+                s = ms + l;
+                nextEmit = s;
+                const bool canRepO2 = HIST ? canRep : (nseq > 2);
+                canRep = nseq > 2;
+                if (s >= sLimit) { fin = true; continue; }
+                pendO2 = canRepO2;
+            }
+        }
+        KC_WAVE_SYNC();
+        if (lane < (nseq & 63)) sq[(nseq & ~63) + lane] = sbuf[lane];
+        KC_WAVE_SYNC();
+        const int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
+        const int nlit = sumLL + extra;
+        const bool rle = nseq == 1 && nlit <= 1 && (int)firstLL == nlit && firstOf - 3u == 1u;
+        const int saved = srcLen - nlit - (srcLen >> 6);
+        uint32_t flags = 0;
+        if (nseq > 0 && !rle && saved < 16) flags |= KC_BF_POP_A;
+        if (P.pop_blk != nullptr && P.pop_blk[blk0 + (uint32_t)b] != 0) flags |= KC_BF_FORCED;
+        const int o1c = o1, o2c = o2;
+        if (flags) { o1 = o1_in; o2 = o2_in; }
+        flags |= rounds << 8;
+        if (lane == 0) {
+            KcBlkMeta m;
+            m.nseq = (uint32_t)nseq;
+            m.nlit = (uint32_t)nlit;
+            m.extra_lits = (uint32_t)extra;
+            m.flags = flags;
+            m.o1_in = (uint32_t)o1_in; m.o2_in = (uint32_t)o2_in;
+            m.o1_out = (uint32_t)o1c; m.o2_out = (uint32_t)o2c;
+            P.meta[blk0 + (uint32_t)b] = m;
+        }
+    }
+}
+
 void kc_launch_zfast_match_lds(const KcMatchParams& P, const uint32_t* proto, uint32_t proto_stride, uint32_t n_launch, hipStream_t st) {
     if (n_launch == 0) return;
-    // spec_w0 0 (the default): units up to 128 KiB without history take the instantiation with the source ring (width 16), the others
-    // the first form at width 16; -1: the fused single-step kernel instead (measured slower on text: kept for the record); > 0: the
-    // first form for every unit at that width
-    const bool eligible = proto == nullptr && P.hist0 == 0 && P.unit_hist == nullptr && P.job_flags == nullptr;
-    const bool small = P.spec_w0 == 0 && eligible, fused = P.spec_w0 < 0 && eligible;
+    // spec_w0 > 0: the first form for every unit at that width.  Units up to 128 KiB without history can take another kernel (the other
+    // units of the launch stay with the first form at width 16): 0 the four-step fused kernel, -1 the single-step fused kernel, -2 the
+    // first form's instantiation with the source ring
+    const bool eligible = P.spec_w0 <= 0 && proto == nullptr && P.hist0 == 0 && P.unit_hist == nullptr && P.job_flags == nullptr && P.max_match_off >= 131072;
     KcMatchParams Q = P;
     if (Q.spec_w0 <= 0) Q.spec_w0 = 16;
-    if (fused) hipLaunchKernelGGL(kc_zfast_match_lds2_kernel, dim3(n_launch), dim3(64), 0, st, P, n_launch);
-    if (small) hipLaunchKernelGGL(kc_zfast_match_lds_kernel<true>, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, true);
-    if (!(fused || small) || P.lds_any_big != 0)
-        hipLaunchKernelGGL(kc_zfast_match_lds_kernel<false>, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, fused || small);
+    if (eligible && P.spec_w0 == 0) hipLaunchKernelGGL(kc_zfast_match_lds3_kernel, dim3(n_launch), dim3(64), 0, st, P, n_launch);
+    if (eligible && P.spec_w0 == -1) hipLaunchKernelGGL(kc_zfast_match_lds2_kernel, dim3(n_launch), dim3(64), 0, st, P, n_launch);
+    if (eligible && P.spec_w0 <= -2) hipLaunchKernelGGL(kc_zfast_match_lds_kernel<true>, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, true);
+    if (!eligible || P.lds_any_big != 0)
+        hipLaunchKernelGGL(kc_zfast_match_lds_kernel<false>, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, eligible);
 }

@@ -124,6 +124,7 @@ static inline unsigned long long __builtin_amdgcn_s_memtime() { return 0; }
 // ---- atomics (one OS thread: plain read-modify-write) ----
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = (T)(o + v); return o; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = (T)(o | v); return o; }
+template <class T> static inline T atomicAnd(T* p, T v) { T o = *p; *p = (T)(o & v); return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
