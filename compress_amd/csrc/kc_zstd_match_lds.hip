@@ -470,648 +470,14 @@ __global__ __launch_bounds__(64) void kc_zfast_match_lds_kernel(KcMatchParams P,
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// kc_zfast_match_lds2_kernel — the "fused step" form of the kernel above for units of at most 128 KiB without history (one EncodeAll of
-// up to two blocks: the latency case), same sequences.  What changes is what sits on the critical path of ONE wave (one instruction
-// per ~4.7 clocks, an LDS round trip ~150 of them, a global one ~950):
-//  * the SOURCE is in LDS too: the table shrinks to 2^15 x 16 bits + one bit per entry (position+1 below 2^17: the low half in a u16,
-//    bit 16 in a 4 KiB bitmap that is only touched once positions pass 64 KiB) = 68 KiB, which leaves a 64 KiB ring (+ mirror) for the
-//    source: every probe, candidate and extension byte of the first block, and of the second block unless the candidate lies more than
-//    ~60 KiB back (then, and for matches longer than the lanes hold, the bytes come through L2 like before);
-//  * without the tag (no room for it) every candidate is verified on its bytes — an LDS read now, and the same read gives both
-//    extensions: a probe step is two dependent LDS trips.  Trip 1: the lanes of groups 0 / 1 hash the bytes at s / s+1 (their own
-//    loads, issued a step ahead) and read their buckets; with an offset-2 test pending (enc_fast.go:250) all 64 lanes also compare
-//    8 bytes each at s and s - offset2.  Then lanes 0 and 16 store s and s+1.  Trip 2: three 16-lane groups — candidate at s, candidate
-//    at s+1, repeat at s+2 — load 8 bytes per lane on both sides: lane 0 of a group the 4 bytes before and at the candidate (backward
-//    extension, verification), lanes 1..15 the 120 bytes behind (matchlen).  One ballot holds the verdicts and the lengths; the
-//    reference's priority (repeat, candidate, candidate2; :133,176,188) picks the winner in scalar code.
-#define ZF2_MAX_UNIT 131072
-#define ZF2_RING 65536
-#define ZF2_MIRROR 576   // the first bytes of the ring again behind it: reads of up to 63 x 8 + 8 bytes from any position never wrap
-#define ZF2_FILL 1024    // bytes per refill (16 per lane)
-__global__ __launch_bounds__(64) void kc_zfast_match_lds2_kernel(KcMatchParams P, uint32_t n_launch) {
-    __shared__ uint16_t tab[1 << ZF_TABLE_BITS];          // (position + 1) & 0xFFFF, 0 with a clear bit below = empty
-    __shared__ uint32_t hib[(1 << ZF_TABLE_BITS) / 32];   // bit 16 of position + 1
-    __shared__ __attribute__((aligned(16))) uint8_t ring[ZF2_RING + ZF2_MIRROR];
-    __shared__ uint64_t sbuf[64];
-    __shared__ uint32_t sink[64];  // where the lanes without a table store of their own write (one store instruction, no exec masking)
-    const int lane = (int)threadIdx.x;
-    const uint32_t ui = blockIdx.x;
-    if (ui >= n_launch) return;
-    const uint32_t u = P.unit_list ? P.unit_list[ui] : P.unit_base + ui;
-    const uint8_t* __restrict__ base = P.src + P.unit_off[u];
-    const int boff = (int)((uintptr_t)base & 15);  // ring positions are relative to the 16-byte aligned abase
-    const uint8_t* __restrict__ abase = base - boff;
-    const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]);
-    if (ulen > ZF2_MAX_UNIT) return;  // the first form's unit
-    const uint32_t blk0 = P.unit_blk0[u];
-    const int bs = P.block_size;
-    const int mmo = P.max_match_off;
-    const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
-    const int nblk = (P.unit_done != nullptr && P.unit_done[u] != 0u) ? 0 : UB.nblk;
-    const bool HIST = ulen > bs || UB.streamU;
-    const uint8_t* const srcHi = P.src_end;
-    for (int i = lane * 8; i < (1 << ZF_TABLE_BITS); i += 512) *(uint4*)&tab[i] = make_uint4(0, 0, 0, 0);
-    for (int i = lane; i < (1 << ZF_TABLE_BITS) / 32; i += 64) hib[i] = 0u;
-    KC_WAVE_SYNC();
-
-    const int g4 = lane >> 4, j16 = lane & 15;
-    const int off16 = j16 == 0 ? -4 : 8 * j16 - 4;  // a lane's 8 bytes inside its 16-lane group: [-4, +4) then [+4, +124) from the position
-    const int pg = g4 < 2 ? g4 : 2;                  // groups 0 / 1: the candidates of s / s+1; group 2 (and 3, idle): the repeat candidate of s+2
-    const int soff16 = pg + off16;
-    const int off64 = lane == 0 ? -4 : 8 * lane - 4; // the offset-2 test: one 64-lane group, [+4, +508)
-    const int q = g4 == 1 ? 1 : 0;                   // group 1 hashes the bytes at s+1, everybody else those at s
-    const uint32_t hiOnly = j16 == 0 ? 0u : ~0u;     // a group's lane 0 verifies on the upper four bytes of its difference only
-    const uint32_t hiOnly64 = lane == 0 ? 0u : ~0u;
-    uint32_t* const sinkL = &sink[lane];
-    uint16_t* const sink16 = (uint16_t*)sinkL;
-
-    // ---- the source ring: abase[wlo, whi) at ring[(x) & (ZF2_RING - 1)] ----
-    const int alen = boff + ulen;
-    int wlo = 0, whi = 0;
-    bool pend = false;
-    uint4 rf = make_uint4(0, 0, 0, 0);
-    auto ring_store = [&](int at, const uint4 v) {
-        const int ro = (at + 16 * lane) & (ZF2_RING - 1);
-        *(uint4*)(ring + ro) = v;
-        if (ro < ZF2_MIRROR) *(uint4*)(ring + ZF2_RING + ro) = v;
-    };
-    auto gload16 = [&](int at) -> uint4 {
-        const uint8_t* qq = abase + at + 16 * lane;
-        return qq < srcHi ? *(const uint4*)qq : make_uint4(0, 0, 0, 0);  // aligned: never leaves the 16-byte granule of a readable byte
-    };
-    auto fill_to = [&](int upto) {  // blocking: until whi >= upto (or the unit's end), four refills per round trip
-        if (pend) { ring_store(whi, rf); whi += ZF2_FILL; pend = false; }
-        while (whi < upto && whi < alen) {
-            const uint4 v0 = gload16(whi), v1 = gload16(whi + ZF2_FILL), v2 = gload16(whi + 2 * ZF2_FILL), v3 = gload16(whi + 3 * ZF2_FILL);
-            ring_store(whi, v0); ring_store(whi + ZF2_FILL, v1); ring_store(whi + 2 * ZF2_FILL, v2); ring_store(whi + 3 * ZF2_FILL, v3);
-            whi += 4 * ZF2_FILL;
-        }
-        if (whi - wlo > ZF2_RING) wlo = whi - ZF2_RING;
-        KC_WAVE_SYNC();
-    };
-    auto rd64r = [&](int pos) -> uint64_t { return ld64(ring + ((pos + boff) & (ZF2_RING - 1))); };
-    // 8 bytes of a candidate chunk at unit position c + off (off = -4: the four bytes before c and the four at c), from the ring, or
-    // through L2 where the ring no longer holds them; positions before the unit's start read as zero (the callers never count them)
-    auto cand8 = [&](int c, int off, bool inRing) -> uint64_t {
-        if (inRing) return rd64r(c + off);
-        if (off < 0) {
-            const uint32_t hi = ld32(base + c);
-            const uint32_t lo = c >= 4 ? ld32(base + c - 4) : (c > 0 ? ld32(base) << (8 * (4 - c)) : 0u);
-            return (uint64_t)lo | ((uint64_t)hi << 32);
-        }
-        const uint8_t* qq = base + c + off;
-        return qq + 8 <= srcHi ? ld64(qq) : 0ull;  // (past the end of the buffer: beyond the block's end too, the length is capped there)
-    };
-
-    int o1 = P.rep1, o2 = P.rep2;
-    for (int b = 0; b < nblk; b++) {
-        const int blkStart = kc_blk_begin(P.blk_start, blk0, b, bs);
-        const int blkEnd = kc_blk_end(P.blk_start, blk0, b, nblk, bs, ulen);
-        const int srcLen = blkEnd - blkStart;
-        const int o1_in = o1, o2_in = o2;
-        uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
-        int nseq = 0, sumLL = 0;
-        uint32_t rounds = 0;
-        int nextEmit = blkStart, s = blkStart;
-        uint32_t firstLL = 0, firstOf = 0;
-        auto emit = [&](int ll, int ml3, uint32_t of) {
-            if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
-            if (lane == 0) sbuf[nseq & 63] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
-            nseq++;
-            sumLL += ll;
-            if ((nseq & 63) == 0) {
-                KC_WAVE_SYNC();
-                sq[nseq - 64 + lane] = sbuf[lane];
-                KC_WAVE_SYNC();
-            }
-        };
-        const int SK = 5;  // kSearchStrength - 1
-        if (srcLen >= 10) {
-            const int sLimit = blkEnd - 8;
-            bool canRep = false, fin = false, pendO2 = false;
-            if (whi - (s + boff) < 4 * ZF2_FILL && whi < alen) fill_to(s + boff + 12 * ZF2_FILL);
-            uint64_t cvL = rd64r(s + q);
-            while (!fin) {
-                if (++rounds > (uint32_t)srcLen + 16u) break;  // every step advances s: cannot happen; never spin on the device
-                // ---------------- source window ----------------
-                if (pend) {  // the refill issued one step ago has landed
-                    ring_store(whi, rf);
-                    whi += ZF2_FILL;
-                    if (whi - wlo > ZF2_RING) wlo = whi - ZF2_RING;
-                    pend = false;
-                    KC_WAVE_SYNC();
-                }
-                if (whi < alen) {
-                    const int ahead = whi - (s + boff);
-                    if (ahead < 2 * ZF2_FILL) {  // a long match ran past what was buffered: restart the ring just behind s, or catch up
-                        if (ahead < 0) { wlo = whi = (s + boff - 64) & ~15; if (wlo < 0) wlo = whi = 0; }
-                        fill_to(s + boff + 12 * ZF2_FILL);
-                        cvL = rd64r(s + q);
-                    } else if (ahead < 6 * ZF2_FILL) {
-                        rf = gload16(whi);
-                        pend = true;
-                    }
-                }
-                // ---------------- trip 1: the table (and the offset-2 test, enc_fast.go:250) ----------------
-                const int nextS = s + 2 + ((s - nextEmit) >> SK);
-                const bool hiMode = s + 2 >= 65536;  // positions + 1 with bit 16: the bitmap is live
-                const uint32_t hL = hash6(cvL, ZF_TABLE_BITS);
-                uint32_t e = tab[hL];
-                if (hiMode) e |= ((hib[hL >> 5] >> (hL & 31u)) & 1u) << 16;
-                const uint64_t cvN = rd64r(nextS + q);  // the next step's bytes travel with this step's table entries
-                if (pendO2) {
-                    pendO2 = false;
-                    const int o2pos = s - o2;
-                    const bool inR = wlo == 0 || o2pos + boff - 4 >= wlo;
-                    const uint64_t dO = cand8(o2pos, off64, inR) ^ rd64r(s + off64);
-                    const uint64_t BO = ballot64((((uint32_t)dO & hiOnly64) | (uint32_t)(dO >> 32)) != 0u);
-                    if (!(BO & 1ull)) {  // four equal bytes at s and s - offset2
-                        const uint64_t fw = BO >> 1;
-                        int M;
-                        if (fw != 0ull) M = s + 4 + 8 * ctz64(fw) + (ctz64(rdlane64(dO, 1 + ctz64(fw))) >> 3);
-                        else if (s + 508 >= blkEnd) M = blkEnd;
-                        else M = s + 508 + wave_matchlen(base + s + 508, base + o2pos + 508, blkEnd - (s + 508), lane);
-                        const int l2 = (M < blkEnd ? M : blkEnd) - s;
-                        KC_WAVE_SYNC();
-                        *(lane == 0 ? &tab[hL] : sink16) = (uint16_t)(s + 1);  // table[hash(cv)] = s (:256)
-                        if (s + 1 >= 65536) atomicOr(lane == 0 ? &hib[hL >> 5] : sinkL, 1u << (hL & 31u));
-                        KC_WAVE_SYNC();
-                        emit(0, l2 - 3, 1u);
-                        s += l2;
-                        nextEmit = s;
-                        const int tmp = o1; o1 = o2; o2 = tmp;
-                        canRep = nseq > 2;
-                        if (s >= sLimit) fin = true;
-                        else cvL = rd64r(s + q);
-                        continue;
-                    }
-                }
-                KC_WAVE_SYNC();
-                *(lane == 0 ? &tab[hL] : sink16) = (uint16_t)(s + 1);    // table[nextHash] = s
-                KC_WAVE_SYNC();
-                *(lane == 16 ? &tab[hL] : sink16) = (uint16_t)(s + 2);   // table[nextHash2] = s + 1 (behind the first store: one bucket for both keeps s + 1)
-                if (hiMode) {
-                    atomicOr((lane == 0 && s + 1 >= 65536) || lane == 16 ? &hib[hL >> 5] : sinkL, 1u << (hL & 31u));
-                }
-                KC_WAVE_SYNC();
-                // ---------------- trip 2: candidate at s, candidate2 at s+1, repeat at s+2 — verification and both extensions ----------------
-                const int repIndex = s - o1 + 2;
-                const int tL = (int)e - 1;
-                const int cL = g4 < 2 ? tL : repIndex;
-                const bool okL = g4 == 0 ? (e != 0u && (s - tL) < mmo) : (g4 == 1 ? (e != 0u && (s - tL + 1) < mmo) : (g4 == 2 && canRep && repIndex >= 0));
-                const bool inRL = wlo == 0 || cL + boff - 4 >= wlo;
-                uint64_t diff = ~0ull;
-                if (okL) diff = cand8(cL, off16, inRL) ^ rd64r(s + soff16);
-                const uint64_t B = ballot64((((uint32_t)diff & hiOnly) | (uint32_t)(diff >> 32)) != 0u);
-                if ((~B & 0x0000000100010001ull) == 0ull) {  // no candidate verified
-                    s = nextS;
-                    cvL = cvN;
-                    if (s >= sLimit) fin = true;
-                    continue;
-                }
-                int kind, gs;  // 1 repeat at s+2, 2 candidate at s, 3 candidate2 at s+1 — the reference's order (:133, 176, 188)
-                if (!((B >> 32) & 1ull)) { kind = 1; gs = 2; }
-                else if (!(B & 1ull)) { kind = 2; gs = 0; }
-                else { kind = 3; gs = 1; }
-                const int gb = 16 * gs;
-                const int p = s + gs;              // (group g sits at s + g for all three)
-                int mt = (int)rdlane32((uint32_t)cL, gb);
-                // forward: the exact common prefix up to the block's end (matchlen, enc_base.go:117-131)
-                int mEnd;
-                {
-                    const uint32_t fwd = ((uint32_t)(B >> gb) >> 1) & 0x7FFFu;
-                    if (fwd != 0u) {
-                        const int f = __builtin_ctz(fwd);
-                        mEnd = p + 4 + 8 * f + (ctz64(rdlane64(diff, gb + 1 + f)) >> 3);
-                    } else if (p + 124 >= blkEnd) mEnd = blkEnd;
-                    else mEnd = p + 124 + wave_matchlen(base + p + 124, base + mt + 124, blkEnd - (p + 124), lane);
-                    if (mEnd > blkEnd) mEnd = blkEnd;
-                }
-                const uint32_t dlo = rdlane32((uint32_t)diff, gb);
-                const int nb = dlo == 0u ? 4 : (__builtin_clz(dlo) >> 3);  // equal bytes going down from p-1 / mt-1, of the 4 the lane holds
-                auto backlen = [&](int kmax) -> int {
-                    if (kmax <= 0) return 0;
-                    if (nb < 4 || kmax <= 4) return nb < kmax ? nb : kmax;
-                    return 4 + wave_backlen(base, p - 4, mt - 4, kmax - 4, lane);
-                };
-                if (kind == 1) {
-                    // ---------------- repeat at s+2 (:133-173) ----------------
-                    const int length = mEnd - p;
-                    const int sMin = (s - mmo) > 0 ? (s - mmo) : 0;
-                    int kmax = mt - sMin;
-                    if (p - (nextEmit + 1) < kmax) kmax = p - (nextEmit + 1);
-                    if (HIST) {
-                        const int cap = (ZF_MAX_MATCH_LENGTH - 3) - (length - 3);
-                        if (cap < kmax) kmax = cap;
-                    }
-                    const int bk = backlen(kmax);
-                    emit(p - bk - nextEmit, length - 3 + bk, 1u);
-                    s = p + length;
-                    nextEmit = s;
-                    if (s >= sLimit) fin = true;
-                    else cvL = rd64r(s + q);
-                    continue;
-                }
-                // ---------------- candidate / candidate2 (:176-247) ----------------
-                o2 = o1;
-                o1 = p - mt;
-                int l = mEnd - p;
-                int ms = p;
-                {
-                    const int tMin = (p - mmo) > 0 ? (p - mmo) : 0;
-                    int kmax = mt - tMin;
-                    if (p - nextEmit < kmax) kmax = p - nextEmit;
-                    if (HIST && (ZF_MAX_MATCH_LENGTH - l) < kmax) kmax = ZF_MAX_MATCH_LENGTH - l;
-                    const int bk = backlen(kmax);
-                    ms -= bk;
-                    mt -= bk;
-                    l += bk;
-                }
-                emit(ms - nextEmit, l - 3, (uint32_t)(ms - mt) + 3u);
-                s = ms + l;
-                nextEmit = s;
-                const bool canRepO2 = HIST ? canRep : (nseq > 2);
-                canRep = nseq > 2;
-                if (s >= sLimit) { fin = true; continue; }
-                pendO2 = canRepO2;
-                cvL = rd64r(s + q);
-            }
-        }
-        KC_WAVE_SYNC();
-        if (lane < (nseq & 63)) sq[(nseq & ~63) + lane] = sbuf[lane];  // the buffered tail of the sequence list
-        KC_WAVE_SYNC();
-        const int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
-        const int nlit = sumLL + extra;
-        const bool rle = nseq == 1 && nlit <= 1 && (int)firstLL == nlit && firstOf - 3u == 1u;
-        const int saved = srcLen - nlit - (srcLen >> 6);
-        uint32_t flags = 0;
-        if (nseq > 0 && !rle && saved < 16) flags |= KC_BF_POP_A;
-        if (P.pop_blk != nullptr && P.pop_blk[blk0 + (uint32_t)b] != 0) flags |= KC_BF_FORCED;
-        const int o1c = o1, o2c = o2;
-        if (flags) { o1 = o1_in; o2 = o2_in; }
-        flags |= rounds << 8;
-        if (lane == 0) {
-            KcBlkMeta m;
-            m.nseq = (uint32_t)nseq;
-            m.nlit = (uint32_t)nlit;
-            m.extra_lits = (uint32_t)extra;
-            m.flags = flags;
-            m.o1_in = (uint32_t)o1_in; m.o2_in = (uint32_t)o2_in;
-            m.o1_out = (uint32_t)o1c; m.o2_out = (uint32_t)o2c;
-            P.meta[blk0 + (uint32_t)b] = m;
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// kc_zfast_match_lds3_kernel — four probe steps per round in the fused layout.  The lone wave is issue-bound (~4.7 clocks per
-// instruction, whatever it is), so the round is built for the fewest instructions per step, not for the fewest lanes:
-//  * 16 lanes per step (step k = lanes 16k..16k+15), three groups inside: candidate at s_k (5 lanes), candidate2 at s_k+1 (5 lanes),
-//    repeat at s_k+2 (6 lanes); every lane hashes its own group's position — one hash, one table read, two chunk loads and one compare
-//    instruction stream serve all twelve candidates of the round;
-//  * the table accesses of the four steps are ISSUED in the sequential encoder's order — read_k, store s_k, store s_k+1, k = 0..3 —
-//    and LDS runs one wave's instructions in order, so step k sees what the steps before it wrote with no conflict detection at all;
-//    the stores are speculative: every lane keeps what it read, and the steps behind the first hit are undone by storing those values
-//    back, last step first (a handful of stores, only in rounds that end on a hit before the fourth step);
-//  * one ballot carries the twelve verdicts and the forward lengths (36 / 44 bytes per candidate; longer matches take the generic
-//    matchlen), the reference's order — first step, then repeat, candidate, candidate2 (enc_fast.go:133, 176, 188) — picks the winner.
-// Units up to 128 KiB without history, window not smaller than the unit; table and source ring as in kc_zfast_match_lds2_kernel.
-#define ZF3_K 4
-__global__ __launch_bounds__(64) void kc_zfast_match_lds3_kernel(KcMatchParams P, uint32_t n_launch) {
-    __shared__ uint16_t tab[1 << ZF_TABLE_BITS];          // (position + 1) & 0xFFFF
-    __shared__ uint32_t hib[(1 << ZF_TABLE_BITS) / 32];   // bit 16 of position + 1
-    __shared__ __attribute__((aligned(16))) uint8_t ring[ZF2_RING + ZF2_MIRROR];
-    __shared__ uint64_t sbuf[64];
-    __shared__ uint32_t sink[64];
-    const int lane = (int)threadIdx.x;
-    const uint32_t ui = blockIdx.x;
-    if (ui >= n_launch) return;
-    const uint32_t u = P.unit_list ? P.unit_list[ui] : P.unit_base + ui;
-    const uint8_t* __restrict__ base = P.src + P.unit_off[u];
-    const int boff = (int)((uintptr_t)base & 15);
-    const uint8_t* __restrict__ abase = base - boff;
-    const int ulen = (int)(P.unit_off[u + 1] - P.unit_off[u]);
-    const int mmo = P.max_match_off;
-    if (ulen > ZF2_MAX_UNIT) return;  // the first form's unit (the launcher sends windows below 128 KiB there too: every offset of these units is inside the window)
-    const uint32_t blk0 = P.unit_blk0[u];
-    const int bs = P.block_size;
-    const KcUnitBlocks UB = kc_unit_blocks(P.blk_start, P.unit_flags, P.unit_blk0, u, ulen, bs, P.stream_mode);
-    const int nblk = (P.unit_done != nullptr && P.unit_done[u] != 0u) ? 0 : UB.nblk;
-    const bool HIST = ulen > bs || UB.streamU;
-    const uint8_t* const srcHi = P.src_end;
-    for (int i = lane * 8; i < (1 << ZF_TABLE_BITS); i += 512) *(uint4*)&tab[i] = make_uint4(0, 0, 0, 0);
-    for (int i = lane; i < (1 << ZF_TABLE_BITS) / 32; i += 64) hib[i] = 0u;
-    KC_WAVE_SYNC();
-
-    const int k4 = lane >> 4, j = lane & 15;
-    const int gi = j >= 10 ? 2 : (j >= 5 ? 1 : 0);  // 0: candidate at s_k, 1: candidate2 at s_k+1, 2: repeat at s_k+2
-    const int jj = j - 5 * gi;                       // 0: the 4 bytes before and at the position; 1..: the 8-byte chunks behind them
-    const int off = jj == 0 ? -4 : 8 * jj - 4;
-    const int soff = gi + off;
-    const int hq = gi == 1 ? 1 : 0;                  // group 1 hashes the bytes at s_k + 1, the others those at s_k
-    const uint32_t hiOnly = jj == 0 ? 0u : ~0u;
-    const bool own0 = j == 0, own1 = j == 5;        // the lanes that store s_k / s_k + 1
-    const int off64 = lane == 0 ? -4 : 8 * lane - 4;
-    const uint32_t hiOnly64 = lane == 0 ? 0u : ~0u;
-    uint32_t* const sinkL = &sink[lane];
-    uint16_t* const sink16 = (uint16_t*)sinkL;
-    const uint64_t VER = 0x0421042104210421ull;      // the verification lanes: bits 0 / 5 / 10 of every step
-    const uint64_t REP = 0x0400040004000400ull;
-
-    const int alen = boff + ulen;
-    int wlo = 0, whi = 0;
-    bool pend = false;
-    uint4 rf = make_uint4(0, 0, 0, 0);
-    auto ring_store = [&](int at, const uint4 v) {
-        const int ro = (at + 16 * lane) & (ZF2_RING - 1);
-        *(uint4*)(ring + ro) = v;
-        if (ro < ZF2_MIRROR) *(uint4*)(ring + ZF2_RING + ro) = v;
-    };
-    auto gload16 = [&](int at) -> uint4 {
-        const uint8_t* qq = abase + at + 16 * lane;
-        return qq < srcHi ? *(const uint4*)qq : make_uint4(0, 0, 0, 0);
-    };
-    auto fill_to = [&](int upto) {
-        if (pend) { ring_store(whi, rf); whi += ZF2_FILL; pend = false; }
-        while (whi < upto && whi < alen) {
-            const uint4 v0 = gload16(whi), v1 = gload16(whi + ZF2_FILL), v2 = gload16(whi + 2 * ZF2_FILL), v3 = gload16(whi + 3 * ZF2_FILL);
-            ring_store(whi, v0); ring_store(whi + ZF2_FILL, v1); ring_store(whi + 2 * ZF2_FILL, v2); ring_store(whi + 3 * ZF2_FILL, v3);
-            whi += 4 * ZF2_FILL;
-        }
-        if (whi - wlo > ZF2_RING) wlo = whi - ZF2_RING;
-        KC_WAVE_SYNC();
-    };
-    auto rd64r = [&](int pos) -> uint64_t { return ld64(ring + ((pos + boff) & (ZF2_RING - 1))); };
-    // a candidate chunk the ring no longer holds (second half of a unit, candidate more than ~60 KiB back): through L2
-    auto cand8g = [&](int c, int o) -> uint64_t {
-        if (o < 0) {
-            const uint32_t hi = ld32(base + c);
-            const uint32_t lo = c >= 4 ? ld32(base + c - 4) : (c > 0 ? ld32(base) << (8 * (4 - c)) : 0u);
-            return (uint64_t)lo | ((uint64_t)hi << 32);
-        }
-        const uint8_t* qq = base + c + o;
-        return qq + 8 <= srcHi ? ld64(qq) : 0ull;
-    };
-
-    int o1 = P.rep1, o2 = P.rep2;
-    for (int b = 0; b < nblk; b++) {
-        const int blkStart = kc_blk_begin(P.blk_start, blk0, b, bs);
-        const int blkEnd = kc_blk_end(P.blk_start, blk0, b, nblk, bs, ulen);
-        const int srcLen = blkEnd - blkStart;
-        const int o1_in = o1, o2_in = o2;
-        uint64_t* __restrict__ sq = P.seqs + (size_t)(blk0 + (uint32_t)b) * P.seq_stride;
-        int nseq = 0, sumLL = 0;
-        uint32_t rounds = 0;
-        int nextEmit = blkStart, s = blkStart;
-        uint32_t firstLL = 0, firstOf = 0;
-        auto emit = [&](int ll, int ml3, uint32_t of) {
-            if (nseq == 0) { firstLL = (uint32_t)ll; firstOf = of; }
-            if (lane == 0) sbuf[nseq & 63] = seq_pack((uint32_t)ll, (uint32_t)ml3, of);
-            nseq++;
-            sumLL += ll;
-            if ((nseq & 63) == 0) {
-                KC_WAVE_SYNC();
-                sq[nseq - 64 + lane] = sbuf[lane];
-                KC_WAVE_SYNC();
-            }
-        };
-        if (srcLen >= 10) {
-            const int sLimit = blkEnd - 8;
-            bool canRep = false, fin = false, pendO2 = false, haveCv = false;
-            if (whi - (s + boff) < 4 * ZF2_FILL && whi < alen) fill_to(s + boff + 12 * ZF2_FILL);
-            uint64_t cvL = 0;
-            while (!fin) {
-                if (++rounds > (uint32_t)srcLen + 16u) break;  // every round advances s: cannot happen; never spin on the device
-                // ---------------- source window ----------------
-                if (pend) {
-                    ring_store(whi, rf);
-                    whi += ZF2_FILL;
-                    if (whi - wlo > ZF2_RING) wlo = whi - ZF2_RING;
-                    pend = false;
-                    KC_WAVE_SYNC();
-                }
-                // ---------------- the round's positions: s_0 .. s_3 (and s_4 .. s_7 for the bytes of the next round) ----------------
-                int sk[2 * ZF3_K];
-                sk[0] = s;
-                for (int k = 1; k < 2 * ZF3_K; k++) sk[k] = sk[k - 1] + 2 + ((sk[k - 1] - nextEmit) >> 5);
-                int nv = 1;  // steps of this round inside the block (s_0 < sLimit holds)
-                for (int k = 1; k < ZF3_K; k++) if (sk[k] < sLimit) nv = k + 1;
-                if (whi < alen) {  // (long literal runs take long steps: what the round reads ahead is measured from its last step)
-                    const int need = sk[nv - 1] + boff + 64;
-                    const int ahead = whi - need;
-                    if (ahead < ZF2_FILL) {
-                        if (whi < s + boff) { wlo = whi = (s + boff - 64) & ~15; if (wlo < 0) wlo = whi = 0; }
-                        fill_to(need + 8 * ZF2_FILL);
-                        haveCv = false;
-                    } else if (ahead < 5 * ZF2_FILL) {
-                        rf = gload16(whi);
-                        pend = true;
-                    }
-                }
-                const bool prefOk = whi >= alen || sk[2 * ZF3_K - 1] + boff + 16 <= whi;  // the next round's bytes are in the ring already
-                const int skL = k4 == 0 ? sk[0] : (k4 == 1 ? sk[1] : (k4 == 2 ? sk[2] : sk[3]));
-                if (!haveCv) cvL = rd64r(skL + hq);
-                const uint64_t cvN = rd64r((k4 == 0 ? sk[4] : (k4 == 1 ? sk[5] : (k4 == 2 ? sk[6] : sk[7]))) + hq);
-                // ---------------- trip 1: the table, in the sequential encoder's order ----------------
-                const bool hiMode = sk[ZF3_K - 1] + 2 >= 65536;
-                const uint32_t hL = hash6(cvL, ZF_TABLE_BITS);
-                uint16_t* const tp = &tab[hL];
-                const uint32_t* const tp32 = (const uint32_t*)&tab[hL & ~1u];  // the entry is read as half of an aligned word and cut out behind the last store
-                uint32_t* const hp = &hib[hL >> 5];
-                const uint32_t hbit = 1u << (hL & 31u);
-                const uint32_t myVal = (uint32_t)(skL + hq + 1);  // what this lane's group stores: position + 1
-                uint64_t dO = 0;
-                const bool doO2 = pendO2;
-                const int o2pos = s - o2;
-                if (doO2) {
-                    const bool inR = wlo == 0 || o2pos + boff - 4 >= wlo;
-                    dO = (inR ? rd64r(o2pos + off64) : cand8g(o2pos, off64)) ^ rd64r(s + off64);
-                }
-                uint32_t rr[ZF3_K] = {0, 0, 0, 0}, rh[ZF3_K] = {0, 0, 0, 0};  // what the steps read (used only behind the last store: one wait for all)
-#pragma unroll
-                for (int k = 0; k < ZF3_K; k++) {
-                    if (k < nv) {
-                        rr[k] = *tp32;
-                        if (hiMode) rh[k] = *hp;
-                        KC_WAVE_SYNC();
-                        *((k4 == k && own0) ? tp : sink16) = (uint16_t)myVal;   // table[nextHash] = s_k
-                        if (hiMode && sk[k] + 1 >= 65536) atomicOr((k4 == k && own0) ? hp : sinkL, hbit);
-                        KC_WAVE_SYNC();
-                        *((k4 == k && own1) ? tp : sink16) = (uint16_t)myVal;   // table[nextHash2] = s_k + 1
-                        if (hiMode && sk[k] + 2 >= 65536) atomicOr((k4 == k && own1) ? hp : sinkL, hbit);
-                        KC_WAVE_SYNC();
-                    }
-                }
-                uint32_t eOwn = ((k4 == 0 ? rr[0] : (k4 == 1 ? rr[1] : (k4 == 2 ? rr[2] : rr[3]))) >> ((hL & 1u) << 4)) & 0xFFFFu;
-                if (hiMode) eOwn |= (((k4 == 0 ? rh[0] : (k4 == 1 ? rh[1] : (k4 == 2 ? rh[2] : rh[3]))) & hbit) != 0u ? 1u : 0u) << 16;
-                // undo the table stores of steps [from, nv), last first (every lane kept what it read in front of its step's stores)
-                auto undo = [&](int from) {
-                    for (int k = nv - 1; k >= from; k--) {
-                        KC_WAVE_SYNC();
-                        *((k4 == k && own1) ? tp : sink16) = (uint16_t)eOwn;
-                        if (hiMode && !(eOwn >> 16)) atomicAnd((k4 == k && own1) ? hp : sinkL, ~hbit);
-                        KC_WAVE_SYNC();
-                        *((k4 == k && own0) ? tp : sink16) = (uint16_t)eOwn;
-                        if (hiMode && !(eOwn >> 16)) atomicAnd((k4 == k && own0) ? hp : sinkL, ~hbit);
-                        KC_WAVE_SYNC();
-                    }
-                };
-                if (doO2) {
-                    pendO2 = false;
-                    const uint64_t BO = ballot64((((uint32_t)dO & hiOnly64) | (uint32_t)(dO >> 32)) != 0u);
-                    if (!(BO & 1ull)) {  // four equal bytes at s and s - offset2 (enc_fast.go:250): only table[hash(cv)] = s stays
-                        undo(1);
-                        {   // ... and step 0's second store: back to what it read — or, where both stores hit one bucket, to the first store's s + 1
-                            const bool same = rdlane32(hL, 0) == rdlane32(hL, 5);
-                            const uint32_t rv = same ? (uint32_t)(s + 1) : eOwn;
-                            KC_WAVE_SYNC();
-                            *((lane == 5) ? tp : sink16) = (uint16_t)rv;
-                            if (hiMode && !(rv >> 16)) atomicAnd((lane == 5) ? hp : sinkL, ~hbit);
-                            KC_WAVE_SYNC();
-                        }
-                        const uint64_t fw = BO >> 1;
-                        int M;
-                        if (fw != 0ull) M = s + 4 + 8 * ctz64(fw) + (ctz64(rdlane64(dO, 1 + ctz64(fw))) >> 3);
-                        else if (s + 508 >= blkEnd) M = blkEnd;
-                        else M = s + 508 + wave_matchlen(base + s + 508, base + o2pos + 508, blkEnd - (s + 508), lane);
-                        const int l2 = (M < blkEnd ? M : blkEnd) - s;
-                        emit(0, l2 - 3, 1u);
-                        s += l2;
-                        nextEmit = s;
-                        const int tmp = o1; o1 = o2; o2 = tmp;
-                        canRep = nseq > 2;
-                        haveCv = false;
-                        if (s >= sLimit) fin = true;
-                        continue;
-                    }
-                }
-                // ---------------- trip 2: the twelve candidates — verification and both extensions ----------------
-                const int cL = gi == 2 ? skL - o1 + 2 : (int)eOwn - 1;   // (an empty entry gives -1: not a candidate)
-                const bool inRL = wlo == 0 || cL + boff - 4 >= wlo;
-                uint64_t diff = (inRL ? rd64r(cL + off) : cand8g(cL < 0 ? 0 : cL, off)) ^ rd64r(skL + soff);
-                const uint32_t bad = cL < 0 ? ~0u : 0u;
-                const uint64_t B = ballot64(((((uint32_t)diff & hiOnly) | (uint32_t)(diff >> 32)) | bad) != 0u);
-                uint64_t m = ~B & VER;
-                if (nv < ZF3_K) m &= (1ull << (16 * nv)) - 1ull;
-                if (!canRep) m &= ~REP;
-                if (m == 0ull) {  // no candidate verified: all steps of the round stand
-                    s = sk[nv];   // (nv < 4: the step behind the last one is at or past sLimit)
-                    cvL = cvN;
-                    haveCv = prefOk;
-                    if (nv < ZF3_K || s >= sLimit) fin = true;
-                    continue;
-                }
-                const int ks = ctz64(m) >> 4;
-                undo(ks + 1);
-                const uint32_t vb = (uint32_t)(m >> (16 * ks)) & 0x421u;
-                int kind, g;  // 1 repeat at s+2, 2 candidate at s, 3 candidate2 at s+1 — the reference's order (:133, 176, 188)
-                if (vb & 0x400u) { kind = 1; g = 2; }
-                else if (vb & 1u) { kind = 2; g = 0; }
-                else { kind = 3; g = 1; }
-                const int sx = ks == 0 ? sk[0] : (ks == 1 ? sk[1] : (ks == 2 ? sk[2] : sk[3]));
-                const int gb = 16 * ks + 5 * g;
-                const int p = sx + g;
-                int mt = (int)rdlane32((uint32_t)cL, gb);
-                int mEnd;
-                {
-                    const int nch = g == 2 ? 5 : 4;  // forward chunks the group holds
-                    const uint32_t fwd = ((uint32_t)(B >> (gb + 1))) & ((1u << nch) - 1u);
-                    const int span = 4 + 8 * nch;
-                    if (fwd != 0u) {
-                        const int f = __builtin_ctz(fwd);
-                        mEnd = p + 4 + 8 * f + (ctz64(rdlane64(diff, gb + 1 + f)) >> 3);
-                    } else if (p + span >= blkEnd) mEnd = blkEnd;
-                    else mEnd = p + span + wave_matchlen(base + p + span, base + mt + span, blkEnd - (p + span), lane);
-                    if (mEnd > blkEnd) mEnd = blkEnd;
-                }
-                const uint32_t dlo = rdlane32((uint32_t)diff, gb);
-                const int nb = dlo == 0u ? 4 : (__builtin_clz(dlo) >> 3);
-                auto backlen = [&](int kmax) -> int {
-                    if (kmax <= 0) return 0;
-                    if (nb < 4 || kmax <= 4) return nb < kmax ? nb : kmax;
-                    return 4 + wave_backlen(base, p - 4, mt - 4, kmax - 4, lane);
-                };
-                haveCv = false;
-                if (kind == 1) {
-                    // ---------------- repeat at s+2 (:133-173) ----------------
-                    const int length = mEnd - p;
-                    const int sMin = (sx - mmo) > 0 ? (sx - mmo) : 0;
-                    int kmax = mt - sMin;
-                    if (p - (nextEmit + 1) < kmax) kmax = p - (nextEmit + 1);
-                    if (HIST) {
-                        const int cap = (ZF_MAX_MATCH_LENGTH - 3) - (length - 3);
-                        if (cap < kmax) kmax = cap;
-                    }
-                    const int bk = backlen(kmax);
-                    emit(p - bk - nextEmit, length - 3 + bk, 1u);
-                    s = p + length;
-                    nextEmit = s;
-                    if (s >= sLimit) fin = true;
-                    continue;
-                }
-                // ---------------- candidate / candidate2 (:176-247) ----------------
-                o2 = o1;
-                o1 = p - mt;
-                int l = mEnd - p;
-                int ms = p;
-                {
-                    const int tMin = (p - mmo) > 0 ? (p - mmo) : 0;
-                    int kmax = mt - tMin;
-                    if (p - nextEmit < kmax) kmax = p - nextEmit;
-                    if (HIST && (ZF_MAX_MATCH_LENGTH - l) < kmax) kmax = ZF_MAX_MATCH_LENGTH - l;
-                    const int bk = backlen(kmax);
-                    ms -= bk;
-                    mt -= bk;
-                    l += bk;
-                }
-                emit(ms - nextEmit, l - 3, (uint32_t)(ms - mt) + 3u);
-                s = ms + l;
-                nextEmit = s;
-                const bool canRepO2 = HIST ? canRep : (nseq > 2);
-                canRep = nseq > 2;
-                if (s >= sLimit) { fin = true; continue; }
-                pendO2 = canRepO2;
-            }
-        }
-        KC_WAVE_SYNC();
-        if (lane < (nseq & 63)) sq[(nseq & ~63) + lane] = sbuf[lane];
-        KC_WAVE_SYNC();
-        const int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;
-        const int nlit = sumLL + extra;
-        const bool rle = nseq == 1 && nlit <= 1 && (int)firstLL == nlit && firstOf - 3u == 1u;
-        const int saved = srcLen - nlit - (srcLen >> 6);
-        uint32_t flags = 0;
-        if (nseq > 0 && !rle && saved < 16) flags |= KC_BF_POP_A;
-        if (P.pop_blk != nullptr && P.pop_blk[blk0 + (uint32_t)b] != 0) flags |= KC_BF_FORCED;
-        const int o1c = o1, o2c = o2;
-        if (flags) { o1 = o1_in; o2 = o2_in; }
-        flags |= rounds << 8;
-        if (lane == 0) {
-            KcBlkMeta m;
-            m.nseq = (uint32_t)nseq;
-            m.nlit = (uint32_t)nlit;
-            m.extra_lits = (uint32_t)extra;
-            m.flags = flags;
-            m.o1_in = (uint32_t)o1_in; m.o2_in = (uint32_t)o2_in;
-            m.o1_out = (uint32_t)o1c; m.o2_out = (uint32_t)o2c;
-            P.meta[blk0 + (uint32_t)b] = m;
-        }
-    }
-}
-
 void kc_launch_zfast_match_lds(const KcMatchParams& P, const uint32_t* proto, uint32_t proto_stride, uint32_t n_launch, hipStream_t st) {
     if (n_launch == 0) return;
-    // spec_w0 > 0: the first form for every unit at that width.  Units up to 128 KiB without history can take another kernel (the other
-    // units of the launch stay with the first form at width 16): 0 the four-step fused kernel, -1 the single-step fused kernel, -2 the
-    // first form's instantiation with the source ring
-    const bool eligible = P.spec_w0 <= 0 && proto == nullptr && P.hist0 == 0 && P.unit_hist == nullptr && P.job_flags == nullptr && P.max_match_off >= 131072;
+    // spec_w0 0: units up to 128 KiB without history through the instantiation with the source ring (the other units of the launch stay
+    // with the tagged form); measured no faster than the tagged form on text — the kernel is issue-bound, DESIGN.md 4.1c — so not the default
+    const bool small = P.spec_w0 <= 0 && proto == nullptr && P.hist0 == 0 && P.unit_hist == nullptr && P.job_flags == nullptr;
     KcMatchParams Q = P;
     if (Q.spec_w0 <= 0) Q.spec_w0 = 16;
-    if (eligible && P.spec_w0 == 0) hipLaunchKernelGGL(kc_zfast_match_lds3_kernel, dim3(n_launch), dim3(64), 0, st, P, n_launch);
-    if (eligible && P.spec_w0 == -1) hipLaunchKernelGGL(kc_zfast_match_lds2_kernel, dim3(n_launch), dim3(64), 0, st, P, n_launch);
-    if (eligible && P.spec_w0 <= -2) hipLaunchKernelGGL(kc_zfast_match_lds_kernel<true>, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, true);
-    if (!eligible || P.lds_any_big != 0)
-        hipLaunchKernelGGL(kc_zfast_match_lds_kernel<false>, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, eligible);
+    if (small) hipLaunchKernelGGL(kc_zfast_match_lds_kernel<true>, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, true);
+    if (!small || P.lds_any_big != 0)
+        hipLaunchKernelGGL(kc_zfast_match_lds_kernel<false>, dim3(n_launch), dim3(64), 0, st, Q, proto, proto_stride, n_launch, small);
 }

@@ -148,7 +148,7 @@ typedef enum {
     KC_OPT_S2_LDS_MAX_BLOCKS = 3,    /* KC_S2_LDS_MAX_BLOCKS      auto: s2 block batches of at most this many blocks take KC_PATH_LDS */
     KC_OPT_SPEC_W0 = 4,              /* KC_SPEC_W0                HBM kernels: probe steps per round after a match (-1: per-level default) */
     KC_OPT_SPEC_GROW = 5,            /* KC_SPEC_GROW              HBM kernels: width after a miss: 0 keep, 1 +1, 2 double (-1: default) */
-    KC_OPT_LDS_SPEC_W0 = 6,          /* KC_LDS_SPEC_W0            SpeedFastest LDS kernels: 0 (default) = units up to 128 KiB without history take the fused-step kernel; else the first form's probe steps per round after a match (doubles on a miss, max 64) */
+    KC_OPT_LDS_SPEC_W0 = 6,          /* KC_LDS_SPEC_W0            SpeedFastest LDS kernel: probe steps per round after a match (doubles on a miss, max 64; default 16); 0 = units up to 128 KiB without history through the source-ring instantiation at 16 */
     KC_OPT_S2_LDS_SPEC_W0 = 17,      /* KC_S2_LDS_SPEC_W0         S2 LDS kernel: the same; blocks up to 64 KiB: 0 (default) the fused wave-uniform step, 1 its first form */
     KC_OPT_HOST_SERIAL = 7,          /* KC_HOST_SERIAL            host-buffer entry points: no pipelining (copy, encode, copy) */
     KC_OPT_HOST_PIPE_MIB = 8,        /* KC_HOST_PIPE_MIB          host-buffer entry points: sub-batch size of the three-stage pipeline */

@@ -127,8 +127,8 @@ def _zfast_units(big=True):
 @pytest.mark.parametrize("w0", [0, 1, 8, 64])
 def test_zfast_lds_parse_matches_oracle(w0):
     """kc_zfast_match_lds_kernel: the sequence list of every block equals the oracle's fastEncoder (EncodeNoHist for
-    one-block units, Encode with history for longer ones), at every speculation width; 0: units up to 128 KiB through the fused-step
-    kernel (kc_zfast_match_lds2_kernel: 16-bit table + ring source window), the longer ones of the same launch through the first form."""
+    one-block units, Encode with history for longer ones), at every speculation width; 0: units up to 128 KiB through the instantiation
+    with the source in a 64 KiB LDS ring and the untagged 17-bit table, the longer ones of the same launch through the tagged form."""
     units = _zfast_units(big=w0 in (0, 64))
     got = emu_lib.zfast_parse(units, spec_w0=w0)
     bi = 0
