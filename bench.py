@@ -210,12 +210,13 @@ def main():
     ap.add_argument("--kind", default=None, help="corpus override (T|H|J|M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive host-buffer measurement after the timed region")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="zstd only: two contexts on two streams, the match finder of step i+1 under the entropy stage of step i. "
-                         "Measured on MI355X: round 1 184.0 vs 184.7 ms/step (the kernels did not co-reside); round 2, with the two "
-                         "streams in different hardware-queue pools, the entropy stage does run under the next match finder and the "
-                         "match finder loses more than the entropy stage hides (C2 167.9 vs 162.6 ms/step, C3 344.0 vs 317.3): both "
-                         "compete for the same DRAM transaction queue.  The default is one context.")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="zstd: ONE context instead of two.  Default (round 4): two contexts on two streams, the match finder of step i+1 "
+                         "under the entropy stage of step i — every step still encodes the whole batch and all K steps end inside the timed "
+                         "region.  Measured on MI355X: round 1 184.0 vs 184.7 ms/step (the kernels did not co-reside); round 2 a loss (C2 "
+                         "167.9 vs 162.6: both compete for the DRAM transaction queue); round 4, without the per-batch table clear (epoch "
+                         "stamps), a gain: C2 152.2 vs 156.9 ms/step on one box (profiles/r04_pipeline_ab.json).")
+    ap.set_defaults(pipeline=True)
     ap.add_argument("--no-device-verify", action="store_true",
                     help="skip the on-device round trip (decode ALL frames on the device + compare with the input)")
     ap.add_argument("--gather", default="root", choices=["root", "none"],
@@ -417,6 +418,9 @@ def main():
                 "kernel_ms": round(k_match, 3), "table_prep_ms": round(k_prep, 3), "entropy_kernel_ms": round(k_entropy, 3), "pipeline_kernel_ms": round(k_total, 3),
                 "pipeline_frac": round(algo_bytes / (k_total / 1000.0) / 1e9 / HBM_PEAK_GBS, 5),
                 "read_only_frac": round(in_bytes / (k_match / 1000.0) / 1e9 / HBM_PEAK_GBS, 5)}
+    if npipe == 2:  # two steps in flight: the event brackets of one step's kernels contain the other step's work
+        roofline["overlap_note"] = ("two contexts: kernel_ms is the match finder's duration WITH the previous step's entropy stage running beside it (alone: "
+                                    "--no-pipeline); entropy_kernel_ms / pipeline_kernel_ms span the match finder they run under and do not add up to ms_per_step")
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement of the reference on the host threads + byte compare ----
     cpu = None
