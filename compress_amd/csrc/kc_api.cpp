@@ -88,7 +88,7 @@ struct Plan {
 struct KcCfg {
     int64_t match_path = KC_PATH_AUTO;
     int64_t zfast_lds_max_units = 768;    // auto: SpeedFastest batches up to this many units take the LDS-table kernel (profiles/r03_crossover_zfast.csv)
-    int64_t s2_lds_max_blocks = 768;      // auto: s2.Encode / EncodeSnappy batches up to this many blocks (profiles/r03_crossover_s2.csv)
+    int64_t s2_lds_max_blocks = 1280;     // auto: s2.Encode / EncodeSnappy batches up to this many blocks (profiles/r04_crossover_s2.csv: the LDS kernel 2.8 ms per 256 blocks, the HBM kernel ~16.5 ms up to 2 048)
     int64_t spec_w0 = -1, spec_grow = -1; // HBM-table kernels: speculation width after a match / growth policy; -1 = the per-level defaults
     int64_t lds_spec_w0 = 16;             // SpeedFastest LDS-table kernel: probe steps per round after a match (doubles on a miss up to 64); 0 = units up to 128 KiB without history through the instantiation with the source in a 64 KiB LDS ring (untagged 17-bit table): same time on text
     int64_t s2_lds_spec_w0 = 0;           // S2 LDS-table kernel: the same; blocks held in LDS: 0 = the fused wave-uniform step (two LDS round trips per step), 1 = its first form
