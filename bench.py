@@ -210,13 +210,13 @@ def main():
     ap.add_argument("--kind", default=None, help="corpus override (T|H|J|M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive host-buffer measurement after the timed region")
-    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
-                    help="zstd: ONE context instead of two.  Default (round 4): two contexts on two streams, the match finder of step i+1 "
-                         "under the entropy stage of step i — every step still encodes the whole batch and all K steps end inside the timed "
-                         "region.  Measured on MI355X: round 1 184.0 vs 184.7 ms/step (the kernels did not co-reside); round 2 a loss (C2 "
-                         "167.9 vs 162.6: both compete for the DRAM transaction queue); round 4, without the per-batch table clear (epoch "
-                         "stamps), a gain: C2 152.2 vs 156.9 ms/step on one box (profiles/r04_pipeline_ab.json).")
-    ap.set_defaults(pipeline=True)
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=None,
+                    help="zstd: two contexts on two streams, the match finder of step i+1 under the entropy stage of step i — every step still "
+                         "encodes the whole batch and all K steps end inside the timed region.  Default for C2 since round 4 (without the "
+                         "per-batch table clear it is a gain there: 152.2 vs 156.9 and 154.5 vs 156.6 ms/step on two boxes, "
+                         "profiles/r04_pipeline_ab.json; round 2 measured a loss, round 1 no overlap at all); not for the other "
+                         "configurations (C3 / C5: no gain; C2H: 3.9 vs 2.9 ms; B4: a second set of 70 GB table slots).")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context: steps back to back on one stream")
     ap.add_argument("--no-device-verify", action="store_true",
                     help="skip the on-device round trip (decode ALL frames on the device + compare with the input)")
     ap.add_argument("--gather", default="root", choices=["root", "none"],
@@ -239,6 +239,8 @@ def main():
     ap.add_argument("--also-steps", type=int, default=3)
     ap.add_argument("--path", default="auto", choices=["auto", "hbm", "lds"], help="kernel family of SpeedFastest / s2.Encode (KC_OPT_MATCH_PATH)")
     args = ap.parse_args()
+    if args.pipeline is None:
+        args.pipeline = args.config == "C2"
     cfg = dict(CONFIGS[args.config])
     if args.gib is not None:
         cfg["gib"] = args.gib
@@ -536,12 +538,15 @@ def main():
             cfg["what"], cfg["gib"], kind, UNIT >> 10,
             "blocks" if is_s2 else "units (2 x 64 KiB blocks with history)" if cfg["level"] == 1 else "units",
             "" if not dict_content else ", dictionary = 64 KiB of corpus 'T'")
+        # two contexts complete their steps in alternation (one context's step ends shortly after the other's): the spread is taken over
+        # consecutive PAIRS of steps, which is what a step costs in that mode
+        walls_s = [(walls[i] + walls[i + 1]) / 2.0 for i in range(len(walls) - 1)] if (npipe == 2 and len(walls) > 1) else walls
         line = {
             "metric": METRIC if args.config in ("C2", "C2H") else "encode MB/s (input) + ratio, %s" % cfg["what"],
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": round(float(np.median(walls)), 3),
+            "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": round(float(np.median(walls_s)), 3),
             # the spread over the timed steps of THIS run on THIS box (boxes of the pool differ by more than steps do: DESIGN.md 5)
-            "ms_per_step_spread": {"min": round(float(np.min(walls)), 3), "median": round(float(np.median(walls)), 3), "max": round(float(np.max(walls)), 3)},
+            "ms_per_step_spread": {"min": round(float(np.min(walls_s)), 3), "median": round(float(np.median(walls_s)), 3), "max": round(float(np.max(walls_s)), 3)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "name": args.config, "units_per_gpu": n_units, "unit_bytes": UNIT, "corpus": kind,
