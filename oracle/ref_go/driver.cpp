@@ -11,35 +11,68 @@ struct Call {
     int level, window, crc, single, full_zero, no_entropy, all_lit, lowmem;
     const uint8_t* dict; int64_t dict_len; uint32_t dict_id;
     int64_t result; char err[256];
+    int concurrency = 0;            // WithEncoderConcurrency (0: the reference's default, GOMAXPROCS; 1: the synchronous nextBlock)
+    const int64_t* cuts = nullptr;  // stream mode: Flush() after these input offsets (ascending)
+    int64_t n_cuts = -1;            // -1: EncodeAll
 };
+
+void init_packages() {
+    using namespace go;
+    fse::go_init(); huff0::go_init(); xxhash::go_init(); compress::go_init(); zstd::go_init();
+    zstd::initPredefined();  // NewWriter's first statement (encoder.go:72)
+}
+// zstd.NewWriter's option loop (encoder.go:73-80), the options in the order a caller would write them: level first — it sets the
+// window / block size / allLitEntropy defaults — then the explicit overrides
+void apply_options(zstd::Encoder& e, const Call* c) {
+    using namespace go;
+    e.o.setDefault();
+    auto apply = [&](zstd::EOption opt) { error er = opt(&e.o); if (er != nil) panic(er); };
+    if (c->level > 0) apply(zstd::WithEncoderLevel(zstd::EncoderLevel(K((long long)c->level))));
+    if (c->window > 0) apply(zstd::WithWindowSize(Int(K((long long)c->window))));
+    if (c->crc >= 0) apply(zstd::WithEncoderCRC(c->crc != 0));
+    if (c->single >= 0) apply(zstd::WithSingleSegment(c->single != 0));
+    if (c->full_zero >= 0) apply(zstd::WithZeroFrames(c->full_zero != 0));
+    if (c->no_entropy >= 0) apply(zstd::WithNoEntropyCompression(c->no_entropy != 0));
+    if (c->all_lit >= 0) apply(zstd::WithAllLitEntropyCompression(c->all_lit != 0));
+    if (c->lowmem > 0) apply(zstd::WithLowerEncoderMem(true));
+    if (c->concurrency > 0) apply(zstd::WithEncoderConcurrency(Int(K((long long)c->concurrency))));
+    if (c->dict != nullptr && c->dict_len > 0) {
+        Slice<byte> d = make_slice<byte>(c->dict_len);
+        memcpy((void*)d.p, c->dict, (size_t)c->dict_len);
+        apply(zstd::WithEncoderDictRaw(uint32::raw(c->dict_id), d));
+    }
+}
 
 void run(Call* c) {
     using namespace go;
     try {
-        fse::go_init(); huff0::go_init(); xxhash::go_init(); compress::go_init(); zstd::go_init();
-        zstd::initPredefined();  // NewWriter's first statement (encoder.go:72)
+        init_packages();
         zstd::Encoder e;
-        e.o.setDefault();
-        auto apply = [&](zstd::EOption opt) { error er = opt(&e.o); if (er != nil) panic(er); };
-        // (the order NewWriter's caller would write them in: level first — it sets window / block size / allLitEntropy defaults —
-        // then the explicit overrides)
-        if (c->level > 0) apply(zstd::WithEncoderLevel(zstd::EncoderLevel(K((long long)c->level))));
-        if (c->window > 0) apply(zstd::WithWindowSize(Int(K((long long)c->window))));
-        if (c->crc >= 0) apply(zstd::WithEncoderCRC(c->crc != 0));
-        if (c->single >= 0) apply(zstd::WithSingleSegment(c->single != 0));
-        if (c->full_zero >= 0) apply(zstd::WithZeroFrames(c->full_zero != 0));
-        if (c->no_entropy >= 0) apply(zstd::WithNoEntropyCompression(c->no_entropy != 0));
-        if (c->all_lit >= 0) apply(zstd::WithAllLitEntropyCompression(c->all_lit != 0));
-        if (c->lowmem > 0) apply(zstd::WithLowerEncoderMem(true));
-        if (c->dict != nullptr && c->dict_len > 0) {
-            Slice<byte> d = make_slice<byte>(c->dict_len);
-            memcpy((void*)d.p, c->dict, (size_t)c->dict_len);
-            apply(zstd::WithEncoderDictRaw(uint32::raw(c->dict_id), d));
-        }
-        auto enc = e.o.encoder();
+        apply_options(e, c);
         Slice<byte> src = make_slice<byte>(c->n);
         if (c->n) memcpy((void*)src.p, c->src, (size_t)c->n);
-        Slice<byte> out = e.encodeAll(enc, src, Slice<byte>());
+        Slice<byte> out;
+        if (c->n_cuts < 0) {
+            auto enc = e.o.encoder();
+            out = e.encodeAll(enc, src, Slice<byte>());
+        } else {
+            // a stream: NewWriter(w, opts...) -> Reset(w); Write(src[a:b]) and Flush() at every cut; Close()
+            struct Sink : io::WriterImpl {
+                Slice<byte> buf;
+                std::tuple<Int, error> Write(Slice<byte> p) override { buf = append_all(buf, p); return std::tuple<Int, error>(len(p), error()); }
+            } sink;
+            e.Reset(io::Writer(&sink));
+            long long pos = 0;
+            auto check = [&](error er) { if (er != nil) panic(er); };
+            for (long long i = 0; i < c->n_cuts; i++) {
+                const long long cut = c->cuts[i] < c->n ? c->cuts[i] : c->n;
+                if (cut > pos) { auto r = e.Write(src.sl(pos, cut)); check(std::get<1>(r)); pos = cut; }
+                check(e.Flush());
+            }
+            if (c->n > pos) { auto r = e.Write(src.sl(pos, c->n)); check(std::get<1>(r)); }
+            check(e.Close());
+            out = sink.buf;
+        }
         if (out.n > c->cap) { snprintf(c->err, sizeof c->err, "output of %lld bytes does not fit %lld", out.n, (long long)c->cap); c->result = -2; return; }
         if (out.n) memcpy(c->dst, out.p, (size_t)out.n);
         c->result = out.n;
@@ -81,6 +114,21 @@ void* s2_thread(void* a) {
 }
 }  // namespace
 
+namespace {
+// the translated encoders hold their tables by value, like the Go structs do on Go's heap: a thread with a large stack
+long long run_on_big_stack(Call* c, char* err, int err_cap) {
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, (size_t)1 << 30);
+    pthread_t th;
+    if (pthread_create(&th, &at, thread_main, c) != 0) return -3;
+    pthread_join(th, nullptr);
+    pthread_attr_destroy(&at);
+    if (err && err_cap > 0) { strncpy(err, c->err, (size_t)err_cap - 1); err[err_cap - 1] = 0; }
+    return c->result;
+}
+}  // namespace
+
 extern "C" {
 // s2.Encode* (nil, src) of a build WITHOUT the assembly (encode_go.go: the portable Go encoders, what arm64 / noasm builds run)
 long long goref_s2_encode(int level, const uint8_t* src, long long n, uint8_t* dst, long long cap, char* err, int err_cap) {
@@ -96,19 +144,21 @@ long long goref_s2_encode(int level, const uint8_t* src, long long n, uint8_t* d
     return c.result;
 }
 // EncodeAll(src, nil) of zstd.NewWriter(nil, <options>); options < 0 (or 0 for level / window / dict): the reference's defaults.
-// Runs on a thread with a large stack (the translated encoders hold their tables by value, like the Go structs do on Go's heap).
 long long goref_zstd_encode_all(const uint8_t* src, long long n, uint8_t* dst, long long cap, int level, int window, int crc, int single,
                                 int full_zero, int no_entropy, int all_lit, int lowmem, const uint8_t* dict, long long dict_len,
                                 unsigned dict_id, char* err, int err_cap) {
     Call c{src, n, dst, cap, level, window, crc, single, full_zero, no_entropy, all_lit, lowmem, dict, dict_len, dict_id, 0, {0}};
-    pthread_attr_t at;
-    pthread_attr_init(&at);
-    pthread_attr_setstacksize(&at, (size_t)1 << 30);
-    pthread_t th;
-    if (pthread_create(&th, &at, thread_main, &c) != 0) return -3;
-    pthread_join(th, nullptr);
-    pthread_attr_destroy(&at);
-    if (err && err_cap > 0) { strncpy(err, c.err, (size_t)err_cap - 1); err[err_cap - 1] = 0; }
-    return c.result;
+    return run_on_big_stack(&c, err, err_cap);
+}
+// zstd.NewWriter(w, <options>) as a STREAM: Write(src[..cut]) + Flush() at every cut, then Close(); returns what w received.
+// concurrency 1: the synchronous form of nextBlock (encoder.go:361-386), else the asynchronous one (its goroutines run where started).
+long long goref_zstd_encode_stream(const uint8_t* src, long long n, uint8_t* dst, long long cap, int level, int window, int crc, int no_entropy,
+                                   int all_lit, int lowmem, int concurrency, const uint8_t* dict, long long dict_len, unsigned dict_id,
+                                   const long long* cuts, long long n_cuts, char* err, int err_cap) {
+    Call c{src, n, dst, cap, level, window, crc, -1, -1, no_entropy, all_lit, lowmem, dict, dict_len, dict_id, 0, {0}};
+    c.concurrency = concurrency;
+    c.cuts = (const int64_t*)cuts;
+    c.n_cuts = n_cuts < 0 ? 0 : n_cuts;
+    return run_on_big_stack(&c, err, err_cap);
 }
 }

@@ -40,7 +40,7 @@ CPP_RESERVED = {"new", "delete", "this", "class", "template", "typename", "union
                 "nil", "I", "K", "Slice", "Array", "String", "Int", "Uint", "uint8", "uint16", "uint32", "uint64", "int8", "int16",
                 "int32", "int64", "byte", "rune", "error", "idx", "def", "main", "signal", "index", "abs", "log", "exp", "floor", "ceil", "round",
                 "time", "clock", "rand", "random", "exit", "abort", "free", "malloc", "calloc", "div", "remove", "rename", "link", "read", "write"}
-BUILTIN_FUNCS = {"len", "cap", "append", "copy", "make", "new", "panic", "min", "max", "print", "println", "delete", "close", "clear"}
+BUILTIN_FUNCS = {"len", "cap", "append", "copy", "make", "new", "panic", "min", "max", "print", "println", "delete", "close", "clear", "recover"}
 LIBRARY_PKGS = {"bits", "binary", "math", "fmt", "errors", "bytes", "sync", "io", "rand", "race", "le", "hex", "strings", "strconv", "os", "runtime", "sort", "cpuinfo", "debug", "unsafe", "hash", "bufio", "log", "time", "atomic"}
 
 
@@ -422,6 +422,8 @@ class Emitter:
             return r
         if name == "clear":
             return "go::clear(%s)" % self.ex(args[0])
+        if name == "recover":
+            return "go::recover_()"  # a panic of the translated code is a C++ exception that travels to the driver: nothing to recover
         if name in ("print", "println"):
             return "go::println(%s)" % ", ".join(self.ex(a) for a in args)
         raise Unsupported("builtin %s" % name)
@@ -1072,7 +1074,11 @@ class Emitter:
             self.w("go::Defer %s([&] { %s; });" % (d, self.ex(call)))
 
     def st_go(self, s):
-        raise Unsupported("go statement")
+        # `go f(x)`: run to completion where it is started.  A valid schedule of the program wherever the goroutine never waits for
+        # something its starter does later — the encoder's two (encoder.go nextBlock: block encode, block write) only wait for the
+        # PREVIOUS block's goroutines through sync.WaitGroup, which have then already finished — and the only one a translation
+        # without a scheduler can offer; files whose goroutines talk through channels (enc_jobs.go) are not translated.
+        self.w("%s;  // go" % self.ex(s[1]))
 
     def st_send(self, s):
         self.w("go::send(%s, %s);" % (self.ex(s[1]), self.ex(s[2])))

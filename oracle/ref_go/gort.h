@@ -284,6 +284,10 @@ template <class A, class T> A* as_array(const Slice<T>& s) { if (s.n < (long lon
 template <class B, class D> B* base(D* d) { return static_cast<B*>(d); }
 template <class B, class D> B* base(D& d) { return static_cast<B*>(&d); }
 struct Any { Any() {} template <class T> Any(const T&) {} Any* operator->() { return this; } };
+// recover(): a panic of the translated code is a C++ exception that travels to the driver; there is never anything to recover
+struct Recovered { friend bool operator==(const Recovered&, Nil) { return true; } friend bool operator!=(const Recovered&, Nil) { return false; } };
+inline Recovered recover_() { return Recovered{}; }
+inline Recovered def(Recovered r) { return r; }
 
 template <class T> void clear(const Slice<T>& s) { for (long long i = 0; i < s.n; i++) s.p[i] = T(); }
 // min / max builtins (Go 1.21)
@@ -462,12 +466,25 @@ struct Pool { Pool* operator->() { return this; } template <class T> void Put(co
 }  // namespace sync
 namespace io {
 struct Reader { Reader* operator->() { return this; } };
-struct Writer { Writer* operator->() { return this; } };
+// io.Writer: the driver's sink implements WriterImpl (what `w` of zstd.NewWriter(w, ...) is to the reference)
+struct WriterImpl { virtual std::tuple<go::Int, go::error> Write(go::Slice<go::byte> p) = 0; virtual ~WriterImpl() {} };
+struct Writer {
+    WriterImpl* p = nullptr;
+    Writer() {}
+    Writer(WriterImpl* q) : p(q) {}
+    Writer(go::Nil) {}
+    WriterImpl* operator->() const { if (!p) go::panic_str("nil io.Writer"); return p; }
+    friend bool operator==(const Writer& a, go::Nil) { return a.p == nullptr; }
+    friend bool operator!=(const Writer& a, go::Nil) { return a.p != nullptr; }
+};
 static const go::error ErrUnexpectedEOF = go::error(new go::ErrorObj{"unexpected EOF"});
 static const go::error EOF_ = go::error(new go::ErrorObj{"EOF"});
 static const go::error ErrShortBuffer = go::error(new go::ErrorObj{"short buffer"});
 inline std::tuple<go::Int, go::error> ReadFull(const Reader&, const go::Slice<go::byte>& b) { return {go::len(b), go::error()}; }
 }  // namespace io
+namespace rdebug {
+inline void PrintStack() {}
+}
 namespace rand_ {
 static io::Reader Reader;
 }

@@ -29,7 +29,9 @@ CFG = {
         "s2/decode.go": {"ErrCorrupt", "ErrCRC", "ErrTooLarge", "ErrUnsupported"},   # the package's error values
         "zstd/seqdec.go": {"seq", "seqCompMode", "compModePredefined", "compModeRLE", "compModeFSE", "compModeRepeat"},
         "zstd/dict.go": {"dict", "dict.*", "dictMagic", "dictMaxLength"},
-        "zstd/encoder.go": {"Encoder", "encoder", "Encoder.encodeAll", "Encoder.MaxEncodedSize"},
+        # EncodeAll, and the streaming writer without its job mode (enc_jobs.go: worker goroutines fed through channels)
+        "zstd/encoder.go": {"Encoder", "encoder", "encoderState", "Encoder.encodeAll", "Encoder.MaxEncodedSize", "Encoder.Reset", "Encoder.Write",
+                            "Encoder.writeBlocks", "Encoder.nextBlock", "Encoder.Flush", "Encoder.Close"},
         # constants and the block / literals type enumerations the encoder shares with the decoder
         "zstd/blockdec.go": {"blockType", "blockTypeRaw", "blockTypeRLE", "blockTypeCompressed", "blockTypeReserved", "literalsBlockType",
                              "literalsBlockRaw", "literalsBlockRLE", "literalsBlockCompressed", "literalsBlockTreeless", "maxCompressedBlockSize",
@@ -41,11 +43,18 @@ CFG = {
                                 "decSymbolValue", "fseDecoder.transform"},
     },
     "drop_fields": {
-        "zstd.Encoder": {"encoders", "state", "init"},     # the goroutine pool and the streaming writer's state
+        "zstd.Encoder": {"encoders", "init"},              # the pool of encoders EncodeAll draws from (the driver hands it one)
+        "zstd.encoderState": {"jobs"},                     # WithConcurrentBlocks' state (enc_jobs.go)
         "zstd.dict": {"llDec", "ofDec", "mlDec"},          # decoder tables of a loaded dictionary
 "fse.Scratch": {"decTable"}, "huff0.Scratch": {"dt", "decPool"}},  # decoder halves of the shared scratch structs
     # path -> [(regular expression, replacement, why)]: source patches applied before parsing
     "patches": {
+        "zstd/encoder.go": [
+            (r"\tif e\.o\.concurrentBlocks \{\n\t\treturn e\.(writeJobs\(p\)|flushJobs\(\)|closeJobs\(\))\n\t\}\n", "",
+             "Write / Flush / Close hand over to the job mode first: not translated (goroutines fed through channels), never taken here"),
+            (r"\tif e\.o\.concurrentBlocks \{\n\t\te\.shutdownJobWorkers\(\)\n.*?\t\tjs\.started = false\n\t\}\n", "",
+             "Reset's job-mode block, likewise"),
+        ],
         "s2/hashtable_pool.go": [
             (r"= sync\.Pool\{New: func\(\) any \{ return &\w+\{\} \}\}", " sync.Pool",
              "sync.Pool is an allocation cache: its New hook is not needed when Get is replaced by a fresh table (next patch)"),

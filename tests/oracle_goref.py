@@ -29,6 +29,9 @@ def lib():
         L.goref_zstd_encode_all.restype = C.c_longlong
         L.goref_zstd_encode_all.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 8 + [C.c_char_p, C.c_longlong, C.c_uint,
                                             C.c_char_p, C.c_int]
+        L.goref_zstd_encode_stream.restype = C.c_longlong
+        L.goref_zstd_encode_stream.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 7 + [C.c_char_p, C.c_longlong, C.c_uint,
+                                               C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         L.goref_s2_encode.restype = C.c_longlong
         L.goref_s2_encode.argtypes = [C.c_int, C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         _lib = L
@@ -49,6 +52,27 @@ def zstd_encode_all(src: bytes, level=1, window_size=None, crc=None, single=None
     d = bytes(dict_content) if dict_content else None
     n = lib().goref_zstd_encode_all(src, len(src), out, cap, int(level), int(window_size or 0), _flag(crc), _flag(single), _flag(full_zero),
                                     _flag(no_entropy), _flag(all_lit_entropy), int(bool(low_mem)), d, len(d) if d else 0, int(dict_id), err, 256)
+    if n < 0:
+        raise RuntimeError("translated reference failed (%d): %s" % (n, err.value.decode(errors="replace")))
+    return out.raw[:n]
+
+
+def zstd_encode_stream(src: bytes, flush_at=(), level=1, window_size=None, crc=None, no_entropy=None, all_lit_entropy=None, low_mem=False,
+                       concurrent=0, dict_id=0, dict_content=None) -> bytes:
+    """w := new(bytes.Buffer); e := zstd.NewWriter(w, WithEncoderLevel(level), <the options given>); e.Write(src[..cut]) and e.Flush()
+    at every position of flush_at; e.Close(); w.Bytes() — the reference's streaming writer (encoder.go Write / nextBlock / Flush /
+    Close).  concurrent=1: WithEncoderConcurrency(1), the synchronous nextBlock; 0: the reference's default, the asynchronous one
+    (its two goroutines per block run to completion where they are started: the schedule their WaitGroups allow)."""
+    import numpy as np
+    src = bytes(src)
+    cuts = np.ascontiguousarray(sorted(int(x) for x in flush_at), dtype=np.int64)
+    cap = len(src) + (len(src) >> 6) + 1024 + 4 * (len(cuts) + 2)
+    out = C.create_string_buffer(cap)
+    err = C.create_string_buffer(256)
+    d = bytes(dict_content) if dict_content else None
+    n = lib().goref_zstd_encode_stream(src, len(src), out, cap, int(level), int(window_size or 0), _flag(crc), _flag(no_entropy), _flag(all_lit_entropy),
+                                       int(bool(low_mem)), int(concurrent), d, len(d) if d else 0, int(dict_id),
+                                       cuts.ctypes.data if len(cuts) else None, len(cuts), err, 256)
     if n < 0:
         raise RuntimeError("translated reference failed (%d): %s" % (n, err.value.decode(errors="replace")))
     return out.raw[:n]

@@ -87,6 +87,28 @@ def test_oracle_equals_the_translated_reference_with_a_dictionary_above_one_mib(
     assert not bad, bad
 
 
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+@pytest.mark.parametrize("concurrent", [0, 1])
+def test_oracle_equals_the_translated_reference_streams(oracle, level, concurrent):
+    """Write ... Flush ... Close streams (encoder.go:203-283 writeBlocks, :286-438 nextBlock, :547-570 Flush, :590-660 Close) in both
+    forms of nextBlock — the asynchronous one and WithEncoderConcurrency(1)'s synchronous one —, with Flush points inside and on
+    block boundaries, short streams that take the single-block EncodeAll shortcut, empty streams, and raw dictionaries (the two forms
+    differ there: the synchronous one resets the block before its first Encode, encoder.go:371)."""
+    t = corpora.corpus("T", 4, 131072, first_unit=11).tobytes()
+    m = corpora.corpus("M", 3, 131072, first_unit=2).tobytes()
+    dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
+    bs = 65536 if level == 1 else 131072
+    cases = [(t[:300000], ()), (t[:300000], (70000, 70010, 200001)), (t[:bs], ()), (t[:bs], (bs,)), (t[:2 * bs], (bs,)), (t[:5000], ()),
+             (t[:5000], (100, 4000)), (b"", ()), (b"", (0,)), (m[:250000], (1, 131072, 249999)), (t[:bs + 1], ()), (t[:3 * bs], (bs - 1, bs, bs + 1))]
+    bad = []
+    for kw in (dict(), dict(crc=False), dict(dict_id=3, dict_content=dct), dict(window_size=1 << 16)):
+        ref = oracle.ZstdOracle(level=level, concurrent=concurrent, **kw)
+        for i, (data, cuts) in enumerate(cases):
+            if oracle_goref.zstd_encode_stream(data, cuts, level=level, concurrent=concurrent, **kw) != ref.encode_stream(data, cuts):
+                bad.append((sorted(kw), i, len(data), cuts))
+    assert not bad, bad[:10]
+
+
 def _ref_inputs(limit):
     out = []
     for name in ("encode-corpus-raw.zip", "comp-crashers.zip", "enc_regressions.zip"):
@@ -158,6 +180,29 @@ def test_device_equals_the_translated_reference_encode_all(kclib, level):
     enc.Close()
     bad = [(i, len(u)) for i, u in enumerate(units) if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != oracle_goref.zstd_encode_all(u, level=lv)]
     assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+@pytest.mark.parametrize("concurrent", [0, 1])
+def test_device_equals_the_translated_reference_streams(kclib, level, concurrent):
+    """The device's Write / Flush / Close streams (kc_zstd_encode_streams_cuts) against the reference's own streaming writer, both
+    forms of nextBlock, with and without a raw dictionary."""
+    from compress_amd import zstd
+    t = corpora.corpus("T", 4, 131072, first_unit=11).tobytes()
+    dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
+    bs = 65536 if level == 1 else 131072
+    cases = [(t[:300000], ()), (t[:300000], (70000, 70010, 200001)), (t[:bs], (bs,)), (t[:5000], (100, 4000)), (b"", ()), (t[:3 * bs], (bs - 1, bs, bs + 1))]
+    buf, off = corpora.pack_units([c[0] for c in cases])
+    for with_dict in (False, True):
+        opts = [zstd.WithEncoderLevel(level)] + ([zstd.WithEncoderConcurrency(1)] if concurrent else []) + ([zstd.WithEncoderDictRaw(3, dct)] if with_dict else [])
+        enc = zstd.NewWriter(None, *opts)
+        out, out_off = enc.EncodeStreams(buf, off, flush_at=[c[1] for c in cases])
+        enc.Close()
+        kw = dict(dict_id=3, dict_content=dct) if with_dict else {}
+        bad = [(with_dict, i, len(u)) for i, (u, cuts) in enumerate(cases)
+               if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != oracle_goref.zstd_encode_stream(u, cuts, level=level, concurrent=concurrent, **kw)]
+        assert not bad, bad
 
 
 @pytest.mark.gpu
