@@ -14,6 +14,8 @@ struct Call {
     int concurrency = 0;            // WithEncoderConcurrency (0: the reference's default, GOMAXPROCS; 1: the synchronous nextBlock)
     const int64_t* cuts = nullptr;  // stream mode: Flush() after these input offsets (ascending)
     int64_t n_cuts = -1;            // -1: EncodeAll
+    int dict_full = 0;              // the dictionary bytes are a full-format dictionary: WithEncoderDict (loadDict) instead of WithEncoderDictRaw
+    int jobs = 0;                   // WithConcurrentBlocks(true)
 };
 
 void init_packages() {
@@ -36,10 +38,12 @@ void apply_options(zstd::Encoder& e, const Call* c) {
     if (c->all_lit >= 0) apply(zstd::WithAllLitEntropyCompression(c->all_lit != 0));
     if (c->lowmem > 0) apply(zstd::WithLowerEncoderMem(true));
     if (c->concurrency > 0) apply(zstd::WithEncoderConcurrency(Int(K((long long)c->concurrency))));
+    if (c->jobs) apply(zstd::WithConcurrentBlocks(true));
     if (c->dict != nullptr && c->dict_len > 0) {
         Slice<byte> d = make_slice<byte>(c->dict_len);
         memcpy((void*)d.p, c->dict, (size_t)c->dict_len);
-        apply(zstd::WithEncoderDictRaw(uint32::raw(c->dict_id), d));
+        if (c->dict_full) apply(zstd::WithEncoderDict(d));
+        else apply(zstd::WithEncoderDictRaw(uint32::raw(c->dict_id), d));
     }
 }
 
@@ -61,11 +65,14 @@ void run(Call* c) {
                 Slice<byte> buf;
                 std::tuple<Int, error> Write(Slice<byte> p) override { buf = append_all(buf, p); return std::tuple<Int, error>(len(p), error()); }
             } sink;
+            // NewWriter, encoder.go:81-83: job mode is switched off with a dictionary or without concurrency
+            if (e.o.concurrentBlocks && (e.o.dict != nil || e.o.concurrent <= K(1LL))) e.o.concurrentBlocks = false;
             e.Reset(io::Writer(&sink));
             long long pos = 0;
             auto check = [&](error er) { if (er != nil) panic(er); };
             for (long long i = 0; i < c->n_cuts; i++) {
-                const long long cut = c->cuts[i] < c->n ? c->cuts[i] : c->n;
+                if (c->cuts[i] > c->n) continue;  // (a Flush position behind the end of the input never happens: the tests' convention)
+                const long long cut = c->cuts[i];
                 if (cut > pos) { auto r = e.Write(src.sl(pos, cut)); check(std::get<1>(r)); pos = cut; }
                 check(e.Flush());
             }
@@ -148,6 +155,7 @@ long long goref_zstd_encode_all(const uint8_t* src, long long n, uint8_t* dst, l
                                 int full_zero, int no_entropy, int all_lit, int lowmem, const uint8_t* dict, long long dict_len,
                                 unsigned dict_id, char* err, int err_cap) {
     Call c{src, n, dst, cap, level, window, crc, single, full_zero, no_entropy, all_lit, lowmem, dict, dict_len, dict_id, 0, {0}};
+    if (dict_id == 0xFFFFFFFFu) { c.dict_full = 1; c.dict_id = 0; }  // (a full-format dictionary carries its own id: WithEncoderDict)
     return run_on_big_stack(&c, err, err_cap);
 }
 // zstd.NewWriter(w, <options>) as a STREAM: Write(src[..cut]) + Flush() at every cut, then Close(); returns what w received.
@@ -156,7 +164,9 @@ long long goref_zstd_encode_stream(const uint8_t* src, long long n, uint8_t* dst
                                    int all_lit, int lowmem, int concurrency, const uint8_t* dict, long long dict_len, unsigned dict_id,
                                    const long long* cuts, long long n_cuts, char* err, int err_cap) {
     Call c{src, n, dst, cap, level, window, crc, -1, -1, no_entropy, all_lit, lowmem, dict, dict_len, dict_id, 0, {0}};
-    c.concurrency = concurrency;
+    c.concurrency = concurrency & 0xFFFF;
+    c.jobs = (concurrency >> 16) & 1;  // (bit 16 of the argument: WithConcurrentBlocks(true))
+    if (dict_id == 0xFFFFFFFFu) { c.dict_full = 1; c.dict_id = 0; }
     c.cuts = (const int64_t*)cuts;
     c.n_cuts = n_cuts < 0 ? 0 : n_cuts;
     return run_on_big_stack(&c, err, err_cap);

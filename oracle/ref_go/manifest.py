@@ -3,15 +3,15 @@ left out (decoder halves, goroutine variants, String() methods of debug output) 
 
 CFG = {
     "packages": [
-        ("fse", ["fse/fse.go", "fse/bitwriter.go", "fse/bytereader.go", "fse/bitreader.go", "fse/compress.go"]),
-        ("huff0", ["huff0/huff0.go", "huff0/bitwriter.go", "huff0/compress.go"]),
+        ("fse", ["fse/fse.go", "fse/bitwriter.go", "fse/bytereader.go", "fse/bitreader.go", "fse/compress.go", "fse/decompress.go"]),
+        ("huff0", ["huff0/huff0.go", "huff0/bitwriter.go", "huff0/compress.go", "huff0/decompress.go"]),
         ("xxhash", ["zstd/internal/xxhash/xxhash.go", "zstd/internal/xxhash/xxhash_other.go"]),
         ("compress", ["compressible.go"]),
         ("s2", ["s2/s2.go", "s2/decode.go", "s2/hashtable_pool.go", "s2/dict.go", "s2/encode.go", "s2/encode_go.go", "s2/encode_all.go", "s2/encode_better.go", "s2/encode_best.go"]),
         ("zstd", ["zstd/zstd.go", "zstd/hash.go", "zstd/matchlen_generic.go", "zstd/bitwriter.go", "zstd/seqenc.go", "zstd/fse_encoder.go",
-                  "zstd/fse_predefined.go", "zstd/frameenc.go", "zstd/blockenc.go", "zstd/enc_base.go", "zstd/enc_fast.go", "zstd/enc_dfast.go",
+                  "zstd/fse_predefined.go", "zstd/frameenc.go", "zstd/blockenc.go", "zstd/bytereader.go", "zstd/enc_base.go", "zstd/enc_fast.go", "zstd/enc_dfast.go",
                   "zstd/enc_better.go", "zstd/enc_best.go", "zstd/seqdec.go", "zstd/dict.go", "zstd/bitreader.go", "zstd/blockdec.go", "zstd/framedec.go", "zstd/fse_decoder.go",
-                  "zstd/fse_decoder_generic.go", "zstd/encoder_options.go", "zstd/encoder.go"]),
+                  "zstd/fse_decoder_generic.go", "zstd/encoder_options.go", "zstd/enc_jobs.go", "zstd/encoder.go"]),
     ],
     # path -> names of top-level declarations (or Type.method) that are not translated
     "skip": {
@@ -22,16 +22,20 @@ CFG = {
         "s2/dict.go": {"Dict.Decode", "MakeDict", "MakeDictManual"},            # the decoder half; dictionary construction by search
         "s2/encode_go.go": {"calcBlockSize", "calcBlockSizeSmall", "cvtLZ4BlockAsm", "cvtLZ4BlockSnappyAsm", "cvtLZ4sBlockAsm", "cvtLZ4sBlockSnappyAsm"},
         "zstd/zstd.go": {"_", "byter"},                                   # an interface assertion on bytes.Buffer (decoder input)
-        "zstd/encoder_options.go": {"EncoderLevelFromString", "EncoderLevel.String", "WithEncoderDict"},  # strings package; loadDict (decoder tables)
+        "zstd/encoder_options.go": {"EncoderLevelFromString", "EncoderLevel.String"},  # strings package
+        "zstd/enc_jobs.go": {"Encoder.jobWorker", "Encoder.jobFlusher"},              # the worker and flusher goroutines (see the patches)
     },
     # path -> the ONLY declarations taken from that file (the rest of it is the decoder / the streaming writer)
     "only": {
         "s2/decode.go": {"ErrCorrupt", "ErrCRC", "ErrTooLarge", "ErrUnsupported"},   # the package's error values
         "zstd/seqdec.go": {"seq", "seqCompMode", "compModePredefined", "compModeRLE", "compModeFSE", "compModeRepeat"},
-        "zstd/dict.go": {"dict", "dict.*", "dictMagic", "dictMaxLength"},
-        # EncodeAll, and the streaming writer without its job mode (enc_jobs.go: worker goroutines fed through channels)
+        "zstd/dict.go": {"dict", "dict.*", "dictMagic", "dictMaxLength", "loadDict"},   # (loadDict: WithEncoderDict, full-format dictionaries)
+        "huff0/decompress.go": {"ReadTable", "dTable", "dEntrySingle"},            # the literal table of a full-format dictionary
+        # EncodeAll and the streaming writer in both modes (blocks; WithConcurrentBlocks jobs) — not ReadFrom (io.Reader plumbing), not the
+        # goroutine pool behind the public EncodeAll (the driver hands encodeAll an encoder)
         "zstd/encoder.go": {"Encoder", "encoder", "encoderState", "Encoder.encodeAll", "Encoder.MaxEncodedSize", "Encoder.Reset", "Encoder.Write",
-                            "Encoder.writeBlocks", "Encoder.nextBlock", "Encoder.Flush", "Encoder.Close"},
+                            "Encoder.writeBlocks", "Encoder.writeJobs", "Encoder.nextBlock", "Encoder.Flush", "Encoder.flushJobs", "Encoder.Close",
+                            "Encoder.closeJobs"},
         # constants and the block / literals type enumerations the encoder shares with the decoder
         "zstd/blockdec.go": {"blockType", "blockTypeRaw", "blockTypeRLE", "blockTypeCompressed", "blockTypeReserved", "literalsBlockType",
                              "literalsBlockRaw", "literalsBlockRLE", "literalsBlockCompressed", "literalsBlockTreeless", "maxCompressedBlockSize",
@@ -40,20 +44,38 @@ CFG = {
         "zstd/framedec.go": {"MinWindowSize", "MaxWindowSize", "frameMagic", "skippableFrameMagic"},
         # initPredefined builds the predefined DECODER tables first and copies their normalised counts into the encoders
         "zstd/fse_decoder.go": {"tablelogAbsoluteMax", "maxMemoryUsage", "maxTableLog", "maxTablesize", "maxTableMask", "minTablelog", "maxSymbolValue", "fseDecoder", "tableStep", "decSymbol", "decSymbol.*", "newDecSymbol",
-                                "decSymbolValue", "fseDecoder.transform"},
+                                "decSymbolValue", "fseDecoder.transform", "fseDecoder.readNCount", "fseDecoder.setRLE"},
     },
     "drop_fields": {
         "zstd.Encoder": {"encoders", "init"},              # the pool of encoders EncodeAll draws from (the driver hands it one)
-        "zstd.encoderState": {"jobs"},                     # WithConcurrentBlocks' state (enc_jobs.go)
+        "zstd.encJob": {"done"},                           # job mode's worker plumbing: see the patches of zstd/enc_jobs.go
+        "zstd.jobState": {"jobCh", "resultCh", "cond", "workerWg", "flusherWg", "inputPool", "outputPool", "overlapPool"},
         "zstd.dict": {"llDec", "ofDec", "mlDec"},          # decoder tables of a loaded dictionary
-"fse.Scratch": {"decTable"}, "huff0.Scratch": {"dt", "decPool"}},  # decoder halves of the shared scratch structs
+"huff0.Scratch": {"decPool"}},  # decoder halves of the shared scratch structs
     # path -> [(regular expression, replacement, why)]: source patches applied before parsing
     "patches": {
-        "zstd/encoder.go": [
-            (r"\tif e\.o\.concurrentBlocks \{\n\t\treturn e\.(writeJobs\(p\)|flushJobs\(\)|closeJobs\(\))\n\t\}\n", "",
-             "Write / Flush / Close hand over to the job mode first: not translated (goroutines fed through channels), never taken here"),
-            (r"\tif e\.o\.concurrentBlocks \{\n\t\te\.shutdownJobWorkers\(\)\n.*?\t\tjs\.started = false\n\t\}\n", "",
-             "Reset's job-mode block, likewise"),
+        # WithConcurrentBlocks (enc_jobs.go).  What decides the bytes is translated as it stands: the job cutting (writeJobs, dispatchJob,
+        # flushJobs, closeJobs), the per-job encode (compressJob: ResetPrefix / Reset, then block by block) and the frame assembly.  What
+        # is replaced is the plumbing that runs compressJob on worker goroutines and writes the results in order (two channels, a
+        # condition variable, three buffer pools): here every job is compressed and written where it is dispatched — the one schedule a
+        # translation without a scheduler can offer, and a valid one (jobs are independent; the flusher writes them in dispatch order).
+        "zstd/enc_jobs.go": [
+            (r"\tjs\.resultCh <- job\n\tjs\.jobCh <- job\n",
+             "\te.compressJob(e.o.encoder(), job)\n\tif job.err != nil {\n\t\treturn job.err\n\t}\n\tif len(job.output) > 0 {\n\t\t_, err := s.w.Write(job.output)\n"
+             "\t\tif err != nil {\n\t\t\treturn err\n\t\t}\n\t\ts.nWritten += int64(len(job.output))\n\t}\n\tjs.flushedSeq++\n",
+             "dispatch = compress + write, in place of the two channel sends (jobWorker's and jobFlusher's loop bodies, enc_jobs.go:69-77, 182-222); "
+             "the worker's encoder comes from e.o.encoder() like the pool's (initialize, encoder.go:89-97) — not s.encoder, whose digest carries the frame's checksum"),
+            (r"\t\tdone:   make\(chan struct\{\}\),\n", "", "no worker to wait for"),
+            (r"func \(e \*Encoder\) startJobWorkers\(\) \{.*?\n\}\n", "func (e *Encoder) startJobWorkers() {\n\te.state.jobs.started = true\n}\n", "no workers to start"),
+            (r"func \(e \*Encoder\) shutdownJobWorkers\(\) \{.*?\n\}\n", "func (e *Encoder) shutdownJobWorkers() {\n\te.state.jobs.started = false\n}\n", "... nor to stop"),
+            (r"func \(e \*Encoder\) waitAllJobs\(\) \{.*?\n\}\n", "func (e *Encoder) waitAllJobs() {\n}\n", "every dispatched job is already written"),
+            (r"\tif v := js\.\w+Pool\.Get\(\); v != nil \{.*?\n\t\}\n", "", "the three sync.Pools are allocation caches: always allocate"),
+            (r"\t\tjs\.\w+Pool\.Put\(&b\)\n", "", "likewise"),
+        ],
+        "zstd/dict.go": [
+            (r"d := dict\{\n\t\tllDec: sequenceDec\{fse: &fseDecoder\{\}\},\n\t\tofDec: sequenceDec\{fse: &fseDecoder\{\}\},\n\t\tmlDec: sequenceDec\{fse: &fseDecoder\{\}\},\n\t\}", "d := dict{}",
+             "the dictionary's three FSE tables are DEcoder state (sequenceDec); loadDict still parses them (next patch) to find what follows"),
+            (r"readDec\((table\w+), d\.\w+Dec\.fse\)", r"readDec(\1, &fseDecoder{})", "parse each table into a scratch decoder instead of the dropped fields"),
         ],
         "s2/hashtable_pool.go": [
             (r"= sync\.Pool\{New: func\(\) any \{ return &\w+\{\} \}\}", " sync.Pool",

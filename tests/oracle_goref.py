@@ -42,9 +42,15 @@ def _flag(v):
     return -1 if v is None else int(bool(v))
 
 
+FULL_DICT = 0xFFFFFFFF  # dict_id value that marks dict_content as a full-format dictionary (WithEncoderDict: it carries its own id)
+
+
 def zstd_encode_all(src: bytes, level=1, window_size=None, crc=None, single=None, full_zero=None, no_entropy=None, all_lit_entropy=None,
-                    low_mem=False, dict_id=0, dict_content=None) -> bytes:
-    """zstd.NewWriter(nil, WithEncoderLevel(level), <the options given>).EncodeAll(src, nil) of the reference (None: its default)."""
+                    low_mem=False, dict_id=0, dict_content=None, dict_blob=None) -> bytes:
+    """zstd.NewWriter(nil, WithEncoderLevel(level), <the options given>).EncodeAll(src, nil) of the reference (None: its default).
+    dict_content + dict_id: WithEncoderDictRaw; dict_blob: WithEncoderDict (a full-format dictionary, parsed by the reference's loadDict)."""
+    if dict_blob is not None:
+        dict_id, dict_content = FULL_DICT, dict_blob
     src = bytes(src)
     cap = len(src) + (len(src) >> 6) + 1024
     out = C.create_string_buffer(cap)
@@ -58,12 +64,16 @@ def zstd_encode_all(src: bytes, level=1, window_size=None, crc=None, single=None
 
 
 def zstd_encode_stream(src: bytes, flush_at=(), level=1, window_size=None, crc=None, no_entropy=None, all_lit_entropy=None, low_mem=False,
-                       concurrent=0, dict_id=0, dict_content=None) -> bytes:
+                       concurrent=0, dict_id=0, dict_content=None, dict_blob=None, jobs=False) -> bytes:
     """w := new(bytes.Buffer); e := zstd.NewWriter(w, WithEncoderLevel(level), <the options given>); e.Write(src[..cut]) and e.Flush()
     at every position of flush_at; e.Close(); w.Bytes() — the reference's streaming writer (encoder.go Write / nextBlock / Flush /
     Close).  concurrent=1: WithEncoderConcurrency(1), the synchronous nextBlock; 0: the reference's default, the asynchronous one
-    (its two goroutines per block run to completion where they are started: the schedule their WaitGroups allow)."""
+    (its two goroutines per block run to completion where they are started: the schedule their WaitGroups allow).
+    jobs=True: WithConcurrentBlocks(true) (enc_jobs.go; needs concurrent > 1 like the reference): every job compressed and written where
+    it is dispatched."""
     import numpy as np
+    if dict_blob is not None:
+        dict_id, dict_content = FULL_DICT, dict_blob
     src = bytes(src)
     cuts = np.ascontiguousarray(sorted(int(x) for x in flush_at), dtype=np.int64)
     cap = len(src) + (len(src) >> 6) + 1024 + 4 * (len(cuts) + 2)
@@ -71,7 +81,7 @@ def zstd_encode_stream(src: bytes, flush_at=(), level=1, window_size=None, crc=N
     err = C.create_string_buffer(256)
     d = bytes(dict_content) if dict_content else None
     n = lib().goref_zstd_encode_stream(src, len(src), out, cap, int(level), int(window_size or 0), _flag(crc), _flag(no_entropy), _flag(all_lit_entropy),
-                                       int(bool(low_mem)), int(concurrent), d, len(d) if d else 0, int(dict_id),
+                                       int(bool(low_mem)), int(concurrent) | (int(bool(jobs)) << 16), d, len(d) if d else 0, int(dict_id),
                                        cuts.ctypes.data if len(cuts) else None, len(cuts), err, 256)
     if n < 0:
         raise RuntimeError("translated reference failed (%d): %s" % (n, err.value.decode(errors="replace")))
