@@ -6,6 +6,7 @@ statement into C++ at build time (oracle/ref_go) — on the seeded corpora of te
 concatenated frames / blocks>` per corpus and level, in the naming of shim/go's TestWriteGolden (which writes
 reference_sha256.txt with a real Go toolchain; the two files must agree where both have a line):
     zstd.L<level>.<kind>.<n>x<unit>[.rawdict64k]       zstd.Encoder.EncodeAll per unit (encoder.go:722), level 1..4
+    zstdstream.L<level>.<kind>.10x300001.flush         Write / Flush / Close streams (WithEncoderConcurrency(1)), level 1..4
     s2|s2better|s2snappy|s2snappybetter|s2best|s2snappybest.<kind>.<n>x<unit>   s2.Encode* per block, portable Go (`noasm`) form
 Run in the build container:  python tests/golden/make_reference_go_golden.py      (about two minutes)"""
 import hashlib
@@ -40,6 +41,15 @@ def main():
                 for i in range(n):
                     h.update(oracle_goref.zstd_encode_all(buf[i * 131072:(i + 1) * 131072], **kw))
                 lines["zstd.L%d.%s.%dx131072%s" % (level, kind, n, ".rawdict64k" if with_dict else "")] = h.hexdigest()
+    # streams with Flush points, as TestWriteGolden writes them: 10 streams of 300001 bytes, Flush after 70000, 70010 and 200000+i bytes
+    for level in (1, 2, 3, 4):
+        for kind in "TM":
+            data = corpora.corpus(kind, 24, 131072).tobytes()
+            h = hashlib.sha256()
+            for i in range(10):
+                u = data[i * 300001:(i + 1) * 300001]
+                h.update(oracle_goref.zstd_encode_stream(u, (70000, 70010, 200000 + i), level=level, concurrent=1))
+            lines["zstdstream.L%d.%s.10x300001.flush" % (level, kind)] = h.hexdigest()
     for lv, name in enumerate(S2):
         n = 128 if lv < 4 else 32
         for kind in "JTMH":

@@ -256,6 +256,34 @@ def test_device_equals_the_translated_reference_streams(kclib, level, concurrent
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_device_equals_the_translated_reference_job_mode_and_full_dictionaries(oracle, kclib, level):
+    """kc_zstd_encode_jobs against the reference's WithConcurrentBlocks stream, and EncodeAll / streams with a full-format dictionary
+    (the reference's d0.dict fixture) against the reference's loadDict + encoders."""
+    from compress_amd import zstd
+    import test_oracle_kats as tk
+    t = corpora.corpus("T", 10, 131072, first_unit=3).tobytes()
+    win = 1 << 17
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(4), zstd.WithWindowSize(win))
+    js = enc.JobSize()
+    for data, cuts in ((t[:js + 70000], ()), (t[:2 * js], (1000, 300000)), (t[:js], (js,)), (t[:100], ()), (t[:70000], (50,))):
+        assert enc.EncodeJobs(data, cuts) == oracle_goref.zstd_encode_stream(data, cuts, level=level, window_size=win, concurrent=4, jobs=True), (len(data), cuts)
+    enc.Close()
+    blob, ins = tk._dict_fixture(oracle)
+    units = list(ins)[:4] + [ins[1][:40], b"", t[:70000]]
+    buf, off = corpora.pack_units(units)
+    enc = zstd.NewWriter(None, zstd.WithEncoderLevel(level), zstd.WithEncoderDict(blob))
+    out, out_off = enc.EncodeUnits(buf, off)
+    bad = [i for i, u in enumerate(units) if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != oracle_goref.zstd_encode_all(u, level=level, dict_blob=blob)]
+    assert not bad, bad
+    cuts = [((len(u) // 3, len(u) // 2) if len(u) > 10 else ()) for u in units]
+    sout, soff = enc.EncodeStreams(buf, off, flush_at=cuts)
+    bad = [i for i, u in enumerate(units) if sout[int(soff[i]):int(soff[i + 1])].tobytes() != oracle_goref.zstd_encode_stream(u, cuts[i], level=level, dict_blob=blob)]
+    assert not bad, bad
+    enc.Close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5])
 def test_device_equals_the_translated_reference_s2(kclib, level):
     from compress_amd import s2
