@@ -538,9 +538,10 @@ def main():
             cfg["what"], cfg["gib"], kind, UNIT >> 10,
             "blocks" if is_s2 else "units (2 x 64 KiB blocks with history)" if cfg["level"] == 1 else "units",
             "" if not dict_content else ", dictionary = 64 KiB of corpus 'T'")
-        # two contexts complete their steps in alternation (one context's step ends shortly after the other's): the spread is taken over
-        # consecutive PAIRS of steps, which is what a step costs in that mode
-        walls_s = [(walls[i] + walls[i + 1]) / 2.0 for i in range(len(walls) - 1)] if (npipe == 2 and len(walls) > 1) else walls
+        # two contexts: a step's call returns when its entropy stage ends, and that stage runs under the NEXT step's match finder — so the
+        # first call of the timed region spans two match finders and the last one only an entropy stage (the pipeline filling and
+        # draining; both are inside the timed region and in ms_per_step).  The spread is taken over the steps in between.
+        walls_s = walls[1:-1] if (npipe == 2 and len(walls) > 3) else walls
         line = {
             "metric": METRIC if args.config in ("C2", "C2H") else "encode MB/s (input) + ratio, %s" % cfg["what"],
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
