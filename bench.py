@@ -309,7 +309,9 @@ def main():
         slot = (encs[0].MaxEncodedSize(UNIT) + 15) & ~15
     enc = encs[0]
     cap = n_units * slot + 64
-    ndst = 2 if (npipe == 2 or world > 1) else 1  # N > 1: the gather of step i reads one buffer while step i+1 fills the other
+    # N > 1: the gather of step i reads one buffer while step i+1 fills the other; with two contexts step i+2 is begun while the gather
+    # of step i may still be reading: a third buffer
+    ndst = 3 if (npipe == 2 and world > 1) else (2 if (npipe == 2 or world > 1) else 1)
     d_dsts = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(ndst)]
     gather = FrameGather(rank, world, bound_bytes=cap) if (world > 1 and args.gather == "root") else None
     if npipe == 2:

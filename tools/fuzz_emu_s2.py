@@ -54,7 +54,7 @@ def main():
             got = emu_lib.s2_encode_blocks_hbm(blocks, level=level, variant=variant, w0=w0, w0b=w0b, grow=grow)
         else:
             level = int(rng.choice([0, 2]))
-            w0 = int(rng.choice([1, 8, 64]))
+            w0 = int(rng.choice([0, 0, 1, 8, 64]))  # 0: the fused step (the default since round 4)
             got = emu_lib.s2_encode_blocks(blocks, level=level, spec_w0=w0, variant=variant)
         if args.kernel == "best":
             pass
