@@ -136,7 +136,48 @@ long long run_on_big_stack(Call* c, char* err, int err_cap) {
 }
 }  // namespace
 
+namespace {
+struct DecCall { const uint8_t* src; int64_t n; uint8_t* dst; int64_t cap; int64_t result; char err[256]; };
+// zstd.NewReader(nil).DecodeAll(src, nil): the reference's own decoder (its pure-Go form: what noasm / non-amd64 builds run) as the
+// judge of a frame's validity.  No dictionaries (decoderOptions.dicts is a map: not translated).
+void* dec_thread(void* a) {
+    using namespace go;
+    DecCall* c = (DecCall*)a;
+    try {
+        init_packages();
+        zstd::Decoder d;
+        d.o.setDefault();  // NewReader's first statement (decoder.go:91)
+        Slice<byte> src = make_slice<byte>(c->n);
+        if (c->n) memcpy((void*)src.p, c->src, (size_t)c->n);
+        auto r = d.DecodeAll(src, Slice<byte>());
+        error er = std::get<1>(r);
+        if (er != nil) { snprintf(c->err, sizeof c->err, "%s", er.e->msg.c_str()); c->result = -5; return nullptr; }
+        Slice<byte> out = std::get<0>(r);
+        if (out.n > c->cap) { c->result = -2; return nullptr; }
+        if (out.n) memcpy(c->dst, out.p, (size_t)out.n);
+        c->result = out.n;
+    } catch (const go::Panic& p) {
+        snprintf(c->err, sizeof c->err, "panic: %s", p.msg.c_str());
+        c->result = -1;
+    }
+    return nullptr;
+}
+}  // namespace
+
 extern "C" {
+// DecodeAll(src, nil) of zstd.NewReader(nil): >= 0 the decoded length, -5 the decoder's error (text in err)
+long long goref_zstd_decode_all(const uint8_t* src, long long n, uint8_t* dst, long long cap, char* err, int err_cap) {
+    DecCall c{src, n, dst, cap, 0, {0}};
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, (size_t)1 << 30);
+    pthread_t th;
+    if (pthread_create(&th, &at, dec_thread, &c) != 0) return -3;
+    pthread_join(th, nullptr);
+    pthread_attr_destroy(&at);
+    if (err && err_cap > 0) { strncpy(err, c.err, (size_t)err_cap - 1); err[err_cap - 1] = 0; }
+    return c.result;
+}
 // s2.Encode* (nil, src) of a build WITHOUT the assembly (encode_go.go: the portable Go encoders, what arm64 / noasm builds run)
 long long goref_s2_encode(int level, const uint8_t* src, long long n, uint8_t* dst, long long cap, char* err, int err_cap) {
     S2Call c{level, src, n, dst, cap, 0, {0}};

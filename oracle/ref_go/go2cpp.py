@@ -709,7 +709,14 @@ class Emitter:
                 elif n in cur:
                     self.w("%s = %s;" % (mangle(n), val))
                 elif n in self.heap_vars:
-                    self.w("auto& %s = *new auto(go::def(%s));" % (mangle(n), val))
+                    used = set()
+                    self.idents_in(rhs[0], used)
+                    if n in used:  # `br := &br[i]`: the right side still means the outer br
+                        t = self.newtmp()
+                        self.w("auto %s = go::def(%s);" % (t, val))
+                        self.w("auto& %s = *new auto(%s);" % (mangle(n), t))
+                    else:
+                        self.w("auto& %s = *new auto(go::def(%s));" % (mangle(n), val))
                     self.declare(n)
                 else:
                     used = set()
@@ -1491,6 +1498,7 @@ class Emitter:
         self.ind += 1
         self.w("virtual ~Base_() {}")
         self.w("virtual void* obj_() = 0;")
+        self.w("virtual const void* tid_() = 0;")  # the dynamic type, for type assertions (go::cast)
         sigs = []
         for mn, sig in methods:
             self.push()
@@ -1507,6 +1515,7 @@ class Emitter:
         self.w("T_* p;")
         self.w("explicit Impl_(T_* q) : p(q) {}")
         self.w("void* obj_() override { return (void*)p; }")
+        self.w("const void* tid_() override { return go::type_tag<T_>(); }")
         for mn, rt, ps, an in sigs:
             self.w("%s %s(%s) override { return p->%s(%s); }" % (rt, mn, ps, mn, an))
         self.ind -= 1

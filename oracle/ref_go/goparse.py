@@ -444,7 +444,20 @@ class Parser:
             if v == "func":
                 return self.simple_stmt()
             if v == "select":
-                self.err("select is not supported")
+                # goroutine plumbing: parsed as an opaque statement (its tokens are skipped to the matching brace) so that a file can
+                # be read for its other declarations; go2cpp refuses a function that contains one
+                self.i += 1
+                depth = 0
+                while True:
+                    if self.is_op("{"):
+                        depth += 1
+                    elif self.is_op("}"):
+                        depth -= 1
+                        if depth == 0:
+                            self.i += 1
+                            break
+                    self.i += 1
+                return ("select", line)
             self.err("unexpected keyword")
         if self.is_op("{"):
             return self.block()

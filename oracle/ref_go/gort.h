@@ -284,6 +284,13 @@ template <class A, class T> A* as_array(const Slice<T>& s) { if (s.n < (long lon
 template <class B, class D> B* base(D* d) { return static_cast<B*>(d); }
 template <class B, class D> B* base(D& d) { return static_cast<B*>(&d); }
 struct Any { Any() {} template <class T> Any(const T&) {} Any* operator->() { return this; } };
+// x.(*T) on a translated interface value: the adapter remembers the concrete type it was made from
+template <class T> inline const void* type_tag() { static const char tag = 0; return &tag; }
+template <class P, class Iface> inline std::tuple<P, bool> cast(const Iface& i) {
+    typedef typename std::remove_pointer<P>::type T;
+    if (i.b_ != nullptr && i.b_->tid_() == type_tag<T>()) return std::tuple<P, bool>((P)i.b_->obj_(), true);
+    return std::tuple<P, bool>((P) nullptr, false);
+}
 // recover(): a panic of the translated code is a C++ exception that travels to the driver; there is never anything to recover
 struct Recovered { friend bool operator==(const Recovered&, Nil) { return true; } friend bool operator!=(const Recovered&, Nil) { return false; } };
 inline Recovered recover_() { return Recovered{}; }

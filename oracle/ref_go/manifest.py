@@ -4,19 +4,23 @@ left out (decoder halves, goroutine variants, String() methods of debug output) 
 CFG = {
     "packages": [
         ("fse", ["fse/fse.go", "fse/bitwriter.go", "fse/bytereader.go", "fse/bitreader.go", "fse/compress.go", "fse/decompress.go"]),
-        ("huff0", ["huff0/huff0.go", "huff0/bitwriter.go", "huff0/compress.go", "huff0/decompress.go"]),
+        ("huff0", ["huff0/huff0.go", "huff0/bitwriter.go", "huff0/bitreader.go", "huff0/compress.go", "huff0/decompress.go", "huff0/decompress_generic.go"]),
         ("xxhash", ["zstd/internal/xxhash/xxhash.go", "zstd/internal/xxhash/xxhash_other.go"]),
         ("compress", ["compressible.go"]),
         ("s2", ["s2/s2.go", "s2/decode.go", "s2/hashtable_pool.go", "s2/dict.go", "s2/encode.go", "s2/encode_go.go", "s2/encode_all.go", "s2/encode_better.go", "s2/encode_best.go"]),
         ("zstd", ["zstd/zstd.go", "zstd/hash.go", "zstd/matchlen_generic.go", "zstd/bitwriter.go", "zstd/seqenc.go", "zstd/fse_encoder.go",
                   "zstd/fse_predefined.go", "zstd/frameenc.go", "zstd/blockenc.go", "zstd/bytereader.go", "zstd/enc_base.go", "zstd/enc_fast.go", "zstd/enc_dfast.go",
-                  "zstd/enc_better.go", "zstd/enc_best.go", "zstd/seqdec.go", "zstd/dict.go", "zstd/bitreader.go", "zstd/blockdec.go", "zstd/framedec.go", "zstd/fse_decoder.go",
-                  "zstd/fse_decoder_generic.go", "zstd/encoder_options.go", "zstd/enc_jobs.go", "zstd/encoder.go"]),
+                  "zstd/enc_better.go", "zstd/enc_best.go", "zstd/seqdec.go", "zstd/seqdec_generic.go", "zstd/dict.go", "zstd/bitreader.go", "zstd/bytebuf.go", "zstd/history.go",
+                  "zstd/blockdec.go", "zstd/framedec.go", "zstd/fse_decoder.go",
+                  "zstd/fse_decoder_generic.go", "zstd/encoder_options.go", "zstd/enc_jobs.go", "zstd/encoder.go", "zstd/decoder_options.go", "zstd/decoder.go"]),
     ],
     # path -> names of top-level declarations (or Type.method) that are not translated
     "skip": {
         "fse/fse.go": set(),
         "huff0/compress.go": {"Scratch.compress4Xp"},  # the goroutine variant, only reachable from an `if false` block
+        "huff0/decompress.go": {"Scratch.matches"},      # a debugging aid (fmt.Fprintf to an io.Writer)
+        "zstd/bytebuf.go": {"readerWrapper", "readerWrapper.*"},   # the io.Reader form of the decoder's input (DecodeAll reads a []byte: byteBuf)
+        "zstd/fse_decoder.go": {"fseDecoder.mustReadFrom"},        # loads a table dump with encoding/binary.Read (a development aid)
         "s2/s2.go": {"_", "byter", "crc", "crcTable"},                          # the stream framing's CRC32C (hash/crc32) and an interface assertion
         "s2/encode.go": {"EstimateBlockSize", "estblockPool", "ConcatBlocks"},  # size estimation (calcBlockSize, not an encoder), block concatenation
         "s2/dict.go": {"Dict.Decode", "MakeDict", "MakeDictManual"},            # the decoder half; dictionary construction by search
@@ -28,32 +32,41 @@ CFG = {
     # path -> the ONLY declarations taken from that file (the rest of it is the decoder / the streaming writer)
     "only": {
         "s2/decode.go": {"ErrCorrupt", "ErrCRC", "ErrTooLarge", "ErrUnsupported"},   # the package's error values
-        "zstd/seqdec.go": {"seq", "seqCompMode", "compModePredefined", "compModeRLE", "compModeFSE", "compModeRepeat"},
-        "zstd/dict.go": {"dict", "dict.*", "dictMagic", "dictMaxLength", "loadDict"},   # (loadDict: WithEncoderDict, full-format dictionaries)
-        "huff0/decompress.go": {"ReadTable", "dTable", "dEntrySingle"},            # the literal table of a full-format dictionary
+        "zstd/decoder.go": {"Decoder", "Decoder.DecodeAll"},   # the stateless DecodeAll; not the streaming reader (goroutines, channels), no dictionaries (a map)
+        "zstd/decoder_options.go": {"DOption", "decoderOptions", "decoderOptions.setDefault"},
+        "zstd/dict.go": {"dict", "dict.*", "dictMagic", "dictMaxLength", "loadDict"},   # (not InspectDictionary / BuildDict)
         # EncodeAll and the streaming writer in both modes (blocks; WithConcurrentBlocks jobs) — not ReadFrom (io.Reader plumbing), not the
         # goroutine pool behind the public EncodeAll (the driver hands encodeAll an encoder)
         "zstd/encoder.go": {"Encoder", "encoder", "encoderState", "Encoder.encodeAll", "Encoder.MaxEncodedSize", "Encoder.Reset", "Encoder.Write",
                             "Encoder.writeBlocks", "Encoder.writeJobs", "Encoder.nextBlock", "Encoder.Flush", "Encoder.flushJobs", "Encoder.Close",
                             "Encoder.closeJobs"},
         # constants and the block / literals type enumerations the encoder shares with the decoder
-        "zstd/blockdec.go": {"blockType", "blockTypeRaw", "blockTypeRLE", "blockTypeCompressed", "blockTypeReserved", "literalsBlockType",
-                             "literalsBlockRaw", "literalsBlockRLE", "literalsBlockCompressed", "literalsBlockTreeless", "maxCompressedBlockSize",
-                             "compressedBlockOverAlloc", "maxCompressedBlockSizeAlloc", "maxBlockSize", "maxMatchLen", "maxSequences", "maxOffsetBits"},
-        "zstd/bitreader.go": {"highBits"},
-        "zstd/framedec.go": {"MinWindowSize", "MaxWindowSize", "frameMagic", "skippableFrameMagic"},
         # initPredefined builds the predefined DECODER tables first and copies their normalised counts into the encoders
-        "zstd/fse_decoder.go": {"tablelogAbsoluteMax", "maxMemoryUsage", "maxTableLog", "maxTablesize", "maxTableMask", "minTablelog", "maxSymbolValue", "fseDecoder", "tableStep", "decSymbol", "decSymbol.*", "newDecSymbol",
-                                "decSymbolValue", "fseDecoder.transform", "fseDecoder.readNCount", "fseDecoder.setRLE"},
     },
     "drop_fields": {
+        "zstd.Decoder": {"decoders", "current", "syncStream", "frame", "streamWg"},
+        "zstd.decoderOptions": {"dicts"},                  # map[uint32]*dict: the translated decoder judges frames without a dictionary
         "zstd.Encoder": {"encoders", "init"},              # the pool of encoders EncodeAll draws from (the driver hands it one)
         "zstd.encJob": {"done"},                           # job mode's worker plumbing: see the patches of zstd/enc_jobs.go
         "zstd.jobState": {"jobCh", "resultCh", "cond", "workerWg", "flusherWg", "inputPool", "outputPool", "overlapPool"},
-        "zstd.dict": {"llDec", "ofDec", "mlDec"},          # decoder tables of a loaded dictionary
-"huff0.Scratch": {"decPool"}},  # decoder halves of the shared scratch structs
+},
     # path -> [(regular expression, replacement, why)]: source patches applied before parsing
     "patches": {
+        "huff0/decompress.go": [
+            (r"\tbuf, ok := d\.bufs\.Get\(\)\.\(\*\[4\]\[256\]byte\)\n\tif ok \{\n\t\treturn buf\n\t\}\n", "", "sync.Pool is an allocation cache: always the fresh buffer of the next line"),
+        ],
+        "zstd/blockdec.go": [
+            (r"\thuffDecoderPool = sync\.Pool\{New: func\(\) any \{.*?\}\}\n", "\thuffDecoderPool sync.Pool\n", "allocation caches: Get is a fresh object (next patches), Put a no-op"),
+            (r"\tfseDecoderPool = sync\.Pool\{New: func\(\) any \{.*?\}\}\n", "\tfseDecoderPool sync.Pool\n", "likewise"),
+            (r"huffDecoderPool\.Get\(\)\.\(\*huff0\.Scratch\)", "&huff0.Scratch{}", "what the pool's New returns"),
+            (r"fseDecoderPool\.Get\(\)\.\(\*fseDecoder\)", "&fseDecoder{}", "what the pool's New returns"),
+        ],
+        "zstd/decoder.go": [
+            (r"\tif d\.decoders == nil \{\n\t\treturn dst, ErrDecoderClosed\n\t\}\n", "", "DecodeAll takes a block decoder from the pool (a channel): here a fresh one"),
+            (r"block := <-d\.decoders\n\tframe := block\.localFrame", "block := newBlockDec(d.o.lowMem)\n\tblock.localFrame = newFrameDec(d.o)\n\tframe := block.localFrame", "what Decoder's pool holds (decoder.go:105-115)"),
+            (r"\t\td\.decoders <- block\n", "", "nothing to give back"),
+            (r"\t\tif err = d\.setDict\(frame\); err != nil \{\n\t\t\treturn nil, err\n\t\t\}\n", "", "no dictionaries here (decoderOptions.dicts is a map)"),
+        ],
         # WithConcurrentBlocks (enc_jobs.go).  What decides the bytes is translated as it stands: the job cutting (writeJobs, dispatchJob,
         # flushJobs, closeJobs), the per-job encode (compressJob: ResetPrefix / Reset, then block by block) and the frame assembly.  What
         # is replaced is the plumbing that runs compressJob on worker goroutines and writes the results in order (two channels, a
@@ -71,11 +84,6 @@ CFG = {
             (r"func \(e \*Encoder\) waitAllJobs\(\) \{.*?\n\}\n", "func (e *Encoder) waitAllJobs() {\n}\n", "every dispatched job is already written"),
             (r"\tif v := js\.\w+Pool\.Get\(\); v != nil \{.*?\n\t\}\n", "", "the three sync.Pools are allocation caches: always allocate"),
             (r"\t\tjs\.\w+Pool\.Put\(&b\)\n", "", "likewise"),
-        ],
-        "zstd/dict.go": [
-            (r"d := dict\{\n\t\tllDec: sequenceDec\{fse: &fseDecoder\{\}\},\n\t\tofDec: sequenceDec\{fse: &fseDecoder\{\}\},\n\t\tmlDec: sequenceDec\{fse: &fseDecoder\{\}\},\n\t\}", "d := dict{}",
-             "the dictionary's three FSE tables are DEcoder state (sequenceDec); loadDict still parses them (next patch) to find what follows"),
-            (r"readDec\((table\w+), d\.\w+Dec\.fse\)", r"readDec(\1, &fseDecoder{})", "parse each table into a scratch decoder instead of the dropped fields"),
         ],
         "s2/hashtable_pool.go": [
             (r"= sync\.Pool\{New: func\(\) any \{ return &\w+\{\} \}\}", " sync.Pool",

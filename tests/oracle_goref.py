@@ -32,6 +32,8 @@ def lib():
         L.goref_zstd_encode_stream.restype = C.c_longlong
         L.goref_zstd_encode_stream.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 7 + [C.c_char_p, C.c_longlong, C.c_uint,
                                                C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+        L.goref_zstd_decode_all.restype = C.c_longlong
+        L.goref_zstd_decode_all.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         L.goref_s2_encode.restype = C.c_longlong
         L.goref_s2_encode.argtypes = [C.c_int, C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         _lib = L
@@ -98,6 +100,20 @@ def zstd_encode_units(src, unit_off, **kw):
         outs.append(f)
         off.append(off[-1] + len(f))
     return b"".join(outs), np.array(off, dtype=np.uint64)
+
+
+def zstd_decode_all(frames: bytes, max_out: int) -> bytes:
+    """zstd.NewReader(nil).DecodeAll(frames, nil) of the reference — its own decoder in the pure-Go form (what noasm / non-amd64 builds
+    run), translated like the encoders: the judge of a frame's validity (block and literal section types, both Huffman forms, the FSE
+    tables and their modes, sequence execution, window and size checks, the content checksum).  No dictionaries.  Raises on the
+    decoder's error, with its message."""
+    frames = bytes(frames)
+    out = C.create_string_buffer(max_out + 64)
+    err = C.create_string_buffer(256)
+    n = lib().goref_zstd_decode_all(frames, len(frames), out, max_out + 64, err, 256)
+    if n < 0:
+        raise ValueError("reference decoder: %s (%d)" % (err.value.decode(errors="replace"), n))
+    return out.raw[:n]
 
 
 def s2_encode(src: bytes, level=0) -> bytes:

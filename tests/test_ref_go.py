@@ -159,6 +159,35 @@ def test_oracle_equals_the_translated_reference_job_mode(oracle, level):
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_reference_decoder_accepts_the_oracles_frames_and_rejects_damage(oracle, level):
+    """The reference's OWN zstd decoder (DecodeAll, pure-Go form: framedec / blockdec / seqdec / fse_decoder / huff0 decompress,
+    translated) decodes what the oracle writes — EncodeAll frames of every corpus kind and size class, streams with Flush points,
+    job-mode streams — back to the input, and refuses damaged frames where the in-repo decoder refuses them too."""
+    ref = oracle.ZstdOracle(level=level, window_size=1 << 17)
+    t = corpora.corpus("T", 5, 131072, first_unit=2).tobytes()
+    units = [t[:131072], t[:300000], t[:100], b"", t[:70000]] + [corpora.corpus(k, 1, 131072, first_unit=3).tobytes() for k in "HJM"]
+    units += corpora.stress_units(seed=7, n=6) + corpora.rle_literal_units(n=3, seed=2)[1][:0]
+    for u in units:
+        assert oracle_goref.zstd_decode_all(ref.encode_all(u), len(u)) == u, len(u)
+    assert oracle_goref.zstd_decode_all(ref.encode_stream(t[:300000], (70000, 70010, 200001)), 300000) == t[:300000]
+    assert oracle_goref.zstd_decode_all(ref.encode_jobs(t[:640000], (1000, 600000)), 640000) == t[:640000]
+    frame = bytearray(ref.encode_all(t[:131072]))
+    rng = np.random.default_rng(level)
+    for pos in [5, 7, 12, len(frame) - 1, len(frame) - 5] + [int(x) for x in rng.integers(13, len(frame) - 6, 12)]:
+        g = bytearray(frame)
+        g[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            ok_ref = oracle_goref.zstd_decode_all(bytes(g), 131072 + 64) == t[:131072]
+        except ValueError:
+            ok_ref = False
+        try:
+            ok_own = oracle.zstd_decompress(bytes(g), 131072 + 64) == t[:131072]
+        except Exception:
+            ok_own = False
+        assert ok_ref == ok_own and not ok_ref, (pos, ok_ref, ok_own)  # (a flipped bit always breaks the checksum if nothing else)
+
+
 def _ref_inputs(limit):
     out = []
     for name in ("encode-corpus-raw.zip", "comp-crashers.zip", "enc_regressions.zip"):
@@ -281,6 +310,32 @@ def test_device_equals_the_translated_reference_job_mode_and_full_dictionaries(o
     bad = [i for i, u in enumerate(units) if sout[int(soff[i]):int(soff[i + 1])].tobytes() != oracle_goref.zstd_encode_stream(u, cuts[i], level=level, dict_blob=blob)]
     assert not bad, bad
     enc.Close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, "1L", 2, 3, 4])
+def test_reference_decoder_accepts_every_device_frame(kclib, level):
+    """What the DEVICE writes — EncodeAll frames at every level and kernel family, streams with Flush points, a job-mode stream — is
+    decoded back to the input by the reference's own zstd decoder (translated; the S2 counterpart is
+    tests/test_ref_s2asm.py::test_reference_decoder_accepts_every_device_level)."""
+    from compress_amd import zstd
+    lv = 1 if level == "1L" else level
+    opts = [zstd.WithEncoderLevel(lv)] + ([zstd.WithMatchPath("lds")] if level == "1L" else ([zstd.WithMatchPath("hbm")] if level == 1 else []))
+    t = corpora.corpus("T", 5, 131072, first_unit=2).tobytes()
+    units = [t[:131072], t[:300000], t[:100], t[:70000]] + [corpora.corpus(k, 1, 131072, first_unit=3).tobytes() for k in "HJM"] + corpora.stress_units(seed=7, n=6)
+    buf, off = corpora.pack_units(units)
+    enc = zstd.NewWriter(None, *opts)
+    out, out_off = enc.EncodeUnits(buf, off)
+    for i, u in enumerate(units):
+        assert oracle_goref.zstd_decode_all(out[int(out_off[i]):int(out_off[i + 1])].tobytes(), len(u)) == u, (i, len(u))
+    cuts = [((len(u) // 3, len(u) // 2) if len(u) > 10 else ()) for u in units]
+    sout, soff = enc.EncodeStreams(buf, off, flush_at=cuts)
+    for i, u in enumerate(units):
+        assert oracle_goref.zstd_decode_all(sout[int(soff[i]):int(soff[i + 1])].tobytes(), len(u)) == u, (i, len(u))
+    enc.Close()
+    jenc = zstd.NewWriter(None, zstd.WithEncoderLevel(lv), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(4), zstd.WithWindowSize(1 << 17))
+    assert oracle_goref.zstd_decode_all(jenc.EncodeJobs(t[:640000], (1000, 600000)), 640000) == t[:640000]
+    jenc.Close()
 
 
 @pytest.mark.gpu
