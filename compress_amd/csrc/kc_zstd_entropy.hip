@@ -480,7 +480,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             // Runs longer than LONG_RUN are copied by the whole workgroup; bytes past the last full 16-byte word stay in
             // LDS as the head of the next batch's window.
             uint8_t* __restrict__ tile = &S.codes[0][0];  // codes + sbits: 9216 bytes, unused until the sequence phase
-            constexpr int TILE = 8192;
+            constexpr int TILE = (int)((sizeof(S.codes) + sizeof(S.sbits) - 1024) & ~(size_t)1023);  // 8192 at SEQ_CHUNK 1024 (9216 bytes of codes + sbits)
             uint64_t run = 0;  // lo32: literal bytes so far, hi32: source bytes so far
             const uint8_t* __restrict__ bsrc = base + blkStart;
             uint64_t sqNext = tid < nseq ? sq[tid] : 0ull;  // the next batch's sequence is loaded under the current batch's work
