@@ -46,6 +46,10 @@ const (
 
 func (x *Ctx) SetVariant(v int) { C.kc_ctx_set_option(x.c, C.int(C.KC_OPT_S2_VARIANT), C.int64_t(v)) }
 
+// SetHookLanes: how many batches of concurrent CustomEncoder callers run on the device at once (KC_OPT_S2_HOOK_LANES, default 4,
+// at most 8; before the first call of the hook).
+func (x *Ctx) SetHookLanes(n int) { C.kc_ctx_set_option(x.c, C.int(C.KC_OPT_S2_HOOK_LANES), C.int64_t(n)) }
+
 // LastBatches reports how many device batches the last EncodeBlocks* call was cut into (0: the call did not reach the device).
 func (x *Ctx) LastBatches() int {
 	return int(C.kc_ctx_get_option(x.c, C.int(C.KC_OPT_LAST_BATCHES)))
@@ -112,7 +116,7 @@ func EncodeBlocksLevel(x *Ctx, level int, src []byte, off []uint64, dst []byte) 
 	if st != C.KC_ERR_UNSUPPORTED && st != C.KC_ERR_NO_DEVICE {
 		return nil, nil, errors.New(msg)
 	}
-	// not served by the device (block above 4 MiB, device memory exhausted, ...): the reference encoder, same bytes
+	// not served by the device (block above 1 GiB, device memory exhausted, ...): the reference encoder, same bytes
 	return encodeRef(level, src, off, dst, outOff)
 }
 

@@ -777,17 +777,12 @@ func (x *Writer) ReadFrom(r io.Reader) (int64, error) {
 	}
 }
 
-// Flush (encoder.go:547) ends the current block early.  The caller wants the bytes on w now: the stream continues on the
-// reference encoder (the cut is replayed there).
+// Flush (encoder.go:547: "all buffered data is written out") ends the current block — in job mode, dispatches the job being
+// filled — early.  The caller wants the bytes on w NOW (a peer may be waiting for them): the stream continues on the reference
+// encoder, job mode included (streamOpts carries WithConcurrentBlocks; what was buffered is replayed there with its cuts, so the
+// bytes are those of the same Write / Flush sequence).  A job stream stays on the device only while nobody flushes it; EncodeJobs
+// takes Flush positions for callers that need the bytes of such a stream but not its latency.
 func (x *Writer) Flush() error {
-	if x.ref == nil && x.e.jobMode() {
-		// job mode keeps the stream for the device: the Flush is recorded as a job cut (enc_jobs.go: a Flush dispatches the
-		// job being filled) and the bytes reach w on Close
-		if len(x.buf) > 0 {
-			x.cuts = append(x.cuts, uint64(len(x.buf)))
-		}
-		return nil
-	}
 	if err := x.fallback(); err != nil {
 		return err
 	}
