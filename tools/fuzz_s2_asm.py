@@ -1,4 +1,6 @@
-"""Device (KC_S2_VARIANT_AMD64) against the reference's assembly encoders (oracle/_ref) on many random blocks.
+"""Device against the reference itself on many random blocks: KC_S2_VARIANT_AMD64 against the reference's assembly encoders
+(oracle/_ref/libs2ref.so) and — round 4 — KC_S2_VARIANT_GO against its portable Go encoders (oracle/_ref/libzstdref.so, translated),
+both kernel families (the LDS one runs the fused step on blocks up to 64 KiB).
 python tools/fuzz_s2_asm.py [n_blocks] [seed]"""
 import os, sys, time
 import numpy as np
@@ -36,4 +38,20 @@ for level in range(4):
         print("level", level, "path", path, "blocks", len(blocks), "bytes", len(b2), "differing", len(bad), bad[:5], flush=True)
         tot_bad += len(bad)
         enc.Close()
+try:
+    import oracle_goref
+    have_go = oracle_goref.available()
+except Exception:
+    have_go = False
+if have_go:
+    sub = list(range(0, len(blocks), 3))  # (one call of the translated reference per block: a third of the set)
+    for level in (0, 2):
+        want = {i: oracle_goref.s2_encode(blocks[i], level) for i in sub}
+        for path in ("hbm", "lds"):
+            enc = s2.BlockEncoder(level=level, path=path)
+            out, oo = enc.EncodeBlocks(b2, off)
+            bad = [i for i in sub if out[int(oo[i]):int(oo[i + 1])].tobytes() != want[i]]
+            print("go variant: level", level, "path", path, "blocks", len(sub), "differing", len(bad), bad[:5], flush=True)
+            tot_bad += len(bad)
+            enc.Close()
 sys.exit(1 if tot_bad else 0)
