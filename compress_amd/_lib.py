@@ -49,6 +49,7 @@ PATH_AUTO, PATH_HBM, PATH_LDS = 0, 1, 2
 OPT_MATCH_PATH, OPT_ZFAST_LDS_MAX_UNITS, OPT_S2_LDS_MAX_BLOCKS, OPT_SPEC_W0, OPT_SPEC_GROW, OPT_LDS_SPEC_W0 = 1, 2, 3, 4, 5, 6
 OPT_HOST_SERIAL, OPT_HOST_PIPE_MIB, OPT_HOST_OVERLAP_MIN_MIB, OPT_HOST_COPY_THREADS, OPT_HOST_TRACE, OPT_HOST_CHUNK_MIB = 7, 8, 9, 10, 11, 12
 OPT_K2_PROF, OPT_S2_HOOK_WAIT_US, OPT_S2_HOOK_BATCH, OPT_TEST_FEED_REDO, OPT_S2_LDS_SPEC_W0, OPT_MAX_SCRATCH_MIB, OPT_LAST_PATH, OPT_LAST_BATCHES = 13, 14, 15, 16, 17, 18, 100, 101
+OPT_JOB_PRIME = 30
 _PATHS = {"auto": PATH_AUTO, "hbm": PATH_HBM, "lds": PATH_LDS, None: PATH_AUTO}
 
 _lib = None

@@ -107,6 +107,7 @@ struct KcCfg {
     int64_t zfast_filter = 1;             // SpeedFastest HBM-table kernel: "nothing written there yet" filter in the idle sequence buffer (units without a sequence so far)
     int64_t xxh_fin_mode = 1;             // kc_xxh64_fin_kernel: how the payload of raw-only frames is stored (KcXxhFinParams.mode)
     int64_t zfast_prescan = -1;           // SpeedFastest: the no-match pre-scan (kc_zstd_prescan.hip): 0 off, 1 on, -1 when the previous batch did not compress
+    int64_t job_prime = 1;                // jobs of a WithConcurrentBlocks stream: tables primed from the overlap prefix on the device (0: on the host)
     int64_t fuse_raw_xxh = 1;             // frames made of raw blocks only: checksum and payload copy in one pass over the source (kc_xxh64_fin_kernel)
 };
 
@@ -143,7 +144,8 @@ struct kc_ctx {
     // a batch whose units are the jobs of ONE WithConcurrentBlocks stream (kc_zstd_encode_jobs), for the duration of that call:
     const uint32_t* job_hist = nullptr;     // host, per unit: bytes of overlap prefix in front of the unit in the source buffer
     const uint32_t* job_flags = nullptr;    // host, per unit: bit 0 = final job
-    const uint8_t* job_tables = nullptr;    // host: the units' tables primed from their prefixes (ResetPrefix), device entry format
+    const uint8_t* job_tables = nullptr;    // host or null: the units' tables primed from their prefixes (ResetPrefix), device entry format
+    bool job_primed = false;                // the units' tables start primed from their prefixes: by kc_zstd_prime_kernel, or from job_tables
     DevBuf d_job_hist, d_job_flags, rawdef, unit_raw;
     DevBuf unit_done, probe_rel;         // no-match pre-scan (kc_zstd_prescan.hip): per-unit verdicts; the probe positions of one block
     int probe_bs = 0;                    // block size probe_rel was built for
@@ -345,6 +347,7 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
         envi("KC_ZFAST_VARIANT", g.zfast_variant);
         envi("KC_ZFAST_PRESCAN", g.zfast_prescan);
         envi("KC_XXH_FIN_MODE", g.xxh_fin_mode);
+        envi("KC_JOB_PRIME", g.job_prime);
         if (const char* e = getenv("KC_HOST_CHUNKS_MIB")) {
             for (const char* q = e; *q;) { g.host_chunks.push_back((uint64_t)strtoull(q, (char**)&q, 10) << 20); if (*q == ',') q++; else if (*q) break; }
             if (g.host_chunks.empty() || g.host_chunks[0] == 0) g.host_chunks = {(uint64_t)512 << 20};
@@ -387,6 +390,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_ZFAST_VARIANT: if (v < -1 || v > 1) return KC_ERR_BAD_ARG; g.zfast_variant = v; break;
         case KC_OPT_ZFAST_PRESCAN: if (v < -1 || v > 1) return KC_ERR_BAD_ARG; g.zfast_prescan = v; break;
         case KC_OPT_XXH_FIN_MODE: if (v < 0 || v > 2) return KC_ERR_BAD_ARG; g.xxh_fin_mode = v; break;
+        case KC_OPT_JOB_PRIME: g.job_prime = v != 0; break;
         default: return KC_ERR_BAD_ARG;
     }
     return KC_OK;
@@ -425,6 +429,7 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_ZFAST_VARIANT: return g.zfast_variant;
         case KC_OPT_ZFAST_PRESCAN: return g.zfast_prescan;
         case KC_OPT_XXH_FIN_MODE: return g.xxh_fin_mode;
+        case KC_OPT_JOB_PRIME: return g.job_prime;
         case KC_OPT_LAST_PATH: return c->last_path;
         case KC_OPT_LAST_PRESCAN_UNITS: return c->last_prescan_units;
         case KC_OPT_LAST_BATCHES: return c->last_batches;
@@ -626,7 +631,7 @@ kc_status ensure_best_slots(kc_ctx* c, uint32_t n_launch, hipStream_t st) {
 // on C5 that costs more (match finder 52.9 -> 63.7 ms per GiB) than the 7.7 ms of copying the dictionary tables it saves
 // (KC_OPT_BETTER_DICT_EPOCH = 1 turns it on for measurements).
 bool better_epoch_mode(const kc_ctx* c, int level, int pos_bits, int hist0) {
-    return level == KC_SPEED_BETTER && c->job_tables == nullptr && c->job_hist == nullptr && pos_bits <= 22 && (hist0 == 0 || c->cfg.better_dict_epoch != 0);
+    return level == KC_SPEED_BETTER && !c->job_primed && c->job_hist == nullptr && pos_bits <= 22 && (hist0 == 0 || c->cfg.better_dict_epoch != 0);
 }
 
 kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, hipStream_t st, int level) {
@@ -650,25 +655,41 @@ kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, 
         c->better_epoch_now = c->tab_ep;
         return KC_OK;  // no dictionary copy either: the kernel reads the shared dictionary tables for buckets it has not written
     }
-    if (zfast_use_lds(c, mp, n_launch, level) && !zfast_lds_needs_hbm(c, mp) && c->job_tables == nullptr) return KC_OK;  // the tables live in LDS (the arena is not touched)
-    const bool fastEpoch = level == KC_SPEED_FASTEST && c->cfg.zfast_epoch != 0 && mp.hist0 == 0 && c->job_tables == nullptr && mp.pos_bits + KC_ZF_EPOCH_BITS + 4 <= 32;
+    if (zfast_use_lds(c, mp, n_launch, level) && !zfast_lds_needs_hbm(c, mp) && !c->job_primed) return KC_OK;  // the tables live in LDS (the arena is not touched)
+    const bool fastEpoch = level == KC_SPEED_FASTEST && c->cfg.zfast_epoch != 0 && mp.hist0 == 0 && !c->job_primed && mp.pos_bits + KC_ZF_EPOCH_BITS + 4 <= 32;
     if (!fastEpoch) c->tab_owner = 0;  // (whatever follows rewrites the arena)
     c->fast_epoch_now = 0;
     const size_t tb = match_table_bytes(level);
-    if (c->job_tables != nullptr && mp.unit_list == nullptr) {  // jobs: every unit's table was primed from its own prefix on the host
+    if (c->job_primed) {  // jobs: slot i holds the table ResetPrefix leaves from the prefix of unit i (or, in a re-run, of unit list[i])
         kc_status sj = ensure(c, c->tables, (size_t)n_launch * tb);
         if (sj != KC_OK) return sj;
-        HIPCHK(c, hipMemcpyAsync(c->tables.p, c->job_tables, (size_t)n_launch * tb, hipMemcpyHostToDevice, st));
-        return KC_OK;
-    }
-    kc_status s = ensure(c, c->tables, (size_t)n_launch * tb);
-    if (s != KC_OK) return s;
-    if (c->job_tables != nullptr) {  // re-run of listed jobs: slot i holds the table of unit list[i]
+        if (c->job_tables == nullptr) {  // primed here, from the prefix bytes already in the source buffer
+            HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n_launch * tb, st));
+            KcPrimeParams pp;
+            pp.src = mp.src;
+            pp.unit_off = mp.unit_off;
+            pp.unit_hist = mp.unit_hist;
+            pp.unit_list = mp.unit_list;
+            pp.unit_base = mp.unit_base;
+            pp.n_launch = n_launch;
+            pp.level = level;
+            pp.pos_bits = mp.pos_bits;
+            pp.tables = (uint8_t*)c->tables.p;
+            pp.table_bytes = tb;
+            kc_launch_zstd_prime(pp, st);
+            return KC_OK;
+        }
+        if (mp.unit_list == nullptr) {
+            HIPCHK(c, hipMemcpyAsync(c->tables.p, c->job_tables, (size_t)n_launch * tb, hipMemcpyHostToDevice, st));
+            return KC_OK;
+        }
         if (c->job_redo_list.size() < n_launch) { c->err = "job re-run without its unit list"; return KC_ERR_INTERNAL; }
         for (uint32_t i = 0; i < n_launch; i++)
             HIPCHK(c, hipMemcpyAsync((uint8_t*)c->tables.p + (size_t)i * tb, c->job_tables + (size_t)c->job_redo_list[i] * tb, tb, hipMemcpyHostToDevice, st));
         return KC_OK;
     }
+    kc_status s = ensure(c, c->tables, (size_t)n_launch * tb);
+    if (s != KC_OK) return s;
     if (mp.hist0 > 0) kc_launch_bcast((const uint8_t*)c->proto.p, (uint8_t*)c->tables.p, tb, n_launch, st);
     else if (fastEpoch) {
         // SpeedFastest, no dictionary: the entries carry this launch's stamp (kc_zstd_match.hip), so what earlier launches left in
@@ -696,7 +717,7 @@ void launch_match_kernel(kc_ctx* c, const KcMatchParams& mp, uint32_t slot0, uin
         KcMatchParams ml = mp;
         ml.spec_w0 = (int32_t)c->cfg.lds_spec_w0;
         ml.lds_any_big = c->plan.max_unit_bytes > (uint64_t)131072 ? 1 : 0;
-        if (c->job_tables != nullptr)  // jobs: slot i of the arena holds the table primed from unit i's prefix (prepare_tables)
+        if (c->job_primed)  // jobs: slot i of the arena holds the table primed from unit i's prefix (prepare_tables)
             kc_launch_zfast_match_lds(ml, (const uint32_t*)((uint8_t*)c->tables.p + (size_t)slot0 * match_table_bytes(level)), 1u << 15, n_launch, st);
         else
             kc_launch_zfast_match_lds(ml, mp.hist0 > 0 ? (const uint32_t*)c->proto.p : nullptr, 0u, n_launch, st);
@@ -2104,61 +2125,92 @@ kc_status kc_zstd_encode_jobs(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* s
     hdr[hl++] = o->crc ? (uint8_t)(1 << 2) : (uint8_t)0;
     hdr[hl++] = (uint8_t)((bitsLen32((uint32_t)o->window_size - 1) - 10) << 3);
     // work buffer: unit k = [prefix_k || job_k]; prefix_k = the last min(overlap, len(job k-1)) bytes of job k-1 (enc_jobs.go:325-331)
-    std::vector<uint64_t> woff(nj + 1);
     std::vector<uint32_t> jhist(nj), jflags(nj);
-    uint64_t maxUnit = 16, need = 0;
+    std::vector<uint64_t> jlen(nj);
     for (uint32_t k = 0; k < nj; k++) {
         const uint64_t ov = k == 0 ? 0 : std::min<uint64_t>(overlap, hi[k - 1] - lo[k - 1]);
         jhist[k] = (uint32_t)ov;
         jflags[k] = k + 1 == nj ? 1u : 0u;
-        woff[k + 1] = woff[k] + ov + (hi[k] - lo[k]);
-        maxUnit = std::max<uint64_t>(maxUnit, ov + (hi[k] - lo[k]));
-        need += ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)(ov + hi[k] - lo[k])) + 15) & ~(uint64_t)15;
+        jlen[k] = ov + (hi[k] - lo[k]);
+        if (jlen[k] > KC_MAX_UNIT_BYTES) { c->err = "job larger than 1 GiB: not served by the device path"; return KC_ERR_UNSUPPORTED; }
     }
-    if (maxUnit > KC_MAX_UNIT_BYTES) { c->err = "job larger than 1 GiB: not served by the device path"; return KC_ERR_UNSUPPORTED; }
-    int pos_bits = 1;
-    while (((uint64_t)1 << pos_bits) <= maxUnit + 2) pos_bits++;
     const size_t tb = match_table_bytes(o->level);
-    std::vector<uint8_t> tabs;
-    try { tabs.assign((size_t)nj * tb, 0); } catch (...) { c->err = "host memory for the jobs' tables"; return KC_ERR_UNSUPPORTED; }
-    {
-        const int T = std::max(1, std::min<int>(host_copy_threads(c), (int)nj));
-        std::vector<std::thread> th;
-        std::atomic<uint32_t> next{0};
-        for (int t = 0; t < T; t++)
-            th.emplace_back([&] {
-                for (uint32_t k = next++; k < nj; k = next++)
-                    if (jhist[k] && tb) build_prefix_tables(o->level, src + lo[k] - jhist[k], jhist[k], pos_bits, tabs.data() + (size_t)k * tb);
-            });
-        for (auto& x : th) x.join();
-    }
-    if ((s = ensure(c, c->tmp_src, woff[nj] + 64)) || (s = ensure(c, c->tmp_dst, need + 64))) return s;
-    for (uint32_t k = 0; k < nj; k++) {
-        const uint64_t n = woff[k + 1] - woff[k];
-        if (n) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->tmp_src.p + woff[k], src + lo[k] - jhist[k], n, hipMemcpyHostToDevice, c->stream));
-    }
     uint64_t crc = 0;
     std::thread crcT;
     if (o->crc) crcT = std::thread([&] { crc = xxh64_host(src, (size_t)len); });  // under the device work
-    std::vector<uint64_t> oo(nj + 1);
-    uint64_t produced = 0;
-    c->job_hist = jhist.data();
-    c->job_flags = jflags.data();
-    c->job_tables = tb ? tabs.data() : nullptr;  // (SpeedBestCompression: the kernel indexes each job's prefix itself)
-    c->last = kc_timings{0, 0, 0, 0, 0, 0};
-    s = run_batch(c, o, (const uint8_t*)c->tmp_src.p, woff.data(), nj, (uint8_t*)c->tmp_dst.p, need, oo.data(), &produced);
-    c->job_hist = nullptr;
-    c->job_flags = nullptr;
-    c->job_tables = nullptr;
-    c->job_redo_list.clear();
-    if (crcT.joinable()) crcT.join();
-    if (s != KC_OK) return s;
-    const uint64_t total = (uint64_t)hl + produced + (o->crc ? 4 : 0);
-    if (total > dst_cap) { c->err = "dst_cap too small"; return KC_ERR_DST_TOO_SMALL; }
+    struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } joinCrc{crcT};
+    struct Unhook { kc_ctx* c; ~Unhook() { c->job_hist = nullptr; c->job_flags = nullptr; c->job_tables = nullptr; c->job_primed = false; c->job_redo_list.clear(); } } unhook{c};
+    if ((uint64_t)hl > dst_cap) { c->err = "dst_cap too small"; return KC_ERR_DST_TOO_SMALL; }
     memcpy(dst, hdr, (size_t)hl);
-    if (produced) HIPCHK(c, hipMemcpyAsync(dst + hl, c->tmp_dst.p, produced, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (o->crc) for (int k = 0; k < 4; k++) dst[hl + produced + k] = (uint8_t)(crc >> (8 * k));
+    c->last = kc_timings{0, 0, 0, 0, 0, 0};
+    c->last_batches = 0;
+    // The jobs go to the device in batches bounded like kc_zstd_encode_units_dev's: by input bytes and by the scratch their
+    // tables and per-block strides ask for (a long stream at a small window is thousands of jobs).  Each batch's tables are
+    // primed for the batch only (on the device; with KC_OPT_JOB_PRIME 0 on the host, whose memory the same budget then bounds).
+    uint64_t budget = scratch_budget(c);
+    uint64_t done = 0;  // frame bytes behind the header so far
+    std::vector<uint8_t> tabs;
+    std::vector<uint64_t> boff, oo;
+    uint32_t k0 = 0;
+    for (int attempt = 0; k0 < nj;) {
+        uint32_t k1 = k0;
+        uint64_t scratch = 0, bytes = 0, need = 0, maxUnit = 16;
+        while (k1 < nj) {
+            const uint64_t us = zstd_unit_scratch(o, jlen[k1]);
+            if (k1 > k0 && (bytes + jlen[k1] > c->max_batch_bytes || (scratch + us) + ((scratch + us) >> 3) > budget)) break;
+            scratch += us;
+            bytes += jlen[k1];
+            need += ((uint64_t)kc_zstd_max_encoded_size(o, (int64_t)jlen[k1]) + 15) & ~(uint64_t)15;
+            maxUnit = std::max(maxUnit, jlen[k1]);
+            k1++;
+        }
+        const uint32_t nb = k1 - k0;
+        int pos_bits = 1;
+        while (((uint64_t)1 << pos_bits) <= maxUnit + 2) pos_bits++;  // batch_begin's, for this batch
+        const bool primeHost = tb != 0 && c->cfg.job_prime == 0;  // (default: kc_zstd_prime_kernel, from the prefix bytes staged below)
+        if (primeHost) {
+            try { tabs.assign((size_t)nb * tb, 0); } catch (...) { c->err = "host memory for the jobs' tables"; return KC_ERR_UNSUPPORTED; }
+            const int T = std::max(1, std::min<int>(host_copy_threads(c), (int)nb));
+            std::vector<std::thread> th;
+            std::atomic<uint32_t> next{0};
+            for (int t = 0; t < T; t++)
+                th.emplace_back([&] {
+                    for (uint32_t k = next++; k < nb; k = next++)
+                        if (jhist[k0 + k]) build_prefix_tables(o->level, src + lo[k0 + k] - jhist[k0 + k], jhist[k0 + k], pos_bits, tabs.data() + (size_t)k * tb);
+                });
+            for (auto& x : th) x.join();
+        }
+        if ((s = ensure(c, c->tmp_src, bytes + 64)) || (s = ensure(c, c->tmp_dst, need + 64))) return s;
+        boff.assign(nb + 1, 0);
+        for (uint32_t k = 0; k < nb; k++) {
+            boff[k + 1] = boff[k] + jlen[k0 + k];
+            if (jlen[k0 + k]) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->tmp_src.p + boff[k], src + lo[k0 + k] - jhist[k0 + k], jlen[k0 + k], hipMemcpyHostToDevice, c->stream));
+        }
+        oo.assign(nb + 1, 0);
+        uint64_t produced = 0;
+        c->job_hist = jhist.data() + k0;
+        c->job_flags = jflags.data() + k0;
+        c->job_tables = primeHost ? tabs.data() : nullptr;
+        c->job_primed = tb != 0;  // (SpeedBestCompression: the kernel indexes each job's prefix itself)
+        s = run_batch(c, o, (const uint8_t*)c->tmp_src.p, boff.data(), nb, (uint8_t*)c->tmp_dst.p, need, oo.data(), &produced);
+        c->job_redo_list.clear();
+        if (s == KC_ERR_UNSUPPORTED && c->err.compare(0, 23, "device memory exhausted") == 0 && nb > 1 && attempt < 6) {
+            attempt++;
+            budget /= 2;  // another process took device memory since hipMemGetInfo: this batch again at half the size
+            c->err.clear();
+            continue;
+        }
+        if (s != KC_OK) return s;
+        c->last_batches++;
+        if ((uint64_t)hl + done + produced + (o->crc ? 4 : 0) > dst_cap) { c->err = "dst_cap too small"; return KC_ERR_DST_TOO_SMALL; }
+        if (produced) HIPCHK(c, hipMemcpyAsync(dst + hl + done, c->tmp_dst.p, produced, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // (tmp_src / tmp_dst and the host tables are the next batch's)
+        done += produced;
+        k0 = k1;
+    }
+    if (crcT.joinable()) crcT.join();
+    const uint64_t total = (uint64_t)hl + done + (o->crc ? 4 : 0);
+    if (o->crc) for (int k = 0; k < 4; k++) dst[hl + done + k] = (uint8_t)(crc >> (8 * k));
     *out_len = total;
     return KC_OK;
 }

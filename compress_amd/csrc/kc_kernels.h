@@ -159,6 +159,24 @@ void kc_launch_zfast_prescan(const KcPrescanParams& P, hipStream_t st);
 // the probe positions of a block of `block_size` bytes relative to its start (host helper: fills rel[], returns the count)
 uint32_t kc_zfast_probe_positions(int block_size, uint32_t* rel, uint32_t cap);
 
+// ---- job tables primed from the overlap prefix (kc_zstd_prime.hip) ----
+// encoder.ResetPrefix of a WithConcurrentBlocks job (enc_jobs.go:325-331 -> enc_fast.go:800-811, enc_dfast.go:1040-1050,
+// enc_better.go:1099-1112): the unit's first unit_hist[u] bytes are the previous job's tail; their positions go into the unit's
+// table slot (zeroed by the caller) in the entry format of the match finders, (position + 1) | tag << pos_bits.
+struct KcPrimeParams {
+    const uint8_t* src;
+    const uint64_t* unit_off;   // device: n_units + 1
+    const uint32_t* unit_hist;  // device: per unit, bytes of prefix
+    const uint32_t* unit_list;  // device or null: slot i primes unit unit_list[i] (re-runs), else unit_base + i
+    uint32_t unit_base;
+    uint32_t n_launch;          // table slots
+    int32_t level;              // KC_SPEED_FASTEST / DEFAULT / BETTER_COMPRESSION's values (1, 2, 3)
+    int32_t pos_bits;
+    uint8_t* tables;            // device: n_launch slots of table_bytes
+    size_t table_bytes;
+};
+void kc_launch_zstd_prime(const KcPrimeParams& P, hipStream_t st);
+
 // ---- S2 block encoder (kc_s2.hip) ----
 struct KcS2Params {
     const uint8_t* src;

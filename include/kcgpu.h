@@ -172,6 +172,7 @@ typedef enum {
     KC_OPT_ZFAST_VARIANT = 27,       /* KC_ZFAST_VARIANT          SpeedFastest HBM-table kernel: 0 the plain form, 1 the form for input without matches (KC_OPT_ZFAST_XSEG_K, KC_OPT_ZFAST_FILTER), -1 (default) per batch: form 1 when the context's previous batch did not compress */
     KC_OPT_ZFAST_PRESCAN = 28,       /* KC_ZFAST_PRESCAN          SpeedFastest, EncodeAll batches without dictionary: 1 = a pre-scan proves units free of matches from their probe positions alone and writes their (raw-block) frames, the match finder and the entropy stage skip them; 0 off; -1 (default) per batch: on when the context's previous batch did not compress */
     KC_OPT_S2_HOOK_LANES = 29,       /* KC_S2_HOOK_LANES          kc_s2_encode_block: batches of concurrent callers on the device at once (own stream and scratch each; default 4, at most 8) */
+    KC_OPT_JOB_PRIME = 30,           /* KC_JOB_PRIME              kc_zstd_encode_jobs: where a job's tables are primed from its overlap prefix (ResetPrefix): 1 (default) on the device (kc_zstd_prime.hip), 0 on the host, uploaded per batch */
     KC_OPT_LAST_PRESCAN_UNITS = 102, /* read-only: units of the last batch the pre-scan settled */
     KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
     KC_OPT_LAST_BATCHES = 101        /* read-only: device batches the last kc_zstd_encode_units_dev / kc_s2_encode_*_dev call was cut into */

@@ -20,6 +20,7 @@ struct Call {
 
 void init_packages() {
     using namespace go;
+    rt::Permanent perm;  // package variables outlive the call that happens to build them
     fse::go_init(); huff0::go_init(); xxhash::go_init(); compress::go_init(); zstd::go_init();
     zstd::initPredefined();  // NewWriter's first statement (encoder.go:72)
 }
@@ -49,6 +50,7 @@ void apply_options(zstd::Encoder& e, const Call* c) {
 
 void run(Call* c) {
     using namespace go;
+    rt::Scope scope;  // the call's allocations (the result is copied out below)
     try {
         init_packages();
         zstd::Encoder e;
@@ -96,8 +98,9 @@ struct S2Call { int level; const uint8_t* src; int64_t n; uint8_t* dst; int64_t 
 void* s2_thread(void* a) {
     using namespace go;
     S2Call* c = (S2Call*)a;
+    rt::Scope scope;
     try {
-        s2::go_init();
+        { rt::Permanent perm; s2::go_init(); }
         Slice<byte> src = make_slice<byte>(c->n);
         if (c->n) memcpy((void*)src.p, c->src, (size_t)c->n);
         Slice<byte> out;
@@ -143,6 +146,7 @@ struct DecCall { const uint8_t* src; int64_t n; uint8_t* dst; int64_t cap; int64
 void* dec_thread(void* a) {
     using namespace go;
     DecCall* c = (DecCall*)a;
+    rt::Scope scope;
     try {
         init_packages();
         zstd::Decoder d;

@@ -412,7 +412,7 @@ class Emitter:
         if name == "new":
             a = args[0]
             ty = a[1] if a[0] == "typeexpr" else (("name", None, a[1]) if a[0] == "ident" else ("name", a[1][1], a[2]))
-            return "(new %s())" % self.ctype(ty)
+            return "(new (go::rt::tag) %s())" % self.ctype(ty)
         if name == "panic":
             return "go::panic(%s)" % self.ex(args[0])
         if name in ("min", "max"):
@@ -545,14 +545,14 @@ class Emitter:
             vals = ", ".join("%s(%s)" % (self.ctype(et), self.elem_val(et, val)) for _, val in elems)
             expr = "%s(Slice<%s>{%s})" % (ct, self.ctype(et), vals) if ty[0] == "name" else "Slice<%s>{%s}" % (self.ctype(et), vals)
             if heap:
-                return "(new %s(%s))" % (ct, expr)
+                return "(new (go::rt::tag) %s(%s))" % (ct, expr)
             return expr
         else:
             raise Unsupported("composite literal of %r" % (u[0],))
         body = " ".join(lines)
         cap = "&" if self.scopes else ""  # (package-level initialisers: a non-local lambda takes no capture default)
         if heap:
-            return "([%s]{ auto* %s_p = new %s(); auto& %s = *%s_p; %s return %s_p; }())" % (cap, v, ct, v, v, body, v)
+            return "([%s]{ auto* %s_p = new (go::rt::tag) %s(); auto& %s = *%s_p; %s return %s_p; }())" % (cap, v, ct, v, v, body, v)
         return "([%s]{ %s %s{}; %s return %s; }())" % (cap, ct, v, body, v)
 
     def elem_val(self, et, val):
@@ -626,7 +626,7 @@ class Emitter:
                 if local and (n in self.heap_vars or (ty is not None and ty[0] == "array" and n in self.sliced_vars)):
                     # its address is taken, or it is an array that is sliced (the slice may outlive the block: frameHeader.appendTo's
                     # `tmp[:1]` is used after tmp's scope): on the heap, like Go's escape analysis puts it
-                    self.w("auto& %s = *new %s();" % (mangle(n), ct))
+                    self.w("auto& %s = *new (go::rt::tag) %s();" % (mangle(n), ct))
                 else:
                     self.w("%s%s %s{};" % (pre, ct, mangle(n)))
                 if local:
@@ -640,9 +640,9 @@ class Emitter:
                     continue
                 if local and n in self.heap_vars:
                     if ty is not None:
-                        self.w("auto& %s = *new %s(%s);" % (mangle(n), self.ctype(ty), val))
+                        self.w("auto& %s = *new (go::rt::tag) %s(%s);" % (mangle(n), self.ctype(ty), val))
                     else:
-                        self.w("auto& %s = *new auto(go::def(%s));" % (mangle(n), val))
+                        self.w("auto& %s = *new (go::rt::tag) auto(go::def(%s));" % (mangle(n), val))
                 elif ty is not None:
                     self.w("%s%s %s = %s(%s);" % (pre, self.ctype(ty), mangle(n), self.ctype(ty), val) if ty[0] == "name" else "%s%s %s = %s;" % (pre, self.ctype(ty), mangle(n), val))
                 else:
@@ -714,9 +714,9 @@ class Emitter:
                     if n in used:  # `br := &br[i]`: the right side still means the outer br
                         t = self.newtmp()
                         self.w("auto %s = go::def(%s);" % (t, val))
-                        self.w("auto& %s = *new auto(%s);" % (mangle(n), t))
+                        self.w("auto& %s = *new (go::rt::tag) auto(%s);" % (mangle(n), t))
                     else:
-                        self.w("auto& %s = *new auto(go::def(%s));" % (mangle(n), val))
+                        self.w("auto& %s = *new (go::rt::tag) auto(go::def(%s));" % (mangle(n), val))
                     self.declare(n)
                 else:
                     used = set()
@@ -740,7 +740,7 @@ class Emitter:
                 if n in cur:
                     self.w("%s = %s;" % (mangle(n), t))
                 elif n in self.heap_vars:
-                    self.w("auto& %s = *new auto(%s);" % (mangle(n), t))
+                    self.w("auto& %s = *new (go::rt::tag) auto(%s);" % (mangle(n), t))
                     self.declare(n)
                 else:
                     self.w("auto %s = %s;" % (mangle(n), t))
@@ -1138,7 +1138,7 @@ class Emitter:
             self.declare(recv[0])
         for p in sig[1]:  # parameters a returned closure captures, or whose address is taken: they may outlive this call (Go: escape to the heap)
             if p[0] and p[0] != "_" and (boxed or p[0] in self.heap_vars):
-                self.w("auto& %s = *new %s(%s__arg);" % (mangle(p[0]), self.param_type(p), mangle(p[0])))
+                self.w("auto& %s = *new (go::rt::tag) %s(%s__arg);" % (mangle(p[0]), self.param_type(p), mangle(p[0])))
         self.func_prologue(sig)
         self.local_types = []
         self.block_body(body)
@@ -1523,7 +1523,7 @@ class Emitter:
         self.w("Base_* b_ = nullptr;")
         self.w("%s() {}" % n)
         self.w("%s(go::Nil) {}" % n)
-        self.w("template <class T_> %s(T_* p) : b_(p ? new Impl_<T_>(p) : nullptr) {}" % n)
+        self.w("template <class T_> %s(T_* p) : b_(p ? new (go::rt::tag) Impl_<T_>(p) : nullptr) {}" % n)
         self.w("%s* operator->() { return this; }" % n)
         for mn, rt, ps, an in sigs:
             self.w("%s %s(%s) { return b_->%s(%s); }" % (rt, mn, ps, mn, an))

@@ -7,7 +7,10 @@
 //   * Slice<T> / Array<T,N> / String: Go's slices (shared backing store, len / cap, append growth irrelevant to the bytes), value
 //     arrays, bounds checks that panic;
 //   * error, panic, defer, sync.Once, interfaces by type erasure (the translator writes one adapter class per interface).
-// Memory is never freed (a test oracle processes bounded inputs).  Standard-library pieces the sources call (math/bits,
+// Memory: there is no collector; what a call of the driver allocates (make, new, append growth, escaping locals) is logged by
+// go::rt and released when the call ends (rt::Scope), large blocks going to a size-keyed cache so that the next call's tables are
+// cleared in place instead of faulted in page by page; package initialisation runs with the log off (rt::Permanent).
+// Standard-library pieces the sources call (math/bits,
 // encoding/binary, bytes.Equal, math.Log2 ...) are restated at the end: they are the Go standard library's, not the reference's.
 #pragma once
 #include <cmath>
@@ -17,11 +20,69 @@
 #include <cstring>
 #include <functional>
 #include <initializer_list>
+#include <map>
+#include <mutex>
+#include <new>
 #include <string>
 #include <tuple>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
+namespace go {
+namespace rt {
+struct Blk { void* p; size_t n; };
+struct Log { std::vector<Blk> blocks; };
+inline Log*& cur() { static thread_local Log* c = nullptr; return c; }
+struct Cache {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_;  // blocks of >= BIG bytes released by finished calls, by exact size
+    size_t held = 0;
+    static Cache& get() { static Cache* c = new Cache(); return *c; }
+};
+constexpr size_t BIG = (size_t)256 << 10, CACHE_MAX = (size_t)1 << 30;
+// zeroed memory that lives until the running call ends (or for ever: package initialisation, calls outside a Scope)
+inline void* alloc(size_t n) {
+    if (n == 0) n = 1;
+    Log* l = cur();
+    void* p = nullptr;
+    if (l != nullptr && n >= BIG) {
+        Cache& c = Cache::get();
+        std::lock_guard<std::mutex> g(c.mu);
+        auto it = c.free_.find(n);
+        if (it != c.free_.end()) { p = it->second; c.free_.erase(it); c.held -= n; }
+    }
+    if (p != nullptr) memset(p, 0, n);
+    else p = calloc(1, n);
+    if (p == nullptr) throw std::bad_alloc();
+    if (l != nullptr) l->blocks.push_back(Blk{p, n});
+    return p;
+}
+struct Scope {  // one driver call: everything the translated code allocates inside it dies with it (no destructors: the
+    Log log;    // translated types own nothing but such memory; message strings of errors are the exception and are small)
+    Log* prev;
+    Scope() : prev(cur()) { cur() = &log; }
+    ~Scope() {
+        cur() = prev;
+        Cache& c = Cache::get();
+        std::lock_guard<std::mutex> g(c.mu);
+        for (const Blk& b : log.blocks) {
+            if (b.n >= BIG && c.held + b.n <= CACHE_MAX) { c.free_.emplace(b.n, b.p); c.held += b.n; }
+            else free(b.p);
+        }
+    }
+};
+struct Permanent {  // package-level state built lazily inside a call (go_init, sync.Once of package variables)
+    Log* prev;
+    Permanent() : prev(cur()) { cur() = nullptr; }
+    ~Permanent() { cur() = prev; }
+};
+struct Tag {};
+constexpr Tag tag{};
+}  // namespace rt
+}  // namespace go
+inline void* operator new(size_t n, go::rt::Tag) { return go::rt::alloc(n); }
+inline void operator delete(void*, go::rt::Tag) noexcept {}  // (a constructor that panics: the block stays in the call's log)
 namespace go {
 
 struct Panic { std::string msg; };
@@ -184,7 +245,7 @@ template <class T> struct Slice {
     Slice(Nil) : p(nullptr), n(0), c(0) {}
     Slice(T* p_, long long n_, long long c_) : p(p_), n(n_), c(c_) {}
     Slice(std::initializer_list<T> il) : p(nullptr), n((long long)il.size()), c((long long)il.size()) {
-        p = (T*)calloc(il.size() ? il.size() : 1, sizeof(T));
+        p = (T*)rt::alloc((il.size() ? il.size() : 1) * sizeof(T));
         long long k = 0;
         for (const T& x : il) new (&p[k++]) T(x);
     }
@@ -230,7 +291,7 @@ template <class C, class X> auto at(C&& c, X i) -> decltype(c[i]) { return c[i];
 template <class T> Slice<T> make_slice(long long n, long long c = -1) {
     if (c < 0) c = n;
     if (n < 0 || c < n) panic_str("makeslice: len out of range");
-    T* p = (T*)calloc((size_t)(c ? c : 1), sizeof(T));
+    T* p = (T*)rt::alloc((size_t)(c ? c : 1) * sizeof(T));
     if (!std::is_trivially_default_constructible<T>::value || true) for (long long i = 0; i < c; i++) new (&p[i]) T();
     return Slice<T>(p, n, c);
 }
@@ -238,7 +299,7 @@ template <class T> Slice<T> grow_(Slice<T> s, long long need) {
     if (need <= s.c) return s;
     long long nc = s.c < 256 ? 2 * s.c : s.c + s.c / 4 + 192;
     if (nc < need) nc = need;
-    T* p = (T*)calloc((size_t)(nc ? nc : 1), sizeof(T));
+    T* p = (T*)rt::alloc((size_t)(nc ? nc : 1) * sizeof(T));
     for (long long i = 0; i < nc; i++) new (&p[i]) T();
     for (long long i = 0; i < s.n; i++) p[i] = s.p[i];
     return Slice<T>(p, s.n, nc);
@@ -277,7 +338,7 @@ inline Slice<byte> to_bytes(const String& s) { Slice<byte> r = make_slice<byte>(
 inline Slice<byte> to_bytes(const Slice<byte>& s) { return s; }
 inline String to_string(const Slice<byte>& b) { return String(std::string((const char*)b.p, (size_t)b.n)); }
 inline String to_string(const String& s) { return s; }
-template <class T> T* new_() { return new T(); }
+template <class T> T* new_() { return new (rt::tag) T(); }
 template <class T, long long N> Array<T, N>& ix(Array<T, N>* p) { return *p; }
 template <class C> C&& ix(C&& c) { return std::forward<C>(c); }
 template <class A, class T> A* as_array(const Slice<T>& s) { if (s.n < (long long)(sizeof(A) / sizeof(T))) panic_str("cannot convert slice to array pointer: too short"); return reinterpret_cast<A*>(s.p); }

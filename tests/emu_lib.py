@@ -414,3 +414,28 @@ def zstd_frames(units, block_size=None, window=None, crc=True, single=-1, full_z
             return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)], int(err[0]), int(err[1]), int(err[2]), int(err[3])
         return [dst[int(doff[i]):int(doff[i + 1])].tobytes() for i in range(n)], int(err[0]), int(err[1]), int(err[2])
     return [stage[int(soff[i]):int(soff[i]) + int(sizes[i])].tobytes() for i in range(n)], int(err[0]), int(err[1])
+
+
+def zstd_prime(level, prefixes, pos_bits, reverse=False, unit_list=None):
+    """kc_zstd_prime_kernel: one table slot per entry of unit_list (default: every unit), primed from the unit's prefix.  Returns the
+    slots as a uint32 array [n_slots, table_words]."""
+    tb = {1: 4 << 15, 2: (4 << 17) + (4 << 15), 3: (8 << 19) + (4 << 13)}[level]
+    n = len(prefixes)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    for i, b in enumerate(prefixes):
+        off[i + 1] = off[i] + len(b) + 16  # (a unit is prefix + job bytes: 16 bytes of "job" behind each prefix)
+    src = np.zeros(int(off[n]) + 64, dtype=np.uint8)
+    for i, b in enumerate(prefixes):
+        src[int(off[i]):int(off[i]) + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        src[int(off[i]) + len(b):int(off[i + 1])] = 0xA5
+    hist = np.array([len(b) for b in prefixes], dtype=np.uint32)
+    ul = None if unit_list is None else np.array(unit_list, dtype=np.uint32)
+    ns = n if ul is None else len(ul)
+    tabs = np.zeros((ns, tb // 4), dtype=np.uint32)
+    L = lib()
+    L.kcemu_zstd_prime.restype = C.c_int
+    L.kcemu_zstd_prime.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    r = L.kcemu_zstd_prime(level, pos_bits, int(reverse), src.ctypes.data, off.ctypes.data, hist.ctypes.data, None if ul is None else ul.ctypes.data,
+                           ns, tabs.ctypes.data, tb)
+    assert r == 0
+    return tabs

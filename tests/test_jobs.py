@@ -154,3 +154,53 @@ def test_device_jobs_default_window_speedfastest(oracle, kclib):
     assert got == ref
     assert enc.ctx().last_path() == "lds"  # 17 jobs: the dispatcher's choice
     enc.Close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_device_jobs_in_scratch_budgeted_batches(oracle, kclib, level):
+    """GPU: the jobs of one stream go to the device in batches bounded by the scratch budget (KC_OPT_MAX_SCRATCH_MIB), like the
+    units of kc_zstd_encode_units_dev: same frame whether the 41 jobs of a 20 MiB stream at a 128 KiB window run as one batch or
+    as many, with Flush cuts landing inside and on batch boundaries."""
+    import torch
+    from compress_amd import _lib
+    assert torch.cuda.is_available()
+    data = corpora.corpus("T" if level != 3 else "M", 160, 131072, first_unit=13000).tobytes()
+    e = oracle.ZstdOracle(level=level, window_size=1 << 17)
+    enc = _enc(level, window=1 << 17)
+    for cuts in ((), (1 << 20, 3000001, 3000002, 19 << 20)):
+        ref = e.encode_jobs(data, cuts)
+        enc.ctx().set_option(_lib.OPT_MAX_SCRATCH_MIB, 160 << 10)
+        assert enc.EncodeJobs(data, cuts) == ref
+        assert enc.ctx().get_option(_lib.OPT_LAST_BATCHES) == 1
+        enc.ctx().set_option(_lib.OPT_MAX_SCRATCH_MIB, 24)
+        got = enc.EncodeJobs(data, cuts)
+        assert enc.ctx().get_option(_lib.OPT_LAST_BATCHES) > 3
+        assert got == ref, "level %d cuts %r: %d bytes vs oracle %d" % (level, cuts, len(got), len(ref))
+    enc.Close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", GPU_LEVELS)
+def test_device_jobs_tables_primed_on_the_device_or_on_the_host(oracle, kclib, level):
+    """GPU: a job's tables come from kc_zstd_prime_kernel (default) or from the host's restatement of ResetPrefix uploaded per batch
+    (KC_OPT_JOB_PRIME 0): the same frame, the oracle's — prefixes of 16 / 32 / 64 KiB (window 128 / 256 / 512 KiB at the level's
+    overlap), a job shorter than the overlap (the prefix is the whole previous job), repetitive text whose buckets collide within a
+    round of 64 inserts, and the speculation re-run's re-priming (KC_OPT_TEST_FEED_REDO does not apply to jobs: the re-run is the
+    regular one of units whose first block had to be redone)."""
+    import torch
+    from compress_amd import _lib
+    assert torch.cuda.is_available()
+    t = corpora.corpus("T", 24, 131072, first_unit=17000).tobytes()
+    rep = (b"abcdefgh" * 40 + b"0123456789abcdef" * 20) * 2000
+    for win in (1 << 17, 1 << 19):
+        e = oracle.ZstdOracle(level=_li(level), window_size=win)
+        enc = _enc(level, window=win)
+        for data, cuts in ((t, ()), (rep + t[:300000] + rep, ()), (t[:1500000], (600000, 600100, 600101)), (rep[:700000], (1,))):
+            ref = e.encode_jobs(data, cuts)
+            for prime in (1, 0):
+                enc.ctx().set_option(_lib.OPT_JOB_PRIME, prime)
+                assert enc.ctx().get_option(_lib.OPT_JOB_PRIME) == prime
+                got = enc.EncodeJobs(data, cuts)
+                assert got == ref, "level %s window %d len %d cuts %r prime %d: %d bytes vs oracle %d" % (level, win, len(data), cuts, prime, len(got), len(ref))
+        enc.Close()

@@ -17,7 +17,8 @@ import corpora
 import oracle_goref
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FULL = os.environ.get("KC_TEST_FULL", "0") == "1"  # the long forms (SpeedBestCompression on every input of the other levels' sets)
+FULL = os.environ.get("KC_TEST_FULL", "1") == "1"  # the long forms (SpeedBestCompression on every input of the other levels' sets): the default
+# since the translation releases a call's memory (gort.h rt::Scope) — the whole file is ~40 s; KC_TEST_FULL=0 trims it
 REFIN = os.path.join(HERE, "golden", "ref_inputs")
 
 pytestmark = pytest.mark.skipif(not oracle_goref.available(), reason="oracle/_ref/libzstdref.so neither present nor buildable (no /root/reference)")

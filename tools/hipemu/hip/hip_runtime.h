@@ -47,6 +47,7 @@ void block_sync();
 int block_or(int p);  // __syncthreads_or
 int lane();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void set_reverse(bool r);    // the scheduler visits the lanes from 63 down (same-address stores of one instruction: the lowest lane's stays)
 void set_group(unsigned g);  // sub-wave groups of g lanes rendezvous among themselves (kernels whose groups diverge); 64: whole waves
 uint64_t collectives();   // cross-lane operations executed so far (diagnostics)
 void pause();             // s_sleep: the lane gives way without a rendezvous (a wave polling a flag another wave of the block sets)

@@ -141,6 +141,11 @@ uint64_t collectives() { return g_coll; }
 // hardware then runs them one after the other under the execution mask, and a ballot / shuffle of one group sees only its own
 // lanes.  With set_group(G) the lanes of a group rendezvous among themselves (G must divide 64; 64 restores whole waves).
 void set_group(unsigned g) { g_group = (g == 0 || g > 64 || (64 % g) != 0) ? 64 : g; }
+// The order in which the scheduler's round robin visits the lanes: when several lanes of one instruction store to one address the
+// hardware keeps ANY of them; forward order keeps the highest lane's value, reverse order the lowest lane's (tests of kernels
+// that resolve such collisions themselves run under both).
+static bool g_reverse = false;
+void set_reverse(bool r) { g_reverse = r; }
 
 // A wave that waits for another wave of its workgroup (a flag or a queue index in LDS, polled around s_sleep): no rendezvous, the
 // lane just gives way; the scheduler's round robin runs every other fiber of the block before it returns here.  The caller's loop
@@ -260,7 +265,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                 }
                 g_blk = &B;
                 while (B.live > 0) {
-                    for (unsigned t = 0; t < nt; t++) {
+                    for (unsigned t0 = 0; t0 < nt; t0++) {
+                        const unsigned t = g_reverse ? nt - 1 - t0 : t0;
                         Fiber& f = B.fibers[t];
                         if (f.done) continue;
                         B.cur = &f;

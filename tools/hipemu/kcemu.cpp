@@ -8,6 +8,7 @@
 #include "../../compress_amd/csrc/kc_misc.hip"
 #include "../../compress_amd/csrc/kc_zstd_entropy.hip"
 #include "../../compress_amd/csrc/kc_zstd_prescan.hip"
+#include "../../compress_amd/csrc/kc_zstd_prime.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_dfast.hip"
 #include "../../compress_amd/csrc/kc_zstd_match_better.hip"
 #include <vector>
@@ -15,6 +16,20 @@
 #include "../../compress_amd/csrc/kc_zstd_match_best.hip"
 
 extern "C" {
+
+// kc_zstd_prime_kernel: n table slots (zeroed by the caller) primed from the first unit_hist[u] bytes of their units; reverse = the
+// emulator keeps the LOWEST lane's value where lanes of one store instruction share an address (the hardware may keep any)
+int kcemu_zstd_prime(int level, int pos_bits, int reverse, const uint8_t* src, const uint64_t* unit_off, const uint32_t* unit_hist,
+                     const uint32_t* unit_list, uint32_t n_launch, uint8_t* tables, uint64_t table_bytes) {
+    KcPrimeParams P;
+    memset(&P, 0, sizeof(P));
+    P.src = src; P.unit_off = unit_off; P.unit_hist = unit_hist; P.unit_list = unit_list; P.unit_base = 0; P.n_launch = n_launch;
+    P.level = level; P.pos_bits = pos_bits; P.tables = tables; P.table_bytes = (size_t)table_bytes;
+    hipemu::set_reverse(reverse != 0);
+    kc_launch_zstd_prime(P, nullptr);
+    hipemu::set_reverse(false);
+    return 0;
+}
 
 // N blocks through kc_s2_encode_lds_kernel; stage slots as the host library lays them out (stage_off, 64-byte aligned)
 int kcemu_s2_encode(int level, int framed, int spec_w0, const uint8_t* src, const uint64_t* blk_off, uint32_t n, uint8_t* stage,
