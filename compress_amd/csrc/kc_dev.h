@@ -25,11 +25,8 @@ __device__ __forceinline__ uint4 ld128u(const uint8_t* p) {  // unaligned 16-byt
 // CPU emulator of the tests, tools/hipemu, which runs lanes out of lockstep, has to synchronise them here).
 #ifdef KC_HIPEMU
 #define KC_WAVE_SYNC() hipemu::wave_sync()
-#define KC_MEM_SYNC() hipemu::wave_sync()
 #else
 #define KC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-// the same through GLOBAL memory (a lane reads what another lane of its wave has just stored): the stores are waited for
-#define KC_MEM_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
 // ---- wave primitives ----

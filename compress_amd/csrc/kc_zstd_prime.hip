@@ -11,6 +11,13 @@
 #include "kc_dev.h"
 #include "kc_kernels.h"
 
+// KC_WAVE_SYNC through GLOBAL memory (a lane reads what another lane of its wave has just stored): the stores are waited for
+#ifdef KC_HIPEMU
+#define KC_MEM_SYNC() hipemu::wave_sync()
+#else
+#define KC_MEM_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+
 #define PRIME_SCR 16384  // scratch cells of the collision check (u16 lane ids)
 
 namespace {
