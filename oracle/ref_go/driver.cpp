@@ -168,7 +168,25 @@ void* dec_thread(void* a) {
 }
 }  // namespace
 
+#ifdef GOREF_AMD64
+// The assembly addresses the fields of these structures by the offsets Go's compiler gives them.  The translation keeps Go's field
+// order and types (gort.h: I<T> is T, Slice is base / len / cap, Array is the elements), so the C++ compiler lays them out the same
+// way; the sizes below are Go's (zstd/seqdec.go:59-98, seqdec_asm.go:13-58, fse_decoder_asm.go:14-25, bitreader.go:17-22,
+// huff0/decompress_asm.go:16-25,131-138, huff0/bitreader.go:126-131) — a drift fails the build, not a test.
+static_assert(sizeof(zstd::seqVals) == 24 && sizeof(zstd::decSymbol) == 8, "seqVals / decSymbol");
+static_assert(sizeof(zstd::bitReader) == 48, "zstd bitReader: in []byte, value uint64, cursor int, bitsRead uint8");
+static_assert(sizeof(zstd::fseState) == 32 && sizeof(zstd::sequenceDec) == 48, "fseState {dt []decSymbol; state decSymbol}, sequenceDec {fse, state, repeat}");
+static_assert(offsetof(zstd::sequenceDecs, offsets) == 48 && offsetof(zstd::sequenceDecs, matchLengths) == 96 && offsetof(zstd::sequenceDecs, prevOffset) == 144, "sequenceDecs");
+static_assert(sizeof(zstd::decodeAsmContext) == 136 && sizeof(zstd::executeAsmContext) == 128 && sizeof(zstd::decodeSyncAsmContext) == 232, "asm contexts");
+static_assert(sizeof(zstd::buildDtableAsmContext) == 40, "buildDtableAsmContext");
+static_assert(offsetof(zstd::fseDecoder, symbolLen) == 4096 && offsetof(zstd::fseDecoder, stateTable) == 4100 && offsetof(zstd::fseDecoder, norm) == 4612, "fseDecoder: dt [512]decSymbol, symbolLen, actualTableLog, maxBits, stateTable [256]uint16, norm [256]int16");
+static_assert(sizeof(huff0::decompress4xContext) == 56 && sizeof(huff0::decompress1xContext) == 48 && sizeof(huff0::bitReaderShifted) == 48, "huff0 asm contexts");
+#endif
+
 extern "C" {
+// amd64 flavour: 0 = the dispatch helpers take the routines without BMI1 / BMI2, -1 = what the host's CPU has (a no-op in the
+// portable flavour, which has no such routines)
+void goref_force_bmi(int mode) { cpuinfo::force() = mode; }
 // DecodeAll(src, nil) of zstd.NewReader(nil): >= 0 the decoded length, -5 the decoder's error (text in err)
 long long goref_zstd_decode_all(const uint8_t* src, long long n, uint8_t* dst, long long cap, char* err, int err_cap) {
     DecCall c{src, n, dst, cap, 0, {0}};

@@ -1306,6 +1306,7 @@ class Emitter:
         # bodies
         for n, f in pkg.funcs.items():
             if f[4] is None:
+                self.emit_asm_thunk(n, f)
                 continue
             path = next(p for p, ast in pkg.files if f in ast[3])
             self.imports = file_imports[path]
@@ -1338,6 +1339,58 @@ class Emitter:
         self.w("}")
         self.w("}  // namespace %s" % ns)
         self.w()
+
+    def emit_asm_thunk(self, n, f):
+        """A Go function declared without a body is implemented in the package's assembly (TEXT ·name).  oracle/ref_s2asm/
+        plan9_to_gas.py re-spells that assembly as p9_name(uint64_t* frame), `frame` being the function's argument frame in Go's
+        stack-based ABI0: arguments, then results, in declaration order, each at its natural alignment (a slice is base / len / cap)."""
+        sig = f[3]
+        words, off = [], 0
+
+        def kind(ty):
+            if ty[0] == "ptr":
+                return "ptr"
+            if ty[0] == "slice":
+                return "slice"
+            if ty[0] == "name" and ty[1] is None and ty[2] in ("int", "uint", "int64", "uint64", "uintptr"):
+                return "word"
+            if ty[0] == "name" and ty[1] is None and ty[2] == "bool":
+                return "bool"
+            raise Unsupported("assembly function %s: parameter type %r" % (n, ty))
+        self.push()
+        names = []
+        for p in sig[1]:
+            pn = mangle(p[0])
+            names.append(pn)
+            k = kind(p[1])
+            if k == "ptr":
+                words.append("(uint64_t)(uintptr_t)%s" % pn)
+            elif k == "word":
+                words.append("(uint64_t)%s.v" % pn)
+            elif k == "slice":
+                words += ["(uint64_t)(uintptr_t)%s.p" % pn, "(uint64_t)%s.n" % pn, "(uint64_t)%s.c" % pn]
+            else:
+                raise Unsupported("assembly function %s: bool argument" % n)
+        nargs = len(words)
+        res = sig[2]
+        if len(res) > 1:
+            raise Unsupported("assembly function %s: several results" % n)
+        self.w('extern "C" void p9_%s(uint64_t* frame);' % n)
+        self.w("%s %s(%s) {" % (self.result_type(res), mangle(n), self.params_text(sig)))
+        self.ind += 1
+        self.w("uint64_t frame__[%d] = {%s};" % (nargs + 1, ", ".join(words)))
+        self.w("p9_%s(frame__);" % n)
+        if res:
+            k = kind(res[0][1])
+            if k == "word":
+                self.w("return %s::raw((%s::raw_type)frame__[%d]);" % (self.ctype(res[0][1]), self.ctype(res[0][1]), nargs))
+            elif k == "bool":
+                self.w("return (frame__[%d] & 0xFF) != 0;" % nargs)
+            else:
+                raise Unsupported("assembly function %s: result type" % n)
+        self.ind -= 1
+        self.w("}")
+        self.pop()
 
     def bound_names(self, e, out):
         """Every name a function binds locally (parameters, :=, var, range): a type of the same name needs another C++ name."""
@@ -1563,7 +1616,8 @@ def translate(root, cfg):
 if __name__ == "__main__":
     import manifest
     root, out = sys.argv[1], sys.argv[2]
-    text, warnings = translate(root, manifest.CFG)
+    flavour = sys.argv[3] if len(sys.argv) > 3 else "generic"
+    text, warnings = translate(root, manifest.CFG if flavour == "generic" else manifest.flavour(flavour))
     with open(out, "w") as f:
         f.write(text)
     for wmsg in warnings:

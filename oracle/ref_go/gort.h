@@ -522,6 +522,11 @@ inline double Abs(double x) { return fabs(x); }
 inline double Float64frombits(go::uint64 b) { double d; memcpy(&d, &b.v, 8); return d; }
 inline go::uint64 Float64bits(double d) { uint64_t b; memcpy(&b, &d, 8); return go::uint64::raw(b); }
 }  // namespace math
+namespace cpuinfo {  // internal/cpuinfo: what the amd64 flavour's dispatch helpers ask (the driver can force the non-BMI2 routines)
+inline int& force() { static int f = -1; return f; }  // -1: the host's CPU; 0: pretend BMI1/BMI2 are absent
+inline bool HasBMI2() { return force() != 0 && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi"); }
+inline bool HasBMI1() { return force() != 0 && __builtin_cpu_supports("bmi"); }
+}  // namespace cpuinfo
 namespace sync {
 struct Once {
     bool done = false;

@@ -93,3 +93,28 @@ CFG = {
         ],
     },
 }
+
+
+def flavour(name):
+    """The amd64 build of the reference (what `go build` gives an x86-64 user): the Go halves of its assembly routines in place of the
+    portable ones — zstd's sequence decoder and executor (seqdec_amd64.s), buildDtable (fse_decoder_amd64.s), matchLen
+    (matchlen_amd64.s, used by all four encoders), huff0's 1X / 4X decoding loops (decompress_amd64.s).  The assembly itself is
+    re-spelt for the GNU assembler by oracle/ref_s2asm/plan9_to_gas.py and linked in; go2cpp.py writes the ABI0 call thunks."""
+    if name != "amd64":
+        raise SystemExit("manifest: unknown flavour %r" % name)
+    import copy
+    cfg = copy.deepcopy(CFG)
+    swap = {"huff0/decompress_generic.go": ["huff0/decompress_amd64.go", "huff0/decompress_asm.go"],
+            "zstd/seqdec_generic.go": ["zstd/seqdec_asm.go", "zstd/seqdec_amd64.go"],
+            "zstd/fse_decoder_generic.go": ["zstd/fse_decoder_asm.go"],
+            "zstd/matchlen_generic.go": ["zstd/matchlen_amd64.go"]}
+    pk = []
+    for pname, files in cfg["packages"]:
+        out = []
+        for f in files:
+            out += swap.pop(f, [f])
+        pk.append((pname, out))
+    if swap:
+        raise SystemExit("manifest: files to swap not in the manifest: %r" % sorted(swap))
+    cfg["packages"] = pk
+    return cfg

@@ -37,12 +37,20 @@ BYSIZE = {8: REG64, 4: REG32, 2: REG16, 1: REG8}
 OPS = {}
 for base, gas in (("MOV", "mov"), ("ADD", "add"), ("SUB", "sub"), ("CMP", "cmp"), ("SHR", "shr"), ("SHL", "shl"), ("SAR", "sar"),
                   ("XOR", "xor"), ("OR", "or"), ("AND", "and"), ("DEC", "dec"), ("INC", "inc"), ("TEST", "test"), ("LEA", "lea"),
-                  ("IMUL", "imul"), ("BSF", "bsf"), ("ROL", "rol")):
+                  ("IMUL", "imul"), ("BSF", "bsf"), ("ROL", "rol"), ("NEG", "neg"), ("BTS", "bts"), ("BSR", "bsr"), ("BSWAP", "bswap"),
+                  ("ADC", "adc")):
     for suf, sz in (("B", 1), ("W", 2), ("L", 4), ("Q", 8)):
         OPS[base + suf] = (gas + suf.lower(), sz)
-SSE = {"MOVOU": "movdqu", "MOVOA": "movdqa", "PXOR": "pxor"}
+SSE = {"MOVOU": "movdqu", "MOVOA": "movdqa", "PXOR": "pxor", "MOVUPS": "movups"}
+# BMI1 / BMI2 three-operand forms (zstd/seqdec_amd64.s, huff0/decompress_amd64.s): Plan 9 and AT&T write them in the same order
+BMI3 = {"BZHIQ": "bzhiq", "BEXTRQ": "bextrq", "SHRXQ": "shrxq", "SHLXQ": "shlxq"}
+CMOV = {"CMOVQEQ": "cmoveq", "CMOVQNE": "cmovneq"}
+SETCC = {"SETGE": "setge"}
+# sign-extending moves
+SX = {"MOVWQSX": ("movswq", 2, 8)}
 JCC = {"JMP": "jmp", "JEQ": "je", "JE": "je", "JNE": "jne", "JZ": "jz", "JNZ": "jnz", "JB": "jb", "JBE": "jbe", "JNA": "jna", "JA": "ja",
-       "JAE": "jae", "JLE": "jle", "JG": "jg", "JGT": "jg", "JL": "jl", "JLT": "jl", "JGE": "jge"}
+       "JAE": "jae", "JLE": "jle", "JG": "jg", "JGT": "jg", "JL": "jl", "JLT": "jl", "JGE": "jge", "JS": "js", "JNS": "jns", "JLS": "jbe", "JHI": "ja",
+       "JCS": "jb", "JCC": "jae"}
 # zero-extending moves: Plan 9 name -> (gas mnemonic, source width, destination width)
 ZX = {"MOVBQZX": ("movzbq", 1, 8), "MOVBLZX": ("movzbl", 1, 4), "MOVWQZX": ("movzwq", 2, 8), "MOVWLZX": ("movzwl", 2, 4), "MOVLQZX": ("movl", 4, 4)}
 
@@ -84,6 +92,10 @@ def operand(fn, op, size):
         return op
     if re.fullmatch(r"X\d+", op):
         return "%xmm" + op[1:]
+    if op in ("AH", "BH", "CH", "DH"):  # the high byte of AX..DX (MOVB AH, CL: the table-log byte of a decSymbol)
+        if size != 1:
+            raise ValueError("byte register in a wider instruction: " + op)
+        return "%" + op.lower()
     if op in ("AL", "BL", "CL", "DL") or re.fullmatch(r"(SI|DI|BP|R\d+)B", op):  # explicit byte registers
         if size != 1:
             raise ValueError("byte register in a wider instruction: " + op)
@@ -248,6 +260,19 @@ def translate(src_lines):
         if mn in SSE:
             out.append("    %s %s" % (SSE[mn], ", ".join(operand(fn, o, None) for o in ops)))
             continue
+        if mn in BMI3:
+            out.append("    %s %s" % (BMI3[mn], ", ".join(operand(fn, o, 8) for o in ops)))
+            continue
+        if mn in CMOV:
+            out.append("    %s %s, %s" % (CMOV[mn], operand(fn, ops[0], 8), operand(fn, ops[1], 8)))
+            continue
+        if mn in SETCC:
+            out.append("    %s %s" % (SETCC[mn], operand(fn, ops[0], 1)))
+            continue
+        if mn in SX:
+            g, sw, dw = SX[mn]
+            out.append("    %s %s, %s" % (g, operand(fn, ops[0], sw), operand(fn, ops[1], dw)))
+            continue
         if mn in ZX:
             g, sw, dw = ZX[mn]
             out.append("    %s %s, %s" % (g, operand(fn, ops[0], sw), operand(fn, ops[1], dw)))
@@ -263,7 +288,7 @@ def translate(src_lines):
         gas, size = OPS[mn]
         if mn.startswith("LEA"):
             o = [operand(fn, ops[0], 8), operand(fn, ops[1], size)]
-        elif mn.startswith(("SHR", "SHL", "SAR")) and ops[0] in REG64:  # shift count in CX
+        elif mn.startswith(("SHR", "SHL", "SAR", "ROL")) and (ops[0] in REG64 or ops[0] == "CL"):  # shift count in CX
             o = ["%cl", operand(fn, ops[1], size)]
         else:
             o = [operand(fn, x, size) for x in ops]

@@ -12,20 +12,50 @@ import subprocess
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ODIR = os.path.join(_ROOT, "oracle")
 _SO = os.path.join(_ODIR, "_ref", "libzstdref.so")
+# The same translation in the reference's amd64 build flavour: the Go halves of its assembly routines + the assembly itself
+# (zstd/seqdec_amd64.s, fse_decoder_amd64.s, matchlen_amd64.s, huff0/decompress_amd64.s) — what an x86-64 user of the package runs.
+_SO_AMD64 = os.path.join(_ODIR, "_ref", "libzstdref_amd64.so")
 _REFSRC = "/root/reference/zstd/encoder.go"
-_lib = None
+_libs = {}
+FLAVOURS = ("generic", "amd64", "amd64-nobmi")   # amd64-nobmi: the amd64 flavour with its BMI1 / BMI2 routines switched off
+_flavour = "generic"
+
+
+class flavour:
+    """with oracle_goref.flavour("amd64"): ... — which build of the reference the calls inside go to."""
+    def __init__(self, name):
+        assert name in FLAVOURS, name
+        self.name = name
+
+    def __enter__(self):
+        global _flavour
+        self.prev, _flavour = _flavour, self.name
+        return self
+
+    def __exit__(self, *a):
+        global _flavour
+        _flavour = self.prev
 
 
 def available():
     return os.path.exists(_SO) or os.path.exists(_REFSRC)
 
 
+def amd64_available():
+    import platform
+    return platform.machine() in ("x86_64", "AMD64") and (os.path.exists(_SO_AMD64) or os.path.exists(_REFSRC))
+
+
 def lib():
-    global _lib
-    if _lib is None:
+    key = "generic" if _flavour == "generic" else "amd64"
+    L = _libs.get(key)
+    if L is None:
+        so = _SO if key == "generic" else _SO_AMD64
         if os.path.exists(_REFSRC):
-            subprocess.check_call(["make", "-C", _ODIR, "-s", "_ref/libzstdref.so"])
-        L = C.CDLL(_SO)
+            subprocess.check_call(["make", "-C", _ODIR, "-s", "_ref/" + os.path.basename(so)])
+        L = C.CDLL(so)
+        L.goref_force_bmi.restype = None
+        L.goref_force_bmi.argtypes = [C.c_int]
         L.goref_zstd_encode_all.restype = C.c_longlong
         L.goref_zstd_encode_all.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 8 + [C.c_char_p, C.c_longlong, C.c_uint,
                                             C.c_char_p, C.c_int]
@@ -36,8 +66,10 @@ def lib():
         L.goref_zstd_decode_all.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         L.goref_s2_encode.restype = C.c_longlong
         L.goref_s2_encode.argtypes = [C.c_int, C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
-        _lib = L
-    return _lib
+        _libs[key] = L
+    if key == "amd64":
+        L.goref_force_bmi(0 if _flavour == "amd64-nobmi" else -1)
+    return L
 
 
 def _flag(v):

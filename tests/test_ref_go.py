@@ -24,6 +24,12 @@ REFIN = os.path.join(HERE, "golden", "ref_inputs")
 pytestmark = pytest.mark.skipif(not oracle_goref.available(), reason="oracle/_ref/libzstdref.so neither present nor buildable (no /root/reference)")
 
 
+def _flavours():
+    """The builds of the reference the decoder / encoder comparisons run against: the portable one, and — on x86-64 — its amd64 build
+    (the package's assembly routines assembled into oracle/_ref/libzstdref_amd64.so) with and without the BMI2 forms."""
+    return list(oracle_goref.FLAVOURS) if oracle_goref.amd64_available() else ["generic"]
+
+
 def _units():
     u = []
     for kind, first in (("T", 1), ("M", 2), ("J", 3), ("H", 4)):
@@ -166,27 +172,77 @@ def test_reference_decoder_accepts_the_oracles_frames_and_rejects_damage(oracle,
     translated) decodes what the oracle writes — EncodeAll frames of every corpus kind and size class, streams with Flush points,
     job-mode streams — back to the input, and refuses damaged frames where the in-repo decoder refuses them too."""
     ref = oracle.ZstdOracle(level=level, window_size=1 << 17)
+    big = oracle.ZstdOracle(level=level)  # the level's own window: offset codes beyond the 56-bit fast path of the assembly (seqdec_asm.go:218)
     t = corpora.corpus("T", 5, 131072, first_unit=2).tobytes()
     units = [t[:131072], t[:300000], t[:100], b"", t[:70000]] + [corpora.corpus(k, 1, 131072, first_unit=3).tobytes() for k in "HJM"]
     units += corpora.stress_units(seed=7, n=6) + corpora.rle_literal_units(n=3, seed=2)[1][:0]
-    for u in units:
-        assert oracle_goref.zstd_decode_all(ref.encode_all(u), len(u)) == u, len(u)
-    assert oracle_goref.zstd_decode_all(ref.encode_stream(t[:300000], (70000, 70010, 200001)), 300000) == t[:300000]
-    assert oracle_goref.zstd_decode_all(ref.encode_jobs(t[:640000], (1000, 600000)), 640000) == t[:640000]
+    frames = [(ref.encode_all(u), u) for u in units] + [(big.encode_all(t[:400000]), t[:400000])]
+    frames.append((ref.encode_stream(t[:300000], (70000, 70010, 200001)), t[:300000]))
+    frames.append((ref.encode_jobs(t[:640000], (1000, 600000)), t[:640000]))
     frame = bytearray(ref.encode_all(t[:131072]))
     rng = np.random.default_rng(level)
+    damaged = []
     for pos in [5, 7, 12, len(frame) - 1, len(frame) - 5] + [int(x) for x in rng.integers(13, len(frame) - 6, 12)]:
         g = bytearray(frame)
         g[pos] ^= 1 << int(rng.integers(0, 8))
+        damaged.append((pos, bytes(g)))
+    for fl in _flavours():
+        with oracle_goref.flavour(fl):
+            for f, u in frames:
+                assert oracle_goref.zstd_decode_all(f, len(u)) == u, (fl, len(u))
+            for pos, g in damaged:
+                try:
+                    ok_ref = oracle_goref.zstd_decode_all(g, 131072 + 64) == t[:131072]
+                except ValueError:
+                    ok_ref = False
+                try:
+                    ok_own = oracle.zstd_decompress(g, 131072 + 64) == t[:131072]
+                except Exception:
+                    ok_own = False
+                assert ok_ref == ok_own and not ok_ref, (fl, pos, ok_ref, ok_own)  # (a flipped bit always breaks the checksum if nothing else)
+
+
+@pytest.mark.skipif(not oracle_goref.amd64_available(), reason="the amd64 flavour of oracle/_ref needs an x86-64 host")
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_the_references_amd64_build_writes_and_reads_the_same_frames(oracle, level):
+    """The amd64 build of the reference — matchLen of zstd/matchlen_amd64.s inside all four encoders; sequenceDecs_decode[_56] /
+    decodeSync[_safe] / executeSimple[_safe] of zstd/seqdec_amd64.s in their plain and BMI2 forms, buildDtable_asm of
+    zstd/fse_decoder_amd64.s, the 1X / 4X loops of huff0/decompress_amd64.s inside its decoder — against its portable build: the
+    same frames out of EncodeAll / streams / dictionaries, and on 400 damaged frames per level the same verdict and, where a frame is
+    still accepted (no checksum), the same bytes."""
+    t = corpora.corpus("T", 4, 131072, first_unit=21).tobytes()
+    m = corpora.corpus("M", 2, 131072, first_unit=4).tobytes()
+    dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
+    units = [t[:131072], t[:300001], m[:200000], t[:4000], t[:9], b""] + corpora.stress_units(seed=31, n=12)
+    want = [oracle_goref.zstd_encode_all(u, level=level) for u in units]
+    wantd = [oracle_goref.zstd_encode_all(u, level=level, dict_id=5, dict_content=dct) for u in units[:4]]
+    wants = oracle_goref.zstd_encode_stream(t[:400000], (100000, 100001, 333333), level=level)
+    nocrc = oracle_goref.zstd_encode_all(t[:200000], level=level, crc=False, window_size=1 << 17)
+    rng = np.random.default_rng(100 + level)
+    damaged = []
+    for _ in range(400):
+        g = bytearray(nocrc)
+        for _k in range(int(rng.integers(1, 3))):
+            g[int(rng.integers(4, len(g)))] ^= 1 << int(rng.integers(0, 8))
+        damaged.append(bytes(g))
+
+    def verdict(g):
         try:
-            ok_ref = oracle_goref.zstd_decode_all(bytes(g), 131072 + 64) == t[:131072]
+            return oracle_goref.zstd_decode_all(g, 300000)
         except ValueError:
-            ok_ref = False
-        try:
-            ok_own = oracle.zstd_decompress(bytes(g), 131072 + 64) == t[:131072]
-        except Exception:
-            ok_own = False
-        assert ok_ref == ok_own and not ok_ref, (pos, ok_ref, ok_own)  # (a flipped bit always breaks the checksum if nothing else)
+            return None
+    base = [verdict(g) for g in damaged]
+    assert any(b is not None for b in base) and any(b is None for b in base)
+    for fl in ("amd64", "amd64-nobmi"):
+        with oracle_goref.flavour(fl):
+            assert [oracle_goref.zstd_encode_all(u, level=level) for u in units] == want, fl
+            assert [oracle_goref.zstd_encode_all(u, level=level, dict_id=5, dict_content=dct) for u in units[:4]] == wantd, fl
+            assert oracle_goref.zstd_encode_stream(t[:400000], (100000, 100001, 333333), level=level) == wants, fl
+            for f, u in zip(want, units):
+                assert oracle_goref.zstd_decode_all(f, len(u)) == u, (fl, len(u))
+            got = [verdict(g) for g in damaged]
+            diff = [i for i in range(len(damaged)) if got[i] != base[i]]
+            assert not diff, (fl, diff[:5])
 
 
 def _ref_inputs(limit):
@@ -327,16 +383,18 @@ def test_reference_decoder_accepts_every_device_frame(kclib, level):
     buf, off = corpora.pack_units(units)
     enc = zstd.NewWriter(None, *opts)
     out, out_off = enc.EncodeUnits(buf, off)
-    for i, u in enumerate(units):
-        assert oracle_goref.zstd_decode_all(out[int(out_off[i]):int(out_off[i + 1])].tobytes(), len(u)) == u, (i, len(u))
     cuts = [((len(u) // 3, len(u) // 2) if len(u) > 10 else ()) for u in units]
     sout, soff = enc.EncodeStreams(buf, off, flush_at=cuts)
-    for i, u in enumerate(units):
-        assert oracle_goref.zstd_decode_all(sout[int(soff[i]):int(soff[i + 1])].tobytes(), len(u)) == u, (i, len(u))
     enc.Close()
     jenc = zstd.NewWriter(None, zstd.WithEncoderLevel(lv), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(4), zstd.WithWindowSize(1 << 17))
-    assert oracle_goref.zstd_decode_all(jenc.EncodeJobs(t[:640000], (1000, 600000)), 640000) == t[:640000]
+    jframe = jenc.EncodeJobs(t[:640000], (1000, 600000))
     jenc.Close()
+    for fl in _flavours():  # the portable decoder, and the amd64 build's assembly decoders with and without BMI2
+        with oracle_goref.flavour(fl):
+            for i, u in enumerate(units):
+                assert oracle_goref.zstd_decode_all(out[int(out_off[i]):int(out_off[i + 1])].tobytes(), len(u)) == u, (fl, i, len(u))
+                assert oracle_goref.zstd_decode_all(sout[int(soff[i]):int(soff[i + 1])].tobytes(), len(u)) == u, (fl, i, len(u))
+            assert oracle_goref.zstd_decode_all(jframe, 640000) == t[:640000], fl
 
 
 @pytest.mark.gpu
