@@ -140,9 +140,12 @@ long long run_on_big_stack(Call* c, char* err, int err_cap) {
 }  // namespace
 
 namespace {
-struct DecCall { const uint8_t* src; int64_t n; uint8_t* dst; int64_t cap; int64_t result; char err[256]; };
-// zstd.NewReader(nil).DecodeAll(src, nil): the reference's own decoder (its pure-Go form: what noasm / non-amd64 builds run) as the
-// judge of a frame's validity.  No dictionaries (decoderOptions.dicts is a map: not translated).
+struct DecCall {
+    const uint8_t* src; int64_t n; uint8_t* dst; int64_t cap; int64_t result; char err[256];
+    const uint8_t* dict = nullptr; int64_t dict_len = 0; uint32_t dict_id = 0; int dict_full = 0;
+};
+// zstd.NewReader(nil, <WithDecoderDicts(d) | WithDecoderDictRaw(id, d)>).DecodeAll(src, nil): the reference's own decoder as the
+// judge of a frame's validity (decoderOptions.dicts, a map in the reference, is a list here: ref_go/manifest.py).
 void* dec_thread(void* a) {
     using namespace go;
     DecCall* c = (DecCall*)a;
@@ -151,6 +154,13 @@ void* dec_thread(void* a) {
         init_packages();
         zstd::Decoder d;
         d.o.setDefault();  // NewReader's first statement (decoder.go:91)
+        if (c->dict != nullptr && c->dict_len > 0) {  // ... then its option loop
+            Slice<byte> dd = make_slice<byte>(c->dict_len);
+            memcpy((void*)dd.p, c->dict, (size_t)c->dict_len);
+            zstd::DOption opt = c->dict_full ? zstd::WithDecoderDicts(Slice<Slice<byte>>{dd}) : zstd::WithDecoderDictRaw(uint32::raw(c->dict_id), dd);
+            error oe = opt(&d.o);
+            if (oe != nil) { snprintf(c->err, sizeof c->err, "%s", oe.e->msg.c_str()); c->result = -6; return nullptr; }
+        }
         Slice<byte> src = make_slice<byte>(c->n);
         if (c->n) memcpy((void*)src.p, c->src, (size_t)c->n);
         auto r = d.DecodeAll(src, Slice<byte>());
@@ -187,9 +197,18 @@ extern "C" {
 // amd64 flavour: 0 = the dispatch helpers take the routines without BMI1 / BMI2, -1 = what the host's CPU has (a no-op in the
 // portable flavour, which has no such routines)
 void goref_force_bmi(int mode) { cpuinfo::force() = mode; }
+long long goref_zstd_decode_all_dict(const uint8_t* src, long long n, uint8_t* dst, long long cap, const uint8_t* dict, long long dict_len,
+                                     unsigned dict_id, char* err, int err_cap);
 // DecodeAll(src, nil) of zstd.NewReader(nil): >= 0 the decoded length, -5 the decoder's error (text in err)
 long long goref_zstd_decode_all(const uint8_t* src, long long n, uint8_t* dst, long long cap, char* err, int err_cap) {
+    return goref_zstd_decode_all_dict(src, n, dst, cap, nullptr, 0, 0, err, err_cap);
+}
+// ... with a dictionary registered: dict_id 0xFFFFFFFF = a full-format dictionary (WithDecoderDicts), else WithDecoderDictRaw(dict_id, dict)
+long long goref_zstd_decode_all_dict(const uint8_t* src, long long n, uint8_t* dst, long long cap, const uint8_t* dict, long long dict_len,
+                                     unsigned dict_id, char* err, int err_cap) {
     DecCall c{src, n, dst, cap, 0, {0}};
+    c.dict = dict; c.dict_len = dict_len; c.dict_id = dict_id;
+    if (dict_id == 0xFFFFFFFFu) { c.dict_full = 1; c.dict_id = 0; }
     pthread_attr_t at;
     pthread_attr_init(&at);
     pthread_attr_setstacksize(&at, (size_t)1 << 30);

@@ -32,8 +32,8 @@ CFG = {
     # path -> the ONLY declarations taken from that file (the rest of it is the decoder / the streaming writer)
     "only": {
         "s2/decode.go": {"ErrCorrupt", "ErrCRC", "ErrTooLarge", "ErrUnsupported"},   # the package's error values
-        "zstd/decoder.go": {"Decoder", "Decoder.DecodeAll"},   # the stateless DecodeAll; not the streaming reader (goroutines, channels), no dictionaries (a map)
-        "zstd/decoder_options.go": {"DOption", "decoderOptions", "decoderOptions.setDefault"},
+        "zstd/decoder.go": {"Decoder", "Decoder.DecodeAll", "Decoder.setDict"},   # the stateless DecodeAll; not the streaming reader (goroutines, channels)
+        "zstd/decoder_options.go": {"DOption", "decoderOptions", "decoderOptions.setDefault", "WithDecoderDicts", "WithDecoderDictRaw"},
         "zstd/dict.go": {"dict", "dict.*", "dictMagic", "dictMaxLength", "loadDict"},   # (not InspectDictionary / BuildDict)
         # EncodeAll and the streaming writer in both modes (blocks; WithConcurrentBlocks jobs) — not ReadFrom (io.Reader plumbing), not the
         # goroutine pool behind the public EncodeAll (the driver hands encodeAll an encoder)
@@ -45,7 +45,6 @@ CFG = {
     },
     "drop_fields": {
         "zstd.Decoder": {"decoders", "current", "syncStream", "frame", "streamWg"},
-        "zstd.decoderOptions": {"dicts"},                  # map[uint32]*dict: the translated decoder judges frames without a dictionary
         "zstd.Encoder": {"encoders", "init"},              # the pool of encoders EncodeAll draws from (the driver hands it one)
         "zstd.encJob": {"done"},                           # job mode's worker plumbing: see the patches of zstd/enc_jobs.go
         "zstd.jobState": {"jobCh", "resultCh", "cond", "workerWg", "flusherWg", "inputPool", "outputPool", "overlapPool"},
@@ -65,7 +64,16 @@ CFG = {
             (r"\tif d\.decoders == nil \{\n\t\treturn dst, ErrDecoderClosed\n\t\}\n", "", "DecodeAll takes a block decoder from the pool (a channel): here a fresh one"),
             (r"block := <-d\.decoders\n\tframe := block\.localFrame", "block := newBlockDec(d.o.lowMem)\n\tblock.localFrame = newFrameDec(d.o)\n\tframe := block.localFrame", "what Decoder's pool holds (decoder.go:105-115)"),
             (r"\t\td\.decoders <- block\n", "", "nothing to give back"),
-            (r"\t\tif err = d\.setDict\(frame\); err != nil \{\n\t\t\treturn nil, err\n\t\t\}\n", "", "no dictionaries here (decoderOptions.dicts is a map)"),
+            (r"\tdict, ok := d\.o\.dicts\[frame\.DictionaryID\]\n",
+             "\tvar dd *dict\n\tok := false\n\tfor i := len(d.o.dicts) - 1; i >= 0; i-- {\n\t\tif d.o.dicts[i].id == frame.DictionaryID {\n\t\t\tdd = d.o.dicts[i]\n\t\t\tok = true\n\t\t\tbreak\n\t\t}\n\t}\n",
+             "decoderOptions.dicts is a map[uint32]*dict (the translation has no maps): kept as the list of registered dictionaries, looked up from the end (the last one registered under an id wins, like the map's overwrite)"),
+            (r"frame\.history\.setDict\(dict\)", "frame.history.setDict(dd)", "the lookup's variable (previous patch)"),
+        ],
+        "zstd/decoder_options.go": [
+            (r"\tdicts           map\[uint32\]\*dict\n", "\tdicts           []*dict\n", "see zstd/decoder.go: a list instead of a map"),
+            (r"\t\tif o\.dicts == nil \{\n\t\t\to\.dicts = make\(map\[uint32\]\*dict\)\n\t\t\}\n", "", "nothing to allocate for a list"),
+            (r"o\.dicts\[d\.id\] = d\n", "o.dicts = append(o.dicts, d)\n", "register = append"),
+            (r"o\.dicts\[id\] = (&dict\{[^\n]*\})\n", r"o.dicts = append(o.dicts, \1)\n", "register = append"),
         ],
         # WithConcurrentBlocks (enc_jobs.go).  What decides the bytes is translated as it stands: the job cutting (writeJobs, dispatchJob,
         # flushJobs, closeJobs), the per-job encode (compressJob: ResetPrefix / Reset, then block by block) and the frame assembly.  What

@@ -64,6 +64,8 @@ def lib():
                                                C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         L.goref_zstd_decode_all.restype = C.c_longlong
         L.goref_zstd_decode_all.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+        L.goref_zstd_decode_all_dict.restype = C.c_longlong
+        L.goref_zstd_decode_all_dict.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_longlong, C.c_uint, C.c_char_p, C.c_int]
         L.goref_s2_encode.restype = C.c_longlong
         L.goref_s2_encode.argtypes = [C.c_int, C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         _libs[key] = L
@@ -134,15 +136,18 @@ def zstd_encode_units(src, unit_off, **kw):
     return b"".join(outs), np.array(off, dtype=np.uint64)
 
 
-def zstd_decode_all(frames: bytes, max_out: int) -> bytes:
+def zstd_decode_all(frames: bytes, max_out: int, dict_id=0, dict_content=None, dict_blob=None) -> bytes:
     """zstd.NewReader(nil).DecodeAll(frames, nil) of the reference — its own decoder in the pure-Go form (what noasm / non-amd64 builds
     run), translated like the encoders: the judge of a frame's validity (block and literal section types, both Huffman forms, the FSE
-    tables and their modes, sequence execution, window and size checks, the content checksum).  No dictionaries.  Raises on the
-    decoder's error, with its message."""
+    tables and their modes, sequence execution, window and size checks, the content checksum).  dict_content + dict_id:
+    WithDecoderDictRaw; dict_blob: WithDecoderDicts (a full-format dictionary).  Raises on the decoder's error, with its message."""
+    if dict_blob is not None:
+        dict_id, dict_content = FULL_DICT, dict_blob
     frames = bytes(frames)
     out = C.create_string_buffer(max_out + 64)
     err = C.create_string_buffer(256)
-    n = lib().goref_zstd_decode_all(frames, len(frames), out, max_out + 64, err, 256)
+    d = bytes(dict_content) if dict_content else None
+    n = lib().goref_zstd_decode_all_dict(frames, len(frames), out, max_out + 64, d, len(d) if d else 0, int(dict_id), err, 256)
     if n < 0:
         raise ValueError("reference decoder: %s (%d)" % (err.value.decode(errors="replace"), n))
     return out.raw[:n]

@@ -202,6 +202,32 @@ def test_reference_decoder_accepts_the_oracles_frames_and_rejects_damage(oracle,
                 assert ok_ref == ok_own and not ok_ref, (fl, pos, ok_ref, ok_own)  # (a flipped bit always breaks the checksum if nothing else)
 
 
+def _dict_cases(oracle):
+    """(keyword arguments for the encoders / decoders, inputs): a raw dictionary, the reference's d0.dict fixture with inputs of its kind."""
+    import test_oracle_kats as tk
+    dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
+    t = corpora.corpus("T", 3, 131072, first_unit=8).tobytes()
+    blob, ins = tk._dict_fixture(oracle)
+    return [(dict(dict_id=7, dict_content=dct), [t[:131072], t[:300000], dct[100:9000] + t[:4000], t[:50]]),
+            (dict(dict_blob=blob), list(ins)[:5] + [ins[1][:40], t[:70000]])]
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_reference_decoder_reads_dictionary_frames(oracle, level):
+    """WithDecoderDictRaw / WithDecoderDicts (decoder_options.go:112-141; history.setDict): the reference's decoder, in every build
+    flavour, returns the input of the oracle's dictionary frames, and refuses them without the dictionary (`unknown dictionary`)."""
+    for kw, units in _dict_cases(oracle):
+        okw = dict(dict_id=kw["dict_id"], dict_content=kw["dict_content"]) if "dict_id" in kw else dict(dict_blob=kw["dict_blob"])
+        ref = oracle.ZstdOracle(level=level, **okw)
+        frames = [ref.encode_all(u) for u in units]
+        for fl in _flavours():
+            with oracle_goref.flavour(fl):
+                for f, u in zip(frames, units):
+                    assert oracle_goref.zstd_decode_all(f, len(u), **kw) == u, (fl, len(u))
+                with pytest.raises(ValueError, match="unknown dictionary"):
+                    oracle_goref.zstd_decode_all(frames[0], len(units[0]))
+
+
 @pytest.mark.skipif(not oracle_goref.amd64_available(), reason="the amd64 flavour of oracle/_ref needs an x86-64 host")
 @pytest.mark.parametrize("level", [1, 2, 3, 4])
 def test_the_references_amd64_build_writes_and_reads_the_same_frames(oracle, level):
@@ -389,12 +415,25 @@ def test_reference_decoder_accepts_every_device_frame(kclib, level):
     jenc = zstd.NewWriter(None, zstd.WithEncoderLevel(lv), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(4), zstd.WithWindowSize(1 << 17))
     jframe = jenc.EncodeJobs(t[:640000], (1000, 600000))
     jenc.Close()
+    # dictionary frames: a raw dictionary and the reference's d0.dict (EncodeAll; C5 is a dictionary configuration)
+    import oracle_lib
+    dframes = []
+    for kw, dunits in _dict_cases(oracle_lib):
+        dopts = [zstd.WithEncoderDictRaw(kw["dict_id"], kw["dict_content"])] if "dict_id" in kw else [zstd.WithEncoderDict(kw["dict_blob"])]
+        denc = zstd.NewWriter(None, *(opts + dopts))
+        dbuf, doff = corpora.pack_units(dunits)
+        dout, dout_off = denc.EncodeUnits(dbuf, doff)
+        denc.Close()
+        dframes.append((kw, dunits, dout, dout_off))
     for fl in _flavours():  # the portable decoder, and the amd64 build's assembly decoders with and without BMI2
         with oracle_goref.flavour(fl):
             for i, u in enumerate(units):
                 assert oracle_goref.zstd_decode_all(out[int(out_off[i]):int(out_off[i + 1])].tobytes(), len(u)) == u, (fl, i, len(u))
                 assert oracle_goref.zstd_decode_all(sout[int(soff[i]):int(soff[i + 1])].tobytes(), len(u)) == u, (fl, i, len(u))
             assert oracle_goref.zstd_decode_all(jframe, 640000) == t[:640000], fl
+            for kw, dunits, dout, dout_off in dframes:
+                for i, u in enumerate(dunits):
+                    assert oracle_goref.zstd_decode_all(dout[int(dout_off[i]):int(dout_off[i + 1])].tobytes(), len(u), **kw) == u, (fl, sorted(kw), i, len(u))
 
 
 @pytest.mark.gpu
