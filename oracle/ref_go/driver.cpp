@@ -125,6 +125,68 @@ void* s2_thread(void* a) {
 }  // namespace
 
 namespace {
+// s2.NewWriter(w, WriterConcurrency(1), <options>) as a stream: Write(src[..cut]) + Flush() at every cut, Close(); what w received.
+// NewWriter's body (s2/writer.go:34-57) is restated here — its defaults are runtime.GOMAXPROCS(0) and crypto/rand — around the
+// translated option functions, Reset, Write / writeSync, Flush, Close / closeIndex, Index.add / appendTo, skippableFrame.
+struct S2StreamCall {
+    const uint8_t* src; int64_t n; uint8_t* dst; int64_t cap;
+    int level, snappy, block_size, add_index, padding, flush_on_write;
+    const int64_t* cuts; int64_t n_cuts; int64_t result; char err[256];
+};
+void* s2_stream_thread(void* a) {
+    using namespace go;
+    S2StreamCall* c = (S2StreamCall*)a;
+    rt::Scope scope;
+    try {
+        { rt::Permanent perm; s2::go_init(); }
+        struct Sink : io::WriterImpl {
+            Slice<byte> buf;
+            std::tuple<Int, error> Write(Slice<byte> p) override { buf = append_all(buf, p); return std::tuple<Int, error>(len(p), error()); }
+        } sink;
+        s2::Writer w;
+        w.blockSize = Int(s2::defaultBlockSize);
+        w.concurrency = Int(K(1LL));
+        w.randSrc = rand_::Reader;  // (padding bytes: the io.Reader stub of gort.h leaves the zeroes of make([]byte, n): a zero source)
+        w.level = uint8(s2::levelFast);
+        auto apply = [&](s2::WriterOption opt) { error er = opt(&w); if (er != nil) panic(er); };
+        apply(s2::WriterConcurrency(Int(K(1LL))));
+        if (c->level == 1) apply(s2::WriterBetterCompression());
+        if (c->level == 2) apply(s2::WriterBestCompression());
+        if (c->level == 3) apply(s2::WriterUncompressed());
+        if (c->snappy) apply(s2::WriterSnappyCompat());
+        if (c->block_size > 0) apply(s2::WriterBlockSize(Int(K((long long)c->block_size))));
+        if (c->add_index) apply(s2::WriterAddIndex());
+        if (c->padding > 0) apply(s2::WriterPadding(Int(K((long long)c->padding))));
+        if (c->flush_on_write) apply(s2::WriterFlushOnWrite());
+        w.obufLen = Int(s2::obufHeaderLen) + s2::MaxEncodedLen(w.blockSize);
+        w.paramsOK = true;
+        w.ibuf = make_slice<byte>(0, w.blockSize.v);
+        w.Reset(io::Writer(&sink));
+        Slice<byte> src = make_slice<byte>(c->n);
+        if (c->n) memcpy((void*)src.p, c->src, (size_t)c->n);
+        auto check = [&](error er) { if (er != nil) panic(er); };
+        long long pos = 0;
+        for (long long i = 0; i < c->n_cuts; i++) {
+            const long long cut = c->cuts[i];
+            if (cut > c->n) continue;
+            if (cut > pos) { auto r = w.Write(src.sl(pos, cut)); check(std::get<1>(r)); pos = cut; }
+            check(w.Flush());
+        }
+        if (c->n > pos) { auto r = w.Write(src.sl(pos, c->n)); check(std::get<1>(r)); }
+        check(w.Close());
+        Slice<byte> out = sink.buf;
+        if (out.n > c->cap) { c->result = -2; return nullptr; }
+        if (out.n) memcpy(c->dst, out.p, (size_t)out.n);
+        c->result = out.n;
+    } catch (const go::Panic& p) {
+        snprintf(c->err, sizeof c->err, "panic: %s", p.msg.c_str());
+        c->result = -1;
+    }
+    return nullptr;
+}
+}  // namespace
+
+namespace {
 // the translated encoders hold their tables by value, like the Go structs do on Go's heap: a thread with a large stack
 long long run_on_big_stack(Call* c, char* err, int err_cap) {
     pthread_attr_t at;
@@ -227,6 +289,21 @@ long long goref_s2_encode(int level, const uint8_t* src, long long n, uint8_t* d
     pthread_attr_setstacksize(&at, (size_t)1 << 30);
     pthread_t th;
     if (pthread_create(&th, &at, s2_thread, &c) != 0) return -3;
+    pthread_join(th, nullptr);
+    pthread_attr_destroy(&at);
+    if (err && err_cap > 0) { strncpy(err, c.err, (size_t)err_cap - 1); err[err_cap - 1] = 0; }
+    return c.result;
+}
+// The framed S2 stream of s2.NewWriter(w, WriterConcurrency(1), ...): level 0 fast / 1 better / 2 best / 3 uncompressed; block_size 0 =
+// the default (1 MiB); padding 0 = none (padding bytes are zeroes: a zero WriterPaddingSrc); Flush() after the input offsets in cuts
+long long goref_s2_stream(const uint8_t* src, long long n, uint8_t* dst, long long cap, int level, int snappy, int block_size, int add_index,
+                          int padding, int flush_on_write, const long long* cuts, long long n_cuts, char* err, int err_cap) {
+    S2StreamCall c{src, n, dst, cap, level, snappy, block_size, add_index, padding, flush_on_write, (const int64_t*)cuts, n_cuts < 0 ? 0 : n_cuts, 0, {0}};
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, (size_t)1 << 30);
+    pthread_t th;
+    if (pthread_create(&th, &at, s2_stream_thread, &c) != 0) return -3;
     pthread_join(th, nullptr);
     pthread_attr_destroy(&at);
     if (err && err_cap > 0) { strncpy(err, c.err, (size_t)err_cap - 1); err[err_cap - 1] = 0; }

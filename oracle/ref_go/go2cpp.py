@@ -41,7 +41,7 @@ CPP_RESERVED = {"new", "delete", "this", "class", "template", "typename", "union
                 "int32", "int64", "byte", "rune", "error", "idx", "def", "main", "signal", "index", "abs", "log", "exp", "floor", "ceil", "round",
                 "time", "clock", "rand", "random", "exit", "abort", "free", "malloc", "calloc", "div", "remove", "rename", "link", "read", "write"}
 BUILTIN_FUNCS = {"len", "cap", "append", "copy", "make", "new", "panic", "min", "max", "print", "println", "delete", "close", "clear", "recover"}
-LIBRARY_PKGS = {"bits", "binary", "math", "fmt", "errors", "bytes", "sync", "io", "rand", "race", "le", "hex", "strings", "strconv", "os", "runtime", "sort", "cpuinfo", "debug", "unsafe", "hash", "bufio", "log", "time", "atomic"}
+LIBRARY_PKGS = {"crc32", "bits", "binary", "math", "fmt", "errors", "bytes", "sync", "io", "rand", "race", "le", "hex", "strings", "strconv", "os", "runtime", "sort", "cpuinfo", "debug", "unsafe", "hash", "bufio", "log", "time", "atomic"}
 
 
 class Unsupported(Exception):
@@ -240,7 +240,10 @@ class Emitter:
         return s
 
     def ex_str(self, e):
-        return "String(%s)" % c_string(e[1])
+        lit = c_string(e[1])
+        if re.search(r"\\(x00|0(?![0-7])|00(?![0-7])|000)", lit):  # a NUL inside the literal: a C string would end there (s2's magic chunk)
+            return "String(std::string(%s, sizeof(%s) - 1))" % (lit, lit)
+        return "String(%s)" % lit
 
     def ex_ident(self, e):
         n = e[1]
@@ -253,6 +256,8 @@ class Emitter:
                 return "K(%dLL)" % self.iota
             if n in BUILTIN_TYPES and n not in self.pkg.types:
                 return BUILTIN_TYPES[n]
+            if n in getattr(self, "recv_methods", ()) and n in self.pkg.funcs:
+                return "%s::%s" % (mangle(self.pkg.name), mangle(n))
         return mangle(n)
 
     def ex_paren(self, e):
@@ -1122,6 +1127,12 @@ class Emitter:
             if p[0]:
                 self.declare(p[0])
         boxed = any(st[0] == "return" and len(st[1]) == 1 and st[1][0][0] == "funclit" for st in body[1])
+        # inside a method, C++ finds the class's members before the namespace's functions: a package-level function that shares its
+        # name with a method of the receiver's type (s2: encodeBlock) has to be written with its namespace
+        self.recv_methods = set()
+        if recv is not None:
+            rt = recv[1][1] if recv[1][0] == "ptr" else recv[1]
+            self.recv_methods = {m[1][1] for m in self.pkg.methods.get(rt[2], [])}
         self.heap_vars = set()
         self.addr_roots(body, self.heap_vars)
         self.sliced_vars = set()

@@ -452,6 +452,12 @@ inline Int PutUvarint(const Slice<byte>& buf, uint64 x) {
     buf[K(i)] = byte::raw((uint8_t)v);
     return Int::raw(i + 1);
 }
+// encoding/binary.PutVarint: zig-zag, then PutUvarint
+inline Int PutVarint(const Slice<byte>& buf, int64 x) {
+    uint64_t ux = (uint64_t)x.v << 1;
+    if (x.v < 0) ux = ~ux;
+    return PutUvarint(buf, uint64::raw(ux));
+}
 inline std::tuple<uint64, Int> Uvarint(const Slice<byte>& buf) {
     uint64_t x = 0;
     unsigned sft = 0;
@@ -553,8 +559,27 @@ struct Writer {
 static const go::error ErrUnexpectedEOF = go::error(new go::ErrorObj{"unexpected EOF"});
 static const go::error EOF_ = go::error(new go::ErrorObj{"EOF"});
 static const go::error ErrShortBuffer = go::error(new go::ErrorObj{"short buffer"});
+static const go::error ErrShortWrite = go::error(new go::ErrorObj{"short write"});
 inline std::tuple<go::Int, go::error> ReadFull(const Reader&, const go::Slice<go::byte>& b) { return {go::len(b), go::error()}; }
 }  // namespace io
+namespace crc32 {  // hash/crc32 of the Go standard library: table-driven, reflected (s2 uses the Castagnoli polynomial)
+struct Table { uint32_t t[256]; };
+static constexpr go::K Castagnoli = go::K(0x82f63b78LL);
+inline Table* MakeTable(go::K poly) {
+    Table* tb = new Table();
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ (uint32_t)poly.v : c >> 1;
+        tb->t[i] = c;
+    }
+    return tb;
+}
+inline go::uint32 Update(go::uint32 crc, Table* tab, const go::Slice<go::byte>& p) {
+    uint32_t c = ~crc.v;
+    for (long long i = 0; i < p.n; i++) c = tab->t[(c ^ p.p[i].v) & 0xFF] ^ (c >> 8);
+    return go::uint32::raw(~c);
+}
+}  // namespace crc32
 namespace rdebug {
 inline void PrintStack() {}
 }

@@ -7,7 +7,7 @@ CFG = {
         ("huff0", ["huff0/huff0.go", "huff0/bitwriter.go", "huff0/bitreader.go", "huff0/compress.go", "huff0/decompress.go", "huff0/decompress_generic.go"]),
         ("xxhash", ["zstd/internal/xxhash/xxhash.go", "zstd/internal/xxhash/xxhash_other.go"]),
         ("compress", ["compressible.go"]),
-        ("s2", ["s2/s2.go", "s2/decode.go", "s2/hashtable_pool.go", "s2/dict.go", "s2/encode.go", "s2/encode_go.go", "s2/encode_all.go", "s2/encode_better.go", "s2/encode_best.go"]),
+        ("s2", ["s2/s2.go", "s2/decode.go", "s2/hashtable_pool.go", "s2/dict.go", "s2/encode.go", "s2/encode_go.go", "s2/encode_all.go", "s2/encode_better.go", "s2/encode_best.go", "s2/index.go", "s2/writer.go"]),
         ("zstd", ["zstd/zstd.go", "zstd/hash.go", "zstd/matchlen_generic.go", "zstd/bitwriter.go", "zstd/seqenc.go", "zstd/fse_encoder.go",
                   "zstd/fse_predefined.go", "zstd/frameenc.go", "zstd/blockenc.go", "zstd/bytereader.go", "zstd/enc_base.go", "zstd/enc_fast.go", "zstd/enc_dfast.go",
                   "zstd/enc_better.go", "zstd/enc_best.go", "zstd/seqdec.go", "zstd/seqdec_generic.go", "zstd/dict.go", "zstd/bitreader.go", "zstd/bytebuf.go", "zstd/history.go",
@@ -21,7 +21,7 @@ CFG = {
         "huff0/decompress.go": {"Scratch.matches"},      # a debugging aid (fmt.Fprintf to an io.Writer)
         "zstd/bytebuf.go": {"readerWrapper", "readerWrapper.*"},   # the io.Reader form of the decoder's input (DecodeAll reads a []byte: byteBuf)
         "zstd/fse_decoder.go": {"fseDecoder.mustReadFrom"},        # loads a table dump with encoding/binary.Read (a development aid)
-        "s2/s2.go": {"_", "byter", "crc", "crcTable"},                          # the stream framing's CRC32C (hash/crc32) and an interface assertion
+        "s2/s2.go": {"_", "byter"},                                             # an interface assertion
         "s2/encode.go": {"EstimateBlockSize", "estblockPool", "ConcatBlocks"},  # size estimation (calcBlockSize, not an encoder), block concatenation
         "s2/dict.go": {"Dict.Decode", "MakeDict", "MakeDictManual"},            # the decoder half; dictionary construction by search
         "s2/encode_go.go": {"calcBlockSize", "calcBlockSizeSmall", "cvtLZ4BlockAsm", "cvtLZ4BlockSnappyAsm", "cvtLZ4sBlockAsm", "cvtLZ4sBlockSnappyAsm"},
@@ -32,6 +32,15 @@ CFG = {
     # path -> the ONLY declarations taken from that file (the rest of it is the decoder / the streaming writer)
     "only": {
         "s2/decode.go": {"ErrCorrupt", "ErrCRC", "ErrTooLarge", "ErrUnsupported"},   # the package's error values
+        # the stream writer in its synchronous form (WriterConcurrency(1): Write / Flush / Close run writeSync in the caller — the
+        # framing, the index and the padding do not depend on the concurrency) and the index it appends
+        "s2/writer.go": {"Writer", "Writer.err", "Writer.Reset", "Writer.Write", "Writer.EncodeBuffer", "Writer.encodeBlock", "Writer.write", "Writer.writeSync",
+                         "Writer.AsyncFlush", "Writer.Flush", "Writer.Close", "Writer.CloseIndex", "Writer.closeIndex", "calcSkippableFrame", "skippableFrame",
+                         "errClosed", "WriterOption", "WriterConcurrency", "WriterAddIndex", "WriterBetterCompression", "WriterBestCompression",
+                         "WriterUncompressed", "WriterBlockSize", "WriterPadding", "WriterSnappyCompat", "WriterFlushOnWrite",
+                         "levelUncompressed", "levelFast", "levelBetter", "levelBest"},
+        "s2/index.go": {"S2IndexHeader", "S2IndexTrailer", "maxIndexEntries", "minIndexDist", "indexInfo", "Index", "Index.reset", "Index.allocInfos", "Index.add",
+                        "Index.reduce", "Index.appendTo"},
         "zstd/decoder.go": {"Decoder", "Decoder.DecodeAll", "Decoder.setDict"},   # the stateless DecodeAll; not the streaming reader (goroutines, channels)
         "zstd/decoder_options.go": {"DOption", "decoderOptions", "decoderOptions.setDefault", "WithDecoderDicts", "WithDecoderDictRaw"},
         "zstd/dict.go": {"dict", "dict.*", "dictMagic", "dictMaxLength", "loadDict"},   # (not InspectDictionary / BuildDict)
@@ -44,6 +53,7 @@ CFG = {
         # initPredefined builds the predefined DECODER tables first and copies their normalised counts into the encoders
     },
     "drop_fields": {
+        "s2.Writer": {"output", "buffers", "writerWg", "bufferCB", "customEnc"},   # the concurrent form's channel, buffer pool and wait group; callbacks
         "zstd.Decoder": {"decoders", "current", "syncStream", "frame", "streamWg"},
         "zstd.Encoder": {"encoders", "init"},              # the pool of encoders EncodeAll draws from (the driver hands it one)
         "zstd.encJob": {"done"},                           # job mode's worker plumbing: see the patches of zstd/enc_jobs.go
@@ -92,6 +102,28 @@ CFG = {
             (r"func \(e \*Encoder\) waitAllJobs\(\) \{.*?\n\}\n", "func (e *Encoder) waitAllJobs() {\n}\n", "every dispatched job is already written"),
             (r"\tif v := js\.\w+Pool\.Get\(\); v != nil \{.*?\n\t\}\n", "", "the three sync.Pools are allocation caches: always allocate"),
             (r"\t\tjs\.\w+Pool\.Put\(&b\)\n", "", "likewise"),
+        ],
+        # s2.Writer: everything behind `if w.concurrency == 1 { ... return }` is the concurrent form (one goroutine per block, results
+        # written in order through a channel of channels): cut, the driver only builds writers with WriterConcurrency(1)
+        "s2/writer.go": [
+            (r"\t// Close previous writer, if any\.\n\tif w\.output != nil \{.*?\n\t\}\n", "", "no writer goroutine to close"),
+            (r"(\tif w\.concurrency == 1 \{\n\t\treturn\n\t\}\n).*?\n\}\n", r"\1}\n", "Reset: the writer goroutine of the concurrent form"),
+            (r"(\tif w\.concurrency == 1 \{\n\t\treturn w\.writeSync\(p\)\n\t\}\n).*?\n\}\n", r'\1\tpanic("concurrent form not translated")\n}\n', "write"),
+            (r"(\tif w\.concurrency == 1 \{\n\t\t_, err := w\.writeSync\(buf\)\n)\t\tif w\.bufferCB != nil \{\n\t\t\tw\.bufferCB\(buf\)\n\t\t\}\n(\t\treturn err\n\t\}\n).*?\n\}\n",
+             r'\1\2\tpanic("concurrent form not translated")\n}\n', "EncodeBuffer"),
+            (r"\tif w\.customEnc != nil \{.*?\n\t\}\n(\tif w\.snappy \{)", r"\1", "encodeBlock: no custom encoder here"),
+            (r"obuf := w\.buffers\.Get\(\)\.\(\[\]byte\)\[:w\.obufLen\]", "obuf := make([]byte, w.obufLen)", "sync.Pool is an allocation cache"),
+            (r"\t\tw\.buffers\.Put\(obuf\)\n", "", "likewise"),
+            (r"(\tif err := w\.AsyncFlush\(\); err != nil \{\n\t\treturn err\n\t\}\n)\tif w\.output == nil \{\n\t\treturn w\.err\(nil\)\n\t\}\n.*?\n\}\n", r"\1\treturn w.err(nil)\n}\n",
+             "Flush: nothing queued anywhere in the synchronous form"),
+            (r"\tif w\.output != nil \{\n\t\tclose\(w\.output\)\n\t\tw\.writerWg\.Wait\(\)\n\t\tw\.output = nil\n\t\}\n", "", "closeIndex: no writer goroutine"),
+            (r"tmp = w\.buffers\.Get\(\)\.\(\[\]byte\)\[:0\]\n\t\t\t\tdefer w\.buffers\.Put\(tmp\)\n", "tmp = make([]byte, 0, w.obufLen)\n", "sync.Pool is an allocation cache"),
+        ],
+        "s2/index.go": [
+            (r"struct \{\n\t+compressedOffset   int64\n\t+uncompressedOffset int64\n\t+\}", "indexInfo",
+             "the element type of Index.info is an anonymous struct: given a name (the translation names every struct type)"),
+            (r"// Index represents an S2/Snappy index\.\n", "type indexInfo struct {\n\tcompressedOffset   int64\n\tuncompressedOffset int64\n}\n\n// Index represents an S2/Snappy index.\n",
+             "... declared here"),
         ],
         "s2/hashtable_pool.go": [
             (r"= sync\.Pool\{New: func\(\) any \{ return &\w+\{\} \}\}", " sync.Pool",

@@ -66,6 +66,8 @@ def lib():
         L.goref_zstd_decode_all.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         L.goref_zstd_decode_all_dict.restype = C.c_longlong
         L.goref_zstd_decode_all_dict.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_longlong, C.c_uint, C.c_char_p, C.c_int]
+        L.goref_s2_stream.restype = C.c_longlong
+        L.goref_s2_stream.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 6 + [C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         L.goref_s2_encode.restype = C.c_longlong
         L.goref_s2_encode.argtypes = [C.c_int, C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         _libs[key] = L
@@ -161,6 +163,26 @@ def s2_encode(src: bytes, level=0) -> bytes:
     out = C.create_string_buffer(cap)
     err = C.create_string_buffer(256)
     n = lib().goref_s2_encode(int(level), src, len(src), out, cap, err, 256)
+    if n < 0:
+        raise RuntimeError("translated reference failed (%d): %s" % (n, err.value.decode(errors="replace")))
+    return out.raw[:n]
+
+
+def s2_stream(src: bytes, flush_at=(), level=0, snappy=False, block_size=0, add_index=False, padding=0, flush_on_write=False) -> bytes:
+    """w := new(bytes.Buffer); e := s2.NewWriter(w, WriterConcurrency(1), <options>); e.Write(src[..cut]) + e.Flush() at every position of
+    flush_at; e.Close(); w.Bytes() — the reference's own stream writer in its synchronous form (s2/writer.go Write / writeSync / Flush /
+    closeIndex, s2/index.go add / appendTo, skippableFrame), translated.  level: 0 default, 1 WriterBetterCompression, 2
+    WriterBestCompression, 3 WriterUncompressed; snappy: WriterSnappyCompat; padding: WriterPadding(n) with zero bytes as the padding
+    source; the chunk bodies are the portable Go block encoders' (s2_encode)."""
+    import numpy as np
+    src = bytes(src)
+    cuts = np.ascontiguousarray(sorted(int(x) for x in flush_at), dtype=np.int64)
+    nblk = len(src) // (block_size or (1 << 20)) + len(cuts) + 2
+    cap = len(src) + len(src) // 6 + 32 * nblk + 2 * max(int(padding), 0) + 20 * nblk + 4096
+    out = C.create_string_buffer(cap)
+    err = C.create_string_buffer(256)
+    n = lib().goref_s2_stream(src, len(src), out, cap, int(level), int(bool(snappy)), int(block_size), int(bool(add_index)), int(padding),
+                              int(bool(flush_on_write)), cuts.ctypes.data if len(cuts) else None, len(cuts), err, 256)
     if n < 0:
         raise RuntimeError("translated reference failed (%d): %s" % (n, err.value.decode(errors="replace")))
     return out.raw[:n]
