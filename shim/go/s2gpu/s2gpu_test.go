@@ -190,6 +190,32 @@ func TestWriteGolden(t *testing.T) {
 		lines[fmt.Sprintf("s2snappy.%c.128x65536", kind)] = hex.EncodeToString(hs.Sum(nil))
 		lines[fmt.Sprintf("s2snappybetter.%c.128x65536", kind)] = hex.EncodeToString(hsb.Sum(nil))
 	}
+	// framed streams: s2.NewWriter(w, WriterBlockSize(64K), <level>, WriterAddIndex(), WriterPadding(4096) with a zero padding source),
+	// Write + Flush after 100000 and 100001 bytes, Close — the lines tests/golden/make_reference_go_golden.py writes from the translated
+	// Writer (build with -tags noasm: the chunk bodies there are the portable Go encoders')
+	for _, st := range []struct {
+		name string
+		opts []s2.WriterOption
+	}{{"s2", nil}, {"s2better", []s2.WriterOption{s2.WriterBetterCompression()}}, {"s2best", []s2.WriterOption{s2.WriterBestCompression()}},
+		{"s2snappy", []s2.WriterOption{s2.WriterSnappyCompat()}}} {
+		for _, kind := range []byte{'J', 'T'} {
+			data, err := kcgpu.CorpusFill(kind, kcgpu.Seed(kind), 0, 16, 64<<10)
+			if err != nil {
+				t.Fatal(err)
+			}
+			var sink bytes.Buffer
+			opts := append([]s2.WriterOption{s2.WriterBlockSize(64 << 10), s2.WriterAddIndex(), s2.WriterPadding(4096), s2.WriterPaddingSrc(zeroReader{})}, st.opts...)
+			w := s2.NewWriter(&sink, opts...)
+			w.Write(data[:100000])
+			w.Flush()
+			w.Write(data[100000:100001])
+			w.Flush()
+			w.Write(data[100001:])
+			w.Close()
+			sum := sha256.Sum256(sink.Bytes())
+			lines[fmt.Sprintf("s2stream.%s.%c.16x65536.flush.index.pad4096", st.name, kind)] = hex.EncodeToString(sum[:])
+		}
+	}
 	names := make([]string, 0, len(lines))
 	for n := range lines {
 		names = append(names, n)
@@ -202,4 +228,13 @@ func TestWriteGolden(t *testing.T) {
 	if err := os.WriteFile(path, b.Bytes(), 0o644); err != nil {
 		t.Fatal(err)
 	}
+}
+
+type zeroReader struct{}
+
+func (zeroReader) Read(p []byte) (int, error) {
+	for i := range p {
+		p[i] = 0
+	}
+	return len(p), nil
 }

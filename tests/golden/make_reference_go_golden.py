@@ -8,6 +8,8 @@ reference_sha256.txt with a real Go toolchain; the two files must agree where bo
     zstd.L<level>.<kind>.<n>x<unit>[.rawdict64k]       zstd.Encoder.EncodeAll per unit (encoder.go:722), level 1..4
     zstdstream.L<level>.<kind>.10x300001.flush         Write / Flush / Close streams (WithEncoderConcurrency(1)), level 1..4
     s2|s2better|s2snappy|s2snappybetter|s2best|s2snappybest.<kind>.<n>x<unit>   s2.Encode* per block, portable Go (`noasm`) form
+    s2stream.<s2|s2better|s2best|s2snappy>.<kind>.16x65536.flush.index.pad4096   s2.NewWriter(w, WriterBlockSize(64K), level, WriterAddIndex(),
+                                                       WriterPadding(4096) with a zero padding source): Write + Flush after 100000 and 100001 bytes, Close
 Run in the build container:  python tests/golden/make_reference_go_golden.py      (about two minutes)"""
 import hashlib
 import os
@@ -58,6 +60,11 @@ def main():
             for i in range(n):
                 h.update(oracle_goref.s2_encode(buf[i * 65536:(i + 1) * 65536], lv))
             lines["%s.%s.%dx65536" % (name, kind, n)] = h.hexdigest()
+    for name, (lv, snappy) in (("s2", (0, False)), ("s2better", (1, False)), ("s2best", (2, False)), ("s2snappy", (0, True))):
+        for kind in "JT":
+            data = corpora.corpus(kind, 16, 65536).tobytes()
+            out = oracle_goref.s2_stream(data, (100000, 100001), level=lv, snappy=snappy, block_size=65536, add_index=True, padding=4096)
+            lines["s2stream.%s.%s.16x65536.flush.index.pad4096" % (name, kind)] = hashlib.sha256(out).hexdigest()
     with open(os.path.join(HERE, "reference_go_sha256.txt"), "w") as f:
         for k in sorted(lines):
             f.write("%s %s\n" % (k, lines[k]))

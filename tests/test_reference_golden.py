@@ -41,6 +41,9 @@ def _lines():
 
 def _parse(name):
     p = name.split(".")
+    if p[0] == "s2stream":  # s2stream.<level name>.<kind>.<n>x<unit>.flush.index.pad4096: the framed stream of s2.Writer
+        n, usz = p[3].split("x")
+        return dict(codec="s2stream", level={"s2": 0, "s2better": 1, "s2best": 2, "s2snappy": 0}[p[1]], snappy=p[1] == "s2snappy", kind=p[2], n=int(n), unit=int(usz))
     if p[0] == "zstdstream":  # zstdstream.L<level>.<kind>.<n>x<len>.flush: streams with Flush after 70000, 70010 and 200000+i bytes
         n, usz = p[3].split("x")
         return dict(codec="zstdstream", level=int(p[1][1:]), kind=p[2], n=int(n), unit=int(usz))
@@ -64,6 +67,12 @@ def test_oracle_matches_reference_hashes(oracle):
     lines = _lines()
     for name, want in sorted(lines.items()):
         c = _parse(name)
+        if c["codec"] == "s2stream":
+            import test_ref_s2_stream as ts
+            data = corpora.corpus(c["kind"], c["n"], c["unit"]).tobytes()
+            out = ts.expected_stream(oracle, data, (100000, 100001), bs=c["unit"], level=c["level"], snappy=c["snappy"], add_index=True, padding=4096)
+            assert hashlib.sha256(out).hexdigest() == want, "oracle differs from the reference on " + name
+            continue
         if c["codec"] == "zstdstream":
             data = corpora.corpus(c["kind"], 24, 131072).tobytes()
             e = oracle.ZstdOracle(level=c["level"])
@@ -94,6 +103,17 @@ def test_gpu_matches_reference_hashes(kclib):
     lines = _lines()
     for name, want in sorted(lines.items()):
         c = _parse(name)
+        if c["codec"] == "s2stream":
+            import io
+            import test_ref_s2_stream as ts
+            data = corpora.corpus(c["kind"], c["n"], c["unit"]).tobytes()
+            opts = [s2.WriterBlockSize(c["unit"]), s2.WriterAddIndex(), s2.WriterPadding(4096), s2.WriterPaddingSrc(ts._Zeros())]
+            opts += {0: [], 1: [s2.WriterBetterCompression()], 2: [s2.WriterBestCompression()]}[c["level"]] + ([s2.WriterSnappyCompat()] if c["snappy"] else [])
+            sink = io.BytesIO()
+            w = s2.NewWriter(sink, *opts)
+            w.Write(data[:100000]); w.Flush(); w.Write(data[100000:100001]); w.Flush(); w.Write(data[100001:]); w.Close()
+            assert hashlib.sha256(sink.getvalue()).hexdigest() == want, "HIP path differs from the reference on " + name
+            continue
         if c["codec"] == "zstdstream":
             data = corpora.corpus(c["kind"], 24, 131072)[:c["n"] * c["unit"]]
             off = np.arange(c["n"] + 1, dtype=np.uint64) * c["unit"]
