@@ -187,6 +187,63 @@ void* s2_stream_thread(void* a) {
 }  // namespace
 
 namespace {
+// io.ReadAll(s2.NewReader(bytes.NewReader(src), ReaderMaxBlockSize(n))): the reference's own stream reader (sequential Read: chunk
+// types, CRC check, stream identifiers of both kinds, skippable / padding / index chunks, block decode) as the judge of a stream.
+// NewReader's body (s2/reader.go:31-51) is restated here around the translated option functions.
+struct S2ReadCall { const uint8_t* src; int64_t n; uint8_t* dst; int64_t cap; int max_block; int ignore_crc; int64_t result; char err[256]; };
+void* s2_read_thread(void* a) {
+    using namespace go;
+    S2ReadCall* c = (S2ReadCall*)a;
+    rt::Scope scope;
+    try {
+        { rt::Permanent perm; s2::go_init(); }
+        struct Source : io::ReaderImpl {
+            Slice<byte> buf;
+            long long pos = 0;
+            std::tuple<Int, error> Read(Slice<byte> p) override {  // bytes.Reader.Read
+                if (pos >= buf.n) return std::tuple<Int, error>(Int(K(0LL)), io::EOF_);
+                const long long k = p.n < buf.n - pos ? p.n : buf.n - pos;
+                if (k > 0) memcpy((void*)p.p, (const void*)(buf.p + pos), (size_t)k);
+                pos += k;
+                return std::tuple<Int, error>(Int::raw(k), error());
+            }
+        } source;
+        source.buf = make_slice<byte>(c->n);
+        if (c->n) memcpy((void*)source.buf.p, c->src, (size_t)c->n);
+        s2::Reader nr;
+        nr.r = io::Reader(&source);
+        nr.maxBlock = Int(s2::maxBlockSize);
+        auto apply = [&](s2::ReaderOption opt) { error er = opt(&nr); if (er != nil) panic(er); };
+        if (c->max_block > 0) apply(s2::ReaderMaxBlockSize(Int(K((long long)c->max_block))));
+        if (c->ignore_crc) apply(s2::ReaderIgnoreCRC());
+        nr.maxBufSize = s2::MaxEncodedLen(nr.maxBlock) + Int(s2::checksumSize);
+        nr.buf = make_slice<byte>((s2::MaxEncodedLen(Int(s2::defaultBlockSize)) + Int(s2::checksumSize)).v);
+        nr.readHeader = nr.ignoreStreamID;
+        nr.paramsOK = true;
+        Slice<byte> chunk = make_slice<byte>(1 << 16);
+        long long total = 0;
+        for (;;) {  // io.ReadAll
+            auto r = nr.Read(chunk);
+            const long long k = std::get<0>(r).v;
+            if (k > 0) {
+                if (total + k > c->cap) { c->result = -2; return nullptr; }
+                memcpy(c->dst + total, chunk.p, (size_t)k);
+                total += k;
+            }
+            error er = std::get<1>(r);
+            if (er == io::EOF_) break;
+            if (er != nil) { snprintf(c->err, sizeof c->err, "%s", er.e->msg.c_str()); c->result = -5; return nullptr; }
+        }
+        c->result = total;
+    } catch (const go::Panic& p) {
+        snprintf(c->err, sizeof c->err, "panic: %s", p.msg.c_str());
+        c->result = -1;
+    }
+    return nullptr;
+}
+}  // namespace
+
+namespace {
 // the translated encoders hold their tables by value, like the Go structs do on Go's heap: a thread with a large stack
 long long run_on_big_stack(Call* c, char* err, int err_cap) {
     pthread_attr_t at;
@@ -304,6 +361,19 @@ long long goref_s2_stream(const uint8_t* src, long long n, uint8_t* dst, long lo
     pthread_attr_setstacksize(&at, (size_t)1 << 30);
     pthread_t th;
     if (pthread_create(&th, &at, s2_stream_thread, &c) != 0) return -3;
+    pthread_join(th, nullptr);
+    pthread_attr_destroy(&at);
+    if (err && err_cap > 0) { strncpy(err, c.err, (size_t)err_cap - 1); err[err_cap - 1] = 0; }
+    return c.result;
+}
+// io.ReadAll(s2.NewReader(src)): >= 0 the decoded length, -5 the reader's error (text in err); max_block 0 = the default limit (4 MiB)
+long long goref_s2_read_stream(const uint8_t* src, long long n, uint8_t* dst, long long cap, int max_block, int ignore_crc, char* err, int err_cap) {
+    S2ReadCall c{src, n, dst, cap, max_block, ignore_crc, 0, {0}};
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, (size_t)1 << 30);
+    pthread_t th;
+    if (pthread_create(&th, &at, s2_read_thread, &c) != 0) return -3;
     pthread_join(th, nullptr);
     pthread_attr_destroy(&at);
     if (err && err_cap > 0) { strncpy(err, c.err, (size_t)err_cap - 1); err[err_cap - 1] = 0; }

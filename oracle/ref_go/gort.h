@@ -410,6 +410,9 @@ template <class... A> void Println(const A&...) {}
 template <class... A> void Printf(const A&...) {}
 template <class... A> void Print(const A&...) {}
 }  // namespace fmt
+namespace strconv {
+static constexpr go::K IntSize = go::K(64LL);  // strconv.IntSize on a 64-bit platform
+}
 namespace bits {
 using namespace go;
 inline Int Len8(uint8 x) { return Int::raw(x.v ? 32 - __builtin_clz((unsigned)x.v) : 0); }
@@ -544,8 +547,19 @@ struct WaitGroup { WaitGroup* operator->() { return this; } void Add(go::K) {} v
 struct Pool { Pool* operator->() { return this; } template <class T> void Put(const T&) {} };
 }  // namespace sync
 namespace io {
-struct Reader { Reader* operator->() { return this; } };
-// io.Writer: the driver's sink implements WriterImpl (what `w` of zstd.NewWriter(w, ...) is to the reference)
+// io.Reader / io.Writer: the driver's source / sink implement ReaderImpl / WriterImpl (what `r` of s2.NewReader(r) and `w` of
+// zstd.NewWriter(w, ...) are to the reference).  A nil Reader reads as an endless source of zeroes (rand_::Reader: the padding source)
+struct ReaderImpl { virtual std::tuple<go::Int, go::error> Read(go::Slice<go::byte> p) = 0; virtual ~ReaderImpl() {} };
+struct Reader {
+    ReaderImpl* p = nullptr;
+    Reader() {}
+    Reader(ReaderImpl* q) : p(q) {}
+    Reader(go::Nil) {}
+    Reader* operator->() { return this; }
+    std::tuple<go::Int, go::error> Read(go::Slice<go::byte> b) const { if (!p) return {go::len(b), go::error()}; return p->Read(b); }
+    friend bool operator==(const Reader& a, go::Nil) { return a.p == nullptr; }
+    friend bool operator!=(const Reader& a, go::Nil) { return a.p != nullptr; }
+};
 struct WriterImpl { virtual std::tuple<go::Int, go::error> Write(go::Slice<go::byte> p) = 0; virtual ~WriterImpl() {} };
 struct Writer {
     WriterImpl* p = nullptr;
@@ -560,7 +574,19 @@ static const go::error ErrUnexpectedEOF = go::error(new go::ErrorObj{"unexpected
 static const go::error EOF_ = go::error(new go::ErrorObj{"EOF"});
 static const go::error ErrShortBuffer = go::error(new go::ErrorObj{"short buffer"});
 static const go::error ErrShortWrite = go::error(new go::ErrorObj{"short write"});
-inline std::tuple<go::Int, go::error> ReadFull(const Reader&, const go::Slice<go::byte>& b) { return {go::len(b), go::error()}; }
+// io.ReadFull (io.ReadAtLeast with min = len(buf)): EOF only if no byte was read, ErrUnexpectedEOF after a partial read
+inline std::tuple<go::Int, go::error> ReadFull(const Reader& r, const go::Slice<go::byte>& b) {
+    long long n = 0;
+    go::error err;
+    while (n < b.n && err == go::nil) {
+        auto t = r.Read(b.sl(n, b.n));
+        n += std::get<0>(t).v;
+        err = std::get<1>(t);
+    }
+    if (n >= b.n) err = go::error();
+    else if (n > 0 && err == EOF_) err = ErrUnexpectedEOF;
+    return {go::Int::raw(n), err};
+}
 }  // namespace io
 namespace crc32 {  // hash/crc32 of the Go standard library: table-driven, reflected (s2 uses the Castagnoli polynomial)
 struct Table { uint32_t t[256]; };

@@ -7,7 +7,7 @@ CFG = {
         ("huff0", ["huff0/huff0.go", "huff0/bitwriter.go", "huff0/bitreader.go", "huff0/compress.go", "huff0/decompress.go", "huff0/decompress_generic.go"]),
         ("xxhash", ["zstd/internal/xxhash/xxhash.go", "zstd/internal/xxhash/xxhash_other.go"]),
         ("compress", ["compressible.go"]),
-        ("s2", ["s2/s2.go", "s2/decode.go", "s2/hashtable_pool.go", "s2/dict.go", "s2/encode.go", "s2/encode_go.go", "s2/encode_all.go", "s2/encode_better.go", "s2/encode_best.go", "s2/index.go", "s2/writer.go"]),
+        ("s2", ["s2/s2.go", "s2/decode.go", "s2/hashtable_pool.go", "s2/dict.go", "s2/encode.go", "s2/encode_go.go", "s2/encode_all.go", "s2/encode_better.go", "s2/encode_best.go", "s2/index.go", "s2/writer.go", "s2/decode_other.go", "s2/reader.go"]),
         ("zstd", ["zstd/zstd.go", "zstd/hash.go", "zstd/matchlen_generic.go", "zstd/bitwriter.go", "zstd/seqenc.go", "zstd/fse_encoder.go",
                   "zstd/fse_predefined.go", "zstd/frameenc.go", "zstd/blockenc.go", "zstd/bytereader.go", "zstd/enc_base.go", "zstd/enc_fast.go", "zstd/enc_dfast.go",
                   "zstd/enc_better.go", "zstd/enc_best.go", "zstd/seqdec.go", "zstd/seqdec_generic.go", "zstd/dict.go", "zstd/bitreader.go", "zstd/bytebuf.go", "zstd/history.go",
@@ -31,7 +31,10 @@ CFG = {
     },
     # path -> the ONLY declarations taken from that file (the rest of it is the decoder / the streaming writer)
     "only": {
-        "s2/decode.go": {"ErrCorrupt", "ErrCRC", "ErrTooLarge", "ErrUnsupported"},   # the package's error values
+        "s2/decode.go": {"ErrCorrupt", "ErrCRC", "ErrTooLarge", "ErrUnsupported", "DecodedLen", "decodedLen", "decodeErrCodeCorrupt", "Decode"},   # error values; Decode (blocks)
+        # the stream reader as the judge of a framed stream's validity: sequential Read (not DecodeConcurrent's goroutines, not the seeker)
+        "s2/reader.go": {"Reader", "ReaderOption", "ReaderMaxBlockSize", "ReaderIgnoreCRC", "Reader.ensureBufferSize", "Reader.Reset", "Reader.readFull",
+                         "Reader.skippable", "Reader.Read"},
         # the stream writer in its synchronous form (WriterConcurrency(1): Write / Flush / Close run writeSync in the caller — the
         # framing, the index and the padding do not depend on the concurrency) and the index it appends
         "s2/writer.go": {"Writer", "Writer.err", "Writer.Reset", "Writer.Write", "Writer.EncodeBuffer", "Writer.encodeBlock", "Writer.write", "Writer.writeSync",
@@ -53,7 +56,8 @@ CFG = {
         # initPredefined builds the predefined DECODER tables first and copies their normalised counts into the encoders
     },
     "drop_fields": {
-        "s2.Writer": {"output", "buffers", "writerWg", "bufferCB", "customEnc"},   # the concurrent form's channel, buffer pool and wait group; callbacks
+        "s2.Writer": {"output", "buffers", "writerWg", "bufferCB", "customEnc"},
+        "s2.Reader": {"skippableCB"},                      # per-id callbacks for skippable chunks (an array of funcs taking an io.Reader)   # the concurrent form's channel, buffer pool and wait group; callbacks
         "zstd.Decoder": {"decoders", "current", "syncStream", "frame", "streamWg"},
         "zstd.Encoder": {"encoders", "init"},              # the pool of encoders EncodeAll draws from (the driver hands it one)
         "zstd.encJob": {"done"},                           # job mode's worker plumbing: see the patches of zstd/enc_jobs.go
@@ -118,6 +122,10 @@ CFG = {
              "Flush: nothing queued anywhere in the synchronous form"),
             (r"\tif w\.output != nil \{\n\t\tclose\(w\.output\)\n\t\tw\.writerWg\.Wait\(\)\n\t\tw\.output = nil\n\t\}\n", "", "closeIndex: no writer goroutine"),
             (r"tmp = w\.buffers\.Get\(\)\.\(\[\]byte\)\[:0\]\n\t\t\t\tdefer w\.buffers\.Put\(tmp\)\n", "tmp = make([]byte, 0, w.obufLen)\n", "sync.Pool is an allocation cache"),
+        ],
+        "s2/reader.go": [
+            (r"\tif fn := r\.skippableCB\[id-0x80\]; fn != nil \{.*?\n(\tfor n > 0 \{\n)", r"\1",
+             "skippable: no callbacks registered, and the source is a plain io.Reader (not an io.ReadSeeker): what is left is the read-and-discard loop"),
         ],
         "s2/index.go": [
             (r"struct \{\n\t+compressedOffset   int64\n\t+uncompressedOffset int64\n\t+\}", "indexInfo",

@@ -68,6 +68,8 @@ def lib():
         L.goref_zstd_decode_all_dict.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_longlong, C.c_uint, C.c_char_p, C.c_int]
         L.goref_s2_stream.restype = C.c_longlong
         L.goref_s2_stream.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 6 + [C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+        L.goref_s2_read_stream.restype = C.c_longlong
+        L.goref_s2_read_stream.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_char_p, C.c_int]
         L.goref_s2_encode.restype = C.c_longlong
         L.goref_s2_encode.argtypes = [C.c_int, C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         _libs[key] = L
@@ -185,4 +187,17 @@ def s2_stream(src: bytes, flush_at=(), level=0, snappy=False, block_size=0, add_
                               int(bool(flush_on_write)), cuts.ctypes.data if len(cuts) else None, len(cuts), err, 256)
     if n < 0:
         raise RuntimeError("translated reference failed (%d): %s" % (n, err.value.decode(errors="replace")))
+    return out.raw[:n]
+
+
+def s2_read_stream(stream: bytes, max_out: int, max_block=0, ignore_crc=False) -> bytes:
+    """io.ReadAll(s2.NewReader(bytes.NewReader(stream))) of the reference — its own stream reader (sequential Read of s2/reader.go:
+    chunk types, masked-CRC check, S2 and Snappy stream identifiers, skippable / padding / index chunks) over its own block decoder in
+    the portable Go form (decode_other.go), translated: the judge of a framed stream's validity.  Raises on the reader's error."""
+    stream = bytes(stream)
+    out = C.create_string_buffer(max_out + 64)
+    err = C.create_string_buffer(256)
+    n = lib().goref_s2_read_stream(stream, len(stream), out, max_out + 64, int(max_block), int(bool(ignore_crc)), err, 256)
+    if n < 0:
+        raise ValueError("reference s2.Reader: %s (%d)" % (err.value.decode(errors="replace"), n))
     return out.raw[:n]

@@ -150,6 +150,43 @@ def test_translated_writer_streams_decode(oracle):
             assert sizes == [1234, 65536, 65536, 65536, 65536, 300000 - 1234 - 4 * 65536, 65536, 100000 - 65536]
 
 
+def test_reference_reader_reads_oracle_and_translated_streams_and_refuses_damage(oracle):
+    """The reference's own s2.Reader (sequential Read, translated; its block decoder in the portable Go form) returns the input of every
+    stream the translated Writer and the oracle write — S2 and Snappy identifiers, index, padding, stored chunks — and gives the in-repo
+    stream decoder's verdict on 300 damaged streams (CRC, chunk types, lengths, block bodies)."""
+    j, t, h = _inputs()
+    data = (j + h + t)[:400000]
+    for kw in (dict(), dict(level=1), dict(level=2), dict(snappy=True, block_size=65536), dict(add_index=True, padding=4096), dict(level=3, block_size=65536),
+               dict(block_size=4096, add_index=True)):
+        s = oracle_goref.s2_stream(data, (1234, 300000), **kw)
+        assert oracle_goref.s2_read_stream(s, len(data)) == data, kw
+    for olevel in (0, 1, 4):
+        blk = _blocks(len(data), (), 65536)
+        s, _ = oracle.s2_encode_stream(np.frombuffer(data, dtype=np.uint8), blk, level=olevel)
+        assert oracle_goref.s2_read_stream(s.tobytes(), len(data)) == data, olevel
+    assert oracle_goref.s2_read_stream(b"", 16) == b""
+    good = oracle_goref.s2_stream(j[:150000], block_size=16384, add_index=True)
+    rng = np.random.default_rng(5)
+    agree = rejected = 0
+    for _ in range(300):
+        g = bytearray(good)
+        for _k in range(int(rng.integers(1, 3))):
+            g[int(rng.integers(0, len(g)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            a = oracle_goref.s2_read_stream(bytes(g), 200000)
+        except ValueError:
+            a = None
+        try:
+            b = oracle.s2_decode_stream(bytes(g), 200000)
+        except RuntimeError:
+            b = None
+        # (a flip inside the index / a skippable chunk's payload leaves a valid stream: both read the input)
+        assert (a is None) == (b is None) and (a is None or a == b), (a is None, b is None)
+        agree += 1
+        rejected += a is None
+    assert rejected > 200 and agree == 300
+
+
 class _Zeros:
     def read(self, n):
         return b"\0" * n
@@ -198,6 +235,7 @@ def test_device_writer_equals_the_translated_writer(kclib, level):
         want = oracle_goref.s2_stream(data, cuts, level=level, **kw)
         got = sink.getvalue()
         assert got == want, "level %d %r len %d cuts %r: %d bytes vs the reference's %d" % (level, kw, len(data), cuts, len(got), len(want))
+        assert oracle_goref.s2_read_stream(got, len(data)) == data  # ... and the reference's own Reader returns the input
     sink = io.BytesIO()
     w = s2.NewWriter(sink, s2.WriterUncompressed(), s2.WriterBlockSize(65536))
     w.Write(j[:200000])
