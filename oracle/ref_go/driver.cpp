@@ -6,6 +6,7 @@
 #include <pthread.h>
 
 namespace {
+thread_local long long g_readfrom_at = -1;
 struct Call {
     const uint8_t* src; int64_t n; uint8_t* dst; int64_t cap;
     int level, window, crc, single, full_zero, no_entropy, all_lit, lowmem;
@@ -16,6 +17,7 @@ struct Call {
     int64_t n_cuts = -1;            // -1: EncodeAll
     int dict_full = 0;              // the dictionary bytes are a full-format dictionary: WithEncoderDict (loadDict) instead of WithEncoderDictRaw
     int jobs = 0;                   // WithConcurrentBlocks(true)
+    int64_t readfrom_at = -1;       // stream mode: >= 0 = the input from this offset on goes through ReadFrom(bytes.NewReader(src[at:])) instead of Write
 };
 
 void init_packages() {
@@ -78,7 +80,25 @@ void run(Call* c) {
                 if (cut > pos) { auto r = e.Write(src.sl(pos, cut)); check(std::get<1>(r)); pos = cut; }
                 check(e.Flush());
             }
-            if (c->n > pos) { auto r = e.Write(src.sl(pos, c->n)); check(std::get<1>(r)); }
+            const long long wend = (c->readfrom_at >= 0 && c->readfrom_at <= c->n) ? (c->readfrom_at > pos ? c->readfrom_at : pos) : c->n;
+            if (wend > pos) { auto r = e.Write(src.sl(pos, wend)); check(std::get<1>(r)); pos = wend; }
+            if (c->readfrom_at >= 0) {
+                struct Source : io::ReaderImpl {  // bytes.Reader
+                    Slice<byte> buf;
+                    long long at = 0;
+                    std::tuple<Int, error> Read(Slice<byte> p) override {
+                        if (at >= buf.n) return std::tuple<Int, error>(Int(K(0LL)), io::EOF_);
+                        const long long k = p.n < buf.n - at ? p.n : buf.n - at;
+                        if (k > 0) memcpy((void*)p.p, (const void*)(buf.p + at), (size_t)k);
+                        at += k;
+                        return std::tuple<Int, error>(Int::raw(k), error());
+                    }
+                } source;
+                source.buf = src.sl(pos, c->n);
+                auto r = e.ReadFrom(io::Reader(&source));
+                check(std::get<1>(r));
+                if (std::get<0>(r).v != c->n - pos) panic_str("ReadFrom returned another byte count than the source holds");
+            }
             check(e.Close());
             out = sink.buf;
         }
@@ -398,6 +418,10 @@ long long goref_zstd_encode_stream(const uint8_t* src, long long n, uint8_t* dst
     if (dict_id == 0xFFFFFFFFu) { c.dict_full = 1; c.dict_id = 0; }
     c.cuts = (const int64_t*)cuts;
     c.n_cuts = n_cuts < 0 ? 0 : n_cuts;
+    c.readfrom_at = g_readfrom_at;
+    g_readfrom_at = -1;
     return run_on_big_stack(&c, err, err_cap);
 }
+// the NEXT goref_zstd_encode_stream call feeds its input from this offset on through Encoder.ReadFrom (one-shot; -1: Write only)
+void goref_zstd_next_stream_readfrom(long long at) { g_readfrom_at = at; }
 }

@@ -47,11 +47,11 @@ CFG = {
         "zstd/decoder.go": {"Decoder", "Decoder.DecodeAll", "Decoder.setDict"},   # the stateless DecodeAll; not the streaming reader (goroutines, channels)
         "zstd/decoder_options.go": {"DOption", "decoderOptions", "decoderOptions.setDefault", "WithDecoderDicts", "WithDecoderDictRaw"},
         "zstd/dict.go": {"dict", "dict.*", "dictMagic", "dictMaxLength", "loadDict"},   # (not InspectDictionary / BuildDict)
-        # EncodeAll and the streaming writer in both modes (blocks; WithConcurrentBlocks jobs) — not ReadFrom (io.Reader plumbing), not the
+        # EncodeAll and the streaming writer in both modes (blocks; WithConcurrentBlocks jobs), ReadFrom included — not the
         # goroutine pool behind the public EncodeAll (the driver hands encodeAll an encoder)
         "zstd/encoder.go": {"Encoder", "encoder", "encoderState", "Encoder.encodeAll", "Encoder.MaxEncodedSize", "Encoder.Reset", "Encoder.Write",
                             "Encoder.writeBlocks", "Encoder.writeJobs", "Encoder.nextBlock", "Encoder.Flush", "Encoder.flushJobs", "Encoder.Close",
-                            "Encoder.closeJobs"},
+                            "Encoder.closeJobs", "Encoder.ReadFrom", "Encoder.readFromJobs"},
         # constants and the block / literals type enumerations the encoder shares with the decoder
         # initPredefined builds the predefined DECODER tables first and copies their normalised counts into the encoders
     },

@@ -62,6 +62,8 @@ def lib():
         L.goref_zstd_encode_stream.restype = C.c_longlong
         L.goref_zstd_encode_stream.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 7 + [C.c_char_p, C.c_longlong, C.c_uint,
                                                C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+        L.goref_zstd_next_stream_readfrom.restype = None
+        L.goref_zstd_next_stream_readfrom.argtypes = [C.c_longlong]
         L.goref_zstd_decode_all.restype = C.c_longlong
         L.goref_zstd_decode_all.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         L.goref_zstd_decode_all_dict.restype = C.c_longlong
@@ -104,13 +106,14 @@ def zstd_encode_all(src: bytes, level=1, window_size=None, crc=None, single=None
 
 
 def zstd_encode_stream(src: bytes, flush_at=(), level=1, window_size=None, crc=None, no_entropy=None, all_lit_entropy=None, low_mem=False,
-                       concurrent=0, dict_id=0, dict_content=None, dict_blob=None, jobs=False) -> bytes:
+                       concurrent=0, dict_id=0, dict_content=None, dict_blob=None, jobs=False, readfrom_at=None) -> bytes:
     """w := new(bytes.Buffer); e := zstd.NewWriter(w, WithEncoderLevel(level), <the options given>); e.Write(src[..cut]) and e.Flush()
     at every position of flush_at; e.Close(); w.Bytes() — the reference's streaming writer (encoder.go Write / nextBlock / Flush /
     Close).  concurrent=1: WithEncoderConcurrency(1), the synchronous nextBlock; 0: the reference's default, the asynchronous one
     (its two goroutines per block run to completion where they are started: the schedule their WaitGroups allow).
     jobs=True: WithConcurrentBlocks(true) (enc_jobs.go; needs concurrent > 1 like the reference): every job compressed and written where
-    it is dispatched."""
+    it is dispatched.  readfrom_at=a: the input from offset a on (behind the Flush points before it) is handed over with
+    e.ReadFrom(bytes.NewReader(src[a:])) instead of Write."""
     import numpy as np
     if dict_blob is not None:
         dict_id, dict_content = FULL_DICT, dict_blob
@@ -120,6 +123,8 @@ def zstd_encode_stream(src: bytes, flush_at=(), level=1, window_size=None, crc=N
     out = C.create_string_buffer(cap)
     err = C.create_string_buffer(256)
     d = bytes(dict_content) if dict_content else None
+    if readfrom_at is not None:
+        lib().goref_zstd_next_stream_readfrom(int(readfrom_at))
     n = lib().goref_zstd_encode_stream(src, len(src), out, cap, int(level), int(window_size or 0), _flag(crc), _flag(no_entropy), _flag(all_lit_entropy),
                                        int(bool(low_mem)), int(concurrent) | (int(bool(jobs)) << 16), d, len(d) if d else 0, int(dict_id),
                                        cuts.ctypes.data if len(cuts) else None, len(cuts), err, 256)

@@ -118,6 +118,30 @@ def test_oracle_equals_the_translated_reference_streams(oracle, level, concurren
 
 
 @pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_oracle_equals_the_translated_reference_read_from(oracle, level):
+    """Encoder.ReadFrom (encoder.go:444-496) and readFromJobs (:498-542): what is buffered from earlier Writes goes out as a block /
+    a job first, then the source is read block-size (job-size) pieces at a time — for the bytes, a Flush point where ReadFrom takes
+    over, which is how the oracle, the device entry points (`cuts`) and the façades model it."""
+    t = corpora.corpus("T", 6, 131072, first_unit=11).tobytes()
+    bad = []
+    for data, cuts, a in ((t[:300000], (), 0), (t[:300000], (), 70000), (t[:300000], (1000,), 131072), (t[:5000], (), 100), (t[:700000], (5000,), 9000),
+                          (b"", (), 0), (t[:262144], (), 262144), (t[:300000], (70000,), 70000), (t[:5000], (), 5000)):
+        eff = tuple(sorted(set(cuts) | ({a} if 0 < a <= len(data) else set())))  # (a == len: ReadFrom of an empty source still flushes what is buffered)
+        if oracle_goref.zstd_encode_stream(data, cuts, level=level, readfrom_at=a) != oracle.ZstdOracle(level=level).encode_stream(data, eff):
+            bad.append(("blocks", len(data), cuts, a))
+        if oracle_goref.zstd_encode_stream(data, cuts, level=level, concurrent=1, readfrom_at=a) != oracle.ZstdOracle(level=level, concurrent=1).encode_stream(data, eff):
+            bad.append(("blocks, synchronous", len(data), cuts, a))
+    win = 1 << 17
+    e = oracle.ZstdOracle(level=level, window_size=win)
+    big = t[:700000] if level == 4 else t
+    for cuts, a in (((), 0), ((), 100000), ((600000,), 600001), ((1000,), 524288 + 1000), ((), len(big))):
+        eff = tuple(sorted(set(cuts) | ({a} if 0 < a <= len(big) else set())))
+        if oracle_goref.zstd_encode_stream(big, cuts, level=level, window_size=win, concurrent=4, jobs=True, readfrom_at=a) != e.encode_jobs(big, eff):
+            bad.append(("jobs", len(big), cuts, a))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
 def test_oracle_equals_the_translated_reference_with_full_format_dictionaries(oracle, level):
     """WithEncoderDict: the reference's loadDict (zstd/dict.go:70-150 — huff0.ReadTable with its FSE-compressed weights, three
     readNCount tables, the offsets, the content) and what the encoders do with a loaded dictionary (offsets, content as history, the
