@@ -1,7 +1,8 @@
 """CPU campaign: the oracle (hand restatement) against the reference's own Go code (oracle/_ref/libzstdref.so, translated) on random
 units with random options — EncodeAll at four levels (window, checksum, single segment, zero frames, entropy options, low memory, raw
 dictionary), Write / Flush / Close streams in both forms of nextBlock, WithConcurrentBlocks job streams, the six S2 block encoders,
-framed S2 streams (block size, index, padding, Flush points) — and every zstd frame decoded by the reference's decoder in its amd64
+framed S2 streams (block size, index, padding, Flush points; each read back by the reference's s2.Reader), Write + ReadFrom
+sequences — and every zstd frame decoded by the reference's decoder in its amd64
 build (the package's assembly).  python tools/fuzz_oracle_goref.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
@@ -71,9 +72,13 @@ while time.time() - t0 < budget and len(bad) < 20:
             kw["window_size"] = 1 << int(rng.integers(14, 22))
         if rng.random() < 0.3:
             kw["crc"] = False
-        f = oracle_goref.zstd_encode_stream(u, cuts, level=level, concurrent=conc, **kw)
-        if oracle.ZstdOracle(level=level, concurrent=conc, **kw).encode_stream(u, cuts) != f:
-            bad.append(("stream", level, len(u), cuts, conc, sorted(kw)))
+        a = int(rng.integers(0, len(u) + 1)) if rng.random() < 0.3 else None  # from here on through ReadFrom: a Flush point for the bytes
+        if a is not None and cuts:
+            a = max(a, max(cuts))  # (the driver flushes at every cut first: ReadFrom takes over behind the last one)
+        eff = cuts if a is None or a == 0 else tuple(sorted(set(cuts) | {a}))
+        f = oracle_goref.zstd_encode_stream(u, cuts, level=level, concurrent=conc, readfrom_at=a, **kw)
+        if oracle.ZstdOracle(level=level, concurrent=conc, **kw).encode_stream(u, eff) != f:
+            bad.append(("stream", level, len(u), cuts, a, conc, sorted(kw)))
         dkw = {}
         cnt["stream"] += 1
     elif mode < 0.75:
@@ -106,6 +111,11 @@ while time.time() - t0 < budget and len(bad) < 20:
         got = oracle_goref.s2_stream(u, cuts, level=lv, snappy=snappy, block_size=bs, **kw)
         if got != ts.expected_stream(oracle, u, cuts, bs=bs or (1 << 20), level=lv, snappy=snappy, **kw):
             bad.append(("s2stream", lv, snappy, bs, len(u), cuts, sorted(kw.items())))
+        try:  # ... and the reference's own s2.Reader returns the input
+            if oracle_goref.s2_read_stream(got, len(u)) != u:
+                bad.append(("s2.Reader: wrong bytes", lv, snappy, bs, len(u)))
+        except ValueError as e:
+            bad.append(("s2.Reader", str(e), lv, snappy, bs, len(u)))
         cnt["s2stream"] += 1
         continue
     if amd:  # the frame just written, read by the reference's amd64 decoders (assembly), BMI2 on and off in turn
