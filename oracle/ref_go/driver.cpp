@@ -18,6 +18,9 @@ struct Call {
     int dict_full = 0;              // the dictionary bytes are a full-format dictionary: WithEncoderDict (loadDict) instead of WithEncoderDictRaw
     int jobs = 0;                   // WithConcurrentBlocks(true)
     int64_t readfrom_at = -1;       // stream mode: >= 0 = the input from this offset on goes through ReadFrom(bytes.NewReader(src[at:])) instead of Write
+    const int64_t* unit_off = nullptr;  // EncodeAll mode: n_units + 1 offsets into src — every unit through encodeAll on the SAME encoder, one
+    int64_t n_units = 0;                // after the other, like the calls of one goroutine on one zstd.Encoder (its pool hands the encoder back)
+    int64_t* out_off = nullptr;
 };
 
 void init_packages() {
@@ -60,7 +63,20 @@ void run(Call* c) {
         Slice<byte> src = make_slice<byte>(c->n);
         if (c->n) memcpy((void*)src.p, c->src, (size_t)c->n);
         Slice<byte> out;
-        if (c->n_cuts < 0) {
+        if (c->n_cuts < 0 && c->unit_off != nullptr) {
+            auto enc = e.o.encoder();  // ONE encoder for all units: what it keeps from unit to unit must not show in the bytes
+            c->out_off[0] = 0;
+            long long total = 0;
+            for (long long i = 0; i < c->n_units; i++) {  // (frames go straight to the caller's buffer: nothing accumulates here)
+                Slice<byte> f = e.encodeAll(enc, src.sl(c->unit_off[i], c->unit_off[i + 1]), Slice<byte>());
+                if (total + f.n > c->cap) { snprintf(c->err, sizeof c->err, "output does not fit %lld", (long long)c->cap); c->result = -2; return; }
+                if (f.n) memcpy(c->dst + total, f.p, (size_t)f.n);
+                total += f.n;
+                c->out_off[i + 1] = total;
+            }
+            c->result = total;
+            return;
+        } else if (c->n_cuts < 0) {
             auto enc = e.o.encoder();
             out = e.encodeAll(enc, src, Slice<byte>());
         } else {
@@ -405,6 +421,16 @@ long long goref_zstd_encode_all(const uint8_t* src, long long n, uint8_t* dst, l
                                 unsigned dict_id, char* err, int err_cap) {
     Call c{src, n, dst, cap, level, window, crc, single, full_zero, no_entropy, all_lit, lowmem, dict, dict_len, dict_id, 0, {0}};
     if (dict_id == 0xFFFFFFFFu) { c.dict_full = 1; c.dict_id = 0; }  // (a full-format dictionary carries its own id: WithEncoderDict)
+    return run_on_big_stack(&c, err, err_cap);
+}
+// N x EncodeAll on ONE zstd.Encoder (one pooled encoder, re-used from call to call): the frames back to back, out_off[n_units + 1]
+long long goref_zstd_encode_all_reuse(const uint8_t* src, const long long* unit_off, long long n_units, uint8_t* dst, long long cap, long long* out_off,
+                                      int level, int window, const uint8_t* dict, long long dict_len, unsigned dict_id, char* err, int err_cap) {
+    Call c{src, unit_off[n_units], dst, cap, level, window, -1, -1, -1, -1, -1, 0, dict, dict_len, dict_id, 0, {0}};
+    if (dict_id == 0xFFFFFFFFu) { c.dict_full = 1; c.dict_id = 0; }
+    c.unit_off = (const int64_t*)unit_off;
+    c.n_units = n_units;
+    c.out_off = (int64_t*)out_off;
     return run_on_big_stack(&c, err, err_cap);
 }
 // zstd.NewWriter(w, <options>) as a STREAM: Write(src[..cut]) + Flush() at every cut, then Close(); returns what w received.

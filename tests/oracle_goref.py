@@ -62,6 +62,9 @@ def lib():
         L.goref_zstd_encode_stream.restype = C.c_longlong
         L.goref_zstd_encode_stream.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 7 + [C.c_char_p, C.c_longlong, C.c_uint,
                                                C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+        L.goref_zstd_encode_all_reuse.restype = C.c_longlong
+        L.goref_zstd_encode_all_reuse.argtypes = [C.c_char_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_int, C.c_char_p,
+                                                  C.c_longlong, C.c_uint, C.c_char_p, C.c_int]
         L.goref_zstd_next_stream_readfrom.restype = None
         L.goref_zstd_next_stream_readfrom.argtypes = [C.c_longlong]
         L.goref_zstd_decode_all.restype = C.c_longlong
@@ -131,6 +134,29 @@ def zstd_encode_stream(src: bytes, flush_at=(), level=1, window_size=None, crc=N
     if n < 0:
         raise RuntimeError("translated reference failed (%d): %s" % (n, err.value.decode(errors="replace")))
     return out.raw[:n]
+
+
+def zstd_encode_all_reuse(units, level=1, window_size=None, dict_id=0, dict_content=None, dict_blob=None):
+    """e := zstd.NewWriter(nil, ...); for every unit e.EncodeAll(unit, nil) — on ONE encoder object of the reference, re-used from call to
+    call without a reset in between (what a goroutine calling EncodeAll repeatedly gets from the Encoder's pool).  Returns the frames."""
+    import numpy as np
+    if dict_blob is not None:
+        dict_id, dict_content = FULL_DICT, dict_blob
+    off = np.zeros(len(units) + 1, dtype=np.int64)
+    for i, u in enumerate(units):
+        off[i + 1] = off[i] + len(u)
+    src = b"".join(bytes(u) for u in units)
+    cap = len(src) + (len(src) >> 6) + 1024 * (len(units) + 1)
+    out = C.create_string_buffer(cap)
+    oo = np.zeros(len(units) + 1, dtype=np.int64)
+    err = C.create_string_buffer(256)
+    d = bytes(dict_content) if dict_content else None
+    n = lib().goref_zstd_encode_all_reuse(src, off.ctypes.data, len(units), out, cap, oo.ctypes.data, int(level), int(window_size or 0), d, len(d) if d else 0,
+                                          int(dict_id), err, 256)
+    if n < 0:
+        raise RuntimeError("translated reference failed (%d): %s" % (n, err.value.decode(errors="replace")))
+    raw = out.raw[:n]  # (one copy: .raw copies the whole buffer every time it is read)
+    return [raw[int(oo[i]):int(oo[i + 1])] for i in range(len(units))]
 
 
 def zstd_encode_units(src, unit_off, **kw):

@@ -118,6 +118,25 @@ def test_oracle_equals_the_translated_reference_streams(oracle, level, concurren
 
 
 @pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_a_reused_reference_encoder_writes_what_a_fresh_one_writes(oracle, level):
+    """The premise of the device design — every EncodeAll unit is stateless — checked on the reference's OWN encoder objects: one
+    zstd.Encoder / one pooled encoder re-used for a run of EncodeAll calls (its tables and `cur` carry over from call to call,
+    encoder.go:722-729 + enc_*.go Reset) gives, frame for frame, the bytes of a fresh encoder per unit; also with a raw dictionary."""
+    t = corpora.corpus("T", 8, 131072, first_unit=11).tobytes()
+    m = corpora.corpus("M", 4, 131072, first_unit=2).tobytes()
+    j = corpora.corpus("J", 4, 65536, first_unit=7).tobytes()
+    base = [t[:131072], m[:200000], t[:100], b"", t[131072:262144], t[:131072], m[5:90000], t[:300001], j[:65536], j[:9], t[:131072]]
+    units = base * (6 if level < 4 else 1)
+    fresh = {}
+    for u in base:
+        fresh[u] = oracle.ZstdOracle(level=level).encode_all(u)  # (== the translated reference with a fresh encoder: the tests above)
+    assert oracle_goref.zstd_encode_all_reuse(units, level=level) == [fresh[u] for u in units]
+    dct = corpora.corpus("T", 1, 65536, seed=0x5EED0005).tobytes()
+    dref = oracle.ZstdOracle(level=level, dict_id=4, dict_content=dct)
+    assert oracle_goref.zstd_encode_all_reuse(base, level=level, dict_id=4, dict_content=dct) == [dref.encode_all(u) for u in base]
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
 def test_oracle_equals_the_translated_reference_read_from(oracle, level):
     """Encoder.ReadFrom (encoder.go:444-496) and readFromJobs (:498-542): what is buffered from earlier Writes goes out as a block /
     a job first, then the source is read block-size (job-size) pieces at a time — for the bytes, a Flush point where ReadFrom takes
