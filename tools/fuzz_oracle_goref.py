@@ -115,7 +115,10 @@ while time.time() - t0 < budget and len(bad) < 20:
             if oracle_goref.s2_read_stream(got, len(u)) != u:
                 bad.append(("s2.Reader: wrong bytes", lv, snappy, bs, len(u)))
         except ValueError as e:
-            bad.append(("s2.Reader", str(e), lv, snappy, bs, len(u)))
+            # (the reference's quirk: an EMPTY stream closed with WriterAddIndex is an index chunk — and its padding — without a stream
+            # identifier in front, which its own Reader refuses: "s2: corrupt input")
+            if not (len(u) == 0 and kw["add_index"] and "corrupt input" in str(e)):
+                bad.append(("s2.Reader", str(e), lv, snappy, bs, len(u)))
         cnt["s2stream"] += 1
         continue
     if amd:  # the frame just written, read by the reference's amd64 decoders (assembly), BMI2 on and off in turn
