@@ -241,3 +241,26 @@ def test_device_writer_equals_the_translated_writer(kclib, level):
     w.Write(j[:200000])
     w.Close()
     assert sink.getvalue() == oracle_goref.s2_stream(j[:200000], level=3, block_size=65536)
+
+
+def test_facade_host_logic_on_an_empty_stream_equals_the_translated_writer(monkeypatch):
+    """Host logic of compress_amd.s2.Writer that needs no device: an empty stream — nothing at all without options; with
+    WriterAddIndex the index chunk (and with WriterPadding its padding in front) WITHOUT a stream identifier, exactly as the
+    reference's Writer leaves it (its own Reader refuses that stream: a quirk kept as it is)."""
+    from compress_amd import s2
+
+    class _NoDevice:
+        def __init__(self, *a, **k):
+            pass
+
+        def Close(self):
+            pass
+    monkeypatch.setattr(s2, "BlockEncoder", _NoDevice)
+    for kw, opts in ((dict(), []), (dict(add_index=True), [s2.WriterAddIndex()]), (dict(padding=4096), [s2.WriterPadding(4096), s2.WriterPaddingSrc(_Zeros())]),
+                     (dict(add_index=True, padding=4096), [s2.WriterAddIndex(), s2.WriterPadding(4096), s2.WriterPaddingSrc(_Zeros())])):
+        sink = io.BytesIO()
+        w = s2.NewWriter(sink, *opts)
+        w.Close()
+        assert sink.getvalue() == oracle_goref.s2_stream(b"", **kw), kw
+    with pytest.raises(ValueError, match="corrupt input"):
+        oracle_goref.s2_read_stream(oracle_goref.s2_stream(b"", add_index=True), 16)
