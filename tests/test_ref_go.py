@@ -493,3 +493,40 @@ def test_device_equals_the_translated_reference_s2(kclib, level):
     enc.Close()
     bad = [(i, len(b)) for i, b in enumerate(blocks) if out[int(out_off[i]):int(out_off[i + 1])].tobytes() != oracle_goref.s2_encode(b, level)]
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_zstd_facade_host_logic_equals_the_references_writer(oracle, level):
+    """Host logic of compress_amd.zstd.Encoder that needs no device — how Write / Flush / ReadFrom / Close sequences become the stream and
+    its block (job) boundaries — against the reference's own Writer for the same call sequences.  The device entry points it hands
+    the stream to (EncodeStreams, EncodeJobs) are replaced by the oracle here; device == oracle on them is the GPU suite's business."""
+    import io
+    from compress_amd import zstd
+    t = corpora.corpus("T", 8, 131072, first_unit=31).tobytes()
+
+    def facade(data, ops, jobs=False):
+        opts = [zstd.WithEncoderLevel(level)] + ([zstd.WithWindowSize(1 << 17), zstd.WithConcurrentBlocks(True), zstd.WithEncoderConcurrency(4)] if jobs else [])
+        sink = io.BytesIO()
+        w = zstd.NewWriter(sink, *opts)
+        ref = oracle.ZstdOracle(level=level, window_size=1 << 17) if jobs else oracle.ZstdOracle(level=level)
+        w.EncodeStreams = lambda src, off, flush_at=None: (np.frombuffer(ref.encode_stream(bytes(src), tuple(flush_at[0]) if flush_at else ()), dtype=np.uint8), None)
+        w.EncodeJobs = lambda d, cuts: ref.encode_jobs(bytes(d), tuple(cuts))
+        pos = 0
+        for op, arg in ops:
+            if op == "write":
+                w.Write(data[pos:arg])
+                pos = arg
+            elif op == "flush":
+                w.Flush()
+            else:
+                w.ReadFrom(io.BytesIO(data[pos:]))
+                pos = len(data)
+        w.Close()
+        return sink.getvalue()
+    data = t[:700000]
+    cases = [([("write", len(data))], (), None), ([("write", 70000), ("flush", 0), ("write", len(data))], (70000,), None),
+             ([("write", 70000), ("readfrom", 0)], (), 70000), ([("write", 100), ("flush", 0), ("write", 5000), ("readfrom", 0)], (100,), 5000),
+             ([("readfrom", 0)], (), 0), ([("write", 131072), ("flush", 0), ("flush", 0), ("write", 131073), ("flush", 0), ("write", len(data))], (131072, 131073), None)]
+    for ops, cuts, rf in cases:
+        assert facade(data, ops) == oracle_goref.zstd_encode_stream(data, cuts, level=level, readfrom_at=rf), (ops, "blocks")
+        assert facade(data, ops, jobs=True) == oracle_goref.zstd_encode_stream(data, cuts, level=level, window_size=1 << 17, concurrent=4, jobs=True, readfrom_at=rf), (ops, "jobs")
