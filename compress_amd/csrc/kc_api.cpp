@@ -2080,6 +2080,7 @@ int64_t kc_zstd_overlap_size(const kc_zstd_opts* o) {  // encoderOptions.overlap
 kc_status kc_zstd_encode_jobs(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* src, uint64_t len, const uint64_t* cuts, uint64_t n_cuts,
                               uint8_t* dst, uint64_t dst_cap, uint64_t* out_len) {
     if (!c || !o || !out_len || (len && (!src || !dst)) || (n_cuts && !cuts)) return KC_ERR_BAD_ARG;
+    if (c->job_active) return KC_ERR_BAD_ARG;  // a submitted call is still in flight on this context: kc_wait first (c->err belongs to its thread)
     c->err.clear();
     *out_len = 0;
     kc_status s = check_supported(c, o);
