@@ -168,7 +168,10 @@ struct S2StreamCall {
     const uint8_t* src; int64_t n; uint8_t* dst; int64_t cap;
     int level, snappy, block_size, add_index, padding, flush_on_write;
     const int64_t* cuts; int64_t n_cuts; int64_t result; char err[256];
+    int64_t ebuf_a = -1, ebuf_b = -1;  // >= 0: Write(src[:a]); EncodeBuffer(src[a:b]); Write(src[b:]); Close() instead of the Write / Flush sequence
+    int64_t readfrom_at = -1;          // >= 0: behind the Write / Flush sequence, the rest from this offset on through ReadFrom(bytes.NewReader(...))
 };
+thread_local long long g_s2_ebuf_a = -1, g_s2_ebuf_b = -1, g_s2_readfrom_at = -1;
 void* s2_stream_thread(void* a) {
     using namespace go;
     S2StreamCall* c = (S2StreamCall*)a;
@@ -202,11 +205,36 @@ void* s2_stream_thread(void* a) {
         if (c->n) memcpy((void*)src.p, c->src, (size_t)c->n);
         auto check = [&](error er) { if (er != nil) panic(er); };
         long long pos = 0;
-        for (long long i = 0; i < c->n_cuts; i++) {
-            const long long cut = c->cuts[i];
-            if (cut > c->n) continue;
-            if (cut > pos) { auto r = w.Write(src.sl(pos, cut)); check(std::get<1>(r)); pos = cut; }
-            check(w.Flush());
+        if (c->ebuf_a >= 0 && c->ebuf_a <= c->ebuf_b && c->ebuf_b <= c->n) {
+            if (c->ebuf_a > 0) { auto r = w.Write(src.sl(0, c->ebuf_a)); check(std::get<1>(r)); }
+            check(w.EncodeBuffer(src.sl(c->ebuf_a, c->ebuf_b)));
+            pos = c->ebuf_b;
+        } else {
+            for (long long i = 0; i < c->n_cuts; i++) {
+                const long long cut = c->cuts[i];
+                if (cut > c->n) continue;
+                if (cut > pos) { auto r = w.Write(src.sl(pos, cut)); check(std::get<1>(r)); pos = cut; }
+                check(w.Flush());
+            }
+        }
+        if (c->readfrom_at >= 0 && c->readfrom_at <= c->n) {
+            const long long a = c->readfrom_at > pos ? c->readfrom_at : pos;
+            if (a > pos) { auto r = w.Write(src.sl(pos, a)); check(std::get<1>(r)); pos = a; }
+            struct Source : io::ReaderImpl {  // bytes.Reader behind a plain io.Reader (no Bytes() method: the read loop, not the EncodeBuffer shortcut)
+                Slice<byte> buf;
+                long long at = 0;
+                std::tuple<Int, error> Read(Slice<byte> p) override {
+                    if (at >= buf.n) return std::tuple<Int, error>(Int(K(0LL)), io::EOF_);
+                    const long long k = p.n < buf.n - at ? p.n : buf.n - at;
+                    if (k > 0) memcpy((void*)p.p, (const void*)(buf.p + at), (size_t)k);
+                    at += k;
+                    return std::tuple<Int, error>(Int::raw(k), error());
+                }
+            } source;
+            source.buf = src.sl(pos, c->n);
+            auto r = w.ReadFrom(io::Reader(&source));
+            check(std::get<1>(r));
+            pos = c->n;
         }
         if (c->n > pos) { auto r = w.Write(src.sl(pos, c->n)); check(std::get<1>(r)); }
         check(w.Close());
@@ -392,6 +420,8 @@ long long goref_s2_encode(int level, const uint8_t* src, long long n, uint8_t* d
 long long goref_s2_stream(const uint8_t* src, long long n, uint8_t* dst, long long cap, int level, int snappy, int block_size, int add_index,
                           int padding, int flush_on_write, const long long* cuts, long long n_cuts, char* err, int err_cap) {
     S2StreamCall c{src, n, dst, cap, level, snappy, block_size, add_index, padding, flush_on_write, (const int64_t*)cuts, n_cuts < 0 ? 0 : n_cuts, 0, {0}};
+    c.ebuf_a = g_s2_ebuf_a; c.ebuf_b = g_s2_ebuf_b; c.readfrom_at = g_s2_readfrom_at;
+    g_s2_ebuf_a = g_s2_ebuf_b = g_s2_readfrom_at = -1;
     pthread_attr_t at;
     pthread_attr_init(&at);
     pthread_attr_setstacksize(&at, (size_t)1 << 30);
@@ -415,6 +445,10 @@ long long goref_s2_read_stream(const uint8_t* src, long long n, uint8_t* dst, lo
     if (err && err_cap > 0) { strncpy(err, c.err, (size_t)err_cap - 1); err[err_cap - 1] = 0; }
     return c.result;
 }
+// the NEXT goref_s2_stream call does Write(src[:a]); EncodeBuffer(src[a:b]); Write(src[b:]); Close() (one-shot)
+void goref_s2_next_stream_encode_buffer(long long a, long long b) { g_s2_ebuf_a = a; g_s2_ebuf_b = b; }
+// ... or feeds its input from this offset on through Writer.ReadFrom (one-shot)
+void goref_s2_next_stream_readfrom(long long at) { g_s2_readfrom_at = at; }
 // EncodeAll(src, nil) of zstd.NewWriter(nil, <options>); options < 0 (or 0 for level / window / dict): the reference's defaults.
 long long goref_zstd_encode_all(const uint8_t* src, long long n, uint8_t* dst, long long cap, int level, int window, int crc, int single,
                                 int full_zero, int no_entropy, int all_lit, int lowmem, const uint8_t* dict, long long dict_len,

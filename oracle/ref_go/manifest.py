@@ -37,7 +37,7 @@ CFG = {
                          "Reader.skippable", "Reader.Read"},
         # the stream writer in its synchronous form (WriterConcurrency(1): Write / Flush / Close run writeSync in the caller — the
         # framing, the index and the padding do not depend on the concurrency) and the index it appends
-        "s2/writer.go": {"Writer", "Writer.err", "Writer.Reset", "Writer.Write", "Writer.EncodeBuffer", "Writer.encodeBlock", "Writer.write", "Writer.writeSync",
+        "s2/writer.go": {"Writer", "Writer.err", "Writer.Reset", "Writer.Write", "Writer.EncodeBuffer", "Writer.ReadFrom", "Writer.writeFull", "Writer.encodeBlock", "Writer.write", "Writer.writeSync",
                          "Writer.AsyncFlush", "Writer.Flush", "Writer.Close", "Writer.CloseIndex", "Writer.closeIndex", "calcSkippableFrame", "skippableFrame",
                          "errClosed", "WriterOption", "WriterConcurrency", "WriterAddIndex", "WriterBetterCompression", "WriterBestCompression",
                          "WriterUncompressed", "WriterBlockSize", "WriterPadding", "WriterSnappyCompat", "WriterFlushOnWrite",
@@ -116,6 +116,11 @@ CFG = {
             (r"(\tif w\.concurrency == 1 \{\n\t\t_, err := w\.writeSync\(buf\)\n)\t\tif w\.bufferCB != nil \{\n\t\t\tw\.bufferCB\(buf\)\n\t\t\}\n(\t\treturn err\n\t\}\n).*?\n\}\n",
              r'\1\2\tpanic("concurrent form not translated")\n}\n', "EncodeBuffer"),
             (r"\tif w\.customEnc != nil \{.*?\n\t\}\n(\tif w\.snappy \{)", r"\1", "encodeBlock: no custom encoder here"),
+            (r"\tif br, ok := r\.\(byter\); ok \{.*?\n\t\}\n(\tfor \{\n\t\tinbuf := )", r"\1", "ReadFrom: the source is a plain io.Reader (no Bytes() shortcut)"),
+            (r"inbuf := w\.buffers\.Get\(\)\.\(\[\]byte\)\[:w\.blockSize\+obufHeaderLen\]", "inbuf := make([]byte, w.blockSize+obufHeaderLen, w.obufLen)", "sync.Pool is an allocation cache"),
+            (r"\t\t\tif cap\(inbuf\) >= w\.obufLen \{\n\t\t\t\tw\.buffers\.Put\(inbuf\)\n\t\t\t\}\n", "", "likewise"),
+            (r"(\t\t_, err := w\.writeSync\(inbuf\[obufHeaderLen:\]\)\n)\t\tif cap\(inbuf\) >= w\.obufLen \{\n\t\t\tw\.buffers\.Put\(inbuf\)\n\t\t\}\n(\t\treturn err\n\t\}\n).*?\n\}\n",
+             r'\1\2\tpanic("concurrent form not translated")\n}\n', "writeFull"),
             (r"obuf := w\.buffers\.Get\(\)\.\(\[\]byte\)\[:w\.obufLen\]", "obuf := make([]byte, w.obufLen)", "sync.Pool is an allocation cache"),
             (r"\t\tw\.buffers\.Put\(obuf\)\n", "", "likewise"),
             (r"(\tif err := w\.AsyncFlush\(\); err != nil \{\n\t\treturn err\n\t\}\n)\tif w\.output == nil \{\n\t\treturn w\.err\(nil\)\n\t\}\n.*?\n\}\n", r"\1\treturn w.err(nil)\n}\n",

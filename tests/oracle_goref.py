@@ -71,6 +71,10 @@ def lib():
         L.goref_zstd_decode_all.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         L.goref_zstd_decode_all_dict.restype = C.c_longlong
         L.goref_zstd_decode_all_dict.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_longlong, C.c_uint, C.c_char_p, C.c_int]
+        L.goref_s2_next_stream_readfrom.restype = None
+        L.goref_s2_next_stream_readfrom.argtypes = [C.c_longlong]
+        L.goref_s2_next_stream_encode_buffer.restype = None
+        L.goref_s2_next_stream_encode_buffer.argtypes = [C.c_longlong, C.c_longlong]
         L.goref_s2_stream.restype = C.c_longlong
         L.goref_s2_stream.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 6 + [C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         L.goref_s2_read_stream.restype = C.c_longlong
@@ -201,14 +205,19 @@ def s2_encode(src: bytes, level=0) -> bytes:
     return out.raw[:n]
 
 
-def s2_stream(src: bytes, flush_at=(), level=0, snappy=False, block_size=0, add_index=False, padding=0, flush_on_write=False) -> bytes:
+def s2_stream(src: bytes, flush_at=(), level=0, snappy=False, block_size=0, add_index=False, padding=0, flush_on_write=False, encode_buffer=None, readfrom_at=None) -> bytes:
     """w := new(bytes.Buffer); e := s2.NewWriter(w, WriterConcurrency(1), <options>); e.Write(src[..cut]) + e.Flush() at every position of
     flush_at; e.Close(); w.Bytes() — the reference's own stream writer in its synchronous form (s2/writer.go Write / writeSync / Flush /
     closeIndex, s2/index.go add / appendTo, skippableFrame), translated.  level: 0 default, 1 WriterBetterCompression, 2
     WriterBestCompression, 3 WriterUncompressed; snappy: WriterSnappyCompat; padding: WriterPadding(n) with zero bytes as the padding
-    source; the chunk bodies are the portable Go block encoders' (s2_encode)."""
+    source; the chunk bodies are the portable Go block encoders' (s2_encode).  encode_buffer=(a, b): instead of the Write / Flush
+    sequence, e.Write(src[:a]); e.EncodeBuffer(src[a:b]); e.Write(src[b:]); e.Close()."""
     import numpy as np
     src = bytes(src)
+    if encode_buffer is not None:
+        lib().goref_s2_next_stream_encode_buffer(int(encode_buffer[0]), int(encode_buffer[1]))
+    if readfrom_at is not None:  # behind the Write / Flush sequence: e.ReadFrom(reader over src[a:])
+        lib().goref_s2_next_stream_readfrom(int(readfrom_at))
     cuts = np.ascontiguousarray(sorted(int(x) for x in flush_at), dtype=np.int64)
     nblk = len(src) // (block_size or (1 << 20)) + len(cuts) + 2
     cap = len(src) + len(src) // 6 + 32 * nblk + 2 * max(int(padding), 0) + 20 * nblk + 4096

@@ -264,3 +264,85 @@ def test_facade_host_logic_on_an_empty_stream_equals_the_translated_writer(monke
         assert sink.getvalue() == oracle_goref.s2_stream(b"", **kw), kw
     with pytest.raises(ValueError, match="corrupt input"):
         oracle_goref.s2_read_stream(oracle_goref.s2_stream(b"", add_index=True), 16)
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_s2_facade_host_logic_equals_the_translated_writer(oracle, monkeypatch, level):
+    """Host logic of compress_amd.s2.Writer — how Write / Flush / Close sequences become chunks, where the stream identifier, the index
+    entries, the padding chunk and the index go — against the reference's own Writer for the same options and call sequences, on
+    the CPU.  Nothing of the product changes for it: the test stands in for the device underneath the class (a BlockEncoder whose
+    EncodeStreamDevice frames the chunks with the oracle, tensors that stay in host memory); device == oracle on that call is the GPU
+    suite's business, and the same cases run end to end on the device in test_device_writer_equals_the_translated_writer."""
+    import ctypes as C
+    import torch
+    from compress_amd import s2
+
+    class _HostEncoder:
+        def __init__(self, device=0, stream=None, level=0, variant=None):
+            self.level = int(level)
+
+        def EncodeStreamDevice(self, src_ptr, off, dst_ptr, cap, with_stream_id=True):
+            n = int(off[-1])
+            src = np.ctypeslib.as_array((C.c_uint8 * n).from_address(src_ptr)).copy() if n else np.zeros(0, dtype=np.uint8)
+            st, oo = oracle.s2_encode_stream(src, off, with_stream_id=with_stream_id, level=self.level)
+            assert len(st) <= cap
+            C.memmove(dst_ptr, st.ctypes.data, len(st))
+            return oo
+
+        def Close(self):
+            pass
+    monkeypatch.setattr(s2, "BlockEncoder", _HostEncoder)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    j, t, h = _inputs()
+    big = (j + t) * 4
+    lvl = {0: [], 1: [s2.WriterBetterCompression()], 2: [s2.WriterBestCompression()]}[level]
+    cases = [(dict(block_size=65536), j, ()), (dict(block_size=4096), j[:50000], (1000, 9000, 9001, 30000)), (dict(), big if level < 2 else big[:1500000], (2000000,)),
+             (dict(block_size=65536, add_index=True), big if level < 2 else big[:700000], ()), (dict(block_size=65536, add_index=True, padding=4096), j + h, (70000,)),
+             (dict(block_size=65536, padding=1024), t[:200000], ()), (dict(block_size=65536, snappy=True), j + h[:70000], (65536,)),
+             (dict(block_size=65536, flush_on_write=True), j[:100000], (10, 70000)), (dict(block_size=65536), b"", ()),
+             (dict(block_size=16384, add_index=True, padding=512), j[:16384 * 3], (16384, 32768))]
+    for kw, data, cuts in cases:
+        opts = list(lvl)
+        if "block_size" in kw:
+            opts.append(s2.WriterBlockSize(kw["block_size"]))
+        if kw.get("add_index"):
+            opts.append(s2.WriterAddIndex())
+        if kw.get("padding"):
+            opts += [s2.WriterPadding(kw["padding"]), s2.WriterPaddingSrc(_Zeros())]
+        if kw.get("snappy"):
+            opts.append(s2.WriterSnappyCompat())
+        if kw.get("flush_on_write"):
+            opts.append(s2.WriterFlushOnWrite())
+        sink = io.BytesIO()
+        w = s2.NewWriter(sink, *opts, batch_bytes=1 << 20)
+        pos = 0
+        for c in cuts:
+            if c <= len(data):
+                if c > pos:
+                    w.Write(data[pos:c])
+                    pos = c
+                w.Flush()
+        if len(data) > pos:
+            w.Write(data[pos:])
+        w.Close()
+        want = oracle_goref.s2_stream(data, cuts, level=level, **kw)
+        got = sink.getvalue()
+        assert got == want, "level %d %r len %d cuts %r: %d bytes vs the reference's %d" % (level, kw, len(data), cuts, len(got), len(want))
+    # EncodeBuffer (writer.go:357-453): what is buffered goes out first, then ALL of buf as chunks now, short tail included — for the
+    # bytes, a Flush in front of buf and one behind it; ReadFrom (writer.go:220-268): block-size reads, a short last one
+    for a, b in ((1000, 150000), (65536, 65536 * 2), (0, 70000)):
+        sink = io.BytesIO()
+        w = s2.NewWriter(sink, *lvl, s2.WriterBlockSize(65536), batch_bytes=1 << 20)
+        w.Write(j[:a])
+        w.EncodeBuffer(j[a:b])
+        w.Write(j[b:])
+        w.Close()
+        assert sink.getvalue() == oracle_goref.s2_stream(j, level=level, block_size=65536, encode_buffer=(a, b)), ("EncodeBuffer", a, b)
+        assert sink.getvalue() == oracle_goref.s2_stream(j, (a, b), level=level, block_size=65536), ("EncodeBuffer as two Flush points", a, b)
+        sink = io.BytesIO()
+        w = s2.NewWriter(sink, *lvl, s2.WriterBlockSize(65536), batch_bytes=1 << 20)
+        w.Write(j[:a])
+        w.ReadFrom(io.BytesIO(j[a:]))
+        w.Close()
+        assert sink.getvalue() == oracle_goref.s2_stream(j, level=level, block_size=65536, readfrom_at=a), ("ReadFrom", a)
+        assert sink.getvalue() == oracle_goref.s2_stream(j, (a,), level=level, block_size=65536), ("ReadFrom as a Flush point", a)
