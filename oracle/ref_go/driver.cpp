@@ -449,6 +449,27 @@ long long goref_s2_read_stream(const uint8_t* src, long long n, uint8_t* dst, lo
 void goref_s2_next_stream_encode_buffer(long long a, long long b) { g_s2_ebuf_a = a; g_s2_ebuf_b = b; }
 // ... or feeds its input from this offset on through Writer.ReadFrom (one-shot)
 void goref_s2_next_stream_readfrom(long long at) { g_s2_readfrom_at = at; }
+// Encoder.MaxEncodedSize(size) of zstd.NewWriter(nil, WithEncoderLevel(level), WithWindowSize(window)) (encoder.go) and s2.MaxEncodedLen(n)
+// (s2/encode.go): the size bounds of the boundary, from the reference's own code (pure arithmetic: no thread, no big stack)
+long long goref_zstd_max_encoded_size(long long size, int level, int window) {
+    using namespace go;
+    rt::Scope scope;
+    try {
+        init_packages();
+        zstd::Encoder e;
+        Call c{nullptr, 0, nullptr, 0, level, window, -1, -1, -1, -1, -1, 0, nullptr, 0, 0, 0, {0}};
+        apply_options(e, &c);
+        return e.MaxEncodedSize(Int::raw(size)).v;
+    } catch (const go::Panic&) { return -1; }
+}
+long long goref_s2_max_encoded_len(long long n) {
+    using namespace go;
+    rt::Scope scope;
+    try {
+        { rt::Permanent perm; s2::go_init(); }
+        return s2::MaxEncodedLen(Int::raw(n)).v;
+    } catch (const go::Panic&) { return -2; }
+}
 // EncodeAll(src, nil) of zstd.NewWriter(nil, <options>); options < 0 (or 0 for level / window / dict): the reference's defaults.
 long long goref_zstd_encode_all(const uint8_t* src, long long n, uint8_t* dst, long long cap, int level, int window, int crc, int single,
                                 int full_zero, int no_entropy, int all_lit, int lowmem, const uint8_t* dict, long long dict_len,

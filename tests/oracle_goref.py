@@ -71,6 +71,10 @@ def lib():
         L.goref_zstd_decode_all.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
         L.goref_zstd_decode_all_dict.restype = C.c_longlong
         L.goref_zstd_decode_all_dict.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_longlong, C.c_uint, C.c_char_p, C.c_int]
+        L.goref_zstd_max_encoded_size.restype = C.c_longlong
+        L.goref_zstd_max_encoded_size.argtypes = [C.c_longlong, C.c_int, C.c_int]
+        L.goref_s2_max_encoded_len.restype = C.c_longlong
+        L.goref_s2_max_encoded_len.argtypes = [C.c_longlong]
         L.goref_s2_next_stream_readfrom.restype = None
         L.goref_s2_next_stream_readfrom.argtypes = [C.c_longlong]
         L.goref_s2_next_stream_encode_buffer.restype = None
@@ -241,3 +245,13 @@ def s2_read_stream(stream: bytes, max_out: int, max_block=0, ignore_crc=False) -
     if n < 0:
         raise ValueError("reference s2.Reader: %s (%d)" % (err.value.decode(errors="replace"), n))
     return out.raw[:n]
+
+
+def zstd_max_encoded_size(size: int, level=1, window_size=None) -> int:
+    """(*zstd.Encoder).MaxEncodedSize(size) of the reference."""
+    return int(lib().goref_zstd_max_encoded_size(int(size), int(level), int(window_size or 0)))
+
+
+def s2_max_encoded_len(n: int) -> int:
+    """s2.MaxEncodedLen(n) of the reference (-1: too large)."""
+    return int(lib().goref_s2_max_encoded_len(int(n)))

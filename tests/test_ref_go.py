@@ -530,3 +530,20 @@ def test_zstd_facade_host_logic_equals_the_references_writer(oracle, level):
     for ops, cuts, rf in cases:
         assert facade(data, ops) == oracle_goref.zstd_encode_stream(data, cuts, level=level, readfrom_at=rf), (ops, "blocks")
         assert facade(data, ops, jobs=True) == oracle_goref.zstd_encode_stream(data, cuts, level=level, window_size=1 << 17, concurrent=4, jobs=True, readfrom_at=rf), (ops, "jobs")
+
+
+def test_size_bounds_of_the_boundary_equal_the_references(oracle, kclib):
+    """kc_zstd_max_encoded_size == (*Encoder).MaxEncodedSize and kc_s2_max_encoded_len == s2.MaxEncodedLen of the reference itself
+    (translated): the caller-side buffer arithmetic of the drop-in (include/kcgpu.h), over sizes around every block / window boundary."""
+    import ctypes as C
+    from compress_amd import zstd
+    sizes = sorted(set([0, 1, 9, 10, 100, 65535, 65536, 65537, 131071, 131072, 131073, 1 << 20, (1 << 20) + 1, (4 << 20) - 1, 4 << 20, (8 << 20) + 7, 1 << 27, (1 << 30) - 1]
+                       + [int(x) for x in np.random.default_rng(3).integers(0, 1 << 26, 200)]))
+    for level in (1, 2, 3, 4):
+        for win in (None, 1 << 10, 1 << 16, 1 << 17, 1 << 20, 1 << 23):
+            opts = [zstd.WithEncoderLevel(level)] + ([zstd.WithWindowSize(win)] if win else [])
+            e = zstd.NewWriter(None, *opts)
+            bad = [n for n in sizes if e.MaxEncodedSize(n) != oracle_goref.zstd_max_encoded_size(n, level=level, window_size=win)]
+            assert not bad, (level, win, bad[:5])
+    for n in sizes + [(1 << 32) - 1, 1 << 32, 0xFFFFFFFF - 100, 6 * (1 << 29)]:
+        assert int(kclib.kc_s2_max_encoded_len(C.c_int64(n))) == oracle_goref.s2_max_encoded_len(n), n
