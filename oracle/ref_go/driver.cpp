@@ -462,6 +462,28 @@ long long goref_zstd_max_encoded_size(long long size, int level, int window) {
         return e.MaxEncodedSize(Int::raw(size)).v;
     } catch (const go::Panic&) { return -1; }
 }
+// encoderOptions.jobSize() / overlapSize() (encoder_options.go:356-371) of the options a level and a window give; calcSkippableFrame of the
+// zstd package (frameenc.go:100-116) and of s2 (writer.go:858-874): which: 0 job size, 1 overlap size; pkg: 0 zstd, 1 s2
+long long goref_zstd_job_geometry(int which, int level, int window) {
+    using namespace go;
+    rt::Scope scope;
+    try {
+        init_packages();
+        zstd::Encoder e;
+        Call c{nullptr, 0, nullptr, 0, level, window, -1, -1, -1, -1, -1, 0, nullptr, 0, 0, 0, {0}};
+        apply_options(e, &c);
+        return which == 0 ? e.o.jobSize().v : e.o.overlapSize().v;
+    } catch (const go::Panic&) { return -1; }
+}
+long long goref_calc_skippable_frame(int pkg, long long written, long long want_multiple) {
+    using namespace go;
+    rt::Scope scope;
+    try {
+        init_packages();
+        { rt::Permanent perm; s2::go_init(); }
+        return pkg == 0 ? zstd::calcSkippableFrame(int64::raw(written), int64::raw(want_multiple)).v : s2::calcSkippableFrame(int64::raw(written), int64::raw(want_multiple)).v;
+    } catch (const go::Panic&) { return -1; }
+}
 long long goref_s2_max_encoded_len(long long n) {
     using namespace go;
     rt::Scope scope;

@@ -73,6 +73,10 @@ def lib():
         L.goref_zstd_decode_all_dict.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_char_p, C.c_longlong, C.c_uint, C.c_char_p, C.c_int]
         L.goref_zstd_max_encoded_size.restype = C.c_longlong
         L.goref_zstd_max_encoded_size.argtypes = [C.c_longlong, C.c_int, C.c_int]
+        L.goref_zstd_job_geometry.restype = C.c_longlong
+        L.goref_zstd_job_geometry.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.goref_calc_skippable_frame.restype = C.c_longlong
+        L.goref_calc_skippable_frame.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
         L.goref_s2_max_encoded_len.restype = C.c_longlong
         L.goref_s2_max_encoded_len.argtypes = [C.c_longlong]
         L.goref_s2_next_stream_readfrom.restype = None
@@ -255,3 +259,14 @@ def zstd_max_encoded_size(size: int, level=1, window_size=None) -> int:
 def s2_max_encoded_len(n: int) -> int:
     """s2.MaxEncodedLen(n) of the reference (-1: too large)."""
     return int(lib().goref_s2_max_encoded_len(int(n)))
+
+
+def zstd_job_geometry(level=1, window_size=None):
+    """(encoderOptions.jobSize(), encoderOptions.overlapSize()) of the reference for a level and a window."""
+    L = lib()
+    return int(L.goref_zstd_job_geometry(0, int(level), int(window_size or 0))), int(L.goref_zstd_job_geometry(1, int(level), int(window_size or 0)))
+
+
+def calc_skippable_frame(written: int, want_multiple: int, s2=False) -> int:
+    """calcSkippableFrame of the reference's zstd package (frameenc.go) or — s2=True — of its s2 package (writer.go); -1: it panicked."""
+    return int(lib().goref_calc_skippable_frame(int(bool(s2)), int(written), int(want_multiple)))

@@ -547,3 +547,19 @@ def test_size_bounds_of_the_boundary_equal_the_references(oracle, kclib):
             assert not bad, (level, win, bad[:5])
     for n in sizes + [(1 << 32) - 1, 1 << 32, 0xFFFFFFFF - 100, 6 * (1 << 29)]:
         assert int(kclib.kc_s2_max_encoded_len(C.c_int64(n))) == oracle_goref.s2_max_encoded_len(n), n
+
+
+def test_job_geometry_and_padding_arithmetic_equal_the_references(kclib):
+    """kc_zstd_job_size / kc_zstd_overlap_size == encoderOptions.jobSize() / overlapSize(); the façades' padding arithmetic ==
+    calcSkippableFrame of the reference's zstd and s2 packages (the zstd one needs 8 bytes of frame header, the s2 one 4)."""
+    from compress_amd import zstd, s2
+    for level in (1, 2, 3, 4):
+        for win in (None, 1 << 10, 1 << 16, 1 << 17, 1 << 19, 1 << 20, 1 << 23, 1 << 25):
+            e = zstd.NewWriter(None, zstd.WithEncoderLevel(level), *([zstd.WithWindowSize(win)] if win else []))
+            assert (e.JobSize(), e.OverlapSize()) == oracle_goref.zstd_job_geometry(level, win), (level, win)
+    rng = np.random.default_rng(8)
+    for _ in range(3000):
+        mult = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 512, 4096, 65536, int(rng.integers(1, 1 << 22))]))
+        written = int(rng.choice([0, 1, mult - 1, mult, mult + 1, int(rng.integers(0, 1 << 33))]))
+        assert zstd.calc_skippable_frame(written, mult) == oracle_goref.calc_skippable_frame(written, mult), (written, mult)
+        assert s2.calc_skippable_frame(written, mult) == oracle_goref.calc_skippable_frame(written, mult, s2=True), (written, mult)
