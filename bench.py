@@ -398,7 +398,7 @@ def main():
     khash = kernel_source_hash(cfg["src"])
     traffic, traffic_src = None, None
     if args.pmc and rank == 0 and world == 1:
-        argv = ["--config", args.config, "--gib", str(cfg["gib"]), "--kind", kind]
+        argv = ["--config", args.config, "--gib", str(cfg["gib"]), "--kind", kind, "--s2-level", str(args.s2_level), "--path", args.path, "--no-pipeline"]
         pm = collect_pmc(argv, cfg["kernel"].split("<")[0])
         if pm.get("FETCH_SIZE") and pm.get("WRITE_SIZE"):
             traffic, traffic_src = int(pm["FETCH_SIZE"] + pm["WRITE_SIZE"]), "measured in this run (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, 1 step each)"
@@ -440,24 +440,42 @@ def main():
                 cores = args.cpu_threads
             default_sample = {"C2": 16384, "C2H": 16384, "C3": 8192, "C4": 16384, "C4A": 16384, "C5": 2048, "B4": 256}[args.config]
             sample = min(n_units, args.cpu_sample_units or default_sample)
-            t0 = time.perf_counter()
             kind_cpu = "port"
             if is_s2 and cfg.get("variant") == "amd64":
                 import oracle_ref  # oracle/_ref: the reference's own assembly encoders
-                ref, ref_off = oracle_ref.encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], level=args.s2_level, threads=cores)
                 kind_cpu = "reference"
+
+                def cpu_once():
+                    return oracle_ref.encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], level=args.s2_level, threads=cores)
             elif is_s2:
-                ref, ref_off = oracle_lib.s2_encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], threads=cores,
-                                                           level=args.s2_level)
+                def cpu_once():
+                    return oracle_lib.s2_encode_blocks(host[:sample * UNIT], unit_off[:sample + 1], threads=cores, level=args.s2_level)
             else:
                 kw = dict(level=cfg["level"])
                 if dict_content:
                     kw.update(dict_id=1, dict_content=dict_content)
-                ref, ref_off = oracle_lib.zstd_encode_units(host[:sample * UNIT], unit_off[:sample + 1], threads=cores, **kw)
-            cdt = time.perf_counter() - t0
-            cpu = {"value": round(sample * UNIT / cdt / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": kind_cpu,
-                   "sample": "first %d units (%.2f GiB) of the same corpus, %d std::threads (host has %d hardware threads%s)"
-                             % (sample, sample * UNIT / 2**30, cores, host_threads, ", cgroup cpu.max allows %d CPUs" % quota if quota else "")}
+
+                def cpu_once():
+                    return oracle_lib.zstd_encode_units(host[:sample * UNIT], unit_off[:sample + 1], threads=cores, **kw)
+            # a measurement, not a single cold call: one untimed pass (thread start-up, page faults of the output; its bytes are the
+            # parity sample), then 3 timed measurements of >= 1 s each (the sample looped), the median reported with the spread
+            t0 = time.perf_counter()
+            ref, ref_off = cpu_once()
+            first = time.perf_counter() - t0
+            loops = max(1, int(1.0 / max(first, 1e-4)) + 1) if first < 1.0 else 1
+            rates = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _k in range(loops):
+                    cpu_once()
+                rates.append(loops * sample * UNIT / (time.perf_counter() - t0) / 1e6)
+            rates.sort()
+            cpu = {"value": round(rates[1], 1), "unit": "MB/s", "cores": cores, "kind": kind_cpu,
+                   "spread": {"min": round(rates[0], 1), "median": round(rates[1], 1), "max": round(rates[2], 1), "first_cold_call": round(sample * UNIT / first / 1e6, 1)},
+                   "sample": "first %d units (%.2f GiB) of the same corpus, %d std::threads (host has %d hardware threads%s); median of 3 measurements of %d pass%s each (>= 1 s of work per measurement) after one untimed pass"
+                             % (sample, sample * UNIT / 2**30, cores, host_threads, ", cgroup cpu.max allows %d CPUs" % quota if quota else "", loops, "" if loops == 1 else "es")}
+            if host_threads > cores:
+                cpu["note"] = "the host has %d hardware threads; this container may run %d: a projection to the whole host (x%.1f) is NOT a measurement" % (host_threads, cores, host_threads / cores)
             got = d_dst[:int(out_off[sample])].cpu().numpy()
             parity = bool(np.array_equal(got, np.asarray(ref)) and np.array_equal(out_off[:sample + 1], ref_off))
         except Exception as e:  # the timed result must still be reported
@@ -518,16 +536,18 @@ def main():
         also = {}
         # the five BASELINE configurations at their per-GPU sizes, then the N3 levels at small sizes (not BASELINE configurations:
         # zstd SpeedBestCompression, s2.EncodeBetter, s2.EncodeBest) so that the driver's one run times those too
-        for name, extra in (("C2H", []), ("C3", []), ("C4", []), ("C4A", []), ("C5", []), ("B4", ["--gib", "0.25"]),
+        for name, extra in (("C2/one-context", ["--no-pipeline"]), ("C2H", []), ("C3", []), ("C4", []), ("C4A", []), ("C5", []), ("B4", ["--gib", "0.25"]),
                             ("C4/s2.EncodeBetter", ["--s2-level", "1", "--gib", "1.0"]), ("C4/s2.EncodeBest", ["--s2-level", "4", "--gib", "0.25"])):
             cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("/")[0], "--steps", str(args.also_steps), "--warmup", "1", "--no-end-to-end",
                    "--no-also", "--cpu-sample-units", "1024" if not extra else "256", "--path", args.path] + extra
+            if name == "C2/one-context":  # like for like with rounds 1-3 (one context, steps back to back): no second CPU baseline
+                cmd += ["--no-cpu-baseline", "--no-device-verify"]
             t0 = time.perf_counter()
             try:
                 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, check=False)
                 js = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
                 j = json.loads(js[-1])
-                also[name] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "steps": j["steps"], "ms_per_step": j["ms_per_step"],
+                also[name] = {"workload": j["config"]["workload"], "contexts": j.get("contexts"), "value": j["value"], "unit": j["unit"], "steps": j["steps"], "ms_per_step": j["ms_per_step"],
                               "ms_per_step_spread": j.get("ms_per_step_spread"),
                               "ratio": j["ratio"], "roofline": j["roofline"], "bit_exact_vs_oracle_on_sample": j["bit_exact_vs_oracle_on_sample"],
                               "device_roundtrip_all_frames": j["device_roundtrip_all_frames"], "cpu_baseline": j["cpu_baseline"],
@@ -557,6 +577,7 @@ def main():
                        "pipeline": ("2 contexts / 2 streams: match finder of step i+1 overlaps the entropy stage of step i" if npipe == 2
                                     else "none: steps back to back on one stream"),
                        "device": info},
+            "contexts": npipe,  # machine-readable: 2 = the two-context pipeline (kernel timings of consecutive steps overlap), 1 = steps back to back
             "ratio": round(out_bytes / in_bytes, 5),
             "value_GiBps": round(value * 1e6 / 2**30, 3),
             "roofline": roofline,

@@ -50,6 +50,8 @@ OPT_MATCH_PATH, OPT_ZFAST_LDS_MAX_UNITS, OPT_S2_LDS_MAX_BLOCKS, OPT_SPEC_W0, OPT
 OPT_HOST_SERIAL, OPT_HOST_PIPE_MIB, OPT_HOST_OVERLAP_MIN_MIB, OPT_HOST_COPY_THREADS, OPT_HOST_TRACE, OPT_HOST_CHUNK_MIB = 7, 8, 9, 10, 11, 12
 OPT_K2_PROF, OPT_S2_HOOK_WAIT_US, OPT_S2_HOOK_BATCH, OPT_TEST_FEED_REDO, OPT_S2_LDS_SPEC_W0, OPT_MAX_SCRATCH_MIB, OPT_LAST_PATH, OPT_LAST_BATCHES = 13, 14, 15, 16, 17, 18, 100, 101
 OPT_JOB_PRIME = 30
+OPT_STAGE2_STREAM = 31
+OPT_HOST_CHUNK_MIB_APPEND = 32
 _PATHS = {"auto": PATH_AUTO, "hbm": PATH_HBM, "lds": PATH_LDS, None: PATH_AUTO}
 
 _lib = None
@@ -175,6 +177,31 @@ class Context:
         if st != KC_OK:
             raise KcError(st, "kc_ctx_create (is a gfx950 GPU visible? there is no CPU fallback)")
         self.h = h
+        self._apply_env()
+
+    # Measurement knobs: the library itself reads no environment variable (include/kcgpu.h); this harness maps the KC_* variables the
+    # tools/ scripts set onto kc_ctx_set_option, once per context.
+    _ENV_OPTS = (("KC_MATCH_PATH", 1), ("KC_ZFAST_LDS_MAX_UNITS", 2), ("KC_S2_LDS_MAX_BLOCKS", 3), ("KC_SPEC_W0", 4), ("KC_SPEC_GROW", 5),
+                 ("KC_LDS_SPEC_W0", 6), ("KC_S2_LDS_SPEC_W0", 17), ("KC_HOST_PIPE_MIB", 8), ("KC_HOST_OVERLAP_MIN_MIB", 9),
+                 ("KC_HOST_COPY_THREADS", 10), ("KC_S2_HOOK_WAIT_US", 14), ("KC_S2_HOOK_BATCH", 15), ("KC_S2_HOOK_LANES", 29),
+                 ("KC_ZFAST_EPOCH", 22), ("KC_ZFAST_XSEG_K", 23), ("KC_FUSE_RAW_XXH", 24), ("KC_ZFAST_FILTER", 25), ("KC_XXH_FIN_MODE", 26),
+                 ("KC_ZFAST_VARIANT", 27), ("KC_ZFAST_PRESCAN", 28), ("KC_JOB_PRIME", 30))
+    _ENV_FLAGS = (("KC_HOST_SERIAL", 7), ("KC_HOST_TRACE", 11), ("KC_K2_PROF", 13))  # set by their presence
+
+    def _apply_env(self):
+        for name, key in self._ENV_OPTS:
+            v = os.environ.get(name)
+            if v not in (None, ""):
+                self.set_option(key, int(v))
+        for name, key in self._ENV_FLAGS:
+            if os.environ.get(name) is not None:
+                self.set_option(key, 1)
+        v = os.environ.get("KC_HOST_CHUNKS_MIB")
+        if v:
+            sizes = [int(x) for x in v.split(",") if x.strip()]
+            self.set_option(OPT_HOST_CHUNK_MIB, sizes[0])
+            for x in sizes[1:]:
+                self.set_option(OPT_HOST_CHUNK_MIB_APPEND, x)
 
     def close(self):
         if getattr(self, "h", None):

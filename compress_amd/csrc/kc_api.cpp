@@ -115,8 +115,10 @@ struct kc_ctx {
     KcCfg cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // KC_OPT_STAGE2_STREAM: device-resident zstd batches run the entropy stage and everything behind it here (null: on `stream`)
     bool own_stream = false;
     std::string err;
+    bool oom = false;                // the last failure was "device memory exhausted" (KC_ERR_UNSUPPORTED to the caller): the batch cutters retry at half the scratch budget on THIS flag, never on the message text
     hipDeviceProp_t prop;
     DevBuf blk_start, unit_flags, redo_blk, pop_blk;
     DevBuf unit_off, unit_blk0, stage_off, seqs, aux, lits, meta, stage, out_size, xxh, redo, popmask, unit_list, out_off,
@@ -171,6 +173,7 @@ struct kc_ctx {
 // 4 MiB on); the device kernels keep positions in 31 bits and sizes in 32: blocks up to 1 GiB are served, larger ones are refused
 // (KC_ERR_UNSUPPORTED: the Go shim then calls the reference encoder).  s2.Writer never cuts blocks above 4 MiB (s2.maxBlockSize).
 #define KC_S2_MAX_BLOCK ((uint64_t)1 << 30)
+#define KC_S2_MAX_FRAMED_BLOCK ((uint64_t)4 << 20)  // s2.maxBlockSize: the largest block of a framed stream
 
 namespace {
 
@@ -201,6 +204,7 @@ kc_status ensure(kc_ctx* c, DevBuf& b, size_t bytes) {
         if (e == hipErrorOutOfMemory) {
             // not an error of the request: the device path cannot serve it now, the caller uses the reference encoder
             c->err = "device memory exhausted (" + std::to_string(want >> 20) + " MiB of scratch wanted)";
+            c->oom = true;
             return KC_ERR_UNSUPPORTED;
         }
         c->err = std::string("hipMalloc: ") + hipGetErrorString(e);
@@ -321,38 +325,8 @@ kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
     }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return KC_ERR_HIP; }
-    {   // the environment seeds the tunables once; kc_ctx_set_option is the interface
-        KcCfg& g = c->cfg;
-        auto envi = [](const char* k, int64_t& v) { if (const char* e = getenv(k)) v = atoll(e); };
-        envi("KC_MATCH_PATH", g.match_path);
-        envi("KC_ZFAST_LDS_MAX_UNITS", g.zfast_lds_max_units);
-        envi("KC_S2_LDS_MAX_BLOCKS", g.s2_lds_max_blocks);
-        envi("KC_SPEC_W0", g.spec_w0);
-        envi("KC_SPEC_GROW", g.spec_grow);
-        envi("KC_LDS_SPEC_W0", g.lds_spec_w0);
-        envi("KC_S2_LDS_SPEC_W0", g.s2_lds_spec_w0);
-        if (getenv("KC_HOST_SERIAL")) g.host_serial = 1;
-        envi("KC_HOST_PIPE_MIB", g.host_pipe_mib);
-        envi("KC_HOST_OVERLAP_MIN_MIB", g.host_overlap_min_mib);
-        envi("KC_HOST_COPY_THREADS", g.host_copy_threads);
-        if (getenv("KC_HOST_TRACE")) g.host_trace = 1;
-        if (getenv("KC_K2_PROF")) g.k2_prof = 1;
-        envi("KC_S2_HOOK_WAIT_US", g.hook_wait_us);
-        envi("KC_S2_HOOK_BATCH", g.hook_batch);
-        envi("KC_S2_HOOK_LANES", g.hook_lanes);
-        envi("KC_ZFAST_EPOCH", g.zfast_epoch);
-        envi("KC_ZFAST_XSEG_K", g.zfast_xseg_k);
-        envi("KC_FUSE_RAW_XXH", g.fuse_raw_xxh);
-        envi("KC_ZFAST_FILTER", g.zfast_filter);
-        envi("KC_ZFAST_VARIANT", g.zfast_variant);
-        envi("KC_ZFAST_PRESCAN", g.zfast_prescan);
-        envi("KC_XXH_FIN_MODE", g.xxh_fin_mode);
-        envi("KC_JOB_PRIME", g.job_prime);
-        if (const char* e = getenv("KC_HOST_CHUNKS_MIB")) {
-            for (const char* q = e; *q;) { g.host_chunks.push_back((uint64_t)strtoull(q, (char**)&q, 10) << 20); if (*q == ',') q++; else if (*q) break; }
-            if (g.host_chunks.empty() || g.host_chunks[0] == 0) g.host_chunks = {(uint64_t)512 << 20};
-        }
-    }
+    // every tunable is a field of the context with its default in KcCfg; kc_ctx_set_option is the only way to change one (the library
+    // reads no environment variable: measurement harnesses map their KC_* variables to options above the C ABI, compress_amd/_lib.py)
     *out = c;
     return KC_OK;
 }
@@ -374,6 +348,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_HOST_COPY_THREADS: g.host_copy_threads = v; break;
         case KC_OPT_HOST_TRACE: g.host_trace = v; break;
         case KC_OPT_HOST_CHUNK_MIB: g.host_chunks.clear(); if (v > 0) g.host_chunks.push_back((uint64_t)v << 20); break;
+        case KC_OPT_HOST_CHUNK_MIB_APPEND: if (v < 1) return KC_ERR_BAD_ARG; g.host_chunks.push_back((uint64_t)v << 20); break;
         case KC_OPT_K2_PROF: g.k2_prof = v; break;
         case KC_OPT_S2_HOOK_WAIT_US: g.hook_wait_us = v; break;
         case KC_OPT_S2_HOOK_BATCH: g.hook_batch = v < 1 ? 1 : v; break;
@@ -391,6 +366,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_ZFAST_PRESCAN: if (v < -1 || v > 1) return KC_ERR_BAD_ARG; g.zfast_prescan = v; break;
         case KC_OPT_XXH_FIN_MODE: if (v < 0 || v > 2) return KC_ERR_BAD_ARG; g.xxh_fin_mode = v; break;
         case KC_OPT_JOB_PRIME: g.job_prime = v != 0; break;
+        case KC_OPT_STAGE2_STREAM: if (c->pend) return KC_ERR_BAD_ARG; c->stream2 = (hipStream_t)(intptr_t)v; break;
         default: return KC_ERR_BAD_ARG;
     }
     return KC_OK;
@@ -430,6 +406,7 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_ZFAST_PRESCAN: return g.zfast_prescan;
         case KC_OPT_XXH_FIN_MODE: return g.xxh_fin_mode;
         case KC_OPT_JOB_PRIME: return g.job_prime;
+        case KC_OPT_STAGE2_STREAM: return (int64_t)(intptr_t)c->stream2;
         case KC_OPT_LAST_PATH: return c->last_path;
         case KC_OPT_LAST_PRESCAN_UNITS: return c->last_prescan_units;
         case KC_OPT_LAST_BATCHES: return c->last_batches;
@@ -598,7 +575,7 @@ kc_status ensure_best_slots(kc_ctx* c, uint32_t n_launch, hipStream_t st) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
         const uint64_t room = (uint64_t)((double)(fr + c->best_tables.cap) * 0.8) / kc_zbest_table_bytes();
-        if (room < 1) { c->err = "device memory exhausted: no room for one SpeedBestCompression table slot (34 MiB)"; return KC_ERR_UNSUPPORTED; }
+        if (room < 1) { c->err = "device memory exhausted: no room for one SpeedBestCompression table slot (34 MiB)"; c->oom = true; return KC_ERR_UNSUPPORTED; }
         if ((uint64_t)n > room) n = (uint32_t)room;
     } else (void)hipGetLastError();
     if (n <= c->best_n) return KC_OK;
@@ -613,6 +590,7 @@ kc_status ensure_best_slots(kc_ctx* c, uint32_t n_launch, hipStream_t st) {
             (void)hipGetLastError();
             c->best_tables.p = nullptr;
             c->err = "device memory exhausted (" + std::to_string(((size_t)n * kc_zbest_table_bytes()) >> 20) + " MiB of SpeedBestCompression tables wanted)";
+            c->oom = true;
             return KC_ERR_UNSUPPORTED;
         }
         c->best_tables.cap = (size_t)n * kc_zbest_table_bytes();
@@ -1140,6 +1118,10 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
     std::unique_ptr<Pending> P((Pending*)c->pend);
     c->pend = nullptr;
     hipStream_t st = c->stream;
+    if (c->stream2 != nullptr) {  // the second stage on a stream of its own (e.g. one restricted to other CUs than the match finder's)
+        st = c->stream2;
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev[2], 0));
+    }
     const kc_zstd_opts* o = &P->o;
     KcMatchParams& mp = P->mp;
     KcEntropyParams& ep = P->ep;
@@ -1403,8 +1385,9 @@ kc_status kc_zstd_encode_units_dev(kc_ctx* c, const kc_zstd_opts* o, const uint8
             tmp.resize(nb + 1);
             uint64_t produced = 0;
             c->cut_unit0 = i0;
+            c->oom = false;
             s = run_batch(c, o, d_src, unit_off + i0, nb, d_dst + pos, dst_cap - pos, tmp.data(), &produced);
-            if (s == KC_ERR_UNSUPPORTED && c->err.compare(0, 23, "device memory exhausted") == 0 && nb > 1 && attempt < 6) { oom = true; break; }
+            if (s == KC_ERR_UNSUPPORTED && c->oom && nb > 1 && attempt < 6) { oom = true; break; }
             if (s != KC_OK) return s;
             c->last_batches++;
             for (uint32_t k = 0; k <= nb; k++) out_off[i0 + k] = pos + tmp[k];
@@ -2193,9 +2176,10 @@ kc_status kc_zstd_encode_jobs(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* s
         c->job_flags = jflags.data() + k0;
         c->job_tables = primeHost ? tabs.data() : nullptr;
         c->job_primed = tb != 0;  // (SpeedBestCompression: the kernel indexes each job's prefix itself)
+        c->oom = false;
         s = run_batch(c, o, (const uint8_t*)c->tmp_src.p, boff.data(), nb, (uint8_t*)c->tmp_dst.p, need, oo.data(), &produced);
         c->job_redo_list.clear();
-        if (s == KC_ERR_UNSUPPORTED && c->err.compare(0, 23, "device memory exhausted") == 0 && nb > 1 && attempt < 6) {
+        if (s == KC_ERR_UNSUPPORTED && c->oom && nb > 1 && attempt < 6) {
             attempt++;
             budget /= 2;  // another process took device memory since hipMemGetInfo: this batch again at half the size
             c->err.clear();
@@ -2208,6 +2192,7 @@ kc_status kc_zstd_encode_jobs(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* s
         HIPCHK(c, hipStreamSynchronize(c->stream));  // (tmp_src / tmp_dst and the host tables are the next batch's)
         done += produced;
         k0 = k1;
+        if (attempt) { attempt = 0; budget = scratch_budget(c); }  // the squeeze was this batch's: later batches start from what is free now
     }
     if (crcT.joinable()) crcT.join();
     const uint64_t total = (uint64_t)hl + done + (o->crc ? 4 : 0);
@@ -2392,6 +2377,9 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
         const uint64_t len = blk_off[i + 1] - blk_off[i];
         maxLen = std::max(maxLen, len);
         if (len > KC_S2_MAX_BLOCK) { c->err = "S2 block larger than 1 GiB not served by the device path"; return KC_ERR_UNSUPPORTED; }
+        // a framed block is a chunk of the stream format: its header holds a 24-bit length and the reference's Reader refuses chunks of
+        // blocks above s2.maxBlockSize (4 MiB; s2/s2.go, writer.go:986-989 WriterBlockSize) — the 1 GiB bound is for bare blocks only
+        if (framed && len > KC_S2_MAX_FRAMED_BLOCK) { c->err = "framed S2 block larger than 4 MiB (s2.maxBlockSize): not a valid chunk of the stream format"; return KC_ERR_BAD_ARG; }
         rel[i] = blk_off[i] - blk_off[0];
         so[i] = acc;
         reg[i] = acc16;
@@ -2621,8 +2609,9 @@ static kc_status s2_encode_dev_budgeted(kc_ctx* c, const uint8_t* d_src, const u
         if (i0 == 0) c->last_batches = 0;
         const uint32_t nb = i1 - i0;
         tmp.resize(nb + 1);
+        c->oom = false;
         kc_status s = s2_encode_dev(c, d_src, blk_off + i0, nb, d_dst + pos, dst_cap - pos, tmp.data(), framed, i0 == 0 ? with_stream_id : 0, level);
-        if (s == KC_ERR_UNSUPPORTED && c->err.compare(0, 23, "device memory exhausted") == 0 && nb > 1 && budget > ((uint64_t)64 << 20)) {
+        if (s == KC_ERR_UNSUPPORTED && c->oom && nb > 1 && budget > ((uint64_t)64 << 20)) {
             budget /= 2;  // another process took device memory since hipMemGetInfo
             c->err.clear();
             continue;
@@ -2861,7 +2850,15 @@ int64_t kc_s2_encode_block(kc_ctx* c, uint8_t* dst, uint64_t dst_cap, const uint
         if (h->cur >= 0 && &h->slots[h->cur] == sl) h->cur = -1;
         sl->cv.wait(lk, [&] { return sl->copied == sl->n; });
         kc_ctx* const lc = h->lanes[ln];
-        lc->cfg = c->cfg;  // the caller's options (variant, kernel family, ...) as they are now
+        // the caller's options as they are now — only the scalar fields the S2 block path reads (not the whole KcCfg: it holds a
+        // vector, and another thread may be in kc_ctx_set_option on c), and the caller's scratch ceiling
+        lc->cfg.s2_variant = c->cfg.s2_variant;
+        lc->cfg.match_path = c->cfg.match_path;
+        lc->cfg.s2_lds_max_blocks = c->cfg.s2_lds_max_blocks;
+        lc->cfg.s2_lds_spec_w0 = c->cfg.s2_lds_spec_w0;
+        lc->cfg.spec_w0 = c->cfg.spec_w0;
+        lc->cfg.spec_grow = c->cfg.spec_grow;
+        lc->max_scratch_bytes = c->max_scratch_bytes;
         lk.unlock();
         const kc_status st = s2_hook_run(lc, *sl);
         h->n_batches++;

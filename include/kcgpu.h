@@ -125,15 +125,18 @@ const char* kc_last_error(const kc_ctx* ctx);
  * the jobs are independent units, which is what this engine wants: this is the reference's own way of turning ONE stream into
  * device work.  src / dst are HOST buffers; dst_cap >= sum over jobs of kc_zstd_max_encoded_size(job + overlap) + 16.  A stream of
  * at most one block is the EncodeAll frame (enc_jobs.go:263-279).  With a dictionary the reference switches the option off
- * (zstd/encoder.go:81,174): KC_ERR_UNSUPPORTED. */
+ * (zstd/encoder.go:81,174): KC_ERR_UNSUPPORTED.  The frame is assembled in dst batch by batch: on any error *out_len is 0 and the
+ * bytes already written to dst (the frame header, earlier batches) are unspecified — dst is clobbered, not rolled back. */
 kc_status kc_zstd_encode_jobs(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* src, uint64_t len, const uint64_t* cuts, uint64_t n_cuts,
                               uint8_t* dst, uint64_t dst_cap, uint64_t* out_len);
 int64_t kc_zstd_job_size(const kc_zstd_opts* o);     /* encoderOptions.jobSize, zstd/encoder_options.go:356-359 */
 int64_t kc_zstd_overlap_size(const kc_zstd_opts* o); /* encoderOptions.overlapSize, zstd/encoder_options.go:362-371 */
 
 /* ---- context options ----
- * Every tunable of the library is a field of the context.  kc_ctx_create seeds them ONCE from the environment variable named
- * beside each key (no entry point reads the environment afterwards); kc_ctx_set_option changes them.
+ * Every tunable of the library is a field of the context with a built-in default; kc_ctx_set_option is the only way to change one.
+ * The library reads NO environment variable (round 5).  The name beside each key is the variable the measurement harness above the
+ * C ABI maps to it (compress_amd/_lib.py: Context applies KC_* variables as options after kc_ctx_create) — a convenience of the
+ * Python tooling, not of the shipped library.
  *
  * Two kernel families serve SpeedFastest and s2.Encode / s2.EncodeSnappy (KC_OPT_MATCH_PATH):
  *   KC_PATH_HBM  per-unit hash tables in an HBM arena, 8 units per wave: the throughput path, needs ~10^4 units in flight;
@@ -171,8 +174,10 @@ typedef enum {
     KC_OPT_XXH_FIN_MODE = 26,        /* KC_XXH_FIN_MODE           checksum-and-copy kernel, payload of raw-only frames: 0 stored from the registers, 1 the same software-pipelined, 2 through an LDS ring as aligned stores */
     KC_OPT_ZFAST_VARIANT = 27,       /* KC_ZFAST_VARIANT          SpeedFastest HBM-table kernel: 0 the plain form, 1 the form for input without matches (KC_OPT_ZFAST_XSEG_K, KC_OPT_ZFAST_FILTER), -1 (default) per batch: form 1 when the context's previous batch did not compress */
     KC_OPT_ZFAST_PRESCAN = 28,       /* KC_ZFAST_PRESCAN          SpeedFastest, EncodeAll batches without dictionary: 1 = a pre-scan proves units free of matches from their probe positions alone and writes their (raw-block) frames, the match finder and the entropy stage skip them; 0 off; -1 (default) per batch: on when the context's previous batch did not compress */
-    KC_OPT_S2_HOOK_LANES = 29,       /* KC_S2_HOOK_LANES          kc_s2_encode_block: batches of concurrent callers on the device at once (own stream and scratch each; default 4, at most 8) */
+    KC_OPT_S2_HOOK_LANES = 29,       /* KC_S2_HOOK_LANES          kc_s2_encode_block: batches of concurrent callers on the device at once (own stream and scratch each; default 4, at most 8).  Footprint: on the first hook call the context creates `lanes` contexts and (lanes + 2) slots of 2 x 8 MiB pinned host memory (96 MiB at the default), each lane's device scratch grows to its largest batch (a few MiB per 256 blocks of 64 KiB); a lane takes the caller's variant / kernel-family options and scratch ceiling per batch */
     KC_OPT_JOB_PRIME = 30,           /* KC_JOB_PRIME              kc_zstd_encode_jobs: where a job's tables are primed from its overlap prefix (ResetPrefix): 1 (default) on the device (kc_zstd_prime.hip), 0 on the host, uploaded per batch */
+    KC_OPT_HOST_CHUNK_MIB_APPEND = 32, /* KC_HOST_CHUNKS_MIB (list) one more chunk size behind KC_OPT_HOST_CHUNK_MIB's: an uneven chunk schedule (the last size repeats) */
+    KC_OPT_STAGE2_STREAM = 31,       /* (no variable)             a hipStream_t handle (0: none): kc_zstd_encode_units_dev[_begin/_end] run the entropy stage and everything behind it on this stream, behind an event of the match finder's — for callers that give the two stages different CU masks (hipExtStreamCreateWithCUMask) */
     KC_OPT_LAST_PRESCAN_UNITS = 102, /* read-only: units of the last batch the pre-scan settled */
     KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
     KC_OPT_LAST_BATCHES = 101        /* read-only: device batches the last kc_zstd_encode_units_dev / kc_s2_encode_*_dev call was cut into */
@@ -284,7 +289,9 @@ kc_status kc_s2_encode_stream_lvl_dev(kc_ctx* ctx, int level, const uint8_t* d_s
 /* s2.Writer framing on the device (s2/writer.go:394-451): every block becomes one chunk
  * `type(1) | len24 | masked CRC32C(4) | body` (compressed 0x00: uvarint(len) + block; incompressible 0x01: raw bytes),
  * optionally preceded by the stream identifier `ff 06 00 00 "S2sTwO"`.  The result is a complete, concatenable .s2
- * stream; out_off[i] is the start of chunk i (out_off[0] == 10 with the identifier).  dst_cap >= sum(MaxEncodedLen+8)+10. */
+ * stream; out_off[i] is the start of chunk i (out_off[0] == 10 with the identifier).  dst_cap >= sum(MaxEncodedLen+8)+10.
+ * A block of a framed stream is at most 4 MiB (s2.maxBlockSize: the chunk header holds a 24-bit length and the reference's
+ * Reader refuses larger chunks): a larger block is KC_ERR_BAD_ARG (bare blocks: kc_s2_encode_blocks*, up to 1 GiB). */
 kc_status kc_s2_encode_stream_dev(kc_ctx* ctx, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
                                   uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off, int with_stream_id);
 /* s2.Decode (s2/decode.go:58 -> s2Decode, s2/decode_other.go:22) over N encoded blocks (uvarint length + body), for

@@ -656,6 +656,29 @@ def test_s2_blocks_above_4_mib(oracle, kclib, level, variant):
     enc.Close()
 
 
+@pytest.mark.parametrize("level", [0, 1, 6])
+def test_framed_blocks_above_4_mib_are_refused(kclib, level):
+    """A chunk of the stream format holds one block of at most s2.maxBlockSize = 4 MiB (24-bit chunk length; the reference's Reader
+    refuses larger chunks): the framed entry points refuse a larger block with KC_ERR_BAD_ARG before any byte moves, at every level
+    incl. WriterUncompressed; exactly 4 MiB is served; bare blocks keep the 1 GiB bound (test_s2_blocks_above_4_mib)."""
+    import torch
+    from compress_amd import s2, _lib
+    t = corpora.corpus("T", 6, 1 << 20, first_unit=3)
+    d_src = torch.from_numpy(t).cuda()
+    enc = s2.BlockEncoder(level=level)
+    cap = 3 * s2.MaxEncodedLen(6 << 20) + 1024
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    for sizes in ([(4 << 20) + 1], [5 << 20], [1 << 20, (4 << 20) + 4096]):
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        with pytest.raises(_lib.KcError) as ei:
+            enc.EncodeStreamDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+        assert ei.value.status == _lib.KC_ERR_BAD_ARG, ei.value
+    off = np.array([0, 4 << 20], dtype=np.uint64)
+    oo = enc.EncodeStreamDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    assert int(oo[1]) > 10
+    enc.Close()
+
+
 @pytest.mark.parametrize("variant", [None, "amd64"])
 @pytest.mark.parametrize("snappy", [False, True])
 def test_s2_best_blocks_bit_exact(oracle, kclib, snappy, variant):
