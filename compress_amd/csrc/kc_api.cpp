@@ -1261,6 +1261,15 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
                 fprintf(stderr, "  (total %.4g cycles over %u units)\n", (double)lt, n_units);
             }
         }
+        {
+            unsigned long long ft = 0;
+            for (int i = 40; i < 48; i++) ft += pv[i];
+            if (ft) {
+                fprintf(stderr, "[K2 fine] wave 0, shader clocks per unit; -DKC_K2_FINE=1: gather (pass A, barrier, step: sequences + scan, step: literal loads + ORs, step: flush + histogram, step: carry + zero, tail, closing barrier); =2: (Huffman size pass, payload zero fill + barrier, stream emit, barrier, payload copy + headers, code staging, chains, pack):");
+                for (int i = 40; i < 48; i++) fprintf(stderr, " %.0f", (double)pv[i] / (double)(n_units ? n_units : 1));
+                fprintf(stderr, "\n");
+            }
+        }
         unsigned long long tot = 0;
         for (int i = 0; i < 16; i++) tot += pv[i];
         fprintf(stderr, "[K2 prof] shader-clock share per phase:");

@@ -33,10 +33,14 @@
 #define KC_K2_WGS 4
 #endif
 #ifndef KC_CHAIN_WARM
-#define KC_CHAIN_WARM 48  // warm-up symbols per tANS chain segment (speculation, verified; any value is exact; 16..48 measure the same)
+#define KC_CHAIN_WARM 48  // warm-up symbols per tANS chain segment (speculation, verified; any multiple of 16 up to 48 is exact)
 #endif
-#define LONG_RUN 32       // literal runs longer than this are copied cooperatively (256 x LONG_RUN fits one LDS window)
-#define LONG_CAP 64
+#define CH_PAD 16         // front pad of the chain slots (the init-only element of a block's first chunk sits at CH_PAD - 1)
+#define CH_SEG 16         // stream elements per lane segment of a tANS chain
+#define CH_WB (KC_CHAIN_WARM / CH_SEG)  // warm-up, in segments
+static_assert(KC_CHAIN_WARM % CH_SEG == 0 && CH_WB >= 1 && CH_WB <= 3, "warm-up is whole segments");
+static_assert(SEQ_CHUNK % CH_SEG == 0 && SEQ_CHUNK / CH_SEG <= 64, "one segment per lane");
+#define LONG_RUN 32       // literal runs longer than this are copied cooperatively by the wave (64 x LONG_RUN fits one LDS window)
 
 static_assert(sizeof(KcFsePredefBlob) == 3 * sizeof(KcFseT), "blob layout");
 size_t kc_fse_predef_bytes() { return sizeof(KcFsePredefBlob); }
@@ -78,8 +82,8 @@ __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v, int lane) {
     return ((uint64_t)hi << 32) | lo;
 }
 // Exclusive scan over the 256 threads; *total receives the block sum.  wsum: 4 x u64 LDS scratch.
-__device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t* wsum, uint64_t* total) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+__device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t* wsum, uint64_t* total, int tid) {  // tid: the kernel's (rotated) thread index
+    const int lane = tid & 63, w = tid >> 6;
     const uint64_t inc = wave_incl_scan64(v, lane);
     __syncthreads();  // protect wsum reuse
     if (lane == 63) wsum[w] = inc;
@@ -155,15 +159,18 @@ struct Shared {
     int ncLen[3];
     uint8_t seqMode;
     int seqhdrLen;
-    alignas(16) uint8_t codes[3][SEQ_CHUNK];     // ll / of / ml code per staged sequence
-    uint16_t sbits[3][SEQ_CHUNK];    // state bits emitted for that sequence: nb<<12 | value
+    // Chain slots (round 5): the staged element j of a chunk (stream order) lives at index CH_PAD + j - jb, jb = 1 in a block's first chunk
+    // (whose element 0 only initialises the states) — so that chain position x = j - jb of lane x / 16 starts a 16-byte aligned row:
+    // a lane fetches the 16 codes of its segment with ONE ds_read_b128 and leaves its 16 results with two ds_write_b128
+    alignas(16) uint8_t codes[3][CH_PAD + SEQ_CHUNK + 16];     // ll / of / ml code per staged sequence
+    alignas(16) uint16_t sbits[3][CH_PAD + SEQ_CHUNK + 16];    // state bits emitted for that sequence: nb<<12 | value
+    uint32_t cpk[3][64];             // per code of the block's three encoders: deltaNbBits << 12 | (deltaFindState & 0xFFF), one lookup per symbol
     uint16_t state[3];               // running FSE states (ll, of, ml)
     // --- scan / misc ---
     uint64_t wsum[4];
     uint32_t wtot[4];
-    uint32_t longList[LONG_CAP][3];
-    uint32_t longCnt;
     int ivar[24];  // broadcast slots
+    unsigned long long profAcc[24];  // KC_OPT_K2_PROF: shader clocks per phase (0..15) and per sub-step of a measurement build (16..23)
 };
 
 enum { IV_SYMLEN = 0, IV_MAXCNT, IV_CANREUSE, IV_LITMODE, IV_USEPREV, IV_TABLOG, IV_DESCLEN, IV_DATALEN, IV_LITSEC,
@@ -264,6 +271,13 @@ __device__ __forceinline__ uint32_t huf_lane_bits(const uint8_t* __restrict__ se
     // 64-address memory instruction each — the texture/L1 path, not the ALU, was the limiter)
     int p = segLen - 1 - r0;
     const int lo = segLen - r1;
+    for (; p - 15 >= lo; p -= 16) {  // two loads in flight per round trip (the literals were just written: they come from the L2)
+        const uint64_t v = ld64(seg + p - 7), v2 = ld64(seg + p - 15);
+#pragma unroll
+        for (int b = 7; b >= 0; b--) bits += T->nb[(uint32_t)(v >> (8 * b)) & 0xFFu];
+#pragma unroll
+        for (int b = 7; b >= 0; b--) bits += T->nb[(uint32_t)(v2 >> (8 * b)) & 0xFFu];
+    }
     for (; p - 7 >= lo; p -= 8) {
         const uint64_t v = ld64(seg + p - 7);
 #pragma unroll
@@ -296,6 +310,13 @@ __device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, i
     };
     int p = segLen - 1 - r0;
     const int lo = segLen - r1;
+    for (; p - 15 >= lo; p -= 16) {
+        const uint64_t v = ld64(seg + p - 7), v2 = ld64(seg + p - 15);
+#pragma unroll
+        for (int b = 7; b >= 0; b--) put((uint32_t)(v >> (8 * b)) & 0xFFu);
+#pragma unroll
+        for (int b = 7; b >= 0; b--) put((uint32_t)(v2 >> (8 * b)) & 0xFFu);
+    }
     for (; p - 7 >= lo; p -= 8) {
         const uint64_t v = ld64(seg + p - 7);
 #pragma unroll
@@ -303,6 +324,39 @@ __device__ __forceinline__ void huf_lane_emit(const uint8_t* __restrict__ seg, i
     }
     for (; p >= lo; p--) put(seg[p]);
     if (nb > 0 && (uint32_t)acc != 0u) atomicOr(wp, (uint32_t)acc);
+}
+
+// ---------------------------------------------------------------------------------------
+// tANS chain over one 16-symbol segment held in registers (blockenc.go:757-787, fse_encoder.go cState.encode): pk[q] is the packed
+// constant of the q-th symbol (cpk above), tbl the encoder's state table.  Only the state-table read is on the dependent chain:
+// t = (st << 12) + pk = (st + deltaNbBits) << 12 | dfs12, nbBitsOut = t >> 28, st' = tbl[(st >> nbBitsOut) + deltaFindState].
+// EMIT: the state bits of step q (nb << 12 | value) packed two per register.  Returns the state after `cnt` steps (cnt <= 16:
+// the slots behind a chunk's last element hold a valid code, their steps run and are ignored).
+// ---------------------------------------------------------------------------------------
+template <bool EMIT>
+__device__ __forceinline__ uint32_t chain_seg16(uint32_t st, const uint32_t (&pk)[CH_SEG], int cnt, const uint16_t* __restrict__ tbl, uint32_t (&sbp)[CH_SEG / 2]) {
+    uint32_t out = st;
+#pragma unroll
+    for (int q = 0; q < CH_SEG; q++) {
+        const uint32_t w = pk[q];
+        const uint32_t t = (st << 12) + w;
+        const uint32_t nb = t >> 28;
+        const char* pb = (const char*)tbl + (((int32_t)(w << 20)) >> 19);  // &tbl[deltaFindState], off the dependent chain
+        if (EMIT) {
+            const uint32_t v = (nb << 12) | (st & ((1u << nb) - 1u));
+            if (q & 1) sbp[q >> 1] |= v << 16; else sbp[q >> 1] = v;
+        }
+        st = *(const uint16_t*)(pb + ((st >> nb) << 1));
+        if (q + 1 == cnt) out = st;
+    }
+    return cnt >= CH_SEG ? st : out;
+}
+// the 16 codes at cod[0..16) (16-byte aligned: one ds_read_b128) -> their packed constants
+__device__ __forceinline__ void chain_load16(const uint8_t* __restrict__ cod, const uint32_t* __restrict__ cpk, uint32_t (&pk)[CH_SEG]) {
+    const uint4 c4 = *(const uint4*)cod;
+    const uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int q = 0; q < CH_SEG; q++) pk[q] = cpk[(cw[q >> 2] >> (8 * (q & 3))) & 0xFFu];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -314,7 +368,14 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
     __shared__ uint32_t padLds[KC_K2_PAD / 4];  // occupancy experiment only
     if (P.block_size == -12345) padLds[threadIdx.x] = 1;
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // Thread roles are rotated by whole waves, per workgroup: the hardware starts every workgroup's wave 0 on the same SIMD of its CU, and
+    // this kernel's single-wave and single-lane phases (Huffman tree, table descriptions, mode choice, headers: "wave 0", "thread 0")
+    // would all queue on that one SIMD while the other three idle at barriers.  tid / wv below are the ROLE indices; lane is physical.
+#ifndef KC_K2_ROT
+#define KC_K2_ROT 1
+#endif
+    const int rot = KC_K2_ROT ? (int)(((uint32_t)blockIdx.x * 0x9E3779B1u) >> 30) : 0;
+    const int tid = ((int)threadIdx.x + (rot << 6)) & (ET - 1), lane = tid & 63, wv = tid >> 6;
     const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : P.unit_base + blockIdx.x;
     if (P.unit_done != nullptr && P.unit_done[u] != 0u) return;  // the pre-scan proved the unit free of matches and wrote its frame (kc_zstd_prescan.hip)
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
@@ -348,8 +409,32 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
     }
     int opos = 0;  // bytes written to the staging area (wave-uniform, tracked by every thread)
     long long pt0 = 0;
-#define PROF_MARK(i) do { if (P.prof && tid == 0) { const long long t1__ = clock64(); atomicAdd(&P.prof[i], (unsigned long long)(t1__ - pt0)); pt0 = t1__; } } while (0)
+    // (summed in LDS by the one profiling thread and added to the buffer once, at the kernel's end: a global atomic per mark would be
+    // waited for by the next barrier's vmcnt(0) and show up as the phases' time)
+#define PROF_MARK(i) do { if (P.prof && tid == 0) { const long long t1__ = clock64(); S.profAcc[i] += (unsigned long long)(t1__ - pt0); pt0 = t1__; } } while (0)
+    if (P.prof && tid == 0) for (int i = 0; i < 24; i++) S.profAcc[i] = 0;
     if (P.prof && tid == 0) pt0 = clock64();
+    // measurement builds only (-DKC_K2_FINE): the gather's sub-steps on wave 0, every mark behind a full s_waitcnt so that a step's
+    // memory latency is charged to the step that waits for it (slots 40..47 of the profile buffer)
+#ifdef KC_K2_FINE
+    long long pf0 = 0;
+#define PROF_FINE(i) do { if (P.prof && tid == 0) { __builtin_amdgcn_s_waitcnt(0); const long long t1__ = clock64(); S.profAcc[16 + (i)] += (unsigned long long)(t1__ - pf0); pf0 = t1__; } } while (0)
+#define PROF_FINE0() do { if (P.prof && tid == 0) { __builtin_amdgcn_s_waitcnt(0); pf0 = clock64(); } } while (0)
+#else
+#define PROF_FINE(i) do { } while (0)
+#define PROF_FINE0() do { } while (0)
+#endif
+#if defined(KC_K2_FINE) && KC_K2_FINE == 2   // second set: the phases behind the gather
+#define PROF_FINB(i) do { if (P.prof && tid == 0) { __builtin_amdgcn_s_waitcnt(0); const long long t1__ = clock64(); S.profAcc[16 + (i)] += (unsigned long long)(t1__ - pf0); pf0 = t1__; } } while (0)
+#define PROF_FINB0() do { if (P.prof && tid == 0) { __builtin_amdgcn_s_waitcnt(0); pf0 = clock64(); } } while (0)
+#undef PROF_FINE
+#undef PROF_FINE0
+#define PROF_FINE(i) do { } while (0)
+#define PROF_FINE0() do { } while (0)
+#else
+#define PROF_FINB(i) do { } while (0)
+#define PROF_FINB0() do { } while (0)
+#endif
     // ---- frame header (frameenc.go:25-92; encoder.go:756-772) ----
     // Streaming layout (Write ... Close, zstd/encoder.go:257-428) for units of at least one block: frame header without content
     // size or single segment, window = the encoder's, `last` only on a short final block, otherwise an empty raw last block.
@@ -468,120 +553,195 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             for (int i = tid; i < 3 * 64; i += ET) ((uint32_t*)S.shist)[i] = 0;
             if (tid < 3) S.smax[tid] = 0;
         }
-        if (tid == 0) S.longCnt = 0;
         __syncthreads();
         if (litsOnly) {
             for (int k = tid; k < size; k += ET) atomicAdd(&S.whist[wv][org[k]], 1u);
         } else
         {
-            // Literal gather = compaction of the literal runs of all sequences into `lits`.  One sequence per thread per
-            // batch of ET; the runs are written into an LDS window over the literal stream (ds_write_b8 is cheap, a global
-            // byte store per lane is a 64-address memory instruction) and the window is flushed with 16-byte stores.
-            // Runs longer than LONG_RUN are copied by the whole workgroup; bytes past the last full 16-byte word stay in
-            // LDS as the head of the next batch's window.
-            uint8_t* __restrict__ tile = &S.codes[0][0];  // codes + sbits: 9216 bytes, unused until the sequence phase
-            constexpr int TILE = (int)((sizeof(S.codes) + sizeof(S.sbits) - 1024) & ~(size_t)1023);  // 8192 at SEQ_CHUNK 1024 (9216 bytes of codes + sbits)
-            uint64_t run = 0;  // lo32: literal bytes so far, hi32: source bytes so far
+            // Literal gather = compaction of the literal runs of all sequences into `lits` (the match finder stores no literal
+            // bytes).  Round 5: every WAVE gathers its own contiguous quarter of the sequence list, without a workgroup barrier:
+            //   pass A  the wave sums litLen / litLen + matchLen of its quarter (and, while the sequences are in registers, adds
+            //           their codes to the three sequence histograms: genCodes, blockenc.go:831-893) -> one barrier -> the
+            //           quarter's first literal offset and first source position;
+            //   pass B  64 sequences per step: a wave scan gives every run's place, the runs are ORed into the wave's own window
+            //           of LDS (ds_or_b64; a global byte store per lane is a 64-address memory instruction), complete 16-byte
+            //           words are flushed to `lits` and counted into the wave's histogram copy, the open word stays as the head
+            //           of the next step's window.  The next step's sequences are loaded under the current step's work.
+            // Runs longer than LONG_RUN are copied by the whole wave, 4 bytes per lane.  A quarter's first and last 16-byte word
+            // may be shared with the neighbouring wave's: their bytes are stored one by one.
+            uint8_t* __restrict__ tile = &S.codes[0][0];  // codes + sbits: unused until the sequence phase
+            constexpr int TWB = 2304;   // bytes of a wave's window region: 2048 flushed per pass + the open word + slack
+            constexpr int TWC = 2048;
+            static_assert(sizeof(S.codes) + sizeof(S.sbits) >= 4 * TWB, "four gather windows");
+            uint8_t* __restrict__ tw = tile + wv * TWB;
             const uint8_t* __restrict__ bsrc = base + blkStart;
-            uint64_t sqNext = tid < nseq ? sq[tid] : 0ull;  // the next batch's sequence is loaded under the current batch's work
-            for (int t0 = 0; t0 < nseq; t0 += ET) {
-                const int i = t0 + tid;
-                uint32_t ll = 0, adv = 0;
-                if (i < nseq) { const uint64_t s = sqNext; ll = seq_ll(s); adv = ll + seq_ml(s) + 3u; }
-                sqNext = (i + ET < nseq) ? sq[i + ET] : 0ull;
-                if (tid == 0) S.longCnt = 0;
-                uint64_t tot;
-                const uint64_t ex = block_excl_scan64((uint64_t)ll | ((uint64_t)adv << 32), S.wsum, &tot) + run;
-                const uint32_t lo = (uint32_t)ex, sp = (uint32_t)(ex >> 32);
-                bool mine = ll > 0;
-                if (ll > LONG_RUN) {
-                    const uint32_t slot = atomicAdd(&S.longCnt, 1u);
-                    if (slot < LONG_CAP) { S.longList[slot][0] = sp; S.longList[slot][1] = lo; S.longList[slot][2] = ll; mine = false; }
+            const int per = (((nseq + 3) >> 2) + 63) & ~63;  // sequences per wave: whole steps of 64
+            const int q0 = wv * per < nseq ? wv * per : nseq;
+            const int q1 = q0 + per < nseq ? q0 + per : nseq;
+            // ---- pass A ----
+            PROF_FINE0();
+            {
+                uint64_t acc = 0;  // lo32: literal bytes, hi32: source bytes
+                uint32_t mll = 0, mof = 0, mml = 0;
+                for (int i0 = q0 + lane; i0 < q1; i0 += 8 * 64) {
+                    uint64_t sv[8];  // eight loads in flight: a round trip to memory is what this pass waits for
+#pragma unroll
+                    for (int r = 0; r < 8; r++) sv[r] = i0 + 64 * r < q1 ? sq[i0 + 64 * r] : 0ull;
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        if (i0 + 64 * r < q1) {
+                            const uint32_t ll = seq_ll(sv[r]), ml = seq_ml(sv[r]), of = seq_of(sv[r]);
+                            acc += (uint64_t)ll | ((uint64_t)(ll + ml + 3u) << 32);
+                            const uint32_t cl = kc_ll_code(ll), co = kc_of_code(of), cm = kc_ml_code(ml);
+                            atomicAdd(&S.shist[0][cl], 1u);
+                            atomicAdd(&S.shist[1][co], 1u);
+                            atomicAdd(&S.shist[2][cm], 1u);
+                            mll = cl > mll ? cl : mll;
+                            mof = co > mof ? co : mof;
+                            mml = cm > mml ? cm : mml;
+                        }
+                    }
                 }
-                __syncthreads();
-                const int nl = (int)(S.longCnt < LONG_CAP ? S.longCnt : LONG_CAP);
+                mll = wave_reduce_max(mll); mof = wave_reduce_max(mof); mml = wave_reduce_max(mml);
+                const uint64_t tot = wave_incl_scan64(acc, lane);
+                if (lane == 63) S.wsum[wv] = tot;
+                if (lane == 0) { atomicMax(&S.smax[0], mll); atomicMax(&S.smax[1], mof); atomicMax(&S.smax[2], mml); }
+            }
+            PROF_FINE(0);
+            __syncthreads();
+            PROF_FINE(1);
+            uint64_t run = 0;  // lo32: literal bytes in front of the wave's next step, hi32: source bytes (wave-uniform)
+            for (int k = 0; k < wv; k++) run += S.wsum[k];
+            const uint32_t firstLo = (uint32_t)run;        // the quarter's first literal offset
+            const uint32_t fw = firstLo & ~15u;            // its first 16-byte word: the bytes below firstLo are the previous wave's
+            const uint32_t hs = firstLo & 15u;
+            // ---- pass B ----
+            // A global round trip costs this kernel ~4 000 shader clocks (measured, -DKC_K2_FINE: 5 000 clocks per step for the literal
+            // loads + ORs, 1 000 for the scan, 1 100 for flush + histogram, 300 for carry + zero), and the step's literal loads are one.
+            // Both ways of hiding it were built and measured, and both LOST on this kernel, which sits at its 128-VGPR ceiling: the
+            // next step's 32 bytes per lane held in registers while this step is processed (19.9 vs 19.1 ms: more spills than hidden
+            // latency), and touching one byte at each end of the next step's runs a step ahead (19.6 ms: the touch is waited for too).
+            // The step's sequences are loaded one step ahead.
+            struct GStep { uint32_t ll, lo, sp; uint64_t tot, longMask; };
+            auto place = [&](uint64_t sx, bool have, uint64_t at, GStep& g) {  // the step's runs: a wave scan from the literal / source offsets `at`
+                uint32_t ll = 0, adv = 0;
+                if (have) { ll = seq_ll(sx); adv = ll + seq_ml(sx) + 3u; }
+                const uint64_t v = (uint64_t)ll | ((uint64_t)adv << 32);
+                const uint64_t inc = wave_incl_scan64(v, lane);
+                g.tot = bcast64(inc, 63);
+                const uint64_t ex = inc - v + at;
+                g.ll = ll; g.lo = (uint32_t)ex; g.sp = (uint32_t)(ex >> 32);
+                g.longMask = ballot64(ll > LONG_RUN);
+            };
+            auto fetch = [&](const GStep& g, uint64_t (&vv)[4]) {  // a run of up to LONG_RUN (32) bytes: four 8-byte loads
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const uint32_t k = 8u * (uint32_t)kk;
+                    vv[kk] = 0;
+                    if (g.ll <= LONG_RUN && k < g.ll) {
+                        const uint32_t n8 = g.ll - k < 8u ? g.ll - k : 8u;
+                        if ((int)(g.sp + k) + 8 <= size) vv[kk] = ld64(bsrc + g.sp + k);
+                        else { uint64_t t = 0; for (uint32_t q = 0; q < n8; q++) t |= (uint64_t)bsrc[g.sp + k + q] << (8 * q); vv[kk] = t; }
+                    }
+                }
+            };
+            GStep cur;
+            uint64_t vv[4];
+            uint64_t sq1 = q0 + lane < q1 ? sq[q0 + lane] : 0ull;
+            for (int t0 = q0; t0 < q1; t0 += 64) {
+                const int i = t0 + lane;
+                place(sq1, i < q1, run, cur);
+                sq1 = i + 64 < q1 ? sq[i + 64] : 0ull;
+                PROF_FINE(2);
+                fetch(cur, vv);
+                const uint32_t ll = cur.ll, lo = cur.lo, sp = cur.sp;
+                const uint64_t tot = cur.tot, longMask = cur.longMask;
+                const bool mine = ll > 0 && ll <= LONG_RUN;
                 const uint32_t begLo = (uint32_t)run;
-                const uint32_t endLo = begLo + (uint32_t)tot;  // literal bytes after this batch
-                for (uint32_t winBase = begLo & ~15u; winBase < endLo; winBase += TILE) {
-                    if (mine && lo < winBase + TILE && lo + ll > winBase) {
-                        // runs of up to LONG_RUN (32) bytes: all four 8-byte loads are issued before the first byte is used; a longer
-                        // run is only "mine" when the cooperative long-run list overflowed: chunks of 32 bytes the same way
-                        for (uint32_t k0 = 0; k0 < ll; k0 += 32) {
-                            uint64_t vv[4] = {0, 0, 0, 0};
+                const uint32_t endLo = begLo + (uint32_t)tot;  // literal bytes after this step
+                for (uint32_t winBase = begLo & ~15u; winBase < endLo; winBase += TWC) {
+                    if (mine && lo < winBase + TWC && lo + ll > winBase) {
 #pragma unroll
-                            for (int kk = 0; kk < 4; kk++) {
-                                const uint32_t k = k0 + 8u * (uint32_t)kk;
-                                if (k < ll) {
-                                    const uint32_t n8 = ll - k < 8u ? ll - k : 8u;
-                                    if ((int)(sp + k) + 8 <= size) vv[kk] = ld64(bsrc + sp + k);
-                                    else { uint64_t t = 0; for (uint32_t q = 0; q < n8; q++) t |= (uint64_t)bsrc[sp + k + q] << (8 * q); vv[kk] = t; }
-                                }
-                            }
-#pragma unroll
-                            for (int kk = 0; kk < 4; kk++) {
-                                const uint32_t k = k0 + 8u * (uint32_t)kk;
-                                if (k < ll) {
-                                    const uint32_t n8 = ll - k < 8u ? ll - k : 8u;
-                                    const uint64_t v = n8 < 8u ? vv[kk] & ((1ull << (8u * n8)) - 1ull) : vv[kk];
-                                    const uint32_t o = lo + k - winBase;  // wraps for bytes in front of the window
-                                    if (lo + k >= winBase && o + n8 <= (uint32_t)TILE) {
-                                        // the window is zero where nothing has been written yet: up to 8 bytes at any alignment are
-                                        // one or two 64-bit ORs (ds_or_b64) instead of 8 byte writes
-                                        unsigned long long* p = (unsigned long long*)(tile + (o & ~7u));
-                                        const uint32_t sh = (o & 7u) * 8u;
-                                        atomicOr(p, (unsigned long long)(v << sh));
-                                        if (sh != 0u && (v >> (64u - sh)) != 0ull) atomicOr(p + 1, (unsigned long long)(v >> (64u - sh)));
-                                    } else {  // run cut by a window edge (only when a batch holds more than TILE literal bytes)
-                                        for (uint32_t q = 0; q < n8; q++) {
-                                            const uint32_t oo = lo + k + q - winBase;
-                                            if (oo < (uint32_t)TILE) atomicOr((uint32_t*)(tile + (oo & ~3u)), (uint32_t)((v >> (8u * q)) & 0xFFu) << (8u * (oo & 3u)));
-                                        }
+                        for (int kk = 0; kk < 4; kk++) {
+                            const uint32_t k = 8u * (uint32_t)kk;
+                            if (k < ll) {
+                                const uint32_t n8 = ll - k < 8u ? ll - k : 8u;
+                                const uint64_t x = n8 < 8u ? vv[kk] & ((1ull << (8u * n8)) - 1ull) : vv[kk];
+                                const uint32_t o = lo + k - winBase;  // wraps for bytes in front of the window
+                                if (lo + k >= winBase && o + n8 <= (uint32_t)TWC) {
+                                    // the window is zero where nothing has been written yet: up to 8 bytes at any alignment are
+                                    // one or two 64-bit ORs (ds_or_b64) instead of 8 byte writes
+                                    unsigned long long* pq = (unsigned long long*)(tw + (o & ~7u));
+                                    const uint32_t sh = (o & 7u) * 8u;
+                                    atomicOr(pq, (unsigned long long)(x << sh));
+                                    if (sh != 0u && (x >> (64u - sh)) != 0ull) atomicOr(pq + 1, (unsigned long long)(x >> (64u - sh)));
+                                } else {  // run cut by a window edge (only when a step holds more than TWC literal bytes)
+                                    for (uint32_t q = 0; q < n8; q++) {
+                                        const uint32_t oo = lo + k + q - winBase;
+                                        if (oo < (uint32_t)TWC) atomicOr((uint32_t*)(tw + (oo & ~3u)), (uint32_t)((x >> (8u * q)) & 0xFFu) << (8u * (oo & 3u)));
                                     }
                                 }
                             }
                         }
                     }
-                    for (int e = 0; e < nl; e++) {
-                        const uint32_t lsp = S.longList[e][0], llo = S.longList[e][1], lln = S.longList[e][2];
+                    for (uint64_t lm = longMask; lm != 0ull; lm &= lm - 1ull) {  // wave-uniform: the long runs, one after the other
+                        const int e = ctz64(lm);
+                        const uint32_t lsp = bcast32(sp, e), llo = bcast32(lo, e), lln = bcast32(ll, e);
                         const uint32_t o0 = llo > winBase ? llo : winBase;
-                        const uint32_t o1 = llo + lln < winBase + TILE ? llo + lln : winBase + TILE;
-                        for (uint32_t o = o0 + tid; o < o1; o += ET) {
+                        const uint32_t o1 = llo + lln < winBase + TWC ? llo + lln : winBase + TWC;
+                        for (uint32_t o = o0 + 4u * (uint32_t)lane; o < o1; o += 4u * 64u) {
+                            const uint32_t n4 = o1 - o < 4u ? o1 - o : 4u;
+                            const uint32_t si = lsp + (o - llo);
+                            uint32_t x;
+                            if ((int)si + 4 <= size) x = ld32(bsrc + si);
+                            else { x = 0; for (uint32_t q = 0; q < n4; q++) x |= (uint32_t)bsrc[si + q] << (8u * q); }
+                            if (n4 < 4u) x &= (1u << (8u * n4)) - 1u;
                             const uint32_t oo = o - winBase;
-                            atomicOr((uint32_t*)(tile + (oo & ~3u)), (uint32_t)bsrc[lsp + (o - llo)] << (8u * (oo & 3u)));
+                            unsigned long long* pq = (unsigned long long*)(tw + (oo & ~7u));
+                            const uint32_t sh = (oo & 7u) * 8u;
+                            atomicOr(pq, (unsigned long long)x << sh);
+                            if (sh > 32u && (x >> (64u - sh)) != 0u) atomicOr(pq + 1, (unsigned long long)(x >> (64u - sh)));
                         }
                     }
-                    __syncthreads();
-                    const uint32_t wEnd = endLo < winBase + TILE ? endLo : winBase + TILE;
+                    KC_WAVE_SYNC();
+                    PROF_FINE(3);
+                    const uint32_t wEnd = endLo < winBase + TWC ? endLo : winBase + TWC;
                     const uint32_t nfull = (wEnd - winBase) >> 4;
-                    for (uint32_t w = tid; w < nfull; w += ET) ((uint4*)(lits + winBase))[w] = ((const uint4*)tile)[w];
-                    // literal histogram from the flushed words, four bytes per thread and step: every lane active, where the per-run
-                    // loop above runs max(run length) steps with a handful of lanes each (the LDS pipe of the CU, shared by 16 waves,
-                    // is what bounds this phase)
-                    for (uint32_t d = tid; d < 4 * nfull; d += ET) {
-                        const uint32_t x = ((const uint32_t*)tile)[d];
+                    const bool shared0 = hs != 0u && winBase == fw && nfull > 0u;  // word 0 holds bytes of the previous wave's quarter
+                    if (shared0 && (uint32_t)lane >= hs && lane < 16) { const uint8_t c = tw[lane]; lits[fw + lane] = c; atomicAdd(&S.whist[wv][c], 1u); }
+                    for (uint32_t w = (shared0 ? 1u : 0u) + (uint32_t)lane; w < nfull; w += 64u) ((uint4*)(lits + winBase))[w] = ((const uint4*)tw)[w];
+                    // literal histogram from the flushed words, four bytes per lane and step
+                    for (uint32_t d = (shared0 ? 4u : 0u) + (uint32_t)lane; d < 4u * nfull; d += 64u) {
+                        const uint32_t x = ((const uint32_t*)tw)[d];
                         atomicAdd(&S.whist[wv][x & 0xFFu], 1u);
                         atomicAdd(&S.whist[wv][(x >> 8) & 0xFFu], 1u);
                         atomicAdd(&S.whist[wv][(x >> 16) & 0xFFu], 1u);
                         atomicAdd(&S.whist[wv][x >> 24], 1u);
                     }
-                    const uint32_t tail = (wEnd - winBase) & 15u;  // only the last window of a batch has a tail
+                    const uint32_t tail = (wEnd - winBase) & 15u;  // only the last window of a step has a tail
                     uint8_t carry = 0;
-                    if (nfull > 0 && tid < (int)tail) carry = tile[(nfull << 4) + tid];
-                    __syncthreads();
-                    if (nfull > 0) {  // the flushed words become zero again; the tail moves to the window's first word
-                        for (uint32_t w = 1 + tid; w <= nfull; w += ET) ((uint4*)tile)[w] = make_uint4(0, 0, 0, 0);
-                        if (tid < 16) tile[tid] = carry;
+                    if (nfull > 0u && lane < (int)tail) carry = tw[(nfull << 4) + lane];
+                    KC_WAVE_SYNC();
+                    PROF_FINE(4);
+                    if (nfull > 0u) {  // the flushed words become zero again; the tail moves to the window's first word
+                        for (uint32_t w = 1u + (uint32_t)lane; w <= nfull; w += 64u) ((uint4*)tw)[w] = make_uint4(0, 0, 0, 0);
+                        if (lane < 16) tw[lane] = carry;
                     }
-                    if (winBase + TILE < endLo) __syncthreads();  // another window of this batch follows
+                    KC_WAVE_SYNC();
+                    PROF_FINE(5);
                 }
                 run += tot;
-                __syncthreads();
             }
-            // bytes still in LDS (less than one 16-byte word) + trailing literals after the last sequence
+            // the quarter's last bytes still in LDS (less than one 16-byte word; if the quarter never left its first word: not the
+            // previous wave's part of it)
             {
                 const uint32_t total = (uint32_t)run;
                 const uint32_t rem = total & 15u;
-                if (tid < (int)rem) { const uint8_t c = tile[tid]; lits[(total & ~15u) + tid] = c; atomicAdd(&S.whist[wv][c], 1u); }
+                const uint32_t lowT = ((total & ~15u) == fw) ? hs : 0u;
+                if ((uint32_t)lane >= lowT && (uint32_t)lane < rem) { const uint8_t c = tw[lane]; lits[(total & ~15u) + lane] = c; atomicAdd(&S.whist[wv][c], 1u); }
+            }
+            // trailing literals after the last sequence
+            {
                 const uint32_t len = m.extra_lits, spos = (uint32_t)size - len, lo = (uint32_t)nlit - len;
                 for (uint32_t k = tid; k < len; k += ET) {
                     const uint8_t c = bsrc[spos + k];
@@ -589,8 +749,10 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     atomicAdd(&S.whist[wv][c], 1u);
                 }
             }
+            PROF_FINE(6);
         }
         __syncthreads();
+        PROF_FINE(7);
         {
             // reduce histogram (huff0 countSimple, compress.go:351): maxCount, symbolLen
             const uint32_t c = S.whist[0][tid] + S.whist[1][tid] + S.whist[2][tid] + S.whist[3][tid];
@@ -605,21 +767,6 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         // Sequence-side preparation that does not depend on the literals.  When a Huffman table is built for this block the
         // two long single-lane phases of huff0 (tree build, weight-table FSE) run on wave 0, and waves 1-3 use that time:
         // histograms under the tree build, normalizeCount + buildCTable under the table description.
-        auto seq_hist = [&](int t0, int stride) {
-            uint32_t mll = 0, mof = 0, mml = 0;
-            for (int i = t0; i < nseq; i += stride) {
-                const uint64_t s = sq[i];
-                const uint32_t cl = kc_ll_code(seq_ll(s)), co = kc_of_code(seq_of(s)), cm = kc_ml_code(seq_ml(s));
-                atomicAdd(&S.shist[0][cl], 1u);
-                atomicAdd(&S.shist[1][co], 1u);
-                atomicAdd(&S.shist[2][cm], 1u);
-                mll = cl > mll ? cl : mll;
-                mof = co > mof ? co : mof;
-                mml = cm > mml ? cm : mml;
-            }
-            mll = wave_reduce_max(mll); mof = wave_reduce_max(mof); mml = wave_reduce_max(mml);
-            if (lane == 0) { atomicMax(&S.smax[0], mll); atomicMax(&S.smax[1], mof); atomicMax(&S.smax[2], mml); }
-        };
         auto seq_build = [&](int k) {  // whole wave: normalizeCount on lane 0, buildCTable on all lanes
             KcFseT* f = &S.fse[S.curIdx[k]];
             int doBuild = 0;
@@ -647,7 +794,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 }
             }
         };
-        bool seqHistDone = false, seqBuildDone = false;  // workgroup-uniform
+        bool seqHistDone = !litsOnly, seqBuildDone = false;  // workgroup-uniform (the histograms: filled by the gather's pass A)
         // ---------- 2. huff0.compress decisions (compress.go:43-163) ----------
         const bool wantHuf = litsOnly ? (nlitE > 16) : (!noEntropy && nlitE > 16);  // encodeLits ignores noEntropy (encoder.go:795)
         const bool four = nlitE >= 1024;
@@ -707,8 +854,6 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     if (tl == 0xFF) atomicExch(P.err_flag, 1u);
                     S.ivar[IV_TABLOG] = tl;
                 }
-            } else if (!litsOnly) {
-                seq_hist(tid - 64, ET - 64);
             }
             seqHistDone = !litsOnly;
             __syncthreads();
@@ -760,7 +905,9 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 if (segLen < 0) segLen = 0;
                 chunk = (segLen + 63) / 64;
                 if (chunk < 1) chunk = 1;
+                PROF_FINB0();
                 laneBits = huf_lane_bits(L + segStart, segLen, T, lane, chunk);
+                PROF_FINB(0);
                 const uint32_t inc = wave_incl_scan(laneBits, lane);
                 laneOff = inc - laneBits;
                 streamBits = (uint32_t)__shfl((int)inc, 63, 64);
@@ -811,14 +958,18 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 // Emit streams into the zeroed, word-aligned staging area (aux scratch), each stream
                 // at its final byte offset relative to the payload start.
                 const int payloadWords = (outLen + 3 + 4) >> 2;
+                PROF_FINB0();
                 for (int i = tid; i < payloadWords; i += ET) auxw[i] = 0;
                 __syncthreads();
+                PROF_FINB(1);
                 if (wv < nstreams) {
                     const uint64_t bitBase = (uint64_t)myByteOff * 8 + laneOff;
                     huf_lane_emit(L + segStart, segLen, T, lane, chunk, auxw, bitBase);
                     if (lane == 63) or_bits(auxw, (uint64_t)myByteOff * 8 + streamBits, 1, 1);  // end mark
                 }
+                PROF_FINB(2);
                 __syncthreads();
+                PROF_FINB(3);
                 // copy payload to its final place and write the byte-granular headers
                 uint8_t* lsec = bout + 3;
                 wg_copy(lsec + hsz + tabLen + (four ? 6 : 0), (const uint8_t*)auxw + tabLen + (four ? 6 : 0), outLen - tabLen - (four ? 6 : 0));
@@ -833,6 +984,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     }
                 }
                 litSecLen = hsz + outLen;
+                PROF_FINB(4);
             }
         }
         if (litsOnly) {
@@ -869,14 +1021,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         __syncthreads();
 
         PROF_MARK(6);
-        // ---------- 3. sequence codes + histograms (genCodes, blockenc.go:831-893), unless done under the Huffman build ----------
-        if (!seqHistDone) {
-            for (int i = tid; i < 3 * 64; i += ET) ((uint32_t*)S.shist)[i] = 0;
-            if (tid < 3) S.smax[tid] = 0;
-            __syncthreads();
-            seq_hist(tid, ET);
-            __syncthreads();
-        }
+        // ---------- 3. sequence codes + histograms (genCodes, blockenc.go:831-893): filled by the gather's pass A ----------
         PROF_MARK(7);
         // ---------- 4. normalizeCount (one lane) + buildCTable (whole wave) for the three "cur" encoders, one wave each ----------
         if (!seqBuildDone && wv < 3) seq_build(wv);
@@ -965,6 +1110,11 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         __syncthreads();
         const KcFseT* E[3] = {&S.fse[S.useIdx[0]], &S.fse[S.useIdx[1]], &S.fse[S.useIdx[2]]};
         const int seqhdrLen = S.seqhdrLen;
+        if (tid < 192) {  // the chains' per-code constants of this block's three encoders (an RLE encoder: all zero, the state stays 0)
+            const KcFseT* f = &S.fse[S.useIdx[tid >> 6]];
+            const int c = tid & 63;
+            S.cpk[tid >> 6][c] = c < (int)f->symbolLen || f->stLen1 ? ((f->dnb[c] << 12) | ((uint32_t)(int32_t)f->dfs[c] & 0xFFFu)) : 0u;
+        }
         PROF_MARK(9);
         // ---------- 6. FSE state chains + bit packing, chunk by chunk from the last sequence ----------
         // Stream element order (blockenc.go:725-807): element 0 = last sequence (extra bits only, states
@@ -979,87 +1129,77 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         for (int hiSeq = nseq; hiSeq > 0 && !overflow; hiSeq -= SEQ_CHUNK) {
             const int loSeq = hiSeq - SEQ_CHUNK > 0 ? hiSeq - SEQ_CHUNK : 0;
             const int cn = hiSeq - loSeq;
-            // stage codes of sequences [loSeq, hiSeq), stored in stream order: slot j <-> seq hiSeq-1-j
+            const int jb = hiSeq == nseq ? 1 : 0;  // very first stream element: cState.init, no state bits
+            const int nrem = cn - jb;              // elements the chains encode: chain position x = j - jb
+            const int slot0 = CH_PAD - jb;         // staged element j <-> index slot0 + j
+            PROF_FINB0();
+            // stage codes of sequences [loSeq, hiSeq), stored in stream order: element j <-> seq hiSeq-1-j; the positions up to the
+            // end of the last 16-element segment repeat the last code (a valid symbol: their chain steps run and are ignored)
             {
                 constexpr int R = SEQ_CHUNK / ET;  // all loads of the chunk are issued before the first code is computed
                 uint64_t sv[R];
+                const int cpad = jb + ((nrem + CH_SEG - 1) & ~(CH_SEG - 1));  // (up to SEQ_CHUNK + 1: the rows have the room)
 #pragma unroll
                 for (int r = 0; r < R; r++) { const int j = tid + r * ET; sv[r] = j < cn ? sq[hiSeq - 1 - j] : 0ull; }
+                const uint64_t svl = tid < cpad - cn ? sq[loSeq] : 0ull;  // the chunk's last element (stream order)
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const int j = tid + r * ET;
                     if (j < cn) {
-                        S.codes[0][j] = (uint8_t)kc_ll_code(seq_ll(sv[r]));
-                        S.codes[1][j] = (uint8_t)kc_of_code(seq_of(sv[r]));
-                        S.codes[2][j] = (uint8_t)kc_ml_code(seq_ml(sv[r]));
+                        S.codes[0][slot0 + j] = (uint8_t)kc_ll_code(seq_ll(sv[r]));
+                        S.codes[1][slot0 + j] = (uint8_t)kc_of_code(seq_of(sv[r]));
+                        S.codes[2][slot0 + j] = (uint8_t)kc_ml_code(seq_ml(sv[r]));
                     }
+                }
+                if (tid < cpad - cn) {
+                    S.codes[0][slot0 + cn + tid] = (uint8_t)kc_ll_code(seq_ll(svl));
+                    S.codes[1][slot0 + cn + tid] = (uint8_t)kc_of_code(seq_of(svl));
+                    S.codes[2][slot0 + cn + tid] = (uint8_t)kc_ml_code(seq_ml(svl));
                 }
             }
             __syncthreads();
+            PROF_FINB(5);
             PROF_MARK(10);
             if (wv < 3) {
                 // tANS state chains, one wave per stream (LL, OF, ML).  The chain st -> stateTable[...] -> st is serial, but
-                // chains started from different states coalesce after a few symbols, so the chunk is cut into 64 segments:
-                // lane i warms up over the KC_CHAIN_WARM symbols before its segment from an arbitrary valid state, encodes
-                // its segment, and the wave then VERIFIES that every lane's assumed entry state equals its predecessor's
-                // exit state.  A lane that guessed wrong re-encodes its segment from the proven state (rare), so the result
-                // is exactly the sequential chain of blockenc.go:757-787.
+                // chains started from different states coalesce after a few symbols, so the chunk is cut into segments of 16:
+                // lane i warms up over the KC_CHAIN_WARM symbols before its segment from an arbitrary valid state (the first
+                // lanes: from the chunk's true entry state), encodes its segment, and the wave then VERIFIES that every lane's
+                // assumed entry state equals its predecessor's exit state.  A lane that guessed wrong re-encodes its segment
+                // from the proven state, so the result is exactly the sequential chain of blockenc.go:757-787.
+                // Round 5: a segment lives in registers — its 16 codes arrive with one aligned 16-byte LDS read, each symbol's
+                // two constants with one lookup (cpk), the state bits leave with two 16-byte writes after the last repair; the
+                // only LDS access on the dependent chain (and in a repair pass the only one at all) is the state-table read.
                 const int k = wv;
                 const KcFseT* f = &S.fse[S.useIdx[k]];  // derived from S directly: keeps the LDS address space (ds_read, not flat_load)
-                const uint8_t* __restrict__ cod = S.codes[k];
-                uint16_t* __restrict__ sb = S.sbits[k];
-                const bool firstChunk = hiSeq == nseq;
-                const int jb = firstChunk ? 1 : 0;  // very first stream element: cState.init, no state bits
-                uint16_t trueIn = firstChunk ? fse_init_state(f, cod[0]) : S.state[k];
-                if (firstChunk && lane == 0) sb[0] = 0;
-                const int nrem = cn - jb;
-                const int L = (nrem + 63) >> 6;
-                const int nL = L > 0 ? (nrem + L - 1) / L : 0;  // lanes with a non-empty segment
-                const int a = jb + lane * L;
-                int bnd = a + L;
-                if (bnd > cn) bnd = cn;
+                const uint16_t* __restrict__ tbl = f->st;
+                const uint32_t* __restrict__ cpk = S.cpk[k];
+                const uint8_t* __restrict__ cod = &S.codes[k][CH_PAD];  // chain position x at cod[x]
+                const uint32_t trueIn = jb ? (uint32_t)fse_init_state(f, S.codes[k][CH_PAD - 1]) : (uint32_t)S.state[k];
+                if (jb && lane == 0) S.sbits[k][CH_PAD - 1] = 0;
+                const int nL = (nrem + CH_SEG - 1) / CH_SEG;  // lanes with a non-empty segment
                 const bool act = lane < nL;
-                uint16_t st = trueIn, assumed = trueIn, endSt = trueIn;
-                auto step = [&](int jj, bool emit) {
-                    const uint32_t c = cod[jj];
-                    const uint32_t d = f->dnb[c];
-                    const int32_t fs = (int32_t)f->dfs[c];
-                    const uint32_t nbBitsOut = ((uint32_t)st + d) >> 16;
-                    const int32_t dstState = (int32_t)(st >> (nbBitsOut & 15)) + fs;
-                    if (emit) sb[jj] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
-                    st = f->st[dstState];
-                };
-                // 8 symbols per pass: their codes and per-symbol constants (deltaNbBits, deltaFindState) do not depend on the state and
-                // are fetched together; only the state-table lookups form the dependent chain (one LDS latency per symbol instead of three)
-                auto run = [&](int j0, int j1, bool emit) {
-                    int jj = j0;
-                    for (; jj + 8 <= j1; jj += 8) {
-                        uint32_t cc[8], dd[8];
-                        int32_t ff[8];
+                const int x0 = lane * CH_SEG;
+                const int cnt = nrem - x0 < CH_SEG ? nrem - x0 : CH_SEG;
+                uint32_t pk[CH_SEG], sbp[CH_SEG / 2];
 #pragma unroll
-                        for (int q = 0; q < 8; q++) cc[q] = cod[jj + q];
+                for (int q = 0; q < CH_SEG / 2; q++) sbp[q] = 0;
+                uint32_t st = trueIn, assumed = trueIn, endSt = trueIn;
+                if (act) {
+                    if (lane > CH_WB) st = tbl[0];  // any table entry is a valid state; lanes 0..CH_WB run from the chunk's entry state, exactly
 #pragma unroll
-                        for (int q = 0; q < 8; q++) { dd[q] = f->dnb[cc[q]]; ff[q] = (int32_t)f->dfs[cc[q]]; }
-#pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            const uint32_t nbBitsOut = ((uint32_t)st + dd[q]) >> 16;
-                            const int32_t dstState = (int32_t)(st >> (nbBitsOut & 15)) + ff[q];
-                            if (emit) sb[jj + q] = (uint16_t)((nbBitsOut << 12) | ((uint32_t)st & ((1u << nbBitsOut) - 1u)));
-                            st = f->st[dstState];
+                    for (int b = CH_WB; b >= 1; b--) {
+                        if (lane >= b) {
+                            chain_load16(cod + x0 - b * CH_SEG, cpk, pk);
+                            st = chain_seg16<false>(st, pk, CH_SEG, tbl, sbp);
                         }
                     }
-                    for (; jj < j1; jj++) step(jj, emit);
-                };
-                if (act) {
-                    int w = a - KC_CHAIN_WARM;
-                    if (w <= jb) w = jb; else st = f->st[0];  // any table entry is a valid state
-                    run(w, a, false);
                     assumed = st;
-                    run(a, bnd, true);
-                    endSt = st;
+                    chain_load16(cod + x0, cpk, pk);
+                    endSt = chain_seg16<true>(st, pk, cnt, tbl, sbp);
                 }
                 for (;;) {
-                    uint16_t prevEnd = (uint16_t)__shfl_up((int)endSt, 1, 64);
+                    uint32_t prevEnd = (uint32_t)__shfl_up((int)endSt, 1, 64);
                     if (lane == 0) prevEnd = trueIn;
                     const unsigned long long bad = __ballot(act && assumed != prevEnd);
                     if (bad == 0ull) break;
@@ -1074,19 +1214,23 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     // predecessor, so each pass fixes at least that lane for good; on exit every entry state equals the
                     // predecessor's exit state, i.e. the sequential chain.
                     if ((bad & ~(bad << 1)) >> lane & 1ull) {
-                        st = prevEnd;
                         assumed = prevEnd;
-                        run(a, bnd, true);
-                        endSt = st;
+                        endSt = chain_seg16<true>(prevEnd, pk, cnt, tbl, sbp);
                     }
+                }
+                if (act) {  // the segment's state bits: 16 x u16, 32-byte aligned
+                    uint4* o = (uint4*)&S.sbits[k][CH_PAD + x0];
+                    o[0] = make_uint4(sbp[0], sbp[1], sbp[2], sbp[3]);
+                    o[1] = make_uint4(sbp[4], sbp[5], sbp[6], sbp[7]);
                 }
 #ifdef KC_CHAIN_STATS
                 if (P.prof && lane == 0) { atomicAdd(&P.prof[16], 1ull); if (f->useRLE) atomicAdd(&P.prof[26], 1ull); if (f->preDefined) atomicAdd(&P.prof[27], 1ull); }
 #endif
-                const uint16_t fin = (uint16_t)__shfl((int)endSt, nL > 0 ? nL - 1 : 0, 64);
-                if (lane == 0) S.state[k] = nL > 0 ? fin : trueIn;
+                const uint32_t fin = (uint32_t)__shfl((int)endSt, nL > 0 ? nL - 1 : 0, 64);
+                if (lane == 0) S.state[k] = (uint16_t)(nL > 0 ? fin : trueIn);
             }
             __syncthreads();
+            PROF_FINB(6);
             PROF_MARK(11);
             // pack this chunk
             for (int t0 = 0; t0 < cn; t0 += ET) {
@@ -1095,14 +1239,14 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 int fb0 = 0, fb1 = 0;
                 if (j < cn) {
                     const uint64_t s = sq[hiSeq - 1 - j];
-                    const uint32_t cl = S.codes[0][j], co = S.codes[1][j], cm = S.codes[2][j];
+                    const uint32_t cl = S.codes[0][slot0 + j], co = S.codes[1][slot0 + j], cm = S.codes[2][slot0 + j];
                     const int lb = E[0]->outBits[cl] & 31, ob = E[1]->outBits[co] & 31, mb = E[2]->outBits[cm] & 31;
                     const uint32_t ll = seq_ll(s), ml = seq_ml(s), of = seq_of(s);
                     const uint64_t lv = ll & (lb ? (0xFFFFFFFFu >> (32 - lb)) : 0u);
                     const uint64_t mv = ml & (mb ? (0xFFFFFFFFu >> (32 - mb)) : 0u);
                     const uint64_t ov = of & (ob ? (0xFFFFFFFFu >> (32 - ob)) : 0u);
                     // state bits: OF, ML, LL (blockenc.go:757-787)
-                    const uint32_t so = S.sbits[1][j], sm = S.sbits[2][j], sl = S.sbits[0][j];
+                    const uint32_t so = S.sbits[1][slot0 + j], sm = S.sbits[2][slot0 + j], sl = S.sbits[0][slot0 + j];
                     fv0 = (uint64_t)(so & 0xFFF); fb0 = (int)(so >> 12);
                     fv0 |= (uint64_t)(sm & 0xFFF) << fb0; fb0 += (int)(sm >> 12);
                     fv0 |= (uint64_t)(sl & 0xFFF) << fb0; fb0 += (int)(sl >> 12);
@@ -1111,7 +1255,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     fb1 = lb + mb + ob;
                 }
                 uint64_t tot;
-                const uint64_t ex = block_excl_scan64((uint64_t)(fb0 + fb1), S.wsum, &tot) + bitRun;
+                const uint64_t ex = block_excl_scan64((uint64_t)(fb0 + fb1), S.wsum, &tot, tid) + bitRun;
                 if ((int64_t)((bitRun + tot + 7) >> 3) >= (int64_t)seqBudgetBytes) { overflow = true; break; }
                 // Pack this step's fields in LDS (ds_or), then flush the complete words to the staging stream with coalesced stores.
                 // The word a step ends in the middle of is not stored: it is carried into the next step's first LDS word, so no
@@ -1135,6 +1279,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 bitRun += tot;
             }
             __syncthreads();
+            PROF_FINB(7);
         }
         PROF_MARK(12);
         int seqStreamBytes = 0;
@@ -1208,6 +1353,10 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             outp[opos] = (uint8_t)h; outp[opos + 1] = (uint8_t)(h >> 8); outp[opos + 2] = (uint8_t)(h >> 16); outp[opos + 3] = (uint8_t)(h >> 24);
         }
         opos += 4;
+    }
+    if (P.prof && tid == 0) {
+        for (int i = 0; i < 16; i++) atomicAdd(&P.prof[i], S.profAcc[i]);
+        for (int i = 0; i < 8; i++) atomicAdd(&P.prof[40 + i], S.profAcc[16 + i]);
     }
     if (tid == 0) {
         P.out_size[u] = (uint32_t)opos;

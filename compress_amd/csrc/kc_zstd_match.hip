@@ -33,6 +33,7 @@
 #include "kc_dev.h"
 #include "kc_kernels.h"
 #include "kc_zfast_dev.h"
+#include "kc_wave.h"
 
 
 #ifndef ZW_RB
@@ -287,12 +288,23 @@ __global__ __launch_bounds__(64) void kc_zfast_match_grp_kernel(KcMatchParams P,
                     }
                 }
                 // exact in-round conflict detection: a lower lane of the group touches one of my buckets
+                // (the bucket indices of the d lanes below come over the DPP path — row_shr:d, one VALU operation each — instead of
+                // ds_bpermute round trips through the LDS crossbar: a lane with lig >= d reads inside its own group, which is active as a
+                // whole; what the other lanes receive is not looked at)
                 bool dep = false;
+#ifndef KC_MATCH_DEP_SHFL
+                static_assert(G == 8, "row_shr distances below are written out for 8-lane groups");
+#define KC_DEP_STEP(d) do { const uint32_t a0 = kc_dpp_or0<0x110 + (d), 0xf>(h0), a1 = kc_dpp_or0<0x110 + (d), 0xf>(h1); \
+                            if (lig >= (d) && (a0 == h0 || a0 == h1 || a1 == h0 || a1 == h1)) dep = true; } while (0)
+                KC_DEP_STEP(1); KC_DEP_STEP(2); KC_DEP_STEP(3); KC_DEP_STEP(4); KC_DEP_STEP(5); KC_DEP_STEP(6); KC_DEP_STEP(7);
+#undef KC_DEP_STEP
+#else
 #pragma unroll
                 for (int d = 1; d < G; d++) {
                     const uint32_t a0 = (uint32_t)__shfl_up((int)h0, d, G), a1 = (uint32_t)__shfl_up((int)h1, d, G);
                     if (lig >= d && (a0 == h0 || a0 == h1 || a1 == h0 || a1 == h1)) dep = true;
                 }
+#endif
                 // ---------------- round trip 2: tagged candidates, one 16-byte load each ----------------
                 const uint32_t e0 = c0 & posMask, e1 = c1 & posMask;
                 const int t0 = (int)e0 - 1, t1 = (int)e1 - 1;

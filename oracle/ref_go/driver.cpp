@@ -484,6 +484,46 @@ long long goref_calc_skippable_frame(int pkg, long long written, long long want_
         return pkg == 0 ? zstd::calcSkippableFrame(int64::raw(written), int64::raw(want_multiple)).v : s2::calcSkippableFrame(int64::raw(written), int64::raw(want_multiple)).v;
     } catch (const go::Panic&) { return -1; }
 }
+// s2's block-format emitters as the translated reference runs them (encode_go.go: emitLiteral / emitCopy / emitRepeat /
+// emitCopyNoRepeat), for the known-answer strings of the reference's own tests (s2/s2_test.go:827-942).  kind 0: emitLiteral(dst,
+// lit[:a]); 1: emitCopy(dst, a, b); 2: emitRepeat(dst, a, b); 3: emitCopyNoRepeat(dst, a, b).  Returns the bytes written.
+long long goref_s2_emit(int kind, const uint8_t* lit, long long a, long long b, uint8_t* dst, long long cap) {
+    using namespace go;
+    rt::Scope scope;
+    try {
+        { rt::Permanent perm; s2::go_init(); }
+        Slice<byte> d = make_slice<byte>(cap);
+        Int n;
+        if (kind == 0) {
+            Slice<byte> l = make_slice<byte>(a);
+            if (a) memcpy((void*)l.p, lit, (size_t)a);
+            n = s2::emitLiteral(d, l);
+        } else if (kind == 1) n = s2::emitCopy(d, Int::raw(a), Int::raw(b));
+        else if (kind == 2) n = s2::emitRepeat(d, Int::raw(a), Int::raw(b));
+        else if (kind == 3) n = s2::emitCopyNoRepeat(d, Int::raw(a), Int::raw(b));
+        else return -4;
+        if (n.v > cap) return -2;
+        if (n.v) memcpy(dst, d.p, (size_t)n.v);
+        return n.v;
+    } catch (const go::Panic&) { return -1; }
+}
+// s2.Decode(nil, src) of the reference (decode.go:53 -> s2Decode, decode_other.go): one block, Snappy blocks included.
+// >= 0 the decoded length, -5 the decoder's error
+long long goref_s2_decode(const uint8_t* src, long long n, uint8_t* dst, long long cap) {
+    using namespace go;
+    rt::Scope scope;
+    try {
+        { rt::Permanent perm; s2::go_init(); }
+        Slice<byte> in = make_slice<byte>(n);
+        if (n) memcpy((void*)in.p, src, (size_t)n);
+        auto r = s2::Decode(Slice<byte>(), in);
+        if (std::get<1>(r) != nil) return -5;
+        Slice<byte> out = std::get<0>(r);
+        if (out.n > cap) return -2;
+        if (out.n) memcpy(dst, out.p, (size_t)out.n);
+        return out.n;
+    } catch (const go::Panic&) { return -1; }
+}
 long long goref_s2_max_encoded_len(long long n) {
     using namespace go;
     rt::Scope scope;

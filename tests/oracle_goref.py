@@ -256,6 +256,33 @@ def zstd_max_encoded_size(size: int, level=1, window_size=None) -> int:
     return int(lib().goref_zstd_max_encoded_size(int(size), int(level), int(window_size or 0)))
 
 
+def s2_emit(kind: str, a: int, b: int = 0, lit: bytes = b"") -> bytes:
+    """The reference's own block-format emitters (s2/encode_go.go), translated: kind 'literal' (lit), 'copy' / 'repeat' / 'copy_norepeat'
+    (offset a, length b).  Returns the bytes the emitter wrote."""
+    k = {"literal": 0, "copy": 1, "repeat": 2, "copy_norepeat": 3}[kind]
+    L = lib()
+    L.goref_s2_emit.restype = C.c_longlong
+    L.goref_s2_emit.argtypes = [C.c_int, C.c_char_p, C.c_longlong, C.c_longlong, C.c_void_p, C.c_longlong]
+    cap = len(lit) + 64
+    out = C.create_string_buffer(cap)
+    n = L.goref_s2_emit(k, bytes(lit), len(lit) if k == 0 else int(a), int(b), out, cap)
+    if n < 0:
+        raise ValueError("goref_s2_emit: %d" % n)
+    return out.raw[:n]
+
+
+def s2_decode(block: bytes, max_out: int) -> bytes:
+    """s2.Decode(nil, block) of the reference (translated): one block, Snappy blocks included.  Raises on the decoder's error."""
+    L = lib()
+    L.goref_s2_decode.restype = C.c_longlong
+    L.goref_s2_decode.argtypes = [C.c_char_p, C.c_longlong, C.c_void_p, C.c_longlong]
+    out = C.create_string_buffer(max_out + 64)
+    n = L.goref_s2_decode(bytes(block), len(block), out, max_out + 64)
+    if n < 0:
+        raise ValueError("reference s2.Decode: %d" % n)
+    return out.raw[:n]
+
+
 def s2_max_encoded_len(n: int) -> int:
     """s2.MaxEncodedLen(n) of the reference (-1: too large)."""
     return int(lib().goref_s2_max_encoded_len(int(n)))
