@@ -364,7 +364,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_ZFAST_FILTER: g.zfast_filter = v != 0; break;
         case KC_OPT_ZFAST_VARIANT: if (v < -1 || v > 1) return KC_ERR_BAD_ARG; g.zfast_variant = v; break;
         case KC_OPT_ZFAST_PRESCAN: if (v < -1 || v > 1) return KC_ERR_BAD_ARG; g.zfast_prescan = v; break;
-        case KC_OPT_XXH_FIN_MODE: if (v < 0 || v > 2) return KC_ERR_BAD_ARG; g.xxh_fin_mode = v; break;
+        case KC_OPT_XXH_FIN_MODE: if (v < 0 || v > 3) return KC_ERR_BAD_ARG; g.xxh_fin_mode = v; break;
         case KC_OPT_JOB_PRIME: g.job_prime = v != 0; break;
         case KC_OPT_STAGE2_STREAM: if (c->pend) return KC_ERR_BAD_ARG; c->stream2 = (hipStream_t)(intptr_t)v; break;
         default: return KC_ERR_BAD_ARG;
@@ -1255,7 +1255,10 @@ kc_status batch_end(kc_ctx* c, uint64_t* out_off_host, uint64_t* produced) {
         {
             unsigned long long lt = 0;
             for (int i = 32; i < 40; i++) lt += pv[i];
-            if (lt) {
+            if (lt && o->level == KC_SPEED_DEFAULT) {  // -DKC_ZD_STATS build of kc_zstd_match_dfast.hip
+                fprintf(stderr, "[dfast stats] per unit: probes looked up %.0f, committed %.0f, candidate / repeat 16-byte loads %.0f, long lookups at s+1 %.0f, matches %.0f, offset-2 matches %.0f, ring refills (128 B) %.0f\n",
+                        (double)pv[32] / n_units, (double)pv[33] / n_units, (double)pv[34] / n_units, (double)pv[35] / n_units, (double)pv[36] / n_units, (double)pv[37] / n_units, (double)pv[38] / n_units);
+            } else if (lt) {
                 fprintf(stderr, "[LDS match prof] shader clocks per phase (window, probe bytes, table, candidates issued, verdicts, commit, -, round tail):");
                 for (int i = 32; i < 40; i++) fprintf(stderr, " %.1f%%", 100.0 * (double)pv[i] / (double)lt);
                 fprintf(stderr, "  (total %.4g cycles over %u units)\n", (double)lt, n_units);

@@ -195,6 +195,40 @@ __global__ __launch_bounds__(256) void kc_xxh64_fin_kernel(KcXxhFinParams P) {
             v = xround(v, word(c3, false)); v = xround(v, word(c3, true));
         }
         if (raw && staged) bytes_out(hi, (int64_t)(i << 6));  // (the rest of the unit, below, is stored straight from the registers)
+    } else if (MODE == 3) {
+        // MODE 1 with twice the bytes in flight: the kernel's parallelism is fixed by XXH64 (four accumulators = four lanes per unit:
+        // 8 waves per CU whatever the launch shape), so what it keeps in flight is lanes x loads per lane — 4 x 16 bytes per lane are
+        // 8 MiB on the chip, which at a ~2 us round trip is the 4 TB/s MODE 1 measures; eight loads of the next step are issued
+        // before the current step's eight stores and 32 hash rounds.
+        uint4 c[8], n[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = make_uint4(0, 0, 0, 0);
+        if (pairs >= 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = ld128u(q16 + 64 * k);
+        }
+        for (; i + 8 <= pairs; i += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) n[k] = c[k];
+            if (i + 16 <= pairs) {
+                const uint8_t* qq = q16 + ((i + 8) << 6);
+#pragma unroll
+                for (int k = 0; k < 8; k++) n[k] = ld128u(qq + 64 * k);
+            }
+            if (raw) {  // (the block size is a multiple of 256: a 256-byte half step never straddles two blocks)
+#pragma unroll
+                for (int hlf = 0; hlf < 2; hlf++) {
+                    const uint64_t x = (i + 4 * hlf) << 6;
+                    if (x >= bend) block_of(x);
+                    uint8_t* d = dbase + (int64_t)x + shift + 16 * a;
+                    st128u(d, c[4 * hlf]); st128u(d + 64, c[4 * hlf + 1]); st128u(d + 128, c[4 * hlf + 2]); st128u(d + 192, c[4 * hlf + 3]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { v = xround(v, word(c[k], false)); v = xround(v, word(c[k], true)); }
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = n[k];
+        }
     } else if (PIPE) {
         // software-pipelined: the loads of step i+1 are issued BEFORE the stores of step i.  gfx9 counts loads and stores in one
         // in-order counter (vmcnt), so with the stores first every wait for a load also waits for the (slower, misaligned) stores in
@@ -278,7 +312,8 @@ __global__ __launch_bounds__(256) void kc_xxh64_fin_kernel(KcXxhFinParams P) {
 void kc_launch_xxh64_fin(const KcXxhFinParams& P, hipStream_t st) {
     if (P.n_units == 0) return;
     const uint32_t threads = P.n_units * 4;
-    if (P.mode == 2) hipLaunchKernelGGL(kc_xxh64_fin_kernel<2>, dim3((threads + 255) / 256), dim3(256), 0, st, P);
+    if (P.mode == 3) hipLaunchKernelGGL(kc_xxh64_fin_kernel<3>, dim3((threads + 255) / 256), dim3(256), 0, st, P);
+    else if (P.mode == 2) hipLaunchKernelGGL(kc_xxh64_fin_kernel<2>, dim3((threads + 255) / 256), dim3(256), 0, st, P);
     else if (P.mode == 1) hipLaunchKernelGGL(kc_xxh64_fin_kernel<1>, dim3((threads + 255) / 256), dim3(256), 0, st, P);
     else hipLaunchKernelGGL(kc_xxh64_fin_kernel<0>, dim3((threads + 255) / 256), dim3(256), 0, st, P);
 }

@@ -171,7 +171,7 @@ typedef enum {
     KC_OPT_ZFAST_XSEG_K = 23,        /* KC_ZFAST_XSEG_K           SpeedFastest HBM-table kernel: a probe round crosses skip-segment boundaries once (s - nextEmit) >> 5 has reached this value (default 0: always; large: never); acts in the kernel form KC_OPT_ZFAST_VARIANT selects */
     KC_OPT_FUSE_RAW_XXH = 24,        /* KC_FUSE_RAW_XXH           frames made of raw blocks only: 1 (default) = XXH64 and the payload copy in one pass over the source */
     KC_OPT_ZFAST_FILTER = 25,        /* KC_ZFAST_FILTER           SpeedFastest HBM-table kernel: 1 (default) = units that have emitted no sequence yet skip the table loads of bucket groups they have not written (a 512-bit map in their idle sequence buffer) */
-    KC_OPT_XXH_FIN_MODE = 26,        /* KC_XXH_FIN_MODE           checksum-and-copy kernel, payload of raw-only frames: 0 stored from the registers, 1 the same software-pipelined, 2 through an LDS ring as aligned stores */
+    KC_OPT_XXH_FIN_MODE = 26,        /* KC_XXH_FIN_MODE           checksum-and-copy kernel, payload of raw-only frames: 0 stored from the registers, 1 the same software-pipelined, 2 through an LDS ring as aligned stores, 3 like 1 with eight 16-byte loads per lane in flight instead of four */
     KC_OPT_ZFAST_VARIANT = 27,       /* KC_ZFAST_VARIANT          SpeedFastest HBM-table kernel: 0 the plain form, 1 the form for input without matches (KC_OPT_ZFAST_XSEG_K, KC_OPT_ZFAST_FILTER), -1 (default) per batch: form 1 when the context's previous batch did not compress */
     KC_OPT_ZFAST_PRESCAN = 28,       /* KC_ZFAST_PRESCAN          SpeedFastest, EncodeAll batches without dictionary: 1 = a pre-scan proves units free of matches from their probe positions alone and writes their (raw-block) frames, the match finder and the entropy stage skip them; 0 off; -1 (default) per batch: on when the context's previous batch did not compress */
     KC_OPT_S2_HOOK_LANES = 29,       /* KC_S2_HOOK_LANES          kc_s2_encode_block: batches of concurrent callers on the device at once (own stream and scratch each; default 4, at most 8).  Footprint: on the first hook call the context creates `lanes` contexts and (lanes + 2) slots of 2 x 8 MiB pinned host memory (96 MiB at the default), each lane's device scratch grows to its largest batch (a few MiB per 256 blocks of 64 KiB); a lane takes the caller's variant / kernel-family options and scratch ceiling per batch */

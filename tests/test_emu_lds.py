@@ -262,7 +262,7 @@ def test_s2_lds_amd64_variant_equals_the_assembly_restatement(level, w0):
     assert not bad, bad[:10]
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_xxh_fin_kernel_checksum_and_raw_payload_copy(mode):
     """kc_xxh64_fin_kernel (checksum behind the entropy stage; the payload of raw-only frames copied by the pass that hashes it) in its
     three store schedules: every unit's XXH64 equals the oracle's and lands in the frame's last four bytes; the payloads of the flagged
@@ -373,7 +373,7 @@ def test_whole_pipeline_options_and_streams():
     assert not bad, ("stream", bad)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_whole_pipeline_with_the_checksum_behind_the_entropy_stage(mode):
     """batch_end's sequence on the emulator — entropy stage with the raw payloads deferred and the checksum field left open, size scan,
     kc_xxh64_fin_kernel (checksum of every frame, payload of the raw-only ones, in each store schedule), kc_compact_kernel — gives

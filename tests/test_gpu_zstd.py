@@ -838,7 +838,7 @@ def test_no_match_prescan_settles_incompressible_units(oracle, kclib, level, var
     enc.Close()
 
 
-@pytest.mark.parametrize("fuse,mode", [(1, 0), (1, 1), (1, 2), (0, 0)])
+@pytest.mark.parametrize("fuse,mode", [(1, 0), (1, 1), (1, 2), (1, 3), (0, 0)])
 @pytest.mark.parametrize("level", [1, "1L", 2, 3])
 def test_raw_only_frames_checksum_and_copy_in_one_pass(oracle, kclib, level, fuse, mode):
     """Frames that end up as raw blocks only get their payload copied by the kernel that hashes it, behind the entropy stage
