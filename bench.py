@@ -217,6 +217,7 @@ def main():
                          "profiles/r04_pipeline_ab.json; round 2 measured a loss, round 1 no overlap at all); not for the other "
                          "configurations (C3 / C5: no gain; C2H: 3.9 vs 2.9 ms; B4: a second set of 70 GB table slots).")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context: steps back to back on one stream")
+    ap.add_argument("--contexts", type=int, default=0, help="zstd with --pipeline: contexts in flight (default 2; 3: the entropy stage of step i may drain under the match finders of steps i+1 AND i+2)")
     ap.add_argument("--no-device-verify", action="store_true",
                     help="skip the on-device round trip (decode ALL frames on the device + compare with the input)")
     ap.add_argument("--gather", default="root", choices=["root", "none"],
@@ -292,7 +293,7 @@ def main():
             dict_content = broadcast_bytes(dict_content, torch.device("cuda", local_rank))
 
     is_s2 = cfg["codec"] == "s2"
-    npipe = 2 if (args.pipeline and not is_s2) else 1
+    npipe = (args.contexts if args.contexts >= 2 else 2) if (args.pipeline and not is_s2) else 1
     streams = [torch.cuda.Stream() for _ in range(npipe)]
     if is_s2:
         encs = [s2.BlockEncoder(device=local_rank, stream=streams[0].cuda_stream, level=args.s2_level, path=args.path, variant=cfg.get("variant"))]
@@ -311,12 +312,12 @@ def main():
     cap = n_units * slot + 64
     # N > 1: the gather of step i reads one buffer while step i+1 fills the other; with two contexts step i+2 is begun while the gather
     # of step i may still be reading: a third buffer
-    ndst = 3 if (npipe == 2 and world > 1) else (2 if (npipe == 2 or world > 1) else 1)
+    ndst = npipe + 1 if (npipe >= 2 and world > 1) else (npipe if npipe >= 2 else (2 if world > 1 else 1))
     d_dsts = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(ndst)]
     gather = FrameGather(rank, world, bound_bytes=cap) if (world > 1 and args.gather == "root") else None
-    if npipe == 2:
-        encs[0].ChainAfter(encs[1])
-        encs[1].ChainAfter(encs[0])
+    if npipe >= 2:  # one match finder at a time: context j's waits for context j-1's
+        for j in range(npipe):
+            encs[j].ChainAfter(encs[(j - 1) % npipe])
     ctx0 = enc._ctx if is_s2 else enc.ctx()
     info = ctx0.device_info()
     torch.cuda.synchronize()
@@ -330,17 +331,20 @@ def main():
             return off, last, tms, walls
         pending = None
         tw = time.perf_counter()
+        begun = 0
         if not is_s2:
             encs[0].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[0].data_ptr(), cap)
+            begun = 1
         for i in range(k):
-            cur, nxt = i % npipe, (i + 1) % npipe
+            cur = i % npipe
             db = i % ndst
             if is_s2:
                 off = enc.EncodeBlocksDevice(d_src.data_ptr(), unit_off, d_dsts[db].data_ptr(), cap)
                 tms.append(ctx0.timings())
             else:
-                if npipe == 2 and i + 1 < k:
-                    encs[nxt].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[(i + 1) % ndst].data_ptr(), cap)
+                while npipe >= 2 and begun < k and begun < i + npipe:  # the match finders of the next npipe - 1 steps are enqueued before this step's second half
+                    encs[begun % npipe].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[begun % ndst].data_ptr(), cap)
+                    begun += 1
                 off = encs[cur].EncodeUnitsDeviceEnd()
                 tms.append(encs[cur].ctx().timings())
             if gather is not None:
@@ -422,7 +426,7 @@ def main():
                 "kernel_ms": round(k_match, 3), "table_prep_ms": round(k_prep, 3), "entropy_kernel_ms": round(k_entropy, 3), "pipeline_kernel_ms": round(k_total, 3),
                 "pipeline_frac": round(algo_bytes / (k_total / 1000.0) / 1e9 / HBM_PEAK_GBS, 5),
                 "read_only_frac": round(in_bytes / (k_match / 1000.0) / 1e9 / HBM_PEAK_GBS, 5)}
-    if npipe == 2:  # two steps in flight: the event brackets of one step's kernels contain the other step's work
+    if npipe >= 2:  # several steps in flight: the event brackets of one step's kernels contain the other steps' work
         roofline["overlap_note"] = ("two contexts: kernel_ms is the match finder's duration WITH the previous step's entropy stage running beside it (alone: "
                                     "--no-pipeline); entropy_kernel_ms / pipeline_kernel_ms span the match finder they run under and do not add up to ms_per_step")
 
@@ -563,7 +567,7 @@ def main():
         # two contexts: a step's call returns when its entropy stage ends, and that stage runs under the NEXT step's match finder — so the
         # first call of the timed region spans two match finders and the last one only an entropy stage (the pipeline filling and
         # draining; both are inside the timed region and in ms_per_step).  The spread is taken over the steps in between.
-        walls_s = walls[1:-1] if (npipe == 2 and len(walls) > 3) else walls
+        walls_s = walls[npipe - 1:-(npipe - 1)] if (npipe >= 2 and len(walls) > 2 * npipe) else walls
         line = {
             "metric": METRIC if args.config in ("C2", "C2H") else "encode MB/s (input) + ratio, %s" % cfg["what"],
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -574,7 +578,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "name": args.config, "units_per_gpu": n_units, "unit_bytes": UNIT, "corpus": kind,
                        "parallelism": ("units sharded contiguously over %d GPU(s); %s" % (world, "RCCL gather of frames to rank 0" if gather is not None else "no gather: every rank keeps its shard of frames")) if world > 1 else "1 GPU",
-                       "pipeline": ("2 contexts / 2 streams: match finder of step i+1 overlaps the entropy stage of step i" if npipe == 2
+                       "pipeline": ("%d contexts / %d streams: match finder of step i+1 overlaps the entropy stage of step i" % (npipe, npipe) if npipe >= 2
                                     else "none: steps back to back on one stream"),
                        "device": info},
             "contexts": npipe,  # machine-readable: 2 = the two-context pipeline (kernel timings of consecutive steps overlap), 1 = steps back to back

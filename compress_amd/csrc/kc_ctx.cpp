@@ -1,0 +1,233 @@
+// kc_ctx.cpp — option resolution (mirrors zstd/encoder_options.go) and the context: creation, options, scratch, timings.
+#include "kc_host.h"
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------
+// options (zstd/encoder_options.go)
+// ---------------------------------------------------------------------------------------
+void kc_zstd_opts_default(kc_zstd_opts* o) {  // setDefault :36-48
+    memset(o, 0, sizeof(*o));
+    o->level = KC_SPEED_DEFAULT;
+    o->window_size = 8 << 20;
+    o->block_size = kMaxCompressedBlockSize;
+    o->crc = 1;
+    o->single = -1;
+    o->full_zero = 1;
+    o->no_entropy = 0;
+    o->all_lit_entropy = 0;
+    o->low_mem = 0;
+    o->dict_offsets[0] = 1; o->dict_offsets[1] = 4; o->dict_offsets[2] = 8;
+    o->concurrent = 0;
+}
+
+int kc_zstd_opts_concurrency(kc_zstd_opts* o, int n) {  // WithEncoderConcurrency :76-87
+    if (n < 1) return KC_ERR_BAD_ARG;
+    o->concurrent = n;
+    return KC_OK;
+}
+
+int kc_zstd_opts_level(kc_zstd_opts* o, int l) {  // WithEncoderLevel :236-266
+    if (l < KC_SPEED_FASTEST || l > 4) return KC_ERR_BAD_ARG;  // speedNotSet < l < speedLast
+    o->level = l;
+    if (!o->custom_window) {
+        switch (l) {
+        case KC_SPEED_FASTEST:
+            o->window_size = 4 << 20;
+            if (!o->custom_block) o->block_size = 1 << 16;
+            break;
+        default:
+            o->window_size = 8 << 20;
+            break;
+        }
+    }
+    if (!o->custom_alent) o->all_lit_entropy = l > KC_SPEED_DEFAULT;
+    return KC_OK;
+}
+
+int kc_zstd_opts_window(kc_zstd_opts* o, int n) {  // WithWindowSize :110-133
+    if (n < kMinWindowSize || n > kMaxWindowSize || (n & (n - 1)) != 0) return KC_ERR_BAD_ARG;
+    o->window_size = n;
+    o->custom_window = 1;
+    if (o->block_size > o->window_size) {
+        o->block_size = o->window_size;
+        o->custom_block = 1;
+    }
+    return KC_OK;
+}
+int kc_zstd_opts_crc(kc_zstd_opts* o, int b) { o->crc = b != 0; return KC_OK; }
+int kc_zstd_opts_zero_frames(kc_zstd_opts* o, int b) { o->full_zero = b != 0; return KC_OK; }
+int kc_zstd_opts_no_entropy(kc_zstd_opts* o, int b) { o->no_entropy = b != 0; return KC_OK; }
+int kc_zstd_opts_all_lit_entropy(kc_zstd_opts* o, int b) { o->custom_alent = 1; o->all_lit_entropy = b != 0; return KC_OK; }
+int kc_zstd_opts_single_segment(kc_zstd_opts* o, int b) { o->single = b != 0; return KC_OK; }
+int kc_zstd_opts_dict_raw(kc_zstd_opts* o, uint32_t id, const uint8_t* content, uint64_t len) {  // :398-406
+    if (len > ((uint64_t)1 << 31)) return KC_ERR_BAD_ARG;
+    o->dict_id = id;
+    o->dict = content;
+    o->dict_len = len;
+    o->dict_offsets[0] = 1; o->dict_offsets[1] = 4; o->dict_offsets[2] = 8;  // offsets: [3]int{1, 4, 8}, no litEnc
+    o->dict_huf_len = 0;
+    o->dict_huf_log = 0;
+    return KC_OK;
+}
+
+int64_t kc_zstd_max_encoded_size(const kc_zstd_opts* o, int64_t size) {  // encoder.go:843-873
+    int64_t frameHeader = 4 + 2;
+    if (o->dict != nullptr || o->dict_id != 0) frameHeader += 4;
+    if (size < 256) frameHeader++;
+    else if (size < 65536 + 256) frameHeader += 2;
+    else if (size < 0x7fffffff) frameHeader += 4;
+    else frameHeader += 8;
+    if (o->crc) frameHeader += 4;
+    const int64_t blocks = (size + o->block_size) / o->block_size;
+    return frameHeader + 3 * blocks + size;
+}
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
+    if (!out) return KC_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return KC_ERR_NO_DEVICE;
+    kc_ctx* c = new kc_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess) {
+        delete c;
+        return KC_ERR_NO_DEVICE;
+    }
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return KC_ERR_HIP; }
+        c->own_stream = true;
+    }
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return KC_ERR_HIP; }
+    // every tunable is a field of the context with its default in KcCfg; kc_ctx_set_option is the only way to change one (the library
+    // reads no environment variable: measurement harnesses map their KC_* variables to options above the C ABI, compress_amd/_lib.py)
+    *out = c;
+    return KC_OK;
+}
+
+kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
+    if (!c) return KC_ERR_BAD_ARG;
+    KcCfg& g = c->cfg;
+    switch (key) {
+        case KC_OPT_MATCH_PATH: if (v < KC_PATH_AUTO || v > KC_PATH_LDS) return KC_ERR_BAD_ARG; g.match_path = v; break;
+        case KC_OPT_ZFAST_LDS_MAX_UNITS: g.zfast_lds_max_units = v; break;
+        case KC_OPT_S2_LDS_MAX_BLOCKS: g.s2_lds_max_blocks = v; break;
+        case KC_OPT_SPEC_W0: g.spec_w0 = v; break;
+        case KC_OPT_SPEC_GROW: g.spec_grow = v; break;
+        case KC_OPT_LDS_SPEC_W0: g.lds_spec_w0 = v; break;
+        case KC_OPT_S2_LDS_SPEC_W0: g.s2_lds_spec_w0 = v; break;
+        case KC_OPT_HOST_SERIAL: g.host_serial = v; break;
+        case KC_OPT_HOST_PIPE_MIB: g.host_pipe_mib = v; break;
+        case KC_OPT_HOST_OVERLAP_MIN_MIB: g.host_overlap_min_mib = v; break;
+        case KC_OPT_HOST_COPY_THREADS: g.host_copy_threads = v; break;
+        case KC_OPT_HOST_TRACE: g.host_trace = v; break;
+        case KC_OPT_HOST_CHUNK_MIB: g.host_chunks.clear(); if (v > 0) g.host_chunks.push_back((uint64_t)v << 20); break;
+        case KC_OPT_HOST_CHUNK_MIB_APPEND: if (v < 1) return KC_ERR_BAD_ARG; g.host_chunks.push_back((uint64_t)v << 20); break;
+        case KC_OPT_K2_PROF: g.k2_prof = v; break;
+        case KC_OPT_S2_HOOK_WAIT_US: g.hook_wait_us = v; break;
+        case KC_OPT_S2_HOOK_BATCH: g.hook_batch = v < 1 ? 1 : v; break;
+        case KC_OPT_S2_HOOK_LANES: g.hook_lanes = v < 1 ? 1 : (v > 8 ? 8 : v); break;
+        case KC_OPT_TEST_FEED_REDO: g.test_feed_redo = v; break;
+        case KC_OPT_MAX_SCRATCH_MIB: if (v < 1) return KC_ERR_BAD_ARG; c->max_scratch_bytes = (uint64_t)v << 20; break;
+        case KC_OPT_BEST_SLOTS: if (v < 1 || v > 8192) return KC_ERR_BAD_ARG; g.best_slots = v; break;
+        case KC_OPT_S2_VARIANT: if (v != KC_S2_VARIANT_GO && v != KC_S2_VARIANT_AMD64) return KC_ERR_BAD_ARG; g.s2_variant = v; break;
+        case KC_OPT_BETTER_DICT_EPOCH: g.better_dict_epoch = v != 0; break;
+        case KC_OPT_ZFAST_EPOCH: g.zfast_epoch = v != 0; break;
+        case KC_OPT_ZFAST_XSEG_K: if (v < 0) return KC_ERR_BAD_ARG; g.zfast_xseg_k = v > (1 << 30) ? (1 << 30) : v; break;
+        case KC_OPT_FUSE_RAW_XXH: g.fuse_raw_xxh = v != 0; break;
+        case KC_OPT_ZFAST_FILTER: g.zfast_filter = v != 0; break;
+        case KC_OPT_ZFAST_VARIANT: if (v < -1 || v > 1) return KC_ERR_BAD_ARG; g.zfast_variant = v; break;
+        case KC_OPT_ZFAST_PRESCAN: if (v < -1 || v > 1) return KC_ERR_BAD_ARG; g.zfast_prescan = v; break;
+        case KC_OPT_XXH_FIN_MODE: if (v < 0 || v > 3) return KC_ERR_BAD_ARG; g.xxh_fin_mode = v; break;
+        case KC_OPT_JOB_PRIME: g.job_prime = v != 0; break;
+        case KC_OPT_STAGE2_STREAM: if (c->pend) return KC_ERR_BAD_ARG; c->stream2 = (hipStream_t)(intptr_t)v; break;
+        default: return KC_ERR_BAD_ARG;
+    }
+    return KC_OK;
+}
+
+int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
+    if (!c) return -1;
+    const KcCfg& g = c->cfg;
+    switch (key) {
+        case KC_OPT_MATCH_PATH: return g.match_path;
+        case KC_OPT_ZFAST_LDS_MAX_UNITS: return g.zfast_lds_max_units;
+        case KC_OPT_S2_LDS_MAX_BLOCKS: return g.s2_lds_max_blocks;
+        case KC_OPT_SPEC_W0: return g.spec_w0;
+        case KC_OPT_SPEC_GROW: return g.spec_grow;
+        case KC_OPT_LDS_SPEC_W0: return g.lds_spec_w0;
+        case KC_OPT_S2_LDS_SPEC_W0: return g.s2_lds_spec_w0;
+        case KC_OPT_HOST_SERIAL: return g.host_serial;
+        case KC_OPT_HOST_PIPE_MIB: return g.host_pipe_mib;
+        case KC_OPT_HOST_OVERLAP_MIN_MIB: return g.host_overlap_min_mib;
+        case KC_OPT_HOST_COPY_THREADS: return g.host_copy_threads;
+        case KC_OPT_HOST_TRACE: return g.host_trace;
+        case KC_OPT_HOST_CHUNK_MIB: return g.host_chunks.empty() ? 0 : (int64_t)(g.host_chunks[0] >> 20);
+        case KC_OPT_K2_PROF: return g.k2_prof;
+        case KC_OPT_S2_HOOK_WAIT_US: return g.hook_wait_us;
+        case KC_OPT_S2_HOOK_BATCH: return g.hook_batch;
+        case KC_OPT_S2_HOOK_LANES: return g.hook_lanes;
+        case KC_OPT_TEST_FEED_REDO: return g.test_feed_redo;
+        case KC_OPT_MAX_SCRATCH_MIB: return (int64_t)(c->max_scratch_bytes >> 20);
+        case KC_OPT_BEST_SLOTS: return g.best_slots;
+        case KC_OPT_S2_VARIANT: return g.s2_variant;
+        case KC_OPT_BETTER_DICT_EPOCH: return g.better_dict_epoch;
+        case KC_OPT_ZFAST_EPOCH: return g.zfast_epoch;
+        case KC_OPT_ZFAST_XSEG_K: return g.zfast_xseg_k;
+        case KC_OPT_FUSE_RAW_XXH: return g.fuse_raw_xxh;
+        case KC_OPT_ZFAST_FILTER: return g.zfast_filter;
+        case KC_OPT_ZFAST_VARIANT: return g.zfast_variant;
+        case KC_OPT_ZFAST_PRESCAN: return g.zfast_prescan;
+        case KC_OPT_XXH_FIN_MODE: return g.xxh_fin_mode;
+        case KC_OPT_JOB_PRIME: return g.job_prime;
+        case KC_OPT_STAGE2_STREAM: return (int64_t)(intptr_t)c->stream2;
+        case KC_OPT_LAST_PATH: return c->last_path;
+        case KC_OPT_LAST_PRESCAN_UNITS: return c->last_prescan_units;
+        case KC_OPT_LAST_BATCHES: return c->last_batches;
+        default: return -1;
+    }
+}
+
+void kc_ctx_destroy(kc_ctx* c) {
+    if (!c) return;
+    if (c->job_active && c->job.joinable()) c->job.join();
+    (void)hipSetDevice(c->device);
+    DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
+                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->redo_blk, &c->pop_blk, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf,
+                      &c->d_job_hist, &c->d_job_flags, &c->rawdef, &c->unit_raw, &c->unit_done, &c->probe_rel, &c->best_tables, &c->best_cur, &c->best_cost};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->pend) { delete (Pending*)c->pend; c->pend = nullptr; }
+    if (c->hook) { s2_hook_free(c->hook); c->hook = nullptr; }
+    if (c->hpipe) { host_pipe_free(c->hpipe); c->hpipe = nullptr; }
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* kc_last_error(const kc_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+kc_status kc_device_info(const kc_ctx* c, int32_t* n_cu, int32_t* lds_per_cu, int32_t* clock_khz, char* name, size_t name_cap) {
+    if (!c) return KC_ERR_BAD_ARG;
+    if (n_cu) *n_cu = c->prop.multiProcessorCount;
+    if (lds_per_cu) *lds_per_cu = (int32_t)c->prop.maxSharedMemoryPerMultiProcessor;
+    if (clock_khz) *clock_khz = c->prop.clockRate;
+    if (name && name_cap) { strncpy(name, c->prop.gcnArchName, name_cap - 1); name[name_cap - 1] = 0; }
+    return KC_OK;
+}
+
+kc_status kc_last_timings(const kc_ctx* c, kc_timings* t) {
+    if (!c || !t) return KC_ERR_BAD_ARG;
+    *t = c->last;
+    return KC_OK;
+}
+
+}  // extern "C"
+

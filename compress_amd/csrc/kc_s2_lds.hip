@@ -6,7 +6,7 @@
 // cover the latency of its dependent table -> candidate chain and takes ~30 ms for one block.  Here the block's hash
 // table (2^14 x u32 = 64 KiB) AND, for blocks up to 64 KiB, the block itself live in the CU's LDS (128 KiB of its
 // 160 KiB), so a probe round is LDS-only: ~1 ms per 64 KiB block, whatever the number of blocks in flight.  The
-// dispatcher in kc_api.cpp picks the path by blocks in flight (measured crossover, profiles/r03_crossover_s2.csv).
+// dispatcher in kc_s2_api.cpp picks the path by blocks in flight (measured crossover, profiles/r03_crossover_s2.csv).
 //
 // Execution scheme: the 64 lanes evaluate the next W probe steps of the reference's scan (positions follow
 // nextS = s + (s-nextEmit)>>skip + 4 exactly, each lane iterating the recurrence up to its own step) against the

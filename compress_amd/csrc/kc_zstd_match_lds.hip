@@ -7,7 +7,7 @@
 // chain (~30 ms for one 128 KiB unit).  Here the unit's table (2^15 x u32 = 128 KiB of the CU's 160 KiB of LDS) is on
 // chip, so a table lookup is an LDS round trip and only candidate bytes come through L2: a few ms per unit, whatever
 // the number of units in flight — and a handful of rounds per block where the scan finds nothing (high-entropy input:
-// 64 probe steps per round instead of 8, and no table traffic to HBM at all).  The dispatcher in kc_api.cpp picks the
+// 64 probe steps per round instead of 8, and no table traffic to HBM at all).  The dispatcher in kc_batch.cpp picks the
 // path by units in flight (measured crossover, profiles/r03_crossover_zfast.csv).
 //
 // Scheme: the 64 lanes evaluate the next W probe steps of the scan (positions follow s += 2 + (s-nextEmit)>>5 exactly,

@@ -441,7 +441,7 @@ struct BlockEnc {  // zstd/blockenc.go:17
         if ((int64_t)output.size() - 3 - (int64_t)bhOffset >= (int64_t)size) {
             encodeRawTo(bhOffset, org, orgLen);
             // test diagnostics: a late raw fallback that really changes the carried offsets of a non-last block is what the device
-            // path's speculation re-run (kc_api.cpp batch_end) exists for; tests use the counter to know their inputs reach it
+            // path's speculation re-run (kc_batch.cpp batch_end) exists for; tests use the counter to know their inputs reach it
             if (!last && memcmp(recentOffsets, prevRecentOffsets, sizeof(recentOffsets)) != 0) lateRawPops()++;
             popOffsets();
             litEnc->Reuse = huff0::ReusePolicyNone;

@@ -1,4 +1,4 @@
-"""Inputs that reach the speculation re-run of the device path (kc_api.cpp batch_end).
+"""Inputs that reach the speculation re-run of the device path (kc_batch.cpp batch_end).
 
 A block whose sequences look worth coding (saved >= 16) but whose coded form ends no smaller than the block is re-emitted raw
 AFTER entropy coding and its repeat offsets are popped (zstd/blockenc.go:811-817).  The device match finder has by then parsed

@@ -147,7 +147,7 @@ int kcemu_xxh_fin(const uint8_t* src, const uint64_t* unit_off, uint32_t n, uint
 // The whole SpeedFastest EncodeAll pipeline of the device on the emulator: checksum kernel, match finder (LDS-table kernel, or with
 // use_grp = 1 the HBM-table group kernel in the form `tuned`; use_grp = 2 / 3 / 4: the SpeedDefault / SpeedBetterCompression /
 // SpeedBestCompression match finders), entropy stage — the frames as they sit in the staging slots (raw blocks'
-// payloads included: no rawdef), with the host's layout rules (seq_stride, lit_stride: kc_api.cpp batch_begin).
+// payloads included: no rawdef), with the host's layout rules (seq_stride, lit_stride: kc_batch.cpp batch_begin).
 int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, int block_size, int window, int crc, int single, int full_zero,
                       int stream_mode, int use_grp, int tuned, int entropy_opts /* bit 0: no_entropy, bit 1: all_lit_entropy */, uint8_t* stage, const uint64_t* stage_off, uint32_t* out_size, uint32_t* err_out,
                       uint8_t* fused_dst /* or null */, uint64_t* fused_off, int fused_mode) {
@@ -178,7 +178,7 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
         kc_launch_xxh64(src, unit_off, n, xxh.data(), nullptr);
         hipemu::set_group(64);
     }
-    // the no-match pre-scan in front of the match finder (tuned bit 8; kc_api.cpp batch_begin runs it on fused batches only)
+    // the no-match pre-scan in front of the match finder (tuned bit 8; kc_batch.cpp batch_begin runs it on fused batches only)
     const bool prescan = (tuned & 0x100) != 0 && fused_dst != nullptr && crc && use_grp <= 1;
     tuned &= 0xFF;
     std::vector<KcRawDef> rawdef;
@@ -240,7 +240,7 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     E.crc = crc; E.single = single; E.no_entropy = entropy_opts & 1; E.all_lit_entropy = ((entropy_opts >> 1) & 1) | (use_grp >= 3 && use_grp <= 4 ? 1 : 0) /* allLitEntropy: levels above SpeedDefault */; E.full_zero = full_zero; E.stream_mode = stream_mode;
     E.err_flag = err;
     if (prescan) E.unit_done = unit_done.data();
-    if (fused_dst != nullptr) {  // the layout of kc_api.cpp batch_end: raw payloads deferred, checksum behind the entropy stage
+    if (fused_dst != nullptr) {  // the layout of kc_batch.cpp batch_end: raw payloads deferred, checksum behind the entropy stage
         E.rawdef = rawdef.data();
         E.unit_raw = unit_raw.data();
         if (crc) E.xxh = nullptr;
