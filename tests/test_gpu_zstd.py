@@ -775,6 +775,30 @@ def test_fastest_epoch_stamped_tables_over_many_batches(oracle, kclib):
     enc.Close()
 
 
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_second_stage_on_a_stream_of_its_own(oracle, kclib, level):
+    """KC_OPT_STAGE2_STREAM: the entropy stage and everything behind it (size scan, checksum, compaction, the speculation re-run) on a
+    second stream behind an event of the match finder's — what a caller does who gives the two stages different CU masks
+    (tools/cu_mask_probe.py).  Same bytes as on one stream, over several batches, and the option can be taken back."""
+    torch = _torch()
+    from compress_amd import _lib
+    t = corpora.corpus("T", 24, 131072, first_unit=6).tobytes()
+    m = corpora.corpus("M", 24, 131072, first_unit=3).tobytes()
+    enc = _enc(level)
+    s2 = torch.cuda.Stream()
+    enc.ctx().set_option(_lib.OPT_STAGE2_STREAM, s2.cuda_stream)
+    assert enc.ctx().get_option(_lib.OPT_STAGE2_STREAM) == s2.cuda_stream
+    for k, (src, n, ln) in enumerate([(t, 24, 131072), (m, 17, 100000), (t, 5, 300000), (m, 24, 131072)]):
+        units = [src[(i * 7919 + k * 131) % (len(src) - ln):][:ln] for i in range(n)]
+        ubuf, off = corpora.pack_units(units)
+        if k == 3:
+            enc.ctx().set_option(_lib.OPT_STAGE2_STREAM, 0)
+        out, out_off = enc.EncodeUnits(ubuf, off)
+        ref, ref_off = oracle.zstd_encode_units(ubuf, off, threads=8, level=_li(level))
+        assert np.array_equal(out_off, ref_off) and np.array_equal(out, np.asarray(ref)), (k, n, ln)
+    enc.Close()
+
+
 @pytest.mark.parametrize("variant,xseg,filt", [(1, 0, 1), (1, 2, 1), (1, 1 << 20, 1), (1, 0, 0), (0, 0, 1)])
 def test_probe_rounds_across_skip_segments(oracle, kclib, variant, xseg, filt):
     """SpeedFastest, HBM-table kernel: a probe round follows the reference's position recurrence across skip-segment boundaries
