@@ -29,6 +29,9 @@
 #ifndef SEQ_CHUNK
 #define SEQ_CHUNK 1024    // sequences staged in LDS per FSE chain chunk
 #endif
+#ifndef KC_HCOPIES
+#define KC_HCOPIES 2   // 2: 19.19-19.26 vs 19.36-19.41 ms on one box, SQ_LDS_ADDR_CONFLICT 581 M -> 504 M per launch (profiles/r05_entropy_hist_copies.txt)
+#endif
 #ifndef KC_K2_WGS
 #define KC_K2_WGS 4
 #endif
@@ -135,7 +138,7 @@ struct HufState {  // huff0.Scratch fields that persist across the blocks of a u
 
 struct Shared {
     // --- literal histogram / huffman build ---
-    uint32_t whist[4][256];
+    uint32_t whist[4 * KC_HCOPIES][256];   // literal histogram copies: per wave, and per lane parity inside a wave when KC_HCOPIES is 2 (same-address LDS atomics serialise)
     uint32_t cnt[256];
     KcHufNodes nodes;
     KcHufTable cur;     // freshly built cTable
@@ -368,14 +371,9 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
     __shared__ uint32_t padLds[KC_K2_PAD / 4];  // occupancy experiment only
     if (P.block_size == -12345) padLds[threadIdx.x] = 1;
 #endif
-    // Thread roles are rotated by whole waves, per workgroup: the hardware starts every workgroup's wave 0 on the same SIMD of its CU, and
-    // this kernel's single-wave and single-lane phases (Huffman tree, table descriptions, mode choice, headers: "wave 0", "thread 0")
-    // would all queue on that one SIMD while the other three idle at barriers.  tid / wv below are the ROLE indices; lane is physical.
-#ifndef KC_K2_ROT
-#define KC_K2_ROT 1
-#endif
-    const int rot = KC_K2_ROT ? (int)(((uint32_t)blockIdx.x * 0x9E3779B1u) >> 30) : 0;
-    const int tid = ((int)threadIdx.x + (rot << 6)) & (ET - 1), lane = tid & 63, wv = tid >> 6;
+    // (Rotating the thread roles by whole waves per workgroup — every workgroup's "wave 0" with its single-wave phases on another SIMD —
+    // was measured in round 5 and changes nothing: profiles/r05_entropy_rotation.txt.)
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t u = P.unit_list ? P.unit_list[blockIdx.x] : P.unit_base + blockIdx.x;
     if (P.unit_done != nullptr && P.unit_done[u] != 0u) return;  // the pre-scan proved the unit free of matches and wrote its frame (kc_zstd_prescan.hip)
     const uint8_t* __restrict__ base = P.src + P.unit_off[u];
@@ -547,7 +545,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         PROF_MARK(0);
         // ==================== compressed block attempt ====================
         // ---------- 1. gather literals + histogram ----------
-        for (int i = tid; i < 4 * 256; i += ET) ((uint32_t*)S.whist)[i] = 0;
+        for (int i = tid; i < 4 * KC_HCOPIES * 256; i += ET) ((uint32_t*)S.whist)[i] = 0;
         if (!litsOnly) for (int i = tid; i < (int)((sizeof(S.codes) + sizeof(S.sbits)) / 16); i += ET) ((uint4*)&S.codes[0][0])[i] = make_uint4(0, 0, 0, 0);  // gather window
         if (!litsOnly) {  // the sequence histograms may be filled early, under the Huffman tree build (see 2.)
             for (int i = tid; i < 3 * 64; i += ET) ((uint32_t*)S.shist)[i] = 0;
@@ -555,7 +553,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         }
         __syncthreads();
         if (litsOnly) {
-            for (int k = tid; k < size; k += ET) atomicAdd(&S.whist[wv][org[k]], 1u);
+            for (int k = tid; k < size; k += ET) atomicAdd(&S.whist[wv * KC_HCOPIES + (lane & (KC_HCOPIES - 1))][org[k]], 1u);
         } else
         {
             // Literal gather = compaction of the literal runs of all sequences into `lits` (the match finder stores no literal
@@ -708,15 +706,16 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                     const uint32_t wEnd = endLo < winBase + TWC ? endLo : winBase + TWC;
                     const uint32_t nfull = (wEnd - winBase) >> 4;
                     const bool shared0 = hs != 0u && winBase == fw && nfull > 0u;  // word 0 holds bytes of the previous wave's quarter
-                    if (shared0 && (uint32_t)lane >= hs && lane < 16) { const uint8_t c = tw[lane]; lits[fw + lane] = c; atomicAdd(&S.whist[wv][c], 1u); }
+                    if (shared0 && (uint32_t)lane >= hs && lane < 16) { const uint8_t c = tw[lane]; lits[fw + lane] = c; atomicAdd(&S.whist[wv * KC_HCOPIES][c], 1u); }
                     for (uint32_t w = (shared0 ? 1u : 0u) + (uint32_t)lane; w < nfull; w += 64u) ((uint4*)(lits + winBase))[w] = ((const uint4*)tw)[w];
                     // literal histogram from the flushed words, four bytes per lane and step
                     for (uint32_t d = (shared0 ? 4u : 0u) + (uint32_t)lane; d < 4u * nfull; d += 64u) {
                         const uint32_t x = ((const uint32_t*)tw)[d];
-                        atomicAdd(&S.whist[wv][x & 0xFFu], 1u);
-                        atomicAdd(&S.whist[wv][(x >> 8) & 0xFFu], 1u);
-                        atomicAdd(&S.whist[wv][(x >> 16) & 0xFFu], 1u);
-                        atomicAdd(&S.whist[wv][x >> 24], 1u);
+                        uint32_t* const hc = S.whist[wv * KC_HCOPIES + (lane & (KC_HCOPIES - 1))];
+                        atomicAdd(&hc[x & 0xFFu], 1u);
+                        atomicAdd(&hc[(x >> 8) & 0xFFu], 1u);
+                        atomicAdd(&hc[(x >> 16) & 0xFFu], 1u);
+                        atomicAdd(&hc[x >> 24], 1u);
                     }
                     const uint32_t tail = (wEnd - winBase) & 15u;  // only the last window of a step has a tail
                     uint8_t carry = 0;
@@ -738,7 +737,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 const uint32_t total = (uint32_t)run;
                 const uint32_t rem = total & 15u;
                 const uint32_t lowT = ((total & ~15u) == fw) ? hs : 0u;
-                if ((uint32_t)lane >= lowT && (uint32_t)lane < rem) { const uint8_t c = tw[lane]; lits[(total & ~15u) + lane] = c; atomicAdd(&S.whist[wv][c], 1u); }
+                if ((uint32_t)lane >= lowT && (uint32_t)lane < rem) { const uint8_t c = tw[lane]; lits[(total & ~15u) + lane] = c; atomicAdd(&S.whist[wv * KC_HCOPIES][c], 1u); }
             }
             // trailing literals after the last sequence
             {
@@ -746,7 +745,7 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 for (uint32_t k = tid; k < len; k += ET) {
                     const uint8_t c = bsrc[spos + k];
                     lits[lo + k] = c;
-                    atomicAdd(&S.whist[wv][c], 1u);
+                    atomicAdd(&S.whist[wv * KC_HCOPIES][c], 1u);
                 }
             }
             PROF_FINE(6);
@@ -755,7 +754,9 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
         PROF_FINE(7);
         {
             // reduce histogram (huff0 countSimple, compress.go:351): maxCount, symbolLen
-            const uint32_t c = S.whist[0][tid] + S.whist[1][tid] + S.whist[2][tid] + S.whist[3][tid];
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < 4 * KC_HCOPIES; k++) c += S.whist[k][tid];
             S.cnt[tid] = c;
             const uint32_t wm = wave_reduce_max(c);
             const uint32_t wl = wave_reduce_max(c ? (uint32_t)tid + 1u : 0u);
