@@ -29,6 +29,9 @@
 #ifndef SEQ_CHUNK
 #define SEQ_CHUNK 1024    // sequences staged in LDS per FSE chain chunk
 #endif
+#ifndef KC_PACK_REUSE
+#define KC_PACK_REUSE 1   // the bit packing takes the chunk's sequences from the registers the code staging loaded them into (four per thread, kept across the chain phase) instead of loading them again: 18.83 -> 18.53 ms (profiles/r05_entropy_pack_reuse.txt)
+#endif
 #ifndef KC_HCOPIES
 #define KC_HCOPIES 2   // 2: 19.19-19.26 vs 19.36-19.41 ms on one box, SQ_LDS_ADDR_CONFLICT 581 M -> 504 M per launch (profiles/r05_entropy_hist_copies.txt)
 #endif
@@ -1136,9 +1139,9 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
             PROF_FINB0();
             // stage codes of sequences [loSeq, hiSeq), stored in stream order: element j <-> seq hiSeq-1-j; the positions up to the
             // end of the last 16-element segment repeat the last code (a valid symbol: their chain steps run and are ignored)
+            constexpr int R = SEQ_CHUNK / ET;  // all loads of the chunk are issued before the first code is computed
+            uint64_t sv[R];                     // (KC_PACK_REUSE: kept across the chain phase for the bit packing below)
             {
-                constexpr int R = SEQ_CHUNK / ET;  // all loads of the chunk are issued before the first code is computed
-                uint64_t sv[R];
                 const int cpad = jb + ((nrem + CH_SEG - 1) & ~(CH_SEG - 1));  // (up to SEQ_CHUNK + 1: the rows have the room)
 #pragma unroll
                 for (int r = 0; r < R; r++) { const int j = tid + r * ET; sv[r] = j < cn ? sq[hiSeq - 1 - j] : 0ull; }
@@ -1239,7 +1242,13 @@ __global__ __launch_bounds__(ET, KC_K2_WGS) void kc_zstd_entropy_kernel(KcEntrop
                 uint64_t fv0 = 0, fv1 = 0;  // up to 27 state bits, then up to 63 extra bits
                 int fb0 = 0, fb1 = 0;
                 if (j < cn) {
+#if KC_PACK_REUSE
+                    static_assert(R == 4, "the select below is written for four staged sequences per thread");
+                    const int rr = t0 / ET;
+                    const uint64_t s = rr == 0 ? sv[0] : (rr == 1 ? sv[1] : (rr == 2 ? sv[2] : sv[3]));
+#else
                     const uint64_t s = sq[hiSeq - 1 - j];
+#endif
                     const uint32_t cl = S.codes[0][slot0 + j], co = S.codes[1][slot0 + j], cm = S.codes[2][slot0 + j];
                     const int lb = E[0]->outBits[cl] & 31, ob = E[1]->outBits[co] & 31, mb = E[2]->outBits[cm] & 31;
                     const uint32_t ll = seq_ll(s), ml = seq_ml(s), of = seq_of(s);

@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${SESSION:-r5e}
 mkdir -p $OUT
 cd $R
+ulimit -c 0
 if [ -z "$NO_PYTEST" ]; then
 timeout 900 python -m pytest tests/test_gpu_zstd.py -x -q -m gpu -k "${PYTEST_K:-corpus_units or edge or stress or ragged or raw_only or rle_literal or long_units or randomized_options or parse_matches}" > $OUT/pytest_subset.log 2>&1; echo "pytest rc=$? $(tail -1 $OUT/pytest_subset.log)"
 fi
