@@ -337,6 +337,27 @@ def test_whole_pipeline_speed_default_and_better(level):
     assert not bad, bad[:8]
 
 
+@pytest.mark.parametrize("w0,grow", [(1, 1), (1, 2), (3, 1), (4, 0), (8, 0)])
+def test_speed_default_rounds_of_other_shapes(w0, grow, monkeypatch):
+    """The SpeedDefault match finder (round 5: LDS source ring, one 16-byte load per candidate with fused lengths, the s+1 lookup's
+    bytes from the winner's registers) under other speculation policies than the shipped one (2 then doubling): narrower and wider
+    rounds put the winner on other lanes, move the ring's refills and change which candidates are verified speculatively — the frames
+    must not change."""
+    monkeypatch.setenv("KC_EMU_SPEC_W0", str(w0))
+    monkeypatch.setenv("KC_EMU_SPEC_GROW", str(grow))
+    units = [corpora.corpus("T", 1, 131072, first_unit=5).tobytes(), corpora.corpus("M", 1, 131072, first_unit=2).tobytes()[:70001],
+             corpora.corpus("J", 1, 65536, first_unit=3).tobytes()[:40000], corpora.corpus("T", 2, 131072, first_unit=40).tobytes()[:150000]]
+    units += [u[:60000] for u in corpora.edge_units() if len(u) < 140000][:24]
+    units += [u[:100000] for u in corpora.stress_units(seed=11, n=4)]
+    ref = oracle_lib.ZstdOracle(level=2)
+    frames, err, redo = emu_lib.zstd_frames(units, level=2, max_encoded_size=ref.max_encoded_size)
+    assert err == 0
+    if redo:
+        pytest.skip("a unit of the set asks for the re-run at this level")
+    bad = [(i, len(u), len(f)) for i, (u, f) in enumerate(zip(units, frames)) if f != ref.encode_all(u)]
+    assert not bad, bad[:8]
+
+
 @pytest.mark.parametrize("finder", ["lds", "grp", "grp-tuned"])
 def test_whole_pipeline_frames_equal_the_oracle(finder):
     """The device's whole SpeedFastest EncodeAll pipeline on the wave emulator — XXH64 kernel, match finder (LDS-table kernel, or the

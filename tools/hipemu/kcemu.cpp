@@ -213,6 +213,8 @@ int kcemu_zstd_frames(const uint8_t* src, const uint64_t* unit_off, uint32_t n, 
     } else if (use_grp == 2) {  // SpeedDefault: kc_zdfast_match_grp_kernel, 8 lanes per unit
         tables.assign((size_t)((n + 7) / 8 * 8) * (kc_zdfast_table_bytes() / 4), 0);
         M.spec_w0 = 2; M.spec_grow = 2;
+        if (const char* e = getenv("KC_EMU_SPEC_W0")) M.spec_w0 = atoi(e);      // (tests: other speculation policies = other round shapes)
+        if (const char* e = getenv("KC_EMU_SPEC_GROW")) M.spec_grow = atoi(e);
         hipemu::set_group(8);
         kc_launch_zdfast_match_grp(M, tables.data(), n, nullptr);
         hipemu::set_group(64);
