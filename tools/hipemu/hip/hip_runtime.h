@@ -61,6 +61,7 @@ void pause();             // s_sleep: the lane gives way without a rendezvous (a
 #define __global__
 #define __device__
 #define __host__
+#define __constant__ static
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static
@@ -130,3 +131,9 @@ template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+
+// ---- the host API (hipMalloc, streams, events ...) as synchronous stand-ins: only for the whole-library build of
+// tools/emu_host_check.py (-DKC_HIPEMU_HOST); the kernel-level emulator tests do not see it ----
+#ifdef KC_HIPEMU_HOST
+#include "hip_host_emu.h"
+#endif
