@@ -13,7 +13,8 @@ The other configurations print the same JSON shape:
     C5   zstd SpeedBetterCompression with a 64 KiB raw dictionary on mixed text+binary 'M', 1 GiB per GPU (= 8 GiB over 8)
 A "step" is one pass of the whole hot path (checksum + match finder + entropy/emit + compaction) over the batch; for
 N > 1 each rank encodes its own shard (weak scaling) and the compressed frames are gathered to rank 0 over RCCL (the only
-exchange step of this path).  Prints ONE JSON line on rank 0.
+exchange step of this path; "gather_verified": rank 0's gathered stream checked against every rank's own frames by digest, after
+the timed region).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import hashlib
@@ -380,6 +381,33 @@ def main():
     out_bytes = int(out_off[n_units])
     value = world * in_bytes / (ms_per_step / 1000.0) / 1e6  # MB/s (1e6) of input, whole job
 
+    # ---- N > 1, outside the timed region: the gathered stream IS the ranks' frames in rank order.  Every rank digests the frames of
+    # its last step on its own GPU (two wrapping 64-bit sums, one position-weighted), the digests travel in one small all_gather,
+    # the last step's frames are gathered once more and rank 0 digests each segment of what arrived ----
+    gather_ok = None
+    if gather is not None:
+        try:
+            def digest(t):
+                n = t.numel()
+                pad = torch.zeros((n + 7) // 8 * 8, dtype=torch.uint8, device=t.device)
+                pad[:n].copy_(t)
+                v = pad.view(torch.int64)
+                w = torch.arange(v.numel(), dtype=torch.int64, device=t.device) * 2654435761 + 1
+                return [int(v.sum().item()), int((v * w).sum().item()), n]
+            mine = torch.tensor(digest(d_dst[:out_bytes]), dtype=torch.int64, device="cuda")
+            allv = torch.empty(3 * world, dtype=torch.int64, device="cuda")
+            dist.all_gather_into_tensor(allv, mine)
+            res = gather.start(d_dst, out_bytes).wait()
+            if rank == 0:
+                g_out, g_offs = res
+                want = allv.cpu().tolist()
+                gather_ok = g_offs[-1] == sum(want[2::3])
+                for r in range(world):
+                    gather_ok = gather_ok and digest(g_out[g_offs[r]:g_offs[r + 1]]) == want[3 * r:3 * r + 3]
+                gather_ok = bool(gather_ok)
+        except Exception as e:  # the timed result must still be reported
+            gather_ok = "error: " + repr(e)[:200]
+
     # ---- roofline of the dominant kernel, from HIP events on the launch stream (kc_last_timings) ----
     tm = ktimes[-1]
     k_match = float(np.median([t["match_ms"] for t in ktimes]))
@@ -589,6 +617,7 @@ def main():
             "end_to_end": e2e,
             "bit_exact_vs_oracle_on_sample": parity,
             "device_roundtrip_all_frames": verified,
+            "gather_verified": gather_ok,  # N > 1: rank 0's gathered stream == every rank's frames, by digest (null at N = 1 / --gather none)
             "device_roundtrip_ms": None if verify_ms is None else round(verify_ms, 1),
             "redo_units": tm["redo_units"],
             "host": {"gen_s": round(gen_s, 2), "nproc": os.cpu_count()},

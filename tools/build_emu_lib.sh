@@ -4,7 +4,8 @@
 # TEST INFRASTRUCTURE: see tools/emu_host_check.py.
 set -e
 cd "$(dirname "$0")/.."
-B=tools/_build/emu${ASAN:+_asan}
+T=${EMU_TAG:-emu}
+B=tools/_build/$T${ASAN:+_asan}
 mkdir -p $B
 FL="-O1 -g -std=c++17 -fPIC -x c++ -DKC_HIPEMU_HOST -I tools/hipemu -Wall -Wno-unused-function -Wno-unused-variable -Wno-unknown-pragmas ${ASAN:+-fsanitize=address -fno-omit-frame-pointer}"
 pids=()
@@ -12,6 +13,6 @@ for f in compress_amd/csrc/kc_*.cpp tools/hipemu/kcgpu_emu_kernels.cpp tools/hip
   g++ $FL -c $f -o $B/$(basename $f).o & pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-g++ -shared ${ASAN:+-fsanitize=address} -o $B/libkcgpu_emu.so $B/*.o -ldl -lpthread
-ln -sf ../$B/libkcgpu_emu.so compress_amd/libkcgpu_emu.so
-echo $B/libkcgpu_emu.so
+g++ -shared ${ASAN:+-fsanitize=address} -o $B/libkcgpu_$T.so $B/*.o -ldl -lpthread
+ln -sf ../$B/libkcgpu_$T.so compress_amd/libkcgpu_$T.so   # KC_LIB_TAG=$T loads it (EMU_TAG=emu2: a second build beside a running one)
+echo $B/libkcgpu_$T.so

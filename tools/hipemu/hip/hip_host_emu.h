@@ -94,8 +94,12 @@ static inline const char* hipGetErrorString(hipError_t e) {
     return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory" : e == hipErrorNotReady ? "not ready" : "hipemu error";
 }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+namespace hipemu {
+inline int device_count() { static int n = 0; if (!n) { const char* e = getenv("HIPEMU_DEVICES"); n = e ? atoi(e) : 1; if (n < 1) n = 1; } return n; }
+}  // namespace hipemu
+// (HIPEMU_DEVICES=N: N "devices" that are all this process's memory — one rank per device in tools/emu_bench_rank.py)
+static inline hipError_t hipGetDeviceCount(int* n) { *n = hipemu::device_count(); return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { return d >= 0 && d < hipemu::device_count() ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     memset(p, 0, sizeof(*p));
     strcpy(p->name, "hipemu");
