@@ -202,6 +202,11 @@ def self_launch(n):
 
 
 def main():
+    try:  # a faulting GPU process must not fill the box's disk with a core file of the resident batch
+        import resource
+        resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
+    except Exception:
+        pass
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
