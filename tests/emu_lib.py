@@ -24,9 +24,22 @@ def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", EMU, "-Wall", "-Wno-unused-function",
-           "-Wno-unused-variable", "-Wno-unknown-pragmas"] + srcs + ["-o", OUT, "-ldl"]
-    subprocess.check_call(cmd)
+    # several test processes (pytest -n) may get here at once: one builds, under a file lock, into a name of its own and renames
+    # the finished file into place; the others wait for the lock and find it up to date
+    import fcntl
+    with open(OUT + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
+            return OUT
+        tmp = "%s.%d.tmp" % (OUT, os.getpid())
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", EMU, "-Wall", "-Wno-unused-function",
+               "-Wno-unused-variable", "-Wno-unknown-pragmas"] + srcs + ["-o", tmp, "-ldl"]
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, OUT)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return OUT
 
 
