@@ -42,6 +42,7 @@ SYMBOLS = [
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts", "kc_zstd_encode_units_submit", "kc_s2_encode_blocks_lvl_submit", "kc_wait", "kc_zstd_plan_stream_blocks", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
     "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats", "kc_s2_encode_blocks_lvl", "kc_s2_encode_blocks_lvl_dev", "kc_s2_encode_stream_lvl_dev",
     "kc_last_timings", "kc_corpus_fill", "kc_ctx_set_option", "kc_ctx_get_option", "kc_zstd_encode_jobs", "kc_zstd_job_size", "kc_zstd_overlap_size",
+    "kc_probe_table_pattern", "kc_probe_pcie",
 ]
 
 # kc_option / KC_PATH_* (include/kcgpu.h)
@@ -52,6 +53,7 @@ OPT_K2_PROF, OPT_S2_HOOK_WAIT_US, OPT_S2_HOOK_BATCH, OPT_TEST_FEED_REDO, OPT_S2_
 OPT_JOB_PRIME = 30
 OPT_STAGE2_STREAM = 31
 OPT_HOST_CHUNK_MIB_APPEND = 32
+OPT_HOST_ROLL, OPT_HOST_ROLL_MIB = 33, 34
 _PATHS = {"auto": PATH_AUTO, "hbm": PATH_HBM, "lds": PATH_LDS, None: PATH_AUTO}
 
 _lib = None
@@ -163,6 +165,11 @@ def load():
     L.kc_ctx_get_option.restype = C.c_int64
     L.kc_corpus_fill.argtypes = [C.c_int, u64, u64, C.c_uint32, C.c_uint32, vp, C.c_int]
     L.kc_corpus_fill.restype = C.c_int
+    if hasattr(L, "kc_probe_pcie"):  # (the wave-emulator build of the library, tools/build_emu_lib.sh, leaves the device probes out)
+        L.kc_probe_table_pattern.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+        L.kc_probe_table_pattern.restype = C.c_int
+        L.kc_probe_pcie.argtypes = [vp, u64, C.POINTER(C.c_double)]
+        L.kc_probe_pcie.restype = C.c_int
     _lib = L
     return L
 
@@ -185,7 +192,7 @@ class Context:
                  ("KC_LDS_SPEC_W0", 6), ("KC_S2_LDS_SPEC_W0", 17), ("KC_HOST_PIPE_MIB", 8), ("KC_HOST_OVERLAP_MIN_MIB", 9),
                  ("KC_HOST_COPY_THREADS", 10), ("KC_S2_HOOK_WAIT_US", 14), ("KC_S2_HOOK_BATCH", 15), ("KC_S2_HOOK_LANES", 29),
                  ("KC_ZFAST_EPOCH", 22), ("KC_ZFAST_XSEG_K", 23), ("KC_FUSE_RAW_XXH", 24), ("KC_ZFAST_FILTER", 25), ("KC_XXH_FIN_MODE", 26),
-                 ("KC_ZFAST_VARIANT", 27), ("KC_ZFAST_PRESCAN", 28), ("KC_JOB_PRIME", 30))
+                 ("KC_ZFAST_VARIANT", 27), ("KC_ZFAST_PRESCAN", 28), ("KC_JOB_PRIME", 30), ("KC_HOST_ROLL", 33), ("KC_HOST_ROLL_MIB", 34))
     _ENV_FLAGS = (("KC_HOST_SERIAL", 7), ("KC_HOST_TRACE", 11), ("KC_K2_PROF", 13))  # set by their presence
 
     def _apply_env(self):
@@ -237,6 +244,19 @@ class Context:
         name = C.create_string_buffer(128)
         self.check(self.L.kc_device_info(self.h, C.byref(ncu), C.byref(lds), C.byref(clk), name, 128))
         return {"n_cu": ncu.value, "lds_per_cu": lds.value, "clock_khz": clk.value, "arch": name.value.decode()}
+
+    def probe_table_pattern(self, n_tables=32768, table_bytes=131072, waves=4096, iters=512):
+        """kc_probe_table_pattern: requests per second of the match finders' table traffic on this device."""
+        out = (C.c_double * 3)()
+        self.check(self.L.kc_probe_table_pattern(self.h, n_tables, table_bytes, waves, iters, out))
+        return {"pairs_per_s": out[0], "reads_per_s": out[1], "stores_per_s": out[2]}
+
+    def probe_pcie(self, nbytes=1 << 30):
+        """kc_probe_pcie: pinned H2D / D2H GB/s (alone, both at once) and the pageable <-> pinned host copy rates."""
+        out = (C.c_double * 7)()
+        self.check(self.L.kc_probe_pcie(self.h, nbytes, out))
+        return {"h2d_GBps": out[0], "d2h_GBps": out[1], "h2d_bidir_GBps": out[2], "d2h_bidir_GBps": out[3],
+                "host_copy_in_GBps": out[4], "host_copy_out_GBps": out[5], "copy_threads": int(out[6])}
 
     def timings(self):
         t = Timings()

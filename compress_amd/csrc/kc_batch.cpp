@@ -165,6 +165,7 @@ bool better_epoch_mode(const kc_ctx* c, int level, int pos_bits, int hist0) {
 
 kc_status prepare_tables(kc_ctx* c, const KcMatchParams& mp, uint32_t n_launch, hipStream_t st, int level) {
     if (level == KC_SPEED_BEST) return ensure_best_slots(c, n_launch, st);
+    { const kc_status sc = tables_claim(c, st); if (sc != KC_OK) return sc; }
     c->better_epoch_now = 0;
     if (better_epoch_mode(c, level, mp.pos_bits, mp.hist0)) {
         const size_t tbb = match_table_bytes(level);

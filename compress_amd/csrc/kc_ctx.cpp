@@ -127,6 +127,8 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_HOST_OVERLAP_MIN_MIB: g.host_overlap_min_mib = v; break;
         case KC_OPT_HOST_COPY_THREADS: g.host_copy_threads = v; break;
         case KC_OPT_HOST_TRACE: g.host_trace = v; break;
+        case KC_OPT_HOST_ROLL: g.host_roll = v != 0; break;
+        case KC_OPT_HOST_ROLL_MIB: if (v < 0) return KC_ERR_BAD_ARG; g.host_roll_mib = v; break;
         case KC_OPT_HOST_CHUNK_MIB: g.host_chunks.clear(); if (v > 0) g.host_chunks.push_back((uint64_t)v << 20); break;
         case KC_OPT_HOST_CHUNK_MIB_APPEND: if (v < 1) return KC_ERR_BAD_ARG; g.host_chunks.push_back((uint64_t)v << 20); break;
         case KC_OPT_K2_PROF: g.k2_prof = v; break;
@@ -168,6 +170,8 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_HOST_OVERLAP_MIN_MIB: return g.host_overlap_min_mib;
         case KC_OPT_HOST_COPY_THREADS: return g.host_copy_threads;
         case KC_OPT_HOST_TRACE: return g.host_trace;
+        case KC_OPT_HOST_ROLL: return g.host_roll;
+        case KC_OPT_HOST_ROLL_MIB: return g.host_roll_mib;
         case KC_OPT_HOST_CHUNK_MIB: return g.host_chunks.empty() ? 0 : (int64_t)(g.host_chunks[0] >> 20);
         case KC_OPT_K2_PROF: return g.k2_prof;
         case KC_OPT_S2_HOOK_WAIT_US: return g.hook_wait_us;
@@ -205,6 +209,7 @@ void kc_ctx_destroy(kc_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    if (c->ev_preclear) (void)hipEventDestroy(c->ev_preclear);
     if (c->pend) { delete (Pending*)c->pend; c->pend = nullptr; }
     if (c->hook) { s2_hook_free(c->hook); c->hook = nullptr; }
     if (c->hpipe) { host_pipe_free(c->hpipe); c->hpipe = nullptr; }

@@ -97,6 +97,8 @@ struct KcCfg {
     int64_t lds_spec_w0 = 16;             // SpeedFastest LDS-table kernel: probe steps per round after a match (doubles on a miss up to 64); 0 = units up to 128 KiB without history through the instantiation with the source in a 64 KiB LDS ring (untagged 17-bit table): same time on text
     int64_t s2_lds_spec_w0 = 0;           // S2 LDS-table kernel: the same; blocks held in LDS: 0 = the fused wave-uniform step (two LDS round trips per step), 1 = its first form
     int64_t host_serial = 0, host_pipe_mib = 0, host_overlap_min_mib = -1, host_copy_threads = 0, host_trace = 0;
+    int64_t host_roll = 1;                // large host-buffer calls go through the device's rolling pipeline (kc_roll.cpp); 0: round 5's one-batch chunk-fed path
+    int64_t host_roll_mib = 0;            // rolling pipeline: sub-batch size (0: a quarter of the call's input, 64 MiB .. 1 GiB)
     std::vector<uint64_t> host_chunks;    // chunk-fed host path: chunk sizes in bytes (empty: a quarter of the batch each)
     int64_t k2_prof = 0;
     int64_t hook_wait_us = 0, hook_batch = 256, hook_lanes = 4;
@@ -119,6 +121,14 @@ struct kc_ctx {
     KcCfg cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    // lanes of the rolling host pipeline (kc_roll.cpp) only: the S2 HBM-table path zeroes the table arena for the NEXT batch on
+    // stream2 as soon as this batch's encoder is done with it (behind ev[1]) - under the partner lane's encoder instead of 4 ms in
+    // front of its own (the arena is 64 KiB per block whatever the block holds).  preclear_bytes of tables.p are then zero once
+    // ev_preclear has fired; every other user of the arena waits for the event and drops the claim (tables_claim).
+    bool lane_preclear = false;
+    hipEvent_t ev_preclear = nullptr;
+    void* preclear_ptr = nullptr;
+    size_t preclear_bytes = 0;
     hipStream_t stream2 = nullptr;   // KC_OPT_STAGE2_STREAM: device-resident zstd batches run the entropy stage and everything behind it here (null: on `stream`)
     bool own_stream = false;
     std::string err;
@@ -218,6 +228,15 @@ inline kc_status ensure(kc_ctx* c, DevBuf& b, size_t bytes) {
     return KC_OK;
 }
 
+// Before anything but the S2 pre-clear's owner touches c->tables on stream st: wait for a pending pre-clear, forget it.
+inline kc_status tables_claim(kc_ctx* c, hipStream_t st) {
+    if (c->preclear_bytes != 0) {
+        c->preclear_bytes = 0;
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_preclear, 0));
+    }
+    return KC_OK;
+}
+
 inline int bitsLen32(uint32_t v) { return v == 0 ? 0 : 32 - __builtin_clz(v); }
 
 void s2_hook_free(void* h);  // S2Hook (kc_s2_encode_block's micro-batcher), defined with it
@@ -242,4 +261,11 @@ kc_status feed_finish(kc_ctx* c, bool* redo_needed);
 kc_status run_batch(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_base, const uint64_t* unit_off, uint32_t n_units,
                     uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off_host, uint64_t* produced);
 kc_status validate_units(kc_ctx* c, const kc_zstd_opts* o, const uint64_t* unit_off, uint32_t n_units);
+// kc_roll.cpp: the rolling host pipeline (one engine per device).  enc runs one sub-batch on a lane context of the engine's
+// (synchronous, device pointers, offsets relative to the sub-batch); max_out bounds one unit's output.  KC_ERR_UNSUPPORTED with an
+// empty error text: no engine on this device - the caller's older paths serve the call.
+typedef std::function<kc_status(kc_ctx* lane, const uint8_t* d_in, const uint64_t* rel_off, uint32_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_off_rel)> RollEncFn;
+kc_status host_rolling(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint8_t* dst, uint64_t dst_cap,
+                       uint64_t* out_off, const RollEncFn& enc, const std::function<uint64_t(uint64_t)>& max_out);
+uint64_t host_roll_sub_bytes(const kc_ctx* c, uint64_t total);
 }  // namespace kci

@@ -340,37 +340,42 @@ void kc_launch_clear(const KcClearList& L, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------
-// exclusive scan of per-unit sizes -> output offsets (single workgroup; n is at most a few 1e5)
+// exclusive scan of per-unit sizes -> output offsets.  ONE wave (round 6; before: one workgroup of 16 waves): n is at most a few
+// 1e5, and a 16-wave workgroup needs 16 free wave slots on ONE CU — beside other streams' long-running one-wave workgroups (the
+// rolling host pipeline: three other lanes' match finders / S2 encoders fill every slot that frees up) it waited 5-25 ms for a
+// 50 us job (gpurun_out/r6d/timeline_C4.txt).  A single wave fits any slot.  Eight sizes per lane and step.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void kc_scan_sizes_kernel(const uint32_t* __restrict__ sizes, uint32_t n, uint64_t* __restrict__ out_off) {
-    __shared__ uint64_t wsum[16];
-    __shared__ uint64_t carry;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + tid;
-        uint64_t v = i < n ? sizes[i] : 0;
-        uint64_t inc = v;
+__global__ __launch_bounds__(64) void kc_scan_sizes_kernel(const uint32_t* __restrict__ sizes, uint32_t n, uint64_t* __restrict__ out_off) {
+    const int lane = threadIdx.x & 63;
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 512) {
+        const uint32_t i0 = base + (uint32_t)lane * 8u;
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = i0 + k < n ? sizes[i0 + k] : 0u;
+        uint64_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) mine += v[k];
+        uint64_t inc = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d, 64);
-            uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d, 64);
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d, 64);
+            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d, 64);
             if (lane >= d) inc += ((uint64_t)hi << 32) | lo;
         }
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        uint64_t pre = carry;
-        for (int k = 0; k < w; k++) pre += wsum[k];
-        if (i < n) out_off[i] = pre + inc - v;
-        __syncthreads();
-        if (tid == 1023) carry = pre + inc;
-        __syncthreads();
+        uint64_t run = carry + inc - mine;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (i0 + k < n) out_off[i0 + k] = run;
+            run += v[k];
+        }
+        const uint32_t tlo = (uint32_t)__shfl((int)(uint32_t)inc, 63, 64), thi = (uint32_t)__shfl((int)(uint32_t)(inc >> 32), 63, 64);
+        carry += ((uint64_t)thi << 32) | tlo;
     }
-    if (tid == 0) out_off[n] = carry;
+    if (lane == 0) out_off[n] = carry;
 }
 void kc_launch_scan_sizes(const uint32_t* sizes, uint32_t n, uint64_t* out_off, hipStream_t st) {
-    hipLaunchKernelGGL(kc_scan_sizes_kernel, dim3(1), dim3(1024), 0, st, sizes, n, out_off);
+    hipLaunchKernelGGL(kc_scan_sizes_kernel, dim3(1), dim3(64), 0, st, sizes, n, out_off);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -86,7 +86,18 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     HIPCHK(c, hipMemcpyAsync(c->stage_off.p, so.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     c->up_ptr[0] = c->up_ptr[1] = c->up_ptr[2] = nullptr;  // (the zstd batch path re-uploads its layout arrays)
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    if (!lds) { c->tab_owner = 0; HIPCHK(c, hipMemsetAsync(c->tables.p, 0, (size_t)n * kc_s2_table_bytes(level, maxLen, s2var), st)); }
+    const size_t tab_bytes = lds ? 0 : (size_t)n * kc_s2_table_bytes(level, maxLen, s2var);
+    if (!lds) {
+        c->tab_owner = 0;
+        if (c->preclear_bytes >= tab_bytes && c->preclear_ptr == c->tables.p) {  // zeroed behind the previous batch's encoder (below)
+            c->preclear_bytes = 0;
+            HIPCHK(c, hipStreamWaitEvent(st, c->ev_preclear, 0));
+        } else {
+            kc_status sc = tables_claim(c, st);
+            if (sc != KC_OK) return sc;
+            HIPCHK(c, hipMemsetAsync(c->tables.p, 0, tab_bytes, st));
+        }
+    }
     KcS2Params P;
     P.src = d_src + blk_off[0];
     P.blk_off = (const uint64_t*)c->unit_off.p;
@@ -143,6 +154,14 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
         kc_launch_s2_encode(P, st);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], st));
+    if (!lds && c->lane_preclear && c->stream2 != nullptr && level < KC_S2_LEVEL_BEST) {  // the arena for the next batch of this lane (kc_host.h)
+        if (c->ev_preclear == nullptr) HIPCHK(c, hipEventCreateWithFlags(&c->ev_preclear, hipEventDisableTiming));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[1], 0));
+        HIPCHK(c, hipMemsetAsync(c->tables.p, 0, tab_bytes, c->stream2));
+        HIPCHK(c, hipEventRecord(c->ev_preclear, c->stream2));
+        c->preclear_ptr = c->tables.p;
+        c->preclear_bytes = tab_bytes;
+    }
     kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n, (uint64_t*)c->out_off.p, st);
     kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p, (const uint32_t*)c->out_size.p,
                       (const uint64_t*)c->out_off.p, d_dst + lead, n, st);
@@ -341,6 +360,14 @@ kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, cons
     }
     const uint64_t total = blk_off[n] - blk_off[0];
     const uint64_t ov_min = c->cfg.host_overlap_min_mib >= 0 ? (uint64_t)c->cfg.host_overlap_min_mib << 20 : (uint64_t)512 << 20;
+    if (total >= ov_min && !c->cfg.host_serial && c->cfg.host_pipe_mib < 16 && level < KC_S2_LEVEL_BEST && c->cfg.host_roll) {
+        RollEncFn enc = [level](kc_ctx* lane, const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
+            return kc_s2_encode_blocks_lvl_dev(lane, level, d_in, rel, nu, d_out, cap, oo);
+        };
+        auto mx = [](uint64_t len) { return (uint64_t)kc_s2_max_encoded_len((int64_t)len); };
+        const kc_status rs = host_rolling(c, src, blk_off, n, dst, dst_cap, out_off, enc, mx);
+        if (rs != KC_ERR_UNSUPPORTED || !c->err.empty()) return rs;  // UNSUPPORTED with no message: no engine on this device
+    }
     if (total >= ov_min && total <= c->max_batch_bytes && !c->cfg.host_serial && c->cfg.host_pipe_mib < 16 && level < KC_S2_LEVEL_BEST) {  // (the best levels: 4.5 MiB of tables per block, several device batches)
         uint64_t need = 0;
         for (uint32_t i = 0; i < n; i++) need += ((uint64_t)kc_s2_max_encoded_len((int64_t)(blk_off[i + 1] - blk_off[i])) + 15) & ~(uint64_t)15;

@@ -15,6 +15,17 @@ kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* 
     if ((s = validate_units(c, o, unit_off, n_units)) != KC_OK) return s;
     const uint64_t total = unit_off[n_units] - unit_off[0];
     const uint64_t ov_min = c->cfg.host_overlap_min_mib >= 0 ? (uint64_t)c->cfg.host_overlap_min_mib << 20 : (uint64_t)1 << 30;
+    if (total >= ov_min && !c->cfg.host_serial && c->cfg.host_pipe_mib < 16 && c->cuts == nullptr && c->cfg.host_roll && c->job_hist == nullptr &&
+        o->level != KC_SPEED_BEST) {  // (the best level: 34 MiB of persistent table slots per unit and context - not on four lanes at once)
+        const kc_zstd_opts oc = *o;
+        const int sm = c->stream_mode;
+        RollEncFn enc = [oc, sm](kc_ctx* lane, const uint8_t* d_in, const uint64_t* rel, uint32_t nu, uint8_t* d_out, uint64_t cap, uint64_t* oo) {
+            return sm ? kc_zstd_encode_streams_dev(lane, &oc, d_in, rel, nu, d_out, cap, oo) : kc_zstd_encode_units_dev(lane, &oc, d_in, rel, nu, d_out, cap, oo);
+        };
+        auto mx = [oc](uint64_t len) { return (uint64_t)kc_zstd_max_encoded_size(&oc, (int64_t)len); };
+        s = host_rolling(c, src, unit_off, n_units, dst, dst_cap, out_off, enc, mx);
+        if (s != KC_ERR_UNSUPPORTED || !c->err.empty()) return s;  // UNSUPPORTED with no message: no engine on this device
+    }
     if (total >= ov_min && !c->cfg.host_serial && c->cfg.host_pipe_mib < 16 && c->cuts == nullptr) {
         s = host_overlapped_zstd(c, o, src, unit_off, n_units, dst, dst_cap, out_off);
         if (s != KC_ERR_UNSUPPORTED || !c->err.empty()) return s;  // UNSUPPORTED with no message: shape not served by the one-batch path

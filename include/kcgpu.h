@@ -178,6 +178,8 @@ typedef enum {
     KC_OPT_JOB_PRIME = 30,           /* KC_JOB_PRIME              kc_zstd_encode_jobs: where a job's tables are primed from its overlap prefix (ResetPrefix): 1 (default) on the device (kc_zstd_prime.hip), 0 on the host, uploaded per batch */
     KC_OPT_HOST_CHUNK_MIB_APPEND = 32, /* KC_HOST_CHUNKS_MIB (list) one more chunk size behind KC_OPT_HOST_CHUNK_MIB's: an uneven chunk schedule (the last size repeats) */
     KC_OPT_STAGE2_STREAM = 31,       /* (no variable)             a hipStream_t handle (0: none): kc_zstd_encode_units_dev[_begin/_end] run the entropy stage and everything behind it on this stream, behind an event of the match finder's — for callers that give the two stages different CU masks (hipExtStreamCreateWithCUMask) */
+    KC_OPT_HOST_ROLL = 33,           /* KC_HOST_ROLL              host-buffer entry points, large inputs: 1 (default) = the device's rolling pipeline (sub-batches of all calls in flight staged, encoded on four lanes and drained in arrival order: consecutive calls overlap), 0 = one chunk-fed device batch per call (round 5) */
+    KC_OPT_HOST_ROLL_MIB = 34,       /* KC_HOST_ROLL_MIB          rolling pipeline: sub-batch size (0: a quarter of the call's input, 64 MiB .. 1 GiB) */
     KC_OPT_LAST_PRESCAN_UNITS = 102, /* read-only: units of the last batch the pre-scan settled */
     KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
     KC_OPT_LAST_BATCHES = 101        /* read-only: device batches the last kc_zstd_encode_units_dev / kc_s2_encode_*_dev call was cut into */
@@ -332,6 +334,18 @@ typedef struct {
     float prep_ms;    /* part of match_ms: zeroing / dictionary-priming of the per-unit hash tables before the match finder */
 } kc_timings;
 kc_status kc_last_timings(const kc_ctx* ctx, kc_timings* t);
+
+/* ---- probes (measurement only; nothing on the encode path calls them) ----
+ * kc_probe_table_pattern: the match finders' hash-table traffic on THIS device — scattered 4-byte accesses into n_tables tables of
+ * table_bytes each (8 lanes per table, 8 tables per wave, two independent accesses per lane per iteration: the two buckets a
+ * fastEncoder step looks up and overwrites, zstd/enc_fast.go:147-207).  out3[0] = read + write-back pairs per second, out3[1] = plain
+ * reads per second, out3[2] = plain stores per second (each counts one request per access).  bench.py prices the match finder's
+ * measured transactions per unit at these rates (roofline.floor).  Allocates and frees n_tables * table_bytes of device memory.
+ * kc_probe_pcie: one pinned copy of `bytes` each way.  out7[0] H2D GB/s, [1] D2H GB/s, [2] / [3] H2D / D2H GB/s with both in flight,
+ * [4] pageable -> pinned host copy GB/s with the context's copy threads (KC_OPT_HOST_COPY_THREADS), [5] pinned -> pageable, [6] the
+ * thread count: the ceilings of the host-buffer entry points (bench.py end_to_end.pcie_ceiling). */
+kc_status kc_probe_table_pattern(kc_ctx* ctx, uint32_t n_tables, uint32_t table_bytes, uint32_t waves, uint32_t iters, double* out3);
+kc_status kc_probe_pcie(kc_ctx* ctx, uint64_t bytes, double* out7);
 
 /* ---- synthetic corpora: deterministic, per-unit seeded, host-side generator ----
  * kind: 'T' enwik-style text, 'H' high-entropy, 'J' JSON records, 'M' mixed.  Fills

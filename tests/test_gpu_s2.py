@@ -560,6 +560,7 @@ def test_s2_host_chunk_fed_equals_oracle(oracle, kclib, level, monkeypatch):
     empty and large blocks across the chunk boundaries."""
     from compress_amd import s2
     monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_ROLL", "0")  # (round 6: large calls take the rolling pipeline; this test keeps the chunk-fed path covered)
     monkeypatch.setenv("KC_HOST_CHUNKS_MIB", "1,2,4")
     blocks = corpora.stress_units(seed=31 + level, n=160)
     j = corpora.corpus("J", 96, 65536).tobytes()
@@ -579,6 +580,31 @@ def test_s2_host_chunk_fed_equals_oracle(oracle, kclib, level, monkeypatch):
     enc._ctx.set_option(_lib.OPT_HOST_SERIAL, 1)
     out3, out_off3 = enc.EncodeBlocks(buf, off)
     assert np.array_equal(out3, out) and np.array_equal(out_off3, out_off)
+    enc.Close()
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_s2_host_rolling_pipeline_equals_oracle(oracle, kclib, level, monkeypatch):
+    """Round 6: kc_s2_encode_blocks_lvl on a large host buffer goes through the device's rolling pipeline (kc_roll.cpp).  Same bytes
+    as the oracle's and as the serial host path's, ragged / empty / large blocks across the sub-batch boundaries."""
+    from compress_amd import s2, _lib
+    monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_ROLL_MIB", "2")
+    blocks = corpora.stress_units(seed=131 + level, n=160)
+    j = corpora.corpus("J", 96, 65536).tobytes()
+    blocks += [j[i * 65536:(i + 1) * 65536] for i in range(96)]
+    blocks[7] = b""
+    blocks.append(j[:1 << 20])
+    blocks.append(b"x")
+    buf, off = corpora.pack_units(blocks)
+    enc = s2.BlockEncoder(level=level)
+    out, out_off = enc.EncodeBlocks(buf, off)
+    assert enc._ctx.get_option(_lib.OPT_LAST_BATCHES) >= 4
+    ref, ref_off = oracle.s2_encode_blocks(buf, off, threads=8, better=level in (1, 3), snappy=level in (2, 3))
+    assert np.array_equal(out_off, np.asarray(ref_off))
+    assert np.array_equal(out, np.asarray(ref))
+    out2, out_off2 = enc.EncodeBlocks(buf, off)
+    assert np.array_equal(out2, out) and np.array_equal(out_off2, out_off)
     enc.Close()
 
 

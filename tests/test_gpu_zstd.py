@@ -652,6 +652,7 @@ def test_host_chunk_fed_batch_equals_device_path(oracle, kclib, level, monkeypat
     as the device-resident path (chunk boundaries fall inside the ragged part; empty and tiny units included)."""
     torch = _torch()
     monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_ROLL", "0")  # (round 6: large calls take the rolling pipeline; this test keeps the one-batch chunk-fed path covered)
     monkeypatch.setenv("KC_HOST_CHUNKS_MIB", "1,3,8,16")
     n, usz = 512, 131072
     buf = corpora.corpus("T", n, usz)
@@ -899,6 +900,7 @@ def test_submit_wait_two_contexts_overlap(oracle, kclib, monkeypatch):
     _torch()
     from compress_amd import zstd, _lib
     monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_ROLL", "0")
     monkeypatch.setenv("KC_HOST_CHUNKS_MIB", "2")
     n, usz = 128, 131072
     batches = [corpora.corpus("TMJ"[k % 3], n, usz, first_unit=1000 * k) for k in range(6)]
@@ -919,6 +921,90 @@ def test_submit_wait_two_contexts_overlap(oracle, kclib, monkeypatch):
     with pytest.raises(_lib.KcError):
         ctx = encs[0].ctx()
         ctx.check(ctx.L.kc_wait(ctx.h))
+    for e in encs + [sync]:
+        e.Close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_host_rolling_pipeline_equals_device_path(oracle, kclib, level, monkeypatch):
+    """Round 6: kc_zstd_encode_units on a large input goes through the device's rolling pipeline (kc_roll.cpp): sub-batches staged,
+    encoded on the engine's four lanes and drained in arrival order.  Same bytes and offsets as the device-resident path (sub-batch
+    boundaries inside the ragged part, empty and tiny units, raw blocks), again on a second call, with a raw dictionary, and with a
+    destination that is too small (refused, no crash, the engine serves the next call)."""
+    torch = _torch()
+    from compress_amd import _lib, zstd
+    monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_ROLL_MIB", "5")  # 5 MiB sub-batches: ~11 of them in flight through 6 slots / 4 lanes
+    n, usz = 448, 131072
+    buf = corpora.corpus("T", n, usz)
+    buf[5 * usz:9 * usz] = corpora.corpus("H", 4, usz)
+    buf[40 * usz:56 * usz] = corpora.corpus("M", 16, usz)
+    sizes = np.full(n, usz, dtype=np.uint64)
+    sizes[::7] = 100000
+    sizes[3] = 0
+    sizes[11] = 5
+    sizes[n - 1] = 17
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)
+    buf = buf[:int(off[n])]
+    enc = _enc(level)
+    out, out_off = enc.EncodeUnits(buf, off)
+    assert enc.ctx().get_option(_lib.OPT_LAST_BATCHES) >= 8  # the call really was cut into sub-batches
+    d_src = torch.from_numpy(buf).cuda()
+    cap = sum(((enc.MaxEncodedSize(int(x)) + 15) & ~15) for x in sizes) + 64
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    dev_off = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    assert np.array_equal(out_off, dev_off)
+    assert np.array_equal(out, d_dst[:int(dev_off[n])].cpu().numpy())
+    ref, ref_off = oracle.zstd_encode_units(buf[:int(off[64])], off[:65], threads=8, level=_li(level))
+    assert np.array_equal(out[:int(out_off[64])], ref) and np.array_equal(out_off[:65], ref_off)
+    out3, out_off3 = enc.EncodeUnits(buf, off)  # slots, lanes and rings reused
+    assert np.array_equal(out3, out) and np.array_equal(out_off3, out_off)
+    # a destination one byte short: KC_ERR_DST_TOO_SMALL from the drainer, and the engine is fine afterwards
+    ctx = enc.ctx()
+    import ctypes as C
+    small = np.zeros(int(out_off[n]) - 1, dtype=np.uint8)
+    eo = np.zeros(n + 1, dtype=np.uint64)
+    st = ctx.L.kc_zstd_encode_units(ctx.h, C.byref(enc.o), buf.ctypes.data, off.ctypes.data, n, small.ctypes.data, small.size, eo.ctypes.data)
+    assert st == _lib.KC_ERR_DST_TOO_SMALL
+    out4, out_off4 = enc.EncodeUnits(buf, off)
+    assert np.array_equal(out4, out) and np.array_equal(out_off4, out_off)
+    enc.Close()
+    # with a raw dictionary (every lane stages the dictionary itself)
+    d = corpora.corpus("T", 1, 65536, first_unit=77).tobytes()
+    encd = zstd.NewWriter(None, *_lo(level), zstd.WithEncoderDictRaw(1, d))
+    outd, outd_off = encd.EncodeUnits(buf, off)
+    refd, refd_off = oracle.zstd_encode_units(buf[:int(off[48])], off[:49], threads=8, level=_li(level), dict_id=1, dict_content=d)
+    assert np.array_equal(outd[:int(outd_off[48])], refd) and np.array_equal(outd_off[:49], refd_off)
+    dd_off = encd.EncodeUnitsDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    assert np.array_equal(outd_off, dd_off) and np.array_equal(outd, d_dst[:int(dd_off[n])].cpu().numpy())
+    encd.Close()
+
+
+def test_host_rolling_pipeline_two_callers(oracle, kclib, monkeypatch):
+    """Two contexts keep calls in flight through submit / wait: their sub-batches interleave in the ONE engine of the device (arrival
+    order), every call gets its own frames back."""
+    _torch()
+    from compress_amd import _lib
+    monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_ROLL_MIB", "3")
+    n, usz = 128, 131072
+    batches = [corpora.corpus("TMJ"[k % 3], n, usz, first_unit=1000 * k) for k in range(6)]
+    off = np.arange(n + 1, dtype=np.uint64) * usz
+    sync = _enc(1)
+    sync.ctx().set_option(_lib.OPT_HOST_SERIAL, 1)
+    want = [sync.EncodeUnits(b, off) for b in batches]
+    encs = [_enc(1), _enc(2)]
+    want2 = [encs[1].EncodeUnits(b, off) for b in batches]
+    got = [None] * 6
+    encs[0].EncodeUnitsSubmit(batches[0], off)
+    for k in range(1, 7):
+        if k < 6:
+            encs[k & 1].EncodeUnitsSubmit(batches[k], off)
+        got[k - 1] = encs[(k - 1) & 1].Wait()
+    for k in range(6):
+        w = want[k] if (k & 1) == 0 else want2[k]
+        assert np.array_equal(got[k][1], w[1]) and np.array_equal(got[k][0], w[0]), k
     for e in encs + [sync]:
         e.Close()
 
