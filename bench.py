@@ -215,6 +215,7 @@ def main():
     ap.add_argument("--gib", type=float, default=None, help="input GiB per GPU (default: the configuration's)")
     ap.add_argument("--kind", default=None, help="corpus override (T|H|J|M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-floor", action="store_true", help="skip roofline.floor (a ~0.3 s probe of the table access pattern after the timed region)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive host-buffer measurement after the timed region")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true", default=None,
                     help="zstd: two contexts on two streams, the match finder of step i+1 under the entropy stage of step i — every step still "
@@ -245,7 +246,11 @@ def main():
                          "per-GPU sizes, one child process each) after the timed region and attach them as \"also\"")
     ap.add_argument("--also-steps", type=int, default=3)
     ap.add_argument("--path", default="auto", choices=["auto", "hbm", "lds"], help="kernel family of SpeedFastest / s2.Encode (KC_OPT_MATCH_PATH)")
+    ap.add_argument("--e2e-calls", type=int, default=3, help="end_to_end steady state: host-buffer calls kept in flight (contexts used with submit / wait)")
+    ap.add_argument("--e2e-steps", type=int, default=12, help="end_to_end steady state: batches timed")
     args = ap.parse_args()
+    if args.contexts == 1:
+        ap.error("--contexts counts the contexts of the two-stage pipeline (2 or 3); for one context with steps back to back use --no-pipeline")
     if args.pipeline is None:
         args.pipeline = args.config == "C2"
     cfg = dict(CONFIGS[args.config])
@@ -391,27 +396,46 @@ def main():
     # the last step's frames are gathered once more and rank 0 digests each segment of what arrived ----
     gather_ok = None
     if gather is not None:
-        try:
-            def digest(t):
-                n = t.numel()
-                pad = torch.zeros((n + 7) // 8 * 8, dtype=torch.uint8, device=t.device)
-                pad[:n].copy_(t)
+        def digest(t):
+            """two wrapping 64-bit sums of a byte tensor (one position-weighted) + its length, in 64 MiB pieces (no full-size temporaries)"""
+            n = t.numel()
+            s0, s1, pos, step = 0, 0, 0, 64 << 20
+            for a0 in range(0, n, step):
+                piece = t[a0:min(n, a0 + step)]
+                m = piece.numel()
+                pad = torch.zeros((m + 7) // 8 * 8, dtype=torch.uint8, device=t.device)
+                pad[:m].copy_(piece)
                 v = pad.view(torch.int64)
-                w = torch.arange(v.numel(), dtype=torch.int64, device=t.device) * 2654435761 + 1
-                return [int(v.sum().item()), int((v * w).sum().item()), n]
-            mine = torch.tensor(digest(d_dst[:out_bytes]), dtype=torch.int64, device="cuda")
-            allv = torch.empty(3 * world, dtype=torch.int64, device="cuda")
-            dist.all_gather_into_tensor(allv, mine)
-            res = gather.start(d_dst, out_bytes).wait()
-            if rank == 0:
+                w = (torch.arange(v.numel(), dtype=torch.int64, device=t.device) + pos) * 2654435761 + 1
+                s0 = (s0 + int(v.sum().item())) & 0xFFFFFFFFFFFFFFFF
+                s1 = (s1 + int((v * w).sum().item())) & 0xFFFFFFFFFFFFFFFF
+                pos += v.numel()
+            to_i64 = lambda x: x - (1 << 64) if x >= (1 << 63) else x
+            return [to_i64(s0), to_i64(s1), n]
+        # only the LOCAL digest may fail quietly: a rank that skipped a collective would leave the others waiting in it (ADVICE r5).  A
+        # failed digest travels as a sentinel; every rank enters both collectives.
+        local_err = None
+        try:
+            mine_l = digest(d_dst[:out_bytes])
+        except Exception as e:
+            mine_l, local_err = [0, 0, -1], repr(e)[:200]
+        mine = torch.tensor(mine_l, dtype=torch.int64, device="cuda")
+        allv = torch.empty(3 * world, dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(allv, mine)
+        res = gather.start(d_dst, out_bytes).wait()
+        if rank == 0:
+            try:
                 g_out, g_offs = res
                 want = allv.cpu().tolist()
-                gather_ok = g_offs[-1] == sum(want[2::3])
-                for r in range(world):
-                    gather_ok = gather_ok and digest(g_out[g_offs[r]:g_offs[r + 1]]) == want[3 * r:3 * r + 3]
-                gather_ok = bool(gather_ok)
-        except Exception as e:  # the timed result must still be reported
-            gather_ok = "error: " + repr(e)[:200]
+                if any(x < 0 for x in want[2::3]):
+                    gather_ok = "error: a rank could not digest its frames" + ((": " + local_err) if local_err else "")
+                else:
+                    gather_ok = g_offs[-1] == sum(want[2::3])
+                    for r in range(world):
+                        gather_ok = gather_ok and digest(g_out[g_offs[r]:g_offs[r + 1]]) == want[3 * r:3 * r + 3]
+                    gather_ok = bool(gather_ok)
+            except Exception as e:  # the timed result must still be reported
+                gather_ok = "error: " + repr(e)[:200]
 
     # ---- roofline of the dominant kernel, from HIP events on the launch stream (kc_last_timings) ----
     tm = ktimes[-1]
@@ -459,9 +483,34 @@ def main():
                 "kernel_ms": round(k_match, 3), "table_prep_ms": round(k_prep, 3), "entropy_kernel_ms": round(k_entropy, 3), "pipeline_kernel_ms": round(k_total, 3),
                 "pipeline_frac": round(algo_bytes / (k_total / 1000.0) / 1e9 / HBM_PEAK_GBS, 5),
                 "read_only_frac": round(in_bytes / (k_match / 1000.0) / 1e9 / HBM_PEAK_GBS, 5)}
+    # ---- the floor of this design: the dominant kernel's DRAM requests per dispatch (TCC_EA0_RDREQ / WRREQ,
+    # profiles/r06_transactions.json, stamped with the kernel's source hash) priced at the request rates THIS box gives the same access
+    # pattern right now (kc_probe_table_pattern: scattered 4-byte read + write-back pairs / plain reads into per-unit tables of the
+    # configuration's geometry).  Every table store is one DRAM write behind a table read of the same line (a pair); the reads beyond
+    # that (candidate bytes, source lines) are priced as plain scattered reads.  frac_of_floor = floor_ms / kernel_ms.
+    if rank == 0 and world == 1 and not args.no_floor:
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r06_transactions.json")))
+            ent = [e for e in tj["entries"] if e["config"] == args.config and e["units"] == n_units and e["corpus"] == kind]
+            if ent and args.config in ("C2", "C3", "C4", "C5") and (not is_s2 or args.s2_level == 0):
+                ent = ent[0]
+                pr = ctx0.probe_table_pattern(n_units, ent["table_bytes_per_unit"], 4096, 4096)
+                rd, wr = ent["rdreq_per_dispatch"], ent["wrreq_per_dispatch"]
+                floor_ms = (wr / pr["pairs_per_s"] + max(0.0, rd - wr) / pr["reads_per_s"]) * 1e3
+                k_alone = k_match  # with two contexts the event bracket includes the overlapped entropy stage: the also-line C2/one-context carries the kernel alone
+                roofline["floor"] = {
+                    "transactions_per_unit": round((rd + wr) / n_units, 1), "reads_per_unit": ent["rdreq_per_unit"], "writes_per_unit": ent["wrreq_per_unit"],
+                    "measured_pairs_per_s": round(pr["pairs_per_s"]), "measured_reads_per_s": round(pr["reads_per_s"]),
+                    "measured_tx_per_s": round(2 * pr["pairs_per_s"]),
+                    "floor_ms": round(floor_ms, 2), "kernel_ms": round(k_alone, 3), "frac_of_floor": round(floor_ms / k_alone, 3),
+                    "model": "writes x (1 / pair rate) + (reads - writes) x (1 / scattered read rate); rates from kc_probe_table_pattern on this box in this run (%d tables of %d KiB, 4096 waves); requests from profiles/r06_transactions.json" % (n_units, ent["table_bytes_per_unit"] >> 10),
+                    "transactions_source_current": ent["kernel_source_sha16"] == khash,
+                    "note": "a bit-exact %s keeps one hash table per unit in HBM (%d GiB live): every probe is a DRAM read and a DRAM write-back of a 64-byte line that carries 4 useful bytes; the kernel runs at the request ceiling of that pattern, not at a byte roofline" % (cfg["what"], (n_units * ent["table_bytes_per_unit"]) >> 30)}
+        except Exception as e:  # the timed result must still be reported
+            roofline["floor"] = {"error": repr(e)[:200]}
     if npipe >= 2:  # several steps in flight: the event brackets of one step's kernels contain the other steps' work
-        roofline["overlap_note"] = ("two contexts: kernel_ms is the match finder's duration WITH the previous step's entropy stage running beside it (alone: "
-                                    "--no-pipeline); entropy_kernel_ms / pipeline_kernel_ms span the match finder they run under and do not add up to ms_per_step")
+        roofline["overlap_note"] = ("%d contexts: kernel_ms is the match finder's duration WITH the previous step's entropy stage running beside it (alone: "
+                                    "--no-pipeline); entropy_kernel_ms / pipeline_kernel_ms span the match finder they run under and do not add up to ms_per_step" % npipe)
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement of the reference on the host threads + byte compare ----
     cpu = None
@@ -536,47 +585,107 @@ def main():
         except Exception as e:
             verified = "error: " + repr(e)[:300]
 
-    # ---- PCIe-inclusive rate of the host-buffer entry point (what the cgo shim calls), outside the timed region: the whole
-    # batch from pageable host memory through kc_zstd_encode_units / kc_s2_encode_blocks (pinned double-buffered pipeline of
-    # H2D, kernels and D2H over 1-2 GiB sub-batches) into a pre-faulted pageable destination ----
+    # ---- PCIe-inclusive rate of the host-buffer entry points (what the cgo shim calls; include/kcgpu.h), outside the timed region.
+    # Source and destination are pageable host memory, the destination pre-faulted.  Large calls go through the device's rolling
+    # pipeline (compress_amd/csrc/kc_roll.cpp): sub-batches of every call in flight are staged, encoded on lanes and drained in
+    # arrival order.  Reported: (1) ONE call over the whole batch (latency form: transfer of the first sub-batch and drain of the last
+    # are exposed); (2) the steady state of a caller that keeps --e2e-calls calls in flight through kc_*_submit / kc_wait on as many
+    # contexts (SURVEY 8b "async submit/wait"), the same number of batches per second the device-resident `value` counts; (3) this
+    # box's ceilings: pinned H2D / D2H rates and the pageable <-> pinned host copy rate (kc_probe_pcie). ----
     e2e = None
     if rank == 0 and world == 1 and not args.no_end_to_end:
         try:
             import ctypes as C
-            h_dst = np.empty(cap, dtype=np.uint8)
-            h_dst.fill(0)
-            eo = np.zeros(n_units + 1, dtype=np.uint64)
-            best = None
-            for _ in range(2):
-                t0 = time.perf_counter()
+            ref_out = d_dst[:out_bytes].cpu().numpy()
+            del d_dsts, d_dst, d_src  # the timed region's buffers: the host path brings its own
+            d_dsts = d_dst = d_src = None
+            torch.cuda.empty_cache()
+            pc = ctx0.probe_pcie(1 << 30)
+            ncall = max(1, args.e2e_calls)
+            if is_s2:
+                eencs = [enc] + [s2.BlockEncoder(device=local_rank, level=args.s2_level, path=args.path, variant=cfg.get("variant")) for _ in range(ncall - 1)]
+                ectx = [e._ctx for e in eencs]
+            else:
+                eencs = [enc] + [zstd.NewWriter(None, *zopts, device=local_rank) for _ in range(ncall - 1)]
+                ectx = [e.ctx() for e in eencs]
+            h_dsts = [np.zeros(cap, dtype=np.uint8) for _ in range(ncall)]
+            eos = [np.zeros(n_units + 1, dtype=np.uint64) for _ in range(ncall)]
+
+            def ecall(i, submit):
+                c = ectx[i]
                 if is_s2:
-                    ctx0.check(ctx0.L.kc_s2_encode_blocks_lvl(ctx0.h, args.s2_level, host.ctypes.data, unit_off.ctypes.data, n_units, h_dst.ctypes.data, cap, eo.ctypes.data))
+                    f = c.L.kc_s2_encode_blocks_lvl_submit if submit else c.L.kc_s2_encode_blocks_lvl
+                    c.check(f(c.h, args.s2_level, host.ctypes.data, unit_off.ctypes.data, n_units, h_dsts[i].ctypes.data, cap, eos[i].ctypes.data))
                 else:
-                    ctx0.check(ctx0.L.kc_zstd_encode_units(ctx0.h, C.byref(enc.o), host.ctypes.data, unit_off.ctypes.data, n_units,
-                                                           h_dst.ctypes.data, cap, eo.ctypes.data))
-                edt = time.perf_counter() - t0
-                best = edt if best is None else min(best, edt)
-            same = bool(np.array_equal(eo, out_off)) and bool(np.array_equal(h_dst[:int(eo[n_units])], d_dst[:out_bytes].cpu().numpy()))
-            e2e = {"value": round(in_bytes / best / 1e6, 1), "unit": "MB/s", "frac_of_device_resident": round(in_bytes / best / 1e6 / (value / world), 3),
-                   "sample": "all %d units (%.2f GiB) from pageable host memory through kc_%s: source staged and frames drained chunk by chunk under the kernels (H2D + encode + D2H), best of 2"
-                             % (n_units, in_bytes / 2**30, "s2_encode_blocks" if is_s2 else "zstd_encode_units"),
+                    f = c.L.kc_zstd_encode_units_submit if submit else c.L.kc_zstd_encode_units
+                    c.check(f(c.h, C.byref(eencs[i].o), host.ctypes.data, unit_off.ctypes.data, n_units, h_dsts[i].ctypes.data, cap, eos[i].ctypes.data))
+
+            def ewait(i):
+                ectx[i].check(ectx[i].L.kc_wait(ectx[i].h))
+
+            for _w in range(2):  # warm: every lane of the engine has held a sub-batch of this shape (its scratch is allocated) before a clock starts
+                for i in range(ncall):
+                    ecall(i, True)
+                for i in range(ncall):
+                    ewait(i)
+            one = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ecall(0, False)
+                one.append(time.perf_counter() - t0)
+            ksteps = max(ncall, args.e2e_steps)
+            t0 = time.perf_counter()
+            sub = 0
+            for k in range(ksteps):  # ncall calls in flight: call k + ncall - 1 is submitted before call k is waited for
+                while sub < ksteps and sub < k + ncall:
+                    ecall(sub % ncall, True)
+                    sub += 1
+                ewait(k % ncall)
+            steady = (time.perf_counter() - t0) / ksteps
+            same = all(bool(np.array_equal(eos[i], out_off)) and bool(np.array_equal(h_dsts[i][:out_bytes], ref_out)) for i in range(ncall))
+            dev_rate = value / world  # MB/s, device-resident
+            pcie_rate = min(pc["h2d_bidir_GBps"], pc["host_copy_in_GBps"]) * 1e3  # MB/s of input the link can take while frames flow back
+            rate = in_bytes / steady / 1e6
+            e2e = {"value": round(rate, 1), "unit": "MB/s", "frac_of_device_resident": round(rate / dev_rate, 3),
+                   "ms_per_batch": round(steady * 1e3, 2), "calls_in_flight": ncall, "batches_timed": ksteps,
+                   "sample": "all %d units (%.2f GiB) per call from pageable host memory into pageable host memory through kc_%s_submit / kc_wait on %d contexts, %d calls in flight, %d batches timed after warm-up; the calls' sub-batches share the device's rolling pipeline (staging, 8 encoder lanes on 4 queues, drain)"
+                             % (n_units, in_bytes / 2**30, "s2_encode_blocks_lvl" if is_s2 else "zstd_encode_units", ncall, ncall, ksteps),
+                   "single_call": {"value": round(in_bytes / min(one) / 1e6, 1), "unit": "MB/s", "ms": round(min(one) * 1e3, 2), "frac_of_device_resident": round(in_bytes / min(one) / 1e6 / dev_rate, 3),
+                                   "note": "one synchronous kc_%s call over the whole batch, best of 3: the first sub-batch's transfer and the last one's drain are exposed" % ("s2_encode_blocks_lvl" if is_s2 else "zstd_encode_units")},
+                   "pcie_ceiling": {"h2d_GBps": round(pc["h2d_GBps"], 2), "d2h_GBps": round(pc["d2h_GBps"], 2), "h2d_with_d2h_GBps": round(pc["h2d_bidir_GBps"], 2),
+                                    "d2h_with_h2d_GBps": round(pc["d2h_bidir_GBps"], 2), "host_copy_in_GBps": round(pc["host_copy_in_GBps"], 2),
+                                    "host_copy_out_GBps": round(pc["host_copy_out_GBps"], 2), "copy_threads": pc["copy_threads"],
+                                    "note": "pinned 1 GiB copies each way, alone and both at once; pageable <-> pinned memcpy with the library's copy threads (kc_probe_pcie, this box, this run)"},
+                   "frac_of_min_device_pcie": round(rate / min(dev_rate, pcie_rate), 3),
                    "same_bytes_as_device_path": same}
-            del h_dst
+            for e in eencs[1:]:
+                e.Close()
+            del h_dsts
         except Exception as e:
             e2e = {"error": repr(e)[:300]}
 
     # ---- the other BASELINE configurations, driver-visible: one child process each, after the timed region ----
     also = None
     if rank == 0 and world == 1 and args.config == "C2" and not args.no_also and args.gib is None and args.kind is None:
-        del d_dsts, d_dst, d_src
+        d_dsts = d_dst = d_src = None
         torch.cuda.empty_cache()
+        # the children get the device to themselves: this process keeps its handles but gives the memory back (each context's scratch
+        # for the 4 GiB batch, and what the rolling host pipeline's slots and lanes hold after end_to_end: ~230 GiB together)
+        try:
+            for e_ in encs:
+                (e_._ctx if is_s2 else e_.ctx()).trim()
+            _lib.device_trim(local_rank)
+        except Exception:
+            pass
         also = {}
         # the five BASELINE configurations at their per-GPU sizes, then the N3 levels at small sizes (not BASELINE configurations:
         # zstd SpeedBestCompression, s2.EncodeBetter, s2.EncodeBest) so that the driver's one run times those too
         for name, extra in (("C2/one-context", ["--no-pipeline"]), ("C2H", []), ("C3", []), ("C4", []), ("C4A", []), ("C5", []), ("B4", ["--gib", "0.25"]),
                             ("C4/s2.EncodeBetter", ["--s2-level", "1", "--gib", "1.0"]), ("C4/s2.EncodeBest", ["--s2-level", "4", "--gib", "1.0"])):  # (one wave per block: 16 384 blocks = two residencies of the chip; 0.25 GiB left half of it idle: 3.97 vs 5.02 GB/s, gpurun_out/r5n)
-            cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("/")[0], "--steps", str(args.also_steps), "--warmup", "1", "--no-end-to-end",
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("/")[0], "--steps", str(args.also_steps), "--warmup", "1",
                    "--no-also", "--cpu-sample-units", "1024" if not extra else "256", "--path", args.path] + extra
+            if name not in ("C3", "C4", "C5"):  # the host-buffer rate of every BASELINE configuration; not of the side lines
+                cmd.append("--no-end-to-end")
             if name == "C2/one-context":  # like for like with rounds 1-3 (one context, steps back to back): no second CPU baseline
                 cmd += ["--no-cpu-baseline", "--no-device-verify"]
             t0 = time.perf_counter()
@@ -587,7 +696,7 @@ def main():
                 also[name] = {"workload": j["config"]["workload"], "contexts": j.get("contexts"), "value": j["value"], "unit": j["unit"], "steps": j["steps"], "ms_per_step": j["ms_per_step"],
                               "ms_per_step_spread": j.get("ms_per_step_spread"),
                               "ratio": j["ratio"], "roofline": j["roofline"], "bit_exact_vs_oracle_on_sample": j["bit_exact_vs_oracle_on_sample"],
-                              "device_roundtrip_all_frames": j["device_roundtrip_all_frames"], "cpu_baseline": j["cpu_baseline"],
+                              "device_roundtrip_all_frames": j["device_roundtrip_all_frames"], "cpu_baseline": j["cpu_baseline"], "end_to_end": j.get("end_to_end"),
                               "wall_s": round(time.perf_counter() - t0, 1)}
             except Exception as e:
                 also[name] = {"error": repr(e)[:300]}

@@ -42,7 +42,7 @@ SYMBOLS = [
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts", "kc_zstd_encode_units_submit", "kc_s2_encode_blocks_lvl_submit", "kc_wait", "kc_zstd_plan_stream_blocks", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
     "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats", "kc_s2_encode_blocks_lvl", "kc_s2_encode_blocks_lvl_dev", "kc_s2_encode_stream_lvl_dev",
     "kc_last_timings", "kc_corpus_fill", "kc_ctx_set_option", "kc_ctx_get_option", "kc_zstd_encode_jobs", "kc_zstd_job_size", "kc_zstd_overlap_size",
-    "kc_probe_table_pattern", "kc_probe_pcie",
+    "kc_probe_table_pattern", "kc_probe_pcie", "kc_ctx_trim", "kc_device_trim",
 ]
 
 # kc_option / KC_PATH_* (include/kcgpu.h)
@@ -163,6 +163,10 @@ def load():
     L.kc_ctx_set_option.restype = C.c_int
     L.kc_ctx_get_option.argtypes = [vp, C.c_int]
     L.kc_ctx_get_option.restype = C.c_int64
+    L.kc_ctx_trim.argtypes = [vp]
+    L.kc_ctx_trim.restype = C.c_int
+    L.kc_device_trim.argtypes = [C.c_int]
+    L.kc_device_trim.restype = C.c_int
     L.kc_corpus_fill.argtypes = [C.c_int, u64, u64, C.c_uint32, C.c_uint32, vp, C.c_int]
     L.kc_corpus_fill.restype = C.c_int
     if hasattr(L, "kc_probe_pcie"):  # (the wave-emulator build of the library, tools/build_emu_lib.sh, leaves the device probes out)
@@ -258,11 +262,22 @@ class Context:
         return {"h2d_GBps": out[0], "d2h_GBps": out[1], "h2d_bidir_GBps": out[2], "d2h_bidir_GBps": out[3],
                 "host_copy_in_GBps": out[4], "host_copy_out_GBps": out[5], "copy_threads": int(out[6])}
 
+    def trim(self):
+        """kc_ctx_trim: free this context's device scratch (it grows back with the next call)."""
+        self.check(self.L.kc_ctx_trim(self.h))
+
     def timings(self):
         t = Timings()
         self.check(self.L.kc_last_timings(self.h, C.byref(t)))
         return {"total_ms": t.total_ms, "match_ms": t.match_ms, "entropy_ms": t.entropy_ms, "other_ms": t.other_ms,
                 "redo_units": t.redo_units, "prep_ms": t.prep_ms}
+
+
+def device_trim(device=0):
+    """kc_device_trim: free what the device's rolling host pipeline holds (slots + lane scratch); raises while calls are in flight."""
+    st = load().kc_device_trim(int(device))
+    if st != KC_OK:
+        raise KcError(st, "kc_device_trim")
 
 
 def corpus_fill(kind, seed, first_unit, n_units, unit_size, threads=None):

@@ -198,15 +198,46 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
     }
 }
 
+static void ctx_free_scratch(kc_ctx* c) {
+    DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
+                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->redo_blk, &c->pop_blk, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf,
+                      &c->d_job_hist, &c->d_job_flags, &c->rawdef, &c->unit_raw, &c->unit_done, &c->probe_rel, &c->best_tables, &c->best_cur, &c->best_cost};
+    for (DevBuf* b : bufs) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    // what the context remembered about the freed buffers' contents
+    c->predef_ready = false;
+    c->tab_owner = 0;
+    c->tab_ptr = nullptr;
+    c->tab_units = c->tab_ep = 0;
+    c->proto_key = 0;
+    c->best_n = 0;
+    c->probe_bs = 0;
+    c->probe_n = 0;
+    c->preclear_bytes = 0;
+    c->preclear_ptr = nullptr;
+    c->up_ptr[0] = c->up_ptr[1] = c->up_ptr[2] = nullptr;
+}
+
+kc_status kc_ctx_trim(kc_ctx* c) {
+    if (!c) return KC_ERR_BAD_ARG;
+    if (c->pend || c->job_active) { c->err = "kc_ctx_trim: a batch or a submitted job is in flight on this context"; return KC_ERR_BAD_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ctx_free_scratch(c);
+    if (c->hpipe) { host_pipe_free(c->hpipe); c->hpipe = nullptr; }
+    return KC_OK;
+}
+
+kc_status kc_device_trim(int device) { return kci::host_roll_trim(device); }
+
 void kc_ctx_destroy(kc_ctx* c) {
     if (!c) return;
     if (c->job_active && c->job.joinable()) c->job.join();
     (void)hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->unit_off, &c->unit_blk0, &c->stage_off, &c->seqs, &c->aux, &c->lits, &c->meta, &c->stage, &c->out_size, &c->xxh,
-                      &c->redo, &c->popmask, &c->unit_list, &c->out_off, &c->blk_start, &c->unit_flags, &c->redo_blk, &c->pop_blk, &c->predef, &c->errflag, &c->tmp_src, &c->tmp_dst, &c->tables, &c->prof, &c->work, &c->work_off, &c->dictbuf, &c->proto, &c->dicthuf,
-                      &c->d_job_hist, &c->d_job_flags, &c->rawdef, &c->unit_raw, &c->unit_done, &c->probe_rel, &c->best_tables, &c->best_cur, &c->best_cost};
-    for (DevBuf* b : bufs)
-        if (b->p) (void)hipFree(b->p);
+    ctx_free_scratch(c);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_preclear) (void)hipEventDestroy(c->ev_preclear);

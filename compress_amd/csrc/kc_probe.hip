@@ -16,7 +16,7 @@ __device__ __forceinline__ uint32_t kc_lcg(uint32_t& s) { s = s * 1664525u + 101
 // MODE 0: read + write-back of the same entry (a table probe), 1: read only, 2: store only.  K independent accesses per lane per
 // iteration (the match finder looks up two buckets per step).
 template <int MODE>
-__global__ __launch_bounds__(64) void kc_probe_table_kernel(uint32_t* __restrict__ arena, uint32_t n_tables, uint32_t entries_mask,
+__global__ __launch_bounds__(64) void kc_probe_table_kernel(uint32_t* __restrict__ arena, uint32_t n_tables,
                                                             uint32_t table_words, uint32_t iters, uint32_t* sink) {
     const uint32_t gl = blockIdx.x * 64 + threadIdx.x;
     const uint32_t unit = (gl >> 3) % n_tables;
@@ -24,7 +24,8 @@ __global__ __launch_bounds__(64) void kc_probe_table_kernel(uint32_t* __restrict
     uint32_t rs = gl * 2654435761u + 12345u;
     uint32_t acc = 0;
     for (uint32_t it = 0; it < iters; it++) {
-        const uint32_t i0 = kc_lcg(rs) & entries_mask, i1 = kc_lcg(rs) & entries_mask;
+        // (24 random bits scaled to the table: any table size, not only powers of two — SpeedDefault's tables are 640 KiB per unit)
+        const uint32_t i0 = (uint32_t)(((uint64_t)kc_lcg(rs) * table_words) >> 24), i1 = (uint32_t)(((uint64_t)kc_lcg(rs) * table_words) >> 24);
         uint32_t v0 = 0, v1 = 0;
         if (MODE != 2) {
             v0 = *(volatile uint32_t*)(tab + i0);
@@ -42,10 +43,10 @@ __global__ __launch_bounds__(64) void kc_probe_table_kernel(uint32_t* __restrict
 template <int MODE>
 hipError_t run_table(uint32_t* arena, uint32_t n_tables, uint32_t table_words, uint32_t waves, uint32_t iters, uint32_t* sink,
                      hipStream_t st, hipEvent_t a, hipEvent_t b, double* req_per_s) {
-    hipLaunchKernelGGL((kc_probe_table_kernel<MODE>), dim3(waves), dim3(64), 0, st, arena, n_tables, table_words - 1, table_words, iters / 8 + 1, sink);
+    hipLaunchKernelGGL((kc_probe_table_kernel<MODE>), dim3(waves), dim3(64), 0, st, arena, n_tables, table_words, iters / 8 + 1, sink);
     hipError_t e = hipEventRecord(a, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((kc_probe_table_kernel<MODE>), dim3(waves), dim3(64), 0, st, arena, n_tables, table_words - 1, table_words, iters, sink);
+    hipLaunchKernelGGL((kc_probe_table_kernel<MODE>), dim3(waves), dim3(64), 0, st, arena, n_tables, table_words, iters, sink);
     if ((e = hipEventRecord(b, st)) != hipSuccess) return e;
     if ((e = hipEventSynchronize(b)) != hipSuccess) return e;
     float ms = 0;
@@ -62,7 +63,7 @@ extern "C" {
 
 kc_status kc_probe_table_pattern(kc_ctx* c, uint32_t n_tables, uint32_t table_bytes, uint32_t waves, uint32_t iters, double* out3) {
     if (!c || !out3 || n_tables == 0 || waves == 0 || iters == 0) return KC_ERR_BAD_ARG;
-    if (table_bytes < 1024 || (table_bytes & (table_bytes - 1))) { c->err = "table_bytes must be a power of two >= 1024"; return KC_ERR_BAD_ARG; }
+    if (table_bytes < 1024 || (table_bytes & 3)) { c->err = "table_bytes must be a multiple of 4, at least 1024"; return KC_ERR_BAD_ARG; }
     c->err.clear();
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t* arena = nullptr;

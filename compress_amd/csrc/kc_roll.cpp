@@ -326,6 +326,32 @@ RollEngine* engine_for(int device) {
 
 }  // namespace
 
+// kc_device_trim: with no call in flight, give the engine's device memory back (slots and the lanes' scratch: ~10 GiB per lane for
+// SpeedFastest sub-batches of 1 GiB); the next large call allocates again.  KC_ERR_BAD_ARG while calls are in flight.
+kc_status host_roll_trim(int device) {
+    RollEngine* E = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_eng_m);
+        if (device < 0 || device >= 64) return KC_ERR_BAD_ARG;
+        E = g_eng[device];
+    }
+    if (!E) return KC_OK;  // never started: nothing held
+    std::lock_guard<std::mutex> lk(E->m);  // (the stages take jobs under this lock: holding it keeps the engine idle)
+    if (!E->q_stage.empty() || !E->q_enc.empty() || !E->q_drain.empty()) return KC_ERR_BAD_ARG;
+    for (int e = 0; e < RollEngine::kEnc; e++) if (E->lane_busy[e] || E->lane_job[e]) return KC_ERR_BAD_ARG;
+    for (auto& sl : E->slots) if (sl.busy) return KC_ERR_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess) return KC_ERR_HIP;
+    for (auto& sl : E->slots) {
+        if (sl.in.p) (void)hipFree(sl.in.p);
+        if (sl.out.p) (void)hipFree(sl.out.p);
+        sl.in = DevBuf();
+        sl.out = DevBuf();
+    }
+    kc_status rs = KC_OK;
+    for (kc_ctx* l : E->lanes) { const kc_status s = kc_ctx_trim(l); if (s != KC_OK) rs = s; }
+    return rs;
+}
+
 uint64_t host_roll_sub_bytes(const kc_ctx* c, uint64_t total) {
     if (c->cfg.host_roll_mib >= 1) return (uint64_t)c->cfg.host_roll_mib << 20;
     const uint64_t q = (total + 3) / 4;

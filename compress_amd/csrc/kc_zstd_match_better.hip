@@ -34,6 +34,23 @@ static_assert(ZBG <= 32, "group ballots are 32-bit");
 // width changes or when the arena was used by something else.  `prev` words are stored resolved and unstamped: they are only read
 // together with a valid `offset` word.  P.epoch == 0 is the old contract (tables fully initialised by the host): jobs, whose
 // tables the host primes per unit, and units too long for the stamp to fit.
+// Source window (round 6, the SpeedFastest / SpeedDefault kernels' ring): the unit's bytes around the parse position live in a per-unit
+// ring in LDS, refilled 256 bytes at a time by the group's 16 lanes (one aligned 16-byte load each, one round ahead of use).  A probe
+// round was three dependent round trips (8 source bytes at the probe position -> table entries -> candidate bytes) on a kernel
+// that is latency-bound at the 8192 units of a 1 GiB batch (2 waves per SIMD); the first now is an LDS read, and so are the source
+// reads of the re-indexing loop behind a match, the lazy lookup at s+1, the end-of-match re-search and the offset-2 loop whenever the
+// window holds them (rd64 / rd32 fall back to memory where it does not: behind a match longer than the look-ahead).
+#ifndef ZB_RB
+#define ZB_RB 1024      // ring bytes per unit (power of two)
+#endif
+#define ZB_MIRROR 32    // the first 32 ring bytes again behind the ring: 12-byte reads never wrap
+#define ZB_STRIDE (ZB_RB + ZB_MIRROR)
+#ifndef ZB_AHEAD
+#define ZB_AHEAD 384    // refill while fewer than this many bytes are buffered ahead of s
+#endif
+#ifndef ZB_RING
+#define ZB_RING 1       // 0: measurement builds (KC_EXTRA_FLAGS=-DZB_RING=0): every source read from memory, as before round 6
+#endif
 #define ZB_EPOCH_BITS 4
 #define ZB_EPOCH_SHIFT (32 - ZB_EPOCH_BITS)
 
@@ -85,9 +102,11 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
     constexpr int G = ZBG;
     constexpr int UPW = 64 / G;
     __shared__ uint64_t sbuf_all[UPW * G];  // per unit: the last (nseq mod G) sequences
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[UPW * ZB_STRIDE];
     const int lane = (int)threadIdx.x;
     const int lig = lane % G, grp = lane / G;
     uint64_t* const sbuf = sbuf_all + grp * G;
+    uint8_t* const ring = ring_all + grp * ZB_STRIDE;
     const uint32_t ui = blockIdx.x * UPW + (uint32_t)grp;
     const bool gact = ui < n_launch;
     const uint32_t u = gact ? (P.unit_list ? P.unit_list[ui] : P.unit_base + ui) : 0u;
@@ -117,6 +136,65 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
     const int mmo = C.mmo;
     auto hL = [&](uint64_t v) -> uint32_t { return hash8(v, ZB_LONG_BITS); };
     auto hS = [&](uint64_t v) -> uint32_t { return hash5(v, ZB_SHORT_BITS); };
+    // ---- source window ----
+    const int boff = (int)((uintptr_t)base & 15);  // window positions are relative to the 16-byte aligned abase
+    const uint8_t* __restrict__ abase = base - boff;
+    const uint8_t* const srcHi = P.src_end;
+    int wlo = 0, whi = 0;   // the ring holds the bytes abase[wlo .. whi)
+    bool pend = false;      // rf holds the 16*G bytes abase[whi ..) loaded during the previous round
+    uint4 rf = make_uint4(0, 0, 0, 0);
+    // top of every probe round (group-uniform): take in the refill issued a round ago, keep the window ahead of s
+    auto window = [&](int s) {
+        if (!ZB_RING) { KC_EMU_SYNC(); return; }
+        if (pend) {
+            const int ro = (whi + 16 * lig) & (ZB_RB - 1);
+            *(uint4*)(ring + ro) = rf;
+            if (ro < ZB_MIRROR) *(uint4*)(ring + ZB_RB + ro) = rf;
+            whi += 16 * G;
+            if (whi - wlo > ZB_RB) wlo = whi - ZB_RB;
+            pend = false;
+        }
+        KC_EMU_SYNC();  // (the ring is written by all lanes of the group and read by all of them)
+        const int sa = s + boff;
+        if (sa >= whi || sa < wlo) {  // block start, or a match jumped past the window: restart it at s
+            const int w0 = sa & ~15;
+            wlo = whi = w0;
+        }
+        if (whi - sa < ZB_AHEAD) {
+            const uint8_t* q = abase + whi + 16 * lig;
+            rf = make_uint4(0, 0, 0, 0);
+            if (q < srcHi) rf = *(const uint4*)q;  // aligned: never leaves the 16-byte granule of a readable byte
+            pend = true;
+        }
+    };
+    // 8 / 4 source bytes at unit position pos (any lane, any position): from the ring when it holds them, else from memory
+    auto rd64 = [&](int pos) -> uint64_t {
+        const int a = pos + boff;
+        const int a4 = a & ~3;
+        if (ZB_RING && a4 >= wlo && a4 + 12 <= whi) {
+            const uint32_t* r = (const uint32_t*)(ring + (a4 & (ZB_RB - 1)));
+            const uint32_t r0 = r[0], r1 = r[1], r2 = r[2];
+            const uint32_t sh = (uint32_t)(a & 3);
+            return (uint64_t)__builtin_amdgcn_alignbyte(r1, r0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(r2, r1, sh) << 32);
+        }
+        return ld64(base + pos);
+    };
+    auto rd32 = [&](int pos) -> uint32_t {
+        const int a = pos + boff;
+        const int a4 = a & ~3;
+        if (ZB_RING && a4 >= wlo && a4 + 8 <= whi) {
+            const uint32_t* r = (const uint32_t*)(ring + (a4 & (ZB_RB - 1)));
+            return __builtin_amdgcn_alignbyte(r[1], r[0], (uint32_t)(a & 3));
+        }
+        return ld32(base + pos);
+    };
+    // candidate acceptable for an 8-byte compare against cv at position s? (ZbCtx::long_ok with the candidate's bytes from the window)
+    auto long_ok = [&](uint32_t e, int sp, uint64_t cv) -> bool {
+        const int t = C.posOf(e);
+        if (t < 0 || (sp - t) >= mmo) return false;
+        if ((e >> C.PB) != C.tagOf((uint32_t)cv)) return false;
+        return rd64(t) == cv;
+    };
 
     int o1 = P.rep1, o2 = P.rep2;  // {1,4} (blockenc.go:78) or the dictionary's offsets (enc_base.go:189-195)
     for (int b = 0; b < nblk; b++) {
@@ -148,7 +226,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                 const bool act = idx < upto;
                 uint64_t cv0 = 0;
                 uint32_t h0 = 0xFFFFFFFFu - (uint32_t)lig, h1 = 0xFFFFFF00u - (uint32_t)lig;
-                if (act) { cv0 = ld64(base + idx); h0 = hL(cv0); h1 = hS(cv0 >> 8); }
+                if (act) { cv0 = rd64(idx); h0 = hL(cv0); h1 = hS(cv0 >> 8); }
                 uint32_t oldOff = 0;
                 if (act) oldOff = C.rdLx(h0);
                 // nearest lower lane with the same long bucket supplies `prev`; a higher lane with the same bucket owns the store
@@ -192,7 +270,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                 bool brk = false;
                 for (;;) {  // search loop: speculative probe rounds with ordered commit (as in the other match finders)
                     rounds++;
-                    KC_EMU_SYNC();
+                    window(s);
                     // While no match is found the probe positions are a pure function of (s, nextEmit): s += 1 + ((s-nextEmit)>>8).
                     // The lanes probe the next W of them against the pre-round tables; a lane whose long or short bucket was
                     // touched by a lower lane ends the round; lanes up to the first hit commit their table writes (the reference
@@ -208,7 +286,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     uint2 eL = make_uint2(0u, 0u);
                     uint32_t eS = 0;
                     if (valid) {
-                        cvl = ld64(base + pp);
+                        cvl = rd64(pp);
                         hl = hL(cvl);
                         hs = hS(cvl);
                         eL = C.rdL(hl);
@@ -223,13 +301,14 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     uint32_t hit = 0;  // 1 repeat at s+1, 2 long (offset), 4 long (prev), 8 short
                     if (valid) {
                         const int ri = pp - o1 + 1;
-                        if (canRep && ri >= 0 && ld32(base + ri) == (uint32_t)(cvl >> 8)) hit = 1;
+                        // (candidates a few hundred bytes back are in the window too: rd32 / rd64)
+                        if (canRep && ri >= 0 && rd32(ri) == (uint32_t)(cvl >> 8)) hit = 1;
                         else {
-                            if (C.long_ok(eL.x, pp, cvl)) hit |= 2;
-                            if (C.long_ok(eL.y, pp, cvl)) hit |= 4;
+                            if (long_ok(eL.x, pp, cvl)) hit |= 2;
+                            if (long_ok(eL.y, pp, cvl)) hit |= 4;
                             if (hit == 0) {
                                 const int ts = C.posOf(eS);
-                                if (ts >= 0 && (pp - ts) < mmo && (eS >> C.PB) == C.tagOf((uint32_t)cvl) && ld32(base + ts) == (uint32_t)cvl) hit = 8;
+                                if (ts >= 0 && (pp - ts) < mmo && (eS >> C.PB) == C.tagOf((uint32_t)cvl) && rd32(ts) == (uint32_t)cvl) hit = 8;
                             }
                         }
                     }
@@ -312,7 +391,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                         {  // whit == 8: the short candidate was accepted on its 4 bytes
                             matched = grp_matchlen<G>(base, s + 4, ts + 4, blkEnd - (s + 4), lig, grp) + 4;
                             // long match at s+1? (:309-343)
-                            const uint64_t cv2 = ld64(base + s + 1);
+                            const uint64_t cv2 = rd64(s + 1);
                             const uint32_t nh2 = hL(cv2);
                             const uint2 c2 = C.rdL(nh2);
                             KC_EMU_SYNC();
@@ -343,9 +422,9 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                 // ---- end-of-match re-search (:419-460) ----
                 if (s + matched < sLimit) {
                     const int skipBeginning = DICT ? 0 : 3;
-                    const uint32_t nh = hL(ld64(base + s + matched));
+                    const uint32_t nh = hL(rd64(s + matched));
                     const int s2 = s + skipBeginning;
-                    const uint32_t cv4 = ld32(base + s2);
+                    const uint32_t cv4 = rd32(s2);
                     KC_EMU_SYNC();
                     const uint2 cE = C.rdL(nh);
                     {
@@ -384,7 +463,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                 reindex(index0, s - 1);
                 if (!canRep) continue;
                 for (;;) {  // offset-2 loop (:482-522)
-                    const uint64_t cvs = ld64(base + s);
+                    const uint64_t cvs = rd64(s);
                     const int o2pos = s - o2;
                     if (ld32(base + o2pos) != (uint32_t)cvs) break;
                     const uint32_t nhL2 = hL(cvs), nhS2 = hS(cvs);
@@ -402,6 +481,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                 }
             }
         }
+        pend = false;  // a refill still in flight at the end of a block is dropped; the window itself stays valid
         __builtin_amdgcn_wave_barrier();
         if (lig < (nseq & (G - 1))) sq[(nseq & ~(G - 1)) + lig] = sbuf[lig];  // the buffered tail of the sequence list
         int extra = nextEmit < blkEnd ? blkEnd - nextEmit : 0;

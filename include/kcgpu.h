@@ -115,6 +115,13 @@ int64_t kc_zstd_max_encoded_size(const kc_zstd_opts* o, int64_t size);
  * shim/go/zstdgpu, compress_amd/zstd.py; tests/test_zz_gpu_threads.py runs 8 threads on one encoder on the device). */
 kc_status kc_ctx_create(kc_ctx** out, int device, void* stream);
 void kc_ctx_destroy(kc_ctx* ctx);
+/* Give device memory back without giving the handles up (long-lived hosts, several processes on one device).  kc_ctx_trim frees
+ * the context's device scratch (it grows back with the next call; KC_ERR_BAD_ARG while a begin / submit is in flight on it).
+ * kc_device_trim frees what the device's rolling host pipeline holds (kc_zstd_encode_units / kc_s2_encode_blocks_lvl on large inputs:
+ * ten device slots of a sub-batch each and the scratch of its eight encoder lanes, ~100 GiB after 1 GiB SpeedFastest sub-batches);
+ * KC_ERR_BAD_ARG while host-buffer calls are in flight on that device, KC_OK when the pipeline never started. */
+kc_status kc_ctx_trim(kc_ctx* ctx);
+kc_status kc_device_trim(int device);
 const char* kc_last_error(const kc_ctx* ctx);
 /* ONE stream with WithConcurrentBlocks(true) (zstd/encoder_options.go:340-353; zstd/enc_jobs.go): the bytes equal
  *   enc, _ := zstd.NewWriter(w, opts..., zstd.WithConcurrentBlocks(true))   (with WithEncoderConcurrency > 1)
