@@ -42,7 +42,7 @@ SYMBOLS = [
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts", "kc_zstd_encode_units_submit", "kc_s2_encode_blocks_lvl_submit", "kc_wait", "kc_zstd_plan_stream_blocks", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
     "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats", "kc_s2_encode_blocks_lvl", "kc_s2_encode_blocks_lvl_dev", "kc_s2_encode_stream_lvl_dev",
     "kc_last_timings", "kc_corpus_fill", "kc_ctx_set_option", "kc_ctx_get_option", "kc_zstd_encode_jobs", "kc_zstd_job_size", "kc_zstd_overlap_size",
-    "kc_probe_table_pattern", "kc_probe_pcie", "kc_ctx_trim", "kc_device_trim",
+    "kc_probe_table_pattern", "kc_probe_pcie", "kc_ctx_trim", "kc_device_trim", "kc_s2_hook_declined", "kc_create_error",
 ]
 
 # kc_option / KC_PATH_* (include/kcgpu.h)
@@ -54,6 +54,7 @@ OPT_JOB_PRIME = 30
 OPT_STAGE2_STREAM = 31
 OPT_HOST_CHUNK_MIB_APPEND = 32
 OPT_HOST_ROLL, OPT_HOST_ROLL_MIB = 33, 34
+OPT_S2_HOOK_HOST_FIRST = 35
 _PATHS = {"auto": PATH_AUTO, "hbm": PATH_HBM, "lds": PATH_LDS, None: PATH_AUTO}
 
 _lib = None
@@ -163,6 +164,10 @@ def load():
     L.kc_ctx_set_option.restype = C.c_int
     L.kc_ctx_get_option.argtypes = [vp, C.c_int]
     L.kc_ctx_get_option.restype = C.c_int64
+    L.kc_s2_hook_declined.argtypes = [vp]
+    L.kc_s2_hook_declined.restype = C.c_uint64
+    L.kc_create_error.argtypes = []
+    L.kc_create_error.restype = C.c_char_p
     L.kc_ctx_trim.argtypes = [vp]
     L.kc_ctx_trim.restype = C.c_int
     L.kc_device_trim.argtypes = [C.c_int]
@@ -186,7 +191,8 @@ class Context:
         h = C.c_void_p()
         st = self.L.kc_ctx_create(C.byref(h), device, C.c_void_p(stream) if stream else None)
         if st != KC_OK:
-            raise KcError(st, "kc_ctx_create (is a gfx950 GPU visible? there is no CPU fallback)")
+            why = self.L.kc_create_error().decode(errors="replace")
+            raise KcError(st, "kc_ctx_create: %s (is a gfx950 GPU visible? there is no CPU fallback)" % (why or "no reason recorded"))
         self.h = h
         self._apply_env()
 
@@ -196,7 +202,7 @@ class Context:
                  ("KC_LDS_SPEC_W0", 6), ("KC_S2_LDS_SPEC_W0", 17), ("KC_HOST_PIPE_MIB", 8), ("KC_HOST_OVERLAP_MIN_MIB", 9),
                  ("KC_HOST_COPY_THREADS", 10), ("KC_S2_HOOK_WAIT_US", 14), ("KC_S2_HOOK_BATCH", 15), ("KC_S2_HOOK_LANES", 29),
                  ("KC_ZFAST_EPOCH", 22), ("KC_ZFAST_XSEG_K", 23), ("KC_FUSE_RAW_XXH", 24), ("KC_ZFAST_FILTER", 25), ("KC_XXH_FIN_MODE", 26),
-                 ("KC_ZFAST_VARIANT", 27), ("KC_ZFAST_PRESCAN", 28), ("KC_JOB_PRIME", 30), ("KC_HOST_ROLL", 33), ("KC_HOST_ROLL_MIB", 34))
+                 ("KC_ZFAST_VARIANT", 27), ("KC_ZFAST_PRESCAN", 28), ("KC_JOB_PRIME", 30), ("KC_HOST_ROLL", 33), ("KC_HOST_ROLL_MIB", 34), ("KC_S2_HOOK_HOST_FIRST", 35))
     _ENV_FLAGS = (("KC_HOST_SERIAL", 7), ("KC_HOST_TRACE", 11), ("KC_K2_PROF", 13))  # set by their presence
 
     def _apply_env(self):

@@ -84,13 +84,107 @@ int64_t kc_zstd_max_encoded_size(const kc_zstd_opts* o, int64_t size) {  // enco
 }
 
 // ---------------------------------------------------------------------------------------
+// device self-check (round 6).  Three GPU sessions of round 5 died in their first process on boxes whose GPU did
+// not answer (memory-access faults in the first hipMalloc, a 20-minute hang before the first test line).  The first kc_ctx_create
+// on a device therefore runs one known-answer launch on a thread of its own — a 256-byte buffer through the XXH64 kernel, digest
+// compared with the published value (xxhash.go:27-230; XXH64(seed 0) of the bytes 0..255 = 0x1FACBE8406CD904B) — and waits for it
+// with a deadline: a device that faults, hangs or computes something else makes kc_ctx_create return an error with a text
+// (kc_create_error) instead of taking the host process with it.  The verdict is kept per device for the life of the process.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct SelfCheck {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    kc_status st = KC_OK;
+    std::string text;
+};
+std::mutex g_sc_m;
+int g_sc_state[64] = {0};  // 0 not run, 1 passed, -1 failed
+kc_status g_sc_status[64];
+std::string g_sc_text[64];
+thread_local std::string t_create_err;
+
+void selfcheck_body(int device, const std::shared_ptr<SelfCheck>& sc) {
+    kc_status st = KC_OK;
+    std::string text;
+    uint8_t h_in[256];
+    for (int i = 0; i < 256; i++) h_in[i] = (uint8_t)i;
+    const uint64_t h_off[2] = {0, 256};
+    uint64_t h_out = 0;
+    uint8_t* d_in = nullptr;
+    uint64_t *d_off = nullptr, *d_out = nullptr;
+    hipStream_t s = nullptr;
+    auto fail = [&](const char* what, hipError_t e) { st = KC_ERR_HIP; text = std::string("device self-check: ") + what + ": " + hipGetErrorString(e); };
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) fail("hipSetDevice", e);
+    if (st == KC_OK && (e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) fail("hipStreamCreate", e);
+    if (st == KC_OK && (e = hipMalloc((void**)&d_in, 256 + 64)) != hipSuccess) fail("hipMalloc", e);
+    if (st == KC_OK && (e = hipMalloc((void**)&d_off, 16)) != hipSuccess) fail("hipMalloc", e);
+    if (st == KC_OK && (e = hipMalloc((void**)&d_out, 8)) != hipSuccess) fail("hipMalloc", e);
+    if (st == KC_OK && (e = hipMemcpyAsync(d_in, h_in, 256, hipMemcpyHostToDevice, s)) != hipSuccess) fail("hipMemcpyAsync (H2D)", e);
+    if (st == KC_OK && (e = hipMemcpyAsync(d_off, h_off, 16, hipMemcpyHostToDevice, s)) != hipSuccess) fail("hipMemcpyAsync (H2D)", e);
+    if (st == KC_OK) {
+        kc_launch_xxh64(d_in, d_off, 1, d_out, s);
+        if ((e = hipGetLastError()) != hipSuccess) fail("kernel launch", e);
+    }
+    if (st == KC_OK && (e = hipMemcpyAsync(&h_out, d_out, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) fail("hipMemcpyAsync (D2H)", e);
+    if (st == KC_OK && (e = hipStreamSynchronize(s)) != hipSuccess) fail("hipStreamSynchronize", e);
+    if (st == KC_OK && h_out != 0x1FACBE8406CD904BULL) {
+        char b[160];
+        snprintf(b, sizeof(b), "device self-check: XXH64 known answer differs (got %016llx, want 1facbe8406cd904b): the device computes wrong results", (unsigned long long)h_out);
+        st = KC_ERR_INTERNAL;
+        text = b;
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_off) (void)hipFree(d_off);
+    if (d_out) (void)hipFree(d_out);
+    if (s) (void)hipStreamDestroy(s);
+    std::lock_guard<std::mutex> lk(sc->m);
+    sc->st = st;
+    sc->text = text;
+    sc->done = true;
+    sc->cv.notify_all();
+}
+
+kc_status device_selfcheck(int device, std::string* text) {
+    if (device < 0 || device >= 64) return KC_OK;
+    std::lock_guard<std::mutex> g(g_sc_m);  // (a second creator waits for the first one's verdict)
+    if (g_sc_state[device] == 0) {
+        auto sc = std::make_shared<SelfCheck>();
+        std::thread([device, sc] { selfcheck_body(device, sc); }).detach();  // detached: a device that never answers keeps this thread, not the caller
+        std::unique_lock<std::mutex> lk(sc->m);
+        const int deadline_s = 90;  // (the first launch of a process loads the code object and may page the runtime in: seconds on a healthy box)
+        if (!sc->cv.wait_for(lk, std::chrono::seconds(deadline_s), [&] { return sc->done; })) {
+            g_sc_state[device] = -1;
+            g_sc_status[device] = KC_ERR_HIP;
+            g_sc_text[device] = "device self-check: the device did not answer a 256-byte known-answer launch within " + std::to_string(deadline_s) + " s (hung queue or faulted context): no kc_* call was attempted";
+        } else {
+            g_sc_state[device] = sc->st == KC_OK ? 1 : -1;
+            g_sc_status[device] = sc->st;
+            g_sc_text[device] = sc->text;
+        }
+    }
+    if (g_sc_state[device] < 0) { *text = g_sc_text[device]; return g_sc_status[device]; }
+    return KC_OK;
+}
+}  // namespace
+
+const char* kc_create_error(void) { return t_create_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------
 kc_status kc_ctx_create(kc_ctx** out, int device, void* stream) {
     if (!out) return KC_ERR_BAD_ARG;
     *out = nullptr;
+    t_create_err.clear();
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return KC_ERR_NO_DEVICE;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) { t_create_err = "no such HIP device"; return KC_ERR_NO_DEVICE; }
+    {
+        const kc_status sc = device_selfcheck(device, &t_create_err);
+        if (sc != KC_OK) return sc;
+    }
     kc_ctx* c = new kc_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess) {
@@ -135,6 +229,7 @@ kc_status kc_ctx_set_option(kc_ctx* c, int key, int64_t v) {
         case KC_OPT_S2_HOOK_WAIT_US: g.hook_wait_us = v; break;
         case KC_OPT_S2_HOOK_BATCH: g.hook_batch = v < 1 ? 1 : v; break;
         case KC_OPT_S2_HOOK_LANES: g.hook_lanes = v < 1 ? 1 : (v > 8 ? 8 : v); break;
+        case KC_OPT_S2_HOOK_HOST_FIRST: g.hook_host_first = v < -1 ? -1 : v; break;
         case KC_OPT_TEST_FEED_REDO: g.test_feed_redo = v; break;
         case KC_OPT_MAX_SCRATCH_MIB: if (v < 1) return KC_ERR_BAD_ARG; c->max_scratch_bytes = (uint64_t)v << 20; break;
         case KC_OPT_BEST_SLOTS: if (v < 1 || v > 8192) return KC_ERR_BAD_ARG; g.best_slots = v; break;
@@ -177,6 +272,7 @@ int64_t kc_ctx_get_option(const kc_ctx* c, int key) {
         case KC_OPT_S2_HOOK_WAIT_US: return g.hook_wait_us;
         case KC_OPT_S2_HOOK_BATCH: return g.hook_batch;
         case KC_OPT_S2_HOOK_LANES: return g.hook_lanes;
+        case KC_OPT_S2_HOOK_HOST_FIRST: return g.hook_host_first;
         case KC_OPT_TEST_FEED_REDO: return g.test_feed_redo;
         case KC_OPT_MAX_SCRATCH_MIB: return (int64_t)(c->max_scratch_bytes >> 20);
         case KC_OPT_BEST_SLOTS: return g.best_slots;

@@ -1,5 +1,6 @@
 // kc_hook.cpp — kc_s2_encode_block, the s2.WriterCustomEncoder hook: concurrent callers micro-batched onto device lanes.
-#include "kc_host.h"
+#include "kc_hostpipe.h"
+#include <deque>
 
 // ---------------------------------------------------------------------------------------
 // kc_s2_encode_block: the s2.WriterCustomEncoder hook (s2/writer.go:1053-1064).
@@ -40,10 +41,26 @@ struct S2Hook {
     uint32_t max_n = 256;
     int wait_us = 0;
     bool ok = false;
-    std::atomic<uint64_t> n_calls{0}, n_batches{0};
+    std::atomic<uint64_t> n_calls{0}, n_batches{0}, n_declined{0};
+    // host first: the deadlines (steady clock, ns) until which the callers that were sent back to the built-in encoder are taken to be
+    // busy with their block; ascending (equal block sizes) or nearly so — expired ones are dropped from the front
+    std::mutex hm;
+    std::deque<int64_t> host_busy;
+    int host_cores = 1;
 
     bool init(const KcCfg& g, int device) {
         wait_us = (int)g.hook_wait_us;
+        host_cores = host_copy_threads() >= 16 ? (int)std::thread::hardware_concurrency() : host_copy_threads();  // (host_copy_threads: the cgroup's CPUs, capped at 16)
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char qs[32];
+            long long per = 0;
+            if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0 && per > 0) {
+                const long long lim = (atoll(qs) + per - 1) / per;
+                if (lim >= 1 && lim < host_cores) host_cores = (int)lim;
+            }
+            fclose(f);
+        }
+        if (host_cores < 1) host_cores = 1;
         max_n = (uint32_t)std::max<int64_t>(1, g.hook_batch);
         n_lanes = (int)std::min<int64_t>(kMaxLanes, std::max<int64_t>(1, g.hook_lanes));
         n_slots = n_lanes + 2;
@@ -106,6 +123,19 @@ int64_t kc_s2_encode_block(kc_ctx* c, uint8_t* dst, uint64_t dst_cap, const uint
     S2Hook* h = (S2Hook*)c->hook;
     if (!h) return -1;
     h->n_calls++;
+    {   // host first (include/kcgpu.h): while the host has a CPU that is not booked, the built-in encoder serves the caller faster
+        const int64_t hf = c->cfg.hook_host_first < 0 ? h->host_cores : c->cfg.hook_host_first;
+        if (hf > 0) {
+            const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            std::lock_guard<std::mutex> g(h->hm);
+            while (!h->host_busy.empty() && h->host_busy.front() <= now) h->host_busy.pop_front();
+            if ((int64_t)h->host_busy.size() < hf) {
+                h->host_busy.push_back(now + (int64_t)src_len * 2);  // 500 MB/s = 2 ns per byte: the built-in encoder's rate on text-like input
+                h->n_declined++;
+                return -1;
+            }
+        }
+    }
     std::unique_lock<std::mutex> lk(h->m);
     S2Hook::Slot* sl = nullptr;
     for (;;) {
@@ -202,8 +232,13 @@ int64_t kc_s2_encode_block(kc_ctx* c, uint8_t* dst, uint64_t dst_cap, const uint
 // diagnostics of the hook's micro-batcher: calls served and device batches run so far
 void kc_s2_hook_stats(const kc_ctx* c, uint64_t* calls, uint64_t* batches) {
     const S2Hook* h = c ? (const S2Hook*)c->hook : nullptr;
-    if (calls) *calls = h ? h->n_calls.load() : 0;
+    if (calls) *calls = h ? h->n_calls.load() - h->n_declined.load() : 0;  // calls served on the device
     if (batches) *batches = h ? h->n_batches.load() : 0;
+}
+// calls answered -1 by the host-first rule (the caller's built-in encoder took them)
+uint64_t kc_s2_hook_declined(const kc_ctx* c) {
+    const S2Hook* h = c ? (const S2Hook*)c->hook : nullptr;
+    return h ? h->n_declined.load() : 0;
 }
 
 }  // extern "C"

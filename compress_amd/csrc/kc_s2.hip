@@ -25,6 +25,22 @@
 #include "kc_wave.h"
 
 #define S2G 8
+// Source window of the default / Snappy levels (round 6; the zstd match finders' ring): the block's bytes around the parse position in a
+// per-block ring in LDS, refilled 128 bytes at a time by the group's lanes, so the 8 bytes at a probe position (and near candidates)
+// are an LDS read instead of the first of three dependent round trips.  MEASURED AND LEFT OFF (profiles/r06_ab_kernels.txt, C4 same
+// box): without 43.6 ms per 2 GiB; with it 61.3 ms — the kernel sits at 127 VGPRs and the window's state takes it to 139, i.e. from
+// 16 to 12 waves per CU; held at 128 VGPRs (S2_WPE=4: 28 bytes of scratch) 44.8 ms.  This kernel runs at 0.9 of the DRAM-request floor
+// of its tables (bench.py roofline.floor): the round trip the ring saves is not what bounds it, occupancy is.  Kept for measurement
+// builds (KC_EXTRA_FLAGS=-DS2_RING=1).
+#ifndef S2_RING
+#define S2_RING 0
+#endif
+#define S2_RB 512
+#define S2_MIRROR 32
+#define S2_STRIDE (S2_RB + S2_MIRROR)
+#ifndef S2_AHEAD
+#define S2_AHEAD 224
+#endif
 
 __device__ __forceinline__ uint32_t s2g_ballot(bool p, int grp) { return (uint32_t)((ballot64(p) >> (grp * S2G)) & 0xFFull); }
 __device__ __forceinline__ uint32_t s2g_bcast32(uint32_t v, int grp, int srcLig) { return (uint32_t)__shfl((int)v, grp * S2G + srcLig, 64); }
@@ -86,8 +102,13 @@ __device__ __forceinline__ int s2_extend_exact(const uint8_t* __restrict__ base,
     }
 }
 
+#ifdef S2_WPE
+#define S2_KATTR __attribute__((amdgpu_waves_per_eu(S2_WPE, S2_WPE)))
+#else
+#define S2_KATTR
+#endif
 template <int LEVEL>  // 0: s2.Encode (encodeBlockGo / ...64K), 1: s2.EncodeBetter (encodeBlockBetterGo / ...64K), 2: s2.EncodeSnappy (encodeBlockSnappyGo / ...64K), 3: s2.EncodeSnappyBetter (encodeBlockBetterSnappyGo / ...64K)
-__global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
+__global__ __launch_bounds__(64) S2_KATTR void kc_s2_encode_kernel(KcS2Params P) {
     constexpr int G = S2G;
     __shared__ uint32_t crcT[4][256];
     if (P.framed) {
@@ -235,7 +256,54 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
     };
 
     if ((LEVEL == 0 || LEVEL == 2) && !stored) {
-        constexpr bool SNAPPY = LEVEL == 2;  // encode_all.go:502 / :692: the same parse, every copy through emitCopyNoRepeat
+        constexpr bool SNAPPY = LEVEL == 2;
+        // ---- source window ----
+        __shared__ __attribute__((aligned(16))) uint8_t sring_all[S2_RING ? (64 / G) * S2_STRIDE : 16];
+        uint8_t* const sring = sring_all + (S2_RING ? grp * S2_STRIDE : 0);
+        const int boff = (int)((uintptr_t)src & 15);
+        const uint8_t* __restrict__ abase = src - boff;
+        const uint8_t* const srcHi = src + len;  // (the block's own end: the bytes behind it belong to the next block or to the buffer's padding)
+        int wlo = 0, whi = 0;
+        bool pend = false;
+        uint4 rf = make_uint4(0, 0, 0, 0);
+        auto window = [&](int sp) {  // top of every probe round (group-uniform)
+            if (!S2_RING) return;
+            if (pend) {
+                const int ro = (whi + 16 * lig) & (S2_RB - 1);
+                *(uint4*)(sring + ro) = rf;
+                if (ro < S2_MIRROR) *(uint4*)(sring + S2_RB + ro) = rf;
+                whi += 16 * G;
+                if (whi - wlo > S2_RB) wlo = whi - S2_RB;
+                pend = false;
+            }
+            KC_EMU_SYNC();
+            const int sa = sp + boff;
+            if (sa >= whi || sa < wlo) { const int w0 = sa & ~15; wlo = whi = w0; }
+            if (whi - sa < S2_AHEAD) {
+                const uint8_t* q = abase + whi + 16 * lig;
+                rf = make_uint4(0, 0, 0, 0);
+                if (q < srcHi) rf = *(const uint4*)q;  // aligned: never leaves the 16-byte granule of a readable byte
+                pend = true;
+            }
+        };
+        auto rd64 = [&](int pos) -> uint64_t {
+            const int a = pos + boff, a4 = a & ~3;
+            if (S2_RING && a4 >= wlo && a4 + 12 <= whi) {
+                const uint32_t* r = (const uint32_t*)(sring + (a4 & (S2_RB - 1)));
+                const uint32_t r0 = r[0], r1 = r[1], r2 = r[2];
+                const uint32_t sh = (uint32_t)(a & 3);
+                return (uint64_t)__builtin_amdgcn_alignbyte(r1, r0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(r2, r1, sh) << 32);
+            }
+            return ld64(src + pos);
+        };
+        auto rd32 = [&](int pos) -> uint32_t {
+            const int a = pos + boff, a4 = a & ~3;
+            if (S2_RING && a4 >= wlo && a4 + 8 <= whi) {
+                const uint32_t* r = (const uint32_t*)(sring + (a4 & (S2_RB - 1)));
+                return __builtin_amdgcn_alignbyte(r[1], r[0], (uint32_t)(a & 3));
+            }
+            return ld32(src + pos);
+        };  // encode_all.go:502 / :692: the same parse, every copy through emitCopyNoRepeat
         int SKIP = len <= (64 << 10) ? 5 : 6;  // encodeBlockGo64K vs encodeBlockGo (encode_go.go:23-26)
         // P.variant 1: the bytes of the amd64 ASSEMBLY encoders (s2/encode_amd64.go:23-87, 176-239; generator s2/_generate/gen.go:170-855)
         // — the same algorithm with, per size class, another table size / hash length / skip rate, matches extended to the very end
@@ -266,6 +334,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
         int W = G;  // speculation width: every speculative probe step costs three table lines from HBM, and matches come every few steps
         while (!fin && !stored) {
             KC_EMU_SYNC();  // (lane 0's table stores behind a match precede the next round's lookups)
+            window(s);
             // ---------------- speculative probe round ----------------
             const int d0 = s - nextEmit;
             const int k0 = d0 >> SKIP;
@@ -279,7 +348,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
             uint64_t cv = 0;
             uint32_t h0 = 0xFFFFFFF0u, h1 = 0xFFFFFFF1u, h2 = 0xFFFFFFF2u, e0 = 0, e1 = 0, e2 = 0;
             if (valid) {
-                cv = ld64(src + p);
+                cv = rd64(p);
                 h0 = hashOf(cv); h1 = hashOf(cv >> 8); h2 = hashOf(cv >> 16);
                 e0 = tab[h0]; e1 = tab[h1]; e2 = tab[h2];
             }
@@ -299,10 +368,10 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 const bool ok0 = e0 == 0 || (e0 >> PB) == tagOf((uint32_t)cv);
                 const bool ok1 = e1 == 0 || (e1 >> PB) == tagOf((uint32_t)(cv >> 8));
                 const bool ok2 = e2v == 0 || (e2v >> PB) == tagOf((uint32_t)(cv >> 16));
-                const uint32_t wr = ld32(src + (p - repeat + 1));
-                const uint32_t w0 = ok0 ? ld32(src + c0) : ~(uint32_t)cv;
-                const uint32_t w1 = ok1 ? ld32(src + c1) : ~(uint32_t)(cv >> 8);
-                const uint32_t w2 = ok2 ? ld32(src + c2) : ~(uint32_t)(cv >> 16);
+                const uint32_t wr = rd32(p - repeat + 1);
+                const uint32_t w0 = ok0 ? rd32(c0) : ~(uint32_t)cv;
+                const uint32_t w1 = ok1 ? rd32(c1) : ~(uint32_t)(cv >> 8);
+                const uint32_t w2 = ok2 ? rd32(c2) : ~(uint32_t)(cv >> 16);
                 if ((uint32_t)(cv >> 8) == wr) kind = 1;
                 else if ((uint32_t)cv == w0) { kind = 2; cand = c0; }
                 else if ((uint32_t)(cv >> 8) == w1) { kind = 3; cand = c1; }
@@ -384,7 +453,7 @@ __global__ __launch_bounds__(64) void kc_s2_encode_kernel(KcS2Params P) {
                 if (s >= sLimit) { fin = true; break; }
                 if (d > cpLim) { stored = true; break; }
                 // check for an immediate match, otherwise start the search at s+1 (:474-488)
-                const uint64_t x = ld64(src + s - 2);
+                const uint64_t x = rd64(s - 2);
                 const uint32_t m2Hash = hashOf(x), currHash = hashOf(x >> 16);
                 const uint32_t ec = tab[currHash];
                 KC_EMU_SYNC();

@@ -91,12 +91,17 @@ class BlockEncoder:
         out, _ = self.EncodeBlocks(np.frombuffer(src, dtype=np.uint8), np.array([0, len(src)], dtype=np.uint64))
         return out.tobytes()
 
-    def CustomEncoder(self):
+    def CustomEncoder(self, host_first=0):
         """The function to hand to s2.WriterCustomEncoder (s2/writer.go:1053): fn(dst, src) -> int.  The hook (kc_s2_encode_block)
-        encodes at the default level, like the reference's built-in encodeBlock of a default Writer."""
+        encodes at the default level, like the reference's built-in encodeBlock of a default Writer.
+        host_first: KC_OPT_S2_HOOK_HOST_FIRST — how many callers at a time the hook leaves to the caller's built-in encoder (fn returns
+        -1 for them) before the overflow goes to the device.  This Python façade has no built-in encoder, so its default is 0 (every
+        caller to the device); the library's own default (None here: the CPUs of the process) is what the Go shim gets."""
         if self.level != LevelDefault:
             raise ValueError("the WriterCustomEncoder hook serves the default level only (s2.Encode); use EncodeBlocks for level %d" % self.level)
         ctx = self._ctx
+        if host_first is not None:
+            ctx.set_option(_lib.OPT_S2_HOOK_HOST_FIRST, int(host_first))
 
         def fn(dst, src):
             src = bytes(src)

@@ -115,6 +115,11 @@ int64_t kc_zstd_max_encoded_size(const kc_zstd_opts* o, int64_t size);
  * shim/go/zstdgpu, compress_amd/zstd.py; tests/test_zz_gpu_threads.py runs 8 threads on one encoder on the device). */
 kc_status kc_ctx_create(kc_ctx** out, int device, void* stream);
 void kc_ctx_destroy(kc_ctx* ctx);
+/* Why the last kc_ctx_create of the calling thread failed ("" after a success).  The first kc_ctx_create on a device runs a
+ * known-answer launch (256 bytes through the XXH64 kernel) on a thread of its own and waits for it with a 90 s deadline: a device
+ * that faults, hangs or miscomputes makes kc_ctx_create return KC_ERR_HIP / KC_ERR_INTERNAL with the reason here instead of hanging
+ * or aborting the host (the promise at the top of this file); the verdict is remembered per device for the life of the process. */
+const char* kc_create_error(void);
 /* Give device memory back without giving the handles up (long-lived hosts, several processes on one device).  kc_ctx_trim frees
  * the context's device scratch (it grows back with the next call; KC_ERR_BAD_ARG while a begin / submit is in flight on it).
  * kc_device_trim frees what the device's rolling host pipeline holds (kc_zstd_encode_units / kc_s2_encode_blocks_lvl on large inputs:
@@ -187,6 +192,7 @@ typedef enum {
     KC_OPT_STAGE2_STREAM = 31,       /* (no variable)             a hipStream_t handle (0: none): kc_zstd_encode_units_dev[_begin/_end] run the entropy stage and everything behind it on this stream, behind an event of the match finder's — for callers that give the two stages different CU masks (hipExtStreamCreateWithCUMask) */
     KC_OPT_HOST_ROLL = 33,           /* KC_HOST_ROLL              host-buffer entry points, large inputs: 1 (default) = the device's rolling pipeline (sub-batches of all calls in flight staged, encoded on four lanes and drained in arrival order: consecutive calls overlap), 0 = one chunk-fed device batch per call (round 5) */
     KC_OPT_HOST_ROLL_MIB = 34,       /* KC_HOST_ROLL_MIB          rolling pipeline: sub-batch size (0: a quarter of the call's input, 64 MiB .. 1 GiB) */
+    KC_OPT_S2_HOOK_HOST_FIRST = 35,  /* KC_S2_HOOK_HOST_FIRST     kc_s2_encode_block: how many callers at a time are left to the host's built-in encoder (they get -1) before the overflow goes to the device: -1 (default) the CPUs this process may run on, 0 every caller to the device (see kc_s2_encode_block) */
     KC_OPT_LAST_PRESCAN_UNITS = 102, /* read-only: units of the last batch the pre-scan settled */
     KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
     KC_OPT_LAST_BATCHES = 101        /* read-only: device batches the last kc_zstd_encode_units_dev / kc_s2_encode_*_dev call was cut into */
@@ -326,10 +332,20 @@ kc_status kc_zstd_decode_units_dict_dev(kc_ctx* ctx, const uint8_t* d_enc, const
  * context.  Concurrent callers are micro-batched: the blocks that arrive while the previous batch is on the device share
  * one H2D copy, one kernel launch and one D2H copy (pinned staging; KC_S2_HOOK_WAIT_US adds an optional collection window,
  * KC_S2_HOOK_BATCH caps the blocks per launch, default 256).  A context serving this hook must not be used for other calls
- * at the same time. */
+ * at the same time.
+ * Host first (round 6): one block through the device takes ~3 ms (copy in, one wave on one CU, copy out) where the reference's own
+ * encoder takes ~0.1 ms on a host core, so a caller the host could serve is never faster here (measured: 23 MB/s per lone caller,
+ * 669 MB/s at 64 callers against ~600 MB/s per core for the built-in encoder; profiles/r04_hook_bench_final.json).  The hook
+ * therefore answers -1 ("use the built-in encoder", writer.go:455-460) while fewer callers than the process has CPUs are busy
+ * encoding on the host — it books every caller it sends back as busy for the time the built-in encoder needs for that block
+ * (len / 500 MB/s) — and takes only the overflow: callers that arrive while all CPUs are booked.  Wiring the hook is so never
+ * slower than not wiring it.  KC_OPT_S2_HOOK_HOST_FIRST: the number of callers left to the host (default: the CPUs the process may
+ * use), 0 = every caller to the device (what the parity tests and a CPU-starved host want). */
 int64_t kc_s2_encode_block(kc_ctx* ctx, uint8_t* dst, uint64_t dst_cap, const uint8_t* src, uint64_t src_len);
 /* hook diagnostics: calls served and device batches run on this context so far */
 void kc_s2_hook_stats(const kc_ctx* ctx, uint64_t* calls, uint64_t* batches);
+/* calls the hook answered -1 by the host-first rule (left to the caller's built-in encoder) */
+uint64_t kc_s2_hook_declined(const kc_ctx* ctx);
 
 /* ---- timing of the last call (HIP events recorded on the launch stream) ---- */
 typedef struct {

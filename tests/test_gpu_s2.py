@@ -145,6 +145,45 @@ def test_s2_custom_encoder_concurrent_callers(oracle, kclib, s2path):
     enc.Close()
 
 
+def test_s2_custom_encoder_host_first(oracle, kclib):
+    """Round 6: the hook leaves the callers the host can serve to the built-in encoder.  With host_first = 2 the
+    first two of four concurrent callers get -1 (booked as busy for len / 500 MB/s), the next ones go to the device and return the
+    oracle's bytes; once the bookings have expired the next callers are sent back again; host_first = 0 sends everyone to the device."""
+    import threading
+    import time
+    from compress_amd import s2
+    enc = s2.BlockEncoder()
+    blk = corpora.corpus("J", 1, 1 << 20).tobytes()  # 1 MiB: booked for ~2 ms
+    want = oracle.s2_encode_block(blk)
+    cap = s2.MaxEncodedLen(len(blk))
+    fn0 = enc.CustomEncoder(host_first=0)
+    dst = bytearray(cap)
+    n = fn0(dst, blk)
+    assert n > 0 and bytes(dst[:n]) == want  # warm: pinned staging, lanes
+    fn = enc.CustomEncoder(host_first=2)
+    res = [None] * 4
+    bar = threading.Barrier(4)
+
+    def worker(i):
+        d = bytearray(cap)
+        bar.wait()
+        r = fn(d, blk)
+        res[i] = bytes(d[:r]) if r > 0 else r
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert sorted(1 if r == -1 else 0 for r in res) == [0, 0, 1, 1], [r if isinstance(r, int) else len(r) for r in res]
+    assert all(r == want for r in res if r != -1)
+    assert enc._ctx.L.kc_s2_hook_declined(enc._ctx.h) == 2
+    time.sleep(0.02)  # the two bookings (2 ms each) have expired
+    assert fn(dst, blk) == -1 and fn(dst, blk) == -1
+    n = fn(dst, blk)  # both slots booked again: the third goes to the device
+    assert n > 0 and bytes(dst[:n]) == want
+    enc.Close()
+
+
 def test_s2_full_size_roundtrip(oracle, kclib, s2path):
     """C4-size property check: 16384 x 64 KiB JSON blocks, device resident, sample decodes back."""
     import torch
