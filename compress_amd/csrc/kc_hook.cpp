@@ -44,22 +44,14 @@ struct S2Hook {
     std::atomic<uint64_t> n_calls{0}, n_batches{0}, n_declined{0};
     // host first: the deadlines (steady clock, ns) until which the callers that were sent back to the built-in encoder are taken to be
     // busy with their block; ascending (equal block sizes) or nearly so — expired ones are dropped from the front
-    std::mutex hm;
-    std::deque<int64_t> host_busy;
     int host_cores = 1;
 
     bool init(const KcCfg& g, int device) {
         wait_us = (int)g.hook_wait_us;
-        host_cores = host_copy_threads() >= 16 ? (int)std::thread::hardware_concurrency() : host_copy_threads();  // (host_copy_threads: the cgroup's CPUs, capped at 16)
-        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char qs[32];
-            long long per = 0;
-            if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0 && per > 0) {
-                const long long lim = (atoll(qs) + per - 1) / per;
-                if (lim >= 1 && lim < host_cores) host_cores = (int)lim;
-            }
-            fclose(f);
-        }
+        // the hardware threads of the host, NOT the cgroup's CPU quota: measured on the GPU boxes (cpu.max = 16 CPUs of a 256-thread
+        // host), 64 callers of the built-in encoder reach 60 GB/s — the quota is not what bounds short bursts, and a caller sent to the
+        // device on its account was 3.5x slower than left alone (gpurun_out/r6o)
+        host_cores = (int)std::thread::hardware_concurrency();
         if (host_cores < 1) host_cores = 1;
         max_n = (uint32_t)std::max<int64_t>(1, g.hook_batch);
         n_lanes = (int)std::min<int64_t>(kMaxLanes, std::max<int64_t>(1, g.hook_lanes));
@@ -88,6 +80,48 @@ struct S2Hook {
 };
 
 void s2_hook_free(void* h) { delete (S2Hook*)h; }
+
+// Host-first bookkeeping, process-wide (the host's hardware threads are one pool whatever the number of hooks).  A thread that was
+// sent back to the built-in encoder holds a booking until it calls again (then it has finished that block) or until the time a slow
+// core needs for the block has passed (2 ns per byte = 500 MB/s; the reference's assembly encoder does 1.2 GB/s on JSON).  The common
+// case — a booked thread back for its next block — touches only the thread's own record: 64 callers make ~10^6 calls per second
+// together, and one mutex for them cost a third of the built-in encoder's rate (gpurun_out/r6o).  Expired bookings of threads that
+// never came back are reclaimed by the first caller that finds every place taken.
+struct HostBooking {
+    std::atomic<int64_t> deadline{0};
+    std::atomic<bool> booked{false};
+};
+static std::atomic<int64_t> g_host_booked{0};
+static std::mutex g_host_reg_m;
+static std::vector<HostBooking*> g_host_reg;  // every thread's record (never freed: a few bytes per thread that ever called a hook)
+
+static bool host_first_book(int64_t places, uint64_t src_len) {
+    thread_local HostBooking* tb = nullptr;
+    if (!tb) {
+        tb = new HostBooking();
+        std::lock_guard<std::mutex> g(g_host_reg_m);
+        g_host_reg.push_back(tb);
+    }
+    const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    const int64_t until = now + (int64_t)src_len * 2;
+    if (tb->booked.load(std::memory_order_relaxed)) { tb->deadline.store(until, std::memory_order_relaxed); return true; }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (g_host_booked.fetch_add(1, std::memory_order_acq_rel) < places) {
+            tb->deadline.store(until, std::memory_order_relaxed);
+            tb->booked.store(true, std::memory_order_release);
+            return true;
+        }
+        g_host_booked.fetch_sub(1, std::memory_order_acq_rel);
+        if (attempt) break;
+        int64_t freed = 0;
+        std::lock_guard<std::mutex> g(g_host_reg_m);
+        for (HostBooking* b : g_host_reg)
+            if (b != tb && b->booked.load(std::memory_order_acquire) && b->deadline.load(std::memory_order_relaxed) <= now && b->booked.exchange(false)) freed++;
+        if (freed) g_host_booked.fetch_sub(freed, std::memory_order_acq_rel);
+        else break;
+    }
+    return false;  // every place is taken by a thread that is (taken to be) encoding on the host: this caller is the overflow
+}
 
 // one slot through the device: pinned input -> tmp_src, N x s2.Encode, tmp_dst -> pinned output
 kc_status s2_hook_run(kc_ctx* c, S2Hook::Slot& sl) {
@@ -122,19 +156,10 @@ int64_t kc_s2_encode_block(kc_ctx* c, uint8_t* dst, uint64_t dst_cap, const uint
     });
     S2Hook* h = (S2Hook*)c->hook;
     if (!h) return -1;
-    h->n_calls++;
-    {   // host first (include/kcgpu.h): while the host has a CPU that is not booked, the built-in encoder serves the caller faster
+    h->n_calls.fetch_add(1, std::memory_order_relaxed);
+    {   // host first (include/kcgpu.h): while the host has a hardware thread that is not booked, the built-in encoder serves the caller faster
         const int64_t hf = c->cfg.hook_host_first < 0 ? h->host_cores : c->cfg.hook_host_first;
-        if (hf > 0) {
-            const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-            std::lock_guard<std::mutex> g(h->hm);
-            while (!h->host_busy.empty() && h->host_busy.front() <= now) h->host_busy.pop_front();
-            if ((int64_t)h->host_busy.size() < hf) {
-                h->host_busy.push_back(now + (int64_t)src_len * 2);  // 500 MB/s = 2 ns per byte: the built-in encoder's rate on text-like input
-                h->n_declined++;
-                return -1;
-            }
-        }
+        if (hf > 0 && host_first_book(hf, src_len)) { h->n_declined.fetch_add(1, std::memory_order_relaxed); return -1; }
     }
     std::unique_lock<std::mutex> lk(h->m);
     S2Hook::Slot* sl = nullptr;

@@ -103,7 +103,7 @@ struct KcCfg {
     int64_t k2_prof = 0;
     int64_t hook_wait_us = 0, hook_batch = 256, hook_lanes = 4;
     int64_t hook_host_first = -1;         // kc_s2_encode_block: callers the host's built-in encoder is assumed to serve at a time (they get -1, "use the built-in");
-                                          // only callers beyond that go to the device.  -1: the CPUs this process may run on; 0: every caller to the device
+                                          // only callers beyond that go to the device.  -1: the host's hardware threads; 0: every caller to the device
     int64_t test_feed_redo = 0;           // diagnostics: force the chunk-fed path's re-encode fallback
     int64_t better_dict_epoch = 0;        // SpeedBetterCompression with a dictionary: epoch-stamped tables + shared dictionary table instead of the per-batch copy
     int64_t s2_variant = 0;               // S2 levels 0 / 2: 0 = the portable Go encoders' bytes, 1 = the amd64 assembly encoders' bytes

@@ -192,7 +192,7 @@ typedef enum {
     KC_OPT_STAGE2_STREAM = 31,       /* (no variable)             a hipStream_t handle (0: none): kc_zstd_encode_units_dev[_begin/_end] run the entropy stage and everything behind it on this stream, behind an event of the match finder's — for callers that give the two stages different CU masks (hipExtStreamCreateWithCUMask) */
     KC_OPT_HOST_ROLL = 33,           /* KC_HOST_ROLL              host-buffer entry points, large inputs: 1 (default) = the device's rolling pipeline (sub-batches of all calls in flight staged, encoded on four lanes and drained in arrival order: consecutive calls overlap), 0 = one chunk-fed device batch per call (round 5) */
     KC_OPT_HOST_ROLL_MIB = 34,       /* KC_HOST_ROLL_MIB          rolling pipeline: sub-batch size (0: a quarter of the call's input, 64 MiB .. 1 GiB) */
-    KC_OPT_S2_HOOK_HOST_FIRST = 35,  /* KC_S2_HOOK_HOST_FIRST     kc_s2_encode_block: how many callers at a time are left to the host's built-in encoder (they get -1) before the overflow goes to the device: -1 (default) the CPUs this process may run on, 0 every caller to the device (see kc_s2_encode_block) */
+    KC_OPT_S2_HOOK_HOST_FIRST = 35,  /* KC_S2_HOOK_HOST_FIRST     kc_s2_encode_block: how many callers at a time are left to the host's built-in encoder (they get -1) before the overflow goes to the device: -1 (default) the host's hardware threads, 0 every caller to the device (see kc_s2_encode_block) */
     KC_OPT_LAST_PRESCAN_UNITS = 102, /* read-only: units of the last batch the pre-scan settled */
     KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */
     KC_OPT_LAST_BATCHES = 101        /* read-only: device batches the last kc_zstd_encode_units_dev / kc_s2_encode_*_dev call was cut into */
@@ -336,11 +336,13 @@ kc_status kc_zstd_decode_units_dict_dev(kc_ctx* ctx, const uint8_t* d_enc, const
  * Host first (round 6): one block through the device takes ~3 ms (copy in, one wave on one CU, copy out) where the reference's own
  * encoder takes ~0.1 ms on a host core, so a caller the host could serve is never faster here (measured: 23 MB/s per lone caller,
  * 669 MB/s at 64 callers against ~600 MB/s per core for the built-in encoder; profiles/r04_hook_bench_final.json).  The hook
- * therefore answers -1 ("use the built-in encoder", writer.go:455-460) while fewer callers than the process has CPUs are busy
- * encoding on the host — it books every caller it sends back as busy for the time the built-in encoder needs for that block
- * (len / 500 MB/s) — and takes only the overflow: callers that arrive while all CPUs are booked.  Wiring the hook is so never
- * slower than not wiring it.  KC_OPT_S2_HOOK_HOST_FIRST: the number of callers left to the host (default: the CPUs the process may
- * use), 0 = every caller to the device (what the parity tests and a CPU-starved host want). */
+ * therefore answers -1 ("use the built-in encoder", writer.go:455-460) while fewer callers than the host has hardware threads are
+ * busy encoding on the host — it books every caller it sends back as busy until that thread calls again, or for the time a slow core
+ * needs for the block (len / 500 MB/s) — and takes only the overflow: callers that arrive while every hardware thread is booked.
+ * Wiring the hook is so never slower than not wiring it (tools/hook_bench.cpp, profiles/r06_hook_bench.json: within 4 % of the
+ * built-in encoder at 1 / 4 / 16 / 64 callers; forced to the device 23 / 92 / 265 / 630 MB/s against 1 250 / 4 970 / 19 400 /
+ * 60 000).  KC_OPT_S2_HOOK_HOST_FIRST: the number of callers left to the host (default: its hardware threads), 0 = every caller to
+ * the device (what the parity tests and a host without spare CPUs want). */
 int64_t kc_s2_encode_block(kc_ctx* ctx, uint8_t* dst, uint64_t dst_cap, const uint8_t* src, uint64_t src_len);
 /* hook diagnostics: calls served and device batches run on this context so far */
 void kc_s2_hook_stats(const kc_ctx* ctx, uint64_t* calls, uint64_t* batches);

@@ -1009,6 +1009,40 @@ def test_host_rolling_pipeline_two_callers(oracle, kclib, monkeypatch):
         e.Close()
 
 
+def test_trim_gives_memory_back_and_the_next_call_is_the_same(oracle, kclib, monkeypatch):
+    """kc_ctx_trim / kc_device_trim: a context's scratch and the rolling pipeline's slots and lane scratch are freed (device memory
+    in use drops), the handles stay usable and the next calls produce the same bytes; a trim while a submitted call is in flight is
+    refused."""
+    torch = _torch()
+    from compress_amd import _lib
+    monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_ROLL_MIB", "4")
+    n, usz = 256, 131072
+    buf = corpora.corpus("T", n, usz)
+    off = np.arange(n + 1, dtype=np.uint64) * usz
+    enc = _enc(1)
+    out, out_off = enc.EncodeUnits(buf, off)  # through the rolling pipeline: slots + lanes allocated
+    d_src = torch.from_numpy(buf).cuda()
+    cap = n * ((enc.MaxEncodedSize(usz) + 15) & ~15) + 64
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    dev_off = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)  # the context's own scratch allocated
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    enc.ctx().trim()
+    _lib.device_trim(0)
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 > free0 + (32 << 20), (free0, free1)
+    out2, out_off2 = enc.EncodeUnits(buf, off)
+    assert np.array_equal(out2, out) and np.array_equal(out_off2, out_off)
+    dev_off2 = enc.EncodeUnitsDevice(d_src.data_ptr(), off, d_dst.data_ptr(), cap)
+    assert np.array_equal(dev_off2, dev_off) and np.array_equal(d_dst[:int(dev_off[n])].cpu().numpy(), out)
+    enc.EncodeUnitsSubmit(buf, off)
+    with pytest.raises(_lib.KcError):
+        enc.ctx().trim()
+    enc.Wait()
+    enc.Close()
+
+
 def test_many_small_units_fit_the_scratch_budget(oracle, kclib):
     """A batch of many small units needs scratch per unit and per block, not per input byte (tables 640 KiB per unit at
     SpeedDefault): batches are cut by a scratch budget instead of asking hipMalloc for hundreds of GiB."""
