@@ -209,9 +209,12 @@ class Context:
         for name, key in self._ENV_OPTS:
             v = os.environ.get(name)
             if v not in (None, ""):
-                self.set_option(key, int(v))
+                try:
+                    self.set_option(key, int(v))
+                except (ValueError, KcError) as e:  # say WHICH variable
+                    raise ValueError("environment variable %s=%r is not a valid value of option %d: %s" % (name, v, key, e)) from None
         for name, key in self._ENV_FLAGS:
-            if os.environ.get(name) is not None:
+            if os.environ.get(name) not in (None, "", "0"):  # '0' and the empty string mean off
                 self.set_option(key, 1)
         v = os.environ.get("KC_HOST_CHUNKS_MIB")
         if v:

@@ -16,7 +16,12 @@
 
 // Wave-wide scans and reductions on the DPP data path (row shifts inside the 16-lane rows, then the row_bcast:15 / row_bcast:31
 // steps across rows): six dependent VALU operations, where __shfl_up / __shfl_xor compile to six dependent ds_bpermute round trips
-// through the LDS crossbar.  All 64 lanes must be active (every caller is in wave-uniform control flow).
+// through the LDS crossbar.  The scans / reductions below need all 64 lanes active (their callers are in wave-uniform control flow).
+// kc_dpp_or0 alone is also used under DIVERGENT control flow by the match finders' dependency checks (kc_zstd_match.hip,
+// kc_zstd_match_dfast.hip: inside the per-group `while (!fin)` loops, where whole 8-lane groups are masked off): a row_shr:d read
+// by a lane with lig >= d stays inside that lane's own group, which is active as a whole; what lanes with lig < d receive comes
+// from another group (possibly inactive: then 0, bound_ctrl) and is never looked at (`lig >= d &&` guards every use).  A DPP read
+// from an inactive lane is not an error on the hardware — it yields the old value / 0 — so the guard is what makes it correct.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t kc_dpp_or0(uint32_t v) {  // the DPP-selected lane's v, 0 where there is none
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
