@@ -246,7 +246,7 @@ def main():
                          "per-GPU sizes, one child process each) after the timed region and attach them as \"also\"")
     ap.add_argument("--also-steps", type=int, default=3)
     ap.add_argument("--path", default="auto", choices=["auto", "hbm", "lds"], help="kernel family of SpeedFastest / s2.Encode (KC_OPT_MATCH_PATH)")
-    ap.add_argument("--e2e-calls", type=int, default=3, help="end_to_end steady state: host-buffer calls kept in flight (contexts used with submit / wait)")
+    ap.add_argument("--e2e-calls", type=int, default=4, help="end_to_end steady state: host-buffer calls kept in flight (contexts used with submit / wait)")
     ap.add_argument("--e2e-steps", type=int, default=12, help="end_to_end steady state: batches timed")
     args = ap.parse_args()
     if args.contexts == 1:
