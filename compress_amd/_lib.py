@@ -42,7 +42,7 @@ SYMBOLS = [
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts", "kc_zstd_encode_units_submit", "kc_s2_encode_blocks_lvl_submit", "kc_wait", "kc_zstd_plan_stream_blocks", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
     "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats", "kc_s2_encode_blocks_lvl", "kc_s2_encode_blocks_lvl_dev", "kc_s2_encode_stream_lvl_dev",
     "kc_last_timings", "kc_corpus_fill", "kc_ctx_set_option", "kc_ctx_get_option", "kc_zstd_encode_jobs", "kc_zstd_job_size", "kc_zstd_overlap_size",
-    "kc_probe_table_pattern", "kc_probe_pcie", "kc_ctx_trim", "kc_device_trim", "kc_s2_hook_declined", "kc_create_error",
+    "kc_probe_table_pattern", "kc_probe_pcie", "kc_ctx_trim", "kc_device_trim", "kc_s2_hook_declined", "kc_create_error", "kc_host_alloc", "kc_host_free",
 ]
 
 # kc_option / KC_PATH_* (include/kcgpu.h)
@@ -166,6 +166,10 @@ def load():
     L.kc_ctx_get_option.restype = C.c_int64
     L.kc_s2_hook_declined.argtypes = [vp]
     L.kc_s2_hook_declined.restype = C.c_uint64
+    L.kc_host_alloc.argtypes = [C.POINTER(vp), u64]
+    L.kc_host_alloc.restype = C.c_int
+    L.kc_host_free.argtypes = [vp]
+    L.kc_host_free.restype = None
     L.kc_create_error.argtypes = []
     L.kc_create_error.restype = C.c_char_p
     L.kc_ctx_trim.argtypes = [vp]
@@ -280,6 +284,32 @@ class Context:
         self.check(self.L.kc_last_timings(self.h, C.byref(t)))
         return {"total_ms": t.total_ms, "match_ms": t.match_ms, "entropy_ms": t.entropy_ms, "other_ms": t.other_ms,
                 "redo_units": t.redo_units, "prep_ms": t.prep_ms}
+
+
+class PinnedBuffer:
+    """kc_host_alloc: page-locked host memory as a numpy uint8 array (`.a`); the host-buffer entry points DMA straight from / into it."""
+
+    def __init__(self, nbytes):
+        import numpy as np
+        self.L = load()
+        p = C.c_void_p()
+        st = self.L.kc_host_alloc(C.byref(p), int(nbytes))
+        if st != KC_OK:
+            raise KcError(st, "kc_host_alloc(%d)" % nbytes)
+        self.p = p
+        self.a = np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(p.value))
+
+    def free(self):
+        if getattr(self, "p", None):
+            self.a = None
+            self.L.kc_host_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def device_trim(device=0):

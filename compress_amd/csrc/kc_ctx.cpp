@@ -329,6 +329,17 @@ kc_status kc_ctx_trim(kc_ctx* c) {
 
 kc_status kc_device_trim(int device) { return kci::host_roll_trim(device); }
 
+kc_status kc_host_alloc(void** out, uint64_t bytes) {
+    if (!out || bytes == 0) return KC_ERR_BAD_ARG;
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return e == hipErrorOutOfMemory ? KC_ERR_UNSUPPORTED : KC_ERR_HIP; }
+    return KC_OK;
+}
+void kc_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 void kc_ctx_destroy(kc_ctx* c) {
     if (!c) return;
     if (c->job_active && c->job.joinable()) c->job.join();

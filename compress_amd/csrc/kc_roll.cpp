@@ -54,6 +54,7 @@ struct RollCall {
     std::string err;
     int last_path = 0;
     bool trace = false;
+    bool src_pinned = false, dst_pinned = false;  // the caller's buffers are page-locked (kc_host_alloc / hipHostMalloc / hipHostRegister): DMA straight from / into them
     std::chrono::steady_clock::time_point t0;
     double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
@@ -174,6 +175,9 @@ struct RollEngine {
                 hipError_t e = hipSuccess;
                 if (s == KC_OK) {
                     const int Tc = c->owner->cfg.host_copy_threads >= 1 ? host_copy_threads(c->owner) : T;
+                    if (c->src_pinned) {  // no staging copy: one DMA from the caller's pinned pages
+                        e = hipMemcpyAsync(S.in.p, c->src + a0, (size_t)(a1 - a0), hipMemcpyHostToDevice, s_h2d);
+                    } else
                     for (uint64_t a = a0; a < a1 && e == hipSuccess; a += kPiece, n_in++) {
                         const uint64_t len = std::min(kPiece, a1 - a);
                         if (n_in >= 2) e = hipEventSynchronize(ev_in[n_in & 1]);
@@ -265,8 +269,12 @@ struct RollEngine {
                 } else {
                     for (uint32_t i = 0; i <= nu; i++) c->out_off[u0 + i] = c->pos + j->oo[i];
                     const int Tc = c->owner->cfg.host_copy_threads >= 1 ? host_copy_threads(c->owner) : T;
-                    // device -> pinned -> dst in pieces, the DMA of a piece under the host copy of the one before
+                    // device -> pinned -> dst in pieces, the DMA of a piece under the host copy of the one before (a pinned dst: one DMA)
                     hipError_t e = hipSuccess;
+                    if (c->dst_pinned) {
+                        if (L) e = hipMemcpyAsync(c->dst + c->pos, S.out.p, (size_t)L, hipMemcpyDeviceToHost, s_d2h);
+                        if (e == hipSuccess) e = hipStreamSynchronize(s_d2h);
+                    } else {
                     uint64_t q_off[2] = {0, 0}, q_len[2] = {0, 0};
                     size_t n_sub = 0, n_ret = 0;
                     auto retire = [&] {
@@ -286,6 +294,7 @@ struct RollEngine {
                         n_sub++;
                     }
                     while (n_ret < n_sub && e == hipSuccess) retire();
+                    }
                     if (e != hipSuccess) {
                         (void)hipStreamSynchronize(s_d2h);
                         std::lock_guard<std::mutex> lk(m);
@@ -372,6 +381,17 @@ kc_status host_rolling(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off, 
     call.out_off = out_off;
     call.trace = c->cfg.host_trace != 0;
     call.t0 = std::chrono::steady_clock::now();
+    {   // page-locked caller buffers need no staging copies (hipPointerGetAttributes fails on ordinary memory: that is the answer "no")
+        auto pinned = [](const void* p, uint64_t len) {
+            hipPointerAttribute_t a0, a1;
+            if (len == 0) return false;
+            if (hipPointerGetAttributes(&a0, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipPointerGetAttributes(&a1, (const uint8_t*)p + len - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+            return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost;
+        };
+        call.src_pinned = pinned(src + unit_off[0], unit_off[n_units] - unit_off[0]);
+        call.dst_pinned = pinned(dst, dst_cap);
+    }
     const uint64_t total = unit_off[n_units] - unit_off[0];
     const uint64_t sub = host_roll_sub_bytes(c, total);
     call.cut.push_back(0);

@@ -127,6 +127,12 @@ const char* kc_create_error(void);
  * KC_ERR_BAD_ARG while host-buffer calls are in flight on that device, KC_OK when the pipeline never started. */
 kc_status kc_ctx_trim(kc_ctx* ctx);
 kc_status kc_device_trim(int device);
+/* Page-locked host memory for callers that own their buffers (a Go caller: C memory wrapped in a slice with unsafe.Slice).  The
+ * host-buffer entry points recognise page-locked source / destination buffers — these, hipHostMalloc'ed or hipHostRegister'ed ones —
+ * and DMA straight from / into them: the rolling pipeline's staging copies (16 host threads at ~100 GB/s while a call runs) are not
+ * made at all.  Pageable buffers work as before.  kc_host_alloc: KC_ERR_UNSUPPORTED when the host cannot lock that much memory. */
+kc_status kc_host_alloc(void** out, uint64_t bytes);
+void kc_host_free(void* p);
 const char* kc_last_error(const kc_ctx* ctx);
 /* ONE stream with WithConcurrentBlocks(true) (zstd/encoder_options.go:340-353; zstd/enc_jobs.go): the bytes equal
  *   enc, _ := zstd.NewWriter(w, opts..., zstd.WithConcurrentBlocks(true))   (with WithEncoderConcurrency > 1)

@@ -1009,6 +1009,33 @@ def test_host_rolling_pipeline_two_callers(oracle, kclib, monkeypatch):
         e.Close()
 
 
+def test_host_rolling_pipeline_with_pinned_caller_buffers(oracle, kclib, monkeypatch):
+    """kc_host_alloc: page-locked source and destination buffers are recognised by the host-buffer entry points and used for the
+    DMA directly (no staging copies); pinned source + pageable destination and the reverse work too.  Same bytes as pageable."""
+    _torch()
+    import ctypes as C
+    from compress_amd import _lib
+    monkeypatch.setenv("KC_HOST_OVERLAP_MIN_MIB", "1")
+    monkeypatch.setenv("KC_HOST_ROLL_MIB", "6")
+    n, usz = 320, 131072
+    buf = corpora.corpus("M", n, usz)
+    off = np.arange(n + 1, dtype=np.uint64) * usz
+    enc = _enc(1)
+    want, want_off = enc.EncodeUnits(buf, off)
+    cap = n * ((enc.MaxEncodedSize(usz) + 15) & ~15) + 64
+    psrc, pdst = _lib.PinnedBuffer(buf.size), _lib.PinnedBuffer(cap)
+    psrc.a[:] = buf
+    ctx = enc.ctx()
+    for src_a, dst_a in ((psrc.a, pdst.a), (psrc.a, np.zeros(cap, dtype=np.uint8)), (buf, pdst.a)):
+        eo = np.zeros(n + 1, dtype=np.uint64)
+        dst_a[:int(want_off[n])] = 0
+        ctx.check(ctx.L.kc_zstd_encode_units(ctx.h, C.byref(enc.o), src_a.ctypes.data, off.ctypes.data, n, dst_a.ctypes.data, cap, eo.ctypes.data))
+        assert np.array_equal(eo, want_off) and np.array_equal(dst_a[:int(eo[n])], want)
+    enc.Close()
+    psrc.free()
+    pdst.free()
+
+
 def test_trim_gives_memory_back_and_the_next_call_is_the_same(oracle, kclib, monkeypatch):
     """kc_ctx_trim / kc_device_trim: a context's scratch and the rolling pipeline's slots and lane scratch are freed (device memory
     in use drops), the handles stay usable and the next calls produce the same bytes; a trim while a submitted call is in flight is

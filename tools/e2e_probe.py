@@ -24,6 +24,7 @@ def main():
     trace = "--trace" in sys.argv
     only_two = "--only-two" in sys.argv  # skip the single calls (kernel-trace runs of the steady state)
     nctx = int(sys.argv[sys.argv.index("--ctx") + 1]) if "--ctx" in sys.argv else 2  # calls kept in flight in the steady state
+    pinned = "--pinned" in sys.argv  # source and destinations in page-locked memory (kc_host_alloc): no staging copies
     configs = args or ["C2"]
     ctx = _lib.Context(0)
     print(json.dumps({"probe_pcie": ctx.probe_pcie(1 << 30)}), flush=True)
@@ -34,6 +35,10 @@ def main():
         n = int(cfg["gib"] * (1 << 30)) // usz
         kind = cfg["kind"]
         buf = _lib.corpus_fill(kind, bench.SEEDS[kind], 0, n, usz)
+        if pinned:
+            keep = [_lib.PinnedBuffer(buf.size)]
+            keep[0].a[:] = buf
+            buf = keep[0].a
         off = np.arange(n + 1, dtype=np.uint64) * usz
         is_s2 = cfg["codec"] == "s2"
         if is_s2:
@@ -46,7 +51,11 @@ def main():
             encs = [zstd.NewWriter(None, *zo, device=0) for _ in range(nctx)]
             slot = (encs[0].MaxEncodedSize(usz) + 15) & ~15
         cap = n * slot + 64
-        dsts = [np.zeros(cap, dtype=np.uint8) for _ in range(nctx)]
+        if pinned:
+            keep += [_lib.PinnedBuffer(cap) for _ in range(nctx)]
+            dsts = [k.a for k in keep[1:]]
+        else:
+            dsts = [np.zeros(cap, dtype=np.uint8) for _ in range(nctx)]
         offs = [np.zeros(n + 1, dtype=np.uint64) for _ in range(nctx)]
 
         def ctx_of(e):
@@ -117,7 +126,7 @@ def main():
         print(json.dumps({"config": name, "GiB": cfg["gib"], "ratio": round(int(ro[n]) / (n * usz), 4), "device_resident_ms": round(dev_ms, 2),
                           "device_resident_GBps": round(gb / dev_ms * 1e3, 2),
                           "one_call_ms": [round(x, 1) for x in one], "one_call_GBps": round(gb / min(one) * 1e3, 2),
-                          "calls_in_flight": nctx, "two_contexts_ms_per_batch": round(two_ms, 1), "two_contexts_GBps": round(gb / two_ms * 1e3, 2),
+                          "calls_in_flight": nctx, "pinned_buffers": pinned, "two_contexts_ms_per_batch": round(two_ms, 1), "two_contexts_GBps": round(gb / two_ms * 1e3, 2),
                           "frac_one_call": round(dev_ms / min(one), 3), "frac_two_contexts": round(dev_ms / two_ms, 3),
                           "same_bytes": same and same2}), flush=True)
         for e in encs:
