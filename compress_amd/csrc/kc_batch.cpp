@@ -427,20 +427,37 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
             (s = ensure(c, c->dictbuf, (size_t)hist0 + 64)) || (s = ensure(c, c->proto, kc_zbetter_table_bytes())))
             return s;
         HIPCHK(c, hipMemcpyAsync(c->work_off.p, woff.data(), (n_units + 1) * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->dictbuf.p, o->dict, (size_t)hist0, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));  // woff is a local
+        // The dictionary's content and its pristine tables (betterFastEncoderDict.Reset, enc_better.go:1114-1183, in the device entry
+        // format) are the same from batch to batch: rebuilt and uploaded only when the dictionary, the level, the position width or the
+        // stamp mode changed (round 6: the rolling host pipeline runs a batch per 256 MiB — 4 MiB of host table building, two uploads
+        // and a stream synchronisation per batch before).
+        const bool epochMode = better_epoch_mode(c, o->level, pos_bits, hist0);
+        uint64_t key = 0xcbf29ce484222325ULL;
+        for (int i = 0; i < hist0; i++) key = (key ^ o->dict[i]) * 0x100000001b3ULL;
+        key ^= ((uint64_t)(uint32_t)hist0 << 32) ^ ((uint64_t)o->level << 8) ^ ((uint64_t)pos_bits << 16) ^ (epochMode ? (uint64_t)1 << 24 : 0);
+        if (key == 0) key = 1;
+        const size_t tbz = kc_zbetter_table_bytes();
+        if (c->proto_key != key || c->proto_ptr != c->proto.p || c->dictbuf_ptr != c->dictbuf.p) {
+            c->proto_key = 0;
+            HIPCHK(c, hipMemcpyAsync(c->dictbuf.p, o->dict, (size_t)hist0, hipMemcpyHostToDevice, st));
+            std::vector<uint8_t> proto(tbz, 0);
+            if (o->level == KC_SPEED_BEST) { /* the kernel indexes the dictionary itself, per unit (bestFastEncoder.Reset) */ }
+            else if (o->level == KC_SPEED_BETTER) {
+                build_better_dict_tables(o->dict, (size_t)hist0, pos_bits, proto.data(), epochMode ? 4 : 0);
+            } else if (o->level == KC_SPEED_DEFAULT) {
+                build_dfast_dict_long(o->dict, (size_t)hist0, pos_bits, (uint32_t*)proto.data());
+                build_fast_dict_table(o->dict, (size_t)hist0, pos_bits, (uint32_t*)(proto.data() + ((size_t)4 << 17)));
+            } else build_fast_dict_table(o->dict, (size_t)hist0, pos_bits, (uint32_t*)proto.data());
+            HIPCHK(c, hipMemcpyAsync(c->proto.p, proto.data(), proto.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));  // proto and woff are locals
+            c->proto_key = key;
+            c->proto_ptr = c->proto.p;
+            c->dictbuf_ptr = c->dictbuf.p;
+        } else {
+            HIPCHK(c, hipStreamSynchronize(st));  // woff is a local
+        }
         kc_launch_prefix_units(d_src, (const uint64_t*)c->unit_off.p, (const uint64_t*)c->work_off.p, (const uint8_t*)c->dictbuf.p,
                                (uint32_t)hist0, (uint8_t*)c->work.p, n_units, st);
-        // pristine dictionary tables (betterFastEncoderDict.Reset, enc_better.go:1114-1183) in the device entry format
-        std::vector<uint8_t> proto(kc_zbetter_table_bytes(), 0);
-        if (o->level == KC_SPEED_BEST) { /* the kernel indexes the dictionary itself, per unit (bestFastEncoder.Reset) */ }
-        else if (o->level == KC_SPEED_BETTER) build_better_dict_tables(o->dict, (size_t)hist0, pos_bits, proto.data(), better_epoch_mode(c, o->level, pos_bits, hist0) ? 4 : 0);
-        else if (o->level == KC_SPEED_DEFAULT) {
-            build_dfast_dict_long(o->dict, (size_t)hist0, pos_bits, (uint32_t*)proto.data());
-            build_fast_dict_table(o->dict, (size_t)hist0, pos_bits, (uint32_t*)(proto.data() + ((size_t)4 << 17)));
-        } else build_fast_dict_table(o->dict, (size_t)hist0, pos_bits, (uint32_t*)proto.data());
-        HIPCHK(c, hipMemcpyAsync(c->proto.p, proto.data(), proto.size(), hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));
         k_src = (const uint8_t*)c->work.p;
         k_off = (const uint64_t*)c->work_off.p;
     }

@@ -309,6 +309,7 @@ static void ctx_free_scratch(kc_ctx* c) {
     c->tab_ptr = nullptr;
     c->tab_units = c->tab_ep = 0;
     c->proto_key = 0;
+    c->proto_ptr = c->dictbuf_ptr = nullptr;
     c->best_n = 0;
     c->probe_bs = 0;
     c->probe_n = 0;

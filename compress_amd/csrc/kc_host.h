@@ -146,6 +146,8 @@ struct kc_ctx {
     uint32_t tab_units = 0, tab_ep = 0, better_epoch_now = 0, fast_epoch_now = 0;  // (tab_owner 2: SpeedFastest tables, kc_zstd_match.hip)
     void* tab_ptr = nullptr;
     uint64_t proto_key = 0;     // the dictionary tables in c->proto were built for this (content hash, level, position bits, stamp mode)
+    void* proto_ptr = nullptr;  // ... in these allocations (a re-grown buffer is rebuilt)
+    void* dictbuf_ptr = nullptr;
     DevBuf best_tables, best_cur, best_cost;  // SpeedBestCompression: persistent table slots, their position-space counters, the bit costs
     uint32_t best_n = 0;                      // slots allocated (and zeroed) so far
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [6]: batch prepared (chunk-fed launches wait on it); [7]: tables prepared

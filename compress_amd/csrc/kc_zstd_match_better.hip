@@ -30,7 +30,8 @@ static_assert(ZBG <= 32, "group ballots are 32-bit");
 // into them — for every batch is 33 GB of writes per GiB of input (7.7 ms of a 68 ms step).  With P.epoch != 0 the top ZB_EPOCH_BITS
 // bits of a long entry's `offset` word and of a short entry carry the stamp of the launch that wrote it: an entry with another
 // stamp is one left by an earlier launch and reads as the dictionary's entry for that bucket (a shared, read-only table that
-// stays in L2) or as empty.  The host advances the stamp per launch and clears the arena only when it wraps, when the position
+// stays in L2) or as empty (round 6 also tried a 64 KiB map of the buckets the dictionary fills in front of the shared table: slower
+// still, profiles/r06_ab_kernels.txt).  The host advances the stamp per launch and clears the arena only when it wraps, when the position
 // width changes or when the arena was used by something else.  `prev` words are stored resolved and unstamped: they are only read
 // together with a valid `offset` word.  P.epoch == 0 is the old contract (tables fully initialised by the host): jobs, whose
 // tables the host primes per unit, and units too long for the stamp to fit.
