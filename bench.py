@@ -252,7 +252,11 @@ def main():
     if args.contexts == 1:
         ap.error("--contexts counts the contexts of the two-stage pipeline (2 or 3); for one context with steps back to back use --no-pipeline")
     if args.pipeline is None:
-        args.pipeline = args.config == "C2"
+        # C2 since round 4; C3 and C5 since round 6 (same-box A/B, gpurun_out/r6w: C3 272.3 -> 266.8 ms per step with two contexts,
+        # C5 64.4 -> 63.2 with three; C2H / B4 lose, S2 has no second stage)
+        args.pipeline = args.config in ("C2", "C3", "C5")
+        if args.config == "C5" and args.contexts == 0:
+            args.contexts = 3
     cfg = dict(CONFIGS[args.config])
     if args.gib is not None:
         cfg["gib"] = args.gib

@@ -426,6 +426,9 @@ kc_status host_rolling(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off, 
     c->last_path = call.last_path;
     c->last_batches = (int)nsub;
     if (call.fail) {
+        // device memory exhausted in a lane or a slot (eight lanes' scratch is more than one context's): not an error of the request —
+        // the caller's older paths (one context, smaller footprint) serve the call, and only if they cannot does it go back to the host
+        if (call.st == KC_ERR_UNSUPPORTED) { c->err.clear(); return KC_ERR_UNSUPPORTED; }
         c->err = call.err;
         return call.st;
     }
