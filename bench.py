@@ -604,6 +604,8 @@ def main():
             del d_dsts, d_dst, d_src  # the timed region's buffers: the host path brings its own
             d_dsts = d_dst = d_src = None
             torch.cuda.empty_cache()
+            for e_ in encs:  # the timed region's contexts keep their handles; their device scratch (tens of GiB each) goes back: the
+                (e_._ctx if is_s2 else e_.ctx()).trim()  # host path encodes on the rolling pipeline's own lanes
             pc = ctx0.probe_pcie(1 << 30)
             ncall = max(1, args.e2e_calls)
             if is_s2:
