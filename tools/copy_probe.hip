@@ -44,6 +44,36 @@ __global__ __launch_bounds__(256) void k_flat4(const uint8_t* __restrict__ src, 
     for (; i < n16; i += stride) st128u(dst + (i << 4) + mis, *(const uint4*)(src + (i << 4)));
 }
 
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+// N: flat copies with non-temporal loads / stores (MODE bit 0: nt load, bit 1: nt store), grid-stride, U loads in flight per lane
+template <int MODE, int U>
+__global__ __launch_bounds__(256) void k_flat_nt(const v4u* __restrict__ src, v4u* __restrict__ dst, uint64_t n16) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        v4u v[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = (MODE & 1) ? __builtin_nontemporal_load(src + i + k * stride) : src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; k++) { if (MODE & 2) __builtin_nontemporal_store(v[k], dst + i + k * stride); else dst[i + k * stride] = v[k]; }
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+// C: every workgroup copies ONE contiguous chunk of the arena (chunk = n16 / gridDim.x words), U loads in flight per lane
+template <int MODE, int U>
+__global__ __launch_bounds__(256) void k_chunk(const v4u* __restrict__ src, v4u* __restrict__ dst, uint64_t n16) {
+    const uint64_t per = n16 / gridDim.x;
+    const v4u* s = src + (uint64_t)blockIdx.x * per;
+    v4u* d = dst + (uint64_t)blockIdx.x * per;
+    for (uint64_t i = threadIdx.x; i + (U - 1) * 256 < per; i += U * 256) {
+        v4u v[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = (MODE & 1) ? __builtin_nontemporal_load(s + i + k * 256) : s[i + k * 256];
+#pragma unroll
+        for (int k = 0; k < U; k++) { if (MODE & 2) __builtin_nontemporal_store(v[k], d + i + k * 256); else d[i + k * 256] = v[k]; }
+    }
+}
+
 // Q: the quad layout of kc_xxh64_fin_kernel: 4 lanes per unit, 16 units per wave, K loads of 16 bytes in flight per lane.
 // HASH: the XXH64 rounds (each lane hashes its own words: the same ALU work, no quad permutes).  FRAME: the frame layout (else a
 // plain unit -> unit copy, aligned).
@@ -163,6 +193,11 @@ int main(int argc, char** argv) {
         snprintf(nm, sizeof nm, "flat4 dst+12 grid=%d", grid);
         run(nm, [&] { hipLaunchKernelGGL(k_flat4, dim3(grid), dim3(256), 0, 0, src, dst, n16, 12); });
     }
+#define FNT(M, U, G) run("flat nt mode=" #M " U=" #U " grid=" #G, [&] { hipLaunchKernelGGL((k_flat_nt<M, U>), dim3(G), dim3(256), 0, 0, (const v4u*)src, (v4u*)dst, n16); })
+#define CHK(M, U, G) run("chunk mode=" #M " U=" #U " grid=" #G, [&] { hipLaunchKernelGGL((k_chunk<M, U>), dim3(G), dim3(256), 0, 0, (const v4u*)src, (v4u*)dst, n16); })
+    FNT(0, 4, 1024); FNT(0, 4, 2048); FNT(0, 4, 4096); FNT(0, 8, 2048);
+    FNT(1, 4, 2048); FNT(2, 4, 2048); FNT(3, 4, 2048); FNT(3, 4, 1024); FNT(3, 8, 2048); FNT(3, 4, 8192);
+    CHK(0, 4, 1024); CHK(0, 4, 2048); CHK(0, 4, 4096); CHK(0, 4, 16384); CHK(3, 4, 2048); CHK(3, 4, 16384); CHK(3, 8, 4096); CHK(0, 8, 65536); CHK(3, 4, 65536);
     const dim3 gq((n_units * 4 + 255) / 256);
 #define QUAD(K, H, F, P) run("quad K=" #K " hash=" #H " frame=" #F " pipe=" #P, [&] { hipLaunchKernelGGL((k_quad<K, H, F, P>), gq, dim3(256), 0, 0, src, dst, n_units, sink); })
     QUAD(4, false, false, false);
