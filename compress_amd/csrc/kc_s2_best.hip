@@ -1,4 +1,6 @@
-// kc_s2_best.hip — s2.EncodeBest / s2.EncodeSnappyBest on the device: one wave per block.
+// kc_s2_best.hip — s2.EncodeBest / s2.EncodeSnappyBest on the device: 16 lanes per block, four blocks per wave (round 6; one wave per
+// block before: at most 16 lanes of it ever had a candidate to score, and the 28 waves a CU holds were 28 blocks in flight on a kernel
+// that is three dependent round trips per input position — now 112).
 //
 // Replaces encodeBlockBest (s2/encode_best.go:22-455, dict == nil) and encodeBlockBestSnappy (:457-710) with their size
 // estimates (:715-797), behind s2.EncodeBest / s2.EncodeSnappyBest (s2/encode.go:146-202, 278-305).  The best level keeps, per
@@ -6,17 +8,26 @@
 // arena — scores up to five candidates at a position and, once one matches, up to eleven more at s+1, s+2 and behind the end of
 // the best match, and indexes every position of every match.
 //
-// Mapping: the control flow is wave-uniform (the sequential algorithm, state in scalar registers); the lanes are used where
+// Mapping: the control flow is uniform within a block's lane group (the sequential algorithm; the groups of a wave diverge freely);
+// the lanes are used where
 // the reference has independent work: every candidate of a phase is evaluated by its own lane (4-byte check, match extension,
 // score), the winner is then folded in the reference's order — including its "same offset as the current best: not retested"
 // rule, which is what makes the fold order-dependent —, literals are copied 8 bytes per lane, and the table updates after a
-// match take 64 positions per pass (positions whose bucket an earlier position of the pass also hits are applied afterwards, in
+// match take one position per lane and pass (positions whose bucket an earlier position of the pass also hits are applied afterwards, in
 // order: the {cur, prev} chain is order-dependent).  Tables are read and written with plain loads / stores: a wave's accesses to
 // one address are performed in program order.
 #include "kc_dev.h"
 #include "kc_kernels.h"
 #include "kc_s2_dev.h"
+#include "kc_wave.h"
 
+#ifndef SBG
+#define SBG 16          // lanes per block (64: the round-3 form, one wave per block — measurement builds)
+#endif
+static_assert(SBG == 16 || SBG == 64, "phase B holds nine candidates: at least 16 lanes per block; the duplicate test below is written for 16 and 64");
+#define SB_GMASK (SBG == 64 ? ~0ull : ((1ull << (SBG & 63)) - 1ull))
+__device__ __forceinline__ uint64_t sb_ballot(bool p, int grp) { return (ballot64(p) >> (grp * SBG)) & SB_GMASK; }
+__device__ __forceinline__ uint32_t sb_bcast32(uint32_t v, int grp, int k) { return (uint32_t)__shfl((int)v, grp * SBG + k, 64); }
 #define SB_LBITS 19
 #define SB_SBITS 16
 
@@ -68,23 +79,24 @@ struct SbMatch { int offset, s, length, score, rep; };
 
 template <bool SNAPPY>
 __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
-    const int lane = (int)threadIdx.x;
-    const uint32_t bi = blockIdx.x;
-    if (bi >= P.n_blocks) return;
+    const int wl = (int)threadIdx.x;                 // lane of the wave
+    const int lane = wl % SBG, grp = wl / SBG;       // lane of the block's group, group of the wave
+    const uint32_t bi = blockIdx.x * (64 / SBG) + (uint32_t)grp;
     __shared__ uint32_t crcT[4][256];
     if (P.framed) {  // s2.Writer chunks carry the masked CRC32C of the uncompressed block (slice-by-4 tables, as kc_s2_encode_kernel)
-        for (int i = lane; i < 256; i += 64) {
+        for (int i = wl; i < 256; i += 64) {
             uint32_t c = (uint32_t)i;
             for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
             crcT[0][i] = c;
         }
-        KC_WAVE_SYNC();
-        for (int i = lane; i < 256; i += 64) {
+        __syncthreads();  // (whole wave: before any group leaves)
+        for (int i = wl; i < 256; i += 64) {
             uint32_t c = crcT[0][i];
             for (int t = 1; t < 4; t++) { c = crcT[0][c & 0xFF] ^ (c >> 8); crcT[t][i] = c; }
         }
-        KC_WAVE_SYNC();
+        __syncthreads();
     }
+    if (bi >= P.n_blocks) return;  // a group without a block (the launch's tail): the whole group leaves
     const uint8_t* __restrict__ src = P.src + P.blk_off[bi];
     const int len = (int)(P.blk_off[bi + 1] - P.blk_off[bi]);
     uint8_t* __restrict__ slot = P.stage + P.stage_off[bi];
@@ -116,8 +128,8 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
         else if (m < (1u << 24)) { i = 4; if (lane == 0) { o[0] = 62 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); o[3] = (uint8_t)(m >> 16); } }
         else { i = 5; if (lane == 0) { o[0] = 63 << 2; o[1] = (uint8_t)m; o[2] = (uint8_t)(m >> 8); o[3] = (uint8_t)(m >> 16); o[4] = (uint8_t)(m >> 24); } }
         const int body = n & ~7;
-        for (int k = lane * 8; k < body; k += 512) st64(o + i + k, ld64(src + from + k));
-        for (int k = body + lane; k < n; k += 64) o[i + k] = src[from + k];
+        for (int k = lane * 8; k < body; k += 8 * SBG) st64(o + i + k, ld64(src + from + k));
+        for (int k = body + lane; k < n; k += SBG) o[i + k] = src[from + k];
         return i + n;
     };
 
@@ -178,12 +190,12 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
                         ok = !same && best.score + mine.s < mine.score + best.s;  // bestOf keeps a when a.score + b.s >= b.score + a.s
                     }
                 }
-                const uint64_t mask = ballot64(ok);
+                const uint64_t mask = sb_ballot(ok, grp);
                 if (mask == 0) break;
                 const int k = ctz64(mask);
-                best.offset = (int)rdlane32((uint32_t)mine.offset, k); best.s = (int)rdlane32((uint32_t)mine.s, k);
-                best.length = (int)rdlane32((uint32_t)mine.length, k); best.score = (int)rdlane32((uint32_t)mine.score, k);
-                best.rep = (int)rdlane32((uint32_t)mine.rep, k);
+                best.offset = (int)sb_bcast32((uint32_t)mine.offset, grp, k); best.s = (int)sb_bcast32((uint32_t)mine.s, grp, k);
+                best.length = (int)sb_bcast32((uint32_t)mine.length, grp, k); best.score = (int)sb_bcast32((uint32_t)mine.score, grp, k);
+                best.rep = (int)sb_bcast32((uint32_t)mine.rep, grp, k);
                 j = k + 1;
             }
         };
@@ -274,10 +286,10 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
                     const int k = cnt + lane + 1;
                     bool ne = true;
                     if (k <= kmax) ne = src[best.offset - k] != src[s - k];
-                    const uint64_t mm = ballot64(ne);
-                    const int c = mm ? ctz64(mm) : 64;
+                    const uint64_t mm = sb_ballot(ne, grp);
+                    const int c = mm ? ctz64(mm) : SBG;
                     cnt += c;
-                    if (c < 64) break;
+                    if (c < SBG) break;
                 }
                 if (cnt > kmax) cnt = kmax;
                 best.offset -= cnt; best.length += cnt; s -= cnt;
@@ -310,22 +322,31 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
             nextEmit = s;
             if (s >= sLimit) { fin = true; break; }
             if (d > dstLimit) { stored = true; break; }
-            // ---- index every position of the match (:422-432): 64 positions per pass, chain order kept ----
-            for (int i0 = best.s + 1; i0 < s; i0 += 64) {
+            // ---- index every position of the match (:422-432): one position per lane and pass, chain order kept ----
+            for (int i0 = best.s + 1; i0 < s; i0 += SBG) {
                 const int i = i0 + lane;
                 const bool act = i < s;
                 uint32_t hl = 0xFFFFFFFFu, hs = 0xFFFFFFFFu;
                 if (act) { const uint64_t cv0 = ld64(src + i); hl = sb_hash8(cv0); hs = sb_hash4(cv0); }
                 // does an earlier position of this pass hit the same bucket?
                 bool dupL = false, dupS = false;
+#if SBG == 16
+                // a group is one DPP row: row_shr:d hands every lane the value d lanes below it in its own group (0 where there is none)
+#define SB_DUP_STEP(dd) do { const uint32_t kl = kc_dpp_or0<0x110 + (dd), 0xf>(hl), ks = kc_dpp_or0<0x110 + (dd), 0xf>(hs); \
+                             if (lane >= (dd)) { dupL = dupL || kl == hl; dupS = dupS || ks == hs; } } while (0)
+                SB_DUP_STEP(1); SB_DUP_STEP(2); SB_DUP_STEP(3); SB_DUP_STEP(4); SB_DUP_STEP(5); SB_DUP_STEP(6); SB_DUP_STEP(7); SB_DUP_STEP(8);
+                SB_DUP_STEP(9); SB_DUP_STEP(10); SB_DUP_STEP(11); SB_DUP_STEP(12); SB_DUP_STEP(13); SB_DUP_STEP(14); SB_DUP_STEP(15);
+#undef SB_DUP_STEP
+#else
                 const int npass = s - i0 < 64 ? s - i0 : 64;
                 for (int k = 0; k + 1 < npass; k++) {
                     const uint32_t kl = rdlane32(hl, k), ks = rdlane32(hs, k);
                     if (k < lane) { dupL = dupL || kl == hl; dupS = dupS || ks == hs; }
                 }
+#endif
                 if (act && !dupL) { const uint64_t old = lT[hl]; lT[hl] = (uint64_t)(uint32_t)i | (old << 32); }
                 if (act && !dupS) { const uint64_t old = sT[hs]; sT[hs] = (uint64_t)(uint32_t)i | (old << 32); }
-                uint64_t mL = ballot64(act && dupL), mS = ballot64(act && dupS);
+                uint64_t mL = sb_ballot(act && dupL, grp), mS = sb_ballot(act && dupS, grp);
                 while (mL) {  // in order: each sees the entry its predecessors of the pass left
                     const int k = ctz64(mL);
                     mL &= mL - 1;
@@ -363,7 +384,7 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
     uint32_t chunkLen;
     uint8_t chunkType;
     if (stored) {
-        for (int k = lane; k < len; k += 64) out[k] = src[k];
+        for (int k = lane; k < len; k += SBG) out[k] = src[k];
         chunkType = 0x01;
         chunkLen = 4u + (uint32_t)len;
     } else {
@@ -382,6 +403,7 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
 
 void kc_launch_s2_best(const KcS2Params& P, hipStream_t st) {
     if (P.n_blocks == 0) return;
-    if (P.level == 5) hipLaunchKernelGGL((kc_s2_best_kernel<true>), dim3(P.n_blocks), dim3(64), 0, st, P);
-    else hipLaunchKernelGGL((kc_s2_best_kernel<false>), dim3(P.n_blocks), dim3(64), 0, st, P);
+    const uint32_t grid = (P.n_blocks + (64 / SBG) - 1) / (64 / SBG);
+    if (P.level == 5) hipLaunchKernelGGL((kc_s2_best_kernel<true>), dim3(grid), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL((kc_s2_best_kernel<false>), dim3(grid), dim3(64), 0, st, P);
 }

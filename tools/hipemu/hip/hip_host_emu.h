@@ -74,7 +74,7 @@ inline hipError_t dev_free(void* p) {
 // kernel name, as tools/hipemu/kcemu.cpp sets it around its launches.
 namespace hipemu {
 inline unsigned group_for(const char* k) {
-    if (strstr(k, "kc_zbetter_match_grp")) return 16;
+    if (strstr(k, "kc_zbetter_match_grp") || strstr(k, "kc_s2_best_kernel")) return 16;
     if (strstr(k, "kc_zfast_match_grp") || strstr(k, "kc_zdfast_match_grp") || strstr(k, "kc_s2_encode_kernel") || strstr(k, "kc_s2_decode_kernel")) return 8;
     if (strstr(k, "kc_xxh64")) return 4;
     return 64;

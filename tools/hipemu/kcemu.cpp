@@ -285,7 +285,9 @@ int kcemu_s2_best(int level, const uint8_t* src, const uint64_t* blk_off, uint32
     P.table_stride = (uint32_t)(kc_s2_table_bytes(level, 0) / 4);
     P.n_blocks = n;
     P.level = level;
+    hipemu::set_group(SBG);  // 16 lanes per block, the groups of a wave diverge freely
     kc_launch_s2_best(P, nullptr);
+    hipemu::set_group(64);
     return 0;
 }
 
