@@ -28,6 +28,17 @@ static_assert(SBG == 16 || SBG == 64, "phase B holds nine candidates: at least 1
 #define SB_GMASK (SBG == 64 ? ~0ull : ((1ull << (SBG & 63)) - 1ull))
 __device__ __forceinline__ uint64_t sb_ballot(bool p, int grp) { return (ballot64(p) >> (grp * SBG)) & SB_GMASK; }
 __device__ __forceinline__ uint32_t sb_bcast32(uint32_t v, int grp, int k) { return (uint32_t)__shfl((int)v, grp * SBG + k, 64); }
+// Source window (round 6, as in the zstd match finders): the block's bytes around the parse position in a 512-byte ring per block in
+// LDS, refilled 16 bytes per lane a pass ahead of use: the 8 bytes at s, s+1, s+2, behind and at the end of the best match, the forward
+// side of the match extensions and the positions indexed behind a match are LDS reads instead of the first of a step's three dependent
+// round trips (rd64 / rd32 fall back to memory for what the window does not hold).
+#ifndef SB_RING
+#define SB_RING 1
+#endif
+#define SB_RB 512
+#define SB_MIRROR 32
+#define SB_STRIDE (SB_RB + SB_MIRROR)
+#define SB_AHEAD 224
 #define SB_LBITS 19
 #define SB_SBITS 16
 
@@ -77,8 +88,13 @@ __device__ inline int sb_copy_nr_size(int offset, int length) {  // emitCopyNoRe
 
 struct SbMatch { int offset, s, length, score, rep; };
 
+#ifdef SB_WPE
+#define SB_KATTR __attribute__((amdgpu_waves_per_eu(SB_WPE, SB_WPE)))
+#else
+#define SB_KATTR
+#endif
 template <bool SNAPPY>
-__global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
+__global__ __launch_bounds__(64) SB_KATTR void kc_s2_best_kernel(KcS2Params P) {
     const int wl = (int)threadIdx.x;                 // lane of the wave
     const int lane = wl % SBG, grp = wl / SBG;       // lane of the block's group, group of the wave
     const uint32_t bi = blockIdx.x * (64 / SBG) + (uint32_t)grp;
@@ -117,6 +133,53 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
     if (len == 0 && !P.framed) { if (lane == 0) P.out_size[bi] = (uint32_t)hdr; return; }
     bool stored = len < 32;  // minNonLiteralBlockSize
 
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[SB_RING ? (64 / SBG) * SB_STRIDE : 16];
+    uint8_t* const ring = ring_all + (SB_RING ? grp * SB_STRIDE : 0);
+    const int boff = (int)((uintptr_t)src & 15);
+    const uint8_t* __restrict__ abase = src - boff;
+    int wlo = 0, whi = 0;   // the ring holds the bytes abase[wlo .. whi)
+    bool pend = false;      // rf holds the 16 * SBG bytes abase[whi ..) loaded a pass ago
+    uint4 rf = make_uint4(0, 0, 0, 0);
+    auto window = [&](int sp) {  // top of every pass (group-uniform)
+        if (!SB_RING) return;
+        if (pend) {
+            const int ro = (whi + 16 * lane) & (SB_RB - 1);
+            if (lane < 16) {  // (SBG == 64: only the first 16 lanes carry a refill)
+                *(uint4*)(ring + ro) = rf;
+                if (ro < SB_MIRROR) *(uint4*)(ring + SB_RB + ro) = rf;
+            }
+            whi += 256;
+            if (whi - wlo > SB_RB) wlo = whi - SB_RB;
+            pend = false;
+        }
+        KC_WAVE_SYNC();
+        const int sa = sp + boff;
+        if (sa >= whi || sa < wlo) { const int w0 = sa & ~15; wlo = whi = w0; }
+        if (whi - sa < SB_AHEAD) {
+            const uint8_t* q = abase + whi + 16 * lane;
+            rf = make_uint4(0, 0, 0, 0);
+            if (lane < 16 && q < src + len) rf = *(const uint4*)q;  // aligned: never leaves the 16-byte granule of a readable byte
+            pend = true;
+        }
+    };
+    auto rd64 = [&](int pos) -> uint64_t {
+        const int a = pos + boff, a4 = a & ~3;
+        if (SB_RING && a4 >= wlo && a4 + 12 <= whi) {
+            const uint32_t* r = (const uint32_t*)(ring + (a4 & (SB_RB - 1)));
+            const uint32_t r0 = r[0], r1 = r[1], r2 = r[2];
+            const uint32_t sh = (uint32_t)(a & 3);
+            return (uint64_t)__builtin_amdgcn_alignbyte(r1, r0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(r2, r1, sh) << 32);
+        }
+        return ld64(src + pos);
+    };
+    auto rd32 = [&](int pos) -> uint32_t {
+        const int a = pos + boff, a4 = a & ~3;
+        if (SB_RING && a4 >= wlo && a4 + 8 <= whi) {
+            const uint32_t* r = (const uint32_t*)(ring + (a4 & (SB_RB - 1)));
+            return __builtin_amdgcn_alignbyte(r[1], r[0], (uint32_t)(a & 3));
+        }
+        return ld32(src + pos);
+    };
     auto emit_lit = [&](int from, int n) -> int {  // emitLiteral (encode_go.go:80)
         if (n == 0) return 0;
         const uint32_t m = (uint32_t)(n - 1);
@@ -143,12 +206,12 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
             SbMatch m;
             m.offset = offset; m.s = s_; m.length = 0; m.score = 0; m.rep = rep ? 1 : 0;
             if (!act) return m;
-            if (ld32(src + offset) != first) return m;
+            if (rd32(offset) != first) return m;
             int la = 4 + offset;  // m.length while it is an absolute position
             int sp = s_ + 4;
             if (SNAPPY) {
                 while (sp <= sLimit) {
-                    const uint64_t diff = ld64(src + sp) ^ ld64(src + la);
+                    const uint64_t diff = rd64(sp) ^ rd64(la);
                     if (diff != 0) { la += ctz64(diff) >> 3; break; }
                     sp += 8; la += 8;
                 }
@@ -158,7 +221,7 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
                         if (src[sp] == src[la]) { la++; sp++; continue; }
                         break;
                     }
-                    const uint64_t diff = ld64(src + sp) ^ ld64(src + la);
+                    const uint64_t diff = rd64(sp) ^ rd64(la);
                     if (diff != 0) { la += ctz64(diff) >> 3; break; }
                     sp += 8; la += 8;
                 }
@@ -200,15 +263,19 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
             }
         };
         uint32_t guard = 0;
+        // ONE loop for the scan and for what follows a match (round 6): every pass, every group of the wave takes one probe step; the
+        // groups that found a match then emit and index it while the others wait for that — not, as with the reference's nested loops
+        // taken literally, every group waiting until ALL groups of the wave have found theirs.
         while (!fin && !stored) {
             SbMatch best;
             best.offset = 0; best.s = 0; best.length = 0; best.score = 0; best.rep = 0;
-            for (;;) {
+            {
                 if (++guard > 2u * (uint32_t)len + 64u) { stored = true; break; }  // every step advances s: cannot happen; never spin on the device
                 int nextS = ((s - nextEmit) >> 8) + 1;
                 if (nextS > 64) nextS = s + 64; else nextS += s;  // maxSkip
                 if (nextS > sLimit) { fin = true; break; }
-                const uint64_t cv = ld64(src + s);
+                window(s);
+                const uint64_t cv = rd64(s);
                 const uint32_t hashL = sb_hash8(cv), hashS = sb_hash4(cv);
                 const uint64_t candidateL = lT[hashL], candidateS = sT[hashS];
                 // ---- phase A: the four table candidates at s, the repeat at s+1 (:232-250) ----
@@ -226,11 +293,11 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
                     // ---- phase B: s+1 and s+2 (:252-311) ----
                     const uint64_t nextShort1 = sT[sb_hash4(cv >> 8)];
                     const int s1 = s + 1;
-                    const uint64_t cv1 = ld64(src + s1);
+                    const uint64_t cv1 = rd64(s1);
                     const uint64_t nextLong1 = lT[sb_hash8(cv1)];
                     const uint64_t nextShort2 = sT[sb_hash4(cv1 >> 8)];
                     const int s2 = s + 2;
-                    const uint64_t cv2 = ld64(src + s2);
+                    const uint64_t cv2 = rd64(s2);
                     const uint64_t nextLong2 = lT[sb_hash8(cv2)];
                     {
                         int off = 0, sp = s1; uint32_t first = (uint32_t)cv1; bool rep = false, act = lane < 10;
@@ -258,8 +325,8 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
                     if (sAt < sLimit) {
                         const int sBack = best.s + skipBeginning - skipEnd;
                         const int backL = best.length - skipBeginning;
-                        const uint64_t cvb = ld64(src + sBack);
-                        const uint64_t next = lT[sb_hash8(ld64(src + sAt))];
+                        const uint64_t cvb = rd64(sBack);
+                        const uint64_t next = lT[sb_hash8(rd64(sAt))];
                         const int chk0 = (int)(uint32_t)next - backL, chk1 = (int)(next >> 32) - backL;
                         const bool act = (lane == 0 && chk0 > 0) || (lane == 1 && chk1 > 0);
                         const SbMatch mine = eval(act, lane == 0 ? chk0 : chk1, sBack, (uint32_t)cvb, false);
@@ -273,10 +340,8 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
                     sT[hashS] = (uint64_t)(uint32_t)s | (candidateS << 32);
                 }
                 KC_WAVE_SYNC();
-                if (best.length > 0) break;
-                s = nextS;
+                if (best.length == 0) { s = nextS; continue; }
             }
-            if (fin || stored) break;
             // ---- the match: extend backwards (not for repeats; always at the Snappy level), bail-outs, emit (:358-420) ----
             s = best.s;
             if (SNAPPY || !best.rep) {
@@ -327,7 +392,7 @@ __global__ __launch_bounds__(64) void kc_s2_best_kernel(KcS2Params P) {
                 const int i = i0 + lane;
                 const bool act = i < s;
                 uint32_t hl = 0xFFFFFFFFu, hs = 0xFFFFFFFFu;
-                if (act) { const uint64_t cv0 = ld64(src + i); hl = sb_hash8(cv0); hs = sb_hash4(cv0); }
+                if (act) { const uint64_t cv0 = rd64(i); hl = sb_hash8(cv0); hs = sb_hash4(cv0); }
                 // does an earlier position of this pass hit the same bucket?
                 bool dupL = false, dupS = false;
 #if SBG == 16

@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd $R
 ulimit -c 0
 bash tools/gpu_guard.sh $OUT/pytest_best timeout 900 python -m pytest tests/test_gpu_s2.py -m gpu -q -x -k "best or writer or stream"; echo "pytest rc $? $(tail -1 $OUT/pytest_best.log)" | tee $OUT/summary.txt
-for tag in sbg64 base sbg64 base; do
+for tag in ${TAGS:-sbg64 base sbg64 base}; do
   E="KC_X=0"; [ $tag != base ] && E="KC_LIB_TAG=$tag"
   for lvl in 4 5; do
   env $E timeout 300 python bench.py --config C4 --s2-level $lvl --gib 1.0 --no-also --no-cpu-baseline --no-end-to-end --no-floor --steps 3 --warmup 1 2>/dev/null | tail -1 | python -c "
