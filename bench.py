@@ -48,7 +48,7 @@ CONFIGS = {
     "C4A": dict(codec="s2", level=0, kind="J", unit=64 << 10, gib=2.0, dict_kib=0, kernel="kc_s2_encode_kernel",
                 src="kc_s2.hip", what="s2.Encode, amd64 assembly variant", variant="amd64"),
     # not a BASELINE configuration (and not part of the default run's "also"): the best level, one wave per unit on persistent table slots
-    "B4": dict(codec="zstd", level=4, kind="T", unit=128 << 10, gib=0.5, dict_kib=0, kernel="kc_zbest_match_kernel",
+    "B4": dict(codec="zstd", level=4, kind="T", unit=128 << 10, gib=0.75, dict_kib=0, kernel="kc_zbest_match_kernel",
                src="kc_zstd_match_best.hip", what="zstd SpeedBestCompression EncodeAll"),
 }
 METRIC = "encode MB/s (input) + ratio, zstd SpeedFastest 128KiB blocks, 1/2/4/8 GPU"
@@ -686,7 +686,7 @@ def main():
         also = {}
         # the five BASELINE configurations at their per-GPU sizes, then the N3 levels at small sizes (not BASELINE configurations:
         # zstd SpeedBestCompression, s2.EncodeBetter, s2.EncodeBest) so that the driver's one run times those too
-        for name, extra in (("C2/one-context", ["--no-pipeline"]), ("C2H", []), ("C3", []), ("C4", []), ("C4A", []), ("C5", []), ("B4", ["--gib", "0.25"]),
+        for name, extra in (("C2/one-context", ["--no-pipeline"]), ("C2H", []), ("C3", []), ("C4", []), ("C4A", []), ("C5", []), ("B4", ["--gib", "0.75"]),
                             ("C4/s2.EncodeBetter", ["--s2-level", "1", "--gib", "1.0"]), ("C4/s2.EncodeBest", ["--s2-level", "4", "--gib", "1.0"])):  # (one wave per block: 16 384 blocks = two residencies of the chip; 0.25 GiB left half of it idle: 3.97 vs 5.02 GB/s, gpurun_out/r5n)
             cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("/")[0], "--steps", str(args.also_steps), "--warmup", "1",
                    "--no-also", "--cpu-sample-units", "1024" if not extra else "256", "--path", args.path] + extra

@@ -107,7 +107,7 @@ struct KcCfg {
     int64_t test_feed_redo = 0;           // diagnostics: force the chunk-fed path's re-encode fallback
     int64_t better_dict_epoch = 0;        // SpeedBetterCompression with a dictionary: epoch-stamped tables + shared dictionary table instead of the per-batch copy
     int64_t s2_variant = 0;               // S2 levels 0 / 2: 0 = the portable Go encoders' bytes, 1 = the amd64 assembly encoders' bytes
-    int64_t best_slots = 2048;            // SpeedBestCompression: table slots (34 MiB each) = units encoded at a time
+    int64_t best_slots = 6144;            // SpeedBestCompression: table slots (34 MiB each) = units encoded at a time (round 6: 2048 -> 6144 = 204 GiB when a batch has that many units and the device the room — the level is one unit's latency whatever is in flight: 1.49 -> 3.17 GB/s, gpurun_out/r7a)
     int64_t zfast_epoch = 1;              // SpeedFastest HBM-table kernel without a dictionary: epoch-stamped tables instead of clearing 128 KiB per unit per batch
     int64_t zfast_xseg_k = 0;             // SpeedFastest HBM-table kernel, tuned form: probe rounds cross skip-segment boundaries once (s - nextEmit) >> 5 reaches this (0: always)
     int64_t zfast_variant = -1;           // SpeedFastest HBM-table kernel: 0 the plain form, 1 the form for input without matches (cross-segment rounds + empty-group

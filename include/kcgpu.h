@@ -182,7 +182,7 @@ typedef enum {
     KC_OPT_S2_HOOK_BATCH = 15,       /* KC_S2_HOOK_BATCH          kc_s2_encode_block: most blocks per device batch */
     KC_OPT_TEST_FEED_REDO = 16,      /* (no variable)             diagnostics: force the chunk-fed path's re-encode fallback */
     KC_OPT_MAX_SCRATCH_MIB = 18,     /* (no variable)             ceiling of the device scratch one batch may take (default 160 GiB, and 85 % of the free memory): larger calls are cut into several batches */
-    KC_OPT_BEST_SLOTS = 19,          /* (no variable)             SpeedBestCompression: table slots of 34 MiB = units encoded at a time (default 2048 = 68 GiB, allocated on demand) */
+    KC_OPT_BEST_SLOTS = 19,          /* (no variable)             SpeedBestCompression: table slots of 34 MiB = units encoded at a time (default 6144 = 204 GiB; allocated on demand for the units a batch has, never more than 80 % of the free device memory) */
     KC_OPT_S2_VARIANT = 20,          /* (no variable)             s2.Encode / s2.EncodeSnappy: KC_S2_VARIANT_GO (default) or KC_S2_VARIANT_AMD64 */
     KC_OPT_BETTER_DICT_EPOCH = 21,   /* (no variable)             SpeedBetterCompression with a dictionary: 1 = epoch-stamped tables + shared dictionary table (measurements; default 0: per-batch copy) */
     KC_OPT_ZFAST_EPOCH = 22,         /* KC_ZFAST_EPOCH            SpeedFastest HBM-table kernel, no dictionary: 1 (default) = epoch-stamped table entries, the arena is cleared every 15 batches instead of every batch */
