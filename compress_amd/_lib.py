@@ -206,7 +206,7 @@ class Context:
                  ("KC_LDS_SPEC_W0", 6), ("KC_S2_LDS_SPEC_W0", 17), ("KC_HOST_PIPE_MIB", 8), ("KC_HOST_OVERLAP_MIN_MIB", 9),
                  ("KC_HOST_COPY_THREADS", 10), ("KC_S2_HOOK_WAIT_US", 14), ("KC_S2_HOOK_BATCH", 15), ("KC_S2_HOOK_LANES", 29),
                  ("KC_ZFAST_EPOCH", 22), ("KC_ZFAST_XSEG_K", 23), ("KC_FUSE_RAW_XXH", 24), ("KC_ZFAST_FILTER", 25), ("KC_XXH_FIN_MODE", 26),
-                 ("KC_ZFAST_VARIANT", 27), ("KC_ZFAST_PRESCAN", 28), ("KC_JOB_PRIME", 30), ("KC_HOST_ROLL", 33), ("KC_HOST_ROLL_MIB", 34), ("KC_S2_HOOK_HOST_FIRST", 35), ("KC_BETTER_DICT_EPOCH", 21), ("KC_BEST_SLOTS", 19))
+                 ("KC_ZFAST_VARIANT", 27), ("KC_ZFAST_PRESCAN", 28), ("KC_JOB_PRIME", 30), ("KC_HOST_ROLL", 33), ("KC_HOST_ROLL_MIB", 34), ("KC_S2_HOOK_HOST_FIRST", 35), ("KC_BETTER_DICT_EPOCH", 21), ("KC_BEST_SLOTS", 19), ("KC_MAX_SCRATCH_MIB", 18))
     _ENV_FLAGS = (("KC_HOST_SERIAL", 7), ("KC_HOST_TRACE", 11), ("KC_K2_PROF", 13))  # set by their presence
 
     def _apply_env(self):

@@ -88,11 +88,14 @@ __device__ inline int sb_copy_nr_size(int offset, int length) {  // emitCopyNoRe
 
 struct SbMatch { int offset, s, length, score, rep; };
 
-#ifdef SB_WPE
-#define SB_KATTR __attribute__((amdgpu_waves_per_eu(SB_WPE, SB_WPE)))
-#else
-#define SB_KATTR
+// Six waves per SIMD (80 VGPRs and 36-60 bytes of scratch instead of 109 and none): 24 576 blocks resident instead of 16 384.  A block
+// takes ~170-200 ms whatever shares the chip with it, so the rate is the blocks in flight: at 1.5 GiB of 64 KiB blocks 7.9 GB/s against
+// 5.5 at four waves (at 1 GiB, one residency either way, 6.3 against 6.5); seven waves lose to the spills and to the LDS ring's share of
+// a CU (gpurun_out/r7b, r7c).
+#ifndef SB_WPE
+#define SB_WPE 6
 #endif
+#define SB_KATTR __attribute__((amdgpu_waves_per_eu(SB_WPE, SB_WPE)))
 template <bool SNAPPY>
 __global__ __launch_bounds__(64) SB_KATTR void kc_s2_best_kernel(KcS2Params P) {
     const int wl = (int)threadIdx.x;                 // lane of the wave
