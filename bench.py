@@ -84,7 +84,7 @@ def collect_pmc(argv, kernel_key):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="kcpmc_", dir="/tmp")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "--", sys.executable, os.path.abspath(__file__)] + argv + [
-            "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-device-verify", "--no-end-to-end", "--no-also"]
+            "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-device-verify", "--no-end-to-end", "--no-also", "--no-floor"]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400, check=False)
@@ -472,6 +472,8 @@ def main():
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             for ent in pj.get("entries", [pj]):
                 if ent.get("config") != args.config or ent.get("units") != n_units or ent.get("corpus") != kind:
+                    continue
+                if is_s2 and ent.get("kernel") and ent["kernel"] != cfg["kernel"]:  # (the S2 levels share a configuration name and, at 2 GiB, a size)
                     continue
                 if ent.get("kernel_source_sha16") == khash:
                     traffic, traffic_src = ent["kernel_hbm_bytes"], "profiles/pmc_traffic.json (same workload, same kernel source)"

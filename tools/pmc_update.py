@@ -76,7 +76,7 @@ def main():
                 algo = int(n * ub * (1 + j["ratio"]))
                 e = {"config": cfg, "args": " ".join(parts[1:]), "units": n, "corpus": j["config"]["corpus"], "unit_bytes": ub, "kernel": rf["kernel"],
                      "kernel_source_sha16": rf["kernel_source_sha16"], "kernel_hbm_bytes": rf["traffic"], "algorithmic_bytes": algo,
-                     "ratio_to_algorithmic": round(rf["traffic"] / algo, 2), "kernel_ms": rf["kernel_ms"], "collected": "round 5, tools/pmc_update.py"}
+                     "ratio_to_algorithmic": round(rf["traffic"] / algo, 2), "kernel_ms": rf["kernel_ms"], "collected": "round 6, tools/pmc_update.py"}
                 ents = [x for x in ents if not (x.get("config") == cfg and x.get("units") == n and x.get("corpus") == e["corpus"] and x.get("kernel", "").split("<")[0] == rf["kernel"].split("<")[0]
                                                 and x.get("kernel") == rf["kernel"])] + [e]
                 print("pmc", spec, rf["traffic"], e["ratio_to_algorithmic"], rf["kernel_source_sha16"], flush=True)
