@@ -35,6 +35,9 @@ __device__ __forceinline__ uint32_t sb_bcast32(uint32_t v, int grp, int k) { ret
 #ifndef SB_RING
 #define SB_RING 1
 #endif
+#ifndef SB_PRE
+#define SB_PRE 0        // 1: the buckets of s+1 looked up a pass ahead — measured 3 % slower (profiles/r06_ab_kernels.txt), kept for A/B
+#endif
 #define SB_RB 512
 #define SB_MIRROR 32
 #define SB_STRIDE (SB_RB + SB_MIRROR)
@@ -265,6 +268,12 @@ __global__ __launch_bounds__(64) SB_KATTR void kc_s2_best_kernel(KcS2Params P) {
                 j = k + 1;
             }
         };
+        // The two buckets of s+1 are looked up a pass ahead (round 6): phase B of this pass needs them if this pass finds a match, the
+        // next pass needs them if it does not (nextS == s + 1 while fewer than 256 literals are pending) — no lookup is wasted, and the
+        // next pass starts its candidate loads without waiting for its own table round trip.  What this pass writes into the same bucket
+        // is patched into the registers; anything else that writes the tables (the index pass behind a match) drops them.
+        int prePos = -1;
+        uint64_t preL = 0, preS = 0;
         uint32_t guard = 0;
         // ONE loop for the scan and for what follows a match (round 6): every pass, every group of the wave takes one probe step; the
         // groups that found a match then emit and index it while the others wait for that — not, as with the reference's nested loops
@@ -280,7 +289,14 @@ __global__ __launch_bounds__(64) SB_KATTR void kc_s2_best_kernel(KcS2Params P) {
                 window(s);
                 const uint64_t cv = rd64(s);
                 const uint32_t hashL = sb_hash8(cv), hashS = sb_hash4(cv);
-                const uint64_t candidateL = lT[hashL], candidateS = sT[hashS];
+                uint64_t candidateL, candidateS;
+                if (SB_PRE && prePos == s) { candidateL = preL; candidateS = preS; }
+                else { candidateL = lT[hashL]; candidateS = sT[hashS]; }
+                const int s1 = s + 1;
+                const uint64_t cv1 = rd64(s1);
+                const uint32_t hashL1 = sb_hash8(cv1), hashS1 = sb_hash4(cv1);  // (sb_hash4(cv >> 8) == hashS1: the same four bytes)
+                uint64_t nextLong1 = 0, nextShort1 = 0;
+                if (SB_PRE) { nextLong1 = lT[hashL1]; nextShort1 = sT[hashS1]; }
                 // ---- phase A: the four table candidates at s, the repeat at s+1 (:232-250) ----
                 {
                     int off = 0, sp = s; uint32_t first = (uint32_t)cv; bool rep = false, act = lane < 5;
@@ -294,10 +310,7 @@ __global__ __launch_bounds__(64) SB_KATTR void kc_s2_best_kernel(KcS2Params P) {
                 }
                 if (best.length > 0) {
                     // ---- phase B: s+1 and s+2 (:252-311) ----
-                    const uint64_t nextShort1 = sT[sb_hash4(cv >> 8)];
-                    const int s1 = s + 1;
-                    const uint64_t cv1 = rd64(s1);
-                    const uint64_t nextLong1 = lT[sb_hash8(cv1)];
+                    if (!SB_PRE) { nextShort1 = sT[hashS1]; nextLong1 = lT[hashL1]; }
                     const uint64_t nextShort2 = sT[sb_hash4(cv1 >> 8)];
                     const int s2 = s + 2;
                     const uint64_t cv2 = rd64(s2);
@@ -343,6 +356,11 @@ __global__ __launch_bounds__(64) SB_KATTR void kc_s2_best_kernel(KcS2Params P) {
                     sT[hashS] = (uint64_t)(uint32_t)s | (candidateS << 32);
                 }
                 KC_WAVE_SYNC();
+                if (SB_PRE) {  // the entries of s+1 as the tables hold them now
+                    if (hashL1 == hashL) nextLong1 = (uint64_t)(uint32_t)s | (candidateL << 32);
+                    if (hashS1 == hashS) nextShort1 = (uint64_t)(uint32_t)s | (candidateS << 32);
+                    prePos = s1; preL = nextLong1; preS = nextShort1;
+                }
                 if (best.length == 0) { s = nextS; continue; }
             }
             // ---- the match: extend backwards (not for repeats; always at the Snappy level), bail-outs, emit (:358-420) ----
@@ -429,6 +447,7 @@ __global__ __launch_bounds__(64) SB_KATTR void kc_s2_best_kernel(KcS2Params P) {
                 }
                 KC_WAVE_SYNC();
             }
+            prePos = -1;  // the index pass rewrote buckets
         }
         if (!stored) {  // emitRemainder (:435-450)
             if (nextEmit < len) {
