@@ -52,6 +52,9 @@ static_assert(ZBG <= 32, "group ballots are 32-bit");
 #ifndef ZB_RING
 #define ZB_RING 1       // 0: measurement builds (KC_EXTRA_FLAGS=-DZB_RING=0): every source read from memory, as before round 6
 #endif
+#ifndef ZB_FUSE
+#define ZB_FUSE 1       // 0: measurement builds: the candidate loads of a round / of the lazy lookup / of the re-search one dependent trip each, as before
+#endif
 #define ZB_EPOCH_BITS 4
 #define ZB_EPOCH_SHIFT (32 - ZB_EPOCH_BITS)
 
@@ -303,6 +306,29 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     if (valid) {
                         const int ri = pp - o1 + 1;
                         // (candidates a few hundred bytes back are in the window too: rd32 / rd64)
+#if ZB_FUSE
+                        // One round trip for the round's candidate bytes: the repeat, both long candidates and the short one are loaded
+                        // together (each behind its own position / tag test) and judged afterwards in the reference's order — they used
+                        // to be up to four dependent trips (repeat -> long -> prev -> short) on a kernel bound by exactly those.
+                        const bool tryR = canRep && ri >= 0;
+                        const int tx = C.posOf(eL.x), ty = C.posOf(eL.y), ts = C.posOf(eS);
+                        const uint32_t tg = C.tagOf((uint32_t)cvl);
+                        const bool okx = tx >= 0 && (pp - tx) < mmo && (eL.x >> C.PB) == tg;
+                        const bool oky = ty >= 0 && (pp - ty) < mmo && (eL.y >> C.PB) == tg;
+                        const bool oks = ts >= 0 && (pp - ts) < mmo && (eS >> C.PB) == tg;
+                        uint32_t vr = 0, vs = 0;
+                        uint64_t vx = 0, vy = 0;
+                        if (tryR) vr = rd32(ri);
+                        if (okx) vx = rd64(tx);
+                        if (oky) vy = rd64(ty);
+                        if (oks) vs = rd32(ts);
+                        if (tryR && vr == (uint32_t)(cvl >> 8)) hit = 1;
+                        else {
+                            if (okx && vx == cvl) hit |= 2;
+                            if (oky && vy == cvl) hit |= 4;
+                            if (hit == 0 && oks && vs == (uint32_t)cvl) hit = 8;
+                        }
+#else
                         if (canRep && ri >= 0 && rd32(ri) == (uint32_t)(cvl >> 8)) hit = 1;
                         else {
                             if (long_ok(eL.x, pp, cvl)) hit |= 2;
@@ -312,6 +338,7 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                                 if (ts >= 0 && (pp - ts) < mmo && (eS >> C.PB) == C.tagOf((uint32_t)cvl) && rd32(ts) == (uint32_t)cvl) hit = 8;
                             }
                         }
+#endif
                     }
                     const uint32_t vm = gballot<G>(valid, grp);
                     const uint32_t depm = gballot<G>(valid && dep, grp);
@@ -390,6 +417,35 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     {
                         const int ts = C.posOf(cS);
                         {  // whit == 8: the short candidate was accepted on its 4 bytes
+#if ZB_FUSE
+                            // long match at s+1? (:309-343) — its table entry is requested BEFORE the short candidate is extended (the
+                            // two trips overlap), and its two candidates' bytes are loaded together
+                            const uint64_t cv2 = rd64(s + 1);
+                            const uint32_t nh2 = hL(cv2);
+                            const uint2 c2 = C.rdL(nh2);
+                            matched = grp_matchlen<G>(base, s + 4, ts + 4, blkEnd - (s + 4), lig, grp) + 4;
+                            KC_EMU_SYNC();
+                            if (lig == 0) C.wrL(nh2, C.mk(s + 1, (uint32_t)cv2), c2.x);
+                            // s-coffsetL < maxMatchOff is evaluated with s (not s+1) in the reference
+                            const int tl = C.posOf(c2.x), tp = C.posOf(c2.y);
+                            const uint32_t tg2 = C.tagOf((uint32_t)cv2);
+                            const bool okl = tl >= 0 && (s - tl) < mmo && (c2.x >> C.PB) == tg2;
+                            const bool okp = tp >= 0 && (s - tp) < mmo && (c2.y >> C.PB) == tg2;
+                            uint64_t vl = 0, vp = 0;
+                            if (okl) vl = ld64(base + tl);
+                            if (okp) vp = ld64(base + tp);
+                            bool taken = false;
+                            if (okl && vl == cv2) {
+                                const int mn = grp_matchlen<G>(base, s + 9, tl + 8, blkEnd - (s + 9), lig, grp) + 8;
+                                if (mn > matched) { t = tl; s += 1; matched = mn; taken = true; }
+                            }
+                            if (!taken && okp && vp == cv2) {
+                                const int mn = grp_matchlen<G>(base, s + 9, tp + 8, blkEnd - (s + 9), lig, grp) + 8;
+                                if (mn > matched) { t = tp; s += 1; matched = mn; taken = true; }
+                            }
+                            if (!taken) t = ts;
+                            break;
+#else
                             matched = grp_matchlen<G>(base, s + 4, ts + 4, blkEnd - (s + 4), lig, grp) + 4;
                             // long match at s+1? (:309-343)
                             const uint64_t cv2 = rd64(s + 1);
@@ -415,12 +471,28 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                             }
                             if (!taken) t = ts;
                             break;
+#endif
                         }
                     }
                     // not reached: a found round always ends in one of the branches above
                 }
                 if (brk) continue;  // leaves encodeLoop when fin, or restarts the search after nothing (not reached)
                 // ---- end-of-match re-search (:419-460) ----
+#if ZB_FUSE
+                // The backward extension's first G bytes are requested here for the match as it stands, under the re-search's table trip:
+                // the re-search rarely replaces the match, and when it does they are dropped and the extension starts over.
+                auto back_kmax = [&](int sp, int tp, int len) -> int {
+                    const int tMin = (sp - mmo) > 0 ? (sp - mmo) : 0;
+                    int kmax = tp - tMin;
+                    if (sp - nextEmit < kmax) kmax = sp - nextEmit;
+                    if ((ZB_MAX_MATCH_LENGTH - len) < kmax) kmax = ZB_MAX_MATCH_LENGTH - len;
+                    return kmax < 0 ? 0 : kmax;
+                };
+                const int s_pre = s, t_pre = t, m_pre = matched;
+                const int kmax_pre = back_kmax(s, t, matched);
+                uint32_t bpS = 0, bpT = 1;  // (unequal: a lane beyond kmax ends the extension)
+                if (lig + 1 <= kmax_pre) { bpS = base[s - (lig + 1)]; bpT = base[t - (lig + 1)]; }
+#endif
                 if (s + matched < sLimit) {
                     const int skipBeginning = DICT ? 0 : 3;
                     const uint32_t nh = hL(rd64(s + matched));
@@ -428,6 +500,32 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     const uint32_t cv4 = rd32(s2);
                     KC_EMU_SYNC();
                     const uint2 cE = C.rdL(nh);
+#if ZB_FUSE
+                    // both candidates' bytes in one trip; the prev candidate's position depends on the match length (:445), so when the
+                    // first candidate lengthened the match it is looked at again
+                    const int m0 = matched;
+                    const int cox = C.posOf(cE.x) - m0 + skipBeginning;
+                    int coy = C.posOf(cE.y) - m0 + skipBeginning;
+                    const bool okx = C.posOf(cE.x) >= 0 && cox >= 0 && cox < s2 && (s2 - cox) < mmo;
+                    bool oky = C.posOf(cE.y) >= 0 && coy >= 0 && coy < s2 && (s2 - coy) < mmo;
+                    uint32_t vx = 0, vy = 0;
+                    if (okx) vx = ld32(base + cox);
+                    if (oky) vy = ld32(base + coy);
+                    if (okx && cv4 == vx) {
+                        const int mn = grp_matchlen<G>(base, s2 + 4, cox + 4, blkEnd - (s2 + 4), lig, grp) + 4;
+                        if (mn > matched) { t = cox; s = s2; matched = mn; }
+                    }
+                    if (matched != m0) {
+                        coy = C.posOf(cE.y) - matched + skipBeginning;
+                        oky = C.posOf(cE.y) >= 0 && coy >= 0 && coy < s2 && (s2 - coy) < mmo;
+                        vy = 0;
+                        if (oky) vy = ld32(base + coy);
+                    }
+                    if (oky && cv4 == vy) {
+                        const int mn = grp_matchlen<G>(base, s2 + 4, coy + 4, blkEnd - (s2 + 4), lig, grp) + 4;
+                        if (mn > matched) { t = coy; s = s2; matched = mn; }
+                    }
+#else
                     {
                         const int co = C.posOf(cE.x) - matched + skipBeginning;
                         if (C.posOf(cE.x) >= 0 && co >= 0 && co < s2 && (s2 - co) < mmo && cv4 == ld32(base + co)) {
@@ -442,10 +540,29 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                             if (mn > matched) { t = co; s = s2; matched = mn; }
                         }
                     }
+#endif
                 }
                 o2 = o1;
                 o1 = s - t;
                 int l = matched;
+#if ZB_FUSE
+                {
+                    const int kmax = back_kmax(s, t, l);
+                    int back;
+                    if (s == s_pre && t == t_pre && l == m_pre) {  // the match the bytes were requested for (kmax == kmax_pre)
+                        const uint32_t m = gballot<G>(bpS != bpT, grp);
+                        const int c = m ? __builtin_ctz(m) : G;
+                        back = c;
+                        if (c == G && G < kmax) back = G + grp_backlen<G>(base, s - G, t - G, kmax - G, lig, grp);
+                        if (back > kmax) back = kmax;
+                    } else {
+                        back = grp_backlen<G>(base, s, t, kmax, lig, grp);
+                    }
+                    s -= back;
+                    t -= back;
+                    l += back;
+                }
+#else
                 {
                     const int tMin = (s - mmo) > 0 ? (s - mmo) : 0;
                     int kmax = t - tMin;
@@ -457,16 +574,25 @@ __global__ __launch_bounds__(64) void kc_zbetter_match_grp_kernel(KcMatchParams 
                     t -= back;
                     l += back;
                 }
+#endif
                 emit(s - nextEmit, l - 3, (uint32_t)(s - t) + 3u);
                 s += l;
                 nextEmit = s;
                 if (s >= sLimit) { fin = true; continue; }
+#if ZB_FUSE
+                uint32_t o2pre = 0;  // the offset-2 loop's first candidate bytes, requested in front of the re-indexing's table trips
+                if (canRep) o2pre = ld32(base + (s - o2));
+#endif
                 reindex(index0, s - 1);
                 if (!canRep) continue;
-                for (;;) {  // offset-2 loop (:482-522)
+                for (bool first = true;; first = false) {  // offset-2 loop (:482-522)
                     const uint64_t cvs = rd64(s);
                     const int o2pos = s - o2;
+#if ZB_FUSE
+                    if ((first ? o2pre : ld32(base + o2pos)) != (uint32_t)cvs) break;
+#else
                     if (ld32(base + o2pos) != (uint32_t)cvs) break;
+#endif
                     const uint32_t nhL2 = hL(cvs), nhS2 = hS(cvs);
                     const int l2 = 4 + grp_matchlen<G>(base, s + 4, o2pos + 4, blkEnd - (s + 4), lig, grp);
                     const uint32_t oldx = C.rdLx(nhL2);
