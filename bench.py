@@ -240,6 +240,7 @@ def main():
                          "rank 0 (value null).  Run under torch.distributed.run like the real bench.")
     ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic in this run (two extra rocprofv3 passes of one step each)")
     ap.add_argument("--cpu-sample-units", type=int, default=0, help="units of the CPU-baseline / byte-compare sample (0: per configuration)")
+    ap.add_argument("--cpu-ref-units", type=int, default=256, help="units the translated reference encodes for cpu_baseline.reference_translated (one thread, ~35 MB/s)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="override the CPU baseline thread count")
     ap.add_argument("--no-also", action="store_true",
                     help="default invocation (C2, 1 GPU): do NOT run the other BASELINE configurations (C2H, C3, C4, C5: 3 steps each at their "
@@ -570,6 +571,30 @@ def main():
                 cpu["note"] = "the host has %d hardware threads; this container may run %d: a projection to the whole host (x%.1f) is NOT a measurement" % (host_threads, cores, host_threads / cores)
             got = d_dst[:int(out_off[sample])].cpu().numpy()
             parity = bool(np.array_equal(got, np.asarray(ref)) and np.array_equal(out_off[:sample + 1], ref_off))
+            # The reference's OWN encoder beside the port (zstd configurations): its Go source translated statement by statement to
+            # C++ (oracle/ref_go -> oracle/_ref/libzstdref*.so; no Go toolchain in this image, so this is not the Go compiler's code
+            # generation), one thread, one pooled encoder re-used across the units (encoder.go:722 with its pool) — and a second byte
+            # compare of the device's frames, against the reference itself.  A crash-safe leg: single-threaded, as the tests use it.
+            if not is_s2:
+                try:
+                    import oracle_goref
+                    if oracle_goref.available():
+                        ns = min(sample, args.cpu_ref_units)
+                        units_ = [bytes(host[i * UNIT:(i + 1) * UNIT]) for i in range(ns)]
+                        kwr = dict(level=cfg["level"])
+                        if dict_content:
+                            kwr.update(dict_id=1, dict_content=dict_content)
+                        fl = "amd64" if oracle_goref.amd64_available() else "generic"
+                        with oracle_goref.flavour(fl):
+                            t0 = time.perf_counter()
+                            frames_ = oracle_goref.zstd_encode_all_reuse(units_, **kwr)
+                            dt_ = time.perf_counter() - t0
+                        same_ = all(bytes(got[int(out_off[i]):int(out_off[i + 1])]) == frames_[i] for i in range(ns))
+                        cpu["reference_translated"] = {"value": round(ns * UNIT / dt_ / 1e6, 1), "unit": "MB/s", "cores": 1, "kind": "reference-translated",
+                                                       "device_bytes_equal": bool(same_),
+                                                       "sample": "first %d units through the reference's own zstd.Encoder.EncodeAll (Go source translated to C++ at build time, %s flavour: oracle/ref_go), one thread, one pooled encoder; one pass" % (ns, fl)}
+                except Exception as e:
+                    cpu["reference_translated"] = {"error": repr(e)[:200]}
         except Exception as e:  # the timed result must still be reported
             cpu = {"error": repr(e)[:300]}
 

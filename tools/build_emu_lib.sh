@@ -9,7 +9,7 @@ B=tools/_build/$T${ASAN:+_asan}
 mkdir -p $B
 FL="-O1 -g -std=c++17 -fPIC -x c++ -DKC_HIPEMU_HOST -I tools/hipemu -Wall -Wno-unused-function -Wno-unused-variable -Wno-unknown-pragmas ${ASAN:+-fsanitize=address -fno-omit-frame-pointer}"
 pids=()
-for f in compress_amd/csrc/kc_*.cpp tools/hipemu/kcgpu_emu_kernels.cpp tools/hipemu/hipemu.cpp; do
+for f in compress_amd/csrc/kc_*.cpp tools/hipemu/kcgpu_emu_kernels.cpp tools/hipemu/kcgpu_emu_probe.cpp tools/hipemu/hipemu.cpp; do
   g++ $FL -c $f -o $B/$(basename $f).o & pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
