@@ -446,15 +446,42 @@ void kc_launch_prefix_units(const uint8_t* src, const uint64_t* unit_off, const 
     if (n == 0) return;
     hipLaunchKernelGGL(kc_prefix_units_kernel, dim3(n), dim3(256), 0, st, src, unit_off, work_off, dict, dict_len, work, n);
 }
+#ifndef KC_BCAST_V
+#define KC_BCAST_V 1   // 0: measurement builds: one 16-byte word per thread, plain stores (4 KiB per workgroup and table)
+#endif
+// The dictionary-primed table image (4 MiB for SpeedBetter) written into every unit's table slot: a pure HBM write stream.  Each
+// workgroup holds 16 KiB of the image in registers (four 16-byte words per thread, read once) and writes it to its share of the
+// slots as four contiguous 4 KiB pieces per slot with non-temporal stores (nothing reads the lines before the match finder does).
 __global__ __launch_bounds__(256) void kc_bcast_kernel(const uint4* __restrict__ proto, uint4* __restrict__ dst, size_t n16, uint32_t n) {
+#if KC_BCAST_V
+    const size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    uint4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = i0 + 256u * q < n16 ? proto[i0 + 256u * q] : make_uint4(0, 0, 0, 0);
+    for (uint32_t k = blockIdx.y; k < n; k += gridDim.y) {
+        uint4* d = dst + (size_t)k * n16 + i0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (i0 + 256u * q < n16) {
+#ifdef KC_HIPEMU
+                d[256u * q] = v[q];
+#else
+                typedef uint32_t kc_v4u __attribute__((ext_vector_type(4)));
+                kc_v4u w; w.x = v[q].x; w.y = v[q].y; w.z = v[q].z; w.w = v[q].w;
+                __builtin_nontemporal_store(w, (kc_v4u*)(d + 256u * q));
+#endif
+            }
+    }
+#else
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n16) return;
     const uint4 v = proto[i];
     for (uint32_t k = blockIdx.y; k < n; k += gridDim.y) dst[(size_t)k * n16 + i] = v;
+#endif
 }
 void kc_launch_bcast(const uint8_t* proto, uint8_t* dst, size_t bytes, uint32_t n, hipStream_t st) {
     if (n == 0 || bytes == 0) return;
     const size_t n16 = bytes / 16;
     const uint32_t gy = n < 64 ? n : 64;
-    hipLaunchKernelGGL(kc_bcast_kernel, dim3((unsigned)((n16 + 255) / 256), gy), dim3(256), 0, st, (const uint4*)proto, (uint4*)dst, n16, n);
+    hipLaunchKernelGGL(kc_bcast_kernel, dim3((unsigned)(KC_BCAST_V ? (n16 + 1023) / 1024 : (n16 + 255) / 256), gy), dim3(256), 0, st, (const uint4*)proto, (uint4*)dst, n16, n);
 }
