@@ -18,6 +18,8 @@ BDIR = os.path.join(HERE, "_build" + ("_" + TAG if TAG else ""))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-munsafe-fp-atomics"] + os.environ.get("KC_EXTRA_FLAGS", "").split()
+# KC_FILE_FLAGS="kc_zstd_entropy.hip=-Os;kc_s2.hip=-O2 -DX=1" (measurement builds): flags appended for single source files
+FILE_FLAGS = dict((kv.split("=", 1)[0].strip(), kv.split("=", 1)[1].split()) for kv in os.environ.get("KC_FILE_FLAGS", "").split(";") if "=" in kv)
 
 
 def _newer(a, b):
@@ -36,7 +38,7 @@ def build(force=False, verbose=False):
         op = os.path.join(BDIR, s + ".o")
         objs.append(op)
         if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", op]
+            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
