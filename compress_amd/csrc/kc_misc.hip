@@ -438,8 +438,8 @@ __global__ __launch_bounds__(256) void kc_prefix_units_kernel(const uint8_t* __r
     uint8_t* w = work + work_off[u];
     const uint8_t* s = src + unit_off[u];
     const uint32_t len = (uint32_t)(unit_off[u + 1] - unit_off[u]);
-    for (uint32_t i = threadIdx.x; i < dict_len; i += 256) w[i] = dict[i];
-    for (uint32_t i = threadIdx.x; i < len; i += 256) w[dict_len + i] = s[i];
+    kc_copy_bytes(w, dict, dict_len, (int)threadIdx.x);  // (16-byte stores; a byte per thread and step made this kernel 1.7 ms per GiB of C5)
+    kc_copy_bytes(w + dict_len, s, len, (int)threadIdx.x);
 }
 void kc_launch_prefix_units(const uint8_t* src, const uint64_t* unit_off, const uint64_t* work_off, const uint8_t* dict, uint32_t dict_len,
                             uint8_t* work, uint32_t n, hipStream_t st) {
