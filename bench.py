@@ -225,6 +225,8 @@ def main():
                          "configurations (C3 / C5: no gain; C2H: 3.9 vs 2.9 ms; B4: a second set of 70 GB table slots).")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context: steps back to back on one stream")
     ap.add_argument("--contexts", type=int, default=0, help="zstd with --pipeline: contexts in flight (default 2; 3: the entropy stage of step i may drain under the match finders of steps i+1 AND i+2)")
+    ap.add_argument("--mf-in-flight", type=int, default=0, help="zstd with --pipeline: match finders of consecutive steps allowed on the chip together (0: per configuration; 1: one at a time; "
+                    "a kernel that does not fill the CUs with one batch, C5's, can share them with the next batch's)")
     ap.add_argument("--no-device-verify", action="store_true",
                     help="skip the on-device round trip (decode ALL frames on the device + compare with the input)")
     ap.add_argument("--gather", default="root", choices=["root", "none"],
@@ -241,6 +243,8 @@ def main():
     ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic in this run (two extra rocprofv3 passes of one step each)")
     ap.add_argument("--cpu-sample-units", type=int, default=0, help="units of the CPU-baseline / byte-compare sample (0: per configuration)")
     ap.add_argument("--cpu-ref-units", type=int, default=256, help="units the translated reference encodes for cpu_baseline.reference_translated (one thread, ~35 MB/s)")
+    ap.add_argument("--cpu-ref-units-per-thread", type=int, default=128, help="units per thread for cpu_baseline.reference_translated_parallel (the translated reference on one thread per CPU, child process)")
+    ap.add_argument("--no-cpu-ref-parallel", action="store_true", help="skip cpu_baseline.reference_translated_parallel")
     ap.add_argument("--cpu-threads", type=int, default=0, help="override the CPU baseline thread count")
     ap.add_argument("--no-also", action="store_true",
                     help="default invocation (C2, 1 GPU): do NOT run the other BASELINE configurations (C2H, C3, C4, C5: 3 steps each at their "
@@ -256,8 +260,13 @@ def main():
         # C2 since round 4; C3 and C5 since round 6 (same-box A/B, gpurun_out/r6w: C3 272.3 -> 266.8 ms per step with two contexts,
         # C5 64.4 -> 63.2 with three; C2H / B4 lose, S2 has no second stage)
         args.pipeline = args.config in ("C2", "C3", "C5")
-        if args.config == "C5" and args.contexts == 0:
+        if args.config in ("C2", "C5") and args.contexts == 0:
             args.contexts = 3
+        # Two match finders on the chip together (same-box A/B, gpurun_out/r8a-r8c): C5's kernel fills 8 of 12 wave slots per CU with one
+        # batch (a chain of dependent trips per unit, 0.63 of its request floor alone): 57.9 -> 49.2-50.6 ms per step; C2's is one
+        # residency per batch and gains the tail only: 150.9 -> 148.7 ms; C3 277.9 -> 276.9 (left at one)
+        if args.config in ("C2", "C5") and args.mf_in_flight == 0 and args.contexts >= 3:
+            args.mf_in_flight = 2
     cfg = dict(CONFIGS[args.config])
     if args.gib is not None:
         cfg["gib"] = args.gib
@@ -331,9 +340,10 @@ def main():
     ndst = npipe + 1 if (npipe >= 2 and world > 1) else (npipe if npipe >= 2 else (2 if world > 1 else 1))
     d_dsts = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(ndst)]
     gather = FrameGather(rank, world, bound_bytes=cap) if (world > 1 and args.gather == "root") else None
-    if npipe >= 2:  # one match finder at a time: context j's waits for context j-1's
+    mf_lag = max(1, args.mf_in_flight)
+    if npipe >= 2 and mf_lag < npipe:  # at most mf_lag match finders at a time (default one): context j's waits for context j-mf_lag's
         for j in range(npipe):
-            encs[j].ChainAfter(encs[(j - 1) % npipe])
+            encs[j].ChainAfter(encs[(j - mf_lag) % npipe])
     ctx0 = enc._ctx if is_s2 else enc.ctx()
     info = ctx0.device_info()
     torch.cuda.synchronize()
@@ -505,6 +515,9 @@ def main():
                 rd, wr = ent["rdreq_per_dispatch"], ent["wrreq_per_dispatch"]
                 floor_ms = (wr / pr["pairs_per_s"] + max(0.0, rd - wr) / pr["reads_per_s"]) * 1e3
                 k_alone = k_match  # with two contexts the event bracket includes the overlapped entropy stage: the also-line C2/one-context carries the kernel alone
+                shared = npipe >= 2 and 2 <= mf_lag < npipe and ms_per_step < k_match
+                if shared:  # two launches share the chip (C5): the time one batch's requests have is the step, not the launch (which also waits for CUs)
+                    k_alone = ms_per_step
                 roofline["floor"] = {
                     "transactions_per_unit": round((rd + wr) / n_units, 1), "reads_per_unit": ent["rdreq_per_unit"], "writes_per_unit": ent["wrreq_per_unit"],
                     "measured_pairs_per_s": round(pr["pairs_per_s"]), "measured_reads_per_s": round(pr["reads_per_s"]),
@@ -512,12 +525,22 @@ def main():
                     "floor_ms": round(floor_ms, 2), "kernel_ms": round(k_alone, 3), "frac_of_floor": round(floor_ms / k_alone, 3),
                     "model": "writes x (1 / pair rate) + (reads - writes) x (1 / scattered read rate); rates from kc_probe_table_pattern on this box in this run (%d tables of %d KiB, 4096 waves); requests from profiles/r06_transactions.json" % (n_units, ent["table_bytes_per_unit"] >> 10),
                     "transactions_source_current": ent["kernel_source_sha16"] == khash,
+                    "kernel_ms_is": "ms_per_step (two launches share the chip: a launch lasts longer than a step; the step also holds the other stages, so this fraction is a lower bound)" if shared else "the launch duration",
                     "note": "a bit-exact %s keeps one hash table per unit in HBM (%d GiB live): every probe is a DRAM read and a DRAM write-back of a 64-byte line that carries 4 useful bytes; the kernel runs at the request ceiling of that pattern, not at a byte roofline" % (cfg["what"], (n_units * ent["table_bytes_per_unit"]) >> 30)}
         except Exception as e:  # the timed result must still be reported
             roofline["floor"] = {"error": repr(e)[:200]}
     if npipe >= 2:  # several steps in flight: the event brackets of one step's kernels contain the other steps' work
         roofline["overlap_note"] = ("%d contexts: kernel_ms is the match finder's duration WITH the previous step's entropy stage running beside it (alone: "
                                     "--no-pipeline); entropy_kernel_ms / pipeline_kernel_ms span the match finder they run under and do not add up to ms_per_step" % npipe)
+        if mf_lag >= 2 and mf_lag < npipe:
+            # consecutive steps' match finders share the chip: a launch lasts longer than a step takes.  `achieved` / `frac` stay what the
+            # contract defines (bytes of one launch / its duration); the kernel's rate while two launches run is the second pair of fields
+            roofline["match_finders_in_flight"] = mf_lag
+            roofline["achieved_launches_in_flight"] = round(achieved * mf_lag, 2)
+            roofline["frac_launches_in_flight"] = round(achieved * mf_lag / HBM_PEAK_GBS, 5)
+            roofline["overlap_note"] += ("; up to %d match finders of consecutive steps run together (the next batch's starts as soon as the one two steps back "
+                                         "has ended), so kernel_ms also contains the wait for the CUs the other launch holds: achieved_launches_in_flight = %d x achieved "
+                                         "is the kernel's rate while they share the chip" % (mf_lag, mf_lag))
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement of the reference on the host threads + byte compare ----
     cpu = None
@@ -595,6 +618,32 @@ def main():
                                                        "sample": "first %d units through the reference's own zstd.Encoder.EncodeAll (Go source translated to C++ at build time, %s flavour: oracle/ref_go), one thread, one pooled encoder; one pass" % (ns, fl)}
                 except Exception as e:
                     cpu["reference_translated"] = {"error": repr(e)[:200]}
+                # ... and its goroutine-parallel form (north_star: "the reference's own goroutine-parallel CPU path"): one thread per
+                # CPU this container may run, each with ONE encoder of the reference re-used from unit to unit (what N goroutines on a
+                # zstd.Encoder get from its pool, encoder.go:90-99, 722-729).  A child process (tools/ref_parallel.py): a fault of the
+                # translated runtime under threads must not take this line along.  The child's frames are compared by digest.
+                if "value" in (cpu.get("reference_translated") or {}) and not args.no_cpu_ref_parallel:
+                    try:
+                        np_ = int(min(sample, cores * args.cpu_ref_units_per_thread))
+                        cmd = [sys.executable, os.path.join(ROOT, "tools", "ref_parallel.py"), "--kind", kind, "--seed", hex(SEEDS[kind]),
+                               "--first-unit", str(first_unit), "--units", str(np_), "--unit", str(UNIT), "--level", str(cfg["level"]),
+                               "--threads", str(cores), "--passes", "2"]
+                        if dict_content:
+                            cmd += ["--dict-kib", str(cfg["dict_kib"]), "--dict-seed", hex(DICT_SEED)]
+                        pr_ = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+                        if pr_.returncode != 0:
+                            cpu["reference_translated_parallel"] = {"error": "child rc %d: %s" % (pr_.returncode, pr_.stderr.decode(errors="replace")[-200:])}
+                        else:
+                            rp = json.loads(pr_.stdout.decode().strip().splitlines()[-1])
+                            if "value" in rp:
+                                dig = hashlib.sha256(got[:int(out_off[np_])].tobytes()).hexdigest()
+                                rp = {"value": rp["value"], "unit": "MB/s", "cores": rp["cores"], "kind": "reference-translated, one thread per CPU",
+                                      "device_bytes_equal": bool(dig == rp["frames_sha256"] and int(out_off[np_]) == rp["frames_bytes"]),
+                                      "sample": "first %d units, %d threads with one pooled encoder of the reference each (%s flavour), best of %d passes after an untimed one (passes: %s s); child process tools/ref_parallel.py"
+                                                % (np_, rp["cores"], rp["flavour"], len(rp["passes_s"]), rp["passes_s"])}
+                            cpu["reference_translated_parallel"] = rp
+                    except Exception as e:
+                        cpu["reference_translated_parallel"] = {"error": repr(e)[:200]}
         except Exception as e:  # the timed result must still be reported
             cpu = {"error": repr(e)[:300]}
 
@@ -753,7 +802,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "name": args.config, "units_per_gpu": n_units, "unit_bytes": UNIT, "corpus": kind,
                        "parallelism": ("units sharded contiguously over %d GPU(s); %s" % (world, "RCCL gather of frames to rank 0" if gather is not None else "no gather: every rank keeps its shard of frames")) if world > 1 else "1 GPU",
-                       "pipeline": ("%d contexts / %d streams: match finder of step i+1 overlaps the entropy stage of step i" % (npipe, npipe) if npipe >= 2
+                       "pipeline": ("%d contexts / %d streams: match finder of step i+1 overlaps the entropy stage of step i%s" % (npipe, npipe, "" if not (2 <= mf_lag < npipe) else " and the match finder of step i+%d" % (mf_lag - 1)) if npipe >= 2
                                     else "none: steps back to back on one stream"),
                        "device": info},
             "contexts": npipe,  # machine-readable: 2 = the two-context pipeline (kernel timings of consecutive steps overlap), 1 = steps back to back

@@ -270,7 +270,7 @@ kc_status validate_units(kc_ctx* c, const kc_zstd_opts* o, const uint64_t* unit_
 // empty error text: no engine on this device - the caller's older paths serve the call.
 typedef std::function<kc_status(kc_ctx* lane, const uint8_t* d_in, const uint64_t* rel_off, uint32_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_off_rel)> RollEncFn;
 kc_status host_rolling(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint8_t* dst, uint64_t dst_cap,
-                       uint64_t* out_off, const RollEncFn& enc, const std::function<uint64_t(uint64_t)>& max_out);
+                       uint64_t* out_off, const RollEncFn& enc, const std::function<uint64_t(uint64_t)>& max_out, uint64_t sub_bytes = 0);  // sub_bytes 0: host_roll_sub_bytes
 uint64_t host_roll_sub_bytes(const kc_ctx* c, uint64_t total);
 kc_status host_roll_trim(int device);  // kc_device_trim: free the idle engine's device slots and its lanes' scratch
 }  // namespace kci

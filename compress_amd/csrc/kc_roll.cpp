@@ -368,7 +368,7 @@ uint64_t host_roll_sub_bytes(const kc_ctx* c, uint64_t total) {
 }
 
 kc_status host_rolling(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off, uint32_t n_units, uint8_t* dst, uint64_t dst_cap,
-                       uint64_t* out_off, const RollEncFn& enc, const std::function<uint64_t(uint64_t)>& max_out) {
+                       uint64_t* out_off, const RollEncFn& enc, const std::function<uint64_t(uint64_t)>& max_out, uint64_t sub_bytes) {
     RollEngine* E = engine_for(c->device);
     if (!E) { c->err.clear(); return KC_ERR_UNSUPPORTED; }  // no engine on this device (start-up failed): the caller's older paths serve the call
     RollCall call;
@@ -393,7 +393,7 @@ kc_status host_rolling(kc_ctx* c, const uint8_t* src, const uint64_t* unit_off, 
         call.dst_pinned = pinned(dst, dst_cap);
     }
     const uint64_t total = unit_off[n_units] - unit_off[0];
-    const uint64_t sub = host_roll_sub_bytes(c, total);
+    const uint64_t sub = sub_bytes ? sub_bytes : host_roll_sub_bytes(c, total);
     call.cut.push_back(0);
     {
         uint64_t acc = 0, nd = 0;

@@ -23,7 +23,13 @@ kc_status kc_zstd_encode_units(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* 
             return sm ? kc_zstd_encode_streams_dev(lane, &oc, d_in, rel, nu, d_out, cap, oo) : kc_zstd_encode_units_dev(lane, &oc, d_in, rel, nu, d_out, cap, oo);
         };
         auto mx = [oc](uint64_t len) { return (uint64_t)kc_zstd_max_encoded_size(&oc, (int64_t)len); };
-        s = host_rolling(c, src, unit_off, n_units, dst, dst_cap, out_off, enc, mx);
+        // SpeedBetterCompression: a unit takes ~45 ms however few are resident (a chain of dependent table trips), so its sub-batches are
+        // halves, not quarters: measured on C5 (1 GiB calls, four in flight) 15.2 GB/s with quarters, 18.4 with halves, 19.5 uncut; one
+        // call alone 13.7 / 13.0 / 12.0 (profiles/r06_ab_kernels.txt, session r8c)
+        uint64_t sub = 0;
+        if (o->level == KC_SPEED_BETTER && c->cfg.host_roll_mib < 1)
+            sub = std::min<uint64_t>((uint64_t)1 << 30, std::max<uint64_t>((total + 1) / 2, (uint64_t)64 << 20));
+        s = host_rolling(c, src, unit_off, n_units, dst, dst_cap, out_off, enc, mx, sub);
         if (s != KC_ERR_UNSUPPORTED || !c->err.empty()) return s;  // UNSUPPORTED with no message: no engine on this device
     }
     if (total >= ov_min && !c->cfg.host_serial && c->cfg.host_pipe_mib < 16 && c->cuts == nullptr) {
