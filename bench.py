@@ -764,7 +764,9 @@ def main():
         # zstd SpeedBestCompression, s2.EncodeBetter, s2.EncodeBest) so that the driver's one run times those too
         for name, extra in (("C2/one-context", ["--no-pipeline"]), ("C2H", []), ("C3", []), ("C4", []), ("C4A", []), ("C5", []), ("B4", ["--gib", "0.75"]),
                             ("C4/s2.EncodeBetter", ["--s2-level", "1"]), ("C4/s2.EncodeBest", ["--s2-level", "4", "--gib", "1.5"])):  # (s2.EncodeBest: 24 576 blocks = one residency at 4 blocks per wave, 6 waves per SIMD; B4: 6 144 units = the default table slots)
-            cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("/")[0], "--steps", str(args.also_steps), "--warmup", "1",
+            # (C5: three contexts with two match finders in flight — a launch lasts longer than a step, so 3 steps would be mostly fill and drain)
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("/")[0], "--steps", str(max(args.also_steps, 9) if name == "C5" else args.also_steps),
+                   "--warmup", "3" if name == "C5" else "1",
                    "--no-also", "--cpu-sample-units", "1024" if not extra else "256", "--path", args.path] + extra
             if name not in ("C3", "C4", "C5"):  # the host-buffer rate of every BASELINE configuration; not of the side lines
                 cmd.append("--no-end-to-end")
