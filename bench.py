@@ -260,12 +260,14 @@ def main():
         # C2 since round 4; C3 and C5 since round 6 (same-box A/B, gpurun_out/r6w: C3 272.3 -> 266.8 ms per step with two contexts,
         # C5 64.4 -> 63.2 with three; C2H / B4 lose, S2 has no second stage)
         args.pipeline = args.config in ("C2", "C3", "C5")
-        if args.config in ("C2", "C5") and args.contexts == 0:
+        if args.config == "C5" and args.contexts == 0:
             args.contexts = 3
-        # Two match finders on the chip together (same-box A/B, gpurun_out/r8a-r8c): C5's kernel fills 8 of 12 wave slots per CU with one
-        # batch (a chain of dependent trips per unit, 0.63 of its request floor alone): 57.9 -> 49.2-50.6 ms per step; C2's is one
-        # residency per batch and gains the tail only: 150.9 -> 148.7 ms; C3 277.9 -> 276.9 (left at one)
-        if args.config in ("C2", "C5") and args.mf_in_flight == 0 and args.contexts >= 3:
+        # Two match finders on the chip together (same-box A/B, gpurun_out/r8a-r8c, r8e): C5's kernel fills 8 of 12 wave slots per CU with
+        # one batch (a chain of dependent trips per unit, 0.63 of its request floor alone): 57.9 -> 49.2-50.6 ms per step.  C2's and C3's
+        # are one residency per batch: a second launch gets nothing until the first ends (kernel trace: 299 ms for a launch beside
+        # another) and the steady state is one after the other again (C2 150.9 -> 148.7, C3 277.9 -> 276.9): left at one at a time,
+        # whose launch durations are the kernel's own
+        if args.config == "C5" and args.mf_in_flight == 0 and args.contexts >= 3:
             args.mf_in_flight = 2
     cfg = dict(CONFIGS[args.config])
     if args.gib is not None:
@@ -454,7 +456,8 @@ def main():
 
     # ---- roofline of the dominant kernel, from HIP events on the launch stream (kc_last_timings) ----
     tm = ktimes[-1]
-    k_match = float(np.median([t["match_ms"] for t in ktimes]))
+    # the AVERAGE launch duration over the timed steps (what rocprofv3 --stats reports under the kernel's name); the per-step values are in the line
+    k_match = float(np.mean([t["match_ms"] for t in ktimes]))
     k_entropy = float(np.median([t["entropy_ms"] for t in ktimes]))
     k_total = float(np.median([t["total_ms"] for t in ktimes]))
     k_prep = float(np.median([t.get("prep_ms", 0.0) for t in ktimes]))
@@ -497,7 +500,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": cfg["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_source_sha16": khash,
-                "kernel_ms": round(k_match, 3), "table_prep_ms": round(k_prep, 3), "entropy_kernel_ms": round(k_entropy, 3), "pipeline_kernel_ms": round(k_total, 3),
+                "kernel_ms": round(k_match, 3), "kernel_ms_steps": [round(t["match_ms"] - t.get("prep_ms", 0.0), 2) for t in ktimes][:64], "table_prep_ms": round(k_prep, 3), "entropy_kernel_ms": round(k_entropy, 3), "pipeline_kernel_ms": round(k_total, 3),
                 "pipeline_frac": round(algo_bytes / (k_total / 1000.0) / 1e9 / HBM_PEAK_GBS, 5),
                 "read_only_frac": round(in_bytes / (k_match / 1000.0) / 1e9 / HBM_PEAK_GBS, 5)}
     # ---- the floor of this design: the dominant kernel's DRAM requests per dispatch (TCC_EA0_RDREQ / WRREQ,
