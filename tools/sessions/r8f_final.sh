@@ -1,18 +1,18 @@
 #!/bin/bash
-# Session r8d: closing state of round 6 after the shared-match-finder arrangement (C2, C5: three contexts, two match finders in flight): kernel-trace stats of C2 and C5, then the driver's three commands (smoke, default bench, pytest -m gpu).
+# Session r8f: closing state of round 6 after the shared-match-finder arrangement (C2, C5: three contexts, two match finders in flight): kernel-trace stats of C2 and C5, then the driver's three commands (smoke, default bench, pytest -m gpu).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r8d
+OUT=$R/gpurun_out/r8f
 mkdir -p $OUT
 cd $R
 ulimit -c 0
-for c in C2 C5; do
+for c in C5; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_$c -- python bench.py --config $c --no-also --no-cpu-baseline --no-end-to-end --no-device-verify --no-floor > $OUT/kt_$c.log 2>&1
 done
 python - <<PY
 import sqlite3, glob, csv, os
 out = "$OUT"
-for tag in ("C2", "C5"):
+for tag in ("C5",):
     f = glob.glob(os.path.join(out, "kt_" + tag, "**", "*.db"), recursive=True)
     if not f: print("no db for", tag); continue
     k = sqlite3.connect(f[0])
