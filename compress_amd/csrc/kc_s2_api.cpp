@@ -365,7 +365,12 @@ kc_status kc_s2_encode_blocks_lvl(kc_ctx* c, int level, const uint8_t* src, cons
             return kc_s2_encode_blocks_lvl_dev(lane, level, d_in, rel, nu, d_out, cap, oo);
         };
         auto mx = [](uint64_t len) { return (uint64_t)kc_s2_max_encoded_len((int64_t)len); };
-        const kc_status rs = host_rolling(c, src, blk_off, n, dst, dst_cap, out_off, enc, mx);
+        // sub-batches: halves (at most 1 GiB), not the engine's quarters — an S2 launch of 512 MiB is a quarter of a residency and four such
+        // launches side by side run behind one of 2 GiB: C4 (2 GiB calls, four in flight) 40.9-41.9 GB/s with quarters, 45.2-45.3 with halves,
+        // one call alone 25.5 / 25.3 (profiles/r06_ab_kernels.txt, session r8g)
+        uint64_t sub = 0;
+        if (c->cfg.host_roll_mib < 1) sub = std::min<uint64_t>((uint64_t)1 << 30, std::max<uint64_t>((total + 1) / 2, (uint64_t)64 << 20));
+        const kc_status rs = host_rolling(c, src, blk_off, n, dst, dst_cap, out_off, enc, mx, sub);
         if (rs != KC_ERR_UNSUPPORTED || !c->err.empty()) return rs;  // UNSUPPORTED with no message: no engine on this device
     }
     if (total >= ov_min && total <= c->max_batch_bytes && !c->cfg.host_serial && c->cfg.host_pipe_mib < 16 && level < KC_S2_LEVEL_BEST) {  // (the best levels: 4.5 MiB of tables per block, several device batches)
