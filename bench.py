@@ -225,6 +225,8 @@ def main():
                          "configurations (C3 / C5: no gain; C2H: 3.9 vs 2.9 ms; B4: a second set of 70 GB table slots).")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context: steps back to back on one stream")
     ap.add_argument("--contexts", type=int, default=0, help="zstd with --pipeline: contexts in flight (default 2; 3: the entropy stage of step i may drain under the match finders of steps i+1 AND i+2)")
+    ap.add_argument("--split", type=int, default=0, help="zstd with --pipeline: every step's batch runs as this many launches of n_units / split units each, going round the contexts; "
+                    "each part's frames are put right behind the previous part's (kc_zstd_encode_units_dev_end_at), so the pass produces the same contiguous output (0: per configuration)")
     ap.add_argument("--mf-in-flight", type=int, default=0, help="zstd with --pipeline: match finders of consecutive steps allowed on the chip together (0: per configuration; 1: one at a time; "
                     "a kernel that does not fill the CUs with one batch, C5's, can share them with the next batch's)")
     ap.add_argument("--no-device-verify", action="store_true",
@@ -260,6 +262,12 @@ def main():
         # C2 since round 4; C3 and C5 since round 6 (same-box A/B, gpurun_out/r6w: C3 272.3 -> 266.8 ms per step with two contexts,
         # C5 64.4 -> 63.2 with three; C2H / B4 lose, S2 has no second stage)
         args.pipeline = args.config in ("C2", "C3", "C5")
+        # One 4 GiB batch as TWO launches of half the units, three contexts, two match finders in flight (same-box A/B, gpurun_out/r8h,
+        # r8i): C2 151.3 -> 144.4-145.5 ms per 4 GiB (+4.4 %), C3 262-266 -> 244-247 (+7.5 %).  A launch of all 32 768 units is exactly
+        # one residency of the chip: every workgroup starts together and the chip drains while the slowest finish; with halves the
+        # next half's workgroups take the slots as the previous half's leave them.  (1 GiB quarters: slower — launches too small.)
+        if args.config in ("C2", "C3") and args.contexts == 0 and args.split == 0 and args.mf_in_flight == 0:
+            args.contexts, args.split, args.mf_in_flight = 3, 2, 2
         if args.config == "C5" and args.contexts == 0:
             args.contexts = 3
         # Two match finders on the chip together (same-box A/B, gpurun_out/r8a-r8c, r8e): C5's kernel fills 8 of 12 wave slots per CU with
@@ -269,6 +277,8 @@ def main():
         # whose launch durations are the kernel's own
         if args.config == "C5" and args.mf_in_flight == 0 and args.contexts >= 3:
             args.mf_in_flight = 2
+    if args.split <= 0 or not args.pipeline:
+        args.split = 1
     cfg = dict(CONFIGS[args.config])
     if args.gib is not None:
         cfg["gib"] = args.gib
@@ -343,6 +353,8 @@ def main():
     d_dsts = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(ndst)]
     gather = FrameGather(rank, world, bound_bytes=cap) if (world > 1 and args.gather == "root") else None
     mf_lag = max(1, args.mf_in_flight)
+    S = args.split if (npipe >= 2 and not is_s2) else 1
+    cuts = [n_units * h // S for h in range(S + 1)]
     if npipe >= 2 and mf_lag < npipe:  # at most mf_lag match finders at a time (default one): context j's waits for context j-mf_lag's
         for j in range(npipe):
             encs[j].ChainAfter(encs[(j - mf_lag) % npipe])
@@ -360,6 +372,37 @@ def main():
         pending = None
         tw = time.perf_counter()
         begun = 0
+        if S > 1:
+            # the batch of every step as S launches (parts), the parts of consecutive steps going round the contexts; a part's frames go
+            # right behind the previous part's, so a step leaves the same contiguous frames + offsets as one launch would
+            def begin_part(g):
+                a, b = cuts[g % S], cuts[g % S + 1]
+                encs[g % npipe].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off[a:b + 1], d_dsts[(g // S) % ndst].data_ptr(), cap)
+            for i in range(k):
+                db = i % ndst
+                pos = 0
+                off = np.zeros(n_units + 1, dtype=np.uint64)
+                for h in range(S):
+                    g = i * S + h
+                    while begun < k * S and begun < g + npipe:
+                        begin_part(begun)
+                        begun += 1
+                    o = encs[g % npipe].EncodeUnitsDeviceEnd(d_dsts[db].data_ptr() + pos, cap - pos)
+                    a, b = cuts[h], cuts[h + 1]
+                    off[a + 1:b + 1] = o[1:] + np.uint64(pos)
+                    pos += int(o[b - a])
+                    tms.append(encs[g % npipe].ctx().timings())
+                if gather is not None:
+                    if pending is not None:
+                        pending.wait()
+                    pending = gather.start(d_dsts[db], int(off[n_units]))
+                last = db
+                tn = time.perf_counter()
+                walls.append((tn - tw) * 1e3)
+                tw = tn
+            if pending is not None:
+                pending.wait()
+            return off, last, tms, walls
         if not is_s2:
             encs[0].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off, d_dsts[0].data_ptr(), cap)
             begun = 1
@@ -463,7 +506,7 @@ def main():
     k_prep = float(np.median([t.get("prep_ms", 0.0) for t in ktimes]))
     k_match -= k_prep  # match_ms brackets table preparation + kernel: the kernel alone is what rocprofv3 reports under its name
     algo_bytes = in_bytes + out_bytes  # 1 B read + ratio B written per input byte
-    achieved = algo_bytes / (k_match / 1000.0) / 1e9
+    achieved = (algo_bytes / S) / (k_match / 1000.0) / 1e9  # one LAUNCH processes n_units / S units (--split)
     if args.config == "C2H":
         # high-entropy input: the match finder skips most bytes and no kernel dominates; the "dominant kernel" of this
         # configuration is the whole pipeline (match finder + entropy stage + checksum-and-copy + compaction of the headers)
@@ -491,6 +534,9 @@ def main():
                     continue
                 if ent.get("kernel_source_sha16") == khash:
                     traffic, traffic_src = ent["kernel_hbm_bytes"], "profiles/pmc_traffic.json (same workload, same kernel source)"
+                    if S > 1:  # the counters were collected on the dispatch of all units; a launch of this run holds 1 / S of them (per-unit requests do not depend on the launch size)
+                        traffic = int(traffic / S)
+                        traffic_src += "; per launch of %d units = the %d-unit dispatch's bytes / %d" % (n_units // S, n_units, S)
                 elif khash in ent.get("also_valid_for_sha16", []):
                     # collected on an earlier form of this kernel's source; the entry says why it still describes the running one
                     traffic = ent["kernel_hbm_bytes"]
@@ -501,8 +547,11 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_source_sha16": khash,
                 "kernel_ms": round(k_match, 3), "kernel_ms_steps": [round(t["match_ms"] - t.get("prep_ms", 0.0), 2) for t in ktimes][:64], "table_prep_ms": round(k_prep, 3), "entropy_kernel_ms": round(k_entropy, 3), "pipeline_kernel_ms": round(k_total, 3),
-                "pipeline_frac": round(algo_bytes / (k_total / 1000.0) / 1e9 / HBM_PEAK_GBS, 5),
-                "read_only_frac": round(in_bytes / (k_match / 1000.0) / 1e9 / HBM_PEAK_GBS, 5)}
+                "pipeline_frac": round((algo_bytes / S) / (k_total / 1000.0) / 1e9 / HBM_PEAK_GBS, 5),
+                # the step's algorithmic bytes over the step's wall time: with launches that share the chip, `frac` (one launch / its duration, which
+                # contains the wait for the CUs the other launch holds) is below and frac_launches_in_flight above what the kernel sustains; this is its floor
+                "step_frac": round(algo_bytes / (ms_per_step / 1000.0) / 1e9 / HBM_PEAK_GBS, 5),
+                "read_only_frac": round((in_bytes / S) / (k_match / 1000.0) / 1e9 / HBM_PEAK_GBS, 5)}
     # ---- the floor of this design: the dominant kernel's DRAM requests per dispatch (TCC_EA0_RDREQ / WRREQ,
     # profiles/r06_transactions.json, stamped with the kernel's source hash) priced at the request rates THIS box gives the same access
     # pattern right now (kc_probe_table_pattern: scattered 4-byte read + write-back pairs / plain reads into per-unit tables of the
@@ -518,8 +567,8 @@ def main():
                 rd, wr = ent["rdreq_per_dispatch"], ent["wrreq_per_dispatch"]
                 floor_ms = (wr / pr["pairs_per_s"] + max(0.0, rd - wr) / pr["reads_per_s"]) * 1e3
                 k_alone = k_match  # with two contexts the event bracket includes the overlapped entropy stage: the also-line C2/one-context carries the kernel alone
-                shared = npipe >= 2 and 2 <= mf_lag < npipe and ms_per_step < k_match
-                if shared:  # two launches share the chip (C5): the time one batch's requests have is the step, not the launch (which also waits for CUs)
+                shared = npipe >= 2 and 2 <= mf_lag < npipe and ms_per_step < S * k_match
+                if shared:  # launches share the chip (C5; the halves of C2 / C3): the time one batch's requests have is the step, not the launches (which also wait for CUs)
                     k_alone = ms_per_step
                 roofline["floor"] = {
                     "transactions_per_unit": round((rd + wr) / n_units, 1), "reads_per_unit": ent["rdreq_per_unit"], "writes_per_unit": ent["wrreq_per_unit"],
@@ -535,6 +584,9 @@ def main():
     if npipe >= 2:  # several steps in flight: the event brackets of one step's kernels contain the other steps' work
         roofline["overlap_note"] = ("%d contexts: kernel_ms is the match finder's duration WITH the previous step's entropy stage running beside it (alone: "
                                     "--no-pipeline); entropy_kernel_ms / pipeline_kernel_ms span the match finder they run under and do not add up to ms_per_step" % npipe)
+        if S > 1:
+            roofline["launches_per_step"] = S
+            roofline["overlap_note"] += "; every step's batch runs as %d launches of %d units (kernel_ms, achieved and traffic are per launch)" % (S, n_units // S)
         if mf_lag >= 2 and mf_lag < npipe:
             # consecutive steps' match finders share the chip: a launch lasts longer than a step takes.  `achieved` / `frac` stay what the
             # contract defines (bytes of one launch / its duration); the kernel's rate while two launches run is the second pair of fields
@@ -768,8 +820,9 @@ def main():
         for name, extra in (("C2/one-context", ["--no-pipeline"]), ("C2H", []), ("C3", []), ("C4", []), ("C4A", []), ("C5", []), ("B4", ["--gib", "0.75"]),
                             ("C4/s2.EncodeBetter", ["--s2-level", "1"]), ("C4/s2.EncodeBest", ["--s2-level", "4", "--gib", "1.5"])):  # (s2.EncodeBest: 24 576 blocks = one residency at 4 blocks per wave, 6 waves per SIMD; B4: 6 144 units = the default table slots)
             # (C5: three contexts with two match finders in flight — a launch lasts longer than a step, so 3 steps would be mostly fill and drain)
-            cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("/")[0], "--steps", str(max(args.also_steps, 9) if name == "C5" else args.also_steps),
-                   "--warmup", "3" if name == "C5" else "1",
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("/")[0],
+                   "--steps", str(max(args.also_steps, 9) if name == "C5" else max(args.also_steps, 6) if name == "C3" else args.also_steps),  # (C3: two launches per step, two in flight)
+                   "--warmup", "3" if name == "C5" else "2" if name == "C3" else "1",
                    "--no-also", "--cpu-sample-units", "1024" if not extra else "256", "--path", args.path] + extra
             if name not in ("C3", "C4", "C5"):  # the host-buffer rate of every BASELINE configuration; not of the side lines
                 cmd.append("--no-end-to-end")
@@ -807,9 +860,12 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "name": args.config, "units_per_gpu": n_units, "unit_bytes": UNIT, "corpus": kind,
                        "parallelism": ("units sharded contiguously over %d GPU(s); %s" % (world, "RCCL gather of frames to rank 0" if gather is not None else "no gather: every rank keeps its shard of frames")) if world > 1 else "1 GPU",
-                       "pipeline": ("%d contexts / %d streams: match finder of step i+1 overlaps the entropy stage of step i%s" % (npipe, npipe, "" if not (2 <= mf_lag < npipe) else " and the match finder of step i+%d" % (mf_lag - 1)) if npipe >= 2
+                       "pipeline": (("%d contexts / %d streams: " % (npipe, npipe)) + (
+                                        "every step's batch as %d launches of %d units going round the contexts, up to %d match finders on the chip together, the entropy stage of a launch under the following launches' match finders; frames contiguous as from one launch" % (S, n_units // S, mf_lag) if S > 1 else
+                                        "match finder of step i+1 overlaps the entropy stage of step i%s" % ("" if not (2 <= mf_lag < npipe) else " and the match finder of step i+%d" % (mf_lag - 1))) if npipe >= 2
                                     else "none: steps back to back on one stream"),
                        "device": info},
+            "split": S,  # launches per step (--split): the batch's units in S parts, frames contiguous as from one launch
             "contexts": npipe,  # machine-readable: 2 = the two-context pipeline (kernel timings of consecutive steps overlap), 1 = steps back to back
             "ratio": round(out_bytes / in_bytes, 5),
             "value_GiBps": round(value * 1e6 / 2**30, 3),

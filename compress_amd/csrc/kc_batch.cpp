@@ -676,6 +676,8 @@ kc_status batch_begin(kc_ctx* c, const kc_zstd_opts* o, const uint8_t* d_src_bas
     P->unit_off.assign(unit_off, unit_off + n_units + 1);
     P->n_units = n_units;
     P->d_dst = d_dst;
+    P->need = pl.stage_off[n_units];
+    P->fed = feed != nullptr;
     P->bs = bs;
     P->k2prof = k2prof;
     c->pend = P;
@@ -1020,6 +1022,17 @@ kc_status kc_zstd_encode_units_dev_end(kc_ctx* c, uint64_t* out_off) {
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t produced = 0;
     return batch_end(c, out_off, &produced);
+}
+
+kc_status kc_zstd_encode_units_dev_end_at(kc_ctx* c, uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off) {
+    if (!c || !out_off || !d_dst) return KC_ERR_BAD_ARG;
+    if (!c->pend) { c->err = "no batch in flight on this context"; return KC_ERR_BAD_ARG; }
+    Pending* P = (Pending*)c->pend;
+    // the frames leave the staging slots only in _end (sizes -> offsets -> compaction): until then their place can still be named
+    if (P->fed) { c->err = "a chunk-fed batch has written its frames already"; return KC_ERR_UNSUPPORTED; }
+    if (P->need > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedSize(unit)"; return KC_ERR_DST_TOO_SMALL; }
+    P->d_dst = d_dst;
+    return kc_zstd_encode_units_dev_end(c, out_off);
 }
 
 void kc_ctx_chain_after(kc_ctx* c, kc_ctx* prev) {

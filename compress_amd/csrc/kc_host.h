@@ -48,6 +48,8 @@ struct Pending {
     std::vector<uint64_t> unit_off;
     uint32_t n_units = 0;
     uint8_t* d_dst = nullptr;
+    uint64_t need = 0;   // sum of the units' staging slots: what dst must hold (checked again when _end_at names another place)
+    bool fed = false;    // chunk-fed batch: its frames went to dst while the chunks ran — _end_at cannot move them
     int bs = 0;
     bool k2prof = false;
 };

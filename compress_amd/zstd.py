@@ -500,12 +500,17 @@ class Encoder:
         ctx.check(ctx.L.kc_zstd_encode_units_dev_begin(ctx.h, C.byref(self.o), d_src_ptr, unit_off.ctypes.data, self._pending_n,
                                                        d_dst_ptr, int(dst_cap)))
 
-    def EncodeUnitsDeviceEnd(self):
-        """Second half: entropy stage, wait, offsets (uint64[n+1], host numpy)."""
+    def EncodeUnitsDeviceEnd(self, d_dst_ptr=None, dst_cap=0):
+        """Second half: entropy stage, wait, offsets (uint64[n+1], host numpy).  d_dst_ptr: the frames go THERE instead of to the
+        place given to Begin (kc_zstd_encode_units_dev_end_at: the parts of one batch run as several launches, each part's frames
+        right behind the previous part's); the offsets are relative to it."""
         import numpy as np
         ctx = self.ctx()
         out_off = np.zeros(self._pending_n + 1, dtype=np.uint64)
-        ctx.check(ctx.L.kc_zstd_encode_units_dev_end(ctx.h, out_off.ctypes.data))
+        if d_dst_ptr is None:
+            ctx.check(ctx.L.kc_zstd_encode_units_dev_end(ctx.h, out_off.ctypes.data))
+        else:
+            ctx.check(ctx.L.kc_zstd_encode_units_dev_end_at(ctx.h, d_dst_ptr, int(dst_cap), out_off.ctypes.data))
         return out_off
 
     def ChainAfter(self, other):

@@ -271,6 +271,12 @@ kc_status kc_wait(kc_ctx* ctx);
 kc_status kc_zstd_encode_units_dev_begin(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
                                          uint32_t n_units, uint8_t* d_dst, uint64_t dst_cap);
 kc_status kc_zstd_encode_units_dev_end(kc_ctx* ctx, uint64_t* out_off);
+/* _end with the place of the frames named only now (d_dst of _begin is then just the capacity check): the frames of a batch leave
+ * their staging slots in _end, so a caller that runs ONE EncodeAll batch as several smaller launches — two halves of a 4 GiB batch
+ * on three contexts, chained two apart, are 4-8 % faster than one launch (the second half's units fill the first half's tail:
+ * DESIGN.md 4.1) — puts each part's frames right behind the previous part's and gets the same contiguous output, out_off relative
+ * to the d_dst given here.  KC_ERR_DST_TOO_SMALL if dst_cap is below the sum of MaxEncodedSize(unit) of this batch. */
+kc_status kc_zstd_encode_units_dev_end_at(kc_ctx* ctx, uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
 void kc_ctx_chain_after(kc_ctx* ctx, kc_ctx* prev);
 
 /* XXH64(seed 0) of every unit (the frame checksum primitive), device-resident input, host output. */

@@ -296,6 +296,64 @@ def test_begin_end_pipeline_two_contexts(oracle, kclib):
         e.Close()
 
 
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_one_batch_as_parts_on_three_contexts(oracle, kclib, level):
+    """One EncodeAll batch run as several launches (bench.py --split): the parts go round three contexts chained TWO apart (two
+    match finders on the device together) and every part's frames are put right behind the previous part's with
+    kc_zstd_encode_units_dev_end_at.  Same offsets and bytes as the one blocking call, pass after pass, with ragged parts."""
+    torch = _torch()
+    from compress_amd import zstd
+    n, usz = 768, 131072
+    bufs = [corpora.corpus(k, n, usz, first_unit=29 * j) for j, k in enumerate("TM")]
+    off = np.arange(n + 1, dtype=np.uint64) * usz
+    d_srcs = [torch.from_numpy(b).cuda() for b in bufs]
+    ref_enc = _enc(level)
+    cap = n * ((ref_enc.MaxEncodedSize(usz) + 15) & ~15) + 64
+    d_ref = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    refs = []
+    for d in d_srcs:
+        o = ref_enc.EncodeUnitsDevice(d.data_ptr(), off, d_ref.data_ptr(), cap)
+        refs.append((o.copy(), d_ref[:int(o[n])].cpu().numpy().copy()))
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    encs = [zstd.NewWriter(None, zstd.WithEncoderLevel(level), stream=s.cuda_stream) for s in streams]
+    for j in range(3):
+        encs[j].ChainAfter(encs[(j - 2) % 3])
+    cuts = [0, 300, 301, 768]  # ragged parts, one of a single unit
+    parts = [(p, a, b) for p in range(len(d_srcs)) for a, b in zip(cuts[:-1], cuts[1:])]
+    d_dst = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(len(d_srcs))]
+    torch.cuda.synchronize()
+
+    def begin(g):
+        p, a, b = parts[g]
+        encs[g % 3].EncodeUnitsDeviceBegin(d_srcs[p].data_ptr(), off[a:b + 1], d_dst[p].data_ptr(), cap)
+
+    begun = 0
+    pos = 0
+    offs = [0]
+    for g in range(len(parts)):
+        while begun < len(parts) and begun < g + 3:
+            begin(begun)
+            begun += 1
+        p, a, b = parts[g]
+        if a == 0:
+            pos, offs = 0, [0]
+        o = encs[g % 3].EncodeUnitsDeviceEnd(d_dst[p].data_ptr() + pos, cap - pos)
+        assert int(o[0]) == 0
+        offs += [pos + int(x) for x in o[1:]]
+        pos += int(o[b - a])
+        if b == n:
+            assert np.array_equal(np.array(offs, dtype=np.uint64), refs[p][0]), (level, p)
+            assert np.array_equal(d_dst[p][:pos].cpu().numpy(), refs[p][1]), (level, p)
+    # the capacity is checked against the place named at the end
+    encs[0].EncodeUnitsDeviceBegin(d_srcs[0].data_ptr(), off[:9], d_dst[0].data_ptr(), cap)
+    with pytest.raises(Exception):
+        encs[0].EncodeUnitsDeviceEnd(d_dst[0].data_ptr(), 100)
+    o = encs[0].EncodeUnitsDeviceEnd()  # the batch is still in flight after the refusal: finished where Begin said
+    assert np.array_equal(o, refs[0][0][:9]) and np.array_equal(d_dst[0][:int(o[8])].cpu().numpy(), refs[0][1][:int(o[8])])
+    for e in encs + [ref_enc]:
+        e.Close()
+
+
 @pytest.mark.parametrize("level", LEVELS_B)
 def test_streams_bit_exact(oracle, kclib, level):
     """N2: NewWriter(w).Write(...) / Close() streams (kc_zstd_encode_streams_dev) against the oracle's restatement of
