@@ -261,7 +261,11 @@ def main():
     if args.pipeline is None:
         # C2 since round 4; C3 and C5 since round 6 (same-box A/B, gpurun_out/r6w: C3 272.3 -> 266.8 ms per step with two contexts,
         # C5 64.4 -> 63.2 with three; C2H / B4 lose, S2 has no second stage)
-        args.pipeline = args.config in ("C2", "C3", "C5")
+        args.pipeline = args.config in ("C2", "C3", "C5") or (args.config in ("C4", "C4A") and args.s2_level < 4)
+        # s2.Encode (no second stage): the 2 GiB batch of 64 KiB blocks is one residency too; as two launches on three contexts
+        # (kc_s2_encode_blocks_lvl_dev_begin / _end_at) 43.5 -> 41.1 ms (tools/s2_split_probe.py, gpurun_out/r8k)
+        if args.config in ("C4", "C4A") and args.s2_level < 4 and args.contexts == 0 and args.split == 0:
+            args.contexts, args.split = 3, 2
         # One 4 GiB batch as TWO launches of half the units, three contexts, two match finders in flight (same-box A/B, gpurun_out/r8h,
         # r8i): C2 151.3 -> 144.4-145.5 ms per 4 GiB (+4.4 %), C3 262-266 -> 244-247 (+7.5 %).  A launch of all 32 768 units is exactly
         # one residency of the chip: every workgroup starts together and the chip drains while the slowest finish; with halves the
@@ -330,10 +334,10 @@ def main():
             dict_content = broadcast_bytes(dict_content, torch.device("cuda", local_rank))
 
     is_s2 = cfg["codec"] == "s2"
-    npipe = (args.contexts if args.contexts >= 2 else 2) if (args.pipeline and not is_s2) else 1
+    npipe = (args.contexts if args.contexts >= 2 else 2) if (args.pipeline and (not is_s2 or (args.split > 1 and args.s2_level < 4))) else 1
     streams = [torch.cuda.Stream() for _ in range(npipe)]
     if is_s2:
-        encs = [s2.BlockEncoder(device=local_rank, stream=streams[0].cuda_stream, level=args.s2_level, path=args.path, variant=cfg.get("variant"))]
+        encs = [s2.BlockEncoder(device=local_rank, stream=st.cuda_stream, level=args.s2_level, path=args.path, variant=cfg.get("variant")) for st in streams]
         cfg["what"] = {0: cfg["what"], 1: "s2.EncodeBetter", 2: "s2.EncodeSnappy", 3: "s2.EncodeSnappyBetter", 4: "s2.EncodeBest", 5: "s2.EncodeSnappyBest"}[args.s2_level]
         cfg["kernel"] = "kc_s2_encode_kernel<%d>" % args.s2_level if args.s2_level < 4 else "kc_s2_best_kernel<%s>" % ("true" if args.s2_level == 5 else "false")
         if args.s2_level >= 4:
@@ -353,9 +357,12 @@ def main():
     d_dsts = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(ndst)]
     gather = FrameGather(rank, world, bound_bytes=cap) if (world > 1 and args.gather == "root") else None
     mf_lag = max(1, args.mf_in_flight)
-    S = args.split if (npipe >= 2 and not is_s2) else 1
+    S = args.split if npipe >= 2 else 1
+    if is_s2 and npipe >= 2 and S < 2:
+        ap.error("s2 with --pipeline runs through the begin / end_at pair: give --split >= 2")
     cuts = [n_units * h // S for h in range(S + 1)]
-    if npipe >= 2 and mf_lag < npipe:  # at most mf_lag match finders at a time (default one): context j's waits for context j-mf_lag's
+    inflight = 1 if npipe < 2 else (npipe if (is_s2 or mf_lag >= npipe) else mf_lag)  # dominant-kernel launches that may be on the chip together
+    if npipe >= 2 and mf_lag < npipe and not is_s2:  # at most mf_lag match finders at a time (default one): context j's waits for context j-mf_lag's
         for j in range(npipe):
             encs[j].ChainAfter(encs[(j - mf_lag) % npipe])
     ctx0 = enc._ctx if is_s2 else enc.ctx()
@@ -377,7 +384,10 @@ def main():
             # right behind the previous part's, so a step leaves the same contiguous frames + offsets as one launch would
             def begin_part(g):
                 a, b = cuts[g % S], cuts[g % S + 1]
-                encs[g % npipe].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off[a:b + 1], d_dsts[(g // S) % ndst].data_ptr(), cap)
+                if is_s2:
+                    encs[g % npipe].EncodeBlocksDeviceBegin(d_src.data_ptr(), unit_off[a:b + 1])
+                else:
+                    encs[g % npipe].EncodeUnitsDeviceBegin(d_src.data_ptr(), unit_off[a:b + 1], d_dsts[(g // S) % ndst].data_ptr(), cap)
             for i in range(k):
                 db = i % ndst
                 pos = 0
@@ -387,11 +397,14 @@ def main():
                     while begun < k * S and begun < g + npipe:
                         begin_part(begun)
                         begun += 1
-                    o = encs[g % npipe].EncodeUnitsDeviceEnd(d_dsts[db].data_ptr() + pos, cap - pos)
+                    if is_s2:
+                        o = encs[g % npipe].EncodeBlocksDeviceEnd(d_dsts[db].data_ptr() + pos, cap - pos)
+                    else:
+                        o = encs[g % npipe].EncodeUnitsDeviceEnd(d_dsts[db].data_ptr() + pos, cap - pos)
                     a, b = cuts[h], cuts[h + 1]
                     off[a + 1:b + 1] = o[1:] + np.uint64(pos)
                     pos += int(o[b - a])
-                    tms.append(encs[g % npipe].ctx().timings())
+                    tms.append((encs[g % npipe]._ctx if is_s2 else encs[g % npipe].ctx()).timings())
                 if gather is not None:
                     if pending is not None:
                         pending.wait()
@@ -567,7 +580,7 @@ def main():
                 rd, wr = ent["rdreq_per_dispatch"], ent["wrreq_per_dispatch"]
                 floor_ms = (wr / pr["pairs_per_s"] + max(0.0, rd - wr) / pr["reads_per_s"]) * 1e3
                 k_alone = k_match  # with two contexts the event bracket includes the overlapped entropy stage: the also-line C2/one-context carries the kernel alone
-                shared = npipe >= 2 and 2 <= mf_lag < npipe and ms_per_step < S * k_match
+                shared = inflight >= 2 and ms_per_step < S * k_match
                 if shared:  # launches share the chip (C5; the halves of C2 / C3): the time one batch's requests have is the step, not the launches (which also wait for CUs)
                     k_alone = ms_per_step
                 roofline["floor"] = {
@@ -581,21 +594,24 @@ def main():
                     "note": "a bit-exact %s keeps one hash table per unit in HBM (%d GiB live): every probe is a DRAM read and a DRAM write-back of a 64-byte line that carries 4 useful bytes; the kernel runs at the request ceiling of that pattern, not at a byte roofline" % (cfg["what"], (n_units * ent["table_bytes_per_unit"]) >> 30)}
         except Exception as e:  # the timed result must still be reported
             roofline["floor"] = {"error": repr(e)[:200]}
-    if npipe >= 2:  # several steps in flight: the event brackets of one step's kernels contain the other steps' work
+    if npipe >= 2 and is_s2:
+        roofline["overlap_note"] = "%d contexts, the launches unchained: kernel_ms is one launch's duration with the other launches beside it" % npipe
+    elif npipe >= 2:  # several steps in flight: the event brackets of one step's kernels contain the other steps' work
         roofline["overlap_note"] = ("%d contexts: kernel_ms is the match finder's duration WITH the previous step's entropy stage running beside it (alone: "
                                     "--no-pipeline); entropy_kernel_ms / pipeline_kernel_ms span the match finder they run under and do not add up to ms_per_step" % npipe)
+    if npipe >= 2:
         if S > 1:
             roofline["launches_per_step"] = S
             roofline["overlap_note"] += "; every step's batch runs as %d launches of %d units (kernel_ms, achieved and traffic are per launch)" % (S, n_units // S)
-        if mf_lag >= 2 and mf_lag < npipe:
+        if inflight >= 2:
             # consecutive steps' match finders share the chip: a launch lasts longer than a step takes.  `achieved` / `frac` stay what the
             # contract defines (bytes of one launch / its duration); the kernel's rate while two launches run is the second pair of fields
-            roofline["match_finders_in_flight"] = mf_lag
-            roofline["achieved_launches_in_flight"] = round(achieved * mf_lag, 2)
-            roofline["frac_launches_in_flight"] = round(achieved * mf_lag / HBM_PEAK_GBS, 5)
-            roofline["overlap_note"] += ("; up to %d match finders of consecutive steps run together (the next batch's starts as soon as the one two steps back "
-                                         "has ended), so kernel_ms also contains the wait for the CUs the other launch holds: achieved_launches_in_flight = %d x achieved "
-                                         "is the kernel's rate while they share the chip" % (mf_lag, mf_lag))
+            roofline["match_finders_in_flight"] = inflight
+            roofline["achieved_launches_in_flight"] = round(achieved * inflight, 2)
+            roofline["frac_launches_in_flight"] = round(achieved * inflight / HBM_PEAK_GBS, 5)
+            roofline["overlap_note"] += ("; up to %d launches of the dominant kernel are on the chip together, so kernel_ms also contains the wait for the CUs the "
+                                         "other launches hold: achieved_launches_in_flight = %d x achieved is an upper bound of the kernel's rate while they share the chip, "
+                                         "step_frac (the step's bytes over the step's time) a lower one" % (inflight, inflight))
 
     # ---- CPU baseline (rank 0, N == 1 only): the oracle restatement of the reference on the host threads + byte compare ----
     cpu = None
@@ -860,7 +876,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "name": args.config, "units_per_gpu": n_units, "unit_bytes": UNIT, "corpus": kind,
                        "parallelism": ("units sharded contiguously over %d GPU(s); %s" % (world, "RCCL gather of frames to rank 0" if gather is not None else "no gather: every rank keeps its shard of frames")) if world > 1 else "1 GPU",
-                       "pipeline": (("%d contexts / %d streams: " % (npipe, npipe)) + (
+                       "pipeline": ("%d contexts / %d streams: every step's batch as %d launches of %d blocks going round the contexts (begin / end_at), unchained; blocks contiguous as from one launch" % (npipe, npipe, S, n_units // S)) if (is_s2 and npipe >= 2) else (("%d contexts / %d streams: " % (npipe, npipe)) + (
                                         "every step's batch as %d launches of %d units going round the contexts, up to %d match finders on the chip together, the entropy stage of a launch under the following launches' match finders; frames contiguous as from one launch" % (S, n_units // S, mf_lag) if S > 1 else
                                         "match finder of step i+1 overlaps the entropy stage of step i%s" % ("" if not (2 <= mf_lag < npipe) else " and the match finder of step i+%d" % (mf_lag - 1))) if npipe >= 2
                                     else "none: steps back to back on one stream"),

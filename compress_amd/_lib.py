@@ -40,7 +40,7 @@ SYMBOLS = [
     "kc_zstd_opts_no_entropy", "kc_zstd_opts_all_lit_entropy", "kc_zstd_opts_single_segment", "kc_zstd_opts_concurrency", "kc_zstd_opts_dict_raw", "kc_zstd_opts_dict",
     "kc_zstd_max_encoded_size", "kc_ctx_create", "kc_ctx_destroy", "kc_last_error", "kc_device_info",
     "kc_zstd_encode_units", "kc_zstd_encode_units_dev", "kc_zstd_encode_streams_dev", "kc_zstd_encode_streams", "kc_zstd_encode_streams_cuts_dev", "kc_zstd_encode_streams_cuts", "kc_zstd_encode_units_submit", "kc_s2_encode_blocks_lvl_submit", "kc_wait", "kc_zstd_plan_stream_blocks", "kc_zstd_encode_units_dev_begin", "kc_zstd_encode_units_dev_end", "kc_zstd_encode_units_dev_end_at", "kc_ctx_chain_after", "kc_xxh64_units_dev", "kc_zstd_debug_parse_dev",
-    "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats", "kc_s2_encode_blocks_lvl", "kc_s2_encode_blocks_lvl_dev", "kc_s2_encode_stream_lvl_dev",
+    "kc_s2_max_encoded_len", "kc_s2_encode_blocks", "kc_s2_encode_blocks_dev", "kc_s2_encode_stream_dev", "kc_s2_decode_blocks_dev", "kc_zstd_decode_units_dev", "kc_zstd_decode_units_dict_dev", "kc_s2_encode_block", "kc_s2_hook_stats", "kc_s2_encode_blocks_lvl", "kc_s2_encode_blocks_lvl_dev", "kc_s2_encode_blocks_lvl_dev_begin", "kc_s2_encode_blocks_lvl_dev_end_at", "kc_s2_encode_stream_lvl_dev",
     "kc_last_timings", "kc_corpus_fill", "kc_ctx_set_option", "kc_ctx_get_option", "kc_zstd_encode_jobs", "kc_zstd_job_size", "kc_zstd_overlap_size",
     "kc_probe_table_pattern", "kc_probe_pcie", "kc_ctx_trim", "kc_device_trim", "kc_s2_hook_declined", "kc_create_error", "kc_host_alloc", "kc_host_free",
 ]
@@ -123,6 +123,10 @@ def load():
     L.kc_zstd_encode_units_dev_end.argtypes = [vp, vp]
     L.kc_zstd_encode_units_dev_end.restype = C.c_int
     L.kc_zstd_encode_units_dev_end_at.argtypes = [vp, vp, C.c_uint64, vp]
+    L.kc_s2_encode_blocks_lvl_dev_begin.argtypes = [vp, C.c_int, vp, vp, C.c_uint32]
+    L.kc_s2_encode_blocks_lvl_dev_begin.restype = C.c_int
+    L.kc_s2_encode_blocks_lvl_dev_end_at.argtypes = [vp, vp, C.c_uint64, vp]
+    L.kc_s2_encode_blocks_lvl_dev_end_at.restype = C.c_int
     L.kc_zstd_encode_units_dev_end_at.restype = C.c_int
     L.kc_ctx_chain_after.argtypes = [vp, vp]
     L.kc_ctx_chain_after.restype = None

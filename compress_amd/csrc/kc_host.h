@@ -125,6 +125,7 @@ struct kc_ctx {
     KcCfg cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    uint32_t s2_pend_n = 0;  // blocks of the S2 batch between kc_s2_encode_blocks_lvl_dev_begin and _end_at (0: none in flight)
     // lanes of the rolling host pipeline (kc_roll.cpp) only: the S2 HBM-table path zeroes the table arena for the NEXT batch on
     // stream2 as soon as this batch's encoder is done with it (behind ev[1]) - under the partner lane's encoder instead of 4 ms in
     // front of its own (the arena is 64 KiB per block whatever the block holds).  preclear_bytes of tables.p are then zero once

@@ -17,10 +17,38 @@ int64_t kc_s2_max_encoded_len(int64_t srcLen) {  // s2/encode.go:389-418 (64-bit
     return (int64_t)n;
 }
 
+// phase 0: the whole call.  phase 1 (_begin): everything up to and including the encoder kernel, no wait — d_dst / dst_cap / out_off unused;
+// phase 2 (_end_at): sizes -> offsets -> compaction to the d_dst named NOW, offsets to the host, wait (the blocks of a batch leave their
+// staging slots only here, which is what lets one batch run as several launches with one contiguous output).
 static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
                                uint64_t dst_cap, uint64_t* out_off, int framed, int with_stream_id, int level = KC_S2_LEVEL_DEFAULT,
-                               ChunkFeed* feed = nullptr) {
-    if (!c || !blk_off || !out_off || (n && (!d_src || !d_dst))) return KC_ERR_BAD_ARG;
+                               ChunkFeed* feed = nullptr, int phase = 0) {
+    if (phase == 2) {
+        if (!c || !out_off || !d_dst) return KC_ERR_BAD_ARG;
+        if (c->s2_pend_n == 0) { c->err = "no S2 batch in flight on this context"; return KC_ERR_BAD_ARG; }
+        HIPCHK(c, hipSetDevice(c->device));
+        n = c->s2_pend_n;
+        if (c->plan.stage_off[n] > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
+        c->s2_pend_n = 0;
+        hipStream_t st = c->stream;
+        kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n, (uint64_t*)c->out_off.p, st);
+        kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p, (const uint32_t*)c->out_size.p,
+                          (const uint64_t*)c->out_off.p, d_dst, n, st);
+        HIPCHK(c, hipEventRecord(c->ev[2], st));
+        HIPCHK(c, hipMemcpyAsync(out_off, c->out_off.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipGetLastError());
+        float t01 = 0, t12 = 0;
+        (void)hipEventElapsedTime(&t01, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&t12, c->ev[1], c->ev[2]);
+        c->last.match_ms = t01;
+        c->last.other_ms = t12;
+        c->last.total_ms = t01 + t12;
+        return KC_OK;
+    }
+    if (!c || !blk_off || (phase == 0 && !out_off) || (n && (!d_src || (phase == 0 && !d_dst)))) return KC_ERR_BAD_ARG;
+    if (phase == 1 && (framed || feed || n == 0 || level >= KC_S2_LEVEL_BEST)) { c->err = "begin / end: bare blocks of one batch below the best levels"; return KC_ERR_UNSUPPORTED; }
+    if (phase == 1 && c->s2_pend_n != 0) { c->err = "an S2 batch is in flight on this context"; return KC_ERR_BAD_ARG; }
     if (feed && (framed || n == 0)) { c->err = "chunk feed: bare blocks only"; return KC_ERR_INTERNAL; }
     // s2.WriterUncompressed: a level of the writer (writer.go:951; encodeBlock returns 0 for it, :455-480): framed only, every block one
     // uncompressed chunk — served by the LDS-table kernels' stored path (wave-parallel CRC32C + copy), whatever the batch
@@ -67,7 +95,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     rel[n] = blk_off[n] - blk_off[0];
     so[n] = acc;
     reg[n] = acc16;
-    if (acc16 + lead > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
+    if (phase == 0 && acc16 + lead > dst_cap) { c->err = "dst_cap smaller than the sum of MaxEncodedLen(block)"; return KC_ERR_DST_TOO_SMALL; }
     // s2.Encode / s2.EncodeSnappy: the LDS-table kernel (one wave per block, ~1 ms per 64 KiB block whatever the batch) while the
     // blocks in flight cannot cover the HBM-table kernel's latency (measured crossover: profiles/r03_crossover_s2.csv)
     // The best levels are pure Go in the reference — one form on every platform (s2/encode_best.go) — so the variant does not
@@ -161,6 +189,11 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
         HIPCHK(c, hipEventRecord(c->ev_preclear, c->stream2));
         c->preclear_ptr = c->tables.p;
         c->preclear_bytes = tab_bytes;
+    }
+    if (phase == 1) {  // the rest is _end_at's
+        HIPCHK(c, hipGetLastError());
+        c->s2_pend_n = n;
+        return KC_OK;
     }
     kc_launch_scan_sizes((const uint32_t*)c->out_size.p, n, (uint64_t*)c->out_off.p, st);
     kc_launch_compact((const uint8_t*)c->stage.p, (const uint64_t*)c->stage_off.p, (const uint32_t*)c->out_size.p,
@@ -335,6 +368,25 @@ kc_status kc_s2_encode_stream_dev(kc_ctx* c, const uint8_t* d_src, const uint64_
 kc_status kc_s2_encode_blocks_lvl_dev(kc_ctx* c, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,
                                       uint64_t dst_cap, uint64_t* out_off) {
     return s2_encode_dev_budgeted(c, d_src, blk_off, n, d_dst, dst_cap, out_off, 0, 0, level);
+}
+
+kc_status kc_s2_encode_blocks_lvl_dev_begin(kc_ctx* c, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n) {
+    if (!c || !blk_off || !d_src || n == 0) return KC_ERR_BAD_ARG;
+    // one device batch: what the scratch budget would cut goes through the blocking call
+    uint64_t maxLen = 0;
+    for (uint32_t i = 0; i < n; i++) if (blk_off[i + 1] >= blk_off[i]) maxLen = std::max(maxLen, blk_off[i + 1] - blk_off[i]);
+    if (level >= KC_S2_LEVEL_DEFAULT && level < KC_S2_LEVEL_BEST) {
+        const uint64_t tb = kc_s2_table_bytes(level, maxLen, (int)c->cfg.s2_variant);
+        uint64_t scratch = 0;
+        for (uint32_t i = 0; i < n; i++) scratch += tb + (((uint64_t)std::max<int64_t>(0, kc_s2_max_encoded_len((int64_t)(blk_off[i + 1] >= blk_off[i] ? blk_off[i + 1] - blk_off[i] : 0))) + 8 + 63) & ~(uint64_t)63);
+        if (scratch + (scratch >> 3) > scratch_budget(c)) { c->err = "begin / end serves one device batch; use kc_s2_encode_blocks_lvl_dev for larger inputs"; return KC_ERR_UNSUPPORTED; }
+    }
+    return s2_encode_dev(c, d_src, blk_off, n, nullptr, 0, nullptr, 0, 0, level, nullptr, 1);
+}
+
+kc_status kc_s2_encode_blocks_lvl_dev_end_at(kc_ctx* c, uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off) {
+    if (!c) return KC_ERR_BAD_ARG;
+    return s2_encode_dev(c, nullptr, nullptr, 0, d_dst, dst_cap, out_off, 0, 0, KC_S2_LEVEL_DEFAULT, nullptr, 2);
 }
 
 kc_status kc_s2_encode_stream_lvl_dev(kc_ctx* c, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n, uint8_t* d_dst,

@@ -60,6 +60,26 @@ class BlockEncoder:
             ctx.check(ctx.L.kc_s2_encode_blocks_lvl_dev(ctx.h, self.level, d_src_ptr, blk_off.ctypes.data, n, d_dst_ptr, int(dst_cap), out_off.ctypes.data))
         return out_off
 
+    def EncodeBlocksDeviceBegin(self, d_src_ptr, blk_off):
+        """First half of EncodeBlocksDevice (one device batch, bare blocks): enqueue up to and including the encoder kernel, no wait
+        (kc_s2_encode_blocks_lvl_dev_begin)."""
+        import numpy as np
+        ctx = self._ctx
+        blk_off = np.ascontiguousarray(blk_off, dtype=np.uint64)
+        self._pending_n = len(blk_off) - 1
+        with self._mu:
+            ctx.check(ctx.L.kc_s2_encode_blocks_lvl_dev_begin(ctx.h, self.level, d_src_ptr, blk_off.ctypes.data, self._pending_n))
+
+    def EncodeBlocksDeviceEnd(self, d_dst_ptr, dst_cap):
+        """Second half: the blocks are compacted to d_dst_ptr (named only now: the parts of one batch run as several launches, each part
+        right behind the previous one), offsets relative to it (uint64[n+1]), wait."""
+        import numpy as np
+        ctx = self._ctx
+        out_off = np.zeros(self._pending_n + 1, dtype=np.uint64)
+        with self._mu:
+            ctx.check(ctx.L.kc_s2_encode_blocks_lvl_dev_end_at(ctx.h, d_dst_ptr, int(dst_cap), out_off.ctypes.data))
+        return out_off
+
     def EncodeStreamDevice(self, d_src_ptr, blk_off, d_dst_ptr, dst_cap, with_stream_id=True):
         """s2.Writer framing of the blocks (stream identifier + chunks).  Returns uint64[n+1] chunk offsets."""
         import numpy as np

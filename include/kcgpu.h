@@ -314,6 +314,14 @@ kc_status kc_s2_encode_blocks_lvl(kc_ctx* ctx, int level, const uint8_t* src, co
                                   uint8_t* dst, uint64_t dst_cap, uint64_t* out_off);
 kc_status kc_s2_encode_blocks_lvl_dev(kc_ctx* ctx, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
                                       uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
+/* Split form of kc_s2_encode_blocks_lvl_dev for ONE device batch of bare blocks below the best levels (the S2 sibling of
+ * kc_zstd_encode_units_dev_begin / _end_at): _begin enqueues everything up to and including the encoder kernel and returns without
+ * waiting; _end_at compacts the blocks to the d_dst named there, copies the offsets (relative to it) and waits.  A 2 GiB batch of
+ * 64 KiB blocks is exactly one residency of the chip; run as two launches on three contexts (three host threads, or begin / begin /
+ * end_at / ...) the next launch's blocks take the wave slots as the previous launch's leave them: measured +5-6 %.
+ * d_src must stay valid until _end_at returns; blk_off is copied.  KC_ERR_UNSUPPORTED: framed, best levels, more than one batch. */
+kc_status kc_s2_encode_blocks_lvl_dev_begin(kc_ctx* ctx, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks);
+kc_status kc_s2_encode_blocks_lvl_dev_end_at(kc_ctx* ctx, uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off);
 /* kc_s2_encode_stream_dev at a chosen level (s2.WriterBetterCompression, s2/writer.go:931) */
 kc_status kc_s2_encode_stream_lvl_dev(kc_ctx* ctx, int level, const uint8_t* d_src, const uint64_t* blk_off, uint32_t n_blocks,
                                       uint8_t* d_dst, uint64_t dst_cap, uint64_t* out_off, int with_stream_id);

@@ -654,6 +654,56 @@ def test_s2_host_rolling_pipeline_equals_oracle(oracle, kclib, level, monkeypatc
     enc.Close()
 
 
+@pytest.mark.parametrize("level,path", [(0, "hbm"), (0, "lds"), (1, "hbm"), (2, "hbm")])
+def test_s2_one_batch_as_parts_on_three_contexts(oracle, kclib, level, path):
+    """One batch of blocks run as several launches (bench.py --split for C4): kc_s2_encode_blocks_lvl_dev_begin / _end_at on three
+    contexts, the launches unchained, every part's blocks right behind the previous part's.  Same offsets and bytes as the oracle's and
+    as the one blocking call; misuse (a second begin, an end without a begin, a place too small) is reported."""
+    import torch
+    from compress_amd import s2
+    blocks = corpora.stress_units(seed=977 + level, n=96)
+    j = corpora.corpus("J", 160, 65536).tobytes()
+    blocks += [j[i * 65536:(i + 1) * 65536] for i in range(160)]
+    blocks[11] = b""
+    buf, off = corpora.pack_units(blocks)
+    n = len(blocks)
+    ref, ref_off = oracle.s2_encode_blocks(buf, off, threads=8, better=level in (1, 3), snappy=level in (2, 3))
+    d_src = torch.from_numpy(np.ascontiguousarray(buf)).cuda()
+    cap = sum((s2.MaxEncodedLen(len(b)) + 15) & ~15 for b in blocks) + 64
+    d_dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    encs = [s2.BlockEncoder(level=level, stream=st.cuda_stream, path=path) for st in streams]
+    cuts = [0, 100, 101, 180, n]
+    parts = list(zip(cuts[:-1], cuts[1:])) * 2  # two passes
+    torch.cuda.synchronize()
+    begun, pos, offs = 0, 0, [0]
+    for g, (a, b) in enumerate(parts):
+        while begun < len(parts) and begun < g + 3:
+            pa, pb = parts[begun]
+            encs[begun % 3].EncodeBlocksDeviceBegin(d_src.data_ptr(), off[pa:pb + 1])
+            begun += 1
+        if a == 0:
+            pos, offs = 0, [0]
+        o = encs[g % 3].EncodeBlocksDeviceEnd(d_dst.data_ptr() + pos, cap - pos)
+        assert int(o[0]) == 0
+        offs += [pos + int(x) for x in o[1:]]
+        pos += int(o[b - a])
+        if b == n:
+            assert np.array_equal(np.array(offs, dtype=np.uint64), np.asarray(ref_off)), (level, path)
+            assert np.array_equal(d_dst[:pos].cpu().numpy(), np.asarray(ref)), (level, path)
+    with pytest.raises(Exception):
+        encs[0].EncodeBlocksDeviceEnd(d_dst.data_ptr(), cap)  # nothing in flight
+    encs[0].EncodeBlocksDeviceBegin(d_src.data_ptr(), off[:9])
+    with pytest.raises(Exception):
+        encs[0].EncodeBlocksDeviceBegin(d_src.data_ptr(), off[:9])  # busy
+    with pytest.raises(Exception):
+        encs[0].EncodeBlocksDeviceEnd(d_dst.data_ptr(), 16)  # too small: the batch stays in flight
+    o = encs[0].EncodeBlocksDeviceEnd(d_dst.data_ptr(), cap)
+    assert np.array_equal(o, np.asarray(ref_off)[:9])
+    for e in encs:
+        e.Close()
+
+
 @pytest.mark.parametrize("level", [0, 1])
 def test_s2_batches_cut_by_the_scratch_budget(oracle, kclib, level):
     """the S2 device path cuts a call into several batches when its tables + staging slots exceed the scratch budget
