@@ -856,8 +856,9 @@ def main():
                             ("C4/s2.EncodeBetter", ["--s2-level", "1"]), ("C4/s2.EncodeBest", ["--s2-level", "4", "--gib", "1.5"])):  # (s2.EncodeBest: 24 576 blocks = one residency at 4 blocks per wave, 6 waves per SIMD; B4: 6 144 units = the default table slots)
             # (C5: three contexts with two match finders in flight — a launch lasts longer than a step, so 3 steps would be mostly fill and drain)
             cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("/")[0],
-                   "--steps", str(max(args.also_steps, 9) if name == "C5" else max(args.also_steps, 6) if name == "C3" else args.also_steps),  # (C3: two launches per step, two in flight)
-                   "--warmup", "3" if name == "C5" else "2" if name == "C3" else "1",
+                   # (launches of consecutive steps share the chip: 3 steps would be mostly fill and drain)
+                   "--steps", str(max(args.also_steps, 9) if name == "C5" else max(args.also_steps, 6) if name == "C3" else max(args.also_steps, 12) if (name.startswith("C4") and "Best" not in name) else args.also_steps),
+                   "--warmup", "3" if (name == "C5" or (name.startswith("C4") and "Best" not in name)) else "2" if name == "C3" else "1",
                    "--no-also", "--cpu-sample-units", "1024" if not extra else "256", "--path", args.path] + extra
             if name not in ("C3", "C4", "C5"):  # the host-buffer rate of every BASELINE configuration; not of the side lines
                 cmd.append("--no-end-to-end")
