@@ -279,8 +279,10 @@ def main():
         # are one residency per batch: a second launch gets nothing until the first ends (kernel trace: 299 ms for a launch beside
         # another) and the steady state is one after the other again (C2 150.9 -> 148.7, C3 277.9 -> 276.9): left at one at a time,
         # whose launch durations are the kernel's own
+        # (C5, r8p: the three contexts' match finders unchained — the third takes wave slots as the first one's workgroups leave — 48.6-48.8 ms
+        # against 50.5-51.1 with the chain of lag two; C2 within the noise of its box, C3 slower: they keep the chain)
         if args.config == "C5" and args.mf_in_flight == 0 and args.contexts >= 3:
-            args.mf_in_flight = 2
+            args.mf_in_flight = args.contexts
     if args.split <= 0 or not args.pipeline:
         args.split = 1
     cfg = dict(CONFIGS[args.config])
