@@ -265,8 +265,8 @@ kc_status kc_wait(kc_ctx* ctx);
  * finder wait for A's (and vice versa), which keeps one match finder on the device at a time: right for SpeedFastest and
  * SpeedDefault, whose kernels are one residency of the chip per 4 GiB batch.  A SpeedBetterCompression batch of 1 GiB fills
  * 8 of 12 wave slots per CU and every unit is a chain of dependent table trips: with three contexts chained two apart
- * (chain_after(C, A), chain_after(A, B), chain_after(B, C)) two consecutive batches' match finders share the chip
- * (measured +16 %: DESIGN.md 4.2).  d_src, d_dst and the options' dictionary must stay valid until _end returns; unit_off
+ * (chain_after(C, A), chain_after(A, B), chain_after(B, C)) — or not chained at all — consecutive batches' match finders share the
+ * chip (measured +16-20 %: DESIGN.md 4.2).  d_src, d_dst and the options' dictionary must stay valid until _end returns; unit_off
  * is copied. */
 kc_status kc_zstd_encode_units_dev_begin(kc_ctx* ctx, const kc_zstd_opts* o, const uint8_t* d_src, const uint64_t* unit_off,
                                          uint32_t n_units, uint8_t* d_dst, uint64_t dst_cap);
