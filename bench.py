@@ -227,6 +227,8 @@ def main():
     ap.add_argument("--contexts", type=int, default=0, help="zstd with --pipeline: contexts in flight (default 2; 3: the entropy stage of step i may drain under the match finders of steps i+1 AND i+2)")
     ap.add_argument("--split", type=int, default=0, help="zstd with --pipeline: every step's batch runs as this many launches of n_units / split units each, going round the contexts; "
                     "each part's frames are put right behind the previous part's (kc_zstd_encode_units_dev_end_at), so the pass produces the same contiguous output (0: per configuration)")
+    ap.add_argument("--stage2-priority", type=int, default=0, help="zstd with --pipeline (measurement): 1 = every context's entropy stage and what follows on a HIGH-priority stream of its own "
+                    "(KC_OPT_STAGE2_STREAM), the match finders on LOW-priority streams — what the rolling host pipeline's lanes do; 0 = one default-priority stream per context")
     ap.add_argument("--mf-in-flight", type=int, default=0, help="zstd with --pipeline: match finders of consecutive steps allowed on the chip together (0: per configuration; 1: one at a time; "
                     "a kernel that does not fill the CUs with one batch, C5's, can share them with the next batch's)")
     ap.add_argument("--no-device-verify", action="store_true",
@@ -338,6 +340,10 @@ def main():
     is_s2 = cfg["codec"] == "s2"
     npipe = (args.contexts if args.contexts >= 2 else 2) if (args.pipeline and (not is_s2 or (args.split > 1 and args.s2_level < 4))) else 1
     streams = [torch.cuda.Stream() for _ in range(npipe)]
+    streams2 = []
+    if args.stage2_priority and npipe >= 2 and cfg["codec"] != "s2":
+        streams = [torch.cuda.Stream(priority=0) for _ in range(npipe)]    # (ROCm: 0 = low / normal, -1 = high)
+        streams2 = [torch.cuda.Stream(priority=-1) for _ in range(npipe)]
     if is_s2:
         encs = [s2.BlockEncoder(device=local_rank, stream=st.cuda_stream, level=args.s2_level, path=args.path, variant=cfg.get("variant")) for st in streams]
         cfg["what"] = {0: cfg["what"], 1: "s2.EncodeBetter", 2: "s2.EncodeSnappy", 3: "s2.EncodeSnappyBetter", 4: "s2.EncodeBest", 5: "s2.EncodeSnappyBest"}[args.s2_level]
@@ -350,6 +356,8 @@ def main():
         if dict_content:
             zopts.append(zstd.WithEncoderDictRaw(1, dict_content))
         encs = [zstd.NewWriter(None, *zopts, device=local_rank, stream=st.cuda_stream) for st in streams]
+        for e_, s2_ in zip(encs, streams2):
+            e_.ctx().set_option(_lib.OPT_STAGE2_STREAM, s2_.cuda_stream)
         slot = (encs[0].MaxEncodedSize(UNIT) + 15) & ~15
     enc = encs[0]
     cap = n_units * slot + 64
