@@ -100,7 +100,7 @@ struct KcCfg {
     int64_t s2_lds_spec_w0 = 0;           // S2 LDS-table kernel: the same; blocks held in LDS: 0 = the fused wave-uniform step (two LDS round trips per step), 1 = its first form
     int64_t host_serial = 0, host_pipe_mib = 0, host_overlap_min_mib = -1, host_copy_threads = 0, host_trace = 0;
     int64_t host_roll = 1;                // large host-buffer calls go through the device's rolling pipeline (kc_roll.cpp); 0: round 5's one-batch chunk-fed path
-    int64_t host_roll_mib = 0;            // rolling pipeline: sub-batch size (0: a quarter of the call's input, 64 MiB .. 1 GiB)
+    int64_t host_roll_mib = 0;            // rolling pipeline: sub-batch size (0: a quarter of the call's input — SpeedBetter and S2: half —, 64 MiB .. 1 GiB)
     std::vector<uint64_t> host_chunks;    // chunk-fed host path: chunk sizes in bytes (empty: a quarter of the batch each)
     int64_t k2_prof = 0;
     int64_t hook_wait_us = 0, hook_batch = 256, hook_lanes = 4;

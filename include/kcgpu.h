@@ -197,7 +197,7 @@ typedef enum {
     KC_OPT_HOST_CHUNK_MIB_APPEND = 32, /* KC_HOST_CHUNKS_MIB (list) one more chunk size behind KC_OPT_HOST_CHUNK_MIB's: an uneven chunk schedule (the last size repeats) */
     KC_OPT_STAGE2_STREAM = 31,       /* (no variable)             a hipStream_t handle (0: none): kc_zstd_encode_units_dev[_begin/_end] run the entropy stage and everything behind it on this stream, behind an event of the match finder's — for callers that give the two stages different CU masks (hipExtStreamCreateWithCUMask).  Scope: the device-resident zstd entry points only (the host-buffer entry points and S2 ignore it).  Lifetime: the handle must belong to the context's device and outlive the option — reset it to 0 before destroying the stream; the library never destroys it */
     KC_OPT_HOST_ROLL = 33,           /* KC_HOST_ROLL              host-buffer entry points, large inputs: 1 (default) = the device's rolling pipeline (sub-batches of all calls in flight staged, encoded on four lanes and drained in arrival order: consecutive calls overlap), 0 = one chunk-fed device batch per call (round 5) */
-    KC_OPT_HOST_ROLL_MIB = 34,       /* KC_HOST_ROLL_MIB          rolling pipeline: sub-batch size (0: a quarter of the call's input, 64 MiB .. 1 GiB) */
+    KC_OPT_HOST_ROLL_MIB = 34,       /* KC_HOST_ROLL_MIB          rolling pipeline: sub-batch size (0: a quarter of the call's input — SpeedBetterCompression and S2: half —, 64 MiB .. 1 GiB) */
     KC_OPT_S2_HOOK_HOST_FIRST = 35,  /* KC_S2_HOOK_HOST_FIRST     kc_s2_encode_block: how many callers at a time are left to the host's built-in encoder (they get -1) before the overflow goes to the device: -1 (default) the host's hardware threads, 0 every caller to the device (see kc_s2_encode_block) */
     KC_OPT_LAST_PRESCAN_UNITS = 102, /* read-only: units of the last batch the pre-scan settled */
     KC_OPT_LAST_PATH = 100,          /* read-only: KC_PATH_HBM / KC_PATH_LDS the last batch ran on */

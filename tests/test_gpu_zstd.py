@@ -296,14 +296,14 @@ def test_begin_end_pipeline_two_contexts(oracle, kclib):
         e.Close()
 
 
+@pytest.mark.parametrize("n,usz", [(768, 131072), (40, 16384)])  # (the small shape also runs on the wave emulator under ASan: tools/emu_host_check.sh)
 @pytest.mark.parametrize("level", [1, 2, 3])
-def test_one_batch_as_parts_on_three_contexts(oracle, kclib, level):
+def test_one_batch_as_parts_on_three_contexts(oracle, kclib, level, n, usz):
     """One EncodeAll batch run as several launches (bench.py --split): the parts go round three contexts chained TWO apart (two
     match finders on the device together) and every part's frames are put right behind the previous part's with
     kc_zstd_encode_units_dev_end_at.  Same offsets and bytes as the one blocking call, pass after pass, with ragged parts."""
     torch = _torch()
     from compress_amd import zstd
-    n, usz = 768, 131072
     bufs = [corpora.corpus(k, n, usz, first_unit=29 * j) for j, k in enumerate("TM")]
     off = np.arange(n + 1, dtype=np.uint64) * usz
     d_srcs = [torch.from_numpy(b).cuda() for b in bufs]
@@ -318,7 +318,7 @@ def test_one_batch_as_parts_on_three_contexts(oracle, kclib, level):
     encs = [zstd.NewWriter(None, zstd.WithEncoderLevel(level), stream=s.cuda_stream) for s in streams]
     for j in range(3):
         encs[j].ChainAfter(encs[(j - 2) % 3])
-    cuts = [0, 300, 301, 768]  # ragged parts, one of a single unit
+    cuts = [0, n * 300 // 768, n * 300 // 768 + 1, n]  # ragged parts, one of a single unit
     parts = [(p, a, b) for p in range(len(d_srcs)) for a, b in zip(cuts[:-1], cuts[1:])]
     d_dst = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(len(d_srcs))]
     torch.cuda.synchronize()
