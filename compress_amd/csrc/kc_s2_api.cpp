@@ -48,7 +48,7 @@ static kc_status s2_encode_dev(kc_ctx* c, const uint8_t* d_src, const uint64_t* 
     }
     if (!c || !blk_off || (phase == 0 && !out_off) || (n && (!d_src || (phase == 0 && !d_dst)))) return KC_ERR_BAD_ARG;
     if (phase == 1 && (framed || feed || n == 0 || level >= KC_S2_LEVEL_BEST)) { c->err = "begin / end: bare blocks of one batch below the best levels"; return KC_ERR_UNSUPPORTED; }
-    if (phase == 1 && c->s2_pend_n != 0) { c->err = "an S2 batch is in flight on this context"; return KC_ERR_BAD_ARG; }
+    if (c->s2_pend_n != 0) { c->err = "an S2 batch is in flight on this context (kc_s2_encode_blocks_lvl_dev_begin without _end_at)"; return KC_ERR_BAD_ARG; }  // its staging slots and sizes are this context's
     if (feed && (framed || n == 0)) { c->err = "chunk feed: bare blocks only"; return KC_ERR_INTERNAL; }
     // s2.WriterUncompressed: a level of the writer (writer.go:951; encodeBlock returns 0 for it, :455-480): framed only, every block one
     // uncompressed chunk — served by the LDS-table kernels' stored path (wave-parallel CRC32C + copy), whatever the batch

@@ -697,6 +697,8 @@ def test_s2_one_batch_as_parts_on_three_contexts(oracle, kclib, level, path):
     with pytest.raises(Exception):
         encs[0].EncodeBlocksDeviceBegin(d_src.data_ptr(), off[:9])  # busy
     with pytest.raises(Exception):
+        encs[0].EncodeBlocksDevice(d_src.data_ptr(), off[:9], d_dst.data_ptr(), cap)  # busy for the blocking call too
+    with pytest.raises(Exception):
         encs[0].EncodeBlocksDeviceEnd(d_dst.data_ptr(), 16)  # too small: the batch stays in flight
     o = encs[0].EncodeBlocksDeviceEnd(d_dst.data_ptr(), cap)
     assert np.array_equal(o, np.asarray(ref_off)[:9])
