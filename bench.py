@@ -561,16 +561,23 @@ def main():
     if traffic is None:
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            for ent in pj.get("entries", [pj]):
-                if ent.get("config") != args.config or ent.get("units") != n_units or ent.get("corpus") != kind:
+            ents_ = pj.get("entries", [pj])
+            # a launch of this run holds n_units / S units: the counters of a dispatch of exactly that size if the summary has one (collected with
+            # --gib halved, one launch per step), else those of the whole-batch dispatch scaled (per-unit requests do not depend on the launch size)
+            exact_ = S > 1 and any(e.get("config") == args.config and e.get("units") == n_units // S and e.get("corpus") == kind and e.get("kernel_source_sha16") == khash for e in ents_)
+            want_units = n_units // S if exact_ else n_units
+            for ent in ents_:
+                if ent.get("config") != args.config or ent.get("units") != want_units or ent.get("corpus") != kind:
                     continue
                 if is_s2 and ent.get("kernel") and ent["kernel"] != cfg["kernel"]:  # (the S2 levels share a configuration name and, at 2 GiB, a size)
                     continue
                 if ent.get("kernel_source_sha16") == khash:
                     traffic, traffic_src = ent["kernel_hbm_bytes"], "profiles/pmc_traffic.json (same workload, same kernel source)"
-                    if S > 1:  # the counters were collected on the dispatch of all units; a launch of this run holds 1 / S of them (per-unit requests do not depend on the launch size)
+                    if S > 1 and not exact_:  # the counters were collected on the dispatch of all units; a launch of this run holds 1 / S of them
                         traffic = int(traffic / S)
                         traffic_src += "; per launch of %d units = the %d-unit dispatch's bytes / %d" % (n_units // S, n_units, S)
+                    elif S > 1:
+                        traffic_src += "; a dispatch of %d units, the size of this run's launches" % (n_units // S)
                 elif khash in ent.get("also_valid_for_sha16", []):
                     # collected on an earlier form of this kernel's source; the entry says why it still describes the running one
                     traffic = ent["kernel_hbm_bytes"]
