@@ -564,7 +564,8 @@ def main():
             ents_ = pj.get("entries", [pj])
             # a launch of this run holds n_units / S units: the counters of a dispatch of exactly that size if the summary has one (collected with
             # --gib halved, one launch per step), else those of the whole-batch dispatch scaled (per-unit requests do not depend on the launch size)
-            exact_ = S > 1 and any(e.get("config") == args.config and e.get("units") == n_units // S and e.get("corpus") == kind and e.get("kernel_source_sha16") == khash for e in ents_)
+            exact_ = S > 1 and any(e.get("config") == args.config and e.get("units") == n_units // S and e.get("corpus") == kind and e.get("kernel_source_sha16") == khash
+                                   and (not is_s2 or not e.get("kernel") or e["kernel"] == cfg["kernel"]) for e in ents_)
             want_units = n_units // S if exact_ else n_units
             for ent in ents_:
                 if ent.get("config") != args.config or ent.get("units") != want_units or ent.get("corpus") != kind:
@@ -577,7 +578,11 @@ def main():
                         traffic = int(traffic / S)
                         traffic_src += "; per launch of %d units = the %d-unit dispatch's bytes / %d" % (n_units // S, n_units, S)
                     elif S > 1:
-                        traffic_src += "; a dispatch of %d units, the size of this run's launches" % (n_units // S)
+                        traffic_src += "; a dispatch of %d units — the size of this run's launches — running alone" % (n_units // S)
+                        whole_ = [e for e in ents_ if e.get("config") == args.config and e.get("units") == n_units and e.get("corpus") == kind and e.get("kernel_source_sha16") == khash
+                                  and (not is_s2 or not e.get("kernel") or e["kernel"] == cfg["kernel"])]
+                        if whole_:  # beside another launch the caches are as full as under the whole batch's dispatch: its bytes / S bound the figure from above
+                            traffic_src += "; the %d-unit dispatch's bytes / %d = %d" % (n_units, S, int(whole_[0]["kernel_hbm_bytes"] / S))
                 elif khash in ent.get("also_valid_for_sha16", []):
                     # collected on an earlier form of this kernel's source; the entry says why it still describes the running one
                     traffic = ent["kernel_hbm_bytes"]
